@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py — placement decisions/sec on the BASELINE.json headline config.
+
+A "step" is one pass of the hot path over one batch: 100k load-target decisions
+(one per model, CacheMissForwardingLB.getNext semantics) against a committed
+10k-pod snapshot (config C3), with requests, model table and outputs already
+resident in HBM.  N>1 (torch.distributed.run, one rank per GPU): decisions are
+independent, so ranks shard the model axis with no data-path collective and the
+line reports weak scaling (100k decisions per rank per step).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying
+`roofline` and `cpu_baseline` objects.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(fleet, reqs) -> int:
+    """bytes(d) = 32*P + (24 + 12*(k+f) + 4*e) + 16 summed over the batch."""
+    m = fleet.models[reqs["model"]]
+    per = 32 * fleet.n_pods + 24 + 12 * (m["n_loaded"].astype(np.int64) + m["n_failed"]) + 4 * reqs["n_extra"] + 16
+    return int(per.sum())
+
+
+def kernel_bytes(fleet, reqs) -> int:
+    """What this kernel design must move per batch: request + model row + entries + result, plus
+    each workgroup's read of the type's eligibility words (served from L2, counted once per decision)."""
+    m = fleet.models[reqs["model"]]
+    w = (fleet.n_pods + 63) // 64
+    per = 64 + 24 + 4 * (m["n_loaded"].astype(np.int64) + m["n_failed"] + reqs["n_extra"]) + 16 + 8 * w
+    return int(per.sum())
+
+
+def cpu_baseline(fleet, reqs, extra, budget_s: float = 6.0):
+    """The CPU restatement of the reference algorithm (oracle/, NOT the JVM) on this box's host cores."""
+    from oracle.bind import OracleFleet
+    orc = OracleFleet(fleet)
+    cores = os.cpu_count() or 1
+    out = {}
+    for label, th in (("single", 1), ("all", cores)):
+        n_done, t0 = 0, time.perf_counter()
+        while True:
+            orc.place(reqs, extra, fleet.now, threads=th)
+            n_done += len(reqs)
+            dt = time.perf_counter() - t0
+            if dt >= budget_s:
+                break
+        out[label] = n_done / dt
+    _, lat = orc.place(reqs[:20000], extra, fleet.now, threads=1, latencies=True)
+    return {
+        "value": out["all"], "unit": "decisions/s", "cores": cores, "kind": "port",
+        "sample": f"{len(reqs)} C3 decisions repeated for ~{budget_s:.0f}s per leg; CPU restatement of the "
+                  "reference algorithm (oracle/mm_oracle.c, gcc -O2), not the JVM",
+        "single_thread_value": out["single"],
+        "p50_us": float(np.percentile(lat, 50) / 1e3), "p99_us": float(np.percentile(lat, 99) / 1e3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C4"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from modelmesh_amd import workload as wl
+    from modelmesh_amd.solver import Solver
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libmmplace has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    fleet = wl.make_fleet(args.workload)
+    # model-axis shard: every rank owns its own batch of one-decision-per-model requests
+    reqs, extra = wl.make_requests(fleet, seed=0xBE7C0 + rank)
+    n = len(reqs)
+
+    solver = Solver(fleet.min_space_units, fleet.min_churn_age_ms, device=local_rank)
+    solver.load_fleet(fleet)
+
+    dev = torch.device("cuda", local_rank)
+    d_reqs = torch.from_numpy(reqs.view(np.uint8).reshape(-1)).to(dev)
+    d_extra = torch.from_numpy(np.ascontiguousarray(extra if len(extra) else np.zeros(1, np.int32))).to(dev)
+    d_outs = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        solver.place_dev(d_reqs.data_ptr(), n, d_extra.data_ptr(), fleet.now, d_outs.data_ptr(), stream.cuda_stream)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        starts[i].record(stream)
+        step()
+        ends[i].record(stream)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # the batch the GPU just decided must equal the oracle's answer (parity gate before any number)
+    from modelmesh_amd._lib import PLACE_OUT
+    got = np.frombuffer(d_outs.cpu().numpy().tobytes(), dtype=PLACE_OUT)
+    parity = None
+    if rank == 0:
+        from oracle.bind import OracleFleet
+        want = OracleFleet(fleet).place(reqs, extra, fleet.now, threads=os.cpu_count() or 1)
+        parity = bool(all(np.array_equal(got[f], want[f]) for f in ("chosen", "best", "n_candidates", "hash")))
+
+    if rank == 0:
+        total = n * args.steps * world
+        value = total / elapsed
+        alg = algorithmic_bytes(fleet, reqs)
+        kb = kernel_bytes(fleet, reqs)
+        achieved = alg / (kern_ms * 1e-3) / 1e9
+        line = {
+            "metric": "placement decisions/sec at 100k models x 10k pods; p99 decision latency",
+            "value": value, "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "i64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {fleet.n_models} models x {fleet.n_pods} pods, one load-target "
+                                   "decision per model per step (SURVEY.md §8d synthetic fleet)",
+                       "decisions_per_step_per_gpu": n, "sharding": "model axis, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "place_batch_kernel", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": alg,
+                         "note": "achieved uses SURVEY.md §8(d) algorithmic bytes (32 B x P per decision: the "
+                                 "reference's full scan); the kernel reads rank-ordered bitmaps instead, so its own "
+                                 "compulsory traffic is kernel_bytes_per_launch (frac_kernel)",
+                         "kernel_bytes_per_launch": kb,
+                         "frac_kernel": kb / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "parity_vs_oracle": parity,
+        }
+        # single-decision latency through the host-pointer C ABI (n=1, PCIe + launch inclusive)
+        lat = []
+        one = reqs[:1].copy()
+        for i in range(300):
+            one[0] = reqs[i % n]
+            one["extra_off"] = 0
+            one["n_extra"] = 0
+            t1 = time.perf_counter()
+            solver.place(one, None, fleet.now)
+            lat.append(time.perf_counter() - t1)
+        lat = np.array(lat[50:]) * 1e6
+        line["p50_decision_latency_us"] = float(np.percentile(lat, 50))
+        line["p99_decision_latency_us"] = float(np.percentile(lat, 99))
+        t1 = time.perf_counter()
+        for _ in range(5):
+            solver.place(reqs, extra, fleet.now)
+        line["host_boundary_decisions_per_s"] = 5 * n / (time.perf_counter() - t1)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(fleet, reqs, extra)
+        print(json.dumps(line), flush=True)
+
+    solver.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

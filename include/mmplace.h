@@ -1,0 +1,235 @@
+/*
+ * mmplace.h — C ABI of libmmplace: the MI355X (gfx950) placement / eviction
+ * solver that replaces the bodies of ModelMesh's instance-selection hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes, never
+ * throws and never aborts the process.  Return value: 0 (MMP_OK) or a negative
+ * MMP_E* code; text via mmp_last_error().  There is NO CPU fallback: if no HIP
+ * device is usable mmp_create() fails with MMP_ENODEVICE.
+ *
+ * Each function cites the reference interface it replaces.  "MM.java" =
+ * src/main/java/com/ibm/watson/modelmesh/ModelMesh.java of kserve/modelmesh.
+ * The JNI / Java binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Pod and model indices are dense ints chosen by the caller (the Java side
+ * interns instance ids; `id_order` carries String.compareTo order).
+ */
+#ifndef MMPLACE_H
+#define MMPLACE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMP_ABI_VERSION 1
+
+/* return codes */
+#define MMP_OK 0
+#define MMP_EINVAL (-1)     /* bad argument                                    */
+#define MMP_ENODEVICE (-2)  /* no usable HIP device (never falls back to CPU)  */
+#define MMP_EHIP (-3)       /* a HIP runtime call failed                       */
+#define MMP_EORDER (-4)     /* PLACEMENT_ORDER is not a total order on rows    */
+#define MMP_ESTATE (-5)     /* call sequence error (e.g. place before commit)  */
+#define MMP_ENOMEM (-6)
+
+/* `chosen` conventions — LoadBalancer.getNext return values:
+ *   null                         -> MMP_NONE   (MM.java:4796,4803,4872,4942)
+ *   LoadBalancer.ABORT_REQUEST   -> MMP_SELF   (MM.java:4384,4894,4932,4990)
+ *   a ServiceInstanceInfo        -> its pod index */
+#define MMP_NONE (-1)
+#define MMP_SELF (-2)
+
+typedef struct mmp_ctx mmp_ctx;
+
+/* Solver parameters that are inputs, not constants. */
+typedef struct {
+    int32_t device;           /* HIP device ordinal                             */
+    int32_t reserved0;
+    int64_t min_space_units;  /* MM.java:765-771 (see mmp_min_space_units)      */
+    int64_t min_churn_age_ms; /* MM.java:697                                    */
+} mmp_config;
+
+/* One InstanceRecord (InstanceRecord.java:37-69) — 64 bytes.
+ * flags: bit0 shuttingDown (row is treated as deleted, MM.java:1462-1464),
+ *        bit1 live = present in the litelinks instance map (MM.java:4765),
+ *        bit2 tombstone (slot unused; keeps indices stable across removals). */
+#define MMP_POD_SHUTTING_DOWN 1u
+#define MMP_POD_LIVE 2u
+#define MMP_POD_TOMBSTONE 4u
+typedef struct {
+    int64_t lru_time; /* Long.MAX_VALUE when empty */
+    int64_t capacity; /* 8 KiB units, ModelLoader.java:37 */
+    int64_t used;
+    int64_t version;  /* instanceVersion */
+    int32_t count;
+    int32_t loading_threads;
+    int32_t loading_in_progress;
+    int32_t rpm;
+    uint32_t id_order;   /* dense rank of the id under String.compareTo  */
+    int32_t replica_set; /* interned id.substring(0,6); -1 if |id| < 7   */
+    uint32_t flags;
+    uint32_t reserved;
+} mmp_pod_row;
+
+/* One ModelRecord (ModelRecord.java:61-114) — 24 bytes + 12 bytes per entry.
+ * Entries [ent_off, ent_off+n_loaded) are instanceIds in TreeMap (id) order,
+ * followed by n_failed loadFailedInstanceIds. */
+typedef struct {
+    int32_t type;     /* interned model type; ignored when no type table */
+    int32_t ent_off;
+    int32_t n_loaded;
+    int32_t n_failed;
+    int64_t last_used;
+} mmp_model_row;
+
+/* One CacheMissForwardingLB.getNext call (MM.java:4776) — 64 bytes.
+ * flags bit0 = exclude.favourSelf (MM.java:4781).  The fresh_* fields are the
+ * caller's getFreshInstanceRecord() (MM.java:5369-5386; its rpm is 0 there). */
+#define MMP_REQ_FAVOUR_SELF 1u
+typedef struct {
+    int32_t model;      /* row in the model table                            */
+    int32_t self_pod;   /* caller's pod index, -1 if not in the table        */
+    uint32_t flags;
+    uint32_t pick;      /* replaces ThreadLocalRandom: index=(pick*n)>>32    */
+    int64_t last_used;  /* exclude.lastUsedTime (MM.java:4736,4951)          */
+    int32_t extra_off;  /* tried-this-request ∪ explicit excludes (pool idx) */
+    int32_t n_extra;
+    int64_t fresh_lru;
+    int64_t fresh_capacity;
+    int64_t fresh_used;
+    int32_t fresh_count;
+    int32_t fresh_rpm;
+} mmp_place_req;
+
+/* 16 bytes per decision. On early returns (no eligible pod, or the immediate
+ * "choose self" returns at MM.java:4872,4894,4932) n_candidates = hash = 0. */
+typedef struct {
+    int32_t chosen;       /* pod index | MMP_NONE | MMP_SELF                 */
+    int32_t best;         /* final bestIid's pod index, -1 if none           */
+    int32_t n_candidates; /* candidates.size() before the rpm filter         */
+    uint32_t hash;        /* shortlist bitmap hash (audit)      */
+} mmp_place_out;
+
+/* One ForwardingLB.getNext call (MM.java:4315) — cache-hit routing. */
+#define MMP_SERVE_EXCLUDE_SELF 1u
+#define MMP_SERVE_PREFER_SELF 2u
+typedef struct {
+    int32_t model;
+    int32_t self_pod;
+    uint32_t flags;
+    int32_t local_in_flight;     /* localInvokesInFlight (MM.java:4303)         */
+    int64_t last_invoke_time;    /* lastInvokeTime (MM.java:4304)               */
+    int64_t assume_completed_ms; /* TimeStats.assumeCompletedAfterMillis        */
+    int32_t excl_off;            /* (pod,loadStart) pairs already tried + keyExcludes */
+    int32_t n_excl;
+} mmp_serve_req;
+
+typedef struct {
+    int32_t chosen; /* pod index | MMP_NONE | MMP_SELF */
+    int32_t pad;
+    int64_t chosen_load_start;
+} mmp_serve_out;
+
+/* ClusterStats (MM.java:1570-1591, InstanceSetStatsTracker.java:53-92). */
+typedef struct {
+    int64_t total_capacity;
+    int64_t total_free;
+    int64_t global_lru; /* Long.MAX_VALUE if none */
+    int32_t instance_count;
+    int32_t model_copy_count;
+} mmp_stats;
+
+/* One eviction evaluation on one pod's cache (clhm/ConcurrentLinkedHashMap.java
+ * :329-352,590-652; clhm/LinkedDeque.java:243-288): insert an entry of `weight`
+ * stamped `last_used` (0 = now) into the time-ordered deque, then evict from
+ * the head while weightedSize > capacity. */
+typedef struct {
+    int32_t cache;      /* which per-pod cache segment                        */
+    int32_t weight;     /* weight of the incoming entry (or weight delta)     */
+    int64_t last_used;  /* 0 means now (clhm :1357-1360)                      */
+} mmp_evict_req;
+
+typedef struct {
+    int32_t insert_pos;    /* deque position the new node is linked at         */
+    int32_t n_victims;     /* nodes polled from the head                       */
+    int32_t self_evicted;  /* 1 if the new node itself was among the victims   */
+    int32_t pad;
+    int64_t weighted_size; /* after eviction                                   */
+    int64_t oldest_time;   /* oldestTime() after eviction, -1 if empty         */
+} mmp_evict_out;
+
+/* ---- lifecycle --------------------------------------------------------- */
+int mmp_abi_version(void);
+int mmp_create(const mmp_config *cfg, mmp_ctx **out);
+void mmp_destroy(mmp_ctx *ctx);
+const char *mmp_last_error(mmp_ctx *ctx); /* ctx may be NULL: last create() error */
+/* 1 = hip (single device). There is no host backend. */
+int mmp_backend(mmp_ctx *ctx);
+
+/* MM.java:765-771 */
+int64_t mmp_min_space_units(int32_t default_model_size_units, int32_t loading_threads,
+                            int64_t capacity_units, int have_unload_manager);
+
+/* ---- snapshot: what clusterState/registry/typeConstraints hold --------- */
+/* Replace the whole instance table (MM.java:332 clusterState, fed by
+ * handleInstanceTableChange MM.java:1455). Host pointer, copied. */
+int mmp_pods_load(mmp_ctx *ctx, const mmp_pod_row *rows, int32_t n_pods);
+/* Upsert / delete single rows by index (ENTRY_ADDED/UPDATED/DELETED,
+ * MM.java:1476-1542). idx[i] may equal the current pod count to append. */
+int mmp_pods_upsert(mmp_ctx *ctx, const int32_t *idx, const mmp_pod_row *rows, int32_t n);
+int mmp_pods_remove(mmp_ctx *ctx, const int32_t *idx, int32_t n);
+/* TypeConstraintManager.getCandidateInstances / getPreferredInstances
+ * (TypeConstraintManager.java:242-251) as bitmaps over pod index, row-major
+ * [n_types][ceil(n_pods/64)] uint64 words, bit p%64 of word p/64.
+ * has_allowed[t]==0 / has_prefer[t]==0 mean the Java returned null.
+ * n_types==0 means typeConstraints==null. */
+int mmp_types_load(mmp_ctx *ctx, int32_t n_types, const uint64_t *allowed, const uint64_t *prefer,
+                   const uint8_t *has_allowed, const uint8_t *has_prefer);
+/* UpgradeTracker.getLikelyReplacedReplicaSets (UpgradeTracker.java:78). */
+int mmp_replaced_rs_load(mmp_ctx *ctx, const int32_t *replica_sets, int32_t n);
+/* The model registry view (MM.java:308). ent_pod / ent_time have n_entries items. */
+int mmp_models_load(mmp_ctx *ctx, const mmp_model_row *rows, int32_t n_models,
+                    const int32_t *ent_pod, const int64_t *ent_time, int32_t n_entries);
+/* Rank pods by PLACEMENT_ORDER (MM.java:4646-4703) on the device and publish
+ * the new immutable snapshot. MMP_EORDER if the comparator is inconsistent. */
+int mmp_snapshot_commit(mmp_ctx *ctx);
+/* clusterState iteration order (the `getCacheState` dump, MM.java:5552-5608).
+ * order_out has room for n_pods ints; *n_out = rows actually in the set. */
+int mmp_get_order(mmp_ctx *ctx, int32_t *order_out, int32_t *n_out);
+/* ClusterStats of the committed snapshot (MM.java:1570-1591). */
+int mmp_cluster_stats(mmp_ctx *ctx, mmp_stats *out);
+
+/* ---- decisions --------------------------------------------------------- */
+/* n load-target decisions = n × CacheMissForwardingLB.getNext (MM.java:4776-5005).
+ * extra_pool: pod indices referenced by reqs[i].extra_off/n_extra. Host pointers. */
+int mmp_place_batch(mmp_ctx *ctx, const mmp_place_req *reqs, int32_t n, const int32_t *extra_pool,
+                    int32_t n_extra_pool, int64_t now_ms, mmp_place_out *outs);
+/* Same, with every buffer already in device memory and launched on `stream`
+ * (a hipStream_t, NULL = default) without synchronising. */
+int mmp_place_batch_dev(mmp_ctx *ctx, const void *d_reqs, int32_t n, const void *d_extra_pool,
+                        int64_t now_ms, void *d_outs, void *stream);
+
+/* n serve-target decisions = n × ForwardingLB.getNext (MM.java:4315-4392).
+ * in_use / last_used: ServiceInstance.getInUseCount / getLastUsedTime per pod
+ * (MM.java:4356,4360). excl_pod/excl_time: pairs referenced by excl_off. */
+int mmp_serve_batch(mmp_ctx *ctx, const mmp_serve_req *reqs, int32_t n, const int32_t *in_use,
+                    const int64_t *last_used, const int32_t *excl_pod, const int64_t *excl_time,
+                    int32_t n_excl_pool, int64_t now_ms, mmp_serve_out *outs);
+
+/* Per-pod cache segments for eviction: seg_off has n_caches+1 entries; entry i
+ * of a segment is the i-th node of that cache's evictionDeque (oldest first). */
+int mmp_caches_load(mmp_ctx *ctx, int32_t n_caches, const int32_t *seg_off, const int64_t *last_used,
+                    const int32_t *weight, const int64_t *capacity);
+int mmp_evict_batch(mmp_ctx *ctx, const mmp_evict_req *reqs, int32_t n, int64_t now_ms,
+                    mmp_evict_out *outs);
+
+/* Wait for everything queued on the context's own stream. */
+int mmp_sync(mmp_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMPLACE_H */

@@ -1,0 +1,112 @@
+"""ctypes binding of libmmplace (include/mmplace.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).
+There is no Python or CPU implementation behind this module: if the shared
+object is missing, import of the solver fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libmmplace.so")
+
+MMP_OK = 0
+MMP_EINVAL, MMP_ENODEVICE, MMP_EHIP, MMP_EORDER, MMP_ESTATE, MMP_ENOMEM = -1, -2, -3, -4, -5, -6
+MMP_NONE, MMP_SELF = -1, -2
+POD_SHUTTING_DOWN, POD_LIVE, POD_TOMBSTONE = 1, 2, 4
+REQ_FAVOUR_SELF = 1
+SERVE_EXCLUDE_SELF, SERVE_PREFER_SELF = 1, 2
+ANY_TIME = -(2**63)
+JAVA_LONG_MAX = 2**63 - 1
+
+# numpy mirrors of the C structs (all naturally aligned, no padding surprises)
+POD_ROW = np.dtype(
+    [("lru_time", "<i8"), ("capacity", "<i8"), ("used", "<i8"), ("version", "<i8"),
+     ("count", "<i4"), ("loading_threads", "<i4"), ("loading_in_progress", "<i4"), ("rpm", "<i4"),
+     ("id_order", "<u4"), ("replica_set", "<i4"), ("flags", "<u4"), ("reserved", "<u4")])
+MODEL_ROW = np.dtype(
+    [("type", "<i4"), ("ent_off", "<i4"), ("n_loaded", "<i4"), ("n_failed", "<i4"), ("last_used", "<i8")])
+PLACE_REQ = np.dtype(
+    [("model", "<i4"), ("self_pod", "<i4"), ("flags", "<u4"), ("pick", "<u4"), ("last_used", "<i8"),
+     ("extra_off", "<i4"), ("n_extra", "<i4"), ("fresh_lru", "<i8"), ("fresh_capacity", "<i8"),
+     ("fresh_used", "<i8"), ("fresh_count", "<i4"), ("fresh_rpm", "<i4")])
+PLACE_OUT = np.dtype([("chosen", "<i4"), ("best", "<i4"), ("n_candidates", "<i4"), ("hash", "<u4")])
+SERVE_REQ = np.dtype(
+    [("model", "<i4"), ("self_pod", "<i4"), ("flags", "<u4"), ("local_in_flight", "<i4"),
+     ("last_invoke_time", "<i8"), ("assume_completed_ms", "<i8"), ("excl_off", "<i4"), ("n_excl", "<i4")])
+SERVE_OUT = np.dtype([("chosen", "<i4"), ("pad", "<i4"), ("chosen_load_start", "<i8")])
+STATS = np.dtype(
+    [("total_capacity", "<i8"), ("total_free", "<i8"), ("global_lru", "<i8"),
+     ("instance_count", "<i4"), ("model_copy_count", "<i4")])
+EVICT_REQ = np.dtype([("cache", "<i4"), ("weight", "<i4"), ("last_used", "<i8")])
+EVICT_OUT = np.dtype(
+    [("insert_pos", "<i4"), ("n_victims", "<i4"), ("self_evicted", "<i4"), ("pad", "<i4"),
+     ("weighted_size", "<i8"), ("oldest_time", "<i8")])
+
+assert POD_ROW.itemsize == 64 and MODEL_ROW.itemsize == 24 and PLACE_REQ.itemsize == 64
+assert PLACE_OUT.itemsize == 16 and SERVE_REQ.itemsize == 40 and SERVE_OUT.itemsize == 16
+assert STATS.itemsize == 32 and EVICT_REQ.itemsize == 16 and EVICT_OUT.itemsize == 32
+
+
+class MmpConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("reserved0", C.c_int32),
+                ("min_space_units", C.c_int64), ("min_churn_age_ms", C.c_int64)]
+
+
+# every symbol include/mmplace.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("mmp_abi_version", C.c_int, []),
+    ("mmp_create", C.c_int, [C.POINTER(MmpConfig), C.POINTER(_P)]),
+    ("mmp_destroy", None, [_P]),
+    ("mmp_last_error", C.c_char_p, [_P]),
+    ("mmp_backend", C.c_int, [_P]),
+    ("mmp_min_space_units", C.c_int64, [C.c_int32, C.c_int32, C.c_int64, C.c_int]),
+    ("mmp_pods_load", C.c_int, [_P, _P, C.c_int32]),
+    ("mmp_pods_upsert", C.c_int, [_P, _P, _P, C.c_int32]),
+    ("mmp_pods_remove", C.c_int, [_P, _P, C.c_int32]),
+    ("mmp_types_load", C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
+    ("mmp_replaced_rs_load", C.c_int, [_P, _P, C.c_int32]),
+    ("mmp_models_load", C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32]),
+    ("mmp_snapshot_commit", C.c_int, [_P]),
+    ("mmp_get_order", C.c_int, [_P, _P, C.POINTER(C.c_int32)]),
+    ("mmp_cluster_stats", C.c_int, [_P, _P]),
+    ("mmp_place_batch", C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int64, _P]),
+    ("mmp_place_batch_dev", C.c_int, [_P, _P, C.c_int32, _P, C.c_int64, _P, _P]),
+    ("mmp_serve_batch", C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int64, _P]),
+    ("mmp_caches_load", C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
+    ("mmp_evict_batch", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
+    ("mmp_sync", C.c_int, [_P]),
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen libmmplace.so and type every exported entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP library first "
+            "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError here == a header symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(a):
+    """void* of a numpy array (None -> NULL)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)

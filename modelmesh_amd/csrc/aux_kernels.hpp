@@ -1,0 +1,177 @@
+// aux_kernels.hpp — serve-target selection and eviction-victim kernels.
+#pragma once
+#include "snapshot.hpp"
+
+namespace mmp {
+
+#define MMP_ANY_TIME INT64_MIN  // excl_time wildcard: MapFilteringSet.keyExcludes (MM.java:4282)
+
+struct ServeArgs {
+    const mmp_serve_req *reqs;
+    const mmp_model_row *models;
+    const int32_t *ent_pod;
+    const int64_t *ent_time;
+    const mmp_pod_row *pods;  // for the live flag
+    const int32_t *in_use;
+    const int64_t *last_used;
+    const int32_t *excl_pod;
+    const int64_t *excl_time;
+    mmp_serve_out *outs;
+    int32_t n, n_models, P;
+    int64_t now;
+};
+
+// ForwardingLB.getNext (MM.java:4315-4392): k is tiny (1-3 copies), so one
+// lane runs the loop exactly as written; lanes = independent requests.
+__global__ void serve_batch_kernel(ServeArgs A)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    const mmp_serve_req r = A.reqs[i];
+    mmp_serve_out o;
+    o.chosen = MMP_NONE;
+    o.pad = 0;
+    o.chosen_load_start = 0;
+    if (r.model < 0 || r.model >= A.n_models) {
+        A.outs[i] = o;
+        return;
+    }
+    const mmp_model_row m = A.models[r.model];
+    const bool exclude_self = r.flags & MMP_SERVE_EXCLUDE_SELF, prefer_self = r.flags & MMP_SERVE_PREFER_SELF;
+    bool seen_self = false;
+    int32_t chosen = -1;
+    int64_t chosen_ts = 0;
+    int32_t mn = INT32_MAX;
+    int64_t lru = INT64_MAX, first_started = INT64_MAX;
+    const int64_t cutoff = (int64_t)((uint64_t)A.now - (uint64_t)r.assume_completed_ms);  // :4350
+    for (int e = 0; e < m.n_loaded; e++) {
+        const int32_t iid = A.ent_pod[m.ent_off + e];
+        const int64_t load_started = A.ent_time[m.ent_off + e];
+        // MapFilteringSet.apply (MM.java:4279-4283)
+        bool filtered = false;
+        for (int x = 0; x < r.n_excl; x++) {
+            const int32_t xp = A.excl_pod[r.excl_off + x];
+            const int64_t xt = A.excl_time[r.excl_off + x];
+            if (xp == iid && (xt == MMP_ANY_TIME || xt == load_started)) filtered = true;
+        }
+        if (filtered) continue;
+        bool us = false;
+        if (!seen_self && iid == r.self_pod) {  // :4334-4342
+            seen_self = true;
+            if (exclude_self) continue;
+            us = true;
+        }
+        if (iid < 0 || iid >= A.P || !(A.pods[iid].flags & MMP_POD_LIVE)) continue;  // sii == null
+        if (load_started < cutoff) {  // :4352-4367
+            const int32_t inuse = us ? r.local_in_flight : A.in_use[iid];
+            if (inuse > mn) continue;
+            const int64_t nlu = us ? (prefer_self ? 0 : r.last_invoke_time) : A.last_used[iid];
+            if (inuse < mn)
+                mn = inuse;
+            else if (nlu >= lru)
+                continue;
+            chosen = iid;
+            chosen_ts = load_started;
+            lru = nlu;
+        } else if (mn == INT32_MAX && load_started < first_started) {  // :4369-4376
+            chosen = iid;
+            chosen_ts = load_started;
+            first_started = load_started;
+        }
+    }
+    if (chosen >= 0) {
+        o.chosen = (!exclude_self && chosen == r.self_pod) ? MMP_SELF : chosen;  // :4381-4385
+        o.chosen_load_start = chosen_ts;
+    }
+    A.outs[i] = o;
+}
+
+struct EvictArgs {
+    const mmp_evict_req *reqs;
+    const int32_t *seg_off;   // [n_caches+1]
+    const int64_t *last_used;  // deque order, oldest first
+    const int32_t *weight;
+    const int64_t *capacity;   // [n_caches]
+    mmp_evict_out *outs;
+    int32_t n, n_caches;
+    int64_t now;
+};
+
+// AddTask.run → evictionDeque.insert → evict()
+// (clhm/ConcurrentLinkedHashMap.java:590-611,329-352; clhm/LinkedDeque.java:259-288).
+// One wave per request: ballot for the insertion point, wave prefix-sum of the
+// merged weight sequence for the victim count.
+__global__ __launch_bounds__(256) void evict_batch_kernel(EvictArgs A)
+{
+    const int lane = lane_id();
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= A.n) return;
+    const mmp_evict_req r = A.reqs[i];
+    mmp_evict_out o;
+    o.insert_pos = 0; o.n_victims = 0; o.self_evicted = 0; o.pad = 0; o.weighted_size = 0; o.oldest_time = -1;
+    if (r.cache < 0 || r.cache >= A.n_caches) {
+        if (lane == 0) A.outs[i] = o;
+        return;
+    }
+    const int s0 = A.seg_off[r.cache], E = A.seg_off[r.cache + 1] - s0;
+    const int64_t *lu = A.last_used + s0;
+    const int32_t *wt = A.weight + s0;
+    const int64_t cap = A.capacity[r.cache];
+    const int64_t ts = r.last_used == 0 ? A.now : r.last_used;  // Node ctor / touch, clhm :1357-1360
+
+    // insert(): walk from the tail to the first node with lastUsed <= ts, link after it
+    int pos = 0;
+    int64_t sum = 0;
+    for (int base = 0; base < E; base += 64) {
+        const int j = base + lane;
+        const bool le = j < E && lu[j] <= ts;
+        const uint64_t b = __ballot(le);
+        if (b) pos = base + (63 - __clzll((unsigned long long)b)) + 1;
+        sum += j < E ? (int64_t)wt[j] : 0;
+    }
+    sum = wave_sum_i64(sum);
+    const int64_t total = sum + (int64_t)r.weight;  // weightedSize + weight, clhm :603
+
+    // evict(): poll the head while weightedSize > capacity
+    int n_victims = 0;
+    int64_t after = total;
+    if (total > cap) {
+        int64_t carry = 0;
+        n_victims = E + 1;
+        after = 0;
+        bool done = false;
+        for (int base = 0; base <= E && !done; base += 64) {
+            const int j = base + lane;
+            int64_t w = 0;
+            if (j <= E) w = j < pos ? (int64_t)wt[j] : (j == pos ? (int64_t)r.weight : (int64_t)wt[j - 1]);
+            // inclusive scan of 64-bit weights
+            int64_t incl = w;
+#pragma unroll
+            for (int o2 = 1; o2 < 64; o2 <<= 1) {
+                const int64_t t = (int64_t)shfl_u64((uint64_t)incl, lane >= o2 ? lane - o2 : lane);
+                if (lane >= o2) incl += t;
+            }
+            const int64_t left = total - (carry + incl);
+            const uint64_t b = __ballot(j <= E && left <= cap);
+            if (b) {
+                const int l = __ffsll((unsigned long long)b) - 1;
+                n_victims = base + l + 1;
+                after = (int64_t)shfl_u64((uint64_t)left, l);
+                done = true;
+            }
+            carry += (int64_t)shfl_u64((uint64_t)incl, 63);
+        }
+    }
+    if (lane == 0) {
+        o.insert_pos = pos;
+        o.n_victims = n_victims;
+        o.self_evicted = n_victims > pos ? 1 : 0;
+        o.weighted_size = after;
+        // oldestTime(): head of what is left, clhm :1125-1133
+        const int h = n_victims;  // merged index of the new head
+        if (h <= E) o.oldest_time = h < pos ? lu[h] : (h == pos ? ts : lu[h - 1]);
+        A.outs[i] = o;
+    }
+}
+
+}  // namespace mmp

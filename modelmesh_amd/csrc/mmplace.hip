@@ -1,0 +1,616 @@
+// mmplace.hip — libmmplace: C-ABI (include/mmplace.h) over the gfx950 kernels.
+//
+// Host side only marshals: it keeps a staging copy of the instance table so
+// single-row events (MM.java:1455 handleInstanceTableChange) can be applied,
+// uploads, launches, and hands results back.  All ranking, filtering,
+// shortlisting and victim selection runs in the kernels; there is no CPU
+// implementation of the path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mmplace.h"
+#include "aux_kernels.hpp"
+#include "place_kernel.hpp"
+#include "snapshot.hpp"
+
+using namespace mmp;
+
+namespace {
+
+thread_local std::string g_create_err;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max<size_t>(bytes, 256);
+        want = (want + 255) & ~size_t(255);
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// device storage of one committed snapshot
+struct SnapBufs {
+    DevBuf pods, lru, rem, cnt, rpm, orig, pos_of, elig, elig_nors, pref, has_pref, fullw;
+    void release()
+    {
+        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw})
+            b->release();
+    }
+};
+
+}  // namespace
+
+struct mmp_ctx {
+    mmp_config cfg{};
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+
+    // host staging (inputs of the next commit)
+    std::vector<mmp_pod_row> pods;
+    int32_t n_types = 0, types_w = 0;
+    std::vector<uint64_t> allowed, prefer;
+    std::vector<uint8_t> has_allowed, has_prefer;
+    std::vector<int32_t> replaced_rs;
+
+    // committed snapshot (double-buffered; `cur` is what decisions read)
+    SnapBufs sb[2];
+    int cur = 0;
+    bool committed = false;
+    Snap snap{};
+    mmp_stats stats{};
+
+    // commit scratch
+    DevBuf rank, occupancy, flag, rs_list, rs_bad, d_allowed, d_prefer, d_has_allowed, stats_acc;
+
+    // model registry view
+    DevBuf models, ent_pod, ent_time;
+    int32_t n_models = 0, n_entries = 0;
+
+    // eviction caches
+    DevBuf c_seg, c_lu, c_wt, c_cap;
+    int32_t n_caches = 0;
+
+    // per-call scratch for the host-pointer entry points
+    DevBuf s_reqs, s_outs, s_extra, s_a, s_b, s_c, s_d;
+};
+
+namespace {
+
+int fail(mmp_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c)
+        c->err = buf;
+    else
+        g_create_err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail((c), MMP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs,
+                 hipStream_t st)
+{
+    if (n == 0) return MMP_OK;
+    PlaceArgs A;
+    A.reqs = static_cast<const mmp_place_req *>(d_reqs);
+    A.models = c->models.as<mmp_model_row>();
+    A.ent_pod = c->ent_pod.as<int32_t>();
+    A.extra = static_cast<const int32_t *>(d_extra);
+    A.outs = static_cast<mmp_place_out *>(d_outs);
+    A.n = n;
+    A.n_models = c->n_models;
+    A.now = now;
+    const int wpad = (c->snap.W + 1) & ~1;
+    const size_t lds = (size_t)kPlaceWaves * 2 * wpad * sizeof(uint64_t);
+    if (lds > 64 * 1024) return fail(c, MMP_EINVAL, "instance table too large for the LDS staging tile (%d pods)", c->snap.P);
+    const int blocks = std::min(div_up(n, kPlaceWaves), 256 * 8);
+    hipLaunchKernelGGL(place_batch_kernel, dim3(blocks), dim3(kPlaceWaves * 64), lds, st, c->snap, A, wpad);
+    HIP_TRY(c, hipGetLastError());
+    return MMP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mmp_abi_version(void) { return MMP_ABI_VERSION; }
+
+int64_t mmp_min_space_units(int32_t dflt, int32_t threads, int64_t cap_units, int have_unload)
+{
+    // MM.java:765-771, Java int arithmetic
+    const int32_t mn = (int32_t)((uint32_t)dflt * ((have_unload || threads <= 1) ? 1u : 2u));
+    const int32_t a = (int32_t)((uint32_t)dflt * (uint32_t)threads);
+    const int32_t b = (int32_t)(cap_units / 20);
+    const int32_t target = a < b ? a : b;
+    return mn > target ? mn : target;
+}
+
+int mmp_create(const mmp_config *cfg, mmp_ctx **out)
+{
+    if (!cfg || !out) return fail(nullptr, MMP_EINVAL, "mmp_create: null argument");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, MMP_ENODEVICE, "no HIP device available (%s); libmmplace has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, MMP_EINVAL, "device %d out of range (have %d)", cfg->device, ndev);
+    if ((e = hipSetDevice(cfg->device)) != hipSuccess)
+        return fail(nullptr, MMP_EHIP, "hipSetDevice: %s", hipGetErrorString(e));
+    mmp_ctx *c = new (std::nothrow) mmp_ctx();
+    if (!c) return fail(nullptr, MMP_ENOMEM, "out of memory");
+    c->cfg = *cfg;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        delete c;
+        return fail(nullptr, MMP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return MMP_OK;
+}
+
+void mmp_destroy(mmp_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamDestroy(c->stream);
+    }
+    c->sb[0].release();
+    c->sb[1].release();
+    for (DevBuf *b : {&c->rank, &c->occupancy, &c->flag, &c->rs_list, &c->rs_bad, &c->d_allowed, &c->d_prefer,
+                      &c->d_has_allowed, &c->stats_acc, &c->models, &c->ent_pod, &c->ent_time, &c->c_seg,
+                      &c->c_lu, &c->c_wt, &c->c_cap, &c->s_reqs, &c->s_outs, &c->s_extra, &c->s_a, &c->s_b,
+                      &c->s_c, &c->s_d})
+        b->release();
+    delete c;
+}
+
+const char *mmp_last_error(mmp_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int mmp_backend(mmp_ctx *c) { return c ? 1 : 0; }
+
+int mmp_sync(mmp_ctx *c)
+{
+    if (!c) return MMP_EINVAL;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MMP_OK;
+}
+
+/* ---- staging of the instance table -------------------------------------- */
+
+int mmp_pods_load(mmp_ctx *c, const mmp_pod_row *rows, int32_t n)
+{
+    if (!c || n < 0 || (n > 0 && !rows)) return fail(c, MMP_EINVAL, "mmp_pods_load: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    c->pods.assign(rows, rows + n);
+    return MMP_OK;
+}
+
+int mmp_pods_upsert(mmp_ctx *c, const int32_t *idx, const mmp_pod_row *rows, int32_t n)
+{
+    if (!c || n < 0 || (n > 0 && (!rows || !idx))) return fail(c, MMP_EINVAL, "mmp_pods_upsert: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    for (int32_t i = 0; i < n; i++) {
+        const int32_t k = idx[i];
+        if (k < 0 || k > (int32_t)c->pods.size()) return fail(c, MMP_EINVAL, "mmp_pods_upsert: index %d out of range", k);
+        if (k == (int32_t)c->pods.size())
+            c->pods.push_back(rows[i]);
+        else
+            c->pods[k] = rows[i];
+    }
+    return MMP_OK;
+}
+
+int mmp_pods_remove(mmp_ctx *c, const int32_t *idx, int32_t n)
+{
+    if (!c || n < 0 || (n > 0 && !idx)) return fail(c, MMP_EINVAL, "mmp_pods_remove: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    for (int32_t i = 0; i < n; i++) {
+        const int32_t k = idx[i];
+        if (k < 0 || k >= (int32_t)c->pods.size()) return fail(c, MMP_EINVAL, "mmp_pods_remove: index %d out of range", k);
+        c->pods[k].flags |= MMP_POD_TOMBSTONE;
+        c->pods[k].flags &= ~MMP_POD_LIVE;
+    }
+    return MMP_OK;
+}
+
+int mmp_types_load(mmp_ctx *c, int32_t n_types, const uint64_t *allowed, const uint64_t *prefer,
+                   const uint8_t *has_allowed, const uint8_t *has_prefer)
+{
+    if (!c || n_types < 0) return fail(c, MMP_EINVAL, "mmp_types_load: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    const int32_t W = div_up((int)c->pods.size(), 64);
+    c->n_types = n_types;
+    c->types_w = W;
+    const size_t words = (size_t)n_types * W;
+    c->allowed.assign(words, 0);
+    c->prefer.assign(words, 0);
+    c->has_allowed.assign(std::max(n_types, 1), 0);
+    c->has_prefer.assign(std::max(n_types, 1), 0);
+    for (int32_t t = 0; t < n_types; t++) {
+        if (has_allowed && has_allowed[t]) {
+            if (!allowed) return fail(c, MMP_EINVAL, "mmp_types_load: allowed bitmap missing");
+            c->has_allowed[t] = 1;
+            std::copy(allowed + (size_t)t * W, allowed + (size_t)(t + 1) * W, c->allowed.begin() + (size_t)t * W);
+        }
+        if (has_prefer && has_prefer[t]) {
+            if (!prefer) return fail(c, MMP_EINVAL, "mmp_types_load: prefer bitmap missing");
+            c->has_prefer[t] = 1;
+            std::copy(prefer + (size_t)t * W, prefer + (size_t)(t + 1) * W, c->prefer.begin() + (size_t)t * W);
+        }
+    }
+    return MMP_OK;
+}
+
+int mmp_replaced_rs_load(mmp_ctx *c, const int32_t *rs, int32_t n)
+{
+    if (!c || n < 0 || (n > 0 && !rs)) return fail(c, MMP_EINVAL, "mmp_replaced_rs_load: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    c->replaced_rs.assign(rs, rs + n);
+    return MMP_OK;
+}
+
+int mmp_models_load(mmp_ctx *c, const mmp_model_row *rows, int32_t n_models, const int32_t *ent_pod,
+                    const int64_t *ent_time, int32_t n_entries)
+{
+    if (!c || n_models < 0 || n_entries < 0 || (n_models > 0 && !rows) || (n_entries > 0 && (!ent_pod || !ent_time)))
+        return fail(c, MMP_EINVAL, "mmp_models_load: bad argument");
+    for (int32_t i = 0; i < n_models; i++) {
+        const mmp_model_row &m = rows[i];
+        if (m.n_loaded < 0 || m.n_failed < 0 || m.ent_off < 0 ||
+            (int64_t)m.ent_off + m.n_loaded + m.n_failed > (int64_t)n_entries)
+            return fail(c, MMP_EINVAL, "mmp_models_load: model %d entry range out of bounds", i);
+    }
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, c->models.ensure((size_t)std::max(n_models, 1) * sizeof(mmp_model_row)));
+    HIP_TRY(c, c->ent_pod.ensure((size_t)std::max(n_entries, 1) * sizeof(int32_t)));
+    HIP_TRY(c, c->ent_time.ensure((size_t)std::max(n_entries, 1) * sizeof(int64_t)));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n_models) HIP_TRY(c, hipMemcpy(c->models.p, rows, (size_t)n_models * sizeof(mmp_model_row), hipMemcpyHostToDevice));
+    if (n_entries) {
+        HIP_TRY(c, hipMemcpy(c->ent_pod.p, ent_pod, (size_t)n_entries * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->ent_time.p, ent_time, (size_t)n_entries * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    c->n_models = n_models;
+    c->n_entries = n_entries;
+    return MMP_OK;
+}
+
+/* ---- commit: rank + permute + bitmaps + stats, all on the device --------- */
+
+int mmp_snapshot_commit(mmp_ctx *c)
+{
+    if (!c) return MMP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int32_t P = (int32_t)c->pods.size();
+    const int32_t W = std::max(div_up(P, 64), 1);
+    const int32_t T = std::max(c->n_types, 1);
+    if (c->n_types > 0 && c->types_w != div_up(P, 64))
+        return fail(c, MMP_ESTATE, "type bitmaps were loaded for a different pod count; reload them before commit");
+    const size_t padded = (size_t)W * 64;
+    SnapBufs &B = c->sb[1 - c->cur];
+    hipStream_t st = c->stream;
+
+    HIP_TRY(c, B.pods.ensure(std::max<size_t>(P, 1) * sizeof(mmp_pod_row)));
+    HIP_TRY(c, B.lru.ensure(padded * 8));
+    HIP_TRY(c, B.rem.ensure(padded * 8));
+    HIP_TRY(c, B.cnt.ensure(padded * 4));
+    HIP_TRY(c, B.rpm.ensure(padded * 4));
+    HIP_TRY(c, B.orig.ensure(padded * 4));
+    HIP_TRY(c, B.pos_of.ensure(padded * 4));
+    HIP_TRY(c, B.elig.ensure((size_t)T * W * 8));
+    HIP_TRY(c, B.elig_nors.ensure((size_t)T * W * 8));
+    HIP_TRY(c, B.pref.ensure((size_t)T * W * 8));
+    HIP_TRY(c, B.has_pref.ensure(T));
+    HIP_TRY(c, B.fullw.ensure((size_t)W * 8));
+    HIP_TRY(c, c->rank.ensure(padded * 4));
+    HIP_TRY(c, c->occupancy.ensure(padded * 4));
+    HIP_TRY(c, c->flag.ensure(sizeof(int32_t)));
+    HIP_TRY(c, c->stats_acc.ensure(sizeof(StatsAcc)));
+    HIP_TRY(c, c->rs_bad.ensure(padded));
+    HIP_TRY(c, c->rs_list.ensure(std::max<size_t>(c->replaced_rs.size(), 1) * 4));
+    HIP_TRY(c, c->d_allowed.ensure(std::max<size_t>((size_t)T * W, 1) * 8));
+    HIP_TRY(c, c->d_prefer.ensure(std::max<size_t>((size_t)T * W, 1) * 8));
+    HIP_TRY(c, c->d_has_allowed.ensure(T));
+
+    if (P) HIP_TRY(c, hipMemcpyAsync(B.pods.p, c->pods.data(), (size_t)P * sizeof(mmp_pod_row), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(c->rank.p, 0, padded * 4, st));
+    HIP_TRY(c, hipMemsetAsync(c->occupancy.p, 0, padded * 4, st));
+    HIP_TRY(c, hipMemsetAsync(c->flag.p, 0, sizeof(int32_t), st));
+    HIP_TRY(c, hipMemsetAsync(B.lru.p, 0, padded * 8, st));
+    HIP_TRY(c, hipMemsetAsync(B.rem.p, 0, padded * 8, st));
+    HIP_TRY(c, hipMemsetAsync(B.cnt.p, 0, padded * 4, st));
+    HIP_TRY(c, hipMemsetAsync(B.rpm.p, 0, padded * 4, st));
+    HIP_TRY(c, hipMemsetAsync(B.orig.p, 0, padded * 4, st));
+    HIP_TRY(c, hipMemsetAsync(B.pos_of.p, 0, padded * 4, st));
+
+    std::vector<uint8_t> hp(T, 0), ha(T, 0);
+    for (int32_t t = 0; t < c->n_types; t++) {
+        hp[t] = c->has_prefer[t];
+        ha[t] = c->has_allowed[t];
+    }
+    HIP_TRY(c, hipMemcpyAsync(B.has_pref.p, hp.data(), T, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_has_allowed.p, ha.data(), T, hipMemcpyHostToDevice, st));
+    if (c->n_types > 0 && !c->allowed.empty()) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_allowed.p, c->allowed.data(), c->allowed.size() * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->d_prefer.p, c->prefer.data(), c->prefer.size() * 8, hipMemcpyHostToDevice, st));
+    }
+    const int32_t n_rs = (int32_t)c->replaced_rs.size();
+    if (n_rs) HIP_TRY(c, hipMemcpyAsync(c->rs_list.p, c->replaced_rs.data(), (size_t)n_rs * 4, hipMemcpyHostToDevice, st));
+
+    const int64_t min_space = c->cfg.min_space_units;
+    const int64_t churn2 = (int64_t)((uint64_t)c->cfg.min_churn_age_ms * 2u);
+    StatsAcc init{};
+    init.global_lru = INT64_MAX;
+    HIP_TRY(c, hipMemcpyAsync(c->stats_acc.p, &init, sizeof init, hipMemcpyHostToDevice, st));
+
+    if (P > 0) {
+        const int pb = div_up(P, kRankBlock);
+        const int slices = std::max(1, std::min(64, 2048 / pb));
+        hipLaunchKernelGGL(rank_pods_kernel, dim3(pb, slices), dim3(kRankBlock), 0, st, B.pods.as<mmp_pod_row>(), P,
+                           min_space, churn2, slices, c->rank.as<int32_t>());
+        hipLaunchKernelGGL(scatter_pods_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(), P,
+                           min_space, c->rank.as<int32_t>(), c->occupancy.as<int32_t>(), B.lru.as<int64_t>(),
+                           B.rem.as<int64_t>(), B.cnt.as<int32_t>(), B.rpm.as<int32_t>(), B.orig.as<int32_t>(),
+                           B.pos_of.as<int32_t>(), c->flag.as<int32_t>());
+        if (n_rs)
+            hipLaunchKernelGGL(mark_replaced_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(),
+                               P, c->rs_list.as<int32_t>(), n_rs, c->rs_bad.as<uint8_t>());
+        const int waves = T * W;
+        hipLaunchKernelGGL(build_masks_kernel, dim3(div_up(waves, 4)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(), P,
+                           W, T, min_space, B.orig.as<int32_t>(), c->d_allowed.as<uint64_t>(),
+                           c->d_has_allowed.as<uint8_t>(), c->d_prefer.as<uint64_t>(), B.has_pref.as<uint8_t>(),
+                           n_rs ? c->rs_bad.as<uint8_t>() : nullptr, B.elig.as<uint64_t>(),
+                           B.elig_nors.as<uint64_t>(), B.pref.as<uint64_t>(), B.fullw.as<uint64_t>());
+        hipLaunchKernelGGL(cluster_stats_kernel, dim3(std::min(div_up(P, 256), 512)), dim3(256), 0, st,
+                           B.pods.as<mmp_pod_row>(), P, min_space, c->stats_acc.as<StatsAcc>());
+        HIP_TRY(c, hipGetLastError());
+    } else {
+        HIP_TRY(c, hipMemsetAsync(B.elig.p, 0, (size_t)T * W * 8, st));
+        HIP_TRY(c, hipMemsetAsync(B.elig_nors.p, 0, (size_t)T * W * 8, st));
+        HIP_TRY(c, hipMemsetAsync(B.pref.p, 0, (size_t)T * W * 8, st));
+        HIP_TRY(c, hipMemsetAsync(B.fullw.p, 0, (size_t)W * 8, st));
+    }
+    int32_t bad = 0;
+    StatsAcc acc{};
+    HIP_TRY(c, hipMemcpyAsync(&bad, c->flag.p, sizeof bad, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(&acc, c->stats_acc.p, sizeof acc, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (bad)
+        return fail(c, MMP_EORDER,
+                    "PLACEMENT_ORDER is not a total order on these rows (a full instance with lruTime <= "
+                    "2*minChurnAgeMs next to differing instanceVersions); snapshot not published");
+
+    Snap S{};
+    S.P = P;
+    S.W = W;
+    S.T = T;
+    S.any_rs = n_rs > 0;
+    S.min_space = min_space;
+    S.lru = B.lru.as<int64_t>();
+    S.rem = B.rem.as<int64_t>();
+    S.cnt = B.cnt.as<int32_t>();
+    S.rpm = B.rpm.as<int32_t>();
+    S.orig = B.orig.as<int32_t>();
+    S.pos_of = B.pos_of.as<int32_t>();
+    S.elig = B.elig.as<uint64_t>();
+    S.elig_nors = B.elig_nors.as<uint64_t>();
+    S.pref = B.pref.as<uint64_t>();
+    S.has_pref = B.has_pref.as<uint8_t>();
+    S.fullw = B.fullw.as<uint64_t>();
+    c->snap = S;
+    c->cur = 1 - c->cur;
+    c->committed = true;
+    c->stats.total_capacity = (int64_t)acc.total_capacity;
+    c->stats.total_free = (int64_t)acc.total_free;
+    c->stats.global_lru = (int64_t)acc.global_lru;
+    c->stats.instance_count = acc.instance_count;
+    c->stats.model_copy_count = acc.model_copy_count;
+    return MMP_OK;
+}
+
+int mmp_get_order(mmp_ctx *c, int32_t *order_out, int32_t *n_out)
+{
+    if (!c || !order_out || !n_out) return fail(c, MMP_EINVAL, "mmp_get_order: null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int32_t n = c->stats.instance_count;  // absent rows sort last
+    if (n) HIP_TRY(c, hipMemcpy(order_out, c->snap.orig, (size_t)n * 4, hipMemcpyDeviceToHost));
+    *n_out = n;
+    return MMP_OK;
+}
+
+int mmp_cluster_stats(mmp_ctx *c, mmp_stats *out)
+{
+    if (!c || !out) return fail(c, MMP_EINVAL, "mmp_cluster_stats: null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    *out = c->stats;
+    return MMP_OK;
+}
+
+/* ---- decisions ---------------------------------------------------------- */
+
+int mmp_place_batch_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs,
+                        void *stream)
+{
+    if (!c || n < 0 || (n > 0 && (!d_reqs || !d_outs))) return fail(c, MMP_EINVAL, "mmp_place_batch_dev: bad argument");
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    return place_launch(c, d_reqs, n, d_extra, now, d_outs, static_cast<hipStream_t>(stream));
+}
+
+int mmp_place_batch(mmp_ctx *c, const mmp_place_req *reqs, int32_t n, const int32_t *extra_pool, int32_t n_extra,
+                    int64_t now, mmp_place_out *outs)
+{
+    if (!c || n < 0 || n_extra < 0 || (n > 0 && (!reqs || !outs)) || (n_extra > 0 && !extra_pool))
+        return fail(c, MMP_EINVAL, "mmp_place_batch: bad argument");
+    for (int32_t i = 0; i < n; i++)
+        if (reqs[i].n_extra < 0 || reqs[i].extra_off < 0 || (int64_t)reqs[i].extra_off + reqs[i].n_extra > n_extra)
+            return fail(c, MMP_EINVAL, "mmp_place_batch: request %d extra range out of bounds", i);
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    if (n == 0) return MMP_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = c->stream;
+    HIP_TRY(c, c->s_reqs.ensure((size_t)n * sizeof(mmp_place_req)));
+    HIP_TRY(c, c->s_outs.ensure((size_t)n * sizeof(mmp_place_out)));
+    HIP_TRY(c, c->s_extra.ensure((size_t)std::max(n_extra, 1) * 4));
+    HIP_TRY(c, hipMemcpyAsync(c->s_reqs.p, reqs, (size_t)n * sizeof(mmp_place_req), hipMemcpyHostToDevice, st));
+    if (n_extra) HIP_TRY(c, hipMemcpyAsync(c->s_extra.p, extra_pool, (size_t)n_extra * 4, hipMemcpyHostToDevice, st));
+    int rc = place_launch(c, c->s_reqs.p, n, c->s_extra.p, now, c->s_outs.p, st);
+    if (rc != MMP_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(outs, c->s_outs.p, (size_t)n * sizeof(mmp_place_out), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    return MMP_OK;
+}
+
+int mmp_serve_batch(mmp_ctx *c, const mmp_serve_req *reqs, int32_t n, const int32_t *in_use, const int64_t *last_used,
+                    const int32_t *excl_pod, const int64_t *excl_time, int32_t n_excl, int64_t now, mmp_serve_out *outs)
+{
+    if (!c || n < 0 || n_excl < 0 || (n > 0 && (!reqs || !outs || !in_use || !last_used)) ||
+        (n_excl > 0 && (!excl_pod || !excl_time)))
+        return fail(c, MMP_EINVAL, "mmp_serve_batch: bad argument");
+    for (int32_t i = 0; i < n; i++)
+        if (reqs[i].n_excl < 0 || reqs[i].excl_off < 0 || (int64_t)reqs[i].excl_off + reqs[i].n_excl > n_excl)
+            return fail(c, MMP_EINVAL, "mmp_serve_batch: request %d exclude range out of bounds", i);
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    if (n == 0) return MMP_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = c->stream;
+    const int32_t P = c->snap.P;
+    HIP_TRY(c, c->s_reqs.ensure((size_t)n * sizeof(mmp_serve_req)));
+    HIP_TRY(c, c->s_outs.ensure((size_t)n * sizeof(mmp_serve_out)));
+    HIP_TRY(c, c->s_a.ensure((size_t)std::max(P, 1) * 4));
+    HIP_TRY(c, c->s_b.ensure((size_t)std::max(P, 1) * 8));
+    HIP_TRY(c, c->s_c.ensure((size_t)std::max(n_excl, 1) * 4));
+    HIP_TRY(c, c->s_d.ensure((size_t)std::max(n_excl, 1) * 8));
+    HIP_TRY(c, hipMemcpyAsync(c->s_reqs.p, reqs, (size_t)n * sizeof(mmp_serve_req), hipMemcpyHostToDevice, st));
+    if (P) {
+        HIP_TRY(c, hipMemcpyAsync(c->s_a.p, in_use, (size_t)P * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->s_b.p, last_used, (size_t)P * 8, hipMemcpyHostToDevice, st));
+    }
+    if (n_excl) {
+        HIP_TRY(c, hipMemcpyAsync(c->s_c.p, excl_pod, (size_t)n_excl * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->s_d.p, excl_time, (size_t)n_excl * 8, hipMemcpyHostToDevice, st));
+    }
+    ServeArgs A;
+    A.reqs = c->s_reqs.as<mmp_serve_req>();
+    A.models = c->models.as<mmp_model_row>();
+    A.ent_pod = c->ent_pod.as<int32_t>();
+    A.ent_time = c->ent_time.as<int64_t>();
+    A.pods = c->sb[c->cur].pods.as<mmp_pod_row>();
+    A.in_use = c->s_a.as<int32_t>();
+    A.last_used = c->s_b.as<int64_t>();
+    A.excl_pod = c->s_c.as<int32_t>();
+    A.excl_time = c->s_d.as<int64_t>();
+    A.outs = c->s_outs.as<mmp_serve_out>();
+    A.n = n;
+    A.n_models = c->n_models;
+    A.P = P;
+    A.now = now;
+    hipLaunchKernelGGL(serve_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, A);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(outs, c->s_outs.p, (size_t)n * sizeof(mmp_serve_out), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    return MMP_OK;
+}
+
+int mmp_caches_load(mmp_ctx *c, int32_t n_caches, const int32_t *seg_off, const int64_t *last_used,
+                    const int32_t *weight, const int64_t *capacity)
+{
+    if (!c || n_caches < 0 || !seg_off || (n_caches > 0 && !capacity)) return fail(c, MMP_EINVAL, "mmp_caches_load: bad argument");
+    if (seg_off[0] != 0) return fail(c, MMP_EINVAL, "mmp_caches_load: seg_off[0] must be 0");
+    for (int32_t i = 0; i < n_caches; i++)
+        if (seg_off[i + 1] < seg_off[i]) return fail(c, MMP_EINVAL, "mmp_caches_load: seg_off not monotone at %d", i);
+    const int32_t E = seg_off[n_caches];
+    if (E > 0 && (!last_used || !weight)) return fail(c, MMP_EINVAL, "mmp_caches_load: null entry arrays");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, c->c_seg.ensure((size_t)(n_caches + 1) * 4));
+    HIP_TRY(c, c->c_lu.ensure((size_t)std::max(E, 1) * 8));
+    HIP_TRY(c, c->c_wt.ensure((size_t)std::max(E, 1) * 4));
+    HIP_TRY(c, c->c_cap.ensure((size_t)std::max(n_caches, 1) * 8));
+    HIP_TRY(c, hipMemcpy(c->c_seg.p, seg_off, (size_t)(n_caches + 1) * 4, hipMemcpyHostToDevice));
+    if (E) {
+        HIP_TRY(c, hipMemcpy(c->c_lu.p, last_used, (size_t)E * 8, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->c_wt.p, weight, (size_t)E * 4, hipMemcpyHostToDevice));
+    }
+    if (n_caches) HIP_TRY(c, hipMemcpy(c->c_cap.p, capacity, (size_t)n_caches * 8, hipMemcpyHostToDevice));
+    c->n_caches = n_caches;
+    return MMP_OK;
+}
+
+int mmp_evict_batch(mmp_ctx *c, const mmp_evict_req *reqs, int32_t n, int64_t now, mmp_evict_out *outs)
+{
+    if (!c || n < 0 || (n > 0 && (!reqs || !outs))) return fail(c, MMP_EINVAL, "mmp_evict_batch: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->n_caches <= 0 && n > 0) return fail(c, MMP_ESTATE, "no caches loaded");
+    if (n == 0) return MMP_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = c->stream;
+    HIP_TRY(c, c->s_reqs.ensure((size_t)n * sizeof(mmp_evict_req)));
+    HIP_TRY(c, c->s_outs.ensure((size_t)n * sizeof(mmp_evict_out)));
+    HIP_TRY(c, hipMemcpyAsync(c->s_reqs.p, reqs, (size_t)n * sizeof(mmp_evict_req), hipMemcpyHostToDevice, st));
+    EvictArgs A;
+    A.reqs = c->s_reqs.as<mmp_evict_req>();
+    A.seg_off = c->c_seg.as<int32_t>();
+    A.last_used = c->c_lu.as<int64_t>();
+    A.weight = c->c_wt.as<int32_t>();
+    A.capacity = c->c_cap.as<int64_t>();
+    A.outs = c->s_outs.as<mmp_evict_out>();
+    A.n = n;
+    A.n_caches = c->n_caches;
+    A.now = now;
+    hipLaunchKernelGGL(evict_batch_kernel, dim3(div_up(n, 4)), dim3(256), 0, st, A);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(outs, c->s_outs.p, (size_t)n * sizeof(mmp_evict_out), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    return MMP_OK;
+}
+
+}  // extern "C"

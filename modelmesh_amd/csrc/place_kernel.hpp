@@ -1,0 +1,463 @@
+// place_kernel.hpp — load-target selection, one wavefront per decision.
+//
+// Device form of CacheMissForwardingLB.getNext + filter (MM.java:4760-5005).
+// The Java walks clusterState (a skip list in PLACEMENT_ORDER) with sequential
+// `break`s; here the pods are already stored in that order (snapshot.hpp), so:
+//   filter()                    -> eligibility bitmap E (staged per wave in LDS,
+//                                  per-request exclusions cleared with ds_and)
+//   it.next() (best)            -> first set bit of E           (ballot + ctz)
+//   "break at first violator"   -> min position over the break predicates
+//   candidates list             -> bits of E in (best, firstBreak)
+//   index-th non-null candidate -> wave prefix-popcount + select-in-word
+// Every quirk of SURVEY.md Appendix B is kept (curInst substitution, fresh rpm,
+// bestIsFull not recomputed, >>2 vs "half", ...).  `us` is evaluated in its
+// closed form `pod == self`: with unique instance ids an eligible self is never
+// excluded and the `!us &&` toggle never fires (tests/test_place_parity.py
+// checks this against the literal oracle).
+#pragma once
+#include "snapshot.hpp"
+
+namespace mmp {
+
+constexpr int kPlaceWaves = 4;  // waves (decisions in flight) per workgroup
+
+struct PlaceArgs {
+    const mmp_place_req *reqs;
+    const mmp_model_row *models;
+    const int32_t *ent_pod;  // model entries: loaded ids then failed ids
+    const int32_t *extra;    // per-request extra exclusions
+    mmp_place_out *outs;
+    int32_t n;
+    int32_t n_models;
+    int64_t now;
+};
+
+__device__ __forceinline__ int64_t jsub64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
+__device__ __forceinline__ int64_t age_of(int64_t t, int64_t now) { return t == 0 ? 0 : jsub64(now, t); }  // MM.java:4162
+
+// (int)(double) with Java narrowing semantics
+__device__ __forceinline__ int32_t jd2i(double d)
+{
+    if (d != d) return 0;
+    if (d >= 2147483647.0) return INT32_MAX;
+    if (d <= -2147483648.0) return INT32_MIN;
+    return (int32_t)d;
+}
+
+__device__ __forceinline__ bool test_bit(const uint64_t *m, int pos) { return (m[pos >> 6] >> (pos & 63)) & 1ull; }
+
+// bits of word w that fall inside positions [lo, hi)
+__device__ __forceinline__ uint64_t clip_word(uint64_t v, int w, int lo, int hi)
+{
+    const int wl = lo >> 6, wh = hi >> 6;
+    if (w < wl || w > wh) return 0;
+    if (w == wl) v &= (~0ull) << (lo & 63);
+    if (w == wh) v &= (1ull << (hi & 63)) - 1ull;
+    return v;
+}
+
+// first position >= start whose bit is set in (ew & andmask); kNoPos if none
+__device__ __forceinline__ int first_set_from(const uint64_t *ew, const uint64_t *andmask, int start, int W)
+{
+    const int lane = lane_id();
+    if (start >= W * 64) return kNoPos;
+    const int w0 = start >> 6;
+    for (int base = w0; base < W; base += 64) {
+        const int w = base + lane;
+        uint64_t v = 0;
+        if (w < W) {
+            v = ew[w];
+            if (andmask) v &= andmask[w];
+            if (w == w0) v &= (~0ull) << (start & 63);
+        }
+        const uint64_t b = __ballot(v != 0);
+        if (b) {
+            const int l = __ffsll((unsigned long long)b) - 1;
+            const uint64_t vv = shfl_u64(v, l);
+            return (base + l) * 64 + (__ffsll((unsigned long long)vv) - 1);
+        }
+    }
+    return kNoPos;
+}
+
+// first position in [start,end) with bit set in (ew&andmask) and
+// cnt >= 10 && cnt > thr   (MM.java:4925-4926)
+__device__ __forceinline__ int first_count_break(const uint64_t *ew, const uint64_t *andmask, int start,
+                                                 int end, const int32_t *cnt, int32_t thr)
+{
+    const int lane = lane_id();
+    if (start >= end) return kNoPos;
+    const int g1 = (end - 1) >> 6;
+    for (int g = start >> 6; g <= g1; g++) {
+        uint64_t word = ew[g];
+        if (andmask) word &= andmask[g];
+        word = clip_word(word, g, start, end);
+        if (word == 0) continue;  // wave-uniform
+        const int32_t c = cnt[g * 64 + lane];  // columns are padded to W*64
+        const bool hit = ((word >> lane) & 1ull) && c >= 10 && c > thr;
+        const uint64_t b = __ballot(hit);
+        if (b) return g * 64 + (__ffsll((unsigned long long)b) - 1);
+    }
+    return kNoPos;
+}
+
+// first position >= start with bit set in ew and
+// (lru - oldest) > abs_ms && (lru - oldest) > rel   (MM.java:4862-4866)
+__device__ __forceinline__ int first_lru_break(const uint64_t *ew, int start, int W, const int64_t *lru,
+                                               int64_t oldest, int64_t abs_ms, int64_t rel)
+{
+    const int lane = lane_id();
+    if (start >= W * 64) return kNoPos;
+    for (int g = start >> 6; g < W; g++) {
+        const uint64_t word = clip_word(ew[g], g, start, W * 64);
+        if (word == 0) continue;
+        const int64_t d = jsub64(lru[g * 64 + lane], oldest);
+        const bool hit = ((word >> lane) & 1ull) && d > abs_ms && d > rel;
+        const uint64_t b = __ballot(hit);
+        if (b) return g * 64 + (__ffsll((unsigned long long)b) - 1);
+    }
+    return kNoPos;
+}
+
+struct RpmRule {
+    bool active;  // lastUsedAgo < FIVE_DAYS_MS
+    int64_t ago;
+    int32_t min_load, m11, m15, m3, m4;
+    __device__ __forceinline__ void init(int64_t ago_, int32_t min_rpm)
+    {
+        ago = ago_;
+        active = ago < 5LL * 24 * 3600 * 1000;
+        min_load = min_rpm > 100 ? min_rpm : 100;       // MM.java:4957
+        m11 = jd2i(1.1 * (double)min_load);             // :4958
+        m15 = jd2i(1.5 * (double)min_load);
+        m3 = (int32_t)((uint32_t)min_load * 3u);
+        m4 = (int32_t)((uint32_t)min_load * 4u);
+    }
+    // MM.java:4961-4972
+    __device__ __forceinline__ bool nulls(int32_t rpm) const
+    {
+        return active && rpm >= 100 &&
+               ((ago < -1000LL && rpm > m11) || (ago < 5000LL && rpm > m15) ||
+                (ago < 12LL * 60 * 1000 && rpm > m3) || (ago < 24LL * 3600 * 1000 && rpm > m4));
+    }
+};
+
+// index-th set bit (in position order) over fw words [wlo, whi]
+__device__ __forceinline__ int select_in_range(const uint64_t *fw, int wlo, int whi, int index)
+{
+    const int lane = lane_id();
+    int running = 0;
+    for (int base = wlo; base <= whi; base += 64) {
+        const int w = base + lane;
+        const uint64_t v = (w <= whi) ? fw[w] : 0ull;
+        const int c = __popcll((unsigned long long)v);
+        const int incl = wave_incl_scan_i32(c);
+        const int total = shfl_i32(incl, 63);
+        if (index < running + total) {
+            const uint64_t b = __ballot(running + incl > index);
+            const int l = __ffsll((unsigned long long)b) - 1;
+            const uint64_t vv = shfl_u64(v, l);
+            const int before = running + shfl_i32(incl, l) - shfl_i32(c, l);
+            return (base + l) * 64 + select_kth_bit(vv, index - before);
+        }
+        running += total;
+    }
+    return kNoPos;
+}
+
+__device__ __forceinline__ void write_out(mmp_place_out *o, int32_t chosen, int32_t best, int32_t n,
+                                          uint32_t hash)
+{
+    if (lane_id() == 0) {
+        o->chosen = chosen;
+        o->best = best;
+        o->n_candidates = n;
+        o->hash = hash;
+    }
+}
+
+// Stage the eligibility bitmap of this decision into LDS and clear the
+// CacheMissExcludeSet members (MM.java:4740-4743).
+__device__ __forceinline__ void stage_eligible(const Snap &S, const uint64_t *src, uint64_t *ew,
+                                               const int32_t *ents, int32_t n_ents, const int32_t *extra,
+                                               int32_t n_extra)
+{
+    const int lane = lane_id();
+    for (int w = lane; w < S.W; w += 64) ew[w] = src[w];
+    wave_sync();
+    const int nex = n_ents + n_extra;
+    for (int i = lane; i < nex; i += 64) {
+        const int32_t pod = i < n_ents ? ents[i] : extra[i - n_ents];
+        if (pod >= 0 && pod < S.P) {
+            const int pos = S.pos_of[pod];
+            atomicAnd((unsigned long long *)&ew[pos >> 6], ~(1ull << (pos & 63)));
+        }
+    }
+    wave_sync();
+}
+
+__device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int d, uint64_t *ew, uint64_t *fw)
+{
+    const int lane = lane_id();
+    const int P = S.P, W = S.W;
+    mmp_place_out *out = &A.outs[d];
+    const mmp_place_req rq = A.reqs[d];
+    if (rq.model < 0 || rq.model >= A.n_models) {
+        write_out(out, MMP_NONE, -1, 0, 0);
+        return;
+    }
+    const mmp_model_row m = A.models[rq.model];
+    int type = m.type;
+    if (type < 0 || type >= S.T) type = 0;
+    const int32_t *ents = A.ent_pod + m.ent_off;
+    const int32_t n_ents = m.n_loaded + m.n_failed;
+    const int32_t *extra = A.extra + rq.extra_off;
+
+    const int selfpos = (rq.self_pod >= 0 && rq.self_pod < P) ? S.pos_of[rq.self_pod] : -1;
+    const bool favour = (rq.flags & MMP_REQ_FAVOUR_SELF) != 0;
+
+    // filter(...) and the retry without excludeReplicaSets, MM.java:4793-4805
+    stage_eligible(S, S.elig + (size_t)type * W, ew, ents, n_ents, extra, rq.n_extra);
+    int best0 = first_set_from(ew, nullptr, 0, W);
+    if (best0 == kNoPos && S.any_rs) {
+        stage_eligible(S, S.elig_nors + (size_t)type * W, ew, ents, n_ents, extra, rq.n_extra);
+        best0 = first_set_from(ew, nullptr, 0, W);
+    }
+    if (best0 == kNoPos) {
+        write_out(out, MMP_NONE, -1, 0, 0);
+        return;
+    }
+
+    // the caller's getFreshInstanceRecord()
+    const int64_t f_lru = rq.fresh_lru;
+    const int64_t f_rem = remaining_of(rq.fresh_capacity, rq.fresh_used);
+    const int32_t f_rpm = rq.fresh_rpm;
+
+    // bestEntry.getValue(): the snapshot row of the first eligible pod
+    const int64_t e_lru = S.lru[best0], e_rem = S.rem[best0];
+    const int32_t e_cnt = S.cnt[best0], e_rpm = S.rpm[best0];
+
+    bool us = (best0 == selfpos);                    // :4808
+    int64_t b_lru = us ? f_lru : e_lru;              // bestInst, :4810
+    int64_t b_rem = us ? f_rem : e_rem;
+    int32_t b_cnt = us ? rq.fresh_count : e_cnt;
+    int32_t b_rpm = us ? f_rpm : e_rpm;
+    const bool best_is_full = b_rem < S.min_space;   // :4811, never recomputed (quirk B#14)
+
+    const uint64_t *Pm = S.has_pref[type] ? S.pref + (size_t)type * W : nullptr;  // :4817
+    int bestpos = best0;
+    const uint64_t *Dm = Pm;  // "treat preference as required" mask of the simple loop (:4905)
+    int limit = P;            // exclusive end of the iterator the simple loop walks
+    bool mode_b = false;
+
+    if (Pm && !test_bit(Pm, best0)) {  // !simpleCase, :4822-4823
+        if (!best_is_full) {
+            // case (a) :4828-4852 — first preferred pod before the first full pod
+            const int q1 = first_set_from(ew, Pm, best0 + 1, W);
+            const int q2 = first_set_from(ew, S.fullw, best0 + 1, W);
+            if (q1 != kNoPos && q1 <= q2) {
+                bestpos = q1;
+                b_lru = S.lru[q1];
+                b_rem = S.rem[q1];
+                b_cnt = S.cnt[q1];
+                b_rpm = S.rpm[q1];
+                us = (q1 == selfpos);
+            } else {
+                Dm = nullptr;  // prefer = null, replay list = eligible pods before q2
+                limit = q2 < P ? q2 : P;
+            }
+        } else {
+            // case (b) :4853-4887
+            const int q3 = first_lru_break(ew, best0 + 1, W, S.lru, b_lru, 120000LL, age_of(b_lru, A.now) / 4);
+            const int lim = q3 < P ? q3 : P;
+            const int qp = first_set_from(ew, Pm, best0 + 1, W);
+            limit = lim;
+            if (qp < lim)
+                mode_b = true;
+            else
+                Dm = nullptr;
+        }
+    }
+
+    const int64_t ago = age_of(rq.last_used, A.now);  // :4951
+    int wlo, whi, ccount;
+    uint64_t hsum;
+    RpmRule rule;
+    int remaining;
+
+    if (mode_b) {
+        // only preferred pods inside the age window are candidates; best0 is not (:4867-4877)
+        const int start = best0 + 1;
+        if (selfpos >= start && selfpos < limit && test_bit(ew, selfpos) && test_bit(Pm, selfpos) && favour) {
+            write_out(out, MMP_NONE, S.orig[best0], 0, 0);  // :4871-4873 return null
+            return;
+        }
+        wlo = start >> 6;
+        whi = (limit - 1) >> 6;
+        int cc = 0, mn = INT32_MAX;
+        uint64_t h = 0;
+        for (int base = wlo; base <= whi; base += 64) {
+            const int w = base + lane;
+            uint64_t v = 0;
+            if (w <= whi) {
+                v = clip_word(ew[w] & Pm[w], w, start, limit);
+                fw[w] = v;
+            }
+            cc += __popcll((unsigned long long)v);
+            if (v) h += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)(w + 1)));
+            for (uint64_t t = v; t; t &= t - 1) {
+                const int32_t r = S.rpm[w * 64 + (__ffsll((unsigned long long)t) - 1)];
+                mn = r < mn ? r : mn;
+            }
+        }
+        ccount = wave_sum_i32(cc);
+        hsum = wave_sum_u64(h);
+        mn = wave_min_i32(mn);
+        remaining = ccount;
+        if (ccount >= 2) {
+            rule.init(ago, mn);
+            if (rule.active) {
+                wave_sync();
+                int nulled = 0;
+                for (int base = wlo; base <= whi; base += 64) {
+                    const int w = base + lane;
+                    if (w <= whi) {
+                        uint64_t v = fw[w], keep = v;
+                        for (uint64_t t = v; t; t &= t - 1) {
+                            const int bit = __ffsll((unsigned long long)t) - 1;
+                            if (rule.nulls(S.rpm[w * 64 + bit])) {
+                                keep &= ~(1ull << bit);
+                                nulled++;
+                            }
+                        }
+                        fw[w] = keep;
+                    }
+                }
+                remaining = ccount - wave_sum_i32(nulled);
+            }
+        }
+        wave_sync();
+    } else {
+        // simple case :4890-4938
+        if (us && favour) {
+            write_out(out, MMP_SELF, S.orig[bestpos], 0, 0);  // :4891-4895
+            return;
+        }
+        const int64_t oldest = b_lru;
+        bool ns_break, self_break;  // break predicate for non-self pods (curInst = caller's fresh
+                                    // row) and for the self pod (curInst = bestEntry's row), :4909
+        if (best_is_full) {
+            const int64_t rel = age_of(oldest, A.now) / 10;
+            const int64_t d1 = jsub64(f_lru, oldest), d2 = jsub64(e_lru, oldest);
+            ns_break = d1 > 45000LL && d1 > rel;  // :4913-4917
+            self_break = d2 > 45000LL && d2 > rel;
+        } else {
+            const int64_t q = b_rem >> 2;  // :4922 ("half" in the comment, quarter in the code)
+            ns_break = f_rem < S.min_space || f_rem < q;
+            self_break = e_rem < S.min_space || e_rem < q;
+        }
+        const int start = bestpos + 1;
+        const bool self_in_d = selfpos >= start && selfpos < limit && test_bit(ew, selfpos) &&
+                               (!Dm || test_bit(Dm, selfpos));
+        int end = limit;
+        if (ns_break) {
+            int p1 = first_set_from(ew, Dm, start, W);
+            if (p1 == selfpos) p1 = first_set_from(ew, Dm, selfpos + 1, W);
+            end = p1 < end ? p1 : end;
+        }
+        if (self_in_d && self_break) end = selfpos < end ? selfpos : end;
+        if (!best_is_full) {
+            const int32_t thr = (int32_t)((uint32_t)b_cnt + (uint32_t)(b_cnt >> 2));  // :4926
+            const int pc = first_count_break(ew, Dm, start, end, S.cnt, thr);
+            end = pc < end ? pc : end;
+        }
+        const bool self_in_c = self_in_d && selfpos < end;
+        if (self_in_c && favour) {
+            write_out(out, MMP_SELF, S.orig[bestpos], 0, 0);  // :4931-4933
+            return;
+        }
+        // candidates = {best} ∪ D∩[start,end)
+        wlo = bestpos >> 6;
+        whi = end > start ? (end - 1) >> 6 : wlo;
+        int cc = 0;
+        uint64_t h = 0;
+        for (int base = wlo; base <= whi; base += 64) {
+            const int w = base + lane;
+            uint64_t v = 0;
+            if (w <= whi) {
+                v = ew[w];
+                if (Dm) v &= Dm[w];
+                v = clip_word(v, w, start, end);
+                if (w == wlo) v |= 1ull << (bestpos & 63);
+                fw[w] = v;
+            }
+            cc += __popcll((unsigned long long)v);
+            if (v) h += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)(w + 1)));
+        }
+        ccount = wave_sum_i32(cc);
+        hsum = wave_sum_u64(h);
+        remaining = ccount;
+        wave_sync();
+        if (ccount >= 2) {
+            // instReqLoad: bestInst.rpm for the best, bestEntry's rpm for a self entry,
+            // the caller's fresh rpm for every other pod (quirks B#2, B#3)
+            const int n_others = ccount - 1 - (self_in_c ? 1 : 0);
+            int32_t mn = b_rpm;
+            if (self_in_c && e_rpm < mn) mn = e_rpm;
+            if (n_others > 0 && f_rpm < mn) mn = f_rpm;
+            rule.init(ago, mn);
+            const bool null0 = rule.nulls(b_rpm);
+            const bool null_s = self_in_c && rule.nulls(e_rpm);
+            const bool null_o = n_others > 0 && rule.nulls(f_rpm);
+            if (null0 || null_s || null_o) {
+                remaining = ccount - (null0 ? 1 : 0) - (null_s ? 1 : 0) - (null_o ? n_others : 0);
+                const int bw = bestpos >> 6, sw = self_in_c ? (selfpos >> 6) : -1;
+                for (int base = wlo; base <= whi; base += 64) {
+                    const int w = base + lane;
+                    if (w <= whi) {
+                        uint64_t v = fw[w];
+                        uint64_t special = 0;
+                        if (w == bw) special |= 1ull << (bestpos & 63);
+                        if (w == sw) special |= 1ull << (selfpos & 63);
+                        if (null_o) v &= special;
+                        if (null0 && w == bw) v &= ~(1ull << (bestpos & 63));
+                        if (null_s && w == sw) v &= ~(1ull << (selfpos & 63));
+                        fw[w] = v;
+                    }
+                }
+                wave_sync();
+            }
+        }
+    }
+
+    const int32_t best_idx = S.orig[bestpos];
+    if (ccount == 0) {  // :4941-4943
+        write_out(out, MMP_NONE, best_idx, 0, 0);
+        return;
+    }
+    const uint32_t hash = (uint32_t)(hsum ^ (hsum >> 32)) ^ ((uint32_t)remaining * 0x9E3779B1u);
+    // :4981-4986 — index-th non-null candidate
+    const int index = remaining <= 1 ? 0 : (int)(((uint64_t)rq.pick * (uint64_t)(uint32_t)remaining) >> 32);
+    const int cpos = remaining >= 1 ? select_in_range(fw, wlo, whi, index) : kNoPos;
+    int32_t chosen = MMP_NONE;
+    if (cpos != kNoPos) {
+        chosen = S.orig[cpos];
+        if (!favour && cpos == selfpos) chosen = MMP_SELF;  // :4989-4991
+    }
+    write_out(out, chosen, best_idx, ccount, hash);
+}
+
+// LDS per workgroup: kPlaceWaves × 2 bitmaps × Wpad words.
+__global__ __launch_bounds__(kPlaceWaves * 64) void place_batch_kernel(Snap S, PlaceArgs A, int32_t wpad)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint64_t *ew = reinterpret_cast<uint64_t *>(smem) + (size_t)wave * 2 * wpad;
+    uint64_t *fw = ew + wpad;
+    for (int d = blockIdx.x * kPlaceWaves + wave; d < A.n; d += gridDim.x * kPlaceWaves) {
+        place_one(S, A, d, ew, fw);
+        wave_sync();
+    }
+}
+
+}  // namespace mmp

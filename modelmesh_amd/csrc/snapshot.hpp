@@ -1,0 +1,248 @@
+// snapshot.hpp — the immutable device snapshot the decision kernels read, and
+// the kernels that build it from raw InstanceRecord rows.
+//
+// Layout in HBM.  All per-pod columns are stored in
+// PLACEMENT_ORDER (MM.java:4646-4703) so that "position" == rank and every
+// ordered construct of CacheMissForwardingLB.getNext (first eligible, break at
+// the first violator, index-th survivor) becomes a bit-scan / prefix-popcount
+// over 64-pod words.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mmplace.h"
+#include "wave.hpp"
+
+namespace mmp {
+
+struct Snap {
+    int32_t P;       // pod slots (including tombstones / shutting-down rows)
+    int32_t W;       // ceil(P/64) words per bitmap
+    int32_t T;       // bitmap rows (>=1; row 0 is "no type table")
+    int32_t any_rs;  // excludeReplicaSets non-empty (MM.java:4792)
+    int64_t min_space;
+    // rank-ordered columns
+    const int64_t *lru;
+    const int64_t *rem;
+    const int32_t *cnt;
+    const int32_t *rpm;
+    const int32_t *orig;    // position -> pod index
+    const int32_t *pos_of;  // pod index -> position
+    // rank-ordered bitmaps, [T][W] unless noted
+    const uint64_t *elig;       // allowed ∧ live ∧ present ∧ ¬replaced-replica-set
+    const uint64_t *elig_nors;  // allowed ∧ live ∧ present
+    const uint64_t *pref;       // preferred instances
+    const uint8_t *has_pref;    // [T] getPreferredInstances(type) != null
+    const uint64_t *fullw;      // [W] isFull(row.remaining)
+};
+
+// Row staged in LDS by the rank kernel: exactly the fields PLACEMENT_ORDER reads.
+struct __attribute__((aligned(16))) RankRow {
+    int64_t vers, rem, lru, cap;
+    int32_t count, lt_free, lip, rpm;
+    uint32_t id_order, flags;  // flags: bit0 absent (shutting down / tombstone), bit1 full
+    uint32_t pad0, pad1;
+};
+static_assert(sizeof(RankRow) == 64, "RankRow is 64 bytes");
+
+__device__ __forceinline__ int64_t remaining_of(int64_t cap, int64_t used)
+{
+    int64_t d = (int64_t)((uint64_t)cap - (uint64_t)used);
+    return d > 0 ? d : 0;  // InstanceRecord.java:203-205
+}
+
+__device__ __forceinline__ RankRow make_rank_row(const mmp_pod_row &r, int64_t min_space)
+{
+    RankRow o;
+    o.vers = r.version;
+    o.rem = remaining_of(r.capacity, r.used);
+    o.lru = r.lru_time;
+    o.cap = r.capacity;
+    o.count = r.count;
+    o.lt_free = (int32_t)((uint32_t)r.loading_threads - (uint32_t)r.loading_in_progress);
+    o.lip = r.loading_in_progress;
+    o.rpm = r.rpm;
+    o.id_order = r.id_order;
+    const bool absent = (r.flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE)) != 0;
+    o.flags = (absent ? 1u : 0u) | ((o.rem < min_space) ? 2u : 0u);
+    o.pad0 = o.pad1 = 0;
+    return o;
+}
+
+// PLACEMENT_ORDER.compare(a,b) < 0, transcribed clause by clause from
+// MM.java:4646-4703.  Absent rows play the shuttingDown role (sorted last).
+__device__ __forceinline__ bool placement_less(const RankRow &a, const RankRow &b, int64_t churn2)
+{
+    const bool sd1 = a.flags & 1u, sd2 = b.flags & 1u;
+    if (sd1 != sd2) return !sd1;  // :4653-4656
+    const bool full1 = a.flags & 2u, full2 = b.flags & 2u;
+    if (a.vers != b.vers) {  // :4660-4666
+        if (a.vers > b.vers) {
+            if (!full1 || a.lru > churn2) return true;
+        } else if (!full2 || b.lru > churn2)
+            return false;
+    }
+    if (full1 != full2) return !full1;  // :4669
+    if (full1 && a.lru != b.lru) return a.lru < b.lru;  // :4670-4674
+    const int32_t cd = (int32_t)((uint32_t)a.count - (uint32_t)b.count);  // :4676 int subtraction
+    if (cd != 0) return cd < 0;
+    if (a.rem != b.rem) return a.rem > b.rem;            // :4679-4680
+    if (!full1 && a.lru != b.lru) return a.lru < b.lru;  // :4681-4685
+    if (a.lt_free != b.lt_free) return a.lt_free > b.lt_free;  // :4692
+    if (a.lip != b.lip) return a.lip < b.lip;                  // :4693
+    if (a.cap != b.cap) return a.cap > b.cap;                  // :4694
+    if (a.rpm != b.rpm) return a.rpm < b.rpm;                  // :4695
+    return a.id_order < b.id_order;                            // :4696
+}
+
+// rank[p] += #{q in this block's slice : q sorts before p}.  All-pairs: P is at
+// most tens of thousands, the row tile is broadcast from LDS, and the literal
+// comparator (not a derived key) is what gets evaluated.
+constexpr int kRankBlock = 256;
+__global__ __launch_bounds__(kRankBlock) void rank_pods_kernel(const mmp_pod_row *__restrict__ pods,
+                                                               int32_t P, int64_t min_space,
+                                                               int64_t churn2, int32_t slices,
+                                                               int32_t *__restrict__ rank)
+{
+    __shared__ RankRow tile[kRankBlock];
+    const int p = blockIdx.x * kRankBlock + threadIdx.x;
+    RankRow me;
+    if (p < P) me = make_rank_row(pods[p], min_space);
+    // this block compares against q in [q0, q1)
+    const int per = (P + slices - 1) / slices;
+    const int q0 = blockIdx.y * per;
+    const int q1 = min(P, q0 + per);
+    int32_t before = 0;
+    for (int base = q0; base < q1; base += kRankBlock) {
+        const int q = base + threadIdx.x;
+        __syncthreads();
+        if (q < q1) tile[threadIdx.x] = make_rank_row(pods[q], min_space);
+        __syncthreads();
+        const int nq = min(kRankBlock, q1 - base);
+        if (p < P) {
+            for (int j = 0; j < nq; j++) {
+                if (base + j != p && placement_less(tile[j], me, churn2)) before++;
+            }
+        }
+    }
+    if (p < P && before) atomicAdd(&rank[p], before);
+}
+
+// Scatter rows into rank order; detect a non-total order (two rows with the
+// same rank) through the occupancy counters.
+__global__ void scatter_pods_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int64_t min_space,
+                                    const int32_t *__restrict__ rank, int32_t *__restrict__ occupancy,
+                                    int64_t *__restrict__ lru, int64_t *__restrict__ rem,
+                                    int32_t *__restrict__ cnt, int32_t *__restrict__ rpm,
+                                    int32_t *__restrict__ orig, int32_t *__restrict__ pos_of,
+                                    int32_t *__restrict__ err)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int pos = rank[p];
+    if (pos < 0 || pos >= P || atomicAdd(&occupancy[pos], 1) != 0) {
+        atomicExch(err, 1);
+        return;
+    }
+    const mmp_pod_row r = pods[p];
+    lru[pos] = r.lru_time;
+    rem[pos] = remaining_of(r.capacity, r.used);
+    cnt[pos] = r.count;
+    rpm[pos] = r.rpm;
+    orig[pos] = p;
+    pos_of[p] = pos;
+}
+
+// One wave per (bitmap row, word): gather 64 per-pod predicates through the
+// rank permutation and ballot them into one rank-ordered word.
+//   allowed/prefer: [T][W] over pod index (or null = all / none)
+//   rs_bad: per pod, 1 if its replica set is "likely replaced"
+__global__ void build_masks_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int32_t W, int32_t T,
+                                   int64_t min_space, const int32_t *__restrict__ orig,
+                                   const uint64_t *__restrict__ allowed,
+                                   const uint8_t *__restrict__ has_allowed,
+                                   const uint64_t *__restrict__ prefer,
+                                   const uint8_t *__restrict__ has_prefer,
+                                   const uint8_t *__restrict__ rs_bad, uint64_t *__restrict__ elig,
+                                   uint64_t *__restrict__ elig_nors, uint64_t *__restrict__ pref,
+                                   uint64_t *__restrict__ fullw)
+{
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= T * W) return;
+    const int t = wave / W, w = wave - t * W;
+    const int pos = w * 64 + lane;
+    bool e = false, en = false, pf = false, fl = false;
+    if (pos < P) {
+        const int p = orig[pos];
+        const mmp_pod_row r = pods[p];
+        const bool present = (r.flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE)) == 0;
+        const bool live = (r.flags & MMP_POD_LIVE) != 0;
+        bool al = true;
+        if (has_allowed && has_allowed[t]) al = (allowed[(size_t)t * W + (p >> 6)] >> (p & 63)) & 1ull;
+        en = present && live && al;
+        e = en && !(rs_bad && rs_bad[p]);
+        if (has_prefer && has_prefer[t]) pf = (prefer[(size_t)t * W + (p >> 6)] >> (p & 63)) & 1ull;
+        fl = remaining_of(r.capacity, r.used) < min_space;
+    }
+    const uint64_t be = __ballot(e), ben = __ballot(en), bp = __ballot(pf), bf = __ballot(fl);
+    if (lane == 0) {
+        elig[(size_t)t * W + w] = be;
+        elig_nors[(size_t)t * W + w] = ben;
+        pref[(size_t)t * W + w] = bp;
+        if (t == 0) fullw[w] = bf;
+    }
+}
+
+// rs_bad[p] = pod p's replica set is in the replaced list (MM.java:4769-4770)
+__global__ void mark_replaced_kernel(const mmp_pod_row *__restrict__ pods, int32_t P,
+                                     const int32_t *__restrict__ rs, int32_t n_rs,
+                                     uint8_t *__restrict__ rs_bad)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int32_t mine = pods[p].replica_set;
+    uint8_t bad = 0;
+    if (mine >= 0)
+        for (int i = 0; i < n_rs; i++)
+            if (rs[i] == mine) bad = 1;
+    rs_bad[p] = bad;
+}
+
+// ClusterStats (InstanceSetStatsTracker.java:53-92): sums and min over present rows.
+struct StatsAcc {
+    unsigned long long total_capacity, total_free;
+    long long global_lru;
+    int32_t instance_count, model_copy_count;
+};
+
+__global__ void cluster_stats_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int64_t min_space,
+                                     StatsAcc *__restrict__ acc)
+{
+    int64_t cap = 0, fre = 0, lru = INT64_MAX;
+    int32_t n = 0, mc = 0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const mmp_pod_row r = pods[p];
+        if (r.flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE)) continue;
+        n++;
+        mc = (int32_t)((uint32_t)mc + (uint32_t)r.count);
+        cap = (int64_t)((uint64_t)cap + (uint64_t)r.capacity);
+        const int64_t avail = remaining_of(r.capacity, r.used);
+        if (!(avail < min_space)) fre = (int64_t)((uint64_t)fre + (uint64_t)avail);
+        if (r.lru_time > 0 && r.lru_time < lru) lru = r.lru_time;  // addLru ignores <= 0
+    }
+    cap = wave_sum_i64(cap);
+    fre = wave_sum_i64(fre);
+    lru = wave_min_i64(lru);
+    n = wave_sum_i32(n);
+    mc = wave_sum_i32(mc);
+    if (lane_id() == 0) {
+        atomicAdd(&acc->total_capacity, (unsigned long long)cap);
+        atomicAdd(&acc->total_free, (unsigned long long)fre);
+        atomicMin(&acc->global_lru, (long long)lru);
+        atomicAdd(&acc->instance_count, n);
+        atomicAdd(&acc->model_copy_count, mc);
+    }
+}
+
+}  // namespace mmp

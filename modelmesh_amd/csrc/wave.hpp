@@ -1,0 +1,118 @@
+// wave.hpp — wave64 (gfx950) cross-lane helpers used by the solver kernels.
+// A wavefront is 64 lanes; every helper assumes the whole wave is active.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mmp {
+
+constexpr int kWave = 64;
+constexpr int kNoPos = 0x7fffffff;  // "no such position" for first_set_* searches
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// LDS written by some lanes of a wave and read by other lanes of the same wave:
+// DS operations of one wave execute in order, so only the compiler has to be
+// stopped from moving accesses across this point.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int32_t shfl_i32(int32_t v, int src) { return __shfl(v, src, 64); }
+
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = (uint32_t)__shfl((int)lo, src, 64);
+    hi = (uint32_t)__shfl((int)hi, src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ int32_t wave_sum_i32(int32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        int32_t t = __shfl_xor(v, o, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
+        uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int64_t wave_sum_i64(int64_t v) { return (int64_t)wave_sum_u64((uint64_t)v); }
+
+__device__ __forceinline__ int64_t wave_min_i64(int64_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        int64_t t = (int64_t)shfl_u64((uint64_t)v, lane_id() ^ o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+// inclusive prefix sum across the 64 lanes
+__device__ __forceinline__ int32_t wave_incl_scan_i32(int32_t v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int32_t t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// position of the k-th (0-based) set bit of v; requires k < popcount(v)
+__device__ __forceinline__ int select_kth_bit(uint64_t v, int k)
+{
+    int r = 0;
+    uint32_t x = (uint32_t)v;
+    int c = __popc(x);
+    if (k >= c) { k -= c; r = 32; x = (uint32_t)(v >> 32); }
+    c = __popc(x & 0xffffu);
+    if (k >= c) { k -= c; r += 16; x >>= 16; }
+    x &= 0xffffu;
+    c = __popc(x & 0xffu);
+    if (k >= c) { k -= c; r += 8; x >>= 8; }
+    x &= 0xffu;
+    c = __popc(x & 0xfu);
+    if (k >= c) { k -= c; r += 4; x >>= 4; }
+    x &= 0xfu;
+    c = __popc(x & 0x3u);
+    if (k >= c) { k -= c; r += 2; x >>= 2; }
+    x &= 0x3u;
+    c = (int)(x & 1u);
+    if (k >= c) r += 1;
+    return r;
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+}  // namespace mmp

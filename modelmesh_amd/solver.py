@@ -1,0 +1,195 @@
+"""Thin Python veneer over the libmmplace C ABI (used by tests and bench.py).
+
+Names follow the reference's domain: an *instance table* of pods
+(InstanceRecord), a *registry* of models (ModelRecord), load-target decisions
+(CacheMissForwardingLB.getNext, MM.java:4776), serve-target decisions
+(ForwardingLB.getNext, MM.java:4315) and cache eviction (clhm).
+Everything is computed by the HIP kernels behind the C ABI; nothing here
+implements placement logic.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import (EVICT_OUT, EVICT_REQ, MODEL_ROW, PLACE_OUT, PLACE_REQ, POD_ROW, SERVE_OUT,
+                   SERVE_REQ, STATS, MmpConfig, ptr)
+
+
+class MmpError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libmmplace error {code}: {msg}")
+        self.code = code
+
+
+@dataclass
+class Fleet:
+    """One consistent view of clusterState + registry + typeConstraints."""
+    pods: np.ndarray                      # POD_ROW[P]
+    models: np.ndarray                    # MODEL_ROW[M]
+    ent_pod: np.ndarray                   # int32: loaded ids then failed ids per model
+    ent_time: np.ndarray                  # int64: load start / failure time per entry
+    min_space_units: int
+    min_churn_age_ms: int
+    now: int
+    n_types: int = 0                      # 0 == typeConstraints is null
+    allowed: Optional[np.ndarray] = None  # uint64 [T][W] bit p = pod p allowed
+    prefer: Optional[np.ndarray] = None
+    has_allowed: Optional[np.ndarray] = None  # uint8 [T]
+    has_prefer: Optional[np.ndarray] = None
+    replaced_rs: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+
+    @property
+    def n_pods(self) -> int:
+        return int(self.pods.shape[0])
+
+    @property
+    def n_models(self) -> int:
+        return int(self.models.shape[0])
+
+
+def bitmap_from_bool(mask: np.ndarray) -> np.ndarray:
+    """bool [T][P] -> uint64 [T][ceil(P/64)], bit p%64 of word p//64."""
+    mask = np.atleast_2d(mask).astype(bool)
+    t, p = mask.shape
+    w = (p + 63) // 64
+    padded = np.zeros((t, w * 64), dtype=np.uint8)
+    padded[:, :p] = mask
+    by = np.packbits(padded.reshape(t, w, 8, 8), axis=-1, bitorder="little").reshape(t, w, 8)
+    return np.ascontiguousarray(by).view("<u8").reshape(t, w)
+
+
+class Solver:
+    def __init__(self, min_space_units: int, min_churn_age_ms: int, device: int = 0):
+        self.lib = _lib.load()
+        cfg = MmpConfig(device, 0, int(min_space_units), int(min_churn_age_ms))
+        h = C.c_void_p()
+        rc = self.lib.mmp_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise MmpError(rc, (self.lib.mmp_last_error(None) or b"").decode())
+        self.h = h
+        self.n_pods = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mmp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc: int):
+        if rc != 0:
+            raise MmpError(rc, (self.lib.mmp_last_error(self.h) or b"").decode())
+
+    # ---- snapshot ------------------------------------------------------
+    def load_pods(self, pods: np.ndarray):
+        pods = np.ascontiguousarray(pods, dtype=POD_ROW)
+        self._ck(self.lib.mmp_pods_load(self.h, ptr(pods), len(pods)))
+        self.n_pods = len(pods)
+
+    def upsert_pods(self, idx: np.ndarray, rows: np.ndarray):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        rows = np.ascontiguousarray(rows, dtype=POD_ROW)
+        self._ck(self.lib.mmp_pods_upsert(self.h, ptr(idx), ptr(rows), len(idx)))
+        self.n_pods = max(self.n_pods, int(idx.max()) + 1 if len(idx) else 0)
+
+    def remove_pods(self, idx: np.ndarray):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        self._ck(self.lib.mmp_pods_remove(self.h, ptr(idx), len(idx)))
+
+    def load_types(self, n_types, allowed=None, prefer=None, has_allowed=None, has_prefer=None):
+        def u64(a):
+            return None if a is None else np.ascontiguousarray(a, dtype=np.uint64)
+
+        def u8(a):
+            return None if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+        allowed, prefer, has_allowed, has_prefer = u64(allowed), u64(prefer), u8(has_allowed), u8(has_prefer)
+        self._ck(self.lib.mmp_types_load(self.h, int(n_types), ptr(allowed), ptr(prefer),
+                                         ptr(has_allowed), ptr(has_prefer)))
+
+    def load_replaced_rs(self, rs):
+        rs = np.ascontiguousarray(rs, dtype=np.int32)
+        self._ck(self.lib.mmp_replaced_rs_load(self.h, ptr(rs) if len(rs) else None, len(rs)))
+
+    def load_models(self, models, ent_pod, ent_time):
+        models = np.ascontiguousarray(models, dtype=MODEL_ROW)
+        ent_pod = np.ascontiguousarray(ent_pod, dtype=np.int32)
+        ent_time = np.ascontiguousarray(ent_time, dtype=np.int64)
+        self._ck(self.lib.mmp_models_load(self.h, ptr(models), len(models),
+                                          ptr(ent_pod) if len(ent_pod) else None,
+                                          ptr(ent_time) if len(ent_time) else None, len(ent_pod)))
+        self.n_models = len(models)
+
+    def commit(self):
+        self._ck(self.lib.mmp_snapshot_commit(self.h))
+
+    def load_fleet(self, f: Fleet):
+        self.load_pods(f.pods)
+        self.load_types(f.n_types, f.allowed, f.prefer, f.has_allowed, f.has_prefer)
+        self.load_replaced_rs(f.replaced_rs)
+        self.load_models(f.models, f.ent_pod, f.ent_time)
+        self.commit()
+
+    def order(self) -> np.ndarray:
+        out = np.zeros(max(self.n_pods, 1), dtype=np.int32)
+        n = C.c_int32(0)
+        self._ck(self.lib.mmp_get_order(self.h, ptr(out), C.byref(n)))
+        return out[: n.value].copy()
+
+    def stats(self) -> np.ndarray:
+        out = np.zeros(1, dtype=STATS)
+        self._ck(self.lib.mmp_cluster_stats(self.h, ptr(out)))
+        return out[0]
+
+    # ---- decisions -----------------------------------------------------
+    def place(self, reqs: np.ndarray, extra_pool: Optional[np.ndarray], now: int) -> np.ndarray:
+        reqs = np.ascontiguousarray(reqs, dtype=PLACE_REQ)
+        extra = np.zeros(0, np.int32) if extra_pool is None else np.ascontiguousarray(extra_pool, dtype=np.int32)
+        outs = np.zeros(len(reqs), dtype=PLACE_OUT)
+        self._ck(self.lib.mmp_place_batch(self.h, ptr(reqs), len(reqs), ptr(extra) if len(extra) else None,
+                                          len(extra), int(now), ptr(outs)))
+        return outs
+
+    def place_dev(self, d_reqs: int, n: int, d_extra: int, now: int, d_outs: int, stream: int = 0):
+        """Launch on raw device pointers (torch ``data_ptr()``), no sync."""
+        self._ck(self.lib.mmp_place_batch_dev(self.h, C.c_void_p(d_reqs), int(n), C.c_void_p(d_extra or None),
+                                              int(now), C.c_void_p(d_outs), C.c_void_p(stream or None)))
+
+    def serve(self, reqs, in_use, last_used, excl_pod, excl_time, now) -> np.ndarray:
+        reqs = np.ascontiguousarray(reqs, dtype=SERVE_REQ)
+        in_use = np.ascontiguousarray(in_use, dtype=np.int32)
+        last_used = np.ascontiguousarray(last_used, dtype=np.int64)
+        excl_pod = np.ascontiguousarray(excl_pod, dtype=np.int32)
+        excl_time = np.ascontiguousarray(excl_time, dtype=np.int64)
+        outs = np.zeros(len(reqs), dtype=SERVE_OUT)
+        self._ck(self.lib.mmp_serve_batch(self.h, ptr(reqs), len(reqs), ptr(in_use), ptr(last_used),
+                                          ptr(excl_pod) if len(excl_pod) else None,
+                                          ptr(excl_time) if len(excl_time) else None, len(excl_pod),
+                                          int(now), ptr(outs)))
+        return outs
+
+    def load_caches(self, seg_off, last_used, weight, capacity):
+        seg_off = np.ascontiguousarray(seg_off, dtype=np.int32)
+        last_used = np.ascontiguousarray(last_used, dtype=np.int64)
+        weight = np.ascontiguousarray(weight, dtype=np.int32)
+        capacity = np.ascontiguousarray(capacity, dtype=np.int64)
+        self._ck(self.lib.mmp_caches_load(self.h, len(capacity), ptr(seg_off),
+                                          ptr(last_used) if len(last_used) else None,
+                                          ptr(weight) if len(weight) else None, ptr(capacity)))
+
+    def evict(self, reqs, now) -> np.ndarray:
+        reqs = np.ascontiguousarray(reqs, dtype=EVICT_REQ)
+        outs = np.zeros(len(reqs), dtype=EVICT_OUT)
+        self._ck(self.lib.mmp_evict_batch(self.h, ptr(reqs), len(reqs), int(now), ptr(outs)))
+        return outs
+
+    def sync(self):
+        self._ck(self.lib.mmp_sync(self.h))

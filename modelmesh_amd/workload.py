@@ -1,0 +1,247 @@
+"""Seeded synthetic fleets for the BASELINE.json configs and an
+adversarial fuzz fleet for parity tests.  Pure numpy data generation — no
+placement logic lives here.
+
+Configs: C1 256x8, C2 10k x 1k (Zipf), C3 100k x 10k (log-normal), C4 1M x 50k.
+Seed = 0x4D4D00 + config index; now_ms = 1_760_000_000_000.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ._lib import (JAVA_LONG_MAX, MODEL_ROW, PLACE_REQ, POD_LIVE, POD_ROW, POD_SHUTTING_DOWN,  # noqa: F401
+                   POD_TOMBSTONE)
+from .solver import Fleet, bitmap_from_bool
+
+NOW_MS = 1_760_000_000_000
+DEFAULT_MODEL_UNITS = 6400  # 50 MiB in 8 KiB units
+
+CONFIGS = {
+    "C1": dict(index=1, models=256, pods=8, cap=131072, types=False),
+    "C2": dict(index=2, models=10_000, pods=1_000, cap=8_388_608, types=False),
+    "C3": dict(index=3, models=100_000, pods=10_000, cap=8_388_608, types=True),
+    "C4": dict(index=4, models=1_000_000, pods=50_000, cap=8_388_608, types=True),
+}
+
+
+def min_space_units(default_units: int, threads: int, cap_units: int, unload_mgr: bool = True) -> int:
+    """MM.java:765-771 for config construction only (the library exports the same formula)."""
+    mn = default_units * (1 if (unload_mgr or threads <= 1) else 2)
+    return max(mn, min(default_units * threads, cap_units // 20))
+
+
+def _models(rng, n_models, n_pods, now, n_types, last_used, id_order):
+    k = rng.choice(4, size=n_models, p=[0.3, 0.5, 0.15, 0.05]).astype(np.int32)
+    k = np.minimum(k, n_pods)
+    nf = np.where(rng.random(n_models) < 0.01, rng.integers(1, 3, n_models), 0).astype(np.int32)
+    nf = np.minimum(nf, max(n_pods - 3, 0))
+    tot = k + nf
+    off = np.zeros(n_models + 1, dtype=np.int64)
+    np.cumsum(tot, out=off[1:])
+    n_ent = int(off[-1])
+    # distinct pods per model: a random start + distinct strides keeps ids unique without a loop
+    start = rng.integers(0, n_pods, n_models)
+    step = rng.integers(1, max(n_pods // 4, 2), n_models)
+    for dj in range(1, 5):  # a stride with dj*step == 0 (mod P) would repeat a pod: fall back to 1
+        step = np.where((dj * step) % n_pods == 0, 1, step)
+    seg = np.repeat(np.arange(n_models), tot)
+    j = np.arange(n_ent) - off[seg]
+    ent_pod = ((start[seg] + j * step[seg]) % n_pods).astype(np.int32)
+    # guard against stride collisions for tiny fleets
+    if n_pods < 64:
+        for m in range(n_models):
+            s, e = off[m], off[m + 1]
+            if e - s > 0:
+                ent_pod[s:e] = rng.choice(n_pods, size=e - s, replace=False)
+    # instanceIds / loadFailedInstanceIds iterate in TreeMap (instance id) order
+    for_sort = id_order[ent_pod].astype(np.int64) + (j >= k[seg]) * (1 << 40) + seg.astype(np.int64) * (1 << 42)
+    order = np.argsort(for_sort, kind="stable")
+    ent_pod = ent_pod[order]
+    ent_time = (now - rng.integers(1_000, 86_400_000, n_ent)).astype(np.int64)
+    models = np.zeros(n_models, dtype=MODEL_ROW)
+    models["type"] = rng.choice(n_types, size=n_models, p=_type_p(n_types)) if n_types else 0
+    models["ent_off"] = off[:-1]
+    models["n_loaded"] = k
+    models["n_failed"] = nf
+    models["last_used"] = last_used
+    return models, ent_pod, ent_time
+
+
+def _type_p(n_types):
+    if n_types <= 1:
+        return [1.0]
+    rest = 0.3 / (n_types - 1)
+    return [0.7] + [rest] * (n_types - 1)
+
+
+def make_fleet(name: str, models: int | None = None, pods: int | None = None) -> Fleet:
+    cfg = CONFIGS[name]
+    M = models or cfg["models"]
+    P = pods or cfg["pods"]
+    rng = np.random.Generator(np.random.PCG64(0x4D4D00 + cfg["index"]))
+    now = NOW_MS
+    cap = cfg["cap"]
+    rows = np.zeros(P, dtype=POD_ROW)
+    rows["capacity"] = cap
+    rows["used"] = np.rint(cap * rng.beta(5, 2, P)).astype(np.int64)
+    rows["count"] = rng.poisson(2 * M / P, P)
+    lru = now - rng.lognormal(np.log(3.6e6), 1.5, P).astype(np.int64)
+    rows["lru_time"] = np.where(rows["count"] == 0, JAVA_LONG_MAX, lru)
+    rows["rpm"] = np.minimum(rng.lognormal(np.log(300), 1.2, P), 2_000_000).astype(np.int32)
+    rows["loading_threads"] = 8
+    rows["loading_in_progress"] = rng.binomial(8, 0.1, P)
+    rows["version"] = 1
+    rows["id_order"] = np.arange(P, dtype=np.uint32)  # ids "%06x-%05x" % (rs, i) sort by i
+    rows["replica_set"] = 0
+    rows["flags"] = POD_LIVE
+
+    if name == "C2":  # Zipf(s=1) request rates over model rank
+        rate = 1000.0 / np.arange(1, M + 1)  # req/min
+        last_used = now - (rng.exponential(60_000.0 / rate)).astype(np.int64) - 1
+    else:
+        last_used = now - rng.lognormal(np.log(3.6e6), 2.0, M).astype(np.int64) - 1
+
+    n_types = 0
+    allowed = prefer = has_allowed = has_prefer = None
+    if cfg["types"]:
+        # three label groups; type 0 unconstrained, 1 requires group A, 2 prefers group B,
+        # 3 requires A∪B and prefers C∩(A∪B) = none -> inferred-empty preference stays null
+        n_types = 4
+        group = rng.integers(0, 3, P)
+        al = np.ones((n_types, P), bool)
+        pf = np.zeros((n_types, P), bool)
+        al[1] = group == 0
+        pf[2] = group == 1
+        al[3] = group != 2
+        allowed, prefer = bitmap_from_bool(al), bitmap_from_bool(pf)
+        has_allowed = np.array([0, 1, 0, 1], np.uint8)
+        has_prefer = np.array([0, 0, 1, 0], np.uint8)
+    mrows, ent_pod, ent_time = _models(rng, M, P, now, n_types, last_used, rows["id_order"])
+    return Fleet(pods=rows, models=mrows, ent_pod=ent_pod, ent_time=ent_time,
+                 min_space_units=min_space_units(DEFAULT_MODEL_UNITS, 8, cap),
+                 min_churn_age_ms=600_000, now=now, n_types=n_types, allowed=allowed, prefer=prefer,
+                 has_allowed=has_allowed, has_prefer=has_prefer)
+
+
+def make_requests(fleet: Fleet, seed: int, n: int | None = None, *, favour_frac=0.05, extra_frac=0.05,
+                  drift_frac=0.25):
+    """One load-target decision per model: self = m mod P, lastUsedTime from the model row."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    M, P = fleet.n_models, fleet.n_pods
+    n = n or M
+    reqs = np.zeros(n, dtype=PLACE_REQ)
+    m = np.arange(n) % M
+    reqs["model"] = m
+    self_pod = (np.arange(n) % P).astype(np.int32)
+    reqs["self_pod"] = self_pod
+    reqs["flags"] = (rng.random(n) < favour_frac).astype(np.uint32)
+    reqs["pick"] = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    lu = fleet.models["last_used"][m].copy()
+    kind = rng.random(n)
+    lu = np.where(kind < 0.30, 0, lu)                       # inference-triggered: lastUsedTime 0 (MM.java:3484)
+    lu = np.where(kind > 0.97, fleet.now + 20_000, lu)      # rpm scale-up stamps now+20s (MM.java:5675)
+    reqs["last_used"] = lu
+    # the caller's getFreshInstanceRecord(): its snapshot row, rpm never set (0), sometimes drifted
+    sp = fleet.pods[self_pod]
+    drift = rng.random(n) < drift_frac
+    reqs["fresh_lru"] = sp["lru_time"]
+    reqs["fresh_capacity"] = sp["capacity"]
+    reqs["fresh_used"] = sp["used"] + np.where(drift, rng.integers(0, 200_000, n), 0)
+    reqs["fresh_count"] = sp["count"] + np.where(drift, rng.integers(0, 3, n), 0)
+    reqs["fresh_rpm"] = 0
+    ne = np.where(rng.random(n) < extra_frac, rng.integers(1, 4, n), 0).astype(np.int32)
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(ne, out=off[1:])
+    reqs["extra_off"] = off[:-1]
+    reqs["n_extra"] = ne
+    extra = rng.integers(0, P, int(off[-1])).astype(np.int32)
+    return reqs, extra
+
+
+# --------------------------------------------------------------------------
+def fuzz_fleet(seed: int, pods: int = 200, models: int = 300) -> Fleet:
+    """Adversarial small fleet: ties everywhere, full pods, Long.MAX lru, dead /
+    shutting-down / tombstoned pods, several versions, type masks, preferences,
+    replaced replica sets.  Hits every branch of getNext with a few hundred requests."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    now = NOW_MS
+    P, M = pods, models
+    cap = int(rng.choice([131072, 1_000_000]))
+    msu = int(rng.choice([6553, 51200, 2560]))
+    rows = np.zeros(P, dtype=POD_ROW)
+    rows["capacity"] = np.where(rng.random(P) < 0.8, cap, cap // 2)
+    fullish = rng.random(P) < rng.choice([0.05, 0.5, 0.95])
+    used_frac = np.where(fullish, rng.uniform(0.97, 1.05, P), rng.choice([0.1, 0.5, 0.9], P))
+    rows["used"] = (rows["capacity"] * used_frac).astype(np.int64)
+    rows["count"] = rng.choice([0, 1, 2, 9, 10, 11, 12, 13, 40], P)
+    base_lru = now - rng.choice([1_000, 30_000, 44_000, 46_000, 119_000, 121_000, 600_000, 3_600_000,
+                                 86_400_000], P) - rng.integers(0, 3, P)
+    rows["lru_time"] = np.where(rows["count"] == 0, JAVA_LONG_MAX, base_lru)
+    rows["rpm"] = rng.choice([0, 50, 99, 100, 101, 150, 151, 300, 1000, 5000], P)
+    rows["loading_threads"] = rng.choice([1, 8], P)
+    rows["loading_in_progress"] = rng.integers(0, 3, P)
+    multi_version = rng.random() < 0.5
+    rows["version"] = rng.choice([1, 2, 3], P) if multi_version else 7
+    perm = rng.permutation(P)
+    rows["id_order"] = perm.astype(np.uint32)
+    n_rs = int(rng.integers(1, 4))
+    rows["replica_set"] = rng.integers(0, n_rs, P)
+    rows["replica_set"] = np.where(rng.random(P) < 0.05, -1, rows["replica_set"])
+    flags = np.full(P, POD_LIVE, dtype=np.uint32)
+    flags = np.where(rng.random(P) < 0.05, flags & ~np.uint32(POD_LIVE), flags)
+    flags = np.where(rng.random(P) < 0.04, flags | POD_SHUTTING_DOWN, flags)
+    flags = np.where(rng.random(P) < 0.03, (flags | POD_TOMBSTONE) & ~np.uint32(POD_LIVE), flags)
+    rows["flags"] = flags
+    replaced = np.zeros(0, np.int32)
+    r = rng.random()
+    if r < 0.3:
+        replaced = np.array([0], np.int32)
+    elif r < 0.4:
+        replaced = np.arange(n_rs, dtype=np.int32)  # everything replaced -> retry path
+
+    n_types = int(rng.choice([0, 1, 3, 5]))
+    allowed = prefer = has_allowed = has_prefer = None
+    if n_types:
+        al = rng.random((n_types, P)) < rng.choice([0.1, 0.6, 1.0], (n_types, 1))
+        pf = rng.random((n_types, P)) < rng.choice([0.0, 0.05, 0.5], (n_types, 1))
+        has_allowed = (rng.random(n_types) < 0.6).astype(np.uint8)
+        has_prefer = (rng.random(n_types) < 0.7).astype(np.uint8)
+        allowed, prefer = bitmap_from_bool(al), bitmap_from_bool(pf)
+    last_used = now - rng.choice([0, 500, 4_000, 6_000, 700_000, 800_000, 80_000_000, 90_000_000,
+                                  431_000_000, 433_000_000], M) - 1
+    mrows, ent_pod, ent_time = _models(rng, M, P, now, n_types, last_used, rows["id_order"])
+    return Fleet(pods=rows, models=mrows, ent_pod=ent_pod, ent_time=ent_time, min_space_units=msu,
+                 min_churn_age_ms=int(rng.choice([30_000, 600_000])), now=now, n_types=n_types,
+                 allowed=allowed, prefer=prefer, has_allowed=has_allowed, has_prefer=has_prefer,
+                 replaced_rs=replaced)
+
+
+def fuzz_requests(fleet: Fleet, seed: int, n: int):
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0x5EED))
+    M, P = fleet.n_models, fleet.n_pods
+    reqs = np.zeros(n, dtype=PLACE_REQ)
+    reqs["model"] = rng.integers(0, M, n)
+    sp = rng.integers(0, P, n).astype(np.int32)
+    reqs["self_pod"] = np.where(rng.random(n) < 0.05, -1, sp)
+    reqs["flags"] = (rng.random(n) < 0.4).astype(np.uint32)
+    reqs["pick"] = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    lu = fleet.models["last_used"][reqs["model"]].copy()
+    kind = rng.random(n)
+    lu = np.where(kind < 0.2, 0, lu)
+    lu = np.where(kind > 0.85, fleet.now + 20_000, lu)
+    reqs["last_used"] = lu
+    row = fleet.pods[sp]
+    stale = rng.random(n) < 0.5
+    reqs["fresh_lru"] = np.where(stale, row["lru_time"],
+                                 fleet.now - rng.choice([10_000, 50_000, 130_000, 4_000_000], n))
+    reqs["fresh_capacity"] = row["capacity"]
+    reqs["fresh_used"] = np.where(stale, row["used"], (row["capacity"] * rng.choice([0.2, 0.8, 0.99], n)).astype(np.int64))
+    reqs["fresh_count"] = row["count"] + rng.integers(0, 2, n)
+    reqs["fresh_rpm"] = rng.choice([0, 0, 0, 120, 400], n)
+    ne = np.where(rng.random(n) < 0.3, rng.integers(1, 6, n), 0).astype(np.int32)
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(ne, out=off[1:])
+    reqs["extra_off"] = off[:-1]
+    reqs["n_extra"] = ne
+    extra = rng.integers(0, P, int(off[-1])).astype(np.int32)
+    return reqs, extra

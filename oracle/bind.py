@@ -1,0 +1,176 @@
+"""ctypes binding of oracle/liboracle.so — the CPU parity checker.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, never by the modelmesh_amd package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "liboracle.so")
+
+ORC_POD = np.dtype(
+    [("lru_time", "<i8"), ("capacity", "<i8"), ("used", "<i8"), ("start_time", "<i8"), ("version", "<i8"),
+     ("count", "<i4"), ("loading_threads", "<i4"), ("loading_in_progress", "<i4"), ("rpm", "<i4"),
+     ("shutting_down", "<i4"), ("id_order", "<u4"), ("replica_set", "<i4"), ("pad_", "<i4")])
+assert ORC_POD.itemsize == 72
+ORC_STATS = np.dtype([("total_capacity", "<i8"), ("total_free", "<i8"), ("global_lru", "<i8"),
+                      ("instance_count", "<i4"), ("model_copy_count", "<i4")])
+ORC_NODE = np.dtype([("last_used", "<i8"), ("weight", "<i4"), ("key", "<i4")])
+
+
+class OrcSnapshot(C.Structure):
+    _fields_ = [("pods", C.c_void_p), ("n_pods", C.c_int32), ("order", C.c_void_p),
+                ("min_space_units", C.c_int64), ("min_churn_age_ms", C.c_int64), ("n_types", C.c_int32),
+                ("allowed", C.POINTER(C.c_void_p)), ("prefer", C.POINTER(C.c_void_p)), ("live", C.c_void_p),
+                ("replaced_rs", C.c_void_p), ("n_replaced_rs", C.c_int32), ("n_rows", C.c_int32)]
+
+
+class OrcServeReq(C.Structure):
+    _fields_ = [("self", C.c_int32), ("exclude_self", C.c_int32), ("prefer_self", C.c_int32),
+                ("n_copies", C.c_int32), ("copy_pod", C.c_void_p), ("copy_loaded", C.c_void_p),
+                ("now", C.c_int64), ("assume_completed_ms", C.c_int64), ("local_in_flight", C.c_int32),
+                ("pad_", C.c_int32), ("last_invoke_time", C.c_int64)]
+
+
+class OrcCache(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("n", C.c_int32), ("cap_nodes", C.c_int32),
+                ("weighted_size", C.c_int64), ("capacity", C.c_int64)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE])
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        lib = C.CDLL(LIB)
+        lib.orc_min_space_units.restype = C.c_int64
+        lib.orc_min_space_units.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.c_int]
+        lib.orc_sort_pods.restype = C.c_int
+        lib.orc_sort_pods.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]
+        lib.orc_place_batch.restype = C.c_int
+        lib.orc_place_batch.argtypes = [C.POINTER(OrcSnapshot), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
+        lib.orc_serve.restype = C.c_int32
+        lib.orc_serve.argtypes = [C.POINTER(OrcServeReq), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        lib.orc_cluster_stats_of.restype = None
+        lib.orc_cluster_stats_of.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
+        lib.orc_cache_init.argtypes = [C.POINTER(OrcCache), C.c_int64]
+        lib.orc_cache_free.argtypes = [C.POINTER(OrcCache)]
+        lib.orc_cache_put_if_absent.restype = C.c_int32
+        lib.orc_cache_put_if_absent.argtypes = [C.POINTER(OrcCache), C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                                                C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        lib.orc_cache_get.restype = C.c_int
+        lib.orc_cache_get.argtypes = [C.POINTER(OrcCache), C.c_int32, C.c_int64, C.c_int64]
+        lib.orc_cache_update_weight.restype = C.c_int32
+        lib.orc_cache_update_weight.argtypes = [C.POINTER(OrcCache), C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                                                C.c_void_p, C.c_int32]
+        lib.orc_cache_remove.restype = C.c_int
+        lib.orc_cache_remove.argtypes = [C.POINTER(OrcCache), C.c_int32]
+        lib.orc_cache_oldest_time.restype = C.c_int64
+        lib.orc_cache_oldest_time.argtypes = [C.POINTER(OrcCache)]
+        _lib = lib
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def to_orc_pods(pods: np.ndarray) -> np.ndarray:
+    """mmp pod rows -> oracle rows. Tombstones are expressed as shutting-down
+    (both mean "not in clusterState", MM.java:1462-1464)."""
+    o = np.zeros(len(pods), dtype=ORC_POD)
+    for f in ("lru_time", "capacity", "used", "version", "count", "loading_threads", "loading_in_progress",
+              "rpm", "id_order", "replica_set"):
+        o[f] = pods[f]
+    o["shutting_down"] = (pods["flags"] & 5) != 0
+    return o
+
+
+def unpack_bitmap(bm: np.ndarray, n_pods: int) -> np.ndarray:
+    """uint64 [T][W] -> uint8 [T][P]"""
+    by = np.ascontiguousarray(bm).view(np.uint8).reshape(bm.shape[0], -1)
+    bits = np.unpackbits(by, axis=1, bitorder="little")
+    return np.ascontiguousarray(bits[:, :n_pods])
+
+
+class OracleFleet:
+    """The oracle's view of a modelmesh_amd.solver.Fleet (duck-typed)."""
+
+    def __init__(self, fleet):
+        self.lib = load()
+        self.fleet = fleet
+        P = fleet.n_pods
+        self.pods = to_orc_pods(fleet.pods)
+        present = self.pods["shutting_down"] == 0
+        # clusterState only holds present rows; sort those with the literal comparator
+        self.present_idx = np.nonzero(present)[0].astype(np.int32)
+        sub = np.ascontiguousarray(self.pods[self.present_idx])
+        order = np.zeros(max(len(sub), 1), dtype=np.int32)
+        self.order_rc = self.lib.orc_sort_pods(_p(sub), len(sub), fleet.min_space_units,
+                                               fleet.min_churn_age_ms, _p(order))
+        self.order = self.present_idx[order[: len(sub)]].astype(np.int32)
+        # orc_place walks `order` over the FULL pods array; absent rows simply are not in it.
+        # It needs n_pods == len(order) for iteration, but indexes pods[] by pod index.
+        self.live = np.ascontiguousarray(((fleet.pods["flags"] & 2) != 0).astype(np.uint8))
+        T = fleet.n_types
+        self._keep = []
+        self.allowed_rows = self.prefer_rows = None
+        if T > 0:
+            al = unpack_bitmap(fleet.allowed, P) if fleet.allowed is not None else np.zeros((T, P), np.uint8)
+            pf = unpack_bitmap(fleet.prefer, P) if fleet.prefer is not None else np.zeros((T, P), np.uint8)
+            self._keep += [al, pf]
+            self.allowed_rows = (C.c_void_p * T)()
+            self.prefer_rows = (C.c_void_p * T)()
+            for t in range(T):
+                ha = fleet.has_allowed is not None and fleet.has_allowed[t]
+                hp = fleet.has_prefer is not None and fleet.has_prefer[t]
+                self.allowed_rows[t] = al[t].ctypes.data if ha else None
+                self.prefer_rows[t] = pf[t].ctypes.data if hp else None
+        self.rs = np.ascontiguousarray(fleet.replaced_rs, dtype=np.int32)
+        s = OrcSnapshot()
+        s.pods = self.pods.ctypes.data
+        s.n_pods = len(self.order)
+        s.order = self.order.ctypes.data
+        s.min_space_units = fleet.min_space_units
+        s.min_churn_age_ms = fleet.min_churn_age_ms
+        s.n_types = T
+        s.allowed = C.cast(self.allowed_rows, C.POINTER(C.c_void_p)) if T > 0 else None
+        s.prefer = C.cast(self.prefer_rows, C.POINTER(C.c_void_p)) if T > 0 else None
+        s.live = self.live.ctypes.data
+        s.replaced_rs = self.rs.ctypes.data if len(self.rs) else None
+        s.n_replaced_rs = len(self.rs)
+        s.n_rows = P
+        self.snap = s
+
+    def place(self, reqs: np.ndarray, extra: np.ndarray, now: int, threads: int = 1, latencies: bool = False):
+        from modelmesh_amd._lib import PLACE_OUT  # dtype only
+        reqs = np.ascontiguousarray(reqs)
+        extra = np.ascontiguousarray(extra if extra is not None and len(extra) else np.zeros(1, np.int32),
+                                     dtype=np.int32)
+        outs = np.zeros(len(reqs), dtype=PLACE_OUT)
+        lat = np.zeros(len(reqs), dtype=np.float64) if latencies else None
+        models = np.ascontiguousarray(self.fleet.models)
+        ent = np.ascontiguousarray(self.fleet.ent_pod if len(self.fleet.ent_pod) else np.zeros(1, np.int32),
+                                   dtype=np.int32)
+        self.lib.orc_place_batch(C.byref(self.snap), _p(models), _p(ent), _p(reqs), _p(extra), len(reqs),
+                                 int(now), _p(outs), int(threads), _p(lat) if latencies else None)
+        return (outs, lat) if latencies else outs
+
+    def stats(self):
+        out = np.zeros(1, dtype=ORC_STATS)
+        self.lib.orc_cluster_stats_of(_p(self.pods), len(self.pods), self.fleet.min_space_units, _p(out))
+        return out[0]

@@ -1,0 +1,208 @@
+/*
+ * mm_oracle.h — CPU restatement of ModelMesh's placement / eviction hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the parity checker for the HIP library in
+ * modelmesh_amd/csrc; it is never linked into, called from or shipped with the
+ * product path.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may use it.
+ *
+ * Every function cites the reference file:line it follows.  "MM.java" is
+ * src/main/java/com/ibm/watson/modelmesh/ModelMesh.java in kserve/modelmesh.
+ *
+ * Pinning status:
+ *   - eviction / capacity arithmetic: pinned against the reference's own
+ *     known-answer tests (EvictionsModelMeshTest.java:36-125,
+ *     ModelMeshEvictionsTest.java:156-280) — see tests/test_oracle_kat.py.
+ *   - PLACEMENT_ORDER, load-target shortlist, rpm filter, serve-target choice:
+ *     PARITY UNPINNED — the reference has no test that names them and the
+ *     reference (Java 21 + un-vendored kv-utils/litelinks + etcd) cannot be
+ *     built or run here.  Pinned only by a second, independently written
+ *     restatement (oracle/py_oracle.py) that must agree on random snapshots.
+ *
+ * All arithmetic is Java semantics: int64/int32 two's-complement wrap, '/'
+ * truncating toward zero, '>>' arithmetic.
+ */
+#ifndef MM_ORACLE_H
+#define MM_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_NONE (-1) /* getNext returned null                     */
+#define ORC_SELF (-2) /* getNext returned LoadBalancer.ABORT_REQUEST */
+
+/* InstanceRecord.java:37-69 — one pod row.  Strings are interned by the
+ * caller: id_order is the dense rank of the instance id under
+ * String.compareTo (UTF-16 code-unit order), replica_set is the interned
+ * id.substring(0,6) or -1 when id.length() < 7 (MM.java:4769-4770). */
+typedef struct {
+    int64_t lru_time; /* Long.MAX_VALUE when empty */
+    int64_t capacity;
+    int64_t used;
+    int64_t start_time;
+    int64_t version;
+    int32_t count;
+    int32_t loading_threads;
+    int32_t loading_in_progress;
+    int32_t rpm;
+    int32_t shutting_down;
+    uint32_t id_order;
+    int32_t replica_set;
+    int32_t pad_;
+} orc_pod;
+
+/* A view of everything CacheMissForwardingLB.getNext reads that is not
+ * per-request: clusterState (MM.java:332,774), typeConstraints
+ * (TypeConstraintManager.java:242-251), the litelinks live-instance map
+ * (MM.java:4778) and UpgradeTracker's replaced replica sets (MM.java:4792). */
+typedef struct {
+    const orc_pod *pods;  /* n_rows rows, indexed by pod index                     */
+    int32_t n_pods;       /* rows in clusterState = entries of order[]             */
+    const int32_t *order; /* pod indices in clusterState iteration order           */
+    int64_t min_space_units;
+    int64_t min_churn_age_ms;
+    int32_t n_types;
+    /* per type: byte-per-pod membership; a NULL row means "null set"
+     * (no constraint / no preference) exactly as in the Java. */
+    const uint8_t *const *allowed;
+    const uint8_t *const *prefer;
+    const uint8_t *live; /* siMap.containsKey(iid) */
+    const int32_t *replaced_rs;
+    int32_t n_replaced_rs;
+    int32_t n_rows;       /* size of pods[] (>= n_pods: absent rows keep their index) */
+} orc_snapshot;
+
+typedef struct {
+    int32_t type;          /* exclude.modelType                              */
+    int32_t self;          /* index of instanceId in pods[], -1 if absent    */
+    int32_t favour_self;   /* exclude.favourSelf                             */
+    uint32_t pick;         /* replaces ThreadLocalRandom: idx=(pick*n)>>32   */
+    int64_t last_used;     /* exclude.lastUsedTime                           */
+    int64_t now;           /* replaces currentTimeMillis()                   */
+    const int32_t *loaded; /* mr.getInstanceIds().keySet()                   */
+    int32_t n_loaded;
+    const int32_t *failed; /* mr.getLoadFailedInstanceIds().keySet()         */
+    int32_t n_failed;
+    const int32_t *extra;  /* the HashSet itself ∪ explicit                  */
+    int32_t n_extra;
+    orc_pod fresh;         /* getFreshInstanceRecord() of the caller         */
+} orc_place_req;
+
+typedef struct {
+    int32_t chosen;       /* pod index | ORC_NONE | ORC_SELF */
+    int32_t best;         /* final bestIid's pod index, -1 if none           */
+    int32_t n_candidates; /* candidates.size(); 0 on early returns           */
+    int32_t n_remaining;  /* after the rpm filter                            */
+    uint32_t hash;        /* shortlist hash, see orc_shortlist_hash          */
+} orc_place_out;
+
+/* MM.java:765-771 */
+int64_t orc_min_space_units(int32_t default_model_size_units, int32_t loading_threads,
+                            int64_t cap_units, int have_unload_manager);
+/* InstanceRecord.java:203-205 */
+int64_t orc_remaining(const orc_pod *p);
+/* MM.java:4640-4642 */
+int orc_is_full(int64_t avail, int64_t min_space_units);
+/* MM.java:4646-4703 (ids unique ⇒ location/zone/labels never reached) */
+int orc_placement_compare(const orc_pod *a, const orc_pod *b, int64_t min_space_units,
+                          int64_t min_churn_age_ms);
+/* Sorted iteration order of the ConcurrentSkipListSet (MM.java:774).
+ * Returns 0, or -1 if the comparator is not a consistent total order on
+ * these rows (SURVEY.md §7 "Transitivity"). */
+int orc_sort_pods(const orc_pod *pods, int32_t n, int64_t min_space_units,
+                  int64_t min_churn_age_ms, int32_t *order_out);
+
+/* MM.java:4776-5005.  cand_out (optional, capacity n_pods) receives the
+ * shortlist before the rpm filter. */
+int orc_place(const orc_snapshot *s, const orc_place_req *r, orc_place_out *o, int32_t *cand_out);
+
+/* Commutative hash of the shortlist as a bitmap over clusterState positions. */
+uint32_t orc_shortlist_hash(const int32_t *pos_of, const int32_t *cand, int32_t n,
+                            int32_t n_remaining, int32_t n_pods);
+
+/* ---------- serve-target selection, MM.java:4315-4392 ------------------- */
+typedef struct {
+    int32_t self;
+    int32_t exclude_self; /* filtered.excludeSelf */
+    int32_t prefer_self;  /* filtered.preferSelf  */
+    int32_t n_copies;
+    const int32_t *copy_pod;    /* filteredInstances keys, in TreeMap (id) order */
+    const int64_t *copy_loaded; /* values: load start time                       */
+    int64_t now;
+    int64_t assume_completed_ms; /* loadingTimeStats(type).assumeCompletedAfterMillis() */
+    int32_t local_in_flight;     /* localInvokesInFlight.get() */
+    int32_t pad_;
+    int64_t last_invoke_time;    /* lastInvokeTime             */
+} orc_serve_req;
+
+/* live: siMap membership; in_use/last_used: ServiceInstance.getInUseCount /
+ * getLastUsedTime per pod (MM.java:4356,4360). */
+int32_t orc_serve(const orc_serve_req *r, const uint8_t *live, const int32_t *in_use,
+                  const int64_t *last_used, int64_t *chosen_ts);
+
+/* ---------- cluster stats, InstanceSetStatsTracker.java:53-92 ------------ */
+typedef struct {
+    int64_t total_capacity, total_free, global_lru;
+    int32_t instance_count, model_copy_count;
+} orc_cluster_stats;
+void orc_cluster_stats_of(const orc_pod *pods, int32_t n, int64_t min_space_units,
+                          orc_cluster_stats *out);
+
+/* ---------- batch driver over flat tables (mm_oracle_batch.c) ------------ */
+typedef struct {
+    int32_t type, ent_off, n_loaded, n_failed;
+    int64_t last_used;
+} orc_flat_model;
+typedef struct {
+    int32_t model, self_pod;
+    uint32_t flags, pick;
+    int64_t last_used;
+    int32_t extra_off, n_extra;
+    int64_t fresh_lru, fresh_capacity, fresh_used;
+    int32_t fresh_count, fresh_rpm;
+} orc_flat_req;
+typedef struct {
+    int32_t chosen, best, n_candidates;
+    uint32_t hash;
+} orc_flat_out;
+/* n decisions split over n_threads pthreads; lat_ns (optional) gets the wall
+ * time of every single orc_place call. */
+int orc_place_batch(const orc_snapshot *snap, const orc_flat_model *models, const int32_t *ent_pod,
+                    const orc_flat_req *reqs, const int32_t *extra, int32_t n, int64_t now,
+                    orc_flat_out *outs, int32_t n_threads, double *lat_ns);
+
+/* ---------- local LRU cache + eviction (clhm) --------------------------- */
+typedef struct {
+    int64_t last_used;
+    int32_t weight;
+    int32_t key;
+} orc_node;
+
+/* nodes[] is the evictionDeque, oldest (head) first. */
+typedef struct {
+    orc_node *nodes;
+    int32_t n, cap_nodes;
+    int64_t weighted_size;
+    int64_t capacity;
+} orc_cache;
+
+void orc_cache_init(orc_cache *c, int64_t capacity);
+void orc_cache_free(orc_cache *c);
+int32_t orc_cache_find(const orc_cache *c, int32_t key);
+int32_t orc_cache_put_if_absent(orc_cache *c, int32_t key, int32_t weight, int64_t last_used,
+                                int64_t now, int32_t *victims, int32_t max_victims,
+                                int32_t *insert_pos);
+int orc_cache_get(orc_cache *c, int32_t key, int64_t last_used, int64_t now);
+int32_t orc_cache_update_weight(orc_cache *c, int32_t key, int32_t new_weight, int64_t new_time,
+                                int64_t now, int32_t *victims, int32_t max_victims);
+int orc_cache_remove(orc_cache *c, int32_t key);
+int64_t orc_cache_oldest_time(const orc_cache *c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

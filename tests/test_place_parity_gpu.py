@@ -1,0 +1,121 @@
+"""GPU parity: HIP load-target selection vs the CPU oracle, bit-exact.
+
+Every comparison goes through the C ABI (modelmesh_amd.solver -> libmmplace).
+Reference semantics: CacheMissForwardingLB.getNext, MM.java:4776-5005, and
+PLACEMENT_ORDER, MM.java:4646-4703.
+"""
+import numpy as np
+import pytest
+
+from modelmesh_amd import workload as wl
+from modelmesh_amd.solver import Solver
+from oracle.bind import OracleFleet
+from tests.util import assert_same_decisions
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_fleet(fleet, reqs, extra):
+    orc = OracleFleet(fleet)
+    assert orc.order_rc == 0
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        # clusterState order, MM.java:774 / getCacheState dump MM.java:5552
+        got_order = s.order()
+        assert np.array_equal(got_order, orc.order), (got_order[:20], orc.order[:20])
+        st, ost = s.stats(), orc.stats()
+        for f in ("total_capacity", "total_free", "global_lru", "instance_count", "model_copy_count"):
+            assert int(st[f]) == int(ost[f]), (f, st, ost)
+        got = s.place(reqs, extra, fleet.now)
+        want = orc.place(reqs, extra, fleet.now, threads=8)
+        assert_same_decisions(fleet, reqs, got, want)
+        return got
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_fleets(seed):
+    fleet = wl.fuzz_fleet(seed, pods=int(np.random.default_rng(seed).choice([1, 7, 63, 64, 65, 200, 700])))
+    reqs, extra = wl.fuzz_requests(fleet, seed, 3000)
+    _check_fleet(fleet, reqs, extra)
+
+
+def test_c1_256x8():
+    fleet = wl.make_fleet("C1")
+    reqs, extra = wl.make_requests(fleet, 11)
+    _check_fleet(fleet, reqs, extra)
+
+
+def test_c2_10k_x_1k():
+    fleet = wl.make_fleet("C2")
+    reqs, extra = wl.make_requests(fleet, 12)
+    _check_fleet(fleet, reqs, extra)
+
+
+def test_c3_100k_x_10k_full_size():
+    fleet = wl.make_fleet("C3")
+    reqs, extra = wl.make_requests(fleet, 13)
+    got = _check_fleet(fleet, reqs, extra)
+    # size-independent properties: a chosen pod is never one the model excludes, and is live
+    ch = got["chosen"]
+    ok = ch >= 0
+    m = fleet.models[reqs["model"][ok]]
+    for j in range(5):
+        has = (m["n_loaded"] + m["n_failed"]) > j
+        ent = fleet.ent_pod[np.minimum(m["ent_off"] + j, len(fleet.ent_pod) - 1)]
+        assert not np.any(has & (ent == ch[ok]))
+
+
+def test_empty_and_degenerate():
+    fleet = wl.make_fleet("C1")
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        assert len(s.place(np.zeros(0, dtype=wl.PLACE_REQ), None, fleet.now)) == 0
+        # every pod excluded -> null (MM.java:4795-4804)
+        reqs, _ = wl.make_requests(fleet, 5, n=4)
+        reqs["n_extra"] = fleet.n_pods
+        reqs["extra_off"] = 0
+        out = s.place(reqs, np.arange(fleet.n_pods, dtype=np.int32), fleet.now)
+        assert np.all(out["chosen"] == -1) and np.all(out["best"] == -1) and np.all(out["n_candidates"] == 0)
+    finally:
+        s.close()
+    # an empty instance table
+    s = Solver(100, 1000)
+    try:
+        s.load_pods(np.zeros(0, dtype=wl.POD_ROW))
+        s.load_models(fleet.models[:1], fleet.ent_pod[:0], fleet.ent_time[:0])
+        with pytest.raises(Exception):
+            s.load_models(fleet.models[:10], fleet.ent_pod[:0], fleet.ent_time[:0])  # entry range check
+        m = np.zeros(1, dtype=wl.MODEL_ROW)
+        s.load_models(m, np.zeros(0, np.int32), np.zeros(0, np.int64))
+        s.commit()
+        r = np.zeros(3, dtype=wl.PLACE_REQ)
+        r["self_pod"] = -1
+        out = s.place(r, None, 1)
+        assert np.all(out["chosen"] == -1)
+    finally:
+        s.close()
+
+
+def test_order_inconsistent_rows_are_rejected():
+    """PLACEMENT_ORDER's version clause compares lruTime with a duration (quirk B#1):
+    a full pod with a tiny lruTime next to another version breaks transitivity."""
+    fleet = wl.fuzz_fleet(1, pods=64)
+    pods = fleet.pods.copy()
+    pods["flags"] = wl.POD_LIVE
+    pods["version"] = np.arange(64) % 3
+    pods["used"] = pods["capacity"]  # all full
+    pods["lru_time"] = np.arange(64) % 7 + 1  # <= 2*minChurnAgeMs
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_pods(pods)
+        s.load_models(fleet.models, fleet.ent_pod, fleet.ent_time)
+        from modelmesh_amd.solver import MmpError
+        with pytest.raises(MmpError) as ei:
+            s.commit()
+        assert ei.value.code == -4
+    finally:
+        s.close()
