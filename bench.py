@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-only", action="store_true",
+                    help="skip the n=1 latency / host-boundary legs (used under rocprofv3 so that every "
+                         "place_batch_kernel dispatch in the trace is a full batch)")
     args = ap.parse_args()
 
     import torch
@@ -171,21 +174,22 @@ def main():
         # single-decision latency through the host-pointer C ABI (n=1, PCIe + launch inclusive)
         lat = []
         one = reqs[:1].copy()
-        for i in range(300):
+        for i in range(0 if args.kernel_only else 300):
             one[0] = reqs[i % n]
             one["extra_off"] = 0
             one["n_extra"] = 0
             t1 = time.perf_counter()
             solver.place(one, None, fleet.now)
             lat.append(time.perf_counter() - t1)
-        lat = np.array(lat[50:]) * 1e6
-        line["p50_decision_latency_us"] = float(np.percentile(lat, 50))
-        line["p99_decision_latency_us"] = float(np.percentile(lat, 99))
-        t1 = time.perf_counter()
-        for _ in range(5):
-            solver.place(reqs, extra, fleet.now)
-        line["host_boundary_decisions_per_s"] = 5 * n / (time.perf_counter() - t1)
-        if world == 1 and not args.no_cpu_baseline:
+        if lat:
+            lat = np.array(lat[50:]) * 1e6
+            line["p50_decision_latency_us"] = float(np.percentile(lat, 50))
+            line["p99_decision_latency_us"] = float(np.percentile(lat, 99))
+            t1 = time.perf_counter()
+            for _ in range(5):
+                solver.place(reqs, extra, fleet.now)
+            line["host_boundary_decisions_per_s"] = 5 * n / (time.perf_counter() - t1)
+        if world == 1 and not args.no_cpu_baseline and not args.kernel_only:
             line["cpu_baseline"] = cpu_baseline(fleet, reqs, extra)
         print(json.dumps(line), flush=True)
 

@@ -81,8 +81,46 @@ def load() -> C.CDLL:
         lib.orc_cache_remove.argtypes = [C.POINTER(OrcCache), C.c_int32]
         lib.orc_cache_oldest_time.restype = C.c_int64
         lib.orc_cache_oldest_time.argtypes = [C.POINTER(OrcCache)]
+        lib.orc_evict_eval.restype = None
+        lib.orc_evict_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int64, C.c_int64,
+                                       C.c_void_p]
         _lib = lib
     return _lib
+
+
+ORC_EVICT_RESULT = np.dtype([("insert_pos", "<i4"), ("n_victims", "<i4"), ("self_evicted", "<i4"), ("pad_", "<i4"),
+                             ("weighted_size", "<i8"), ("oldest_time", "<i8")])
+
+
+def evict_eval(lu, wt, capacity, weight, last_used, now):
+    lib = load()
+    lu = np.ascontiguousarray(lu, dtype=np.int64)
+    wt = np.ascontiguousarray(wt, dtype=np.int32)
+    out = np.zeros(1, dtype=ORC_EVICT_RESULT)
+    lib.orc_evict_eval(_p(lu) if len(lu) else None, _p(wt) if len(wt) else None, len(lu), int(capacity),
+                       int(weight), int(last_used), int(now), _p(out))
+    return out[0]
+
+
+def serve(self_pod, exclude_self, prefer_self, copy_pod, copy_loaded, now, assume_completed_ms, local_in_flight,
+          last_invoke_time, live, in_use, last_used):
+    lib = load()
+    copy_pod = np.ascontiguousarray(copy_pod, dtype=np.int32)
+    copy_loaded = np.ascontiguousarray(copy_loaded, dtype=np.int64)
+    r = OrcServeReq()
+    r.self = int(self_pod)
+    r.exclude_self = int(bool(exclude_self))
+    r.prefer_self = int(bool(prefer_self))
+    r.n_copies = len(copy_pod)
+    r.copy_pod = copy_pod.ctypes.data if len(copy_pod) else None
+    r.copy_loaded = copy_loaded.ctypes.data if len(copy_loaded) else None
+    r.now = int(now)
+    r.assume_completed_ms = int(assume_completed_ms)
+    r.local_in_flight = int(local_in_flight)
+    r.last_invoke_time = int(last_invoke_time)
+    ts = C.c_int64(0)
+    ch = lib.orc_serve(C.byref(r), _p(live), _p(in_use), _p(last_used), C.byref(ts))
+    return ch, ts.value
 
 
 def _p(a):

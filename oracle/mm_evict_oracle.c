@@ -166,3 +166,34 @@ int orc_cache_remove(orc_cache *c, int32_t key)
 
 /* oldestTime(), clhm :1125-1133 */
 int64_t orc_cache_oldest_time(const orc_cache *c) { return c->n ? c->nodes[0].last_used : -1; }
+
+/* Convenience for the parity tests: rebuild a cache whose deque is exactly
+ * (lu[i], wt[i]) oldest-first, then run one putIfAbsent of a new key. */
+void orc_evict_eval(const int64_t *lu, const int32_t *wt, int32_t n, int64_t capacity, int32_t weight,
+                    int64_t last_used, int64_t now, orc_evict_result *out)
+{
+    orc_cache c;
+    orc_cache_init(&c, INT64_MAX);
+    for (int32_t i = 0; i < n; i++) {
+        /* append in deque order: equal timestamps keep FIFO order (LinkedDeque.java:267) */
+        reserve(&c, c.n + 1);
+        c.nodes[c.n].key = i;
+        c.nodes[c.n].weight = wt[i];
+        c.nodes[c.n].last_used = lu[i];
+        c.n++;
+        c.weighted_size += wt[i];
+    }
+    c.capacity = capacity;
+    int32_t pos = 0;
+    int32_t *victims = (int32_t *)malloc((size_t)(n + 2) * sizeof(int32_t));
+    int32_t nv = orc_cache_put_if_absent(&c, n /* new key */, weight, last_used, now, victims, n + 2, &pos);
+    out->insert_pos = pos;
+    out->n_victims = nv;
+    out->self_evicted = 0;
+    for (int32_t i = 0; i < nv; i++)
+        if (victims[i] == n) out->self_evicted = 1;
+    out->weighted_size = c.weighted_size;
+    out->oldest_time = orc_cache_oldest_time(&c);
+    free(victims);
+    orc_cache_free(&c);
+}

@@ -202,6 +202,13 @@ int32_t orc_cache_update_weight(orc_cache *c, int32_t key, int32_t new_weight, i
 int orc_cache_remove(orc_cache *c, int32_t key);
 int64_t orc_cache_oldest_time(const orc_cache *c);
 
+typedef struct {
+    int32_t insert_pos, n_victims, self_evicted, pad_;
+    int64_t weighted_size, oldest_time;
+} orc_evict_result;
+void orc_evict_eval(const int64_t *lu, const int32_t *wt, int32_t n, int64_t capacity, int32_t weight,
+                    int64_t last_used, int64_t now, orc_evict_result *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,7 +86,6 @@ def test_empty_and_degenerate():
     s = Solver(100, 1000)
     try:
         s.load_pods(np.zeros(0, dtype=wl.POD_ROW))
-        s.load_models(fleet.models[:1], fleet.ent_pod[:0], fleet.ent_time[:0])
         with pytest.raises(Exception):
             s.load_models(fleet.models[:10], fleet.ent_pod[:0], fleet.ent_time[:0])  # entry range check
         m = np.zeros(1, dtype=wl.MODEL_ROW)
@@ -101,21 +100,33 @@ def test_empty_and_degenerate():
 
 
 def test_order_inconsistent_rows_are_rejected():
-    """PLACEMENT_ORDER's version clause compares lruTime with a duration (quirk B#1):
-    a full pod with a tiny lruTime next to another version breaks transitivity."""
+    """PLACEMENT_ORDER's version clause compares lruTime with a duration (quirk B#1), so it is only
+    decisive for a full pod whose lruTime > 2*minChurnAgeMs.  A (v3, full, tiny lru), C (v2, full,
+    normal lru), B (v1, not full) then form a cycle A<C<B<A; a skip list would be corrupt, the
+    solver refuses the snapshot (MMP_EORDER) instead of publishing an arbitrary order."""
+    from modelmesh_amd.solver import MmpError
     fleet = wl.fuzz_fleet(1, pods=64)
     pods = fleet.pods.copy()
     pods["flags"] = wl.POD_LIVE
-    pods["version"] = np.arange(64) % 3
-    pods["used"] = pods["capacity"]  # all full
-    pods["lru_time"] = np.arange(64) % 7 + 1  # <= 2*minChurnAgeMs
+    pods["version"] = 1
+    pods["used"] = 0
+    pods["version"][0], pods["used"][0], pods["lru_time"][0] = 3, pods["capacity"][0], 5
+    pods["version"][1], pods["used"][1], pods["lru_time"][1] = 2, pods["capacity"][1], fleet.now - 1000
     s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
     try:
         s.load_pods(pods)
         s.load_models(fleet.models, fleet.ent_pod, fleet.ent_time)
-        from modelmesh_amd.solver import MmpError
         with pytest.raises(MmpError) as ei:
             s.commit()
         assert ei.value.code == -4
+        # all-full rows with tiny lru never take the version shortcut: consistent, accepted
+        pods["used"] = pods["capacity"]
+        pods["lru_time"] = np.arange(64) % 7 + 1
+        pods["version"] = np.arange(64) % 3
+        s.load_pods(pods)
+        s.commit()
+        from oracle.bind import OracleFleet
+        fleet.pods = pods
+        assert np.array_equal(s.order(), OracleFleet(fleet).order)
     finally:
         s.close()

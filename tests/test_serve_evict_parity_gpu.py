@@ -1,0 +1,115 @@
+"""GPU parity for serve-target selection (ForwardingLB.getNext, MM.java:4315-4392) and
+eviction-victim selection (clhm AddTask/evict, ConcurrentLinkedHashMap.java:590-611,329-352;
+LinkedDeque.insert, LinkedDeque.java:259-288) against the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from modelmesh_amd import _lib
+from modelmesh_amd import workload as wl
+from modelmesh_amd.solver import Solver
+from oracle import bind as ob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_serve_target_matches_oracle(seed):
+    rng = np.random.default_rng(1000 + seed)
+    fleet = wl.fuzz_fleet(seed, pods=int(rng.choice([8, 64, 300])), models=400)
+    P, now = fleet.n_pods, fleet.now
+    # make load-start times straddle the "assume completed" cutoff and collide
+    fleet.ent_time[:] = now - rng.choice([500, 2_999, 3_000, 3_001, 10_000, 10_000, 60_000], len(fleet.ent_time))
+    n = 4000
+    reqs = np.zeros(n, dtype=_lib.SERVE_REQ)
+    reqs["model"] = rng.integers(0, fleet.n_models, n)
+    reqs["self_pod"] = np.where(rng.random(n) < 0.1, -1, rng.integers(0, P, n))
+    # make self one of the copies often
+    m = fleet.models[reqs["model"]]
+    has = m["n_loaded"] > 0
+    pickc = (m["ent_off"] + rng.integers(0, 4, n) % np.maximum(m["n_loaded"], 1)).clip(0, max(len(fleet.ent_pod) - 1, 0))
+    if len(fleet.ent_pod):
+        reqs["self_pod"] = np.where(has & (rng.random(n) < 0.5), fleet.ent_pod[pickc], reqs["self_pod"])
+    reqs["flags"] = rng.integers(0, 4, n)
+    reqs["local_in_flight"] = rng.integers(0, 3, n)
+    reqs["last_invoke_time"] = now - rng.choice([0, 10, 1000], n)
+    reqs["assume_completed_ms"] = rng.choice([3000, 30_000], n)
+    in_use = rng.integers(0, 3, P).astype(np.int32)
+    last_used = (now - rng.choice([0, 5, 5, 100, 10_000], P)).astype(np.int64)
+    # tried-this-request pairs / key excludes
+    ne = np.where(rng.random(n) < 0.3, rng.integers(1, 3, n), 0).astype(np.int32)
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(ne, out=off[1:])
+    reqs["excl_off"], reqs["n_excl"] = off[:-1], ne
+    excl_pod = np.zeros(int(off[-1]), np.int32)
+    excl_time = np.zeros(int(off[-1]), np.int64)
+    for i in np.nonzero(ne)[0]:
+        mm = fleet.models[reqs["model"][i]]
+        for j in range(ne[i]):
+            if mm["n_loaded"] > 0 and rng.random() < 0.8:
+                e = mm["ent_off"] + rng.integers(0, mm["n_loaded"])
+                excl_pod[off[i] + j] = fleet.ent_pod[e]
+                excl_time[off[i] + j] = _lib.ANY_TIME if rng.random() < 0.5 else fleet.ent_time[e] + rng.integers(0, 2)
+            else:
+                excl_pod[off[i] + j] = rng.integers(0, P)
+                excl_time[off[i] + j] = _lib.ANY_TIME
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        got = s.serve(reqs, in_use, last_used, excl_pod, excl_time, now)
+    finally:
+        s.close()
+    live = np.ascontiguousarray(((fleet.pods["flags"] & 2) != 0).astype(np.uint8))
+    for i in range(n):
+        r = reqs[i]
+        mm = fleet.models[r["model"]]
+        pods = fleet.ent_pod[mm["ent_off"]: mm["ent_off"] + mm["n_loaded"]]
+        times = fleet.ent_time[mm["ent_off"]: mm["ent_off"] + mm["n_loaded"]]
+        keep = np.ones(len(pods), bool)
+        for j in range(r["n_excl"]):  # MapFilteringSet.apply, MM.java:4279-4283
+            xp, xt = excl_pod[r["excl_off"] + j], excl_time[r["excl_off"] + j]
+            keep &= ~((pods == xp) & ((xt == _lib.ANY_TIME) | (times == xt)))
+        ch, ts = ob.serve(r["self_pod"], r["flags"] & 1, r["flags"] & 2, pods[keep], times[keep], now,
+                          r["assume_completed_ms"], r["local_in_flight"], r["last_invoke_time"], live, in_use, last_used)
+        assert got[i]["chosen"] == ch, (i, got[i], ch, ts)
+        if ch != -1:
+            assert got[i]["chosen_load_start"] == ts, (i, got[i], ch, ts)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_eviction_victims_match_oracle(seed):
+    rng = np.random.default_rng(2000 + seed)
+    now = wl.NOW_MS
+    n_caches = 40
+    sizes = rng.choice([0, 1, 2, 20, 63, 64, 65, 130, 400], n_caches)
+    seg_off = np.zeros(n_caches + 1, np.int32)
+    np.cumsum(sizes, out=seg_off[1:])
+    lu = np.zeros(seg_off[-1], np.int64)
+    wt = np.zeros(seg_off[-1], np.int32)
+    cap = np.zeros(n_caches, np.int64)
+    for c in range(n_caches):
+        e = sizes[c]
+        t = np.sort(now - rng.choice([1_000, 2_000, 2_000, 5_000, 3_600_000], e) - rng.integers(0, 2, e))
+        if e and rng.random() < 0.5:
+            t[-1] = _lib.JAVA_LONG_MAX  # the pinned ___UNLOADBUF entry (ModelCacheUnloadBufManager.java:130)
+        lu[seg_off[c]: seg_off[c + 1]] = t
+        wt[seg_off[c]: seg_off[c + 1]] = rng.choice([1, 2560, 6400, 12800], e)
+        tot = int(wt[seg_off[c]: seg_off[c + 1]].sum())
+        cap[c] = int(rng.choice([tot, tot + 1, tot + 6400, max(tot - 1, 0), tot // 2, 0, 10 * tot + 1]))
+    n = 600
+    reqs = np.zeros(n, dtype=_lib.EVICT_REQ)
+    reqs["cache"] = rng.integers(0, n_caches, n)
+    reqs["weight"] = rng.choice([1, 6400, 25_600, 1_000_000], n)
+    reqs["last_used"] = np.where(rng.random(n) < 0.3, 0,
+                                 now - rng.choice([500, 1_000, 2_000, 2_001, 5_000, 9_000_000], n))
+    s = Solver(100, 1000)
+    try:
+        s.load_caches(seg_off, lu, wt, cap)
+        got = s.evict(reqs, now)
+    finally:
+        s.close()
+    for i in range(n):
+        c = reqs["cache"][i]
+        want = ob.evict_eval(lu[seg_off[c]: seg_off[c + 1]], wt[seg_off[c]: seg_off[c + 1]], cap[c],
+                             reqs["weight"][i], reqs["last_used"][i], now)
+        for f in ("insert_pos", "n_victims", "self_evicted", "weighted_size", "oldest_time"):
+            assert int(got[i][f]) == int(want[f]), (i, f, got[i], want, sizes[c], cap[c], reqs[i])
