@@ -12,8 +12,8 @@
 // Every quirk of SURVEY.md Appendix B is kept (curInst substitution, fresh rpm,
 // bestIsFull not recomputed, >>2 vs "half", ...).  `us` is evaluated in its
 // closed form `pod == self`: with unique instance ids an eligible self is never
-// excluded and the `!us &&` toggle never fires (tests/test_place_parity.py
-// checks this against the literal oracle).
+// excluded and the `!us &&` toggle never fires (tests/test_place_parity_gpu.py
+// checks this against the literal CPU restatement).
 #pragma once
 #include "snapshot.hpp"
 

@@ -159,7 +159,7 @@ def make_requests(fleet: Fleet, seed: int, n: int | None = None, *, favour_frac=
 
 
 # --------------------------------------------------------------------------
-def fuzz_fleet(seed: int, pods: int = 200, models: int = 300) -> Fleet:
+def fuzz_fleet(seed: int, pods: int = 200, models: int = 300, profile: str | None = None) -> Fleet:
     """Adversarial small fleet: ties everywhere, full pods, Long.MAX lru, dead /
     shutting-down / tombstoned pods, several versions, type masks, preferences,
     replaced replica sets.  Hits every branch of getNext with a few hundred requests."""
@@ -170,7 +170,7 @@ def fuzz_fleet(seed: int, pods: int = 200, models: int = 300) -> Fleet:
     msu = int(rng.choice([6553, 51200, 2560]))
     rows = np.zeros(P, dtype=POD_ROW)
     rows["capacity"] = np.where(rng.random(P) < 0.8, cap, cap // 2)
-    fullish = rng.random(P) < rng.choice([0.05, 0.5, 0.95])
+    fullish = rng.random(P) < (rng.choice([0.9, 1.0]) if profile == "full" else rng.choice([0.05, 0.5, 0.95]))
     used_frac = np.where(fullish, rng.uniform(0.97, 1.05, P), rng.choice([0.1, 0.5, 0.9], P))
     rows["used"] = (rows["capacity"] * used_frac).astype(np.int64)
     rows["count"] = rng.choice([0, 1, 2, 9, 10, 11, 12, 13, 40], P)
@@ -199,13 +199,15 @@ def fuzz_fleet(seed: int, pods: int = 200, models: int = 300) -> Fleet:
     elif r < 0.4:
         replaced = np.arange(n_rs, dtype=np.int32)  # everything replaced -> retry path
 
-    n_types = int(rng.choice([0, 1, 3, 5]))
+    n_types = int(rng.choice([0, 1, 3, 5])) if profile is None else int(rng.choice([3, 5]))
     allowed = prefer = has_allowed = has_prefer = None
     if n_types:
         al = rng.random((n_types, P)) < rng.choice([0.1, 0.6, 1.0], (n_types, 1))
         pf = rng.random((n_types, P)) < rng.choice([0.0, 0.05, 0.5], (n_types, 1))
         has_allowed = (rng.random(n_types) < 0.6).astype(np.uint8)
         has_prefer = (rng.random(n_types) < 0.7).astype(np.uint8)
+        if profile is not None:
+            has_prefer[0] = 0  # keep one plain type so the simple case is exercised too
         allowed, prefer = bitmap_from_bool(al), bitmap_from_bool(pf)
     last_used = now - rng.choice([0, 500, 4_000, 6_000, 700_000, 800_000, 80_000_000, 90_000_000,
                                   431_000_000, 433_000_000], M) - 1
@@ -245,3 +247,75 @@ def fuzz_requests(fleet: Fleet, seed: int, n: int):
     reqs["n_extra"] = ne
     extra = rng.integers(0, P, int(off[-1])).astype(np.int32)
     return reqs, extra
+
+
+def scenario_fleets():
+    """Hand-built fleets that force the rare branches of getNext random fuzzing seldom reaches.
+    Yields (name, fleet, reqs, extra)."""
+    now = NOW_MS
+    msu = 1000
+
+    def pods_of(spec):
+        rows = np.zeros(len(spec), dtype=POD_ROW)
+        for i, (count, rem, lru, rpm) in enumerate(spec):
+            rows[i]["capacity"] = 1_000_000
+            rows[i]["used"] = 1_000_000 - rem
+            rows[i]["count"] = count
+            rows[i]["lru_time"] = lru
+            rows[i]["rpm"] = rpm
+        rows["loading_threads"] = 8
+        rows["version"] = 1
+        rows["id_order"] = np.arange(len(spec), dtype=np.uint32)
+        rows["flags"] = POD_LIVE
+        return rows
+
+    def fleet_of(rows, pref_pods, n_models=4):
+        P = len(rows)
+        pf = np.zeros((2, P), bool)
+        pf[1, pref_pods] = True
+        models = np.zeros(n_models, dtype=MODEL_ROW)
+        models["type"] = 1
+        models["last_used"] = now - 1000
+        return Fleet(pods=rows, models=models, ent_pod=np.zeros(0, np.int32), ent_time=np.zeros(0, np.int64),
+                     min_space_units=msu, min_churn_age_ms=600_000, now=now, n_types=2,
+                     allowed=bitmap_from_bool(np.ones((2, P), bool)), prefer=bitmap_from_bool(pf),
+                     has_allowed=np.array([0, 0], np.uint8), has_prefer=np.array([0, 1], np.uint8))
+
+    def reqs_of(fleet, self_pods, favour):
+        n = len(self_pods)
+        r = np.zeros(n, dtype=PLACE_REQ)
+        r["model"] = 0
+        r["self_pod"] = self_pods
+        r["flags"] = favour
+        r["pick"] = np.arange(n, dtype=np.uint32) * 977_777_777
+        r["last_used"] = now - 1000
+        sp = fleet.pods[np.maximum(self_pods, 0)]
+        r["fresh_lru"], r["fresh_capacity"], r["fresh_used"], r["fresh_count"] = (
+            sp["lru_time"], sp["capacity"], sp["used"], sp["count"])
+        return r
+
+    # S1: case (a) re-designates a preferred best with 4x the space of bestEntry; the self pod then
+    # breaks on bestEntry's (small) remaining (quirk B#2 'curInst = bestEntry.getValue()' for self)
+    rows = pods_of([(0, msu + 10, now - 5000, 10), (5, 900_000, now - 5000, 20), (6, 900_000, now - 5000, 30),
+                    (7, 900_000, now - 5000, 40)])
+    f = fleet_of(rows, [1, 2, 3])
+    yield "a_found_self_breaks_on_best_entry", f, reqs_of(f, np.array([2, 3, 0, 1, -1], np.int32),
+                                                        np.array([0, 0, 0, 0, 0], np.uint32)), np.zeros(0, np.int32)
+    # S2: case (b): everything full, best not preferred, self preferred inside the age window + favourSelf => null
+    rows = pods_of([(3, 0, now - 900_000, 10), (3, 0, now - 890_000, 500), (3, 0, now - 880_000, 30),
+                    (3, 0, now - 100_000, 40)])
+    f = fleet_of(rows, [1, 2, 3])
+    yield "b_self_preferred_favour_null", f, reqs_of(f, np.array([1, 2, 2, 3, 0], np.int32),
+                                                   np.array([1, 1, 0, 1, 1], np.uint32)), np.zeros(0, np.int32)
+    # S3: nothing eligible and no replaced replica sets => null straight away
+    rows = pods_of([(1, 500_000, now - 5000, 10), (2, 500_000, now - 5000, 10)])
+    f = fleet_of(rows, [0])
+    r = reqs_of(f, np.array([0, 1], np.int32), np.array([0, 1], np.uint32))
+    r["extra_off"], r["n_extra"] = 0, 2
+    yield "all_excluded", f, r, np.array([0, 1], np.int32)
+    # S4: rpm filter with a busy best: model used <5 s ago, best rpm 5000 vs others 0 (fresh rpm) => best nulled
+    rows = pods_of([(1, 500_000, now - 5000, 5000), (1, 499_999, now - 5000, 0), (1, 499_998, now - 5000, 0)])
+    f = fleet_of(rows, [])
+    f.has_prefer[:] = 0
+    yield "busy_best_is_filtered", f, reqs_of(f, np.array([-1, 1, 2, 0], np.int32),
+                                            np.array([0, 0, 1, 0], np.uint32)), np.zeros(0, np.int32)

@@ -43,6 +43,12 @@ class OrcCache(C.Structure):
                 ("weighted_size", C.c_int64), ("capacity", C.c_int64)]
 
 
+class OrcUbm(C.Structure):
+    _fields_ = [("cache", C.POINTER(OrcCache)), ("reserved", C.c_int32), ("total_unloading", C.c_int32),
+                ("total_occupancy", C.c_int64), ("cache_deficit", C.c_int32), ("n_evicted", C.c_int32),
+                ("evicted", C.c_int32 * 1024)]
+
+
 _lib = None
 
 
@@ -81,6 +87,19 @@ def load() -> C.CDLL:
         lib.orc_cache_remove.argtypes = [C.POINTER(OrcCache), C.c_int32]
         lib.orc_cache_oldest_time.restype = C.c_int64
         lib.orc_cache_oldest_time.argtypes = [C.POINTER(OrcCache)]
+        U = C.POINTER(OrcUbm)
+        lib.orc_ubm_init.argtypes = [U, C.POINTER(OrcCache), C.c_int32, C.c_int64]
+        lib.orc_ubm_buffer_weight.restype = C.c_int32
+        lib.orc_ubm_buffer_weight.argtypes = [U]
+        lib.orc_ubm_insert_new_entry.restype = C.c_int
+        lib.orc_ubm_insert_new_entry.argtypes = [U, C.c_int32, C.c_int32, C.c_int64, C.c_int64]
+        lib.orc_ubm_adjust_new_entry_space_request.argtypes = [U, C.c_int32, C.c_int32, C.c_int64]
+        lib.orc_ubm_cache_space_is_ready.restype = C.c_int
+        lib.orc_ubm_cache_space_is_ready.argtypes = [U, C.c_int32]
+        lib.orc_ubm_claim_requested_space_if_ready.restype = C.c_int
+        lib.orc_ubm_claim_requested_space_if_ready.argtypes = [U, C.c_int32, C.c_int64]
+        lib.orc_ubm_adjust_weight_after_load.argtypes = [U, C.c_int32, C.c_int32, C.c_int64]
+        lib.orc_ubm_unload_complete.argtypes = [U, C.c_int32, C.c_int, C.c_int64]
         lib.orc_evict_eval.restype = None
         lib.orc_evict_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int64, C.c_int64,
                                        C.c_void_p]
@@ -212,3 +231,57 @@ class OracleFleet:
         out = np.zeros(1, dtype=ORC_STATS)
         self.lib.orc_cluster_stats_of(_p(self.pods), len(self.pods), self.fleet.min_space_units, _p(out))
         return out[0]
+
+
+class CCache:
+    """Pythonic handle on the C oracle's cache + unload-buffer manager (for the KAT tests)."""
+
+    def __init__(self, capacity, reserved=None, now=0):
+        self.lib = load()
+        self.c = OrcCache()
+        self.lib.orc_cache_init(C.byref(self.c), int(capacity))
+        self.u = None
+        self.now = now
+        if reserved is not None:
+            self.u = OrcUbm()
+            self.lib.orc_ubm_init(C.byref(self.u), C.byref(self.c), int(reserved), int(now))
+
+    def __del__(self):
+        try:
+            self.lib.orc_cache_free(C.byref(self.c))
+        except Exception:
+            pass
+
+    # plain clhm operations
+    def put_if_absent(self, key, weight, last_used, now):
+        v = np.zeros(4096, np.int32)
+        pos = C.c_int32(0)
+        n = self.lib.orc_cache_put_if_absent(C.byref(self.c), key, weight, last_used, now, _p(v), len(v), C.byref(pos))
+        return None if n < 0 else list(v[:n])
+
+    def get(self, key, last_used, now):
+        return bool(self.lib.orc_cache_get(C.byref(self.c), key, last_used, now))
+
+    def update_weight(self, key, w, new_time, now):
+        v = np.zeros(4096, np.int32)
+        n = self.lib.orc_cache_update_weight(C.byref(self.c), key, w, new_time, now, _p(v), len(v))
+        return None if n < 0 else list(v[:n])
+
+    def remove(self, key):
+        return bool(self.lib.orc_cache_remove(C.byref(self.c), key))
+
+    def oldest_time(self):
+        return self.lib.orc_cache_oldest_time(C.byref(self.c))
+
+    def keys(self):
+        nodes = np.ctypeslib.as_array(C.cast(self.c.nodes, C.POINTER(C.c_byte)), shape=(self.c.n * 16,)) if self.c.n else np.zeros(0, np.int8)
+        arr = np.frombuffer(nodes.tobytes(), dtype=ORC_NODE)
+        return [int(k) for k in arr["key"] if k != -1000000]
+
+    @property
+    def weighted_size(self):
+        return self.c.weighted_size
+
+    # unload-buffer manager
+    def evicted(self):
+        return [int(self.u.evicted[i]) for i in range(self.u.n_evicted)]

@@ -197,3 +197,181 @@ void orc_evict_eval(const int64_t *lu, const int32_t *wt, int32_t n, int64_t cap
     free(victims);
     orc_cache_free(&c);
 }
+
+/* ======================================================================== */
+/* ModelCacheUnloadBufManager.java — unload-buffer accounting on top of the  */
+/* cache.  Evictions are fed back through entryRemoved exactly as            */
+/* ModelMesh.onEviction does while still under the eviction lock             */
+/* (MM.java:2876-2878).                                                     */
+#define ORC_UNLOADBUF_KEY (-1000000)
+
+static void ubm_adjust_agg(orc_ubm *u, int32_t delta, int64_t now);
+
+static void ubm_on_evicted(orc_ubm *u, const int32_t *keys, const int32_t *weights, int32_t n, int64_t now)
+{
+    for (int32_t i = 0; i < n; i++) {
+        if (u->n_evicted < ORC_UBM_MAX_EVICTED) u->evicted[u->n_evicted] = keys[i];
+        u->n_evicted++;
+        /* entryRemoved(weight), ModelCacheUnloadBufManager.java:311-316 */
+        u->total_occupancy -= weights[i];
+        ubm_adjust_agg(u, weights[i], now);
+    }
+}
+
+/* CacheEntry.updateWeightLocked → replaceQuietly → UpdateTask(quiet) */
+static void ubm_set_weight(orc_ubm *u, int32_t key, int32_t w, int64_t now)
+{
+    orc_cache *c = u->cache;
+    int32_t i = orc_cache_find(c, key);
+    if (i < 0) return;
+    int32_t diff = w - c->nodes[i].weight;
+    if (diff == 0) return;
+    c->nodes[i].weight = w;
+    c->weighted_size += diff;
+    /* evict() with victim weights captured for the listener */
+    int32_t vk[256], vw[256], nv = 0;
+    while (c->weighted_size > c->capacity && c->n > 0) {
+        orc_node e = c->nodes[0];
+        memmove(&c->nodes[0], &c->nodes[1], (size_t)(c->n - 1) * sizeof(orc_node));
+        c->n--;
+        c->weighted_size -= e.weight < 0 ? -e.weight : e.weight;
+        if (nv < 256) { vk[nv] = e.key; vw[nv] = e.weight; nv++; }
+    }
+    ubm_on_evicted(u, vk, vw, nv, now);
+}
+
+/* adjustAggregateUnloadingWeight, :375-392 */
+static void ubm_adjust_agg(orc_ubm *u, int32_t delta, int64_t now)
+{
+    if (delta == 0) return;
+    u->total_unloading += delta;
+    int32_t nw = u->total_unloading;
+    if (nw <= u->reserved) {
+        nw = u->reserved;
+    } else {
+        int32_t cap = u->cache->capacity > INT32_MAX ? INT32_MAX : (int32_t)u->cache->capacity;
+        if (cap < nw) nw = cap;
+    }
+    ubm_set_weight(u, ORC_UNLOADBUF_KEY, nw, now);
+}
+
+void orc_ubm_init(orc_ubm *u, orc_cache *cache, int32_t reserved, int64_t now)
+{
+    memset(u, 0, sizeof *u);
+    u->cache = cache;
+    u->reserved = reserved;
+    /* newInternalCacheEntry: pinned with Long.MAX_VALUE, MM.java:1617-1622 */
+    orc_cache_put_if_absent(cache, ORC_UNLOADBUF_KEY, reserved, INT64_MAX, now, NULL, 0, NULL);
+}
+
+int32_t orc_ubm_buffer_weight(const orc_ubm *u)
+{
+    int32_t i = orc_cache_find(u->cache, ORC_UNLOADBUF_KEY);
+    return i < 0 ? 0 : u->cache->nodes[i].weight;
+}
+
+/* insertNewEntry, :130-145 */
+int orc_ubm_insert_new_entry(orc_ubm *u, int32_t key, int32_t weight, int64_t last_used, int64_t now)
+{
+    ubm_adjust_agg(u, -weight, now);
+    orc_cache *c = u->cache;
+    if (orc_cache_find(c, key) >= 0) {
+        orc_cache_get(c, key, last_used, now);
+        ubm_adjust_agg(u, weight, now);
+        return 0;
+    }
+    /* putIfAbsent with the victims' weights captured */
+    orc_node nd = {0, weight, key};
+    nd.last_used = last_used == 0 ? now : last_used;
+    c->weighted_size += weight;
+    int32_t l = c->n - 1;
+    while (l >= 0 && !(c->nodes[l].last_used <= nd.last_used)) l--;
+    if (c->n + 1 > c->cap_nodes) {
+        int32_t nc = c->cap_nodes ? c->cap_nodes * 2 : 16;
+        c->nodes = (orc_node *)realloc(c->nodes, (size_t)nc * sizeof(orc_node));
+        c->cap_nodes = nc;
+    }
+    memmove(&c->nodes[l + 2], &c->nodes[l + 1], (size_t)(c->n - l - 1) * sizeof(orc_node));
+    c->nodes[l + 1] = nd;
+    c->n++;
+    u->total_occupancy += weight;
+    int32_t vk[256], vw[256], nv = 0;
+    while (c->weighted_size > c->capacity && c->n > 0) {
+        orc_node e = c->nodes[0];
+        memmove(&c->nodes[0], &c->nodes[1], (size_t)(c->n - 1) * sizeof(orc_node));
+        c->n--;
+        c->weighted_size -= e.weight < 0 ? -e.weight : e.weight;
+        if (nv < 256) { vk[nv] = e.key; vw[nv] = e.weight; nv++; }
+    }
+    ubm_on_evicted(u, vk, vw, nv, now);
+    return 1;
+}
+
+/* adjustNewEntrySpaceRequest, :152-166 */
+void orc_ubm_adjust_new_entry_space_request(orc_ubm *u, int32_t increase, int32_t key, int64_t now)
+{
+    int32_t i = orc_cache_find(u->cache, key);
+    if (i < 0) return;
+    int32_t nw = u->cache->nodes[i].weight + increase;
+    u->total_occupancy += increase;
+    ubm_adjust_agg(u, -increase, now);
+    ubm_set_weight(u, key, nw, now);
+}
+
+/* cacheSpaceIsReady, :395-402 */
+int orc_ubm_cache_space_is_ready(const orc_ubm *u, int32_t required)
+{
+    int32_t new_tuw = u->total_unloading + required;
+    if (new_tuw <= u->reserved) return 1;
+    return (int64_t)new_tuw + u->total_occupancy <= u->cache->capacity;
+}
+
+/* claimRequestedSpaceIfReady, :190-202 */
+int orc_ubm_claim_requested_space_if_ready(orc_ubm *u, int32_t required, int64_t now)
+{
+    if (!orc_ubm_cache_space_is_ready(u, required)) return 0;
+    ubm_adjust_agg(u, required, now);
+    return 1;
+}
+
+/* payDownDeficitAndNotifyWaiters, :351-366 */
+static void ubm_pay_down(orc_ubm *u, int32_t weight, int release, int64_t now)
+{
+    int32_t reduction = weight < u->cache_deficit ? weight : u->cache_deficit;
+    if (reduction != 0) {
+        u->cache_deficit -= reduction;
+        weight -= reduction;
+    }
+    ubm_adjust_agg(u, release ? -weight : reduction, now);
+}
+
+/* adjustWeightAfterLoad, :224-246 */
+void orc_ubm_adjust_weight_after_load(orc_ubm *u, int32_t delta, int32_t key, int64_t now)
+{
+    if (delta == 0) return;
+    if (delta > 0) {
+        int64_t rem = u->cache->capacity - u->cache->weighted_size;
+        int32_t remaining = rem > INT32_MAX ? INT32_MAX : (int32_t)rem; /* cacheRemaining :340-342 */
+        int32_t deficit = delta - remaining;
+        if (deficit > 0) {
+            ubm_adjust_agg(u, -deficit, now);
+            u->cache_deficit += deficit;
+        }
+    }
+    u->total_occupancy += delta;
+    int32_t i = orc_cache_find(u->cache, key);
+    if (i >= 0) ubm_set_weight(u, key, u->cache->nodes[i].weight + delta, now);
+    if (delta < 0) ubm_pay_down(u, -delta, 0, now);
+}
+
+/* unloadComplete, :318-338 */
+void orc_ubm_unload_complete(orc_ubm *u, int32_t weight, int success, int64_t now)
+{
+    if (success) {
+        ubm_pay_down(u, weight, 1, now);
+        return;
+    }
+    int64_t cap = u->cache->capacity;
+    ubm_adjust_agg(u, -weight, now);
+    u->cache->capacity = cap - weight > 1 ? cap - weight : 1;
+}

@@ -209,6 +209,26 @@ typedef struct {
 void orc_evict_eval(const int64_t *lu, const int32_t *wt, int32_t n, int64_t capacity, int32_t weight,
                     int64_t last_used, int64_t now, orc_evict_result *out);
 
+/* ---------- unload-buffer accounting (ModelCacheUnloadBufManager.java) -- */
+#define ORC_UBM_MAX_EVICTED 1024
+typedef struct {
+    orc_cache *cache;
+    int32_t reserved;         /* unloadsReservedSizeUnits */
+    int32_t total_unloading;  /* totalUnloadingWeight     */
+    int64_t total_occupancy;  /* totalModelCacheOccupancy */
+    int32_t cache_deficit;    /* cacheDeficit             */
+    int32_t n_evicted;
+    int32_t evicted[ORC_UBM_MAX_EVICTED]; /* keys in eviction order */
+} orc_ubm;
+void orc_ubm_init(orc_ubm *u, orc_cache *cache, int32_t reserved, int64_t now);
+int32_t orc_ubm_buffer_weight(const orc_ubm *u);
+int orc_ubm_insert_new_entry(orc_ubm *u, int32_t key, int32_t weight, int64_t last_used, int64_t now);
+void orc_ubm_adjust_new_entry_space_request(orc_ubm *u, int32_t increase, int32_t key, int64_t now);
+int orc_ubm_cache_space_is_ready(const orc_ubm *u, int32_t required);
+int orc_ubm_claim_requested_space_if_ready(orc_ubm *u, int32_t required, int64_t now);
+void orc_ubm_adjust_weight_after_load(orc_ubm *u, int32_t delta, int32_t key, int64_t now);
+void orc_ubm_unload_complete(orc_ubm *u, int32_t weight, int success, int64_t now);
+
 #ifdef __cplusplus
 }
 #endif

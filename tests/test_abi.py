@@ -1,0 +1,72 @@
+"""CPU-side checks of the drop-in boundary: libmmplace loads, exports every symbol that
+include/mmplace.h declares, and refuses to run without a GPU (there is no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from modelmesh_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ensure_built():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+
+
+def test_header_symbols_are_all_exported_and_typed():
+    _ensure_built()
+    hdr = open(os.path.join(ROOT, "include", "mmplace.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mmp_[a-z0-9_]+)\s*\(", hdr))
+    bound = {name for name, _, _ in _lib.SYMBOLS}
+    assert declared == bound, (declared - bound, bound - declared)
+    lib = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/mmplace.h but not exported"
+    assert _lib.load().mmp_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header():
+    """The numpy mirrors must have the sizes the header documents (64 B pod row / request, 24 B model
+    row, 16 B result)."""
+    assert _lib.POD_ROW.itemsize == 64 and _lib.PLACE_REQ.itemsize == 64
+    assert _lib.MODEL_ROW.itemsize == 24 and _lib.PLACE_OUT.itemsize == 16
+    assert _lib.POD_ROW.fields["flags"][1] == 56 and _lib.PLACE_REQ.fields["fresh_lru"][1] == 32
+
+
+def test_no_cpu_fallback_without_a_device():
+    _ensure_built()
+    lib = _lib.load()
+    cfg = _lib.MmpConfig(0, 0, 100, 1000)
+    h = C.c_void_p()
+    rc = lib.mmp_create(C.byref(cfg), C.byref(h))
+    if os.path.exists("/dev/kfd"):
+        assert rc == 0
+        lib.mmp_destroy(h)
+    else:
+        assert rc == _lib.MMP_ENODEVICE and not h.value
+        assert b"no CPU path" in lib.mmp_last_error(None)
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure; nothing under modelmesh_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "modelmesh_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cc", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_bitmap_packing_roundtrip():
+    from modelmesh_amd.solver import bitmap_from_bool
+    from oracle.bind import unpack_bitmap
+    rng = np.random.default_rng(0)
+    for p in (1, 63, 64, 65, 1000):
+        m = rng.random((3, p)) < 0.4
+        assert np.array_equal(unpack_bitmap(bitmap_from_bool(m), p).astype(bool), m)

@@ -1,0 +1,152 @@
+"""The comparator / shortlist / rpm-filter half of the path is NOT pinned by any reference test
+(SURVEY.md §4, §8c), so the C oracle is cross-checked against a second restatement written
+independently from the Java text (oracle/py_oracle.py) on adversarial random snapshots."""
+import numpy as np
+import pytest
+
+from modelmesh_amd import workload as wl
+from oracle import bind as ob
+from oracle import py_oracle as po
+
+
+def _py_pods(fleet):
+    out = []
+    for r in fleet.pods:
+        out.append(dict(lru_time=int(r["lru_time"]), capacity=int(r["capacity"]), used=int(r["used"]),
+                        version=int(r["version"]), count=int(r["count"]), loading_threads=int(r["loading_threads"]),
+                        loading_in_progress=int(r["loading_in_progress"]), rpm=int(r["rpm"]),
+                        id_order=int(r["id_order"]), replica_set=int(r["replica_set"]),
+                        shutting_down=bool(r["flags"] & 5)))
+    return out
+
+
+def _py_hash(order, shortlist, remaining):
+    pos = {p: i for i, p in enumerate(order)}
+    words = {}
+    for c in shortlist:
+        words[pos[c] >> 6] = words.get(pos[c] >> 6, 0) | (1 << (pos[c] & 63))
+    M = (1 << 64) - 1
+
+    def sm(x):
+        x = (x + 0x9E3779B97F4A7C15) & M
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
+        return x ^ (x >> 31)
+    h = 0
+    for w, b in words.items():
+        h = (h + sm(b ^ ((0x9E3779B97F4A7C15 * (w + 1)) & M))) & M
+    return ((h ^ (h >> 32)) & 0xFFFFFFFF) ^ ((remaining * 0x9E3779B1) & 0xFFFFFFFF)
+
+
+@pytest.mark.parametrize("profile", [None, "full", "prefer"])
+@pytest.mark.parametrize("seed", range(12))
+def test_place_c_vs_python(seed, profile):
+    P = int(np.random.default_rng(seed).choice([1, 5, 40, 64, 130]))
+    fleet = wl.fuzz_fleet(seed, pods=P, models=120, profile=profile)
+    reqs, extra = wl.fuzz_requests(fleet, seed, 250)
+    _compare(fleet, reqs, extra)
+
+
+def test_place_c_vs_python_scenarios():
+    for name, fleet, reqs, extra in wl.scenario_fleets():
+        _compare(fleet, reqs, extra)
+
+
+def _compare(fleet, reqs, extra):
+    P = fleet.n_pods
+    orc = ob.OracleFleet(fleet)
+    want = orc.place(reqs, extra, fleet.now)
+
+    mesh = po.Mesh(fleet.min_space_units, fleet.min_churn_age_ms, fleet.now)
+    pods = _py_pods(fleet)
+    order = mesh.sorted_cluster_state(pods)
+    assert order == list(orc.order)
+    live = {i for i in range(P) if fleet.pods["flags"][i] & 2}
+    rs = set(int(x) for x in fleet.replaced_rs)
+    T = fleet.n_types
+    al = ob.unpack_bitmap(fleet.allowed, P) if T else None
+    pf = ob.unpack_bitmap(fleet.prefer, P) if T else None
+    for i, r in enumerate(reqs):
+        m = fleet.models[r["model"]]
+        t = int(m["type"])
+        constrain = set(np.nonzero(al[t])[0]) if T and fleet.has_allowed[t] else None
+        prefer = set(np.nonzero(pf[t])[0]) if T and fleet.has_prefer[t] else None
+        ents = fleet.ent_pod[m["ent_off"]: m["ent_off"] + m["n_loaded"] + m["n_failed"]]
+        loaded = set(int(x) for x in ents[: m["n_loaded"]])
+        failed = set(int(x) for x in ents[m["n_loaded"]:])
+        tried = set(int(x) for x in extra[r["extra_off"]: r["extra_off"] + r["n_extra"]])
+        fresh = dict(lru_time=int(r["fresh_lru"]), capacity=int(r["fresh_capacity"]), used=int(r["fresh_used"]),
+                     count=int(r["fresh_count"]), rpm=int(r["fresh_rpm"]))
+        chosen, best, shortlist, remaining = po.get_next(
+            mesh, pods, order, live, rs, constrain, prefer, [tried, loaded, failed], int(r["self_pod"]),
+            bool(r["flags"] & 1), fresh, int(r["last_used"]), int(r["pick"]))
+        w = want[i]
+        assert (chosen, best, len(shortlist)) == (w["chosen"], w["best"], w["n_candidates"]), (i, r, w)
+        if shortlist:
+            assert _py_hash(order, shortlist, remaining) == w["hash"], (i, shortlist, remaining)
+
+
+def test_serve_c_vs_python():
+    rng = np.random.default_rng(5)
+    P = 12
+    live_arr = (rng.random(P) < 0.85).astype(np.uint8)
+    live = set(np.nonzero(live_arr)[0])
+    now = wl.NOW_MS
+    for _ in range(3000):
+        k = int(rng.integers(0, 5))
+        pods = rng.choice(P, size=k, replace=False)
+        times = now - rng.choice([100, 2_999, 3_000, 3_001, 9_000], k)
+        in_use = rng.integers(0, 3, P).astype(np.int32)
+        lu = (now - rng.choice([0, 5, 5, 70], P)).astype(np.int64)
+        self_id = int(rng.integers(-1, P))
+        ex, pr = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        lif, lit = int(rng.integers(0, 3)), int(now - rng.choice([0, 5, 70]))
+        got = ob.serve(self_id, ex, pr, pods, times, now, 3000, lif, lit, live_arr, in_use, lu)
+        want = po.serve_get_next(list(zip(map(int, pods), map(int, times))), self_id, ex, pr, live, now, 3000, lif,
+                                 lit, in_use, lu)
+        assert got[0] == want[0]
+        if want[0] != -1:
+            assert got[1] == want[1]
+
+
+def test_cache_ops_c_vs_python():
+    """Random sequences of putIfAbsent / get / weight update / remove on both clhm models."""
+    rng = np.random.default_rng(9)
+    now = wl.NOW_MS
+    for trial in range(40):
+        cap = int(rng.choice([50, 200, 1000]))
+        c, p = ob.CCache(cap), po.Clhm(cap)
+        for step in range(200):
+            op = rng.integers(0, 10)
+            key = int(rng.integers(0, 30))
+            t = int(now + step - rng.choice([0, 0, 5, 5, 50, 1000]))
+            if op < 5:
+                w = int(rng.choice([1, 5, 20, 60]))
+                lu = 0 if rng.random() < 0.3 else t
+                assert c.put_if_absent(key, w, lu, now + step) == p.putIfAbsent(key, w, lu, now + step)
+            elif op < 7:
+                lu = 0 if rng.random() < 0.5 else t
+                assert c.get(key, lu, now + step) == p.get(key, lu, now + step)
+            elif op < 9:
+                w = int(rng.choice([1, 5, 20, 60, 300]))
+                nt = int(rng.choice([-1, 0, t]))
+                assert c.update_weight(key, w, nt, now + step) == p.updateWeight(key, w, nt, now + step)
+            else:
+                assert c.remove(key) == p.remove(key)
+            assert c.keys() == p.keys() and c.weighted_size == p.weightedSize
+            assert c.oldest_time() == p.oldestTime()
+
+
+def test_fuzz_fleets_reach_every_branch_of_get_next():
+    """Run after the parametrised cases above in the same process: the union of the fuzz fleets must
+    have visited every branch of getNext that the kernel has to reproduce."""
+    if len(po.BRANCHES) == 0:
+        pytest.skip("run together with test_place_c_vs_python")
+    expected = {"none_no_candidates", "retry_without_replica_sets", "case_a_found", "case_a_stop_at_full",
+                "case_a_not_found", "case_b_age_break", "case_b_preferred", "case_b_no_preferred",
+                "case_b_self_null", "self_is_best", "skip_non_preferred", "full_mode", "full_mode_self",
+                "break_lru", "break_rem", "break_rem_self", "break_count", "self_in_shortlist",
+                "rpm_nulled_first", "rpm_nulled_other", "rpm_break_at_one", "older_than_five_days",
+                "chosen_is_self"}
+    missing = expected - po.BRANCHES
+    assert not missing, f"fuzz fleets never reached: {sorted(missing)}"

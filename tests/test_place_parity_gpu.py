@@ -35,11 +35,18 @@ def _check_fleet(fleet, reqs, extra):
         s.close()
 
 
-@pytest.mark.parametrize("seed", range(24))
-def test_fuzz_fleets(seed):
-    fleet = wl.fuzz_fleet(seed, pods=int(np.random.default_rng(seed).choice([1, 7, 63, 64, 65, 200, 700])))
+@pytest.mark.parametrize("profile", [None, "full", "prefer"])
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_fleets(seed, profile):
+    fleet = wl.fuzz_fleet(seed, pods=int(np.random.default_rng(seed).choice([1, 7, 63, 64, 65, 200, 700, 5000])),
+                          profile=profile)
     reqs, extra = wl.fuzz_requests(fleet, seed, 3000)
     _check_fleet(fleet, reqs, extra)
+
+
+def test_scenarios_rare_branches():
+    for name, fleet, reqs, extra in wl.scenario_fleets():
+        _check_fleet(fleet, reqs, extra)
 
 
 def test_c1_256x8():
