@@ -1,0 +1,104 @@
+/*
+ * GpuPlacementLB.java — the reference-side binding a ModelMesh maintainer adds.
+ * Lives in package com.ibm.watson.modelmesh next to ModelMesh.java and is installed where the two
+ * litelinks clients are built (ModelMesh.java:1103-1110):
+ *
+ *     cacheMissClient = ThriftClientBuilder.newBuilder(iface).withServiceName(serviceName)
+ *             .withLoadBalancer(useGpu ? () -> new GpuCacheMissLB() : CacheMissForwardingLB::new) ...
+ *
+ * It is NOT compiled in this repository (no JDK in the image); it documents the exact mapping
+ * between the Java objects of the hot path and the C ABI of include/mmplace.h.
+ */
+package com.ibm.watson.modelmesh;
+
+import java.nio.ByteBuffer;
+import java.nio.ByteOrder;
+import java.util.Map;
+import java.util.concurrent.ThreadLocalRandom;
+
+import com.ibm.watson.litelinks.client.LoadBalancer;
+import com.ibm.watson.litelinks.client.ServiceInstanceInfo;
+
+/** static natives implemented by integration/mmplace_jni.cc */
+final class MmPlace {
+    static { System.loadLibrary("mmplace_jni"); }
+    static native long create(int device, long minSpaceUnits, long minChurnAgeMs);
+    static native void destroy(long h);
+    static native int podsLoad(long h, ByteBuffer rows, int n);
+    static native int podsUpsert(long h, ByteBuffer idx, ByteBuffer rows, int n);
+    static native int podsRemove(long h, ByteBuffer idx, int n);
+    static native int typesLoad(long h, int nTypes, ByteBuffer allowed, ByteBuffer prefer,
+                                ByteBuffer hasAllowed, ByteBuffer hasPrefer);
+    static native int replacedReplicaSetsLoad(long h, ByteBuffer rs, int n);
+    static native int modelsLoad(long h, ByteBuffer rows, int nModels, ByteBuffer entPod, ByteBuffer entTime, int nEntries);
+    static native int commit(long h);
+    static native int placeBatch(long h, ByteBuffer reqs, int n, ByteBuffer extraPool, int nExtra, long nowMs, ByteBuffer outs);
+    static native int serveBatch(long h, ByteBuffer reqs, int n, ByteBuffer inUse, ByteBuffer lastUsed,
+                                 ByteBuffer exclPod, ByteBuffer exclTime, int nExcl, long nowMs, ByteBuffer outs);
+    static native int clusterStats(long h, ByteBuffer out);
+    static final int NONE = -1, SELF = -2;
+}
+
+/**
+ * Inner class of ModelMesh in the real patch (it needs instanceId, clusterState listeners,
+ * getFreshInstanceRecord(), cacheMissExcludeTl). Replaces the BODY of
+ * CacheMissForwardingLB.getNext (ModelMesh.java:4776-5005); everything around it is unchanged.
+ */
+abstract class GpuCacheMissLB extends ModelMesh.IdBasedLoadBalancer {
+    // One snapshot handle per ModelMesh instance, refreshed by the instance-table listener
+    // (handleInstanceTableChange, ModelMesh.java:1455): podsUpsert/podsRemove + commit, and by the
+    // registry listener for modelsLoad. The interner maps instance id -> dense pod index and keeps
+    // id_order == rank under String.compareTo, replica_set == interned id.substring(0,6).
+    abstract long handle();
+    abstract int podIndexOf(String instanceId);     // -1 if unknown
+    abstract String instanceIdOf(int podIndex);
+    abstract int modelIndexOf(String modelId);
+    abstract String selfInstanceId();
+    abstract InstanceRecord freshSelf();            // getFreshInstanceRecord(), ModelMesh.java:5369
+    abstract ModelMesh.CacheMissExcludeSet excludeSet(); // cacheMissExcludeTl.get()
+    abstract String currentModelId();
+
+    private static final ThreadLocal<ByteBuffer> REQ = ThreadLocal.withInitial(
+            () -> ByteBuffer.allocateDirect(64).order(ByteOrder.LITTLE_ENDIAN));
+    private static final ThreadLocal<ByteBuffer> OUT = ThreadLocal.withInitial(
+            () -> ByteBuffer.allocateDirect(16).order(ByteOrder.LITTLE_ENDIAN));
+    private static final ThreadLocal<ByteBuffer> EXTRA = ThreadLocal.withInitial(
+            () -> ByteBuffer.allocateDirect(4 * 64).order(ByteOrder.LITTLE_ENDIAN));
+
+    @SuppressWarnings("unchecked")
+    @Override
+    public <T> T getNext(Object[] sis, String method, Object[] args) {
+        final ModelMesh.CacheMissExcludeSet exclude = excludeSet();
+        final Map<String, ServiceInstanceInfo> siMap = getMap(sis);
+        final InstanceRecord fresh = freshSelf();
+
+        // mmp_place_req, 64 bytes (include/mmplace.h)
+        ByteBuffer q = REQ.get(); q.clear();
+        q.putInt(modelIndexOf(currentModelId()));          // model
+        q.putInt(podIndexOf(selfInstanceId()));            // self_pod
+        q.putInt(exclude.favourSelf ? 1 : 0);              // flags (MMP_REQ_FAVOUR_SELF)
+        q.putInt(ThreadLocalRandom.current().nextInt());   // pick (replaces nextInt(remaining), :4981)
+        q.putLong(exclude.lastUsedTime);                   // last_used (:4951)
+        ByteBuffer x = EXTRA.get(); x.clear();
+        int nExtra = 0;                                    // the HashSet itself ∪ explicit (:4740-4743);
+        for (String iid : exclude) {                       // loaded/failed come from the model table
+            int p = podIndexOf(iid); if (p >= 0 && nExtra < 64) { x.putInt(p); nExtra++; }
+        }
+        if (exclude.explicit != null) for (String iid : exclude.explicit) {
+            int p = podIndexOf(iid); if (p >= 0 && nExtra < 64) { x.putInt(p); nExtra++; }
+        }
+        q.putInt(0); q.putInt(nExtra);                     // extra_off, n_extra
+        q.putLong(fresh.getLruTime()); q.putLong(fresh.getCapacity()); q.putLong(fresh.getUsed());
+        q.putInt(fresh.getCount()); q.putInt(fresh.getReqsPerMinute()); // 0, InstanceRecord.java:97-109
+
+        ByteBuffer o = OUT.get();
+        MmPlace.placeBatch(handle(), q, 1, x, nExtra, System.currentTimeMillis(), o); // throws on error
+        final int chosen = o.getInt(0);
+        if (chosen == MmPlace.NONE) return null;                       // :4796, :4803, :4872, :4942
+        if (chosen == MmPlace.SELF) return (T) LoadBalancer.ABORT_REQUEST; // :4894, :4932, :4990
+        final String chosenInstId = instanceIdOf(chosen);
+        // side effects stay in Java exactly as at ModelMesh.java:4992-5003
+        exclude.add(chosenInstId);
+        return (T) siMap.get(chosenInstId);
+    }
+}
