@@ -43,6 +43,20 @@ def kernel_bytes(fleet, reqs) -> int:
     return int(per.sum())
 
 
+def measured_traffic(workload: str):
+    """HBM bytes per place_batch_kernel launch from the committed rocprofv3 PMC passes of this same
+    command (profiles/rNN/pmc_place_batch_<workload>.json, written by tools/pmc_summary.py); None if
+    no PMC pass has been recorded for this workload."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_place_batch_{workload}.json"))):
+        try:
+            best = json.load(open(f)).get("traffic_bytes_per_launch")
+        except Exception:
+            pass
+    return best
+
+
 def cpu_baseline(fleet, reqs, extra, budget_s: float = 6.0):
     """The CPU restatement of the reference algorithm (oracle/, NOT the JVM) on this box's host cores."""
     from oracle.bind import OracleFleet
@@ -161,7 +175,7 @@ def main():
                                    "decision per model per step (SURVEY.md §8d synthetic fleet)",
                        "decisions_per_step_per_gpu": n, "sharding": "model axis, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload),
                          "kernel": "place_batch_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg,
                          "note": "achieved uses SURVEY.md §8(d) algorithmic bytes (32 B x P per decision: the "
