@@ -161,6 +161,53 @@ typedef struct {
     int64_t oldest_time;   /* oldestTime() after eviction, -1 if empty         */
 } mmp_evict_out;
 
+/* The request-level guards invokeModel evaluates around the two selections
+ * (SURVEY.md §8 rows a10, a11, a14, a20), batched.  One struct carries the
+ * scalar inputs of all of them; unused groups may be left zero. */
+#define MMP_GATE_FAVOUR_SELF_FOR_HITS 1u /* favourSelfForHits, MM.java:3606             */
+#define MMP_GATE_HAVE_CACHE_ENTRY 2u     /* getFromCache(...) != null, MM.java:3607-3612  */
+#define MMP_GATE_ENTRY_DONE 4u           /* cacheEntry.isDone(), MM.java:3613             */
+#define MMP_GATE_WE_CREATED_ENTRY 8u     /* weCreatedCacheEntry, MM.java:5186             */
+#define MMP_GATE_ENTRY_FAILED 16u        /* ce.isFailed(), MM.java:2886                   */
+#define MMP_GATE_HAVE_SIZE_HINT 32u      /* tas.known_size present, MM.java:5160          */
+#define MMP_GATE_PUBLISH_FORCE 64u       /* publishInstanceRecord(force, ...), MM.java:5388 */
+#define MMP_GATE_PRE_SHUTDOWN 128u
+#define MMP_GATE_FRESH_SHUTTING_DOWN 256u
+typedef struct {
+    int32_t model;
+    int32_t self_pod;
+    uint32_t flags;
+    int32_t excl_off, n_excl;         /* cache-hit (pod,loadStart) excludes filtering the copies */
+    int32_t explicit_off, n_explicit; /* explicitExcludes / load-target filter members (pod idx)  */
+    int32_t size_hint;                /* tas.known_size                                          */
+    int64_t last_used_time;
+    int64_t cache_capacity;           /* runtimeCache.capacity()                                 */
+    int64_t cache_weighted_size;      /* runtimeCache.weightedSize()                             */
+    int64_t cache_oldest_time;        /* runtimeCache.oldestTime(), -1 if empty                  */
+    int32_t loader_predicted;         /* ce.loaderPredictedWeight()                              */
+    int32_t loading_count;            /* loadingCount.get()                                      */
+    int32_t weight_predict_cutoff;    /* loadingThreads + loadingThreads/3, MM.java:5013         */
+    int32_t reserved;
+    int64_t loaded_time;              /* registry load time of the evicted copy, <0 if absent    */
+    int64_t load_timeout_ms;
+    int64_t fresh_lru, fresh_capacity, fresh_used; /* getFreshInstanceRecord(), MM.java:5369     */
+    int32_t fresh_count, fresh_loading_threads, fresh_in_progress, fresh_rpm;
+    int64_t last_published;           /* lastPublished, MM.java:5387                             */
+} mmp_gate_req;
+
+#define MMP_GATE_GO_LOCAL 1u            /* serve the hit locally, MM.java:3603-3626               */
+#define MMP_GATE_FAILURES_BREACHED 2u   /* checkLoadFailureCount would throw, MM.java:4607-4627   */
+#define MMP_GATE_LOCATIONS_BREACHED 4u  /* checkLoadLocationCount would throw, MM.java:4590-4604  */
+#define MMP_GATE_LOCAL_NOT_ALLOWED 8u   /* throwIfLocalLoadNotAllowed would throw, MM.java:4003    */
+#define MMP_GATE_CHURN_REJECT 16u       /* "Cache churn threshold exceeded", MM.java:3870-3884     */
+#define MMP_GATE_EARLY_REJECT 32u       /* loadLocal aborts before inserting, MM.java:5185-5197    */
+#define MMP_GATE_RELOAD_ELSEWHERE 64u   /* onEviction re-places the model, MM.java:2895,2919-2920  */
+#define MMP_GATE_SHOULD_PUBLISH 128u    /* publishInstanceRecord writes an update, MM.java:5397-5468 */
+typedef struct {
+    uint32_t bits;
+    int32_t initial_size; /* signed initialSize of loadLocal (negative = average-based), MM.java:5158-5179 */
+} mmp_gate_out;
+
 /* ---- lifecycle --------------------------------------------------------- */
 int mmp_abi_version(void);
 int mmp_create(const mmp_config *cfg, mmp_ctx **out);
@@ -225,6 +272,13 @@ int mmp_caches_load(mmp_ctx *ctx, int32_t n_caches, const int32_t *seg_off, cons
                     const int32_t *weight, const int64_t *capacity);
 int mmp_evict_batch(mmp_ctx *ctx, const mmp_evict_req *reqs, int32_t n, int64_t now_ms,
                     mmp_evict_out *outs);
+
+/* n guard evaluations (rows a10/a11/a14/a20). in_use_failure_expiry_ms = IN_USE_LOAD_FAILURE_EXPIRY_MS
+ * (MM.java:221). excl_pod/excl_time and explicit_pool are the pools the requests index. */
+int mmp_gate_batch(mmp_ctx *ctx, const mmp_gate_req *reqs, int32_t n, const int32_t *excl_pod,
+                   const int64_t *excl_time, int32_t n_excl_pool, const int32_t *explicit_pool,
+                   int32_t n_explicit_pool, int64_t now_ms, int64_t in_use_failure_expiry_ms,
+                   mmp_gate_out *outs);
 
 /* Wait for everything queued on the context's own stream. */
 int mmp_sync(mmp_ctx *ctx);

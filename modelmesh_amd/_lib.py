@@ -47,6 +47,19 @@ EVICT_OUT = np.dtype(
     [("insert_pos", "<i4"), ("n_victims", "<i4"), ("self_evicted", "<i4"), ("pad", "<i4"),
      ("weighted_size", "<i8"), ("oldest_time", "<i8")])
 
+GATE_REQ = np.dtype(
+    [("model", "<i4"), ("self_pod", "<i4"), ("flags", "<u4"), ("excl_off", "<i4"), ("n_excl", "<i4"),
+     ("explicit_off", "<i4"), ("n_explicit", "<i4"), ("size_hint", "<i4"), ("last_used_time", "<i8"),
+     ("cache_capacity", "<i8"), ("cache_weighted_size", "<i8"), ("cache_oldest_time", "<i8"),
+     ("loader_predicted", "<i4"), ("loading_count", "<i4"), ("weight_predict_cutoff", "<i4"), ("reserved", "<i4"),
+     ("loaded_time", "<i8"), ("load_timeout_ms", "<i8"), ("fresh_lru", "<i8"), ("fresh_capacity", "<i8"),
+     ("fresh_used", "<i8"), ("fresh_count", "<i4"), ("fresh_loading_threads", "<i4"), ("fresh_in_progress", "<i4"),
+     ("fresh_rpm", "<i4"), ("last_published", "<i8")])
+GATE_OUT = np.dtype([("bits", "<u4"), ("initial_size", "<i4")])
+assert GATE_REQ.itemsize == 144 and GATE_OUT.itemsize == 8
+GATE_GO_LOCAL, GATE_FAILURES_BREACHED, GATE_LOCATIONS_BREACHED, GATE_LOCAL_NOT_ALLOWED = 1, 2, 4, 8
+GATE_CHURN_REJECT, GATE_EARLY_REJECT, GATE_RELOAD_ELSEWHERE, GATE_SHOULD_PUBLISH = 16, 32, 64, 128
+
 assert POD_ROW.itemsize == 64 and MODEL_ROW.itemsize == 24 and PLACE_REQ.itemsize == 64
 assert PLACE_OUT.itemsize == 16 and SERVE_REQ.itemsize == 40 and SERVE_OUT.itemsize == 16
 assert STATS.itemsize == 32 and EVICT_REQ.itemsize == 16 and EVICT_OUT.itemsize == 32
@@ -80,6 +93,7 @@ SYMBOLS = [
     ("mmp_serve_batch", C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int64, _P]),
     ("mmp_caches_load", C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
     ("mmp_evict_batch", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
+    ("mmp_gate_batch", C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32, _P, C.c_int32, C.c_int64, C.c_int64, _P]),
     ("mmp_sync", C.c_int, [_P]),
 ]
 

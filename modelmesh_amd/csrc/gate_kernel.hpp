@@ -1,0 +1,208 @@
+// gate_kernel.hpp — the request-level guards invokeModel evaluates around instance selection
+// (SURVEY.md §8 rows a10, a11, a14, a20).  Pure scalar arithmetic: one lane per request, every
+// branch transcribed from the cited Java lines with Java integer semantics.
+#pragma once
+#include "aux_kernels.hpp"
+
+namespace mmp {
+
+struct GateArgs {
+    const mmp_gate_req *reqs;
+    const mmp_model_row *models;
+    const int32_t *ent_pod;
+    const int64_t *ent_time;
+    const mmp_pod_row *pods;
+    const uint64_t *allowed;        // [T][W] over pod index, as loaded by mmp_types_load
+    const uint8_t *has_allowed;     // [T]
+    const StatsAcc *stats;          // ClusterStats of the committed snapshot
+    const int32_t *excl_pod;
+    const int64_t *excl_time;
+    const int32_t *explicit_pool;
+    mmp_gate_out *outs;
+    int32_t n, n_models, P, W, T;
+    int64_t now, in_use_expiry, min_space, min_churn;
+};
+
+__device__ __forceinline__ int64_t jabs64(int64_t a) { return a < 0 ? (int64_t)(0ull - (uint64_t)a) : a; }
+__device__ __forceinline__ int32_t jabs32(int32_t a) { return a < 0 ? (int32_t)(0u - (uint32_t)a) : a; }
+
+// loadingChange / loadChange, MM.java:5536-5550
+__device__ __forceinline__ bool loading_change(int32_t cur_in_prog, int32_t cur_threads, int32_t in_prog)
+{
+    if (in_prog == cur_in_prog) return false;
+    if ((in_prog == 0) != (cur_in_prog == 0)) return true;
+    if ((in_prog <= cur_threads) != (cur_in_prog <= cur_threads)) return true;
+    return jabs32(in_prog - cur_in_prog) >= 3;
+}
+__device__ __forceinline__ bool load_change(int32_t cur_rpm, int32_t rpm)
+{
+    const int32_t diff = jabs32(cur_rpm - rpm);
+    return diff >= 100 || (cur_rpm == 0 ? rpm != 0 : (100 * diff) / cur_rpm > 10);
+}
+
+__global__ void gate_batch_kernel(GateArgs A)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    const mmp_gate_req r = A.reqs[i];
+    uint32_t bits = 0;
+    int32_t initial = 0;
+    const bool have_model = r.model >= 0 && r.model < A.n_models;
+    mmp_model_row m{};
+    if (have_model) m = A.models[r.model];
+    const int64_t total_cap = (int64_t)A.stats->total_capacity, total_free = (int64_t)A.stats->total_free;
+    const int32_t copy_count = A.stats->model_copy_count, inst_count = A.stats->instance_count;
+
+    if (have_model) {
+        // ---- goLocal, MM.java:3598-3626 over filteredInstances = copies minus MapFilteringSet excludes
+        int32_t n_f = 0;
+        bool has_local = false;
+        int64_t local_loaded = 0, oldest = INT64_MAX;
+        for (int e = 0; e < m.n_loaded; e++) {
+            const int32_t iid = A.ent_pod[m.ent_off + e];
+            const int64_t t = A.ent_time[m.ent_off + e];
+            bool filtered = false;
+            for (int x = 0; x < r.n_excl; x++) {
+                const int32_t xp = A.excl_pod[r.excl_off + x];
+                const int64_t xt = A.excl_time[r.excl_off + x];
+                if (xp == iid && (xt == MMP_ANY_TIME || xt == t)) filtered = true;
+            }
+            if (filtered) continue;
+            n_f++;
+            if (t < oldest) oldest = t;
+            if (iid == r.self_pod && !has_local) { has_local = true; local_loaded = t; }
+        }
+        bool go_local = false;
+        if (n_f > 0 && has_local) {
+            go_local = n_f == 1;
+            if (!go_local && (r.flags & MMP_GATE_FAVOUR_SELF_FOR_HITS) && (r.flags & MMP_GATE_HAVE_CACHE_ENTRY)) {
+                if (r.flags & MMP_GATE_ENTRY_DONE)
+                    go_local = true;
+                else if (oldest == local_loaded || age_of(oldest, A.now) < 1500)
+                    go_local = true;
+            }
+        }
+        if (go_local) bits |= MMP_GATE_GO_LOCAL;
+
+        // ---- checkLoadFailureCount, MM.java:4607-4627 (MAX_LOAD_FAILURES = 3)
+        {
+            int count = 0;
+            const int64_t cutoff = jsub64(A.now, A.in_use_expiry);
+            for (int e = 0; e < m.n_failed; e++) {
+                if (A.ent_time[m.ent_off + m.n_loaded + e] > cutoff) count++;
+                if (count >= 3) { bits |= MMP_GATE_FAILURES_BREACHED; break; }
+            }
+        }
+        // ---- checkLoadLocationCount, MM.java:4590-4604 (MAX_LOAD_LOCATIONS = 5)
+        {
+            int count = 0;
+            for (int e = 0; e < m.n_loaded; e++) {
+                const int32_t iid = A.ent_pod[m.ent_off + e];
+                bool excl = false;
+                for (int x = 0; x < r.n_explicit; x++)
+                    if (A.explicit_pool[r.explicit_off + x] == iid) excl = true;
+                const bool in_table = iid >= 0 && iid < A.P && !(A.pods[iid].flags & MMP_POD_TOMBSTONE);
+                if (!excl && in_table && ++count >= 5) { bits |= MMP_GATE_LOCATIONS_BREACHED; break; }
+            }
+        }
+        // ---- throwIfLocalLoadNotAllowed, MM.java:4003-4017
+        {
+            bool local_filtered = false;
+            for (int x = 0; x < r.n_explicit; x++)
+                if (A.explicit_pool[r.explicit_off + x] == r.self_pod) local_filtered = true;
+            for (int e = 0; e < m.n_loaded + m.n_failed; e++)
+                if (A.ent_pod[m.ent_off + e] == r.self_pod) local_filtered = true;
+            bool blocked = false;
+            int type = m.type;
+            if (A.T > 0 && type >= 0 && type < A.T && A.has_allowed[type]) {
+                blocked = !(r.self_pod >= 0 && r.self_pod < A.P &&
+                            ((A.allowed[(size_t)type * A.W + (r.self_pod >> 6)] >> (r.self_pod & 63)) & 1ull));
+            }
+            if (local_filtered || blocked) bits |= MMP_GATE_LOCAL_NOT_ALLOWED;
+        }
+    }
+
+    // ---- churn guard, MM.java:3870-3884
+    if (A.min_churn > 0) {
+        const int64_t remaining = jsub64(r.cache_capacity, r.cache_weighted_size);
+        if (remaining < A.min_space) {
+            const int64_t lru = r.cache_oldest_time;
+            if (lru >= 0 && lru != INT64_MAX && age_of(lru, A.now) < A.min_churn) bits |= MMP_GATE_CHURN_REJECT;
+        }
+    }
+
+    // ---- loadLocal size prediction + early reject, MM.java:5158-5197
+    if (r.flags & MMP_GATE_HAVE_SIZE_HINT) {
+        initial = r.size_hint;
+    } else if (r.loading_count > r.weight_predict_cutoff) {
+        if (copy_count >= 10) {
+            // (int)(totalCapacity - totalFree) / copyCount — the cast binds first (quirk B#7)
+            const int32_t narrowed = (int32_t)(uint32_t)(uint64_t)jsub64(total_cap, total_free);
+            const int32_t q = narrowed / copy_count;
+            initial = (int32_t)(0u - (1u + (uint32_t)q));
+        }
+    }
+    if (initial == 0) initial = r.loader_predicted;
+    {
+        const int32_t abs_size = jabs32(initial);
+        if (r.flags & MMP_GATE_WE_CREATED_ENTRY) {
+            if ((int64_t)abs_size > r.cache_capacity ||
+                (r.last_used_time > 0 && (int64_t)abs_size > jsub64(r.cache_capacity, r.cache_weighted_size) &&
+                 r.last_used_time < r.cache_oldest_time))
+                bits |= MMP_GATE_EARLY_REJECT;
+        }
+    }
+
+    // ---- onEviction reload rule, MM.java:2886-2920
+    if (!(r.flags & MMP_GATE_ENTRY_FAILED) && r.loaded_time >= 0 &&
+        jsub64(A.now, r.loaded_time) > 2 * r.load_timeout_ms) {
+        if (total_cap > 0 && inst_count > 1 && (20 * total_free) / total_cap >= 1) bits |= MMP_GATE_RELOAD_ELSEWHERE;
+    }
+
+    // ---- publishInstanceRecord hysteresis, MM.java:5397-5468
+    {
+        const int64_t FREQ = 40000, MINP = 2000;
+        const bool pre = r.flags & MMP_GATE_PRE_SHUTDOWN, force = r.flags & MMP_GATE_PUBLISH_FORCE;
+        const int64_t last_done = jsub64(A.now, r.last_published);
+        bool publish = true;
+        if (!pre && (last_done < MINP || (!force && last_done < FREQ - 1000))) {
+            publish = false;
+        } else {
+            const bool old = last_done > FREQ * 4;
+            const bool have_cur = r.self_pod >= 0 && r.self_pod < A.P && !(A.pods[r.self_pod].flags & MMP_POD_TOMBSTONE);
+            if (have_cur) {
+                const mmp_pod_row cur = A.pods[r.self_pod];
+                const bool cur_sd = cur.flags & MMP_POD_SHUTTING_DOWN, sd = r.flags & MMP_GATE_FRESH_SHUTTING_DOWN;
+                const int64_t cap = r.fresh_capacity, used = r.fresh_used, oldest = r.fresh_lru;
+                const int32_t count = r.fresh_count;
+                if (!old) {
+                    const int64_t d_lru = jabs64(jsub64(cur.lru_time, oldest));
+                    const int64_t d_cnt = jabs32(cur.count - count);
+                    int64_t fr = jsub64(cap, used);
+                    fr = fr > 0 ? fr : 0;
+                    if (cur_sd == sd && jabs64(jsub64(cur.capacity, cap)) < cap / 50 && d_lru < 20000 &&
+                        (cur.lru_time == INT64_MAX || d_lru < jsub64(A.now, cur.lru_time) / 16) && d_cnt < 10 &&
+                        (cur.count == 0 ? count == 0 : (d_cnt * 100) / cur.count < 15) &&
+                        (cur.used == 0 ? used == 0 : (jabs64(jsub64(cur.used, used)) * 100) / cur.used < 20) &&
+                        (remaining_of(cur.capacity, cur.used) < A.min_space) == (fr < A.min_space) &&
+                        cur.loading_threads == r.fresh_loading_threads &&
+                        !loading_change(cur.loading_in_progress, cur.loading_threads, r.fresh_in_progress) &&
+                        !load_change(cur.rpm, r.fresh_rpm))
+                        publish = false;
+                } else if (cur_sd == sd && cur.capacity == cap && cur.count == count && cur.lru_time == oldest &&
+                           cur.used == used && cur.loading_threads == r.fresh_loading_threads &&
+                           cur.loading_in_progress == r.fresh_in_progress && cur.rpm == r.fresh_rpm) {
+                    publish = false;
+                }
+            }
+        }
+        if (publish) bits |= MMP_GATE_SHOULD_PUBLISH;
+    }
+
+    mmp_gate_out o;
+    o.bits = bits;
+    o.initial_size = initial;
+    A.outs[i] = o;
+}
+
+}  // namespace mmp

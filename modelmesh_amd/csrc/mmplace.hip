@@ -18,6 +18,7 @@
 
 #include "../../include/mmplace.h"
 #include "aux_kernels.hpp"
+#include "gate_kernel.hpp"
 #include "place_kernel.hpp"
 #include "snapshot.hpp"
 
@@ -555,6 +556,64 @@ int mmp_serve_batch(mmp_ctx *c, const mmp_serve_req *reqs, int32_t n, const int3
     hipLaunchKernelGGL(serve_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, A);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(outs, c->s_outs.p, (size_t)n * sizeof(mmp_serve_out), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    return MMP_OK;
+}
+
+int mmp_gate_batch(mmp_ctx *c, const mmp_gate_req *reqs, int32_t n, const int32_t *excl_pod, const int64_t *excl_time,
+                   int32_t n_excl, const int32_t *explicit_pool, int32_t n_explicit, int64_t now, int64_t in_use_expiry,
+                   mmp_gate_out *outs)
+{
+    if (!c || n < 0 || n_excl < 0 || n_explicit < 0 || (n > 0 && (!reqs || !outs)) ||
+        (n_excl > 0 && (!excl_pod || !excl_time)) || (n_explicit > 0 && !explicit_pool))
+        return fail(c, MMP_EINVAL, "mmp_gate_batch: bad argument");
+    for (int32_t i = 0; i < n; i++) {
+        const mmp_gate_req &r = reqs[i];
+        if (r.n_excl < 0 || r.excl_off < 0 || (int64_t)r.excl_off + r.n_excl > n_excl || r.n_explicit < 0 ||
+            r.explicit_off < 0 || (int64_t)r.explicit_off + r.n_explicit > n_explicit)
+            return fail(c, MMP_EINVAL, "mmp_gate_batch: request %d pool range out of bounds", i);
+    }
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    if (n == 0) return MMP_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = c->stream;
+    HIP_TRY(c, c->s_reqs.ensure((size_t)n * sizeof(mmp_gate_req)));
+    HIP_TRY(c, c->s_outs.ensure((size_t)n * sizeof(mmp_gate_out)));
+    HIP_TRY(c, c->s_a.ensure((size_t)std::max(n_explicit, 1) * 4));
+    HIP_TRY(c, c->s_c.ensure((size_t)std::max(n_excl, 1) * 4));
+    HIP_TRY(c, c->s_d.ensure((size_t)std::max(n_excl, 1) * 8));
+    HIP_TRY(c, hipMemcpyAsync(c->s_reqs.p, reqs, (size_t)n * sizeof(mmp_gate_req), hipMemcpyHostToDevice, st));
+    if (n_explicit) HIP_TRY(c, hipMemcpyAsync(c->s_a.p, explicit_pool, (size_t)n_explicit * 4, hipMemcpyHostToDevice, st));
+    if (n_excl) {
+        HIP_TRY(c, hipMemcpyAsync(c->s_c.p, excl_pod, (size_t)n_excl * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->s_d.p, excl_time, (size_t)n_excl * 8, hipMemcpyHostToDevice, st));
+    }
+    GateArgs A;
+    A.reqs = c->s_reqs.as<mmp_gate_req>();
+    A.models = c->models.as<mmp_model_row>();
+    A.ent_pod = c->ent_pod.as<int32_t>();
+    A.ent_time = c->ent_time.as<int64_t>();
+    A.pods = c->sb[c->cur].pods.as<mmp_pod_row>();
+    A.allowed = c->d_allowed.as<uint64_t>();
+    A.has_allowed = c->d_has_allowed.as<uint8_t>();
+    A.stats = c->stats_acc.as<StatsAcc>();
+    A.excl_pod = c->s_c.as<int32_t>();
+    A.excl_time = c->s_d.as<int64_t>();
+    A.explicit_pool = c->s_a.as<int32_t>();
+    A.outs = c->s_outs.as<mmp_gate_out>();
+    A.n = n;
+    A.n_models = c->n_models;
+    A.P = c->snap.P;
+    A.W = c->snap.W;
+    A.T = c->n_types;
+    A.now = now;
+    A.in_use_expiry = in_use_expiry;
+    A.min_space = c->cfg.min_space_units;
+    A.min_churn = c->cfg.min_churn_age_ms;
+    hipLaunchKernelGGL(gate_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, A);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(outs, c->s_outs.p, (size_t)n * sizeof(mmp_gate_out), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     return MMP_OK;
 }

@@ -32,9 +32,6 @@ struct PlaceArgs {
     int64_t now;
 };
 
-__device__ __forceinline__ int64_t jsub64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
-__device__ __forceinline__ int64_t age_of(int64_t t, int64_t now) { return t == 0 ? 0 : jsub64(now, t); }  // MM.java:4162
-
 // (int)(double) with Java narrowing semantics
 __device__ __forceinline__ int32_t jd2i(double d)
 {

@@ -45,6 +45,10 @@ struct __attribute__((aligned(16))) RankRow {
 };
 static_assert(sizeof(RankRow) == 64, "RankRow is 64 bytes");
 
+// Java long subtraction (two's-complement wrap) and ModelMesh.age(), MM.java:4162-4164 (0 means "now")
+__device__ __forceinline__ int64_t jsub64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
+__device__ __forceinline__ int64_t age_of(int64_t t, int64_t now) { return t == 0 ? 0 : jsub64(now, t); }
+
 __device__ __forceinline__ int64_t remaining_of(int64_t cap, int64_t used)
 {
     int64_t d = (int64_t)((uint64_t)cap - (uint64_t)used);

@@ -191,5 +191,18 @@ class Solver:
         self._ck(self.lib.mmp_evict_batch(self.h, ptr(reqs), len(reqs), int(now), ptr(outs)))
         return outs
 
+    def gates(self, reqs, excl_pod, excl_time, explicit_pool, now, in_use_failure_expiry_ms=450_000) -> np.ndarray:
+        from ._lib import GATE_OUT, GATE_REQ
+        reqs = np.ascontiguousarray(reqs, dtype=GATE_REQ)
+        excl_pod = np.ascontiguousarray(excl_pod, dtype=np.int32)
+        excl_time = np.ascontiguousarray(excl_time, dtype=np.int64)
+        explicit_pool = np.ascontiguousarray(explicit_pool, dtype=np.int32)
+        outs = np.zeros(len(reqs), dtype=GATE_OUT)
+        self._ck(self.lib.mmp_gate_batch(self.h, ptr(reqs), len(reqs), ptr(excl_pod) if len(excl_pod) else None,
+                                         ptr(excl_time) if len(excl_time) else None, len(excl_pod),
+                                         ptr(explicit_pool) if len(explicit_pool) else None, len(explicit_pool),
+                                         int(now), int(in_use_failure_expiry_ms), ptr(outs)))
+        return outs
+
     def sync(self):
         self._ck(self.lib.mmp_sync(self.h))

@@ -100,6 +100,22 @@ def load() -> C.CDLL:
         lib.orc_ubm_claim_requested_space_if_ready.argtypes = [U, C.c_int32, C.c_int64]
         lib.orc_ubm_adjust_weight_after_load.argtypes = [U, C.c_int32, C.c_int32, C.c_int64]
         lib.orc_ubm_unload_complete.argtypes = [U, C.c_int32, C.c_int, C.c_int64]
+        I32, I64, VP = C.c_int32, C.c_int64, C.c_void_p
+        lib.orc_go_local.restype = C.c_int
+        lib.orc_go_local.argtypes = [VP, VP, I32, I32, C.c_int, C.c_int, C.c_int, I64]
+        lib.orc_load_failures_breached.restype = C.c_int
+        lib.orc_load_failures_breached.argtypes = [VP, I32, I64, I64]
+        lib.orc_load_locations_breached.restype = C.c_int
+        lib.orc_load_locations_breached.argtypes = [VP, I32, VP, I32, VP]
+        lib.orc_churn_reject.restype = C.c_int
+        lib.orc_churn_reject.argtypes = [I64, I64, I64, I64, I64, I64]
+        lib.orc_load_local_initial_size.restype = I32
+        lib.orc_load_local_initial_size.argtypes = [C.c_int, I32, I32, I32, I32, VP, C.c_int, I64, I64, I64, I64,
+                                                    C.POINTER(C.c_int)]
+        lib.orc_reload_elsewhere.restype = C.c_int
+        lib.orc_reload_elsewhere.argtypes = [C.c_int, I64, I64, I64, VP]
+        lib.orc_should_publish.restype = C.c_int
+        lib.orc_should_publish.argtypes = [VP, VP, I64, I64, C.c_int, C.c_int, I64]
         lib.orc_evict_eval.restype = None
         lib.orc_evict_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int64, C.c_int64,
                                        C.c_void_p]

@@ -209,6 +209,24 @@ typedef struct {
 void orc_evict_eval(const int64_t *lu, const int32_t *wt, int32_t n, int64_t capacity, int32_t weight,
                     int64_t last_used, int64_t now, orc_evict_result *out);
 
+/* ---------- request-level guards (mm_gates_oracle.c) ---------------------- */
+int orc_go_local(const int32_t *copy_pod, const int64_t *copy_loaded, int32_t n, int32_t self,
+                 int favour_self_for_hits, int have_cache_entry, int entry_done, int64_t now);
+int orc_load_failures_breached(const int64_t *fail_time, int32_t n, int64_t now, int64_t in_use_expiry_ms);
+int orc_load_locations_breached(const int32_t *loaded_pod, int32_t n, const int32_t *explicit_excl,
+                                int32_t n_explicit, const uint8_t *in_table);
+int orc_churn_reject(int64_t min_churn_age_ms, int64_t min_space_units, int64_t cache_capacity,
+                     int64_t cache_weighted_size, int64_t cache_oldest_time, int64_t now);
+int32_t orc_load_local_initial_size(int have_size_hint, int32_t size_hint, int32_t loading_count,
+                                    int32_t weight_predict_cutoff, int32_t loader_predicted,
+                                    const orc_cluster_stats *stats, int we_created_entry, int64_t last_used_time,
+                                    int64_t cache_capacity, int64_t cache_weighted_size, int64_t cache_oldest_time,
+                                    int *reject);
+int orc_reload_elsewhere(int entry_failed, int64_t loaded_time, int64_t load_timeout_ms, int64_t now,
+                         const orc_cluster_stats *stats);
+int orc_should_publish(const orc_pod *cur, const orc_pod *fresh, int64_t now, int64_t last_published,
+                       int force, int pre_shutdown, int64_t min_space_units);
+
 /* ---------- unload-buffer accounting (ModelCacheUnloadBufManager.java) -- */
 #define ORC_UBM_MAX_EVICTED 1024
 typedef struct {
