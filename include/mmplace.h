@@ -208,6 +208,18 @@ typedef struct {
     int32_t initial_size; /* signed initialSize of loadLocal (negative = average-based), MM.java:5158-5179 */
 } mmp_gate_out;
 
+/* Leader "reaper" proactive-load plan. */
+typedef struct {
+    int32_t size_estimate; /* sizeEstimate, MM.java:6622-6629                           */
+    int32_t free_count;    /* freeSpaceProactiveLoadCount, MM.java:6651                  */
+    int32_t total_count;   /* totalProactiveLoadCount, MM.java:6655                      */
+    int32_t n_candidates;  /* models passing the registry rule MM.java:6574-6577         */
+    int32_t n_selected;    /* ensureLoadedInternal calls the Java would make             */
+    int32_t error;         /* 1: sizeEstimate == 0 (the Java throws ArithmeticException) */
+    int64_t space_to_fill; /* MM.java:6633-6650                                          */
+    int64_t cutoff;        /* proactiveLastUsedCutoff, MM.java:6662-6664                 */
+} mmp_proactive_info;
+
 /* ---- lifecycle --------------------------------------------------------- */
 int mmp_abi_version(void);
 int mmp_create(const mmp_config *cfg, mmp_ctx **out);
@@ -279,6 +291,13 @@ int mmp_gate_batch(mmp_ctx *ctx, const mmp_gate_req *reqs, int32_t n, const int3
                    const int64_t *excl_time, int32_t n_excl_pool, const int32_t *explicit_pool,
                    int32_t n_explicit_pool, int64_t now_ms, int64_t in_use_failure_expiry_ms,
                    mmp_gate_out *outs);
+
+/* triggerProactiveLoadsForInstanceSubset (MM.java:6616-6747, excludeTypes == null) over the
+ * committed snapshot and the loaded model table (models in registry iteration order): which
+ * unloaded models the leader would proactively load, most recently used first. The caller then
+ * feeds them to mmp_place_batch with last_used = out_last_used[i] (MM.java:6727). */
+int mmp_proactive_plan(mmp_ctx *ctx, int32_t default_model_size_units, int64_t now_ms, int32_t max_out,
+                       int32_t *out_model, int64_t *out_last_used, mmp_proactive_info *info);
 
 /* Wait for everything queued on the context's own stream. */
 int mmp_sync(mmp_ctx *ctx);

@@ -60,6 +60,11 @@ assert GATE_REQ.itemsize == 144 and GATE_OUT.itemsize == 8
 GATE_GO_LOCAL, GATE_FAILURES_BREACHED, GATE_LOCATIONS_BREACHED, GATE_LOCAL_NOT_ALLOWED = 1, 2, 4, 8
 GATE_CHURN_REJECT, GATE_EARLY_REJECT, GATE_RELOAD_ELSEWHERE, GATE_SHOULD_PUBLISH = 16, 32, 64, 128
 
+PROACTIVE_INFO = np.dtype(
+    [("size_estimate", "<i4"), ("free_count", "<i4"), ("total_count", "<i4"), ("n_candidates", "<i4"),
+     ("n_selected", "<i4"), ("error", "<i4"), ("space_to_fill", "<i8"), ("cutoff", "<i8")])
+assert PROACTIVE_INFO.itemsize == 40
+
 assert POD_ROW.itemsize == 64 and MODEL_ROW.itemsize == 24 and PLACE_REQ.itemsize == 64
 assert PLACE_OUT.itemsize == 16 and SERVE_REQ.itemsize == 40 and SERVE_OUT.itemsize == 16
 assert STATS.itemsize == 32 and EVICT_REQ.itemsize == 16 and EVICT_OUT.itemsize == 32
@@ -94,6 +99,7 @@ SYMBOLS = [
     ("mmp_caches_load", C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
     ("mmp_evict_batch", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
     ("mmp_gate_batch", C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32, _P, C.c_int32, C.c_int64, C.c_int64, _P]),
+    ("mmp_proactive_plan", C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P]),
     ("mmp_sync", C.c_int, [_P]),
 ]
 

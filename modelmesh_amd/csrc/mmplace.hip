@@ -6,6 +6,7 @@
 // shortlisting and victim selection runs in the kernels; there is no CPU
 // implementation of the path in this library.
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
 #include <cstdarg>
@@ -20,6 +21,7 @@
 #include "aux_kernels.hpp"
 #include "gate_kernel.hpp"
 #include "place_kernel.hpp"
+#include "rebalance_kernels.hpp"
 #include "snapshot.hpp"
 
 using namespace mmp;
@@ -98,6 +100,8 @@ struct mmp_ctx {
 
     // per-call scratch for the host-pointer entry points
     DevBuf s_reqs, s_outs, s_extra, s_a, s_b, s_c, s_d;
+    // rebalancer scratch
+    DevBuf r_ps, r_counts, r_keys, r_vals, r_keys2, r_vals2, r_tmp, r_out_model, r_out_lu;
 };
 
 namespace {
@@ -201,7 +205,8 @@ void mmp_destroy(mmp_ctx *c)
     for (DevBuf *b : {&c->rank, &c->occupancy, &c->flag, &c->rs_list, &c->rs_bad, &c->d_allowed, &c->d_prefer,
                       &c->d_has_allowed, &c->stats_acc, &c->models, &c->ent_pod, &c->ent_time, &c->c_seg,
                       &c->c_lu, &c->c_wt, &c->c_cap, &c->s_reqs, &c->s_outs, &c->s_extra, &c->s_a, &c->s_b,
-                      &c->s_c, &c->s_d})
+                      &c->s_c, &c->s_d, &c->r_ps, &c->r_counts, &c->r_keys, &c->r_vals, &c->r_keys2, &c->r_vals2,
+                      &c->r_tmp, &c->r_out_model, &c->r_out_lu})
         b->release();
     delete c;
 }
@@ -615,6 +620,79 @@ int mmp_gate_batch(mmp_ctx *c, const mmp_gate_req *reqs, int32_t n, const int32_
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(outs, c->s_outs.p, (size_t)n * sizeof(mmp_gate_out), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    return MMP_OK;
+}
+
+int mmp_proactive_plan(mmp_ctx *c, int32_t default_units, int64_t now, int32_t max_out, int32_t *out_model,
+                       int64_t *out_last_used, mmp_proactive_info *info)
+{
+    if (!c || !info || max_out < 0 || (max_out > 0 && (!out_model || !out_last_used)))
+        return fail(c, MMP_EINVAL, "mmp_proactive_plan: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = c->stream;
+    const int32_t M = c->n_models, P = c->snap.P;
+    const int nb = std::max(div_up(std::max(M, 1), kCompactBlock), 1);
+    HIP_TRY(c, c->r_ps.ensure(sizeof(PlanScalars)));
+    HIP_TRY(c, c->r_counts.ensure((size_t)(nb + 1) * 4));
+    HIP_TRY(c, c->r_keys.ensure((size_t)std::max(M, 1) * 8));
+    HIP_TRY(c, c->r_keys2.ensure((size_t)std::max(M, 1) * 8));
+    HIP_TRY(c, c->r_vals.ensure((size_t)std::max(M, 1) * 4));
+    HIP_TRY(c, c->r_vals2.ensure((size_t)std::max(M, 1) * 4));
+    HIP_TRY(c, c->r_out_model.ensure((size_t)std::max(max_out, 1) * 4));
+    HIP_TRY(c, c->r_out_lu.ensure((size_t)std::max(max_out, 1) * 8));
+    PlanScalars *ps = c->r_ps.as<PlanScalars>();
+    const StatsAcc *stats = c->stats_acc.as<StatsAcc>();
+    const mmp_pod_row *pods = c->sb[c->cur].pods.as<mmp_pod_row>();
+    const mmp_model_row *models = c->models.as<mmp_model_row>();
+    int32_t *counts = c->r_counts.as<int32_t>();
+    HIP_TRY(c, hipMemsetAsync(ps, 0, sizeof(PlanScalars), st));
+    hipLaunchKernelGGL(proactive_space_kernel, dim3(std::min(std::max(div_up(P, 256), 1), 512)), dim3(256), 0, st, pods, P,
+                       stats, default_units, ps);
+    hipLaunchKernelGGL(proactive_scalars_kernel, dim3(1), dim3(64), 0, st, stats, default_units, now, ps);
+    hipLaunchKernelGGL(proactive_count_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, stats, ps, counts,
+                       &ps->n_candidates);
+    hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(256), 0, st, counts, nb, &ps->n_qualified);
+    HIP_TRY(c, hipGetLastError());
+    PlanScalars h{};
+    HIP_TRY(c, hipMemcpyAsync(&h, ps, sizeof h, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    const int32_t nq = h.n_qualified;
+    if (nq > 0) {
+        hipLaunchKernelGGL(proactive_scatter_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, stats, ps, counts,
+                           c->r_keys.as<int64_t>(), c->r_vals.as<int32_t>());
+        // stable descending radix sort: equal lastUsed keep registry order, so the first one seen wins
+        size_t tmp_bytes = 0;
+        HIP_TRY(c, rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, c->r_keys.as<int64_t>(), c->r_keys2.as<int64_t>(),
+                                                  c->r_vals.as<int32_t>(), c->r_vals2.as<int32_t>(), (size_t)nq, 0, 64, st));
+        HIP_TRY(c, c->r_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
+        HIP_TRY(c, rocprim::radix_sort_pairs_desc(c->r_tmp.p, tmp_bytes, c->r_keys.as<int64_t>(), c->r_keys2.as<int64_t>(),
+                                                  c->r_vals.as<int32_t>(), c->r_vals2.as<int32_t>(), (size_t)nq, 0, 64, st));
+        const int nb2 = div_up(nq, kCompactBlock);
+        hipLaunchKernelGGL(distinct_count_kernel, dim3(nb2), dim3(kCompactBlock), 0, st, c->r_keys2.as<int64_t>(), nq, counts);
+        hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(256), 0, st, counts, nb2, &ps->n_distinct);
+        hipLaunchKernelGGL(distinct_scatter_kernel, dim3(nb2), dim3(kCompactBlock), 0, st, c->r_keys2.as<int64_t>(),
+                           c->r_vals2.as<int32_t>(), nq, counts, ps, max_out, c->r_out_model.as<int32_t>(),
+                           c->r_out_lu.as<int64_t>());
+        hipLaunchKernelGGL(proactive_final_kernel, dim3(1), dim3(64), 0, st, ps);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(&h, ps, sizeof h, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        const int32_t n_copy = std::min(h.n_selected, max_out);
+        if (n_copy > 0) {
+            HIP_TRY(c, hipMemcpy(out_model, c->r_out_model.p, (size_t)n_copy * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy(out_last_used, c->r_out_lu.p, (size_t)n_copy * 8, hipMemcpyDeviceToHost));
+        }
+    }
+    info->size_estimate = h.size_estimate;
+    info->free_count = h.free_count;
+    info->total_count = h.total_count;
+    info->n_candidates = h.n_candidates;
+    info->n_selected = h.n_selected;
+    info->error = h.error;
+    info->space_to_fill = h.space_to_fill;
+    info->cutoff = h.cutoff;
     return MMP_OK;
 }
 

@@ -204,5 +204,16 @@ class Solver:
                                          int(now), int(in_use_failure_expiry_ms), ptr(outs)))
         return outs
 
+    def proactive_plan(self, default_model_size_units: int, now: int, max_out: int):
+        """a17: (models, last_used, info) the leader would proactively load, MRU first."""
+        from ._lib import PROACTIVE_INFO
+        om = np.zeros(max(max_out, 1), np.int32)
+        ol = np.zeros(max(max_out, 1), np.int64)
+        info = np.zeros(1, dtype=PROACTIVE_INFO)
+        self._ck(self.lib.mmp_proactive_plan(self.h, int(default_model_size_units), int(now), int(max_out),
+                                             ptr(om), ptr(ol), ptr(info)))
+        n = min(int(info[0]["n_selected"]), max_out)
+        return om[:n].copy(), ol[:n].copy(), info[0]
+
     def sync(self):
         self._ck(self.lib.mmp_sync(self.h))

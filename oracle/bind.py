@@ -116,6 +116,8 @@ def load() -> C.CDLL:
         lib.orc_reload_elsewhere.argtypes = [C.c_int, I64, I64, I64, VP]
         lib.orc_should_publish.restype = C.c_int
         lib.orc_should_publish.argtypes = [VP, VP, I64, I64, C.c_int, C.c_int, I64]
+        lib.orc_proactive_plan.restype = C.c_int32
+        lib.orc_proactive_plan.argtypes = [VP, I32, VP, VP, I32, I32, I64, VP, VP, I32, VP]
         lib.orc_evict_eval.restype = None
         lib.orc_evict_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int64, C.c_int64,
                                        C.c_void_p]
@@ -301,3 +303,24 @@ class CCache:
     # unload-buffer manager
     def evicted(self):
         return [int(self.u.evicted[i]) for i in range(self.u.n_evicted)]
+
+
+ORC_PROACTIVE_INFO = np.dtype(
+    [("size_estimate", "<i4"), ("free_count", "<i4"), ("total_count", "<i4"), ("n_candidates", "<i4"),
+     ("n_selected", "<i4"), ("error", "<i4"), ("space_to_fill", "<i8"), ("cutoff", "<i8")])
+
+
+def proactive_plan(fleet, default_units, now, max_out):
+    """a17 on the oracle: returns (models, last_used, info)."""
+    lib = load()
+    orc = OracleFleet(fleet)
+    stats = np.zeros(1, dtype=ORC_STATS)
+    stats[0] = orc.stats()
+    om = np.zeros(max(max_out, 1), np.int32)
+    ol = np.zeros(max(max_out, 1), np.int64)
+    info = np.zeros(1, dtype=ORC_PROACTIVE_INFO)
+    models = np.ascontiguousarray(fleet.models)
+    n = lib.orc_proactive_plan(_p(orc.pods), len(orc.pods), _p(stats), _p(models), len(models), int(default_units),
+                               int(now), _p(om), _p(ol), int(max_out), _p(info))
+    n = min(n, max_out)
+    return om[:n].copy(), ol[:n].copy(), info[0]

@@ -227,6 +227,22 @@ int orc_reload_elsewhere(int entry_failed, int64_t loaded_time, int64_t load_tim
 int orc_should_publish(const orc_pod *cur, const orc_pod *fresh, int64_t now, int64_t last_published,
                        int force, int pre_shutdown, int64_t min_space_units);
 
+/* ---------- batch rebalancers (mm_rebalance_oracle.c) --------------------- */
+typedef struct {
+    int32_t size_estimate; /* sizeEstimate, MM.java:6622-6629             */
+    int32_t free_count;    /* freeSpaceProactiveLoadCount, :6651           */
+    int32_t total_count;   /* totalProactiveLoadCount, :6655               */
+    int32_t n_candidates;  /* |proactiveLoadCandidates|, :6574-6577        */
+    int32_t n_selected;    /* ensureLoadedInternal calls made, :6709-6734  */
+    int32_t error;         /* 1: sizeEstimate == 0 (ArithmeticException)   */
+    int64_t space_to_fill; /* after the /2, :6650                          */
+    int64_t cutoff;        /* proactiveLastUsedCutoff, :6662-6664          */
+} orc_proactive_info;
+int32_t orc_proactive_plan(const orc_pod *pods, int32_t n_pods, const orc_cluster_stats *stats,
+                           const orc_flat_model *models, int32_t n_models, int32_t default_model_size_units,
+                           int64_t now, int32_t *out_model, int64_t *out_last_used, int32_t max_out,
+                           orc_proactive_info *info);
+
 /* ---------- unload-buffer accounting (ModelCacheUnloadBufManager.java) -- */
 #define ORC_UBM_MAX_EVICTED 1024
 typedef struct {
