@@ -220,6 +220,59 @@ typedef struct {
     int64_t cutoff;        /* proactiveLastUsedCutoff, MM.java:6662-6664                 */
 } mmp_proactive_info;
 
+/* One local CacheEntry as the rebalancers see it (rows a15, a16, a21) — 56 bytes. */
+#define MMP_CE_FAILED 1u /* ce == null || ce.isFailed() */
+typedef struct {
+    int32_t model;                 /* registry row, -1 if registry.get(modelId) == null */
+    int32_t weight;                /* ce.getWeight()                                    */
+    int64_t last_used;             /* cache last-used time                              */
+    int64_t interval_count;        /* getAndResetIntervalCount() / getIntervalCount()   */
+    int64_t last_heavy_time;       /* ce.getLastHeavyTime()                             */
+    int64_t last_unload_time;      /* mr.getLastUnloadTime()                            */
+    int32_t earlier_use_iteration; /* ce.earlierUseIteration                            */
+    int32_t last_used_iteration;   /* ce.lastUsedIteration                              */
+    uint32_t flags;
+    int32_t reserved;
+} mmp_cache_entry;
+
+/* rateTrackingTask (MM.java:5636-5832), limitModelConcurrency == false. */
+typedef struct {
+    int32_t self_pod;
+    int32_t iteration_counter;
+    int32_t second_copy_max_age_iters; /* MM.java:5621 */
+    int32_t second_copy_min_age_iters; /* MM.java:5622 */
+    int32_t scale_up_rpm_threshold;    /* MM.java:240  */
+    int32_t our_rpm;                   /* invokeCounter.getBusyness(), MM.java:5837 */
+    int64_t now;
+    int64_t last_check_time;
+    int64_t rate_check_interval_ms;        /* MM.java:238  */
+    int64_t second_copy_lru_threshold_ms;  /* MM.java:5628 */
+    int64_t assume_completed_ms;           /* loadingTimeStats(type).assumeCompletedAfterMillis() */
+} mmp_scaleup_params;
+#define MMP_SCALE_NONE 0
+#define MMP_SCALE_SECOND_COPY 1 /* ensureLoadedInternalAsync(id, lastTime, w, excludeThisInstance, 0), MM.java:5755 */
+#define MMP_SCALE_UP 2          /* ensureLoadedInternalAsync(id, now+20s, w, exclude, copies-1), MM.java:5805     */
+typedef struct {
+    int32_t action;
+    int32_t copies;    /* copiesToLoad */
+    int64_t timestamp; /* lastUsedTime to pass to the load-target decision */
+    int32_t new_i1, new_i2; /* updated earlierUseIteration / lastUsedIteration */
+    int32_t heavy;     /* ce.setLastHeavyTime(now) */
+    int32_t rpm;
+} mmp_scaleup_out;
+
+/* janitor scale-down (MM.java:6110-6145, removeModelCopies :6197-6310). */
+typedef struct {
+    int32_t self_pod;
+    int32_t shutting_down;
+    int64_t now;
+    int64_t last_check_time;
+    int64_t rate_check_interval_ms;
+    int64_t adjusted_cache_capacity; /* getAdjustedCacheCapacity(), MM.java:6117 */
+    int32_t scale_up_rpm_threshold;
+    int32_t reserved;
+} mmp_scaledown_params;
+
 /* ---- lifecycle --------------------------------------------------------- */
 int mmp_abi_version(void);
 int mmp_create(const mmp_config *cfg, mmp_ctx **out);
@@ -298,6 +351,21 @@ int mmp_gate_batch(mmp_ctx *ctx, const mmp_gate_req *reqs, int32_t n, const int3
  * feeds them to mmp_place_batch with last_used = out_last_used[i] (MM.java:6727). */
 int mmp_proactive_plan(mmp_ctx *ctx, int32_t default_model_size_units, int64_t now_ms, int32_t max_out,
                        int32_t *out_model, int64_t *out_last_used, mmp_proactive_info *info);
+
+/* a15: entries = usedSinceLastRun (runtimeCache.descendingMapWithCutoff(lastTime)) in iteration order.
+ * overloaded_out has one byte per pod = membership in getExcludeSet() (MM.java:5835-5856); for
+ * MMP_SCALE_UP rows the caller passes those pods as extra excludes of the load-target decisions.
+ * *skipped = 1 when the task returns before looking at the entries (MM.java:5646, :5658). */
+int mmp_scaleup_plan(mmp_ctx *ctx, const mmp_cache_entry *entries, int32_t n, const mmp_scaleup_params *params,
+                     mmp_scaleup_out *outs, uint8_t *overloaded_out, int32_t *skipped);
+/* a16: entries = scaleCopiesCandidates, oldest first; removed_out[i] = this copy is removed. */
+int mmp_scaledown_plan(mmp_ctx *ctx, const mmp_cache_entry *entries, int32_t n,
+                       const mmp_scaledown_params *params, uint8_t *removed_out);
+/* a21: entries = runtimeCache.descendingLruMap() (MRU first). action_out[i] = 1:
+ * triggerNewModelCopyElsewhere (MM.java:6913-6928) is issued with lastUsedTime = entry.last_used
+ * and excludes = current holders ∪ self; wait_out[i] = 1: shutdown waits for it (CUTOFF_AGE_MS). */
+int mmp_migration_plan(mmp_ctx *ctx, const mmp_cache_entry *entries, int32_t n, int32_t self_pod, int64_t now_ms,
+                       int64_t cutoff_age_ms, uint8_t *action_out, uint8_t *wait_out);
 
 /* Wait for everything queued on the context's own stream. */
 int mmp_sync(mmp_ctx *ctx);

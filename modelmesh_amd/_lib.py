@@ -65,6 +65,24 @@ PROACTIVE_INFO = np.dtype(
      ("n_selected", "<i4"), ("error", "<i4"), ("space_to_fill", "<i8"), ("cutoff", "<i8")])
 assert PROACTIVE_INFO.itemsize == 40
 
+CACHE_ENTRY = np.dtype(
+    [("model", "<i4"), ("weight", "<i4"), ("last_used", "<i8"), ("interval_count", "<i8"), ("last_heavy_time", "<i8"),
+     ("last_unload_time", "<i8"), ("earlier_use_iteration", "<i4"), ("last_used_iteration", "<i4"), ("flags", "<u4"),
+     ("reserved", "<i4")])
+SCALEUP_PARAMS = np.dtype(
+    [("self_pod", "<i4"), ("iteration_counter", "<i4"), ("second_copy_max_age_iters", "<i4"),
+     ("second_copy_min_age_iters", "<i4"), ("scale_up_rpm_threshold", "<i4"), ("our_rpm", "<i4"), ("now", "<i8"),
+     ("last_check_time", "<i8"), ("rate_check_interval_ms", "<i8"), ("second_copy_lru_threshold_ms", "<i8"),
+     ("assume_completed_ms", "<i8")])
+SCALEUP_OUT = np.dtype([("action", "<i4"), ("copies", "<i4"), ("timestamp", "<i8"), ("new_i1", "<i4"),
+                        ("new_i2", "<i4"), ("heavy", "<i4"), ("rpm", "<i4")])
+SCALEDOWN_PARAMS = np.dtype(
+    [("self_pod", "<i4"), ("shutting_down", "<i4"), ("now", "<i8"), ("last_check_time", "<i8"),
+     ("rate_check_interval_ms", "<i8"), ("adjusted_cache_capacity", "<i8"), ("scale_up_rpm_threshold", "<i4"),
+     ("reserved", "<i4")])
+assert CACHE_ENTRY.itemsize == 56 and SCALEUP_PARAMS.itemsize == 64 and SCALEUP_OUT.itemsize == 32
+assert SCALEDOWN_PARAMS.itemsize == 48
+
 assert POD_ROW.itemsize == 64 and MODEL_ROW.itemsize == 24 and PLACE_REQ.itemsize == 64
 assert PLACE_OUT.itemsize == 16 and SERVE_REQ.itemsize == 40 and SERVE_OUT.itemsize == 16
 assert STATS.itemsize == 32 and EVICT_REQ.itemsize == 16 and EVICT_OUT.itemsize == 32
@@ -100,6 +118,9 @@ SYMBOLS = [
     ("mmp_evict_batch", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
     ("mmp_gate_batch", C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32, _P, C.c_int32, C.c_int64, C.c_int64, _P]),
     ("mmp_proactive_plan", C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P]),
+    ("mmp_scaleup_plan", C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32)]),
+    ("mmp_scaledown_plan", C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    ("mmp_migration_plan", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _P, _P]),
     ("mmp_sync", C.c_int, [_P]),
 ]
 

@@ -696,6 +696,120 @@ int mmp_proactive_plan(mmp_ctx *c, int32_t default_units, int64_t now, int32_t m
     return MMP_OK;
 }
 
+int mmp_scaleup_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, const mmp_scaleup_params *p,
+                     mmp_scaleup_out *outs, uint8_t *overloaded_out, int32_t *skipped)
+{
+    if (!c || !p || !skipped || n < 0 || (n > 0 && (!entries || !outs)))
+        return fail(c, MMP_EINVAL, "mmp_scaleup_plan: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    const int32_t P = c->snap.P;
+    if (P > 0 && !overloaded_out) return fail(c, MMP_EINVAL, "mmp_scaleup_plan: overloaded_out is null");
+    if (P > 0) memset(overloaded_out, 0, (size_t)P);
+    for (int32_t i = 0; i < n; i++) {
+        outs[i] = mmp_scaleup_out{};
+        outs[i].new_i1 = entries[i].earlier_use_iteration;
+        outs[i].new_i2 = entries[i].last_used_iteration;
+    }
+    // the three early returns of the task, MM.java:5646-5648, :5658-5660, :5667-5669
+    const int64_t time_delta = (int64_t)((uint64_t)p->now - (uint64_t)p->last_check_time);
+    *skipped = (time_delta * 5 < p->rate_check_interval_ms * 3 || c->stats.instance_count < 2 || n == 0) ? 1 : 0;
+    if (*skipped) return MMP_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = c->stream;
+    HIP_TRY(c, c->s_reqs.ensure((size_t)n * sizeof(mmp_cache_entry)));
+    HIP_TRY(c, c->s_outs.ensure((size_t)n * sizeof(mmp_scaleup_out)));
+    HIP_TRY(c, c->s_a.ensure((size_t)std::max(P, 1)));
+    HIP_TRY(c, c->s_b.ensure(sizeof(int32_t)));
+    HIP_TRY(c, hipMemcpyAsync(c->s_reqs.p, entries, (size_t)n * sizeof(mmp_cache_entry), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(c->s_b.p, 0, sizeof(int32_t), st));
+    const int32_t a = (int32_t)((uint32_t)p->scale_up_rpm_threshold * 4u);
+    const int32_t b = (int32_t)((uint32_t)p->our_rpm - 2u * (uint32_t)p->scale_up_rpm_threshold);
+    const mmp_pod_row *pods = c->sb[c->cur].pods.as<mmp_pod_row>();
+    if (P > 0)
+        hipLaunchKernelGGL(overloaded_pods_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, pods, P, p->self_pod,
+                           a > b ? a : b, c->s_a.as<uint8_t>(), c->s_b.as<int32_t>());
+    ScaleupArgs A;
+    A.entries = c->s_reqs.as<mmp_cache_entry>();
+    A.models = c->models.as<mmp_model_row>();
+    A.ent_pod = c->ent_pod.as<int32_t>();
+    A.ent_time = c->ent_time.as<int64_t>();
+    A.stats = c->stats_acc.as<StatsAcc>();
+    A.overloaded = c->s_a.as<uint8_t>();
+    A.excluded_count = c->s_b.as<int32_t>();
+    A.outs = c->s_outs.as<mmp_scaleup_out>();
+    A.p = *p;
+    A.n = n;
+    A.n_models = c->n_models;
+    A.P = P;
+    hipLaunchKernelGGL(scaleup_plan_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, A);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(outs, c->s_outs.p, (size_t)n * sizeof(mmp_scaleup_out), hipMemcpyDeviceToHost, st));
+    if (P > 0) HIP_TRY(c, hipMemcpyAsync(overloaded_out, c->s_a.p, (size_t)P, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    return MMP_OK;
+}
+
+int mmp_scaledown_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, const mmp_scaledown_params *p,
+                       uint8_t *removed_out)
+{
+    if (!c || !p || n < 0 || (n > 0 && (!entries || !removed_out)))
+        return fail(c, MMP_EINVAL, "mmp_scaledown_plan: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    if (n == 0) return MMP_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = c->stream;
+    HIP_TRY(c, c->s_reqs.ensure((size_t)n * sizeof(mmp_cache_entry)));
+    HIP_TRY(c, c->s_a.ensure((size_t)n));
+    HIP_TRY(c, c->s_b.ensure((size_t)n));
+    HIP_TRY(c, hipMemcpyAsync(c->s_reqs.p, entries, (size_t)n * sizeof(mmp_cache_entry), hipMemcpyHostToDevice, st));
+    ScaledownArgs A;
+    A.entries = c->s_reqs.as<mmp_cache_entry>();
+    A.models = c->models.as<mmp_model_row>();
+    A.ent_pod = c->ent_pod.as<int32_t>();
+    A.ent_time = c->ent_time.as<int64_t>();
+    A.pods = c->sb[c->cur].pods.as<mmp_pod_row>();
+    A.pos_of = c->snap.pos_of;
+    A.stats = c->stats_acc.as<StatsAcc>();
+    A.decide = c->s_a.as<uint8_t>();
+    A.removed = c->s_b.as<uint8_t>();
+    A.p = *p;
+    A.n = n;
+    A.n_models = c->n_models;
+    A.P = c->snap.P;
+    hipLaunchKernelGGL(scaledown_decide_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(scaledown_budget_kernel, dim3(1), dim3(64), 0, st, A);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(removed_out, c->s_b.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    return MMP_OK;
+}
+
+int mmp_migration_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, int32_t self_pod, int64_t now,
+                       int64_t cutoff_age_ms, uint8_t *action_out, uint8_t *wait_out)
+{
+    if (!c || n < 0 || (n > 0 && (!entries || !action_out || !wait_out)))
+        return fail(c, MMP_EINVAL, "mmp_migration_plan: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    if (n == 0) return MMP_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = c->stream;
+    HIP_TRY(c, c->s_reqs.ensure((size_t)n * sizeof(mmp_cache_entry)));
+    HIP_TRY(c, c->s_a.ensure((size_t)n));
+    HIP_TRY(c, c->s_b.ensure((size_t)n));
+    HIP_TRY(c, hipMemcpyAsync(c->s_reqs.p, entries, (size_t)n * sizeof(mmp_cache_entry), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(migration_plan_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, c->s_reqs.as<mmp_cache_entry>(), n,
+                       c->models.as<mmp_model_row>(), c->n_models, c->ent_pod.as<int32_t>(), self_pod,
+                       (int64_t)((uint64_t)now - (uint64_t)cutoff_age_ms), c->s_a.as<uint8_t>(), c->s_b.as<uint8_t>());
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(action_out, c->s_a.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(wait_out, c->s_b.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    return MMP_OK;
+}
+
 int mmp_caches_load(mmp_ctx *c, int32_t n_caches, const int32_t *seg_off, const int64_t *last_used,
                     const int32_t *weight, const int64_t *capacity)
 {

@@ -240,3 +240,237 @@ __global__ void proactive_final_kernel(PlanScalars *ps)
 }
 
 }  // namespace mmp
+
+namespace mmp {
+
+// ---- a15 ---------------------------------------------------------------------------------------
+// getExcludeSet(), MM.java:5835-5856: pods of clusterState (present rows) other than self whose
+// published rpm exceeds max(4*threshold, ourRpm - 2*threshold)
+__global__ void overloaded_pods_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int32_t self_pod,
+                                       int32_t max_rpm, uint8_t *__restrict__ overloaded, int32_t *__restrict__ count)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    bool ov = false;
+    if (p < P) {
+        const mmp_pod_row r = pods[p];
+        ov = !(r.flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE)) && p != self_pod && r.rpm > max_rpm;
+        overloaded[p] = ov ? 1 : 0;
+    }
+    const int c = __popcll(__ballot(ov));
+    if (lane_id() == 0 && c) atomicAdd(count, c);
+}
+
+struct ScaleupArgs {
+    const mmp_cache_entry *entries;
+    const mmp_model_row *models;
+    const int32_t *ent_pod;
+    const int64_t *ent_time;
+    const StatsAcc *stats;
+    const uint8_t *overloaded;
+    const int32_t *excluded_count;
+    mmp_scaleup_out *outs;
+    mmp_scaleup_params p;
+    int32_t n, n_models, P;
+};
+
+// loadedSince, MM.java:5860-5871
+__device__ __forceinline__ bool loaded_since(const int32_t *pods, const int64_t *times, int n, int64_t cutoff,
+                                             int32_t ignore)
+{
+    for (int i = 0; i < n; i++) {
+        if (ignore >= 0 && pods[i] == ignore) continue;
+        if (times[i] > cutoff) return true;
+    }
+    return false;
+}
+
+// rateTrackingTask body for one used-since-last-run entry, MM.java:5687-5806
+__global__ void scaleup_plan_kernel(ScaleupArgs A)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= A.n) return;
+    const mmp_cache_entry ce = A.entries[e];
+    const mmp_scaleup_params &p = A.p;
+    mmp_scaleup_out o;
+    o.action = MMP_SCALE_NONE;
+    o.copies = 0;
+    o.timestamp = 0;
+    o.new_i1 = ce.earlier_use_iteration;
+    o.new_i2 = ce.last_used_iteration;
+    o.heavy = 0;
+    const int64_t time_delta = jsub64(p.now, p.last_check_time);
+    const int32_t lower = p.iteration_counter - p.second_copy_max_age_iters;
+    const int32_t upper = p.iteration_counter - p.second_copy_min_age_iters;
+    const int32_t suitable = A.stats->instance_count;
+    const int32_t scale_up = p.scale_up_rpm_threshold;
+    const int32_t heavy = (int32_t)((uint32_t)scale_up * 3u) / 4;
+    const int32_t rpm = (int32_t)((ce.interval_count * 60000) / time_delta);
+    o.rpm = rpm;
+    if (rpm > heavy) o.heavy = 1;
+    do {
+        if (ce.model < 0 || ce.model >= A.n_models) break;
+        const mmp_model_row mr = A.models[ce.model];
+        const int32_t loaded = mr.n_loaded, failed = mr.n_failed;
+        if (loaded == 0) break;
+        int32_t cand = suitable - (loaded + failed);
+        if (cand <= 0) break;
+        const int32_t *lp = A.ent_pod + mr.ent_off;
+        const int64_t *lt = A.ent_time + mr.ent_off;
+        if (loaded == 1) {  // :5726-5758
+            const int32_t i1 = ce.earlier_use_iteration, i2 = ce.last_used_iteration;
+            bool i1in = false, i2in = false;
+            if (i2 >= lower && i1 <= upper) {
+                i1in = i1 >= lower;
+                i2in = i2 <= upper;
+            }
+            if (i2in || !i1in) o.new_i1 = i2;
+            o.new_i2 = p.iteration_counter;
+            if (i1in || i2in) {
+                const int64_t tc = (int64_t)A.stats->total_capacity, tf = (int64_t)A.stats->total_free;
+                if (tc == 0) break;  // the Java throws ArithmeticException here; caught, entry skipped
+                if ((10 * tf) / tc >= 1 || jsub64(p.now, A.stats->global_lru) > p.second_copy_lru_threshold_ms) {
+                    o.action = MMP_SCALE_SECOND_COPY;
+                    o.timestamp = p.last_check_time;
+                    o.copies = 1;
+                    break;
+                }
+            }
+        }
+        if (rpm < scale_up) break;
+        if (scale_up == 0) break;
+        const int64_t recent = jsub64(p.now, time_delta + p.rate_check_interval_ms + 2 * p.assume_completed_ms);
+        if (loaded_since(lp, lt, loaded, recent, p.self_pod)) break;
+        const int32_t excluded = *A.excluded_count;
+        if (excluded != 0) {  // :5776-5787
+            int32_t members = 0;  // excluded pods that ARE in loaded ∪ failed
+            for (int k = 0; k < loaded + failed; k++) {
+                const int32_t iid = lp[k];
+                if (iid >= 0 && iid < A.P && A.overloaded[iid]) members++;
+            }
+            cand -= (excluded - members);
+            cand -= excluded;
+            if (cand <= 0) break;
+        }
+        int32_t copies = rpm / scale_up < cand ? rpm / scale_up : cand;
+        if (copies > 2) copies = copies < suitable / 3 ? copies : suitable / 3;
+        o.action = MMP_SCALE_UP;
+        o.copies = copies;
+        o.timestamp = p.now + 20000;
+    } while (false);
+    A.outs[e] = o;
+}
+
+// ---- a16 ---------------------------------------------------------------------------------------
+struct ScaledownArgs {
+    const mmp_cache_entry *entries;
+    const mmp_model_row *models;
+    const int32_t *ent_pod;
+    const int64_t *ent_time;
+    const mmp_pod_row *pods;
+    const int32_t *pos_of;
+    const StatsAcc *stats;
+    uint8_t *decide;   // per entry: removeModelCopies would remove if canRemove
+    uint8_t *removed;  // final
+    mmp_scaledown_params p;
+    int32_t n, n_models, P;
+};
+
+// removeModelCopies with canRemove == true, MM.java:6197-6310 — everything except the running budget
+__global__ void scaledown_decide_kernel(ScaledownArgs A)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= A.n) return;
+    const mmp_cache_entry ce = A.entries[e];
+    const mmp_scaledown_params &p = A.p;
+    bool removed = false;
+    do {
+        if (ce.last_used == 0 || ce.model < 0 || ce.model >= A.n_models) break;
+        const mmp_model_row mr = A.models[ce.model];
+        const int32_t num = mr.n_loaded;
+        if (num < 2) break;
+        const int64_t tc = (int64_t)A.stats->total_capacity, tf = (int64_t)A.stats->total_free;
+        if (tc == 0 || tf * 100 / tc > 5) break;  // :6229
+        const int32_t *lp = A.ent_pod + mr.ent_off;
+        const int64_t *lt = A.ent_time + mr.ent_off;
+        int32_t other = -1;
+        for (int k = 0; k < num; k++) {
+            const int32_t iid = lp[k];
+            if (iid != p.self_pod && iid >= 0 && iid < A.P &&
+                !(A.pods[iid].flags & (MMP_POD_TOMBSTONE | MMP_POD_SHUTTING_DOWN))) {
+                other = iid;
+                break;
+            }
+        }
+        if (other < 0) break;
+        const int64_t glru = A.stats->global_lru;
+        if (num == 2) {
+            const int64_t cache_age = jsub64(p.now, glru);
+            int64_t sda = cache_age / 10;
+            if (ce.last_heavy_time == 0 || jsub64(p.now, ce.last_heavy_time) < cache_age / 5)
+                sda = 36000000LL < sda ? 36000000LL : sda;  // SECOND_COPY_REMOVE_MAX_AGE_MS, MM.java:257
+            if (jsub64(p.now, ce.last_used) > sda) {
+                const bool self_ok = p.self_pod >= 0 && p.self_pod < A.P &&
+                                     !(A.pods[p.self_pod].flags & (MMP_POD_TOMBSTONE | MMP_POD_SHUTTING_DOWN));
+                if (!self_ok) break;
+                if (A.pos_of[other] > A.pos_of[p.self_pod]) break;  // PLACEMENT_ORDER.compare(other, this) > 0
+                removed = true;
+            }
+        } else {
+            if (ce.last_unload_time > 0 && jsub64(p.now, ce.last_unload_time) < 8 * p.rate_check_interval_ms) break;
+            if (loaded_since(lp, lt, num, p.now - 1800000, -1)) break;
+            int64_t min_age = (int64_t)(3ull * (uint64_t)glru + 10400000ull) / 100;  // absolute timestamp: quirk B#13
+            min_age = min_age < 600000 ? 600000 : (min_age > 18000000 ? 18000000 : min_age);
+            if (jsub64(p.now, ce.last_heavy_time) < min_age) break;
+            const int64_t since = jsub64(p.now, p.last_check_time);
+            if (since < p.rate_check_interval_ms / 10) break;
+            const int64_t rpm = ce.interval_count == 0 ? 0 : (60000 * ce.interval_count) / since;
+            if (rpm > ((int64_t)p.scale_up_rpm_threshold * 2) / 3) break;
+            removed = true;
+        }
+    } while (false);
+    A.decide[e] = removed ? 1 : 0;
+}
+
+// the janitor's running allowance, MM.java:6117-6136: a serial recurrence over the (short) list
+__global__ void scaledown_budget_kernel(ScaledownArgs A)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int64_t max_weight = A.p.adjusted_cache_capacity / 20;
+    int32_t removed_count = 0;
+    for (int e = 0; e < A.n; e++) {
+        const int32_t w = A.entries[e].weight;
+        const bool can = removed_count == 0 || w <= max_weight;
+        const bool rem = !A.p.shutting_down && can && A.decide[e];
+        A.removed[e] = rem ? 1 : 0;
+        if (rem) {
+            removed_count++;
+            max_weight -= w;
+        }
+    }
+}
+
+// ---- a21 ---------------------------------------------------------------------------------------
+__global__ void migration_plan_kernel(const mmp_cache_entry *__restrict__ entries, int32_t n,
+                                      const mmp_model_row *__restrict__ models, int32_t n_models,
+                                      const int32_t *__restrict__ ent_pod, int32_t self_pod, int64_t cutoff,
+                                      uint8_t *__restrict__ action, uint8_t *__restrict__ wait)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const mmp_cache_entry ce = entries[e];
+    uint8_t a = 0, w = 0;
+    if (ce.model >= 0 && ce.model < n_models && !(ce.flags & MMP_CE_FAILED)) {
+        const mmp_model_row mr = models[ce.model];
+        bool has_us = false;
+        for (int k = 0; k < mr.n_loaded; k++)
+            if (ent_pod[mr.ent_off + k] == self_pod) has_us = true;  // :7008
+        if (has_us && ce.last_used > 0) {
+            a = 1;
+            w = ce.last_used >= cutoff ? 1 : 0;
+        }
+    }
+    action[e] = a;
+    wait[e] = w;
+}
+
+}  // namespace mmp

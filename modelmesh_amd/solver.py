@@ -215,5 +215,35 @@ class Solver:
         n = min(int(info[0]["n_selected"]), max_out)
         return om[:n].copy(), ol[:n].copy(), info[0]
 
+    def scaleup_plan(self, entries, params):
+        """a15: (outs, overloaded[P], skipped)"""
+        from ._lib import CACHE_ENTRY, SCALEUP_OUT, SCALEUP_PARAMS
+        entries = np.ascontiguousarray(entries, dtype=CACHE_ENTRY)
+        params = np.ascontiguousarray(params, dtype=SCALEUP_PARAMS).reshape(1)
+        outs = np.zeros(len(entries), dtype=SCALEUP_OUT)
+        ov = np.zeros(max(self.n_pods, 1), np.uint8)
+        sk = C.c_int32(0)
+        self._ck(self.lib.mmp_scaleup_plan(self.h, ptr(entries) if len(entries) else None, len(entries), ptr(params),
+                                           ptr(outs) if len(entries) else None, ptr(ov), C.byref(sk)))
+        return outs, ov[: self.n_pods], sk.value
+
+    def scaledown_plan(self, entries, params):
+        from ._lib import CACHE_ENTRY, SCALEDOWN_PARAMS
+        entries = np.ascontiguousarray(entries, dtype=CACHE_ENTRY)
+        params = np.ascontiguousarray(params, dtype=SCALEDOWN_PARAMS).reshape(1)
+        rem = np.zeros(max(len(entries), 1), np.uint8)
+        self._ck(self.lib.mmp_scaledown_plan(self.h, ptr(entries) if len(entries) else None, len(entries), ptr(params),
+                                             ptr(rem)))
+        return rem[: len(entries)]
+
+    def migration_plan(self, entries, self_pod, now, cutoff_age_ms=3_600_000):
+        from ._lib import CACHE_ENTRY
+        entries = np.ascontiguousarray(entries, dtype=CACHE_ENTRY)
+        act = np.zeros(max(len(entries), 1), np.uint8)
+        wait = np.zeros(max(len(entries), 1), np.uint8)
+        self._ck(self.lib.mmp_migration_plan(self.h, ptr(entries) if len(entries) else None, len(entries), int(self_pod),
+                                             int(now), int(cutoff_age_ms), ptr(act), ptr(wait)))
+        return act[: len(entries)], wait[: len(entries)]
+
     def sync(self):
         self._ck(self.lib.mmp_sync(self.h))

@@ -118,6 +118,12 @@ def load() -> C.CDLL:
         lib.orc_should_publish.argtypes = [VP, VP, I64, I64, C.c_int, C.c_int, I64]
         lib.orc_proactive_plan.restype = C.c_int32
         lib.orc_proactive_plan.argtypes = [VP, I32, VP, VP, I32, I32, I64, VP, VP, I32, VP]
+        lib.orc_scaleup_plan.restype = C.c_int
+        lib.orc_scaleup_plan.argtypes = [VP, I32, VP, I32, VP, VP, VP, VP, VP, I32, VP, VP, VP]
+        lib.orc_scaledown_plan.restype = None
+        lib.orc_scaledown_plan.argtypes = [VP, VP, VP, VP, VP, VP, VP, VP, I32, VP, VP]
+        lib.orc_migration_plan.restype = None
+        lib.orc_migration_plan.argtypes = [VP, VP, VP, I32, I32, I64, I64, VP, VP]
         lib.orc_evict_eval.restype = None
         lib.orc_evict_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int64, C.c_int64,
                                        C.c_void_p]
@@ -324,3 +330,69 @@ def proactive_plan(fleet, default_units, now, max_out):
                                int(now), _p(om), _p(ol), int(max_out), _p(info))
     n = min(n, max_out)
     return om[:n].copy(), ol[:n].copy(), info[0]
+
+
+ORC_SCALEUP_PARAMS = np.dtype(
+    [("self_pod", "<i4"), ("iteration_counter", "<i4"), ("second_copy_max_age_iters", "<i4"),
+     ("second_copy_min_age_iters", "<i4"), ("scale_up_rpm_threshold", "<i4"), ("our_rpm", "<i4"), ("now", "<i8"),
+     ("last_check_time", "<i8"), ("rate_check_interval_ms", "<i8"), ("second_copy_lru_threshold_ms", "<i8"),
+     ("assume_completed_ms", "<i8")])
+ORC_SCALEDOWN_PARAMS = np.dtype(
+    [("self_pod", "<i4"), ("shutting_down", "<i4"), ("now", "<i8"), ("last_check_time", "<i8"),
+     ("rate_check_interval_ms", "<i8"), ("adjusted_cache_capacity", "<i8"), ("scale_up_rpm_threshold", "<i4"),
+     ("pad_", "<i4")])
+
+
+def _ent(fleet):
+    e = fleet.ent_pod if len(fleet.ent_pod) else np.zeros(1, np.int32)
+    t = fleet.ent_time if len(fleet.ent_time) else np.zeros(1, np.int64)
+    return np.ascontiguousarray(e, dtype=np.int32), np.ascontiguousarray(t, dtype=np.int64)
+
+
+def scaleup_plan(fleet, entries, params):
+    from modelmesh_amd._lib import SCALEUP_OUT
+    lib = load()
+    orc = OracleFleet(fleet)
+    stats = np.zeros(1, dtype=ORC_STATS)
+    stats[0] = orc.stats()
+    entries = np.ascontiguousarray(entries)
+    params = np.ascontiguousarray(params).reshape(1)
+    outs = np.zeros(max(len(entries), 1), dtype=SCALEUP_OUT)
+    ov = np.zeros(max(fleet.n_pods, 1), np.uint8)
+    ep, et = _ent(fleet)
+    models = np.ascontiguousarray(fleet.models)
+    sk = lib.orc_scaleup_plan(_p(orc.pods), fleet.n_pods, _p(orc.order), len(orc.order), _p(stats), _p(models), _p(ep),
+                              _p(et), _p(entries) if len(entries) else None, len(entries), _p(params), _p(outs), _p(ov))
+    return outs[: len(entries)], ov[: fleet.n_pods], sk
+
+
+def scaledown_plan(fleet, entries, params):
+    lib = load()
+    orc = OracleFleet(fleet)
+    stats = np.zeros(1, dtype=ORC_STATS)
+    stats[0] = orc.stats()
+    pos_of = np.full(max(fleet.n_pods, 1), 2**31 - 1, np.int32)
+    pos_of[orc.order] = np.arange(len(orc.order), dtype=np.int32)
+    in_table = np.ascontiguousarray(((fleet.pods["flags"] & 4) == 0).astype(np.uint8))
+    opods = orc.pods.copy()
+    opods["shutting_down"] = (fleet.pods["flags"] & 1) != 0
+    entries = np.ascontiguousarray(entries)
+    params = np.ascontiguousarray(params).reshape(1)
+    rem = np.zeros(max(len(entries), 1), np.uint8)
+    ep, et = _ent(fleet)
+    models = np.ascontiguousarray(fleet.models)
+    lib.orc_scaledown_plan(_p(opods), _p(pos_of), _p(in_table), _p(stats), _p(models), _p(ep), _p(et),
+                           _p(entries) if len(entries) else None, len(entries), _p(params), _p(rem))
+    return rem[: len(entries)]
+
+
+def migration_plan(fleet, entries, self_pod, now, cutoff_age_ms=3_600_000):
+    lib = load()
+    entries = np.ascontiguousarray(entries)
+    act = np.zeros(max(len(entries), 1), np.uint8)
+    wait = np.zeros(max(len(entries), 1), np.uint8)
+    ep, _ = _ent(fleet)
+    models = np.ascontiguousarray(fleet.models)
+    lib.orc_migration_plan(_p(models), _p(ep), _p(entries) if len(entries) else None, len(entries), int(self_pod),
+                           int(now), int(cutoff_age_ms), _p(act), _p(wait))
+    return act[: len(entries)], wait[: len(entries)]

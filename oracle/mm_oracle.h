@@ -243,6 +243,49 @@ int32_t orc_proactive_plan(const orc_pod *pods, int32_t n_pods, const orc_cluste
                            int64_t now, int32_t *out_model, int64_t *out_last_used, int32_t max_out,
                            orc_proactive_info *info);
 
+/* one local CacheEntry as the rebalancers see it */
+typedef struct {
+    int32_t model;                 /* registry row, -1 if registry.get(modelId) == null */
+    int32_t weight;                /* ce.getWeight()                                    */
+    int64_t last_used;             /* cache last-used time of the entry                 */
+    int64_t interval_count;        /* getAndResetIntervalCount() / getIntervalCount()   */
+    int64_t last_heavy_time;       /* ce.getLastHeavyTime()                             */
+    int64_t last_unload_time;      /* mr.getLastUnloadTime()                            */
+    int32_t earlier_use_iteration; /* ce.earlierUseIteration                            */
+    int32_t last_used_iteration;   /* ce.lastUsedIteration                              */
+    uint32_t flags;                /* bit0 failed / gone                                */
+    int32_t pad_;
+} orc_cache_entry;
+typedef struct {
+    int32_t self_pod, iteration_counter, second_copy_max_age_iters, second_copy_min_age_iters;
+    int32_t scale_up_rpm_threshold, our_rpm;
+    int64_t now, last_check_time, rate_check_interval_ms, second_copy_lru_threshold_ms, assume_completed_ms;
+} orc_scaleup_params;
+typedef struct {
+    int32_t action; /* 0 none, 1 second copy (exclude self, lastUsed = lastCheckTime), 2 scale up */
+    int32_t copies; /* copiesToLoad                                                                */
+    int64_t timestamp;
+    int32_t new_i1, new_i2;
+    int32_t heavy; /* ce.setLastHeavyTime(now) */
+    int32_t rpm;
+} orc_scaleup_out;
+int orc_scaleup_plan(const orc_pod *pods, int32_t n_pods, const int32_t *order, int32_t n_order,
+                     const orc_cluster_stats *stats, const orc_flat_model *models, const int32_t *ent_pod,
+                     const int64_t *ent_time, const orc_cache_entry *entries, int32_t n, const orc_scaleup_params *p,
+                     orc_scaleup_out *outs, uint8_t *overloaded_out);
+typedef struct {
+    int32_t self_pod, shutting_down;
+    int64_t now, last_check_time, rate_check_interval_ms, adjusted_cache_capacity;
+    int32_t scale_up_rpm_threshold, pad_;
+} orc_scaledown_params;
+void orc_scaledown_plan(const orc_pod *pods, const int32_t *pos_of, const uint8_t *in_table,
+                        const orc_cluster_stats *stats, const orc_flat_model *models, const int32_t *ent_pod,
+                        const int64_t *ent_time, const orc_cache_entry *entries, int32_t n,
+                        const orc_scaledown_params *p, uint8_t *removed_out);
+void orc_migration_plan(const orc_flat_model *models, const int32_t *ent_pod, const orc_cache_entry *entries,
+                        int32_t n, int32_t self_pod, int64_t now, int64_t cutoff_age_ms, uint8_t *action_out,
+                        uint8_t *wait_out);
+
 /* ---------- unload-buffer accounting (ModelCacheUnloadBufManager.java) -- */
 #define ORC_UBM_MAX_EVICTED 1024
 typedef struct {

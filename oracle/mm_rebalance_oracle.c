@@ -115,3 +115,212 @@ int32_t orc_proactive_plan(const orc_pod *pods, int32_t n_pods, const orc_cluste
     free(set_model);
     return count;
 }
+
+/* ======================================================================== */
+/* a15 — rateTrackingTask, MM.java:5636-5832 (limitModelConcurrency == false, typeSetStats ==
+ * clusterStats), getExcludeSet :5835-5856, loadedSince :5860-5871.  entries = usedSinceLastRun in
+ * its iteration order.  overloaded_out[p] = 1 for members of getExcludeSet().  Returns 0, or 1 if
+ * the task returns before looking at any entry (:5646-5648, :5658-5660). */
+static int loaded_since(const int32_t *pods, const int64_t *times, int32_t n, int64_t cutoff, int32_t ignore)
+{
+    for (int32_t i = 0; i < n; i++) {
+        if (ignore >= 0 && pods[i] == ignore) continue;
+        if (times[i] > cutoff) return 1;
+    }
+    return 0;
+}
+
+int orc_scaleup_plan(const orc_pod *pods, int32_t n_pods, const int32_t *order, int32_t n_order,
+                     const orc_cluster_stats *stats, const orc_flat_model *models, const int32_t *ent_pod,
+                     const int64_t *ent_time, const orc_cache_entry *entries, int32_t n, const orc_scaleup_params *p,
+                     orc_scaleup_out *outs, uint8_t *overloaded_out)
+{
+    memset(outs, 0, (size_t)n * sizeof *outs);
+    memset(overloaded_out, 0, (size_t)n_pods);
+    for (int32_t i = 0; i < n; i++) { /* untouched entries keep their iteration markers */
+        outs[i].new_i1 = entries[i].earlier_use_iteration;
+        outs[i].new_i2 = entries[i].last_used_iteration;
+    }
+    const int64_t last_time = p->last_check_time, now = p->now;
+    const int64_t time_delta = jsub64(now, last_time);
+    if (time_delta * 5 < p->rate_check_interval_ms * 3) return 1; /* :5646 */
+    const int32_t lower = p->iteration_counter - p->second_copy_max_age_iters;
+    const int32_t upper = p->iteration_counter - p->second_copy_min_age_iters;
+    const int32_t inst_count = stats->instance_count;
+    if (inst_count < 2) return 1; /* :5658 */
+    if (n == 0) return 1;         /* :5667 */
+    const int64_t new_copies_ts = now + 20000; /* :5675 */
+    const int32_t scale_up_rpms = p->scale_up_rpm_threshold;
+    const int32_t heavy_rpms = (int32_t)((uint32_t)scale_up_rpms * 3u) / 4;
+    int have_exclude_set = 0;
+    int32_t excluded_count = 0;
+    for (int32_t e = 0; e < n; e++) {
+        const orc_cache_entry *ce = &entries[e];
+        orc_scaleup_out *o = &outs[e];
+        const int64_t count = ce->interval_count;
+        const int32_t suitable = inst_count;
+        const int32_t rpm = (int32_t)((count * 60000) / time_delta);
+        o->rpm = rpm;
+        if (rpm > heavy_rpms) o->heavy = 1; /* ce.setLastHeavyTime(now) */
+        if (ce->model < 0) continue;        /* mr == null */
+        const orc_flat_model *mr = &models[ce->model];
+        const int32_t loaded_count = mr->n_loaded;
+        if (loaded_count == 0) continue;
+        const int32_t failed_count = mr->n_failed;
+        int32_t candidate_count = suitable - (loaded_count + failed_count);
+        if (candidate_count <= 0) continue;
+        const int32_t *lp = ent_pod + mr->ent_off;
+        const int64_t *lt = ent_time + mr->ent_off;
+        if (loaded_count == 1) { /* :5726-5758 */
+            const int32_t i1 = ce->earlier_use_iteration, i2 = ce->last_used_iteration;
+            int i1in = 0, i2in = 0;
+            if (i2 >= lower && i1 <= upper) {
+                i1in = i1 >= lower;
+                i2in = i2 <= upper;
+            }
+            if (i2in || !i1in) o->new_i1 = i2;
+            o->new_i2 = p->iteration_counter;
+            if (i1in || i2in) {
+                if (stats->total_capacity == 0) continue; /* ArithmeticException, caught at :5810 */
+                if ((10 * stats->total_free) / stats->total_capacity >= 1 ||
+                    jsub64(now, stats->global_lru) > p->second_copy_lru_threshold_ms) {
+                    o->action = 1; /* ensureLoadedInternalAsync(modelId, lastTime, weight, excludeThisInstance, 0) */
+                    o->timestamp = last_time;
+                    o->copies = 1;
+                    continue;
+                }
+            }
+        }
+        if (rpm < scale_up_rpms) continue; /* :5762 */
+        if (scale_up_rpms == 0) continue;  /* rpm / scaleUpRpms would throw; caught at :5810 */
+        const int64_t recent_cutoff = jsub64(now, time_delta + p->rate_check_interval_ms + 2 * p->assume_completed_ms);
+        if (loaded_since(lp, lt, loaded_count, recent_cutoff, p->self_pod)) continue; /* :5769 */
+        if (!have_exclude_set) { /* getExcludeSet(), :5835-5856 */
+            have_exclude_set = 1;
+            const int32_t a = (int32_t)((uint32_t)scale_up_rpms * 4u);
+            const int32_t b = (int32_t)((uint32_t)p->our_rpm - 2u * (uint32_t)scale_up_rpms);
+            const int32_t max_rpm = a > b ? a : b;
+            for (int32_t k = 0; k < n_order; k++) {
+                const int32_t iid = order[k];
+                if (iid == p->self_pod) continue;
+                if (pods[iid].rpm > max_rpm) {
+                    overloaded_out[iid] = 1;
+                    excluded_count++;
+                }
+            }
+        }
+        if (excluded_count != 0) { /* :5776-5787 (non-member excluded pods are subtracted twice) */
+            for (int32_t iid = 0; iid < n_pods; iid++) {
+                if (!overloaded_out[iid]) continue;
+                int in = 0;
+                for (int32_t k = 0; k < loaded_count + failed_count; k++)
+                    if (lp[k] == iid) in = 1;
+                if (!in) candidate_count--;
+            }
+            candidate_count -= excluded_count;
+            if (candidate_count <= 0) continue;
+        }
+        int32_t copies = rpm / scale_up_rpms < candidate_count ? rpm / scale_up_rpms : candidate_count; /* :5792 */
+        if (copies > 2) copies = copies < suitable / 3 ? copies : suitable / 3;
+        o->action = 2;
+        o->copies = copies;
+        o->timestamp = new_copies_ts;
+    }
+    return 0;
+}
+
+/* a16 — janitor scale-down, MM.java:6110-6145 with removeModelCopies :6197-6310 and
+ * removeSecondModelCopy :6314-6335 (mcce == null).  entries = scaleCopiesCandidates, oldest first;
+ * entry.interval_count carries ce.getRpm(timeSinceLastCheck) inputs (the count). in_table[p] =
+ * instanceInfo.get(iid) != null. pos_of = PLACEMENT_ORDER position of every present pod. */
+void orc_scaledown_plan(const orc_pod *pods, const int32_t *pos_of, const uint8_t *in_table,
+                        const orc_cluster_stats *stats, const orc_flat_model *models, const int32_t *ent_pod,
+                        const int64_t *ent_time, const orc_cache_entry *entries, int32_t n,
+                        const orc_scaledown_params *p, uint8_t *removed_out)
+{
+    memset(removed_out, 0, (size_t)n);
+    if (p->shutting_down) return; /* :6111 */
+    int64_t max_weight = p->adjusted_cache_capacity / 20;
+    int32_t removed_count = 0;
+    const int64_t now = p->now;
+    for (int32_t e = 0; e < n; e++) {
+        const orc_cache_entry *ce = &entries[e];
+        const int32_t weight = ce->weight;
+        const int can_remove = removed_count == 0 || weight <= max_weight;
+        int removed = 0;
+        do {
+            const int64_t last_used = ce->last_used;
+            if (last_used == 0) break; /* :6199 */
+            const orc_flat_model *mr = &models[ce->model];
+            const int32_t num = mr->n_loaded;
+            if (!can_remove || num < 2) break;
+            if (stats->total_capacity == 0 || stats->total_free * 100 / stats->total_capacity > 5) break; /* :6229 */
+            const int32_t *lp = ent_pod + mr->ent_off;
+            const int64_t *lt = ent_time + mr->ent_off;
+            int32_t other = -1;
+            for (int32_t k = 0; k < num; k++) { /* :6234-6243 */
+                const int32_t iid = lp[k];
+                if (iid != p->self_pod && in_table[iid] && !pods[iid].shutting_down) { other = iid; break; }
+            }
+            if (other < 0) break;
+            if (num == 2) { /* :6250-6261 */
+                const int64_t last_heavy = ce->last_heavy_time, cache_age = jsub64(now, stats->global_lru);
+                int64_t scale_down_age = cache_age / 10;
+                if (last_heavy == 0 || jsub64(now, last_heavy) < cache_age / 5)
+                    scale_down_age = 36000000LL < scale_down_age ? 36000000LL : scale_down_age;
+                if (jsub64(now, last_used) > scale_down_age) {
+                    /* removeSecondModelCopy :6314-6335 */
+                    if (!(p->self_pod >= 0 && in_table[p->self_pod] && !pods[p->self_pod].shutting_down)) break;
+                    if (pos_of[other] > pos_of[p->self_pod]) break; /* PLACEMENT_ORDER.compare(other, this) > 0 */
+                    removed = 1;
+                }
+            } else { /* :6263-6307 */
+                const int64_t last_unload = ce->last_unload_time;
+                if (last_unload > 0 && jsub64(now, last_unload) < 8 * p->rate_check_interval_ms) break;
+                if (loaded_since(lp, lt, num, now - 1800000, -1)) break;
+                int64_t min_age = (int64_t)(((uint64_t)3 * (uint64_t)stats->global_lru + 10400000ull)) / 100; /* quirk B#13 */
+                if (min_age < 600000) min_age = 600000;
+                else if (min_age > 18000000) min_age = 18000000;
+                if (jsub64(now, ce->last_heavy_time) < min_age) break;
+                const int64_t since = jsub64(now, p->last_check_time);
+                if (since < p->rate_check_interval_ms / 10) break;
+                const int64_t rpm = ce->interval_count == 0 ? 0 : (60000 * ce->interval_count) / since;
+                const int64_t threshold = p->scale_up_rpm_threshold;
+                if (rpm > (threshold * 2) / 3) break;
+                removed = 1;
+            }
+        } while (0);
+        if (removed) {
+            removed_out[e] = 1;
+            removed_count++;
+            max_weight -= weight;
+        }
+    }
+}
+
+/* a21 — preShutdown migration order, MM.java:7000-7040 with triggerNewModelCopyElsewhere
+ * :6913-6928.  entries = runtimeCache.descendingLruMap() (most recently used first).
+ * action_out: 1 = triggerNewModelCopyElsewhere(modelId, mr, lruTime, weight) is called;
+ * wait_out: 1 = the shutdown waits for that copy (lruTime >= now - CUTOFF_AGE_MS). */
+void orc_migration_plan(const orc_flat_model *models, const int32_t *ent_pod, const orc_cache_entry *entries,
+                        int32_t n, int32_t self_pod, int64_t now, int64_t cutoff_age_ms, uint8_t *action_out,
+                        uint8_t *wait_out)
+{
+    const int64_t cutoff = jsub64(now, cutoff_age_ms);
+    for (int32_t e = 0; e < n; e++) {
+        action_out[e] = wait_out[e] = 0;
+        const orc_cache_entry *ce = &entries[e];
+        if (ce->model < 0) continue; /* mr == null */
+        const orc_flat_model *mr = &models[ce->model];
+        int has_us = 0;
+        for (int32_t k = 0; k < mr->n_loaded; k++)
+            if (ent_pod[mr->ent_off + k] == self_pod) has_us = 1;
+        if (!has_us) continue;          /* :7008-7010 */
+        if (ce->flags & 1u) continue;   /* ce == null || ce.isFailed() */
+        const int64_t lru_time = ce->last_used;
+        if (lru_time > 0) {
+            action_out[e] = 1;
+            wait_out[e] = lru_time >= cutoff; /* when the status comes back LOADING */
+        }
+    }
+}

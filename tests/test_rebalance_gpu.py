@@ -69,3 +69,110 @@ def test_proactive_plan_matches_oracle(seed, pods, models, used):
                 assert np.array_equal(out["chosen"], want["chosen"]) and np.array_equal(out["hash"], want["hash"])
     finally:
         s.close()
+
+
+def _local_entries(fleet, self_pod, rng, n):
+    """A plausible local cache of `self_pod`: mostly models it holds, plus noise."""
+    from modelmesh_amd import _lib
+    m = fleet.models
+    e = np.zeros(n, dtype=_lib.CACHE_ENTRY)
+    e["model"] = rng.integers(0, fleet.n_models, n)
+    e["model"] = np.where(rng.random(n) < 0.03, -1, e["model"])
+    e["weight"] = rng.choice([1, 2560, 6400, 60_000], n)
+    e["last_used"] = np.where(rng.random(n) < 0.05, 0, fleet.now - rng.choice([500, 30_000, 4_000_000, 50_000_000], n))
+    e["interval_count"] = rng.choice([0, 1, 50, 400, 5000], n)
+    e["last_heavy_time"] = np.where(rng.random(n) < 0.4, 0, fleet.now - rng.choice([1_000, 700_000, 30_000_000], n))
+    e["last_unload_time"] = np.where(rng.random(n) < 0.6, 0, fleet.now - rng.choice([10_000, 100_000], n))
+    e["earlier_use_iteration"] = rng.integers(0, 120, n)
+    e["last_used_iteration"] = e["earlier_use_iteration"] + rng.integers(0, 60, n)
+    e["flags"] = (rng.random(n) < 0.05).astype(np.uint32)
+    return e
+
+
+def _rebalance_fleet(seed, pods, models, used):
+    """Fleet where many models have 1-4 copies, often including `self_pod` = 0."""
+    rng = np.random.default_rng(8000 + seed)
+    fleet = wl.fuzz_fleet(seed + 70, pods=pods, models=models)
+    now = fleet.now
+    p = fleet.pods
+    p["flags"] = np.where(rng.random(pods) < 0.05, 1, 2)
+    p["flags"][0] = 2
+    p["used"] = (p["capacity"] * np.clip(rng.normal(used, 0.02, pods), 0, 1.0)).astype(np.int64)
+    p["rpm"] = rng.choice([0, 100, 3000, 9000, 50_000], pods)
+    m = fleet.models
+    k = rng.choice([0, 1, 1, 2, 2, 3, 4], models).clip(0, pods)
+    f = rng.choice([0, 0, 0, 1], models).clip(0, max(pods - 4, 0))
+    m["n_loaded"], m["n_failed"] = k, f
+    off = np.zeros(models + 1, np.int64)
+    np.cumsum(k + f, out=off[1:])
+    m["ent_off"] = off[:-1]
+    ent = np.zeros(int(off[-1]), np.int32)
+    for i in range(models):
+        c = rng.choice(pods, size=k[i] + f[i], replace=False)
+        if k[i] and rng.random() < 0.7 and 0 not in c:
+            c[0] = 0
+        ent[off[i]: off[i + 1]] = c
+    fleet.ent_pod = ent
+    fleet.ent_time = (now - rng.choice([1_000, 25_000, 2_000_000, 90_000_000], len(ent))).astype(np.int64)
+    return fleet, rng
+
+
+@pytest.mark.parametrize("seed,pods,used", [(0, 12, 0.5), (1, 200, 0.97), (2, 200, 0.2), (3, 1, 0.5)])
+def test_scaleup_scaledown_migration_plans_match_oracle(seed, pods, used):
+    from modelmesh_amd import _lib
+    fleet, rng = _rebalance_fleet(seed, pods, 600, used)
+    now = fleet.now
+    entries = _local_entries(fleet, 0, rng, 800)
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        seen_actions = set()
+        for thr, our_rpm, last_check in ((2000, 100, now - 10_000), (100, 50_000, now - 9_000), (0, 0, now - 10_000),
+                                         (2000, 0, now - 1_000)):
+            sp = np.zeros(1, dtype=_lib.SCALEUP_PARAMS)
+            sp["self_pod"], sp["iteration_counter"] = 0, 130
+            sp["second_copy_max_age_iters"], sp["second_copy_min_age_iters"] = 240, 42
+            sp["scale_up_rpm_threshold"], sp["our_rpm"] = thr, our_rpm
+            sp["now"], sp["last_check_time"], sp["rate_check_interval_ms"] = now, last_check, 10_000
+            sp["second_copy_lru_threshold_ms"], sp["assume_completed_ms"] = 72_000_000, 30_000
+            g_out, g_ov, g_sk = s.scaleup_plan(entries, sp)
+            w_out, w_ov, w_sk = ob.scaleup_plan(fleet, entries, sp.view(ob.ORC_SCALEUP_PARAMS))
+            assert g_sk == w_sk
+            assert np.array_equal(g_ov, w_ov)
+            for f in ("action", "copies", "timestamp", "new_i1", "new_i2", "heavy", "rpm"):
+                if g_sk and f == "rpm":
+                    continue
+                assert np.array_equal(g_out[f], w_out[f]), (f, thr, np.nonzero(g_out[f] != w_out[f])[0][:5])
+            seen_actions |= set(np.unique(g_out["action"]))
+        if pods > 1:
+            assert seen_actions >= {0, 1, 2}
+
+        for thr, cap, sd in ((2000, 200_000, 0), (2000, 1_000, 0), (10, 10_000_000, 0), (2000, 200_000, 1)):
+            dp = np.zeros(1, dtype=_lib.SCALEDOWN_PARAMS)
+            dp["self_pod"], dp["shutting_down"], dp["now"] = 0, sd, now
+            dp["last_check_time"], dp["rate_check_interval_ms"] = now - 7_000, 10_000
+            dp["adjusted_cache_capacity"], dp["scale_up_rpm_threshold"] = cap, thr
+            got = s.scaledown_plan(entries, dp)
+            want = ob.scaledown_plan(fleet, entries, dp.view(ob.ORC_SCALEDOWN_PARAMS))
+            assert np.array_equal(got, want), (thr, cap, sd, np.nonzero(got != want)[0][:5])
+
+        ga, gw = s.migration_plan(entries, 0, now)
+        wa, ww = ob.migration_plan(fleet, entries, 0, now)
+        assert np.array_equal(ga, wa) and np.array_equal(gw, ww)
+        if pods > 1:
+            assert ga.sum() > 0 and gw.sum() > 0 and (ga & ~gw).sum() > 0
+        # a21 then issues triggerNewModelCopyElsewhere = getNext with lastUsedTime = lruTime and
+        # excludes = current holders ∪ self (MM.java:6913-6928)
+        idx = np.nonzero(ga)[0]
+        if len(idx):
+            reqs, _ = wl.make_requests(fleet, 5, n=len(idx))
+            reqs["model"], reqs["last_used"] = entries["model"][idx], entries["last_used"][idx]
+            reqs["self_pod"], reqs["flags"] = 0, 1
+            reqs["extra_off"], reqs["n_extra"] = 0, 1
+            extra = np.zeros(1, np.int32)
+            out = s.place(reqs, extra, now)
+            want = ob.OracleFleet(fleet).place(reqs, extra, now)
+            assert np.array_equal(out["chosen"], want["chosen"])
+            assert not np.any(out["chosen"] == 0)  # never back onto the instance that is shutting down
+    finally:
+        s.close()
