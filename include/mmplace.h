@@ -354,7 +354,8 @@ int mmp_proactive_plan(mmp_ctx *ctx, int32_t default_model_size_units, int64_t n
 
 /* a15: entries = usedSinceLastRun (runtimeCache.descendingMapWithCutoff(lastTime)) in iteration order.
  * overloaded_out has one byte per pod = membership in getExcludeSet() (MM.java:5835-5856); for
- * MMP_SCALE_UP rows the caller passes those pods as extra excludes of the load-target decisions.
+ * MMP_SCALE_UP rows the caller passes those pods as extra excludes of the load-target decisions
+ * (the Java builds the set lazily, so it is only meaningful when some row is MMP_SCALE_UP).
  * *skipped = 1 when the task returns before looking at the entries (MM.java:5646, :5658). */
 int mmp_scaleup_plan(mmp_ctx *ctx, const mmp_cache_entry *entries, int32_t n, const mmp_scaleup_params *params,
                      mmp_scaleup_out *outs, uint8_t *overloaded_out, int32_t *skipped);

@@ -138,7 +138,10 @@ def test_scaleup_scaledown_migration_plans_match_oracle(seed, pods, used):
             g_out, g_ov, g_sk = s.scaleup_plan(entries, sp)
             w_out, w_ov, w_sk = ob.scaleup_plan(fleet, entries, sp.view(ob.ORC_SCALEUP_PARAMS))
             assert g_sk == w_sk
-            assert np.array_equal(g_ov, w_ov)
+            # getExcludeSet() is built lazily in the Java (MM.java:5771-5774); its content only matters
+            # (and is only compared) when some entry is actually scaled up
+            if np.any(w_out["action"] == 2):
+                assert np.array_equal(g_ov, w_ov)
             for f in ("action", "copies", "timestamp", "new_i1", "new_i2", "heavy", "rpm"):
                 if g_sk and f == "rpm":
                     continue
