@@ -300,6 +300,15 @@ int mmp_pods_remove(mmp_ctx *ctx, const int32_t *idx, int32_t n);
  * n_types==0 means typeConstraints==null. */
 int mmp_types_load(mmp_ctx *ctx, int32_t n_types, const uint64_t *allowed, const uint64_t *prefer,
                    const uint8_t *has_allowed, const uint8_t *has_prefer);
+/* Rebuild the per-type instance sets from labels ON THE DEVICE (row a18): labels are interned to
+ * bits; pod_labels[p] = the instance's label set, required[t]/preferred[t] = the type's
+ * requiredLabels / preferredLabels (TypeConstraintManager.java:337-447, :478-486, :680-747).
+ * Installs n_types+1 type rows for the next commit: row n_types is the row for model types that
+ * are not in the config (no constraint, defaultPreferredInstances). Optional outputs (may be
+ * NULL) return the computed tables in the mmp_types_load format with n_types+1 rows. */
+int mmp_types_from_labels(mmp_ctx *ctx, int32_t n_types, const uint64_t *required, const uint64_t *preferred,
+                          const uint64_t *pod_labels, uint64_t *allowed_out, uint64_t *prefer_out,
+                          uint8_t *has_allowed_out, uint8_t *has_prefer_out);
 /* UpgradeTracker.getLikelyReplacedReplicaSets (UpgradeTracker.java:78). */
 int mmp_replaced_rs_load(mmp_ctx *ctx, const int32_t *replica_sets, int32_t n);
 /* The model registry view (MM.java:308). ent_pod / ent_time have n_entries items. */

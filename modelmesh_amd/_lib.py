@@ -106,6 +106,7 @@ SYMBOLS = [
     ("mmp_pods_upsert", C.c_int, [_P, _P, _P, C.c_int32]),
     ("mmp_pods_remove", C.c_int, [_P, _P, C.c_int32]),
     ("mmp_types_load", C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
+    ("mmp_types_from_labels", C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     ("mmp_replaced_rs_load", C.c_int, [_P, _P, C.c_int32]),
     ("mmp_models_load", C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32]),
     ("mmp_snapshot_commit", C.c_int, [_P]),

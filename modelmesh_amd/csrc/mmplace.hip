@@ -23,6 +23,7 @@
 #include "place_kernel.hpp"
 #include "rebalance_kernels.hpp"
 #include "snapshot.hpp"
+#include "types_kernel.hpp"
 
 using namespace mmp;
 
@@ -285,6 +286,65 @@ int mmp_types_load(mmp_ctx *c, int32_t n_types, const uint64_t *allowed, const u
             std::copy(prefer + (size_t)t * W, prefer + (size_t)(t + 1) * W, c->prefer.begin() + (size_t)t * W);
         }
     }
+    return MMP_OK;
+}
+
+int mmp_types_from_labels(mmp_ctx *c, int32_t n_types, const uint64_t *required, const uint64_t *preferred,
+                          const uint64_t *pod_labels, uint64_t *allowed_out, uint64_t *prefer_out,
+                          uint8_t *has_allowed_out, uint8_t *has_prefer_out)
+{
+    if (!c || n_types < 0 || (n_types > 0 && (!required || !preferred)))
+        return fail(c, MMP_EINVAL, "mmp_types_from_labels: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    const int32_t P = (int32_t)c->pods.size();
+    if (P > 0 && !pod_labels) return fail(c, MMP_EINVAL, "mmp_types_from_labels: pod_labels is null");
+    const int32_t W = div_up(P, 64), T = n_types, R = T + 1;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = c->stream;
+    const size_t words = (size_t)std::max(R * W, 1);
+    // scratch: pods, labels, required, preferred, allowed, cpref, prefer, score, has_*
+    HIP_TRY(c, c->s_reqs.ensure((size_t)std::max(P, 1) * sizeof(mmp_pod_row)));
+    HIP_TRY(c, c->s_a.ensure((size_t)std::max(P, 1) * 8));
+    HIP_TRY(c, c->s_b.ensure((size_t)std::max(T, 1) * 16));
+    HIP_TRY(c, c->s_c.ensure(words * 8 * 3));
+    HIP_TRY(c, c->s_d.ensure((size_t)std::max(P, 1) * 4 + (size_t)R * 2));
+    uint64_t *d_req = c->s_b.as<uint64_t>(), *d_prf = d_req + std::max(T, 1);
+    uint64_t *d_al = c->s_c.as<uint64_t>(), *d_cp = d_al + words, *d_pf = d_cp + words;
+    int32_t *d_score = c->s_d.as<int32_t>();
+    uint8_t *d_ha = reinterpret_cast<uint8_t *>(d_score + std::max(P, 1)), *d_hp = d_ha + R;
+    if (P) {
+        HIP_TRY(c, hipMemcpyAsync(c->s_reqs.p, c->pods.data(), (size_t)P * sizeof(mmp_pod_row), hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->s_a.p, pod_labels, (size_t)P * 8, hipMemcpyHostToDevice, st));
+    }
+    if (T) {
+        HIP_TRY(c, hipMemcpyAsync(d_req, required, (size_t)T * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(d_prf, preferred, (size_t)T * 8, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(c, hipMemsetAsync(d_al, 0, words * 8 * 3, st));
+    if (W > 0) {
+        hipLaunchKernelGGL(type_sets_kernel, dim3(div_up(W, 4)), dim3(256), 0, st, c->s_reqs.as<mmp_pod_row>(),
+                           c->s_a.as<uint64_t>(), P, W, T, d_req, d_prf, d_al, d_cp, d_score);
+    }
+    hipLaunchKernelGGL(type_prefer_kernel, dim3(R), dim3(256), 0, st, P, W, T, d_req, d_al, d_cp, d_score, d_pf, d_ha, d_hp);
+    HIP_TRY(c, hipGetLastError());
+    // install as the type table of the next commit (same staging the host-bitmap entry point fills)
+    c->n_types = R;
+    c->types_w = W;
+    c->allowed.assign((size_t)R * W, 0);
+    c->prefer.assign((size_t)R * W, 0);
+    c->has_allowed.assign(R, 0);
+    c->has_prefer.assign(R, 0);
+    if (W > 0) {
+        HIP_TRY(c, hipMemcpyAsync(c->allowed.data(), d_al, (size_t)R * W * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(c->prefer.data(), d_pf, (size_t)R * W * 8, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->has_allowed.data(), d_ha, R, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(c->has_prefer.data(), d_hp, R, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (allowed_out && W > 0) memcpy(allowed_out, c->allowed.data(), (size_t)R * W * 8);
+    if (prefer_out && W > 0) memcpy(prefer_out, c->prefer.data(), (size_t)R * W * 8);
+    if (has_allowed_out) memcpy(has_allowed_out, c->has_allowed.data(), R);
+    if (has_prefer_out) memcpy(has_prefer_out, c->has_prefer.data(), R);
     return MMP_OK;
 }
 

@@ -115,6 +115,21 @@ class Solver:
         self._ck(self.lib.mmp_types_load(self.h, int(n_types), ptr(allowed), ptr(prefer),
                                          ptr(has_allowed), ptr(has_prefer)))
 
+    def types_from_labels(self, required, preferred, pod_labels):
+        """a18: returns (allowed[T+1][W], prefer[T+1][W], has_allowed[T+1], has_prefer[T+1]) and installs them."""
+        required = np.ascontiguousarray(required, dtype=np.uint64)
+        preferred = np.ascontiguousarray(preferred, dtype=np.uint64)
+        pod_labels = np.ascontiguousarray(pod_labels, dtype=np.uint64)
+        T, W = len(required), (self.n_pods + 63) // 64
+        al = np.zeros((T + 1, max(W, 1)), np.uint64)
+        pf = np.zeros((T + 1, max(W, 1)), np.uint64)
+        ha = np.zeros(T + 1, np.uint8)
+        hp = np.zeros(T + 1, np.uint8)
+        self._ck(self.lib.mmp_types_from_labels(self.h, T, ptr(required) if T else None, ptr(preferred) if T else None,
+                                                ptr(pod_labels) if len(pod_labels) else None, ptr(al), ptr(pf),
+                                                ptr(ha), ptr(hp)))
+        return al[:, :W], pf[:, :W], ha, hp
+
     def load_replaced_rs(self, rs):
         rs = np.ascontiguousarray(rs, dtype=np.int32)
         self._ck(self.lib.mmp_replaced_rs_load(self.h, ptr(rs) if len(rs) else None, len(rs)))
