@@ -377,6 +377,32 @@ int mmp_scaledown_plan(mmp_ctx *ctx, const mmp_cache_entry *entries, int32_t n,
 int mmp_migration_plan(mmp_ctx *ctx, const mmp_cache_entry *entries, int32_t n, int32_t self_pod, int64_t now_ms,
                        int64_t cutoff_age_ms, uint8_t *action_out, uint8_t *wait_out);
 
+/* ---- pod-axis sharding across the GPUs of one node ---------------------------
+ * There is no reference counterpart: the reference walks clusterState (MM.java:4763) on one JVM
+ * thread.  Here shard g of G owns a contiguous range of PLACEMENT_ORDER positions (the words
+ * [g*ceil(W/G), ...) of every rank-ordered bitmap and column); every shard sees the whole request
+ * batch, and one CacheMissForwardingLB.getNext (MM.java:4776-5005) is evaluated as six local scans
+ * with an all-reduce of a small per-decision int64 vector after each (MIN, except phase 5 = SUM).
+ * The library launches the kernels; the HOST performs the collectives between phases (RCCL
+ * all-reduce over xGMI: modelmesh_amd/dist.py does it with torch.distributed; a Java host would
+ * call ncclAllReduce on the same device buffers).  Results are bit-identical to mmp_place_batch.
+ *
+ *   mmp_shard_configure(ctx, g, G)        once, before the first commit (G = 1 is allowed)
+ *   commit:  mmp_shard_rank_dev(ctx, d_rank)   -> all-reduce SUM of int32 d_rank[n_pods]
+ *            mmp_shard_commit_dev(ctx, d_rank)     (both synchronise the context's stream)
+ *   batch:   for phase in 1..6: mmp_shard_place_phase_dev(...); all-reduce d_xchg[phase-1]
+ *            mmp_shard_place_phase_dev(phase 7) writes d_outs on every shard
+ * d_xchg[k] (k = 0..5) are device int64 buffers of n * mmp_shard_xchg_slots(k+1, G) elements. */
+int mmp_shard_configure(mmp_ctx *ctx, int32_t shard, int32_t n_shards);
+int32_t mmp_shard_xchg_slots(int32_t phase, int32_t n_shards);
+int32_t mmp_shard_xchg_is_sum(int32_t phase); /* 1: SUM, 0: MIN */
+/* PLACEMENT_ORDER ranks (MM.java:4646-4703) of this shard's slice of the pod table against all
+ * pods; other entries of d_rank (device int32[n_pods]) are zeroed. */
+int mmp_shard_rank_dev(mmp_ctx *ctx, void *d_rank);
+int mmp_shard_commit_dev(mmp_ctx *ctx, const void *d_rank);
+int mmp_shard_place_phase_dev(mmp_ctx *ctx, int32_t phase, const void *d_reqs, int32_t n, const void *d_extra_pool,
+                              int64_t now_ms, void *const *d_xchg, void *d_outs, void *stream);
+
 /* Wait for everything queued on the context's own stream. */
 int mmp_sync(mmp_ctx *ctx);
 

@@ -122,6 +122,12 @@ SYMBOLS = [
     ("mmp_scaleup_plan", C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32)]),
     ("mmp_scaledown_plan", C.c_int, [_P, _P, C.c_int32, _P, _P]),
     ("mmp_migration_plan", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _P, _P]),
+    ("mmp_shard_configure", C.c_int, [_P, C.c_int32, C.c_int32]),
+    ("mmp_shard_xchg_slots", C.c_int32, [C.c_int32, C.c_int32]),
+    ("mmp_shard_xchg_is_sum", C.c_int32, [C.c_int32]),
+    ("mmp_shard_rank_dev", C.c_int, [_P, _P]),
+    ("mmp_shard_commit_dev", C.c_int, [_P, _P]),
+    ("mmp_shard_place_phase_dev", C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int64, _P, _P, _P]),
     ("mmp_sync", C.c_int, [_P]),
 ]
 

@@ -22,6 +22,7 @@
 #include "gate_kernel.hpp"
 #include "place_kernel.hpp"
 #include "rebalance_kernels.hpp"
+#include "shard_kernels.hpp"
 #include "snapshot.hpp"
 #include "types_kernel.hpp"
 
@@ -87,6 +88,12 @@ struct mmp_ctx {
     bool committed = false;
     Snap snap{};
     mmp_stats stats{};
+
+    // pod-axis shard mode (mmp_shard_configure): this context owns the rank positions of
+    // `ssnap` only; n_shards == 0 means the ordinary single-device snapshot
+    int32_t shard = 0, n_shards = 0;
+    ShardSnap ssnap{};
+    bool rank_pending = false;
 
     // commit scratch
     DevBuf rank, occupancy, flag, rs_list, rs_bad, d_allowed, d_prefer, d_has_allowed, stats_acc;
@@ -389,6 +396,8 @@ int mmp_snapshot_commit(mmp_ctx *c)
 {
     if (!c) return MMP_EINVAL;
     std::lock_guard<std::mutex> g(c->mu);
+    if (c->n_shards > 0)
+        return fail(c, MMP_ESTATE, "context is a pod-axis shard: commit with mmp_shard_rank_dev + mmp_shard_commit_dev");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const int32_t P = (int32_t)c->pods.size();
     const int32_t W = std::max(div_up(P, 64), 1);
@@ -456,7 +465,7 @@ int mmp_snapshot_commit(mmp_ctx *c)
         const int pb = div_up(P, kRankBlock);
         const int slices = std::max(1, std::min(64, 2048 / pb));
         hipLaunchKernelGGL(rank_pods_kernel, dim3(pb, slices), dim3(kRankBlock), 0, st, B.pods.as<mmp_pod_row>(), P,
-                           min_space, churn2, slices, c->rank.as<int32_t>());
+                           min_space, churn2, slices, 0, P, c->rank.as<int32_t>());
         hipLaunchKernelGGL(scatter_pods_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(), P,
                            min_space, c->rank.as<int32_t>(), c->occupancy.as<int32_t>(), B.lru.as<int64_t>(),
                            B.rem.as<int64_t>(), B.cnt.as<int32_t>(), B.rpm.as<int32_t>(), B.orig.as<int32_t>(),
@@ -522,6 +531,7 @@ int mmp_get_order(mmp_ctx *c, int32_t *order_out, int32_t *n_out)
     if (!c || !order_out || !n_out) return fail(c, MMP_EINVAL, "mmp_get_order: null argument");
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    if (c->n_shards > 0) return fail(c, MMP_ESTATE, "mmp_get_order: a pod-axis shard holds only its own slice of the order");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const int32_t n = c->stats.instance_count;  // absent rows sort last
     if (n) HIP_TRY(c, hipMemcpy(order_out, c->snap.orig, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -538,6 +548,243 @@ int mmp_cluster_stats(mmp_ctx *c, mmp_stats *out)
     return MMP_OK;
 }
 
+/* ---- pod-axis sharding --------------------------------- */
+
+int mmp_shard_configure(mmp_ctx *c, int32_t shard, int32_t n_shards)
+{
+    if (!c || n_shards < 1 || n_shards > kMaxShards || shard < 0 || shard >= n_shards)
+        return fail(c, MMP_EINVAL, "mmp_shard_configure: need 0 <= shard < n_shards <= %d", kMaxShards);
+    std::lock_guard<std::mutex> g(c->mu);
+    c->shard = shard;
+    c->n_shards = n_shards;
+    c->committed = false;
+    c->rank_pending = false;
+    return MMP_OK;
+}
+
+int32_t mmp_shard_xchg_slots(int32_t phase, int32_t n_shards)
+{
+    switch (phase) {
+    case 1: return kX1;
+    case 2: return kX2;
+    case 3: return kX3;
+    case 4: return kX4;
+    case 5: return x5_slots(n_shards);
+    case 6: return kX6;
+    default: return 0;
+    }
+}
+
+int32_t mmp_shard_xchg_is_sum(int32_t phase) { return phase == 5 ? 1 : 0; }
+
+int mmp_shard_rank_dev(mmp_ctx *c, void *d_rank)
+{
+    if (!c || !d_rank) return fail(c, MMP_EINVAL, "mmp_shard_rank_dev: null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->n_shards < 1) return fail(c, MMP_ESTATE, "mmp_shard_configure has not been called");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int32_t P = (int32_t)c->pods.size();
+    SnapBufs &B = c->sb[1 - c->cur];
+    hipStream_t st = c->stream;
+    HIP_TRY(c, B.pods.ensure(std::max<size_t>(P, 1) * sizeof(mmp_pod_row)));
+    if (P) {
+        HIP_TRY(c, hipMemcpyAsync(B.pods.p, c->pods.data(), (size_t)P * sizeof(mmp_pod_row), hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemsetAsync(d_rank, 0, (size_t)P * 4, st));
+        const int per = div_up(P, c->n_shards);
+        const int p_lo = std::min(P, c->shard * per), p_hi = std::min(P, p_lo + per);
+        if (p_hi > p_lo) {
+            const int pb = div_up(p_hi - p_lo, kRankBlock);
+            const int slices = std::max(1, std::min(64, 2048 / pb));
+            const int64_t churn2 = (int64_t)((uint64_t)c->cfg.min_churn_age_ms * 2u);
+            hipLaunchKernelGGL(rank_pods_kernel, dim3(pb, slices), dim3(kRankBlock), 0, st, B.pods.as<mmp_pod_row>(), P,
+                               c->cfg.min_space_units, churn2, slices, p_lo, p_hi, static_cast<int32_t *>(d_rank));
+            HIP_TRY(c, hipGetLastError());
+        }
+    }
+    HIP_TRY(c, hipStreamSynchronize(st));
+    c->rank_pending = true;
+    return MMP_OK;
+}
+
+int mmp_shard_commit_dev(mmp_ctx *c, const void *d_rank)
+{
+    if (!c || !d_rank) return fail(c, MMP_EINVAL, "mmp_shard_commit_dev: null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->n_shards < 1 || !c->rank_pending) return fail(c, MMP_ESTATE, "mmp_shard_commit_dev: call mmp_shard_rank_dev first");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int32_t P = (int32_t)c->pods.size();
+    const int32_t W = std::max(div_up(P, 64), 1);
+    const int32_t Wfull = div_up(P, 64);
+    const int32_t T = std::max(c->n_types, 1);
+    if (c->n_types > 0 && c->types_w != Wfull)
+        return fail(c, MMP_ESTATE, "type bitmaps were loaded for a different pod count; reload them before commit");
+    const int32_t Wl = div_up(W, c->n_shards);
+    const int32_t w_lo = std::min(W, c->shard * Wl);
+    const int32_t Wn = std::min(W, w_lo + Wl) - w_lo;
+    const int32_t Wn1 = std::max(Wn, 1);
+    const size_t padded = (size_t)Wn1 * 64, padded_full = (size_t)W * 64;
+    SnapBufs &B = c->sb[1 - c->cur];  // B.pods was filled by mmp_shard_rank_dev
+    hipStream_t st = c->stream;
+
+    HIP_TRY(c, B.lru.ensure(padded * 8));
+    HIP_TRY(c, B.rem.ensure(padded * 8));
+    HIP_TRY(c, B.cnt.ensure(padded * 4));
+    HIP_TRY(c, B.rpm.ensure(padded * 4));
+    HIP_TRY(c, B.orig.ensure(padded * 4));
+    HIP_TRY(c, B.pos_of.ensure(padded_full * 4));
+    HIP_TRY(c, B.elig.ensure((size_t)T * Wn1 * 8));
+    HIP_TRY(c, B.elig_nors.ensure((size_t)T * Wn1 * 8));
+    HIP_TRY(c, B.pref.ensure((size_t)T * Wn1 * 8));
+    HIP_TRY(c, B.has_pref.ensure(T));
+    HIP_TRY(c, B.fullw.ensure((size_t)Wn1 * 8));
+    HIP_TRY(c, c->occupancy.ensure(padded_full * 4));
+    HIP_TRY(c, c->flag.ensure(sizeof(int32_t)));
+    HIP_TRY(c, c->stats_acc.ensure(sizeof(StatsAcc)));
+    HIP_TRY(c, c->rs_bad.ensure(padded_full));
+    HIP_TRY(c, c->rs_list.ensure(std::max<size_t>(c->replaced_rs.size(), 1) * 4));
+    HIP_TRY(c, c->d_allowed.ensure(std::max<size_t>((size_t)T * W, 1) * 8));
+    HIP_TRY(c, c->d_prefer.ensure(std::max<size_t>((size_t)T * W, 1) * 8));
+    HIP_TRY(c, c->d_has_allowed.ensure(T));
+
+    HIP_TRY(c, hipMemsetAsync(c->occupancy.p, 0, padded_full * 4, st));
+    HIP_TRY(c, hipMemsetAsync(c->flag.p, 0, sizeof(int32_t), st));
+    HIP_TRY(c, hipMemsetAsync(B.lru.p, 0, padded * 8, st));
+    HIP_TRY(c, hipMemsetAsync(B.rem.p, 0, padded * 8, st));
+    HIP_TRY(c, hipMemsetAsync(B.cnt.p, 0, padded * 4, st));
+    HIP_TRY(c, hipMemsetAsync(B.rpm.p, 0, padded * 4, st));
+    HIP_TRY(c, hipMemsetAsync(B.orig.p, 0, padded * 4, st));
+    HIP_TRY(c, hipMemsetAsync(B.pos_of.p, 0, padded_full * 4, st));
+    HIP_TRY(c, hipMemsetAsync(B.elig.p, 0, (size_t)T * Wn1 * 8, st));
+    HIP_TRY(c, hipMemsetAsync(B.elig_nors.p, 0, (size_t)T * Wn1 * 8, st));
+    HIP_TRY(c, hipMemsetAsync(B.pref.p, 0, (size_t)T * Wn1 * 8, st));
+    HIP_TRY(c, hipMemsetAsync(B.fullw.p, 0, (size_t)Wn1 * 8, st));
+
+    std::vector<uint8_t> hp(T, 0), ha(T, 0);
+    for (int32_t t = 0; t < c->n_types; t++) {
+        hp[t] = c->has_prefer[t];
+        ha[t] = c->has_allowed[t];
+    }
+    HIP_TRY(c, hipMemcpyAsync(B.has_pref.p, hp.data(), T, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_has_allowed.p, ha.data(), T, hipMemcpyHostToDevice, st));
+    if (c->n_types > 0 && !c->allowed.empty()) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_allowed.p, c->allowed.data(), c->allowed.size() * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->d_prefer.p, c->prefer.data(), c->prefer.size() * 8, hipMemcpyHostToDevice, st));
+    }
+    const int32_t n_rs = (int32_t)c->replaced_rs.size();
+    if (n_rs) HIP_TRY(c, hipMemcpyAsync(c->rs_list.p, c->replaced_rs.data(), (size_t)n_rs * 4, hipMemcpyHostToDevice, st));
+    const int64_t min_space = c->cfg.min_space_units;
+    StatsAcc init{};
+    init.global_lru = INT64_MAX;
+    HIP_TRY(c, hipMemcpyAsync(c->stats_acc.p, &init, sizeof init, hipMemcpyHostToDevice, st));
+
+    if (P > 0) {
+        hipLaunchKernelGGL(scatter_shard_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(), P,
+                           static_cast<const int32_t *>(d_rank), c->occupancy.as<int32_t>(), w_lo * 64, (w_lo + Wn) * 64,
+                           B.lru.as<int64_t>(), B.rem.as<int64_t>(), B.cnt.as<int32_t>(), B.rpm.as<int32_t>(),
+                           B.orig.as<int32_t>(), B.pos_of.as<int32_t>(), c->flag.as<int32_t>());
+        if (n_rs)
+            hipLaunchKernelGGL(mark_replaced_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(),
+                               P, c->rs_list.as<int32_t>(), n_rs, c->rs_bad.as<uint8_t>());
+        if (Wn > 0)
+            hipLaunchKernelGGL(build_masks_shard_kernel, dim3(div_up(T * Wn, 4)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(),
+                               P, Wfull, w_lo, Wn, T, min_space, B.orig.as<int32_t>(), c->d_allowed.as<uint64_t>(),
+                               c->d_has_allowed.as<uint8_t>(), c->d_prefer.as<uint64_t>(), B.has_pref.as<uint8_t>(),
+                               n_rs ? c->rs_bad.as<uint8_t>() : nullptr, B.elig.as<uint64_t>(),
+                               B.elig_nors.as<uint64_t>(), B.pref.as<uint64_t>(), B.fullw.as<uint64_t>());
+        hipLaunchKernelGGL(cluster_stats_kernel, dim3(std::min(div_up(P, 256), 512)), dim3(256), 0, st,
+                           B.pods.as<mmp_pod_row>(), P, min_space, c->stats_acc.as<StatsAcc>());
+        HIP_TRY(c, hipGetLastError());
+    }
+    int32_t bad = 0;
+    StatsAcc acc{};
+    HIP_TRY(c, hipMemcpyAsync(&bad, c->flag.p, sizeof bad, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(&acc, c->stats_acc.p, sizeof acc, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    c->rank_pending = false;
+    if (bad)
+        return fail(c, MMP_EORDER, "PLACEMENT_ORDER is not a total order on these rows; snapshot not published");
+
+    ShardSnap S{};
+    S.P = P;
+    S.W = W;
+    S.T = T;
+    S.any_rs = n_rs > 0;
+    S.min_space = min_space;
+    S.shard = c->shard;
+    S.n_shards = c->n_shards;
+    S.Wl = Wl;
+    S.w_lo = w_lo;
+    S.Wn = Wn;
+    S.lru = B.lru.as<int64_t>();
+    S.rem = B.rem.as<int64_t>();
+    S.cnt = B.cnt.as<int32_t>();
+    S.rpm = B.rpm.as<int32_t>();
+    S.orig = B.orig.as<int32_t>();
+    S.pos_of = B.pos_of.as<int32_t>();
+    S.elig = B.elig.as<uint64_t>();
+    S.elig_nors = B.elig_nors.as<uint64_t>();
+    S.pref = B.pref.as<uint64_t>();
+    S.has_pref = B.has_pref.as<uint8_t>();
+    S.fullw = B.fullw.as<uint64_t>();
+    c->ssnap = S;
+    Snap M{};  // what the non-placement entry points read in shard mode
+    M.P = P;
+    M.W = W;
+    M.T = T;
+    M.any_rs = S.any_rs;
+    M.min_space = min_space;
+    M.pos_of = S.pos_of;
+    c->snap = M;
+    c->cur = 1 - c->cur;
+    c->committed = true;
+    c->stats.total_capacity = (int64_t)acc.total_capacity;
+    c->stats.total_free = (int64_t)acc.total_free;
+    c->stats.global_lru = (int64_t)acc.global_lru;
+    c->stats.instance_count = acc.instance_count;
+    c->stats.model_copy_count = acc.model_copy_count;
+    return MMP_OK;
+}
+
+int mmp_shard_place_phase_dev(mmp_ctx *c, int32_t phase, const void *d_reqs, int32_t n, const void *d_extra, int64_t now,
+                              void *const *d_xchg, void *d_outs, void *stream)
+{
+    if (!c || phase < 1 || phase > 7 || n < 0 || !d_xchg || (n > 0 && (!d_reqs || (phase == 7 && !d_outs))))
+        return fail(c, MMP_EINVAL, "mmp_shard_place_phase_dev: bad argument");
+    for (int i = 0; i < 6; i++)
+        if (n > 0 && !d_xchg[i]) return fail(c, MMP_EINVAL, "mmp_shard_place_phase_dev: exchange buffer %d is null", i + 1);
+    if (c->n_shards < 1 || !c->committed) return fail(c, MMP_ESTATE, "no committed shard snapshot");
+    if (n == 0) return MMP_OK;
+    PlaceArgs A;
+    A.reqs = static_cast<const mmp_place_req *>(d_reqs);
+    A.models = c->models.as<mmp_model_row>();
+    A.ent_pod = c->ent_pod.as<int32_t>();
+    A.extra = static_cast<const int32_t *>(d_extra);
+    A.outs = static_cast<mmp_place_out *>(d_outs);
+    A.n = n;
+    A.n_models = c->n_models;
+    A.now = now;
+    XchgPtrs X{static_cast<int64_t *>(d_xchg[0]), static_cast<int64_t *>(d_xchg[1]), static_cast<int64_t *>(d_xchg[2]),
+               static_cast<int64_t *>(d_xchg[3]), static_cast<int64_t *>(d_xchg[4]), static_cast<int64_t *>(d_xchg[5])};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const ShardSnap &S = c->ssnap;
+    const int wpad = (std::max(S.Wn, 1) + 1) & ~1;
+    const size_t lds = (size_t)kPlaceWaves * 2 * wpad * sizeof(uint64_t);
+    if (lds > 64 * 1024) return fail(c, MMP_EINVAL, "shard slice too large for the LDS staging tile (%d words)", S.Wn);
+    const int blocks = std::min(div_up(n, kPlaceWaves), 256 * 8);
+    const dim3 grid(blocks), block(kPlaceWaves * 64);
+    switch (phase) {
+    case 1: hipLaunchKernelGGL(place_shard_kernel<1>, grid, block, lds, st, S, A, X, wpad); break;
+    case 2: hipLaunchKernelGGL(place_shard_kernel<2>, grid, block, lds, st, S, A, X, wpad); break;
+    case 3: hipLaunchKernelGGL(place_shard_kernel<3>, grid, block, lds, st, S, A, X, wpad); break;
+    case 4: hipLaunchKernelGGL(place_shard_kernel<4>, grid, block, lds, st, S, A, X, wpad); break;
+    case 5: hipLaunchKernelGGL(place_shard_kernel<5>, grid, block, lds, st, S, A, X, wpad); break;
+    case 6: hipLaunchKernelGGL(place_shard_kernel<6>, grid, block, lds, st, S, A, X, wpad); break;
+    default: hipLaunchKernelGGL(place_shard_finish_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, S, A, X); break;
+    }
+    HIP_TRY(c, hipGetLastError());
+    return MMP_OK;
+}
+
 /* ---- decisions ---------------------------------------------------------- */
 
 int mmp_place_batch_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs,
@@ -545,6 +792,7 @@ int mmp_place_batch_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d
 {
     if (!c || n < 0 || (n > 0 && (!d_reqs || !d_outs))) return fail(c, MMP_EINVAL, "mmp_place_batch_dev: bad argument");
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
     return place_launch(c, d_reqs, n, d_extra, now, d_outs, static_cast<hipStream_t>(stream));
 }
 
@@ -558,6 +806,7 @@ int mmp_place_batch(mmp_ctx *c, const mmp_place_req *reqs, int32_t n, const int3
             return fail(c, MMP_EINVAL, "mmp_place_batch: request %d extra range out of bounds", i);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
     if (n == 0) return MMP_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     hipStream_t st = c->stream;

@@ -1,0 +1,662 @@
+// shard_kernels.hpp — load-target selection with the POD AXIS sharded across GPUs.
+//
+// SURVEY.md §8(e)(2) / BASELINE.json north_star: shard g owns a contiguous range of
+// PLACEMENT_ORDER positions (rank space), i.e. the words [w_lo, w_lo+Wn) of every
+// rank-ordered bitmap and the matching slice of every per-pod column.  Every
+// shard sees the whole decision batch.  One CacheMissForwardingLB.getNext
+// (MM.java:4776-5005) then becomes six local scans separated by all-reduces of
+// small per-decision vectors (the host does the collective between two phase
+// launches — RCCL all-reduce over xGMI, see modelmesh_amd/dist.py):
+//
+//   phase 1  first eligible position, with / without excludeReplicaSets   -> MIN
+//   phase 2  bestEntry's row (owner), first preferred / first full after it,
+//            self's eligibility bits (owner)                              -> MIN
+//   phase 3  the re-designated preferred best's row (case (a), :4836-4841)
+//            or the first pod outside the LRU window (case (b), :4862-4866) -> MIN
+//   phase 4  first break position of the shortlist loop (:4905-4928), or
+//            the minimum rpm of the preferred candidates (case (b))       -> MIN
+//   phase 5  per-shard candidate counts + shortlist hash                  -> SUM
+//   phase 6  the shard that holds the index-th survivor picks it (:4981-4986) -> MIN
+//   phase 7  every shard writes the (identical) result rows
+//
+// Each phase re-derives the decision state from the reduced vectors of the
+// earlier phases (derive1..derive5 below are the single source of that logic and
+// mirror place_one() in place_kernel.hpp clause by clause), then does its own
+// local scan.  Results are bit-identical to the single-GPU kernel (tests/test_shard_gpu.py).
+#pragma once
+#include "place_kernel.hpp"
+
+namespace mmp {
+
+constexpr int64_t kXMax = INT64_MAX;  // identity of the MIN all-reduce
+constexpr int kX1 = 2, kX2 = 9, kX3 = 6, kX4 = 3, kX6 = 1;
+__host__ __device__ constexpr int x5_slots(int n_shards) { return 1 + n_shards; }
+constexpr int kMaxShards = 64;
+
+struct ShardSnap {
+    int32_t P, W, T, any_rs;
+    int64_t min_space;
+    int32_t shard, n_shards;
+    int32_t Wl;    // words per shard: owner(pos) = (pos >> 6) / Wl
+    int32_t w_lo;  // first owned word
+    int32_t Wn;    // owned words (0 if this shard is beyond the table)
+    // local slices, indexed by (pos - w_lo*64)
+    const int64_t *lru, *rem;
+    const int32_t *cnt, *rpm, *orig;
+    const int32_t *pos_of;  // full: pod index -> global position
+    const uint64_t *elig, *elig_nors, *pref;  // [T][max(Wn,1)]
+    const uint8_t *has_pref;
+    const uint64_t *fullw;  // [Wn]
+};
+
+struct XchgPtrs {
+    int64_t *x1, *x2, *x3, *x4, *x5, *x6;
+};
+
+__device__ __forceinline__ int xpos(int64_t v) { return v >= (int64_t)kNoPos ? kNoPos : (int)v; }
+__device__ __forceinline__ int64_t gpos(const ShardSnap &S, int local) { return local == kNoPos ? kXMax : (int64_t)(local + S.w_lo * 64); }
+// global position -> local position clamped into [0, Wn*64]
+__device__ __forceinline__ int lpos(const ShardSnap &S, int64_t g)
+{
+    const int64_t l = g - (int64_t)S.w_lo * 64;
+    const int64_t hi = (int64_t)S.Wn * 64;
+    return (int)(l < 0 ? 0 : (l > hi ? hi : l));
+}
+__device__ __forceinline__ bool owns(const ShardSnap &S, int g) { return g >= S.w_lo * 64 && g < (S.w_lo + S.Wn) * 64; }
+__device__ __forceinline__ int owner_of(const ShardSnap &S, int g) { return (g >> 6) / S.Wl; }
+
+// The decision state every shard re-derives identically from the reduced vectors.
+struct DState {
+    // request
+    int selfpos;
+    bool favour;
+    int64_t f_lru, f_rem;
+    int32_t f_rpm, f_cnt;
+    int64_t ago;
+    bool has_pm;
+    // after X1
+    bool none, use_nors;
+    int best0;
+    // after X2
+    int64_t e_lru, e_rem;
+    int32_t e_cnt, e_rpm, e_orig;
+    bool e_pref, self_in_ew, self_in_pm;
+    int q1, q2;
+    bool us, best_is_full, case_a, case_b;
+    int64_t b_lru, b_rem;
+    int32_t b_cnt, b_rpm, b_orig;
+    int bestpos, limit;
+    bool use_dm, mode_b;
+    // after X3
+    int exit_chosen;  // 0: keep going; else MMP_NONE / MMP_SELF early return with best = exit_best
+    int exit_best;
+    int start;
+    bool ns_break, self_break;
+    int32_t thr;
+    // after X4
+    int end;
+    bool self_in_d, self_in_c;
+    int32_t mn_b;
+    // after X5
+    int ccount, remaining, index;
+    uint64_t hsum;
+    bool null0, null_s, null_o, apply_b;
+    RpmRule rule;
+    int sel_shard, sel_prefix;
+};
+
+__device__ __forceinline__ void derive0(const ShardSnap &S, const PlaceArgs &A, const mmp_place_req &rq, int type, DState &D)
+{
+    D.selfpos = (rq.self_pod >= 0 && rq.self_pod < S.P) ? S.pos_of[rq.self_pod] : -1;
+    D.favour = (rq.flags & MMP_REQ_FAVOUR_SELF) != 0;
+    D.f_lru = rq.fresh_lru;
+    D.f_rem = remaining_of(rq.fresh_capacity, rq.fresh_used);
+    D.f_rpm = rq.fresh_rpm;
+    D.f_cnt = rq.fresh_count;
+    D.ago = age_of(rq.last_used, A.now);
+    D.has_pm = S.has_pref[type] != 0;
+    D.exit_chosen = 0;
+    D.exit_best = -1;
+}
+
+// MM.java:4793-4805
+__device__ __forceinline__ void derive1(const ShardSnap &S, const int64_t *x1, DState &D)
+{
+    const int fe = xpos(x1[0]), fn = xpos(x1[1]);
+    D.use_nors = (fe == kNoPos) && S.any_rs;
+    D.best0 = fe != kNoPos ? fe : (S.any_rs ? fn : kNoPos);
+    D.none = D.best0 == kNoPos;
+    if (D.none) {
+        D.exit_chosen = MMP_NONE;
+        D.exit_best = -1;
+    }
+}
+
+// MM.java:4806-4823 and the split into case (a) / case (b)
+__device__ __forceinline__ void derive2(const ShardSnap &S, const int64_t *x2, DState &D)
+{
+    D.e_lru = x2[0];
+    D.e_rem = x2[1];
+    D.e_cnt = (int32_t)x2[2];
+    D.e_rpm = (int32_t)x2[3];
+    D.e_orig = (int32_t)x2[4];
+    D.e_pref = x2[5] == 1;
+    D.q1 = xpos(x2[6]);
+    D.q2 = xpos(x2[7]);
+    const int64_t sb = x2[8] == kXMax ? 0 : x2[8];
+    D.self_in_ew = sb & 1;
+    D.self_in_pm = (sb >> 1) & 1;
+    D.us = D.best0 == D.selfpos;  // :4808
+    D.b_lru = D.us ? D.f_lru : D.e_lru;
+    D.b_rem = D.us ? D.f_rem : D.e_rem;
+    D.b_cnt = D.us ? D.f_cnt : D.e_cnt;
+    D.b_rpm = D.us ? D.f_rpm : D.e_rpm;
+    D.b_orig = D.e_orig;
+    D.best_is_full = D.b_rem < S.min_space;  // :4811 (never recomputed, quirk B#14)
+    D.bestpos = D.best0;
+    D.use_dm = D.has_pm;
+    D.limit = S.P;
+    D.mode_b = false;
+    D.case_a = D.case_b = false;
+    if (D.has_pm && !D.e_pref) {  // !simpleCase
+        if (!D.best_is_full) {
+            if (D.q1 != kNoPos && D.q1 <= D.q2)
+                D.case_a = true;  // a preferred pod before the first full one: its row comes in X3
+            else {
+                D.use_dm = false;
+                D.limit = D.q2 < S.P ? D.q2 : S.P;
+            }
+        } else
+            D.case_b = true;  // the LRU-window bound comes in X3
+    }
+}
+
+__device__ __forceinline__ void derive3(const ShardSnap &S, const PlaceArgs &A, const int64_t *x3, DState &D)
+{
+    if (D.case_a) {  // :4836-4841
+        D.bestpos = D.q1;
+        D.b_lru = x3[0];
+        D.b_rem = x3[1];
+        D.b_cnt = (int32_t)x3[2];
+        D.b_rpm = (int32_t)x3[3];
+        D.b_orig = (int32_t)x3[4];
+        D.us = D.q1 == D.selfpos;
+    } else if (D.case_b) {  // :4853-4887
+        const int q3 = xpos(x3[5]);
+        const int lim = q3 < S.P ? q3 : S.P;
+        D.limit = lim;
+        if (D.q1 < lim)
+            D.mode_b = true;
+        else
+            D.use_dm = false;
+    }
+    if (D.mode_b) {
+        D.start = D.best0 + 1;
+        if (D.selfpos >= D.start && D.selfpos < D.limit && D.self_in_ew && D.self_in_pm && D.favour) {
+            D.exit_chosen = MMP_NONE;  // :4871-4873
+            D.exit_best = D.e_orig;
+        }
+        D.ns_break = D.self_break = false;
+        D.thr = 0;
+        return;
+    }
+    if (D.us && D.favour) {  // :4891-4895
+        D.exit_chosen = MMP_SELF;
+        D.exit_best = D.b_orig;
+    }
+    const int64_t oldest = D.b_lru;
+    if (D.best_is_full) {
+        const int64_t rel = age_of(oldest, A.now) / 10;
+        const int64_t d1 = jsub64(D.f_lru, oldest), d2 = jsub64(D.e_lru, oldest);
+        D.ns_break = d1 > 45000LL && d1 > rel;  // :4913-4917
+        D.self_break = d2 > 45000LL && d2 > rel;
+    } else {
+        const int64_t q = D.b_rem >> 2;  // :4922
+        D.ns_break = D.f_rem < S.min_space || D.f_rem < q;
+        D.self_break = D.e_rem < S.min_space || D.e_rem < q;
+    }
+    D.start = D.bestpos + 1;
+    D.thr = (int32_t)((uint32_t)D.b_cnt + (uint32_t)(D.b_cnt >> 2));  // :4926
+}
+
+__device__ __forceinline__ void derive4(const ShardSnap &S, const int64_t *x4, DState &D)
+{
+    D.end = D.limit;
+    D.self_in_d = D.self_in_c = false;
+    D.mn_b = (int32_t)(x4[2] == kXMax ? INT32_MAX : x4[2]);
+    if (D.mode_b) return;
+    D.self_in_d = D.selfpos >= D.start && D.selfpos < D.limit && D.self_in_ew && (!D.use_dm || D.self_in_pm);
+    if (D.ns_break) {
+        const int p1 = xpos(x4[0]);
+        D.end = p1 < D.end ? p1 : D.end;
+    }
+    if (D.self_in_d && D.self_break) D.end = D.selfpos < D.end ? D.selfpos : D.end;
+    if (!D.best_is_full) {
+        const int pc = xpos(x4[1]);
+        D.end = pc < D.end ? pc : D.end;
+    }
+    D.self_in_c = D.self_in_d && D.selfpos < D.end;
+    if (D.self_in_c && D.favour && D.exit_chosen == 0) {  // :4931-4933
+        D.exit_chosen = MMP_SELF;
+        D.exit_best = D.b_orig;
+    }
+}
+
+// rpm filter (:4951-4980) and the owner of the index-th survivor
+__device__ __forceinline__ void derive5(const ShardSnap &S, const mmp_place_req &rq, const int64_t *x5, DState &D)
+{
+    D.hsum = (uint64_t)x5[0];
+    int cc = 0, nn = 0;
+    for (int g = 0; g < S.n_shards; g++) {
+        cc += (int)(uint32_t)((uint64_t)x5[1 + g] & 0xffffffffull);
+        nn += (int)(uint32_t)((uint64_t)x5[1 + g] >> 32);
+    }
+    D.ccount = cc;
+    D.remaining = cc;
+    D.null0 = D.null_s = D.null_o = D.apply_b = false;
+    const int own_b = owner_of(S, D.bestpos), own_s = D.self_in_c ? owner_of(S, D.selfpos) : -1;
+    if (cc >= 2) {
+        if (D.mode_b) {
+            D.rule.init(D.ago, D.mn_b);
+            if (D.rule.active) {
+                D.apply_b = true;
+                D.remaining = nn;
+            }
+        } else {
+            const int n_others = cc - 1 - (D.self_in_c ? 1 : 0);
+            int32_t mn = D.b_rpm;
+            if (D.self_in_c && D.e_rpm < mn) mn = D.e_rpm;
+            if (n_others > 0 && D.f_rpm < mn) mn = D.f_rpm;
+            D.rule.init(D.ago, mn);
+            D.null0 = D.rule.nulls(D.b_rpm);
+            D.null_s = D.self_in_c && D.rule.nulls(D.e_rpm);
+            D.null_o = n_others > 0 && D.rule.nulls(D.f_rpm);
+            D.remaining = cc - (D.null0 ? 1 : 0) - (D.null_s ? 1 : 0) - (D.null_o ? n_others : 0);
+        }
+    }
+    D.index = D.remaining <= 1 ? 0 : (int)(((uint64_t)rq.pick * (uint64_t)(uint32_t)D.remaining) >> 32);
+    D.sel_shard = -1;
+    D.sel_prefix = 0;
+    if (D.remaining >= 1) {
+        int run = 0;
+        for (int g = 0; g < S.n_shards; g++) {
+            const int c = (int)(uint32_t)((uint64_t)x5[1 + g] & 0xffffffffull);
+            int r;
+            if (D.mode_b)
+                r = D.apply_b ? (int)(uint32_t)((uint64_t)x5[1 + g] >> 32) : c;
+            else {
+                const int sp = (g == own_b ? 1 : 0) + (g == own_s ? 1 : 0);
+                r = c - ((D.null0 && g == own_b) ? 1 : 0) - ((D.null_s && g == own_s) ? 1 : 0) - (D.null_o ? c - sp : 0);
+            }
+            if (D.index < run + r) {
+                D.sel_shard = g;
+                D.sel_prefix = run;
+                break;
+            }
+            run += r;
+        }
+    }
+}
+
+// local staging of the filter() result for this shard's words
+__device__ __forceinline__ void stage_local(const ShardSnap &S, const uint64_t *src, uint64_t *ew, const int32_t *ents,
+                                            int32_t n_ents, const int32_t *extra, int32_t n_extra)
+{
+    const int lane = lane_id();
+    for (int w = lane; w < S.Wn; w += 64) ew[w] = src[w];
+    wave_sync();
+    const int nex = n_ents + n_extra;
+    for (int i = lane; i < nex; i += 64) {
+        const int32_t pod = i < n_ents ? ents[i] : extra[i - n_ents];
+        if (pod >= 0 && pod < S.P) {
+            const int pos = S.pos_of[pod];
+            if (owns(S, pos)) {
+                const int lp = pos - S.w_lo * 64;
+                atomicAnd((unsigned long long *)&ew[lp >> 6], ~(1ull << (lp & 63)));
+            }
+        }
+    }
+    wave_sync();
+}
+
+// candidate word lw of this shard (before the rpm filter)
+__device__ __forceinline__ uint64_t cand_word(const ShardSnap &S, const DState &D, const uint64_t *ew, const uint64_t *Pm, int lw)
+{
+    const int ls = lpos(S, D.start), le = lpos(S, D.mode_b ? D.limit : D.end);
+    uint64_t v = ew[lw];
+    if (D.mode_b || D.use_dm) v &= Pm[lw];
+    v = ls < le ? clip_word(v, lw, ls, le) : 0ull;
+    if (!D.mode_b && owns(S, D.bestpos)) {
+        const int lb = D.bestpos - S.w_lo * 64;
+        if ((lb >> 6) == lw) v |= 1ull << (lb & 63);
+    }
+    return v;
+}
+
+__device__ __forceinline__ void store_lane0(int64_t *p, int64_t v)
+{
+    if (lane_id() == 0) *p = v;
+}
+
+template <int PH>
+__device__ __forceinline__ void shard_phase(const ShardSnap &S, const PlaceArgs &A, const XchgPtrs &X, int d, uint64_t *ew, uint64_t *fw)
+{
+    const int lane = lane_id();
+    const int G = S.n_shards;
+    int64_t *x1 = X.x1 + (size_t)d * kX1, *x2 = X.x2 + (size_t)d * kX2, *x3 = X.x3 + (size_t)d * kX3;
+    int64_t *x4 = X.x4 + (size_t)d * kX4, *x5 = X.x5 + (size_t)d * x5_slots(G), *x6 = X.x6 + (size_t)d * kX6;
+    const mmp_place_req rq = A.reqs[d];
+    const bool bad_model = rq.model < 0 || rq.model >= A.n_models;
+    mmp_model_row m{};
+    if (!bad_model) m = A.models[rq.model];
+    int type = m.type;
+    if (type < 0 || type >= S.T) type = 0;
+    const int32_t *ents = A.ent_pod + m.ent_off;
+    const int32_t n_ents = bad_model ? 0 : m.n_loaded + m.n_failed;
+    const int32_t *extra = A.extra + rq.extra_off;
+    const int Wn1 = S.Wn > 0 ? S.Wn : 1;
+    const uint64_t *Pm = S.pref + (size_t)type * Wn1;
+
+    if (PH == 1) {
+        int64_t fe = kXMax, fn = kXMax;
+        if (!bad_model) {
+            stage_local(S, S.elig + (size_t)type * Wn1, ew, ents, n_ents, extra, rq.n_extra);
+            fe = gpos(S, first_set_from(ew, nullptr, 0, S.Wn));
+            if (S.any_rs) {
+                wave_sync();
+                stage_local(S, S.elig_nors + (size_t)type * Wn1, ew, ents, n_ents, extra, rq.n_extra);
+                fn = gpos(S, first_set_from(ew, nullptr, 0, S.Wn));
+            }
+        }
+        store_lane0(&x1[0], fe);
+        store_lane0(&x1[1], fn);
+        return;
+    }
+
+    DState D;
+    derive0(S, A, rq, type, D);
+    derive1(S, x1, D);
+    if (!D.none) stage_local(S, (D.use_nors ? S.elig_nors : S.elig) + (size_t)type * Wn1, ew, ents, n_ents, extra, rq.n_extra);
+
+    if (PH == 2) {
+        int64_t v[kX2];
+        for (int i = 0; i < kX2; i++) v[i] = kXMax;
+        if (!D.none) {
+            if (owns(S, D.best0)) {
+                const int lb = D.best0 - S.w_lo * 64;
+                v[0] = S.lru[lb];
+                v[1] = S.rem[lb];
+                v[2] = S.cnt[lb];
+                v[3] = S.rpm[lb];
+                v[4] = S.orig[lb];
+                v[5] = (D.has_pm && test_bit(Pm, lb)) ? 1 : 0;
+            }
+            const int lnext = lpos(S, (int64_t)D.best0 + 1);
+            if (D.has_pm) v[6] = gpos(S, first_set_from(ew, Pm, lnext, S.Wn));
+            v[7] = gpos(S, first_set_from(ew, S.fullw, lnext, S.Wn));
+            if (D.selfpos >= 0 && owns(S, D.selfpos)) {
+                const int lsp = D.selfpos - S.w_lo * 64;
+                v[8] = (test_bit(ew, lsp) ? 1 : 0) | ((D.has_pm && test_bit(Pm, lsp)) ? 2 : 0);
+            }
+        }
+        if (lane < kX2) {
+            int64_t mine = kXMax;
+            for (int i = 0; i < kX2; i++)
+                if (lane == i) mine = v[i];
+            x2[lane] = mine;
+        }
+        return;
+    }
+    if (!D.none) derive2(S, x2, D);
+
+    if (PH == 3) {
+        int64_t v[kX3];
+        for (int i = 0; i < kX3; i++) v[i] = kXMax;
+        if (!D.none) {
+            if (D.case_a && owns(S, D.q1)) {
+                const int lq = D.q1 - S.w_lo * 64;
+                v[0] = S.lru[lq];
+                v[1] = S.rem[lq];
+                v[2] = S.cnt[lq];
+                v[3] = S.rpm[lq];
+                v[4] = S.orig[lq];
+            }
+            if (D.case_b)
+                v[5] = gpos(S, first_lru_break(ew, lpos(S, (int64_t)D.best0 + 1), S.Wn, S.lru, D.b_lru, 120000LL,
+                                               age_of(D.b_lru, A.now) / 4));
+        }
+        if (lane < kX3) {
+            int64_t mine = kXMax;
+            for (int i = 0; i < kX3; i++)
+                if (lane == i) mine = v[i];
+            x3[lane] = mine;
+        }
+        return;
+    }
+    if (!D.none) derive3(S, A, x3, D);
+
+    if (PH == 4) {
+        int64_t p1 = kXMax, pc = kXMax, mnb = kXMax;
+        if (D.exit_chosen == 0) {
+            const int ls = lpos(S, D.start), ll = lpos(S, D.limit);
+            if (D.mode_b) {
+                int mn = INT32_MAX;
+                for (int base = 0; base < S.Wn; base += 64) {
+                    const int w = base + lane;
+                    if (w < S.Wn) {
+                        const uint64_t v = cand_word(S, D, ew, Pm, w);
+                        for (uint64_t t = v; t; t &= t - 1) {
+                            const int32_t r = S.rpm[w * 64 + (__ffsll((unsigned long long)t) - 1)];
+                            mn = r < mn ? r : mn;
+                        }
+                    }
+                }
+                mn = wave_min_i32(mn);
+                if (mn != INT32_MAX) mnb = mn;
+            } else {
+                const uint64_t *Dm = D.use_dm ? Pm : nullptr;
+                if (D.ns_break) {
+                    int l1 = first_set_from(ew, Dm, ls, S.Wn);
+                    if (l1 != kNoPos && l1 + S.w_lo * 64 == D.selfpos) l1 = first_set_from(ew, Dm, l1 + 1, S.Wn);
+                    p1 = gpos(S, l1);
+                }
+                if (!D.best_is_full) pc = gpos(S, first_count_break(ew, Dm, ls, ll, S.cnt, D.thr));
+            }
+        }
+        store_lane0(&x4[0], p1);
+        store_lane0(&x4[1], pc);
+        store_lane0(&x4[2], mnb);
+        return;
+    }
+    if (!D.none) derive4(S, x4, D);
+
+    if (PH == 5) {
+        int cc = 0, nn = 0;
+        uint64_t h = 0;
+        if (D.exit_chosen == 0) {
+            RpmRule rb;
+            rb.init(D.ago, D.mn_b);
+            for (int base = 0; base < S.Wn; base += 64) {
+                const int w = base + lane;
+                if (w < S.Wn) {
+                    const uint64_t v = cand_word(S, D, ew, Pm, w);
+                    cc += __popcll((unsigned long long)v);
+                    if (v) h += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)(S.w_lo + w + 1)));
+                    if (D.mode_b) {
+                        for (uint64_t t = v; t; t &= t - 1)
+                            if (!rb.nulls(S.rpm[w * 64 + (__ffsll((unsigned long long)t) - 1)])) nn++;
+                    }
+                }
+            }
+            cc = wave_sum_i32(cc);
+            nn = wave_sum_i32(nn);
+            h = wave_sum_u64(h);
+        }
+        for (int g = lane; g < G; g += 64)
+            x5[1 + g] = g == S.shard ? (int64_t)(((uint64_t)(uint32_t)nn << 32) | (uint64_t)(uint32_t)cc) : 0;
+        store_lane0(&x5[0], (int64_t)h);
+        return;
+    }
+    if (D.exit_chosen == 0) derive5(S, rq, x5, D);
+
+    if (PH == 6) {
+        int64_t chosen = kXMax;
+        if (D.exit_chosen == 0 && D.ccount > 0 && D.sel_shard == S.shard) {
+            // rebuild this shard's surviving candidate words
+            const int lb = owns(S, D.bestpos) ? D.bestpos - S.w_lo * 64 : -1;
+            const int lsf = (D.self_in_c && owns(S, D.selfpos)) ? D.selfpos - S.w_lo * 64 : -1;
+            for (int base = 0; base < S.Wn; base += 64) {
+                const int w = base + lane;
+                if (w < S.Wn) {
+                    uint64_t v = cand_word(S, D, ew, Pm, w);
+                    if (D.mode_b) {
+                        if (D.apply_b) {
+                            uint64_t keep = v;
+                            for (uint64_t t = v; t; t &= t - 1) {
+                                const int bit = __ffsll((unsigned long long)t) - 1;
+                                if (D.rule.nulls(S.rpm[w * 64 + bit])) keep &= ~(1ull << bit);
+                            }
+                            v = keep;
+                        }
+                    } else {
+                        uint64_t special = 0;
+                        if (lb >= 0 && (lb >> 6) == w) special |= 1ull << (lb & 63);
+                        if (lsf >= 0 && (lsf >> 6) == w) special |= 1ull << (lsf & 63);
+                        if (D.null_o) v &= special;
+                        if (D.null0 && lb >= 0 && (lb >> 6) == w) v &= ~(1ull << (lb & 63));
+                        if (D.null_s && lsf >= 0 && (lsf >> 6) == w) v &= ~(1ull << (lsf & 63));
+                    }
+                    fw[w] = v;
+                }
+            }
+            wave_sync();
+            const int cl = S.Wn > 0 ? select_in_range(fw, 0, S.Wn - 1, D.index - D.sel_prefix) : kNoPos;
+            if (cl != kNoPos) {
+                chosen = S.orig[cl];
+                if (!D.favour && cl + S.w_lo * 64 == D.selfpos) chosen = MMP_SELF;  // :4989-4991
+            }
+        }
+        store_lane0(&x6[0], chosen);
+        return;
+    }
+}
+
+// LDS per workgroup: kPlaceWaves × 2 bitmaps × wpad words (wpad covers the owned words).
+template <int PH>
+__global__ __launch_bounds__(kPlaceWaves * 64) void place_shard_kernel(ShardSnap S, PlaceArgs A, XchgPtrs X, int32_t wpad)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint64_t *ew = reinterpret_cast<uint64_t *>(smem) + (size_t)wave * 2 * wpad;
+    uint64_t *fw = ew + wpad;
+    for (int d = blockIdx.x * kPlaceWaves + wave; d < A.n; d += gridDim.x * kPlaceWaves) {
+        shard_phase<PH>(S, A, X, d, ew, fw);
+        wave_sync();
+    }
+}
+
+// phase 7: one thread per decision writes the result row (identical on every shard)
+__global__ void place_shard_finish_kernel(ShardSnap S, PlaceArgs A, XchgPtrs X)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= A.n) return;
+    const int G = S.n_shards;
+    const mmp_place_req rq = A.reqs[d];
+    mmp_place_out o;
+    o.chosen = MMP_NONE;
+    o.best = -1;
+    o.n_candidates = 0;
+    o.hash = 0;
+    if (rq.model >= 0 && rq.model < A.n_models) {
+        const mmp_model_row m = A.models[rq.model];
+        int type = m.type;
+        if (type < 0 || type >= S.T) type = 0;
+        DState D;
+        derive0(S, A, rq, type, D);
+        derive1(S, X.x1 + (size_t)d * kX1, D);
+        if (!D.none) {
+            derive2(S, X.x2 + (size_t)d * kX2, D);
+            derive3(S, A, X.x3 + (size_t)d * kX3, D);
+            derive4(S, X.x4 + (size_t)d * kX4, D);
+            if (D.exit_chosen == 0) {
+                derive5(S, rq, X.x5 + (size_t)d * x5_slots(G), D);
+                o.best = D.b_orig;
+                if (D.ccount > 0) {  // :4941-4943 otherwise
+                    const int64_t c = X.x6[(size_t)d * kX6];
+                    o.chosen = c == kXMax ? MMP_NONE : (int32_t)c;
+                    o.n_candidates = D.ccount;
+                    o.hash = (uint32_t)(D.hsum ^ (D.hsum >> 32)) ^ ((uint32_t)D.remaining * 0x9E3779B1u);
+                }
+            } else {
+                o.chosen = D.exit_chosen;
+                o.best = D.exit_best;
+            }
+        }
+    }
+    A.outs[d] = o;
+}
+
+// ---- sharded commit ---------------------------------------------------------------------------
+// After the SUM all-reduce every shard holds the full rank[] (4 B per pod — the only replicated
+// per-pod state besides the raw input rows).  Each shard keeps the columns of the positions it owns.
+__global__ void scatter_shard_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, const int32_t *__restrict__ rank,
+                                     int32_t *__restrict__ occupancy, int32_t pos_lo, int32_t pos_hi,
+                                     int64_t *__restrict__ lru, int64_t *__restrict__ rem, int32_t *__restrict__ cnt,
+                                     int32_t *__restrict__ rpm, int32_t *__restrict__ orig, int32_t *__restrict__ pos_of,
+                                     int32_t *__restrict__ err)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int pos = rank[p];
+    if (pos < 0 || pos >= P || atomicAdd(&occupancy[pos], 1) != 0) {
+        atomicExch(err, 1);
+        return;
+    }
+    pos_of[p] = pos;
+    if (pos < pos_lo || pos >= pos_hi) return;
+    const mmp_pod_row r = pods[p];
+    const int l = pos - pos_lo;
+    lru[l] = r.lru_time;
+    rem[l] = remaining_of(r.capacity, r.used);
+    cnt[l] = r.count;
+    rpm[l] = r.rpm;
+    orig[l] = p;
+}
+
+// One wave per (bitmap row, owned word); `orig` is the local position -> pod slice.
+__global__ void build_masks_shard_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int32_t Wfull, int32_t w_lo,
+                                         int32_t Wn, int32_t T, int64_t min_space, const int32_t *__restrict__ orig,
+                                         const uint64_t *__restrict__ allowed, const uint8_t *__restrict__ has_allowed,
+                                         const uint64_t *__restrict__ prefer, const uint8_t *__restrict__ has_prefer,
+                                         const uint8_t *__restrict__ rs_bad, uint64_t *__restrict__ elig,
+                                         uint64_t *__restrict__ elig_nors, uint64_t *__restrict__ pref,
+                                         uint64_t *__restrict__ fullw)
+{
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= T * Wn) return;
+    const int t = wave / Wn, w = wave - t * Wn;
+    const int pos = (w_lo + w) * 64 + lane;
+    bool e = false, en = false, pf = false, fl = false;
+    if (pos < P) {
+        const int p = orig[w * 64 + lane];
+        const mmp_pod_row r = pods[p];
+        const bool present = (r.flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE)) == 0;
+        const bool live = (r.flags & MMP_POD_LIVE) != 0;
+        bool al = true;
+        if (has_allowed && has_allowed[t]) al = (allowed[(size_t)t * Wfull + (p >> 6)] >> (p & 63)) & 1ull;
+        en = present && live && al;
+        e = en && !(rs_bad && rs_bad[p]);
+        if (has_prefer && has_prefer[t]) pf = (prefer[(size_t)t * Wfull + (p >> 6)] >> (p & 63)) & 1ull;
+        fl = remaining_of(r.capacity, r.used) < min_space;
+    }
+    const uint64_t be = __ballot(e), ben = __ballot(en), bp = __ballot(pf), bf = __ballot(fl);
+    if (lane == 0) {
+        elig[(size_t)t * Wn + w] = be;
+        elig_nors[(size_t)t * Wn + w] = ben;
+        pref[(size_t)t * Wn + w] = bp;
+        if (t == 0) fullw[w] = bf;
+    }
+}
+
+}  // namespace mmp

@@ -106,12 +106,15 @@ constexpr int kRankBlock = 256;
 __global__ __launch_bounds__(kRankBlock) void rank_pods_kernel(const mmp_pod_row *__restrict__ pods,
                                                                int32_t P, int64_t min_space,
                                                                int64_t churn2, int32_t slices,
+                                                               int32_t p_lo, int32_t p_hi,
                                                                int32_t *__restrict__ rank)
 {
+    // ranks the pods [p_lo, p_hi) against ALL pods (a pod-axis shard ranks only its own slice,
+    // the slices are then summed by an all-reduce; unsharded: [0, P))
     __shared__ RankRow tile[kRankBlock];
-    const int p = blockIdx.x * kRankBlock + threadIdx.x;
+    const int p = p_lo + blockIdx.x * kRankBlock + threadIdx.x;
     RankRow me;
-    if (p < P) me = make_rank_row(pods[p], min_space);
+    if (p < p_hi) me = make_rank_row(pods[p], min_space);
     // this block compares against q in [q0, q1)
     const int per = (P + slices - 1) / slices;
     const int q0 = blockIdx.y * per;
@@ -123,13 +126,13 @@ __global__ __launch_bounds__(kRankBlock) void rank_pods_kernel(const mmp_pod_row
         if (q < q1) tile[threadIdx.x] = make_rank_row(pods[q], min_space);
         __syncthreads();
         const int nq = min(kRankBlock, q1 - base);
-        if (p < P) {
+        if (p < p_hi) {
             for (int j = 0; j < nq; j++) {
                 if (base + j != p && placement_less(tile[j], me, churn2)) before++;
             }
         }
     }
-    if (p < P && before) atomicAdd(&rank[p], before);
+    if (p < p_hi && before) atomicAdd(&rank[p], before);
 }
 
 // Scatter rows into rank order; detect a non-total order (two rows with the

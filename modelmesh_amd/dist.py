@@ -1,11 +1,17 @@
-"""Multi-GPU layout of the path: one process per GPU, model-axis sharding, no data-path collective.
+"""Multi-GPU layouts of the path: one process per GPU (torch.distributed; backend "nccl" IS RCCL on
+ROCm, the same code runs on "gloo" — tests/test_dist_gloo.py).
 
-Decisions against one snapshot are independent and the snapshot is ~1 MB, so
-every rank holds the full snapshot and owns a contiguous slice of the request table.  The only
-collectives are control-plane: a barrier around timed regions, a MAX over ranks of elapsed time,
-and (when the caller wants the full result table in one place) an all_gather of the 16-byte
-results.  `torch.distributed` with backend "nccl" is RCCL on ROCm; the same code runs on "gloo"
-(tests/test_dist_gloo.py).
+1. Model axis (the throughput layout): decisions against one snapshot are
+   independent and the snapshot is ~1 MB, so every rank holds the full snapshot and owns a contiguous
+   slice of the request table.  No data-path collective; control-plane only (barrier, MAX of elapsed
+   time, optional all_gather of the 16-byte results).
+
+2. Pod axis (BASELINE.json north_star / config C4): rank g owns a contiguous range
+   of PLACEMENT_ORDER positions; every rank sees the whole batch.  `PodShardedPlacer` drives the
+   library's phase kernels (include/mmplace.h, csrc/shard_kernels.hpp) and performs the all-reduce
+   between two phases: MIN of per-shard best positions / break positions / owner-supplied rows,
+   SUM of per-shard candidate counts.  Six small all-reduces per batch, latency-bound on xGMI, so the
+   batch should be >= 16k decisions.
 """
 from __future__ import annotations
 
@@ -55,3 +61,112 @@ def gather_results(local: np.ndarray, n_total: int, device=None) -> np.ndarray:
         out[lo:hi] = np.frombuffer(parts[r].cpu().numpy().tobytes()[: (hi - lo) * item], dtype=local.dtype)
     assert sizes[rank][1] - sizes[rank][0] == len(local)
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# pod-axis sharding
+
+N_PHASES = 7  # phases 1..6 end in an all-reduce, phase 7 writes the result rows
+
+
+class SolverShardBackend:
+    """The product backend: one libmmplace context in shard mode, buffers are torch CUDA tensors."""
+
+    def __init__(self, solver, shard: int, n_shards: int, device):
+        import torch
+        self.solver, self.shard, self.n_shards = solver, shard, n_shards
+        self.device = torch.device(device)
+        solver.shard_configure(shard, n_shards)
+
+    @property
+    def n_pods(self) -> int:
+        return self.solver.n_pods
+
+    def xchg_slots(self, phase: int) -> int:
+        return self.solver.shard_xchg_slots(phase)
+
+    def rank_partial(self):
+        import torch
+        r = torch.zeros(max(self.n_pods, 1), dtype=torch.int32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        self.solver.shard_rank_dev(r.data_ptr())  # synchronises the library's stream before returning
+        return r
+
+    def commit(self, rank):
+        import torch
+        torch.cuda.synchronize(self.device)  # the all-reduce ran on torch's stream
+        self.solver.shard_commit_dev(rank.data_ptr())
+
+    def phase(self, ph, d_reqs, n, d_extra, now, xchg, d_outs):
+        import torch
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        self.solver.shard_phase_dev(ph, d_reqs.data_ptr(), n, d_extra.data_ptr() if d_extra is not None else 0, now,
+                                    [x.data_ptr() for x in xchg], d_outs.data_ptr(), st)
+
+
+def _dist_all_reduce(t, op: str):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MIN if op == "min" else dist.ReduceOp.SUM)
+
+
+class PodShardedPlacer:
+    """Drives one shard through commit and through the phases of a batch.  `all_reduce(tensor, op)`
+    (op in {"min", "sum"}) defaults to torch.distributed.all_reduce on the default group."""
+
+    def __init__(self, backend, all_reduce=None):
+        self.b = backend
+        self.all_reduce = all_reduce or _dist_all_reduce
+        self._xchg, self._xn = None, -1
+
+    def commit_steps(self):
+        r = self.b.rank_partial()
+        yield r, "sum"
+        self.b.commit(r)
+
+    def commit(self):
+        for t, op in self.commit_steps():
+            self.all_reduce(t, op)
+
+    def _buffers(self, n: int):
+        import torch
+        if self._xn < n:
+            self._xchg = [torch.empty(max(n, 1) * self.b.xchg_slots(ph), dtype=torch.int64, device=self.b.device)
+                          for ph in range(1, N_PHASES)]
+            self._xn = n
+        return self._xchg
+
+    def place_steps(self, d_reqs, n: int, d_extra, now: int, d_outs):
+        """Generator: launches phase k, then yields (exchange tensor, op) for the caller to all-reduce."""
+        xchg = self._buffers(n)
+        for ph in range(1, N_PHASES):
+            self.b.phase(ph, d_reqs, n, d_extra, now, xchg, d_outs)
+            yield xchg[ph - 1][: n * self.b.xchg_slots(ph)], ("sum" if ph == 5 else "min")
+        self.b.phase(N_PHASES, d_reqs, n, d_extra, now, xchg, d_outs)
+
+    def place(self, d_reqs, n: int, d_extra, now: int, d_outs):
+        for t, op in self.place_steps(d_reqs, n, d_extra, now, d_outs):
+            self.all_reduce(t, op)
+
+
+def run_lockstep(generators):
+    """Advance several shards' step generators together inside ONE process, doing the all-reduce
+    with tensor ops (tests on a single GPU: G virtual shards; also how a single process would drive
+    several devices)."""
+    import torch
+    gens = list(generators)
+    while True:
+        steps = []
+        for g in gens:
+            try:
+                steps.append(next(g))
+            except StopIteration:
+                steps.append(None)
+        if all(s is None for s in steps):
+            return
+        assert all(s is not None for s in steps), "shards fell out of step"
+        op = steps[0][1]
+        stack = torch.stack([t.to(steps[0][0].device) for t, _ in steps])
+        red = stack.amin(dim=0) if op == "min" else stack.sum(dim=0)
+        for t, _ in steps:
+            t.copy_(red.to(t.device))

@@ -260,5 +260,26 @@ class Solver:
                                              int(now), int(cutoff_age_ms), ptr(act), ptr(wait)))
         return act[: len(entries)], wait[: len(entries)]
 
+    # ---- pod-axis shard mode (include/mmplace.h "pod-axis sharding"; orchestrated by dist.py) ----
+    def shard_configure(self, shard: int, n_shards: int):
+        self._ck(self.lib.mmp_shard_configure(self.h, int(shard), int(n_shards)))
+        self.shard, self.n_shards = int(shard), int(n_shards)
+
+    def shard_xchg_slots(self, phase: int) -> int:
+        return int(self.lib.mmp_shard_xchg_slots(int(phase), int(self.n_shards)))
+
+    def shard_rank_dev(self, d_rank: int):
+        self._ck(self.lib.mmp_shard_rank_dev(self.h, C.c_void_p(d_rank)))
+
+    def shard_commit_dev(self, d_rank: int):
+        self._ck(self.lib.mmp_shard_commit_dev(self.h, C.c_void_p(d_rank)))
+
+    def shard_phase_dev(self, phase: int, d_reqs: int, n: int, d_extra: int, now: int, d_xchg, d_outs: int,
+                        stream: int = 0):
+        arr = (C.c_void_p * 6)(*[C.c_void_p(int(x)) for x in d_xchg])
+        self._ck(self.lib.mmp_shard_place_phase_dev(self.h, int(phase), C.c_void_p(d_reqs), int(n),
+                                                    C.c_void_p(d_extra or None), int(now), arr,
+                                                    C.c_void_p(d_outs or None), C.c_void_p(stream or None)))
+
     def sync(self):
         self._ck(self.lib.mmp_sync(self.h))

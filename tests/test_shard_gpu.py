@@ -1,0 +1,161 @@
+"""GPU parity of the POD-AXIS sharded load-target path: G shards, each owning a
+contiguous range of PLACEMENT_ORDER positions, evaluate CacheMissForwardingLB.getNext
+(MM.java:4776-5005) in six phases with an all-reduce after each.  The result must be bit-identical to
+the CPU oracle (and therefore to the single-device kernel) for every G.
+
+On the 1-GPU box the G shards are G libmmplace contexts on cuda:0 advanced in lock step, the
+all-reduce being done with tensor ops (modelmesh_amd.dist.run_lockstep); a second test runs two real
+processes with a gloo process group on the same device.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from modelmesh_amd import dist as mdist
+from modelmesh_amd import workload as wl
+from modelmesh_amd._lib import PLACE_OUT
+from modelmesh_amd.solver import Solver
+from oracle.bind import OracleFleet
+from tests.util import assert_same_decisions
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load_shard(fleet, g, G, dev):
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    s.load_pods(fleet.pods)
+    s.load_types(fleet.n_types, fleet.allowed, fleet.prefer, fleet.has_allowed, fleet.has_prefer)
+    s.load_replaced_rs(fleet.replaced_rs)
+    s.load_models(fleet.models, fleet.ent_pod, fleet.ent_time)
+    return s, mdist.PodShardedPlacer(mdist.SolverShardBackend(s, g, G, dev))
+
+
+def _sharded_place(fleet, reqs, extra, G):
+    import torch
+    dev = torch.device("cuda", 0)
+    solvers, placers = zip(*[_load_shard(fleet, g, G, dev) for g in range(G)])
+    try:
+        mdist.run_lockstep([p.commit_steps() for p in placers])
+        n = len(reqs)
+        d_reqs = torch.from_numpy(np.ascontiguousarray(reqs).view(np.uint8).reshape(-1).copy()).to(dev)
+        d_extra = torch.from_numpy(np.ascontiguousarray(extra if len(extra) else np.zeros(1, np.int32))).to(dev)
+        outs = [torch.zeros(max(n, 1) * 16, dtype=torch.uint8, device=dev) for _ in range(G)]
+        mdist.run_lockstep([p.place_steps(d_reqs, n, d_extra, fleet.now, o) for p, o in zip(placers, outs)])
+        torch.cuda.synchronize()
+        res = [np.frombuffer(o.cpu().numpy().tobytes(), dtype=PLACE_OUT)[:n] for o in outs]
+        stats = [s.stats() for s in solvers]
+    finally:
+        for s in solvers:
+            s.close()
+    for r in res[1:]:  # every shard writes the same rows
+        assert np.array_equal(r, res[0])
+    return res[0], stats
+
+
+def _check(fleet, reqs, extra, G):
+    orc = OracleFleet(fleet)
+    want = orc.place(reqs, extra, fleet.now, threads=8)
+    got, stats = _sharded_place(fleet, reqs, extra, G)
+    assert_same_decisions(fleet, reqs, got, want)
+    ost = orc.stats()
+    for st in stats:
+        for f in ("total_capacity", "total_free", "global_lru", "instance_count", "model_copy_count"):
+            assert int(st[f]) == int(ost[f])
+
+
+@pytest.mark.parametrize("G", [1, 2, 3, 8])
+@pytest.mark.parametrize("profile", [None, "full", "prefer"])
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_fleets_sharded(seed, profile, G):
+    pods = int(np.random.default_rng(seed + 100).choice([1, 7, 64, 65, 200, 700, 3000]))
+    fleet = wl.fuzz_fleet(seed + 100, pods=pods, profile=profile)
+    reqs, extra = wl.fuzz_requests(fleet, seed + 100, 2000)
+    _check(fleet, reqs, extra, G)
+
+
+@pytest.mark.parametrize("G", [2, 4])
+def test_scenarios_sharded(G):
+    for name, fleet, reqs, extra in wl.scenario_fleets():
+        _check(fleet, reqs, extra, G)
+
+
+@pytest.mark.parametrize("G", [2, 8])
+def test_c2_sharded(G):
+    fleet = wl.make_fleet("C2")
+    reqs, extra = wl.make_requests(fleet, 21)
+    _check(fleet, reqs, extra, G)
+
+
+def test_c3_sharded_8_full_size():
+    fleet = wl.make_fleet("C3")
+    reqs, extra = wl.make_requests(fleet, 22)
+    _check(fleet, reqs, extra, 8)
+
+
+def test_shard_mode_refuses_unsharded_calls():
+    from modelmesh_amd.solver import MmpError
+    fleet = wl.make_fleet("C1")
+    s, p = _load_shard(fleet, 0, 1, "cuda:0")
+    try:
+        with pytest.raises(MmpError):
+            s.commit()
+        p.commit()
+        with pytest.raises(MmpError):
+            s.place(np.zeros(1, dtype=wl.PLACE_REQ), None, fleet.now)
+    finally:
+        s.close()
+
+
+# ---- two real processes, gloo process group, both on cuda:0 ------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fleet = wl.fuzz_fleet(7, pods=900, profile="prefer")
+        reqs, extra = wl.fuzz_requests(fleet, 7, 1500)
+        dev = torch.device("cuda", 0)
+        s, placer = _load_shard(fleet, rank, world, dev)
+        placer.commit()
+        n = len(reqs)
+        d_reqs = torch.from_numpy(np.ascontiguousarray(reqs).view(np.uint8).reshape(-1).copy()).to(dev)
+        d_extra = torch.from_numpy(np.ascontiguousarray(extra)).to(dev)
+        d_outs = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+        placer.place(d_reqs, n, d_extra, fleet.now, d_outs)
+        torch.cuda.synchronize()
+        got = np.frombuffer(d_outs.cpu().numpy().tobytes(), dtype=PLACE_OUT)
+        want = OracleFleet(fleet).place(reqs, extra, fleet.now)
+        ok = all(np.array_equal(got[f], want[f]) for f in ("chosen", "best", "n_candidates", "hash"))
+        s.close()
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_gloo_on_one_gpu():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert res == [(0, True), (1, True)]
