@@ -82,6 +82,62 @@ def cpu_baseline(fleet, reqs, extra, budget_s: float = 6.0):
     }
 
 
+def pod_axis_leg(workload: str, rank: int, world: int, dev, steps: int, warmup: int, fence):
+    """The same decisions with the POD axis sharded across the ranks (BASELINE.json
+    config C4): every rank sees the whole batch, owns 1/world of the PLACEMENT_ORDER positions, and the
+    six per-batch exchanges are RCCL all-reduces (MIN / SUM of int64 vectors) issued by
+    modelmesh_amd.dist.PodShardedPlacer.  Strong scaling of the pod table, not of the batch: value =
+    decisions of ONE batch / time."""
+    import torch
+    import torch.distributed as dist
+
+    from modelmesh_amd import dist as mdist
+    from modelmesh_amd import workload as wl
+    from modelmesh_amd._lib import PLACE_OUT
+    from modelmesh_amd.solver import Solver
+
+    fleet = wl.make_fleet(workload)
+    reqs, extra = wl.make_requests(fleet, seed=0xBE7C0)  # identical on every rank
+    n = len(reqs)
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms, device=dev.index)
+    s.load_fleet(fleet, commit=False)
+    placer = mdist.PodShardedPlacer(mdist.SolverShardBackend(s, rank, world, dev))
+    t0 = time.perf_counter()
+    placer.commit()
+    commit_ms = (time.perf_counter() - t0) * 1e3
+    d_reqs = torch.from_numpy(reqs.view(np.uint8).reshape(-1)).to(dev)
+    d_extra = torch.from_numpy(np.ascontiguousarray(extra if len(extra) else np.zeros(1, np.int32))).to(dev)
+    d_outs = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    for _ in range(warmup):
+        placer.place(d_reqs, n, d_extra, fleet.now, d_outs)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        placer.place(d_reqs, n, d_extra, fleet.now, d_outs)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    got = np.frombuffer(d_outs.cpu().numpy().tobytes(), dtype=PLACE_OUT)
+    out = None
+    if rank == 0:
+        from oracle.bind import OracleFleet
+        want = OracleFleet(fleet).place(reqs, extra, fleet.now, threads=os.cpu_count() or 1)
+        parity = bool(all(np.array_equal(got[f], want[f]) for f in ("chosen", "best", "n_candidates", "hash")))
+        slots = sum(s.shard_xchg_slots(ph) for ph in range(1, 7))
+        out = {"workload": f"{workload}: {fleet.n_models} models x {fleet.n_pods} pods", "n_shards": world,
+               "value": n * steps / elapsed, "unit": "decisions/s", "ms_per_step": elapsed / steps * 1e3,
+               "decisions_per_step": n, "scaling": "strong (pod table split, batch replicated)",
+               "collective": "6 x all_reduce(int64; MIN x5, SUM x1) per batch via torch.distributed (RCCL)"
+                             if world > 1 else "none (1 shard)",
+               "allreduce_bytes_per_step": 8 * slots * n, "sharded_commit_ms": commit_ms,
+               "parity_vs_oracle": parity}
+    s.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +145,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pod-axis", action="store_true", help="skip the pod-axis sharded leg")
     ap.add_argument("--kernel-only", action="store_true",
                     help="skip the n=1 latency / host-boundary legs (used under rocprofv3 so that every "
                          "place_batch_kernel dispatch in the trace is a full batch)")
@@ -105,9 +162,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libmmplace has no CPU path")
+    # MMP_BENCH_ONE_DEVICE=1 (with MMP_BENCH_BACKEND=gloo) lets several ranks share cuda:0 — only for
+    # exercising the N>1 code path on a 1-GPU box; the driver's runs use one GPU per rank over RCCL.
+    if os.environ.get("MMP_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("MMP_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     fleet = wl.make_fleet(args.workload)
     # model-axis shard: every rank owns its own batch of one-decision-per-model requests
@@ -160,6 +225,16 @@ def main():
         want = OracleFleet(fleet).place(reqs, extra, fleet.now, threads=os.cpu_count() or 1)
         parity = bool(all(np.array_equal(got[f], want[f]) for f in ("chosen", "best", "n_candidates", "hash")))
 
+    # pod-axis sharded leg (all ranks take part; reported next to the model-axis headline)
+    pod_axis = []
+    if not args.no_pod_axis and not args.kernel_only:
+        legs = [args.workload] + (["C4"] if world >= 8 and args.workload != "C4" else [])
+        for wname in legs:
+            try:
+                pod_axis.append(pod_axis_leg(wname, rank, world, dev, max(args.steps // 10, 5), max(args.warmup // 10, 2), fence))
+            except Exception as e:  # the headline line must still be printed
+                pod_axis.append({"workload": wname, "error": f"{type(e).__name__}: {e}"})
+
     if rank == 0:
         total = n * args.steps * world
         value = total / elapsed
@@ -184,6 +259,7 @@ def main():
                          "kernel_bytes_per_launch": kb,
                          "frac_kernel": kb / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "parity_vs_oracle": parity,
+            "pod_axis": pod_axis,
         }
         # single-decision latency through the host-pointer C ABI (n=1, PCIe + launch inclusive)
         lat = []

@@ -146,12 +146,14 @@ class Solver:
     def commit(self):
         self._ck(self.lib.mmp_snapshot_commit(self.h))
 
-    def load_fleet(self, f: Fleet):
+    def load_fleet(self, f: Fleet, commit: bool = True):
+        """Stage a whole fleet; commit=False leaves the commit to the caller (pod-axis shard mode)."""
         self.load_pods(f.pods)
         self.load_types(f.n_types, f.allowed, f.prefer, f.has_allowed, f.has_prefer)
         self.load_replaced_rs(f.replaced_rs)
         self.load_models(f.models, f.ent_pod, f.ent_time)
-        self.commit()
+        if commit:
+            self.commit()
 
     def order(self) -> np.ndarray:
         out = np.zeros(max(self.n_pods, 1), dtype=np.int32)

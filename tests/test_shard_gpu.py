@@ -27,10 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _load_shard(fleet, g, G, dev):
     s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
-    s.load_pods(fleet.pods)
-    s.load_types(fleet.n_types, fleet.allowed, fleet.prefer, fleet.has_allowed, fleet.has_prefer)
-    s.load_replaced_rs(fleet.replaced_rs)
-    s.load_models(fleet.models, fleet.ent_pod, fleet.ent_time)
+    s.load_fleet(fleet, commit=False)
     return s, mdist.PodShardedPlacer(mdist.SolverShardBackend(s, g, G, dev))
 
 
