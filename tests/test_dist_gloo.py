@@ -69,3 +69,74 @@ def test_shard_bounds_cover_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+# ---- pod-axis sharding: the product's PodShardedPlacer drives a CPU emulation of
+# ---- one shard (oracle/py_shard.py) — what is under test is the exchange protocol and its host driver
+def _order_full(fleet, orc):
+    absent = np.setdiff1d(np.arange(fleet.n_pods, dtype=np.int32), orc.order)
+    return np.concatenate([orc.order, absent]).astype(np.int32)
+
+
+def _emul_fleet(seed, profile, pods):
+    from modelmesh_amd import workload as wl
+    fleet = wl.fuzz_fleet(seed, pods=pods, models=120, profile=profile)
+    reqs, extra = wl.fuzz_requests(fleet, seed, 250)
+    return fleet, reqs, extra
+
+
+@pytest.mark.parametrize("seed,profile,pods,G", [(3, None, 130, 2), (4, "prefer", 200, 3), (5, "full", 200, 2),
+                                                 (6, "prefer", 70, 4), (8, "full", 300, 5)])
+def test_pod_axis_protocol_lockstep_emulation(seed, profile, pods, G):
+    from modelmesh_amd import dist as mdist
+    from modelmesh_amd._lib import PLACE_OUT
+    from oracle.bind import OracleFleet
+    from oracle.py_shard import EmulShardBackend
+    fleet, reqs, extra = _emul_fleet(seed, profile, pods)
+    orc = OracleFleet(fleet)
+    want = orc.place(reqs, extra, fleet.now)
+    placers = [mdist.PodShardedPlacer(EmulShardBackend(fleet, _order_full(fleet, orc), g, G)) for g in range(G)]
+    mdist.run_lockstep([p.commit_steps() for p in placers])
+    outs = [np.zeros(len(reqs), dtype=PLACE_OUT) for _ in range(G)]
+    mdist.run_lockstep([p.place_steps(reqs, len(reqs), extra, fleet.now, o) for p, o in zip(placers, outs)])
+    for o in outs:
+        for f in ("chosen", "best", "n_candidates", "hash"):
+            bad = np.nonzero(o[f] != want[f])[0]
+            assert len(bad) == 0, (f, bad[:5], o[bad[:5]], want[bad[:5]])
+
+
+def _pod_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from modelmesh_amd import dist as mdist
+    from modelmesh_amd._lib import PLACE_OUT
+    from oracle.bind import OracleFleet
+    from oracle.py_shard import EmulShardBackend
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fleet, reqs, extra = _emul_fleet(11, "prefer", 260)
+        orc = OracleFleet(fleet)
+        placer = mdist.PodShardedPlacer(EmulShardBackend(fleet, _order_full(fleet, orc), rank, world))
+        placer.commit()  # all_reduce(SUM) of the per-shard rank slices over gloo
+        out = np.zeros(len(reqs), dtype=PLACE_OUT)
+        placer.place(reqs, len(reqs), extra, fleet.now, out)  # 5 x all_reduce(MIN) + 1 x all_reduce(SUM)
+        want = orc.place(reqs, extra, fleet.now)
+        q.put((rank, all(np.array_equal(out[f], want[f]) for f in ("chosen", "best", "n_candidates", "hash"))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_pod_axis_sharding_over_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pod_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, True), (1, True)]
