@@ -138,6 +138,38 @@ def pod_axis_leg(workload: str, rank: int, world: int, dev, steps: int, warmup: 
     return out
 
 
+def churn_leg(fleet, solver, slices: int = 8, events: int = 20_000):
+    """Config C5 on this rank's solver: per 2 s slice of simulated time apply the changed InstanceRecords,
+    reload the registry view, re-rank on the device, decide the slice's load targets and evaluate its
+    cache evictions (host-pointer C ABI, PCIe inclusive).  Only the library calls are timed; the event
+    generation / bookkeeping between slices (numpy) is not part of the path."""
+    from modelmesh_amd import workload as wl
+    cs = wl.ChurnStream(fleet, 0xC5)
+    solver.load_caches(cs.seg_off, cs.cache_lu, cs.cache_wt, cs.cache_cap)
+    busy, commit_s, n_ev = 0.0, 0.0, 0
+    for it in range(slices + 1):
+        f = cs.fleet
+        t0 = time.perf_counter()
+        if it:
+            solver.upsert_pods(cs.changed_pods, f.pods[cs.changed_pods])
+            solver.load_models(f.models, f.ent_pod, f.ent_time)
+            t1 = time.perf_counter()
+            solver.commit()
+            commit_s += time.perf_counter() - t1
+        sl = cs.next_slice()
+        got = solver.place(sl["place_reqs"], sl["extra"], f.now)
+        solver.evict(sl["evict_reqs"], f.now)
+        if it:  # slice 0 is the warm-up
+            busy += time.perf_counter() - t0
+            n_ev += events
+        cs.apply(sl, got)
+    return {"workload": f"C5: {events} events per 2 s slice (45% load decisions, 45% eviction evaluations, 10% "
+                        f"republishes) over {fleet.n_models} models x {fleet.n_pods} pods, commit per slice",
+            "events_per_s": n_ev / busy, "slices": slices, "ms_per_slice": busy / slices * 1e3,
+            "commit_ms": commit_s / slices * 1e3,
+            "required_events_per_s": 10_000, "headroom_x": n_ev / busy / 10_000}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -279,6 +311,11 @@ def main():
             for _ in range(5):
                 solver.place(reqs, extra, fleet.now)
             line["host_boundary_decisions_per_s"] = 5 * n / (time.perf_counter() - t1)
+        if not args.kernel_only:
+            try:
+                line["churn"] = churn_leg(fleet, solver)
+            except Exception as e:
+                line["churn"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline and not args.kernel_only:
             line["cpu_baseline"] = cpu_baseline(fleet, reqs, extra)
         print(json.dumps(line), flush=True)

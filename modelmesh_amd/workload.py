@@ -319,3 +319,114 @@ def scenario_fleets():
     f.has_prefer[:] = 0
     yield "busy_best_is_filtered", f, reqs_of(f, np.array([-1, 1, 2, 0], np.int32),
                                             np.array([0, 0, 1, 0], np.uint32)), np.zeros(0, np.int32)
+
+
+# --------------------------------------------------------------------------
+class ChurnStream:
+    """Config C5: a steady-state stream of load / evict / republish events over a fleet,
+    cut into slices of `slice_ms` simulated time (INSTANCE_REC_PUBLISH_MIN_PERIOD_MS = 2 s, MM.java:232):
+    45 % model loads (one load-target decision, then the chosen pod's used/count and the model's
+    instanceIds change), 45 % cache-eviction evaluations (clhm insert + evict on one pod's cache),
+    10 % instance-record republishes.  Data generation and bookkeeping only — every decision is made by
+    whoever consumes the slices (the solver, or the oracle in tests)."""
+
+    def __init__(self, fleet: Fleet, seed: int, events_per_slice: int = 20_000, slice_ms: int = 2_000):
+        import copy
+        self.f = copy.deepcopy(fleet)
+        self.rng = np.random.Generator(np.random.PCG64(seed))
+        self.n_events, self.slice_ms = events_per_slice, slice_ms
+        M, P = self.f.n_models, self.f.n_pods
+        # model sizes: LogNormal(ln 50 MiB, 1.0) clipped to [1 MiB, 8 GiB], in 8 KiB units (ModelLoader.java:58-62)
+        mib = np.clip(self.rng.lognormal(np.log(50.0), 1.0, M), 1.0, 8192.0)
+        self.size_units = np.ceil(mib * 128).astype(np.int64)
+        # registry in COO form so that instanceIds can grow: (model, pod, time, failed)
+        m = self.f.models
+        seg = np.repeat(np.arange(M), m["n_loaded"] + m["n_failed"])
+        j = np.arange(len(seg)) - m["ent_off"][seg]
+        self.coo_model, self.coo_pod = seg.astype(np.int32), self.f.ent_pod.copy()
+        self.coo_time, self.coo_failed = self.f.ent_time.copy(), (j >= m["n_loaded"][seg])
+        # one clhm deque per pod: `count` entries whose weights add up to `used`, oldest first
+        cnt = np.maximum(self.f.pods["count"], 0).astype(np.int64)
+        self.seg_off = np.zeros(P + 1, np.int32)
+        np.cumsum(cnt, out=self.seg_off[1:])
+        E = int(self.seg_off[-1])
+        pod_of = np.repeat(np.arange(P), cnt)
+        share = self.rng.random(E) + 0.05
+        tot = np.add.reduceat(share, self.seg_off[:-1][cnt > 0]) if E else np.zeros(0)
+        tot_full = np.zeros(P)
+        tot_full[cnt > 0] = tot
+        self.cache_wt = np.maximum((share / np.maximum(tot_full[pod_of], 1e-9) *
+                                    self.f.pods["used"][pod_of]).astype(np.int64), 1).astype(np.int32)
+        age = self.rng.lognormal(np.log(3.6e6), 1.5, E).astype(np.int64)
+        lu = self.f.now - age
+        order = np.lexsort((lu, pod_of))
+        self.cache_lu = lu[order]
+        self.cache_cap = self.f.pods["capacity"].astype(np.int64).copy()
+        self.changed_pods = np.zeros(0, np.int32)
+
+    @property
+    def fleet(self) -> Fleet:
+        return self.f
+
+    def next_slice(self):
+        f, rng = self.f, self.rng
+        M, P = f.n_models, f.n_pods
+        n_load = int(self.n_events * 0.45)
+        n_evict = int(self.n_events * 0.45)
+        n_pub = self.n_events - n_load - n_evict
+        reqs = np.zeros(n_load, dtype=PLACE_REQ)
+        mdl = rng.integers(0, M, n_load)
+        sp = rng.integers(0, P, n_load).astype(np.int32)
+        reqs["model"], reqs["self_pod"] = mdl, sp
+        reqs["flags"] = (rng.random(n_load) < 0.05).astype(np.uint32)
+        reqs["pick"] = rng.integers(0, 2**32, n_load, dtype=np.uint64).astype(np.uint32)
+        reqs["last_used"] = np.where(rng.random(n_load) < 0.8, 0, f.models["last_used"][mdl])
+        row = f.pods[sp]
+        reqs["fresh_lru"], reqs["fresh_capacity"] = row["lru_time"], row["capacity"]
+        reqs["fresh_used"], reqs["fresh_count"] = row["used"], row["count"]
+        ev = np.zeros(n_evict, dtype=np.dtype([("cache", "<i4"), ("weight", "<i4"), ("last_used", "<i8")]))
+        ev["cache"] = rng.integers(0, P, n_evict)
+        ev["weight"] = np.minimum(self.size_units[rng.integers(0, M, n_evict)], 2**31 - 1)
+        ev["last_used"] = np.where(rng.random(n_evict) < 0.7, 0, f.now - rng.integers(1, 7_200_000, n_evict))
+        pub = np.unique(rng.integers(0, P, n_pub)).astype(np.int32)
+        return {"place_reqs": reqs, "extra": np.zeros(0, np.int32), "evict_reqs": ev, "republish": pub}
+
+    def apply(self, sl, place_outs):
+        """Book the slice's outcomes into the fleet (what the Java mesh would write to the KV store)."""
+        f, rng = self.f, self.rng
+        reqs = sl["place_reqs"]
+        chosen = np.where(place_outs["chosen"] == -2, reqs["self_pod"], place_outs["chosen"])
+        ok = chosen >= 0
+        c, m = chosen[ok].astype(np.int64), reqs["model"][ok]
+        np.add.at(f.pods["used"], c, self.size_units[m])
+        np.add.at(f.pods["count"], c, 1)
+        touched = f.pods["lru_time"][c] == JAVA_LONG_MAX
+        f.pods["lru_time"][c[touched]] = f.now - 3_600_000  # first model on an empty pod (LASTUSED_AGE_ON_ADD_MS)
+        self.coo_model = np.concatenate([self.coo_model, m.astype(np.int32)])
+        self.coo_pod = np.concatenate([self.coo_pod, c.astype(np.int32)])
+        self.coo_time = np.concatenate([self.coo_time, np.full(len(c), f.now, np.int64)])
+        self.coo_failed = np.concatenate([self.coo_failed, np.zeros(len(c), bool)])
+        # a model already on that pod keeps a single entry (instanceIds is a map)
+        key = self.coo_model.astype(np.int64) * (f.n_pods + 1) + self.coo_pod
+        _, first = np.unique(key, return_index=True)
+        keep = np.sort(first)
+        self.coo_model, self.coo_pod = self.coo_model[keep], self.coo_pod[keep]
+        self.coo_time, self.coo_failed = self.coo_time[keep], self.coo_failed[keep]
+        pub = sl["republish"]
+        f.pods["rpm"][pub] = np.minimum(rng.lognormal(np.log(300), 1.2, len(pub)), 2_000_000).astype(np.int32)
+        f.pods["loading_in_progress"][pub] = rng.binomial(8, 0.1, len(pub))
+        has = f.pods["count"][pub] > 0
+        f.pods["lru_time"][pub[has]] += rng.integers(0, 1000, int(has.sum()))
+        self.changed_pods = np.unique(np.concatenate([c.astype(np.int32), pub]))
+        # registry back to CSR: instanceIds in id order, then loadFailedInstanceIds
+        order = np.lexsort((f.pods["id_order"][self.coo_pod], self.coo_failed, self.coo_model))
+        self.coo_model, self.coo_pod = self.coo_model[order], self.coo_pod[order]
+        self.coo_time, self.coo_failed = self.coo_time[order], self.coo_failed[order]
+        M = f.n_models
+        nl = np.bincount(self.coo_model[~self.coo_failed], minlength=M).astype(np.int32)
+        nf = np.bincount(self.coo_model[self.coo_failed], minlength=M).astype(np.int32)
+        off = np.zeros(M + 1, np.int64)
+        np.cumsum(nl + nf, out=off[1:])
+        f.models["ent_off"], f.models["n_loaded"], f.models["n_failed"] = off[:-1], nl, nf
+        f.ent_pod, f.ent_time = self.coo_pod.copy(), self.coo_time.copy()
+        f.now += self.slice_ms
