@@ -143,6 +143,15 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} not found: build the HIP library first "
             "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    # One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64; if
+    # /opt/rocm's copy (libmmplace's DT_NEEDED) initialises first, torch later reports "No HIP GPUs are
+    # available".  Python hosts of this library use torch for device buffers and collectives, so let
+    # torch's runtime load first; libmmplace then binds to the same, already loaded, runtime.
+    if os.environ.get("MMP_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError here == a header symbol is not exported

@@ -9,6 +9,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -69,11 +70,30 @@ struct SnapBufs {
 
 }  // namespace
 
+// Low-latency slot for small host-pointer batches (the single ensureLoaded / invokeModel request):
+// pinned, device-mapped request / result buffers and a stream of its own, so that one decision never
+// queues behind a 100k-decision batch or a commit (SURVEY.md §8b "Threading").
+constexpr int kFastSlots = 4;
+constexpr int kFastN = 64;       // decisions per fast call
+constexpr int kFastExtra = 512;  // extra-exclusion pool entries per fast call
+struct FastSlot {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    mmp_place_req *reqs = nullptr;  // hipHostMalloc'ed: same pointer is valid on the device
+    int32_t *extra = nullptr;
+    mmp_place_out *outs = nullptr;
+};
+
 struct mmp_ctx {
     mmp_config cfg{};
     hipStream_t stream = nullptr;
-    std::mutex mu;
+    // lock order: batch_mu (owner of `stream` and the s_* / r_* scratch for a whole call) -> mu (host
+    // staging + the published snapshot pointers; decision paths hold it only while they capture the
+    // pointers and enqueue, loaders and commit hold it for the whole call)
+    std::mutex batch_mu, mu, err_mu;
     std::string err;
+    FastSlot fast[kFastSlots];
+    std::atomic<uint32_t> fast_rr{0};
 
     // host staging (inputs of the next commit)
     std::vector<mmp_pod_row> pods;
@@ -121,9 +141,10 @@ int fail(mmp_ctx *c, int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (c)
+    if (c) {
+        std::lock_guard<std::mutex> g(c->err_mu);
         c->err = buf;
-    else
+    } else
         g_create_err = buf;
     return code;
 }
@@ -137,6 +158,17 @@ int fail(mmp_ctx *c, int code, const char *fmt, ...)
     } while (0)
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+// Called with c->mu held, before device state that decisions read is overwritten: every decision
+// kernel was enqueued under c->mu, so once the streams are idle nothing reads the old state.
+hipError_t quiesce_decisions(mmp_ctx *c)
+{
+    for (FastSlot &f : c->fast) {
+        hipError_t e = hipStreamSynchronize(f.stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipStreamSynchronize(c->stream);
+}
 
 int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs,
                  hipStream_t st)
@@ -196,6 +228,18 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
         delete c;
         return fail(nullptr, MMP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    for (FastSlot &f : c->fast) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi is the numerically lowest = highest priority
+        hipError_t e1 = hipStreamCreateWithPriority(&f.stream, hipStreamNonBlocking, hi);
+        hipError_t e2 = hipHostMalloc(reinterpret_cast<void **>(&f.reqs), kFastN * sizeof(mmp_place_req), hipHostMallocDefault);
+        hipError_t e3 = hipHostMalloc(reinterpret_cast<void **>(&f.extra), kFastExtra * sizeof(int32_t), hipHostMallocDefault);
+        hipError_t e4 = hipHostMalloc(reinterpret_cast<void **>(&f.outs), kFastN * sizeof(mmp_place_out), hipHostMallocDefault);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+            mmp_destroy(c);
+            return fail(nullptr, MMP_EHIP, "fast-slot allocation failed");
+        }
+    }
     *out = c;
     return MMP_OK;
 }
@@ -204,6 +248,15 @@ void mmp_destroy(mmp_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
+    for (FastSlot &f : c->fast) {
+        if (f.stream) {
+            (void)hipStreamSynchronize(f.stream);
+            (void)hipStreamDestroy(f.stream);
+        }
+        if (f.reqs) (void)hipHostFree(f.reqs);
+        if (f.extra) (void)hipHostFree(f.extra);
+        if (f.outs) (void)hipHostFree(f.outs);
+    }
     if (c->stream) {
         (void)hipStreamSynchronize(c->stream);
         (void)hipStreamDestroy(c->stream);
@@ -235,6 +288,7 @@ int mmp_sync(mmp_ctx *c)
 int mmp_pods_load(mmp_ctx *c, const mmp_pod_row *rows, int32_t n)
 {
     if (!c || n < 0 || (n > 0 && !rows)) return fail(c, MMP_EINVAL, "mmp_pods_load: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     c->pods.assign(rows, rows + n);
     return MMP_OK;
@@ -243,6 +297,7 @@ int mmp_pods_load(mmp_ctx *c, const mmp_pod_row *rows, int32_t n)
 int mmp_pods_upsert(mmp_ctx *c, const int32_t *idx, const mmp_pod_row *rows, int32_t n)
 {
     if (!c || n < 0 || (n > 0 && (!rows || !idx))) return fail(c, MMP_EINVAL, "mmp_pods_upsert: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     for (int32_t i = 0; i < n; i++) {
         const int32_t k = idx[i];
@@ -258,6 +313,7 @@ int mmp_pods_upsert(mmp_ctx *c, const int32_t *idx, const mmp_pod_row *rows, int
 int mmp_pods_remove(mmp_ctx *c, const int32_t *idx, int32_t n)
 {
     if (!c || n < 0 || (n > 0 && !idx)) return fail(c, MMP_EINVAL, "mmp_pods_remove: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     for (int32_t i = 0; i < n; i++) {
         const int32_t k = idx[i];
@@ -272,6 +328,7 @@ int mmp_types_load(mmp_ctx *c, int32_t n_types, const uint64_t *allowed, const u
                    const uint8_t *has_allowed, const uint8_t *has_prefer)
 {
     if (!c || n_types < 0) return fail(c, MMP_EINVAL, "mmp_types_load: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     const int32_t W = div_up((int)c->pods.size(), 64);
     c->n_types = n_types;
@@ -302,6 +359,7 @@ int mmp_types_from_labels(mmp_ctx *c, int32_t n_types, const uint64_t *required,
 {
     if (!c || n_types < 0 || (n_types > 0 && (!required || !preferred)))
         return fail(c, MMP_EINVAL, "mmp_types_from_labels: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     const int32_t P = (int32_t)c->pods.size();
     if (P > 0 && !pod_labels) return fail(c, MMP_EINVAL, "mmp_types_from_labels: pod_labels is null");
@@ -358,6 +416,7 @@ int mmp_types_from_labels(mmp_ctx *c, int32_t n_types, const uint64_t *required,
 int mmp_replaced_rs_load(mmp_ctx *c, const int32_t *rs, int32_t n)
 {
     if (!c || n < 0 || (n > 0 && !rs)) return fail(c, MMP_EINVAL, "mmp_replaced_rs_load: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     c->replaced_rs.assign(rs, rs + n);
     return MMP_OK;
@@ -374,12 +433,13 @@ int mmp_models_load(mmp_ctx *c, const mmp_model_row *rows, int32_t n_models, con
             (int64_t)m.ent_off + m.n_loaded + m.n_failed > (int64_t)n_entries)
             return fail(c, MMP_EINVAL, "mmp_models_load: model %d entry range out of bounds", i);
     }
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, quiesce_decisions(c));  // the table is overwritten in place
     HIP_TRY(c, c->models.ensure((size_t)std::max(n_models, 1) * sizeof(mmp_model_row)));
     HIP_TRY(c, c->ent_pod.ensure((size_t)std::max(n_entries, 1) * sizeof(int32_t)));
     HIP_TRY(c, c->ent_time.ensure((size_t)std::max(n_entries, 1) * sizeof(int64_t)));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (n_models) HIP_TRY(c, hipMemcpy(c->models.p, rows, (size_t)n_models * sizeof(mmp_model_row), hipMemcpyHostToDevice));
     if (n_entries) {
         HIP_TRY(c, hipMemcpy(c->ent_pod.p, ent_pod, (size_t)n_entries * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -395,10 +455,12 @@ int mmp_models_load(mmp_ctx *c, const mmp_model_row *rows, int32_t n_models, con
 int mmp_snapshot_commit(mmp_ctx *c)
 {
     if (!c) return MMP_EINVAL;
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     if (c->n_shards > 0)
         return fail(c, MMP_ESTATE, "context is a pod-axis shard: commit with mmp_shard_rank_dev + mmp_shard_commit_dev");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, quiesce_decisions(c));  // the buffer set about to be rewritten was current two commits ago
     const int32_t P = (int32_t)c->pods.size();
     const int32_t W = std::max(div_up(P, 64), 1);
     const int32_t T = std::max(c->n_types, 1);
@@ -529,6 +591,7 @@ int mmp_snapshot_commit(mmp_ctx *c)
 int mmp_get_order(mmp_ctx *c, int32_t *order_out, int32_t *n_out)
 {
     if (!c || !order_out || !n_out) return fail(c, MMP_EINVAL, "mmp_get_order: null argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     if (c->n_shards > 0) return fail(c, MMP_ESTATE, "mmp_get_order: a pod-axis shard holds only its own slice of the order");
@@ -542,6 +605,7 @@ int mmp_get_order(mmp_ctx *c, int32_t *order_out, int32_t *n_out)
 int mmp_cluster_stats(mmp_ctx *c, mmp_stats *out)
 {
     if (!c || !out) return fail(c, MMP_EINVAL, "mmp_cluster_stats: null argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     *out = c->stats;
@@ -554,6 +618,7 @@ int mmp_shard_configure(mmp_ctx *c, int32_t shard, int32_t n_shards)
 {
     if (!c || n_shards < 1 || n_shards > kMaxShards || shard < 0 || shard >= n_shards)
         return fail(c, MMP_EINVAL, "mmp_shard_configure: need 0 <= shard < n_shards <= %d", kMaxShards);
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     c->shard = shard;
     c->n_shards = n_shards;
@@ -580,6 +645,7 @@ int32_t mmp_shard_xchg_is_sum(int32_t phase) { return phase == 5 ? 1 : 0; }
 int mmp_shard_rank_dev(mmp_ctx *c, void *d_rank)
 {
     if (!c || !d_rank) return fail(c, MMP_EINVAL, "mmp_shard_rank_dev: null argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     if (c->n_shards < 1) return fail(c, MMP_ESTATE, "mmp_shard_configure has not been called");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
@@ -609,9 +675,11 @@ int mmp_shard_rank_dev(mmp_ctx *c, void *d_rank)
 int mmp_shard_commit_dev(mmp_ctx *c, const void *d_rank)
 {
     if (!c || !d_rank) return fail(c, MMP_EINVAL, "mmp_shard_commit_dev: null argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     if (c->n_shards < 1 || !c->rank_pending) return fail(c, MMP_ESTATE, "mmp_shard_commit_dev: call mmp_shard_rank_dev first");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, quiesce_decisions(c));
     const int32_t P = (int32_t)c->pods.size();
     const int32_t W = std::max(div_up(P, 64), 1);
     const int32_t Wfull = div_up(P, 64);
@@ -752,6 +820,7 @@ int mmp_shard_place_phase_dev(mmp_ctx *c, int32_t phase, const void *d_reqs, int
         return fail(c, MMP_EINVAL, "mmp_shard_place_phase_dev: bad argument");
     for (int i = 0; i < 6; i++)
         if (n > 0 && !d_xchg[i]) return fail(c, MMP_EINVAL, "mmp_shard_place_phase_dev: exchange buffer %d is null", i + 1);
+    std::lock_guard<std::mutex> g(c->mu);  // capture the published shard snapshot + enqueue; no wait
     if (c->n_shards < 1 || !c->committed) return fail(c, MMP_ESTATE, "no committed shard snapshot");
     if (n == 0) return MMP_OK;
     PlaceArgs A;
@@ -791,6 +860,7 @@ int mmp_place_batch_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d
                         void *stream)
 {
     if (!c || n < 0 || (n > 0 && (!d_reqs || !d_outs))) return fail(c, MMP_EINVAL, "mmp_place_batch_dev: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);  // capture the published snapshot + enqueue; no wait
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
     return place_launch(c, d_reqs, n, d_extra, now, d_outs, static_cast<hipStream_t>(stream));
@@ -804,19 +874,60 @@ int mmp_place_batch(mmp_ctx *c, const mmp_place_req *reqs, int32_t n, const int3
     for (int32_t i = 0; i < n; i++)
         if (reqs[i].n_extra < 0 || reqs[i].extra_off < 0 || (int64_t)reqs[i].extra_off + reqs[i].n_extra > n_extra)
             return fail(c, MMP_EINVAL, "mmp_place_batch: request %d extra range out of bounds", i);
-    std::lock_guard<std::mutex> g(c->mu);
-    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
-    if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
-    if (n == 0) return MMP_OK;
+    if (n == 0) {
+        std::lock_guard<std::mutex> g(c->mu);
+        if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+        if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
+        return MMP_OK;
+    }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+
+    if (n <= kFastN && n_extra <= kFastExtra) {
+        // latency path: the kernel reads the requests from, and writes the results to, pinned host
+        // memory over the fabric — no staging copies, no contention with batches on c->stream
+        FastSlot *f = nullptr;
+        std::unique_lock<std::mutex> fl;
+        const uint32_t first = c->fast_rr.fetch_add(1, std::memory_order_relaxed);
+        for (int k = 0; k < kFastSlots && !f; k++) {
+            FastSlot &cand = c->fast[(first + k) % kFastSlots];
+            std::unique_lock<std::mutex> t(cand.mu, std::try_to_lock);
+            if (t.owns_lock()) {
+                f = &cand;
+                fl = std::move(t);
+            }
+        }
+        if (!f) {
+            f = &c->fast[first % kFastSlots];
+            fl = std::unique_lock<std::mutex>(f->mu);
+        }
+        memcpy(f->reqs, reqs, (size_t)n * sizeof(mmp_place_req));
+        if (n_extra) memcpy(f->extra, extra_pool, (size_t)n_extra * sizeof(int32_t));
+        {
+            std::lock_guard<std::mutex> g(c->mu);
+            if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+            if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
+            const int rc = place_launch(c, f->reqs, n, f->extra, now, f->outs, f->stream);
+            if (rc != MMP_OK) return rc;
+        }
+        HIP_TRY(c, hipStreamSynchronize(f->stream));
+        memcpy(outs, f->outs, (size_t)n * sizeof(mmp_place_out));
+        return MMP_OK;
+    }
+
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     hipStream_t st = c->stream;
     HIP_TRY(c, c->s_reqs.ensure((size_t)n * sizeof(mmp_place_req)));
     HIP_TRY(c, c->s_outs.ensure((size_t)n * sizeof(mmp_place_out)));
     HIP_TRY(c, c->s_extra.ensure((size_t)std::max(n_extra, 1) * 4));
     HIP_TRY(c, hipMemcpyAsync(c->s_reqs.p, reqs, (size_t)n * sizeof(mmp_place_req), hipMemcpyHostToDevice, st));
     if (n_extra) HIP_TRY(c, hipMemcpyAsync(c->s_extra.p, extra_pool, (size_t)n_extra * 4, hipMemcpyHostToDevice, st));
-    int rc = place_launch(c, c->s_reqs.p, n, c->s_extra.p, now, c->s_outs.p, st);
-    if (rc != MMP_OK) return rc;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+        if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
+        const int rc = place_launch(c, c->s_reqs.p, n, c->s_extra.p, now, c->s_outs.p, st);
+        if (rc != MMP_OK) return rc;
+    }
     HIP_TRY(c, hipMemcpyAsync(outs, c->s_outs.p, (size_t)n * sizeof(mmp_place_out), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     return MMP_OK;
@@ -831,6 +942,7 @@ int mmp_serve_batch(mmp_ctx *c, const mmp_serve_req *reqs, int32_t n, const int3
     for (int32_t i = 0; i < n; i++)
         if (reqs[i].n_excl < 0 || reqs[i].excl_off < 0 || (int64_t)reqs[i].excl_off + reqs[i].n_excl > n_excl)
             return fail(c, MMP_EINVAL, "mmp_serve_batch: request %d exclude range out of bounds", i);
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     if (n == 0) return MMP_OK;
@@ -887,6 +999,7 @@ int mmp_gate_batch(mmp_ctx *c, const mmp_gate_req *reqs, int32_t n, const int32_
             r.explicit_off < 0 || (int64_t)r.explicit_off + r.n_explicit > n_explicit)
             return fail(c, MMP_EINVAL, "mmp_gate_batch: request %d pool range out of bounds", i);
     }
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     if (n == 0) return MMP_OK;
@@ -937,6 +1050,7 @@ int mmp_proactive_plan(mmp_ctx *c, int32_t default_units, int64_t now, int32_t m
 {
     if (!c || !info || max_out < 0 || (max_out > 0 && (!out_model || !out_last_used)))
         return fail(c, MMP_EINVAL, "mmp_proactive_plan: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
@@ -1010,6 +1124,7 @@ int mmp_scaleup_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, cons
 {
     if (!c || !p || !skipped || n < 0 || (n > 0 && (!entries || !outs)))
         return fail(c, MMP_EINVAL, "mmp_scaleup_plan: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     const int32_t P = c->snap.P;
@@ -1064,6 +1179,7 @@ int mmp_scaledown_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, co
 {
     if (!c || !p || n < 0 || (n > 0 && (!entries || !removed_out)))
         return fail(c, MMP_EINVAL, "mmp_scaledown_plan: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     if (n == 0) return MMP_OK;
@@ -1100,6 +1216,7 @@ int mmp_migration_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, in
 {
     if (!c || n < 0 || (n > 0 && (!entries || !action_out || !wait_out)))
         return fail(c, MMP_EINVAL, "mmp_migration_plan: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     if (n == 0) return MMP_OK;
@@ -1128,6 +1245,7 @@ int mmp_caches_load(mmp_ctx *c, int32_t n_caches, const int32_t *seg_off, const 
         if (seg_off[i + 1] < seg_off[i]) return fail(c, MMP_EINVAL, "mmp_caches_load: seg_off not monotone at %d", i);
     const int32_t E = seg_off[n_caches];
     if (E > 0 && (!last_used || !weight)) return fail(c, MMP_EINVAL, "mmp_caches_load: null entry arrays");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1148,6 +1266,7 @@ int mmp_caches_load(mmp_ctx *c, int32_t n_caches, const int32_t *seg_off, const 
 int mmp_evict_batch(mmp_ctx *c, const mmp_evict_req *reqs, int32_t n, int64_t now, mmp_evict_out *outs)
 {
     if (!c || n < 0 || (n > 0 && (!reqs || !outs))) return fail(c, MMP_EINVAL, "mmp_evict_batch: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     if (c->n_caches <= 0 && n > 0) return fail(c, MMP_ESTATE, "no caches loaded");
     if (n == 0) return MMP_OK;

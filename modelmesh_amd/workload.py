@@ -328,7 +328,7 @@ class ChurnStream:
     45 % model loads (one load-target decision, then the chosen pod's used/count and the model's
     instanceIds change), 45 % cache-eviction evaluations (clhm insert + evict on one pod's cache),
     10 % instance-record republishes.  Data generation and bookkeeping only — every decision is made by
-    whoever consumes the slices (the solver, or the oracle in tests)."""
+    whoever consumes the slices."""
 
     def __init__(self, fleet: Fleet, seed: int, events_per_slice: int = 20_000, slice_ms: int = 2_000):
         import copy

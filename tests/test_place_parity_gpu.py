@@ -137,3 +137,52 @@ def test_order_inconsistent_rows_are_rejected():
         assert np.array_equal(s.order(), OracleFleet(fleet).order)
     finally:
         s.close()
+
+
+def test_concurrent_single_decisions_batches_and_commits():
+    """SURVEY.md §8b threading row: getNext is called from many request threads while the instance
+    table changes underneath.  Four threads issue single decisions (latency path, pinned mapped
+    buffers, own streams), one issues 20k-decision batches, the main thread re-commits the same table;
+    every result must still equal the oracle's (the snapshot content never changes, only its buffers)."""
+    import threading
+    fleet = wl.make_fleet("C2")
+    reqs, extra = wl.make_requests(fleet, 77, n=20_000)
+    want = OracleFleet(fleet).place(reqs, extra, fleet.now, threads=8)
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    errors = []
+
+    def singles(tid):
+        try:
+            for i in range(tid, 4000, 4):
+                r = reqs[i:i + 1].copy()
+                ex = extra[r["extra_off"][0]: r["extra_off"][0] + r["n_extra"][0]].copy()
+                r["extra_off"] = 0
+                got = s.place(r, ex, fleet.now)
+                for f in ("chosen", "best", "n_candidates", "hash"):
+                    if got[f][0] != want[f][i]:
+                        errors.append((tid, i, f))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    def batches():
+        try:
+            for _ in range(20):
+                got = s.place(reqs, extra, fleet.now)
+                for f in ("chosen", "best", "n_candidates", "hash"):
+                    if not np.array_equal(got[f], want[f]):
+                        errors.append(("batch", f))
+        except Exception as e:  # noqa: BLE001
+            errors.append(("batch", repr(e)))
+    try:
+        s.load_fleet(fleet)
+        ths = [threading.Thread(target=singles, args=(t,)) for t in range(4)] + [threading.Thread(target=batches)]
+        for t in ths:
+            t.start()
+        for _ in range(30):
+            s.load_models(fleet.models, fleet.ent_pod, fleet.ent_time)
+            s.commit()
+        for t in ths:
+            t.join()
+        assert not errors, errors[:5]
+    finally:
+        s.close()
