@@ -161,6 +161,52 @@ typedef struct {
     int64_t oldest_time;   /* oldestTime() after eviction, -1 if empty         */
 } mmp_evict_out;
 
+/* Stateful per-pod caches (rows a12 + a13): the clhm operations and the ModelCacheUnloadBufManager
+ * methods, replayed in caller order per cache by mmp_cache_replay.  Keys are interned model ids;
+ * MMP_UNLOADBUF_KEY is the manager's pinned "___UNLOADBUF" pseudo-entry
+ * (ModelCacheUnloadBufManager.java:42,88), which a managed cache must contain when it is loaded. */
+#define MMP_UNLOADBUF_KEY (-1000000)
+#define MMP_COP_PUT_IF_ABSENT 0           /* clhm putIfAbsent(key, w=arg, time)  :804-834; result 1 = inserted      */
+#define MMP_COP_GET 1                     /* clhm get(key, time)                 :726-733; result = found           */
+#define MMP_COP_UPDATE_WEIGHT 2           /* replace / replaceQuietly, new weight = arg, time -1 = quiet  :902-985   */
+#define MMP_COP_REMOVE 3                  /* clhm remove(key)                    :861-870                           */
+#define MMP_COP_UBM_INSERT_NEW_ENTRY 4    /* insertNewEntry(key, w=arg, time)    ModelCacheUnloadBufManager :130-145 */
+#define MMP_COP_UBM_ADJUST_SPACE_REQUEST 5 /* adjustNewEntrySpaceRequest(increase=arg, key)              :152-166   */
+#define MMP_COP_UBM_SPACE_IS_READY 6      /* cacheSpaceIsReady(required=arg)     :395-402 (read only)               */
+#define MMP_COP_UBM_CLAIM_SPACE 7         /* claimRequestedSpaceIfReady(required=arg)                    :190-202   */
+#define MMP_COP_UBM_ADJUST_AFTER_LOAD 8   /* adjustWeightAfterLoad(delta=arg, key)                       :224-246   */
+#define MMP_COP_UBM_UNLOAD_COMPLETE 9     /* unloadComplete(weight=arg, success=flag)                    :318-338   */
+#define MMP_COP_UBM_REMOVE_ENTRY 10       /* removeEntry(key) + entryRemoved; result = weight or -1      :281-316   */
+#define MMP_COP_UBM_DISCARD_FAILED 11     /* discardFailedEntry(weight=arg)                              :343-349   */
+#define MMP_COP_UBM_INSERT_FAILED_PLACEHOLDER 12 /* insertFailedPlaceholderEntry(key, w=arg, time)       :250-274   */
+typedef struct {
+    int32_t cache;
+    int32_t op;
+    int32_t key;
+    int32_t arg;
+    int64_t time; /* lastUsed: 0 = now (clhm :1357-1360) */
+    int32_t flag;
+    int32_t reserved;
+} mmp_cache_op;
+
+typedef struct {
+    int32_t result;
+    int32_t n_evicted;     /* entries this operation evicted (listener order)            */
+    int32_t evicted_off;   /* their keys start here in the call's evicted_keys array      */
+    int32_t buffer_weight; /* getUnloadBufferWeight() after the operation (0: unmanaged)  */
+    int64_t weighted_size; /* runtimeCache.weightedSize() after the operation             */
+    int64_t oldest_time;   /* runtimeCache.oldestTime(), -1 if empty                      */
+} mmp_cache_op_out;
+
+/* ModelCacheUnloadBufManager fields (:57-79); reserved < 0 = this cache has no manager. */
+typedef struct {
+    int32_t reserved;        /* unloadsReservedSizeUnits   */
+    int32_t total_unloading; /* totalUnloadingWeight       */
+    int64_t total_occupancy; /* totalModelCacheOccupancy   */
+    int32_t cache_deficit;   /* cacheDeficit               */
+    int32_t pad;
+} mmp_ubm_state;
+
 /* The request-level guards invokeModel evaluates around the two selections
  * (SURVEY.md §8 rows a10, a11, a14, a20), batched.  One struct carries the
  * scalar inputs of all of them; unused groups may be left zero. */
@@ -346,6 +392,19 @@ int mmp_caches_load(mmp_ctx *ctx, int32_t n_caches, const int32_t *seg_off, cons
                     const int32_t *weight, const int64_t *capacity);
 int mmp_evict_batch(mmp_ctx *ctx, const mmp_evict_req *reqs, int32_t n, int64_t now_ms,
                     mmp_evict_out *outs);
+
+/* Stateful caches: entry i of cache c's segment is the i-th node of its evictionDeque (oldest first)
+ * with its key; ubm may be NULL (no cache is managed). */
+int mmp_caches_load_keyed(mmp_ctx *ctx, int32_t n_caches, const int32_t *seg_off, const int64_t *last_used,
+                          const int32_t *weight, const int32_t *key, const int64_t *capacity, const mmp_ubm_state *ubm);
+/* Apply n_ops operations (each cache's operations in the order given) to the stateful caches.
+ * evicted_keys has room for max_evicted keys; *n_evicted_slots = slots the call used (outs index into
+ * it).  MMP_EINVAL if one cache's entries + inserts exceed the 2048-slot tile or max_evicted is too small. */
+int mmp_cache_replay(mmp_ctx *ctx, const mmp_cache_op *ops, int32_t n_ops, int64_t now_ms, mmp_cache_op_out *outs,
+                     int32_t *evicted_keys, int32_t max_evicted, int32_t *n_evicted_slots);
+/* Read one cache back (deque order). */
+int mmp_cache_read(mmp_ctx *ctx, int32_t cache, int32_t max_entries, int64_t *last_used, int32_t *weight, int32_t *key,
+                   int32_t *n_out, int64_t *capacity, int64_t *weighted_size, mmp_ubm_state *ubm);
 
 /* n guard evaluations (rows a10/a11/a14/a20). in_use_failure_expiry_ms = IN_USE_LOAD_FAILURE_EXPIRY_MS
  * (MM.java:221). excl_pod/excl_time and explicit_pool are the pools the requests index. */

@@ -83,6 +83,18 @@ SCALEDOWN_PARAMS = np.dtype(
 assert CACHE_ENTRY.itemsize == 56 and SCALEUP_PARAMS.itemsize == 64 and SCALEUP_OUT.itemsize == 32
 assert SCALEDOWN_PARAMS.itemsize == 48
 
+CACHE_OP = np.dtype([("cache", "<i4"), ("op", "<i4"), ("key", "<i4"), ("arg", "<i4"), ("time", "<i8"), ("flag", "<i4"),
+                     ("reserved", "<i4")])
+CACHE_OP_OUT = np.dtype([("result", "<i4"), ("n_evicted", "<i4"), ("evicted_off", "<i4"), ("buffer_weight", "<i4"),
+                         ("weighted_size", "<i8"), ("oldest_time", "<i8")])
+UBM_STATE = np.dtype([("reserved", "<i4"), ("total_unloading", "<i4"), ("total_occupancy", "<i8"),
+                      ("cache_deficit", "<i4"), ("pad", "<i4")])
+assert CACHE_OP.itemsize == 32 and CACHE_OP_OUT.itemsize == 32 and UBM_STATE.itemsize == 24
+UNLOADBUF_KEY = -1000000
+(COP_PUT_IF_ABSENT, COP_GET, COP_UPDATE_WEIGHT, COP_REMOVE, COP_UBM_INSERT_NEW_ENTRY, COP_UBM_ADJUST_SPACE_REQUEST,
+ COP_UBM_SPACE_IS_READY, COP_UBM_CLAIM_SPACE, COP_UBM_ADJUST_AFTER_LOAD, COP_UBM_UNLOAD_COMPLETE, COP_UBM_REMOVE_ENTRY,
+ COP_UBM_DISCARD_FAILED, COP_UBM_INSERT_FAILED_PLACEHOLDER) = range(13)
+
 assert POD_ROW.itemsize == 64 and MODEL_ROW.itemsize == 24 and PLACE_REQ.itemsize == 64
 assert PLACE_OUT.itemsize == 16 and SERVE_REQ.itemsize == 40 and SERVE_OUT.itemsize == 16
 assert STATS.itemsize == 32 and EVICT_REQ.itemsize == 16 and EVICT_OUT.itemsize == 32
@@ -117,6 +129,10 @@ SYMBOLS = [
     ("mmp_serve_batch", C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int64, _P]),
     ("mmp_caches_load", C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
     ("mmp_evict_batch", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
+    ("mmp_caches_load_keyed", C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    ("mmp_cache_replay", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, C.c_int32, C.POINTER(C.c_int32)]),
+    ("mmp_cache_read", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                                 C.POINTER(C.c_int64), _P]),
     ("mmp_gate_batch", C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32, _P, C.c_int32, C.c_int64, C.c_int64, _P]),
     ("mmp_proactive_plan", C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P]),
     ("mmp_scaleup_plan", C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32)]),

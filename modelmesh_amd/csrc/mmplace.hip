@@ -20,6 +20,7 @@
 
 #include "../../include/mmplace.h"
 #include "aux_kernels.hpp"
+#include "cache_kernels.hpp"
 #include "gate_kernel.hpp"
 #include "place_kernel.hpp"
 #include "rebalance_kernels.hpp"
@@ -125,6 +126,15 @@ struct mmp_ctx {
     // eviction caches
     DevBuf c_seg, c_lu, c_wt, c_cap;
     int32_t n_caches = 0;
+
+    // stateful keyed caches (mmp_caches_load_keyed / mmp_cache_replay): two layouts, ping-pong
+    struct KeyedStore {
+        DevBuf off, lu, wt, key, n;
+    } ks[2];
+    int ks_cur = 0;
+    int32_t k_caches = 0;
+    std::vector<int32_t> k_n;  // host mirror of the live entry counts
+    DevBuf k_cap, k_wsize, k_ubm, k_ops, k_order, k_opoff, k_outs, k_ev, k_evoff;
 
     // per-call scratch for the host-pointer entry points
     DevBuf s_reqs, s_outs, s_extra, s_a, s_b, s_c, s_d;
@@ -267,7 +277,9 @@ void mmp_destroy(mmp_ctx *c)
                       &c->d_has_allowed, &c->stats_acc, &c->models, &c->ent_pod, &c->ent_time, &c->c_seg,
                       &c->c_lu, &c->c_wt, &c->c_cap, &c->s_reqs, &c->s_outs, &c->s_extra, &c->s_a, &c->s_b,
                       &c->s_c, &c->s_d, &c->r_ps, &c->r_counts, &c->r_keys, &c->r_vals, &c->r_keys2, &c->r_vals2,
-                      &c->r_tmp, &c->r_out_model, &c->r_out_lu})
+                      &c->r_tmp, &c->r_out_model, &c->r_out_lu, &c->k_cap, &c->k_wsize, &c->k_ubm, &c->k_ops, &c->k_order,
+                      &c->k_opoff, &c->k_outs, &c->k_ev, &c->k_evoff, &c->ks[0].off, &c->ks[0].lu, &c->ks[0].wt,
+                      &c->ks[0].key, &c->ks[0].n, &c->ks[1].off, &c->ks[1].lu, &c->ks[1].wt, &c->ks[1].key, &c->ks[1].n})
         b->release();
     delete c;
 }
@@ -1233,6 +1245,168 @@ int mmp_migration_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, in
     HIP_TRY(c, hipMemcpyAsync(action_out, c->s_a.p, (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(wait_out, c->s_b.p, (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    return MMP_OK;
+}
+
+/* ---- stateful keyed caches (a12 + a13) ------------------------------------- */
+
+int mmp_caches_load_keyed(mmp_ctx *c, int32_t n_caches, const int32_t *seg_off, const int64_t *last_used,
+                          const int32_t *weight, const int32_t *key, const int64_t *capacity, const mmp_ubm_state *ubm)
+{
+    if (!c || n_caches < 0 || !seg_off || (n_caches > 0 && !capacity)) return fail(c, MMP_EINVAL, "mmp_caches_load_keyed: bad argument");
+    if (seg_off[0] != 0) return fail(c, MMP_EINVAL, "mmp_caches_load_keyed: seg_off[0] must be 0");
+    for (int32_t i = 0; i < n_caches; i++)
+        if (seg_off[i + 1] < seg_off[i]) return fail(c, MMP_EINVAL, "mmp_caches_load_keyed: seg_off not monotone at %d", i);
+    const int32_t E = seg_off[n_caches];
+    if (E > 0 && (!last_used || !weight || !key)) return fail(c, MMP_EINVAL, "mmp_caches_load_keyed: null entry arrays");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    mmp_ctx::KeyedStore &K = c->ks[c->ks_cur];
+    HIP_TRY(c, K.off.ensure((size_t)(n_caches + 1) * 4));
+    HIP_TRY(c, K.lu.ensure((size_t)std::max(E, 1) * 8));
+    HIP_TRY(c, K.wt.ensure((size_t)std::max(E, 1) * 4));
+    HIP_TRY(c, K.key.ensure((size_t)std::max(E, 1) * 4));
+    HIP_TRY(c, K.n.ensure((size_t)std::max(n_caches, 1) * 4));
+    HIP_TRY(c, c->k_cap.ensure((size_t)std::max(n_caches, 1) * 8));
+    HIP_TRY(c, c->k_wsize.ensure((size_t)std::max(n_caches, 1) * 8));
+    HIP_TRY(c, c->k_ubm.ensure((size_t)std::max(n_caches, 1) * sizeof(mmp_ubm_state)));
+    c->k_n.assign(n_caches, 0);
+    std::vector<int64_t> ws(std::max(n_caches, 1), 0);
+    std::vector<mmp_ubm_state> us(std::max(n_caches, 1));
+    for (int32_t i = 0; i < n_caches; i++) {
+        c->k_n[i] = seg_off[i + 1] - seg_off[i];
+        for (int32_t e = seg_off[i]; e < seg_off[i + 1]; e++) ws[i] += weight[e] < 0 ? -(int64_t)weight[e] : weight[e];
+        if (ubm)
+            us[i] = ubm[i];
+        else {
+            us[i] = mmp_ubm_state{};
+            us[i].reserved = -1;
+        }
+    }
+    HIP_TRY(c, hipMemcpy(K.off.p, seg_off, (size_t)(n_caches + 1) * 4, hipMemcpyHostToDevice));
+    if (E) {
+        HIP_TRY(c, hipMemcpy(K.lu.p, last_used, (size_t)E * 8, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(K.wt.p, weight, (size_t)E * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(K.key.p, key, (size_t)E * 4, hipMemcpyHostToDevice));
+    }
+    if (n_caches) {
+        HIP_TRY(c, hipMemcpy(K.n.p, c->k_n.data(), (size_t)n_caches * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->k_cap.p, capacity, (size_t)n_caches * 8, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->k_wsize.p, ws.data(), (size_t)n_caches * 8, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->k_ubm.p, us.data(), (size_t)n_caches * sizeof(mmp_ubm_state), hipMemcpyHostToDevice));
+    }
+    c->k_caches = n_caches;
+    return MMP_OK;
+}
+
+int mmp_cache_replay(mmp_ctx *c, const mmp_cache_op *ops, int32_t n_ops, int64_t now, mmp_cache_op_out *outs,
+                     int32_t *evicted_keys, int32_t max_evicted, int32_t *n_evicted_slots)
+{
+    if (!c || n_ops < 0 || max_evicted < 0 || (n_ops > 0 && (!ops || !outs)) || (max_evicted > 0 && !evicted_keys) ||
+        !n_evicted_slots)
+        return fail(c, MMP_EINVAL, "mmp_cache_replay: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
+    std::lock_guard<std::mutex> g(c->mu);
+    const int32_t NC = c->k_caches;
+    if (NC <= 0 && n_ops > 0) return fail(c, MMP_ESTATE, "no keyed caches loaded");
+    *n_evicted_slots = 0;
+    if (n_ops == 0) return MMP_OK;
+    // group the operations by cache (stable) and size the new layout: every insert may add a slot
+    std::vector<int32_t> cnt(NC + 1, 0), ins(NC, 0);
+    for (int32_t i = 0; i < n_ops; i++) {
+        const mmp_cache_op &o = ops[i];
+        if (o.cache < 0 || o.cache >= NC) return fail(c, MMP_EINVAL, "mmp_cache_replay: op %d names cache %d", i, o.cache);
+        if (o.op < 0 || o.op > MMP_COP_UBM_INSERT_FAILED_PLACEHOLDER) return fail(c, MMP_EINVAL, "mmp_cache_replay: op %d has code %d", i, o.op);
+        cnt[o.cache + 1]++;
+        if (o.op == MMP_COP_PUT_IF_ABSENT || o.op == MMP_COP_UBM_INSERT_NEW_ENTRY || o.op == MMP_COP_UBM_INSERT_FAILED_PLACEHOLDER)
+            ins[o.cache]++;
+    }
+    std::vector<int32_t> op_off(NC + 1, 0), new_off(NC + 1, 0), ev_off(NC + 1, 0);
+    int32_t tile = 1;
+    for (int32_t k = 0; k < NC; k++) {
+        op_off[k + 1] = op_off[k] + cnt[k + 1];
+        const int32_t slots = c->k_n[k] + ins[k];
+        new_off[k + 1] = new_off[k] + slots;
+        ev_off[k + 1] = ev_off[k] + (cnt[k + 1] ? slots : 0);  // a cache cannot evict more than it ever held
+        if (cnt[k + 1]) tile = std::max(tile, slots + 1);
+    }
+    if (tile > kCacheTile) return fail(c, MMP_EINVAL, "mmp_cache_replay: a cache needs %d deque slots, the tile holds %d", tile, kCacheTile);
+    if (ev_off[NC] > max_evicted) return fail(c, MMP_EINVAL, "mmp_cache_replay: evicted_keys needs room for %d keys", ev_off[NC]);
+    std::vector<int32_t> order(n_ops), fill(op_off.begin(), op_off.end() - 1);
+    for (int32_t i = 0; i < n_ops; i++) order[fill[ops[i].cache]++] = i;
+
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = c->stream;
+    mmp_ctx::KeyedStore &S = c->ks[c->ks_cur], &D = c->ks[1 - c->ks_cur];
+    const int32_t Enew = new_off[NC];
+    HIP_TRY(c, D.off.ensure((size_t)(NC + 1) * 4));
+    HIP_TRY(c, D.lu.ensure((size_t)std::max(Enew, 1) * 8));
+    HIP_TRY(c, D.wt.ensure((size_t)std::max(Enew, 1) * 4));
+    HIP_TRY(c, D.key.ensure((size_t)std::max(Enew, 1) * 4));
+    HIP_TRY(c, D.n.ensure((size_t)NC * 4));
+    HIP_TRY(c, c->k_ops.ensure((size_t)n_ops * sizeof(mmp_cache_op)));
+    HIP_TRY(c, c->k_order.ensure((size_t)n_ops * 4));
+    HIP_TRY(c, c->k_opoff.ensure((size_t)(NC + 1) * 4));
+    HIP_TRY(c, c->k_outs.ensure((size_t)n_ops * sizeof(mmp_cache_op_out)));
+    HIP_TRY(c, c->k_ev.ensure((size_t)std::max(ev_off[NC], 1) * 4));
+    HIP_TRY(c, c->k_evoff.ensure((size_t)(NC + 1) * 4));
+    HIP_TRY(c, hipMemcpyAsync(D.off.p, new_off.data(), (size_t)(NC + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->k_ops.p, ops, (size_t)n_ops * sizeof(mmp_cache_op), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->k_order.p, order.data(), (size_t)n_ops * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->k_opoff.p, op_off.data(), (size_t)(NC + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->k_evoff.p, ev_off.data(), (size_t)(NC + 1) * 4, hipMemcpyHostToDevice, st));
+    ReplayArgs A;
+    A.src = CacheStore{S.off.as<int32_t>(), S.lu.as<int64_t>(), S.wt.as<int32_t>(), S.key.as<int32_t>(), S.n.as<int32_t>()};
+    A.dst = CacheStore{D.off.as<int32_t>(), D.lu.as<int64_t>(), D.wt.as<int32_t>(), D.key.as<int32_t>(), D.n.as<int32_t>()};
+    A.capacity = c->k_cap.as<int64_t>();
+    A.weighted_size = c->k_wsize.as<int64_t>();
+    A.ubm = c->k_ubm.as<mmp_ubm_state>();
+    A.ops = c->k_ops.as<mmp_cache_op>();
+    A.op_order = c->k_order.as<int32_t>();
+    A.op_off = c->k_opoff.as<int32_t>();
+    A.outs = c->k_outs.as<mmp_cache_op_out>();
+    A.evicted = c->k_ev.as<int32_t>();
+    A.ev_off = c->k_evoff.as<int32_t>();
+    A.n_caches = NC;
+    A.tile = tile;
+    A.now = now;
+    const size_t lds = (size_t)tile * 24;
+    hipLaunchKernelGGL(cache_replay_kernel, dim3(NC), dim3(64), lds, st, A);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(outs, c->k_outs.p, (size_t)n_ops * sizeof(mmp_cache_op_out), hipMemcpyDeviceToHost, st));
+    if (ev_off[NC]) HIP_TRY(c, hipMemcpyAsync(evicted_keys, c->k_ev.p, (size_t)ev_off[NC] * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(c->k_n.data(), D.n.p, (size_t)NC * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    c->ks_cur = 1 - c->ks_cur;
+    *n_evicted_slots = ev_off[NC];
+    return MMP_OK;
+}
+
+int mmp_cache_read(mmp_ctx *c, int32_t cache, int32_t max_entries, int64_t *last_used, int32_t *weight, int32_t *key,
+                   int32_t *n_out, int64_t *capacity, int64_t *weighted_size, mmp_ubm_state *ubm)
+{
+    if (!c || !n_out || max_entries < 0) return fail(c, MMP_EINVAL, "mmp_cache_read: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
+    std::lock_guard<std::mutex> g(c->mu);
+    if (cache < 0 || cache >= c->k_caches) return fail(c, MMP_EINVAL, "mmp_cache_read: cache %d out of range", cache);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    mmp_ctx::KeyedStore &K = c->ks[c->ks_cur];
+    int32_t off = 0;
+    HIP_TRY(c, hipMemcpy(&off, K.off.as<int32_t>() + cache, 4, hipMemcpyDeviceToHost));
+    const int32_t n = c->k_n[cache];
+    *n_out = n;
+    const int32_t m = std::min(n, max_entries);
+    if (m > 0) {
+        if (last_used) HIP_TRY(c, hipMemcpy(last_used, K.lu.as<int64_t>() + off, (size_t)m * 8, hipMemcpyDeviceToHost));
+        if (weight) HIP_TRY(c, hipMemcpy(weight, K.wt.as<int32_t>() + off, (size_t)m * 4, hipMemcpyDeviceToHost));
+        if (key) HIP_TRY(c, hipMemcpy(key, K.key.as<int32_t>() + off, (size_t)m * 4, hipMemcpyDeviceToHost));
+    }
+    if (capacity) HIP_TRY(c, hipMemcpy(capacity, c->k_cap.as<int64_t>() + cache, 8, hipMemcpyDeviceToHost));
+    if (weighted_size) HIP_TRY(c, hipMemcpy(weighted_size, c->k_wsize.as<int64_t>() + cache, 8, hipMemcpyDeviceToHost));
+    if (ubm) HIP_TRY(c, hipMemcpy(ubm, c->k_ubm.as<mmp_ubm_state>() + cache, sizeof(mmp_ubm_state), hipMemcpyDeviceToHost));
     return MMP_OK;
 }
 

@@ -208,6 +208,46 @@ class Solver:
         self._ck(self.lib.mmp_evict_batch(self.h, ptr(reqs), len(reqs), int(now), ptr(outs)))
         return outs
 
+    # ---- stateful keyed caches (rows a12 + a13) -------------------------------------------------
+    def load_caches_keyed(self, seg_off, last_used, weight, key, capacity, ubm=None):
+        from ._lib import UBM_STATE
+        seg_off = np.ascontiguousarray(seg_off, dtype=np.int32)
+        last_used = np.ascontiguousarray(last_used, dtype=np.int64)
+        weight = np.ascontiguousarray(weight, dtype=np.int32)
+        key = np.ascontiguousarray(key, dtype=np.int32)
+        capacity = np.ascontiguousarray(capacity, dtype=np.int64)
+        ubm = None if ubm is None else np.ascontiguousarray(ubm, dtype=UBM_STATE)
+        self._kcache_slots = int(seg_off[-1])
+        self._ck(self.lib.mmp_caches_load_keyed(self.h, len(capacity), ptr(seg_off),
+                                                ptr(last_used) if len(last_used) else None,
+                                                ptr(weight) if len(weight) else None, ptr(key) if len(key) else None,
+                                                ptr(capacity), ptr(ubm)))
+
+    def cache_replay(self, ops, now):
+        """Apply clhm / ModelCacheUnloadBufManager operations in order; returns (outs, evicted_keys)."""
+        from ._lib import CACHE_OP, CACHE_OP_OUT
+        ops = np.ascontiguousarray(ops, dtype=CACHE_OP)
+        outs = np.zeros(len(ops), dtype=CACHE_OP_OUT)
+        self._kcache_slots = getattr(self, "_kcache_slots", 0) + len(ops)
+        ev = np.zeros(max(self._kcache_slots, 1), np.int32)
+        used = C.c_int32(0)
+        self._ck(self.lib.mmp_cache_replay(self.h, ptr(ops) if len(ops) else None, len(ops), int(now),
+                                           ptr(outs) if len(ops) else None, ptr(ev), len(ev), C.byref(used)))
+        return outs, ev[: used.value]
+
+    def cache_read(self, cache: int, max_entries: int = 4096):
+        from ._lib import UBM_STATE
+        lu = np.zeros(max_entries, np.int64)
+        wt = np.zeros(max_entries, np.int32)
+        key = np.zeros(max_entries, np.int32)
+        n, cap, ws = C.c_int32(0), C.c_int64(0), C.c_int64(0)
+        ubm = np.zeros(1, dtype=UBM_STATE)
+        self._ck(self.lib.mmp_cache_read(self.h, int(cache), max_entries, ptr(lu), ptr(wt), ptr(key), C.byref(n),
+                                         C.byref(cap), C.byref(ws), ptr(ubm)))
+        m = min(n.value, max_entries)
+        return {"last_used": lu[:m], "weight": wt[:m], "key": key[:m], "capacity": cap.value,
+                "weighted_size": ws.value, "ubm": ubm[0]}
+
     def gates(self, reqs, excl_pod, excl_time, explicit_pool, now, in_use_failure_expiry_ms=450_000) -> np.ndarray:
         from ._lib import GATE_OUT, GATE_REQ
         reqs = np.ascontiguousarray(reqs, dtype=GATE_REQ)

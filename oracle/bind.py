@@ -87,6 +87,8 @@ def load() -> C.CDLL:
         lib.orc_cache_remove.argtypes = [C.POINTER(OrcCache), C.c_int32]
         lib.orc_cache_oldest_time.restype = C.c_int64
         lib.orc_cache_oldest_time.argtypes = [C.POINTER(OrcCache)]
+        lib.orc_cache_find.restype = C.c_int32
+        lib.orc_cache_find.argtypes = [C.POINTER(OrcCache), C.c_int32]
         U = C.POINTER(OrcUbm)
         lib.orc_ubm_init.argtypes = [U, C.POINTER(OrcCache), C.c_int32, C.c_int64]
         lib.orc_ubm_buffer_weight.restype = C.c_int32
@@ -100,6 +102,11 @@ def load() -> C.CDLL:
         lib.orc_ubm_claim_requested_space_if_ready.argtypes = [U, C.c_int32, C.c_int64]
         lib.orc_ubm_adjust_weight_after_load.argtypes = [U, C.c_int32, C.c_int32, C.c_int64]
         lib.orc_ubm_unload_complete.argtypes = [U, C.c_int32, C.c_int, C.c_int64]
+        lib.orc_ubm_remove_entry.restype = C.c_int32
+        lib.orc_ubm_remove_entry.argtypes = [U, C.c_int32, C.c_int64]
+        lib.orc_ubm_discard_failed_entry.argtypes = [U, C.c_int32, C.c_int64]
+        lib.orc_ubm_insert_failed_placeholder_entry.restype = C.c_int
+        lib.orc_ubm_insert_failed_placeholder_entry.argtypes = [U, C.c_int32, C.c_int32, C.c_int64, C.c_int64]
         I32, I64, VP = C.c_int32, C.c_int64, C.c_void_p
         lib.orc_go_local.restype = C.c_int
         lib.orc_go_local.argtypes = [VP, VP, I32, I32, C.c_int, C.c_int, C.c_int, I64]
@@ -305,6 +312,60 @@ class CCache:
     @property
     def weighted_size(self):
         return self.c.weighted_size
+
+    def nodes(self):
+        """(last_used, weight, key) arrays in deque order (oldest first)"""
+        if not self.c.n:
+            return np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32)
+        raw = np.ctypeslib.as_array(C.cast(self.c.nodes, C.POINTER(C.c_byte)), shape=(self.c.n * 16,))
+        arr = np.frombuffer(raw.tobytes(), dtype=ORC_NODE)
+        return arr["last_used"].copy(), arr["weight"].copy(), arr["key"].copy()
+
+    def apply(self, op, key, arg, time, flag, now):
+        """One mmp_cache_op on the oracle; returns (result, evicted keys in listener order)."""
+        L, c, u = self.lib, C.byref(self.c), (C.byref(self.u) if self.u is not None else None)
+        ev0 = self.u.n_evicted if self.u is not None else 0
+        plain = None
+        if op == 0:
+            plain = self.put_if_absent(key, arg, time, now)
+            res = 0 if plain is None else 1
+        elif op == 1:
+            res = int(self.get(key, time, now))
+        elif op == 2:
+            plain = self.update_weight(key, arg, time, now)
+            res = 0 if plain is None else 1
+        elif op == 3:
+            res = int(self.remove(key))
+        elif op == 4:
+            res = L.orc_ubm_insert_new_entry(u, key, arg, time, now)
+        elif op == 5:
+            res = 1 if L.orc_cache_find(c, key) >= 0 else 0
+            L.orc_ubm_adjust_new_entry_space_request(u, arg, key, now)
+        elif op == 6:
+            res = L.orc_ubm_cache_space_is_ready(u, arg)
+        elif op == 7:
+            res = L.orc_ubm_claim_requested_space_if_ready(u, arg, now)
+        elif op == 8:
+            res = 1 if (L.orc_cache_find(c, key) >= 0 or arg == 0) else 0
+            L.orc_ubm_adjust_weight_after_load(u, arg, key, now)
+        elif op == 9:
+            L.orc_ubm_unload_complete(u, arg, flag, now)
+            res = 1 if flag else 0
+        elif op == 10:
+            res = L.orc_ubm_remove_entry(u, key, now)
+        elif op == 11:
+            L.orc_ubm_discard_failed_entry(u, arg, now)
+            res = 1
+        elif op == 12:
+            res = L.orc_ubm_insert_failed_placeholder_entry(u, key, arg, time, now)
+        else:
+            raise ValueError(op)
+        if plain is not None:
+            return res, list(plain)
+        if self.u is not None:
+            assert self.u.n_evicted <= 1024, "oracle eviction log overflow"
+            return res, [int(self.u.evicted[i]) for i in range(ev0, self.u.n_evicted)]
+        return res, []
 
     # unload-buffer manager
     def evicted(self):

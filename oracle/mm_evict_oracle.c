@@ -218,6 +218,32 @@ static void ubm_on_evicted(orc_ubm *u, const int32_t *keys, const int32_t *weigh
     }
 }
 
+/* evict() (clhm :329-352) with the victims handed to the listener while still under the lock */
+static void ubm_evict(orc_ubm *u, int64_t now)
+{
+    orc_cache *c = u->cache;
+    int32_t cap = 16, nv = 0;
+    int32_t *vk = (int32_t *)malloc((size_t)cap * sizeof(int32_t));
+    int32_t *vw = (int32_t *)malloc((size_t)cap * sizeof(int32_t));
+    while (c->weighted_size > c->capacity && c->n > 0) {
+        orc_node e = c->nodes[0];
+        memmove(&c->nodes[0], &c->nodes[1], (size_t)(c->n - 1) * sizeof(orc_node));
+        c->n--;
+        c->weighted_size -= e.weight < 0 ? -e.weight : e.weight;
+        if (nv == cap) {
+            cap *= 2;
+            vk = (int32_t *)realloc(vk, (size_t)cap * sizeof(int32_t));
+            vw = (int32_t *)realloc(vw, (size_t)cap * sizeof(int32_t));
+        }
+        vk[nv] = e.key;
+        vw[nv] = e.weight;
+        nv++;
+    }
+    ubm_on_evicted(u, vk, vw, nv, now);
+    free(vk);
+    free(vw);
+}
+
 /* CacheEntry.updateWeightLocked → replaceQuietly → UpdateTask(quiet) */
 static void ubm_set_weight(orc_ubm *u, int32_t key, int32_t w, int64_t now)
 {
@@ -228,16 +254,7 @@ static void ubm_set_weight(orc_ubm *u, int32_t key, int32_t w, int64_t now)
     if (diff == 0) return;
     c->nodes[i].weight = w;
     c->weighted_size += diff;
-    /* evict() with victim weights captured for the listener */
-    int32_t vk[256], vw[256], nv = 0;
-    while (c->weighted_size > c->capacity && c->n > 0) {
-        orc_node e = c->nodes[0];
-        memmove(&c->nodes[0], &c->nodes[1], (size_t)(c->n - 1) * sizeof(orc_node));
-        c->n--;
-        c->weighted_size -= e.weight < 0 ? -e.weight : e.weight;
-        if (nv < 256) { vk[nv] = e.key; vw[nv] = e.weight; nv++; }
-    }
-    ubm_on_evicted(u, vk, vw, nv, now);
+    ubm_evict(u, now);
 }
 
 /* adjustAggregateUnloadingWeight, :375-392 */
@@ -295,15 +312,7 @@ int orc_ubm_insert_new_entry(orc_ubm *u, int32_t key, int32_t weight, int64_t la
     c->nodes[l + 1] = nd;
     c->n++;
     u->total_occupancy += weight;
-    int32_t vk[256], vw[256], nv = 0;
-    while (c->weighted_size > c->capacity && c->n > 0) {
-        orc_node e = c->nodes[0];
-        memmove(&c->nodes[0], &c->nodes[1], (size_t)(c->n - 1) * sizeof(orc_node));
-        c->n--;
-        c->weighted_size -= e.weight < 0 ? -e.weight : e.weight;
-        if (nv < 256) { vk[nv] = e.key; vw[nv] = e.weight; nv++; }
-    }
-    ubm_on_evicted(u, vk, vw, nv, now);
+    ubm_evict(u, now);
     return 1;
 }
 
@@ -374,4 +383,53 @@ void orc_ubm_unload_complete(orc_ubm *u, int32_t weight, int success, int64_t no
     int64_t cap = u->cache->capacity;
     ubm_adjust_agg(u, -weight, now);
     u->cache->capacity = cap - weight > 1 ? cap - weight : 1;
+    ubm_evict(u, now); /* setCapacity evicts and notifies under the lock, clhm :305-316 */
+}
+
+/* removeEntry :281-298 with entryRemoved :311-316; returns the weight at removal or -1 */
+int32_t orc_ubm_remove_entry(orc_ubm *u, int32_t key, int64_t now)
+{
+    orc_cache *c = u->cache;
+    int32_t i = orc_cache_find(c, key);
+    if (i < 0) return -1;
+    int32_t w = c->nodes[i].weight;
+    orc_cache_remove(c, key);
+    u->total_occupancy -= w;
+    ubm_adjust_agg(u, w, now);
+    return w;
+}
+
+/* discardFailedEntry, :343-349 */
+void orc_ubm_discard_failed_entry(orc_ubm *u, int32_t weight, int64_t now)
+{
+    u->total_occupancy -= weight;
+    ubm_pay_down(u, weight, 0, now);
+}
+
+/* insertFailedPlaceholderEntry, :250-274 */
+int orc_ubm_insert_failed_placeholder_entry(orc_ubm *u, int32_t key, int32_t weight, int64_t last_used, int64_t now)
+{
+    orc_cache *c = u->cache;
+    int64_t rem = c->capacity - c->weighted_size;
+    int32_t remaining = rem > INT32_MAX ? INT32_MAX : (int32_t)rem;
+    int32_t deficit = weight - remaining;
+    if (deficit > 0) ubm_adjust_agg(u, -deficit, now);
+    if (orc_cache_find(c, key) >= 0) {
+        orc_cache_get(c, key, last_used, now);
+        if (deficit > 0) ubm_adjust_agg(u, deficit, now);
+        return 0;
+    }
+    orc_node nd = {0, weight, key};
+    nd.last_used = last_used == 0 ? now : last_used;
+    c->weighted_size += weight;
+    int32_t l = c->n - 1;
+    while (l >= 0 && !(c->nodes[l].last_used <= nd.last_used)) l--;
+    reserve(c, c->n + 1);
+    memmove(&c->nodes[l + 2], &c->nodes[l + 1], (size_t)(c->n - l - 1) * sizeof(orc_node));
+    c->nodes[l + 1] = nd;
+    c->n++;
+    ubm_evict(u, now);
+    u->total_occupancy += weight;
+    if (deficit > 0) u->cache_deficit += deficit;
+    return 1;
 }

@@ -305,6 +305,9 @@ int orc_ubm_cache_space_is_ready(const orc_ubm *u, int32_t required);
 int orc_ubm_claim_requested_space_if_ready(orc_ubm *u, int32_t required, int64_t now);
 void orc_ubm_adjust_weight_after_load(orc_ubm *u, int32_t delta, int32_t key, int64_t now);
 void orc_ubm_unload_complete(orc_ubm *u, int32_t weight, int success, int64_t now);
+int32_t orc_ubm_remove_entry(orc_ubm *u, int32_t key, int64_t now);
+void orc_ubm_discard_failed_entry(orc_ubm *u, int32_t weight, int64_t now);
+int orc_ubm_insert_failed_placeholder_entry(orc_ubm *u, int32_t key, int32_t weight, int64_t last_used, int64_t now);
 
 #ifdef __cplusplus
 }

@@ -354,12 +354,14 @@ class Clhm:
 
     def _evict(self):  # clhm :329-352
         out = []
+        self.lastEvictedWeights = []  # the weights the listener sees (CacheEntry.getWeight())
         while self.weightedSize > self.capacity:
             if not self.deque:
                 break
             node = self.deque.pop(0)
             self.weightedSize -= abs(node[2])
             out.append(node[0])
+            self.lastEvictedWeights.append(node[2])
         return out
 
     def _find(self, key):
@@ -443,15 +445,19 @@ class UnloadBufManager:
         cache.putIfAbsent(self.KEY, reserved, LONG_MAX, now)  # MM.java:1617-1622
 
     def buffer_weight(self):
-        return self.cache._find(self.KEY)[2]
+        n = self.cache._find(self.KEY)
+        return n[2] if n is not None else 0  # evicted itself: only with a capacity below the reserve
 
     def _on_evicted(self, keys):  # ModelMesh.onEviction → entryRemoved, still under the lock
-        for k in keys or []:
-            w = self.weights.pop(k)
+        ws = list(self.cache.lastEvictedWeights) if keys else []
+        for k, w in zip(keys or [], ws):
+            self.weights.pop(k, None)  # the pinned buffer entry itself can be evicted (pathological capacity)
             self.evicted.append((k, w))
             self.entryRemoved(w)
 
     def _set_weight(self, key, w, now):  # CacheEntry.updateWeightLocked → replaceQuietly
+        if self.cache._find(key) is None:
+            return  # replaceQuietly fails and the weight is restored, MM.java:1784-1786
         if key != self.KEY:
             self.weights[key] = w
         self._on_evicted(self.cache.updateWeight(key, w, -1, now))
@@ -534,6 +540,37 @@ class UnloadBufManager:
         cap = self.cache.capacity
         self._adjustAggregateUnloadingWeight(-weight, now)
         self.cache.capacity = max(1, cap - weight)
+        self._on_evicted(self.cache._evict())  # setCapacity evicts + notifies under the lock, clhm :305-316
+
+    def removeEntry(self, key, now):  # :281-298
+        n = self.cache._find(key)
+        if n is None:
+            return -1
+        w = n[2]
+        self.cache.remove(key)
+        self.weights.pop(key, None)
+        self.entryRemoved(w, now)
+        return w
+
+    def discardFailedEntry(self, weight, now):  # :343-349
+        self.totalModelCacheOccupancy -= weight
+        self._payDown(weight, False, now)
+
+    def insertFailedPlaceholderEntry(self, key, weight, lastUsed, now):  # :250-274
+        deficit = weight - self._cacheRemaining()
+        if deficit > 0:
+            self._adjustAggregateUnloadingWeight(-deficit, now)
+        ev = self.cache.putIfAbsent(key, weight, lastUsed, now)
+        if ev is None:
+            if deficit > 0:
+                self._adjustAggregateUnloadingWeight(deficit, now)
+            return False
+        self.weights[key] = weight
+        self._on_evicted(ev)
+        self.totalModelCacheOccupancy += weight
+        if deficit > 0:
+            self.cacheDeficit += deficit
+        return True
 
     def adjusted_capacity(self):  # getAdjustedCacheCapacity :90-92
         return self.cache.capacity - self.buffer_weight()

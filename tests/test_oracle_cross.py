@@ -150,3 +150,71 @@ def test_fuzz_fleets_reach_every_branch_of_get_next():
                 "chosen_is_self"}
     missing = expected - po.BRANCHES
     assert not missing, f"fuzz fleets never reached: {sorted(missing)}"
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_unload_buffer_manager_ops_c_vs_python(seed):
+    """Random ModelCacheUnloadBufManager method sequences (:130-349, including removeEntry,
+    discardFailedEntry, insertFailedPlaceholderEntry and the capacity-shrinking unloadComplete(failure))
+    through both restatements: evictions in listener order, deque, and manager fields must agree."""
+    import ctypes as C
+    rng = np.random.default_rng(900 + seed)
+    NOW = 1_760_000_000_000
+    cap, reserved = int(rng.choice([5_000, 25_600, 131_072])), int(rng.choice([0, 256, 2_560]))
+    h = ob.CCache(cap, reserved, NOW)
+    pc = po.Clhm(cap)
+    pu = po.UnloadBufManager(pc, reserved, NOW)
+    nxt = 0
+    for step in range(400):
+        live = [k for k in pc.keys() if k != po.UnloadBufManager.KEY]
+        known = int(rng.choice(live)) if live and rng.random() < 0.8 else 99_000 + int(rng.integers(0, 5))
+        t = int(rng.choice([0, NOW - 500, NOW - 2_000, NOW - 7_200_000]))
+        op = int(rng.choice([4, 4, 4, 5, 6, 7, 8, 9, 10, 11, 12, 1]))
+        w = int(rng.choice([1, 1, 640, 2_560]))
+        before = len(pu.evicted)
+        if op in (4, 12):
+            key = nxt if rng.random() < 0.85 else known
+            nxt += 1
+            r_c, ev_c = h.apply(op, key, w, t, 0, NOW)
+            r_p = (pu.insertNewEntry if op == 4 else pu.insertFailedPlaceholderEntry)(key, w, t, NOW)
+        elif op == 5:
+            if known not in pu.weights:
+                continue
+            inc = int(rng.choice([639, 2_559]))
+            r_c, ev_c = h.apply(op, known, inc, 0, 0, NOW)
+            pu.adjustNewEntrySpaceRequest(inc, known, NOW)
+            r_p = r_c
+        elif op in (6, 7):
+            req = int(rng.choice([1, 640, 100_000]))
+            r_c, ev_c = h.apply(op, 0, req, 0, 0, NOW)
+            r_p = pu.cacheSpaceIsReady(req) if op == 6 else pu.claimRequestedSpaceIfReady(req, NOW)
+        elif op == 8:
+            if known not in pu.weights:
+                continue
+            delta = int(rng.choice([-600, -1, 1, 700, 20_000]))
+            if pu.weights[known] + delta <= 0:
+                continue
+            r_c, ev_c = h.apply(op, known, delta, 0, 0, NOW)
+            pu.adjustWeightAfterLoad(delta, known, NOW)
+            r_p = r_c
+        elif op == 9:
+            ok = int(rng.random() < 0.8)
+            r_c, ev_c = h.apply(op, 0, 640, 0, ok, NOW)
+            pu.unloadComplete(640, bool(ok), NOW)
+            r_p = r_c
+        elif op == 10:
+            r_c, ev_c = h.apply(op, known, 0, 0, 0, NOW)
+            r_p = pu.removeEntry(known, NOW)
+        elif op == 11:
+            r_c, ev_c = h.apply(op, 0, 1, 0, 0, NOW)
+            pu.discardFailedEntry(1, NOW)
+            r_p = r_c
+        else:
+            r_c, ev_c = h.apply(1, known, 0, t, 0, NOW)
+            r_p = pc.get(known, t, NOW)
+        assert int(r_c) == int(r_p), (seed, step, op)
+        assert ev_c == [-1000000 if k == po.UnloadBufManager.KEY else k for k, _ in pu.evicted[before:]], (seed, step, op)
+        assert h.keys() == [k for k in pc.keys() if k != po.UnloadBufManager.KEY]
+        assert (h.u.total_unloading, h.u.total_occupancy, h.u.cache_deficit, h.c.weighted_size, h.c.capacity) == \
+            (pu.totalUnloadingWeight, pu.totalModelCacheOccupancy, pu.cacheDeficit, pc.weightedSize, pc.capacity)
+        h.u.n_evicted = 0
