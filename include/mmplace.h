@@ -357,6 +357,16 @@ int mmp_types_from_labels(mmp_ctx *ctx, int32_t n_types, const uint64_t *require
                           uint8_t *has_allowed_out, uint8_t *has_prefer_out);
 /* UpgradeTracker.getLikelyReplacedReplicaSets (UpgradeTracker.java:78). */
 int mmp_replaced_rs_load(mmp_ctx *ctx, const int32_t *replica_sets, int32_t n);
+/* UpgradeTracker as a stateful part of the context (row a19; UpgradeTracker.java:85-200): the Java
+ * instance-table listener forwards its three calls (MM.java:1532,1553,1563).  labels_key = identity of
+ * the record's labels array as the reference's HashMap<String[],..> sees it (0 for NO_LABELS),
+ * replica_set = interned id.substring(0,6) or -1 if |id| < 7.  The resulting replica-set list replaces
+ * the one given to mmp_replaced_rs_load and takes effect at the next commit. */
+int mmp_upgrade_instance_added(mmp_ctx *ctx, int64_t labels_key, int32_t replica_set, int64_t start_time, int64_t now_ms);
+int mmp_upgrade_instance_removed(mmp_ctx *ctx, int64_t labels_key, int32_t replica_set, int64_t now_ms);
+int mmp_upgrade_housekeeping(mmp_ctx *ctx, int64_t now_ms);
+/* getLikelyReplacedReplicaSets(): up to max entries (replica set, expiry); *n_out = entries in the map. */
+int mmp_upgrade_replaced(mmp_ctx *ctx, int32_t *rs_out, int64_t *expiry_out, int32_t max, int32_t *n_out);
 /* The model registry view (MM.java:308). ent_pod / ent_time have n_entries items. */
 int mmp_models_load(mmp_ctx *ctx, const mmp_model_row *rows, int32_t n_models,
                     const int32_t *ent_pod, const int64_t *ent_time, int32_t n_entries);

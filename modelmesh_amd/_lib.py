@@ -120,6 +120,10 @@ SYMBOLS = [
     ("mmp_types_load", C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
     ("mmp_types_from_labels", C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     ("mmp_replaced_rs_load", C.c_int, [_P, _P, C.c_int32]),
+    ("mmp_upgrade_instance_added", C.c_int, [_P, C.c_int64, C.c_int32, C.c_int64, C.c_int64]),
+    ("mmp_upgrade_instance_removed", C.c_int, [_P, C.c_int64, C.c_int32, C.c_int64]),
+    ("mmp_upgrade_housekeeping", C.c_int, [_P, C.c_int64]),
+    ("mmp_upgrade_replaced", C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     ("mmp_models_load", C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32]),
     ("mmp_snapshot_commit", C.c_int, [_P]),
     ("mmp_get_order", C.c_int, [_P, _P, C.POINTER(C.c_int32)]),

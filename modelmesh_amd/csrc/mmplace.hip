@@ -27,6 +27,7 @@
 #include "shard_kernels.hpp"
 #include "snapshot.hpp"
 #include "types_kernel.hpp"
+#include "upgrade_tracker.hpp"
 
 using namespace mmp;
 
@@ -102,6 +103,7 @@ struct mmp_ctx {
     std::vector<uint64_t> allowed, prefer;
     std::vector<uint8_t> has_allowed, has_prefer;
     std::vector<int32_t> replaced_rs;
+    UpgradeTracker upgrades;
 
     // committed snapshot (double-buffered; `cur` is what decisions read)
     SnapBufs sb[2];
@@ -431,6 +433,55 @@ int mmp_replaced_rs_load(mmp_ctx *c, const int32_t *rs, int32_t n)
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     c->replaced_rs.assign(rs, rs + n);
+    return MMP_OK;
+}
+
+static void publish_upgrades(mmp_ctx *c)
+{
+    c->replaced_rs.clear();
+    for (auto &e : c->upgrades.replaced) c->replaced_rs.push_back(e.first);
+}
+
+int mmp_upgrade_instance_added(mmp_ctx *c, int64_t labels_key, int32_t rs, int64_t start_time, int64_t now)
+{
+    if (!c) return MMP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->upgrades.instance_added(labels_key, rs, start_time, now);
+    publish_upgrades(c);
+    return MMP_OK;
+}
+
+int mmp_upgrade_instance_removed(mmp_ctx *c, int64_t labels_key, int32_t rs, int64_t now)
+{
+    if (!c) return MMP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->upgrades.instance_removed(labels_key, rs, now);
+    publish_upgrades(c);
+    return MMP_OK;
+}
+
+int mmp_upgrade_housekeeping(mmp_ctx *c, int64_t now)
+{
+    if (!c) return MMP_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->upgrades.housekeeping(now);
+    publish_upgrades(c);
+    return MMP_OK;
+}
+
+int mmp_upgrade_replaced(mmp_ctx *c, int32_t *rs_out, int64_t *expiry_out, int32_t max, int32_t *n_out)
+{
+    if (!c || !n_out || max < 0 || (max > 0 && (!rs_out || !expiry_out))) return fail(c, MMP_EINVAL, "mmp_upgrade_replaced: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    int32_t i = 0;
+    for (auto &e : c->upgrades.replaced) {
+        if (i < max) {
+            rs_out[i] = e.first;
+            expiry_out[i] = e.second;
+        }
+        i++;
+    }
+    *n_out = i;
     return MMP_OK;
 }
 

@@ -134,6 +134,23 @@ class Solver:
         rs = np.ascontiguousarray(rs, dtype=np.int32)
         self._ck(self.lib.mmp_replaced_rs_load(self.h, ptr(rs) if len(rs) else None, len(rs)))
 
+    # UpgradeTracker (row a19)
+    def upgrade_instance_added(self, labels_key, replica_set, start_time, now):
+        self._ck(self.lib.mmp_upgrade_instance_added(self.h, int(labels_key), int(replica_set), int(start_time), int(now)))
+
+    def upgrade_instance_removed(self, labels_key, replica_set, now):
+        self._ck(self.lib.mmp_upgrade_instance_removed(self.h, int(labels_key), int(replica_set), int(now)))
+
+    def upgrade_housekeeping(self, now):
+        self._ck(self.lib.mmp_upgrade_housekeeping(self.h, int(now)))
+
+    def upgrade_replaced(self) -> dict:
+        rs = np.zeros(256, np.int32)
+        ex = np.zeros(256, np.int64)
+        n = C.c_int32(0)
+        self._ck(self.lib.mmp_upgrade_replaced(self.h, ptr(rs), ptr(ex), 256, C.byref(n)))
+        return {int(rs[i]): int(ex[i]) for i in range(min(n.value, 256))}
+
     def load_models(self, models, ent_pod, ent_time):
         models = np.ascontiguousarray(models, dtype=MODEL_ROW)
         ent_pod = np.ascontiguousarray(ent_pod, dtype=np.int32)
