@@ -446,6 +446,36 @@ int mmp_scaledown_plan(mmp_ctx *ctx, const mmp_cache_entry *entries, int32_t n,
 int mmp_migration_plan(mmp_ctx *ctx, const mmp_cache_entry *entries, int32_t n, int32_t self_pod, int64_t now_ms,
                        int64_t cutoff_age_ms, uint8_t *action_out, uint8_t *wait_out);
 
+/* ---- ingestion of the KV-store wire format ---------------------------------------
+ * The instance table and the registry live in etcd / ZooKeeper as Jackson JSON values
+ * (MM.java:346 INST_REC_SERIALIZER, :628 registry view; InstanceRecord.java:37-69,
+ * ModelRecord.java:61-114).  These entry points take the raw values and parse them on the device. */
+/* Define the pod index space from the instance ids (the KV keys): computes id_order (rank under
+ * String.compareTo; ids must be ASCII) and replica_set (interned id.substring(0,6), -1 if |id| < 7,
+ * MM.java:4769) for every pod, and the id -> pod table used to resolve ModelRecord.instanceIds keys.
+ * Rows not yet ingested are absent (tombstones).  Optional outputs may be NULL. */
+int mmp_pod_ids_load(mmp_ctx *ctx, const char *ids, const int32_t *id_off, int32_t n_pods, uint32_t *id_order_out,
+                     int32_t *replica_set_out);
+/* n InstanceRecord JSON values, value i = buf[off[i], off[i+1]) for pod pod_idx[i]; live[i] != 0 marks
+ * the instance as present in the litelinks registry (MM.java:4765).  Equivalent to mmp_pods_upsert with
+ * rows parsed from the JSON.  status_out[i] = 1 for a malformed value (that row is left unchanged);
+ * start_time_out[i] = InstanceRecord.startTime (input of mmp_upgrade_instance_added). */
+int mmp_pods_ingest_json(mmp_ctx *ctx, const char *buf, const int64_t *off, int32_t n, const int32_t *pod_idx,
+                         const uint8_t *live, int64_t *start_time_out, int32_t *status_out);
+/* Names of the model types in type-table order (ModelRecord "type"); a name not listed maps to
+ * unknown_type (the extra row mmp_types_from_labels installs), an absent / null type to the index of
+ * "NLCLASSIFIER" (ModelRecord.DEFAULT_TYPE, ModelRecord.java:121-133) if listed, else unknown_type. */
+int mmp_type_names_load(mmp_ctx *ctx, const char *names, const int32_t *name_off, int32_t n_types, int32_t unknown_type);
+/* Replace the registry view (like mmp_models_load) from n_models ModelRecord JSON values; model i =
+ * value i.  Ids that are not in the pod table become entries with pod -1 (they still count as copies).
+ * last_unload_out[i] = "lul" (ModelRecord.lastUnloadTime, an input of the scale-down plan). */
+int mmp_models_ingest_json(mmp_ctx *ctx, const char *buf, const int64_t *off, int32_t n_models, int64_t *last_unload_out,
+                           int32_t *status_out);
+/* Read the staged instance table / the loaded registry view back (tests, diagnostics). */
+int mmp_pods_get(mmp_ctx *ctx, mmp_pod_row *rows_out, int32_t max_rows, int32_t *n_out);
+int mmp_models_get(mmp_ctx *ctx, mmp_model_row *rows_out, int32_t max_models, int32_t *ent_pod_out, int64_t *ent_time_out,
+                   int32_t max_entries, int32_t *n_models_out, int32_t *n_entries_out);
+
 /* ---- pod-axis sharding across the GPUs of one node ---------------------------
  * There is no reference counterpart: the reference walks clusterState (MM.java:4763) on one JVM
  * thread.  Here shard g of G owns a contiguous range of PLACEMENT_ORDER positions (the words

@@ -142,6 +142,12 @@ SYMBOLS = [
     ("mmp_scaleup_plan", C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32)]),
     ("mmp_scaledown_plan", C.c_int, [_P, _P, C.c_int32, _P, _P]),
     ("mmp_migration_plan", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _P, _P]),
+    ("mmp_pod_ids_load", C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
+    ("mmp_pods_ingest_json", C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, _P]),
+    ("mmp_type_names_load", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32]),
+    ("mmp_models_ingest_json", C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
+    ("mmp_pods_get", C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
+    ("mmp_models_get", C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("mmp_shard_configure", C.c_int, [_P, C.c_int32, C.c_int32]),
     ("mmp_shard_xchg_slots", C.c_int32, [C.c_int32, C.c_int32]),
     ("mmp_shard_xchg_is_sum", C.c_int32, [C.c_int32]),

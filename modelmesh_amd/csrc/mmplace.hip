@@ -16,12 +16,14 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/mmplace.h"
 #include "aux_kernels.hpp"
 #include "cache_kernels.hpp"
 #include "gate_kernel.hpp"
+#include "ingest_kernels.hpp"
 #include "place_kernel.hpp"
 #include "rebalance_kernels.hpp"
 #include "shard_kernels.hpp"
@@ -137,6 +139,14 @@ struct mmp_ctx {
     int32_t k_caches = 0;
     std::vector<int32_t> k_n;  // host mirror of the live entry counts
     DevBuf k_cap, k_wsize, k_ubm, k_ops, k_order, k_opoff, k_outs, k_ev, k_evoff;
+
+    // wire-format ingestion: per-pod id attributes and the hash tables the parsers probe
+    std::vector<uint32_t> id_order_v;
+    std::vector<int32_t> replica_set_v;
+    DevBuf idtab_hash, idtab_val, tytab_hash, tytab_val, j_buf, j_off, j_rows, j_aux, j_status;
+    uint32_t idtab_mask = 0, tytab_mask = 0;
+    bool have_ids = false, have_types = false;
+    int32_t unknown_type = 0, default_type = 0;
 
     // per-call scratch for the host-pointer entry points
     DevBuf s_reqs, s_outs, s_extra, s_a, s_b, s_c, s_d;
@@ -280,7 +290,8 @@ void mmp_destroy(mmp_ctx *c)
                       &c->c_lu, &c->c_wt, &c->c_cap, &c->s_reqs, &c->s_outs, &c->s_extra, &c->s_a, &c->s_b,
                       &c->s_c, &c->s_d, &c->r_ps, &c->r_counts, &c->r_keys, &c->r_vals, &c->r_keys2, &c->r_vals2,
                       &c->r_tmp, &c->r_out_model, &c->r_out_lu, &c->k_cap, &c->k_wsize, &c->k_ubm, &c->k_ops, &c->k_order,
-                      &c->k_opoff, &c->k_outs, &c->k_ev, &c->k_evoff, &c->ks[0].off, &c->ks[0].lu, &c->ks[0].wt,
+                      &c->k_opoff, &c->k_outs, &c->k_ev, &c->k_evoff, &c->idtab_hash, &c->idtab_val, &c->tytab_hash,
+                      &c->tytab_val, &c->j_buf, &c->j_off, &c->j_rows, &c->j_aux, &c->j_status, &c->ks[0].off, &c->ks[0].lu, &c->ks[0].wt,
                       &c->ks[0].key, &c->ks[0].n, &c->ks[1].off, &c->ks[1].lu, &c->ks[1].wt, &c->ks[1].key, &c->ks[1].n})
         b->release();
     delete c;
@@ -672,6 +683,242 @@ int mmp_cluster_stats(mmp_ctx *c, mmp_stats *out)
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     *out = c->stats;
+    return MMP_OK;
+}
+
+/* ---- wire-format ingestion (§8f-1) ------------------------------------------ */
+
+namespace {
+// host side of the open-addressing table the device probes (ingest_kernels.hpp: tab_find)
+int build_hash_table(mmp_ctx *c, const char *strs, const int32_t *off, int32_t n, DevBuf &d_hash, DevBuf &d_val,
+                     uint32_t &mask_out, const char *what)
+{
+    uint32_t cap = 16;
+    while (cap < (uint32_t)n * 2u) cap <<= 1;
+    std::vector<uint64_t> hs(cap, 0);
+    std::vector<int32_t> vs(cap, INT32_MIN);
+    for (int32_t i = 0; i < n; i++) {
+        if (off[i + 1] < off[i]) return fail(c, MMP_EINVAL, "%s: offsets not monotone at %d", what, i);
+        const uint64_t h = fnv1a(strs + off[i], off[i + 1] - off[i]);
+        uint32_t s = (uint32_t)(h ^ (h >> 32)) & (cap - 1);
+        while (vs[s] != INT32_MIN) {
+            if (hs[s] == h) return fail(c, MMP_EINVAL, "%s: entries %d and %d are equal or collide under FNV-1a", what, vs[s], i);
+            s = (s + 1) & (cap - 1);
+        }
+        hs[s] = h;
+        vs[s] = i;
+    }
+    HIP_TRY(c, d_hash.ensure((size_t)cap * 8));
+    HIP_TRY(c, d_val.ensure((size_t)cap * 4));
+    HIP_TRY(c, hipMemcpy(d_hash.p, hs.data(), (size_t)cap * 8, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(d_val.p, vs.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
+    mask_out = cap - 1;
+    return MMP_OK;
+}
+}  // namespace
+
+int mmp_pod_ids_load(mmp_ctx *c, const char *ids, const int32_t *id_off, int32_t n_pods, uint32_t *id_order_out,
+                     int32_t *replica_set_out)
+{
+    if (!c || n_pods < 0 || !id_off || (n_pods > 0 && !ids)) return fail(c, MMP_EINVAL, "mmp_pod_ids_load: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, quiesce_decisions(c));
+    int rc = build_hash_table(c, ids, id_off, n_pods, c->idtab_hash, c->idtab_val, c->idtab_mask, "mmp_pod_ids_load");
+    if (rc != MMP_OK) return rc;
+    // String.compareTo on ASCII ids == bytewise comparison, shorter prefix first
+    std::vector<int32_t> perm(n_pods);
+    for (int32_t i = 0; i < n_pods; i++) perm[i] = i;
+    auto less = [&](int32_t a, int32_t b) {
+        const int la = id_off[a + 1] - id_off[a], lb = id_off[b + 1] - id_off[b];
+        const int m = memcmp(ids + id_off[a], ids + id_off[b], (size_t)std::min(la, lb));
+        return m != 0 ? m < 0 : la < lb;
+    };
+    std::sort(perm.begin(), perm.end(), less);
+    c->id_order_v.assign(n_pods, 0);
+    for (int32_t r = 0; r < n_pods; r++) c->id_order_v[perm[r]] = (uint32_t)r;
+    std::unordered_map<std::string, int32_t> rs_intern;
+    c->replica_set_v.assign(n_pods, -1);
+    for (int32_t i = 0; i < n_pods; i++) {
+        const int len = id_off[i + 1] - id_off[i];
+        if (len < 7) continue;  // MM.java:4769: iid.length() > 6
+        auto it = rs_intern.emplace(std::string(ids + id_off[i], 6), (int32_t)rs_intern.size());
+        c->replica_set_v[i] = it.first->second;
+    }
+    const size_t old = c->pods.size();
+    c->pods.resize(n_pods);
+    for (size_t i = 0; i < (size_t)n_pods; i++) {
+        if (i >= old) {
+            c->pods[i] = mmp_pod_row{};
+            c->pods[i].flags = MMP_POD_TOMBSTONE;
+        }
+        c->pods[i].id_order = c->id_order_v[i];
+        c->pods[i].replica_set = c->replica_set_v[i];
+    }
+    c->have_ids = true;
+    if (id_order_out && n_pods) memcpy(id_order_out, c->id_order_v.data(), (size_t)n_pods * 4);
+    if (replica_set_out && n_pods) memcpy(replica_set_out, c->replica_set_v.data(), (size_t)n_pods * 4);
+    return MMP_OK;
+}
+
+int mmp_pods_ingest_json(mmp_ctx *c, const char *buf, const int64_t *off, int32_t n, const int32_t *pod_idx,
+                         const uint8_t *live, int64_t *start_time_out, int32_t *status_out)
+{
+    if (!c || n < 0 || (n > 0 && (!buf || !off || !pod_idx || !status_out)))
+        return fail(c, MMP_EINVAL, "mmp_pods_ingest_json: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ids) return fail(c, MMP_ESTATE, "mmp_pods_ingest_json: load the instance ids first (mmp_pod_ids_load)");
+    if (n == 0) return MMP_OK;
+    const int32_t P = (int32_t)c->pods.size();
+    std::vector<mmp_pod_row> rows(n);
+    for (int32_t i = 0; i < n; i++) {
+        const int32_t k = pod_idx[i];
+        if (k < 0 || k >= P) return fail(c, MMP_EINVAL, "mmp_pods_ingest_json: record %d names pod %d", i, k);
+        if (off[i + 1] < off[i]) return fail(c, MMP_EINVAL, "mmp_pods_ingest_json: offsets not monotone at %d", i);
+        mmp_pod_row r{};
+        r.id_order = c->id_order_v[k];
+        r.replica_set = c->replica_set_v[k];
+        r.flags = (!live || live[i]) ? MMP_POD_LIVE : 0u;
+        rows[i] = r;
+    }
+    const int64_t bytes = off[n] - off[0];
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = c->stream;
+    HIP_TRY(c, c->j_buf.ensure((size_t)std::max<int64_t>(bytes, 1)));
+    HIP_TRY(c, c->j_off.ensure((size_t)(n + 1) * 8));
+    HIP_TRY(c, c->j_rows.ensure((size_t)n * sizeof(mmp_pod_row)));
+    HIP_TRY(c, c->j_aux.ensure((size_t)n * 8));
+    HIP_TRY(c, c->j_status.ensure((size_t)n * 4));
+    std::vector<int64_t> rel(n + 1);
+    for (int32_t i = 0; i <= n; i++) rel[i] = off[i] - off[0];
+    HIP_TRY(c, hipMemcpyAsync(c->j_buf.p, buf + off[0], (size_t)bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->j_off.p, rel.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->j_rows.p, rows.data(), (size_t)n * sizeof(mmp_pod_row), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(c->j_aux.p, 0, (size_t)n * 8, st));
+    hipLaunchKernelGGL(ingest_pods_kernel, dim3(div_up(n, 128)), dim3(128), 0, st, c->j_buf.as<char>(), c->j_off.as<int64_t>(), n,
+                       c->j_rows.as<mmp_pod_row>(), c->j_aux.as<int64_t>(), c->j_status.as<int32_t>());
+    HIP_TRY(c, hipGetLastError());
+    std::vector<int64_t> stt(n);
+    HIP_TRY(c, hipMemcpyAsync(rows.data(), c->j_rows.p, (size_t)n * sizeof(mmp_pod_row), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(stt.data(), c->j_aux.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(status_out, c->j_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    for (int32_t i = 0; i < n; i++) {
+        if (status_out[i] == 0) c->pods[pod_idx[i]] = rows[i];
+        if (start_time_out) start_time_out[i] = stt[i];
+    }
+    return MMP_OK;
+}
+
+int mmp_type_names_load(mmp_ctx *c, const char *names, const int32_t *name_off, int32_t n_types, int32_t unknown_type)
+{
+    if (!c || n_types < 0 || !name_off || (n_types > 0 && !names)) return fail(c, MMP_EINVAL, "mmp_type_names_load: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc = build_hash_table(c, names, name_off, n_types, c->tytab_hash, c->tytab_val, c->tytab_mask, "mmp_type_names_load");
+    if (rc != MMP_OK) return rc;
+    c->unknown_type = unknown_type;
+    c->default_type = unknown_type;
+    static const char kDefault[] = "NLCLASSIFIER";
+    for (int32_t i = 0; i < n_types; i++)
+        if (name_off[i + 1] - name_off[i] == (int)sizeof(kDefault) - 1 && memcmp(names + name_off[i], kDefault, sizeof(kDefault) - 1) == 0)
+            c->default_type = i;
+    c->have_types = true;
+    return MMP_OK;
+}
+
+int mmp_models_ingest_json(mmp_ctx *c, const char *buf, const int64_t *off, int32_t n_models, int64_t *last_unload_out,
+                           int32_t *status_out)
+{
+    if (!c || n_models < 0 || (n_models > 0 && (!buf || !off || !status_out)))
+        return fail(c, MMP_EINVAL, "mmp_models_ingest_json: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->have_ids) return fail(c, MMP_ESTATE, "mmp_models_ingest_json: load the instance ids first (mmp_pod_ids_load)");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, quiesce_decisions(c));  // the registry view is replaced in place
+    hipStream_t st = c->stream;
+    const int32_t n = n_models;
+    if (n == 0) {
+        c->n_models = 0;
+        c->n_entries = 0;
+        return MMP_OK;
+    }
+    for (int32_t i = 0; i < n; i++)
+        if (off[i + 1] < off[i]) return fail(c, MMP_EINVAL, "mmp_models_ingest_json: offsets not monotone at %d", i);
+    const int64_t bytes = off[n] - off[0];
+    HIP_TRY(c, c->j_buf.ensure((size_t)std::max<int64_t>(bytes, 1)));
+    HIP_TRY(c, c->j_off.ensure((size_t)(n + 1) * 8));
+    HIP_TRY(c, c->j_aux.ensure((size_t)n * 8 + 8));
+    HIP_TRY(c, c->j_status.ensure((size_t)n * 4));
+    HIP_TRY(c, c->models.ensure((size_t)n * sizeof(mmp_model_row)));
+    std::vector<int64_t> rel(n + 1);
+    for (int32_t i = 0; i <= n; i++) rel[i] = off[i] - off[0];
+    HIP_TRY(c, hipMemcpyAsync(c->j_buf.p, buf + off[0], (size_t)bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->j_off.p, rel.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(c->models.p, 0, (size_t)n * sizeof(mmp_model_row), st));
+    IngestModelsArgs A{};
+    A.buf = c->j_buf.as<char>();
+    A.off = c->j_off.as<int64_t>();
+    A.n = n;
+    A.ids = HashTab{c->idtab_hash.as<uint64_t>(), c->idtab_val.as<int32_t>(), c->idtab_mask};
+    A.types = c->have_types ? HashTab{c->tytab_hash.as<uint64_t>(), c->tytab_val.as<int32_t>(), c->tytab_mask}
+                            : HashTab{nullptr, nullptr, 0};
+    A.unknown_type = c->have_types ? c->unknown_type : 0;
+    A.default_type = c->have_types ? c->default_type : 0;
+    A.rows = c->models.as<mmp_model_row>();
+    A.last_unload = c->j_aux.as<int64_t>();
+    A.status = c->j_status.as<int32_t>();
+    int32_t *d_total = reinterpret_cast<int32_t *>(c->j_aux.as<int64_t>() + n);
+    hipLaunchKernelGGL(ingest_models_kernel<0>, dim3(div_up(n, 128)), dim3(128), 0, st, A);
+    hipLaunchKernelGGL(model_offsets_kernel, dim3(1), dim3(1024), 0, st, A.rows, n, d_total);
+    HIP_TRY(c, hipGetLastError());
+    int32_t total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, c->ent_pod.ensure((size_t)std::max(total, 1) * 4));
+    HIP_TRY(c, c->ent_time.ensure((size_t)std::max(total, 1) * 8));
+    A.ent_pod = c->ent_pod.as<int32_t>();
+    A.ent_time = c->ent_time.as<int64_t>();
+    hipLaunchKernelGGL(ingest_models_kernel<1>, dim3(div_up(n, 128)), dim3(128), 0, st, A);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(status_out, c->j_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (last_unload_out) HIP_TRY(c, hipMemcpyAsync(last_unload_out, c->j_aux.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    c->n_models = n;
+    c->n_entries = total;
+    return MMP_OK;
+}
+
+int mmp_pods_get(mmp_ctx *c, mmp_pod_row *rows_out, int32_t max_rows, int32_t *n_out)
+{
+    if (!c || !n_out || max_rows < 0 || (max_rows > 0 && !rows_out)) return fail(c, MMP_EINVAL, "mmp_pods_get: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    *n_out = (int32_t)c->pods.size();
+    const int32_t m = std::min(*n_out, max_rows);
+    if (m > 0) memcpy(rows_out, c->pods.data(), (size_t)m * sizeof(mmp_pod_row));
+    return MMP_OK;
+}
+
+int mmp_models_get(mmp_ctx *c, mmp_model_row *rows_out, int32_t max_models, int32_t *ent_pod_out, int64_t *ent_time_out,
+                   int32_t max_entries, int32_t *n_models_out, int32_t *n_entries_out)
+{
+    if (!c || !n_models_out || !n_entries_out || max_models < 0 || max_entries < 0)
+        return fail(c, MMP_EINVAL, "mmp_models_get: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n_models_out = c->n_models;
+    *n_entries_out = c->n_entries;
+    const int32_t m = std::min(c->n_models, max_models), e = std::min(c->n_entries, max_entries);
+    if (m > 0 && rows_out) HIP_TRY(c, hipMemcpy(rows_out, c->models.p, (size_t)m * sizeof(mmp_model_row), hipMemcpyDeviceToHost));
+    if (e > 0 && ent_pod_out) HIP_TRY(c, hipMemcpy(ent_pod_out, c->ent_pod.p, (size_t)e * 4, hipMemcpyDeviceToHost));
+    if (e > 0 && ent_time_out) HIP_TRY(c, hipMemcpy(ent_time_out, c->ent_time.p, (size_t)e * 8, hipMemcpyDeviceToHost));
     return MMP_OK;
 }
 

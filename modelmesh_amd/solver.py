@@ -134,6 +134,67 @@ class Solver:
         rs = np.ascontiguousarray(rs, dtype=np.int32)
         self._ck(self.lib.mmp_replaced_rs_load(self.h, ptr(rs) if len(rs) else None, len(rs)))
 
+    # ---- KV wire format ------------------------------------------------------
+    @staticmethod
+    def _pack(strings):
+        bs = [x if isinstance(x, bytes) else x.encode() for x in strings]
+        off = np.zeros(len(bs) + 1, np.int64)
+        np.cumsum([len(b) for b in bs], out=off[1:])
+        return b"".join(bs), off
+
+    def load_pod_ids(self, ids):
+        """ids: instance id strings in pod-index order; returns (id_order, replica_set)."""
+        blob, off = self._pack(ids)
+        off32 = off.astype(np.int32)
+        n = len(ids)
+        io = np.zeros(max(n, 1), np.uint32)
+        rs = np.zeros(max(n, 1), np.int32)
+        self._ck(self.lib.mmp_pod_ids_load(self.h, blob, ptr(off32), n, ptr(io), ptr(rs)))
+        self.n_pods = n
+        return io[:n], rs[:n]
+
+    def ingest_pods_json(self, values, pod_idx, live=None):
+        """values: InstanceRecord JSON (bytes/str) per record; returns (status, start_time)."""
+        blob, off = self._pack(values)
+        n = len(values)
+        pod_idx = np.ascontiguousarray(pod_idx, dtype=np.int32)
+        live = None if live is None else np.ascontiguousarray(live, dtype=np.uint8)
+        st = np.zeros(max(n, 1), np.int64)
+        status = np.zeros(max(n, 1), np.int32)
+        self._ck(self.lib.mmp_pods_ingest_json(self.h, blob, ptr(off), n, ptr(pod_idx), ptr(live), ptr(st), ptr(status)))
+        return status[:n], st[:n]
+
+    def load_type_names(self, names, unknown_type):
+        blob, off = self._pack(names)
+        off32 = off.astype(np.int32)
+        self._ck(self.lib.mmp_type_names_load(self.h, blob, ptr(off32), len(names), int(unknown_type)))
+
+    def ingest_models_json(self, values):
+        """values: ModelRecord JSON per model; returns (status, last_unload_time)."""
+        blob, off = self._pack(values)
+        n = len(values)
+        lul = np.zeros(max(n, 1), np.int64)
+        status = np.zeros(max(n, 1), np.int32)
+        self._ck(self.lib.mmp_models_ingest_json(self.h, blob, ptr(off), n, ptr(lul), ptr(status)))
+        self.n_models = n
+        return status[:n], lul[:n]
+
+    def get_pods(self) -> np.ndarray:
+        n = C.c_int32(0)
+        self._ck(self.lib.mmp_pods_get(self.h, None, 0, C.byref(n)))
+        rows = np.zeros(max(n.value, 1), dtype=POD_ROW)
+        self._ck(self.lib.mmp_pods_get(self.h, ptr(rows), n.value, C.byref(n)))
+        return rows[: n.value]
+
+    def get_models(self):
+        nm, ne = C.c_int32(0), C.c_int32(0)
+        self._ck(self.lib.mmp_models_get(self.h, None, 0, None, None, 0, C.byref(nm), C.byref(ne)))
+        rows = np.zeros(max(nm.value, 1), dtype=MODEL_ROW)
+        ep = np.zeros(max(ne.value, 1), np.int32)
+        et = np.zeros(max(ne.value, 1), np.int64)
+        self._ck(self.lib.mmp_models_get(self.h, ptr(rows), nm.value, ptr(ep), ptr(et), ne.value, C.byref(nm), C.byref(ne)))
+        return rows[: nm.value], ep[: ne.value], et[: ne.value]
+
     # UpgradeTracker (row a19)
     def upgrade_instance_added(self, labels_key, replica_set, start_time, now):
         self._ck(self.lib.mmp_upgrade_instance_added(self.h, int(labels_key), int(replica_set), int(start_time), int(now)))
