@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libmmplace.so")
+LIB_PATH = os.environ.get("MMP_LIB_PATH") or os.path.join(HERE, "lib", "libmmplace.so")
 
 MMP_OK = 0
 MMP_EINVAL, MMP_ENODEVICE, MMP_EHIP, MMP_EORDER, MMP_ESTATE, MMP_ENOMEM = -1, -2, -3, -4, -5, -6

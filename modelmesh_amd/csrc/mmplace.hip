@@ -12,6 +12,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -64,10 +65,10 @@ struct DevBuf {
 
 // device storage of one committed snapshot
 struct SnapBufs {
-    DevBuf pods, lru, rem, cnt, rpm, orig, pos_of, elig, elig_nors, pref, has_pref, fullw;
+    DevBuf pods, lru, rem, cnt, rpm, orig, pos_of, elig, elig_nors, pref, has_pref, fullw, ge;
     void release()
     {
-        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw})
+        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge})
             b->release();
     }
 };
@@ -98,6 +99,7 @@ struct mmp_ctx {
     std::string err;
     FastSlot fast[kFastSlots];
     std::atomic<uint32_t> fast_rr{0};
+    int32_t force_wave = 0;  // MMP_FORCE_WAVE=1: every decision takes the wave-per-decision kernel (tests)
 
     // host staging (inputs of the next commit)
     std::vector<mmp_pod_row> pods;
@@ -205,11 +207,11 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     A.n = n;
     A.n_models = c->n_models;
     A.now = now;
+    A.force_wave = c->force_wave;
     const int wpad = (c->snap.W + 1) & ~1;
     const size_t lds = (size_t)kPlaceWaves * 2 * wpad * sizeof(uint64_t);
-    if (lds > 64 * 1024) return fail(c, MMP_EINVAL, "instance table too large for the LDS staging tile (%d pods)", c->snap.P);
-    const int blocks = std::min(div_up(n, kPlaceWaves), 256 * 8);
-    hipLaunchKernelGGL(place_batch_kernel, dim3(blocks), dim3(kPlaceWaves * 64), lds, st, c->snap, A, wpad);
+    if (lds > 60 * 1024) return fail(c, MMP_EINVAL, "instance table too large for the LDS staging tile (%d pods)", c->snap.P);
+    hipLaunchKernelGGL(place_batch_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad);
     HIP_TRY(c, hipGetLastError());
     return MMP_OK;
 }
@@ -246,6 +248,7 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     mmp_ctx *c = new (std::nothrow) mmp_ctx();
     if (!c) return fail(nullptr, MMP_ENOMEM, "out of memory");
     c->cfg = *cfg;
+    if (const char *fw = getenv("MMP_FORCE_WAVE")) c->force_wave = fw[0] == '1';
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete c;
         return fail(nullptr, MMP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
@@ -279,6 +282,7 @@ void mmp_destroy(mmp_ctx *c)
         if (f.extra) (void)hipHostFree(f.extra);
         if (f.outs) (void)hipHostFree(f.outs);
     }
+
     if (c->stream) {
         (void)hipStreamSynchronize(c->stream);
         (void)hipStreamDestroy(c->stream);
@@ -556,6 +560,7 @@ int mmp_snapshot_commit(mmp_ctx *c)
     HIP_TRY(c, B.pref.ensure((size_t)T * W * 8));
     HIP_TRY(c, B.has_pref.ensure(T));
     HIP_TRY(c, B.fullw.ensure((size_t)W * 8));
+    HIP_TRY(c, B.ge.ensure((size_t)kGeRows * W * 8));
     HIP_TRY(c, c->rank.ensure(padded * 4));
     HIP_TRY(c, c->occupancy.ensure(padded * 4));
     HIP_TRY(c, c->flag.ensure(sizeof(int32_t)));
@@ -606,6 +611,8 @@ int mmp_snapshot_commit(mmp_ctx *c)
                            min_space, c->rank.as<int32_t>(), c->occupancy.as<int32_t>(), B.lru.as<int64_t>(),
                            B.rem.as<int64_t>(), B.cnt.as<int32_t>(), B.rpm.as<int32_t>(), B.orig.as<int32_t>(),
                            B.pos_of.as<int32_t>(), c->flag.as<int32_t>());
+        hipLaunchKernelGGL(build_ge_kernel, dim3(div_up(kGeRows * W, 4)), dim3(256), 0, st, B.cnt.as<int32_t>(), P, W,
+                           B.ge.as<uint64_t>());
         if (n_rs)
             hipLaunchKernelGGL(mark_replaced_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(),
                                P, c->rs_list.as<int32_t>(), n_rs, c->rs_bad.as<uint8_t>());
@@ -623,6 +630,7 @@ int mmp_snapshot_commit(mmp_ctx *c)
         HIP_TRY(c, hipMemsetAsync(B.elig_nors.p, 0, (size_t)T * W * 8, st));
         HIP_TRY(c, hipMemsetAsync(B.pref.p, 0, (size_t)T * W * 8, st));
         HIP_TRY(c, hipMemsetAsync(B.fullw.p, 0, (size_t)W * 8, st));
+        HIP_TRY(c, hipMemsetAsync(B.ge.p, 0, (size_t)kGeRows * W * 8, st));
     }
     int32_t bad = 0;
     StatsAcc acc{};
@@ -651,6 +659,7 @@ int mmp_snapshot_commit(mmp_ctx *c)
     S.pref = B.pref.as<uint64_t>();
     S.has_pref = B.has_pref.as<uint8_t>();
     S.fullw = B.fullw.as<uint64_t>();
+    S.ge = B.ge.as<uint64_t>();
     c->snap = S;
     c->cur = 1 - c->cur;
     c->committed = true;
@@ -1142,6 +1151,7 @@ int mmp_shard_place_phase_dev(mmp_ctx *c, int32_t phase, const void *d_reqs, int
     A.n = n;
     A.n_models = c->n_models;
     A.now = now;
+    A.force_wave = 0;
     XchgPtrs X{static_cast<int64_t *>(d_xchg[0]), static_cast<int64_t *>(d_xchg[1]), static_cast<int64_t *>(d_xchg[2]),
                static_cast<int64_t *>(d_xchg[3]), static_cast<int64_t *>(d_xchg[4]), static_cast<int64_t *>(d_xchg[5])};
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -21,6 +21,22 @@ namespace mmp {
 
 constexpr int kPlaceWaves = 4;  // waves (decisions in flight) per workgroup
 
+// A request with its indirections followed (request -> model row -> instanceIds / failedIn -> rank
+// positions), as the lane-per-decision path keeps it in registers.
+constexpr int kInlineExcl = 8;
+struct __attribute__((aligned(16))) ResolvedReq {
+    int32_t type;     // bitmap row; -1: unknown model -> null
+    int32_t selfpos;  // rank position of the caller, -1 if not in the table
+    uint32_t flags, pick;
+    int64_t last_used, fresh_lru, f_rem;
+    int32_t fresh_count, fresh_rpm;
+    int32_t n_excl;   // |loaded ∪ failed ∪ tried ∪ explicit|; > kInlineExcl: left to the wave path
+    int32_t model;
+    int32_t excl_pos[kInlineExcl];  // rank positions of the excluded pods, -1 = not in the table
+    int32_t pad[2];
+};
+static_assert(sizeof(ResolvedReq) == 96, "ResolvedReq is 96 bytes");
+
 struct PlaceArgs {
     const mmp_place_req *reqs;
     const mmp_model_row *models;
@@ -30,6 +46,7 @@ struct PlaceArgs {
     int32_t n;
     int32_t n_models;
     int64_t now;
+    int32_t force_wave;  // diagnostics: hand every decision to the wave-per-decision kernel
 };
 
 // (int)(double) with Java narrowing semantics
@@ -70,7 +87,7 @@ __device__ __forceinline__ int first_set_from(const uint64_t *ew, const uint64_t
         const uint64_t b = __ballot(v != 0);
         if (b) {
             const int l = __ffsll((unsigned long long)b) - 1;
-            const uint64_t vv = shfl_u64(v, l);
+            const uint64_t vv = readlane_u64(v, l);
             return (base + l) * 64 + (__ffsll((unsigned long long)vv) - 1);
         }
     }
@@ -78,22 +95,35 @@ __device__ __forceinline__ int first_set_from(const uint64_t *ew, const uint64_t
 }
 
 // first position in [start,end) with bit set in (ew&andmask) and
-// cnt >= 10 && cnt > thr   (MM.java:4925-4926)
+// cnt >= 10 && cnt > thr   (MM.java:4925-4926).  Four 64-pod groups per trip: their count loads are
+// independent, so a scan that has to walk several groups pays one memory latency per four groups.
 __device__ __forceinline__ int first_count_break(const uint64_t *ew, const uint64_t *andmask, int start,
                                                  int end, const int32_t *cnt, int32_t thr)
 {
     const int lane = lane_id();
     if (start >= end) return kNoPos;
     const int g1 = (end - 1) >> 6;
-    for (int g = start >> 6; g <= g1; g++) {
-        uint64_t word = ew[g];
-        if (andmask) word &= andmask[g];
-        word = clip_word(word, g, start, end);
-        if (word == 0) continue;  // wave-uniform
-        const int32_t c = cnt[g * 64 + lane];  // columns are padded to W*64
-        const bool hit = ((word >> lane) & 1ull) && c >= 10 && c > thr;
-        const uint64_t b = __ballot(hit);
-        if (b) return g * 64 + (__ffsll((unsigned long long)b) - 1);
+    for (int g = start >> 6; g <= g1; g += 4) {
+        uint64_t word[4];
+        int32_t c[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            word[j] = 0;
+            if (g + j <= g1) {
+                uint64_t w = ew[g + j];
+                if (andmask) w &= andmask[g + j];
+                word[j] = clip_word(w, g + j, start, end);
+            }
+        }
+        if ((word[0] | word[1] | word[2] | word[3]) == 0) continue;  // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 4; j++) c[j] = word[j] ? cnt[(g + j) * 64 + lane] : 0;  // columns are padded to W*64
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool hit = ((word[j] >> lane) & 1ull) && c[j] >= 10 && c[j] > thr;
+            const uint64_t b = __ballot(hit);
+            if (b) return (g + j) * 64 + (__ffsll((unsigned long long)b) - 1);
+        }
     }
     return kNoPos;
 }
@@ -139,7 +169,9 @@ struct RpmRule {
     }
 };
 
-// index-th set bit (in position order) over fw words [wlo, whi]
+// index-th set bit (in position order) over fw words [wlo, whi].  A shortlist is normally a few
+// words, so the non-empty words are visited one by one with scalar code (ballot + readlane); only a
+// trip with many non-empty words takes the wave-wide prefix scan.
 __device__ __forceinline__ int select_in_range(const uint64_t *fw, int wlo, int whi, int index)
 {
     const int lane = lane_id();
@@ -147,14 +179,26 @@ __device__ __forceinline__ int select_in_range(const uint64_t *fw, int wlo, int 
     for (int base = wlo; base <= whi; base += 64) {
         const int w = base + lane;
         const uint64_t v = (w <= whi) ? fw[w] : 0ull;
+        uint64_t nz = __ballot(v != 0);
+        if (__popcll((unsigned long long)nz) <= 8) {
+            while (nz) {
+                const int l = __ffsll((unsigned long long)nz) - 1;
+                nz &= nz - 1;
+                const uint64_t vv = readlane_u64(v, l);
+                const int c = __popcll((unsigned long long)vv);
+                if (index < running + c) return (base + l) * 64 + select_kth_bit(vv, index - running);
+                running += c;
+            }
+            continue;
+        }
         const int c = __popcll((unsigned long long)v);
         const int incl = wave_incl_scan_i32(c);
-        const int total = shfl_i32(incl, 63);
+        const int total = readlane_i32(incl, 63);
         if (index < running + total) {
             const uint64_t b = __ballot(running + incl > index);
             const int l = __ffsll((unsigned long long)b) - 1;
-            const uint64_t vv = shfl_u64(v, l);
-            const int before = running + shfl_i32(incl, l) - shfl_i32(c, l);
+            const uint64_t vv = readlane_u64(v, l);
+            const int before = running + readlane_i32(incl, l) - readlane_i32(c, l);
             return (base + l) * 64 + select_kth_bit(vv, index - before);
         }
         running += total;
@@ -191,6 +235,273 @@ __device__ __forceinline__ void stage_eligible(const Snap &S, const uint64_t *sr
         }
     }
     wave_sync();
+}
+
+// Follow request -> model row -> exclusion lists -> rank positions (one lane).
+__device__ __forceinline__ ResolvedReq resolve_one(const Snap &S, const PlaceArgs &A, int d)
+{
+    const mmp_place_req rq = A.reqs[d];
+    ResolvedReq r;
+    r.flags = rq.flags;
+    r.pick = rq.pick;
+    r.last_used = rq.last_used;
+    r.fresh_lru = rq.fresh_lru;
+    r.f_rem = remaining_of(rq.fresh_capacity, rq.fresh_used);
+    r.fresh_count = rq.fresh_count;
+    r.fresh_rpm = rq.fresh_rpm;
+    r.model = rq.model;
+    r.selfpos = (rq.self_pod >= 0 && rq.self_pod < S.P) ? S.pos_of[rq.self_pod] : -1;
+    r.pad[0] = r.pad[1] = 0;
+#pragma unroll
+    for (int i = 0; i < kInlineExcl; i++) r.excl_pos[i] = -1;
+    if (rq.model < 0 || rq.model >= A.n_models) {
+        r.type = -1;
+        r.n_excl = 0;
+    } else {
+        const mmp_model_row m = A.models[rq.model];
+        r.type = (m.type < 0 || m.type >= S.T) ? 0 : m.type;
+        const int32_t n_ents = m.n_loaded + m.n_failed;
+        r.n_excl = n_ents + rq.n_extra;
+        if (r.n_excl <= kInlineExcl) {
+#pragma unroll
+            for (int i = 0; i < kInlineExcl; i++) {
+                if (i < r.n_excl) {
+                    const int32_t pod = i < n_ents ? A.ent_pod[m.ent_off + i] : A.extra[rq.extra_off + i - n_ents];
+                    r.excl_pos[i] = (pod >= 0 && pod < S.P) ? S.pos_of[pod] : -1;
+                }
+            }
+        }
+    }
+    return r;
+}
+
+// ---- one LANE per decision -----------------------------------------------------------------------
+// SQ counters of the wave-per-decision kernel (profiles/r1): ~815 instructions per decision, almost
+// all of them wave-uniform control flow — the kernel is bound by instruction issue, not by memory.
+// A shortlist is a handful of 64-pod words, and every step of getNext on it is plain 64-bit word
+// arithmetic, so a single lane can carry a whole decision: 64 decisions per wavefront.  The one step
+// that needed a per-pod column, the count break (MM.java:4925-4926), reads a threshold bitmap built at
+// commit (Snap::ge) instead.  Decisions that leave the common shape — more than kInlineExcl exclusions,
+// the replaced-replica-set retry, a preferred pod behind a full one, preference with a full best
+// (case (b), per-candidate rpm), a count threshold beyond the bitmap rows — are handed, with their
+// resolved request, to the wave-per-decision kernel, which remains the general implementation.
+struct LaneWords {
+    const uint64_t *E;  // eligibility row of the type
+    int32_t ex[kInlineExcl];
+    uint64_t touched;   // bit (w & 63) set if some exclusion falls into a word congruent to w: the
+                        // shortlist words are rarely among them, and then the compares are skipped
+    __device__ __forceinline__ void set_touched()
+    {
+        touched = 0;
+#pragma unroll
+        for (int i = 0; i < kInlineExcl; i++)
+            if (ex[i] >= 0) touched |= 1ull << ((ex[i] >> 6) & 63);
+    }
+    __device__ __forceinline__ uint64_t at(int w) const
+    {
+        uint64_t v = E[w];
+        if ((touched >> (w & 63)) & 1ull) {
+#pragma unroll
+            for (int i = 0; i < kInlineExcl; i++)
+                if ((ex[i] >> 6) == w) v &= ~(1ull << (ex[i] & 63));  // ex[i] == -1 never matches
+        }
+        return v;
+    }
+};
+
+// first set bit of f(w) at a position in [start, stop); kNoPos if none
+template <class F>
+__device__ __forceinline__ int lane_first(F f, int start, int stop)
+{
+    if (start >= stop) return kNoPos;
+    const int w0 = start >> 6, wl = (stop - 1) >> 6;
+    for (int w = w0; w <= wl; w++) {
+        uint64_t v = f(w);
+        if (w == w0) v &= (~0ull) << (start & 63);
+        if (w == wl && (stop & 63)) v &= (1ull << (stop & 63)) - 1ull;
+        if (v) return w * 64 + (__ffsll((unsigned long long)v) - 1);
+    }
+    return kNoPos;
+}
+
+// Returns true when the decision has to go to the wave path; otherwise `o` is the result.
+__device__ __forceinline__ bool lane_decide(const Snap &S, const PlaceArgs &A, int d, mmp_place_out &o)
+{
+    const ResolvedReq r = resolve_one(S, A, d);
+    o.chosen = MMP_NONE;
+    o.best = -1;
+    o.n_candidates = 0;
+    o.hash = 0;
+    bool fb = false;
+    const int P = S.P, W = S.W;
+    do {
+        if (r.type < 0) break;  // unknown model -> null
+        if (r.n_excl > kInlineExcl || A.force_wave) {
+            fb = true;
+            break;
+        }
+        const int type = r.type;
+        LaneWords L;
+        L.E = S.elig + (size_t)type * W;
+#pragma unroll
+        for (int i = 0; i < kInlineExcl; i++) L.ex[i] = r.excl_pos[i];
+        L.set_touched();
+        auto ew = [&](int w) { return L.at(w); };
+        const int selfpos = r.selfpos;
+        const bool favour = (r.flags & MMP_REQ_FAVOUR_SELF) != 0;
+
+        const int best0 = lane_first(ew, 0, P);
+        if (best0 == kNoPos) {
+            if (S.any_rs) fb = true;  // retry ignoring excludeReplicaSets, MM.java:4797-4804
+            break;
+        }
+        const int64_t f_lru = r.fresh_lru, f_rem = r.f_rem;
+        const int32_t f_rpm = r.fresh_rpm;
+        const int64_t e_lru = S.lru[best0], e_rem = S.rem[best0];
+        const int32_t e_cnt = S.cnt[best0], e_rpm = S.rpm[best0];
+        bool us = best0 == selfpos;
+        int64_t b_lru = us ? f_lru : e_lru, b_rem = us ? f_rem : e_rem;
+        int32_t b_cnt = us ? r.fresh_count : e_cnt, b_rpm = us ? f_rpm : e_rpm;
+        const bool best_is_full = b_rem < S.min_space;  // :4811, never recomputed
+        const bool has_pm = S.has_pref[type] != 0;
+        const uint64_t *Pm = S.pref + (size_t)type * W;
+        int bestpos = best0;
+        if (has_pm && !((Pm[best0 >> 6] >> (best0 & 63)) & 1ull)) {
+            if (best_is_full) {  // case (b)
+                fb = true;
+                break;
+            }
+            // case (a): the first preferred pod, provided no full pod comes before it
+            auto ewp = [&](int w) { return L.at(w) & Pm[w]; };
+            const int q1 = lane_first(ewp, best0 + 1, P);
+            if (q1 == kNoPos) {  // none preferred: the replay list ends at the first full pod
+                fb = true;
+                break;
+            }
+            auto ewf = [&](int w) { return L.at(w) & S.fullw[w]; };
+            if (lane_first(ewf, best0 + 1, q1) != kNoPos) {
+                fb = true;
+                break;
+            }
+            bestpos = q1;
+            b_lru = S.lru[q1];
+            b_rem = S.rem[q1];
+            b_cnt = S.cnt[q1];
+            b_rpm = S.rpm[q1];
+            us = q1 == selfpos;
+        }
+        auto dw = [&](int w) {  // eligible ∧ (preference treated as required, :4905)
+            uint64_t v = L.at(w);
+            if (has_pm) v &= Pm[w];
+            return v;
+        };
+        const int32_t best_idx = S.orig[bestpos];
+        if (us && favour) {  // :4891-4895
+            o.chosen = MMP_SELF;
+            o.best = best_idx;
+            break;
+        }
+        const int64_t oldest = b_lru;
+        bool ns_break, self_break;
+        if (best_is_full) {
+            const int64_t rel = age_of(oldest, A.now) / 10;
+            const int64_t d1 = jsub64(f_lru, oldest), d2 = jsub64(e_lru, oldest);
+            ns_break = d1 > 45000LL && d1 > rel;  // :4913-4917
+            self_break = d2 > 45000LL && d2 > rel;
+        } else {
+            const int64_t q = b_rem >> 2;  // :4922
+            ns_break = f_rem < S.min_space || f_rem < q;
+            self_break = e_rem < S.min_space || e_rem < q;
+        }
+        const int start = bestpos + 1;
+        const bool self_in_d = selfpos >= start && selfpos < P && ((dw(selfpos >> 6) >> (selfpos & 63)) & 1ull);
+        int end = P;
+        if (ns_break) {
+            auto dns = [&](int w) {
+                uint64_t v = dw(w);
+                if ((selfpos >> 6) == w) v &= ~(1ull << (selfpos & 63));  // the self pod breaks on its own rule
+                return v;
+            };
+            const int p1 = lane_first(dns, start, P);
+            end = p1 < end ? p1 : end;
+        }
+        if (self_in_d && self_break) end = selfpos < end ? selfpos : end;
+        if (!best_is_full) {
+            const int32_t thr = (int32_t)((uint32_t)b_cnt + (uint32_t)(b_cnt >> 2));  // :4926
+            const int64_t T = thr < kGeBase - 1 ? (int64_t)kGeBase : (int64_t)thr + 1;  // count >= 10 && count > thr
+            if (T >= kGeBase + kGeRows) {
+                fb = true;
+                break;
+            }
+            const uint64_t *G = S.ge + (size_t)(T - kGeBase) * W;
+            auto dc = [&](int w) { return dw(w) & G[w]; };
+            const int pc = lane_first(dc, start, end);
+            end = pc < end ? pc : end;
+        }
+        const bool self_in_c = self_in_d && selfpos < end;
+        if (self_in_c && favour) {  // :4931-4933
+            o.chosen = MMP_SELF;
+            o.best = best_idx;
+            break;
+        }
+        // candidates = {best} ∪ D∩[start,end): count + hash
+        const int wlo = bestpos >> 6, whi = end > start ? (end - 1) >> 6 : wlo;
+        auto cand = [&](int w) {
+            uint64_t v = clip_word(dw(w), w, start, end);
+            if (w == wlo) v |= 1ull << (bestpos & 63);
+            return v;
+        };
+        int ccount = 0;
+        uint64_t hsum = 0;
+        for (int w = wlo; w <= whi; w++) {
+            const uint64_t v = cand(w);
+            ccount += __popcll((unsigned long long)v);
+            if (v) hsum += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)(w + 1)));
+        }
+        int remaining = ccount;
+        bool null0 = false, null_s = false, null_o = false;
+        if (ccount >= 2) {  // rpm filter, :4951-4980 (quirks B#2/B#3: three rpm classes)
+            const int n_others = ccount - 1 - (self_in_c ? 1 : 0);
+            int32_t mn = b_rpm;
+            if (self_in_c && e_rpm < mn) mn = e_rpm;
+            if (n_others > 0 && f_rpm < mn) mn = f_rpm;
+            RpmRule rule;
+            rule.init(age_of(r.last_used, A.now), mn);
+            null0 = rule.nulls(b_rpm);
+            null_s = self_in_c && rule.nulls(e_rpm);
+            null_o = n_others > 0 && rule.nulls(f_rpm);
+            remaining = ccount - (null0 ? 1 : 0) - (null_s ? 1 : 0) - (null_o ? n_others : 0);
+        }
+        const int index = remaining <= 1 ? 0 : (int)(((uint64_t)r.pick * (uint64_t)(uint32_t)remaining) >> 32);
+        int cpos = kNoPos;
+        if (remaining >= 1) {
+            const int bw = bestpos >> 6, sw = self_in_c ? (selfpos >> 6) : -1;
+            int running = 0;
+            for (int w = wlo; w <= whi; w++) {
+                uint64_t v = cand(w);
+                uint64_t special = 0;
+                if (w == bw) special |= 1ull << (bestpos & 63);
+                if (w == sw) special |= 1ull << (selfpos & 63);
+                if (null_o) v &= special;
+                if (null0 && w == bw) v &= ~(1ull << (bestpos & 63));
+                if (null_s && w == sw) v &= ~(1ull << (selfpos & 63));
+                const int c = __popcll((unsigned long long)v);
+                if (index < running + c) {
+                    cpos = w * 64 + select_kth_bit(v, index - running);
+                    break;
+                }
+                running += c;
+            }
+        }
+        o.best = best_idx;
+        o.n_candidates = ccount;
+        o.hash = (uint32_t)(hsum ^ (hsum >> 32)) ^ ((uint32_t)remaining * 0x9E3779B1u);
+        if (cpos != kNoPos) {
+            o.chosen = S.orig[cpos];
+            if (!favour && cpos == selfpos) o.chosen = MMP_SELF;  // :4989-4991
+        }
+    } while (false);
+    return fb;
 }
 
 __device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int d, uint64_t *ew, uint64_t *fw)
@@ -376,8 +687,11 @@ __device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int
         // candidates = {best} ∪ D∩[start,end)
         wlo = bestpos >> 6;
         whi = end > start ? (end - 1) >> 6 : wlo;
-        int cc = 0;
-        uint64_t h = 0;
+        // count + hash the shortlist words: the non-empty ones are normally one or two, visited with
+        // scalar code; a trip with many takes the wave-wide reductions
+        int cc = 0, cc_s = 0;
+        uint64_t h = 0, h_s = 0;
+        bool dense = false;
         for (int base = wlo; base <= whi; base += 64) {
             const int w = base + lane;
             uint64_t v = 0;
@@ -388,11 +702,27 @@ __device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int
                 if (w == wlo) v |= 1ull << (bestpos & 63);
                 fw[w] = v;
             }
-            cc += __popcll((unsigned long long)v);
-            if (v) h += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)(w + 1)));
+            uint64_t nz = __ballot(v != 0);
+            if (__popcll((unsigned long long)nz) <= 8) {
+                while (nz) {
+                    const int l = __ffsll((unsigned long long)nz) - 1;
+                    nz &= nz - 1;
+                    const uint64_t vv = readlane_u64(v, l);
+                    cc_s += __popcll((unsigned long long)vv);
+                    h_s += splitmix64(vv ^ (0x9E3779B97F4A7C15ull * (uint64_t)(base + l + 1)));
+                }
+            } else {
+                dense = true;
+                cc += __popcll((unsigned long long)v);
+                if (v) h += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)(w + 1)));
+            }
         }
-        ccount = wave_sum_i32(cc);
-        hsum = wave_sum_u64(h);
+        ccount = cc_s;
+        hsum = h_s;
+        if (dense) {
+            ccount += wave_sum_i32(cc);
+            hsum += wave_sum_u64(h);
+        }
         remaining = ccount;
         wave_sync();
         if (ccount >= 2) {
@@ -445,14 +775,34 @@ __device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int
 }
 
 // LDS per workgroup: kPlaceWaves × 2 bitmaps × Wpad words.
-__global__ __launch_bounds__(kPlaceWaves * 64) void place_batch_kernel(Snap S, PlaceArgs A, int32_t wpad)
+// The load-target kernel: 256 decisions per workgroup, one per lane (lane_decide); the decisions that
+// leave the common shape are collected in LDS and then taken one wavefront at a time by the general
+// path (place_one) inside the same launch.  LDS: kPlaceWaves × 2 bitmaps × wpad words for that path.
+constexpr int kPlaceBlock = kPlaceWaves * 64;
+__global__ __launch_bounds__(kPlaceBlock) void place_batch_kernel(Snap S, PlaceArgs A, int32_t wpad)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int32_t fb_list[kPlaceBlock];
+    __shared__ int32_t fb_n;
+    if (threadIdx.x == 0) fb_n = 0;
+    __syncthreads();
+    const int d = blockIdx.x * kPlaceBlock + threadIdx.x;
+    if (d < A.n) {
+        mmp_place_out o;
+        if (lane_decide(S, A, d, o))
+            fb_list[atomicAdd(&fb_n, 1)] = d;
+        else
+            A.outs[d] = o;
+    }
+    __syncthreads();
+    const int nfb = fb_n;
+    if (nfb == 0) return;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint64_t *ew = reinterpret_cast<uint64_t *>(smem) + (size_t)wave * 2 * wpad;
     uint64_t *fw = ew + wpad;
-    for (int d = blockIdx.x * kPlaceWaves + wave; d < A.n; d += gridDim.x * kPlaceWaves) {
-        place_one(S, A, d, ew, fw);
+    for (int i = wave; i < nfb; i += kPlaceWaves) {
+        const int fd = __builtin_amdgcn_readfirstlane(fb_list[i]);
+        place_one(S, A, fd, ew, fw);
         wave_sync();
     }
 }

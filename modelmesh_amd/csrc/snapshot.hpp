@@ -34,7 +34,13 @@ struct Snap {
     const uint64_t *pref;       // preferred instances
     const uint8_t *has_pref;    // [T] getPreferredInstances(type) != null
     const uint64_t *fullw;      // [W] isFull(row.remaining)
+    const uint64_t *ge;         // [kGeRows][W] row r: count >= kGeBase + r (the count break of MM.java:4925)
 };
+
+// count >= 10 is a fixed clause of the shortlist's count break (MM.java:4925-4926); the other clause,
+// count > bestCount + bestCount/4, makes the effective threshold max(10, that + 1).
+constexpr int kGeBase = 10;
+constexpr int kGeRows = 54;  // thresholds 10..63; a larger one falls back to the count column scan
 
 // Row staged in LDS by the rank kernel: exactly the fields PLACEMENT_ORDER reads.
 struct __attribute__((aligned(16))) RankRow {
@@ -199,6 +205,18 @@ __global__ void build_masks_kernel(const mmp_pod_row *__restrict__ pods, int32_t
         pref[(size_t)t * W + w] = bp;
         if (t == 0) fullw[w] = bf;
     }
+}
+
+// ge[r][w] = ballot over the 64 rank positions of word w of (count >= kGeBase + r): one wave per (r, w)
+__global__ void build_ge_kernel(const int32_t *__restrict__ cnt, int32_t P, int32_t W, uint64_t *__restrict__ ge)
+{
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= kGeRows * W) return;
+    const int r = wave / W, w = wave - r * W;
+    const int pos = w * 64 + lane;
+    const uint64_t b = __ballot(pos < P && cnt[pos] >= kGeBase + r);
+    if (lane == 0) ge[(size_t)r * W + w] = b;
 }
 
 // rs_bad[p] = pod p's replica set is in the replaced list (MM.java:4769-4770)

@@ -31,6 +31,20 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// Read lane `src` when `src` is wave-uniform (a ballot-derived index): v_readlane, no LDS crossbar trip.
+__device__ __forceinline__ int32_t readlane_i32(int32_t v, int src)
+{
+    return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src));
+}
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src)
+{
+    const int s = __builtin_amdgcn_readfirstlane(src);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, s);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), s);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ int32_t wave_sum_i32(int32_t v)
 {
 #pragma unroll

@@ -1,0 +1,18 @@
+#!/usr/bin/env python
+"""Median per-launch value of every counter rocprofv3 --pmc collected for one kernel.
+usage: tools/sq_summary.py <dir> <kernel-substring> [min_grid]"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+d, kernel = sys.argv[1:3]
+vals = collections.defaultdict(list)
+for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if kernel in r["Kernel_Name"]:
+            vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {k: sorted(v)[len(v) // 2] for k, v in vals.items()}
+out["launches"] = max((len(v) for v in vals.values()), default=0)
+print(json.dumps(out))
