@@ -186,3 +186,28 @@ def test_concurrent_single_decisions_batches_and_commits():
         assert not errors, errors[:5]
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("seed", [0, 5, 9])
+def test_general_wave_path_alone(seed, monkeypatch):
+    """The kernel gives each decision to one lane and keeps the wave-per-decision code for rare shapes;
+    MMP_FORCE_WAVE=1 (read at mmp_create) routes EVERY decision through that general path, so both
+    implementations of getNext are checked against the oracle on the same inputs."""
+    monkeypatch.setenv("MMP_FORCE_WAVE", "1")
+    for profile in (None, "full", "prefer"):
+        fleet = wl.fuzz_fleet(seed, pods=int(np.random.default_rng(seed).choice([65, 700, 5000])), profile=profile)
+        reqs, extra = wl.fuzz_requests(fleet, seed, 2500)
+        _check_fleet(fleet, reqs, extra)
+    fleet = wl.make_fleet("C2")
+    reqs, extra = wl.make_requests(fleet, 12)
+    _check_fleet(fleet, reqs, extra)
+
+
+def test_c4_1m_x_50k_sample():
+    """BASELINE config C4's fleet on one device: 50k pods (782 words per bitmap row), 1M models; 250k of
+    the 1M decisions are compared with the oracle to bound the CPU time."""
+    fleet = wl.make_fleet("C4")
+    reqs, extra = wl.make_requests(fleet, 14)
+    sel = np.arange(0, len(reqs), 4)
+    sub = reqs[sel].copy()
+    _check_fleet(fleet, sub, extra)
