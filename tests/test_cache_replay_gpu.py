@@ -159,3 +159,30 @@ def test_reference_kat_on_device():
         assert set(st["key"]) == set(range(1, 19)) | {_lib.UNLOADBUF_KEY}
     finally:
         s.close()
+
+
+def test_concurrent_eviction_kat_on_device():
+    """EvictionsModelMeshTest.concurrentEvictionTest (:136-200) as ONE replay call: 18 x 50 MiB loaded,
+    ten placeholders inserted together, then grown — exactly myModel0..9 are evicted, in that order."""
+    h = ob.CCache(131072, 9600, NOW)
+    s = Solver(100, 1000)
+    try:
+        s.load_caches_keyed(*_export([h]))
+        rows = []
+        t0 = NOW - 3_600_000
+        for m in range(18):
+            rows.append((0, _lib.COP_UBM_INSERT_NEW_ENTRY, m, 1, t0 + 10 * m, 0, 0))
+            rows.append((0, _lib.COP_UBM_ADJUST_SPACE_REQUEST, m, 6399, 0, 0, 0))
+            rows.append((0, _lib.COP_UBM_CLAIM_SPACE, 0, 6400, 0, 0, 0))
+        for m in range(18, 28):
+            rows.append((0, _lib.COP_UBM_INSERT_NEW_ENTRY, m, 1, t0 + 1000 + m, 0, 0))
+        for m in range(18, 28):
+            rows.append((0, _lib.COP_UBM_ADJUST_SPACE_REQUEST, m, 6399, 0, 0, 0))
+        outs, ev = s.cache_replay(np.array(rows, dtype=_lib.CACHE_OP), NOW)
+        evicted = [int(k) for o in outs for k in ev[o["evicted_off"]: o["evicted_off"] + o["n_evicted"]]]
+        assert evicted == list(range(10))
+        assert all(outs[i]["result"] == 1 for i in range(2, 54, 3))  # every claim of the first 18 succeeded
+        st = s.cache_read(0)
+        assert sorted(int(k) for k in st["key"] if k != _lib.UNLOADBUF_KEY) == list(range(10, 28))
+    finally:
+        s.close()

@@ -217,3 +217,24 @@ def test_min_space_units_kat():
     assert lib.orc_min_space_units(6400, 8, 8_388_608, 1) == 51200
     assert lib.orc_min_space_units(6400, 8, 8_388_608, 0) == 51200
     assert lib.orc_min_space_units(6400, 1, 131072, 0) == 6400
+
+
+@pytest.mark.parametrize("driver", [PyDriver, CDriver])
+def test_concurrent_eviction_kat(driver):
+    """EvictionsModelMeshTest.concurrentEvictionTest (:136-200): 18 x 50 MiB loaded in the 1 GiB cache,
+    then 10 registrations at the same instant (unloads take 1 s, so none completes meanwhile): exactly the
+    10 oldest are evicted — no eviction cascade — and myModel10..17 plus the 10 new ones stay."""
+    cap = 131072
+    d = driver(cap, 9600)
+    t0 = NOW - HOUR
+    for i in range(18):
+        assert load_model(d, i, 6400, t0 + 10 * i)
+    assert d.evicted() == []
+    # the ten placeholders go in together (insertNewEntry, weight 1), then each grows to its
+    # predicted size (adjustNewEntrySpaceRequest) before any unload has completed
+    for i in range(10):
+        d.insert(18 + i, t0 + 1000 + i)
+    for i in range(10):
+        d.grow(18 + i, 6399)
+    assert d.evicted() == list(range(10))
+    assert sorted(d.keys()) == list(range(10, 28))

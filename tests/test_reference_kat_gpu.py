@@ -1,0 +1,168 @@
+"""Known answers the reference's own integration tests hold for this path, replayed
+through the C ABI on the GPU and through the oracle:
+* ModelMeshEvictionsTest.testSecondCopyTrigger (:411-447, Appendix C.3)
+* ModelMeshLoadFailureTest.testLoadFailure (:432-492): failed instances are not tried again and the
+  attempts stop at MAX_LOAD_FAILURES
+* ModelMeshLoadFailureTest.testModelMigration (:222-252) / ModelMeshTearDownTest.testDestroyNode
+  (:116-170): models of stopped / killed instances end up on, and are routed to, live instances only."""
+import numpy as np
+import pytest
+
+from modelmesh_amd import _lib
+from modelmesh_amd import workload as wl
+from modelmesh_amd.solver import Fleet, Solver
+from oracle import bind as ob
+
+pytestmark = pytest.mark.gpu
+NOW = wl.NOW_MS
+
+
+def _small_fleet(n_pods, n_models, copies=None, now=NOW):
+    rows = np.zeros(n_pods, dtype=wl.POD_ROW)
+    rows["capacity"], rows["used"] = 131072, 6400 * 2
+    rows["count"], rows["lru_time"] = 2, now - 3_600_000 - np.arange(n_pods)
+    rows["loading_threads"], rows["version"] = 8, 1
+    rows["id_order"] = np.arange(n_pods, dtype=np.uint32)
+    rows["flags"] = wl.POD_LIVE
+    copies = copies or [[] for _ in range(n_models)]
+    models = np.zeros(n_models, dtype=wl.MODEL_ROW)
+    ent = []
+    for i, c in enumerate(copies):
+        models["ent_off"][i], models["n_loaded"][i] = len(ent), len(c)
+        ent += sorted(c)
+    models["last_used"] = now - 60_000
+    return Fleet(pods=rows, models=models, ent_pod=np.array(ent, np.int32), ent_time=np.full(len(ent), now - 600_000, np.int64),
+                 min_space_units=6553, min_churn_age_ms=600_000, now=now)
+
+
+def test_second_copy_trigger_kat():
+    """Rate-check every 100 ms, second-copy window [4 s, 10 s] -> [40, 100] iterations (test setup
+    :97-103); uses at t = 0.06, 1.06, 12.56, 17.56 s -> copies 1, 1, 1, 2: only the last use has an
+    earlier use inside the window (MM.java:5726-5758)."""
+    fleet = _small_fleet(3, 1, copies=[[0]])
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        uses_ms = [60, 1060, 12_560, 17_560]
+        i1 = i2 = -(2**31)  # CacheEntry fields start at Integer.MIN_VALUE (MM.java:1648)
+        triggered_at = []
+        t_start, last_use = NOW, 0
+        for it in range(1, 200):
+            now, last = t_start + 100 * it, t_start + 100 * (it - 1)
+            used = [u for u in uses_ms if last - t_start < u <= now - t_start]
+            if not used:
+                continue  # usedSinceLastRun is empty: the task returns (:5667), the counter still advances
+            e = np.zeros(1, dtype=_lib.CACHE_ENTRY)
+            e["model"], e["weight"], e["last_used"], e["interval_count"] = 0, 6400, t_start + used[-1], len(used)
+            e["earlier_use_iteration"], e["last_used_iteration"] = i1, i2
+            sp = np.zeros(1, dtype=_lib.SCALEUP_PARAMS)
+            sp["self_pod"], sp["iteration_counter"] = 0, it
+            sp["second_copy_max_age_iters"], sp["second_copy_min_age_iters"] = 100, 40
+            sp["scale_up_rpm_threshold"], sp["our_rpm"] = 100_000, 10
+            sp["now"], sp["last_check_time"], sp["rate_check_interval_ms"] = now, last, 100
+            sp["second_copy_lru_threshold_ms"], sp["assume_completed_ms"] = 21_600_000, 3_000
+            got, _, sk = s.scaleup_plan(e, sp)
+            want, _, wsk = ob.scaleup_plan(fleet, e, sp.view(ob.ORC_SCALEUP_PARAMS))
+            assert sk == wsk == 0
+            for f in ("action", "copies", "timestamp", "new_i1", "new_i2"):
+                assert got[f][0] == want[f][0], (it, f)
+            i1, i2 = int(got["new_i1"][0]), int(got["new_i2"][0])
+            if got["action"][0] == _lib.MMP_NONE + 2:  # MMP_SCALE_SECOND_COPY == 1
+                triggered_at.append(used[-1])
+        assert triggered_at == [17_560]
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("cluster", [2, 3, 5, 8])
+def test_load_failure_cap_kat(cluster):
+    """Every instance fails the load: each attempt picks an instance that has not failed yet, and the
+    attempts stop once MAX_LOAD_FAILURES (3) are recorded or every instance has failed
+    (ModelMeshLoadFailureTest.java:481-488)."""
+    fleet = _small_fleet(cluster, 1)
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    failed = []
+    try:
+        for attempt in range(10):
+            fleet.models["n_failed"][0] = len(failed)
+            fleet.ent_pod = np.array(sorted(failed), np.int32)
+            fleet.ent_time = np.full(len(failed), NOW - 1000, np.int64)
+            s.load_fleet(fleet)
+            g = np.zeros(1, dtype=_lib.GATE_REQ)
+            g["model"], g["self_pod"] = 0, 0
+            bits = int(s.gates(g, np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros(0, np.int32), NOW)[0]["bits"])
+            if bits & _lib.GATE_FAILURES_BREACHED:
+                break
+            r = np.zeros(1, dtype=wl.PLACE_REQ)
+            r["model"], r["self_pod"], r["pick"] = 0, 0, 12345 * (attempt + 1)
+            sp = fleet.pods[0]
+            r["fresh_lru"], r["fresh_capacity"], r["fresh_used"], r["fresh_count"] = sp["lru_time"], sp["capacity"], sp["used"], sp["count"]
+            got = s.place(r, None, NOW)
+            want = ob.OracleFleet(fleet).place(r, None, NOW)
+            assert got["chosen"][0] == want["chosen"][0]
+            ch = int(got["chosen"][0])
+            if ch == -1:
+                break  # nowhere left
+            pod = 0 if ch == -2 else ch
+            assert pod not in failed
+            failed.append(pod)
+        assert len(failed) == min(cluster, 3)
+    finally:
+        s.close()
+
+
+def test_model_migration_and_destroyed_node_kat():
+    """5 instances, 10 models; 3 instances are asked to shut down one after the other: every model they
+    hold is re-placed (preShutdown -> triggerNewModelCopyElsewhere, MM.java:6913-6928, 6959-7147) and
+    all 10 stay loaded on live instances (testModelMigration); requests for models of a killed instance
+    are routed to a live copy or re-loaded on a live instance (testDestroyNode)."""
+    P, M = 5, 10
+    copies = [[m % P] for m in range(M)]
+    fleet = _small_fleet(P, M, copies)
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        for down in (0, 1, 2):
+            s.load_fleet(fleet)
+            mine = [m for m in range(M) if down in copies[m]]
+            e = np.zeros(len(mine), dtype=_lib.CACHE_ENTRY)
+            e["model"], e["weight"], e["last_used"] = mine, 6400, NOW - 30_000 - np.arange(len(mine))
+            act, wait = s.migration_plan(e, down, NOW)
+            wact, wwait = ob.migration_plan(fleet, e, down, NOW)
+            assert np.array_equal(act, wact) and np.array_equal(wait, wwait)
+            assert act.all() and wait.all()  # single copies used within the hour: migrate and wait
+            r = np.zeros(len(mine), dtype=wl.PLACE_REQ)
+            r["model"], r["self_pod"], r["flags"] = mine, down, 1
+            r["last_used"], r["pick"] = e["last_used"], np.arange(len(mine)) * 999_983
+            r["extra_off"], r["n_extra"] = 0, 1  # excludes = current holders ∪ self
+            sp = fleet.pods[down]
+            r["fresh_lru"], r["fresh_capacity"], r["fresh_used"], r["fresh_count"] = sp["lru_time"], sp["capacity"], sp["used"], sp["count"]
+            extra = np.array([down], np.int32)
+            got = s.place(r, extra, NOW)
+            want = ob.OracleFleet(fleet).place(r, extra, NOW)
+            assert np.array_equal(got["chosen"], want["chosen"])
+            for m, ch in zip(mine, got["chosen"]):
+                assert ch >= 0 and ch != down and not (fleet.pods["flags"][ch] & wl.POD_SHUTTING_DOWN)
+                copies[m] = [int(ch)]
+            fleet.pods["flags"][down] = wl.POD_SHUTTING_DOWN  # record republished with shutdown=true
+            fleet = _small_fleet(P, M, copies)
+            fleet.pods["flags"][: down + 1] = wl.POD_SHUTTING_DOWN
+        assert all(c[0] in (3, 4) for c in copies)
+        # a node dies without warning: its record is still in the table but it left the litelinks registry
+        fleet.pods["flags"][3] = 0
+        s.load_fleet(fleet)
+        sr = np.zeros(M, dtype=_lib.SERVE_REQ)
+        sr["model"], sr["self_pod"], sr["assume_completed_ms"] = np.arange(M), 4, 3_000
+        served = s.serve(sr, np.zeros(P, np.int32), np.zeros(P, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int64), NOW)
+        for m in range(M):
+            if copies[m] == [3]:
+                assert served["chosen"][m] == -1  # cache miss ...
+                r = np.zeros(1, dtype=wl.PLACE_REQ)
+                r["model"], r["self_pod"] = m, 4
+                sp = fleet.pods[4]
+                r["fresh_lru"], r["fresh_capacity"], r["fresh_used"], r["fresh_count"] = sp["lru_time"], sp["capacity"], sp["used"], sp["count"]
+                ch = int(s.place(r, None, NOW)["chosen"][0])
+                assert ch in (4, -2)  # ... and the only live instance left loads it
+            else:
+                assert served["chosen"][m] in (4, -2)
+    finally:
+        s.close()
