@@ -179,6 +179,9 @@ def main():
     ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pod-axis", action="store_true", help="skip the pod-axis sharded leg")
+    ap.add_argument("--streams", type=int, default=8,
+                    help="HIP streams the timed steps are issued on round-robin (a 100k-decision batch is 1564 "
+                         "wavefronts — too few to cover HBM latency on 256 CUs — so independent batches overlap)")
     ap.add_argument("--kernel-only", action="store_true",
                     help="skip the n=1 latency / host-boundary legs (used under rocprofv3 so that every "
                          "place_batch_kernel dispatch in the trace is a full batch)")
@@ -221,15 +224,18 @@ def main():
     d_outs = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev)
 
-    # bind the C call once: at ~10 us of GPU work per step the ctypes argument marshalling would
+    # bind the C calls once: at ~10 us of GPU work per step the ctypes argument marshalling would
     # otherwise be what is measured
     import ctypes as C
     _fn = solver.lib.mmp_place_batch_dev
-    _args = (solver.h, C.c_void_p(d_reqs.data_ptr()), C.c_int32(n), C.c_void_p(d_extra.data_ptr()), C.c_int64(fleet.now),
-             C.c_void_p(d_outs.data_ptr()), C.c_void_p(stream.cuda_stream))
+    n_streams = max(1, args.streams)
+    streams = [stream] + [torch.cuda.Stream(dev) for _ in range(n_streams - 1)]
+    outs_bufs = [d_outs] + [torch.zeros(n * 16, dtype=torch.uint8, device=dev) for _ in range(n_streams - 1)]
+    _args = [(solver.h, C.c_void_p(d_reqs.data_ptr()), C.c_int32(n), C.c_void_p(d_extra.data_ptr()), C.c_int64(fleet.now),
+              C.c_void_p(o.data_ptr()), C.c_void_p(st.cuda_stream)) for st, o in zip(streams, outs_bufs)]
 
-    def step():
-        if _fn(*_args) != 0:
+    def step(i=0):
+        if _fn(*_args[i % n_streams]) != 0:
             raise RuntimeError(solver.lib.mmp_last_error(solver.h))
 
     def fence():
@@ -238,27 +244,30 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     fence()
-    # timed region: exactly K steps, one HIP event pair around the whole region (GPU time per step
-    # including launch gaps) ...
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # timed region: exactly K steps (independent batches, issued round-robin on the streams)
     t0 = time.perf_counter()
-    ev0.record(stream)
     for i in range(args.steps):
-        step()
-    ev1.record(stream)
+        step(i)
     fence()
     elapsed = time.perf_counter() - t0
+    # the kernel's own launch duration: K back-to-back launches on ONE stream between a HIP event pair
+    # (region time / K is what rocprofv3 --kernel-trace reports as the kernel's average duration) ...
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(stream)
+    for i in range(args.steps):
+        step(0)
+    ev1.record(stream)
+    fence()
     gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps
-    # ... and the kernel's own launch duration: an event pair around every launch of a second pass over
-    # the same K steps (what rocprofv3 --kernel-trace reports as the kernel's average duration)
+    # ... and an event pair around every single launch (adds ~2 us of event granularity)
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     for i in range(args.steps):
         starts[i].record(stream)
-        step()
+        step(0)
         ends[i].record(stream)
     fence()
     kern_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
@@ -303,7 +312,8 @@ def main():
             "vs_baseline": None, "dtype": "i64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {fleet.n_models} models x {fleet.n_pods} pods, one load-target "
                                    "decision per model per step (SURVEY.md §8d synthetic fleet)",
-                       "decisions_per_step_per_gpu": n, "sharding": "model axis, no collective"},
+                       "decisions_per_step_per_gpu": n, "sharding": "model axis, no collective",
+                       "streams": n_streams},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload),
                          "kernel": "place_batch_kernel", "kernel_ms": gpu_ms_per_step,
@@ -313,6 +323,12 @@ def main():
                                  "reference's full scan), so frac >> 1 only says that scan is not performed; the "
                                  "kernel's own compulsory traffic is kernel_bytes_per_launch (frac_kernel = that / "
                                  "kernel time / peak) and `traffic` is the rocprofv3 FETCH_SIZE+WRITE_SIZE measurement",
+                         "measured_traffic_rate_single_stream_GBs":
+                             None if measured_traffic(args.workload) is None else
+                             measured_traffic(args.workload) / (gpu_ms_per_step * 1e-3) / 1e9,
+                         "measured_traffic_rate_timed_region_GBs":
+                             None if measured_traffic(args.workload) is None else
+                             measured_traffic(args.workload) * args.steps / elapsed / 1e9,
                          "kernel_bytes_per_launch": kb,
                          "frac_kernel": kb / (gpu_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "parity_vs_oracle": parity,
