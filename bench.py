@@ -171,6 +171,147 @@ def churn_leg(fleet, solver, slices: int = 8, events: int = 20_000):
             "required_events_per_s": 10_000, "headroom_x": n_ev / busy / 10_000}
 
 
+def secondary_kernels_leg(fleet, solver, device: int, reps: int = 5):
+    """Every other kernel of the path on C3-sized inputs: device
+    time from the library's own HIP-event bracket around the kernels of one host-pointer call
+    (mmp_profile / mmp_last_kernel_ms: events on the stream the kernels are launched on), median of
+    `reps` calls, against the algorithmic bytes of SURVEY.md §8(d) / DESIGN.md §4."""
+    from modelmesh_amd import _lib
+    from modelmesh_amd import wire
+    from modelmesh_amd import workload as wl
+    from modelmesh_amd.solver import Solver
+    rng = np.random.Generator(np.random.PCG64(0x5EC0))
+    P, M, now = fleet.n_pods, fleet.n_models, fleet.now
+    m = fleet.models
+    k_of = (m["n_loaded"] + m["n_failed"]).astype(np.int64)
+    out = []
+
+    def timed(name, fn, alg_bytes, units, unit_name, note=None, s=solver):
+        ms = []
+        for i in range(reps + 1):
+            fn()
+            if i:
+                ms.append(s.last_kernel_ms())
+        t = float(np.median(ms))
+        row = {"kernel": name, "kernel_ms": t, "units": int(units), "unit": unit_name,
+               "units_per_s": units / (t * 1e-3) if t > 0 else None}
+        if alg_bytes is not None:
+            row["algorithmic_bytes"] = int(alg_bytes)
+            row["achieved_GBs"] = alg_bytes / (t * 1e-3) / 1e9 if t > 0 else None
+            row["frac_hbm_peak"] = row["achieved_GBs"] / HBM_PEAK_GBS if t > 0 else None
+        if note:
+            row["note"] = note
+        out.append(row)
+
+    solver.load_fleet(fleet)  # the churn leg left its own fleet in the context
+    solver.profile(True)
+    try:
+        # a5 / a4: commit = rank (all pairs, literal comparator) + scatter + bitmaps + stats
+        timed("snapshot_commit (rank_pods + scatter + build_ge + build_masks + cluster_stats)", solver.commit,
+              None, P * P, "comparator evaluations", "VALU bound: P^2 literal PLACEMENT_ORDER comparisons, 64*P bytes in")
+
+        # a12 stateless eviction evaluations over one clhm deque per pod
+        cs = wl.ChurnStream(fleet, 0xC5)
+        solver.load_caches(cs.seg_off, cs.cache_lu, cs.cache_wt, cs.cache_cap)
+        n = 100_000
+        ev = np.zeros(n, dtype=_lib.EVICT_REQ)
+        ev["cache"] = rng.integers(0, P, n)
+        ev["weight"] = np.minimum(cs.size_units[rng.integers(0, M, n)], 2**31 - 1)
+        ev["last_used"] = np.where(rng.random(n) < 0.7, 0, now - rng.integers(1, 7_200_000, n))
+        e_of = np.diff(cs.seg_off).astype(np.int64)[ev["cache"]]
+        timed("evict_batch_kernel", lambda: solver.evict(ev, now), int((12 * e_of + 16).sum()), n,
+              "eviction evaluations", "SURVEY 8(d): 12*E + 16 bytes per evaluation; the deques (2.4 MB) are L2 resident")
+
+        # a9 serve-target decisions
+        sr = np.zeros(n, dtype=_lib.SERVE_REQ)
+        sr["model"] = rng.integers(0, M, n)
+        sr["self_pod"] = rng.integers(0, P, n)
+        sr["flags"] = rng.integers(0, 4, n)
+        sr["local_in_flight"] = rng.integers(0, 3, n)
+        sr["last_invoke_time"] = now - rng.choice([0, 10, 1000], n)
+        sr["assume_completed_ms"] = 3000
+        in_use = rng.integers(0, 3, P).astype(np.int32)
+        last_used = (now - rng.integers(0, 10_000, P)).astype(np.int64)
+        kk = m["n_loaded"][sr["model"]].astype(np.int64)
+        z32, z64 = np.zeros(0, np.int32), np.zeros(0, np.int64)
+        timed("serve_batch_kernel", lambda: solver.serve(sr, in_use, last_used, z32, z64, now),
+              int((40 + 16 + 24 + 24 * kk).sum()), n, "serve-target decisions",
+              "request 40 B + model row 24 B + (entry 12 B + inUse/lastUsed 12 B) per copy + result 16 B")
+
+        # a10 / a11 / a14 / a20 request guards
+        g = np.zeros(n, dtype=_lib.GATE_REQ)
+        g["model"] = rng.integers(0, M, n)
+        g["self_pod"] = rng.integers(0, P, n)
+        g["flags"] = rng.integers(0, 512, n)
+        g["size_hint"] = rng.choice([0, 6400], n)
+        g["cache_capacity"] = 8_388_608
+        g["cache_weighted_size"] = rng.integers(0, 8_388_608, n)
+        g["cache_oldest_time"] = now - rng.integers(1, 5_000_000, n)
+        g["loader_predicted"] = 6400
+        g["loading_count"] = rng.integers(0, 20, n)
+        g["weight_predict_cutoff"] = 10
+        g["loaded_time"] = now - rng.integers(1, 5_000_000, n)
+        g["load_timeout_ms"] = 90_000
+        cur = fleet.pods[g["self_pod"]]
+        for a, b in (("fresh_lru", "lru_time"), ("fresh_capacity", "capacity"), ("fresh_used", "used"),
+                     ("fresh_count", "count"), ("fresh_loading_threads", "loading_threads"),
+                     ("fresh_in_progress", "loading_in_progress"), ("fresh_rpm", "rpm")):
+            g[a] = cur[b]
+        g["last_published"] = now - rng.integers(500, 170_000, n)
+        timed("gate_batch_kernel", lambda: solver.gates(g, z32, z64, z32, now),
+              int((144 + 8 + 24 + 12 * k_of[g["model"]]).sum()), n, "guarded requests",
+              "request 144 B + model row 24 B + 12 B per entry + result 8 B")
+
+        # a17 leader proactive-load plan over the whole registry
+        timed("proactive_plan (space reduction + compaction + radix sort + distinct top-K)",
+              lambda: solver.proactive_plan(6400, now, 4096), 24 * M, M, "registry rows scanned",
+              "device span incl. one host round trip for the qualified count; bytes = one pass over the model rows")
+
+        # a12 + a13 stateful keyed caches: one clhm put + one read per cache (10k caches)
+        keys = np.concatenate([np.arange(c, dtype=np.int32) for c in np.diff(cs.seg_off)]) if len(cs.cache_lu) else z32
+        e_cache = np.diff(cs.seg_off).astype(np.int64)
+        ops = np.zeros(2 * P, dtype=_lib.CACHE_OP)
+        ops["cache"] = np.repeat(np.arange(P, dtype=np.int32), 2)
+        ops["op"] = np.tile([_lib.COP_PUT_IF_ABSENT, _lib.COP_GET], P)
+        ops["key"] = np.where(ops["op"] == _lib.COP_PUT_IF_ABSENT, 1_000_000, 0)
+        ops["arg"] = 6400
+        ops["time"] = 0
+
+        def replay():
+            # same starting state every repetition (the replay mutates the caches)
+            solver.load_caches_keyed(cs.seg_off, cs.cache_lu, cs.cache_wt, keys, cs.cache_cap)
+            solver.cache_replay(ops, now)
+        timed("cache_replay_kernel", replay, int((32 * e_cache + 16).sum() + 64 * len(ops)), len(ops),
+              "cache operations", "16 B per deque entry read + 16 B written, 32 B per operation in + 32 B out")
+
+        # f-1 KV wire format: Jackson JSON of the instance table and of the registry, parsed on device
+        ids = wire.make_ids(rng, P)
+        wf = wl.make_fleet("C3", models=min(M, 20_000))  # registry sample: the JSON is generated in Python
+        wire.adopt_ids(wf, ids)
+        pv = wire.pod_values(wf, rng, np.full(P, now - 1000, np.int64))
+        mv = wire.model_values(wf, ids, ["NLCLASSIFIER"] + ["type-%d" % t for t in range(1, max(wf.n_types, 1))], rng,
+                               np.zeros(wf.n_models, np.int64))
+        js = Solver(wf.min_space_units, wf.min_churn_age_ms, device=device)  # a context of its own: ids replace the table
+        try:
+            js.load_pod_ids(ids)
+            js.profile(True)
+            live = np.ones(P, np.uint8)
+            pb = sum(len(v) for v in pv)
+            timed("ingest_pods_kernel", lambda: js.ingest_pods_json(pv, np.arange(P, dtype=np.int32), live),
+                  pb + 64 * P, pb, "JSON bytes", "InstanceRecord JSON read once + 64 B row written", s=js)
+            js.load_type_names(["NLCLASSIFIER"] + ["type-%d" % t for t in range(1, max(wf.n_types, 1))], 0)
+            mb = sum(len(v) for v in mv)
+            timed("ingest_models_kernel<count> + offsets + <fill>", lambda: js.ingest_models_json(mv),
+                  2 * mb + 24 * wf.n_models + 12 * len(wf.ent_pod), mb, "JSON bytes",
+                  "ModelRecord JSON read twice (count pass, fill pass) + CSR registry written; "
+                  f"{wf.n_models} of the {M} registry values", s=js)
+        finally:
+            js.close()
+    finally:
+        solver.profile(False)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,6 +320,7 @@ def main():
     ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pod-axis", action="store_true", help="skip the pod-axis sharded leg")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the per-kernel leg (evict / serve / gates / ...)")
     ap.add_argument("--streams", type=int, default=8,
                     help="HIP streams the timed steps are issued on round-robin (a 100k-decision batch is 1564 "
                          "wavefronts — too few to cover HBM latency on 256 CUs — so independent batches overlap)")
@@ -357,6 +499,11 @@ def main():
                 line["churn"] = churn_leg(fleet, solver)
             except Exception as e:
                 line["churn"] = {"error": f"{type(e).__name__}: {e}"}
+        if not args.kernel_only and not args.no_secondary:
+            try:
+                line["kernels"] = secondary_kernels_leg(fleet, solver, local_rank)
+            except Exception as e:
+                line["kernels"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline and not args.kernel_only:
             line["cpu_baseline"] = cpu_baseline(fleet, reqs, extra)
         print(json.dumps(line), flush=True)

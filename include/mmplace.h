@@ -505,6 +505,13 @@ int mmp_shard_place_phase_dev(mmp_ctx *ctx, int32_t phase, const void *d_reqs, i
 /* Wait for everything queued on the context's own stream. */
 int mmp_sync(mmp_ctx *ctx);
 
+/* Operator metrics (the role of ModelMesh's Metrics timers around these decisions, Metrics.java):
+ * with profiling enabled every host-pointer entry point brackets its kernels (not its staging copies)
+ * with HIP events on the context's stream; mmp_last_kernel_ms returns the device time of the most
+ * recent such call, or a negative value if none was recorded. */
+int mmp_profile(mmp_ctx *ctx, int enable);
+double mmp_last_kernel_ms(mmp_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,50 @@ final class MmPlace {
     static native int serveBatch(long h, ByteBuffer reqs, int n, ByteBuffer inUse, ByteBuffer lastUsed,
                                  ByteBuffer exclPod, ByteBuffer exclTime, int nExcl, long nowMs, ByteBuffer outs);
     static native int clusterStats(long h, ByteBuffer out);
+    // eviction (clhm) and the unload-buffer manager
+    static native int cachesLoad(long h, int nCaches, ByteBuffer segOff, ByteBuffer lastUsed, ByteBuffer weight,
+                                 ByteBuffer capacity);
+    static native int evictBatch(long h, ByteBuffer reqs, int n, long nowMs, ByteBuffer outs);
+    static native int cachesLoadKeyed(long h, int nCaches, ByteBuffer segOff, ByteBuffer lastUsed, ByteBuffer weight,
+                                      ByteBuffer key, ByteBuffer capacity, ByteBuffer ubm);
+    static native int cacheReplay(long h, ByteBuffer ops, int nOps, long nowMs, ByteBuffer outs, ByteBuffer evictedKeys,
+                                  int maxEvicted, ByteBuffer nEvictedSlots);
+    static native int cacheRead(long h, int cache, int maxEntries, ByteBuffer lastUsed, ByteBuffer weight, ByteBuffer key,
+                                ByteBuffer scalars, ByteBuffer ubm);
+    // request guards and rebalancer plans
+    static native int gateBatch(long h, ByteBuffer reqs, int n, ByteBuffer exclPod, ByteBuffer exclTime, int nExcl,
+                                ByteBuffer explicitPool, int nExplicit, long nowMs, long inUseFailureExpiryMs,
+                                ByteBuffer outs);
+    static native int proactivePlan(long h, int defaultModelSizeUnits, long nowMs, int maxOut, ByteBuffer outModel,
+                                    ByteBuffer outLastUsed, ByteBuffer info);
+    static native int scaleupPlan(long h, ByteBuffer entries, int n, ByteBuffer params, ByteBuffer outs,
+                                  ByteBuffer overloadedOut, ByteBuffer skipped);
+    static native int scaledownPlan(long h, ByteBuffer entries, int n, ByteBuffer params, ByteBuffer removedOut);
+    static native int migrationPlan(long h, ByteBuffer entries, int n, int selfPod, long nowMs, long cutoffAgeMs,
+                                    ByteBuffer actionOut, ByteBuffer waitOut);
+    // type constraints, upgrade tracker
+    static native int typesFromLabels(long h, int nTypes, ByteBuffer required, ByteBuffer preferred, ByteBuffer podLabels,
+                                      ByteBuffer allowedOut, ByteBuffer preferOut, ByteBuffer hasAllowedOut,
+                                      ByteBuffer hasPreferOut);
+    static native int upgradeInstanceAdded(long h, long labelsKey, int replicaSet, long startTime, long nowMs);
+    static native int upgradeInstanceRemoved(long h, long labelsKey, int replicaSet, long nowMs);
+    static native int upgradeHousekeeping(long h, long nowMs);
+    static native int upgradeReplaced(long h, ByteBuffer rsOut, ByteBuffer expiryOut, int max, ByteBuffer nOut);
+    // KV wire format (the raw values of the KV events)
+    static native int podIdsLoad(long h, ByteBuffer ids, ByteBuffer idOff, int nPods, ByteBuffer idOrderOut,
+                                 ByteBuffer replicaSetOut);
+    static native int podsIngestJson(long h, ByteBuffer json, ByteBuffer off, int n, ByteBuffer podIdx, ByteBuffer live,
+                                     ByteBuffer startTimeOut, ByteBuffer statusOut);
+    static native int typeNamesLoad(long h, ByteBuffer names, ByteBuffer nameOff, int nTypes, int unknownType);
+    static native int modelsIngestJson(long h, ByteBuffer json, ByteBuffer off, int nModels, ByteBuffer lastUnloadOut,
+                                       ByteBuffer statusOut);
+    // misc
+    static native long minSpaceUnits(int defaultModelSizeUnits, int loadingThreads, long capacityUnits,
+                                     boolean haveUnloadManager);
+    static native int getOrder(long h, ByteBuffer orderOut, ByteBuffer nOut);
+    static native int profile(long h, boolean enable);
+    static native double lastKernelMs(long h);
+    static native int abiVersion();
     static final int NONE = -1, SELF = -2;
 }
 

@@ -1,9 +1,10 @@
 // mmplace_jni.cc — thin JNI veneer over include/mmplace.h for the Java mesh.
 //
-// NOT built in this repository's image (there is no JDK / jni.h here); it is the
-// file a ModelMesh maintainer compiles next to libmmplace.so:
-//   g++ -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../include \
-//       mmplace_jni.cc -L../modelmesh_amd/lib -lmmplace -o libmmplace_jni.so
+// This repository's image has no JDK / jni.h, so the shipped build does not include it; it is the
+// file a ModelMesh maintainer compiles next to libmmplace.so (tests/test_jni_veneer.py compiles and
+// links it against a stub jni.h and checks the exported names against the Java `native` declarations):
+//   g++ -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../include mmplace_jni.cc
+//       -L../modelmesh_amd/lib -lmmplace -o libmmplace_jni.so
 //
 // Java side: integration/GpuPlacementLB.java (class com.ibm.watson.modelmesh.MmPlace).
 // All buffers are direct ByteBuffers laid out exactly as the C structs (little
@@ -110,5 +111,212 @@ JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_clusterStats(JNIEnv
 {
     return check(env, ctx_of(h), mmp_cluster_stats(ctx_of(h), buf<mmp_stats>(env, out)));
 }
+
+// ---- eviction: clhm put/evict (ConcurrentLinkedHashMap.java:590-611,329-352) -----------------------
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_cachesLoad(JNIEnv *env, jclass, jlong h, jint nCaches,
+                                                                        jobject segOff, jobject lastUsed,
+                                                                        jobject weight, jobject capacity)
+{
+    return check(env, ctx_of(h),
+                 mmp_caches_load(ctx_of(h), nCaches, buf<int32_t>(env, segOff), buf<int64_t>(env, lastUsed),
+                                 buf<int32_t>(env, weight), buf<int64_t>(env, capacity)));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_evictBatch(JNIEnv *env, jclass, jlong h, jobject reqs,
+                                                                        jint n, jlong nowMs, jobject outs)
+{
+    return check(env, ctx_of(h),
+                 mmp_evict_batch(ctx_of(h), buf<mmp_evict_req>(env, reqs), n, nowMs, buf<mmp_evict_out>(env, outs)));
+}
+
+// ---- stateful caches + ModelCacheUnloadBufManager (ModelCacheUnloadBufManager.java:130-402) --------
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_cachesLoadKeyed(JNIEnv *env, jclass, jlong h,
+                                                                             jint nCaches, jobject segOff,
+                                                                             jobject lastUsed, jobject weight,
+                                                                             jobject key, jobject capacity,
+                                                                             jobject ubm)
+{
+    return check(env, ctx_of(h),
+                 mmp_caches_load_keyed(ctx_of(h), nCaches, buf<int32_t>(env, segOff), buf<int64_t>(env, lastUsed),
+                                       buf<int32_t>(env, weight), buf<int32_t>(env, key),
+                                       buf<int64_t>(env, capacity), buf<mmp_ubm_state>(env, ubm)));
+}
+// nEvictedSlots: direct IntBuffer of one element
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_cacheReplay(JNIEnv *env, jclass, jlong h, jobject ops,
+                                                                         jint nOps, jlong nowMs, jobject outs,
+                                                                         jobject evictedKeys, jint maxEvicted,
+                                                                         jobject nEvictedSlots)
+{
+    return check(env, ctx_of(h),
+                 mmp_cache_replay(ctx_of(h), buf<mmp_cache_op>(env, ops), nOps, nowMs,
+                                  buf<mmp_cache_op_out>(env, outs), buf<int32_t>(env, evictedKeys), maxEvicted,
+                                  buf<int32_t>(env, nEvictedSlots)));
+}
+// scalars: direct buffer {int32 n; int32 pad; int64 capacity; int64 weightedSize}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_cacheRead(JNIEnv *env, jclass, jlong h, jint cache,
+                                                                       jint maxEntries, jobject lastUsed,
+                                                                       jobject weight, jobject key, jobject scalars,
+                                                                       jobject ubm)
+{
+    struct Scalars {
+        int32_t n, pad;
+        int64_t capacity, weighted_size;
+    } *sc = buf<Scalars>(env, scalars);
+    if (!sc) return check(env, ctx_of(h), MMP_EINVAL);
+    return check(env, ctx_of(h),
+                 mmp_cache_read(ctx_of(h), cache, maxEntries, buf<int64_t>(env, lastUsed), buf<int32_t>(env, weight),
+                                buf<int32_t>(env, key), &sc->n, &sc->capacity, &sc->weighted_size,
+                                buf<mmp_ubm_state>(env, ubm)));
+}
+
+// ---- request guards (MM.java:3603-3626, 3870-3884, 4003-4042, 4590-4627, 5158-5197, 2867-2933, 5440-5468)
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_gateBatch(JNIEnv *env, jclass, jlong h, jobject reqs,
+                                                                       jint n, jobject exclPod, jobject exclTime,
+                                                                       jint nExcl, jobject explicitPool,
+                                                                       jint nExplicit, jlong nowMs,
+                                                                       jlong inUseFailureExpiryMs, jobject outs)
+{
+    return check(env, ctx_of(h),
+                 mmp_gate_batch(ctx_of(h), buf<mmp_gate_req>(env, reqs), n, buf<int32_t>(env, exclPod),
+                                buf<int64_t>(env, exclTime), nExcl, buf<int32_t>(env, explicitPool), nExplicit, nowMs,
+                                inUseFailureExpiryMs, buf<mmp_gate_out>(env, outs)));
+}
+
+// ---- rebalancers (MM.java:5636-5871, 6110-6335, 6616-6747, 6959-7147) ---------------------------------
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_proactivePlan(JNIEnv *env, jclass, jlong h,
+                                                                           jint defaultModelSizeUnits, jlong nowMs,
+                                                                           jint maxOut, jobject outModel,
+                                                                           jobject outLastUsed, jobject info)
+{
+    return check(env, ctx_of(h),
+                 mmp_proactive_plan(ctx_of(h), defaultModelSizeUnits, nowMs, maxOut, buf<int32_t>(env, outModel),
+                                    buf<int64_t>(env, outLastUsed), buf<mmp_proactive_info>(env, info)));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_scaleupPlan(JNIEnv *env, jclass, jlong h, jobject entries,
+                                                                         jint n, jobject params, jobject outs,
+                                                                         jobject overloadedOut, jobject skipped)
+{
+    return check(env, ctx_of(h),
+                 mmp_scaleup_plan(ctx_of(h), buf<mmp_cache_entry>(env, entries), n,
+                                  buf<mmp_scaleup_params>(env, params), buf<mmp_scaleup_out>(env, outs),
+                                  buf<uint8_t>(env, overloadedOut), buf<int32_t>(env, skipped)));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_scaledownPlan(JNIEnv *env, jclass, jlong h,
+                                                                           jobject entries, jint n, jobject params,
+                                                                           jobject removedOut)
+{
+    return check(env, ctx_of(h),
+                 mmp_scaledown_plan(ctx_of(h), buf<mmp_cache_entry>(env, entries), n,
+                                    buf<mmp_scaledown_params>(env, params), buf<uint8_t>(env, removedOut)));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_migrationPlan(JNIEnv *env, jclass, jlong h,
+                                                                           jobject entries, jint n, jint selfPod,
+                                                                           jlong nowMs, jlong cutoffAgeMs,
+                                                                           jobject actionOut, jobject waitOut)
+{
+    return check(env, ctx_of(h),
+                 mmp_migration_plan(ctx_of(h), buf<mmp_cache_entry>(env, entries), n, selfPod, nowMs, cutoffAgeMs,
+                                    buf<uint8_t>(env, actionOut), buf<uint8_t>(env, waitOut)));
+}
+
+// ---- type constraints from labels (TypeConstraintManager.java:337-506, 680-747) ----------------------
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_typesFromLabels(JNIEnv *env, jclass, jlong h,
+                                                                             jint nTypes, jobject required,
+                                                                             jobject preferred, jobject podLabels,
+                                                                             jobject allowedOut, jobject preferOut,
+                                                                             jobject hasAllowedOut,
+                                                                             jobject hasPreferOut)
+{
+    return check(env, ctx_of(h),
+                 mmp_types_from_labels(ctx_of(h), nTypes, buf<uint64_t>(env, required), buf<uint64_t>(env, preferred),
+                                       buf<uint64_t>(env, podLabels), buf<uint64_t>(env, allowedOut),
+                                       buf<uint64_t>(env, preferOut), buf<uint8_t>(env, hasAllowedOut),
+                                       buf<uint8_t>(env, hasPreferOut)));
+}
+
+// ---- UpgradeTracker (UpgradeTracker.java:85-200; called at MM.java:1532,1553,1563) -------------------
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_upgradeInstanceAdded(JNIEnv *env, jclass, jlong h,
+                                                                                  jlong labelsKey, jint replicaSet,
+                                                                                  jlong startTime, jlong nowMs)
+{
+    return check(env, ctx_of(h), mmp_upgrade_instance_added(ctx_of(h), labelsKey, replicaSet, startTime, nowMs));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_upgradeInstanceRemoved(JNIEnv *env, jclass, jlong h,
+                                                                                    jlong labelsKey, jint replicaSet,
+                                                                                    jlong nowMs)
+{
+    return check(env, ctx_of(h), mmp_upgrade_instance_removed(ctx_of(h), labelsKey, replicaSet, nowMs));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_upgradeHousekeeping(JNIEnv *env, jclass, jlong h,
+                                                                                 jlong nowMs)
+{
+    return check(env, ctx_of(h), mmp_upgrade_housekeeping(ctx_of(h), nowMs));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_upgradeReplaced(JNIEnv *env, jclass, jlong h,
+                                                                             jobject rsOut, jobject expiryOut,
+                                                                             jint max, jobject nOut)
+{
+    return check(env, ctx_of(h),
+                 mmp_upgrade_replaced(ctx_of(h), buf<int32_t>(env, rsOut), buf<int64_t>(env, expiryOut), max,
+                                      buf<int32_t>(env, nOut)));
+}
+
+// ---- KV wire format: the raw byte[] of the KV events, packed back to back in a direct buffer ----------
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_podIdsLoad(JNIEnv *env, jclass, jlong h, jobject ids,
+                                                                        jobject idOff, jint nPods,
+                                                                        jobject idOrderOut, jobject replicaSetOut)
+{
+    return check(env, ctx_of(h),
+                 mmp_pod_ids_load(ctx_of(h), buf<char>(env, ids), buf<int32_t>(env, idOff), nPods,
+                                  buf<uint32_t>(env, idOrderOut), buf<int32_t>(env, replicaSetOut)));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_podsIngestJson(JNIEnv *env, jclass, jlong h, jobject json,
+                                                                            jobject off, jint n, jobject podIdx,
+                                                                            jobject live, jobject startTimeOut,
+                                                                            jobject statusOut)
+{
+    return check(env, ctx_of(h),
+                 mmp_pods_ingest_json(ctx_of(h), buf<char>(env, json), buf<int64_t>(env, off), n,
+                                      buf<int32_t>(env, podIdx), buf<uint8_t>(env, live),
+                                      buf<int64_t>(env, startTimeOut), buf<int32_t>(env, statusOut)));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_typeNamesLoad(JNIEnv *env, jclass, jlong h, jobject names,
+                                                                           jobject nameOff, jint nTypes,
+                                                                           jint unknownType)
+{
+    return check(env, ctx_of(h),
+                 mmp_type_names_load(ctx_of(h), buf<char>(env, names), buf<int32_t>(env, nameOff), nTypes, unknownType));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_modelsIngestJson(JNIEnv *env, jclass, jlong h,
+                                                                              jobject json, jobject off,
+                                                                              jint nModels, jobject lastUnloadOut,
+                                                                              jobject statusOut)
+{
+    return check(env, ctx_of(h),
+                 mmp_models_ingest_json(ctx_of(h), buf<char>(env, json), buf<int64_t>(env, off), nModels,
+                                        buf<int64_t>(env, lastUnloadOut), buf<int32_t>(env, statusOut)));
+}
+
+// ---- misc -----------------------------------------------------------------------------------------
+JNIEXPORT jlong JNICALL Java_com_ibm_watson_modelmesh_MmPlace_minSpaceUnits(JNIEnv *, jclass,
+                                                                            jint defaultModelSizeUnits,
+                                                                            jint loadingThreads, jlong capacityUnits,
+                                                                            jboolean haveUnloadManager)
+{
+    return mmp_min_space_units(defaultModelSizeUnits, loadingThreads, capacityUnits, haveUnloadManager ? 1 : 0);
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_getOrder(JNIEnv *env, jclass, jlong h, jobject orderOut,
+                                                                      jobject nOut)
+{
+    return check(env, ctx_of(h), mmp_get_order(ctx_of(h), buf<int32_t>(env, orderOut), buf<int32_t>(env, nOut)));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_profile(JNIEnv *env, jclass, jlong h, jboolean enable)
+{
+    return check(env, ctx_of(h), mmp_profile(ctx_of(h), enable ? 1 : 0));
+}
+JNIEXPORT jdouble JNICALL Java_com_ibm_watson_modelmesh_MmPlace_lastKernelMs(JNIEnv *, jclass, jlong h)
+{
+    return mmp_last_kernel_ms(ctx_of(h));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_abiVersion(JNIEnv *, jclass) { return mmp_abi_version(); }
 
 }  // extern "C"

@@ -155,6 +155,8 @@ SYMBOLS = [
     ("mmp_shard_commit_dev", C.c_int, [_P, _P]),
     ("mmp_shard_place_phase_dev", C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int64, _P, _P, _P]),
     ("mmp_sync", C.c_int, [_P]),
+    ("mmp_profile", C.c_int, [_P, C.c_int]),
+    ("mmp_last_kernel_ms", C.c_double, [_P]),
 ]
 
 _lib = None

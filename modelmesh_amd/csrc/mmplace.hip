@@ -99,6 +99,10 @@ struct mmp_ctx {
     std::string err;
     FastSlot fast[kFastSlots];
     std::atomic<uint32_t> fast_rr{0};
+    // mmp_profile(): HIP events around the kernels (not the staging copies) of each host-pointer call
+    bool prof = false, prof_armed = false;
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    double last_kernel_ms = -1.0;
     int32_t force_wave = 0;  // MMP_FORCE_WAVE=1: every decision takes the wave-per-decision kernel (tests)
 
     // host staging (inputs of the next commit)
@@ -128,6 +132,9 @@ struct mmp_ctx {
     // model registry view
     DevBuf models, ent_pod, ent_time;
     int32_t n_models = 0, n_entries = 0;
+    // the registry view resolved against the current snapshot (place_kernel.hpp: ResolvedModel)
+    DevBuf rmodels;
+    bool rmodels_ok = false;
 
     // eviction caches
     DevBuf c_seg, c_lu, c_wt, c_cap;
@@ -183,6 +190,26 @@ int fail(mmp_ctx *c, int code, const char *fmt, ...)
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
+// Kernel-time bracket of a host-pointer entry point (owner of c->batch_mu): KT_BEGIN after the H2D
+// copies are enqueued, KT_END after the last kernel, kt_collect() once the stream has been synchronised.
+#define KT_BEGIN(c, st)                                             \
+    do {                                                            \
+        (c)->prof_armed = false;                                    \
+        if ((c)->prof && hipEventRecord((c)->pe0, (st)) == hipSuccess) (c)->prof_armed = true; \
+    } while (0)
+#define KT_END(c, st)                                               \
+    do {                                                            \
+        if ((c)->prof_armed && hipEventRecord((c)->pe1, (st)) != hipSuccess) (c)->prof_armed = false; \
+    } while (0)
+inline void kt_collect(mmp_ctx *c)
+{
+    if (!c->prof) return;
+    float ms = -1.f;
+    if (c->prof_armed && hipEventElapsedTime(&ms, c->pe0, c->pe1) != hipSuccess) ms = -1.f;
+    c->last_kernel_ms = ms;
+    c->prof_armed = false;
+}
+
 // Called with c->mu held, before device state that decisions read is overwritten: every decision
 // kernel was enqueued under c->mu, so once the streams are idle nothing reads the old state.
 hipError_t quiesce_decisions(mmp_ctx *c)
@@ -194,6 +221,22 @@ hipError_t quiesce_decisions(mmp_ctx *c)
     return hipStreamSynchronize(c->stream);
 }
 
+// Called with c->mu held and the decision streams idle, after the model table or the snapshot changed:
+// re-resolve every model's entry list against the published snapshot.
+int rebuild_resolved(mmp_ctx *c)
+{
+    c->rmodels_ok = false;
+    if (!c->committed || c->n_shards > 0 || c->n_models <= 0) return MMP_OK;
+    HIP_TRY(c, c->rmodels.ensure((size_t)c->n_models * sizeof(ResolvedModel)));
+    hipLaunchKernelGGL(resolve_models_kernel, dim3(div_up(c->n_models, 256)), dim3(256), 0, c->stream, c->snap,
+                       c->models.as<mmp_model_row>(), c->ent_pod.as<int32_t>(), c->n_models,
+                       c->rmodels.as<ResolvedModel>());
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->rmodels_ok = true;
+    return MMP_OK;
+}
+
 int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs,
                  hipStream_t st)
 {
@@ -201,6 +244,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     PlaceArgs A;
     A.reqs = static_cast<const mmp_place_req *>(d_reqs);
     A.models = c->models.as<mmp_model_row>();
+    A.rmodels = c->rmodels_ok ? c->rmodels.as<ResolvedModel>() : nullptr;
     A.ent_pod = c->ent_pod.as<int32_t>();
     A.extra = static_cast<const int32_t *>(d_extra);
     A.outs = static_cast<mmp_place_out *>(d_outs);
@@ -287,10 +331,12 @@ void mmp_destroy(mmp_ctx *c)
         (void)hipStreamSynchronize(c->stream);
         (void)hipStreamDestroy(c->stream);
     }
+    if (c->pe0) (void)hipEventDestroy(c->pe0);
+    if (c->pe1) (void)hipEventDestroy(c->pe1);
     c->sb[0].release();
     c->sb[1].release();
     for (DevBuf *b : {&c->rank, &c->occupancy, &c->flag, &c->rs_list, &c->rs_bad, &c->d_allowed, &c->d_prefer,
-                      &c->d_has_allowed, &c->stats_acc, &c->models, &c->ent_pod, &c->ent_time, &c->c_seg,
+                      &c->d_has_allowed, &c->stats_acc, &c->models, &c->rmodels, &c->ent_pod, &c->ent_time, &c->c_seg,
                       &c->c_lu, &c->c_wt, &c->c_cap, &c->s_reqs, &c->s_outs, &c->s_extra, &c->s_a, &c->s_b,
                       &c->s_c, &c->s_d, &c->r_ps, &c->r_counts, &c->r_keys, &c->r_vals, &c->r_keys2, &c->r_vals2,
                       &c->r_tmp, &c->r_out_model, &c->r_out_lu, &c->k_cap, &c->k_wsize, &c->k_ubm, &c->k_ops, &c->k_order,
@@ -304,6 +350,22 @@ void mmp_destroy(mmp_ctx *c)
 const char *mmp_last_error(mmp_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
 int mmp_backend(mmp_ctx *c) { return c ? 1 : 0; }
+
+int mmp_profile(mmp_ctx *c, int enable)
+{
+    if (!c) return MMP_EINVAL;
+    std::lock_guard<std::mutex> gb(c->batch_mu);
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (enable && !c->pe0) {
+        HIP_TRY(c, hipEventCreate(&c->pe0));
+        HIP_TRY(c, hipEventCreate(&c->pe1));
+    }
+    c->prof = enable != 0;
+    c->last_kernel_ms = -1.0;
+    return MMP_OK;
+}
+
+double mmp_last_kernel_ms(mmp_ctx *c) { return c ? c->last_kernel_ms : -1.0; }
 
 int mmp_sync(mmp_ctx *c)
 {
@@ -515,6 +577,7 @@ int mmp_models_load(mmp_ctx *c, const mmp_model_row *rows, int32_t n_models, con
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, quiesce_decisions(c));  // the table is overwritten in place
+    c->rmodels_ok = false;
     HIP_TRY(c, c->models.ensure((size_t)std::max(n_models, 1) * sizeof(mmp_model_row)));
     HIP_TRY(c, c->ent_pod.ensure((size_t)std::max(n_entries, 1) * sizeof(int32_t)));
     HIP_TRY(c, c->ent_time.ensure((size_t)std::max(n_entries, 1) * sizeof(int64_t)));
@@ -525,7 +588,7 @@ int mmp_models_load(mmp_ctx *c, const mmp_model_row *rows, int32_t n_models, con
     }
     c->n_models = n_models;
     c->n_entries = n_entries;
-    return MMP_OK;
+    return rebuild_resolved(c);
 }
 
 /* ---- commit: rank + permute + bitmaps + stats, all on the device --------- */
@@ -602,6 +665,7 @@ int mmp_snapshot_commit(mmp_ctx *c)
     init.global_lru = INT64_MAX;
     HIP_TRY(c, hipMemcpyAsync(c->stats_acc.p, &init, sizeof init, hipMemcpyHostToDevice, st));
 
+    KT_BEGIN(c, st);
     if (P > 0) {
         const int pb = div_up(P, kRankBlock);
         const int slices = std::max(1, std::min(64, 2048 / pb));
@@ -632,11 +696,13 @@ int mmp_snapshot_commit(mmp_ctx *c)
         HIP_TRY(c, hipMemsetAsync(B.fullw.p, 0, (size_t)W * 8, st));
         HIP_TRY(c, hipMemsetAsync(B.ge.p, 0, (size_t)kGeRows * W * 8, st));
     }
+    KT_END(c, st);
     int32_t bad = 0;
     StatsAcc acc{};
     HIP_TRY(c, hipMemcpyAsync(&bad, c->flag.p, sizeof bad, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(&acc, c->stats_acc.p, sizeof acc, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    kt_collect(c);
     if (bad)
         return fail(c, MMP_EORDER,
                     "PLACEMENT_ORDER is not a total order on these rows (a full instance with lruTime <= "
@@ -668,7 +734,7 @@ int mmp_snapshot_commit(mmp_ctx *c)
     c->stats.global_lru = (int64_t)acc.global_lru;
     c->stats.instance_count = acc.instance_count;
     c->stats.model_copy_count = acc.model_copy_count;
-    return MMP_OK;
+    return rebuild_resolved(c);
 }
 
 int mmp_get_order(mmp_ctx *c, int32_t *order_out, int32_t *n_out)
@@ -806,14 +872,17 @@ int mmp_pods_ingest_json(mmp_ctx *c, const char *buf, const int64_t *off, int32_
     HIP_TRY(c, hipMemcpyAsync(c->j_off.p, rel.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->j_rows.p, rows.data(), (size_t)n * sizeof(mmp_pod_row), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemsetAsync(c->j_aux.p, 0, (size_t)n * 8, st));
+    KT_BEGIN(c, st);
     hipLaunchKernelGGL(ingest_pods_kernel, dim3(div_up(n, 128)), dim3(128), 0, st, c->j_buf.as<char>(), c->j_off.as<int64_t>(), n,
                        c->j_rows.as<mmp_pod_row>(), c->j_aux.as<int64_t>(), c->j_status.as<int32_t>());
+    KT_END(c, st);
     HIP_TRY(c, hipGetLastError());
     std::vector<int64_t> stt(n);
     HIP_TRY(c, hipMemcpyAsync(rows.data(), c->j_rows.p, (size_t)n * sizeof(mmp_pod_row), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(stt.data(), c->j_aux.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(status_out, c->j_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    kt_collect(c);
     for (int32_t i = 0; i < n; i++) {
         if (status_out[i] == 0) c->pods[pod_idx[i]] = rows[i];
         if (start_time_out) start_time_out[i] = stt[i];
@@ -852,6 +921,7 @@ int mmp_models_ingest_json(mmp_ctx *c, const char *buf, const int64_t *off, int3
     HIP_TRY(c, quiesce_decisions(c));  // the registry view is replaced in place
     hipStream_t st = c->stream;
     const int32_t n = n_models;
+    c->rmodels_ok = false;
     if (n == 0) {
         c->n_models = 0;
         c->n_entries = 0;
@@ -883,6 +953,7 @@ int mmp_models_ingest_json(mmp_ctx *c, const char *buf, const int64_t *off, int3
     A.last_unload = c->j_aux.as<int64_t>();
     A.status = c->j_status.as<int32_t>();
     int32_t *d_total = reinterpret_cast<int32_t *>(c->j_aux.as<int64_t>() + n);
+    KT_BEGIN(c, st);  // spans both passes and the 4-byte read-back of the entry total between them
     hipLaunchKernelGGL(ingest_models_kernel<0>, dim3(div_up(n, 128)), dim3(128), 0, st, A);
     hipLaunchKernelGGL(model_offsets_kernel, dim3(1), dim3(1024), 0, st, A.rows, n, d_total);
     HIP_TRY(c, hipGetLastError());
@@ -894,13 +965,15 @@ int mmp_models_ingest_json(mmp_ctx *c, const char *buf, const int64_t *off, int3
     A.ent_pod = c->ent_pod.as<int32_t>();
     A.ent_time = c->ent_time.as<int64_t>();
     hipLaunchKernelGGL(ingest_models_kernel<1>, dim3(div_up(n, 128)), dim3(128), 0, st, A);
+    KT_END(c, st);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(status_out, c->j_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     if (last_unload_out) HIP_TRY(c, hipMemcpyAsync(last_unload_out, c->j_aux.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    kt_collect(c);
     c->n_models = n;
     c->n_entries = total;
-    return MMP_OK;
+    return rebuild_resolved(c);
 }
 
 int mmp_pods_get(mmp_ctx *c, mmp_pod_row *rows_out, int32_t max_rows, int32_t *n_out)
@@ -1145,6 +1218,7 @@ int mmp_shard_place_phase_dev(mmp_ctx *c, int32_t phase, const void *d_reqs, int
     PlaceArgs A;
     A.reqs = static_cast<const mmp_place_req *>(d_reqs);
     A.models = c->models.as<mmp_model_row>();
+    A.rmodels = nullptr;
     A.ent_pod = c->ent_pod.as<int32_t>();
     A.extra = static_cast<const int32_t *>(d_extra);
     A.outs = static_cast<mmp_place_out *>(d_outs);
@@ -1245,11 +1319,14 @@ int mmp_place_batch(mmp_ctx *c, const mmp_place_req *reqs, int32_t n, const int3
         std::lock_guard<std::mutex> g(c->mu);
         if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
         if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
+        KT_BEGIN(c, st);
         const int rc = place_launch(c, c->s_reqs.p, n, c->s_extra.p, now, c->s_outs.p, st);
         if (rc != MMP_OK) return rc;
+        KT_END(c, st);
     }
     HIP_TRY(c, hipMemcpyAsync(outs, c->s_outs.p, (size_t)n * sizeof(mmp_place_out), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    kt_collect(c);
     return MMP_OK;
 }
 
@@ -1299,10 +1376,13 @@ int mmp_serve_batch(mmp_ctx *c, const mmp_serve_req *reqs, int32_t n, const int3
     A.n_models = c->n_models;
     A.P = P;
     A.now = now;
+    KT_BEGIN(c, st);
     hipLaunchKernelGGL(serve_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, A);
+    KT_END(c, st);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(outs, c->s_outs.p, (size_t)n * sizeof(mmp_serve_out), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    kt_collect(c);
     return MMP_OK;
 }
 
@@ -1358,10 +1438,13 @@ int mmp_gate_batch(mmp_ctx *c, const mmp_gate_req *reqs, int32_t n, const int32_
     A.in_use_expiry = in_use_expiry;
     A.min_space = c->cfg.min_space_units;
     A.min_churn = c->cfg.min_churn_age_ms;
+    KT_BEGIN(c, st);
     hipLaunchKernelGGL(gate_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, A);
+    KT_END(c, st);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(outs, c->s_outs.p, (size_t)n * sizeof(mmp_gate_out), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    kt_collect(c);
     return MMP_OK;
 }
 
@@ -1391,6 +1474,7 @@ int mmp_proactive_plan(mmp_ctx *c, int32_t default_units, int64_t now, int32_t m
     const mmp_model_row *models = c->models.as<mmp_model_row>();
     int32_t *counts = c->r_counts.as<int32_t>();
     HIP_TRY(c, hipMemsetAsync(ps, 0, sizeof(PlanScalars), st));
+    KT_BEGIN(c, st);  // device span of the whole plan, including the host round trip for n_qualified
     hipLaunchKernelGGL(proactive_space_kernel, dim3(std::min(std::max(div_up(P, 256), 1), 512)), dim3(256), 0, st, pods, P,
                        stats, default_units, ps);
     hipLaunchKernelGGL(proactive_scalars_kernel, dim3(1), dim3(64), 0, st, stats, default_units, now, ps);
@@ -1402,7 +1486,11 @@ int mmp_proactive_plan(mmp_ctx *c, int32_t default_units, int64_t now, int32_t m
     HIP_TRY(c, hipMemcpyAsync(&h, ps, sizeof h, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     const int32_t nq = h.n_qualified;
-    if (nq > 0) {
+    if (nq <= 0) {
+        KT_END(c, st);
+        HIP_TRY(c, hipStreamSynchronize(st));
+        kt_collect(c);
+    } else {
         hipLaunchKernelGGL(proactive_scatter_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, stats, ps, counts,
                            c->r_keys.as<int64_t>(), c->r_vals.as<int32_t>());
         // stable descending radix sort: equal lastUsed keep registry order, so the first one seen wins
@@ -1419,9 +1507,11 @@ int mmp_proactive_plan(mmp_ctx *c, int32_t default_units, int64_t now, int32_t m
                            c->r_vals2.as<int32_t>(), nq, counts, ps, max_out, c->r_out_model.as<int32_t>(),
                            c->r_out_lu.as<int64_t>());
         hipLaunchKernelGGL(proactive_final_kernel, dim3(1), dim3(64), 0, st, ps);
+        KT_END(c, st);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipMemcpyAsync(&h, ps, sizeof h, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
+        kt_collect(c);
         const int32_t n_copy = std::min(h.n_selected, max_out);
         if (n_copy > 0) {
             HIP_TRY(c, hipMemcpy(out_model, c->r_out_model.p, (size_t)n_copy * 4, hipMemcpyDeviceToHost));
@@ -1470,6 +1560,7 @@ int mmp_scaleup_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, cons
     const int32_t a = (int32_t)((uint32_t)p->scale_up_rpm_threshold * 4u);
     const int32_t b = (int32_t)((uint32_t)p->our_rpm - 2u * (uint32_t)p->scale_up_rpm_threshold);
     const mmp_pod_row *pods = c->sb[c->cur].pods.as<mmp_pod_row>();
+    KT_BEGIN(c, st);
     if (P > 0)
         hipLaunchKernelGGL(overloaded_pods_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, pods, P, p->self_pod,
                            a > b ? a : b, c->s_a.as<uint8_t>(), c->s_b.as<int32_t>());
@@ -1487,10 +1578,12 @@ int mmp_scaleup_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, cons
     A.n_models = c->n_models;
     A.P = P;
     hipLaunchKernelGGL(scaleup_plan_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, A);
+    KT_END(c, st);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(outs, c->s_outs.p, (size_t)n * sizeof(mmp_scaleup_out), hipMemcpyDeviceToHost, st));
     if (P > 0) HIP_TRY(c, hipMemcpyAsync(overloaded_out, c->s_a.p, (size_t)P, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    kt_collect(c);
     return MMP_OK;
 }
 
@@ -1523,11 +1616,14 @@ int mmp_scaledown_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, co
     A.n = n;
     A.n_models = c->n_models;
     A.P = c->snap.P;
+    KT_BEGIN(c, st);
     hipLaunchKernelGGL(scaledown_decide_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, A);
     hipLaunchKernelGGL(scaledown_budget_kernel, dim3(1), dim3(64), 0, st, A);
+    KT_END(c, st);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(removed_out, c->s_b.p, (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    kt_collect(c);
     return MMP_OK;
 }
 
@@ -1546,13 +1642,16 @@ int mmp_migration_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, in
     HIP_TRY(c, c->s_a.ensure((size_t)n));
     HIP_TRY(c, c->s_b.ensure((size_t)n));
     HIP_TRY(c, hipMemcpyAsync(c->s_reqs.p, entries, (size_t)n * sizeof(mmp_cache_entry), hipMemcpyHostToDevice, st));
+    KT_BEGIN(c, st);
     hipLaunchKernelGGL(migration_plan_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, c->s_reqs.as<mmp_cache_entry>(), n,
                        c->models.as<mmp_model_row>(), c->n_models, c->ent_pod.as<int32_t>(), self_pod,
                        (int64_t)((uint64_t)now - (uint64_t)cutoff_age_ms), c->s_a.as<uint8_t>(), c->s_b.as<uint8_t>());
+    KT_END(c, st);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(action_out, c->s_a.p, (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(wait_out, c->s_b.p, (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    kt_collect(c);
     return MMP_OK;
 }
 
@@ -1681,12 +1780,15 @@ int mmp_cache_replay(mmp_ctx *c, const mmp_cache_op *ops, int32_t n_ops, int64_t
     A.tile = tile;
     A.now = now;
     const size_t lds = (size_t)tile * 24;
+    KT_BEGIN(c, st);
     hipLaunchKernelGGL(cache_replay_kernel, dim3(NC), dim3(64), lds, st, A);
+    KT_END(c, st);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(outs, c->k_outs.p, (size_t)n_ops * sizeof(mmp_cache_op_out), hipMemcpyDeviceToHost, st));
     if (ev_off[NC]) HIP_TRY(c, hipMemcpyAsync(evicted_keys, c->k_ev.p, (size_t)ev_off[NC] * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(c->k_n.data(), D.n.p, (size_t)NC * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    kt_collect(c);
     c->ks_cur = 1 - c->ks_cur;
     *n_evicted_slots = ev_off[NC];
     return MMP_OK;
@@ -1767,10 +1869,13 @@ int mmp_evict_batch(mmp_ctx *c, const mmp_evict_req *reqs, int32_t n, int64_t no
     A.n = n;
     A.n_caches = c->n_caches;
     A.now = now;
+    KT_BEGIN(c, st);
     hipLaunchKernelGGL(evict_batch_kernel, dim3(div_up(n, 4)), dim3(256), 0, st, A);
+    KT_END(c, st);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(outs, c->s_outs.p, (size_t)n * sizeof(mmp_evict_out), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    kt_collect(c);
     return MMP_OK;
 }
 

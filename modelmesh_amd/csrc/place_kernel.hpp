@@ -37,9 +37,22 @@ struct __attribute__((aligned(16))) ResolvedReq {
 };
 static_assert(sizeof(ResolvedReq) == 96, "ResolvedReq is 96 bytes");
 
+// The registry view with its indirections followed once per (registry, snapshot) pair instead of once
+// per decision: model row -> instanceIds / failedIn -> rank positions.  Rebuilt by
+// resolve_models_kernel whenever the model table is reloaded or a snapshot is committed; it takes two
+// levels (entry list, pos_of) out of the dependent-load chain of lane_decide.
+constexpr int kResolvedInline = 6;
+struct __attribute__((aligned(16))) ResolvedModel {
+    int32_t type;    // bitmap row, already clamped to the snapshot's rows
+    int32_t n_ents;  // |instanceIds| + |loadFailedInstanceIds|
+    int32_t pos[kResolvedInline];  // rank positions of the first entries, -1 = pod not in the table
+};
+static_assert(sizeof(ResolvedModel) == 32, "ResolvedModel is 32 bytes");
+
 struct PlaceArgs {
     const mmp_place_req *reqs;
     const mmp_model_row *models;
+    const ResolvedModel *rmodels;  // null: not built (pod-axis shard contexts)
     const int32_t *ent_pod;  // model entries: loaded ids then failed ids
     const int32_t *extra;    // per-request extra exclusions
     mmp_place_out *outs;
@@ -257,6 +270,24 @@ __device__ __forceinline__ ResolvedReq resolve_one(const Snap &S, const PlaceArg
     if (rq.model < 0 || rq.model >= A.n_models) {
         r.type = -1;
         r.n_excl = 0;
+    } else if (A.rmodels && A.rmodels[rq.model].n_ents <= kResolvedInline) {
+        const ResolvedModel m = A.rmodels[rq.model];
+        r.type = m.type;
+        r.n_excl = m.n_ents + rq.n_extra;
+        if (r.n_excl <= kInlineExcl) {
+#pragma unroll
+            for (int i = 0; i < kResolvedInline; i++)
+                if (i < m.n_ents) r.excl_pos[i] = m.pos[i];
+            if (rq.n_extra > 0) {
+#pragma unroll
+                for (int i = 0; i < kInlineExcl; i++) {
+                    if (i >= m.n_ents && i < r.n_excl) {
+                        const int32_t pod = A.extra[rq.extra_off + i - m.n_ents];
+                        r.excl_pos[i] = (pod >= 0 && pod < S.P) ? S.pos_of[pod] : -1;
+                    }
+                }
+            }
+        }
     } else {
         const mmp_model_row m = A.models[rq.model];
         r.type = (m.type < 0 || m.type >= S.T) ? 0 : m.type;
@@ -273,6 +304,29 @@ __device__ __forceinline__ ResolvedReq resolve_one(const Snap &S, const PlaceArg
         }
     }
     return r;
+}
+
+// One lane per model: follow the entry list through pos_of once (see ResolvedModel).
+__global__ void resolve_models_kernel(Snap S, const mmp_model_row *__restrict__ models,
+                                      const int32_t *__restrict__ ent_pod, int32_t n_models,
+                                      ResolvedModel *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_models) return;
+    const mmp_model_row m = models[i];
+    ResolvedModel r;
+    r.type = (m.type < 0 || m.type >= S.T) ? 0 : m.type;
+    r.n_ents = m.n_loaded + m.n_failed;
+#pragma unroll
+    for (int k = 0; k < kResolvedInline; k++) {
+        int32_t pos = -1;
+        if (k < r.n_ents) {
+            const int32_t pod = ent_pod[m.ent_off + k];
+            if (pod >= 0 && pod < S.P) pos = S.pos_of[pod];
+        }
+        r.pos[k] = pos;
+    }
+    out[i] = r;
 }
 
 // ---- one LANE per decision -----------------------------------------------------------------------

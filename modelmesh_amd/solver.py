@@ -403,3 +403,10 @@ class Solver:
 
     def sync(self):
         self._ck(self.lib.mmp_sync(self.h))
+
+    def profile(self, enable: bool = True):
+        """HIP-event timing of the kernels inside each host-pointer call (read with last_kernel_ms())."""
+        self._ck(self.lib.mmp_profile(self.h, 1 if enable else 0))
+
+    def last_kernel_ms(self) -> float:
+        return float(self.lib.mmp_last_kernel_ms(self.h))

@@ -1,0 +1,74 @@
+"""The reference-side binding: integration/mmplace_jni.cc + the `native`
+declarations of integration/GpuPlacementLB.java.  No JDK exists in this image, so the veneer is compiled
+and linked against libmmplace.so with a stub jni.h (tests/jni_stub, types only) and its exported symbols
+are cross-checked, name and arity, against the Java declarations and against include/mmplace.h."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JNI_CC = os.path.join(ROOT, "integration", "mmplace_jni.cc")
+JAVA = os.path.join(ROOT, "integration", "GpuPlacementLB.java")
+LIBDIR = os.path.join(ROOT, "modelmesh_amd", "lib")
+PREFIX = "Java_com_ibm_watson_modelmesh_MmPlace_"
+
+
+def _java_natives():
+    src = open(JAVA).read()
+    body = src[src.index("final class MmPlace"):]
+    body = body[: body.index("\n}")]
+    out = {}
+    for m in re.finditer(r"static\s+native\s+(\w+)\s+(\w+)\s*\(([^)]*)\)\s*;", body):
+        ret, name, params = m.group(1), m.group(2), m.group(3).strip()
+        out[name] = (ret, [p.split()[0] for p in params.split(",")] if params else [])
+    return out
+
+
+def _c_exports():
+    src = open(JNI_CC).read()
+    out = {}
+    for m in re.finditer(r"JNIEXPORT\s+(\w+)\s+JNICALL\s+" + PREFIX + r"(\w+)\s*\(([^)]*)\)", src):
+        ret, name, params = m.group(1), m.group(2), [p.strip() for p in m.group(3).split(",")]
+        out[name] = (ret, [p.split()[0] for p in params])
+    return out
+
+
+JTYPE = {"int": "jint", "long": "jlong", "double": "jdouble", "boolean": "jboolean", "void": "void", "ByteBuffer": "jobject"}
+
+
+def test_every_java_native_has_a_veneer_function_of_the_same_shape():
+    jn, cx = _java_natives(), _c_exports()
+    assert len(jn) >= 36
+    assert set(jn) == set(cx), (sorted(set(jn) - set(cx)), sorted(set(cx) - set(jn)))
+    for name, (ret, params) in jn.items():
+        cret, cparams = cx[name]
+        assert JTYPE[ret] == cret, (name, ret, cret)
+        assert cparams[0] == "JNIEnv" and cparams[1] == "jclass", (name, cparams)
+        assert [JTYPE[p] for p in params] == cparams[2:], (name, params, cparams)
+
+
+def test_veneer_covers_the_whole_c_abi():
+    """Every include/mmplace.h entry point a Java host needs is reachable through the veneer (the
+    *_dev / pod-axis shard calls take device pointers and RCCL streams a JVM does not hold)."""
+    hdr = open(os.path.join(ROOT, "include", "mmplace.h")).read()
+    abi = set(re.findall(r"^\w[\w\s\*]*?\b(mmp_\w+)\s*\(", hdr, flags=re.M))
+    used = set(re.findall(r"\b(mmp_\w+)\s*\(", open(JNI_CC).read()))
+    not_for_jvm = {n for n in abi if n.endswith("_dev") or n.startswith("mmp_shard_")} | {
+        "mmp_backend", "mmp_sync", "mmp_pods_get", "mmp_models_get"}
+    missing = abi - used - not_for_jvm
+    assert not missing, sorted(missing)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LIBDIR, "libmmplace.so")), reason="libmmplace.so not built")
+def test_veneer_compiles_links_and_exports(tmp_path):
+    so = tmp_path / "libmmplace_jni.so"
+    cmd = ["g++", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "tests", "jni_stub"),
+           "-I" + os.path.join(ROOT, "include"), JNI_CC, "-L" + LIBDIR, "-lmmplace", "-Wl,--no-undefined",
+           "-Wl,-rpath," + LIBDIR, "-o", str(so)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    syms = subprocess.run(["nm", "-D", "--defined-only", str(so)], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1][len(PREFIX):] for ln in syms.splitlines() if PREFIX in ln}
+    assert exported == set(_java_natives())

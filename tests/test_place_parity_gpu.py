@@ -211,3 +211,81 @@ def test_c4_1m_x_50k_sample():
     sel = np.arange(0, len(reqs), 4)
     sub = reqs[sel].copy()
     _check_fleet(fleet, sub, extra)
+
+
+def _widen_registry(fleet, rng, max_copies):
+    """Give every model 0..max_copies instanceIds (+ 0..2 failedIn) on distinct pods, TreeMap order."""
+    P, M = fleet.n_pods, fleet.n_models
+    k = np.minimum(rng.integers(0, max_copies + 1, M), P).astype(np.int32)
+    nf = np.minimum(rng.integers(0, 3, M), np.maximum(P - k, 0)).astype(np.int32)
+    off = np.zeros(M + 1, np.int64)
+    np.cumsum(k + nf, out=off[1:])
+    ent_pod = np.zeros(int(off[-1]), np.int32)
+    for i in range(M):
+        pods = rng.choice(P, size=int(k[i] + nf[i]), replace=False)
+        a, b = pods[: k[i]], pods[k[i]:]
+        ent_pod[off[i]: off[i] + k[i]] = a[np.argsort(fleet.pods["id_order"][a], kind="stable")]
+        ent_pod[off[i] + k[i]: off[i + 1]] = b[np.argsort(fleet.pods["id_order"][b], kind="stable")]
+    fleet.models["ent_off"], fleet.models["n_loaded"], fleet.models["n_failed"] = off[:-1], k, nf
+    fleet.ent_pod = ent_pod
+    fleet.ent_time = (fleet.now - rng.integers(1_000, 86_400_000, len(ent_pod))).astype(np.int64)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_many_copies_cross_the_resolved_table_limits(seed):
+    """Models with 0..12 copies: the per-model resolved rows hold 6 positions (ResolvedModel), the lane path
+    8 exclusions in all, beyond that the wave path — every boundary must give the oracle's answer."""
+    rng = np.random.default_rng(7000 + seed)
+    fleet = wl.fuzz_fleet(seed + 100, pods=int(rng.choice([40, 300, 2000])), models=500,
+                          profile=[None, "prefer"][seed % 2])
+    _widen_registry(fleet, rng, 12)
+    reqs, extra = wl.fuzz_requests(fleet, seed, 4000)
+    _check_fleet(fleet, reqs, extra)
+
+
+def test_registry_reload_and_commit_keep_the_resolved_table_current():
+    """The resolved registry view is rebuilt by mmp_models_load and by mmp_snapshot_commit: decisions
+    after either must see the new entry lists at the new rank positions."""
+    rng = np.random.default_rng(7100)
+    fleet = wl.fuzz_fleet(31, pods=300, models=400)
+    reqs, extra = wl.fuzz_requests(fleet, 31, 2000)
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        assert_same_decisions(fleet, reqs, s.place(reqs, extra, fleet.now), OracleFleet(fleet).place(reqs, extra, fleet.now))
+        # registry changes, snapshot does not
+        _widen_registry(fleet, rng, 5)
+        s.load_models(fleet.models, fleet.ent_pod, fleet.ent_time)
+        assert_same_decisions(fleet, reqs, s.place(reqs, extra, fleet.now), OracleFleet(fleet).place(reqs, extra, fleet.now))
+        # snapshot changes (every pod re-ranked), registry does not
+        fleet.pods["count"] = rng.permutation(fleet.pods["count"])
+        fleet.pods["lru_time"] = np.where(fleet.pods["count"] == 0, np.int64(2**63 - 1),
+                                          fleet.now - rng.integers(1_000, 4_000_000, fleet.n_pods))
+        s.upsert_pods(np.arange(fleet.n_pods, dtype=np.int32), fleet.pods)
+        s.commit()
+        orc = OracleFleet(fleet)
+        assert np.array_equal(s.order(), orc.order)
+        assert_same_decisions(fleet, reqs, s.place(reqs, extra, fleet.now), orc.place(reqs, extra, fleet.now))
+    finally:
+        s.close()
+
+
+def test_kernel_time_bracket():
+    """mmp_profile / mmp_last_kernel_ms: device time of the kernels of the last host-pointer call."""
+    fleet = wl.make_fleet("C2")
+    reqs, extra = wl.make_requests(fleet, 3)
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        assert s.last_kernel_ms() < 0
+        s.profile(True)
+        s.commit()
+        t_commit = s.last_kernel_ms()
+        s.place(reqs, extra, fleet.now)
+        t_place = s.last_kernel_ms()
+        assert 0 < t_commit < 1000 and 0 < t_place < 1000
+        s.profile(False)
+        s.place(reqs, extra, fleet.now)
+        assert s.last_kernel_ms() < 0
+    finally:
+        s.close()
