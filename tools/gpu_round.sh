@@ -1,0 +1,29 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, the bench line, rocprofv3 kernel stats and the HBM PMC passes.
+# usage (from the repo root on the GPU box): bash tools/gpu_round.sh [tests|bench|prof|pmc ...]
+set -u
+export TMPDIR=/tmp
+OUT=gpurun_out
+mkdir -p $OUT
+what=${*:-tests bench prof pmc}
+for w in $what; do
+case $w in
+tests)
+  timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
+  tail -5 $OUT/pytest_gpu.log ;;
+smoke)
+  timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log ;;
+bench)
+  timeout 900 python bench.py > $OUT/bench.json.log 2> $OUT/bench.err; echo "bench exit $?"
+  python tools/benchline.py bench < $OUT/bench.json.log ;;
+prof)
+  rm -rf $OUT/prof
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --kernel-only --steps 200 --warmup 20 > $OUT/prof_bench.log 2>&1
+  f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats.csv && head -8 $OUT/kernel_stats.csv ;;
+pmc)
+  rm -rf $OUT/pmc_fetch $OUT/pmc_write
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python bench.py --kernel-only --steps 20 --warmup 2 --streams 1 > $OUT/pmc_fetch.log 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python bench.py --kernel-only --steps 20 --warmup 2 --streams 1 > $OUT/pmc_write.log 2>&1
+  python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write place_batch_kernel $OUT/pmc_place_batch_C3.json; cat $OUT/pmc_place_batch_C3.json ;;
+esac
+done
