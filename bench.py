@@ -324,6 +324,9 @@ def main():
     ap.add_argument("--streams", type=int, default=8,
                     help="HIP streams the timed steps are issued on round-robin (a 100k-decision batch is 1564 "
                          "wavefronts — too few to cover HBM latency on 256 CUs — so independent batches overlap)")
+    ap.add_argument("--leg-timeout", type=float, default=420.0,
+                    help="watchdog for the additional legs (pod axis, latency, churn, per-kernel, cpu baseline): when "
+                         "it fires rank 0 prints the line with the legs completed so far and every rank exits 0")
     ap.add_argument("--kernel-only", action="store_true",
                     help="skip the n=1 latency / host-boundary legs (used under rocprofv3 so that every "
                          "place_batch_kernel dispatch in the trace is a full batch)")
@@ -428,16 +431,10 @@ def main():
         want = OracleFleet(fleet).place(reqs, extra, fleet.now, threads=os.cpu_count() or 1)
         parity = bool(all(np.array_equal(got[f], want[f]) for f in ("chosen", "best", "n_candidates", "hash")))
 
-    # pod-axis sharded leg (all ranks take part; reported next to the model-axis headline)
-    pod_axis = []
-    if not args.no_pod_axis and not args.kernel_only:
-        legs = [args.workload] + (["C4"] if world >= 8 and args.workload != "C4" else [])
-        for wname in legs:
-            try:
-                pod_axis.append(pod_axis_leg(wname, rank, world, dev, max(args.steps // 10, 5), max(args.warmup // 10, 2), fence))
-            except Exception as e:  # the headline line must still be printed
-                pod_axis.append({"workload": wname, "error": f"{type(e).__name__}: {e}"})
-
+    # The headline is complete here.  Everything below is an additional leg; a watchdog makes sure the
+    # ONE JSON line is still printed (with the legs finished so far) if a leg hangs — e.g. a collective
+    # of the pod-axis leg on a node whose RCCL setup misbehaves — instead of losing the measurement.
+    line = None
     if rank == 0:
         total = n * args.steps * world
         value = total / elapsed
@@ -447,6 +444,7 @@ def main():
         # launch duration as rocprofv3 --kernel-trace sees it; the per-launch event pairs of the second
         # pass add ~2 us of event granularity and are reported next to it
         achieved = alg / (gpu_ms_per_step * 1e-3) / 1e9
+        traffic = measured_traffic(args.workload)
         line = {
             "metric": "placement decisions/sec at 100k models x 10k pods; p99 decision latency",
             "value": value, "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -457,7 +455,7 @@ def main():
                        "decisions_per_step_per_gpu": n, "sharding": "model axis, no collective",
                        "streams": n_streams},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "place_batch_kernel", "kernel_ms": gpu_ms_per_step,
                          "kernel_ms_per_launch_event_pairs": kern_ms,
                          "algorithmic_bytes_per_launch": alg,
@@ -466,16 +464,50 @@ def main():
                                  "kernel's own compulsory traffic is kernel_bytes_per_launch (frac_kernel = that / "
                                  "kernel time / peak) and `traffic` is the rocprofv3 FETCH_SIZE+WRITE_SIZE measurement",
                          "measured_traffic_rate_single_stream_GBs":
-                             None if measured_traffic(args.workload) is None else
-                             measured_traffic(args.workload) / (gpu_ms_per_step * 1e-3) / 1e9,
+                             None if traffic is None else traffic / (gpu_ms_per_step * 1e-3) / 1e9,
                          "measured_traffic_rate_timed_region_GBs":
-                             None if measured_traffic(args.workload) is None else
-                             measured_traffic(args.workload) * args.steps / elapsed / 1e9,
+                             None if traffic is None else traffic * args.steps / elapsed / 1e9,
                          "kernel_bytes_per_launch": kb,
                          "frac_kernel": kb / (gpu_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "parity_vs_oracle": parity,
-            "pod_axis": pod_axis,
         }
+
+    import threading
+    emit_lock = threading.Lock()
+    emitted = [False]
+
+    def emit(note=None):
+        with emit_lock:
+            if emitted[0]:
+                return
+            emitted[0] = True
+            if rank == 0:
+                if note:
+                    line["watchdog"] = note
+                print(json.dumps(line), flush=True)
+
+    def on_timeout():
+        emit(f"an additional leg did not finish within {args.leg_timeout:.0f} s; the line carries the legs completed so far")
+        os._exit(0)
+
+    dog = threading.Timer(args.leg_timeout, on_timeout)
+    dog.daemon = True
+    dog.start()
+
+    # pod-axis sharded leg (all ranks take part; reported next to the model-axis headline)
+    pod_axis = []
+    if not args.no_pod_axis and not args.kernel_only:
+        legs = [args.workload] + (["C4"] if world >= 8 and args.workload != "C4" else [])
+        for wname in legs:
+            try:
+                pod_axis.append(pod_axis_leg(wname, rank, world, dev, max(args.steps // 10, 5), max(args.warmup // 10, 2), fence))
+            except Exception as e:  # the headline line must still be printed
+                pod_axis.append({"workload": wname, "error": f"{type(e).__name__}: {e}"})
+            if rank == 0:
+                line["pod_axis"] = list(pod_axis)
+
+    if rank == 0:
+        line["pod_axis"] = pod_axis
         # single-decision latency through the host-pointer C ABI (n=1, PCIe + launch inclusive)
         lat = []
         one = reqs[:1].copy()
@@ -506,7 +538,11 @@ def main():
                 line["kernels"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline and not args.kernel_only:
             line["cpu_baseline"] = cpu_baseline(fleet, reqs, extra)
-        print(json.dumps(line), flush=True)
+    emit()
+    if world > 1:
+        # the other ranks wait for rank 0's single-process legs here, still under the watchdog
+        dist.barrier()
+    dog.cancel()
 
     solver.close()
     if world > 1:

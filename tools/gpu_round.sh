@@ -16,6 +16,11 @@ smoke)
 bench)
   timeout 900 python bench.py > $OUT/bench.json.log 2> $OUT/bench.err; echo "bench exit $?"
   python tools/benchline.py bench < $OUT/bench.json.log ;;
+bench2)
+  # the N>1 code path on a 1-GPU box: two ranks share cuda:0 over gloo (the driver's runs use RCCL, one GPU per rank)
+  MMP_BENCH_ONE_DEVICE=1 MMP_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+    --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 50 --warmup 5 > $OUT/bench2.json.log 2> $OUT/bench2.err; echo "bench2 exit $?"
+  tail -1 $OUT/bench2.json.log | cut -c1-600 ;;
 prof)
   rm -rf $OUT/prof
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --kernel-only --steps 200 --warmup 20 > $OUT/prof_bench.log 2>&1
