@@ -286,7 +286,7 @@ def secondary_kernels_leg(fleet, solver, device: int, reps: int = 5):
 
         # f-1 KV wire format: Jackson JSON of the instance table and of the registry, parsed on device
         ids = wire.make_ids(rng, P)
-        wf = wl.make_fleet("C3", models=min(M, 20_000))  # registry sample: the JSON is generated in Python
+        wf = wl.make_fleet("C3", models=min(M, 50_000))  # registry sample: the JSON is generated in Python
         wire.adopt_ids(wf, ids)
         pv = wire.pod_values(wf, rng, np.full(P, now - 1000, np.int64))
         mv = wire.model_values(wf, ids, ["NLCLASSIFIER"] + ["type-%d" % t for t in range(1, max(wf.n_types, 1))], rng,
@@ -301,10 +301,10 @@ def secondary_kernels_leg(fleet, solver, device: int, reps: int = 5):
                   pb + 64 * P, pb, "JSON bytes", "InstanceRecord JSON read once + 64 B row written", s=js)
             js.load_type_names(["NLCLASSIFIER"] + ["type-%d" % t for t in range(1, max(wf.n_types, 1))], 0)
             mb = sum(len(v) for v in mv)
-            timed("ingest_models_kernel<count> + offsets + <fill>", lambda: js.ingest_models_json(mv),
-                  2 * mb + 24 * wf.n_models + 12 * len(wf.ent_pod), mb, "JSON bytes",
-                  "ModelRecord JSON read twice (count pass, fill pass) + CSR registry written; "
-                  f"{wf.n_models} of the {M} registry values", s=js)
+            timed("ingest_models_kernel + rocprim scan + compact_entries_kernel", lambda: js.ingest_models_json(mv),
+                  mb + 24 * wf.n_models + 36 * len(wf.ent_pod), mb, "JSON bytes",
+                  "ModelRecord JSON read once + rows written + entries parked, read back and written to the CSR "
+                  f"arrays (12 B x 3 per entry); {wf.n_models} of the {M} registry values", s=js)
         finally:
             js.close()
     finally:

@@ -7,6 +7,7 @@
 // implementation of the path in this library.
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <atomic>
@@ -152,7 +153,8 @@ struct mmp_ctx {
     // wire-format ingestion: per-pod id attributes and the hash tables the parsers probe
     std::vector<uint32_t> id_order_v;
     std::vector<int32_t> replica_set_v;
-    DevBuf idtab_hash, idtab_val, tytab_hash, tytab_val, j_buf, j_off, j_rows, j_aux, j_status;
+    DevBuf idtab_hash, idtab_val, tytab_hash, tytab_val, j_buf, j_off, j_rows, j_aux, j_status, j_cnt, j_offs, j_tmp_pod, j_tmp_time,
+        j_scan_tmp;
     uint32_t idtab_mask = 0, tytab_mask = 0;
     bool have_ids = false, have_types = false;
     int32_t unknown_type = 0, default_type = 0;
@@ -341,7 +343,8 @@ void mmp_destroy(mmp_ctx *c)
                       &c->s_c, &c->s_d, &c->r_ps, &c->r_counts, &c->r_keys, &c->r_vals, &c->r_keys2, &c->r_vals2,
                       &c->r_tmp, &c->r_out_model, &c->r_out_lu, &c->k_cap, &c->k_wsize, &c->k_ubm, &c->k_ops, &c->k_order,
                       &c->k_opoff, &c->k_outs, &c->k_ev, &c->k_evoff, &c->idtab_hash, &c->idtab_val, &c->tytab_hash,
-                      &c->tytab_val, &c->j_buf, &c->j_off, &c->j_rows, &c->j_aux, &c->j_status, &c->ks[0].off, &c->ks[0].lu, &c->ks[0].wt,
+                      &c->tytab_val, &c->j_buf, &c->j_off, &c->j_rows, &c->j_aux, &c->j_status, &c->j_cnt, &c->j_offs, &c->j_tmp_pod,
+                      &c->j_tmp_time, &c->j_scan_tmp, &c->ks[0].off, &c->ks[0].lu, &c->ks[0].wt,
                       &c->ks[0].key, &c->ks[0].n, &c->ks[1].off, &c->ks[1].lu, &c->ks[1].wt, &c->ks[1].key, &c->ks[1].n})
         b->release();
     delete c;
@@ -764,6 +767,20 @@ int mmp_cluster_stats(mmp_ctx *c, mmp_stats *out)
 /* ---- wire-format ingestion (§8f-1) ------------------------------------------ */
 
 namespace {
+// Records per wavefront of the wave-path parsers: a group shares the lanes in the per-field phase (more
+// lanes busy), but fewer wavefronts are in flight; keep >= ~8 wavefronts per SIMD before growing the group.
+int ingest_group(int32_t n)
+{
+    static const int forced = [] {
+        const char *e = getenv("MMP_JGROUP");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced >= 1 && forced <= kJGroup) return forced;
+    int g = 1;
+    while (g < kJGroup && n / (g * 2) >= 8192) g *= 2;
+    return g;
+}
+
 // host side of the open-addressing table the device probes (ingest_kernels.hpp: tab_find)
 int build_hash_table(mmp_ctx *c, const char *strs, const int32_t *off, int32_t n, DevBuf &d_hash, DevBuf &d_val,
                      uint32_t &mask_out, const char *what)
@@ -861,7 +878,7 @@ int mmp_pods_ingest_json(mmp_ctx *c, const char *buf, const int64_t *off, int32_
     const int64_t bytes = off[n] - off[0];
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     hipStream_t st = c->stream;
-    HIP_TRY(c, c->j_buf.ensure((size_t)std::max<int64_t>(bytes, 1)));
+    HIP_TRY(c, c->j_buf.ensure((size_t)bytes + 16));  // the wave path stages whole dwords
     HIP_TRY(c, c->j_off.ensure((size_t)(n + 1) * 8));
     HIP_TRY(c, c->j_rows.ensure((size_t)n * sizeof(mmp_pod_row)));
     HIP_TRY(c, c->j_aux.ensure((size_t)n * 8));
@@ -873,8 +890,9 @@ int mmp_pods_ingest_json(mmp_ctx *c, const char *buf, const int64_t *off, int32_
     HIP_TRY(c, hipMemcpyAsync(c->j_rows.p, rows.data(), (size_t)n * sizeof(mmp_pod_row), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemsetAsync(c->j_aux.p, 0, (size_t)n * 8, st));
     KT_BEGIN(c, st);
-    hipLaunchKernelGGL(ingest_pods_kernel, dim3(div_up(n, 128)), dim3(128), 0, st, c->j_buf.as<char>(), c->j_off.as<int64_t>(), n,
-                       c->j_rows.as<mmp_pod_row>(), c->j_aux.as<int64_t>(), c->j_status.as<int32_t>());
+    const int grp = ingest_group(n);
+    hipLaunchKernelGGL(ingest_pods_kernel, dim3(div_up(n, kJWaves * grp)), dim3(kJBlock), 0, st, c->j_buf.as<char>(), c->j_off.as<int64_t>(), n,
+                       grp, c->j_rows.as<mmp_pod_row>(), c->j_aux.as<int64_t>(), c->j_status.as<int32_t>());
     KT_END(c, st);
     HIP_TRY(c, hipGetLastError());
     std::vector<int64_t> stt(n);
@@ -930,7 +948,7 @@ int mmp_models_ingest_json(mmp_ctx *c, const char *buf, const int64_t *off, int3
     for (int32_t i = 0; i < n; i++)
         if (off[i + 1] < off[i]) return fail(c, MMP_EINVAL, "mmp_models_ingest_json: offsets not monotone at %d", i);
     const int64_t bytes = off[n] - off[0];
-    HIP_TRY(c, c->j_buf.ensure((size_t)std::max<int64_t>(bytes, 1)));
+    HIP_TRY(c, c->j_buf.ensure((size_t)bytes + 16));  // the wave path stages whole dwords
     HIP_TRY(c, c->j_off.ensure((size_t)(n + 1) * 8));
     HIP_TRY(c, c->j_aux.ensure((size_t)n * 8 + 8));
     HIP_TRY(c, c->j_status.ensure((size_t)n * 4));
@@ -952,21 +970,34 @@ int mmp_models_ingest_json(mmp_ctx *c, const char *buf, const int64_t *off, int3
     A.rows = c->models.as<mmp_model_row>();
     A.last_unload = c->j_aux.as<int64_t>();
     A.status = c->j_status.as<int32_t>();
-    int32_t *d_total = reinterpret_cast<int32_t *>(c->j_aux.as<int64_t>() + n);
-    KT_BEGIN(c, st);  // spans both passes and the 4-byte read-back of the entry total between them
-    hipLaunchKernelGGL(ingest_models_kernel<0>, dim3(div_up(n, 128)), dim3(128), 0, st, A);
-    hipLaunchKernelGGL(model_offsets_kernel, dim3(1), dim3(1024), 0, st, A.rows, n, d_total);
-    HIP_TRY(c, hipGetLastError());
-    int32_t total = 0;
-    HIP_TRY(c, hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    HIP_TRY(c, c->ent_pod.ensure((size_t)std::max(total, 1) * 4));
-    HIP_TRY(c, c->ent_time.ensure((size_t)std::max(total, 1) * 8));
-    A.ent_pod = c->ent_pod.as<int32_t>();
-    A.ent_time = c->ent_time.as<int64_t>();
-    hipLaunchKernelGGL(ingest_models_kernel<1>, dim3(div_up(n, 128)), dim3(128), 0, st, A);
+    // one pass: every record's entries are parked at slot off / 6 (an entry takes >= 6 bytes of JSON), the
+    // counts are scanned, and the entries move to their CSR position — no host round trip in between
+    const size_t ent_cap = (size_t)(bytes / 6 + 2);
+    HIP_TRY(c, c->j_tmp_pod.ensure(ent_cap * 4));
+    HIP_TRY(c, c->j_tmp_time.ensure(ent_cap * 8));
+    HIP_TRY(c, c->ent_pod.ensure(ent_cap * 4));
+    HIP_TRY(c, c->ent_time.ensure(ent_cap * 8));
+    HIP_TRY(c, c->j_cnt.ensure((size_t)(n + 1) * 4));
+    HIP_TRY(c, c->j_offs.ensure((size_t)(n + 1) * 4));
+    size_t scan_bytes = 0;
+    HIP_TRY(c, rocprim::exclusive_scan(nullptr, scan_bytes, c->j_cnt.as<int32_t>(), c->j_offs.as<int32_t>(), (int32_t)0,
+                                       (size_t)n + 1, rocprim::plus<int32_t>(), st));
+    HIP_TRY(c, c->j_scan_tmp.ensure(std::max<size_t>(scan_bytes, 16)));
+    HIP_TRY(c, hipMemsetAsync(c->j_cnt.as<int32_t>() + n, 0, 4, st));
+    A.cnt = c->j_cnt.as<int32_t>();
+    A.ent_pod = c->j_tmp_pod.as<int32_t>();
+    A.ent_time = c->j_tmp_time.as<int64_t>();
+    A.grp = ingest_group(n);
+    KT_BEGIN(c, st);
+    hipLaunchKernelGGL(ingest_models_kernel, dim3(div_up(n, kJWaves * A.grp)), dim3(kJBlock), 0, st, A);
+    HIP_TRY(c, rocprim::exclusive_scan(c->j_scan_tmp.p, scan_bytes, c->j_cnt.as<int32_t>(), c->j_offs.as<int32_t>(), (int32_t)0,
+                                       (size_t)n + 1, rocprim::plus<int32_t>(), st));
+    hipLaunchKernelGGL(compact_entries_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, A.off, n, A.cnt, c->j_offs.as<int32_t>(),
+                       A.ent_pod, A.ent_time, A.rows, c->ent_pod.as<int32_t>(), c->ent_time.as<int64_t>());
     KT_END(c, st);
     HIP_TRY(c, hipGetLastError());
+    int32_t total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total, c->j_offs.as<int32_t>() + n, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(status_out, c->j_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     if (last_unload_out) HIP_TRY(c, hipMemcpyAsync(last_unload_out, c->j_aux.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));

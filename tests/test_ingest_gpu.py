@@ -96,3 +96,130 @@ def test_models_with_unknown_ids_and_malformed_values():
         assert list(rows["last_used"]) == [9, 0, 3, 0, 0]
     finally:
         s.close()
+
+
+def _ids_for(n):
+    return ["p%d" % i for i in range(n)]
+
+
+def test_records_beyond_one_round_and_beyond_the_lds_tile():
+    """> 64 map entries (several lane rounds of the wave path), > 64 fields, and values longer than the
+    2 KB LDS tile (walked by one lane): same rows as a JSON library."""
+    rng = np.random.default_rng(77)
+    n_pods = 400
+    ids = _ids_for(n_pods)
+    s = Solver(100, 1000)
+    try:
+        s.load_pod_ids(ids)
+        s.load_type_names(["NLCLASSIFIER", "t1"], unknown_type=0)
+        recs = []
+        for n_inst, n_fail, junk in ((100, 0, 0), (64, 65, 0), (3, 2, 90), (300, 5, 0), (0, 0, 0), (129, 128, 3)):
+            inst = sorted(rng.choice(n_pods, n_inst, replace=False).tolist(), key=lambda p: ids[p])
+            fail = sorted(rng.choice(n_pods, n_fail, replace=False).tolist(), key=lambda p: ids[p])
+            d = {"type": "t1", "lu": int(rng.integers(1, 10**12))}
+            for k in range(junk):  # > 64 top-level fields
+                d["x%d" % k] = [k, {"y": "a,b:{c}"}]
+            d["instanceIds"] = {ids[p]: int(rng.integers(1, 10**12)) for p in inst}
+            d["failedIn"] = {ids[p]: int(rng.integers(1, 10**12)) for p in fail}
+            d["lul"] = 7
+            recs.append((d, inst, fail))
+        vals = [json.dumps(d, separators=[(",", ":"), (", ", ": ")][i % 2]) for i, (d, _, _) in enumerate(recs)]
+        assert max(map(len, vals)) > 2048 > min(map(len, vals))
+        status, lul = s.ingest_models_json(vals)
+        assert not status.any()
+        rows, ep, et = s.get_models()
+        off = 0
+        for i, (d, inst, fail) in enumerate(recs):
+            assert (rows["type"][i], rows["n_loaded"][i], rows["n_failed"][i], rows["ent_off"][i], rows["last_used"][i]) == \
+                (1, len(inst), len(fail), off, d["lu"]), i
+            assert list(ep[off: off + len(inst) + len(fail)]) == inst + fail, i
+            assert list(et[off: off + len(inst) + len(fail)]) == list(d["instanceIds"].values()) + list(d["failedIn"].values())
+            assert lul[i] == 7
+            off += len(inst) + len(fail)
+        # an InstanceRecord with a label list longer than the tile
+        big = json.dumps({"count": 3, "labels": ["label-%04d" % k for k in range(300)], "cap": 99, "lruTime": 12345678901234})
+        assert len(big) > 2048
+        st, stt = s.ingest_pods_json([big, '{"cap":5}'], np.array([3, 4], np.int32), np.ones(2, np.uint8))
+        assert list(st) == [0, 0]
+        got = s.get_pods()
+        assert (got["count"][3], got["capacity"][3], got["lru_time"][3]) == (3, 99, 12345678901234) and got["capacity"][4] == 5
+    finally:
+        s.close()
+
+
+MALFORMED_MODELS = [
+    '',                                                         # empty value
+    '   ',
+    '[]',                                                       # not an object
+    '{"lu": 5',                                                 # truncated
+    '{"lu": 5}}',                                               # closes twice
+    '{"lu": 5} {"lu": 6}',                                      # two values
+    '{"lu": 5,}',                                               # trailing comma
+    '{"lu": 5 "lul": 6}',                                       # missing comma
+    '{"lu": 5,, "lul": 6}',                                     # doubled comma
+    '{"lu" 5}',                                                 # missing colon
+    '{lu: 5}',                                                  # key is not a string
+    '{"lu": "5"}',                                              # wrong type for a long
+    '{"lu": 5.5}',
+    '{"lu": 1e3}',
+    '{"lu": -}',
+    '{"lu": }',
+    '{"instanceIds": 5}',                                       # map expected
+    '{"instanceIds": ["p1"]}',
+    '{"instanceIds": {"p1": 5]}',                               # wrong closer
+    '{"instanceIds": {"p1": 5,}}',
+    '{"instanceIds": {"p1": 5 "p2": 6}}',
+    '{"instanceIds": {"p1": {"x": 1}}}',                        # entry value is not a long
+    '{"instanceIds": {"p1": "5"}}',
+    '{"instanceIds": {p1: 5}}',
+    '{"failedIn": {"p1": }}',
+    '{"type": "t1" x}',
+    '{"type": "t1',                                             # unterminated string
+    '{"mPath": "a\\"}',                                         # the escaped quote leaves the string open
+]
+
+WELL_FORMED_MODELS = [
+    ('{}', (0, 0, 0, 0)),
+    ('  {\n}\t', (0, 0, 0, 0)),
+    ('{"lu":5,"lu":6}', (0, 0, 0, 6)),                          # a later duplicate wins (Jackson's default)
+    ('{"instanceIds":{"p1":1},"instanceIds":{"p2":2,"p3":3}}', (0, 2, 0, 0)),
+    ('{"instanceIds":null,"failedIn":null,"type":null}', (0, 0, 0, 0)),
+    ('{"instanceIds":{ },"failedIn":{}}', (0, 0, 0, 0)),
+    ('{"type":"t1","mPath":"a\\\\","lu":-3}', (1, 0, 0, -3)),   # the string ends after an escaped backslash
+    ('{"x":{"instanceIds":{"p1":1}},"lu":2}', (0, 0, 0, 2)),    # a nested look-alike is not the field
+    ('{"x":"\\"lu\\":9,","lu":2}', (0, 0, 0, 2)),               # nor is one inside a string
+    ('{"fails":{"p1":{"msg":"}{][","t":5}},"failedIn":{"p1":4}}', (0, 0, 1, 0)),
+]
+
+
+def test_malformed_and_edge_case_values():
+    s = Solver(100, 1000)
+    try:
+        s.load_pod_ids(_ids_for(8))
+        s.load_type_names(["NLCLASSIFIER", "t1"], unknown_type=0)
+        for v in MALFORMED_MODELS:
+            try:
+                d = json.loads(v)
+                ok = isinstance(d, dict) and all(isinstance(d.get(k, 0), int) for k in ("lu", "lul")) and all(
+                    d.get(k) is None or (isinstance(d[k], dict) and all(isinstance(x, int) for x in d[k].values()))
+                    for k in ("instanceIds", "failedIn"))
+            except ValueError:
+                ok = False
+            assert not ok, v  # the list really is malformed for the bean
+        vals = MALFORMED_MODELS + [v for v, _ in WELL_FORMED_MODELS]
+        status, _ = s.ingest_models_json(vals)
+        nb = len(MALFORMED_MODELS)
+        assert list(status[:nb]) == [1] * nb, [v for v, st in zip(vals, status) if not st][:5]
+        assert not status[nb:].any(), [v for v, st in zip(vals[nb:], status[nb:]) if st]
+        rows, ep, et = s.get_models()
+        for i, (v, want) in enumerate(WELL_FORMED_MODELS):
+            r = rows[nb + i]
+            assert (r["type"], r["n_loaded"], r["n_failed"], r["last_used"]) == want, v
+        assert list(rows["n_loaded"][:nb]) == [0] * nb and list(rows["n_failed"][:nb]) == [0] * nb
+        # pods: same classes on the InstanceRecord parser
+        pv = ['{"count":3,"cap":10}', '{"count":3,"cap":10', '{"count":"3"}', '{"shutdown":1}', '{"shutdown":true,"rpm":4}',
+              '{"count":3 "cap":10}', '{}', '{"labels":["a","b"],"count":2}', '{"count":2,}', 'null']
+        st, _ = s.ingest_pods_json(pv, np.arange(len(pv), dtype=np.int32) % 8, np.ones(len(pv), np.uint8))
+        assert list(st) == [0, 1, 1, 1, 0, 1, 0, 0, 1, 1]
+    finally:
+        s.close()

@@ -30,5 +30,11 @@ pmc)
   timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python bench.py --kernel-only --steps 20 --warmup 2 --streams 1 > $OUT/pmc_fetch.log 2>&1
   timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python bench.py --kernel-only --steps 20 --warmup 2 --streams 1 > $OUT/pmc_write.log 2>&1
   python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write place_batch_kernel $OUT/pmc_place_batch_C3.json; cat $OUT/pmc_place_batch_C3.json ;;
+sq)
+  # SQ counters of one kernel of an arbitrary command: SQ_KERNEL=<substring> SQ_CMD="python ..." bash tools/gpu_round.sh sq
+  rm -rf $OUT/sq1 $OUT/sq2
+  timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $OUT/sq1 -- $SQ_CMD > $OUT/sq1.log 2>&1
+  timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM --kernel-trace --output-format csv -d $OUT/sq2 -- $SQ_CMD > $OUT/sq2.log 2>&1
+  python tools/sq_summary.py $OUT/sq1 "$SQ_KERNEL"; python tools/sq_summary.py $OUT/sq2 "$SQ_KERNEL" ;;
 esac
 done
