@@ -99,77 +99,105 @@ struct EvictArgs {
 
 // AddTask.run → evictionDeque.insert → evict()
 // (clhm/ConcurrentLinkedHashMap.java:590-611,329-352; clhm/LinkedDeque.java:259-288).
-// One wave per request: ballot for the insertion point, wave prefix-sum of the
-// merged weight sequence for the victim count.
-__global__ __launch_bounds__(256) void evict_batch_kernel(EvictArgs A)
+// A pod's deque holds ~2M/P entries (20 at C3), so a whole wavefront per evaluation leaves two thirds of
+// the lanes idle (measured: 39 us per 100k evaluations, VALU-issue bound).  Four evaluations share a
+// wavefront instead, 16 lanes each: the team's slice of a ballot finds the insertion point, a 16-lane
+// prefix sum of the merged weight sequence finds the victim count.
+constexpr int kEvTeam = 16;
+constexpr int kEvBlock = 256;
+constexpr int kEvPerBlock = kEvBlock / kEvTeam;
+
+__device__ __forceinline__ int64_t team_sum_i64(int64_t v)
 {
     const int lane = lane_id();
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (i >= A.n) return;
-    const mmp_evict_req r = A.reqs[i];
-    mmp_evict_out o;
-    o.insert_pos = 0; o.n_victims = 0; o.self_evicted = 0; o.pad = 0; o.weighted_size = 0; o.oldest_time = -1;
-    if (r.cache < 0 || r.cache >= A.n_caches) {
-        if (lane == 0) A.outs[i] = o;
-        return;
+#pragma unroll
+    for (int o = kEvTeam / 2; o > 0; o >>= 1) v += (int64_t)shfl_u64((uint64_t)v, lane ^ o);
+    return v;
+}
+
+__global__ __launch_bounds__(kEvBlock) void evict_batch_kernel(EvictArgs A)
+{
+    const int lane = lane_id();
+    const int team = lane >> 4, tl = lane & (kEvTeam - 1), tbase = team * kEvTeam;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) / kEvTeam;
+    const bool in_range = i < A.n;
+    mmp_evict_req r;
+    r.cache = -1;
+    r.weight = 0;
+    r.last_used = 0;
+    if (in_range) r = A.reqs[i];
+    const bool valid = in_range && r.cache >= 0 && r.cache < A.n_caches;
+    int s0 = 0, E = 0;
+    int64_t cap = 0;
+    if (valid) {
+        s0 = A.seg_off[r.cache];
+        E = A.seg_off[r.cache + 1] - s0;
+        cap = A.capacity[r.cache];
     }
-    const int s0 = A.seg_off[r.cache], E = A.seg_off[r.cache + 1] - s0;
     const int64_t *lu = A.last_used + s0;
     const int32_t *wt = A.weight + s0;
-    const int64_t cap = A.capacity[r.cache];
     const int64_t ts = r.last_used == 0 ? A.now : r.last_used;  // Node ctor / touch, clhm :1357-1360
+    int emax = E;  // the four teams loop together
+#pragma unroll
+    for (int o = 32; o >= kEvTeam; o >>= 1) {
+        const int t = __shfl_xor(emax, o, 64);
+        emax = t > emax ? t : emax;
+    }
 
     // insert(): walk from the tail to the first node with lastUsed <= ts, link after it
     int pos = 0;
     int64_t sum = 0;
-    for (int base = 0; base < E; base += 64) {
-        const int j = base + lane;
+    for (int base = 0; base < emax; base += kEvTeam) {
+        const int j = base + tl;
         const bool le = j < E && lu[j] <= ts;
-        const uint64_t b = __ballot(le);
-        if (b) pos = base + (63 - __clzll((unsigned long long)b)) + 1;
+        const uint32_t tb = (uint32_t)(__ballot(le) >> tbase) & 0xffffu;
+        if (tb) pos = base + (31 - __clz(tb)) + 1;
         sum += j < E ? (int64_t)wt[j] : 0;
     }
-    sum = wave_sum_i64(sum);
+    sum = team_sum_i64(sum);
     const int64_t total = sum + (int64_t)r.weight;  // weightedSize + weight, clhm :603
 
     // evict(): poll the head while weightedSize > capacity
-    int n_victims = 0;
-    int64_t after = total;
-    if (total > cap) {
-        int64_t carry = 0;
-        n_victims = E + 1;
-        after = 0;
-        bool done = false;
-        for (int base = 0; base <= E && !done; base += 64) {
-            const int j = base + lane;
-            int64_t w = 0;
-            if (j <= E) w = j < pos ? (int64_t)wt[j] : (j == pos ? (int64_t)r.weight : (int64_t)wt[j - 1]);
-            // inclusive scan of 64-bit weights
-            int64_t incl = w;
+    const bool need = valid && total > cap;
+    int n_victims = need ? E + 1 : 0;
+    int64_t after = need ? 0 : total;
+    int64_t carry = 0;
+    bool done = !need;
+    for (int base = 0; base <= emax; base += kEvTeam) {
+        if (__ballot(!done) == 0) break;
+        const int j = base + tl;
+        int64_t w = 0;
+        if (need && j <= E) w = j < pos ? (int64_t)wt[j] : (j == pos ? (int64_t)r.weight : (int64_t)wt[j - 1]);
+        int64_t incl = w;  // inclusive scan of the team's 64-bit weights
 #pragma unroll
-            for (int o2 = 1; o2 < 64; o2 <<= 1) {
-                const int64_t t = (int64_t)shfl_u64((uint64_t)incl, lane >= o2 ? lane - o2 : lane);
-                if (lane >= o2) incl += t;
-            }
-            const int64_t left = total - (carry + incl);
-            const uint64_t b = __ballot(j <= E && left <= cap);
-            if (b) {
-                const int l = __ffsll((unsigned long long)b) - 1;
-                n_victims = base + l + 1;
-                after = (int64_t)shfl_u64((uint64_t)left, l);
-                done = true;
-            }
-            carry += (int64_t)shfl_u64((uint64_t)incl, 63);
+        for (int o2 = 1; o2 < kEvTeam; o2 <<= 1) {
+            const int64_t t = (int64_t)shfl_u64((uint64_t)incl, tl >= o2 ? lane - o2 : lane);
+            if (tl >= o2) incl += t;
         }
+        const int64_t left = total - (carry + incl);
+        const uint32_t tb = (uint32_t)(__ballot(!done && j <= E && left <= cap) >> tbase) & 0xffffu;
+        const int l = tb ? __ffs(tb) - 1 : 0;
+        const int64_t left_at = (int64_t)shfl_u64((uint64_t)left, tbase + l);
+        const int64_t last_incl = (int64_t)shfl_u64((uint64_t)incl, tbase + kEvTeam - 1);
+        if (tb && !done) {
+            n_victims = base + l + 1;
+            after = left_at;
+            done = true;
+        }
+        carry += last_incl;
     }
-    if (lane == 0) {
-        o.insert_pos = pos;
-        o.n_victims = n_victims;
-        o.self_evicted = n_victims > pos ? 1 : 0;
-        o.weighted_size = after;
-        // oldestTime(): head of what is left, clhm :1125-1133
-        const int h = n_victims;  // merged index of the new head
-        if (h <= E) o.oldest_time = h < pos ? lu[h] : (h == pos ? ts : lu[h - 1]);
+    if (in_range && tl == 0) {
+        mmp_evict_out o;
+        o.insert_pos = 0; o.n_victims = 0; o.self_evicted = 0; o.pad = 0; o.weighted_size = 0; o.oldest_time = -1;
+        if (valid) {
+            o.insert_pos = pos;
+            o.n_victims = n_victims;
+            o.self_evicted = n_victims > pos ? 1 : 0;
+            o.weighted_size = after;
+            // oldestTime(): head of what is left, clhm :1125-1133
+            const int h = n_victims;  // merged index of the new head
+            if (h <= E) o.oldest_time = h < pos ? lu[h] : (h == pos ? ts : lu[h - 1]);
+        }
         A.outs[i] = o;
     }
 }

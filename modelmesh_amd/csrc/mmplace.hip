@@ -1901,7 +1901,7 @@ int mmp_evict_batch(mmp_ctx *c, const mmp_evict_req *reqs, int32_t n, int64_t no
     A.n_caches = c->n_caches;
     A.now = now;
     KT_BEGIN(c, st);
-    hipLaunchKernelGGL(evict_batch_kernel, dim3(div_up(n, 4)), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(evict_batch_kernel, dim3(div_up(n, kEvPerBlock)), dim3(kEvBlock), 0, st, A);
     KT_END(c, st);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(outs, c->s_outs.p, (size_t)n * sizeof(mmp_evict_out), hipMemcpyDeviceToHost, st));
