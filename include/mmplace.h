@@ -502,6 +502,29 @@ int mmp_shard_commit_dev(mmp_ctx *ctx, const void *d_rank);
 int mmp_shard_place_phase_dev(mmp_ctx *ctx, int32_t phase, const void *d_reqs, int32_t n, const void *d_extra_pool,
                               int64_t now_ms, void *const *d_xchg, void *d_outs, void *stream);
 
+/* The speculative single-exchange form in front of the phases above (csrc/shard_kernels.hpp).  The head of
+ * PLACEMENT_ORDER decides almost every request, so each shard first runs the complete lane-per-decision
+ * getNext on its own slice and publishes, per decision, mmp_shard_fast_slots() int64 words: INT64_MAX = "no
+ * eligible pod in my slice", otherwise its result keyed by the shard number, with an "incomplete" bit when
+ * the shortlist runs off the end of the slice or the decision needs the general path.  After ONE
+ * all-reduce(MIN) of d_xf[n * slots] the lowest shard holding an eligible pod has won every slot:
+ *
+ *   mmp_shard_place_fast_dev(ctx, d_reqs, n, d_extra, now, d_xf, stream)        -> all-reduce MIN d_xf
+ *   mmp_shard_place_fast_finish_dev(..., &n_rest, &d_rest_reqs, &d_rest_outs)      writes the decided rows of
+ *        d_outs, compacts the undecided requests (same order on every shard) into library-owned device
+ *        buffers and synchronises `stream` to return their number
+ *   if n_rest: phases 1..7 of mmp_shard_place_phase_dev on (d_rest_reqs, n_rest, d_rest_outs), then
+ *        mmp_shard_place_fast_scatter_dev(ctx, n_rest, d_outs, stream)             rows back into d_outs
+ *
+ * One batch in flight per shard context (the rest buffers belong to the context).  Results are
+ * bit-identical to mmp_place_batch. */
+int32_t mmp_shard_fast_slots(void);
+int mmp_shard_place_fast_dev(mmp_ctx *ctx, const void *d_reqs, int32_t n, const void *d_extra_pool, int64_t now_ms,
+                             void *d_xf, void *stream);
+int mmp_shard_place_fast_finish_dev(mmp_ctx *ctx, const void *d_reqs, int32_t n, const void *d_xf, void *d_outs,
+                                    void *stream, int32_t *n_rest_out, void **d_rest_reqs_out, void **d_rest_outs_out);
+int mmp_shard_place_fast_scatter_dev(mmp_ctx *ctx, int32_t n_rest, void *d_outs, void *stream);
+
 /* Wait for everything queued on the context's own stream. */
 int mmp_sync(mmp_ctx *ctx);
 

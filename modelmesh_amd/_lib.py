@@ -154,6 +154,11 @@ SYMBOLS = [
     ("mmp_shard_rank_dev", C.c_int, [_P, _P]),
     ("mmp_shard_commit_dev", C.c_int, [_P, _P]),
     ("mmp_shard_place_phase_dev", C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int64, _P, _P, _P]),
+    ("mmp_shard_fast_slots", C.c_int32, []),
+    ("mmp_shard_place_fast_dev", C.c_int, [_P, _P, C.c_int32, _P, C.c_int64, _P, _P]),
+    ("mmp_shard_place_fast_finish_dev", C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_void_p),
+                                                  C.POINTER(C.c_void_p)]),
+    ("mmp_shard_place_fast_scatter_dev", C.c_int, [_P, C.c_int32, _P, _P]),
     ("mmp_sync", C.c_int, [_P]),
     ("mmp_profile", C.c_int, [_P, C.c_int]),
     ("mmp_last_kernel_ms", C.c_double, [_P]),

@@ -125,6 +125,8 @@ struct mmp_ctx {
     // `ssnap` only; n_shards == 0 means the ordinary single-device snapshot
     int32_t shard = 0, n_shards = 0;
     ShardSnap ssnap{};
+    Snap sview{};  // the lane path's view of this shard's slice (place_shard_fast_kernel)
+    DevBuf f_flags, f_offs, f_idx, f_reqs, f_outs, f_scan_tmp;  // speculative form: the compacted rest of a batch
     bool rank_pending = false;
 
     // commit scratch
@@ -254,6 +256,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     A.n_models = c->n_models;
     A.now = now;
     A.force_wave = c->force_wave;
+    A.n_pods_all = c->snap.P;
     const int wpad = (c->snap.W + 1) & ~1;
     const size_t lds = (size_t)kPlaceWaves * 2 * wpad * sizeof(uint64_t);
     if (lds > 60 * 1024) return fail(c, MMP_EINVAL, "instance table too large for the LDS staging tile (%d pods)", c->snap.P);
@@ -344,7 +347,8 @@ void mmp_destroy(mmp_ctx *c)
                       &c->r_tmp, &c->r_out_model, &c->r_out_lu, &c->k_cap, &c->k_wsize, &c->k_ubm, &c->k_ops, &c->k_order,
                       &c->k_opoff, &c->k_outs, &c->k_ev, &c->k_evoff, &c->idtab_hash, &c->idtab_val, &c->tytab_hash,
                       &c->tytab_val, &c->j_buf, &c->j_off, &c->j_rows, &c->j_aux, &c->j_status, &c->j_cnt, &c->j_offs, &c->j_tmp_pod,
-                      &c->j_tmp_time, &c->j_scan_tmp, &c->ks[0].off, &c->ks[0].lu, &c->ks[0].wt,
+                      &c->j_tmp_time, &c->j_scan_tmp, &c->f_flags, &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp,
+                      &c->ks[0].off, &c->ks[0].lu, &c->ks[0].wt,
                       &c->ks[0].key, &c->ks[0].n, &c->ks[1].off, &c->ks[1].lu, &c->ks[1].wt, &c->ks[1].key, &c->ks[1].n})
         b->release();
     delete c;
@@ -1128,6 +1132,7 @@ int mmp_shard_commit_dev(mmp_ctx *c, const void *d_rank)
     HIP_TRY(c, B.pref.ensure((size_t)T * Wn1 * 8));
     HIP_TRY(c, B.has_pref.ensure(T));
     HIP_TRY(c, B.fullw.ensure((size_t)Wn1 * 8));
+    HIP_TRY(c, B.ge.ensure((size_t)kGeRows * Wn1 * 8));
     HIP_TRY(c, c->occupancy.ensure(padded_full * 4));
     HIP_TRY(c, c->flag.ensure(sizeof(int32_t)));
     HIP_TRY(c, c->stats_acc.ensure(sizeof(StatsAcc)));
@@ -1149,6 +1154,7 @@ int mmp_shard_commit_dev(mmp_ctx *c, const void *d_rank)
     HIP_TRY(c, hipMemsetAsync(B.elig_nors.p, 0, (size_t)T * Wn1 * 8, st));
     HIP_TRY(c, hipMemsetAsync(B.pref.p, 0, (size_t)T * Wn1 * 8, st));
     HIP_TRY(c, hipMemsetAsync(B.fullw.p, 0, (size_t)Wn1 * 8, st));
+    HIP_TRY(c, hipMemsetAsync(B.ge.p, 0, (size_t)kGeRows * Wn1 * 8, st));
 
     std::vector<uint8_t> hp(T, 0), ha(T, 0);
     for (int32_t t = 0; t < c->n_types; t++) {
@@ -1182,6 +1188,10 @@ int mmp_shard_commit_dev(mmp_ctx *c, const void *d_rank)
                                c->d_has_allowed.as<uint8_t>(), c->d_prefer.as<uint64_t>(), B.has_pref.as<uint8_t>(),
                                n_rs ? c->rs_bad.as<uint8_t>() : nullptr, B.elig.as<uint64_t>(),
                                B.elig_nors.as<uint64_t>(), B.pref.as<uint64_t>(), B.fullw.as<uint64_t>());
+        const int32_t P_local = std::max(0, std::min(P - w_lo * 64, Wn * 64));
+        if (Wn > 0)  // the count-threshold bitmaps of the slice (the lane path's count break)
+            hipLaunchKernelGGL(build_ge_kernel, dim3(div_up(kGeRows * Wn, 4)), dim3(256), 0, st, B.cnt.as<int32_t>(), P_local, Wn,
+                               B.ge.as<uint64_t>());
         hipLaunchKernelGGL(cluster_stats_kernel, dim3(std::min(div_up(P, 256), 512)), dim3(256), 0, st,
                            B.pods.as<mmp_pod_row>(), P, min_space, c->stats_acc.as<StatsAcc>());
         HIP_TRY(c, hipGetLastError());
@@ -1218,6 +1228,28 @@ int mmp_shard_commit_dev(mmp_ctx *c, const void *d_rank)
     S.has_pref = B.has_pref.as<uint8_t>();
     S.fullw = B.fullw.as<uint64_t>();
     c->ssnap = S;
+    Snap V{};  // the slice as the lane-per-decision path sees it: local positions, global pos_of
+    V.P = std::max(0, std::min(P - w_lo * 64, Wn * 64));
+    V.W = Wn;
+    V.T = T;
+    V.any_rs = S.any_rs;
+    V.min_space = min_space;
+    V.lru = S.lru;
+    V.rem = S.rem;
+    V.cnt = S.cnt;
+    V.rpm = S.rpm;
+    V.orig = S.orig;
+    V.pos_of = S.pos_of;
+    V.elig = S.elig;
+    V.elig_nors = S.elig_nors;
+    V.pref = S.pref;
+    V.has_pref = S.has_pref;
+    V.fullw = S.fullw;
+    V.ge = B.ge.as<uint64_t>();
+    V.pos_base = w_lo * 64;
+    V.w_base = w_lo;
+    V.more_after = (w_lo + Wn) * 64 < P ? 1 : 0;
+    c->sview = V;
     Snap M{};  // what the non-placement entry points read in shard mode
     M.P = P;
     M.W = W;
@@ -1257,6 +1289,7 @@ int mmp_shard_place_phase_dev(mmp_ctx *c, int32_t phase, const void *d_reqs, int
     A.n_models = c->n_models;
     A.now = now;
     A.force_wave = 0;
+    A.n_pods_all = c->ssnap.P;
     XchgPtrs X{static_cast<int64_t *>(d_xchg[0]), static_cast<int64_t *>(d_xchg[1]), static_cast<int64_t *>(d_xchg[2]),
                static_cast<int64_t *>(d_xchg[3]), static_cast<int64_t *>(d_xchg[4]), static_cast<int64_t *>(d_xchg[5])};
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1275,6 +1308,90 @@ int mmp_shard_place_phase_dev(mmp_ctx *c, int32_t phase, const void *d_reqs, int
     case 6: hipLaunchKernelGGL(place_shard_kernel<6>, grid, block, lds, st, S, A, X, wpad); break;
     default: hipLaunchKernelGGL(place_shard_finish_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, S, A, X); break;
     }
+    HIP_TRY(c, hipGetLastError());
+    return MMP_OK;
+}
+
+int32_t mmp_shard_fast_slots(void) { return kXF; }
+
+namespace {
+PlaceArgs shard_args(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs)
+{
+    PlaceArgs A;
+    A.reqs = static_cast<const mmp_place_req *>(d_reqs);
+    A.models = c->models.as<mmp_model_row>();
+    A.rmodels = nullptr;
+    A.ent_pod = c->ent_pod.as<int32_t>();
+    A.extra = static_cast<const int32_t *>(d_extra);
+    A.outs = static_cast<mmp_place_out *>(d_outs);
+    A.n = n;
+    A.n_models = c->n_models;
+    A.now = now;
+    A.force_wave = 0;
+    A.n_pods_all = c->ssnap.P;
+    return A;
+}
+}  // namespace
+
+int mmp_shard_place_fast_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_xf,
+                             void *stream)
+{
+    if (!c || n < 0 || (n > 0 && (!d_reqs || !d_xf))) return fail(c, MMP_EINVAL, "mmp_shard_place_fast_dev: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->n_shards < 1 || !c->committed) return fail(c, MMP_ESTATE, "no committed shard snapshot");
+    if (n == 0) return MMP_OK;
+    const PlaceArgs A = shard_args(c, d_reqs, n, d_extra, now, nullptr);
+    hipLaunchKernelGGL(place_shard_fast_kernel, dim3(div_up(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), c->sview, A,
+                       c->shard, static_cast<int64_t *>(d_xf));
+    HIP_TRY(c, hipGetLastError());
+    return MMP_OK;
+}
+
+int mmp_shard_place_fast_finish_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_xf, void *d_outs, void *stream,
+                                    int32_t *n_rest_out, void **d_rest_reqs_out, void **d_rest_outs_out)
+{
+    if (!c || n < 0 || !n_rest_out || !d_rest_reqs_out || !d_rest_outs_out || (n > 0 && (!d_reqs || !d_xf || !d_outs)))
+        return fail(c, MMP_EINVAL, "mmp_shard_place_fast_finish_dev: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->n_shards < 1 || !c->committed) return fail(c, MMP_ESTATE, "no committed shard snapshot");
+    *n_rest_out = 0;
+    *d_rest_reqs_out = *d_rest_outs_out = nullptr;
+    if (n == 0) return MMP_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(c, c->f_flags.ensure((size_t)(n + 1) * 4));
+    HIP_TRY(c, c->f_offs.ensure((size_t)(n + 1) * 4));
+    HIP_TRY(c, c->f_idx.ensure((size_t)n * 4));
+    HIP_TRY(c, c->f_reqs.ensure((size_t)n * sizeof(mmp_place_req)));
+    HIP_TRY(c, c->f_outs.ensure((size_t)n * sizeof(mmp_place_out)));
+    size_t scan_bytes = 0;
+    HIP_TRY(c, rocprim::exclusive_scan(nullptr, scan_bytes, c->f_flags.as<int32_t>(), c->f_offs.as<int32_t>(), (int32_t)0,
+                                       (size_t)n + 1, rocprim::plus<int32_t>(), st));
+    HIP_TRY(c, c->f_scan_tmp.ensure(std::max<size_t>(scan_bytes, 16)));
+    hipLaunchKernelGGL(place_shard_fast_finish_kernel, dim3(div_up(n + 1, 256)), dim3(256), 0, st, static_cast<const int64_t *>(d_xf),
+                       n, c->ssnap.any_rs, static_cast<mmp_place_out *>(d_outs), c->f_flags.as<int32_t>());
+    HIP_TRY(c, rocprim::exclusive_scan(c->f_scan_tmp.p, scan_bytes, c->f_flags.as<int32_t>(), c->f_offs.as<int32_t>(), (int32_t)0,
+                                       (size_t)n + 1, rocprim::plus<int32_t>(), st));
+    hipLaunchKernelGGL(place_shard_gather_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, static_cast<const mmp_place_req *>(d_reqs),
+                       n, c->f_flags.as<int32_t>(), c->f_offs.as<int32_t>(), c->f_reqs.as<mmp_place_req>(), c->f_idx.as<int32_t>());
+    HIP_TRY(c, hipGetLastError());
+    int32_t n_rest = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n_rest, c->f_offs.as<int32_t>() + n, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    *n_rest_out = n_rest;
+    *d_rest_reqs_out = c->f_reqs.p;
+    *d_rest_outs_out = c->f_outs.p;
+    return MMP_OK;
+}
+
+int mmp_shard_place_fast_scatter_dev(mmp_ctx *c, int32_t n_rest, void *d_outs, void *stream)
+{
+    if (!c || n_rest < 0 || (n_rest > 0 && !d_outs)) return fail(c, MMP_EINVAL, "mmp_shard_place_fast_scatter_dev: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->n_shards < 1 || !c->committed) return fail(c, MMP_ESTATE, "no committed shard snapshot");
+    if (n_rest == 0) return MMP_OK;
+    hipLaunchKernelGGL(place_shard_scatter_kernel, dim3(div_up(n_rest, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       c->f_outs.as<mmp_place_out>(), c->f_idx.as<int32_t>(), n_rest, static_cast<mmp_place_out *>(d_outs));
     HIP_TRY(c, hipGetLastError());
     return MMP_OK;
 }

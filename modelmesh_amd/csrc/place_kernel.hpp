@@ -60,6 +60,7 @@ struct PlaceArgs {
     int32_t n_models;
     int64_t now;
     int32_t force_wave;  // diagnostics: hand every decision to the wave-per-decision kernel
+    int32_t n_pods_all;  // pod slots of the whole table (bounds of pos_of; == Snap::P unless the Snap is a shard view)
 };
 
 // (int)(double) with Java narrowing semantics
@@ -250,9 +251,23 @@ __device__ __forceinline__ void stage_eligible(const Snap &S, const uint64_t *sr
     wave_sync();
 }
 
+// global rank position -> position inside the view (-1: not in it); the identity on a whole snapshot
+__device__ __forceinline__ int32_t view_pos(const Snap &S, int32_t gpos)
+{
+    const int32_t l = gpos - S.pos_base;
+    return (l < 0 || l >= S.P) ? -1 : l;
+}
+
+// pod index -> position inside the view; P_all = pod slots of the whole table (== S.P on a whole snapshot)
+__device__ __forceinline__ int32_t pod_view_pos(const Snap &S, int32_t pod, int32_t P_all)
+{
+    return (pod >= 0 && pod < P_all) ? view_pos(S, S.pos_of[pod]) : -1;
+}
+
 // Follow request -> model row -> exclusion lists -> rank positions (one lane).
 __device__ __forceinline__ ResolvedReq resolve_one(const Snap &S, const PlaceArgs &A, int d)
 {
+    const int32_t P_all = A.n_pods_all;
     const mmp_place_req rq = A.reqs[d];
     ResolvedReq r;
     r.flags = rq.flags;
@@ -263,7 +278,7 @@ __device__ __forceinline__ ResolvedReq resolve_one(const Snap &S, const PlaceArg
     r.fresh_count = rq.fresh_count;
     r.fresh_rpm = rq.fresh_rpm;
     r.model = rq.model;
-    r.selfpos = (rq.self_pod >= 0 && rq.self_pod < S.P) ? S.pos_of[rq.self_pod] : -1;
+    r.selfpos = pod_view_pos(S, rq.self_pod, P_all);
     r.pad[0] = r.pad[1] = 0;
 #pragma unroll
     for (int i = 0; i < kInlineExcl; i++) r.excl_pos[i] = -1;
@@ -282,8 +297,7 @@ __device__ __forceinline__ ResolvedReq resolve_one(const Snap &S, const PlaceArg
 #pragma unroll
                 for (int i = 0; i < kInlineExcl; i++) {
                     if (i >= m.n_ents && i < r.n_excl) {
-                        const int32_t pod = A.extra[rq.extra_off + i - m.n_ents];
-                        r.excl_pos[i] = (pod >= 0 && pod < S.P) ? S.pos_of[pod] : -1;
+                        r.excl_pos[i] = pod_view_pos(S, A.extra[rq.extra_off + i - m.n_ents], P_all);
                     }
                 }
             }
@@ -298,7 +312,7 @@ __device__ __forceinline__ ResolvedReq resolve_one(const Snap &S, const PlaceArg
             for (int i = 0; i < kInlineExcl; i++) {
                 if (i < r.n_excl) {
                     const int32_t pod = i < n_ents ? A.ent_pod[m.ent_off + i] : A.extra[rq.extra_off + i - n_ents];
-                    r.excl_pos[i] = (pod >= 0 && pod < S.P) ? S.pos_of[pod] : -1;
+                    r.excl_pos[i] = pod_view_pos(S, pod, P_all);
                 }
             }
         }
@@ -378,8 +392,13 @@ __device__ __forceinline__ int lane_first(F f, int start, int stop)
     return kNoPos;
 }
 
-// Returns true when the decision has to go to the wave path; otherwise `o` is the result.
-__device__ __forceinline__ bool lane_decide(const Snap &S, const PlaceArgs &A, int d, mmp_place_out &o)
+// Outcome of lane_decide.  kLaneWave: the decision left the common shape and needs the general path.
+// The last two only on a shard view (VIEW = true): the view holds no eligible pod for this decision /
+// the view cannot decide it alone (a scan ran off the end of the view, or kLaneWave).
+enum { kLaneDone = 0, kLaneWave = 1, kLaneNoneHere = 2, kLaneIncomplete = 3 };
+
+template <bool VIEW>
+__device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, int d, mmp_place_out &o)
 {
     const ResolvedReq r = resolve_one(S, A, d);
     o.chosen = MMP_NONE;
@@ -406,6 +425,7 @@ __device__ __forceinline__ bool lane_decide(const Snap &S, const PlaceArgs &A, i
 
         const int best0 = lane_first(ew, 0, P);
         if (best0 == kNoPos) {
+            if (VIEW) return kLaneNoneHere;
             if (S.any_rs) fb = true;  // retry ignoring excludeReplicaSets, MM.java:4797-4804
             break;
         }
@@ -492,6 +512,7 @@ __device__ __forceinline__ bool lane_decide(const Snap &S, const PlaceArgs &A, i
             const int pc = lane_first(dc, start, end);
             end = pc < end ? pc : end;
         }
+        if (VIEW && S.more_after && end >= P) return kLaneIncomplete;  // the shortlist runs into the next shard
         const bool self_in_c = self_in_d && selfpos < end;
         if (self_in_c && favour) {  // :4931-4933
             o.chosen = MMP_SELF;
@@ -510,7 +531,7 @@ __device__ __forceinline__ bool lane_decide(const Snap &S, const PlaceArgs &A, i
         for (int w = wlo; w <= whi; w++) {
             const uint64_t v = cand(w);
             ccount += __popcll((unsigned long long)v);
-            if (v) hsum += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)(w + 1)));
+            if (v) hsum += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)(S.w_base + w + 1)));
         }
         int remaining = ccount;
         bool null0 = false, null_s = false, null_o = false;
@@ -555,7 +576,7 @@ __device__ __forceinline__ bool lane_decide(const Snap &S, const PlaceArgs &A, i
             if (!favour && cpos == selfpos) o.chosen = MMP_SELF;  // :4989-4991
         }
     } while (false);
-    return fb;
+    return fb ? (VIEW ? kLaneIncomplete : kLaneWave) : kLaneDone;
 }
 
 __device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int d, uint64_t *ew, uint64_t *fw)
@@ -843,7 +864,7 @@ __global__ __launch_bounds__(kPlaceBlock) void place_batch_kernel(Snap S, PlaceA
     const int d = blockIdx.x * kPlaceBlock + threadIdx.x;
     if (d < A.n) {
         mmp_place_out o;
-        if (lane_decide(S, A, d, o))
+        if (lane_decide<false>(S, A, d, o) != kLaneDone)
             fb_list[atomicAdd(&fb_n, 1)] = d;
         else
             A.outs[d] = o;

@@ -596,6 +596,90 @@ __global__ void place_shard_finish_kernel(ShardSnap S, PlaceArgs A, XchgPtrs X)
     A.outs[d] = o;
 }
 
+// ---- the speculative single-exchange form ---------------------------------------------------------
+// The head of PLACEMENT_ORDER decides almost every request: the first eligible pod and its whole
+// shortlist normally sit inside one shard's slice, and then that shard can run the complete
+// lane-per-decision getNext (place_kernel.hpp: lane_decide on a view of its slice) on its own.  So before
+// the six-exchange protocol above, every shard publishes per decision either "no eligible pod here"
+// (kXMax) or its local result keyed by its shard number, with an "incomplete" bit when a scan ran off the
+// end of its slice or the decision left the lane path's shape.  ONE all-reduce(MIN) of kXF int64 per
+// decision picks the result of the lowest shard that holds an eligible pod — which is the shard the
+// global walk would have started in.  Only decisions whose winner is incomplete (or that found no
+// eligible pod anywhere while replica sets are excluded: the retry of MM.java:4797-4804) go through the
+// general protocol, on a compacted request list that every shard builds identically (flags -> exclusive
+// scan -> gather, so the order is by decision index on every shard).
+constexpr int kXF = 4;
+
+__global__ __launch_bounds__(256) void place_shard_fast_kernel(Snap V, PlaceArgs A, int32_t shard, int64_t *__restrict__ xf)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= A.n) return;
+    mmp_place_out o;
+    const int code = lane_decide<true>(V, A, d, o);
+    int64_t k0 = kXMax, k1 = kXMax, k2 = kXMax, k3 = kXMax;
+    if (code != kLaneNoneHere) {
+        const int64_t key = (int64_t)shard << 56;
+        k0 = key | ((int64_t)(code != kLaneDone) << 48) | (int64_t)(uint32_t)(o.chosen + 2);
+        k1 = key | (int64_t)(uint32_t)(o.best + 1);
+        k2 = key | (int64_t)(uint32_t)o.n_candidates;
+        k3 = key | (int64_t)o.hash;
+    }
+    int64_t *x = xf + (size_t)d * kXF;
+    x[0] = k0;
+    x[1] = k1;
+    x[2] = k2;
+    x[3] = k3;
+}
+
+// after the all-reduce: write the decided rows, flag the rest
+__global__ void place_shard_fast_finish_kernel(const int64_t *__restrict__ xf, int32_t n, int32_t any_rs,
+                                               mmp_place_out *__restrict__ outs, int32_t *__restrict__ flags)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > n) return;
+    if (d == n) {
+        flags[n] = 0;  // the scan runs over n + 1 items: offs[n] = number of flagged decisions
+        return;
+    }
+    const int64_t *x = xf + (size_t)d * kXF;
+    const int64_t k0 = x[0];
+    mmp_place_out o;
+    o.chosen = MMP_NONE;
+    o.best = -1;
+    o.n_candidates = 0;
+    o.hash = 0;
+    int32_t rest = 0;
+    if (k0 == kXMax)
+        rest = any_rs ? 1 : 0;  // nowhere eligible: null, unless the excludeReplicaSets retry has to run
+    else if ((k0 >> 48) & 1)
+        rest = 1;
+    else {
+        o.chosen = (int32_t)(uint32_t)(k0 & 0xffffffffll) - 2;
+        o.best = (int32_t)(uint32_t)(x[1] & 0xffffffffll) - 1;
+        o.n_candidates = (int32_t)(uint32_t)(x[2] & 0xffffffffll);
+        o.hash = (uint32_t)(x[3] & 0xffffffffll);
+    }
+    flags[d] = rest;
+    if (!rest) outs[d] = o;
+}
+
+__global__ void place_shard_gather_kernel(const mmp_place_req *__restrict__ reqs, int32_t n, const int32_t *__restrict__ flags,
+                                          const int32_t *__restrict__ offs, mmp_place_req *__restrict__ rest_reqs,
+                                          int32_t *__restrict__ rest_idx)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n || !flags[d]) return;
+    rest_reqs[offs[d]] = reqs[d];
+    rest_idx[offs[d]] = d;
+}
+
+__global__ void place_shard_scatter_kernel(const mmp_place_out *__restrict__ rest_outs, const int32_t *__restrict__ rest_idx,
+                                           int32_t n_rest, mmp_place_out *__restrict__ outs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rest) outs[rest_idx[i]] = rest_outs[i];
+}
+
 // ---- sharded commit ---------------------------------------------------------------------------
 // After the SUM all-reduce every shard holds the full rank[] (4 B per pod — the only replicated
 // per-pod state besides the raw input rows).  Each shard keeps the columns of the positions it owns.

@@ -35,6 +35,11 @@ struct Snap {
     const uint8_t *has_pref;    // [T] getPreferredInstances(type) != null
     const uint64_t *fullw;      // [W] isFull(row.remaining)
     const uint64_t *ge;         // [kGeRows][W] row r: count >= kGeBase + r (the count break of MM.java:4925)
+    // A pod-axis shard's view of its own slice (shard_kernels.hpp: place_shard_fast_kernel): positions and
+    // words above are LOCAL, pos_of stays global.  All zero for the ordinary single-device snapshot.
+    int32_t pos_base;    // global position of local position 0
+    int32_t w_base;      // global word of local word 0
+    int32_t more_after;  // positions beyond this view exist (the view is not the tail of the order)
 };
 
 // count >= 10 is a fixed clause of the shortlist's count break (MM.java:4925-4926); the other clause,

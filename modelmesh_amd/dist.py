@@ -10,8 +10,11 @@ ROCm, the same code runs on "gloo" — tests/test_dist_gloo.py).
    of PLACEMENT_ORDER positions; every rank sees the whole batch.  `PodShardedPlacer` drives the
    library's phase kernels (include/mmplace.h, csrc/shard_kernels.hpp) and performs the all-reduce
    between two phases: MIN of per-shard best positions / break positions / owner-supplied rows,
-   SUM of per-shard candidate counts.  Six small all-reduces per batch, latency-bound on xGMI, so the
-   batch should be >= 16k decisions.
+   SUM of per-shard candidate counts.  Six all-reduces per batch in the general protocol — but the head
+   of the order decides almost every request, so a batch first takes the speculative form: every shard
+   decides on its own slice, ONE all-reduce(MIN) of 4 int64 per decision picks the lowest shard holding
+   an eligible pod, and only the decisions that shard could not finish alone go through the six phases
+   (as a compacted sub-batch, identical on every shard).
 """
 from __future__ import annotations
 
@@ -103,6 +106,39 @@ class SolverShardBackend:
         self.solver.shard_phase_dev(ph, d_reqs.data_ptr(), n, d_extra.data_ptr() if d_extra is not None else 0, now,
                                     [x.data_ptr() for x in xchg], d_outs.data_ptr(), st)
 
+    # ---- the speculative single-exchange form --------------------------------------------------
+    def fast_slots(self) -> int:
+        return self.solver.shard_fast_slots()
+
+    def fast(self, d_reqs, n, d_extra, now, xf):
+        import torch
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        self.solver.shard_fast_dev(d_reqs.data_ptr(), n, d_extra.data_ptr() if d_extra is not None else 0, now,
+                                   xf.data_ptr(), st)
+
+    def fast_finish(self, d_reqs, n, xf, d_outs):
+        """-> (n_rest, rest_reqs, rest_outs): the undecided requests, compacted in decision order, and
+        the buffer their result rows go to (library-owned device memory)."""
+        import torch
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        n_rest, rr, ro = self.solver.shard_fast_finish_dev(d_reqs.data_ptr(), n, xf.data_ptr(), d_outs.data_ptr(), st)
+        return n_rest, _DevPtr(rr), _DevPtr(ro)
+
+    def fast_scatter(self, n_rest, rest_outs, d_outs):
+        import torch
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        self.solver.shard_fast_scatter_dev(n_rest, d_outs.data_ptr(), st)
+
+
+class _DevPtr:
+    """A raw device pointer with the one method the backends use of a tensor."""
+
+    def __init__(self, p: int):
+        self._p = p
+
+    def data_ptr(self) -> int:
+        return self._p
+
 
 def _dist_all_reduce(t, op: str):
     import torch.distributed as dist
@@ -114,10 +150,13 @@ class PodShardedPlacer:
     """Drives one shard through commit and through the phases of a batch.  `all_reduce(tensor, op)`
     (op in {"min", "sum"}) defaults to torch.distributed.all_reduce on the default group."""
 
-    def __init__(self, backend, all_reduce=None):
+    def __init__(self, backend, all_reduce=None, speculative: bool = True):
         self.b = backend
         self.all_reduce = all_reduce or _dist_all_reduce
         self._xchg, self._xn = None, -1
+        self._xf, self._xfn = None, -1
+        self.speculative = speculative and hasattr(backend, "fast")
+        self.last_n_rest = 0  # decisions of the last batch that needed the six-phase protocol
 
     def commit_steps(self):
         r = self.b.rank_partial()
@@ -137,7 +176,26 @@ class PodShardedPlacer:
         return self._xchg
 
     def place_steps(self, d_reqs, n: int, d_extra, now: int, d_outs):
-        """Generator: launches phase k, then yields (exchange tensor, op) for the caller to all-reduce."""
+        """Generator: launches a kernel, then yields (exchange tensor, op) for the caller to all-reduce."""
+        if not self.speculative:
+            self.last_n_rest = n
+            yield from self._general_steps(d_reqs, n, d_extra, now, d_outs)
+            return
+        import torch
+        slots = self.b.fast_slots()
+        if self._xfn < n:
+            self._xf = torch.empty(max(n, 1) * slots, dtype=torch.int64, device=self.b.device)
+            self._xfn = n
+        xf = self._xf[: n * slots]
+        self.b.fast(d_reqs, n, d_extra, now, xf)
+        yield xf, "min"
+        n_rest, rest_reqs, rest_outs = self.b.fast_finish(d_reqs, n, xf, d_outs)
+        self.last_n_rest = n_rest
+        if n_rest:  # the same number, the same requests, in the same order on every shard
+            yield from self._general_steps(rest_reqs, n_rest, d_extra, now, rest_outs)
+            self.b.fast_scatter(n_rest, rest_outs, d_outs)
+
+    def _general_steps(self, d_reqs, n: int, d_extra, now: int, d_outs):
         xchg = self._buffers(n)
         for ph in range(1, N_PHASES):
             self.b.phase(ph, d_reqs, n, d_extra, now, xchg, d_outs)

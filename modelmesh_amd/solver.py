@@ -401,6 +401,24 @@ class Solver:
                                                     C.c_void_p(d_extra or None), int(now), arr,
                                                     C.c_void_p(d_outs or None), C.c_void_p(stream or None)))
 
+    def shard_fast_slots(self) -> int:
+        return int(self.lib.mmp_shard_fast_slots())
+
+    def shard_fast_dev(self, d_reqs: int, n: int, d_extra: int, now: int, d_xf: int, stream: int = 0):
+        self._ck(self.lib.mmp_shard_place_fast_dev(self.h, C.c_void_p(d_reqs), int(n), C.c_void_p(d_extra or None), int(now),
+                                                   C.c_void_p(d_xf), C.c_void_p(stream or None)))
+
+    def shard_fast_finish_dev(self, d_reqs: int, n: int, d_xf: int, d_outs: int, stream: int = 0):
+        """-> (n_rest, device pointer of the compacted requests, device pointer of their result rows)"""
+        n_rest, rr, ro = C.c_int32(0), C.c_void_p(0), C.c_void_p(0)
+        self._ck(self.lib.mmp_shard_place_fast_finish_dev(self.h, C.c_void_p(d_reqs), int(n), C.c_void_p(d_xf),
+                                                          C.c_void_p(d_outs), C.c_void_p(stream or None), C.byref(n_rest),
+                                                          C.byref(rr), C.byref(ro)))
+        return n_rest.value, rr.value or 0, ro.value or 0
+
+    def shard_fast_scatter_dev(self, n_rest: int, d_outs: int, stream: int = 0):
+        self._ck(self.lib.mmp_shard_place_fast_scatter_dev(self.h, int(n_rest), C.c_void_p(d_outs), C.c_void_p(stream or None)))
+
     def sync(self):
         self._ck(self.lib.mmp_sync(self.h))
 

@@ -284,6 +284,80 @@ class EmulShardBackend:
             c = sorted(set(c) | {D["bestpos"]})
         return c
 
+    # ---- the speculative single-exchange form (csrc/shard_kernels.hpp "speculative") -----------------
+    # Emulated as what it means: this shard plays the WHOLE protocol alone on its own slice (private
+    # exchange vectors, no reduction), and then judges whether that was legitimate.
+    FAST_SLOTS = 4
+
+    def fast_slots(self):
+        return self.FAST_SLOTS
+
+    def fast(self, reqs, n, extra, now, xf):
+        import torch
+        from modelmesh_amd._lib import PLACE_OUT
+        priv = [torch.full((max(n, 1) * self.xchg_slots(ph),), XMAX, dtype=torch.int64) for ph in range(1, 7)]
+        outs = np.zeros(n, dtype=PLACE_OUT)
+        any_rs, self.any_rs = self.any_rs, False  # alone, only the replica-set-filtered set may be used:
+        try:                                       # whether the retry applies is a global question
+            for ph in range(1, 8):
+                self.phase(ph, reqs, n, extra, now, priv, outs)
+            X = [x.numpy().reshape(n, -1) if n else x.numpy().reshape(0, 1) for x in
+                 [priv[k][: n * self.xchg_slots(k + 1)] for k in range(6)]]
+            xv = xf.numpy().reshape(n, self.FAST_SLOTS) if n else xf.numpy().reshape(0, self.FAST_SLOTS)
+            last = self.hi >= self.n_pods
+            for d in range(n):
+                rq = reqs[d]
+                if not (0 <= rq["model"] < self.f.n_models):
+                    complete, here = True, True  # unknown model: null, every shard says so
+                else:
+                    t = self.f.models[rq["model"]]["type"]
+                    t = int(t) if 0 <= t < max(self.f.n_types, 1) else 0
+                    D = self._derive(rq, now, X, d, 5, self.has_pref[t])
+                    here = not D["none"]
+                    complete = False
+                    if here:
+                        special = D["has_pm"] and not D["e_pref"]
+                        if special and not D["case_a"]:
+                            complete = False  # case (b) / no preferred pod before a full one: general protocol
+                        elif D["exit"] is not None and D.get("end") is None:
+                            complete = True
+                        else:
+                            early_self = D["us"] and D["favour"]  # decided by the best entry alone (:4891-4895)
+                            complete = early_self or last or D["end"] < min(self.hi, self.n_pods)
+                if not here:
+                    xv[d] = XMAX
+                    continue
+                o = outs[d]
+                key = self.shard << 56
+                xv[d] = (key | ((0 if complete else 1) << 48) | ((int(o["chosen"]) + 2) & 0xFFFFFFFF),
+                         key | ((int(o["best"]) + 1) & 0xFFFFFFFF), key | (int(o["n_candidates"]) & 0xFFFFFFFF),
+                         key | (int(o["hash"]) & 0xFFFFFFFF))
+        finally:
+            self.any_rs = any_rs
+
+    def fast_finish(self, reqs, n, xf, outs):
+        xv = xf.numpy().reshape(n, self.FAST_SLOTS) if n else xf.numpy().reshape(0, self.FAST_SLOTS)
+        rest = []
+        for d in range(n):
+            k0 = int(xv[d][0])
+            o = outs[d]
+            o["chosen"], o["best"], o["n_candidates"], o["hash"] = NONE, -1, 0, 0
+            if k0 == XMAX:
+                if self.any_rs:
+                    rest.append(d)
+            elif (k0 >> 48) & 1:
+                rest.append(d)
+            else:
+                o["chosen"] = (k0 & 0xFFFFFFFF) - 2
+                o["best"] = (int(xv[d][1]) & 0xFFFFFFFF) - 1
+                o["n_candidates"] = int(xv[d][2]) & 0xFFFFFFFF
+                o["hash"] = int(xv[d][3]) & 0xFFFFFFFF
+        self._rest_idx = np.asarray(rest, np.int64)
+        return len(rest), reqs[self._rest_idx].copy(), np.zeros(len(rest), dtype=outs.dtype)
+
+    def fast_scatter(self, n_rest, rest_outs, outs):
+        outs[self._rest_idx] = rest_outs
+
     def phase(self, ph, reqs, n, extra, now, xchg, outs):
         X = [x.numpy().reshape(n, -1) if n else x.numpy().reshape(0, 1) for x in
              [xchg[k][: n * self.xchg_slots(k + 1)] for k in range(6)]]

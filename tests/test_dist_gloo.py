@@ -85,9 +85,10 @@ def _emul_fleet(seed, profile, pods):
     return fleet, reqs, extra
 
 
+@pytest.mark.parametrize("speculative", [True, False])
 @pytest.mark.parametrize("seed,profile,pods,G", [(3, None, 130, 2), (4, "prefer", 200, 3), (5, "full", 200, 2),
                                                  (6, "prefer", 70, 4), (8, "full", 300, 5)])
-def test_pod_axis_protocol_lockstep_emulation(seed, profile, pods, G):
+def test_pod_axis_protocol_lockstep_emulation(seed, profile, pods, G, speculative):
     from modelmesh_amd import dist as mdist
     from modelmesh_amd._lib import PLACE_OUT
     from oracle.bind import OracleFleet
@@ -95,7 +96,8 @@ def test_pod_axis_protocol_lockstep_emulation(seed, profile, pods, G):
     fleet, reqs, extra = _emul_fleet(seed, profile, pods)
     orc = OracleFleet(fleet)
     want = orc.place(reqs, extra, fleet.now)
-    placers = [mdist.PodShardedPlacer(EmulShardBackend(fleet, _order_full(fleet, orc), g, G)) for g in range(G)]
+    placers = [mdist.PodShardedPlacer(EmulShardBackend(fleet, _order_full(fleet, orc), g, G), speculative=speculative)
+               for g in range(G)]
     mdist.run_lockstep([p.commit_steps() for p in placers])
     outs = [np.zeros(len(reqs), dtype=PLACE_OUT) for _ in range(G)]
     mdist.run_lockstep([p.place_steps(reqs, len(reqs), extra, fleet.now, o) for p, o in zip(placers, outs)])
@@ -103,6 +105,13 @@ def test_pod_axis_protocol_lockstep_emulation(seed, profile, pods, G):
         for f in ("chosen", "best", "n_candidates", "hash"):
             bad = np.nonzero(o[f] != want[f])[0]
             assert len(bad) == 0, (f, bad[:5], o[bad[:5]], want[bad[:5]])
+    assert len({p.last_n_rest for p in placers}) == 1
+    if speculative:
+        assert placers[0].last_n_rest < len(reqs)  # the single exchange decided something ...
+        if profile == "prefer":
+            assert placers[0].last_n_rest > 0      # ... and these fleets also need the six phases
+    if not speculative:
+        assert placers[0].last_n_rest == len(reqs)
 
 
 def _pod_worker(rank, world, port, q):

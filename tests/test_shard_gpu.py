@@ -25,16 +25,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _load_shard(fleet, g, G, dev):
+def _load_shard(fleet, g, G, dev, speculative=True):
     s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
     s.load_fleet(fleet, commit=False)
-    return s, mdist.PodShardedPlacer(mdist.SolverShardBackend(s, g, G, dev))
+    return s, mdist.PodShardedPlacer(mdist.SolverShardBackend(s, g, G, dev), speculative=speculative)
 
 
-def _sharded_place(fleet, reqs, extra, G):
+LAST_N_REST = [0]  # decisions of the most recent _sharded_place that needed the six-phase protocol
+
+
+def _sharded_place(fleet, reqs, extra, G, speculative=True):
     import torch
     dev = torch.device("cuda", 0)
-    solvers, placers = zip(*[_load_shard(fleet, g, G, dev) for g in range(G)])
+    solvers, placers = zip(*[_load_shard(fleet, g, G, dev, speculative) for g in range(G)])
     try:
         mdist.run_lockstep([p.commit_steps() for p in placers])
         n = len(reqs)
@@ -45,6 +48,8 @@ def _sharded_place(fleet, reqs, extra, G):
         torch.cuda.synchronize()
         res = [np.frombuffer(o.cpu().numpy().tobytes(), dtype=PLACE_OUT)[:n] for o in outs]
         stats = [s.stats() for s in solvers]
+        assert len({p.last_n_rest for p in placers}) == 1  # every shard compacted the same sub-batch
+        LAST_N_REST[0] = placers[0].last_n_rest
     finally:
         for s in solvers:
             s.close()
@@ -53,10 +58,10 @@ def _sharded_place(fleet, reqs, extra, G):
     return res[0], stats
 
 
-def _check(fleet, reqs, extra, G):
+def _check(fleet, reqs, extra, G, speculative=True):
     orc = OracleFleet(fleet)
     want = orc.place(reqs, extra, fleet.now, threads=8)
-    got, stats = _sharded_place(fleet, reqs, extra, G)
+    got, stats = _sharded_place(fleet, reqs, extra, G, speculative)
     assert_same_decisions(fleet, reqs, got, want)
     ost = orc.stats()
     for st in stats:
@@ -64,20 +69,34 @@ def _check(fleet, reqs, extra, G):
             assert int(st[f]) == int(ost[f])
 
 
+@pytest.mark.parametrize("speculative", [True, False])
 @pytest.mark.parametrize("G", [1, 2, 3, 8])
 @pytest.mark.parametrize("profile", [None, "full", "prefer"])
 @pytest.mark.parametrize("seed", range(6))
-def test_fuzz_fleets_sharded(seed, profile, G):
+def test_fuzz_fleets_sharded(seed, profile, G, speculative):
+    """speculative=True: one exchange decides what the lowest shard holding an eligible pod can finish
+    alone, the six-phase protocol takes the rest; False: the six-phase protocol for every decision."""
     pods = int(np.random.default_rng(seed + 100).choice([1, 7, 64, 65, 200, 700, 3000]))
     fleet = wl.fuzz_fleet(seed + 100, pods=pods, profile=profile)
     reqs, extra = wl.fuzz_requests(fleet, seed + 100, 2000)
-    _check(fleet, reqs, extra, G)
+    _check(fleet, reqs, extra, G, speculative)
+    assert LAST_N_REST[0] == len(reqs) if not speculative else LAST_N_REST[0] <= len(reqs)
 
 
+def test_speculative_form_decides_most_of_a_plain_fleet():
+    """On a fleet without preferences / full pods at the head the single exchange must do nearly all the
+    work — otherwise the speculative form silently degenerated into the general protocol."""
+    fleet = wl.fuzz_fleet(101, pods=3000, profile=None)
+    reqs, extra = wl.fuzz_requests(fleet, 101, 4000)
+    _check(fleet, reqs, extra, 4, True)
+    assert LAST_N_REST[0] < len(reqs) // 2, LAST_N_REST[0]
+
+
+@pytest.mark.parametrize("speculative", [True, False])
 @pytest.mark.parametrize("G", [2, 4])
-def test_scenarios_sharded(G):
+def test_scenarios_sharded(G, speculative):
     for name, fleet, reqs, extra in wl.scenario_fleets():
-        _check(fleet, reqs, extra, G)
+        _check(fleet, reqs, extra, G, speculative)
 
 
 @pytest.mark.parametrize("G", [2, 8])
@@ -91,6 +110,7 @@ def test_c3_sharded_8_full_size():
     fleet = wl.make_fleet("C3")
     reqs, extra = wl.make_requests(fleet, 22)
     _check(fleet, reqs, extra, 8)
+    assert LAST_N_REST[0] * 100 < len(reqs), LAST_N_REST[0]  # < 1 % of C3 needs more than the one exchange
 
 
 def test_shard_mode_refuses_unsharded_calls():
