@@ -176,7 +176,7 @@ def churn_leg(fleet, solver, slices: int = 8, events: int = 20_000):
             "required_events_per_s": 10_000, "headroom_x": n_ev / busy / 10_000}
 
 
-def secondary_kernels_leg(fleet, solver, device: int, reps: int = 5):
+def secondary_kernels_leg(fleet, solver, device: int, workload: str = "C3", reps: int = 5):
     """Every other kernel of the path on C3-sized inputs: device
     time from the library's own HIP-event bracket around the kernels of one host-pointer call
     (mmp_profile / mmp_last_kernel_ms: events on the stream the kernels are launched on), median of
@@ -291,7 +291,7 @@ def secondary_kernels_leg(fleet, solver, device: int, reps: int = 5):
 
         # f-1 KV wire format: Jackson JSON of the instance table and of the registry, parsed on device
         ids = wire.make_ids(rng, P)
-        wf = wl.make_fleet("C3", models=min(M, 50_000))  # registry sample: the JSON is generated in Python
+        wf = wl.make_fleet(workload, models=min(M, 50_000))  # registry sample: the JSON is generated in Python
         wire.adopt_ids(wf, ids)
         pv = wire.pod_values(wf, rng, np.full(P, now - 1000, np.int64))
         mv = wire.model_values(wf, ids, ["NLCLASSIFIER"] + ["type-%d" % t for t in range(1, max(wf.n_types, 1))], rng,
@@ -538,7 +538,7 @@ def main():
                 line["churn"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.kernel_only and not args.no_secondary:
             try:
-                line["kernels"] = secondary_kernels_leg(fleet, solver, local_rank)
+                line["kernels"] = secondary_kernels_leg(fleet, solver, local_rank, args.workload)
             except Exception as e:
                 line["kernels"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline and not args.kernel_only:
