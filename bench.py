@@ -531,6 +531,19 @@ def main():
             for _ in range(5):
                 solver.place(reqs, extra, fleet.now)
             line["host_boundary_decisions_per_s"] = 5 * n / (time.perf_counter() - t1)
+            # SURVEY.md §8(d) latency metric: per-batch wall time through the host-pointer ABI for B in {1k, 64k}
+            batches = {}
+            for B in (1_000, 64_000):
+                sub = reqs[: min(B, n)]
+                ts = []
+                for _ in range(60):
+                    t1 = time.perf_counter()
+                    solver.place(sub, extra, fleet.now)
+                    ts.append(time.perf_counter() - t1)
+                ts = np.array(ts[10:]) * 1e6
+                batches[str(len(sub))] = {"p50_us": float(np.percentile(ts, 50)), "p99_us": float(np.percentile(ts, 99)),
+                                          "p99_us_per_decision": float(np.percentile(ts, 99)) / len(sub)}
+            line["host_boundary_batch_latency"] = batches
         if not args.kernel_only:
             try:
                 line["churn"] = churn_leg(fleet, solver)

@@ -7,6 +7,7 @@
 // implementation of the path in this library.
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_merge_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
@@ -125,6 +126,8 @@ struct mmp_ctx {
     // `ssnap` only; n_shards == 0 means the ordinary single-device snapshot
     int32_t shard = 0, n_shards = 0;
     ShardSnap ssnap{};
+    DevBuf rk_rows, rk_idx, rk_idx2, rk_tmp;  // ranking by sorting (snapshot.hpp)
+    int32_t force_allpairs = 0;               // MMP_RANK_ALLPAIRS=1: always the all-pairs kernel (tests)
     Snap sview{};  // the lane path's view of this shard's slice (place_shard_fast_kernel)
     DevBuf f_flags, f_offs, f_idx, f_reqs, f_outs, f_scan_tmp;  // speculative form: the compacted rest of a batch
     bool rank_pending = false;
@@ -298,6 +301,7 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     if (!c) return fail(nullptr, MMP_ENOMEM, "out of memory");
     c->cfg = *cfg;
     if (const char *fw = getenv("MMP_FORCE_WAVE")) c->force_wave = fw[0] == '1';
+    if (const char *fa = getenv("MMP_RANK_ALLPAIRS")) c->force_allpairs = fa[0] == '1';
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete c;
         return fail(nullptr, MMP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
@@ -347,7 +351,7 @@ void mmp_destroy(mmp_ctx *c)
                       &c->r_tmp, &c->r_out_model, &c->r_out_lu, &c->k_cap, &c->k_wsize, &c->k_ubm, &c->k_ops, &c->k_order,
                       &c->k_opoff, &c->k_outs, &c->k_ev, &c->k_evoff, &c->idtab_hash, &c->idtab_val, &c->tytab_hash,
                       &c->tytab_val, &c->j_buf, &c->j_off, &c->j_rows, &c->j_aux, &c->j_status, &c->j_cnt, &c->j_offs, &c->j_tmp_pod,
-                      &c->j_tmp_time, &c->j_scan_tmp, &c->f_flags, &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp,
+                      &c->j_tmp_time, &c->j_scan_tmp, &c->rk_rows, &c->rk_idx, &c->rk_idx2, &c->rk_tmp, &c->f_flags, &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp,
                       &c->ks[0].off, &c->ks[0].lu, &c->ks[0].wt,
                       &c->ks[0].key, &c->ks[0].n, &c->ks[1].off, &c->ks[1].lu, &c->ks[1].wt, &c->ks[1].key, &c->ks[1].n})
         b->release();
@@ -674,10 +678,35 @@ int mmp_snapshot_commit(mmp_ctx *c)
 
     KT_BEGIN(c, st);
     if (P > 0) {
-        const int pb = div_up(P, kRankBlock);
-        const int slices = std::max(1, std::min(64, 2048 / pb));
-        hipLaunchKernelGGL(rank_pods_kernel, dim3(pb, slices), dim3(kRankBlock), 0, st, B.pods.as<mmp_pod_row>(), P,
-                           min_space, churn2, slices, 0, P, c->rank.as<int32_t>());
+        // is the literal comparator a strict total order on these rows?  (see snapshot.hpp "ranking by sorting")
+        bool versions_differ = false, full_low_lru = false, wide_count = false;
+        for (int32_t p = 0; p < P; p++) {
+            const mmp_pod_row &r = c->pods[p];
+            if (r.version != c->pods[0].version) versions_differ = true;
+            if (r.count > (1 << 30) || r.count < -(1 << 30)) wide_count = true;  // :4676 is an int subtraction
+            const uint64_t d = (uint64_t)r.capacity - (uint64_t)r.used;
+            const int64_t rem = (int64_t)d > 0 ? (int64_t)d : 0;
+            if (rem < min_space && r.lru_time <= churn2) full_low_lru = true;
+        }
+        if (!c->force_allpairs && P >= 2 && !(versions_differ && full_low_lru) && !wide_count) {
+            HIP_TRY(c, c->rk_rows.ensure((size_t)P * sizeof(RankRow)));
+            HIP_TRY(c, c->rk_idx.ensure((size_t)P * 4));
+            HIP_TRY(c, c->rk_idx2.ensure((size_t)P * 4));
+            const PlacementIndexLess less{c->rk_rows.as<RankRow>(), churn2};
+            size_t tmp_bytes = 0;
+            HIP_TRY(c, rocprim::merge_sort(nullptr, tmp_bytes, c->rk_idx.as<int32_t>(), c->rk_idx2.as<int32_t>(), (size_t)P, less, st));
+            HIP_TRY(c, c->rk_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
+            hipLaunchKernelGGL(rank_rows_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(), P, min_space,
+                               c->rk_rows.as<RankRow>(), c->rk_idx.as<int32_t>());
+            HIP_TRY(c, rocprim::merge_sort(c->rk_tmp.p, tmp_bytes, c->rk_idx.as<int32_t>(), c->rk_idx2.as<int32_t>(), (size_t)P, less, st));
+            hipLaunchKernelGGL(rank_from_order_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, c->rk_idx2.as<int32_t>(), P,
+                               c->rank.as<int32_t>());
+        } else {
+            const int pb = div_up(P, kRankBlock);
+            const int slices = std::max(1, std::min(64, 2048 / pb));
+            hipLaunchKernelGGL(rank_pods_kernel, dim3(pb, slices), dim3(kRankBlock), 0, st, B.pods.as<mmp_pod_row>(), P,
+                               min_space, churn2, slices, 0, P, c->rank.as<int32_t>());
+        }
         hipLaunchKernelGGL(scatter_pods_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(), P,
                            min_space, c->rank.as<int32_t>(), c->occupancy.as<int32_t>(), B.lru.as<int64_t>(),
                            B.rem.as<int64_t>(), B.cnt.as<int32_t>(), B.rpm.as<int32_t>(), B.orig.as<int32_t>(),

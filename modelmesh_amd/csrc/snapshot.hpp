@@ -86,7 +86,7 @@ __device__ __forceinline__ RankRow make_rank_row(const mmp_pod_row &r, int64_t m
 
 // PLACEMENT_ORDER.compare(a,b) < 0, transcribed clause by clause from
 // MM.java:4646-4703.  Absent rows play the shuttingDown role (sorted last).
-__device__ __forceinline__ bool placement_less(const RankRow &a, const RankRow &b, int64_t churn2)
+__host__ __device__ __forceinline__ bool placement_less(const RankRow &a, const RankRow &b, int64_t churn2)
 {
     const bool sd1 = a.flags & 1u, sd2 = b.flags & 1u;
     if (sd1 != sd2) return !sd1;  // :4653-4656
@@ -144,6 +144,39 @@ __global__ __launch_bounds__(kRankBlock) void rank_pods_kernel(const mmp_pod_row
         }
     }
     if (p < p_hi && before) atomicAdd(&rank[p], before);
+}
+
+// ---- ranking by sorting --------------------------------------------------------------------------
+// PLACEMENT_ORDER's version clause (:4660-4666) is the only place where the comparator can fail to be
+// transitive: "newer version first unless it is full with lruTime <= 2*minChurnAgeMs".  When no full
+// row has such an lruTime, or all rows carry one instanceVersion, the clause reduces to a plain key and
+// the literal comparator is a strict total order (ids are unique), so ANY comparison sort with that
+// same literal comparator yields the one and only order: O(P log P) comparator evaluations
+// (rocprim::merge_sort over pod indices) instead of the P^2 of rank_pods_kernel.  The host checks the
+// condition while it stages the rows; otherwise the all-pairs kernel runs and its duplicate-rank test
+// reports a genuinely cyclic table (MMP_EORDER).
+__global__ void rank_rows_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int64_t min_space,
+                                 RankRow *__restrict__ rows, int32_t *__restrict__ idx)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    rows[p] = make_rank_row(pods[p], min_space);
+    idx[p] = p;
+}
+
+struct PlacementIndexLess {
+    const RankRow *rows;
+    int64_t churn2;
+    __host__ __device__ bool operator()(const int32_t &a, const int32_t &b) const
+    {
+        return placement_less(rows[a], rows[b], churn2);
+    }
+};
+
+__global__ void rank_from_order_kernel(const int32_t *__restrict__ order, int32_t P, int32_t *__restrict__ rank)
+{
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos < P) rank[order[pos]] = pos;
 }
 
 // Scatter rows into rank order; detect a non-total order (two rows with the

@@ -251,6 +251,7 @@ void orc_scaledown_plan(const orc_pod *pods, const int32_t *pos_of, const uint8_
         do {
             const int64_t last_used = ce->last_used;
             if (last_used == 0) break; /* :6199 */
+            if (ce->model < 0) break;  /* no ModelRecord: never entered scaleCopiesCandidates (MM.java:6076-6090) */
             const orc_flat_model *mr = &models[ce->model];
             const int32_t num = mr->n_loaded;
             if (!can_remove || num < 2) break;

@@ -289,3 +289,23 @@ def test_kernel_time_bracket():
         assert s.last_kernel_ms() < 0
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_rank_by_sorting_equals_all_pairs_ranking(seed, monkeypatch):
+    """Commit ranks by rocprim::merge_sort with the literal comparator whenever PLACEMENT_ORDER is provably
+    a strict total order on the table, and by the all-pairs kernel otherwise (MMP_RANK_ALLPAIRS=1 forces
+    it): same order, element for element, and the oracle's."""
+    pods = int(np.random.default_rng(seed).choice([2, 63, 300, 5000]))
+    fleet = wl.fuzz_fleet(seed + 300, pods=pods)
+    orders = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("MMP_RANK_ALLPAIRS", force)
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            s.load_fleet(fleet)
+            orders.append(s.order())
+        finally:
+            s.close()
+    assert np.array_equal(orders[0], orders[1])
+    assert np.array_equal(orders[0], OracleFleet(fleet).order)
