@@ -212,8 +212,9 @@ def secondary_kernels_leg(fleet, solver, device: int, workload: str = "C3", reps
     solver.profile(True)
     try:
         # a5 / a4: commit = rank (all pairs, literal comparator) + scatter + bitmaps + stats
-        timed("snapshot_commit (rank_pods + scatter + build_ge + build_masks + cluster_stats)", solver.commit,
-              None, P * P, "comparator evaluations", "VALU bound: P^2 literal PLACEMENT_ORDER comparisons, 64*P bytes in")
+        timed("snapshot_commit (rank + scatter + build_ge + build_masks + cluster_stats)", solver.commit,
+              None, P, "pods ranked", "rank = rocprim::merge_sort of the 64-byte rank rows with the literal PLACEMENT_ORDER "
+              "comparator from 8192 pods on (all-pairs kernel below that, or when the order is not provably total)")
 
         # a12 stateless eviction evaluations over one clhm deque per pod
         cs = wl.ChurnStream(fleet, 0xC5)

@@ -126,8 +126,8 @@ struct mmp_ctx {
     // `ssnap` only; n_shards == 0 means the ordinary single-device snapshot
     int32_t shard = 0, n_shards = 0;
     ShardSnap ssnap{};
-    DevBuf rk_rows, rk_idx, rk_idx2, rk_tmp;  // ranking by sorting (snapshot.hpp)
-    int32_t force_allpairs = 0;               // MMP_RANK_ALLPAIRS=1: always the all-pairs kernel (tests)
+    DevBuf rk_rows, rk_idx, rk_tmp;  // ranking by sorting (snapshot.hpp)
+    int32_t rank_mode = 0;  // MMP_RANK_MODE: 0 auto (sort from kRankSortMinPods pods), 1 all-pairs, 2 sort whenever legal (tests)
     Snap sview{};  // the lane path's view of this shard's slice (place_shard_fast_kernel)
     DevBuf f_flags, f_offs, f_idx, f_reqs, f_outs, f_scan_tmp;  // speculative form: the compacted rest of a batch
     bool rank_pending = false;
@@ -196,6 +196,7 @@ int fail(mmp_ctx *c, int code, const char *fmt, ...)
     } while (0)
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
+constexpr int kRankSortMinPods = 8192;
 
 // Kernel-time bracket of a host-pointer entry point (owner of c->batch_mu): KT_BEGIN after the H2D
 // copies are enqueued, KT_END after the last kernel, kt_collect() once the stream has been synchronised.
@@ -301,7 +302,7 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     if (!c) return fail(nullptr, MMP_ENOMEM, "out of memory");
     c->cfg = *cfg;
     if (const char *fw = getenv("MMP_FORCE_WAVE")) c->force_wave = fw[0] == '1';
-    if (const char *fa = getenv("MMP_RANK_ALLPAIRS")) c->force_allpairs = fa[0] == '1';
+    if (const char *rm = getenv("MMP_RANK_MODE")) c->rank_mode = atoi(rm);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete c;
         return fail(nullptr, MMP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
@@ -351,7 +352,7 @@ void mmp_destroy(mmp_ctx *c)
                       &c->r_tmp, &c->r_out_model, &c->r_out_lu, &c->k_cap, &c->k_wsize, &c->k_ubm, &c->k_ops, &c->k_order,
                       &c->k_opoff, &c->k_outs, &c->k_ev, &c->k_evoff, &c->idtab_hash, &c->idtab_val, &c->tytab_hash,
                       &c->tytab_val, &c->j_buf, &c->j_off, &c->j_rows, &c->j_aux, &c->j_status, &c->j_cnt, &c->j_offs, &c->j_tmp_pod,
-                      &c->j_tmp_time, &c->j_scan_tmp, &c->rk_rows, &c->rk_idx, &c->rk_idx2, &c->rk_tmp, &c->f_flags, &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp,
+                      &c->j_tmp_time, &c->j_scan_tmp, &c->rk_rows, &c->rk_idx, &c->rk_tmp, &c->f_flags, &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp,
                       &c->ks[0].off, &c->ks[0].lu, &c->ks[0].wt,
                       &c->ks[0].key, &c->ks[0].n, &c->ks[1].off, &c->ks[1].lu, &c->ks[1].wt, &c->ks[1].key, &c->ks[1].n})
         b->release();
@@ -688,18 +689,20 @@ int mmp_snapshot_commit(mmp_ctx *c)
             const int64_t rem = (int64_t)d > 0 ? (int64_t)d : 0;
             if (rem < min_space && r.lru_time <= churn2) full_low_lru = true;
         }
-        if (!c->force_allpairs && P >= 2 && !(versions_differ && full_low_lru) && !wide_count) {
+        // all-pairs is embarrassingly parallel and wins below ~8k pods (measured: 10k pods 172 us all-pairs vs 120 us
+        // sort; 50k pods 4.3 ms vs 0.25 ms); a merge sort of a few thousand 64-byte keys is latency bound
+        const bool want_sort = c->rank_mode == 2 || (c->rank_mode == 0 && P >= kRankSortMinPods);
+        if (want_sort && P >= 2 && !(versions_differ && full_low_lru) && !wide_count) {
             HIP_TRY(c, c->rk_rows.ensure((size_t)P * sizeof(RankRow)));
-            HIP_TRY(c, c->rk_idx.ensure((size_t)P * 4));
-            HIP_TRY(c, c->rk_idx2.ensure((size_t)P * 4));
-            const PlacementIndexLess less{c->rk_rows.as<RankRow>(), churn2};
+            HIP_TRY(c, c->rk_idx.ensure((size_t)P * sizeof(RankRow)));
+            const PlacementRowLess less{churn2};
             size_t tmp_bytes = 0;
-            HIP_TRY(c, rocprim::merge_sort(nullptr, tmp_bytes, c->rk_idx.as<int32_t>(), c->rk_idx2.as<int32_t>(), (size_t)P, less, st));
+            HIP_TRY(c, rocprim::merge_sort(nullptr, tmp_bytes, c->rk_rows.as<RankRow>(), c->rk_idx.as<RankRow>(), (size_t)P, less, st));
             HIP_TRY(c, c->rk_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
             hipLaunchKernelGGL(rank_rows_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(), P, min_space,
-                               c->rk_rows.as<RankRow>(), c->rk_idx.as<int32_t>());
-            HIP_TRY(c, rocprim::merge_sort(c->rk_tmp.p, tmp_bytes, c->rk_idx.as<int32_t>(), c->rk_idx2.as<int32_t>(), (size_t)P, less, st));
-            hipLaunchKernelGGL(rank_from_order_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, c->rk_idx2.as<int32_t>(), P,
+                               c->rk_rows.as<RankRow>());
+            HIP_TRY(c, rocprim::merge_sort(c->rk_tmp.p, tmp_bytes, c->rk_rows.as<RankRow>(), c->rk_idx.as<RankRow>(), (size_t)P, less, st));
+            hipLaunchKernelGGL(rank_from_order_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, c->rk_idx.as<RankRow>(), P,
                                c->rank.as<int32_t>());
         } else {
             const int pb = div_up(P, kRankBlock);

@@ -259,15 +259,19 @@ __device__ __forceinline__ int32_t view_pos(const Snap &S, int32_t gpos)
 }
 
 // pod index -> position inside the view; P_all = pod slots of the whole table (== S.P on a whole snapshot)
+template <bool VIEW>
 __device__ __forceinline__ int32_t pod_view_pos(const Snap &S, int32_t pod, int32_t P_all)
 {
+    if (!VIEW) return (pod >= 0 && pod < P_all) ? S.pos_of[pod] : -1;
     return (pod >= 0 && pod < P_all) ? view_pos(S, S.pos_of[pod]) : -1;
 }
 
-// Follow request -> model row -> exclusion lists -> rank positions (one lane).
+// Follow request -> model row -> exclusion lists -> rank positions (one lane).  VIEW: S is a shard's view
+// of its slice (positions are translated into it, pos_of is bounded by the whole table's pod count).
+template <bool VIEW>
 __device__ __forceinline__ ResolvedReq resolve_one(const Snap &S, const PlaceArgs &A, int d)
 {
-    const int32_t P_all = A.n_pods_all;
+    const int32_t P_all = VIEW ? A.n_pods_all : S.P;
     const mmp_place_req rq = A.reqs[d];
     ResolvedReq r;
     r.flags = rq.flags;
@@ -278,7 +282,7 @@ __device__ __forceinline__ ResolvedReq resolve_one(const Snap &S, const PlaceArg
     r.fresh_count = rq.fresh_count;
     r.fresh_rpm = rq.fresh_rpm;
     r.model = rq.model;
-    r.selfpos = pod_view_pos(S, rq.self_pod, P_all);
+    r.selfpos = pod_view_pos<VIEW>(S, rq.self_pod, P_all);
     r.pad[0] = r.pad[1] = 0;
 #pragma unroll
     for (int i = 0; i < kInlineExcl; i++) r.excl_pos[i] = -1;
@@ -297,7 +301,7 @@ __device__ __forceinline__ ResolvedReq resolve_one(const Snap &S, const PlaceArg
 #pragma unroll
                 for (int i = 0; i < kInlineExcl; i++) {
                     if (i >= m.n_ents && i < r.n_excl) {
-                        r.excl_pos[i] = pod_view_pos(S, A.extra[rq.extra_off + i - m.n_ents], P_all);
+                        r.excl_pos[i] = pod_view_pos<VIEW>(S, A.extra[rq.extra_off + i - m.n_ents], P_all);
                     }
                 }
             }
@@ -312,7 +316,7 @@ __device__ __forceinline__ ResolvedReq resolve_one(const Snap &S, const PlaceArg
             for (int i = 0; i < kInlineExcl; i++) {
                 if (i < r.n_excl) {
                     const int32_t pod = i < n_ents ? A.ent_pod[m.ent_off + i] : A.extra[rq.extra_off + i - n_ents];
-                    r.excl_pos[i] = pod_view_pos(S, pod, P_all);
+                    r.excl_pos[i] = pod_view_pos<VIEW>(S, pod, P_all);
                 }
             }
         }
@@ -400,7 +404,7 @@ enum { kLaneDone = 0, kLaneWave = 1, kLaneNoneHere = 2, kLaneIncomplete = 3 };
 template <bool VIEW>
 __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, int d, mmp_place_out &o)
 {
-    const ResolvedReq r = resolve_one(S, A, d);
+    const ResolvedReq r = resolve_one<VIEW>(S, A, d);
     o.chosen = MMP_NONE;
     o.best = -1;
     o.n_candidates = 0;
@@ -531,7 +535,7 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
         for (int w = wlo; w <= whi; w++) {
             const uint64_t v = cand(w);
             ccount += __popcll((unsigned long long)v);
-            if (v) hsum += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)(S.w_base + w + 1)));
+            if (v) hsum += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)((VIEW ? S.w_base : 0) + w + 1)));
         }
         int remaining = ccount;
         bool null0 = false, null_s = false, null_o = false;

@@ -293,14 +293,15 @@ def test_kernel_time_bracket():
 
 @pytest.mark.parametrize("seed", range(4))
 def test_rank_by_sorting_equals_all_pairs_ranking(seed, monkeypatch):
-    """Commit ranks by rocprim::merge_sort with the literal comparator whenever PLACEMENT_ORDER is provably
-    a strict total order on the table, and by the all-pairs kernel otherwise (MMP_RANK_ALLPAIRS=1 forces
-    it): same order, element for element, and the oracle's."""
-    pods = int(np.random.default_rng(seed).choice([2, 63, 300, 5000]))
+    """From 8192 pods on, commit ranks by rocprim::merge_sort with the literal comparator whenever
+    PLACEMENT_ORDER is provably a strict total order on the table, and by the all-pairs kernel otherwise
+    (MMP_RANK_MODE=1 forces all-pairs, 2 forces the sort whenever it is legal): same order, element for
+    element, and the oracle's."""
+    pods = [2, 63, 300, 9000][seed]
     fleet = wl.fuzz_fleet(seed + 300, pods=pods)
     orders = []
-    for force in ("0", "1"):
-        monkeypatch.setenv("MMP_RANK_ALLPAIRS", force)
+    for mode in ("1", "2"):
+        monkeypatch.setenv("MMP_RANK_MODE", mode)
         s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
         try:
             s.load_fleet(fleet)
