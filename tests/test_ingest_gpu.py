@@ -223,3 +223,82 @@ def test_malformed_and_edge_case_values():
         assert list(st) == [0, 1, 1, 1, 0, 1, 0, 0, 1, 1]
     finally:
         s.close()
+
+
+def _rand_json(rng, depth=0):
+    """A random JSON value (strings with escapes and structural characters inside, nesting, numbers)."""
+    r = rng.random()
+    if depth > 2 or r < 0.35:
+        k = rng.integers(0, 6)
+        if k == 0:
+            return int(rng.integers(-10**12, 10**12))
+        if k == 1:
+            return None
+        if k == 2:
+            return bool(rng.integers(0, 2))
+        if k == 3:
+            return float(rng.integers(-1000, 1000)) / 8
+        alphabet = ['a', 'b', ' ', '"', '\\', '{', '}', '[', ']', ':', ',', '\n', '\t', 'é', '/']
+        return "".join(rng.choice(alphabet, int(rng.integers(0, 12))))
+    if r < 0.65:
+        return [_rand_json(rng, depth + 1) for _ in range(int(rng.integers(0, 4)))]
+    return {"k%d" % i + ("\"" if rng.random() < 0.1 else ""): _rand_json(rng, depth + 1) for i in range(int(rng.integers(0, 4)))}
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_documents_agree_with_a_json_library(seed):
+    """Property test.  Random well-formed ModelRecord values — known fields of the right type in random
+    positions between random junk fields whose values nest, escape and contain every structural character —
+    parse to exactly what json.loads says; every strict prefix of a value is rejected (truncation can never
+    look well-formed: the closing brace of the record is missing)."""
+    rng = np.random.default_rng(9100 + seed)
+    n_pods = 50
+    ids = _ids_for(n_pods)
+    s = Solver(100, 1000)
+    try:
+        s.load_pod_ids(ids)
+        s.load_type_names(["NLCLASSIFIER", "t1", "t2"], unknown_type=0)
+        vals, docs = [], []
+        for i in range(400):
+            d = {}
+            for j in range(int(rng.integers(0, 5))):
+                d["junk%d" % j] = _rand_json(rng)
+            if rng.random() < 0.7:
+                d["type"] = str(rng.choice(["t1", "t2", "NLCLASSIFIER", "unheard-of"]))
+            if rng.random() < 0.7:
+                d["lu"] = int(rng.integers(0, 10**13))
+            if rng.random() < 0.5:
+                d["lul"] = int(rng.integers(-5, 10**13))
+            for fld in ("instanceIds", "failedIn"):
+                if rng.random() < 0.7:
+                    pods = sorted(rng.choice(n_pods, int(rng.integers(0, 5)), replace=False).tolist(), key=lambda p: ids[p])
+                    d[fld] = {ids[p]: int(rng.integers(1, 10**13)) for p in pods}
+            items = list(d.items())
+            rng.shuffle(items)
+            d = dict(items)
+            sep = [(",", ":"), (", ", ": "), (" ,\n ", " :\t")][int(rng.integers(0, 3))]
+            vals.append(json.dumps(d, separators=sep, ensure_ascii=bool(rng.integers(0, 2))))
+            docs.append(d)
+        status, lul = s.ingest_models_json(vals)
+        assert not status.any(), [v for v, st in zip(vals, status) if st][:3]
+        rows, ep, et = s.get_models()
+        tmap = {"NLCLASSIFIER": 0, "t1": 1, "t2": 2}
+        for i, d in enumerate(docs):
+            assert json.loads(vals[i]) == d
+            inst, fail = d.get("instanceIds", {}), d.get("failedIn", {})
+            assert rows["type"][i] == tmap.get(d.get("type", "NLCLASSIFIER"), 0), vals[i]
+            assert (rows["n_loaded"][i], rows["n_failed"][i], rows["last_used"][i], lul[i]) == \
+                (len(inst), len(fail), d.get("lu", 0), d.get("lul", 0)), vals[i]
+            o = rows["ent_off"][i]
+            want = [(ids.index(k), t) for k, t in list(inst.items()) + list(fail.items())]
+            assert list(zip(ep[o:o + len(want)].tolist(), et[o:o + len(want)].tolist())) == want, vals[i]
+        # truncations
+        cut = []
+        for v in vals[:120]:
+            b = v.encode()
+            k = int(rng.integers(0, len(b)))
+            cut.append(b[:k])
+        status, _ = s.ingest_models_json(cut)
+        assert status.all(), [c for c, st in zip(cut, status) if not st][:3]
+    finally:
+        s.close()

@@ -22,9 +22,14 @@ bench2)
     --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 50 --warmup 5 > $OUT/bench2.json.log 2> $OUT/bench2.err; echo "bench2 exit $?"
   tail -1 $OUT/bench2.json.log | cut -c1-600 ;;
 prof)
-  rm -rf $OUT/prof
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --kernel-only --steps 200 --warmup 20 > $OUT/prof_bench.log 2>&1
-  f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats.csv && head -8 $OUT/kernel_stats.csv ;;
+  # kernel stats of the bench command; --streams 1 so that every dispatch is back to back on one stream and the
+  # average duration is the one bench.py reports as roofline.kernel_ms (8 overlapping streams stretch dispatches)
+  rm -rf $OUT/prof $OUT/prof8
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --kernel-only --steps 200 --warmup 20 --streams 1 > $OUT/prof_bench.log 2>&1
+  f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats.csv && head -3 $OUT/kernel_stats.csv | cut -c1-160
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof8 -- python bench.py --kernel-only --steps 200 --warmup 20 > $OUT/prof8_bench.log 2>&1
+  f=$(find $OUT/prof8 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats_8streams.csv && head -2 $OUT/kernel_stats_8streams.csv | cut -c1-160
+  grep "^{" $OUT/prof_bench.log | python tools/benchline.py prof-run ;;
 pmc)
   rm -rf $OUT/pmc_fetch $OUT/pmc_write
   timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python bench.py --kernel-only --steps 20 --warmup 2 --streams 1 > $OUT/pmc_fetch.log 2>&1
