@@ -515,19 +515,36 @@ def main():
     if rank == 0:
         line["pod_axis"] = pod_axis
         # single-decision latency through the host-pointer C ABI (n=1, PCIe + launch inclusive)
-        lat = []
+        # (the C ABI call with its arguments marshalled once, as a JNI caller holding direct ByteBuffers would;
+        # `..._via_python_wrapper` adds what modelmesh_amd.solver.Solver.place spends on numpy / ctypes per call)
+        lat, lat_py = [], []
         one = reqs[:1].copy()
+        one_out = np.zeros(1, dtype=PLACE_OUT)
+        from modelmesh_amd._lib import ptr as _ptr
+        _one_args = (solver.h, _ptr(one), C.c_int32(1), None, C.c_int32(0), C.c_int64(fleet.now), _ptr(one_out))
+        _place = solver.lib.mmp_place_batch
+        for i in range(0 if args.kernel_only else 2000):
+            one[0] = reqs[i % n]
+            one["extra_off"] = 0
+            one["n_extra"] = 0
+            t1 = time.perf_counter()
+            rc = _place(*_one_args)
+            lat.append(time.perf_counter() - t1)
+            if rc != 0 or (reqs[i % n]["n_extra"] == 0 and (one_out[0]["chosen"] != want[i % n]["chosen"] or
+                                                          one_out[0]["hash"] != want[i % n]["hash"])):
+                raise RuntimeError(f"latency path: decision {i % n} differs from the oracle (rc {rc})")
         for i in range(0 if args.kernel_only else 300):
             one[0] = reqs[i % n]
             one["extra_off"] = 0
             one["n_extra"] = 0
             t1 = time.perf_counter()
             solver.place(one, None, fleet.now)
-            lat.append(time.perf_counter() - t1)
+            lat_py.append(time.perf_counter() - t1)
         if lat:
-            lat = np.array(lat[50:]) * 1e6
+            lat = np.array(lat[200:]) * 1e6
             line["p50_decision_latency_us"] = float(np.percentile(lat, 50))
             line["p99_decision_latency_us"] = float(np.percentile(lat, 99))
+            line["p50_decision_latency_us_via_python_wrapper"] = float(np.percentile(np.array(lat_py[50:]) * 1e6, 50))
             t1 = time.perf_counter()
             for _ in range(5):
                 solver.place(reqs, extra, fleet.now)

@@ -7,6 +7,7 @@
 // implementation of the path in this library.
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <chrono>
 #include <rocprim/device/device_merge_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
@@ -89,6 +90,8 @@ struct FastSlot {
     mmp_place_req *reqs = nullptr;  // hipHostMalloc'ed: same pointer is valid on the device
     int32_t *extra = nullptr;
     mmp_place_out *outs = nullptr;
+    uint32_t *done = nullptr;  // pinned: the kernel stores the call's sequence number here when its results are visible
+    uint32_t seq = 0;
 };
 
 struct mmp_ctx {
@@ -246,7 +249,7 @@ int rebuild_resolved(mmp_ctx *c)
 }
 
 int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs,
-                 hipStream_t st)
+                 hipStream_t st, uint32_t *done_flag = nullptr, uint32_t done_seq = 0, const mmp_place_req *inline_req = nullptr)
 {
     if (n == 0) return MMP_OK;
     PlaceArgs A;
@@ -261,10 +264,15 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     A.now = now;
     A.force_wave = c->force_wave;
     A.n_pods_all = c->snap.P;
+    A.done_flag = n <= kPlaceBlock ? done_flag : nullptr;  // the flag protocol needs a single workgroup
+    A.done_seq = done_seq;
     const int wpad = (c->snap.W + 1) & ~1;
     const size_t lds = (size_t)kPlaceWaves * 2 * wpad * sizeof(uint64_t);
     if (lds > 60 * 1024) return fail(c, MMP_EINVAL, "instance table too large for the LDS staging tile (%d pods)", c->snap.P);
-    hipLaunchKernelGGL(place_batch_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad);
+    if (inline_req)
+        hipLaunchKernelGGL(place_single_kernel, dim3(1), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *inline_req);
+    else
+        hipLaunchKernelGGL(place_batch_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad);
     HIP_TRY(c, hipGetLastError());
     return MMP_OK;
 }
@@ -314,6 +322,8 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
         hipError_t e2 = hipHostMalloc(reinterpret_cast<void **>(&f.reqs), kFastN * sizeof(mmp_place_req), hipHostMallocDefault);
         hipError_t e3 = hipHostMalloc(reinterpret_cast<void **>(&f.extra), kFastExtra * sizeof(int32_t), hipHostMallocDefault);
         hipError_t e4 = hipHostMalloc(reinterpret_cast<void **>(&f.outs), kFastN * sizeof(mmp_place_out), hipHostMallocDefault);
+        if (e4 == hipSuccess) e4 = hipHostMalloc(reinterpret_cast<void **>(&f.done), 64, hipHostMallocDefault);
+        if (e4 == hipSuccess) *f.done = 0;
         if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
             mmp_destroy(c);
             return fail(nullptr, MMP_EHIP, "fast-slot allocation failed");
@@ -333,6 +343,7 @@ void mmp_destroy(mmp_ctx *c)
             (void)hipStreamDestroy(f.stream);
         }
         if (f.reqs) (void)hipHostFree(f.reqs);
+        if (f.done) (void)hipHostFree(f.done);
         if (f.extra) (void)hipHostFree(f.extra);
         if (f.outs) (void)hipHostFree(f.outs);
     }
@@ -1322,6 +1333,8 @@ int mmp_shard_place_phase_dev(mmp_ctx *c, int32_t phase, const void *d_reqs, int
     A.now = now;
     A.force_wave = 0;
     A.n_pods_all = c->ssnap.P;
+    A.done_flag = nullptr;
+    A.done_seq = 0;
     XchgPtrs X{static_cast<int64_t *>(d_xchg[0]), static_cast<int64_t *>(d_xchg[1]), static_cast<int64_t *>(d_xchg[2]),
                static_cast<int64_t *>(d_xchg[3]), static_cast<int64_t *>(d_xchg[4]), static_cast<int64_t *>(d_xchg[5])};
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1361,6 +1374,8 @@ PlaceArgs shard_args(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_ex
     A.now = now;
     A.force_wave = 0;
     A.n_pods_all = c->ssnap.P;
+    A.done_flag = nullptr;
+    A.done_seq = 0;
     return A;
 }
 }  // namespace
@@ -1480,10 +1495,24 @@ int mmp_place_batch(mmp_ctx *c, const mmp_place_req *reqs, int32_t n, const int3
             std::lock_guard<std::mutex> g(c->mu);
             if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
             if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
-            const int rc = place_launch(c, f->reqs, n, f->extra, now, f->outs, f->stream);
+            const int rc = place_launch(c, f->reqs, n, f->extra, now, f->outs, f->stream, f->done, ++f->seq,
+                                        (n == 1 && reqs[0].n_extra == 0) ? &reqs[0] : nullptr);
             if (rc != MMP_OK) return rc;
         }
-        HIP_TRY(c, hipStreamSynchronize(f->stream));
+        // The kernel announces its results through the pinned flag; spinning on it skips the completion-signal
+        // path of hipStreamSynchronize; the ordinary synchronisation remains the fallback when the flag
+        // is late, and commit / loaders still quiesce these streams the ordinary way.
+        bool seen = false;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 0;; spins++) {
+            if (__atomic_load_n(f->done, __ATOMIC_ACQUIRE) == f->seq) {
+                seen = true;
+                break;
+            }
+            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) break;
+            __builtin_ia32_pause();
+        }
+        if (!seen) HIP_TRY(c, hipStreamSynchronize(f->stream));
         memcpy(outs, f->outs, (size_t)n * sizeof(mmp_place_out));
         return MMP_OK;
     }

@@ -61,6 +61,11 @@ struct PlaceArgs {
     int64_t now;
     int32_t force_wave;  // diagnostics: hand every decision to the wave-per-decision kernel
     int32_t n_pods_all;  // pod slots of the whole table (bounds of pos_of; == Snap::P unless the Snap is a shard view)
+    // Latency path only (single-workgroup launches whose results go to pinned host memory): once every
+    // result row is globally visible the kernel stores done_seq here, and the host, spinning on this word,
+    // returns without the completion-signal round trip of hipStreamSynchronize.  nullptr otherwise.
+    uint32_t *done_flag;
+    uint32_t done_seq;
 };
 
 // (int)(double) with Java narrowing semantics
@@ -858,9 +863,8 @@ __device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int
 // leave the common shape are collected in LDS and then taken one wavefront at a time by the general
 // path (place_one) inside the same launch.  LDS: kPlaceWaves × 2 bitmaps × wpad words for that path.
 constexpr int kPlaceBlock = kPlaceWaves * 64;
-__global__ __launch_bounds__(kPlaceBlock) void place_batch_kernel(Snap S, PlaceArgs A, int32_t wpad)
+__device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, int32_t wpad, unsigned char *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int32_t fb_list[kPlaceBlock];
     __shared__ int32_t fb_n;
     if (threadIdx.x == 0) fb_n = 0;
@@ -875,15 +879,40 @@ __global__ __launch_bounds__(kPlaceBlock) void place_batch_kernel(Snap S, PlaceA
     }
     __syncthreads();
     const int nfb = fb_n;
-    if (nfb == 0) return;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint64_t *ew = reinterpret_cast<uint64_t *>(smem) + (size_t)wave * 2 * wpad;
-    uint64_t *fw = ew + wpad;
-    for (int i = wave; i < nfb; i += kPlaceWaves) {
-        const int fd = __builtin_amdgcn_readfirstlane(fb_list[i]);
-        place_one(S, A, fd, ew, fw);
-        wave_sync();
+    if (nfb != 0) {
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        uint64_t *ew = reinterpret_cast<uint64_t *>(smem) + (size_t)wave * 2 * wpad;
+        uint64_t *fw = ew + wpad;
+        for (int i = wave; i < nfb; i += kPlaceWaves) {
+            const int fd = __builtin_amdgcn_readfirstlane(fb_list[i]);
+            place_one(S, A, fd, ew, fw);
+            wave_sync();
+        }
     }
+    if (A.done_flag) {  // wave-uniform; single-workgroup launches only
+        __threadfence_system();  // this thread's result rows are visible to the host ...
+        __syncthreads();         // ... and so are everybody else's
+        if (threadIdx.x == 0) __hip_atomic_store(A.done_flag, A.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__global__ __launch_bounds__(kPlaceBlock) void place_batch_kernel(Snap S, PlaceArgs A, int32_t wpad)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    place_block(S, A, wpad, smem);
+}
+
+// One decision whose request rides in the kernel arguments (the latency path's n = 1 call without extra
+// exclusions): the kernel does not have to fetch the request from pinned host memory over the fabric.
+__global__ __launch_bounds__(kPlaceBlock) void place_single_kernel(Snap S, PlaceArgs A, int32_t wpad, mmp_place_req rq)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ mmp_place_req srq;
+    if (threadIdx.x == 0) srq = rq;
+    __syncthreads();
+    A.reqs = &srq;
+    A.n = 1;
+    place_block(S, A, wpad, smem);
 }
 
 }  // namespace mmp

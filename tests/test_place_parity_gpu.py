@@ -310,3 +310,35 @@ def test_rank_by_sorting_equals_all_pairs_ranking(seed, monkeypatch):
             s.close()
     assert np.array_equal(orders[0], orders[1])
     assert np.array_equal(orders[0], OracleFleet(fleet).order)
+
+
+def test_latency_path_sustains_many_calls_without_a_stream_sync():
+    """The n <= 64 path returns as soon as the kernel's completion flag is visible in pinned memory and never
+    calls hipStreamSynchronize on its slot streams; 150k back-to-back single decisions (no commit in between)
+    must neither slow down nor go wrong."""
+    import ctypes as C
+    import time
+    from modelmesh_amd._lib import ptr
+    fleet = wl.make_fleet("C2")
+    reqs, extra = wl.make_requests(fleet, 5, n=4096, extra_frac=0.0)
+    want = OracleFleet(fleet).place(reqs, extra, fleet.now, threads=8)
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        one = reqs[:1].copy()
+        from modelmesh_amd._lib import PLACE_OUT
+        out = np.zeros(1, dtype=PLACE_OUT)
+        args = (s.h, ptr(one), C.c_int32(1), None, C.c_int32(0), C.c_int64(fleet.now), ptr(out))
+        fn = s.lib.mmp_place_batch
+        lat = np.zeros(150_000)
+        for i in range(len(lat)):
+            k = i & 4095
+            one[0] = reqs[k]
+            t0 = time.perf_counter()
+            rc = fn(*args)
+            lat[i] = time.perf_counter() - t0
+            assert rc == 0 and out[0]["chosen"] == want[k]["chosen"] and out[0]["hash"] == want[k]["hash"], (i, rc)
+        first, last = np.median(lat[1000:11000]), np.median(lat[-10000:])
+        assert last < 2 * first + 5e-6, (first, last)
+    finally:
+        s.close()
