@@ -82,8 +82,8 @@ struct SnapBufs {
 // pinned, device-mapped request / result buffers and a stream of its own, so that one decision never
 // queues behind a 100k-decision batch or a commit (SURVEY.md §8b "Threading").
 constexpr int kFastSlots = 4;
-constexpr int kFastN = 64;       // decisions per fast call
-constexpr int kFastExtra = 512;  // extra-exclusion pool entries per fast call
+constexpr int kFastN = 4096;       // decisions per fast call
+constexpr int kFastExtra = 16384;  // extra-exclusion pool entries per fast call
 struct FastSlot {
     std::mutex mu;
     hipStream_t stream = nullptr;
@@ -91,6 +91,7 @@ struct FastSlot {
     int32_t *extra = nullptr;
     mmp_place_out *outs = nullptr;
     uint32_t *done = nullptr;  // pinned: the kernel stores the call's sequence number here when its results are visible
+    uint32_t *blocks = nullptr;  // device: finished-workgroup counter of the call in flight
     uint32_t seq = 0;
 };
 
@@ -199,6 +200,12 @@ int fail(mmp_ctx *c, int code, const char *fmt, ...)
     } while (0)
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+// Blocking copy on the context's own (non-blocking) stream.  The library never touches the legacy null
+// stream: one synchronous hipMemset there at context creation was measured to serialise, for the rest of the
+// process, kernels that the host issues on separate streams (8-stream step time 4.0 -> 9.8 us).
+// tests/test_abi.py::test_library_never_uses_the_null_stream keeps it that way.
+hipError_t copy_sync(mmp_ctx *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
 constexpr int kRankSortMinPods = 8192;
 
 // Kernel-time bracket of a host-pointer entry point (owner of c->batch_mu): KT_BEGIN after the H2D
@@ -223,6 +230,12 @@ inline void kt_collect(mmp_ctx *c)
 
 // Called with c->mu held, before device state that decisions read is overwritten: every decision
 // kernel was enqueued under c->mu, so once the streams are idle nothing reads the old state.
+hipError_t copy_sync(mmp_ctx *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, c->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(c->stream);
+}
+
 hipError_t quiesce_decisions(mmp_ctx *c)
 {
     for (FastSlot &f : c->fast) {
@@ -249,7 +262,8 @@ int rebuild_resolved(mmp_ctx *c)
 }
 
 int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs,
-                 hipStream_t st, uint32_t *done_flag = nullptr, uint32_t done_seq = 0, const mmp_place_req *inline_req = nullptr)
+                 hipStream_t st, uint32_t *done_flag = nullptr, uint32_t done_seq = 0, const mmp_place_req *inline_req = nullptr,
+                 uint32_t *done_blocks = nullptr)
 {
     if (n == 0) return MMP_OK;
     PlaceArgs A;
@@ -264,13 +278,16 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     A.now = now;
     A.force_wave = c->force_wave;
     A.n_pods_all = c->snap.P;
-    A.done_flag = n <= kPlaceBlock ? done_flag : nullptr;  // the flag protocol needs a single workgroup
+    A.done_flag = done_flag;
     A.done_seq = done_seq;
     const int wpad = (c->snap.W + 1) & ~1;
     const size_t lds = (size_t)kPlaceWaves * 2 * wpad * sizeof(uint64_t);
     if (lds > 60 * 1024) return fail(c, MMP_EINVAL, "instance table too large for the LDS staging tile (%d pods)", c->snap.P);
     if (inline_req)
         hipLaunchKernelGGL(place_single_kernel, dim3(1), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *inline_req);
+    else if (done_flag && n > kPlaceBlock)
+        hipLaunchKernelGGL(place_batch_flag_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad,
+                           done_blocks);
     else
         hipLaunchKernelGGL(place_batch_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad);
     HIP_TRY(c, hipGetLastError());
@@ -324,11 +341,14 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
         hipError_t e4 = hipHostMalloc(reinterpret_cast<void **>(&f.outs), kFastN * sizeof(mmp_place_out), hipHostMallocDefault);
         if (e4 == hipSuccess) e4 = hipHostMalloc(reinterpret_cast<void **>(&f.done), 64, hipHostMallocDefault);
         if (e4 == hipSuccess) *f.done = 0;
+        if (e4 == hipSuccess) e4 = hipMalloc(reinterpret_cast<void **>(&f.blocks), 64);
+        if (e4 == hipSuccess) e4 = hipMemsetAsync(f.blocks, 0, 64, c->stream);
         if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
             mmp_destroy(c);
             return fail(nullptr, MMP_EHIP, "fast-slot allocation failed");
         }
     }
+    (void)hipStreamSynchronize(c->stream);
     *out = c;
     return MMP_OK;
 }
@@ -344,6 +364,7 @@ void mmp_destroy(mmp_ctx *c)
         }
         if (f.reqs) (void)hipHostFree(f.reqs);
         if (f.done) (void)hipHostFree(f.done);
+        if (f.blocks) (void)hipFree(f.blocks);
         if (f.extra) (void)hipHostFree(f.extra);
         if (f.outs) (void)hipHostFree(f.outs);
     }
@@ -604,10 +625,10 @@ int mmp_models_load(mmp_ctx *c, const mmp_model_row *rows, int32_t n_models, con
     HIP_TRY(c, c->models.ensure((size_t)std::max(n_models, 1) * sizeof(mmp_model_row)));
     HIP_TRY(c, c->ent_pod.ensure((size_t)std::max(n_entries, 1) * sizeof(int32_t)));
     HIP_TRY(c, c->ent_time.ensure((size_t)std::max(n_entries, 1) * sizeof(int64_t)));
-    if (n_models) HIP_TRY(c, hipMemcpy(c->models.p, rows, (size_t)n_models * sizeof(mmp_model_row), hipMemcpyHostToDevice));
+    if (n_models) HIP_TRY(c, copy_sync(c, c->models.p, rows, (size_t)n_models * sizeof(mmp_model_row), hipMemcpyHostToDevice));
     if (n_entries) {
-        HIP_TRY(c, hipMemcpy(c->ent_pod.p, ent_pod, (size_t)n_entries * sizeof(int32_t), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->ent_time.p, ent_time, (size_t)n_entries * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, copy_sync(c, c->ent_pod.p, ent_pod, (size_t)n_entries * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, copy_sync(c, c->ent_time.p, ent_time, (size_t)n_entries * sizeof(int64_t), hipMemcpyHostToDevice));
     }
     c->n_models = n_models;
     c->n_entries = n_entries;
@@ -796,7 +817,7 @@ int mmp_get_order(mmp_ctx *c, int32_t *order_out, int32_t *n_out)
     if (c->n_shards > 0) return fail(c, MMP_ESTATE, "mmp_get_order: a pod-axis shard holds only its own slice of the order");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const int32_t n = c->stats.instance_count;  // absent rows sort last
-    if (n) HIP_TRY(c, hipMemcpy(order_out, c->snap.orig, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (n) HIP_TRY(c, copy_sync(c, order_out, c->snap.orig, (size_t)n * 4, hipMemcpyDeviceToHost));
     *n_out = n;
     return MMP_OK;
 }
@@ -849,8 +870,8 @@ int build_hash_table(mmp_ctx *c, const char *strs, const int32_t *off, int32_t n
     }
     HIP_TRY(c, d_hash.ensure((size_t)cap * 8));
     HIP_TRY(c, d_val.ensure((size_t)cap * 4));
-    HIP_TRY(c, hipMemcpy(d_hash.p, hs.data(), (size_t)cap * 8, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(d_val.p, vs.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, copy_sync(c, d_hash.p, hs.data(), (size_t)cap * 8, hipMemcpyHostToDevice));
+    HIP_TRY(c, copy_sync(c, d_val.p, vs.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
     mask_out = cap - 1;
     return MMP_OK;
 }
@@ -1076,9 +1097,9 @@ int mmp_models_get(mmp_ctx *c, mmp_model_row *rows_out, int32_t max_models, int3
     *n_models_out = c->n_models;
     *n_entries_out = c->n_entries;
     const int32_t m = std::min(c->n_models, max_models), e = std::min(c->n_entries, max_entries);
-    if (m > 0 && rows_out) HIP_TRY(c, hipMemcpy(rows_out, c->models.p, (size_t)m * sizeof(mmp_model_row), hipMemcpyDeviceToHost));
-    if (e > 0 && ent_pod_out) HIP_TRY(c, hipMemcpy(ent_pod_out, c->ent_pod.p, (size_t)e * 4, hipMemcpyDeviceToHost));
-    if (e > 0 && ent_time_out) HIP_TRY(c, hipMemcpy(ent_time_out, c->ent_time.p, (size_t)e * 8, hipMemcpyDeviceToHost));
+    if (m > 0 && rows_out) HIP_TRY(c, copy_sync(c, rows_out, c->models.p, (size_t)m * sizeof(mmp_model_row), hipMemcpyDeviceToHost));
+    if (e > 0 && ent_pod_out) HIP_TRY(c, copy_sync(c, ent_pod_out, c->ent_pod.p, (size_t)e * 4, hipMemcpyDeviceToHost));
+    if (e > 0 && ent_time_out) HIP_TRY(c, copy_sync(c, ent_time_out, c->ent_time.p, (size_t)e * 8, hipMemcpyDeviceToHost));
     return MMP_OK;
 }
 
@@ -1496,7 +1517,7 @@ int mmp_place_batch(mmp_ctx *c, const mmp_place_req *reqs, int32_t n, const int3
             if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
             if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
             const int rc = place_launch(c, f->reqs, n, f->extra, now, f->outs, f->stream, f->done, ++f->seq,
-                                        (n == 1 && reqs[0].n_extra == 0) ? &reqs[0] : nullptr);
+                                        (n == 1 && reqs[0].n_extra == 0) ? &reqs[0] : nullptr, f->blocks);
             if (rc != MMP_OK) return rc;
         }
         // The kernel announces its results through the pinned flag; spinning on it skips the completion-signal
@@ -1723,8 +1744,8 @@ int mmp_proactive_plan(mmp_ctx *c, int32_t default_units, int64_t now, int32_t m
         kt_collect(c);
         const int32_t n_copy = std::min(h.n_selected, max_out);
         if (n_copy > 0) {
-            HIP_TRY(c, hipMemcpy(out_model, c->r_out_model.p, (size_t)n_copy * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(c, hipMemcpy(out_last_used, c->r_out_lu.p, (size_t)n_copy * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(c, copy_sync(c, out_model, c->r_out_model.p, (size_t)n_copy * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(c, copy_sync(c, out_last_used, c->r_out_lu.p, (size_t)n_copy * 8, hipMemcpyDeviceToHost));
         }
     }
     info->size_estimate = h.size_estimate;
@@ -1901,17 +1922,17 @@ int mmp_caches_load_keyed(mmp_ctx *c, int32_t n_caches, const int32_t *seg_off, 
             us[i].reserved = -1;
         }
     }
-    HIP_TRY(c, hipMemcpy(K.off.p, seg_off, (size_t)(n_caches + 1) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, copy_sync(c, K.off.p, seg_off, (size_t)(n_caches + 1) * 4, hipMemcpyHostToDevice));
     if (E) {
-        HIP_TRY(c, hipMemcpy(K.lu.p, last_used, (size_t)E * 8, hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(K.wt.p, weight, (size_t)E * 4, hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(K.key.p, key, (size_t)E * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, copy_sync(c, K.lu.p, last_used, (size_t)E * 8, hipMemcpyHostToDevice));
+        HIP_TRY(c, copy_sync(c, K.wt.p, weight, (size_t)E * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, copy_sync(c, K.key.p, key, (size_t)E * 4, hipMemcpyHostToDevice));
     }
     if (n_caches) {
-        HIP_TRY(c, hipMemcpy(K.n.p, c->k_n.data(), (size_t)n_caches * 4, hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->k_cap.p, capacity, (size_t)n_caches * 8, hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->k_wsize.p, ws.data(), (size_t)n_caches * 8, hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->k_ubm.p, us.data(), (size_t)n_caches * sizeof(mmp_ubm_state), hipMemcpyHostToDevice));
+        HIP_TRY(c, copy_sync(c, K.n.p, c->k_n.data(), (size_t)n_caches * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, copy_sync(c, c->k_cap.p, capacity, (size_t)n_caches * 8, hipMemcpyHostToDevice));
+        HIP_TRY(c, copy_sync(c, c->k_wsize.p, ws.data(), (size_t)n_caches * 8, hipMemcpyHostToDevice));
+        HIP_TRY(c, copy_sync(c, c->k_ubm.p, us.data(), (size_t)n_caches * sizeof(mmp_ubm_state), hipMemcpyHostToDevice));
     }
     c->k_caches = n_caches;
     return MMP_OK;
@@ -2014,18 +2035,18 @@ int mmp_cache_read(mmp_ctx *c, int32_t cache, int32_t max_entries, int64_t *last
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     mmp_ctx::KeyedStore &K = c->ks[c->ks_cur];
     int32_t off = 0;
-    HIP_TRY(c, hipMemcpy(&off, K.off.as<int32_t>() + cache, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, copy_sync(c, &off, K.off.as<int32_t>() + cache, 4, hipMemcpyDeviceToHost));
     const int32_t n = c->k_n[cache];
     *n_out = n;
     const int32_t m = std::min(n, max_entries);
     if (m > 0) {
-        if (last_used) HIP_TRY(c, hipMemcpy(last_used, K.lu.as<int64_t>() + off, (size_t)m * 8, hipMemcpyDeviceToHost));
-        if (weight) HIP_TRY(c, hipMemcpy(weight, K.wt.as<int32_t>() + off, (size_t)m * 4, hipMemcpyDeviceToHost));
-        if (key) HIP_TRY(c, hipMemcpy(key, K.key.as<int32_t>() + off, (size_t)m * 4, hipMemcpyDeviceToHost));
+        if (last_used) HIP_TRY(c, copy_sync(c, last_used, K.lu.as<int64_t>() + off, (size_t)m * 8, hipMemcpyDeviceToHost));
+        if (weight) HIP_TRY(c, copy_sync(c, weight, K.wt.as<int32_t>() + off, (size_t)m * 4, hipMemcpyDeviceToHost));
+        if (key) HIP_TRY(c, copy_sync(c, key, K.key.as<int32_t>() + off, (size_t)m * 4, hipMemcpyDeviceToHost));
     }
-    if (capacity) HIP_TRY(c, hipMemcpy(capacity, c->k_cap.as<int64_t>() + cache, 8, hipMemcpyDeviceToHost));
-    if (weighted_size) HIP_TRY(c, hipMemcpy(weighted_size, c->k_wsize.as<int64_t>() + cache, 8, hipMemcpyDeviceToHost));
-    if (ubm) HIP_TRY(c, hipMemcpy(ubm, c->k_ubm.as<mmp_ubm_state>() + cache, sizeof(mmp_ubm_state), hipMemcpyDeviceToHost));
+    if (capacity) HIP_TRY(c, copy_sync(c, capacity, c->k_cap.as<int64_t>() + cache, 8, hipMemcpyDeviceToHost));
+    if (weighted_size) HIP_TRY(c, copy_sync(c, weighted_size, c->k_wsize.as<int64_t>() + cache, 8, hipMemcpyDeviceToHost));
+    if (ubm) HIP_TRY(c, copy_sync(c, ubm, c->k_ubm.as<mmp_ubm_state>() + cache, sizeof(mmp_ubm_state), hipMemcpyDeviceToHost));
     return MMP_OK;
 }
 
@@ -2046,12 +2067,12 @@ int mmp_caches_load(mmp_ctx *c, int32_t n_caches, const int32_t *seg_off, const 
     HIP_TRY(c, c->c_lu.ensure((size_t)std::max(E, 1) * 8));
     HIP_TRY(c, c->c_wt.ensure((size_t)std::max(E, 1) * 4));
     HIP_TRY(c, c->c_cap.ensure((size_t)std::max(n_caches, 1) * 8));
-    HIP_TRY(c, hipMemcpy(c->c_seg.p, seg_off, (size_t)(n_caches + 1) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, copy_sync(c, c->c_seg.p, seg_off, (size_t)(n_caches + 1) * 4, hipMemcpyHostToDevice));
     if (E) {
-        HIP_TRY(c, hipMemcpy(c->c_lu.p, last_used, (size_t)E * 8, hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->c_wt.p, weight, (size_t)E * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, copy_sync(c, c->c_lu.p, last_used, (size_t)E * 8, hipMemcpyHostToDevice));
+        HIP_TRY(c, copy_sync(c, c->c_wt.p, weight, (size_t)E * 4, hipMemcpyHostToDevice));
     }
-    if (n_caches) HIP_TRY(c, hipMemcpy(c->c_cap.p, capacity, (size_t)n_caches * 8, hipMemcpyHostToDevice));
+    if (n_caches) HIP_TRY(c, copy_sync(c, c->c_cap.p, capacity, (size_t)n_caches * 8, hipMemcpyHostToDevice));
     c->n_caches = n_caches;
     return MMP_OK;
 }

@@ -61,9 +61,10 @@ struct PlaceArgs {
     int64_t now;
     int32_t force_wave;  // diagnostics: hand every decision to the wave-per-decision kernel
     int32_t n_pods_all;  // pod slots of the whole table (bounds of pos_of; == Snap::P unless the Snap is a shard view)
-    // Latency path only (single-workgroup launches whose results go to pinned host memory): once every
-    // result row is globally visible the kernel stores done_seq here, and the host, spinning on this word,
-    // returns without the completion-signal round trip of hipStreamSynchronize.  nullptr otherwise.
+    // Latency path only (results go to pinned host memory): once every result row is globally visible the
+    // kernel — its last workgroup to finish, counted in done_blocks — stores done_seq here, and the host,
+    // spinning on this word, returns without the completion-signal round trip of hipStreamSynchronize.
+    // nullptr otherwise.
     uint32_t *done_flag;
     uint32_t done_seq;
 };
@@ -863,7 +864,8 @@ __device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int
 // leave the common shape are collected in LDS and then taken one wavefront at a time by the general
 // path (place_one) inside the same launch.  LDS: kPlaceWaves × 2 bitmaps × wpad words for that path.
 constexpr int kPlaceBlock = kPlaceWaves * 64;
-__device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, int32_t wpad, unsigned char *smem)
+__device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, int32_t wpad, unsigned char *smem,
+                                            uint32_t *done_blocks = nullptr)
 {
     __shared__ int32_t fb_list[kPlaceBlock];
     __shared__ int32_t fb_n;
@@ -889,10 +891,17 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
             wave_sync();
         }
     }
-    if (A.done_flag) {  // wave-uniform; single-workgroup launches only
+    if (A.done_flag) {  // wave-uniform
         __threadfence_system();  // this thread's result rows are visible to the host ...
-        __syncthreads();         // ... and so are everybody else's
-        if (threadIdx.x == 0) __hip_atomic_store(A.done_flag, A.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __syncthreads();         // ... and so are the rest of the workgroup's
+        if (threadIdx.x == 0) {
+            bool last = gridDim.x == 1;
+            if (!last && atomicAdd(done_blocks, 1u) == gridDim.x - 1) {
+                *done_blocks = 0;  // the other workgroups have all passed their fence: this one announces
+                last = true;
+            }
+            if (last) __hip_atomic_store(A.done_flag, A.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -900,6 +909,16 @@ __global__ __launch_bounds__(kPlaceBlock) void place_batch_kernel(Snap S, PlaceA
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     place_block(S, A, wpad, smem);
+}
+
+// The latency path's launches of more than one workgroup: done_blocks = device counter of finished
+// workgroups (left at zero); the last one to finish announces completion (PlaceArgs::done_flag).  A kernel of
+// its own so that the throughput kernel's argument block stays as small as it was (measured: the launch
+// path of this runtime is sensitive to it).
+__global__ __launch_bounds__(kPlaceBlock) void place_batch_flag_kernel(Snap S, PlaceArgs A, int32_t wpad, uint32_t *done_blocks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    place_block(S, A, wpad, smem, done_blocks);
 }
 
 // One decision whose request rides in the kernel arguments (the latency path's n = 1 call without extra

@@ -70,3 +70,22 @@ def test_bitmap_packing_roundtrip():
     for p in (1, 63, 64, 65, 1000):
         m = rng.random((3, p)) < 0.4
         assert np.array_equal(unpack_bitmap(bitmap_from_bool(m), p).astype(bool), m)
+
+
+def test_library_never_uses_the_null_stream():
+    """Source lint.  Synchronous hipMemcpy / hipMemset / hipDeviceSynchronize run on (or wait for) the legacy
+    null stream; a single hipMemset there at context creation was measured to serialise, for the rest of the
+    process, kernels issued on separate streams.  The library owns non-blocking streams and uses only the
+    *Async forms on them."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bad = []
+    for f in glob.glob(os.path.join(root, "modelmesh_amd", "csrc", "*")):
+        for i, line in enumerate(open(f), 1):
+            code = line.split("//")[0]
+            if re.search(r"\bhip(Memcpy|Memset|Memcpy2D|MemcpyToSymbol|MemcpyFromSymbol)\s*\(", code) or "hipDeviceSynchronize" in code:
+                bad.append(f"{os.path.basename(f)}:{i}: {line.strip()}")
+            if re.search(r"<<<[^>]*>>>", code) or re.search(r"hipLaunchKernelGGL\([^;]*,\s*0\s*,\s*(0|nullptr)\s*,", code):
+                bad.append(f"{os.path.basename(f)}:{i}: launch on the null stream: {line.strip()}")
+    assert not bad, "\n".join(bad)
