@@ -321,8 +321,8 @@ def secondary_kernels_leg(fleet, solver, device: int, workload: str = "C3", reps
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pod-axis", action="store_true", help="skip the pod-axis sharded leg")
@@ -380,7 +380,9 @@ def main():
     import ctypes as C
     _fn = solver.lib.mmp_place_batch_dev
     n_streams = max(1, args.streams)
-    streams = [stream] + [torch.cuda.Stream(dev) for _ in range(n_streams - 1)]
+    # the timed steps go to streams of their own; torch's current stream is the legacy null stream, whose launches
+    # order against every blocking stream of the process (it is used below only for the single-stream passes)
+    streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
     outs_bufs = [d_outs] + [torch.zeros(n * 16, dtype=torch.uint8, device=dev) for _ in range(n_streams - 1)]
     _args = [(solver.h, C.c_void_p(d_reqs.data_ptr()), C.c_int32(n), C.c_void_p(d_extra.data_ptr()), C.c_int64(fleet.now),
               C.c_void_p(o.data_ptr()), C.c_void_p(st.cuda_stream)) for st, o in zip(streams, outs_bufs)]
@@ -399,13 +401,19 @@ def main():
         step(i)
     fence()
     # timed region: exactly K steps (independent batches, issued round-robin on the streams)
+    # (the loop body is the bare C call: at ~4 us of launch work per step a Python function frame is measurable)
+    sched = [_args[i % n_streams] for i in range(args.steps)]
+    rcs = 0
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    for a in sched:
+        rcs |= _fn(*a)
     fence()
     elapsed = time.perf_counter() - t0
+    if rcs != 0:
+        raise RuntimeError(solver.lib.mmp_last_error(solver.h))
     # the kernel's own launch duration: K back-to-back launches on ONE stream between a HIP event pair
     # (region time / K is what rocprofv3 --kernel-trace reports as the kernel's average duration) ...
+    stream = streams[0]  # events must be recorded on the stream the kernel is launched on
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record(stream)
     for i in range(args.steps):
@@ -414,9 +422,10 @@ def main():
     fence()
     gpu_ms_per_step = ev0.elapsed_time(ev1) / args.steps
     # ... and an event pair around every single launch (adds ~2 us of event granularity)
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    for i in range(args.steps):
+    n_pairs = min(args.steps, 200)
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(n_pairs)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(n_pairs)]
+    for i in range(n_pairs):
         starts[i].record(stream)
         step(0)
         ends[i].record(stream)
@@ -506,7 +515,7 @@ def main():
         legs = [args.workload] + (["C4"] if world >= 8 and args.workload != "C4" else [])
         for wname in legs:
             try:
-                pod_axis.append(pod_axis_leg(wname, rank, world, dev, max(args.steps // 10, 5), max(args.warmup // 10, 2), fence))
+                pod_axis.append(pod_axis_leg(wname, rank, world, dev, min(max(args.steps // 10, 5), 40), min(max(args.warmup // 10, 2), 5), fence))
             except Exception as e:  # the headline line must still be printed
                 pod_axis.append({"workload": wname, "error": f"{type(e).__name__}: {e}"})
             if rank == 0:
