@@ -145,8 +145,8 @@ def pod_axis_leg(workload: str, rank: int, world: int, dev, steps: int, warmup: 
 
 
 def churn_leg(fleet, solver, slices: int = 8, events: int = 20_000):
-    """Config C5 on this rank's solver: per 2 s slice of simulated time apply the changed InstanceRecords,
-    reload the registry view, re-rank on the device, decide the slice's load targets and evaluate its
+    """Config C5 on this rank's solver: per 2 s slice of simulated time apply the changed InstanceRecords and
+    the changed ModelRecords (mmp_pods_upsert / mmp_models_upsert), re-rank on the device, decide the slice's load targets and evaluate its
     cache evictions (host-pointer C ABI, PCIe inclusive).  Only the library calls are timed; the event
     generation / bookkeeping between slices (numpy) is not part of the path."""
     from modelmesh_amd import workload as wl
@@ -155,10 +155,11 @@ def churn_leg(fleet, solver, slices: int = 8, events: int = 20_000):
     busy, commit_s, n_ev = 0.0, 0.0, 0
     for it in range(slices + 1):
         f = cs.fleet
+        ev = cs.model_events() if it else None  # building the event batch is the host mesh's work, not timed
         t0 = time.perf_counter()
         if it:
             solver.upsert_pods(cs.changed_pods, f.pods[cs.changed_pods])
-            solver.load_models(f.models, f.ent_pod, f.ent_time)
+            solver.upsert_models(*ev)  # the ModelRecords the previous slice changed (registry listener events)
             t1 = time.perf_counter()
             solver.commit()
             commit_s += time.perf_counter() - t1

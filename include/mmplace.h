@@ -370,6 +370,15 @@ int mmp_upgrade_replaced(mmp_ctx *ctx, int32_t *rs_out, int64_t *expiry_out, int
 /* The model registry view (MM.java:308). ent_pod / ent_time have n_entries items. */
 int mmp_models_load(mmp_ctx *ctx, const mmp_model_row *rows, int32_t n_models,
                     const int32_t *ent_pod, const int64_t *ent_time, int32_t n_entries);
+/* Registry events (the registry's KV listener, MM.java:628; ModelRecord is replaced as a whole on every
+ * change): rows[i] replaces model idx[i] (idx[i] == current model count appends); rows[i].ent_off indexes
+ * the ent_pod / ent_time arrays of THIS call.  A deleted record is upserted as an empty row.  When a model
+ * appears twice the last row wins.  O(rows + entries) per call: the new entries are appended to an
+ * arena, the rows (and their resolved exclusion positions) are rewritten in place; the arena is squeezed
+ * when it holds more garbage than live entries.  Takes effect immediately (no commit needed: the
+ * registry is not part of the snapshot). */
+int mmp_models_upsert(mmp_ctx *ctx, const int32_t *idx, const mmp_model_row *rows, int32_t n, const int32_t *ent_pod,
+                      const int64_t *ent_time, int32_t n_entries);
 /* Rank pods by PLACEMENT_ORDER (MM.java:4646-4703) on the device and publish
  * the new immutable snapshot. MMP_EORDER if the comparator is inconsistent. */
 int mmp_snapshot_commit(mmp_ctx *ctx);

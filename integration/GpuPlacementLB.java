@@ -31,6 +31,7 @@ final class MmPlace {
                                 ByteBuffer hasAllowed, ByteBuffer hasPrefer);
     static native int replacedReplicaSetsLoad(long h, ByteBuffer rs, int n);
     static native int modelsLoad(long h, ByteBuffer rows, int nModels, ByteBuffer entPod, ByteBuffer entTime, int nEntries);
+    static native int modelsUpsert(long h, ByteBuffer idx, ByteBuffer rows, int n, ByteBuffer entPod, ByteBuffer entTime, int nEntries);
     static native int commit(long h);
     static native int placeBatch(long h, ByteBuffer reqs, int n, ByteBuffer extraPool, int nExtra, long nowMs, ByteBuffer outs);
     static native int serveBatch(long h, ByteBuffer reqs, int n, ByteBuffer inUse, ByteBuffer lastUsed,
@@ -91,7 +92,7 @@ final class MmPlace {
 abstract class GpuCacheMissLB extends ModelMesh.IdBasedLoadBalancer {
     // One snapshot handle per ModelMesh instance, refreshed by the instance-table listener
     // (handleInstanceTableChange, ModelMesh.java:1455): podsUpsert/podsRemove + commit, and by the
-    // registry listener for modelsLoad. The interner maps instance id -> dense pod index and keeps
+    // registry listener: modelsLoad once, modelsUpsert per ModelRecord event. The interner maps instance id -> dense pod index and keeps
     // id_order == rank under String.compareTo, replica_set == interned id.substring(0,6).
     abstract long handle();
     abstract int podIndexOf(String instanceId);     // -1 if unknown

@@ -80,6 +80,15 @@ JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_modelsLoad(JNIEnv *
                  mmp_models_load(ctx_of(h), buf<mmp_model_row>(env, rows), nModels, buf<int32_t>(env, entPod),
                                  buf<int64_t>(env, entTime), nEntries));
 }
+// registry listener events: whole ModelRecords replaced by index (see mmp_models_upsert)
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_modelsUpsert(JNIEnv *env, jclass, jlong h, jobject idx,
+                                                                          jobject rows, jint n, jobject entPod,
+                                                                          jobject entTime, jint nEntries)
+{
+    return check(env, ctx_of(h),
+                 mmp_models_upsert(ctx_of(h), buf<int32_t>(env, idx), buf<mmp_model_row>(env, rows), n,
+                                   buf<int32_t>(env, entPod), buf<int64_t>(env, entTime), nEntries));
+}
 JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_commit(JNIEnv *env, jclass, jlong h)
 {
     return check(env, ctx_of(h), mmp_snapshot_commit(ctx_of(h)));

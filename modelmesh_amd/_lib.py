@@ -125,6 +125,7 @@ SYMBOLS = [
     ("mmp_upgrade_housekeeping", C.c_int, [_P, C.c_int64]),
     ("mmp_upgrade_replaced", C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     ("mmp_models_load", C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32]),
+    ("mmp_models_upsert", C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.c_int32]),
     ("mmp_snapshot_commit", C.c_int, [_P]),
     ("mmp_get_order", C.c_int, [_P, _P, C.POINTER(C.c_int32)]),
     ("mmp_cluster_stats", C.c_int, [_P, _P]),

@@ -141,7 +141,12 @@ struct mmp_ctx {
 
     // model registry view
     DevBuf models, ent_pod, ent_time;
-    int32_t n_models = 0, n_entries = 0;
+    int32_t n_models = 0, n_entries = 0;  // n_entries = used part of the entry arena (mmp_models_upsert appends)
+    std::vector<int32_t> m_cnt;           // host shadow: entries per model (for the arena's garbage accounting)
+    int64_t ent_live = 0;                 // entries still referenced by a row
+    DevBuf u_idx, u_rows, u_cnt, u_offs, u_tmp;
+    std::vector<uint64_t> u_stamp;        // per model: (call generation, row index) of the last row naming it
+    uint32_t u_gen = 0;
     // the registry view resolved against the current snapshot (place_kernel.hpp: ResolvedModel)
     DevBuf rmodels;
     bool rmodels_ok = false;
@@ -384,7 +389,7 @@ void mmp_destroy(mmp_ctx *c)
                       &c->r_tmp, &c->r_out_model, &c->r_out_lu, &c->k_cap, &c->k_wsize, &c->k_ubm, &c->k_ops, &c->k_order,
                       &c->k_opoff, &c->k_outs, &c->k_ev, &c->k_evoff, &c->idtab_hash, &c->idtab_val, &c->tytab_hash,
                       &c->tytab_val, &c->j_buf, &c->j_off, &c->j_rows, &c->j_aux, &c->j_status, &c->j_cnt, &c->j_offs, &c->j_tmp_pod,
-                      &c->j_tmp_time, &c->j_scan_tmp, &c->rk_rows, &c->rk_idx, &c->rk_tmp, &c->f_flags, &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp,
+                      &c->j_tmp_time, &c->j_scan_tmp, &c->rk_rows, &c->rk_idx, &c->rk_tmp, &c->u_idx, &c->u_rows, &c->u_cnt, &c->u_offs, &c->u_tmp, &c->f_flags, &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp,
                       &c->ks[0].off, &c->ks[0].lu, &c->ks[0].wt,
                       &c->ks[0].key, &c->ks[0].n, &c->ks[1].off, &c->ks[1].lu, &c->ks[1].wt, &c->ks[1].key, &c->ks[1].n})
         b->release();
@@ -632,7 +637,146 @@ int mmp_models_load(mmp_ctx *c, const mmp_model_row *rows, int32_t n_models, con
     }
     c->n_models = n_models;
     c->n_entries = n_entries;
+    c->m_cnt.resize(n_models);
+    c->ent_live = 0;
+    for (int32_t i = 0; i < n_models; i++) {
+        c->m_cnt[i] = rows[i].n_loaded + rows[i].n_failed;
+        c->ent_live += c->m_cnt[i];
+    }
     return rebuild_resolved(c);
+}
+
+namespace {
+// grow a device buffer, keeping its first `used` bytes
+int grow_keep(mmp_ctx *c, DevBuf &b, size_t used, size_t want)
+{
+    if (want <= b.cap) return MMP_OK;
+    DevBuf nb;
+    HIP_TRY(c, nb.ensure(std::max(want, b.cap * 2)));
+    if (used && b.p) {
+        const hipError_t e = copy_sync(c, nb.p, b.p, used, hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            nb.release();
+            HIP_TRY(c, e);
+        }
+    }
+    b.release();
+    b = nb;
+    return MMP_OK;
+}
+
+// squeeze the garbage out of the entry arena (rows keep their order, entries their order inside a row)
+int compact_registry(mmp_ctx *c)
+{
+    const int32_t n = c->n_models;
+    hipStream_t st = c->stream;
+    HIP_TRY(c, c->u_cnt.ensure((size_t)(n + 1) * 4));
+    HIP_TRY(c, c->u_offs.ensure((size_t)(n + 1) * 4));
+    size_t tmp = 0;
+    HIP_TRY(c, rocprim::exclusive_scan(nullptr, tmp, c->u_cnt.as<int32_t>(), c->u_offs.as<int32_t>(), (int32_t)0, (size_t)n + 1,
+                                       rocprim::plus<int32_t>(), st));
+    HIP_TRY(c, c->u_tmp.ensure(std::max<size_t>(tmp, 16)));
+    DevBuf np, nt;
+    const size_t cap = (size_t)std::max<int64_t>(c->ent_live + c->ent_live / 2, 1024);
+    HIP_TRY(c, np.ensure(cap * 4));
+    if (nt.ensure(cap * 8) != hipSuccess) {
+        np.release();
+        return fail(c, MMP_ENOMEM, "compact_registry: out of device memory");
+    }
+    hipLaunchKernelGGL(model_counts_kernel, dim3(div_up(n + 1, 256)), dim3(256), 0, st, c->models.as<mmp_model_row>(), n,
+                       c->u_cnt.as<int32_t>());
+    (void)rocprim::exclusive_scan(c->u_tmp.p, tmp, c->u_cnt.as<int32_t>(), c->u_offs.as<int32_t>(), (int32_t)0, (size_t)n + 1,
+                                  rocprim::plus<int32_t>(), st);
+    hipLaunchKernelGGL(move_entries_kernel, dim3(div_up(std::max(n, 1), 256)), dim3(256), 0, st, c->models.as<mmp_model_row>(), n,
+                       c->u_offs.as<int32_t>(), c->ent_pod.as<int32_t>(), c->ent_time.as<int64_t>(), np.as<int32_t>(),
+                       nt.as<int64_t>());
+    const hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        np.release();
+        nt.release();
+        HIP_TRY(c, e);
+    }
+    c->ent_pod.release();
+    c->ent_time.release();
+    c->ent_pod = np;
+    c->ent_time = nt;
+    c->n_entries = (int32_t)c->ent_live;
+    return MMP_OK;
+}
+}  // namespace
+
+int mmp_models_upsert(mmp_ctx *c, const int32_t *idx, const mmp_model_row *rows, int32_t n, const int32_t *ent_pod,
+                      const int64_t *ent_time, int32_t n_entries)
+{
+    if (!c || n < 0 || n_entries < 0 || (n > 0 && (!idx || !rows)) || (n_entries > 0 && (!ent_pod || !ent_time)))
+        return fail(c, MMP_EINVAL, "mmp_models_upsert: bad argument");
+    if (n == 0) return MMP_OK;
+    std::lock_guard<std::mutex> gb(c->batch_mu);
+    std::lock_guard<std::mutex> g(c->mu);
+    int32_t count = c->n_models;
+    for (int32_t i = 0; i < n; i++) {
+        const mmp_model_row &m = rows[i];
+        if (idx[i] < 0 || idx[i] > count) return fail(c, MMP_EINVAL, "mmp_models_upsert: row %d names model %d of %d", i, idx[i], count);
+        if (idx[i] == count) count++;
+        if (m.n_loaded < 0 || m.n_failed < 0 || m.ent_off < 0 || (int64_t)m.ent_off + m.n_loaded + m.n_failed > (int64_t)n_entries)
+            return fail(c, MMP_EINVAL, "mmp_models_upsert: row %d entry range out of bounds", i);
+    }
+    if ((int64_t)c->n_entries + n_entries > INT32_MAX) return fail(c, MMP_EINVAL, "mmp_models_upsert: entry arena overflow; reload the registry");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, quiesce_decisions(c));  // rows are rewritten in place
+    hipStream_t st = c->stream;
+    // the last row wins when a model appears twice in one call (events are applied in order)
+    std::vector<int32_t> last(n);
+    {
+        const uint64_t gen = (uint64_t)(++c->u_gen) << 32;
+        if (c->u_stamp.size() < (size_t)count) c->u_stamp.resize(count, 0);
+        for (int32_t i = 0; i < n; i++) c->u_stamp[idx[i]] = gen | (uint32_t)i;
+        int32_t k = 0;
+        for (int32_t i = 0; i < n; i++)
+            if (c->u_stamp[idx[i]] == (gen | (uint32_t)i)) last[k++] = i;
+        last.resize(k);
+    }
+    const int32_t k = (int32_t)last.size();
+    const int32_t base = c->n_entries;
+    std::vector<int32_t> h_idx(k);
+    std::vector<mmp_model_row> h_rows(k);
+    c->m_cnt.resize(count, 0);
+    for (int32_t j = 0; j < k; j++) {
+        const int32_t i = last[j];
+        h_idx[j] = idx[i];
+        h_rows[j] = rows[i];
+        h_rows[j].ent_off += base;
+        c->ent_live += (int64_t)(rows[i].n_loaded + rows[i].n_failed) - c->m_cnt[idx[i]];
+        c->m_cnt[idx[i]] = rows[i].n_loaded + rows[i].n_failed;
+    }
+    int rc = grow_keep(c, c->models, (size_t)c->n_models * sizeof(mmp_model_row), (size_t)count * sizeof(mmp_model_row));
+    if (rc == MMP_OK) rc = grow_keep(c, c->ent_pod, (size_t)base * 4, (size_t)(base + n_entries) * 4);
+    if (rc == MMP_OK) rc = grow_keep(c, c->ent_time, (size_t)base * 8, (size_t)(base + n_entries) * 8);
+    const bool resolved = c->rmodels_ok && c->committed && c->n_shards == 0;
+    if (rc == MMP_OK && resolved)
+        rc = grow_keep(c, c->rmodels, (size_t)c->n_models * sizeof(ResolvedModel), (size_t)count * sizeof(ResolvedModel));
+    if (rc != MMP_OK) return rc;
+    HIP_TRY(c, c->u_idx.ensure((size_t)k * 4));
+    HIP_TRY(c, c->u_rows.ensure((size_t)k * sizeof(mmp_model_row)));
+    if (n_entries) {
+        HIP_TRY(c, hipMemcpyAsync(c->ent_pod.as<int32_t>() + base, ent_pod, (size_t)n_entries * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->ent_time.as<int64_t>() + base, ent_time, (size_t)n_entries * 8, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->u_idx.p, h_idx.data(), (size_t)k * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->u_rows.p, h_rows.data(), (size_t)k * sizeof(mmp_model_row), hipMemcpyHostToDevice, st));
+    KT_BEGIN(c, st);
+    hipLaunchKernelGGL(upsert_models_kernel, dim3(div_up(k, 256)), dim3(256), 0, st, c->snap, c->u_idx.as<int32_t>(),
+                       c->u_rows.as<mmp_model_row>(), k, c->ent_pod.as<int32_t>(), c->models.as<mmp_model_row>(),
+                       resolved ? c->rmodels.as<ResolvedModel>() : nullptr);
+    KT_END(c, st);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(st));
+    kt_collect(c);
+    c->n_models = count;
+    c->n_entries = base + n_entries;
+    // more garbage than live entries (and enough to matter): squeeze the arena
+    if ((int64_t)c->n_entries - c->ent_live > std::max<int64_t>(c->ent_live, 1 << 16)) return compact_registry(c);
+    return MMP_OK;
 }
 
 /* ---- commit: rank + permute + bitmaps + stats, all on the device --------- */
@@ -1011,6 +1155,8 @@ int mmp_models_ingest_json(mmp_ctx *c, const char *buf, const int64_t *off, int3
     if (n == 0) {
         c->n_models = 0;
         c->n_entries = 0;
+        c->ent_live = 0;
+        c->m_cnt.clear();
         return MMP_OK;
     }
     for (int32_t i = 0; i < n; i++)
@@ -1068,10 +1214,13 @@ int mmp_models_ingest_json(mmp_ctx *c, const char *buf, const int64_t *off, int3
     HIP_TRY(c, hipMemcpyAsync(&total, c->j_offs.as<int32_t>() + n, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(status_out, c->j_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     if (last_unload_out) HIP_TRY(c, hipMemcpyAsync(last_unload_out, c->j_aux.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    c->m_cnt.resize(n);
+    HIP_TRY(c, hipMemcpyAsync(c->m_cnt.data(), c->j_cnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     kt_collect(c);
     c->n_models = n;
     c->n_entries = total;
+    c->ent_live = total;
     return rebuild_resolved(c);
 }
 

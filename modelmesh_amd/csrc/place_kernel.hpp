@@ -330,14 +330,9 @@ __device__ __forceinline__ ResolvedReq resolve_one(const Snap &S, const PlaceArg
     return r;
 }
 
-// One lane per model: follow the entry list through pos_of once (see ResolvedModel).
-__global__ void resolve_models_kernel(Snap S, const mmp_model_row *__restrict__ models,
-                                      const int32_t *__restrict__ ent_pod, int32_t n_models,
-                                      ResolvedModel *__restrict__ out)
+// Follow one model's entry list through pos_of once (see ResolvedModel).
+__device__ __forceinline__ ResolvedModel resolve_model_row(const Snap &S, const mmp_model_row &m, const int32_t *__restrict__ ent_pod)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_models) return;
-    const mmp_model_row m = models[i];
     ResolvedModel r;
     r.type = (m.type < 0 || m.type >= S.T) ? 0 : m.type;
     r.n_ents = m.n_loaded + m.n_failed;
@@ -350,7 +345,54 @@ __global__ void resolve_models_kernel(Snap S, const mmp_model_row *__restrict__ 
         }
         r.pos[k] = pos;
     }
-    out[i] = r;
+    return r;
+}
+
+// One lane per model.
+__global__ void resolve_models_kernel(Snap S, const mmp_model_row *__restrict__ models,
+                                      const int32_t *__restrict__ ent_pod, int32_t n_models,
+                                      ResolvedModel *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_models) return;
+    out[i] = resolve_model_row(S, models[i], ent_pod);
+}
+
+// Registry events (mmp_models_upsert): rows[i] replaces models[idx[i]]; its entries were appended to the
+// entry arena and rows[i].ent_off already points there.  `resolved` may be null (no committed snapshot /
+// shard context).  idx holds no duplicates (the host keeps the last row per model).
+__global__ void upsert_models_kernel(Snap S, const int32_t *__restrict__ idx, const mmp_model_row *__restrict__ rows, int32_t n,
+                                     const int32_t *__restrict__ ent_pod, mmp_model_row *__restrict__ models,
+                                     ResolvedModel *__restrict__ resolved)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const mmp_model_row m = rows[i];
+    models[idx[i]] = m;
+    if (resolved) resolved[idx[i]] = resolve_model_row(S, m, ent_pod);
+}
+
+// Arena compaction: offs = exclusive scan of the per-model entry counts; entries move to the fresh arrays.
+__global__ void model_counts_kernel(const mmp_model_row *__restrict__ models, int32_t n, int32_t *__restrict__ cnt)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cnt[i] = models[i].n_loaded + models[i].n_failed;
+    if (i == n) cnt[n] = 0;
+}
+
+__global__ void move_entries_kernel(mmp_model_row *__restrict__ models, int32_t n, const int32_t *__restrict__ offs,
+                                    const int32_t *__restrict__ old_pod, const int64_t *__restrict__ old_time,
+                                    int32_t *__restrict__ new_pod, int64_t *__restrict__ new_time)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const mmp_model_row m = models[i];
+    const int32_t o = offs[i], k = m.n_loaded + m.n_failed;
+    for (int32_t e = 0; e < k; e++) {
+        new_pod[o + e] = old_pod[m.ent_off + e];
+        new_time[o + e] = old_time[m.ent_off + e];
+    }
+    models[i].ent_off = o;
 }
 
 // ---- one LANE per decision -----------------------------------------------------------------------

@@ -221,6 +221,17 @@ class Solver:
                                           ptr(ent_time) if len(ent_time) else None, len(ent_pod)))
         self.n_models = len(models)
 
+    def upsert_models(self, idx, rows, ent_pod, ent_time):
+        """Registry events: rows[i] (its ent_off indexing ent_pod / ent_time of this call) replaces model idx[i]."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        rows = np.ascontiguousarray(rows, dtype=MODEL_ROW)
+        ent_pod = np.ascontiguousarray(ent_pod, dtype=np.int32)
+        ent_time = np.ascontiguousarray(ent_time, dtype=np.int64)
+        self._ck(self.lib.mmp_models_upsert(self.h, ptr(idx), ptr(rows), len(idx), ptr(ent_pod) if len(ent_pod) else None,
+                                            ptr(ent_time) if len(ent_time) else None, len(ent_pod)))
+        if len(idx):
+            self.n_models = max(getattr(self, "n_models", 0), int(idx.max()) + 1)
+
     def commit(self):
         self._ck(self.lib.mmp_snapshot_commit(self.h))
 

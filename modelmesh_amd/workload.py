@@ -363,6 +363,7 @@ class ChurnStream:
         self.cache_lu = lu[order]
         self.cache_cap = self.f.pods["capacity"].astype(np.int64).copy()
         self.changed_pods = np.zeros(0, np.int32)
+        self.changed_models = np.zeros(0, np.int32)
 
     @property
     def fleet(self) -> Fleet:
@@ -429,4 +430,17 @@ class ChurnStream:
         np.cumsum(nl + nf, out=off[1:])
         f.models["ent_off"], f.models["n_loaded"], f.models["n_failed"] = off[:-1], nl, nf
         f.ent_pod, f.ent_time = self.coo_pod.copy(), self.coo_time.copy()
+        self.changed_models = np.unique(m).astype(np.int32)
         f.now += self.slice_ms
+
+    def model_events(self):
+        """The registry events of the last slice: the changed ModelRecords as (idx, rows, ent_pod, ent_time) with
+        rows' ent_off indexing the returned entry arrays (the form mmp_models_upsert takes)."""
+        f, idx = self.f, self.changed_models
+        rows = f.models[idx].copy()
+        k = (rows["n_loaded"] + rows["n_failed"]).astype(np.int64)
+        off = np.zeros(len(idx) + 1, np.int64)
+        np.cumsum(k, out=off[1:])
+        src = np.repeat(rows["ent_off"].astype(np.int64) - off[:-1], k) + np.arange(int(off[-1]))
+        rows["ent_off"] = off[:-1]
+        return idx, rows, f.ent_pod[src], f.ent_time[src]

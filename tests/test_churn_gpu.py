@@ -1,6 +1,6 @@
 """Config C5 (streaming churn) as a parity case: a stream of load / evict / republish events cut into
 2-second slices.  Per slice the solver applies the changed InstanceRecords (handleInstanceTableChange,
-MM.java:1455-1568 -> mmp_pods_upsert), reloads the registry view, re-ranks (PLACEMENT_ORDER,
+MM.java:1455-1568 -> mmp_pods_upsert) and ModelRecords (mmp_models_upsert, or a full reload), re-ranks (PLACEMENT_ORDER,
 MM.java:4646-4703), decides the slice's load targets (MM.java:4776-5005) and evaluates its cache
 evictions (clhm, ConcurrentLinkedHashMap.java:329-352,590-652).  Every slice is compared with the CPU
 oracle rebuilt from the same evolving fleet: order, ClusterStats, decisions, victims — bit-exact."""
@@ -16,7 +16,7 @@ from tests.util import assert_same_decisions
 pytestmark = pytest.mark.gpu
 
 
-def _run(fleet, seed, slices, events):
+def _run(fleet, seed, slices, events, registry="upsert"):
     cs = wl.ChurnStream(fleet, seed, events_per_slice=events)
     s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
     try:
@@ -28,7 +28,10 @@ def _run(fleet, seed, slices, events):
             if it:
                 ch = cs.changed_pods
                 s.upsert_pods(ch, f.pods[ch])  # only the rows that changed
-                s.load_models(f.models, f.ent_pod, f.ent_time)
+                if registry == "reload":
+                    s.load_models(f.models, f.ent_pod, f.ent_time)
+                else:
+                    s.upsert_models(*cs.model_events())  # only the ModelRecords the slice changed
                 s.commit()
             orc = OracleFleet(f)
             assert np.array_equal(s.order(), orc.order)
@@ -58,9 +61,10 @@ def test_churn_c2_fleet():
     _run(wl.make_fleet("C2"), 51, slices=6, events=4000)
 
 
+@pytest.mark.parametrize("registry", ["upsert", "reload"])
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_churn_fuzz_fleets(seed):
-    _run(wl.fuzz_fleet(seed + 40, pods=300, models=500), seed, slices=5, events=1500)
+def test_churn_fuzz_fleets(seed, registry):
+    _run(wl.fuzz_fleet(seed + 40, pods=300, models=500), seed, slices=5, events=1500, registry=registry)
 
 
 def test_churn_c3_fleet_two_slices():
