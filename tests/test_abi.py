@@ -89,3 +89,33 @@ def test_library_never_uses_the_null_stream():
             if re.search(r"<<<[^>]*>>>", code) or re.search(r"hipLaunchKernelGGL\([^;]*,\s*0\s*,\s*(0|nullptr)\s*,", code):
                 bad.append(f"{os.path.basename(f)}:{i}: launch on the null stream: {line.strip()}")
     assert not bad, "\n".join(bad)
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "modelmesh_amd", "lib")
+    exe = str(tmp_path / "place_one")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "place_one.c"), "-L" + libdir, "-lmmplace", "-Wl,-rpath," + libdir, "-o", exe],
+                   check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_header_is_plain_c99_and_a_c_host_links(tmp_path):
+    """include/mmplace.h is the boundary for JNI / cgo / FFI hosts: it must compile as strict C99, and a C program
+    using it must link against libmmplace.so.  Without a GPU the program reports MMP_ENODEVICE (exit 77)."""
+    import subprocess
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode == 77 and "no CPU path" in r.stderr, (r.returncode, r.stderr)
+
+
+@pytest.mark.gpu
+def test_c_host_places_one_model(tmp_path):
+    import subprocess
+    r = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "best=1" in r.stdout
