@@ -95,6 +95,7 @@ struct EvictArgs {
     mmp_evict_out *outs;
     int32_t n, n_caches;
     int64_t now;
+    DoneFlag done;  // latency path (wave.hpp); {nullptr} otherwise
 };
 
 // AddTask.run → evictionDeque.insert → evict()
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(kEvBlock) void evict_batch_kernel(EvictArgs A)
         }
         A.outs[i] = o;
     }
+    announce_done(A.done);
 }
 
 }  // namespace mmp

@@ -21,6 +21,7 @@ struct GateArgs {
     mmp_gate_out *outs;
     int32_t n, n_models, P, W, T;
     int64_t now, in_use_expiry, min_space, min_churn;
+    DoneFlag done;  // latency path (wave.hpp); {nullptr} otherwise
 };
 
 __device__ __forceinline__ int64_t jabs64(int64_t a) { return a < 0 ? (int64_t)(0ull - (uint64_t)a) : a; }
@@ -40,10 +41,8 @@ __device__ __forceinline__ bool load_change(int32_t cur_rpm, int32_t rpm)
     return diff >= 100 || (cur_rpm == 0 ? rpm != 0 : (100 * diff) / cur_rpm > 10);
 }
 
-__global__ void gate_batch_kernel(GateArgs A)
+__device__ __forceinline__ void gate_one(const GateArgs &A, int i)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.n) return;
     const mmp_gate_req r = A.reqs[i];
     uint32_t bits = 0;
     int32_t initial = 0;
@@ -203,6 +202,13 @@ __global__ void gate_batch_kernel(GateArgs A)
     o.bits = bits;
     o.initial_size = initial;
     A.outs[i] = o;
+}
+
+__global__ void gate_batch_kernel(GateArgs A)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < A.n) gate_one(A, i);
+    announce_done(A.done);
 }
 
 }  // namespace mmp

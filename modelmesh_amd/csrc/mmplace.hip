@@ -266,6 +266,38 @@ int rebuild_resolved(mmp_ctx *c)
     return MMP_OK;
 }
 
+// ---- latency slots (FastSlot): pinned, device-mapped buffers + a completion flag ---------------------
+// Small host-pointer calls do not stage through hipMemcpy and do not hold the context's batch stream: the
+// kernel reads its requests from and writes its results to pinned host memory on the slot's own
+// high-priority stream and announces completion through the slot's pinned flag (wave.hpp: announce_done).
+FastSlot *slot_acquire(mmp_ctx *c, std::unique_lock<std::mutex> &lock)
+{
+    const uint32_t first = c->fast_rr.fetch_add(1, std::memory_order_relaxed);
+    for (int k = 0; k < kFastSlots; k++) {
+        FastSlot &cand = c->fast[(first + k) % kFastSlots];
+        std::unique_lock<std::mutex> t(cand.mu, std::try_to_lock);
+        if (t.owns_lock()) {
+            lock = std::move(t);
+            return &cand;
+        }
+    }
+    FastSlot *f = &c->fast[first % kFastSlots];
+    lock = std::unique_lock<std::mutex>(f->mu);
+    return f;
+}
+
+// Spin on the slot's flag; the ordinary stream synchronisation is the fallback when it is late.
+hipError_t slot_wait(FastSlot *f)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; spins++) {
+        if (__atomic_load_n(f->done, __ATOMIC_ACQUIRE) == f->seq) return hipSuccess;
+        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) break;
+        __builtin_ia32_pause();
+    }
+    return hipStreamSynchronize(f->stream);
+}
+
 int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs,
                  hipStream_t st, uint32_t *done_flag = nullptr, uint32_t done_seq = 0, const mmp_place_req *inline_req = nullptr,
                  uint32_t *done_blocks = nullptr)
@@ -1644,21 +1676,8 @@ int mmp_place_batch(mmp_ctx *c, const mmp_place_req *reqs, int32_t n, const int3
     if (n <= kFastN && n_extra <= kFastExtra) {
         // latency path: the kernel reads the requests from, and writes the results to, pinned host
         // memory over the fabric — no staging copies, no contention with batches on c->stream
-        FastSlot *f = nullptr;
         std::unique_lock<std::mutex> fl;
-        const uint32_t first = c->fast_rr.fetch_add(1, std::memory_order_relaxed);
-        for (int k = 0; k < kFastSlots && !f; k++) {
-            FastSlot &cand = c->fast[(first + k) % kFastSlots];
-            std::unique_lock<std::mutex> t(cand.mu, std::try_to_lock);
-            if (t.owns_lock()) {
-                f = &cand;
-                fl = std::move(t);
-            }
-        }
-        if (!f) {
-            f = &c->fast[first % kFastSlots];
-            fl = std::unique_lock<std::mutex>(f->mu);
-        }
+        FastSlot *f = slot_acquire(c, fl);
         memcpy(f->reqs, reqs, (size_t)n * sizeof(mmp_place_req));
         if (n_extra) memcpy(f->extra, extra_pool, (size_t)n_extra * sizeof(int32_t));
         {
@@ -1669,20 +1688,7 @@ int mmp_place_batch(mmp_ctx *c, const mmp_place_req *reqs, int32_t n, const int3
                                         (n == 1 && reqs[0].n_extra == 0) ? &reqs[0] : nullptr, f->blocks);
             if (rc != MMP_OK) return rc;
         }
-        // The kernel announces its results through the pinned flag; spinning on it skips the completion-signal
-        // path of hipStreamSynchronize; the ordinary synchronisation remains the fallback when the flag
-        // is late, and commit / loaders still quiesce these streams the ordinary way.
-        bool seen = false;
-        const auto t0 = std::chrono::steady_clock::now();
-        for (uint32_t spins = 0;; spins++) {
-            if (__atomic_load_n(f->done, __ATOMIC_ACQUIRE) == f->seq) {
-                seen = true;
-                break;
-            }
-            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) break;
-            __builtin_ia32_pause();
-        }
-        if (!seen) HIP_TRY(c, hipStreamSynchronize(f->stream));
+        HIP_TRY(c, slot_wait(f));
         memcpy(outs, f->outs, (size_t)n * sizeof(mmp_place_out));
         return MMP_OK;
     }
@@ -1765,6 +1771,31 @@ int mmp_serve_batch(mmp_ctx *c, const mmp_serve_req *reqs, int32_t n, const int3
     return MMP_OK;
 }
 
+namespace {
+GateArgs gate_args(mmp_ctx *c, int32_t n, int64_t now, int64_t in_use_expiry)
+{
+    GateArgs A{};
+    A.models = c->models.as<mmp_model_row>();
+    A.ent_pod = c->ent_pod.as<int32_t>();
+    A.ent_time = c->ent_time.as<int64_t>();
+    A.pods = c->sb[c->cur].pods.as<mmp_pod_row>();
+    A.allowed = c->d_allowed.as<uint64_t>();
+    A.has_allowed = c->d_has_allowed.as<uint8_t>();
+    A.stats = c->stats_acc.as<StatsAcc>();
+    A.n = n;
+    A.n_models = c->n_models;
+    A.P = c->snap.P;
+    A.W = c->snap.W;
+    A.T = c->n_types;
+    A.now = now;
+    A.in_use_expiry = in_use_expiry;
+    A.min_space = c->cfg.min_space_units;
+    A.min_churn = c->cfg.min_churn_age_ms;
+    A.done = DoneFlag{nullptr, nullptr, 0};
+    return A;
+}
+}  // namespace
+
 int mmp_gate_batch(mmp_ctx *c, const mmp_gate_req *reqs, int32_t n, const int32_t *excl_pod, const int64_t *excl_time,
                    int32_t n_excl, const int32_t *explicit_pool, int32_t n_explicit, int64_t now, int64_t in_use_expiry,
                    mmp_gate_out *outs)
@@ -1777,6 +1808,37 @@ int mmp_gate_batch(mmp_ctx *c, const mmp_gate_req *reqs, int32_t n, const int32_
         if (r.n_excl < 0 || r.excl_off < 0 || (int64_t)r.excl_off + r.n_excl > n_excl || r.n_explicit < 0 ||
             r.explicit_off < 0 || (int64_t)r.explicit_off + r.n_explicit > n_explicit)
             return fail(c, MMP_EINVAL, "mmp_gate_batch: request %d pool range out of bounds", i);
+    }
+    constexpr int kGatePool = kFastExtra / 4;  // the slot's int pool holds excl_pod | explicit | excl_time (as int64)
+    if (n > 0 && (size_t)n * sizeof(mmp_gate_req) <= kFastN * sizeof(mmp_place_req) &&
+        (size_t)n * sizeof(mmp_gate_out) <= kFastN * sizeof(mmp_place_out) && n_excl <= kGatePool && n_explicit <= kGatePool) {
+        // latency path (see slot_acquire)
+        HIP_TRY(c, hipSetDevice(c->cfg.device));
+        std::unique_lock<std::mutex> fl;
+        FastSlot *f = slot_acquire(c, fl);
+        memcpy(f->reqs, reqs, (size_t)n * sizeof(mmp_gate_req));
+        int32_t *pool = f->extra;
+        if (n_excl) {
+            memcpy(pool, excl_pod, (size_t)n_excl * 4);
+            memcpy(pool + 2 * kGatePool, excl_time, (size_t)n_excl * 8);
+        }
+        if (n_explicit) memcpy(pool + kGatePool, explicit_pool, (size_t)n_explicit * 4);
+        {
+            std::lock_guard<std::mutex> g(c->mu);  // capture the published snapshot + enqueue
+            if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+            GateArgs A = gate_args(c, n, now, in_use_expiry);
+            A.reqs = reinterpret_cast<const mmp_gate_req *>(f->reqs);
+            A.excl_pod = pool;
+            A.explicit_pool = pool + kGatePool;
+            A.excl_time = reinterpret_cast<const int64_t *>(pool + 2 * kGatePool);
+            A.outs = reinterpret_cast<mmp_gate_out *>(f->outs);
+            A.done = DoneFlag{f->done, f->blocks, ++f->seq};
+            hipLaunchKernelGGL(gate_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, f->stream, A);
+            HIP_TRY(c, hipGetLastError());
+        }
+        HIP_TRY(c, slot_wait(f));
+        memcpy(outs, f->outs, (size_t)n * sizeof(mmp_gate_out));
+        return MMP_OK;
     }
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
@@ -1795,28 +1857,12 @@ int mmp_gate_batch(mmp_ctx *c, const mmp_gate_req *reqs, int32_t n, const int32_
         HIP_TRY(c, hipMemcpyAsync(c->s_c.p, excl_pod, (size_t)n_excl * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(c, hipMemcpyAsync(c->s_d.p, excl_time, (size_t)n_excl * 8, hipMemcpyHostToDevice, st));
     }
-    GateArgs A;
+    GateArgs A = gate_args(c, n, now, in_use_expiry);
     A.reqs = c->s_reqs.as<mmp_gate_req>();
-    A.models = c->models.as<mmp_model_row>();
-    A.ent_pod = c->ent_pod.as<int32_t>();
-    A.ent_time = c->ent_time.as<int64_t>();
-    A.pods = c->sb[c->cur].pods.as<mmp_pod_row>();
-    A.allowed = c->d_allowed.as<uint64_t>();
-    A.has_allowed = c->d_has_allowed.as<uint8_t>();
-    A.stats = c->stats_acc.as<StatsAcc>();
     A.excl_pod = c->s_c.as<int32_t>();
     A.excl_time = c->s_d.as<int64_t>();
     A.explicit_pool = c->s_a.as<int32_t>();
     A.outs = c->s_outs.as<mmp_gate_out>();
-    A.n = n;
-    A.n_models = c->n_models;
-    A.P = c->snap.P;
-    A.W = c->snap.W;
-    A.T = c->n_types;
-    A.now = now;
-    A.in_use_expiry = in_use_expiry;
-    A.min_space = c->cfg.min_space_units;
-    A.min_churn = c->cfg.min_churn_age_ms;
     KT_BEGIN(c, st);
     hipLaunchKernelGGL(gate_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, A);
     KT_END(c, st);
@@ -2211,7 +2257,7 @@ int mmp_caches_load(mmp_ctx *c, int32_t n_caches, const int32_t *seg_off, const 
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, quiesce_decisions(c));  // small eviction batches read these tables from the latency slots' streams
     HIP_TRY(c, c->c_seg.ensure((size_t)(n_caches + 1) * 4));
     HIP_TRY(c, c->c_lu.ensure((size_t)std::max(E, 1) * 8));
     HIP_TRY(c, c->c_wt.ensure((size_t)std::max(E, 1) * 4));
@@ -2229,6 +2275,33 @@ int mmp_caches_load(mmp_ctx *c, int32_t n_caches, const int32_t *seg_off, const 
 int mmp_evict_batch(mmp_ctx *c, const mmp_evict_req *reqs, int32_t n, int64_t now, mmp_evict_out *outs)
 {
     if (!c || n < 0 || (n > 0 && (!reqs || !outs))) return fail(c, MMP_EINVAL, "mmp_evict_batch: bad argument");
+    if (n > 0 && (size_t)n * sizeof(mmp_evict_out) <= kFastN * sizeof(mmp_place_out)) {
+        // latency path (see slot_acquire): one launch on a slot stream, no staging copies, no batch lock
+        HIP_TRY(c, hipSetDevice(c->cfg.device));
+        std::unique_lock<std::mutex> fl;
+        FastSlot *f = slot_acquire(c, fl);
+        memcpy(f->reqs, reqs, (size_t)n * sizeof(mmp_evict_req));
+        {
+            std::lock_guard<std::mutex> g(c->mu);  // capture the cache tables + enqueue
+            if (c->n_caches <= 0) return fail(c, MMP_ESTATE, "no caches loaded");
+            EvictArgs A;
+            A.reqs = reinterpret_cast<const mmp_evict_req *>(f->reqs);
+            A.seg_off = c->c_seg.as<int32_t>();
+            A.last_used = c->c_lu.as<int64_t>();
+            A.weight = c->c_wt.as<int32_t>();
+            A.capacity = c->c_cap.as<int64_t>();
+            A.outs = reinterpret_cast<mmp_evict_out *>(f->outs);
+            A.n = n;
+            A.n_caches = c->n_caches;
+            A.now = now;
+            A.done = DoneFlag{f->done, f->blocks, ++f->seq};
+            hipLaunchKernelGGL(evict_batch_kernel, dim3(div_up(n, kEvPerBlock)), dim3(kEvBlock), 0, f->stream, A);
+            HIP_TRY(c, hipGetLastError());
+        }
+        HIP_TRY(c, slot_wait(f));
+        memcpy(outs, f->outs, (size_t)n * sizeof(mmp_evict_out));
+        return MMP_OK;
+    }
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     if (c->n_caches <= 0 && n > 0) return fail(c, MMP_ESTATE, "no caches loaded");
@@ -2248,6 +2321,7 @@ int mmp_evict_batch(mmp_ctx *c, const mmp_evict_req *reqs, int32_t n, int64_t no
     A.n = n;
     A.n_caches = c->n_caches;
     A.now = now;
+    A.done = DoneFlag{nullptr, nullptr, 0};
     KT_BEGIN(c, st);
     hipLaunchKernelGGL(evict_batch_kernel, dim3(div_up(n, kEvPerBlock)), dim3(kEvBlock), 0, st, A);
     KT_END(c, st);

@@ -61,10 +61,8 @@ struct PlaceArgs {
     int64_t now;
     int32_t force_wave;  // diagnostics: hand every decision to the wave-per-decision kernel
     int32_t n_pods_all;  // pod slots of the whole table (bounds of pos_of; == Snap::P unless the Snap is a shard view)
-    // Latency path only (results go to pinned host memory): once every result row is globally visible the
-    // kernel — its last workgroup to finish, counted in done_blocks — stores done_seq here, and the host,
-    // spinning on this word, returns without the completion-signal round trip of hipStreamSynchronize.
-    // nullptr otherwise.
+    // Latency path only (wave.hpp: announce_done); nullptr otherwise.  The workgroup counter of launches with
+    // more than one workgroup is an argument of place_batch_flag_kernel, not part of this block.
     uint32_t *done_flag;
     uint32_t done_seq;
 };
@@ -933,18 +931,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
             wave_sync();
         }
     }
-    if (A.done_flag) {  // wave-uniform
-        __threadfence_system();  // this thread's result rows are visible to the host ...
-        __syncthreads();         // ... and so are the rest of the workgroup's
-        if (threadIdx.x == 0) {
-            bool last = gridDim.x == 1;
-            if (!last && atomicAdd(done_blocks, 1u) == gridDim.x - 1) {
-                *done_blocks = 0;  // the other workgroups have all passed their fence: this one announces
-                last = true;
-            }
-            if (last) __hip_atomic_store(A.done_flag, A.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    announce_done(DoneFlag{A.done_flag, done_blocks, A.done_seq});
 }
 
 __global__ __launch_bounds__(kPlaceBlock) void place_batch_kernel(Snap S, PlaceArgs A, int32_t wpad)

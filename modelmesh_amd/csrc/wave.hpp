@@ -121,6 +121,32 @@ __device__ __forceinline__ int select_kth_bit(uint64_t v, int k)
     return r;
 }
 
+// Latency path of the host-pointer entry points (results go to pinned host memory): once every result row is
+// visible to the host, the kernel — its last workgroup to finish, counted in `blocks` (device memory, left at
+// zero) — stores `seq` into the pinned word `flag`; the host, spinning on that word, returns without the
+// completion-signal round trip of hipStreamSynchronize.  Called by EVERY thread of the grid at the very end
+// (no thread may have returned early); flag == nullptr: nothing to do.
+struct DoneFlag {
+    uint32_t *flag;
+    uint32_t *blocks;
+    uint32_t seq;
+};
+
+__device__ __forceinline__ void announce_done(const DoneFlag &D)
+{
+    if (!D.flag) return;     // wave-uniform
+    __threadfence_system();  // this thread's result rows are visible to the host ...
+    __syncthreads();         // ... and so are the rest of the workgroup's
+    if (threadIdx.x == 0) {
+        bool last = gridDim.x == 1;
+        if (!last && atomicAdd(D.blocks, 1u) == gridDim.x - 1) {
+            *D.blocks = 0;  // the other workgroups have all passed their fence: this one announces
+            last = true;
+        }
+        if (last) __hip_atomic_store(D.flag, D.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
 {
     x += 0x9E3779B97F4A7C15ull;

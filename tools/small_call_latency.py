@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Wall time of the small host-pointer calls a mesh instance makes around one model load: the request guards
+(mmp_gate_batch), the load target (mmp_place_batch) and the cache-eviction evaluation (mmp_evict_batch), n = 1
+and n = 256, arguments marshalled once."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from modelmesh_amd import _lib, workload as wl  # noqa: E402
+from modelmesh_amd._lib import ptr  # noqa: E402
+from modelmesh_amd.solver import Solver  # noqa: E402
+
+fleet = wl.make_fleet("C3")
+s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+s.load_fleet(fleet)
+cs = wl.ChurnStream(fleet, 0xC5)
+s.load_caches(cs.seg_off, cs.cache_lu, cs.cache_wt, cs.cache_cap)
+now = fleet.now
+reqs, _ = wl.make_requests(fleet, 3, n=256, extra_frac=0.0)
+
+
+def timed(fn, args, reps=3000):
+    for _ in range(200):
+        fn(*args)
+    t = np.zeros(reps)
+    for i in range(reps):
+        t0 = time.perf_counter()
+        rc = fn(*args)
+        t[i] = time.perf_counter() - t0
+        assert rc == 0
+    return np.percentile(t, 50) * 1e6, np.percentile(t, 99) * 1e6
+
+
+for n in (1, 256):
+    po = np.zeros(n, dtype=_lib.PLACE_OUT)
+    r = reqs[:n].copy()
+    print(f"n={n:4d} place  p50 %.1f us  p99 %.1f us" % timed(s.lib.mmp_place_batch, (s.h, ptr(r), C.c_int32(n), None, C.c_int32(0), C.c_int64(now), ptr(po))))
+    ev = np.zeros(n, dtype=_lib.EVICT_REQ)
+    ev["cache"] = np.arange(n) % fleet.n_pods
+    ev["weight"] = 6400
+    eo = np.zeros(n, dtype=_lib.EVICT_OUT)
+    print(f"n={n:4d} evict  p50 %.1f us  p99 %.1f us" % timed(s.lib.mmp_evict_batch, (s.h, ptr(ev), C.c_int32(n), C.c_int64(now), ptr(eo))))
+    g = np.zeros(n, dtype=_lib.GATE_REQ)
+    g["model"] = np.arange(n)
+    g["self_pod"] = np.arange(n) % fleet.n_pods
+    g["cache_capacity"] = 8_388_608
+    g["loader_predicted"] = 6400
+    go = np.zeros(n, dtype=_lib.GATE_OUT)
+    print(f"n={n:4d} gates  p50 %.1f us  p99 %.1f us" % timed(s.lib.mmp_gate_batch, (s.h, ptr(g), C.c_int32(n), None, None, C.c_int32(0), None, C.c_int32(0), C.c_int64(now), C.c_int64(450_000), ptr(go))))
+s.close()
