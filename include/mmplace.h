@@ -387,6 +387,21 @@ int mmp_snapshot_commit(mmp_ctx *ctx);
 int mmp_get_order(mmp_ctx *ctx, int32_t *order_out, int32_t *n_out);
 /* ClusterStats of the committed snapshot (MM.java:1570-1591). */
 int mmp_cluster_stats(mmp_ctx *ctx, mmp_stats *out);
+/* With type constraints the mesh does not use the cluster-wide stats everywhere (TypeConstraintManager): the
+ * instances are partitioned by their ProhibitedTypeSet — the constrained types they cannot host — each
+ * partition has its own stats (InstanceSetStatsTracker), typeSetStats(type) is the sum over the partitions
+ * that can host the type (MM.java:1432-1439: loadLocal sizing :5169, the onEviction reload rule :2918, the
+ * scale-up task :5691) and instanceSetStats() is the partition of this instance (:1446-1448: scale-down
+ * :6228).  The library rebuilds all of them at commit and uses them in mmp_gate_batch, mmp_scaleup_plan,
+ * mmp_scaledown_plan; these calls read them back.  A partition's lru is the cluster-wide minimum (the Java
+ * re-accumulates it over ALL instances on every event, MM.java:1515-1542).  Without type constraints there are
+ * no partitions and every type's stats are the cluster's. */
+int mmp_type_stats(mmp_ctx *ctx, int32_t type, mmp_stats *out);
+int mmp_partition_count(mmp_ctx *ctx, int32_t *n_out);
+/* prohibited_out (may be NULL with max_words 0): the partition's prohibited types as a bitset over type rows */
+int mmp_partition_stats(mmp_ctx *ctx, int32_t partition, mmp_stats *out, uint64_t *prohibited_out, int32_t max_words);
+/* partition of every pod slot (-1: not in the table); *n_out = pod slots */
+int mmp_pod_partitions(mmp_ctx *ctx, int32_t *partition_out, int32_t max_pods, int32_t *n_out);
 
 /* ---- decisions --------------------------------------------------------- */
 /* n load-target decisions = n × CacheMissForwardingLB.getNext (MM.java:4776-5005).
@@ -438,6 +453,16 @@ int mmp_gate_batch(mmp_ctx *ctx, const mmp_gate_req *reqs, int32_t n, const int3
  * feeds them to mmp_place_batch with last_used = out_last_used[i] (MM.java:6727). */
 int mmp_proactive_plan(mmp_ctx *ctx, int32_t default_model_size_units, int64_t now_ms, int32_t max_out,
                        int32_t *out_model, int64_t *out_last_used, mmp_proactive_info *info);
+/* The same plan for ONE instance partition: with type constraints the reaper calls
+ * triggerProactiveLoadsForInstanceSubset once per ProhibitedTypeSet partition (MM.java:6473-6488) with that
+ * partition's stats, its instances for the free-space budget, and its prohibited types excluded from the
+ * candidates; skip_models = the models already triggered for an earlier partition of the same run
+ * (allCandidates.set(index, null), :6724).  partition = -1: the whole cluster (typeConstraints == null),
+ * which is what mmp_proactive_plan does.  The candidate rule (pruneModelRegistry, :6459-6462, :6574-6577)
+ * always uses the cluster-wide stats. */
+int mmp_proactive_plan_subset(mmp_ctx *ctx, int32_t partition, const int32_t *skip_models, int32_t n_skip,
+                              int32_t default_model_size_units, int64_t now_ms, int32_t max_out, int32_t *out_model,
+                              int64_t *out_last_used, mmp_proactive_info *info);
 
 /* a15: entries = usedSinceLastRun (runtimeCache.descendingMapWithCutoff(lastTime)) in iteration order.
  * overloaded_out has one byte per pod = membership in getExcludeSet() (MM.java:5835-5856); for

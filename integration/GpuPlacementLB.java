@@ -37,6 +37,10 @@ final class MmPlace {
     static native int serveBatch(long h, ByteBuffer reqs, int n, ByteBuffer inUse, ByteBuffer lastUsed,
                                  ByteBuffer exclPod, ByteBuffer exclTime, int nExcl, long nowMs, ByteBuffer outs);
     static native int clusterStats(long h, ByteBuffer out);
+    static native int typeStats(long h, int type, ByteBuffer out);
+    static native int partitionCount(long h, ByteBuffer nOut);
+    static native int partitionStats(long h, int partition, ByteBuffer out, ByteBuffer prohibitedOut, int maxWords);
+    static native int podPartitions(long h, ByteBuffer partitionOut, int maxPods, ByteBuffer nOut);
     // eviction (clhm) and the unload-buffer manager
     static native int cachesLoad(long h, int nCaches, ByteBuffer segOff, ByteBuffer lastUsed, ByteBuffer weight,
                                  ByteBuffer capacity);
@@ -53,6 +57,8 @@ final class MmPlace {
                                 ByteBuffer outs);
     static native int proactivePlan(long h, int defaultModelSizeUnits, long nowMs, int maxOut, ByteBuffer outModel,
                                     ByteBuffer outLastUsed, ByteBuffer info);
+    static native int proactivePlanSubset(long h, int partition, ByteBuffer skipModels, int nSkip, int defaultModelSizeUnits,
+                                          long nowMs, int maxOut, ByteBuffer outModel, ByteBuffer outLastUsed, ByteBuffer info);
     static native int scaleupPlan(long h, ByteBuffer entries, int n, ByteBuffer params, ByteBuffer outs,
                                   ByteBuffer overloadedOut, ByteBuffer skipped);
     static native int scaledownPlan(long h, ByteBuffer entries, int n, ByteBuffer params, ByteBuffer removedOut);

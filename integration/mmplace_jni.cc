@@ -121,6 +121,27 @@ JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_clusterStats(JNIEnv
     return check(env, ctx_of(h), mmp_cluster_stats(ctx_of(h), buf<mmp_stats>(env, out)));
 }
 
+// typeSetStats / instanceSetStats and the ProhibitedTypeSet partitions (MM.java:1432-1448, TypeConstraintManager)
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_typeStats(JNIEnv *env, jclass, jlong h, jint type, jobject out)
+{
+    return check(env, ctx_of(h), mmp_type_stats(ctx_of(h), type, buf<mmp_stats>(env, out)));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_partitionCount(JNIEnv *env, jclass, jlong h, jobject nOut)
+{
+    return check(env, ctx_of(h), mmp_partition_count(ctx_of(h), buf<int32_t>(env, nOut)));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_partitionStats(JNIEnv *env, jclass, jlong h, jint partition,
+                                                                            jobject out, jobject prohibitedOut, jint maxWords)
+{
+    return check(env, ctx_of(h),
+                 mmp_partition_stats(ctx_of(h), partition, buf<mmp_stats>(env, out), buf<uint64_t>(env, prohibitedOut), maxWords));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_podPartitions(JNIEnv *env, jclass, jlong h, jobject partitionOut,
+                                                                           jint maxPods, jobject nOut)
+{
+    return check(env, ctx_of(h), mmp_pod_partitions(ctx_of(h), buf<int32_t>(env, partitionOut), maxPods, buf<int32_t>(env, nOut)));
+}
+
 // ---- eviction: clhm put/evict (ConcurrentLinkedHashMap.java:590-611,329-352) -----------------------
 JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_cachesLoad(JNIEnv *env, jclass, jlong h, jint nCaches,
                                                                         jobject segOff, jobject lastUsed,
@@ -199,6 +220,17 @@ JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_proactivePlan(JNIEn
     return check(env, ctx_of(h),
                  mmp_proactive_plan(ctx_of(h), defaultModelSizeUnits, nowMs, maxOut, buf<int32_t>(env, outModel),
                                     buf<int64_t>(env, outLastUsed), buf<mmp_proactive_info>(env, info)));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_proactivePlanSubset(JNIEnv *env, jclass, jlong h, jint partition,
+                                                                                 jobject skipModels, jint nSkip,
+                                                                                 jint defaultModelSizeUnits, jlong nowMs,
+                                                                                 jint maxOut, jobject outModel,
+                                                                                 jobject outLastUsed, jobject info)
+{
+    return check(env, ctx_of(h),
+                 mmp_proactive_plan_subset(ctx_of(h), partition, buf<int32_t>(env, skipModels), nSkip, defaultModelSizeUnits,
+                                           nowMs, maxOut, buf<int32_t>(env, outModel), buf<int64_t>(env, outLastUsed),
+                                           buf<mmp_proactive_info>(env, info)));
 }
 JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_scaleupPlan(JNIEnv *env, jclass, jlong h, jobject entries,
                                                                          jint n, jobject params, jobject outs,

@@ -129,6 +129,10 @@ SYMBOLS = [
     ("mmp_snapshot_commit", C.c_int, [_P]),
     ("mmp_get_order", C.c_int, [_P, _P, C.POINTER(C.c_int32)]),
     ("mmp_cluster_stats", C.c_int, [_P, _P]),
+    ("mmp_type_stats", C.c_int, [_P, C.c_int32, _P]),
+    ("mmp_partition_count", C.c_int, [_P, _P]),
+    ("mmp_partition_stats", C.c_int, [_P, C.c_int32, _P, _P, C.c_int32]),
+    ("mmp_pod_partitions", C.c_int, [_P, _P, C.c_int32, _P]),
     ("mmp_place_batch", C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int64, _P]),
     ("mmp_place_batch_dev", C.c_int, [_P, _P, C.c_int32, _P, C.c_int64, _P, _P]),
     ("mmp_serve_batch", C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int64, _P]),
@@ -140,6 +144,7 @@ SYMBOLS = [
                                  C.POINTER(C.c_int64), _P]),
     ("mmp_gate_batch", C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32, _P, C.c_int32, C.c_int64, C.c_int64, _P]),
     ("mmp_proactive_plan", C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P]),
+    ("mmp_proactive_plan_subset", C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P]),
     ("mmp_scaleup_plan", C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32)]),
     ("mmp_scaledown_plan", C.c_int, [_P, _P, C.c_int32, _P, _P]),
     ("mmp_migration_plan", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _P, _P]),

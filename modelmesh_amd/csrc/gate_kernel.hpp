@@ -15,6 +15,8 @@ struct GateArgs {
     const uint64_t *allowed;        // [T][W] over pod index, as loaded by mmp_types_load
     const uint8_t *has_allowed;     // [T]
     const StatsAcc *stats;          // ClusterStats of the committed snapshot
+    const StatsAcc *tstats;         // [T_rows] typeSetStats(type) (MM.java:1432-1439): the subset a type may be placed on
+    int32_t T_rows;
     const int32_t *excl_pod;
     const int64_t *excl_time;
     const int32_t *explicit_pool;
@@ -49,8 +51,10 @@ __device__ __forceinline__ void gate_one(const GateArgs &A, int i)
     const bool have_model = r.model >= 0 && r.model < A.n_models;
     mmp_model_row m{};
     if (have_model) m = A.models[r.model];
-    const int64_t total_cap = (int64_t)A.stats->total_capacity, total_free = (int64_t)A.stats->total_free;
-    const int32_t copy_count = A.stats->model_copy_count, inst_count = A.stats->instance_count;
+    // typeSetStats(mr.getType()) at MM.java:5169 (loadLocal) and :2918 (onEviction); cluster-wide without a record
+    const StatsAcc *st = have_model ? &A.tstats[(m.type < 0 || m.type >= A.T_rows) ? 0 : m.type] : A.stats;
+    const int64_t total_cap = (int64_t)st->total_capacity, total_free = (int64_t)st->total_free;
+    const int32_t copy_count = st->model_copy_count, inst_count = st->instance_count;
 
     if (have_model) {
         // ---- goLocal, MM.java:3598-3626 over filteredInstances = copies minus MapFilteringSet excludes

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -118,6 +119,13 @@ struct mmp_ctx {
     std::vector<uint8_t> has_allowed, has_prefer;
     std::vector<int32_t> replaced_rs;
     UpgradeTracker upgrades;
+
+    // instance partitions by ProhibitedTypeSet and the subset stats of the committed snapshot (snapshot.hpp)
+    std::vector<int32_t> pts_of;        // pod -> partition (-1: not in the table)
+    std::vector<uint64_t> pts_prohib;   // [n_pts][tw] prohibited type rows
+    int32_t n_pts = 0, pts_tw = 1;
+    std::vector<StatsAcc> pstats_h, tstats_h;  // host mirrors (pstats_h has n_pts + 1 entries: the last is EMPTY_STATS)
+    DevBuf d_pts, d_prohib, pstats, tstats;
 
     // committed snapshot (double-buffered; `cur` is what decisions read)
     SnapBufs sb[2];
@@ -421,7 +429,7 @@ void mmp_destroy(mmp_ctx *c)
                       &c->r_tmp, &c->r_out_model, &c->r_out_lu, &c->k_cap, &c->k_wsize, &c->k_ubm, &c->k_ops, &c->k_order,
                       &c->k_opoff, &c->k_outs, &c->k_ev, &c->k_evoff, &c->idtab_hash, &c->idtab_val, &c->tytab_hash,
                       &c->tytab_val, &c->j_buf, &c->j_off, &c->j_rows, &c->j_aux, &c->j_status, &c->j_cnt, &c->j_offs, &c->j_tmp_pod,
-                      &c->j_tmp_time, &c->j_scan_tmp, &c->rk_rows, &c->rk_idx, &c->rk_tmp, &c->u_idx, &c->u_rows, &c->u_cnt, &c->u_offs, &c->u_tmp, &c->f_flags, &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp,
+                      &c->j_tmp_time, &c->j_scan_tmp, &c->rk_rows, &c->rk_idx, &c->rk_tmp, &c->d_pts, &c->d_prohib, &c->pstats, &c->tstats, &c->u_idx, &c->u_rows, &c->u_cnt, &c->u_offs, &c->u_tmp, &c->f_flags, &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp,
                       &c->ks[0].off, &c->ks[0].lu, &c->ks[0].wt,
                       &c->ks[0].key, &c->ks[0].n, &c->ks[1].off, &c->ks[1].lu, &c->ks[1].wt, &c->ks[1].key, &c->ks[1].n})
         b->release();
@@ -813,6 +821,59 @@ int mmp_models_upsert(mmp_ctx *c, const int32_t *idx, const mmp_model_row *rows,
 
 /* ---- commit: rank + permute + bitmaps + stats, all on the device --------- */
 
+namespace {
+// Partition the present instances by their ProhibitedTypeSet and build the per-partition / per-type
+// ClusterStats of the snapshot being committed (snapshot.hpp "instance partitions").  Enqueues on st; the
+// host mirrors are valid once the caller has synchronised st.  Call after cluster_stats_kernel.
+int build_subset_stats(mmp_ctx *c, const mmp_pod_row *d_pods, int32_t P, int64_t min_space, hipStream_t st)
+{
+    const int32_t T = std::max(c->n_types, 1), Tw = div_up(T, 64);
+    c->pts_of.assign(P, -1);
+    c->pts_prohib.clear();
+    c->n_pts = 0;
+    c->pts_tw = Tw;
+    if (c->n_types > 0) {
+        std::map<std::vector<uint64_t>, int32_t> intern;
+        std::vector<uint64_t> sig(Tw);
+        const int32_t Wf = c->types_w;
+        for (int32_t p = 0; p < P; p++) {
+            if (c->pods[p].flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE)) continue;
+            std::fill(sig.begin(), sig.end(), 0);
+            for (int32_t t = 0; t < c->n_types; t++)
+                if (c->has_allowed[t] && !((c->allowed[(size_t)t * Wf + (p >> 6)] >> (p & 63)) & 1ull))
+                    sig[t >> 6] |= 1ull << (t & 63);
+            auto it = intern.find(sig);
+            if (it == intern.end()) {
+                it = intern.emplace(sig, c->n_pts++).first;
+                c->pts_prohib.insert(c->pts_prohib.end(), sig.begin(), sig.end());
+            }
+            c->pts_of[p] = it->second;
+        }
+    }
+    const int32_t NP = c->n_pts;
+    c->pstats_h.assign(NP + 1, StatsAcc{});
+    c->pstats_h[NP].global_lru = INT64_MAX;  // InstanceSetStatsTracker.EMPTY_STATS
+    c->tstats_h.assign(T, StatsAcc{});
+    HIP_TRY(c, c->d_pts.ensure(std::max<size_t>(P, 1) * 4));
+    HIP_TRY(c, c->d_prohib.ensure(std::max<size_t>((size_t)NP * Tw, 1) * 8));
+    HIP_TRY(c, c->pstats.ensure((size_t)(NP + 1) * sizeof(StatsAcc)));
+    HIP_TRY(c, c->tstats.ensure((size_t)T * sizeof(StatsAcc)));
+    if (P) HIP_TRY(c, hipMemcpyAsync(c->d_pts.p, c->pts_of.data(), (size_t)P * 4, hipMemcpyHostToDevice, st));
+    if (NP) HIP_TRY(c, hipMemcpyAsync(c->d_prohib.p, c->pts_prohib.data(), (size_t)NP * Tw * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->pstats.p, c->pstats_h.data(), (size_t)(NP + 1) * sizeof(StatsAcc), hipMemcpyHostToDevice, st));
+    if (NP > 0 && P > 0)
+        hipLaunchKernelGGL(partition_stats_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, d_pods, P, min_space,
+                           c->d_pts.as<int32_t>(), c->pstats.as<StatsAcc>());
+    hipLaunchKernelGGL(subset_stats_finish_kernel, dim3(div_up(std::max(NP, T), 256)), dim3(256), 0, st,
+                       c->stats_acc.as<StatsAcc>(), c->pstats.as<StatsAcc>(), NP, c->d_prohib.as<uint64_t>(), Tw, T,
+                       c->n_types > 0 ? c->d_has_allowed.as<uint8_t>() : nullptr, c->tstats.as<StatsAcc>());
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->pstats_h.data(), c->pstats.p, (size_t)(NP + 1) * sizeof(StatsAcc), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(c->tstats_h.data(), c->tstats.p, (size_t)T * sizeof(StatsAcc), hipMemcpyDeviceToHost, st));
+    return MMP_OK;
+}
+}  // namespace
+
 int mmp_snapshot_commit(mmp_ctx *c)
 {
     if (!c) return MMP_EINVAL;
@@ -943,6 +1004,10 @@ int mmp_snapshot_commit(mmp_ctx *c)
         HIP_TRY(c, hipMemsetAsync(B.fullw.p, 0, (size_t)W * 8, st));
         HIP_TRY(c, hipMemsetAsync(B.ge.p, 0, (size_t)kGeRows * W * 8, st));
     }
+    {
+        const int rc = build_subset_stats(c, B.pods.as<mmp_pod_row>(), P, min_space, st);
+        if (rc != MMP_OK) return rc;
+    }
     KT_END(c, st);
     int32_t bad = 0;
     StatsAcc acc{};
@@ -1005,6 +1070,63 @@ int mmp_cluster_stats(mmp_ctx *c, mmp_stats *out)
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     *out = c->stats;
+    return MMP_OK;
+}
+
+namespace {
+mmp_stats stats_of(const StatsAcc &a)
+{
+    mmp_stats s{};
+    s.total_capacity = (int64_t)a.total_capacity;
+    s.total_free = (int64_t)a.total_free;
+    s.global_lru = (int64_t)a.global_lru;
+    s.instance_count = a.instance_count;
+    s.model_copy_count = a.model_copy_count;
+    return s;
+}
+}  // namespace
+
+int mmp_type_stats(mmp_ctx *c, int32_t type, mmp_stats *out)
+{
+    if (!c || !out) return fail(c, MMP_EINVAL, "mmp_type_stats: null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    const int32_t T = (int32_t)c->tstats_h.size();
+    *out = stats_of(c->tstats_h[(type < 0 || type >= T) ? 0 : type]);
+    return MMP_OK;
+}
+
+int mmp_partition_count(mmp_ctx *c, int32_t *n_out)
+{
+    if (!c || !n_out) return fail(c, MMP_EINVAL, "mmp_partition_count: null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    *n_out = c->n_pts;
+    return MMP_OK;
+}
+
+int mmp_partition_stats(mmp_ctx *c, int32_t partition, mmp_stats *out, uint64_t *prohibited_out, int32_t max_words)
+{
+    if (!c || !out || max_words < 0 || (max_words > 0 && !prohibited_out))
+        return fail(c, MMP_EINVAL, "mmp_partition_stats: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    if (partition < 0 || partition >= c->n_pts) return fail(c, MMP_EINVAL, "mmp_partition_stats: no partition %d", partition);
+    *out = stats_of(c->pstats_h[partition]);
+    for (int32_t w = 0; w < max_words; w++)
+        prohibited_out[w] = w < c->pts_tw ? c->pts_prohib[(size_t)partition * c->pts_tw + w] : 0;
+    return MMP_OK;
+}
+
+int mmp_pod_partitions(mmp_ctx *c, int32_t *partition_out, int32_t max_pods, int32_t *n_out)
+{
+    if (!c || !n_out || max_pods < 0 || (max_pods > 0 && !partition_out))
+        return fail(c, MMP_EINVAL, "mmp_pod_partitions: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    *n_out = (int32_t)c->pts_of.size();
+    const int32_t m = std::min(*n_out, max_pods);
+    if (m > 0) memcpy(partition_out, c->pts_of.data(), (size_t)m * 4);
     return MMP_OK;
 }
 
@@ -1441,6 +1563,10 @@ int mmp_shard_commit_dev(mmp_ctx *c, const void *d_rank)
                            B.pods.as<mmp_pod_row>(), P, min_space, c->stats_acc.as<StatsAcc>());
         HIP_TRY(c, hipGetLastError());
     }
+    {
+        const int rc = build_subset_stats(c, B.pods.as<mmp_pod_row>(), P, min_space, st);
+        if (rc != MMP_OK) return rc;
+    }
     int32_t bad = 0;
     StatsAcc acc{};
     HIP_TRY(c, hipMemcpyAsync(&bad, c->flag.p, sizeof bad, hipMemcpyDeviceToHost, st));
@@ -1782,6 +1908,8 @@ GateArgs gate_args(mmp_ctx *c, int32_t n, int64_t now, int64_t in_use_expiry)
     A.allowed = c->d_allowed.as<uint64_t>();
     A.has_allowed = c->d_has_allowed.as<uint8_t>();
     A.stats = c->stats_acc.as<StatsAcc>();
+    A.tstats = c->tstats.as<StatsAcc>();
+    A.T_rows = std::max(c->n_types, 1);
     A.n = n;
     A.n_models = c->n_models;
     A.P = c->snap.P;
@@ -1876,11 +2004,19 @@ int mmp_gate_batch(mmp_ctx *c, const mmp_gate_req *reqs, int32_t n, const int32_
 int mmp_proactive_plan(mmp_ctx *c, int32_t default_units, int64_t now, int32_t max_out, int32_t *out_model,
                        int64_t *out_last_used, mmp_proactive_info *info)
 {
-    if (!c || !info || max_out < 0 || (max_out > 0 && (!out_model || !out_last_used)))
+    return mmp_proactive_plan_subset(c, -1, nullptr, 0, default_units, now, max_out, out_model, out_last_used, info);
+}
+
+int mmp_proactive_plan_subset(mmp_ctx *c, int32_t partition, const int32_t *skip_models, int32_t n_skip, int32_t default_units,
+                              int64_t now, int32_t max_out, int32_t *out_model, int64_t *out_last_used,
+                              mmp_proactive_info *info)
+{
+    if (!c || !info || max_out < 0 || n_skip < 0 || (n_skip > 0 && !skip_models) || (max_out > 0 && (!out_model || !out_last_used)))
         return fail(c, MMP_EINVAL, "mmp_proactive_plan: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    if (partition >= c->n_pts || partition < -1) return fail(c, MMP_EINVAL, "mmp_proactive_plan: no partition %d", partition);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     hipStream_t st = c->stream;
     const int32_t M = c->n_models, P = c->snap.P;
@@ -1899,11 +2035,28 @@ int mmp_proactive_plan(mmp_ctx *c, int32_t default_units, int64_t now, int32_t m
     const mmp_model_row *models = c->models.as<mmp_model_row>();
     int32_t *counts = c->r_counts.as<int32_t>();
     HIP_TRY(c, hipMemsetAsync(ps, 0, sizeof(PlanScalars), st));
+    PlanSubset U{};
+    U.global = stats;
+    U.stats = partition >= 0 ? c->pstats.as<StatsAcc>() + partition : stats;
+    U.pod_pts = c->d_pts.as<int32_t>();
+    U.prohib = partition >= 0 ? c->d_prohib.as<uint64_t>() + (size_t)partition * c->pts_tw : nullptr;
+    U.skip = nullptr;
+    U.pts = partition;
+    U.n_types = c->n_types;
+    if (n_skip > 0) {  // models already triggered for an earlier partition of this run
+        std::vector<uint8_t> mask((size_t)std::max(M, 1), 0);
+        for (int32_t i = 0; i < n_skip; i++)
+            if (skip_models[i] >= 0 && skip_models[i] < M) mask[skip_models[i]] = 1;
+        HIP_TRY(c, c->s_d.ensure(mask.size()));
+        HIP_TRY(c, hipMemcpyAsync(c->s_d.p, mask.data(), mask.size(), hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipStreamSynchronize(st));  // `mask` leaves scope
+        U.skip = c->s_d.as<uint8_t>();
+    }
     KT_BEGIN(c, st);  // device span of the whole plan, including the host round trip for n_qualified
     hipLaunchKernelGGL(proactive_space_kernel, dim3(std::min(std::max(div_up(P, 256), 1), 512)), dim3(256), 0, st, pods, P,
-                       stats, default_units, ps);
-    hipLaunchKernelGGL(proactive_scalars_kernel, dim3(1), dim3(64), 0, st, stats, default_units, now, ps);
-    hipLaunchKernelGGL(proactive_count_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, stats, ps, counts,
+                       U, default_units, ps);
+    hipLaunchKernelGGL(proactive_scalars_kernel, dim3(1), dim3(64), 0, st, U, default_units, now, ps);
+    hipLaunchKernelGGL(proactive_count_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps, counts,
                        &ps->n_candidates);
     hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(256), 0, st, counts, nb, &ps->n_qualified);
     HIP_TRY(c, hipGetLastError());
@@ -1916,7 +2069,7 @@ int mmp_proactive_plan(mmp_ctx *c, int32_t default_units, int64_t now, int32_t m
         HIP_TRY(c, hipStreamSynchronize(st));
         kt_collect(c);
     } else {
-        hipLaunchKernelGGL(proactive_scatter_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, stats, ps, counts,
+        hipLaunchKernelGGL(proactive_scatter_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps, counts,
                            c->r_keys.as<int64_t>(), c->r_vals.as<int32_t>());
         // stable descending radix sort: equal lastUsed keep registry order, so the first one seen wins
         size_t tmp_bytes = 0;
@@ -1995,6 +2148,9 @@ int mmp_scaleup_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, cons
     A.ent_pod = c->ent_pod.as<int32_t>();
     A.ent_time = c->ent_time.as<int64_t>();
     A.stats = c->stats_acc.as<StatsAcc>();
+    A.tstats = c->tstats.as<StatsAcc>();
+    A.T_rows = std::max(c->n_types, 1);
+    A.has_tc = c->n_types > 0 ? 1 : 0;
     A.overloaded = c->s_a.as<uint8_t>();
     A.excluded_count = c->s_b.as<int32_t>();
     A.outs = c->s_outs.as<mmp_scaleup_out>();
@@ -2034,7 +2190,13 @@ int mmp_scaledown_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, co
     A.ent_time = c->ent_time.as<int64_t>();
     A.pods = c->sb[c->cur].pods.as<mmp_pod_row>();
     A.pos_of = c->snap.pos_of;
-    A.stats = c->stats_acc.as<StatsAcc>();
+    // instanceSetStats(): with type constraints, the stats of the partition this instance belongs to
+    // (EMPTY_STATS when it is not in the table), cluster-wide otherwise
+    {
+        const int32_t sp = p->self_pod;
+        const int32_t k = (sp >= 0 && sp < (int32_t)c->pts_of.size()) ? c->pts_of[sp] : -1;
+        A.stats = c->n_types > 0 ? c->pstats.as<StatsAcc>() + (k >= 0 ? k : c->n_pts) : c->stats_acc.as<StatsAcc>();
+    }
     A.decide = c->s_a.as<uint8_t>();
     A.removed = c->s_b.as<uint8_t>();
     A.p = *p;

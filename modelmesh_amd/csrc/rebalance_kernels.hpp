@@ -18,8 +18,26 @@ struct PlanScalars {  // mirrors mmp_proactive_info + work counters
     int32_t n_qualified;           // candidates that pass the :6683-6685 test (sort input size)
     int32_t n_distinct;            // distinct lastUsed values among them
     int32_t n_ge_cutoff;           // selected entries with lastUsed >= cutoff
-    int32_t pad;
+    int32_t cand_enabled;          // proactiveLoadCandidates != null (globalStats.totalCapacity > 0, MM.java:6459)
+    int64_t cand_glru;             // the reaper's globalLru: 0 <=> the cluster has free space (:6462)
 };
+
+// The instance subset a plan is made for (triggerProactiveLoadsForInstanceSubset, MM.java:6616: one call per
+// ProhibitedTypeSet partition when type constraints exist, :6473-6488).  pts < 0: the whole cluster.
+struct PlanSubset {
+    const StatsAcc *global;   // clusterStats: the candidate rule of pruneModelRegistry uses it (:6459-6462, :6574-6577)
+    const StatsAcc *stats;    // the subset's stats (== global for the whole cluster)
+    const int32_t *pod_pts;   // pod -> partition
+    const uint64_t *prohib;   // the partition's prohibited type rows (excludeTypes), null for the whole cluster
+    const uint8_t *skip;      // per model: already triggered for an earlier partition (allCandidates.set(i, null)), or null
+    int32_t pts, n_types;
+};
+
+__device__ __forceinline__ bool plan_excluded(const PlanSubset &U, int32_t i, int32_t type)
+{
+    if (U.skip && U.skip[i]) return true;
+    return U.prohib && type >= 0 && type < U.n_types && ((U.prohib[type >> 6] >> (type & 63)) & 1ull);
+}
 
 // sizeEstimate, MM.java:6622-6629
 __device__ __forceinline__ int32_t size_estimate_of(const StatsAcc *st, int32_t default_units)
@@ -31,9 +49,10 @@ __device__ __forceinline__ int32_t size_estimate_of(const StatsAcc *st, int32_t 
 }
 
 // spaceToFill accumulation, MM.java:6633-6649
-__global__ void proactive_space_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, const StatsAcc *st,
+__global__ void proactive_space_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, PlanSubset U,
                                        int32_t default_units, PlanScalars *ps)
 {
+    const StatsAcc *st = U.stats;
     const bool active = (int64_t)st->total_capacity > 0 && (int64_t)st->total_free > 0;
     int64_t sum = 0;
     if (active) {
@@ -42,6 +61,7 @@ __global__ void proactive_space_kernel(const mmp_pod_row *__restrict__ pods, int
             for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
                 const mmp_pod_row r = pods[p];
                 if (r.flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE)) continue;
+                if (U.pts >= 0 && U.pod_pts[p] != U.pts) continue;  // !excludeTypes.equals(ir.prohibitedTypes), :6635
                 const int32_t max_loads = (int32_t)((uint32_t)r.loading_threads * 50u - (uint32_t)r.loading_in_progress);
                 if (max_loads <= 0) continue;
                 const int64_t avail = jsub64(remaining_of(r.capacity, r.used), r.capacity / 8);
@@ -57,9 +77,12 @@ __global__ void proactive_space_kernel(const mmp_pod_row *__restrict__ pods, int
 }
 
 // the scalar part of :6621-6664, one lane
-__global__ void proactive_scalars_kernel(const StatsAcc *st, int32_t default_units, int64_t now, PlanScalars *ps)
+__global__ void proactive_scalars_kernel(PlanSubset U, int32_t default_units, int64_t now, PlanScalars *ps)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const StatsAcc *st = U.stats;
+    ps->cand_enabled = (int64_t)U.global->total_capacity > 0 ? 1 : 0;
+    ps->cand_glru = (int64_t)U.global->total_free > 0 ? 0 : U.global->global_lru;
     int32_t free_count = 0, total_count = 0;
     ps->error = 0;
     ps->size_estimate = 0;
@@ -89,16 +112,16 @@ __global__ void proactive_scalars_kernel(const StatsAcc *st, int32_t default_uni
 }
 
 // candidate predicate = registry rule :6574-6577 ∧ per-candidate test :6683-6685
-__device__ __forceinline__ bool proactive_candidate(const mmp_model_row &m, int64_t glru)
+__device__ __forceinline__ bool proactive_candidate(const mmp_model_row &m, const PlanScalars *ps)
 {
-    return m.n_loaded == 0 && m.n_failed < 2 && (glru == 0 || m.last_used > glru);
+    return ps->cand_enabled && m.n_loaded == 0 && m.n_failed < 2 && (ps->cand_glru == 0 || m.last_used > ps->cand_glru);
 }
 
 constexpr int kCompactBlock = 256;
 
 // pass 1: per-block counts of (candidates, qualified)
 __global__ __launch_bounds__(kCompactBlock) void proactive_count_kernel(const mmp_model_row *__restrict__ models,
-                                                                        int32_t M, const StatsAcc *st,
+                                                                        int32_t M, PlanSubset U,
                                                                         const PlanScalars *ps,
                                                                         int32_t *__restrict__ block_counts,
                                                                         int32_t *__restrict__ n_candidates)
@@ -108,8 +131,8 @@ __global__ __launch_bounds__(kCompactBlock) void proactive_count_kernel(const mm
     bool cand = false, q = false;
     if (i < M) {
         const mmp_model_row m = models[i];
-        cand = proactive_candidate(m, st->global_lru);
-        q = cand && ps->total_count > 0 && (ps->free_count > 0 || m.last_used > ps->cutoff);
+        cand = proactive_candidate(m, ps);
+        q = cand && !plan_excluded(U, i, m.type) && ps->total_count > 0 && (ps->free_count > 0 || m.last_used > ps->cutoff);
     }
     const int nq = __popcll(__ballot(q)), nc = __popcll(__ballot(cand));
     if (lane_id() == 0) {
@@ -152,7 +175,7 @@ __global__ __launch_bounds__(256) void block_scan_kernel(int32_t *__restrict__ c
 
 // pass 2: order-preserving scatter of the qualified (lastUsed, model) pairs
 __global__ __launch_bounds__(kCompactBlock) void proactive_scatter_kernel(const mmp_model_row *__restrict__ models,
-                                                                          int32_t M, const StatsAcc *st,
+                                                                          int32_t M, PlanSubset U,
                                                                           const PlanScalars *ps,
                                                                           const int32_t *__restrict__ block_off,
                                                                           int64_t *__restrict__ keys,
@@ -165,7 +188,7 @@ __global__ __launch_bounds__(kCompactBlock) void proactive_scatter_kernel(const 
     if (i < M) {
         const mmp_model_row m = models[i];
         lu = m.last_used;
-        q = proactive_candidate(m, st->global_lru) && ps->total_count > 0 &&
+        q = proactive_candidate(m, ps) && !plan_excluded(U, i, m.type) && ps->total_count > 0 &&
             (ps->free_count > 0 || m.last_used > ps->cutoff);
     }
     const uint64_t b = __ballot(q);
@@ -265,12 +288,14 @@ struct ScaleupArgs {
     const mmp_model_row *models;
     const int32_t *ent_pod;
     const int64_t *ent_time;
-    const StatsAcc *stats;
+    const StatsAcc *stats;   // cluster-wide
+    const StatsAcc *tstats;  // [T_rows] typeSetStats(type), MM.java:5691
     const uint8_t *overloaded;
     const int32_t *excluded_count;
     mmp_scaleup_out *outs;
     mmp_scaleup_params p;
     int32_t n, n_models, P;
+    int32_t T_rows, has_tc;  // has_tc: typeConstraints != null
 };
 
 // loadedSince, MM.java:5860-5871
@@ -301,15 +326,27 @@ __global__ void scaleup_plan_kernel(ScaleupArgs A)
     const int64_t time_delta = jsub64(p.now, p.last_check_time);
     const int32_t lower = p.iteration_counter - p.second_copy_max_age_iters;
     const int32_t upper = p.iteration_counter - p.second_copy_min_age_iters;
-    const int32_t suitable = A.stats->instance_count;
+    const bool have_model = ce.model >= 0 && ce.model < A.n_models;
+    mmp_model_row mr{};
+    if (have_model) mr = A.models[ce.model];
+    // typeSetStats(ce.modelInfo.serviceType), MM.java:5691 (cluster-wide for an entry without a registry record)
+    const StatsAcc *st = (A.has_tc && have_model) ? &A.tstats[(mr.type < 0 || mr.type >= A.T_rows) ? 0 : mr.type] : A.stats;
+    int32_t suitable = A.stats->instance_count;  // instCount, :5692
+    if (A.has_tc) {                              // :5693-5700: a type confined to one instance is skipped outright
+        suitable = st->instance_count;
+        if (suitable < 2) {
+            o.rpm = 0;
+            A.outs[e] = o;
+            return;
+        }
+    }
     const int32_t scale_up = p.scale_up_rpm_threshold;
     const int32_t heavy = (int32_t)((uint32_t)scale_up * 3u) / 4;
     const int32_t rpm = (int32_t)((ce.interval_count * 60000) / time_delta);
     o.rpm = rpm;
     if (rpm > heavy) o.heavy = 1;
     do {
-        if (ce.model < 0 || ce.model >= A.n_models) break;
-        const mmp_model_row mr = A.models[ce.model];
+        if (!have_model) break;
         const int32_t loaded = mr.n_loaded, failed = mr.n_failed;
         if (loaded == 0) break;
         int32_t cand = suitable - (loaded + failed);
@@ -326,9 +363,9 @@ __global__ void scaleup_plan_kernel(ScaleupArgs A)
             if (i2in || !i1in) o.new_i1 = i2;
             o.new_i2 = p.iteration_counter;
             if (i1in || i2in) {
-                const int64_t tc = (int64_t)A.stats->total_capacity, tf = (int64_t)A.stats->total_free;
+                const int64_t tc = (int64_t)st->total_capacity, tf = (int64_t)st->total_free;
                 if (tc == 0) break;  // the Java throws ArithmeticException here; caught, entry skipped
-                if ((10 * tf) / tc >= 1 || jsub64(p.now, A.stats->global_lru) > p.second_copy_lru_threshold_ms) {
+                if ((10 * tf) / tc >= 1 || jsub64(p.now, st->global_lru) > p.second_copy_lru_threshold_ms) {
                     o.action = MMP_SCALE_SECOND_COPY;
                     o.timestamp = p.last_check_time;
                     o.copies = 1;
@@ -368,7 +405,7 @@ struct ScaledownArgs {
     const int64_t *ent_time;
     const mmp_pod_row *pods;
     const int32_t *pos_of;
-    const StatsAcc *stats;
+    const StatsAcc *stats;  // instanceSetStats() (MM.java:1446-1448, :6228): this instance's partition, or cluster-wide
     uint8_t *decide;   // per entry: removeModelCopies would remove if canRemove
     uint8_t *removed;  // final
     mmp_scaledown_params p;

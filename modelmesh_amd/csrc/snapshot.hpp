@@ -308,4 +308,55 @@ __global__ void cluster_stats_kernel(const mmp_pod_row *__restrict__ pods, int32
     }
 }
 
+// ---- instance partitions and per-type subset stats (TypeConstraintManager) ---------------------------
+// With type constraints configured, ModelMesh does not use the cluster-wide ClusterStats everywhere:
+// instances are partitioned by their ProhibitedTypeSet — the constrained types they cannot host
+// (TypeConstraintManager.java:553-578) — every partition keeps its own InstanceSetStatsTracker, a model
+// type's stats are the sum over the partitions that can host it (candidateSubsetStats, :356-377;
+// typeSetStats, MM.java:1432-1439) and an instance's own stats are its partition's (instanceSetStats,
+// MM.java:1446-1448).  pod_pts[p] = partition of pod p (interned on the host at commit from the allowed
+// bitmaps), prohib[k] = the partition's prohibited types as a bitset over type rows.
+// Quirk (MM.java:1515-1542): a partition's lru is reset and re-accumulated over
+// ALL instances of clusterState on every event that touches the partition, so it is the cluster-wide
+// minimum as of that event; rebuilt from a table snapshot it is the cluster-wide minimum.
+__global__ void partition_stats_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int64_t min_space,
+                                       const int32_t *__restrict__ pod_pts, StatsAcc *__restrict__ pstats)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const mmp_pod_row r = pods[p];
+    if (r.flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE)) return;
+    StatsAcc *a = &pstats[pod_pts[p]];
+    const int64_t rem = remaining_of(r.capacity, r.used);
+    atomicAdd(&a->total_capacity, (unsigned long long)r.capacity);
+    if (!(rem < min_space)) atomicAdd(&a->total_free, (unsigned long long)rem);
+    atomicAdd(&a->instance_count, 1);
+    atomicAdd(&a->model_copy_count, r.count);
+}
+
+// one thread per partition / per type row; global = the cluster-wide stats of the same snapshot
+__global__ void subset_stats_finish_kernel(const StatsAcc *__restrict__ global, StatsAcc *__restrict__ pstats, int32_t NP,
+                                           const uint64_t *__restrict__ prohib, int32_t Tw, int32_t T,
+                                           const uint8_t *__restrict__ has_allowed, StatsAcc *__restrict__ tstats)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < NP) pstats[i].global_lru = pstats[i].instance_count > 0 ? global->global_lru : INT64_MAX;
+    if (i < T) {
+        StatsAcc t = *global;
+        if (NP > 0 && has_allowed && has_allowed[i]) {  // a constrained type: the partitions that may host it
+            t.total_capacity = t.total_free = 0;
+            t.instance_count = t.model_copy_count = 0;
+            for (int k = 0; k < NP; k++) {
+                if ((prohib[(size_t)k * Tw + (i >> 6)] >> (i & 63)) & 1ull) continue;
+                t.total_capacity += pstats[k].total_capacity;
+                t.total_free += pstats[k].total_free;
+                t.instance_count += pstats[k].instance_count;
+                t.model_copy_count += pstats[k].model_copy_count;
+            }
+            t.global_lru = t.instance_count > 0 ? global->global_lru : INT64_MAX;
+        }
+        tstats[i] = t;
+    }
+}
+
 }  // namespace mmp

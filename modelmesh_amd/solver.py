@@ -255,6 +255,28 @@ class Solver:
         self._ck(self.lib.mmp_cluster_stats(self.h, ptr(out)))
         return out[0]
 
+    def type_stats(self, type_row: int) -> np.ndarray:
+        """typeSetStats(type): the stats of the instances a type may be placed on (cluster-wide if unconstrained)."""
+        out = np.zeros(1, dtype=STATS)
+        self._ck(self.lib.mmp_type_stats(self.h, int(type_row), ptr(out)))
+        return out[0]
+
+    def partitions(self):
+        """-> (pod -> partition array, [(stats, prohibited type rows as a python int bitset)] per partition)"""
+        n = np.zeros(1, np.int32)
+        self._ck(self.lib.mmp_partition_count(self.h, ptr(n)))
+        npods = np.zeros(1, np.int32)
+        self._ck(self.lib.mmp_pod_partitions(self.h, None, 0, ptr(npods)))
+        pts = np.zeros(max(int(npods[0]), 1), np.int32)
+        self._ck(self.lib.mmp_pod_partitions(self.h, ptr(pts), int(npods[0]), ptr(npods)))
+        out = []
+        for k in range(int(n[0])):
+            st = np.zeros(1, dtype=STATS)
+            words = np.zeros(16, np.uint64)
+            self._ck(self.lib.mmp_partition_stats(self.h, k, ptr(st), ptr(words), len(words)))
+            out.append((st[0], sum(int(w) << (64 * i) for i, w in enumerate(words))))
+        return pts[: int(npods[0])], out
+
     # ---- decisions -----------------------------------------------------
     def place(self, reqs: np.ndarray, extra_pool: Optional[np.ndarray], now: int) -> np.ndarray:
         reqs = np.ascontiguousarray(reqs, dtype=PLACE_REQ)
@@ -350,14 +372,17 @@ class Solver:
                                          int(now), int(in_use_failure_expiry_ms), ptr(outs)))
         return outs
 
-    def proactive_plan(self, default_model_size_units: int, now: int, max_out: int):
-        """a17: (models, last_used, info) the leader would proactively load, MRU first."""
+    def proactive_plan(self, default_model_size_units: int, now: int, max_out: int, partition: int = -1, skip_models=None):
+        """a17: (models, last_used, info) the leader would proactively load, MRU first; partition >= 0: for that
+        ProhibitedTypeSet partition only (one reaper call per partition when type constraints exist)."""
         from ._lib import PROACTIVE_INFO
         om = np.zeros(max(max_out, 1), np.int32)
         ol = np.zeros(max(max_out, 1), np.int64)
         info = np.zeros(1, dtype=PROACTIVE_INFO)
-        self._ck(self.lib.mmp_proactive_plan(self.h, int(default_model_size_units), int(now), int(max_out),
-                                             ptr(om), ptr(ol), ptr(info)))
+        skip = np.ascontiguousarray(skip_models if skip_models is not None else np.zeros(0, np.int32), dtype=np.int32)
+        self._ck(self.lib.mmp_proactive_plan_subset(self.h, int(partition), ptr(skip) if len(skip) else None, len(skip),
+                                                    int(default_model_size_units), int(now), int(max_out),
+                                                    ptr(om), ptr(ol), ptr(info)))
         n = min(int(info[0]["n_selected"]), max_out)
         return om[:n].copy(), ol[:n].copy(), info[0]
 

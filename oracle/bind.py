@@ -124,9 +124,9 @@ def load() -> C.CDLL:
         lib.orc_should_publish.restype = C.c_int
         lib.orc_should_publish.argtypes = [VP, VP, I64, I64, C.c_int, C.c_int, I64]
         lib.orc_proactive_plan.restype = C.c_int32
-        lib.orc_proactive_plan.argtypes = [VP, I32, VP, VP, I32, I32, I64, VP, VP, I32, VP]
+        lib.orc_proactive_plan.argtypes = [VP, I32, VP, VP, VP, VP, I32, VP, VP, I32, I32, I64, VP, VP, I32, VP]
         lib.orc_scaleup_plan.restype = C.c_int
-        lib.orc_scaleup_plan.argtypes = [VP, I32, VP, I32, VP, VP, VP, VP, VP, I32, VP, VP, VP]
+        lib.orc_scaleup_plan.argtypes = [VP, I32, VP, I32, VP, VP, I32, C.c_int, VP, VP, VP, VP, I32, VP, VP, VP]
         lib.orc_scaledown_plan.restype = None
         lib.orc_scaledown_plan.argtypes = [VP, VP, VP, VP, VP, VP, VP, VP, I32, VP, VP]
         lib.orc_migration_plan.restype = None
@@ -377,17 +377,97 @@ ORC_PROACTIVE_INFO = np.dtype(
      ("n_selected", "<i4"), ("error", "<i4"), ("space_to_fill", "<i8"), ("cutoff", "<i8")])
 
 
-def proactive_plan(fleet, default_units, now, max_out):
-    """a17 on the oracle: returns (models, last_used, info)."""
+# ---- instance partitions and subset stats (TypeConstraintManager), restated with numpy --------------------
+def partitions(fleet):
+    """ProhibitedTypeSet partitions of the present instances (TypeConstraintManager.java:553-578): an
+    instance's set = the constrained types it cannot host.  -> (pts[P] with -1 for rows not in the table,
+    [frozenset of prohibited type rows] per partition, interned in instance order)."""
+    P = fleet.n_pods
+    pts = np.full(P, -1, np.int32)
+    sets, index = [], {}
+    if not fleet.n_types:
+        return pts, sets
+    al = unpack_bitmap(fleet.allowed, P)
+    present = (fleet.pods["flags"] & 5) == 0
+    for p in range(P):
+        if not present[p]:
+            continue
+        sig = frozenset(t for t in range(fleet.n_types) if fleet.has_allowed[t] and not al[t][p])
+        if sig not in index:
+            index[sig] = len(sets)
+            sets.append(sig)
+        pts[p] = index[sig]
+    return pts, sets
+
+
+def subset_stats(fleet, mask, global_stats):
+    """InstanceSetStatsTracker over the present instances selected by `mask` (InstanceSetStatsTracker.java:53-92);
+    its lru is the cluster-wide one (re-accumulated over ALL instances on every event, MM.java:1515-1542)."""
+    pods = fleet.pods
+    sel = mask & ((pods["flags"] & 5) == 0)
+    rem = np.maximum(pods["capacity"] - pods["used"], 0)
+    out = np.zeros(1, dtype=ORC_STATS)[0]
+    out["total_capacity"] = int(pods["capacity"][sel].sum())
+    out["total_free"] = int(rem[sel & (rem >= fleet.min_space_units)].sum())
+    out["instance_count"] = int(sel.sum())
+    out["model_copy_count"] = int(pods["count"][sel].sum())
+    out["global_lru"] = int(global_stats["global_lru"]) if sel.any() else 2**63 - 1
+    return out
+
+
+def partition_stats(fleet):
+    """-> (pts, sets, ORC_STATS[n_partitions])"""
+    g = OracleFleet(fleet).stats()
+    pts, sets = partitions(fleet)
+    st = np.zeros(len(sets), dtype=ORC_STATS)
+    for k in range(len(sets)):
+        st[k] = subset_stats(fleet, pts == k, g)
+    return pts, sets, st
+
+
+def type_set_stats(fleet):
+    """typeSetStats(type) for every type row (MM.java:1432-1439): candidateSubsetStats() of a constrained type =
+    the sum over the partitions that do not prohibit it (TypeConstraintManager.java:356-377), the cluster's
+    stats for an unconstrained one (and for every type when typeConstraints == null)."""
+    g = OracleFleet(fleet).stats()
+    T = max(fleet.n_types, 1)
+    out = np.zeros(T, dtype=ORC_STATS)
+    out[:] = g
+    if fleet.n_types:
+        pts, sets = partitions(fleet)
+        for t in range(fleet.n_types):
+            if fleet.has_allowed[t]:
+                ok = np.array([t not in s for s in sets], bool)
+                out[t] = subset_stats(fleet, np.isin(pts, np.nonzero(ok)[0]), g)
+    return out
+
+
+def proactive_plan(fleet, default_units, now, max_out, partition=-1, skip_models=None):
+    """a17 on the oracle: returns (models, last_used, info); partition >= 0: for that partition only."""
     lib = load()
     orc = OracleFleet(fleet)
-    stats = np.zeros(1, dtype=ORC_STATS)
-    stats[0] = orc.stats()
+    gstats = np.zeros(1, dtype=ORC_STATS)
+    gstats[0] = orc.stats()
+    stats, in_subset, prohibited = gstats, None, None
+    if partition >= 0:
+        pts, sets, pst = partition_stats(fleet)
+        stats = np.ascontiguousarray(pst[partition: partition + 1])
+        in_subset = np.ascontiguousarray((pts == partition).astype(np.uint8))
+        words = np.zeros(max(-(-fleet.n_types // 64), 1), np.uint64)
+        for t in sets[partition]:
+            words[t >> 6] |= np.uint64(1) << np.uint64(t & 63)
+        prohibited = words
+    skip = None
+    if skip_models is not None and len(skip_models):
+        skip = np.zeros(max(fleet.n_models, 1), np.uint8)
+        skip[np.asarray(skip_models)] = 1
     om = np.zeros(max(max_out, 1), np.int32)
     ol = np.zeros(max(max_out, 1), np.int64)
     info = np.zeros(1, dtype=ORC_PROACTIVE_INFO)
     models = np.ascontiguousarray(fleet.models)
-    n = lib.orc_proactive_plan(_p(orc.pods), len(orc.pods), _p(stats), _p(models), len(models), int(default_units),
+    n = lib.orc_proactive_plan(_p(orc.pods), len(orc.pods), _p(gstats), _p(stats), _p(in_subset) if in_subset is not None else None,
+                               _p(prohibited) if prohibited is not None else None, int(fleet.n_types),
+                               _p(skip) if skip is not None else None, _p(models), len(models), int(default_units),
                                int(now), _p(om), _p(ol), int(max_out), _p(info))
     n = min(n, max_out)
     return om[:n].copy(), ol[:n].copy(), info[0]
@@ -422,7 +502,9 @@ def scaleup_plan(fleet, entries, params):
     ov = np.zeros(max(fleet.n_pods, 1), np.uint8)
     ep, et = _ent(fleet)
     models = np.ascontiguousarray(fleet.models)
-    sk = lib.orc_scaleup_plan(_p(orc.pods), fleet.n_pods, _p(orc.order), len(orc.order), _p(stats), _p(models), _p(ep),
+    tstats = np.ascontiguousarray(type_set_stats(fleet))
+    sk = lib.orc_scaleup_plan(_p(orc.pods), fleet.n_pods, _p(orc.order), len(orc.order), _p(stats), _p(tstats), len(tstats),
+                              1 if fleet.n_types else 0, _p(models), _p(ep),
                               _p(et), _p(entries) if len(entries) else None, len(entries), _p(params), _p(outs), _p(ov))
     return outs[: len(entries)], ov[: fleet.n_pods], sk
 
@@ -432,6 +514,15 @@ def scaledown_plan(fleet, entries, params):
     orc = OracleFleet(fleet)
     stats = np.zeros(1, dtype=ORC_STATS)
     stats[0] = orc.stats()
+    if fleet.n_types:  # instanceSetStats(): this instance's partition (EMPTY_STATS when it is not in the table)
+        sp = int(np.asarray(params).reshape(-1)[0]["self_pod"])
+        pts, sets, pst = partition_stats(fleet)
+        k = int(pts[sp]) if 0 <= sp < fleet.n_pods else -1
+        if k >= 0:
+            stats[0] = pst[k]
+        else:
+            stats[0] = np.zeros(1, dtype=ORC_STATS)[0]
+            stats[0]["global_lru"] = 2**63 - 1
     pos_of = np.full(max(fleet.n_pods, 1), 2**31 - 1, np.int32)
     pos_of[orc.order] = np.arange(len(orc.order), dtype=np.int32)
     in_table = np.ascontiguousarray(((fleet.pods["flags"] & 4) == 0).astype(np.uint8))

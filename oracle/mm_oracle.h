@@ -238,10 +238,11 @@ typedef struct {
     int64_t space_to_fill; /* after the /2, :6650                          */
     int64_t cutoff;        /* proactiveLastUsedCutoff, :6662-6664          */
 } orc_proactive_info;
-int32_t orc_proactive_plan(const orc_pod *pods, int32_t n_pods, const orc_cluster_stats *stats,
-                           const orc_flat_model *models, int32_t n_models, int32_t default_model_size_units,
-                           int64_t now, int32_t *out_model, int64_t *out_last_used, int32_t max_out,
-                           orc_proactive_info *info);
+int32_t orc_proactive_plan(const orc_pod *pods, int32_t n_pods, const orc_cluster_stats *global,
+                           const orc_cluster_stats *stats, const uint8_t *in_subset, const uint64_t *prohibited,
+                           int32_t n_types, const uint8_t *skip, const orc_flat_model *models, int32_t n_models,
+                           int32_t default_model_size_units, int64_t now, int32_t *out_model, int64_t *out_last_used,
+                           int32_t max_out, orc_proactive_info *info);
 
 /* one local CacheEntry as the rebalancers see it */
 typedef struct {
@@ -270,7 +271,8 @@ typedef struct {
     int32_t rpm;
 } orc_scaleup_out;
 int orc_scaleup_plan(const orc_pod *pods, int32_t n_pods, const int32_t *order, int32_t n_order,
-                     const orc_cluster_stats *stats, const orc_flat_model *models, const int32_t *ent_pod,
+                     const orc_cluster_stats *stats, const orc_cluster_stats *type_stats, int32_t t_rows, int has_tc,
+                     const orc_flat_model *models, const int32_t *ent_pod,
                      const int64_t *ent_time, const orc_cache_entry *entries, int32_t n, const orc_scaleup_params *p,
                      orc_scaleup_out *outs, uint8_t *overloaded_out);
 typedef struct {

@@ -11,14 +11,18 @@
 static inline int64_t jsub64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
 static inline int64_t age(int64_t t, int64_t now) { return t == 0 ? 0 : jsub64(now, t); }
 
-/* a17 — leader "reaper" proactive loading, MM.java:6574-6577 (candidate rule) and
- * triggerProactiveLoadsForInstanceSubset :6616-6747 with excludeTypes == null.
- * models are in registry iteration order.  out_model/out_last_used receive the models the Java
- * would call ensureLoadedInternal for, in call order (most recently used first). */
-int32_t orc_proactive_plan(const orc_pod *pods, int32_t n_pods, const orc_cluster_stats *stats,
-                           const orc_flat_model *models, int32_t n_models, int32_t default_model_size_units,
-                           int64_t now, int32_t *out_model, int64_t *out_last_used, int32_t max_out,
-                           orc_proactive_info *info)
+/* a17 — leader "reaper" proactive loading: the candidate rule of pruneModelRegistry (MM.java:6459-6462,
+ * :6574-6577, always on the cluster-wide stats `global`) and triggerProactiveLoadsForInstanceSubset
+ * :6616-6747 for one instance subset: `stats` = the subset's ClusterStats, in_subset[p] (NULL = all) =
+ * excludeTypes.equals(ir.prohibitedTypes), prohibited (NULL = none) = excludeTypes as a bitset over the
+ * n_types configured type rows, skip[m] (NULL = none) = allCandidates entries nulled by an earlier subset
+ * of the same run (:6724).  models are in registry iteration order.  out_model/out_last_used receive the
+ * models the Java would call ensureLoadedInternal for, in call order (most recently used first). */
+int32_t orc_proactive_plan(const orc_pod *pods, int32_t n_pods, const orc_cluster_stats *global,
+                           const orc_cluster_stats *stats, const uint8_t *in_subset, const uint64_t *prohibited,
+                           int32_t n_types, const uint8_t *skip, const orc_flat_model *models, int32_t n_models,
+                           int32_t default_model_size_units, int64_t now, int32_t *out_model, int64_t *out_last_used,
+                           int32_t max_out, orc_proactive_info *info)
 {
     memset(info, 0, sizeof *info);
     int32_t free_count = 0, total_count = 0;
@@ -43,6 +47,7 @@ int32_t orc_proactive_plan(const orc_pod *pods, int32_t n_pods, const orc_cluste
         for (int32_t i = 0; i < n_pods; i++) { /* :6635-6649, clusterState holds only present rows */
             const orc_pod *ir = &pods[i];
             if (ir->shutting_down) continue;
+            if (in_subset && !in_subset[i]) continue; /* :6635 */
             int32_t max_loads = (int32_t)((uint32_t)ir->loading_threads * 50u - (uint32_t)ir->loading_in_progress);
             if (max_loads <= 0) continue;
             int64_t reserve = ir->capacity / 8, avail = jsub64(orc_remaining(ir), reserve);
@@ -65,7 +70,9 @@ int32_t orc_proactive_plan(const orc_pod *pods, int32_t n_pods, const orc_cluste
                                            (uint64_t)(age(stats->global_lru, now) / 3 > 1200000 ? age(stats->global_lru, now) / 3
                                                                                                   : 1200000));
     info->cutoff = cutoff;
-    const int64_t global_lru = stats->global_lru;
+    /* proactiveLoadCandidates exists only if globalStats.totalCapacity > 0; globalLru == 0 <=> free space (:6459-6462) */
+    const int cand_enabled = global->total_capacity > 0;
+    const int64_t global_lru = global->total_free > 0 ? 0 : global->global_lru;
 
     /* NavigableSet<ModelToLoad> toLoad: a TreeSet ordered by lastUsed DESC whose compareTo looks at
      * lastUsed only, so an element with an equal lastUsed is a duplicate and add() is a no-op. */
@@ -76,8 +83,10 @@ int32_t orc_proactive_plan(const orc_pod *pods, int32_t n_pods, const orc_cluste
     for (int32_t i = 0; i < n_models; i++) {
         const orc_flat_model *mr = &models[i];
         /* proactiveLoadCandidates rule, :6574-6577 */
-        if (!(mr->n_loaded == 0 && mr->n_failed < 2 && (global_lru == 0 || mr->last_used > global_lru))) continue;
+        if (!(cand_enabled && mr->n_loaded == 0 && mr->n_failed < 2 && (global_lru == 0 || mr->last_used > global_lru))) continue;
         n_cand++;
+        if (skip && skip[i]) continue; /* ent == null, :6679 */
+        if (prohibited && mr->type >= 0 && mr->type < n_types && ((prohibited[mr->type >> 6] >> (mr->type & 63)) & 1)) continue; /* :6682 */
         int64_t last_used = mr->last_used;
         if (total_count > 0 && (free_count > 0 || last_used > cutoff)) { /* :6683-6685 */
             if (size < total_count || set_lu[size - 1] < last_used) {
@@ -131,7 +140,8 @@ static int loaded_since(const int32_t *pods, const int64_t *times, int32_t n, in
 }
 
 int orc_scaleup_plan(const orc_pod *pods, int32_t n_pods, const int32_t *order, int32_t n_order,
-                     const orc_cluster_stats *stats, const orc_flat_model *models, const int32_t *ent_pod,
+                     const orc_cluster_stats *stats, const orc_cluster_stats *type_stats, int32_t t_rows, int has_tc,
+                     const orc_flat_model *models, const int32_t *ent_pod,
                      const int64_t *ent_time, const orc_cache_entry *entries, int32_t n, const orc_scaleup_params *p,
                      orc_scaleup_out *outs, uint8_t *overloaded_out)
 {
@@ -158,7 +168,18 @@ int orc_scaleup_plan(const orc_pod *pods, int32_t n_pods, const int32_t *order, 
         const orc_cache_entry *ce = &entries[e];
         orc_scaleup_out *o = &outs[e];
         const int64_t count = ce->interval_count;
-        const int32_t suitable = inst_count;
+        /* clusterStats = typeSetStats(ce.modelInfo.serviceType) (:5691); an entry without a registry record
+         * has no type here and is evaluated against the cluster-wide stats */
+        const orc_cluster_stats *cst = stats;
+        if (has_tc && ce->model >= 0) {
+            const int32_t ty = models[ce->model].type;
+            cst = &type_stats[(ty < 0 || ty >= t_rows) ? 0 : ty];
+        }
+        int32_t suitable = inst_count;
+        if (has_tc) { /* :5693-5700 */
+            suitable = cst->instance_count;
+            if (suitable < 2) continue;
+        }
         const int32_t rpm = (int32_t)((count * 60000) / time_delta);
         o->rpm = rpm;
         if (rpm > heavy_rpms) o->heavy = 1; /* ce.setLastHeavyTime(now) */
@@ -181,9 +202,9 @@ int orc_scaleup_plan(const orc_pod *pods, int32_t n_pods, const int32_t *order, 
             if (i2in || !i1in) o->new_i1 = i2;
             o->new_i2 = p->iteration_counter;
             if (i1in || i2in) {
-                if (stats->total_capacity == 0) continue; /* ArithmeticException, caught at :5810 */
-                if ((10 * stats->total_free) / stats->total_capacity >= 1 ||
-                    jsub64(now, stats->global_lru) > p->second_copy_lru_threshold_ms) {
+                if (cst->total_capacity == 0) continue; /* ArithmeticException, caught at :5810 */
+                if ((10 * cst->total_free) / cst->total_capacity >= 1 ||
+                    jsub64(now, cst->global_lru) > p->second_copy_lru_threshold_ms) {
                     o->action = 1; /* ensureLoadedInternalAsync(modelId, lastTime, weight, excludeThisInstance, 0) */
                     o->timestamp = last_time;
                     o->copies = 1;

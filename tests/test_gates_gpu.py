@@ -90,8 +90,8 @@ def test_gates_match_oracle(seed):
 
     lib = ob.load()
     orc = ob.OracleFleet(fleet)
-    stats = np.zeros(1, dtype=ob.ORC_STATS)
-    stats[0] = orc.stats()
+    # typeSetStats(mr.getType()): the stats of the instances the model's type may be placed on (MM.java:5169, :2918)
+    tstats = np.ascontiguousarray(ob.type_set_stats(fleet))
     in_table = np.ascontiguousarray(((fleet.pods["flags"] & 4) == 0).astype(np.uint8))
     al = ob.unpack_bitmap(fleet.allowed, P) if fleet.n_types else None
     opods = orc.pods
@@ -108,6 +108,8 @@ def test_gates_match_oracle(seed):
             keep &= lp != excl_pod[q["excl_off"] + j]
         ex = np.ascontiguousarray(explicit[q["explicit_off"]: q["explicit_off"] + q["n_explicit"]])
         fl = int(q["flags"])
+        ty = int(mr["type"])
+        stats = tstats[(0 if ty < 0 or ty >= len(tstats) else ty): ][:1]
         want = 0
         cp, ct = np.ascontiguousarray(lp[keep]), np.ascontiguousarray(lt[keep])
         if lib.orc_go_local(_p(cp), _p(ct), len(cp), int(q["self_pod"]), fl & 1, (fl >> 1) & 1, (fl >> 2) & 1, now):

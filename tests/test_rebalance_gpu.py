@@ -147,7 +147,7 @@ def test_scaleup_scaledown_migration_plans_match_oracle(seed, pods, used):
                     continue
                 assert np.array_equal(g_out[f], w_out[f]), (f, thr, np.nonzero(g_out[f] != w_out[f])[0][:5])
             seen_actions |= set(np.unique(g_out["action"]))
-        if pods > 1:
+        if pods >= 200:  # (small fleets with type constraints: a type's subset may leave no candidate instance)
             assert seen_actions >= {0, 1, 2}
 
         for thr, cap, sd in ((2000, 200_000, 0), (2000, 1_000, 0), (10, 10_000_000, 0), (2000, 200_000, 1)):
@@ -177,5 +177,71 @@ def test_scaleup_scaledown_migration_plans_match_oracle(seed, pods, used):
             want = ob.OracleFleet(fleet).place(reqs, extra, now)
             assert np.array_equal(out["chosen"], want["chosen"])
             assert not np.any(out["chosen"] == 0)  # never back onto the instance that is shutting down
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("seed,pods", [(0, 30), (1, 200), (2, 700), (3, 64), (4, 5)])
+def test_partitions_and_subset_stats_match_the_restatement(seed, pods):
+    """With type constraints the mesh uses per-partition / per-type ClusterStats (TypeConstraintManager;
+    typeSetStats MM.java:1432-1439, instanceSetStats :1446-1448): partitions by ProhibitedTypeSet, their
+    stats, and every type row's candidate-subset stats, rebuilt at commit, against the numpy restatement."""
+    fleet = wl.fuzz_fleet(seed + 900, pods=pods, models=50, profile="prefer" if seed % 2 else None)
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        pts, parts = s.partitions()
+        wpts, wsets, wst = ob.partition_stats(fleet)
+        assert np.array_equal(pts, wpts)
+        assert len(parts) == len(wsets)
+        for k, (st, bits) in enumerate(parts):
+            assert bits == sum(1 << t for t in wsets[k]), k
+            for f in ("total_capacity", "total_free", "global_lru", "instance_count", "model_copy_count"):
+                assert int(st[f]) == int(wst[k][f]), (k, f)
+        wt = ob.type_set_stats(fleet)
+        for t in range(len(wt)):
+            st = s.type_stats(t)
+            for f in ("total_capacity", "total_free", "global_lru", "instance_count", "model_copy_count"):
+                assert int(st[f]) == int(wt[t][f]), (t, f)
+        if not fleet.n_types:
+            assert len(parts) == 0 and int(s.type_stats(0)["instance_count"]) == int(s.stats()["instance_count"])
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_proactive_plan_per_partition_matches_oracle(seed):
+    """One reaper pass over a fleet with type constraints (MM.java:6473-6488): a plan per ProhibitedTypeSet
+    partition — its stats, its instances, its prohibited types excluded — each skipping the models the earlier
+    partitions already took."""
+    fleet = _plan_fleet(seed + 20, 300, 6000, [0.5, 0.9, 0.2][seed])
+    if not fleet.n_types:  # make sure the fleet has type constraints
+        rng = np.random.default_rng(seed)
+        fleet.n_types = 3
+        al = rng.random((3, fleet.n_pods)) < np.array([[1.0], [0.4], [0.7]])
+        from modelmesh_amd.solver import bitmap_from_bool
+        fleet.allowed, fleet.prefer = bitmap_from_bool(al), bitmap_from_bool(np.zeros_like(al))
+        fleet.has_allowed, fleet.has_prefer = np.array([0, 1, 1], np.uint8), np.zeros(3, np.uint8)
+        fleet.models["type"] = rng.integers(0, 3, fleet.n_models)
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        _, parts = s.partitions()
+        assert len(parts) >= 2
+        taken = np.zeros(0, np.int32)
+        n_sel = 0
+        for k in range(len(parts)):
+            gm, gl, gi = s.proactive_plan(6400, fleet.now, fleet.n_models, partition=k, skip_models=taken)
+            wm, wl_, wi = ob.proactive_plan(fleet, 6400, fleet.now, fleet.n_models, partition=k, skip_models=taken)
+            for f in ("size_estimate", "free_count", "total_count", "n_candidates", "n_selected", "error",
+                      "space_to_fill", "cutoff"):
+                assert int(gi[f]) == int(wi[f]), (k, f, gi, wi)
+            assert np.array_equal(gm, wm) and np.array_equal(gl, wl_), k
+            _, prohibited = parts[k]
+            assert not any((prohibited >> int(t)) & 1 for t in fleet.models["type"][gm]), "a prohibited type was selected"
+            assert not np.intersect1d(gm, taken).size
+            taken = np.concatenate([taken, gm])
+            n_sel += len(gm)
+        assert n_sel > 0
     finally:
         s.close()
