@@ -862,8 +862,8 @@ int build_subset_stats(mmp_ctx *c, const mmp_pod_row *d_pods, int32_t P, int64_t
     if (NP) HIP_TRY(c, hipMemcpyAsync(c->d_prohib.p, c->pts_prohib.data(), (size_t)NP * Tw * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->pstats.p, c->pstats_h.data(), (size_t)(NP + 1) * sizeof(StatsAcc), hipMemcpyHostToDevice, st));
     if (NP > 0 && P > 0)
-        hipLaunchKernelGGL(partition_stats_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, d_pods, P, min_space,
-                           c->d_pts.as<int32_t>(), c->pstats.as<StatsAcc>());
+        hipLaunchKernelGGL(partition_stats_kernel, dim3(std::min(div_up(P, 256), 64)), dim3(256), 0, st, d_pods, P, min_space,
+                           c->d_pts.as<int32_t>(), NP, c->pstats.as<StatsAcc>());
     hipLaunchKernelGGL(subset_stats_finish_kernel, dim3(div_up(std::max(NP, T), 256)), dim3(256), 0, st,
                        c->stats_acc.as<StatsAcc>(), c->pstats.as<StatsAcc>(), NP, c->d_prohib.as<uint64_t>(), Tw, T,
                        c->n_types > 0 ? c->d_has_allowed.as<uint8_t>() : nullptr, c->tstats.as<StatsAcc>());

@@ -319,19 +319,53 @@ __global__ void cluster_stats_kernel(const mmp_pod_row *__restrict__ pods, int32
 // Quirk (MM.java:1515-1542): a partition's lru is reset and re-accumulated over
 // ALL instances of clusterState on every event that touches the partition, so it is the cluster-wide
 // minimum as of that event; rebuilt from a table snapshot it is the cluster-wide minimum.
-__global__ void partition_stats_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int64_t min_space,
-                                       const int32_t *__restrict__ pod_pts, StatsAcc *__restrict__ pstats)
+// Accumulated in LDS per workgroup first (a few partitions receive every pod: global atomics on the same
+// four words from 10k lanes were measured at 221 us), then one global atomic per touched partition and field.
+constexpr int kPtsLds = 512;  // partitions accumulated in LDS; beyond that, global atomics
+__global__ __launch_bounds__(256) void partition_stats_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int64_t min_space,
+                                                              const int32_t *__restrict__ pod_pts, int32_t NP,
+                                                              StatsAcc *__restrict__ pstats)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    const mmp_pod_row r = pods[p];
-    if (r.flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE)) return;
-    StatsAcc *a = &pstats[pod_pts[p]];
-    const int64_t rem = remaining_of(r.capacity, r.used);
-    atomicAdd(&a->total_capacity, (unsigned long long)r.capacity);
-    if (!(rem < min_space)) atomicAdd(&a->total_free, (unsigned long long)rem);
-    atomicAdd(&a->instance_count, 1);
-    atomicAdd(&a->model_copy_count, r.count);
+    __shared__ unsigned long long cap_s[kPtsLds], free_s[kPtsLds];
+    __shared__ int32_t cnt_s[kPtsLds], mc_s[kPtsLds];
+    const bool lds = NP <= kPtsLds;
+    if (lds) {
+        for (int k = threadIdx.x; k < NP; k += blockDim.x) {
+            cap_s[k] = free_s[k] = 0;
+            cnt_s[k] = mc_s[k] = 0;
+        }
+        __syncthreads();
+    }
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const mmp_pod_row r = pods[p];
+        if (r.flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE)) continue;
+        const int k = pod_pts[p];
+        const int64_t rem = remaining_of(r.capacity, r.used);
+        const unsigned long long fr = !(rem < min_space) ? (unsigned long long)rem : 0ull;
+        if (lds) {
+            atomicAdd(&cap_s[k], (unsigned long long)r.capacity);
+            if (fr) atomicAdd(&free_s[k], fr);
+            atomicAdd(&cnt_s[k], 1);
+            atomicAdd(&mc_s[k], r.count);
+        } else {
+            StatsAcc *a = &pstats[k];
+            atomicAdd(&a->total_capacity, (unsigned long long)r.capacity);
+            if (fr) atomicAdd(&a->total_free, fr);
+            atomicAdd(&a->instance_count, 1);
+            atomicAdd(&a->model_copy_count, r.count);
+        }
+    }
+    if (lds) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < NP; k += blockDim.x) {
+            if (cnt_s[k] == 0) continue;
+            StatsAcc *a = &pstats[k];
+            atomicAdd(&a->total_capacity, cap_s[k]);
+            if (free_s[k]) atomicAdd(&a->total_free, free_s[k]);
+            atomicAdd(&a->instance_count, cnt_s[k]);
+            atomicAdd(&a->model_copy_count, mc_s[k]);
+        }
+    }
 }
 
 // one thread per partition / per type row; global = the cluster-wide stats of the same snapshot
