@@ -342,3 +342,78 @@ def test_latency_path_sustains_many_calls_without_a_stream_sync():
         assert last < 2 * first + 5e-6, (first, last)
     finally:
         s.close()
+
+
+def test_concurrent_small_calls_of_every_kind_with_commits_and_table_reloads():
+    """The guards, the load target and the eviction evaluation of small batches all run on the latency slots
+    (own streams, pinned buffers, completion flag) while the main thread re-commits the snapshot, upserts
+    registry rows and reloads the cache tables underneath: results never change (the contents do not), nothing
+    deadlocks, nothing reads a half-written table."""
+    import threading
+    from modelmesh_amd import _lib
+    fleet = wl.make_fleet("C2")
+    cs = wl.ChurnStream(fleet, 0xC5)
+    reqs, extra = wl.make_requests(fleet, 78, n=3000, extra_frac=0.0)
+    want = OracleFleet(fleet).place(reqs, extra, fleet.now, threads=8)
+    now = fleet.now
+    ev = np.zeros(64, dtype=_lib.EVICT_REQ)
+    ev["cache"] = np.arange(64) % fleet.n_pods
+    ev["weight"] = 6400
+    g = np.zeros(32, dtype=_lib.GATE_REQ)
+    g["model"] = np.arange(32)
+    g["self_pod"] = np.arange(32) % fleet.n_pods
+    g["cache_capacity"], g["loader_predicted"] = 8_388_608, 6400
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    errors = []
+    try:
+        s.load_fleet(fleet)
+        s.load_caches(cs.seg_off, cs.cache_lu, cs.cache_wt, cs.cache_cap)
+        want_ev = s.evict(ev, now)
+        z32, z64 = np.zeros(0, np.int32), np.zeros(0, np.int64)
+        want_g = s.gates(g, z32, z64, z32, now)
+
+        def placer(tid):
+            try:
+                for i in range(tid, 3000, 3):
+                    got = s.place(reqs[i:i + 1], None, now)
+                    if got["chosen"][0] != want["chosen"][i] or got["hash"][0] != want["hash"][i]:
+                        errors.append(("place", i))
+            except Exception as e:  # noqa: BLE001
+                errors.append(("place", repr(e)))
+
+        def evictor():
+            try:
+                for _ in range(600):
+                    if not np.array_equal(s.evict(ev, now), want_ev):
+                        errors.append(("evict",))
+            except Exception as e:  # noqa: BLE001
+                errors.append(("evict", repr(e)))
+
+        def gater():
+            try:
+                for _ in range(600):
+                    if not np.array_equal(s.gates(g, z32, z64, z32, now), want_g):
+                        errors.append(("gate",))
+            except Exception as e:  # noqa: BLE001
+                errors.append(("gate", repr(e)))
+        ths = [threading.Thread(target=placer, args=(t,)) for t in range(3)] + [threading.Thread(target=evictor),
+                                                                                 threading.Thread(target=gater)]
+        for t in ths:
+            t.start()
+        idx = np.arange(0, fleet.n_models, 7, dtype=np.int32)
+        for it in range(25):
+            s.commit()
+            rows = fleet.models[idx].copy()
+            k = (rows["n_loaded"] + rows["n_failed"]).astype(np.int64)
+            off = np.zeros(len(idx) + 1, np.int64)
+            np.cumsum(k, out=off[1:])
+            src = np.repeat(rows["ent_off"].astype(np.int64) - off[:-1], k) + np.arange(int(off[-1]))
+            rows["ent_off"] = off[:-1]
+            s.upsert_models(idx, rows, fleet.ent_pod[src], fleet.ent_time[src])  # same content, rewritten in place
+            s.load_caches(cs.seg_off, cs.cache_lu, cs.cache_wt, cs.cache_cap)
+        for t in ths:
+            t.join(120)
+            assert not t.is_alive(), "a worker is stuck"
+        assert not errors, errors[:5]
+    finally:
+        s.close()
