@@ -427,18 +427,27 @@ struct LaneWords {
     }
 };
 
-// first set bit of f(w) at a position in [start, stop); kNoPos if none
+// A lane walks 64-pod words one after the other; a decision whose scans or shortlist span more than this many
+// words is handed to the wave path, which takes 64 words per step (measured on a cluster where EVERY instance
+// is full — the LRU-window mode of MM.java:4911-4917, where the caller's own lruTime can keep the loop from
+// ever breaking and the shortlist is the whole table: 69 us per 100k decisions with all of it on one lane).
+constexpr int kLaneSpan = 8;
+
+// first set bit of f(w) at a position in [start, stop); kNoPos if none.  `far` is set when the scan was
+// given up after kLaneSpan words with words still to go (the answer is then unknown).
 template <class F>
-__device__ __forceinline__ int lane_first(F f, int start, int stop)
+__device__ __forceinline__ int lane_first(F f, int start, int stop, bool &far)
 {
     if (start >= stop) return kNoPos;
     const int w0 = start >> 6, wl = (stop - 1) >> 6;
-    for (int w = w0; w <= wl; w++) {
+    const int wstop = wl - w0 >= kLaneSpan ? w0 + kLaneSpan - 1 : wl;
+    for (int w = w0; w <= wstop; w++) {
         uint64_t v = f(w);
         if (w == w0) v &= (~0ull) << (start & 63);
         if (w == wl && (stop & 63)) v &= (1ull << (stop & 63)) - 1ull;
         if (v) return w * 64 + (__ffsll((unsigned long long)v) - 1);
     }
+    if (wstop < wl) far = true;
     return kNoPos;
 }
 
@@ -473,7 +482,12 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
         const int selfpos = r.selfpos;
         const bool favour = (r.flags & MMP_REQ_FAVOUR_SELF) != 0;
 
-        const int best0 = lane_first(ew, 0, P);
+        bool far = false;
+        const int best0 = lane_first(ew, 0, P, far);
+        if (far) {
+            fb = true;
+            break;
+        }
         if (best0 == kNoPos) {
             if (VIEW) return kLaneNoneHere;
             if (S.any_rs) fb = true;  // retry ignoring excludeReplicaSets, MM.java:4797-4804
@@ -497,13 +511,13 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
             }
             // case (a): the first preferred pod, provided no full pod comes before it
             auto ewp = [&](int w) { return L.at(w) & Pm[w]; };
-            const int q1 = lane_first(ewp, best0 + 1, P);
-            if (q1 == kNoPos) {  // none preferred: the replay list ends at the first full pod
+            const int q1 = lane_first(ewp, best0 + 1, P, far);
+            if (q1 == kNoPos) {  // (or given up: `far`)  // none preferred: the replay list ends at the first full pod
                 fb = true;
                 break;
             }
             auto ewf = [&](int w) { return L.at(w) & S.fullw[w]; };
-            if (lane_first(ewf, best0 + 1, q1) != kNoPos) {
+            if (lane_first(ewf, best0 + 1, q1, far) != kNoPos || far) {
                 fb = true;
                 break;
             }
@@ -546,7 +560,7 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
                 if ((selfpos >> 6) == w) v &= ~(1ull << (selfpos & 63));  // the self pod breaks on its own rule
                 return v;
             };
-            const int p1 = lane_first(dns, start, P);
+            const int p1 = lane_first(dns, start, P, far);
             end = p1 < end ? p1 : end;
         }
         if (self_in_d && self_break) end = selfpos < end ? selfpos : end;
@@ -559,8 +573,13 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
             }
             const uint64_t *G = S.ge + (size_t)(T - kGeBase) * W;
             auto dc = [&](int w) { return dw(w) & G[w]; };
-            const int pc = lane_first(dc, start, end);
+            const int pc = lane_first(dc, start, end, far);
             end = pc < end ? pc : end;
+        }
+        // a scan was given up, or the shortlist itself is long: the wave path takes 64 words per step
+        if (far || ((end > start ? end - 1 : bestpos) >> 6) - (bestpos >> 6) >= kLaneSpan) {
+            fb = true;
+            break;
         }
         if (VIEW && S.more_after && end >= P) return kLaneIncomplete;  // the shortlist runs into the next shard
         const bool self_in_c = self_in_d && selfpos < end;

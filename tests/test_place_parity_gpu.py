@@ -417,3 +417,25 @@ def test_concurrent_small_calls_of_every_kind_with_commits_and_table_reloads():
         assert not errors, errors[:5]
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("frac", [1.0, 0.97])
+def test_full_cluster_c3(frac):
+    """The steady state of a mesh is a FULL cluster: getNext is then in its LRU-window mode (MM.java:4911-4917),
+    where the caller's own lruTime (quirk B#2) can keep the loop from ever breaking and the shortlist is the whole
+    table.  Such decisions leave the lane path (kLaneSpan) for the wave path; all of C3 against the oracle."""
+    fleet = wl.make_fleet("C3")
+    rng = np.random.default_rng(5)
+    full = rng.random(fleet.n_pods) < frac
+    fleet.pods["used"] = np.where(full, fleet.pods["capacity"] - rng.integers(0, 40_000, fleet.n_pods), fleet.pods["used"])
+    reqs, extra = wl.make_requests(fleet, 31)
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        got = s.place(reqs, extra, fleet.now)
+    finally:
+        s.close()
+    want = OracleFleet(fleet).place(reqs, extra, fleet.now, threads=16)
+    assert_same_decisions(fleet, reqs, got, want)
+    if frac == 1.0:
+        assert got["n_candidates"].max() > 5000  # whole-table shortlists did occur
