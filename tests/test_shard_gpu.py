@@ -176,3 +176,49 @@ def test_two_processes_gloo_on_one_gpu():
         assert p.exitcode == 0
     res = sorted(q.get(timeout=5) for _ in range(2))
     assert res == [(0, True), (1, True)]
+
+
+@pytest.mark.parametrize("G", [2, 4])
+def test_churn_stream_on_pod_axis_shards(G):
+    """Config C5 on the pod-axis layout: every 2 s slice each shard takes the changed InstanceRecords and
+    ModelRecords (mmp_pods_upsert / mmp_models_upsert), the shards re-commit together (all-reduce of the rank
+    slices) and decide the slice's load targets (speculative exchange + six-phase rest); order, ClusterStats and
+    decisions against the oracle rebuilt from the same evolving fleet."""
+    import torch
+    dev = torch.device("cuda", 0)
+    cs = wl.ChurnStream(wl.fuzz_fleet(44, pods=700, models=1500), 7, events_per_slice=3000)
+    solvers, placers = zip(*[_load_shard(cs.fleet, g, G, dev) for g in range(G)])
+    try:
+        loads = 0
+        for it in range(5):
+            f = cs.fleet
+            if it:
+                ev = cs.model_events()
+                for s in solvers:
+                    s.upsert_pods(cs.changed_pods, f.pods[cs.changed_pods])
+                    s.upsert_models(*ev)
+            mdist.run_lockstep([p.commit_steps() for p in placers])
+            orc = OracleFleet(f)
+            ost = orc.stats()
+            for s in solvers:
+                st = s.stats()
+                for k in ("total_capacity", "total_free", "global_lru", "instance_count", "model_copy_count"):
+                    assert int(st[k]) == int(ost[k]), (it, k)
+            sl = cs.next_slice()
+            reqs, extra = sl["place_reqs"], sl["extra"]
+            n = len(reqs)
+            d_reqs = torch.from_numpy(np.ascontiguousarray(reqs).view(np.uint8).reshape(-1).copy()).to(dev)
+            d_extra = torch.from_numpy(np.zeros(1, np.int32)).to(dev)
+            outs = [torch.zeros(max(n, 1) * 16, dtype=torch.uint8, device=dev) for _ in range(G)]
+            mdist.run_lockstep([p.place_steps(d_reqs, n, d_extra, f.now, o) for p, o in zip(placers, outs)])
+            torch.cuda.synchronize()
+            res = [np.frombuffer(o.cpu().numpy().tobytes(), dtype=PLACE_OUT)[:n] for o in outs]
+            want = orc.place(reqs, extra, f.now, threads=8)
+            for r in res:
+                assert_same_decisions(f, reqs, r, want)
+            loads += int((res[0]["chosen"] != -1).sum())
+            cs.apply(sl, res[0])
+        assert loads > 0
+    finally:
+        for s in solvers:
+            s.close()
