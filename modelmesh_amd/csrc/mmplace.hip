@@ -69,10 +69,10 @@ struct DevBuf {
 
 // device storage of one committed snapshot
 struct SnapBufs {
-    DevBuf pods, lru, rem, cnt, rpm, orig, pos_of, elig, elig_nors, pref, has_pref, fullw, ge;
+    DevBuf pods, lru, rem, cnt, rpm, orig, pos_of, elig, elig_nors, pref, has_pref, fullw, ge, pc, ph;
     void release()
     {
-        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge})
+        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge, &pc, &ph})
             b->release();
     }
 };
@@ -139,6 +139,8 @@ struct mmp_ctx {
     int32_t shard = 0, n_shards = 0;
     ShardSnap ssnap{};
     DevBuf rk_rows, rk_idx, rk_tmp;  // ranking by sorting (snapshot.hpp)
+    int32_t long_mode = -1;  // MMP_LONG_MODE: -1 auto (the long-shortlist kernel for snapshots whose instances are nearly all full), 0 never, 1 always (tests)
+    bool snap_long = false;  // the committed snapshot takes place_batch_long_kernel
     int32_t rank_mode = 0;  // MMP_RANK_MODE: 0 auto (sort from kRankSortMinPods pods), 1 all-pairs, 2 sort whenever legal (tests)
     Snap sview{};  // the lane path's view of this shard's slice (place_shard_fast_kernel)
     DevBuf f_flags, f_offs, f_idx, f_reqs, f_outs, f_scan_tmp;  // speculative form: the compacted rest of a batch
@@ -333,6 +335,8 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     else if (done_flag && n > kPlaceBlock)
         hipLaunchKernelGGL(place_batch_flag_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad,
                            done_blocks);
+    else if (c->snap_long)
+        hipLaunchKernelGGL(place_batch_long_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad);
     else
         hipLaunchKernelGGL(place_batch_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad);
     HIP_TRY(c, hipGetLastError());
@@ -373,6 +377,7 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     c->cfg = *cfg;
     if (const char *fw = getenv("MMP_FORCE_WAVE")) c->force_wave = fw[0] == '1';
     if (const char *rm = getenv("MMP_RANK_MODE")) c->rank_mode = atoi(rm);
+    if (const char *lm = getenv("MMP_LONG_MODE")) c->long_mode = atoi(lm);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete c;
         return fail(nullptr, MMP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
@@ -905,6 +910,8 @@ int mmp_snapshot_commit(mmp_ctx *c)
     HIP_TRY(c, B.has_pref.ensure(T));
     HIP_TRY(c, B.fullw.ensure((size_t)W * 8));
     HIP_TRY(c, B.ge.ensure((size_t)kGeRows * W * 8));
+    HIP_TRY(c, B.pc.ensure((size_t)2 * T * (W + 1) * 4));
+    HIP_TRY(c, B.ph.ensure((size_t)2 * T * (W + 1) * 8));
     HIP_TRY(c, c->rank.ensure(padded * 4));
     HIP_TRY(c, c->occupancy.ensure(padded * 4));
     HIP_TRY(c, c->flag.ensure(sizeof(int32_t)));
@@ -946,10 +953,12 @@ int mmp_snapshot_commit(mmp_ctx *c)
     init.global_lru = INT64_MAX;
     HIP_TRY(c, hipMemcpyAsync(c->stats_acc.p, &init, sizeof init, hipMemcpyHostToDevice, st));
 
+    bool next_long = c->long_mode == 1;
     KT_BEGIN(c, st);
     if (P > 0) {
         // is the literal comparator a strict total order on these rows?  (see snapshot.hpp "ranking by sorting")
         bool versions_differ = false, full_low_lru = false, wide_count = false;
+        int32_t n_present = 0, n_nonfull = 0;
         for (int32_t p = 0; p < P; p++) {
             const mmp_pod_row &r = c->pods[p];
             if (r.version != c->pods[0].version) versions_differ = true;
@@ -957,7 +966,13 @@ int mmp_snapshot_commit(mmp_ctx *c)
             const uint64_t d = (uint64_t)r.capacity - (uint64_t)r.used;
             const int64_t rem = (int64_t)d > 0 ? (int64_t)d : 0;
             if (rem < min_space && r.lru_time <= churn2) full_low_lru = true;
+            if (!(r.flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE))) {
+                n_present++;
+                if (!(rem < min_space)) n_nonfull++;
+            }
         }
+        // (nearly) every instance full: getNext is in its LRU-window mode and whole-table shortlists are common
+        next_long = c->long_mode == 1 || (c->long_mode != 0 && n_present > 0 && n_nonfull * 16 <= n_present);
         // all-pairs is embarrassingly parallel and wins below ~8k pods (measured: 10k pods 172 us all-pairs vs 120 us
         // sort; 50k pods 4.3 ms vs 0.25 ms); a merge sort of a few thousand 64-byte keys is latency bound
         const bool want_sort = c->rank_mode == 2 || (c->rank_mode == 0 && P >= kRankSortMinPods);
@@ -994,10 +1009,14 @@ int mmp_snapshot_commit(mmp_ctx *c)
                            c->d_has_allowed.as<uint8_t>(), c->d_prefer.as<uint64_t>(), B.has_pref.as<uint8_t>(),
                            n_rs ? c->rs_bad.as<uint8_t>() : nullptr, B.elig.as<uint64_t>(),
                            B.elig_nors.as<uint64_t>(), B.pref.as<uint64_t>(), B.fullw.as<uint64_t>());
+        hipLaunchKernelGGL(build_prefix_kernel, dim3(2 * T), dim3(64), 0, st, B.elig.as<uint64_t>(), B.pref.as<uint64_t>(), T, W,
+                           B.pc.as<int32_t>(), B.ph.as<uint64_t>());
         hipLaunchKernelGGL(cluster_stats_kernel, dim3(std::min(div_up(P, 256), 512)), dim3(256), 0, st,
                            B.pods.as<mmp_pod_row>(), P, min_space, c->stats_acc.as<StatsAcc>());
         HIP_TRY(c, hipGetLastError());
     } else {
+        HIP_TRY(c, hipMemsetAsync(B.pc.p, 0, (size_t)2 * T * (W + 1) * 4, st));
+        HIP_TRY(c, hipMemsetAsync(B.ph.p, 0, (size_t)2 * T * (W + 1) * 8, st));
         HIP_TRY(c, hipMemsetAsync(B.elig.p, 0, (size_t)T * W * 8, st));
         HIP_TRY(c, hipMemsetAsync(B.elig_nors.p, 0, (size_t)T * W * 8, st));
         HIP_TRY(c, hipMemsetAsync(B.pref.p, 0, (size_t)T * W * 8, st));
@@ -1038,6 +1057,9 @@ int mmp_snapshot_commit(mmp_ctx *c)
     S.has_pref = B.has_pref.as<uint8_t>();
     S.fullw = B.fullw.as<uint64_t>();
     S.ge = B.ge.as<uint64_t>();
+    S.pc = B.pc.as<int32_t>();
+    S.ph = B.ph.as<uint64_t>();
+    c->snap_long = next_long;
     c->snap = S;
     c->cur = 1 - c->cur;
     c->committed = true;

@@ -454,9 +454,12 @@ __device__ __forceinline__ int lane_first(F f, int start, int stop, bool &far)
 // Outcome of lane_decide.  kLaneWave: the decision left the common shape and needs the general path.
 // The last two only on a shard view (VIEW = true): the view holds no eligible pod for this decision /
 // the view cannot decide it alone (a scan ran off the end of the view, or kLaneWave).
-enum { kLaneDone = 0, kLaneWave = 1, kLaneNoneHere = 2, kLaneIncomplete = 3 };
+// kLaneLong: the shortlist spans more than kLaneSpan words — decided by the LONG instantiation of this same
+// function (a later phase of the kernel), which counts / hashes / selects through the prefix tables of Snap
+// instead of walking the words.
+enum { kLaneDone = 0, kLaneWave = 1, kLaneNoneHere = 2, kLaneIncomplete = 3, kLaneLong = 4 };
 
-template <bool VIEW>
+template <bool VIEW, bool LONG = false>
 __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, int d, mmp_place_out &o)
 {
     const ResolvedReq r = resolve_one<VIEW>(S, A, d);
@@ -576,12 +579,19 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
             const int pc = lane_first(dc, start, end, far);
             end = pc < end ? pc : end;
         }
-        // a scan was given up, or the shortlist itself is long: the wave path takes 64 words per step
-        if (far || ((end > start ? end - 1 : bestpos) >> 6) - (bestpos >> 6) >= kLaneSpan) {
+        if (far) {  // a scan was given up: the wave path takes 64 words per step
             fb = true;
             break;
         }
         if (VIEW && S.more_after && end >= P) return kLaneIncomplete;  // the shortlist runs into the next shard
+        const bool is_long = ((end > start ? end - 1 : bestpos) >> 6) - (bestpos >> 6) >= kLaneSpan;
+        if (is_long && (!LONG || !S.pc)) {
+            if (VIEW || !S.pc) {
+                fb = true;
+                break;
+            }
+            return kLaneLong;
+        }
         const bool self_in_c = self_in_d && selfpos < end;
         if (self_in_c && favour) {  // :4931-4933
             o.chosen = MMP_SELF;
@@ -597,10 +607,52 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
         };
         int ccount = 0;
         uint64_t hsum = 0;
-        for (int w = wlo; w <= whi; w++) {
-            const uint64_t v = cand(w);
-            ccount += __popcll((unsigned long long)v);
-            if (v) hsum += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)((VIEW ? S.w_base : 0) + w + 1)));
+        auto term = [&](uint64_t v, int w) {
+            return v ? splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)((VIEW ? S.w_base : 0) + w + 1))) : 0ull;
+        };
+        // LONG: the words strictly between wlo and whi come from the prefix tables; an exclusion that falls into
+        // one of them (and whose bit is set there) takes one off every count behind it — xmask remembers which
+        // of the <= 8 exclusions those are — and changes that word's hash term
+        const int32_t *PC = nullptr;
+        const uint64_t *PH = nullptr;
+        uint32_t xmask = 0;
+        if (LONG && is_long) {
+            const size_t tb = ((size_t)(has_pm ? 1 : 0) * S.T + type) * (size_t)(W + 1);
+            PC = S.pc + tb;
+            PH = S.ph + tb;
+            auto raw = [&](int w) {
+                uint64_t v = L.E[w];
+                if (has_pm) v &= Pm[w];
+                return v;
+            };
+            const uint64_t c_lo = cand(wlo), c_hi = cand(whi);
+            ccount = __popcll((unsigned long long)c_lo) + __popcll((unsigned long long)c_hi) + (PC[whi] - PC[wlo + 1]);
+            hsum = term(c_lo, wlo) + term(c_hi, whi) + (PH[whi] - PH[wlo + 1]);
+#pragma unroll
+            for (int i = 0; i < kInlineExcl; i++) {
+                const int e = L.ex[i], w = e >> 6;  // -1 >> 6 == -1: never a middle word
+                if (w <= wlo || w >= whi) continue;
+                const uint64_t rv = raw(w);
+                if (!((rv >> (e & 63)) & 1ull)) continue;  // not a candidate anyway
+                bool repeated = false;  // the same pod twice among the exclusions (tried and loaded, say)
+#pragma unroll
+                for (int j = 0; j < kInlineExcl; j++)
+                    if (j < i && L.ex[j] == e) repeated = true;
+                if (repeated) continue;
+                bool first_in_word = true;  // the word's hash term is replaced once, by its first effective exclusion
+#pragma unroll
+                for (int j = 0; j < kInlineExcl; j++)
+                    if (j < i && ((xmask >> j) & 1u) && (L.ex[j] >> 6) == w) first_in_word = false;
+                xmask |= 1u << i;
+                ccount--;
+                if (first_in_word) hsum += term(dw(w), w) - term(rv, w);
+            }
+        } else {
+            for (int w = wlo; w <= whi; w++) {
+                const uint64_t v = cand(w);
+                ccount += __popcll((unsigned long long)v);
+                hsum += term(v, w);
+            }
         }
         int remaining = ccount;
         bool null0 = false, null_s = false, null_o = false;
@@ -620,8 +672,7 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
         int cpos = kNoPos;
         if (remaining >= 1) {
             const int bw = bestpos >> 6, sw = self_in_c ? (selfpos >> 6) : -1;
-            int running = 0;
-            for (int w = wlo; w <= whi; w++) {
+            auto surv = [&](int w) {  // the word's candidates that the rpm filter left in
                 uint64_t v = cand(w);
                 uint64_t special = 0;
                 if (w == bw) special |= 1ull << (bestpos & 63);
@@ -629,12 +680,53 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
                 if (null_o) v &= special;
                 if (null0 && w == bw) v &= ~(1ull << (bestpos & 63));
                 if (null_s && w == sw) v &= ~(1ull << (selfpos & 63));
-                const int c = __popcll((unsigned long long)v);
-                if (index < running + c) {
-                    cpos = w * 64 + select_kth_bit(v, index - running);
-                    break;
+                return v;
+            };
+            if (LONG && is_long) {
+                if (null_o) {  // only the best and the self entry can be left, in that order
+                    int k = index;
+                    if (!null0) {
+                        if (k == 0) cpos = bestpos;
+                        k--;
+                    }
+                    if (cpos == kNoPos && self_in_c && !null_s && k == 0) cpos = selfpos;
+                } else {
+                    const int n_lo = __popcll((unsigned long long)surv(wlo));
+                    // survivors in words [wlo, w), wlo < w <= whi
+                    auto before = [&](int w) {
+                        int c = n_lo + (PC[w] - PC[wlo + 1]);
+#pragma unroll
+                        for (int i = 0; i < kInlineExcl; i++)
+                            if (((xmask >> i) & 1u) && (L.ex[i] >> 6) < w) c--;
+                        if (null_s && sw > wlo && sw < w && sw < whi) c -= 1;
+                        return c;
+                    };
+                    int word = wlo, base = 0;
+                    if (index >= n_lo) {
+                        int lo = wlo + 1, hi = whi;
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (before(mid + 1) > index)
+                                hi = mid;
+                            else
+                                lo = mid + 1;
+                        }
+                        word = lo;
+                        base = before(word);
+                    }
+                    cpos = word * 64 + select_kth_bit(surv(word), index - base);
                 }
-                running += c;
+            } else {
+                int running = 0;
+                for (int w = wlo; w <= whi; w++) {
+                    const uint64_t v = surv(w);
+                    const int c = __popcll((unsigned long long)v);
+                    if (index < running + c) {
+                        cpos = w * 64 + select_kth_bit(v, index - running);
+                        break;
+                    }
+                    running += c;
+                }
             }
         }
         o.best = best_idx;
@@ -923,22 +1015,45 @@ __device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int
 // leave the common shape are collected in LDS and then taken one wavefront at a time by the general
 // path (place_one) inside the same launch.  LDS: kPlaceWaves × 2 bitmaps × wpad words for that path.
 constexpr int kPlaceBlock = kPlaceWaves * 64;
+// WITH_LONG: the kernel carries the phase that decides whole-table shortlists on single lanes through the
+// prefix tables (lane_decide<…, LONG>).  That phase needs 108 VGPRs against 94 (4 instead of 5 wavefronts per
+// SIMD: -5 % on a lone 100k launch, -14 % saturated), so it is compiled into a kernel of its own which the host
+// launches only for snapshots in which (nearly) every instance is full — the only regime that produces such
+// shortlists in number; otherwise they take the wave path.
+template <bool WITH_LONG>
 __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, int32_t wpad, unsigned char *smem,
                                             uint32_t *done_blocks = nullptr)
 {
-    __shared__ int32_t fb_list[kPlaceBlock];
-    __shared__ int32_t fb_n;
-    if (threadIdx.x == 0) fb_n = 0;
+    __shared__ int32_t fb_list[kPlaceBlock], lr_list[kPlaceBlock];
+    __shared__ int32_t fb_n, lr_n;
+    if (threadIdx.x == 0) fb_n = lr_n = 0;
     __syncthreads();
     const int d = blockIdx.x * kPlaceBlock + threadIdx.x;
     if (d < A.n) {
         mmp_place_out o;
-        if (lane_decide<false>(S, A, d, o) != kLaneDone)
+        const int code = lane_decide<false>(S, A, d, o);
+        if (WITH_LONG && code == kLaneLong)
+            lr_list[atomicAdd(&lr_n, 1)] = d;
+        else if (code != kLaneDone)
             fb_list[atomicAdd(&fb_n, 1)] = d;
         else
             A.outs[d] = o;
     }
     __syncthreads();
+    // the decisions whose shortlist spans many words: again one lane each, this time through the prefix tables
+    // (a phase of its own so that its registers do not count against the common path above)
+    if (WITH_LONG && lr_n != 0) {
+        const int nlr = lr_n;
+        if ((int)threadIdx.x < nlr) {
+            const int ld = lr_list[threadIdx.x];
+            mmp_place_out o;
+            if (lane_decide<false, true>(S, A, ld, o) != kLaneDone)
+                fb_list[atomicAdd(&fb_n, 1)] = ld;
+            else
+                A.outs[ld] = o;
+        }
+        __syncthreads();
+    }
     const int nfb = fb_n;
     if (nfb != 0) {
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -956,7 +1071,14 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
 __global__ __launch_bounds__(kPlaceBlock) void place_batch_kernel(Snap S, PlaceArgs A, int32_t wpad)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    place_block(S, A, wpad, smem);
+    place_block<false>(S, A, wpad, smem);
+}
+
+// the same with the long-shortlist phase (see place_block)
+__global__ __launch_bounds__(kPlaceBlock) void place_batch_long_kernel(Snap S, PlaceArgs A, int32_t wpad)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    place_block<true>(S, A, wpad, smem);
 }
 
 // The latency path's launches of more than one workgroup: done_blocks = device counter of finished
@@ -966,7 +1088,7 @@ __global__ __launch_bounds__(kPlaceBlock) void place_batch_kernel(Snap S, PlaceA
 __global__ __launch_bounds__(kPlaceBlock) void place_batch_flag_kernel(Snap S, PlaceArgs A, int32_t wpad, uint32_t *done_blocks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    place_block(S, A, wpad, smem, done_blocks);
+    place_block<false>(S, A, wpad, smem, done_blocks);
 }
 
 // One decision whose request rides in the kernel arguments (the latency path's n = 1 call without extra
@@ -979,7 +1101,7 @@ __global__ __launch_bounds__(kPlaceBlock) void place_single_kernel(Snap S, Place
     __syncthreads();
     A.reqs = &srq;
     A.n = 1;
-    place_block(S, A, wpad, smem);
+    place_block<false>(S, A, wpad, smem);
 }
 
 }  // namespace mmp

@@ -40,6 +40,12 @@ struct Snap {
     int32_t pos_base;    // global position of local position 0
     int32_t w_base;      // global word of local word 0
     int32_t more_after;  // positions beyond this view exist (the view is not the tail of the order)
+    // Prefix tables over the words of every type's candidate bitmap, [2][T][W+1] (variant 0: elig, variant 1:
+    // elig & pref): pc[w] = set bits in words [0, w), ph[w] = sum of the audit-hash terms of words [0, w).
+    // They let one lane count / hash / select in a shortlist that spans the table (place_kernel.hpp,
+    // lane_decide<…, LONG>).  Null on shard views.
+    const int32_t *pc;
+    const uint64_t *ph;
 };
 
 // count >= 10 is a fixed clause of the shortlist's count break (MM.java:4925-4926); the other clause,
@@ -390,6 +396,45 @@ __global__ void subset_stats_finish_kernel(const StatsAcc *__restrict__ global, 
             t.global_lru = t.instance_count > 0 ? global->global_lru : INT64_MAX;
         }
         tstats[i] = t;
+    }
+}
+
+// pc / ph of Snap: one wavefront per (variant, type row), 64 words per step
+__global__ __launch_bounds__(64) void build_prefix_kernel(const uint64_t *__restrict__ elig, const uint64_t *__restrict__ pref,
+                                                          int32_t T, int32_t W, int32_t *__restrict__ pc,
+                                                          uint64_t *__restrict__ ph)
+{
+    const int v = blockIdx.x / T, t = blockIdx.x - v * T, lane = threadIdx.x;
+    const uint64_t *E = elig + (size_t)t * W, *Pm = pref + (size_t)t * W;
+    int32_t *PC = pc + ((size_t)v * T + t) * (W + 1);
+    uint64_t *PH = ph + ((size_t)v * T + t) * (W + 1);
+    int32_t carry_c = 0;
+    uint64_t carry_h = 0;
+    if (lane == 0) {
+        PC[0] = 0;
+        PH[0] = 0;
+    }
+    for (int base = 0; base < W; base += 64) {
+        const int w = base + lane;
+        uint64_t word = 0;
+        if (w < W) word = v ? (E[w] & Pm[w]) : E[w];
+        int32_t c = __popcll((unsigned long long)word);
+        uint64_t h = word ? splitmix64(word ^ (0x9E3779B97F4A7C15ull * (uint64_t)(w + 1))) : 0ull;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {  // inclusive scans across the wavefront
+            const int32_t tc = __shfl_up(c, o, 64);
+            const uint64_t th = shfl_u64(h, lane >= o ? lane - o : lane);
+            if (lane >= o) {
+                c += tc;
+                h += th;
+            }
+        }
+        if (w < W) {
+            PC[w + 1] = carry_c + c;
+            PH[w + 1] = carry_h + h;
+        }
+        carry_c += readlane_i32(c, 63);
+        carry_h += readlane_u64(h, 63);
     }
 }
 

@@ -419,6 +419,31 @@ def test_concurrent_small_calls_of_every_kind_with_commits_and_table_reloads():
         s.close()
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_long_shortlists_by_prefix_tables(seed, monkeypatch):
+    """MMP_LONG_MODE=1 makes every snapshot take place_batch_long_kernel, whose extra phase decides shortlists
+    that span more than kLaneSpan words on a single lane through the per-type prefix tables (count, audit hash,
+    index-th survivor by binary search) — fleets of full instances with close lruTimes, exclusions falling into
+    the middle of the range, preferences, self entries; 0 sends the same decisions to the wave path."""
+    rng = np.random.default_rng(7700 + seed)
+    pods = int(rng.choice([1500, 3000, 5000]))
+    fleet = wl.fuzz_fleet(seed + 700, pods=pods, models=400, profile="full" if seed % 2 else None)
+    fleet.pods["used"] = fleet.pods["capacity"] - rng.integers(0, 2000, pods)   # every instance full
+    fleet.pods["lru_time"] = fleet.now - 36_000_000 - rng.integers(0, 1_000_000, pods)  # and about equally old
+    reqs, extra = wl.fuzz_requests(fleet, seed, 3000)
+    reqs["fresh_lru"] = fleet.now - 36_000_000 - rng.integers(0, 1_000_000, len(reqs))
+    want = OracleFleet(fleet).place(reqs, extra, fleet.now, threads=8)
+    assert want["n_candidates"].max() > 512
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MMP_LONG_MODE", mode)
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            s.load_fleet(fleet)
+            assert_same_decisions(fleet, reqs, s.place(reqs, extra, fleet.now), want)
+        finally:
+            s.close()
+
+
 @pytest.mark.parametrize("frac", [1.0, 0.97])
 def test_full_cluster_c3(frac):
     """The steady state of a mesh is a FULL cluster: getNext is then in its LRU-window mode (MM.java:4911-4917),

@@ -16,10 +16,13 @@ from modelmesh_amd.solver import Solver  # noqa: E402
 from oracle.bind import OracleFleet  # noqa: E402
 
 frac = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+spread = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0  # > 0: every cache is about equally old (age 10 h +- spread)
 fleet = wl.make_fleet("C3")
 rng = np.random.default_rng(5)
 full = rng.random(fleet.n_pods) < frac
 fleet.pods["used"] = np.where(full, fleet.pods["capacity"] - rng.integers(0, 40_000, fleet.n_pods), fleet.pods["used"])
+if spread > 0:  # the steady state under global LRU eviction: all caches have about the same age
+    fleet.pods["lru_time"] = fleet.now - (36_000_000 * (1 + rng.uniform(-spread, spread, fleet.n_pods))).astype(np.int64)
 reqs, extra = wl.make_requests(fleet, seed=0xBE7C0)
 s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
 s.load_fleet(fleet)
@@ -43,6 +46,10 @@ dt = (time.perf_counter() - t0) / 50
 got = np.frombuffer(d_outs.cpu().numpy().tobytes(), dtype=PLACE_OUT)
 want = OracleFleet(fleet).place(reqs, extra, fleet.now, threads=os.cpu_count())
 ok = all(np.array_equal(got[f], want[f]) for f in ("chosen", "best", "n_candidates", "hash"))
-print(f"full fraction {frac}: {dt * 1e6:.1f} us per 100k decisions, mean shortlist {got['n_candidates'].mean():.1f}, "
+if not ok:
+    for f in ("chosen", "best", "n_candidates", "hash"):
+        bad = np.nonzero(got[f] != want[f])[0]
+        print(f, len(bad), bad[:5], got[f][bad[:5]], want[f][bad[:5]])
+print(f"full fraction {frac} spread {spread}: {dt * 1e6:.1f} us per 100k decisions, mean shortlist {got['n_candidates'].mean():.1f}, "
       f"max {got['n_candidates'].max()}, parity {ok}")
 s.close()
