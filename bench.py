@@ -196,6 +196,47 @@ def churn_pod_axis_leg(workload: str, rank: int, world: int, dev, fence, slices:
             "ms_per_slice": busy / slices * 1e3, "required_events_per_s": 10_000, "headroom_x": n_ev / busy / 10_000}
 
 
+def full_cluster_leg(workload: str, device: int, dev):
+    """The same batch on the steady state of a mesh: EVERY instance full and all caches about equally old (global
+    LRU eviction) — getNext is then in its LRU-window mode (MM.java:4911-4917) and most shortlists are the whole
+    table.  The library picks place_batch_long_kernel for such a snapshot."""
+    import torch
+
+    from modelmesh_amd import workload as wl
+    from modelmesh_amd._lib import PLACE_OUT
+    from modelmesh_amd.solver import Solver
+    from oracle.bind import OracleFleet
+    fleet = wl.make_fleet(workload)
+    rng = np.random.default_rng(5)
+    P = fleet.n_pods
+    fleet.pods["used"] = fleet.pods["capacity"] - rng.integers(0, 40_000, P)
+    fleet.pods["lru_time"] = fleet.now - (36_000_000 * (1 + rng.uniform(-0.04, 0.04, P))).astype(np.int64)
+    reqs, extra = wl.make_requests(fleet, seed=0xBE7C0)
+    n = len(reqs)
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms, device=device)
+    try:
+        s.load_fleet(fleet)
+        d_reqs = torch.from_numpy(reqs.view(np.uint8).reshape(-1)).to(dev)
+        d_extra = torch.from_numpy(np.ascontiguousarray(extra if len(extra) else np.zeros(1, np.int32))).to(dev)
+        d_outs = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+        st = torch.cuda.Stream(dev)
+        for _ in range(3):
+            s.place_dev(d_reqs.data_ptr(), n, d_extra.data_ptr(), fleet.now, d_outs.data_ptr(), st.cuda_stream)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            s.place_dev(d_reqs.data_ptr(), n, d_extra.data_ptr(), fleet.now, d_outs.data_ptr(), st.cuda_stream)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / 20
+        got = np.frombuffer(d_outs.cpu().numpy().tobytes(), dtype=PLACE_OUT)
+    finally:
+        s.close()
+    want = OracleFleet(fleet).place(reqs, extra, fleet.now, threads=os.cpu_count() or 1)
+    parity = bool(all(np.array_equal(got[f], want[f]) for f in ("chosen", "best", "n_candidates", "hash")))
+    return {"workload": f"{workload} with every instance full, lruTimes within +-4 % of 10 h", "value": n / dt, "unit": "decisions/s",
+            "ms_per_step": dt * 1e3, "mean_shortlist": float(got["n_candidates"].mean()), "parity_vs_oracle": parity}
+
+
 def churn_leg(fleet, solver, slices: int = 8, events: int = 20_000):
     """Config C5 on this rank's solver: per 2 s slice of simulated time apply the changed InstanceRecords and
     the changed ModelRecords (mmp_pods_upsert / mmp_models_upsert), re-rank on the device, decide the slice's load targets and evaluate its
@@ -635,6 +676,11 @@ def main():
                 line["churn"] = churn_leg(fleet, solver)
             except Exception as e:
                 line["churn"] = {"error": f"{type(e).__name__}: {e}"}
+        if not args.kernel_only:
+            try:
+                line["full_cluster"] = full_cluster_leg(args.workload, local_rank, dev)
+            except Exception as e:
+                line["full_cluster"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.kernel_only and not args.no_secondary:
             try:
                 line["kernels"] = secondary_kernels_leg(fleet, solver, local_rank, args.workload)
