@@ -23,6 +23,8 @@ full = rng.random(fleet.n_pods) < frac
 fleet.pods["used"] = np.where(full, fleet.pods["capacity"] - rng.integers(0, 40_000, fleet.n_pods), fleet.pods["used"])
 if spread > 0:  # the steady state under global LRU eviction: all caches have about the same age
     fleet.pods["lru_time"] = fleet.now - (36_000_000 * (1 + rng.uniform(-spread, spread, fleet.n_pods))).astype(np.int64)
+if os.environ.get("NO_PREF") == "1":
+    fleet.has_prefer[:] = 0  # no preferred instances: no case (b)
 reqs, extra = wl.make_requests(fleet, seed=0xBE7C0)
 s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
 s.load_fleet(fleet)
