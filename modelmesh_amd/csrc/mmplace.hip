@@ -69,10 +69,10 @@ struct DevBuf {
 
 // device storage of one committed snapshot
 struct SnapBufs {
-    DevBuf pods, lru, rem, cnt, rpm, orig, pos_of, elig, elig_nors, pref, has_pref, fullw, ge, pc, ph;
+    DevBuf pods, lru, rem, cnt, rpm, orig, pos_of, elig, elig_nors, pref, has_pref, fullw, ge, pc, ph, nz;
     void release()
     {
-        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge, &pc, &ph})
+        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge, &pc, &ph, &nz})
             b->release();
     }
 };
@@ -911,6 +911,7 @@ int mmp_snapshot_commit(mmp_ctx *c)
     HIP_TRY(c, B.fullw.ensure((size_t)W * 8));
     HIP_TRY(c, B.ge.ensure((size_t)kGeRows * W * 8));
     HIP_TRY(c, B.pc.ensure((size_t)2 * T * (W + 1) * 4));
+    HIP_TRY(c, B.nz.ensure((size_t)2 * T * (W + 1) * 4));
     HIP_TRY(c, B.ph.ensure((size_t)2 * T * (W + 1) * 8));
     HIP_TRY(c, c->rank.ensure(padded * 4));
     HIP_TRY(c, c->occupancy.ensure(padded * 4));
@@ -1010,12 +1011,13 @@ int mmp_snapshot_commit(mmp_ctx *c)
                            n_rs ? c->rs_bad.as<uint8_t>() : nullptr, B.elig.as<uint64_t>(),
                            B.elig_nors.as<uint64_t>(), B.pref.as<uint64_t>(), B.fullw.as<uint64_t>());
         hipLaunchKernelGGL(build_prefix_kernel, dim3(2 * T), dim3(64), 0, st, B.elig.as<uint64_t>(), B.pref.as<uint64_t>(), T, W,
-                           B.pc.as<int32_t>(), B.ph.as<uint64_t>());
+                           B.pc.as<int32_t>(), B.ph.as<uint64_t>(), B.nz.as<int32_t>(), c->stats_acc.as<StatsAcc>());
         hipLaunchKernelGGL(cluster_stats_kernel, dim3(std::min(div_up(P, 256), 512)), dim3(256), 0, st,
                            B.pods.as<mmp_pod_row>(), P, min_space, c->stats_acc.as<StatsAcc>());
         HIP_TRY(c, hipGetLastError());
     } else {
         HIP_TRY(c, hipMemsetAsync(B.pc.p, 0, (size_t)2 * T * (W + 1) * 4, st));
+        HIP_TRY(c, hipMemsetAsync(B.nz.p, 0, (size_t)2 * T * (W + 1) * 4, st));
         HIP_TRY(c, hipMemsetAsync(B.ph.p, 0, (size_t)2 * T * (W + 1) * 8, st));
         HIP_TRY(c, hipMemsetAsync(B.elig.p, 0, (size_t)T * W * 8, st));
         HIP_TRY(c, hipMemsetAsync(B.elig_nors.p, 0, (size_t)T * W * 8, st));
@@ -1058,7 +1060,11 @@ int mmp_snapshot_commit(mmp_ctx *c)
     S.fullw = B.fullw.as<uint64_t>();
     S.ge = B.ge.as<uint64_t>();
     S.pc = B.pc.as<int32_t>();
+    S.nz = B.nz.as<int32_t>();
     S.ph = B.ph.as<uint64_t>();
+    // a type only a few instances may host: its first candidate is usually beyond a lane scan's reach, and only the
+    // long variant carries the prefix-table jump that finds it without the wave path
+    if (c->long_mode < 0 && acc.sparse_types) next_long = true;
     c->snap_long = next_long;
     c->snap = S;
     c->cur = 1 - c->cur;

@@ -432,14 +432,38 @@ struct LaneWords {
 // is full — the LRU-window mode of MM.java:4911-4917, where the caller's own lruTime can keep the loop from
 // ever breaking and the shortlist is the whole table: 69 us per 100k decisions with all of it on one lane).
 constexpr int kLaneSpan = 8;
+constexpr int kFarWords = 24;  // non-empty words a two-condition scan visits through the prefix table before giving up
 
 // first set bit of f(w) at a position in [start, stop); kNoPos if none.  `far` is set when the scan was
 // given up after kLaneSpan words with words still to go (the answer is then unknown).
+// `nz_all` (may be null) + `row`: the next-non-empty-word row (Snap::nz) of the bitmap that f() is a subset of (f =
+// that bitmap minus the request's exclusions / the self bit).  With it the scan visits only the bitmap's non-empty
+// words (a type that only a handful of instances may host has its first eligible pod anywhere in the order):
+// kLaneSpan of them plus `tries` — an exclusion can empty a visited word at most kInlineExcl + 1 times; a scan for
+// bits that ALSO pass a second test (count threshold, fullness) is given kFarWords.
 template <class F>
-__device__ __forceinline__ int lane_first(F f, int start, int stop, bool &far)
+__device__ __forceinline__ int lane_first(F f, int start, int stop, bool &far, const int32_t *nz_all = nullptr,
+                                          size_t row = 0, int tries = kInlineExcl + 2)
 {
     if (start >= stop) return kNoPos;
     const int w0 = start >> 6, wl = (stop - 1) >> 6;
+    if (nz_all) {
+        // the word itself and the index of the next non-empty one behind it are fetched together: one load
+        // latency per visited word, and the empty stretches cost nothing
+        const int32_t *nz = nz_all + row;
+        int w = w0;
+        for (int budget = kLaneSpan + tries; budget > 0 && w <= wl; budget--) {
+            uint64_t v = f(w);
+            const int nxt = nz[w + 1];
+            if (w == w0) v &= (~0ull) << (start & 63);
+            if (w == wl && (stop & 63)) v &= (1ull << (stop & 63)) - 1ull;
+            if (v) return w * 64 + (__ffsll((unsigned long long)v) - 1);
+            w = nxt;
+        }
+        if (w > wl) return kNoPos;
+        far = true;
+        return kNoPos;
+    }
     const int wstop = wl - w0 >= kLaneSpan ? w0 + kLaneSpan - 1 : wl;
     for (int w = w0; w <= wstop; w++) {
         uint64_t v = f(w);
@@ -447,7 +471,8 @@ __device__ __forceinline__ int lane_first(F f, int start, int stop, bool &far)
         if (w == wl && (stop & 63)) v &= (1ull << (stop & 63)) - 1ull;
         if (v) return w * 64 + (__ffsll((unsigned long long)v) - 1);
     }
-    if (wstop < wl) far = true;
+    if (wstop == wl) return kNoPos;
+    far = true;
     return kNoPos;
 }
 
@@ -458,6 +483,8 @@ __device__ __forceinline__ int lane_first(F f, int start, int stop, bool &far)
 // function (a later phase of the kernel), which counts / hashes / selects through the prefix tables of Snap
 // instead of walking the words.
 enum { kLaneDone = 0, kLaneWave = 1, kLaneNoneHere = 2, kLaneIncomplete = 3, kLaneLong = 4 };
+// (a scan given up after kLaneSpan words also reports kLaneLong when the snapshot has prefix tables: the LONG
+// instantiation's scans jump through them)
 
 template <bool VIEW, bool LONG = false>
 __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, int d, mmp_place_out &o)
@@ -467,7 +494,7 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
     o.best = -1;
     o.n_candidates = 0;
     o.hash = 0;
-    bool fb = false;
+    bool fb = false, far = false;
     const int P = S.P, W = S.W;
     do {
         if (r.type < 0) break;  // unknown model -> null
@@ -485,8 +512,9 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
         const int selfpos = r.selfpos;
         const bool favour = (r.flags & MMP_REQ_FAVOUR_SELF) != 0;
 
-        bool far = false;
-        const int best0 = lane_first(ew, 0, P, far);
+        // this type's rows in the [2][T][W+1] tables of its two candidate bitmaps (null on shard views)
+        const size_t pc_e = (size_t)type * (size_t)(W + 1), pc_ep = ((size_t)S.T + type) * (size_t)(W + 1);
+        const int best0 = lane_first(ew, 0, P, far, LONG ? S.nz : nullptr, pc_e);
         if (far) {
             fb = true;
             break;
@@ -514,13 +542,13 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
             }
             // case (a): the first preferred pod, provided no full pod comes before it
             auto ewp = [&](int w) { return L.at(w) & Pm[w]; };
-            const int q1 = lane_first(ewp, best0 + 1, P, far);
+            const int q1 = lane_first(ewp, best0 + 1, P, far, LONG ? S.nz : nullptr, pc_ep);
             if (q1 == kNoPos) {  // (or given up: `far`)  // none preferred: the replay list ends at the first full pod
                 fb = true;
                 break;
             }
             auto ewf = [&](int w) { return L.at(w) & S.fullw[w]; };
-            if (lane_first(ewf, best0 + 1, q1, far) != kNoPos || far) {
+            if (lane_first(ewf, best0 + 1, q1, far, LONG ? S.nz : nullptr, pc_e, kFarWords) != kNoPos || far) {
                 fb = true;
                 break;
             }
@@ -563,7 +591,7 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
                 if ((selfpos >> 6) == w) v &= ~(1ull << (selfpos & 63));  // the self pod breaks on its own rule
                 return v;
             };
-            const int p1 = lane_first(dns, start, P, far);
+            const int p1 = lane_first(dns, start, P, far, LONG ? S.nz : nullptr, has_pm ? pc_ep : pc_e);
             end = p1 < end ? p1 : end;
         }
         if (self_in_d && self_break) end = selfpos < end ? selfpos : end;
@@ -576,7 +604,7 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
             }
             const uint64_t *G = S.ge + (size_t)(T - kGeBase) * W;
             auto dc = [&](int w) { return dw(w) & G[w]; };
-            const int pc = lane_first(dc, start, end, far);
+            const int pc = lane_first(dc, start, end, far, LONG ? S.nz : nullptr, has_pm ? pc_ep : pc_e, kFarWords);
             end = pc < end ? pc : end;
         }
         if (far) {  // a scan was given up: the wave path takes 64 words per step
@@ -737,7 +765,7 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
             if (!favour && cpos == selfpos) o.chosen = MMP_SELF;  // :4989-4991
         }
     } while (false);
-    return fb ? (VIEW ? kLaneIncomplete : kLaneWave) : kLaneDone;
+    return fb ? (VIEW ? kLaneIncomplete : (far && !LONG && S.pc ? kLaneLong : kLaneWave)) : kLaneDone;
 }
 
 __device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int d, uint64_t *ew, uint64_t *fw)

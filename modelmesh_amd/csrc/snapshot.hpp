@@ -44,8 +44,11 @@ struct Snap {
     // elig & pref): pc[w] = set bits in words [0, w), ph[w] = sum of the audit-hash terms of words [0, w).
     // They let one lane count / hash / select in a shortlist that spans the table (place_kernel.hpp,
     // lane_decide<…, LONG>).  Null on shard views.
+    // nz[w] = first word index >= w with a bit set (W if none; nz[W] = W): a scan steps over the empty stretches
+    // of a type that few instances may host with one load.
     const int32_t *pc;
     const uint64_t *ph;
+    const int32_t *nz;
 };
 
 // count >= 10 is a fixed clause of the shortlist's count break (MM.java:4925-4926); the other clause,
@@ -283,6 +286,7 @@ struct StatsAcc {
     unsigned long long total_capacity, total_free;
     long long global_lru;
     int32_t instance_count, model_copy_count;
+    int32_t sparse_types;  // set by build_prefix_kernel: some type's eligible instances lie further apart than a lane scan reaches
 };
 
 __global__ void cluster_stats_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int64_t min_space,
@@ -402,7 +406,8 @@ __global__ void subset_stats_finish_kernel(const StatsAcc *__restrict__ global, 
 // pc / ph of Snap: one wavefront per (variant, type row), 64 words per step
 __global__ __launch_bounds__(64) void build_prefix_kernel(const uint64_t *__restrict__ elig, const uint64_t *__restrict__ pref,
                                                           int32_t T, int32_t W, int32_t *__restrict__ pc,
-                                                          uint64_t *__restrict__ ph)
+                                                          uint64_t *__restrict__ ph, int32_t *__restrict__ nz,
+                                                          StatsAcc *__restrict__ acc)
 {
     const int v = blockIdx.x / T, t = blockIdx.x - v * T, lane = threadIdx.x;
     const uint64_t *E = elig + (size_t)t * W, *Pm = pref + (size_t)t * W;
@@ -435,6 +440,26 @@ __global__ __launch_bounds__(64) void build_prefix_kernel(const uint64_t *__rest
         }
         carry_c += readlane_i32(c, 63);
         carry_h += readlane_u64(h, 63);
+    }
+    // fewer candidates than words: a lane scan of kLaneSpan words sees only a few of them (or none)
+    if (v == 0 && lane == 0 && carry_c > 0 && carry_c < W) atomicOr(&acc->sparse_types, 1);
+    // nz: the same words back to front, a suffix minimum of the indices of the non-empty ones
+    int32_t *NZ = nz + ((size_t)v * T + t) * (W + 1);
+    if (lane == 0) NZ[W] = W;
+    int32_t carry_n = W;
+    for (int base = ((W - 1) / 64) * 64; base >= 0; base -= 64) {
+        const int w = base + lane;
+        uint64_t word = 0;
+        if (w < W) word = v ? (E[w] & Pm[w]) : E[w];
+        int32_t m = word ? w : W;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t tm = __shfl_down(m, o, 64);
+            if (lane + o < 64 && tm < m) m = tm;
+        }
+        if (carry_n < m) m = carry_n;
+        if (w < W) NZ[w] = m;
+        carry_n = readlane_i32(m, 0);
     }
 }
 

@@ -464,3 +464,37 @@ def test_full_cluster_c3(frac):
     assert_same_decisions(fleet, reqs, got, want)
     if frac == 1.0:
         assert got["n_candidates"].max() > 5000  # whole-table shortlists did occur
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_types_only_a_few_instances_may_host(seed, monkeypatch):
+    """A type whose label requirement a handful of instances in thousands satisfy (UpgradeTracker / TypeConstraintManager
+    candidate sets, MM.java:4889-4897 filters on them): the first eligible instance lies anywhere in the placement order,
+    beyond a lane scan's kLaneSpan words.  commit() then picks the long kernel variant (StatsAcc.sparse_types), whose
+    scans step from one non-empty word to the next through Snap::nz; MMP_LONG_MODE=0 sends the same decisions to the wave path."""
+    rng = np.random.default_rng(9100 + seed)
+    pods = int(rng.choice([3000, 6000, 10_000]))
+    fleet = wl.fuzz_fleet(seed + 900, pods=pods, models=400)
+    T = max(fleet.n_types, 4)
+    al = rng.random((T, pods)) < np.array([1.0, 0.002, 0.0007, 0.3] + [0.001] * (T - 4))[:, None]
+    al[2, :] = False
+    al[2, rng.choice(pods, 3, replace=False)] = True
+    pf = rng.random((T, pods)) < 0.5
+    fleet.n_types = T
+    fleet.allowed, fleet.prefer = wl.bitmap_from_bool(al), wl.bitmap_from_bool(pf)
+    fleet.has_allowed = np.array([0, 1, 1, 1] + [1] * (T - 4), np.uint8)
+    fleet.has_prefer = np.array([0, 0, 1, 0] + [seed % 2] * (T - 4), np.uint8)
+    fleet.models["type"] = rng.integers(0, T, fleet.n_models)
+    reqs, extra = wl.fuzz_requests(fleet, seed, 4000)
+    want = OracleFleet(fleet).place(reqs, extra, fleet.now, threads=8)
+    for mode in (None, "0", "1"):
+        if mode is None:
+            monkeypatch.delenv("MMP_LONG_MODE", raising=False)
+        else:
+            monkeypatch.setenv("MMP_LONG_MODE", mode)
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            s.load_fleet(fleet)
+            assert_same_decisions(fleet, reqs, s.place(reqs, extra, fleet.now), want)
+        finally:
+            s.close()
