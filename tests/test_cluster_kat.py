@@ -1,0 +1,122 @@
+"""The reference's CLUSTER tests of the hot path (ModelMeshEvictionsTest.java :292-310, :323-358, :371-409),
+replayed through the CPU oracle by tests/minimesh.py: three DummyModelMesh instances, every addModel is one
+load-target decision + guards + loadLocal + evictions + republished records.  These pin the oracle's
+getNext / PLACEMENT_ORDER / clhm restatements TOGETHER to assertions the reference itself makes; the
+GPU twin (test_cluster_kat_gpu.py) runs the device in lock step with the oracle."""
+import pytest
+
+from tests.minimesh import MiniMesh, OracleBackend
+
+CLUSTER = 3                                   # ModelMeshEvictionsTest.java:558
+FIT = int(0.9 * (10 * CLUSTER))               # maxModelsWithoutEviction, :331-333  (= 27)
+
+
+def multi_load_cluster(backends, seed):
+    """:292-310 — 9 models into a 3-instance cluster: all stay loaded, nothing is evicted."""
+    mesh = MiniMesh(CLUSTER, backends, seed)
+    try:
+        for _ in range(9):
+            mesh.add_model()
+        assert mesh.loaded() == list(range(9))
+        assert all(not ev for *_, ev in mesh.trace)
+        # the decisions spread the copies: no instance took more than its share + the shortlist slack
+        per_pod = [sum(1 for c in mesh.copies if p in c) for p in range(CLUSTER)]
+        assert sum(per_pod) == 9 and max(per_pod) <= 9
+        return mesh.trace
+    finally:
+        mesh.close()
+
+
+def multi_load_with_eviction_cluster(backends, seed):
+    """:323-358 — 27 + 3 models; wiggle room 2 x clusterSize: ids[3 + 6 ..] must still be loaded."""
+    mesh = MiniMesh(CLUSTER, backends, seed)
+    try:
+        n = FIT + 3
+        for _ in range(n):
+            mesh.add_model()
+        start = min(n - 1, (n - FIT) + 2 * CLUSTER)          # getIdListOfModelsWhichShouldBeLoaded, :695-702
+        loaded = set(mesh.loaded())
+        assert set(range(start, n)) <= loaded, sorted(set(range(start, n)) - loaded)
+        assert all(len(c) <= 1 for c in mesh.copies)
+        return mesh.trace
+    finally:
+        mesh.close()
+
+
+def multi_load_with_eviction_cluster_reuse(backends, seed):
+    """:371-409 — fill with 27, use the first five, add three: the three new and the five used are loaded."""
+    mesh = MiniMesh(CLUSTER, backends, seed)
+    try:
+        for _ in range(FIT):
+            mesh.add_model()
+        assert mesh.loaded() == list(range(FIT))              # verifyMultiLoadState after the fill, :389
+        for m in range(5):
+            mesh.use_model(m)
+        for _ in range(3):
+            mesh.add_model()
+        loaded = set(mesh.loaded())
+        assert set(range(FIT, FIT + 3)) <= loaded
+        assert set(range(5)) <= loaded, sorted(set(range(5)) - loaded)
+        return mesh.trace
+    finally:
+        mesh.close()
+
+
+SCENARIOS = [multi_load_cluster, multi_load_with_eviction_cluster, multi_load_with_eviction_cluster_reuse]
+
+
+@pytest.mark.parametrize("scenario", SCENARIOS, ids=lambda f: f.__name__)
+@pytest.mark.parametrize("seed", range(12))
+def test_cluster_kat_oracle(scenario, seed):
+    """The reference's assertions, with the client's balancer spreading the addModel calls round-robin
+    over the instances (litelinks' default for the test's clusterClient)."""
+    scenario([OracleBackend], seed)
+
+
+def skewed_ingress(backends, seed, ingress):
+    """The same loop when the client's requests do NOT arrive evenly ("random", or "single": everything
+    enters through instance 0).  The reference's cluster assertions are not claims about this case, and
+    getNext's curInst substitution (MM.java:4909, SURVEY Appendix B#2: the self entry is judged by the BEST
+    entry's record) shows here: a full ingress instance that follows a non-full best in the order elects
+    itself (favourSelf, :4931-4933) and evicts while another instance still has room.  What must hold is
+    consistency: at most one copy per model, registry == cache contents, and every backend in lock step."""
+    mesh = MiniMesh(CLUSTER, backends, seed, ingress=ingress)
+    try:
+        for _ in range(FIT + 6):
+            mesh.add_model()
+        assert all(len(c) <= 1 for c in mesh.copies)
+        for p in range(CLUSTER):
+            assert mesh.backends[0].cache_keys(p) == sorted(m for m, c in enumerate(mesh.copies) if p in c)
+        return mesh.trace
+    finally:
+        mesh.close()
+
+
+@pytest.mark.parametrize("ingress", ["random", "single"])
+@pytest.mark.parametrize("seed", range(6))
+def test_skewed_ingress_oracle(seed, ingress):
+    trace = skewed_ingress([OracleBackend], seed, ingress)
+    assert trace == skewed_ingress([OracleBackend], seed, ingress)   # the loop is deterministic given the seed
+    if ingress == "single":
+        # quirk B#2 made visible: instance 0 evicts although the cluster still has room for the model
+        held = {}
+        early = False
+        for m, _, chosen, target, ev in trace:
+            held[target] = held.get(target, 0) + 1 - len(ev)
+            early |= bool(ev) and sum(held.values()) < FIT
+        assert early
+
+
+def test_full_cluster_evicts_the_globally_oldest():
+    """What makes :323-358 hold: on a full cluster the decision goes to the instance holding the oldest
+    entry (PLACEMENT_ORDER's lruTime clause, MM.java:4672-4676, and the LRU window of getNext :4911-4917),
+    so cluster-wide eviction order follows registration order up to the shortlist slack."""
+    mesh = MiniMesh(CLUSTER, [OracleBackend], 5)
+    try:
+        for _ in range(FIT + 9):
+            mesh.add_model()
+        victims = [k for *_, ev in mesh.trace for k in ev]
+        assert len(victims) == 9 and len(set(victims)) == 9
+        assert max(victims) < 9 + 2 * CLUSTER
+    finally:
+        mesh.close()
