@@ -21,6 +21,28 @@ namespace mmp {
 
 constexpr int kPlaceWaves = 4;  // waves (decisions in flight) per workgroup
 
+// Phase clock (tools/phase_clock.py builds a second library with -DMMP_PHASE_CLOCK; the product build carries
+// none of it): wave-level s_memtime deltas between the markers of lane_decide / place_block, one row per wavefront.
+#ifdef MMP_PHASE_CLOCK
+__device__ unsigned int g_phase[4096][16];  // one row per wavefront of the launch (the last launch's values stay)
+#define PHASE_ROW() (((blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6)) & 4095)
+#define PHASE_T0() unsigned long long ph_t_ = __builtin_amdgcn_s_memtime()
+#define PHASE(k)                                                                                   \
+    do {                                                                                           \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                \
+        if (lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) g_phase[PHASE_ROW()][k] = (unsigned int)(t_ - ph_t_); \
+        ph_t_ = t_;                                                                                \
+    } while (0)
+#define PHASE_COUNT(k, n)                                                                          \
+    do {                                                                                           \
+        if (lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) g_phase[PHASE_ROW()][k] += (unsigned int)(n); \
+    } while (0)
+#else
+#define PHASE_T0() do { } while (0)
+#define PHASE(k) do { } while (0)
+#define PHASE_COUNT(k, n) do { } while (0)
+#endif
+
 // A request with its indirections followed (request -> model row -> instanceIds / failedIn -> rank
 // positions), as the lane-per-decision path keeps it in registers.
 constexpr int kInlineExcl = 8;
@@ -489,7 +511,9 @@ enum { kLaneDone = 0, kLaneWave = 1, kLaneNoneHere = 2, kLaneIncomplete = 3, kLa
 template <bool VIEW, bool LONG = false>
 __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, int d, mmp_place_out &o)
 {
+    PHASE_T0();
     const ResolvedReq r = resolve_one<VIEW>(S, A, d);
+    PHASE(0);  // request + model row resolved
     o.chosen = MMP_NONE;
     o.best = -1;
     o.n_candidates = 0;
@@ -524,6 +548,7 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
             if (S.any_rs) fb = true;  // retry ignoring excludeReplicaSets, MM.java:4797-4804
             break;
         }
+        PHASE(1);  // first eligible pod
         const int64_t f_lru = r.fresh_lru, f_rem = r.f_rem;
         const int32_t f_rpm = r.fresh_rpm;
         const int64_t e_lru = S.lru[best0], e_rem = S.rem[best0];
@@ -564,6 +589,7 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
             if (has_pm) v &= Pm[w];
             return v;
         };
+        PHASE(2);  // best row + preference step
         const int32_t best_idx = S.orig[bestpos];
         if (us && favour) {  // :4891-4895
             o.chosen = MMP_SELF;
@@ -607,6 +633,7 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
             const int pc = lane_first(dc, start, end, far, LONG ? S.nz : nullptr, has_pm ? pc_ep : pc_e, kFarWords);
             end = pc < end ? pc : end;
         }
+        PHASE(3);  // break scans
         if (far) {  // a scan was given up: the wave path takes 64 words per step
             fb = true;
             break;
@@ -682,6 +709,7 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
                 hsum += term(v, w);
             }
         }
+        PHASE(4);  // count + hash
         int remaining = ccount;
         bool null0 = false, null_s = false, null_o = false;
         if (ccount >= 2) {  // rpm filter, :4951-4980 (quirks B#2/B#3: three rpm classes)
@@ -696,6 +724,7 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
             null_o = n_others > 0 && rule.nulls(f_rpm);
             remaining = ccount - (null0 ? 1 : 0) - (null_s ? 1 : 0) - (null_o ? n_others : 0);
         }
+        PHASE(5);  // rpm rule
         const int index = remaining <= 1 ? 0 : (int)(((uint64_t)r.pick * (uint64_t)(uint32_t)remaining) >> 32);
         int cpos = kNoPos;
         if (remaining >= 1) {
@@ -764,6 +793,7 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
             o.chosen = S.orig[cpos];
             if (!favour && cpos == selfpos) o.chosen = MMP_SELF;  // :4989-4991
         }
+        PHASE(6);  // survivor select + translation
     } while (false);
     return fb ? (VIEW ? kLaneIncomplete : (far && !LONG && S.pc ? kLaneLong : kLaneWave)) : kLaneDone;
 }
@@ -1057,6 +1087,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
     if (threadIdx.x == 0) fb_n = lr_n = 0;
     __syncthreads();
     const int d = blockIdx.x * kPlaceBlock + threadIdx.x;
+    PHASE_T0();
     if (d < A.n) {
         mmp_place_out o;
         const int code = lane_decide<false>(S, A, d, o);
@@ -1067,7 +1098,9 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
         else
             A.outs[d] = o;
     }
+    PHASE(8);  // the whole lane phase of this wavefront (incl. the result store)
     __syncthreads();
+    PHASE(9);  // waiting for the workgroup's other wavefronts
     // the decisions whose shortlist spans many words: again one lane each, this time through the prefix tables
     // (a phase of its own so that its registers do not count against the common path above)
     if (WITH_LONG && lr_n != 0) {
@@ -1091,8 +1124,11 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
             const int fd = __builtin_amdgcn_readfirstlane(fb_list[i]);
             place_one(S, A, fd, ew, fw);
             wave_sync();
+            PHASE_COUNT(12, 1);  // decisions the wave path took
         }
     }
+    PHASE(10);  // long phase + wave path
+    PHASE_COUNT(11, 1);  // wavefronts
     announce_done(DoneFlag{A.done_flag, done_blocks, A.done_seq});
 }
 
