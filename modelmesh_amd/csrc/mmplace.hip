@@ -77,6 +77,23 @@ struct SnapBufs {
     }
 };
 
+// What decisions read besides the Snap columns, one set per committed snapshot (double-buffered with SnapBufs, so
+// that a commit builds the next set while decisions keep reading the published one): the type table's allowed
+// rows, the cluster / partition / type-set stats (device + host mirrors), the instance partitions, and the
+// registry view resolved against THIS snapshot's rank positions.
+struct SnapSide {
+    DevBuf d_allowed, d_has_allowed, stats_acc, d_pts, d_prohib, pstats, tstats, rmodels;
+    bool rmodels_ok = false;
+    std::vector<int32_t> pts_of;        // pod -> partition (-1: not in the table)
+    std::vector<uint64_t> pts_prohib;   // [n_pts][tw] prohibited type rows
+    int32_t n_pts = 0, pts_tw = 1;
+    std::vector<StatsAcc> pstats_h, tstats_h;  // host mirrors (pstats_h has n_pts + 1 entries: the last is EMPTY_STATS)
+    void release()
+    {
+        for (DevBuf *b : {&d_allowed, &d_has_allowed, &stats_acc, &d_pts, &d_prohib, &pstats, &tstats, &rmodels}) b->release();
+    }
+};
+
 }  // namespace
 
 // Low-latency slot for small host-pointer batches (the single ensureLoaded / invokeModel request):
@@ -99,9 +116,10 @@ struct FastSlot {
 struct mmp_ctx {
     mmp_config cfg{};
     hipStream_t stream = nullptr;
-    // lock order: batch_mu (owner of `stream` and the s_* / r_* scratch for a whole call) -> mu (host
-    // staging + the published snapshot pointers; decision paths hold it only while they capture the
-    // pointers and enqueue, loaders and commit hold it for the whole call)
+    // lock order: batch_mu (owner of `stream`, the s_* / r_* scratch and the commit's INPUTS — the staged instance
+    // table, type table, replica-set list, registry — for a whole call) -> mu (the published snapshot pointers +
+    // host staging as readers see it; decision paths hold it only while they capture the pointers and enqueue,
+    // loaders hold it for the whole call, a commit only for its final pointer swap)
     std::mutex batch_mu, mu, err_mu;
     std::string err;
     FastSlot fast[kFastSlots];
@@ -120,15 +138,10 @@ struct mmp_ctx {
     std::vector<int32_t> replaced_rs;
     UpgradeTracker upgrades;
 
-    // instance partitions by ProhibitedTypeSet and the subset stats of the committed snapshot (snapshot.hpp)
-    std::vector<int32_t> pts_of;        // pod -> partition (-1: not in the table)
-    std::vector<uint64_t> pts_prohib;   // [n_pts][tw] prohibited type rows
-    int32_t n_pts = 0, pts_tw = 1;
-    std::vector<StatsAcc> pstats_h, tstats_h;  // host mirrors (pstats_h has n_pts + 1 entries: the last is EMPTY_STATS)
-    DevBuf d_pts, d_prohib, pstats, tstats;
-
-    // committed snapshot (double-buffered; `cur` is what decisions read)
+    // committed snapshot (double-buffered; `cur` is what decisions read): the rank-ordered columns and bitmaps,
+    // and the instance partitions / subset stats / resolved registry view that belong to them (snapshot.hpp)
     SnapBufs sb[2];
+    SnapSide side[2];
     int cur = 0;
     bool committed = false;
     Snap snap{};
@@ -147,7 +160,7 @@ struct mmp_ctx {
     bool rank_pending = false;
 
     // commit scratch
-    DevBuf rank, occupancy, flag, rs_list, rs_bad, d_allowed, d_prefer, d_has_allowed, stats_acc;
+    DevBuf rank, occupancy, flag, rs_list, rs_bad, d_prefer;
 
     // model registry view
     DevBuf models, ent_pod, ent_time;
@@ -157,9 +170,7 @@ struct mmp_ctx {
     DevBuf u_idx, u_rows, u_cnt, u_offs, u_tmp;
     std::vector<uint64_t> u_stamp;        // per model: (call generation, row index) of the last row naming it
     uint32_t u_gen = 0;
-    // the registry view resolved against the current snapshot (place_kernel.hpp: ResolvedModel)
-    DevBuf rmodels;
-    bool rmodels_ok = false;
+    // (the registry view resolved against a snapshot, place_kernel.hpp: ResolvedModel, lives in SnapSide)
 
     // eviction caches
     DevBuf c_seg, c_lu, c_wt, c_cap;
@@ -216,6 +227,10 @@ int fail(mmp_ctx *c, int code, const char *fmt, ...)
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
+// the side state of the published snapshot (read with c->mu held, or by the owner of c->batch_mu: only a commit,
+// which holds batch_mu, flips c->cur)
+inline SnapSide &cur_side(mmp_ctx *c) { return c->side[c->cur]; }
+
 // Blocking copy on the context's own (non-blocking) stream.  The library never touches the legacy null
 // stream: one synchronous hipMemset there at context creation was measured to serialise, for the rest of the
 // process, kernels that the host issues on separate streams (8-stream step time 4.0 -> 9.8 us).
@@ -260,21 +275,24 @@ hipError_t quiesce_decisions(mmp_ctx *c)
     return hipStreamSynchronize(c->stream);
 }
 
-// Called with c->mu held and the decision streams idle, after the model table or the snapshot changed:
-// re-resolve every model's entry list against the published snapshot.
-int rebuild_resolved(mmp_ctx *c)
+// Re-resolve every model's entry list against a snapshot's rank positions, into that snapshot's side state.
+// For the PUBLISHED snapshot (after the model table changed): call with c->mu held and the decision streams idle.
+// For the snapshot a commit is building: the side is not visible to decisions yet; the caller owns c->batch_mu,
+// which keeps the model table still.
+int rebuild_resolved(mmp_ctx *c, SnapSide &sd, const Snap &snap, bool committed)
 {
-    c->rmodels_ok = false;
-    if (!c->committed || c->n_shards > 0 || c->n_models <= 0) return MMP_OK;
-    HIP_TRY(c, c->rmodels.ensure((size_t)c->n_models * sizeof(ResolvedModel)));
-    hipLaunchKernelGGL(resolve_models_kernel, dim3(div_up(c->n_models, 256)), dim3(256), 0, c->stream, c->snap,
+    sd.rmodels_ok = false;
+    if (!committed || c->n_shards > 0 || c->n_models <= 0) return MMP_OK;
+    HIP_TRY(c, sd.rmodels.ensure((size_t)c->n_models * sizeof(ResolvedModel)));
+    hipLaunchKernelGGL(resolve_models_kernel, dim3(div_up(c->n_models, 256)), dim3(256), 0, c->stream, snap,
                        c->models.as<mmp_model_row>(), c->ent_pod.as<int32_t>(), c->n_models,
-                       c->rmodels.as<ResolvedModel>());
+                       sd.rmodels.as<ResolvedModel>());
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->rmodels_ok = true;
+    sd.rmodels_ok = true;
     return MMP_OK;
 }
+int rebuild_resolved(mmp_ctx *c) { return rebuild_resolved(c, cur_side(c), c->snap, c->committed); }
 
 // ---- latency slots (FastSlot): pinned, device-mapped buffers + a completion flag ---------------------
 // Small host-pointer calls do not stage through hipMemcpy and do not hold the context's batch stream: the
@@ -316,7 +334,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     PlaceArgs A;
     A.reqs = static_cast<const mmp_place_req *>(d_reqs);
     A.models = c->models.as<mmp_model_row>();
-    A.rmodels = c->rmodels_ok ? c->rmodels.as<ResolvedModel>() : nullptr;
+    A.rmodels = cur_side(c).rmodels_ok ? cur_side(c).rmodels.as<ResolvedModel>() : nullptr;
     A.ent_pod = c->ent_pod.as<int32_t>();
     A.extra = static_cast<const int32_t *>(d_extra);
     A.outs = static_cast<mmp_place_out *>(d_outs);
@@ -427,14 +445,16 @@ void mmp_destroy(mmp_ctx *c)
     if (c->pe1) (void)hipEventDestroy(c->pe1);
     c->sb[0].release();
     c->sb[1].release();
-    for (DevBuf *b : {&c->rank, &c->occupancy, &c->flag, &c->rs_list, &c->rs_bad, &c->d_allowed, &c->d_prefer,
-                      &c->d_has_allowed, &c->stats_acc, &c->models, &c->rmodels, &c->ent_pod, &c->ent_time, &c->c_seg,
+    c->side[0].release();
+    c->side[1].release();
+    for (DevBuf *b : {&c->rank, &c->occupancy, &c->flag, &c->rs_list, &c->rs_bad, &c->d_prefer,
+                      &c->models, &c->ent_pod, &c->ent_time, &c->c_seg,
                       &c->c_lu, &c->c_wt, &c->c_cap, &c->s_reqs, &c->s_outs, &c->s_extra, &c->s_a, &c->s_b,
                       &c->s_c, &c->s_d, &c->r_ps, &c->r_counts, &c->r_keys, &c->r_vals, &c->r_keys2, &c->r_vals2,
                       &c->r_tmp, &c->r_out_model, &c->r_out_lu, &c->k_cap, &c->k_wsize, &c->k_ubm, &c->k_ops, &c->k_order,
                       &c->k_opoff, &c->k_outs, &c->k_ev, &c->k_evoff, &c->idtab_hash, &c->idtab_val, &c->tytab_hash,
                       &c->tytab_val, &c->j_buf, &c->j_off, &c->j_rows, &c->j_aux, &c->j_status, &c->j_cnt, &c->j_offs, &c->j_tmp_pod,
-                      &c->j_tmp_time, &c->j_scan_tmp, &c->rk_rows, &c->rk_idx, &c->rk_tmp, &c->d_pts, &c->d_prohib, &c->pstats, &c->tstats, &c->u_idx, &c->u_rows, &c->u_cnt, &c->u_offs, &c->u_tmp, &c->f_flags, &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp,
+                      &c->j_tmp_time, &c->j_scan_tmp, &c->rk_rows, &c->rk_idx, &c->rk_tmp, &c->u_idx, &c->u_rows, &c->u_cnt, &c->u_offs, &c->u_tmp, &c->f_flags, &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp,
                       &c->ks[0].off, &c->ks[0].lu, &c->ks[0].wt,
                       &c->ks[0].key, &c->ks[0].n, &c->ks[1].off, &c->ks[1].lu, &c->ks[1].wt, &c->ks[1].key, &c->ks[1].n})
         b->release();
@@ -616,6 +636,7 @@ static void publish_upgrades(mmp_ctx *c)
 int mmp_upgrade_instance_added(mmp_ctx *c, int64_t labels_key, int32_t rs, int64_t start_time, int64_t now)
 {
     if (!c) return MMP_EINVAL;
+    std::lock_guard<std::mutex> gb(c->batch_mu);  // replaced_rs is an input of the commit
     std::lock_guard<std::mutex> g(c->mu);
     c->upgrades.instance_added(labels_key, rs, start_time, now);
     publish_upgrades(c);
@@ -625,6 +646,7 @@ int mmp_upgrade_instance_added(mmp_ctx *c, int64_t labels_key, int32_t rs, int64
 int mmp_upgrade_instance_removed(mmp_ctx *c, int64_t labels_key, int32_t rs, int64_t now)
 {
     if (!c) return MMP_EINVAL;
+    std::lock_guard<std::mutex> gb(c->batch_mu);  // replaced_rs is an input of the commit
     std::lock_guard<std::mutex> g(c->mu);
     c->upgrades.instance_removed(labels_key, rs, now);
     publish_upgrades(c);
@@ -634,6 +656,7 @@ int mmp_upgrade_instance_removed(mmp_ctx *c, int64_t labels_key, int32_t rs, int
 int mmp_upgrade_housekeeping(mmp_ctx *c, int64_t now)
 {
     if (!c) return MMP_EINVAL;
+    std::lock_guard<std::mutex> gb(c->batch_mu);  // replaced_rs is an input of the commit
     std::lock_guard<std::mutex> g(c->mu);
     c->upgrades.housekeeping(now);
     publish_upgrades(c);
@@ -671,7 +694,7 @@ int mmp_models_load(mmp_ctx *c, const mmp_model_row *rows, int32_t n_models, con
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, quiesce_decisions(c));  // the table is overwritten in place
-    c->rmodels_ok = false;
+    c->side[0].rmodels_ok = c->side[1].rmodels_ok = false;
     HIP_TRY(c, c->models.ensure((size_t)std::max(n_models, 1) * sizeof(mmp_model_row)));
     HIP_TRY(c, c->ent_pod.ensure((size_t)std::max(n_entries, 1) * sizeof(int32_t)));
     HIP_TRY(c, c->ent_time.ensure((size_t)std::max(n_entries, 1) * sizeof(int64_t)));
@@ -797,9 +820,9 @@ int mmp_models_upsert(mmp_ctx *c, const int32_t *idx, const mmp_model_row *rows,
     int rc = grow_keep(c, c->models, (size_t)c->n_models * sizeof(mmp_model_row), (size_t)count * sizeof(mmp_model_row));
     if (rc == MMP_OK) rc = grow_keep(c, c->ent_pod, (size_t)base * 4, (size_t)(base + n_entries) * 4);
     if (rc == MMP_OK) rc = grow_keep(c, c->ent_time, (size_t)base * 8, (size_t)(base + n_entries) * 8);
-    const bool resolved = c->rmodels_ok && c->committed && c->n_shards == 0;
+    const bool resolved = cur_side(c).rmodels_ok && c->committed && c->n_shards == 0;
     if (rc == MMP_OK && resolved)
-        rc = grow_keep(c, c->rmodels, (size_t)c->n_models * sizeof(ResolvedModel), (size_t)count * sizeof(ResolvedModel));
+        rc = grow_keep(c, cur_side(c).rmodels, (size_t)c->n_models * sizeof(ResolvedModel), (size_t)count * sizeof(ResolvedModel));
     if (rc != MMP_OK) return rc;
     HIP_TRY(c, c->u_idx.ensure((size_t)k * 4));
     HIP_TRY(c, c->u_rows.ensure((size_t)k * sizeof(mmp_model_row)));
@@ -812,7 +835,7 @@ int mmp_models_upsert(mmp_ctx *c, const int32_t *idx, const mmp_model_row *rows,
     KT_BEGIN(c, st);
     hipLaunchKernelGGL(upsert_models_kernel, dim3(div_up(k, 256)), dim3(256), 0, st, c->snap, c->u_idx.as<int32_t>(),
                        c->u_rows.as<mmp_model_row>(), k, c->ent_pod.as<int32_t>(), c->models.as<mmp_model_row>(),
-                       resolved ? c->rmodels.as<ResolvedModel>() : nullptr);
+                       resolved ? cur_side(c).rmodels.as<ResolvedModel>() : nullptr);
     KT_END(c, st);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(st));
@@ -829,14 +852,15 @@ int mmp_models_upsert(mmp_ctx *c, const int32_t *idx, const mmp_model_row *rows,
 namespace {
 // Partition the present instances by their ProhibitedTypeSet and build the per-partition / per-type
 // ClusterStats of the snapshot being committed (snapshot.hpp "instance partitions").  Enqueues on st; the
-// host mirrors are valid once the caller has synchronised st.  Call after cluster_stats_kernel.
-int build_subset_stats(mmp_ctx *c, const mmp_pod_row *d_pods, int32_t P, int64_t min_space, hipStream_t st)
+// host mirrors are valid once the caller has synchronised st.  Call after cluster_stats_kernel.  N = the side
+// state of the snapshot being built (its d_has_allowed / stats_acc are already filled).
+int build_subset_stats(mmp_ctx *c, SnapSide &N, const mmp_pod_row *d_pods, int32_t P, int64_t min_space, hipStream_t st)
 {
     const int32_t T = std::max(c->n_types, 1), Tw = div_up(T, 64);
-    c->pts_of.assign(P, -1);
-    c->pts_prohib.clear();
-    c->n_pts = 0;
-    c->pts_tw = Tw;
+    N.pts_of.assign(P, -1);
+    N.pts_prohib.clear();
+    N.n_pts = 0;
+    N.pts_tw = Tw;
     if (c->n_types > 0) {
         std::map<std::vector<uint64_t>, int32_t> intern;
         std::vector<uint64_t> sig(Tw);
@@ -849,32 +873,32 @@ int build_subset_stats(mmp_ctx *c, const mmp_pod_row *d_pods, int32_t P, int64_t
                     sig[t >> 6] |= 1ull << (t & 63);
             auto it = intern.find(sig);
             if (it == intern.end()) {
-                it = intern.emplace(sig, c->n_pts++).first;
-                c->pts_prohib.insert(c->pts_prohib.end(), sig.begin(), sig.end());
+                it = intern.emplace(sig, N.n_pts++).first;
+                N.pts_prohib.insert(N.pts_prohib.end(), sig.begin(), sig.end());
             }
-            c->pts_of[p] = it->second;
+            N.pts_of[p] = it->second;
         }
     }
-    const int32_t NP = c->n_pts;
-    c->pstats_h.assign(NP + 1, StatsAcc{});
-    c->pstats_h[NP].global_lru = INT64_MAX;  // InstanceSetStatsTracker.EMPTY_STATS
-    c->tstats_h.assign(T, StatsAcc{});
-    HIP_TRY(c, c->d_pts.ensure(std::max<size_t>(P, 1) * 4));
-    HIP_TRY(c, c->d_prohib.ensure(std::max<size_t>((size_t)NP * Tw, 1) * 8));
-    HIP_TRY(c, c->pstats.ensure((size_t)(NP + 1) * sizeof(StatsAcc)));
-    HIP_TRY(c, c->tstats.ensure((size_t)T * sizeof(StatsAcc)));
-    if (P) HIP_TRY(c, hipMemcpyAsync(c->d_pts.p, c->pts_of.data(), (size_t)P * 4, hipMemcpyHostToDevice, st));
-    if (NP) HIP_TRY(c, hipMemcpyAsync(c->d_prohib.p, c->pts_prohib.data(), (size_t)NP * Tw * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->pstats.p, c->pstats_h.data(), (size_t)(NP + 1) * sizeof(StatsAcc), hipMemcpyHostToDevice, st));
+    const int32_t NP = N.n_pts;
+    N.pstats_h.assign(NP + 1, StatsAcc{});
+    N.pstats_h[NP].global_lru = INT64_MAX;  // InstanceSetStatsTracker.EMPTY_STATS
+    N.tstats_h.assign(T, StatsAcc{});
+    HIP_TRY(c, N.d_pts.ensure(std::max<size_t>(P, 1) * 4));
+    HIP_TRY(c, N.d_prohib.ensure(std::max<size_t>((size_t)NP * Tw, 1) * 8));
+    HIP_TRY(c, N.pstats.ensure((size_t)(NP + 1) * sizeof(StatsAcc)));
+    HIP_TRY(c, N.tstats.ensure((size_t)T * sizeof(StatsAcc)));
+    if (P) HIP_TRY(c, hipMemcpyAsync(N.d_pts.p, N.pts_of.data(), (size_t)P * 4, hipMemcpyHostToDevice, st));
+    if (NP) HIP_TRY(c, hipMemcpyAsync(N.d_prohib.p, N.pts_prohib.data(), (size_t)NP * Tw * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(N.pstats.p, N.pstats_h.data(), (size_t)(NP + 1) * sizeof(StatsAcc), hipMemcpyHostToDevice, st));
     if (NP > 0 && P > 0)
         hipLaunchKernelGGL(partition_stats_kernel, dim3(std::min(div_up(P, 256), 64)), dim3(256), 0, st, d_pods, P, min_space,
-                           c->d_pts.as<int32_t>(), NP, c->pstats.as<StatsAcc>());
+                           N.d_pts.as<int32_t>(), NP, N.pstats.as<StatsAcc>());
     hipLaunchKernelGGL(subset_stats_finish_kernel, dim3(div_up(std::max(NP, T), 256)), dim3(256), 0, st,
-                       c->stats_acc.as<StatsAcc>(), c->pstats.as<StatsAcc>(), NP, c->d_prohib.as<uint64_t>(), Tw, T,
-                       c->n_types > 0 ? c->d_has_allowed.as<uint8_t>() : nullptr, c->tstats.as<StatsAcc>());
+                       N.stats_acc.as<StatsAcc>(), N.pstats.as<StatsAcc>(), NP, N.d_prohib.as<uint64_t>(), Tw, T,
+                       c->n_types > 0 ? N.d_has_allowed.as<uint8_t>() : nullptr, N.tstats.as<StatsAcc>());
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->pstats_h.data(), c->pstats.p, (size_t)(NP + 1) * sizeof(StatsAcc), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(c->tstats_h.data(), c->tstats.p, (size_t)T * sizeof(StatsAcc), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(N.pstats_h.data(), N.pstats.p, (size_t)(NP + 1) * sizeof(StatsAcc), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(N.tstats_h.data(), N.tstats.p, (size_t)T * sizeof(StatsAcc), hipMemcpyDeviceToHost, st));
     return MMP_OK;
 }
 }  // namespace
@@ -882,12 +906,19 @@ int build_subset_stats(mmp_ctx *c, const mmp_pod_row *d_pods, int32_t P, int64_t
 int mmp_snapshot_commit(mmp_ctx *c)
 {
     if (!c) return MMP_EINVAL;
+    // Wait-free for decisions (SURVEY.md §8b "Threading"): the whole build runs with batch_mu only.  batch_mu keeps
+    // the inputs still — every loader of the instance table, the type table, the registry and the replica-set list
+    // takes it, and so does any other commit — and it owns c->stream and the commit scratch.  Everything a decision
+    // reads is double-buffered (SnapBufs + SnapSide): the build fills the set that is NOT published, decisions keep
+    // capturing the published one under c->mu, and c->mu is taken only for the pointer swap at the end.
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
     if (c->n_shards > 0)
         return fail(c, MMP_ESTATE, "context is a pod-axis shard: commit with mmp_shard_rank_dev + mmp_shard_commit_dev");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    HIP_TRY(c, quiesce_decisions(c));  // the buffer set about to be rewritten was current two commits ago
+    // The set about to be rewritten was published until the previous commit's swap; a kernel that still reads it
+    // was enqueued before that swap.  Waiting for the decision streams (without c->mu: new decisions only ever
+    // capture the published set) retires those.
+    HIP_TRY(c, quiesce_decisions(c));
     const int32_t P = (int32_t)c->pods.size();
     const int32_t W = std::max(div_up(P, 64), 1);
     const int32_t T = std::max(c->n_types, 1);
@@ -895,6 +926,7 @@ int mmp_snapshot_commit(mmp_ctx *c)
         return fail(c, MMP_ESTATE, "type bitmaps were loaded for a different pod count; reload them before commit");
     const size_t padded = (size_t)W * 64;
     SnapBufs &B = c->sb[1 - c->cur];
+    SnapSide &N = c->side[1 - c->cur];
     hipStream_t st = c->stream;
 
     HIP_TRY(c, B.pods.ensure(std::max<size_t>(P, 1) * sizeof(mmp_pod_row)));
@@ -916,12 +948,12 @@ int mmp_snapshot_commit(mmp_ctx *c)
     HIP_TRY(c, c->rank.ensure(padded * 4));
     HIP_TRY(c, c->occupancy.ensure(padded * 4));
     HIP_TRY(c, c->flag.ensure(sizeof(int32_t)));
-    HIP_TRY(c, c->stats_acc.ensure(sizeof(StatsAcc)));
+    HIP_TRY(c, N.stats_acc.ensure(sizeof(StatsAcc)));
     HIP_TRY(c, c->rs_bad.ensure(padded));
     HIP_TRY(c, c->rs_list.ensure(std::max<size_t>(c->replaced_rs.size(), 1) * 4));
-    HIP_TRY(c, c->d_allowed.ensure(std::max<size_t>((size_t)T * W, 1) * 8));
+    HIP_TRY(c, N.d_allowed.ensure(std::max<size_t>((size_t)T * W, 1) * 8));
     HIP_TRY(c, c->d_prefer.ensure(std::max<size_t>((size_t)T * W, 1) * 8));
-    HIP_TRY(c, c->d_has_allowed.ensure(T));
+    HIP_TRY(c, N.d_has_allowed.ensure(T));
 
     if (P) HIP_TRY(c, hipMemcpyAsync(B.pods.p, c->pods.data(), (size_t)P * sizeof(mmp_pod_row), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemsetAsync(c->rank.p, 0, padded * 4, st));
@@ -940,9 +972,9 @@ int mmp_snapshot_commit(mmp_ctx *c)
         ha[t] = c->has_allowed[t];
     }
     HIP_TRY(c, hipMemcpyAsync(B.has_pref.p, hp.data(), T, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->d_has_allowed.p, ha.data(), T, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(N.d_has_allowed.p, ha.data(), T, hipMemcpyHostToDevice, st));
     if (c->n_types > 0 && !c->allowed.empty()) {
-        HIP_TRY(c, hipMemcpyAsync(c->d_allowed.p, c->allowed.data(), c->allowed.size() * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(N.d_allowed.p, c->allowed.data(), c->allowed.size() * 8, hipMemcpyHostToDevice, st));
         HIP_TRY(c, hipMemcpyAsync(c->d_prefer.p, c->prefer.data(), c->prefer.size() * 8, hipMemcpyHostToDevice, st));
     }
     const int32_t n_rs = (int32_t)c->replaced_rs.size();
@@ -952,7 +984,7 @@ int mmp_snapshot_commit(mmp_ctx *c)
     const int64_t churn2 = (int64_t)((uint64_t)c->cfg.min_churn_age_ms * 2u);
     StatsAcc init{};
     init.global_lru = INT64_MAX;
-    HIP_TRY(c, hipMemcpyAsync(c->stats_acc.p, &init, sizeof init, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(N.stats_acc.p, &init, sizeof init, hipMemcpyHostToDevice, st));
 
     bool next_long = c->long_mode == 1;
     KT_BEGIN(c, st);
@@ -1006,14 +1038,14 @@ int mmp_snapshot_commit(mmp_ctx *c)
                                P, c->rs_list.as<int32_t>(), n_rs, c->rs_bad.as<uint8_t>());
         const int waves = T * W;
         hipLaunchKernelGGL(build_masks_kernel, dim3(div_up(waves, 4)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(), P,
-                           W, T, min_space, B.orig.as<int32_t>(), c->d_allowed.as<uint64_t>(),
-                           c->d_has_allowed.as<uint8_t>(), c->d_prefer.as<uint64_t>(), B.has_pref.as<uint8_t>(),
+                           W, T, min_space, B.orig.as<int32_t>(), N.d_allowed.as<uint64_t>(),
+                           N.d_has_allowed.as<uint8_t>(), c->d_prefer.as<uint64_t>(), B.has_pref.as<uint8_t>(),
                            n_rs ? c->rs_bad.as<uint8_t>() : nullptr, B.elig.as<uint64_t>(),
                            B.elig_nors.as<uint64_t>(), B.pref.as<uint64_t>(), B.fullw.as<uint64_t>());
         hipLaunchKernelGGL(build_prefix_kernel, dim3(2 * T), dim3(64), 0, st, B.elig.as<uint64_t>(), B.pref.as<uint64_t>(), T, W,
-                           B.pc.as<int32_t>(), B.ph.as<uint64_t>(), B.nz.as<int32_t>(), c->stats_acc.as<StatsAcc>());
+                           B.pc.as<int32_t>(), B.ph.as<uint64_t>(), B.nz.as<int32_t>(), N.stats_acc.as<StatsAcc>());
         hipLaunchKernelGGL(cluster_stats_kernel, dim3(std::min(div_up(P, 256), 512)), dim3(256), 0, st,
-                           B.pods.as<mmp_pod_row>(), P, min_space, c->stats_acc.as<StatsAcc>());
+                           B.pods.as<mmp_pod_row>(), P, min_space, N.stats_acc.as<StatsAcc>());
         HIP_TRY(c, hipGetLastError());
     } else {
         HIP_TRY(c, hipMemsetAsync(B.pc.p, 0, (size_t)2 * T * (W + 1) * 4, st));
@@ -1026,14 +1058,14 @@ int mmp_snapshot_commit(mmp_ctx *c)
         HIP_TRY(c, hipMemsetAsync(B.ge.p, 0, (size_t)kGeRows * W * 8, st));
     }
     {
-        const int rc = build_subset_stats(c, B.pods.as<mmp_pod_row>(), P, min_space, st);
+        const int rc = build_subset_stats(c, N, B.pods.as<mmp_pod_row>(), P, min_space, st);
         if (rc != MMP_OK) return rc;
     }
     KT_END(c, st);
     int32_t bad = 0;
     StatsAcc acc{};
     HIP_TRY(c, hipMemcpyAsync(&bad, c->flag.p, sizeof bad, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(&acc, c->stats_acc.p, sizeof acc, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(&acc, N.stats_acc.p, sizeof acc, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     kt_collect(c);
     if (bad)
@@ -1065,6 +1097,13 @@ int mmp_snapshot_commit(mmp_ctx *c)
     // a type only a few instances may host: its first candidate is usually beyond a lane scan's reach, and only the
     // long variant carries the prefix-table jump that finds it without the wave path
     if (c->long_mode < 0 && acc.sparse_types) next_long = true;
+    // the registry view resolved against the new order, still invisible to decisions
+    {
+        const int rc = rebuild_resolved(c, N, S, true);
+        if (rc != MMP_OK) return rc;
+    }
+    // publish: the only part of a commit a decision can ever wait for
+    std::lock_guard<std::mutex> g(c->mu);
     c->snap_long = next_long;
     c->snap = S;
     c->cur = 1 - c->cur;
@@ -1074,7 +1113,7 @@ int mmp_snapshot_commit(mmp_ctx *c)
     c->stats.global_lru = (int64_t)acc.global_lru;
     c->stats.instance_count = acc.instance_count;
     c->stats.model_copy_count = acc.model_copy_count;
-    return rebuild_resolved(c);
+    return MMP_OK;
 }
 
 int mmp_get_order(mmp_ctx *c, int32_t *order_out, int32_t *n_out)
@@ -1119,8 +1158,8 @@ int mmp_type_stats(mmp_ctx *c, int32_t type, mmp_stats *out)
     if (!c || !out) return fail(c, MMP_EINVAL, "mmp_type_stats: null argument");
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
-    const int32_t T = (int32_t)c->tstats_h.size();
-    *out = stats_of(c->tstats_h[(type < 0 || type >= T) ? 0 : type]);
+    const int32_t T = (int32_t)cur_side(c).tstats_h.size();
+    *out = stats_of(cur_side(c).tstats_h[(type < 0 || type >= T) ? 0 : type]);
     return MMP_OK;
 }
 
@@ -1129,7 +1168,7 @@ int mmp_partition_count(mmp_ctx *c, int32_t *n_out)
     if (!c || !n_out) return fail(c, MMP_EINVAL, "mmp_partition_count: null argument");
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
-    *n_out = c->n_pts;
+    *n_out = cur_side(c).n_pts;
     return MMP_OK;
 }
 
@@ -1139,10 +1178,10 @@ int mmp_partition_stats(mmp_ctx *c, int32_t partition, mmp_stats *out, uint64_t 
         return fail(c, MMP_EINVAL, "mmp_partition_stats: bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
-    if (partition < 0 || partition >= c->n_pts) return fail(c, MMP_EINVAL, "mmp_partition_stats: no partition %d", partition);
-    *out = stats_of(c->pstats_h[partition]);
+    if (partition < 0 || partition >= cur_side(c).n_pts) return fail(c, MMP_EINVAL, "mmp_partition_stats: no partition %d", partition);
+    *out = stats_of(cur_side(c).pstats_h[partition]);
     for (int32_t w = 0; w < max_words; w++)
-        prohibited_out[w] = w < c->pts_tw ? c->pts_prohib[(size_t)partition * c->pts_tw + w] : 0;
+        prohibited_out[w] = w < cur_side(c).pts_tw ? cur_side(c).pts_prohib[(size_t)partition * cur_side(c).pts_tw + w] : 0;
     return MMP_OK;
 }
 
@@ -1152,9 +1191,9 @@ int mmp_pod_partitions(mmp_ctx *c, int32_t *partition_out, int32_t max_pods, int
         return fail(c, MMP_EINVAL, "mmp_pod_partitions: bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
-    *n_out = (int32_t)c->pts_of.size();
+    *n_out = (int32_t)cur_side(c).pts_of.size();
     const int32_t m = std::min(*n_out, max_pods);
-    if (m > 0) memcpy(partition_out, c->pts_of.data(), (size_t)m * 4);
+    if (m > 0) memcpy(partition_out, cur_side(c).pts_of.data(), (size_t)m * 4);
     return MMP_OK;
 }
 
@@ -1333,7 +1372,7 @@ int mmp_models_ingest_json(mmp_ctx *c, const char *buf, const int64_t *off, int3
     HIP_TRY(c, quiesce_decisions(c));  // the registry view is replaced in place
     hipStream_t st = c->stream;
     const int32_t n = n_models;
-    c->rmodels_ok = false;
+    c->side[0].rmodels_ok = c->side[1].rmodels_ok = false;
     if (n == 0) {
         c->n_models = 0;
         c->n_entries = 0;
@@ -1514,6 +1553,7 @@ int mmp_shard_commit_dev(mmp_ctx *c, const void *d_rank)
     const int32_t Wn1 = std::max(Wn, 1);
     const size_t padded = (size_t)Wn1 * 64, padded_full = (size_t)W * 64;
     SnapBufs &B = c->sb[1 - c->cur];  // B.pods was filled by mmp_shard_rank_dev
+    SnapSide &N = c->side[1 - c->cur];
     hipStream_t st = c->stream;
 
     HIP_TRY(c, B.lru.ensure(padded * 8));
@@ -1530,12 +1570,12 @@ int mmp_shard_commit_dev(mmp_ctx *c, const void *d_rank)
     HIP_TRY(c, B.ge.ensure((size_t)kGeRows * Wn1 * 8));
     HIP_TRY(c, c->occupancy.ensure(padded_full * 4));
     HIP_TRY(c, c->flag.ensure(sizeof(int32_t)));
-    HIP_TRY(c, c->stats_acc.ensure(sizeof(StatsAcc)));
+    HIP_TRY(c, N.stats_acc.ensure(sizeof(StatsAcc)));
     HIP_TRY(c, c->rs_bad.ensure(padded_full));
     HIP_TRY(c, c->rs_list.ensure(std::max<size_t>(c->replaced_rs.size(), 1) * 4));
-    HIP_TRY(c, c->d_allowed.ensure(std::max<size_t>((size_t)T * W, 1) * 8));
+    HIP_TRY(c, N.d_allowed.ensure(std::max<size_t>((size_t)T * W, 1) * 8));
     HIP_TRY(c, c->d_prefer.ensure(std::max<size_t>((size_t)T * W, 1) * 8));
-    HIP_TRY(c, c->d_has_allowed.ensure(T));
+    HIP_TRY(c, N.d_has_allowed.ensure(T));
 
     HIP_TRY(c, hipMemsetAsync(c->occupancy.p, 0, padded_full * 4, st));
     HIP_TRY(c, hipMemsetAsync(c->flag.p, 0, sizeof(int32_t), st));
@@ -1557,9 +1597,9 @@ int mmp_shard_commit_dev(mmp_ctx *c, const void *d_rank)
         ha[t] = c->has_allowed[t];
     }
     HIP_TRY(c, hipMemcpyAsync(B.has_pref.p, hp.data(), T, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->d_has_allowed.p, ha.data(), T, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(N.d_has_allowed.p, ha.data(), T, hipMemcpyHostToDevice, st));
     if (c->n_types > 0 && !c->allowed.empty()) {
-        HIP_TRY(c, hipMemcpyAsync(c->d_allowed.p, c->allowed.data(), c->allowed.size() * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(N.d_allowed.p, c->allowed.data(), c->allowed.size() * 8, hipMemcpyHostToDevice, st));
         HIP_TRY(c, hipMemcpyAsync(c->d_prefer.p, c->prefer.data(), c->prefer.size() * 8, hipMemcpyHostToDevice, st));
     }
     const int32_t n_rs = (int32_t)c->replaced_rs.size();
@@ -1567,7 +1607,7 @@ int mmp_shard_commit_dev(mmp_ctx *c, const void *d_rank)
     const int64_t min_space = c->cfg.min_space_units;
     StatsAcc init{};
     init.global_lru = INT64_MAX;
-    HIP_TRY(c, hipMemcpyAsync(c->stats_acc.p, &init, sizeof init, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(N.stats_acc.p, &init, sizeof init, hipMemcpyHostToDevice, st));
 
     if (P > 0) {
         hipLaunchKernelGGL(scatter_shard_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(), P,
@@ -1579,8 +1619,8 @@ int mmp_shard_commit_dev(mmp_ctx *c, const void *d_rank)
                                P, c->rs_list.as<int32_t>(), n_rs, c->rs_bad.as<uint8_t>());
         if (Wn > 0)
             hipLaunchKernelGGL(build_masks_shard_kernel, dim3(div_up(T * Wn, 4)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(),
-                               P, Wfull, w_lo, Wn, T, min_space, B.orig.as<int32_t>(), c->d_allowed.as<uint64_t>(),
-                               c->d_has_allowed.as<uint8_t>(), c->d_prefer.as<uint64_t>(), B.has_pref.as<uint8_t>(),
+                               P, Wfull, w_lo, Wn, T, min_space, B.orig.as<int32_t>(), N.d_allowed.as<uint64_t>(),
+                               N.d_has_allowed.as<uint8_t>(), c->d_prefer.as<uint64_t>(), B.has_pref.as<uint8_t>(),
                                n_rs ? c->rs_bad.as<uint8_t>() : nullptr, B.elig.as<uint64_t>(),
                                B.elig_nors.as<uint64_t>(), B.pref.as<uint64_t>(), B.fullw.as<uint64_t>());
         const int32_t P_local = std::max(0, std::min(P - w_lo * 64, Wn * 64));
@@ -1588,17 +1628,17 @@ int mmp_shard_commit_dev(mmp_ctx *c, const void *d_rank)
             hipLaunchKernelGGL(build_ge_kernel, dim3(div_up(kGeRows * Wn, 4)), dim3(256), 0, st, B.cnt.as<int32_t>(), P_local, Wn,
                                B.ge.as<uint64_t>());
         hipLaunchKernelGGL(cluster_stats_kernel, dim3(std::min(div_up(P, 256), 512)), dim3(256), 0, st,
-                           B.pods.as<mmp_pod_row>(), P, min_space, c->stats_acc.as<StatsAcc>());
+                           B.pods.as<mmp_pod_row>(), P, min_space, N.stats_acc.as<StatsAcc>());
         HIP_TRY(c, hipGetLastError());
     }
     {
-        const int rc = build_subset_stats(c, B.pods.as<mmp_pod_row>(), P, min_space, st);
+        const int rc = build_subset_stats(c, N, B.pods.as<mmp_pod_row>(), P, min_space, st);
         if (rc != MMP_OK) return rc;
     }
     int32_t bad = 0;
     StatsAcc acc{};
     HIP_TRY(c, hipMemcpyAsync(&bad, c->flag.p, sizeof bad, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(&acc, c->stats_acc.p, sizeof acc, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(&acc, N.stats_acc.p, sizeof acc, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     c->rank_pending = false;
     if (bad)
@@ -1933,10 +1973,10 @@ GateArgs gate_args(mmp_ctx *c, int32_t n, int64_t now, int64_t in_use_expiry)
     A.ent_pod = c->ent_pod.as<int32_t>();
     A.ent_time = c->ent_time.as<int64_t>();
     A.pods = c->sb[c->cur].pods.as<mmp_pod_row>();
-    A.allowed = c->d_allowed.as<uint64_t>();
-    A.has_allowed = c->d_has_allowed.as<uint8_t>();
-    A.stats = c->stats_acc.as<StatsAcc>();
-    A.tstats = c->tstats.as<StatsAcc>();
+    A.allowed = cur_side(c).d_allowed.as<uint64_t>();
+    A.has_allowed = cur_side(c).d_has_allowed.as<uint8_t>();
+    A.stats = cur_side(c).stats_acc.as<StatsAcc>();
+    A.tstats = cur_side(c).tstats.as<StatsAcc>();
     A.T_rows = std::max(c->n_types, 1);
     A.n = n;
     A.n_models = c->n_models;
@@ -2044,7 +2084,7 @@ int mmp_proactive_plan_subset(mmp_ctx *c, int32_t partition, const int32_t *skip
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
-    if (partition >= c->n_pts || partition < -1) return fail(c, MMP_EINVAL, "mmp_proactive_plan: no partition %d", partition);
+    if (partition >= cur_side(c).n_pts || partition < -1) return fail(c, MMP_EINVAL, "mmp_proactive_plan: no partition %d", partition);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     hipStream_t st = c->stream;
     const int32_t M = c->n_models, P = c->snap.P;
@@ -2058,16 +2098,16 @@ int mmp_proactive_plan_subset(mmp_ctx *c, int32_t partition, const int32_t *skip
     HIP_TRY(c, c->r_out_model.ensure((size_t)std::max(max_out, 1) * 4));
     HIP_TRY(c, c->r_out_lu.ensure((size_t)std::max(max_out, 1) * 8));
     PlanScalars *ps = c->r_ps.as<PlanScalars>();
-    const StatsAcc *stats = c->stats_acc.as<StatsAcc>();
+    const StatsAcc *stats = cur_side(c).stats_acc.as<StatsAcc>();
     const mmp_pod_row *pods = c->sb[c->cur].pods.as<mmp_pod_row>();
     const mmp_model_row *models = c->models.as<mmp_model_row>();
     int32_t *counts = c->r_counts.as<int32_t>();
     HIP_TRY(c, hipMemsetAsync(ps, 0, sizeof(PlanScalars), st));
     PlanSubset U{};
     U.global = stats;
-    U.stats = partition >= 0 ? c->pstats.as<StatsAcc>() + partition : stats;
-    U.pod_pts = c->d_pts.as<int32_t>();
-    U.prohib = partition >= 0 ? c->d_prohib.as<uint64_t>() + (size_t)partition * c->pts_tw : nullptr;
+    U.stats = partition >= 0 ? cur_side(c).pstats.as<StatsAcc>() + partition : stats;
+    U.pod_pts = cur_side(c).d_pts.as<int32_t>();
+    U.prohib = partition >= 0 ? cur_side(c).d_prohib.as<uint64_t>() + (size_t)partition * cur_side(c).pts_tw : nullptr;
     U.skip = nullptr;
     U.pts = partition;
     U.n_types = c->n_types;
@@ -2175,8 +2215,8 @@ int mmp_scaleup_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, cons
     A.models = c->models.as<mmp_model_row>();
     A.ent_pod = c->ent_pod.as<int32_t>();
     A.ent_time = c->ent_time.as<int64_t>();
-    A.stats = c->stats_acc.as<StatsAcc>();
-    A.tstats = c->tstats.as<StatsAcc>();
+    A.stats = cur_side(c).stats_acc.as<StatsAcc>();
+    A.tstats = cur_side(c).tstats.as<StatsAcc>();
     A.T_rows = std::max(c->n_types, 1);
     A.has_tc = c->n_types > 0 ? 1 : 0;
     A.overloaded = c->s_a.as<uint8_t>();
@@ -2222,8 +2262,8 @@ int mmp_scaledown_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, co
     // (EMPTY_STATS when it is not in the table), cluster-wide otherwise
     {
         const int32_t sp = p->self_pod;
-        const int32_t k = (sp >= 0 && sp < (int32_t)c->pts_of.size()) ? c->pts_of[sp] : -1;
-        A.stats = c->n_types > 0 ? c->pstats.as<StatsAcc>() + (k >= 0 ? k : c->n_pts) : c->stats_acc.as<StatsAcc>();
+        const int32_t k = (sp >= 0 && sp < (int32_t)cur_side(c).pts_of.size()) ? cur_side(c).pts_of[sp] : -1;
+        A.stats = c->n_types > 0 ? cur_side(c).pstats.as<StatsAcc>() + (k >= 0 ? k : cur_side(c).n_pts) : cur_side(c).stats_acc.as<StatsAcc>();
     }
     A.decide = c->s_a.as<uint8_t>();
     A.removed = c->s_b.as<uint8_t>();

@@ -188,6 +188,128 @@ def test_concurrent_single_decisions_batches_and_commits():
         s.close()
 
 
+def _two_tables():
+    """One registry, two instance tables that rank the instances differently."""
+    a = wl.make_fleet("C2")
+    b = wl.make_fleet("C2")
+    rng = np.random.default_rng(0xAB)
+    perm = rng.permutation(b.n_pods)
+    for f in ("lru_time", "capacity", "used", "count", "rpm", "loading_in_progress"):
+        b.pods[f] = b.pods[f][perm]
+    return a, b
+
+
+def test_decisions_see_one_snapshot_or_the_other_while_commits_alternate():
+    """The commit publishes with one pointer swap: a decision that runs while the instance table alternates
+    between two contents answers for ONE of them — all four outputs from the same snapshot — never for a mix
+    of a new order with old columns, old stats or a stale resolved registry view."""
+    import threading
+    from modelmesh_amd import _lib
+    a, b = _two_tables()
+    reqs, extra = wl.make_requests(a, 91, n=3000, extra_frac=0.0)
+    wa = OracleFleet(a).place(reqs, extra, a.now, threads=8)
+    wb = OracleFleet(b).place(reqs, extra, b.now, threads=8)
+    assert not np.array_equal(wa["chosen"], wb["chosen"])
+    fields = ("chosen", "best", "n_candidates", "hash")
+    g = np.zeros(16, dtype=_lib.GATE_REQ)
+    g["model"], g["self_pod"] = np.arange(16), np.arange(16)
+    g["cache_capacity"], g["loader_predicted"], g["flags"] = 8_388_608, 6400, 8
+    g["loading_count"], g["weight_predict_cutoff"] = 20, 10      # average-based size prediction: reads typeSetStats
+    z32, z64 = np.zeros(0, np.int32), np.zeros(0, np.int64)
+    s = Solver(a.min_space_units, a.min_churn_age_ms)
+    errors, seen = [], {"a": 0, "b": 0}
+    try:
+        s.load_fleet(a)
+        ga = s.gates(g, z32, z64, z32, a.now)
+        s.load_pods(b.pods)
+        s.commit()
+        gb = s.gates(g, z32, z64, z32, a.now)
+        stop = threading.Event()
+
+        def placer(tid):
+            try:
+                i = tid
+                while not stop.is_set():
+                    got = s.place(reqs[i:i + 1], None, a.now)
+                    is_a = all(got[f][0] == wa[f][i] for f in fields)
+                    is_b = all(got[f][0] == wb[f][i] for f in fields)
+                    if not (is_a or is_b):
+                        errors.append(("place", i, got[0]))
+                    seen["a"] += is_a and not is_b
+                    seen["b"] += is_b and not is_a
+                    i = (i + 3) % len(reqs)
+            except Exception as e:  # noqa: BLE001
+                errors.append(("place", repr(e)))
+
+        def gater():
+            try:
+                while not stop.is_set():
+                    got = s.gates(g, z32, z64, z32, a.now)
+                    if not (np.array_equal(got, ga) or np.array_equal(got, gb)):
+                        errors.append(("gate",))
+            except Exception as e:  # noqa: BLE001
+                errors.append(("gate", repr(e)))
+        ths = [threading.Thread(target=placer, args=(t,)) for t in range(3)] + [threading.Thread(target=gater)]
+        for t in ths:
+            t.start()
+        for it in range(60):
+            s.load_pods((a if it % 2 == 0 else b).pods)
+            s.commit()
+        stop.set()
+        for t in ths:
+            t.join()
+        assert not errors, errors[:5]
+        assert seen["a"] > 0 and seen["b"] > 0, seen
+    finally:
+        s.close()
+
+
+def test_single_decisions_complete_while_a_commit_is_running():
+    """decisions are wait-free with respect to snapshot updates.  A commit of a 50k-instance
+    table takes ~1 ms (rank by sorting, bitmaps, prefix tables, stats, the resolved registry view); single
+    decisions issued from another thread must start AND finish inside that window — they only ever wait for
+    the pointer swap at its end."""
+    import threading
+    import time
+    fleet = wl.make_fleet("C4", models=20_000)
+    reqs, extra = wl.make_requests(fleet, 5, n=2000, extra_frac=0.0)
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    spans, commits, errors = [], [], []
+    try:
+        s.load_fleet(fleet)
+        want = s.place(reqs, None, fleet.now)
+        stop = threading.Event()
+
+        def placer():
+            try:
+                i = 0
+                while not stop.is_set():
+                    t0 = time.perf_counter()
+                    got = s.place(reqs[i:i + 1], None, fleet.now)
+                    spans.append((t0, time.perf_counter()))
+                    if got["chosen"][0] != want["chosen"][i] or got["hash"][0] != want["hash"][i]:
+                        errors.append(i)
+                    i = (i + 1) % len(reqs)
+            except Exception as e:  # noqa: BLE001
+                errors.append(repr(e))
+        th = threading.Thread(target=placer)
+        th.start()
+        time.sleep(0.02)
+        for _ in range(40):
+            t0 = time.perf_counter()
+            s.commit()
+            commits.append((t0, time.perf_counter()))
+            time.sleep(0.002)
+        stop.set()
+        th.join()
+        assert not errors, errors[:5]
+        inside = sum(1 for (c0, c1) in commits for (d0, d1) in spans if d0 > c0 and d1 < c1)
+        mean_commit_ms = 1e3 * float(np.mean([c1 - c0 for c0, c1 in commits]))
+        assert inside >= 40, (inside, mean_commit_ms)   # at least one per commit on average; typically dozens
+    finally:
+        s.close()
+
+
 @pytest.mark.parametrize("seed", [0, 5, 9])
 def test_general_wave_path_alone(seed, monkeypatch):
     """The kernel gives each decision to one lane and keeps the wave-per-decision code for rare shapes;
