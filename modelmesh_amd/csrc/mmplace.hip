@@ -779,8 +779,11 @@ int mmp_models_upsert(mmp_ctx *c, const int32_t *idx, const mmp_model_row *rows,
     if (!c || n < 0 || n_entries < 0 || (n > 0 && (!idx || !rows)) || (n_entries > 0 && (!ent_pod || !ent_time)))
         return fail(c, MMP_EINVAL, "mmp_models_upsert: bad argument");
     if (n == 0) return MMP_OK;
+    // batch_mu keeps the registry's host bookkeeping and device tables to this call (every other writer of them
+    // takes it); decisions are held off (c->mu + idle decision streams) only while the rows are rewritten in place —
+    // the entries of the changed records are appended to the arena beyond anything a published row refers to, and
+    // the new rows wait in scratch, before that.
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
     int32_t count = c->n_models;
     for (int32_t i = 0; i < n; i++) {
         const mmp_model_row &m = rows[i];
@@ -791,7 +794,6 @@ int mmp_models_upsert(mmp_ctx *c, const int32_t *idx, const mmp_model_row *rows,
     }
     if ((int64_t)c->n_entries + n_entries > INT32_MAX) return fail(c, MMP_EINVAL, "mmp_models_upsert: entry arena overflow; reload the registry");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
-    HIP_TRY(c, quiesce_decisions(c));  // rows are rewritten in place
     hipStream_t st = c->stream;
     // the last row wins when a model appears twice in one call (events are applied in order)
     std::vector<int32_t> last(n);
@@ -817,13 +819,21 @@ int mmp_models_upsert(mmp_ctx *c, const int32_t *idx, const mmp_model_row *rows,
         c->ent_live += (int64_t)(rows[i].n_loaded + rows[i].n_failed) - c->m_cnt[idx[i]];
         c->m_cnt[idx[i]] = rows[i].n_loaded + rows[i].n_failed;
     }
-    int rc = grow_keep(c, c->models, (size_t)c->n_models * sizeof(mmp_model_row), (size_t)count * sizeof(mmp_model_row));
-    if (rc == MMP_OK) rc = grow_keep(c, c->ent_pod, (size_t)base * 4, (size_t)(base + n_entries) * 4);
-    if (rc == MMP_OK) rc = grow_keep(c, c->ent_time, (size_t)base * 8, (size_t)(base + n_entries) * 8);
-    const bool resolved = cur_side(c).rmodels_ok && c->committed && c->n_shards == 0;
-    if (rc == MMP_OK && resolved)
-        rc = grow_keep(c, cur_side(c).rmodels, (size_t)c->n_models * sizeof(ResolvedModel), (size_t)count * sizeof(ResolvedModel));
-    if (rc != MMP_OK) return rc;
+    // A table that has to grow moves (the old allocation is freed): only then is the state lock needed this early.
+    const bool grows = (size_t)count * sizeof(mmp_model_row) > c->models.cap || (size_t)(base + n_entries) * 4 > c->ent_pod.cap ||
+                       (size_t)(base + n_entries) * 8 > c->ent_time.cap ||
+                       (cur_side(c).rmodels_ok && (size_t)count * sizeof(ResolvedModel) > cur_side(c).rmodels.cap);
+    if (grows) {
+        std::lock_guard<std::mutex> g(c->mu);
+        HIP_TRY(c, quiesce_decisions(c));
+        int rc = grow_keep(c, c->models, (size_t)c->n_models * sizeof(mmp_model_row), (size_t)count * sizeof(mmp_model_row));
+        if (rc == MMP_OK) rc = grow_keep(c, c->ent_pod, (size_t)base * 4, (size_t)(base + n_entries) * 4);
+        if (rc == MMP_OK) rc = grow_keep(c, c->ent_time, (size_t)base * 8, (size_t)(base + n_entries) * 8);
+        // (the unpublished side's view is rebuilt from the model table by the next commit)
+        if (rc == MMP_OK && cur_side(c).rmodels_ok)
+            rc = grow_keep(c, cur_side(c).rmodels, (size_t)c->n_models * sizeof(ResolvedModel), (size_t)count * sizeof(ResolvedModel));
+        if (rc != MMP_OK) return rc;
+    }
     HIP_TRY(c, c->u_idx.ensure((size_t)k * 4));
     HIP_TRY(c, c->u_rows.ensure((size_t)k * sizeof(mmp_model_row)));
     if (n_entries) {
@@ -832,18 +842,24 @@ int mmp_models_upsert(mmp_ctx *c, const int32_t *idx, const mmp_model_row *rows,
     }
     HIP_TRY(c, hipMemcpyAsync(c->u_idx.p, h_idx.data(), (size_t)k * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->u_rows.p, h_rows.data(), (size_t)k * sizeof(mmp_model_row), hipMemcpyHostToDevice, st));
-    KT_BEGIN(c, st);
-    hipLaunchKernelGGL(upsert_models_kernel, dim3(div_up(k, 256)), dim3(256), 0, st, c->snap, c->u_idx.as<int32_t>(),
-                       c->u_rows.as<mmp_model_row>(), k, c->ent_pod.as<int32_t>(), c->models.as<mmp_model_row>(),
-                       resolved ? cur_side(c).rmodels.as<ResolvedModel>() : nullptr);
-    KT_END(c, st);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(st));
-    kt_collect(c);
-    c->n_models = count;
-    c->n_entries = base + n_entries;
-    // more garbage than live entries (and enough to matter): squeeze the arena
-    if ((int64_t)c->n_entries - c->ent_live > std::max<int64_t>(c->ent_live, 1 << 16)) return compact_registry(c);
+    HIP_TRY(c, hipStreamSynchronize(st));  // the pageable sources above are this call's stack / the caller's arrays
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        HIP_TRY(c, quiesce_decisions(c));  // rows (and their resolved positions) are rewritten in place
+        const bool resolved = cur_side(c).rmodels_ok && c->committed && c->n_shards == 0;
+        KT_BEGIN(c, st);
+        hipLaunchKernelGGL(upsert_models_kernel, dim3(div_up(k, 256)), dim3(256), 0, st, c->snap, c->u_idx.as<int32_t>(),
+                           c->u_rows.as<mmp_model_row>(), k, c->ent_pod.as<int32_t>(), c->models.as<mmp_model_row>(),
+                           resolved ? cur_side(c).rmodels.as<ResolvedModel>() : nullptr);
+        KT_END(c, st);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(st));
+        kt_collect(c);
+        c->n_models = count;
+        c->n_entries = base + n_entries;
+        // more garbage than live entries (and enough to matter): squeeze the arena
+        if ((int64_t)c->n_entries - c->ent_live > std::max<int64_t>(c->ent_live, 1 << 16)) return compact_registry(c);
+    }
     return MMP_OK;
 }
 
