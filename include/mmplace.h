@@ -380,7 +380,11 @@ int mmp_models_load(mmp_ctx *ctx, const mmp_model_row *rows, int32_t n_models,
 int mmp_models_upsert(mmp_ctx *ctx, const int32_t *idx, const mmp_model_row *rows, int32_t n, const int32_t *ent_pod,
                       const int64_t *ent_time, int32_t n_entries);
 /* Rank pods by PLACEMENT_ORDER (MM.java:4646-4703) on the device and publish
- * the new immutable snapshot. MMP_EORDER if the comparator is inconsistent. */
+ * the new immutable snapshot. MMP_EORDER if the comparator is inconsistent.
+ * Wait-free for decisions: the snapshot is built beside the published one and
+ * published with a pointer swap; concurrent mmp_place_batch / _serve / _gate /
+ * _evict calls keep answering for the published snapshot until then.  Loaders
+ * of the commit's inputs and other commits serialise with it. */
 int mmp_snapshot_commit(mmp_ctx *ctx);
 /* clusterState iteration order (the `getCacheState` dump, MM.java:5552-5608).
  * order_out has room for n_pods ints; *n_out = rows actually in the set. */
