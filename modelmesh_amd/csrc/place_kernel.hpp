@@ -312,6 +312,18 @@ __device__ __forceinline__ ResolvedReq resolve_one(const Snap &S, const PlaceArg
     r.pad[0] = r.pad[1] = 0;
 #pragma unroll
     for (int i = 0; i < kInlineExcl; i++) r.excl_pos[i] = -1;
+    // The request's own exclusions (tried-this-request / explicit) depend on the request alone: their pool
+    // entries and rank positions are fetched NOW, beside the model row, instead of behind it — with 5 % of the
+    // requests carrying some, nearly every wavefront would otherwise walk request -> model row -> pool ->
+    // pos_of as four dependent loads (tools/phase_clock.py: this step was the longest of the decision).
+    constexpr int kEarlyExtra = 4;
+    int32_t xpos[kEarlyExtra];
+    const bool early_extra = rq.n_extra > 0 && rq.n_extra <= kEarlyExtra;
+#pragma unroll
+    for (int j = 0; j < kEarlyExtra; j++) {
+        xpos[j] = -1;
+        if (early_extra && j < rq.n_extra) xpos[j] = pod_view_pos<VIEW>(S, A.extra[rq.extra_off + j], P_all);
+    }
     if (rq.model < 0 || rq.model >= A.n_models) {
         r.type = -1;
         r.n_excl = 0;
@@ -323,7 +335,17 @@ __device__ __forceinline__ ResolvedReq resolve_one(const Snap &S, const PlaceArg
 #pragma unroll
             for (int i = 0; i < kResolvedInline; i++)
                 if (i < m.n_ents) r.excl_pos[i] = m.pos[i];
-            if (rq.n_extra > 0) {
+            if (early_extra) {
+#pragma unroll
+                for (int i = 0; i < kInlineExcl; i++) {  // slot n_ents + j takes extra j
+                    const int j = i - m.n_ents;
+                    int32_t v = r.excl_pos[i];
+#pragma unroll
+                    for (int q = 0; q < kEarlyExtra; q++)
+                        if (j == q && q < rq.n_extra) v = xpos[q];
+                    r.excl_pos[i] = v;
+                }
+            } else if (rq.n_extra > 0) {
 #pragma unroll
                 for (int i = 0; i < kInlineExcl; i++) {
                     if (i >= m.n_ents && i < r.n_excl) {
