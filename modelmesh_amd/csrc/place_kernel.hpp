@@ -19,7 +19,10 @@
 
 namespace mmp {
 
-constexpr int kPlaceWaves = 4;  // waves (decisions in flight) per workgroup
+#ifndef MMP_PLACE_WAVES
+#define MMP_PLACE_WAVES 4  // measured on C3, 100k decisions per launch: see DESIGN.md §4.1 (workgroup size)
+#endif
+constexpr int kPlaceWaves = MMP_PLACE_WAVES;  // waves (decisions in flight) per workgroup
 
 // Phase clock (tools/phase_clock.py builds a second library with -DMMP_PHASE_CLOCK; the product build carries
 // none of it): wave-level s_memtime deltas between the markers of lane_decide / place_block, one row per wavefront.
@@ -195,8 +198,16 @@ struct RpmRule {
         ago = ago_;
         active = ago < 5LL * 24 * 3600 * 1000;
         min_load = min_rpm > 100 ? min_rpm : 100;       // MM.java:4957
-        m11 = jd2i(1.1 * (double)min_load);             // :4958
-        m15 = jd2i(1.5 * (double)min_load);
+        // :4958  (int)(1.1 * minLoad), (int)(1.5 * minLoad) in integer arithmetic.  For every 0 <= x < 2^31:
+        // (int)(1.1 * x) == min(x + x / 10, INT_MAX) — double(1.1) lies 8.9e-17 above 1.1, so the rounded product
+        // never falls below an integer it should reach and is never more than 2.4e-7 off — and 1.5 * x is exact:
+        // (int)(1.5 * x) == min(x + x / 2, INT_MAX)  (Java's narrowing saturates).  Checked exhaustively over all
+        // 2^31 values (the CPU test suite samples it: test_rpm_thresholds_in_integer_arithmetic); the two
+        // conversions and two double products were a tenth of the decision's instruction time.
+        const uint32_t x = (uint32_t)min_load;
+        const uint32_t t11 = x + x / 10u, t15 = x + (x >> 1);
+        m11 = t11 > 0x7fffffffu ? INT32_MAX : (int32_t)t11;
+        m15 = t15 > 0x7fffffffu ? INT32_MAX : (int32_t)t15;
         m3 = (int32_t)((uint32_t)min_load * 3u);
         m4 = (int32_t)((uint32_t)min_load * 4u);
     }

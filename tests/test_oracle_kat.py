@@ -238,3 +238,21 @@ def test_concurrent_eviction_kat(driver):
         d.grow(18 + i, 6399)
     assert d.evicted() == list(range(10))
     assert sorted(d.keys()) == list(range(10, 28))
+
+
+def test_rpm_thresholds_in_integer_arithmetic():
+    """MM.java:4958 `(int) (1.1 * minLoad)`, `(int) (1.5 * minLoad)`: the device evaluates them as
+    min(x + x / 10, INT_MAX) and min(x + x / 2, INT_MAX) (place_kernel.hpp RpmRule::init).  Equal to the double
+    products with Java's saturating narrowing for every 0 <= x < 2^31 — the exhaustive check of all 2^31 values
+    takes two minutes; here: both ends, every multiple of ten near powers of two, and 20 million random values."""
+    import numpy as np
+    imax = 2**31 - 1
+    rng = np.random.default_rng(11)
+    parts = [np.arange(0, 3_000_000), np.arange(imax - 3_000_000, imax + 1), rng.integers(0, 2**31, 20_000_000)]
+    for k in range(7, 31):
+        parts.append(np.arange(max(2**k - 5000, 0), min(2**k + 5000, imax + 1)))
+        parts.append((np.arange(-300, 300) + (2**k) // 10) * 10)
+    x = np.unique(np.clip(np.concatenate(parts), 0, imax)).astype(np.int64)
+    d = x.astype(np.float64)
+    assert np.array_equal(np.minimum(np.floor(1.1 * d), imax).astype(np.int64), np.minimum(x + x // 10, imax))
+    assert np.array_equal(np.minimum(np.floor(1.5 * d), imax).astype(np.int64), np.minimum(x + (x >> 1), imax))
