@@ -106,6 +106,82 @@ class OracleBackend:
         pass
 
 
+class PyOracleBackend:
+    """The SECOND, independently written restatement (oracle/py_oracle.py): PLACEMENT_ORDER, getNext, clhm and the
+    unload-buffer manager in plain Python.  It has no restatement of the request guards (gate() returns None and
+    is left out of the comparison); decisions and every cache operation are compared with the other backends."""
+    name = "py-oracle"
+
+    def __init__(self, n_pods, now):
+        from oracle import py_oracle as po
+        self.po = po
+        self.c = [po.Clhm(CAPACITY) for _ in range(n_pods)]
+        self.u = [po.UnloadBufManager(c, RESERVED, now) for c in self.c]
+        self.fleet = None
+
+    def publish(self, fleet, pod_idx, model_idx):
+        self.fleet = fleet
+
+    def place(self, req, now):
+        po, f = self.po, self.fleet
+        mesh = po.Mesh(f.min_space_units, f.min_churn_age_ms, now)
+        pods = [dict(lru_time=int(r["lru_time"]), capacity=int(r["capacity"]), used=int(r["used"]), version=int(r["version"]),
+                     count=int(r["count"]), loading_threads=int(r["loading_threads"]),
+                     loading_in_progress=int(r["loading_in_progress"]), rpm=int(r["rpm"]), id_order=int(r["id_order"]),
+                     replica_set=int(r["replica_set"]), shutting_down=bool(r["flags"] & 5)) for r in f.pods]
+        order = mesh.sorted_cluster_state(pods)
+        r = req[0]
+        m = f.models[r["model"]]
+        ents = f.ent_pod[m["ent_off"]: m["ent_off"] + m["n_loaded"] + m["n_failed"]]
+        loaded, failed = set(int(x) for x in ents[: m["n_loaded"]]), set(int(x) for x in ents[m["n_loaded"]:])
+        fresh = dict(lru_time=int(r["fresh_lru"]), capacity=int(r["fresh_capacity"]), used=int(r["fresh_used"]),
+                     count=int(r["fresh_count"]), rpm=int(r["fresh_rpm"]))
+        live = {i for i in range(f.n_pods) if f.pods["flags"][i] & 2}
+        chosen, best, shortlist, remaining = po.get_next(mesh, pods, order, live, set(), None, None, [set(), loaded, failed],
+                                                         int(r["self_pod"]), bool(r["flags"] & 1), fresh, int(r["last_used"]),
+                                                         int(r["pick"]))
+        h = 0
+        if shortlist:
+            from tests.test_oracle_cross import _py_hash
+            h = _py_hash(order, shortlist, remaining)
+        return int(chosen), int(best), len(shortlist), int(h)
+
+    def gate(self, q, now):
+        return None
+
+    def cache_ops(self, rows, now):
+        out = []
+        for (c, op, key, arg, t, flag) in rows:
+            u, ch = self.u[c], self.c[c]
+            ev0 = len(u.evicted)
+            if op == _lib.COP_UBM_INSERT_NEW_ENTRY:
+                res = int(u.insertNewEntry(key, arg, t, now))
+            elif op == _lib.COP_UBM_ADJUST_SPACE_REQUEST:
+                res = 1 if ch._find(key) is not None else 0
+                u.adjustNewEntrySpaceRequest(arg, key, now)
+            elif op == _lib.COP_UBM_CLAIM_SPACE:
+                res = int(u.claimRequestedSpaceIfReady(arg, now))
+            elif op == _lib.COP_UBM_ADJUST_AFTER_LOAD:
+                res = 1 if (ch._find(key) is not None or arg == 0) else 0
+                u.adjustWeightAfterLoad(arg, key, now)
+            elif op == _lib.COP_UBM_UNLOAD_COMPLETE:
+                u.unloadComplete(arg, bool(flag), now)
+                res = 1 if flag else 0
+            elif op == _lib.COP_GET:
+                res = int(ch.get(key, t, now))
+            else:
+                raise ValueError(op)
+            ev = [(_lib.UNLOADBUF_KEY if k == u.KEY else int(k)) for k, _ in u.evicted[ev0:]]
+            out.append((res, ev, int(ch.weightedSize), int(ch.oldestTime()), int(u.buffer_weight())))
+        return out
+
+    def cache_keys(self, c):
+        return sorted(int(k) for k in self.c[c].keys() if k != self.u[c].KEY)
+
+    def close(self):
+        pass
+
+
 class DeviceBackend:
     """The product: libmmplace through the C ABI (modelmesh_amd.solver.Solver is a ctypes veneer)."""
     name = "device"
@@ -219,7 +295,7 @@ class MiniMesh:
         """Run one step on every backend; they must agree."""
         res = [fn(b) for b in self.backends]
         for b, r in zip(self.backends[1:], res[1:]):
-            assert r == res[0], f"{what}: {b.name} {r} != {self.backends[0].name} {res[0]}"
+            assert r is None or r == res[0], f"{what}: {b.name} {r} != {self.backends[0].name} {res[0]}"
         return res[0]
 
     def _ops(self, rows):

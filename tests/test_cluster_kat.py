@@ -5,7 +5,7 @@ getNext / PLACEMENT_ORDER / clhm restatements TOGETHER to assertions the referen
 GPU twin (test_cluster_kat_gpu.py) runs the device in lock step with the oracle."""
 import pytest
 
-from tests.minimesh import MiniMesh, OracleBackend
+from tests.minimesh import MiniMesh, OracleBackend, PyOracleBackend
 
 CLUSTER = 3                                   # ModelMeshEvictionsTest.java:558
 FIT = int(0.9 * (10 * CLUSTER))               # maxModelsWithoutEviction, :331-333  (= 27)
@@ -120,3 +120,19 @@ def test_full_cluster_evicts_the_globally_oldest():
         assert max(victims) < 9 + 2 * CLUSTER
     finally:
         mesh.close()
+
+
+@pytest.mark.parametrize("scenario", SCENARIOS, ids=lambda f: f.__name__)
+def test_cluster_kat_both_restatements_in_lock_step(scenario):
+    """The C and the Python restatement replay the cluster tests together: every decision (chosen, best, shortlist
+    size, audit hash) and every cache operation (result, evicted keys, weightedSize, oldestTime, buffer weight) must
+    agree step by step — the comparator / shortlist / rpm half of getNext has no reference test of its own, this
+    is where the two independent readings of the Java text are compared on the states a real mesh walks through."""
+    for seed in (0, 1, 2):
+        scenario([OracleBackend, PyOracleBackend], seed)
+
+
+@pytest.mark.parametrize("ingress", ["random", "single"])
+def test_skewed_ingress_both_restatements(ingress):
+    for seed in (0, 1, 2):
+        skewed_ingress([OracleBackend, PyOracleBackend], seed, ingress)
