@@ -218,3 +218,28 @@ def test_unload_buffer_manager_ops_c_vs_python(seed):
         assert (h.u.total_unloading, h.u.total_occupancy, h.u.cache_deficit, h.c.weighted_size, h.c.capacity) == \
             (pu.totalUnloadingWeight, pu.totalModelCacheOccupancy, pu.cacheDeficit, pc.weightedSize, pc.capacity)
         h.u.n_evicted = 0
+
+
+def test_relabelling_instances_renames_the_decisions():
+    """getNext never looks at an instance's index, only at its record and its id ORDER: with the instance table
+    permuted (rows moved, instanceIds / self / exclusions renamed, id_order kept with the row) the oracle picks the
+    renamed instance with the same shortlist size and audit hash.  (The GPU suite runs the same property over all
+    1M decisions of C4, test_c4_full_size_relabelling_and_batch_split.)"""
+    from modelmesh_amd.solver import bitmap_from_bool
+    fleet = wl.make_fleet("C3", models=5000, pods=700)
+    reqs, extra = wl.make_requests(fleet, 14)
+    whole = ob.OracleFleet(fleet).place(reqs, extra, fleet.now)
+    P = fleet.n_pods
+    new_of = np.random.default_rng(99).permutation(P).astype(np.int32)
+    old_of = np.empty(P, np.int32)
+    old_of[new_of] = np.arange(P, dtype=np.int32)
+    f2 = wl.make_fleet("C3", models=5000, pods=700)
+    f2.pods, f2.ent_pod = fleet.pods[old_of].copy(), new_of[fleet.ent_pod]
+    f2.allowed = bitmap_from_bool(ob.unpack_bitmap(fleet.allowed, P)[:, old_of])
+    f2.prefer = bitmap_from_bool(ob.unpack_bitmap(fleet.prefer, P)[:, old_of])
+    r2 = reqs.copy()
+    r2["self_pod"] = np.where(reqs["self_pod"] >= 0, new_of[np.clip(reqs["self_pod"], 0, P - 1)], reqs["self_pod"])
+    got = ob.OracleFleet(f2).place(r2, new_of[extra] if len(extra) else extra, f2.now)
+    for f in ("chosen", "best"):
+        assert np.array_equal(got[f], np.where(whole[f] >= 0, new_of[np.clip(whole[f], 0, P - 1)], whole[f]))
+    assert np.array_equal(got["n_candidates"], whole["n_candidates"]) and np.array_equal(got["hash"], whole["hash"])

@@ -335,6 +335,52 @@ def test_c4_1m_x_50k_sample():
     _check_fleet(fleet, sub, extra)
 
 
+def test_c4_full_size_relabelling_and_batch_split():
+    """All 1M decisions of C4 through two size-independent properties (the oracle takes a sample above):
+    * batch split: deciding the batch in seven uneven pieces gives the same rows as deciding it at once;
+    * relabelling: getNext never looks at an instance's index, only at its record and its id ORDER — so with the
+      instance table permuted (rows moved, instanceIds / self / exclusions renamed, id_order kept with the row) every
+      decision picks the renamed instance, with the same shortlist size and the same audit hash."""
+    fleet = wl.make_fleet("C4")
+    reqs, extra = wl.make_requests(fleet, 14)
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        whole = s.place(reqs, extra, fleet.now)
+        cuts = [0, 1, 4097, 100_000, 333_333, 700_001, 999_999, len(reqs)]
+        parts = [s.place(reqs[a:b], extra, fleet.now) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert np.array_equal(np.concatenate(parts), whole)
+    finally:
+        s.close()
+    rng = np.random.default_rng(99)
+    P = fleet.n_pods
+    new_of = rng.permutation(P).astype(np.int32)          # old index -> new index
+    old_of = np.empty(P, np.int32)
+    old_of[new_of] = np.arange(P, dtype=np.int32)
+    f2 = wl.make_fleet("C4")
+    f2.pods = fleet.pods[old_of].copy()                    # row j of the new table = old row old_of[j]
+    # instanceIds / failedIn stay in instance-id order inside each list: id_order moved with the rows
+    f2.ent_pod = new_of[fleet.ent_pod]
+    if f2.n_types:
+        from modelmesh_amd.solver import bitmap_from_bool
+        from oracle.bind import unpack_bitmap
+        f2.allowed = bitmap_from_bool(unpack_bitmap(fleet.allowed, P)[:, old_of])
+        f2.prefer = bitmap_from_bool(unpack_bitmap(fleet.prefer, P)[:, old_of])
+    r2 = reqs.copy()
+    r2["self_pod"] = np.where(reqs["self_pod"] >= 0, new_of[np.clip(reqs["self_pod"], 0, P - 1)], reqs["self_pod"])
+    e2 = new_of[extra] if len(extra) else extra
+    s = Solver(f2.min_space_units, f2.min_churn_age_ms)
+    try:
+        s.load_fleet(f2)
+        got = s.place(r2, e2, f2.now)
+    finally:
+        s.close()
+    want_chosen = np.where(whole["chosen"] >= 0, new_of[np.clip(whole["chosen"], 0, P - 1)], whole["chosen"])
+    want_best = np.where(whole["best"] >= 0, new_of[np.clip(whole["best"], 0, P - 1)], whole["best"])
+    assert np.array_equal(got["chosen"], want_chosen) and np.array_equal(got["best"], want_best)
+    assert np.array_equal(got["n_candidates"], whole["n_candidates"]) and np.array_equal(got["hash"], whole["hash"])
+
+
 def _widen_registry(fleet, rng, max_copies):
     """Give every model 0..max_copies instanceIds (+ 0..2 failedIn) on distinct pods, TreeMap order."""
     P, M = fleet.n_pods, fleet.n_models
