@@ -131,6 +131,12 @@ REFERENCE_KATS = {
     "typeConstraint": {
         "source": "src/test/java/com/ibm/watson/modelmesh/ModelMeshErrorPropagationTest.java:52-95",
         "type": "my-type-1", "required_label": "my-label-1", "labelled_replicas": ["9000"], "copies": 1},
+    "clusterEvictions": {
+        "source": "src/test/java/com/ibm/watson/modelmesh/ModelMeshEvictionsTest.java:292-310 (testMultiLoadCluster), "
+                  ":323-358 (testMultiLoadWithEvictionCluster), :371-409 (testMultiLoadWithEvictionClusterReuse); "
+                  "clusterSize :558, wiggle room :340, expected ids :695-702",
+        "cluster_size": 3, "multi_load": 9, "fits_models": 27, "beyond_capacity": 3, "wiggle_room": 6,
+        "must_be_loaded_from_index": 9, "reuse": {"touch_first": 5, "add": 3}},
     "loadFailure": {
         "source": "src/test/java/com/ibm/watson/modelmesh/ModelMeshLoadFailureTest.java:432-492",
         "max_load_failures": 3, "failed_instances_never_retried_within_expiry": True},

@@ -11,6 +11,17 @@ CLUSTER = 3                                   # ModelMeshEvictionsTest.java:558
 FIT = int(0.9 * (10 * CLUSTER))               # maxModelsWithoutEviction, :331-333  (= 27)
 
 
+def test_constants_match_the_transcribed_reference_numbers():
+    """tests/golden/reference_kats.json holds the reference tests' numbers with their file:line."""
+    import json
+    import os
+    k = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))["clusterEvictions"]
+    assert (k["cluster_size"], k["fits_models"]) == (CLUSTER, FIT)
+    n = k["fits_models"] + k["beyond_capacity"]
+    assert min(n - 1, k["beyond_capacity"] + k["wiggle_room"]) == k["must_be_loaded_from_index"] == 9
+    assert k["wiggle_room"] == 2 * CLUSTER and k["multi_load"] == 9
+
+
 def multi_load_cluster(backends, seed):
     """:292-310 — 9 models into a 3-instance cluster: all stay loaded, nothing is evicted."""
     mesh = MiniMesh(CLUSTER, backends, seed)
