@@ -87,7 +87,7 @@ def pod_axis_leg(workload: str, rank: int, world: int, dev, steps: int, warmup: 
     """The same decisions with the POD axis sharded across the ranks (BASELINE.json
     config C4): every rank sees the whole batch and owns 1/world of the PLACEMENT_ORDER positions.  A
     batch takes the speculative form first — every shard decides on its own slice, ONE RCCL
-    all-reduce(MIN) of 4 int64 per decision picks the lowest shard holding an eligible pod — and the
+    all-reduce(MIN) of 2 int64 per decision picks the lowest shard holding an eligible pod — and the
     decisions that shard could not finish alone take the six-exchange protocol as a compacted sub-batch
     (modelmesh_amd.dist.PodShardedPlacer).  Strong scaling of the pod table, not of the batch: value =
     decisions of ONE batch / time."""
@@ -134,7 +134,7 @@ def pod_axis_leg(workload: str, rank: int, world: int, dev, steps: int, warmup: 
         out = {"workload": f"{workload}: {fleet.n_models} models x {fleet.n_pods} pods", "n_shards": world,
                "value": n * steps / elapsed, "unit": "decisions/s", "ms_per_step": elapsed / steps * 1e3,
                "decisions_per_step": n, "scaling": "strong (pod table split, batch replicated)",
-               "collective": ("1 x all_reduce(MIN, 4 int64 per decision) + 6 x all_reduce(int64; MIN x5, SUM x1) over the "
+               "collective": ("1 x all_reduce(MIN, 2 int64 per decision) + 6 x all_reduce(int64; MIN x5, SUM x1) over the "
                               "undecided rest, via torch.distributed (RCCL)") if world > 1 else "none (1 shard)",
                "decided_by_the_single_exchange": n - n_rest, "took_the_six_phase_protocol": n_rest,
                "allreduce_bytes_per_step": 8 * s.shard_fast_slots() * n + 8 * slots * n_rest,

@@ -1527,6 +1527,8 @@ int mmp_shard_rank_dev(mmp_ctx *c, void *d_rank)
     if (c->n_shards < 1) return fail(c, MMP_ESTATE, "mmp_shard_configure has not been called");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const int32_t P = (int32_t)c->pods.size();
+    if (P >= kShardMaxPods)
+        return fail(c, MMP_EINVAL, "pod-axis mode: %d instances exceed the %d the exchange words can carry", P, kShardMaxPods - 1);
     SnapBufs &B = c->sb[1 - c->cur];
     hipStream_t st = c->stream;
     HIP_TRY(c, B.pods.ensure(std::max<size_t>(P, 1) * sizeof(mmp_pod_row)));

@@ -602,13 +602,18 @@ __global__ void place_shard_finish_kernel(ShardSnap S, PlaceArgs A, XchgPtrs X)
 // lane-per-decision getNext (place_kernel.hpp: lane_decide on a view of its slice) on its own.  So before
 // the six-exchange protocol above, every shard publishes per decision either "no eligible pod here"
 // (kXMax) or its local result keyed by its shard number, with an "incomplete" bit when a scan ran off the
-// end of its slice or the decision left the lane path's shape.  ONE all-reduce(MIN) of kXF int64 per
+// end of its slice or the decision left the lane path's shape.  ONE all-reduce(MIN) of kXF (= 2) int64 per
 // decision picks the result of the lowest shard that holds an eligible pod — which is the shard the
 // global walk would have started in.  Only decisions whose winner is incomplete (or that found no
 // eligible pod anywhere while replica sets are excluded: the retry of MM.java:4797-4804) go through the
 // general protocol, on a compacted request list that every shard builds identically (flags -> exclusive
 // scan -> gather, so the order is by decision index on every shard).
-constexpr int kXF = 4;
+// Two int64 per decision, both led by the shard number so that MIN takes every field from the same (lowest) shard:
+//   x[0] = shard << 56 | incomplete << 55 | (chosen + 2) << 28 | (best + 1)      (27 + 28 bits)
+//   x[1] = shard << 56 | n_candidates << 32 | hash                                (24 + 32 bits)
+// which bounds a pod-axis table at 2^24 instances (mmp_shard_configure checks) and the node at 127 shards.
+constexpr int kXF = 2;
+constexpr int kShardMaxPods = 1 << 24;
 
 __global__ __launch_bounds__(256) void place_shard_fast_kernel(Snap V, PlaceArgs A, int32_t shard, int64_t *__restrict__ xf)
 {
@@ -616,19 +621,15 @@ __global__ __launch_bounds__(256) void place_shard_fast_kernel(Snap V, PlaceArgs
     if (d >= A.n) return;
     mmp_place_out o;
     const int code = lane_decide<true>(V, A, d, o);
-    int64_t k0 = kXMax, k1 = kXMax, k2 = kXMax, k3 = kXMax;
+    int64_t k0 = kXMax, k1 = kXMax;
     if (code != kLaneNoneHere) {
         const int64_t key = (int64_t)shard << 56;
-        k0 = key | ((int64_t)(code != kLaneDone) << 48) | (int64_t)(uint32_t)(o.chosen + 2);
-        k1 = key | (int64_t)(uint32_t)(o.best + 1);
-        k2 = key | (int64_t)(uint32_t)o.n_candidates;
-        k3 = key | (int64_t)o.hash;
+        k0 = key | ((int64_t)(code != kLaneDone) << 55) | ((int64_t)(uint32_t)(o.chosen + 2) << 28) | (int64_t)(uint32_t)(o.best + 1);
+        k1 = key | ((int64_t)(uint32_t)o.n_candidates << 32) | (int64_t)o.hash;
     }
     int64_t *x = xf + (size_t)d * kXF;
     x[0] = k0;
     x[1] = k1;
-    x[2] = k2;
-    x[3] = k3;
 }
 
 // after the all-reduce: write the decided rows, flag the rest
@@ -642,7 +643,7 @@ __global__ void place_shard_fast_finish_kernel(const int64_t *__restrict__ xf, i
         return;
     }
     const int64_t *x = xf + (size_t)d * kXF;
-    const int64_t k0 = x[0];
+    const int64_t k0 = x[0], k1 = x[1];
     mmp_place_out o;
     o.chosen = MMP_NONE;
     o.best = -1;
@@ -651,13 +652,13 @@ __global__ void place_shard_fast_finish_kernel(const int64_t *__restrict__ xf, i
     int32_t rest = 0;
     if (k0 == kXMax)
         rest = any_rs ? 1 : 0;  // nowhere eligible: null, unless the excludeReplicaSets retry has to run
-    else if ((k0 >> 48) & 1)
+    else if ((k0 >> 55) & 1)
         rest = 1;
     else {
-        o.chosen = (int32_t)(uint32_t)(k0 & 0xffffffffll) - 2;
-        o.best = (int32_t)(uint32_t)(x[1] & 0xffffffffll) - 1;
-        o.n_candidates = (int32_t)(uint32_t)(x[2] & 0xffffffffll);
-        o.hash = (uint32_t)(x[3] & 0xffffffffll);
+        o.chosen = (int32_t)((k0 >> 28) & 0x7ffffffll) - 2;
+        o.best = (int32_t)(k0 & 0xfffffffll) - 1;
+        o.n_candidates = (int32_t)((k1 >> 32) & 0xffffffll);
+        o.hash = (uint32_t)(k1 & 0xffffffffll);
     }
     flags[d] = rest;
     if (!rest) outs[d] = o;

@@ -12,7 +12,7 @@ ROCm, the same code runs on "gloo" — tests/test_dist_gloo.py).
    between two phases: MIN of per-shard best positions / break positions / owner-supplied rows,
    SUM of per-shard candidate counts.  Six all-reduces per batch in the general protocol — but the head
    of the order decides almost every request, so a batch first takes the speculative form: every shard
-   decides on its own slice, ONE all-reduce(MIN) of 4 int64 per decision picks the lowest shard holding
+   decides on its own slice, ONE all-reduce(MIN) of 2 int64 per decision picks the lowest shard holding
    an eligible pod, and only the decisions that shard could not finish alone go through the six phases
    (as a compacted sub-batch, identical on every shard).
 """

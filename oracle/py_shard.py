@@ -287,7 +287,7 @@ class EmulShardBackend:
     # ---- the speculative single-exchange form (csrc/shard_kernels.hpp "speculative") -----------------
     # Emulated as what it means: this shard plays the WHOLE protocol alone on its own slice (private
     # exchange vectors, no reduction), and then judges whether that was legitimate.
-    FAST_SLOTS = 4
+    FAST_SLOTS = 2   # x[0] = shard<<56 | incomplete<<55 | (chosen+2)<<28 | (best+1);  x[1] = shard<<56 | n_candidates<<32 | hash
 
     def fast_slots(self):
         return self.FAST_SLOTS
@@ -329,9 +329,9 @@ class EmulShardBackend:
                     continue
                 o = outs[d]
                 key = self.shard << 56
-                xv[d] = (key | ((0 if complete else 1) << 48) | ((int(o["chosen"]) + 2) & 0xFFFFFFFF),
-                         key | ((int(o["best"]) + 1) & 0xFFFFFFFF), key | (int(o["n_candidates"]) & 0xFFFFFFFF),
-                         key | (int(o["hash"]) & 0xFFFFFFFF))
+                xv[d] = (key | ((0 if complete else 1) << 55) | (((int(o["chosen"]) + 2) & 0x7FFFFFF) << 28) |
+                         ((int(o["best"]) + 1) & 0xFFFFFFF),
+                         key | ((int(o["n_candidates"]) & 0xFFFFFF) << 32) | (int(o["hash"]) & 0xFFFFFFFF))
         finally:
             self.any_rs = any_rs
 
@@ -345,13 +345,14 @@ class EmulShardBackend:
             if k0 == XMAX:
                 if self.any_rs:
                     rest.append(d)
-            elif (k0 >> 48) & 1:
+            elif (k0 >> 55) & 1:
                 rest.append(d)
             else:
-                o["chosen"] = (k0 & 0xFFFFFFFF) - 2
-                o["best"] = (int(xv[d][1]) & 0xFFFFFFFF) - 1
-                o["n_candidates"] = int(xv[d][2]) & 0xFFFFFFFF
-                o["hash"] = int(xv[d][3]) & 0xFFFFFFFF
+                k1 = int(xv[d][1])
+                o["chosen"] = ((k0 >> 28) & 0x7FFFFFF) - 2
+                o["best"] = (k0 & 0xFFFFFFF) - 1
+                o["n_candidates"] = (k1 >> 32) & 0xFFFFFF
+                o["hash"] = k1 & 0xFFFFFFFF
         self._rest_idx = np.asarray(rest, np.int64)
         return len(rest), reqs[self._rest_idx].copy(), np.zeros(len(rest), dtype=outs.dtype)
 
