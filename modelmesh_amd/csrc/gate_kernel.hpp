@@ -197,6 +197,8 @@ __device__ __forceinline__ void gate_one(const GateArgs &A, int i)
                            cur.loading_in_progress == r.fresh_in_progress && cur.rpm == r.fresh_rpm) {
                     publish = false;
                 }
+            } else if (r.flags & MMP_GATE_FRESH_SHUTTING_DOWN) {
+                publish = false;  // :5432-5436: no record of ours in the table and shutting down -> return without creating one
             }
         }
         if (publish) bits |= MMP_GATE_SHOULD_PUBLISH;

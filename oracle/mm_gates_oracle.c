@@ -154,7 +154,7 @@ int orc_should_publish(const orc_pod *cur, const orc_pod *fresh, int64_t now, in
     int64_t last_done = jsub64(now, last_published);
     if (!pre_shutdown && (last_done < MINP || (!force && last_done < FREQ - 1000))) return 0;
     int old = last_done > FREQ * 4;
-    if (!cur) return 1;
+    if (!cur) return fresh->shutting_down ? 0 : 1; /* :5432-5436: no record and shutting down -> return, else create it */
     int64_t cap = fresh->capacity, used = fresh->used, oldest = fresh->lru_time;
     int32_t count = fresh->count;
     if (!old) {

@@ -243,3 +243,108 @@ def test_relabelling_instances_renames_the_decisions():
     for f in ("chosen", "best"):
         assert np.array_equal(got[f], np.where(whole[f] >= 0, new_of[np.clip(whole[f], 0, P - 1)], whole[f]))
     assert np.array_equal(got["n_candidates"], whole["n_candidates"]) and np.array_equal(got["hash"], whole["hash"])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_request_guards_c_vs_python(seed):
+    """The guards around the two selections (goLocal MM.java:3598-3626, the failure / location caps :4590-4627, the
+    churn guard :3870-3884, loadLocal's size prediction and early reject :5158-5197, onEviction's reload rule
+    :2886-2920, the publish hysteresis :5388-5468) in both restatements on random and boundary inputs."""
+    import ctypes as C
+    from oracle import py_gates as pg
+    lib = ob.load()
+    rng = np.random.default_rng(9100 + seed)
+    now = 1_760_000_000_000
+    JMAX = (1 << 63) - 1
+
+    def arr(a, dt):
+        a = np.ascontiguousarray(a, dtype=dt)
+        return a, (a.ctypes.data_as(C.c_void_p) if len(a) else None)
+
+    seen = {k: set() for k in ("go", "fail", "loc", "churn", "reject", "reload", "publish")}
+    for _ in range(1500):
+        # goLocal
+        k = int(rng.integers(0, 5))
+        pods = rng.choice(12, size=k, replace=False)
+        times = rng.choice([0, now - 100, now - 1400, now - 1600, now - 1600, now - 50_000, now + 10], size=k)
+        self_pod = int(pods[rng.integers(0, k)]) if k and rng.random() < 0.7 else 11 - int(rng.integers(0, 3))
+        fs, hc, dn = (int(rng.random() < 0.6) for _ in range(3))
+        cp, cpp = arr(pods, np.int32)
+        ct, ctp = arr(times, np.int64)
+        got = bool(lib.orc_go_local(cpp, ctp, k, self_pod, fs, hc, dn, now))
+        want = pg.go_local(list(zip(map(int, pods), map(int, times))), self_pod, fs, hc, dn, now)
+        assert got == want, ("go_local", pods, times, self_pod, fs, hc, dn)
+        seen["go"].add(got)
+        # failure cap
+        nf = int(rng.integers(0, 6))
+        ft, ftp = arr(now - rng.choice([10, 449_999, 450_000, 450_001, 3_000_000], size=nf), np.int64)
+        got = bool(lib.orc_load_failures_breached(ftp, nf, now, 450_000))
+        assert got == pg.load_failures_breached([int(x) for x in ft], now, 450_000), ("failures", ft)
+        seen["fail"].add(got)
+        # location cap
+        nl = int(rng.integers(0, 9))
+        lp, lpp = arr(rng.choice(12, size=nl, replace=False), np.int32)
+        ex, exp_ = arr(rng.choice(12, size=int(rng.integers(0, 4)), replace=False), np.int32)
+        it, itp = arr(rng.random(12) < 0.85, np.uint8)
+        got = bool(lib.orc_load_locations_breached(lpp, nl, exp_, len(ex), itp))
+        assert got == pg.load_locations_breached([int(x) for x in lp], set(int(x) for x in ex), [bool(x) for x in it]), "locations"
+        seen["loc"].add(got)
+        # churn guard
+        cap = int(rng.choice([131072, 1_000_000]))
+        ws = int(cap * rng.choice([0.1, 0.94, 0.96, 0.999, 1.0, 1.2]))
+        oldest = int(rng.choice([-1, 0, JMAX, now - 1_000, now - 599_999, now - 600_000, now - 600_001, now - 4_500_000]))
+        mca = int(rng.choice([0, 1, 600_000]))
+        got = bool(lib.orc_churn_reject(mca, 6553, cap, ws, oldest, now))
+        assert got == pg.churn_reject(mca, 6553, cap, ws, oldest, now), ("churn", mca, cap, ws, oldest)
+        seen["churn"].add(got)
+        # loadLocal size prediction + early reject
+        st = np.zeros(1, dtype=ob.ORC_STATS)
+        st["total_capacity"] = int(rng.choice([0, 10_000_000, 5_000_000_000, 9_000_000_000]))
+        st["total_free"] = int(rng.choice([0, 1_000_000, 4_000_000_000]))
+        st["model_copy_count"] = int(rng.choice([0, 9, 10, 1000, 300_000]))
+        st["instance_count"] = int(rng.choice([0, 1, 2, 50]))
+        sd = {n: int(st[n][0]) for n in st.dtype.names}
+        hh, hint = int(rng.random() < 0.3), int(rng.choice([0, 1, 6400, 2_000_000, -5]))
+        lc, cut, pred = int(rng.integers(0, 20)), 10, int(rng.choice([6400, 1, 200_000, 0]))
+        wc, lu = int(rng.random() < 0.7), int(rng.choice([0, now - 5_000, now - 4_000_000, -3]))
+        rej = C.c_int(0)
+        got = int(lib.orc_load_local_initial_size(hh, hint, lc, cut, pred, st.ctypes.data_as(C.c_void_p), wc, lu, cap, ws, oldest,
+                                                  C.byref(rej)))
+        want, wrej = pg.load_local_initial_size(hh, hint, lc, cut, pred, sd, wc, lu, cap, ws, oldest)
+        assert (got, bool(rej.value)) == (want, wrej), ("initial size", hh, hint, lc, pred, sd, wc, lu, cap, ws, oldest)
+        seen["reject"].add(bool(rej.value))
+        # onEviction reload rule
+        ef = int(rng.random() < 0.2)
+        lt = int(rng.choice([-1, now - 1_000, now - 180_000, now - 180_001, now - 5_000_000]))
+        got = bool(lib.orc_reload_elsewhere(ef, lt, 90_000, now, st.ctypes.data_as(C.c_void_p)))
+        assert got == pg.reload_elsewhere(ef, lt, 90_000, now, sd), ("reload", ef, lt, sd)
+        seen["reload"].add(got)
+        # publish hysteresis
+        cur = np.zeros(1, dtype=ob.ORC_POD)
+        cur["capacity"] = int(rng.choice([131072, 1_000_000]))
+        cur["used"] = int(cur["capacity"][0] * rng.choice([0.0, 0.5, 0.94, 0.96]))
+        cur["lru_time"] = int(rng.choice([JMAX, now - 30_000, now - 400_000, now - 4_000_000]))
+        cur["count"], cur["loading_threads"] = int(rng.choice([0, 5, 40, 100])), int(rng.choice([3, 8]))
+        cur["loading_in_progress"], cur["rpm"] = int(rng.choice([0, 1, 8, 9, 12])), int(rng.choice([0, 50, 1000]))
+        cur["shutting_down"] = int(rng.random() < 0.1)
+        fresh = cur.copy()
+        if rng.random() < 0.8:
+            fresh["capacity"] = int(cur["capacity"][0] - rng.choice([0, 100, 50_000]))
+            fresh["used"] = int(cur["used"][0] * rng.choice([1.0, 1.1, 1.25]) + rng.choice([0, 0, 1]))
+            fresh["lru_time"] = int(cur["lru_time"][0] - rng.choice([0, 0, 10_000, 19_999, 20_000, 30_000])) \
+                if cur["lru_time"][0] != JMAX else int(rng.choice([JMAX, now - 1000]))
+            fresh["count"] = int(cur["count"][0] + rng.choice([0, 0, 1, 5, 9, 10, 16]))
+            fresh["loading_threads"] = int(rng.choice([cur["loading_threads"][0], 3]))
+            fresh["loading_in_progress"] = int(cur["loading_in_progress"][0] + rng.choice([0, 0, 1, 2, 3, -1]))
+            fresh["rpm"] = int(cur["rpm"][0] + rng.choice([0, 0, 5, 99, 100, 120]))
+            fresh["shutting_down"] = int(rng.random() < 0.1)
+        absent = rng.random() < 0.1
+        lp_ = now - int(rng.choice([500, 1_999, 2_000, 38_999, 39_000, 100_000, 160_000, 160_001, 170_000]))
+        force, pre = int(rng.random() < 0.5), int(rng.random() < 0.15)
+        got = bool(lib.orc_should_publish(None if absent else cur.ctypes.data_as(C.c_void_p), fresh.ctypes.data_as(C.c_void_p), now,
+                                          lp_, force, pre, 6553))
+        cd = None if absent else {n: int(cur[n][0]) for n in cur.dtype.names}
+        want = pg.should_publish(cd, {n: int(fresh[n][0]) for n in fresh.dtype.names}, now, lp_, force, pre, 6553)
+        assert got == want, ("publish", cd, fresh, now - lp_, force, pre)
+        seen["publish"].add(got)
+    assert all(v == {False, True} for v in seen.values()), seen
