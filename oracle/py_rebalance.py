@@ -1,0 +1,217 @@
+"""Second, independent restatement of three batch rebalancers (test infrastructure, never imported by the product):
+rateTrackingTask's scale-up decisions (MM.java:5636-5856), the janitor's scale-down (MM.java:6110-6145 with
+removeModelCopies :6197-6310 and removeSecondModelCopy :6314-6335) and preShutdown's migration order (:6985-7040).
+Written from the Java text in plain Python ints with Java's wrap / truncation semantics, and compared with the C
+restatement (oracle/mm_rebalance_oracle.c) on random fleets by tests/test_oracle_cross.py.
+
+Inputs are plain Python structures:
+  pods[i]    dict(rpm, shutting_down, in_table)            (in_table: instanceInfo.get(iid) != null)
+  models[m]  dict(type, last_used, loaded=[(pod, loadStart)...] in instance-id order, failed=[(pod, time)...])
+  entries[e] dict(model (-1: no ModelRecord), weight, last_used, interval_count, last_heavy_time, last_unload_time,
+                  earlier_use_iteration, last_used_iteration, failed)
+  stats      dict(total_capacity, total_free, global_lru, instance_count, model_copy_count)
+"""
+from oracle.py_oracle import _i, _jdiv, _l
+
+SECOND_COPY_REMOVE_MAX_AGE_MS = 10 * 3_600_000  # MM.java:257
+
+
+def _loaded_since(mr, cutoff, ignore):  # MM.java:5860-5871
+    for pod, start in mr["loaded"]:
+        if ignore is not None and pod == ignore:
+            continue
+        if start is not None and start > cutoff:
+            return True
+    return False
+
+
+def scaleup(pods, order, stats, type_stats, has_type_constraints, models, entries, p):
+    """-> (list of dict(action, copies, timestamp, new_i1, new_i2, heavy, rpm), overloaded set, returned_early).
+    action 0 none, 1 second copy (ensureLoadedInternalAsync(id, lastTime, weight, excludeThisInstance, 0)),
+    2 scale up by `copies` (timestamp = now + 20 s)."""
+    outs = [dict(action=0, copies=0, timestamp=0, new_i1=e["earlier_use_iteration"], new_i2=e["last_used_iteration"],
+                 heavy=0, rpm=0) for e in entries]
+    now, last_time = p["now"], p["last_check_time"]
+    time_delta = _l(now - last_time)
+    if _l(time_delta * 5) < _l(p["rate_check_interval_ms"] * 3):
+        return outs, set(), True
+    lower = _i(p["iteration_counter"] - p["second_copy_max_age_iters"])
+    upper = _i(p["iteration_counter"] - p["second_copy_min_age_iters"])
+    inst_count = stats["instance_count"]
+    if inst_count < 2:
+        return outs, set(), True
+    if not entries:                                    # usedSinceLastRun.isEmpty()
+        return outs, set(), True
+    new_copies_timestamp = _l(now + 20_000)
+    scale_up_rpms = p["scale_up_rpm_threshold"]
+    heavy_rpms = _jdiv(_i(scale_up_rpms * 3), 4)
+    exclude_set = None
+    for e, ce in enumerate(entries):
+        o = outs[e]
+        try:
+            count = ce["interval_count"]
+            mr = models[ce["model"]] if ce["model"] >= 0 else None
+            cluster_stats = stats
+            if has_type_constraints and mr is not None:       # typeSetStats(ce.modelInfo.serviceType)
+                t = mr["type"]
+                cluster_stats = type_stats[t if 0 <= t < len(type_stats) else 0]
+            suitable = inst_count
+            if has_type_constraints:
+                suitable = cluster_stats["instance_count"]
+                if suitable < 2:
+                    continue
+            rpm = _i(_jdiv(_l(count * 60_000), time_delta))
+            o["rpm"] = rpm
+            if rpm > heavy_rpms:
+                o["heavy"] = 1
+            if mr is None:
+                continue
+            loaded_count = len(mr["loaded"])
+            if loaded_count == 0:
+                continue
+            failed_count = len(mr["failed"])
+            candidates = suitable - (loaded_count + failed_count)
+            if candidates <= 0:
+                continue
+            if loaded_count == 1:
+                i1, i2 = ce["earlier_use_iteration"], ce["last_used_iteration"]
+                i1_in = i2_in = False
+                if i2 >= lower and i1 <= upper:
+                    i1_in = i1 >= lower
+                    i2_in = i2 <= upper
+                if i2_in or not i1_in:
+                    o["new_i1"] = i2
+                o["new_i2"] = p["iteration_counter"]
+                if i1_in or i2_in:
+                    if cluster_stats["total_capacity"] == 0:
+                        raise ZeroDivisionError        # caught like the RuntimeException at :5810
+                    if (_jdiv(_l(10 * cluster_stats["total_free"]), cluster_stats["total_capacity"]) >= 1
+                            or _l(now - cluster_stats["global_lru"]) > p["second_copy_lru_threshold_ms"]):
+                        o["action"], o["copies"], o["timestamp"] = 1, 1, last_time
+                        continue
+            if rpm < scale_up_rpms:
+                continue
+            recent_cutoff = _l(now - _l(time_delta + p["rate_check_interval_ms"] + 2 * p["assume_completed_ms"]))
+            if _loaded_since(mr, recent_cutoff, p["self_pod"]):
+                continue
+            if exclude_set is None:                     # getExcludeSet(), :5835-5856
+                max_rpm = max(_i(scale_up_rpms * 4), _i(p["our_rpm"] - _i(2 * scale_up_rpms)))
+                exclude_set = set()
+                for iid in order:
+                    if iid == p["self_pod"]:
+                        continue
+                    if pods[iid]["rpm"] > max_rpm:
+                        exclude_set.add(iid)
+            excluded_count = len(exclude_set)
+            if excluded_count != 0:
+                held = {pod for pod, _ in mr["loaded"]} | {pod for pod, _ in mr["failed"]}
+                for iid in exclude_set:
+                    if iid not in held:
+                        candidates -= 1
+                candidates -= excluded_count
+                if candidates <= 0:
+                    continue
+            if scale_up_rpms == 0:
+                raise ZeroDivisionError
+            copies = min(_jdiv(rpm, scale_up_rpms), candidates)
+            if copies > 2:
+                copies = min(copies, _jdiv(suitable, 3))
+            o["action"], o["copies"], o["timestamp"] = 2, copies, new_copies_timestamp
+        except ZeroDivisionError:
+            continue
+    return outs, (exclude_set or set()), False
+
+
+def scaledown(pods, pos_of, stats, models, entries, p):
+    """-> list of bool (removeModelCopies returned true).  entries = scaleCopiesCandidates, oldest first."""
+    removed_out = [False] * len(entries)
+    if p["shutting_down"]:
+        return removed_out
+    now = p["now"]
+    max_weight = _jdiv(p["adjusted_cache_capacity"], 20)
+    removed_count = 0
+    for e, ce in enumerate(entries):
+        weight = ce["weight"]
+        can_remove = removed_count == 0 or weight <= max_weight
+        removed = _remove_model_copies(pods, pos_of, stats, models, ce, ce["last_used"], now, can_remove, p)
+        if removed:
+            removed_out[e] = True
+            removed_count += 1
+            max_weight -= weight
+    return removed_out
+
+
+def _remove_model_copies(pods, pos_of, stats, models, ce, last_used, now, can_remove, p):
+    if last_used == 0:
+        return False
+    if ce["model"] < 0:
+        return False                                    # never became a candidate: no ModelRecord
+    mr = models[ce["model"]]
+    num = len(mr["loaded"])
+    if not can_remove or num < 2:
+        return False
+    if stats["total_capacity"] == 0 or _jdiv(_l(stats["total_free"] * 100), stats["total_capacity"]) > 5:
+        return False
+    other = None
+    for iid, _ in mr["loaded"]:
+        if iid != p["self_pod"]:
+            ir = pods[iid]
+            if ir["in_table"] and not ir["shutting_down"]:
+                other = iid
+                break
+    if other is None:
+        return False
+    if num == 2:
+        last_heavy = ce["last_heavy_time"]
+        cache_age = _l(now - stats["global_lru"])
+        scale_down_age = _jdiv(cache_age, 10)
+        if last_heavy == 0 or _l(now - last_heavy) < _jdiv(cache_age, 5):
+            scale_down_age = min(SECOND_COPY_REMOVE_MAX_AGE_MS, scale_down_age)
+        if _l(now - last_used) > scale_down_age:
+            # removeSecondModelCopy
+            sp = p["self_pod"]
+            if sp < 0 or not pods[sp]["in_table"] or pods[sp]["shutting_down"]:
+                return False
+            if pos_of[other] > pos_of[sp]:              # PLACEMENT_ORDER.compare(other, this) > 0
+                return False
+            return True
+        return False
+    last_unload = ce["last_unload_time"]
+    if last_unload > 0 and _l(now - last_unload) < 8 * p["rate_check_interval_ms"]:
+        return False
+    if _loaded_since(mr, _l(now - 1_800_000), None):
+        return False
+    min_age = _jdiv(_l(_l(3 * stats["global_lru"]) + 10_400_000), 100)
+    if min_age < 600_000:
+        min_age = 600_000
+    elif min_age > 18_000_000:
+        min_age = 18_000_000
+    if _l(now - ce["last_heavy_time"]) < min_age:
+        return False
+    since = _l(now - p["last_check_time"])
+    if since < _jdiv(p["rate_check_interval_ms"], 10):
+        return False
+    cnt = ce["interval_count"]
+    rpm = 0 if cnt == 0 else _jdiv(_l(60_000 * cnt), since)
+    threshold = p["scale_up_rpm_threshold"]
+    if rpm > _jdiv(threshold * 2, 3):
+        return False
+    return True
+
+
+def migration(models, entries, self_pod, now, cutoff_age_ms):
+    """-> (trigger[], wait[]): triggerNewModelCopyElsewhere is called / the shutdown waits for that copy."""
+    cutoff = _l(now - cutoff_age_ms)
+    act, wait = [], []
+    for ce in entries:
+        a = w = False
+        mr = models[ce["model"]] if ce["model"] >= 0 else None
+        if mr is not None and any(pod == self_pod for pod, _ in mr["loaded"]):
+            if not ce["failed"]:                        # ce == null || ce.isFailed() -> return null
+                lru_time = ce["last_used"]
+                if lru_time > 0:
+                    a = True
+                    w = lru_time >= cutoff              # (when the status comes back LOADING)
+        act.append(a)
+        wait.append(w)
+    return act, wait

@@ -348,3 +348,80 @@ def test_request_guards_c_vs_python(seed):
         assert got == want, ("publish", cd, fresh, now - lp_, force, pre)
         seen["publish"].add(got)
     assert all(v == {False, True} for v in seen.values()), seen
+
+
+@pytest.mark.parametrize("seed,pods,used", [(0, 12, 0.5), (1, 200, 0.97), (2, 200, 0.2), (3, 1, 0.5), (4, 60, 0.99)])
+def test_rebalancers_c_vs_python(seed, pods, used):
+    """rateTrackingTask's scale-up (MM.java:5636-5856), the janitor's scale-down (:6110-6335) and preShutdown's
+    migration order (:6985-7040) in both restatements, on the fleets and local caches the GPU parity test uses."""
+    from modelmesh_amd import _lib
+    from oracle import py_rebalance as pr
+    from tests.test_rebalance_gpu import _local_entries, _rebalance_fleet
+    fleet, rng = _rebalance_fleet(seed, pods, 600, used)
+    now = fleet.now
+    entries = _local_entries(fleet, 0, rng, 800)
+    orc = ob.OracleFleet(fleet)
+    order = [int(x) for x in orc.order]
+    pos_of = {p: i for i, p in enumerate(order)}
+    BIG = 2**31 - 1
+    ppods = [dict(rpm=int(r["rpm"]), shutting_down=bool(r["flags"] & 1), in_table=not bool(r["flags"] & 4)) for r in fleet.pods]
+    pmodels = []
+    for m in fleet.models:
+        o, k, f = int(m["ent_off"]), int(m["n_loaded"]), int(m["n_failed"])
+        pmodels.append(dict(type=int(m["type"]), last_used=int(m["last_used"]),
+                            loaded=[(int(fleet.ent_pod[o + i]), int(fleet.ent_time[o + i])) for i in range(k)],
+                            failed=[(int(fleet.ent_pod[o + k + i]), int(fleet.ent_time[o + k + i])) for i in range(f)]))
+    pent = [dict(model=int(e["model"]), weight=int(e["weight"]), last_used=int(e["last_used"]),
+                 interval_count=int(e["interval_count"]), last_heavy_time=int(e["last_heavy_time"]),
+                 last_unload_time=int(e["last_unload_time"]), earlier_use_iteration=int(e["earlier_use_iteration"]),
+                 last_used_iteration=int(e["last_used_iteration"]), failed=bool(e["flags"] & 1)) for e in entries]
+    sd = lambda st: {n: int(st[n]) for n in st.dtype.names}  # noqa: E731
+    gstats = sd(orc.stats())
+    tstats = [sd(t) for t in ob.type_set_stats(fleet)]
+    seen = set()
+    for thr, our_rpm, last_check in ((2000, 100, now - 10_000), (100, 50_000, now - 9_000), (0, 0, now - 10_000),
+                                     (2000, 0, now - 1_000), (100, 0, now - 12_000)):
+        sp = np.zeros(1, dtype=_lib.SCALEUP_PARAMS)
+        sp["self_pod"], sp["iteration_counter"] = 0, 130
+        sp["second_copy_max_age_iters"], sp["second_copy_min_age_iters"] = 240, 42
+        sp["scale_up_rpm_threshold"], sp["our_rpm"] = thr, our_rpm
+        sp["now"], sp["last_check_time"], sp["rate_check_interval_ms"] = now, last_check, 10_000
+        sp["second_copy_lru_threshold_ms"], sp["assume_completed_ms"] = 72_000_000, 30_000
+        w_out, w_ov, w_sk = ob.scaleup_plan(fleet, entries, sp.view(ob.ORC_SCALEUP_PARAMS))
+        g_out, g_ov, g_sk = pr.scaleup(ppods, order, gstats, tstats, bool(fleet.n_types), pmodels, pent,
+                                       {n: int(sp[n][0]) for n in sp.dtype.names})
+        assert bool(w_sk) == g_sk
+        if g_sk:
+            continue
+        for f in ("action", "copies", "timestamp", "new_i1", "new_i2", "heavy", "rpm"):
+            got = np.array([o[f] for o in g_out])
+            assert np.array_equal(got, w_out[f]), (f, thr, np.nonzero(got != w_out[f])[0][:5])
+        if np.any(w_out["action"] == 2):
+            assert set(np.nonzero(w_ov)[0]) == g_ov
+        seen |= set(int(a) for a in w_out["action"])
+    if pods >= 200:
+        assert seen >= {0, 1, 2}
+
+    removed_any = False
+    for thr, cap, shut in ((2000, 200_000, 0), (2000, 1_000, 0), (10, 10_000_000, 0), (2000, 200_000, 1)):
+        dp = np.zeros(1, dtype=_lib.SCALEDOWN_PARAMS)
+        dp["self_pod"], dp["shutting_down"], dp["now"] = 0, shut, now
+        dp["last_check_time"], dp["rate_check_interval_ms"] = now - 7_000, 10_000
+        dp["adjusted_cache_capacity"], dp["scale_up_rpm_threshold"] = cap, thr
+        want = ob.scaledown_plan(fleet, entries, dp.view(ob.ORC_SCALEDOWN_PARAMS))
+        # instanceSetStats(): this instance's partition (bind.scaledown_plan does the same for the C call)
+        st = gstats
+        if fleet.n_types:
+            pts, _, pst = ob.partition_stats(fleet)
+            st = sd(pst[int(pts[0])]) if int(pts[0]) >= 0 else dict(total_capacity=0, total_free=0, global_lru=2**63 - 1,
+                                                                    instance_count=0, model_copy_count=0)
+        got = pr.scaledown(ppods, {p: pos_of.get(p, BIG) for p in range(fleet.n_pods)}, st, pmodels, pent,
+                           {n: int(dp[n][0]) for n in dp.dtype.names})
+        assert np.array_equal(np.array(got, np.uint8), want), (thr, cap, shut, np.nonzero(np.array(got, np.uint8) != want)[0][:5])
+        removed_any |= bool(want.any())
+    if pods >= 60 and used > 0.9:
+        assert removed_any
+
+    wa, ww = ob.migration_plan(fleet, entries, 0, now)
+    ga, gw = pr.migration(pmodels, pent, 0, now, 3_600_000)
+    assert np.array_equal(np.array(ga, np.uint8), wa) and np.array_equal(np.array(gw, np.uint8), ww)
