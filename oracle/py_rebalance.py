@@ -1,6 +1,7 @@
-"""Second, independent restatement of three batch rebalancers (test infrastructure, never imported by the product):
+"""Second, independent restatement of the batch rebalancers (test infrastructure, never imported by the product):
 rateTrackingTask's scale-up decisions (MM.java:5636-5856), the janitor's scale-down (MM.java:6110-6145 with
-removeModelCopies :6197-6310 and removeSecondModelCopy :6314-6335) and preShutdown's migration order (:6985-7040).
+removeModelCopies :6197-6310 and removeSecondModelCopy :6314-6335), preShutdown's migration order (:6985-7040) and the
+reaper's proactive loads (:6455-6488, :6574-6577, :6616-6747).
 Written from the Java text in plain Python ints with Java's wrap / truncation semantics, and compared with the C
 restatement (oracle/mm_rebalance_oracle.c) on random fleets by tests/test_oracle_cross.py.
 
@@ -215,3 +216,76 @@ def migration(models, entries, self_pod, now, cutoff_age_ms):
         act.append(a)
         wait.append(w)
     return act, wait
+
+
+def proactive(pods, global_stats, stats, in_subset, prohibited_types, skip, models, default_units, now):
+    """The reaper's proactive loads for one instance subset (MM.java:6455-6488 candidate collection with the rule of
+    :6574-6577, triggerProactiveLoadsForInstanceSubset :6616-6747).  pods[i] = dict(capacity, used, loading_threads,
+    loading_in_progress, shutting_down) (clusterState holds only present rows); in_subset[i]: the row's
+    prohibitedTypes equal excludeTypes (None: no type constraints); prohibited_types: set of type rows (or None);
+    skip: set of candidates already nulled by earlier subsets.
+    -> (selected [(model, lastUsed)] in call order, info dict) or (None, info) when sizeEstimate == 0 throws."""
+    info = dict(size_estimate=0, free_count=0, total_count=0, n_candidates=0, n_selected=0, error=0, space_to_fill=0, cutoff=0)
+    free_count = total_count = 0
+    if stats["total_capacity"] > 0 and stats["total_free"] > 0:
+        if stats["model_copy_count"] < 3:
+            size_estimate = default_units
+        else:
+            average = _jdiv(_i(_l(stats["total_capacity"] - stats["total_free"])), stats["model_copy_count"])
+            size_estimate = average if stats["model_copy_count"] > 10 else _jdiv(_i(average + default_units), 2)
+        info["size_estimate"] = size_estimate
+        if size_estimate == 0:
+            info["error"] = 1                            # spaceToFill / sizeEstimate throws
+            return None, info
+        space = 0
+        for i, ir in enumerate(pods):
+            if ir["shutting_down"]:
+                continue
+            if in_subset is not None and not in_subset[i]:
+                continue
+            max_loads = _i(_i(ir["loading_threads"] * 50) - ir["loading_in_progress"])
+            if max_loads <= 0:
+                continue
+            reserve = _jdiv(ir["capacity"], 8)
+            avail = _l(max(0, _l(ir["capacity"] - ir["used"])) - reserve)
+            if avail > 0:
+                space = _l(space + min(avail, _i(max_loads * size_estimate)))
+        space = _jdiv(space, 2)
+        info["space_to_fill"] = space
+        free_count = _i(_jdiv(space, size_estimate))
+        total_count = max(free_count, _i(_jdiv(stats["total_capacity"], _l(20 * size_estimate))))
+    info["free_count"], info["total_count"] = free_count, total_count
+    lru = stats["global_lru"]
+    age = 0 if lru == 0 else _l(now - lru)
+    cutoff = 0 if lru == (1 << 63) - 1 else _l(lru + max(_jdiv(age, 3), 1_200_000))
+    info["cutoff"] = cutoff
+    # candidate collection (pruneModelRegistry): only when the cluster has capacity; globalLru == 0 <=> free space
+    cand_enabled = global_stats["total_capacity"] > 0
+    g_lru = 0 if global_stats["total_free"] > 0 else global_stats["global_lru"]
+    to_load = []                                         # TreeSet<ModelToLoad>: descending lastUsed, equal = duplicate
+    for i, mr in enumerate(models):
+        if not (cand_enabled and not mr["loaded"] and len(mr["failed"]) < 2 and (g_lru == 0 or mr["last_used"] > g_lru)):
+            continue
+        info["n_candidates"] += 1
+        if skip and i in skip:
+            continue
+        if prohibited_types is not None and mr["type"] in prohibited_types:
+            continue
+        last_used = mr["last_used"]
+        if total_count > 0 and (free_count > 0 or last_used > cutoff):
+            if len(to_load) < total_count or to_load[-1][1] < last_used:
+                if all(lu != last_used for _, lu in to_load):
+                    to_load.append((i, last_used))
+                    to_load.sort(key=lambda t: -t[1])
+                if len(to_load) > total_count:
+                    to_load.pop()
+    selected = []
+    fs = free_count
+    for i, lu in to_load:
+        if fs > 0:
+            fs -= 1
+        elif lu < cutoff:
+            break
+        selected.append((i, lu))
+    info["n_selected"] = len(selected)
+    return selected, info

@@ -425,3 +425,42 @@ def test_rebalancers_c_vs_python(seed, pods, used):
     wa, ww = ob.migration_plan(fleet, entries, 0, now)
     ga, gw = pr.migration(pmodels, pent, 0, now, 3_600_000)
     assert np.array_equal(np.array(ga, np.uint8), wa) and np.array_equal(np.array(gw, np.uint8), ww)
+
+
+@pytest.mark.parametrize("seed,pods,models,used", [(0, 8, 300, 0.5), (1, 64, 3000, 0.2), (2, 300, 4000, 0.9), (3, 300, 4000, 0.99),
+                                                  (5, 5, 50, 0.0)])
+def test_proactive_plan_c_vs_python(seed, pods, models, used):
+    """The reaper's proactive loads (MM.java:6455-6488, :6574-6577, :6616-6747) in both restatements, cluster-wide and
+    per ProhibitedTypeSet partition with the skip list, on the GPU parity test's fleets."""
+    from oracle import py_rebalance as pr
+    from tests.test_rebalance_gpu import _plan_fleet
+    fleet = _plan_fleet(seed, pods, models, used)
+    now = fleet.now
+    orc = ob.OracleFleet(fleet)
+    sd = lambda st: {n: int(st[n]) for n in st.dtype.names}  # noqa: E731
+    ppods = [dict(capacity=int(r["capacity"]), used=int(r["used"]), loading_threads=int(r["loading_threads"]),
+                  loading_in_progress=int(r["loading_in_progress"]), shutting_down=bool(r["flags"] & 5)) for r in fleet.pods]
+    pmodels = []
+    for m in fleet.models:
+        o, k, f = int(m["ent_off"]), int(m["n_loaded"]), int(m["n_failed"])
+        pmodels.append(dict(type=int(m["type"]), last_used=int(m["last_used"]), loaded=list(range(k)), failed=list(range(f))))
+    g = sd(orc.stats())
+    plans = [(-1, g, None, None)]
+    if fleet.n_types:
+        pts, sets, pst = ob.partition_stats(fleet)
+        plans += [(k, sd(pst[k]), [int(x) == k for x in pts], set(int(t) for t in sets[k])) for k in range(len(sets))]
+    for default_units in (6400, 1):
+        taken = set()
+        for k, st, in_subset, prohibited in plans:
+            wm, wl_, wi = ob.proactive_plan(fleet, default_units, now, models, partition=k,
+                                            skip_models=np.array(sorted(taken), np.int32) if (k >= 0 and taken) else None)
+            sel, info = pr.proactive(ppods, g, st, in_subset, prohibited, taken if k >= 0 else None, pmodels, default_units, now)
+            for f in ("size_estimate", "free_count", "total_count", "error", "space_to_fill", "cutoff"):
+                assert info[f] == int(wi[f]), (k, f, info, wi)
+            if info["error"]:
+                assert sel is None and len(wm) == 0
+                continue
+            assert info["n_candidates"] == int(wi["n_candidates"]) and info["n_selected"] == int(wi["n_selected"])
+            assert [i for i, _ in sel] == list(wm) and [lu for _, lu in sel] == list(wl_), k
+            if k >= 0:
+                taken |= set(int(x) for x in wm)
