@@ -421,9 +421,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pod-axis", action="store_true", help="skip the pod-axis sharded leg")
     ap.add_argument("--no-secondary", action="store_true", help="skip the per-kernel leg (evict / serve / gates / ...)")
-    ap.add_argument("--streams", type=int, default=8,
+    ap.add_argument("--streams", type=int, default=16,
                     help="HIP streams the timed steps are issued on round-robin (a 100k-decision batch is 1564 "
-                         "wavefronts — too few to cover HBM latency on 256 CUs — so independent batches overlap)")
+                         "wavefronts — too few to cover HBM latency on 256 CUs — so independent batches overlap; "
+                         "measured per step: 8 streams 4.63 us, 12: 4.44, 16: 4.29, 24 / 32: the same as 16)")
     ap.add_argument("--leg-timeout", type=float, default=420.0,
                     help="watchdog for the additional legs (pod axis, latency, churn, per-kernel, cpu baseline): when "
                          "it fires rank 0 prints the line with the legs completed so far and every rank exits 0")

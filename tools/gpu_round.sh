@@ -23,12 +23,12 @@ bench2)
   tail -1 $OUT/bench2.json.log | cut -c1-600 ;;
 prof)
   # kernel stats of the bench command; --streams 1 so that every dispatch is back to back on one stream and the
-  # average duration is the one bench.py reports as roofline.kernel_ms (8 overlapping streams stretch dispatches)
+  # average duration is the one bench.py reports as roofline.kernel_ms (overlapping streams stretch dispatches)
   rm -rf $OUT/prof $OUT/prof8
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --kernel-only --steps 200 --warmup 20 --streams 1 > $OUT/prof_bench.log 2>&1
   f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats.csv && head -3 $OUT/kernel_stats.csv | cut -c1-160
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof8 -- python bench.py --kernel-only --steps 200 --warmup 20 > $OUT/prof8_bench.log 2>&1
-  f=$(find $OUT/prof8 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats_8streams.csv && head -2 $OUT/kernel_stats_8streams.csv | cut -c1-160
+  f=$(find $OUT/prof8 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats_16streams.csv && head -2 $OUT/kernel_stats_16streams.csv | cut -c1-160
   grep "^{" $OUT/prof_bench.log | python tools/benchline.py prof-run ;;
 pmc)
   rm -rf $OUT/pmc_fetch $OUT/pmc_write
