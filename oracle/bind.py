@@ -50,10 +50,39 @@ class OrcUbm(C.Structure):
 
 
 _lib = None
+_native = None
 
 
 def build():
     subprocess.check_call(["make", "-s", "-C", HERE])
+
+
+def load_native():
+    """The same sources rebuilt ON THIS BOX with -O2 -march=native (oracle/_native/, git-ignored), for the
+    cpu_baseline leg only: the shipped liboracle.so is built without -march because it travels to a host CPU
+    that may differ.  Returns (lib, flags string); falls back to the shipped build when no compiler is here."""
+    global _native
+    if _native is None:
+        out_dir = os.path.join(HERE, "_native")
+        out = os.path.join(out_dir, "liboracle_native.so")
+        srcs = [os.path.join(HERE, f) for f in ("mm_oracle.c", "mm_oracle_batch.c")]
+        flags = "-O2 -march=native"
+        try:
+            os.makedirs(out_dir, exist_ok=True)
+            subprocess.check_call(["gcc", "-O2", "-march=native", "-std=c11", "-fPIC", "-shared", "-o", out] + srcs +
+                                  ["-lpthread"], stderr=subprocess.DEVNULL)
+            lib = C.CDLL(out)
+        except Exception:
+            lib, flags = C.CDLL(LIB), "-O2 (shipped build; no compiler on this box)"
+        lib.orc_pool_create.restype = C.c_void_p
+        lib.orc_pool_create.argtypes = [C.c_int32, C.c_int32]
+        lib.orc_pool_destroy.restype = None
+        lib.orc_pool_destroy.argtypes = [C.c_void_p]
+        lib.orc_pool_place.restype = C.c_int
+        lib.orc_pool_place.argtypes = [C.c_void_p, C.POINTER(OrcSnapshot), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
+        _native = (lib, flags)
+    return _native
 
 
 def load() -> C.CDLL:
@@ -257,6 +286,35 @@ class OracleFleet:
         self.lib.orc_place_batch(C.byref(self.snap), _p(models), _p(ent), _p(reqs), _p(extra), len(reqs),
                                  int(now), _p(outs), int(threads), _p(lat) if latencies else None)
         return (outs, lat) if latencies else outs
+
+    def lean_pool(self, threads: int):
+        """A persistent worker pool over orc_place_lean (the algorithm without the checker's audit machinery), in
+        the -march=native build.  Returns a callable place(reqs, extra, now, latencies=False) -> outs [, lat_ns];
+        outs['hash'] carries n_remaining (this path computes no audit hash).  Call .close() when done."""
+        lib, flags = load_native()
+        pool = lib.orc_pool_create(int(threads), int(self.snap.n_pods))
+        if not pool:
+            raise RuntimeError("orc_pool_create failed")
+        fleet, snap = self.fleet, self.snap
+        models = np.ascontiguousarray(fleet.models)
+        ent = np.ascontiguousarray(fleet.ent_pod if len(fleet.ent_pod) else np.zeros(1, np.int32), dtype=np.int32)
+
+        def place(reqs, extra, now, latencies=False):
+            from modelmesh_amd._lib import PLACE_OUT  # dtype only
+            reqs = np.ascontiguousarray(reqs)
+            extra = np.ascontiguousarray(extra if extra is not None and len(extra) else np.zeros(1, np.int32), dtype=np.int32)
+            outs = np.zeros(len(reqs), dtype=PLACE_OUT)
+            lat = np.zeros(len(reqs), dtype=np.float64) if latencies else None
+            rc = lib.orc_pool_place(pool, C.byref(snap), _p(models), _p(ent), _p(reqs), _p(extra), len(reqs), int(now),
+                                    _p(outs), _p(lat) if latencies else None)
+            if rc != 0:
+                raise RuntimeError("orc_pool_place failed")
+            return (outs, lat) if latencies else outs
+
+        place.close = lambda: lib.orc_pool_destroy(pool)
+        place.flags = flags
+        place.keep = (models, ent)
+        return place
 
     def stats(self):
         out = np.zeros(1, dtype=ORC_STATS)

@@ -224,8 +224,13 @@ uint32_t orc_shortlist_hash(const int32_t *pos_of, const int32_t *cand, int32_t 
 #define ONE_DAY_MS (24LL * 3600 * 1000)
 #define FIVE_DAYS_MS (5 * ONE_DAY_MS)
 
-/* CacheMissForwardingLB.getNext, MM.java:4776-5005 */
-int orc_place(const orc_snapshot *s, const orc_place_req *r, orc_place_out *o, int32_t *cand_out)
+/* CacheMissForwardingLB.getNext, MM.java:4776-5005.
+ * One body, two callers: orc_place (the CHECKER: allocates its lists per call, rebuilds pos_of and
+ * computes the audit hash of the shortlist — machinery the reference does not have) and
+ * orc_place_lean (the algorithm alone, on caller-owned scratch: what bench.py times as cpu_baseline).
+ * `sc` holds the four lists of P + 1 ints; `pos_of` non-NULL = compute the audit hash. */
+static int place_impl(const orc_snapshot *s, const orc_place_req *r, orc_place_out *o, int32_t *cand_out,
+                      int32_t *const sc[4], int32_t *pos_of)
 {
     const int32_t P = s->n_pods;
     o->chosen = ORC_NONE;
@@ -234,10 +239,7 @@ int orc_place(const orc_snapshot *s, const orc_place_req *r, orc_place_out *o, i
     o->n_remaining = 0;
     o->hash = 0;
 
-    int32_t *candidates = (int32_t *)malloc((size_t)(P + 1) * sizeof(int32_t));
-    int32_t *inst_req_load = (int32_t *)malloc((size_t)(P + 1) * sizeof(int32_t));
-    int32_t *replay = (int32_t *)malloc((size_t)(P + 1) * sizeof(int32_t));
-    int32_t *pos_of = (int32_t *)malloc((size_t)((s->n_rows > P ? s->n_rows : P) + 1) * sizeof(int32_t));
+    int32_t *candidates = sc[0], *inst_req_load = sc[1], *replay = sc[2];
     int32_t ccount = 0, n_replay = 0;
     int32_t best_iid = -1; /* bestIid; reported in o->best on every path once known */
     int rc = 0;
@@ -348,7 +350,8 @@ int orc_place(const orc_snapshot *s, const orc_place_req *r, orc_place_out *o, i
 
     if (ccount == 0) goto done; /* :4941-4943 */
 
-    for (int32_t i = 0; i < P; i++) pos_of[s->order[i]] = i;
+    if (pos_of)
+        for (int32_t i = 0; i < P; i++) pos_of[s->order[i]] = i;
     if (cand_out) memcpy(cand_out, candidates, (size_t)ccount * sizeof(int32_t));
     o->n_candidates = ccount;
 
@@ -358,7 +361,7 @@ int orc_place(const orc_snapshot *s, const orc_place_req *r, orc_place_out *o, i
     if (ccount == 1) {
         chosen = candidates[0];
     } else {
-        int32_t *cand = (int32_t *)malloc((size_t)ccount * sizeof(int32_t));
+        int32_t *cand = sc[3];
         memcpy(cand, candidates, (size_t)ccount * sizeof(int32_t));
         if (last_used_ago < FIVE_DAYS_MS) { /* :4956 */
             int32_t mn = inst_req_load[0];
@@ -384,10 +387,9 @@ int orc_place(const orc_snapshot *s, const orc_place_req *r, orc_place_out *o, i
             chosen = cand[i];
             if (chosen != -1 && index == j++) break;
         }
-        free(cand);
     }
     o->n_remaining = remaining;
-    o->hash = orc_shortlist_hash(pos_of, candidates, ccount, remaining, P);
+    if (pos_of) o->hash = orc_shortlist_hash(pos_of, candidates, ccount, remaining, P);
     if (!favour_self && r->self >= 0 && r->self == chosen) { /* :4989-4991 */
         o->chosen = ORC_SELF;
         goto done;
@@ -396,11 +398,26 @@ int orc_place(const orc_snapshot *s, const orc_place_req *r, orc_place_out *o, i
 
 done:
     o->best = best_iid;
-    free(candidates);
-    free(inst_req_load);
-    free(replay);
-    free(pos_of);
     return rc;
+}
+
+int orc_place(const orc_snapshot *s, const orc_place_req *r, orc_place_out *o, int32_t *cand_out)
+{
+    const int32_t P = s->n_pods;
+    const size_t list = (size_t)(P + 1), rows = (size_t)((s->n_rows > P ? s->n_rows : P) + 1);
+    int32_t *mem = (int32_t *)malloc((4 * list + rows) * sizeof(int32_t));
+    int32_t *const sc[4] = {mem, mem + list, mem + 2 * list, mem + 3 * list};
+    const int rc = place_impl(s, r, o, cand_out, sc, mem + 4 * list);
+    free(mem);
+    return rc;
+}
+
+/* scratch: 4 * (n_pods + 1) ints owned by the caller (one per thread); o->hash stays 0 */
+int orc_place_lean(const orc_snapshot *s, const orc_place_req *r, orc_place_out *o, int32_t *scratch)
+{
+    const size_t list = (size_t)(s->n_pods + 1);
+    int32_t *const sc[4] = {scratch, scratch + list, scratch + 2 * list, scratch + 3 * list};
+    return place_impl(s, r, o, NULL, sc, NULL);
 }
 
 /* ---------------------------------------------------------------------- */

@@ -120,6 +120,11 @@ int orc_sort_pods(const orc_pod *pods, int32_t n, int64_t min_space_units,
  * shortlist before the rpm filter. */
 int orc_place(const orc_snapshot *s, const orc_place_req *r, orc_place_out *o, int32_t *cand_out);
 
+/* The same algorithm without the checker's audit machinery (no per-call allocation, no pos_of rebuild,
+ * no shortlist hash: o->hash = 0): the CPU port bench.py times as cpu_baseline.  scratch = 4 * (n_pods + 1)
+ * ints owned by the caller. */
+int orc_place_lean(const orc_snapshot *s, const orc_place_req *r, orc_place_out *o, int32_t *scratch);
+
 /* Commutative hash of the shortlist as a bitmap over clusterState positions. */
 uint32_t orc_shortlist_hash(const int32_t *pos_of, const int32_t *cand, int32_t n,
                             int32_t n_remaining, int32_t n_pods);
@@ -174,6 +179,15 @@ typedef struct {
 int orc_place_batch(const orc_snapshot *snap, const orc_flat_model *models, const int32_t *ent_pod,
                     const orc_flat_req *reqs, const int32_t *extra, int32_t n, int64_t now,
                     orc_flat_out *outs, int32_t n_threads, double *lat_ns);
+
+/* cpu_baseline: a persistent pool of n_threads workers (created once, parked on a condition variable between
+ * batches) running orc_place_lean over dynamically dealt chunks of the request table. */
+typedef struct orc_pool orc_pool;
+orc_pool *orc_pool_create(int32_t n_threads, int32_t max_pods);
+void orc_pool_destroy(orc_pool *p);
+int orc_pool_place(orc_pool *p, const orc_snapshot *snap, const orc_flat_model *models, const int32_t *ent_pod,
+                   const orc_flat_req *reqs, const int32_t *extra, int32_t n, int64_t now, orc_flat_out *outs,
+                   double *lat_ns);
 
 /* ---------- local LRU cache + eviction (clhm) --------------------------- */
 typedef struct {
