@@ -69,10 +69,10 @@ struct DevBuf {
 
 // device storage of one committed snapshot
 struct SnapBufs {
-    DevBuf pods, lru, rem, cnt, rpm, orig, pos_of, elig, elig_nors, pref, has_pref, fullw, ge, pc, ph, nz;
+    DevBuf pods, lru, rem, cnt, rpm, orig, pos_of, elig, elig_nors, pref, has_pref, fullw, ge, pc, ph, nz, heads;
     void release()
     {
-        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge, &pc, &ph, &nz})
+        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge, &pc, &ph, &nz, &heads})
             b->release();
     }
 };
@@ -129,6 +129,7 @@ struct mmp_ctx {
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     double last_kernel_ms = -1.0;
     int32_t force_wave = 0;  // MMP_FORCE_WAVE=1: every decision takes the wave-per-decision kernel (tests)
+    int32_t no_heads = 0;    // MMP_NO_HEADS=1: decisions do not use the per-type head records (tests: lane_decide_r alone)
 
     // host staging (inputs of the next commit)
     std::vector<mmp_pod_row> pods;
@@ -335,6 +336,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     A.reqs = static_cast<const mmp_place_req *>(d_reqs);
     A.models = c->models.as<mmp_model_row>();
     A.rmodels = cur_side(c).rmodels_ok ? cur_side(c).rmodels.as<ResolvedModel>() : nullptr;
+    A.heads = (c->no_heads || c->n_shards > 0) ? nullptr : c->sb[c->cur].heads.as<TypeHead>();
     A.ent_pod = c->ent_pod.as<int32_t>();
     A.extra = static_cast<const int32_t *>(d_extra);
     A.outs = static_cast<mmp_place_out *>(d_outs);
@@ -394,6 +396,7 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     if (!c) return fail(nullptr, MMP_ENOMEM, "out of memory");
     c->cfg = *cfg;
     if (const char *fw = getenv("MMP_FORCE_WAVE")) c->force_wave = fw[0] == '1';
+    if (const char *nh = getenv("MMP_NO_HEADS")) c->no_heads = nh[0] == '1';
     if (const char *rm = getenv("MMP_RANK_MODE")) c->rank_mode = atoi(rm);
     if (const char *lm = getenv("MMP_LONG_MODE")) c->long_mode = atoi(lm);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
@@ -961,6 +964,7 @@ int mmp_snapshot_commit(mmp_ctx *c)
     HIP_TRY(c, B.pc.ensure((size_t)2 * T * (W + 1) * 4));
     HIP_TRY(c, B.nz.ensure((size_t)2 * T * (W + 1) * 4));
     HIP_TRY(c, B.ph.ensure((size_t)2 * T * (W + 1) * 8));
+    HIP_TRY(c, B.heads.ensure((size_t)T * sizeof(TypeHead)));
     HIP_TRY(c, c->rank.ensure(padded * 4));
     HIP_TRY(c, c->occupancy.ensure(padded * 4));
     HIP_TRY(c, c->flag.ensure(sizeof(int32_t)));
@@ -1001,6 +1005,28 @@ int mmp_snapshot_commit(mmp_ctx *c)
     StatsAcc init{};
     init.global_lru = INT64_MAX;
     HIP_TRY(c, hipMemcpyAsync(N.stats_acc.p, &init, sizeof init, hipMemcpyHostToDevice, st));
+
+    Snap S{};
+    S.P = P;
+    S.W = W;
+    S.T = T;
+    S.any_rs = c->replaced_rs.size() > 0;
+    S.min_space = min_space;
+    S.lru = B.lru.as<int64_t>();
+    S.rem = B.rem.as<int64_t>();
+    S.cnt = B.cnt.as<int32_t>();
+    S.rpm = B.rpm.as<int32_t>();
+    S.orig = B.orig.as<int32_t>();
+    S.pos_of = B.pos_of.as<int32_t>();
+    S.elig = B.elig.as<uint64_t>();
+    S.elig_nors = B.elig_nors.as<uint64_t>();
+    S.pref = B.pref.as<uint64_t>();
+    S.has_pref = B.has_pref.as<uint8_t>();
+    S.fullw = B.fullw.as<uint64_t>();
+    S.ge = B.ge.as<uint64_t>();
+    S.pc = B.pc.as<int32_t>();
+    S.nz = B.nz.as<int32_t>();
+    S.ph = B.ph.as<uint64_t>();
 
     bool next_long = c->long_mode == 1;
     KT_BEGIN(c, st);
@@ -1062,8 +1088,11 @@ int mmp_snapshot_commit(mmp_ctx *c)
                            B.pc.as<int32_t>(), B.ph.as<uint64_t>(), B.nz.as<int32_t>(), N.stats_acc.as<StatsAcc>());
         hipLaunchKernelGGL(cluster_stats_kernel, dim3(std::min(div_up(P, 256), 512)), dim3(256), 0, st,
                            B.pods.as<mmp_pod_row>(), P, min_space, N.stats_acc.as<StatsAcc>());
+        // the type-level part of getNext, once per type row (place_kernel.hpp: TypeHead)
+        hipLaunchKernelGGL(build_heads_kernel, dim3(T), dim3(64), 0, st, S, B.heads.as<TypeHead>());
         HIP_TRY(c, hipGetLastError());
     } else {
+        HIP_TRY(c, hipMemsetAsync(B.heads.p, 0, (size_t)T * sizeof(TypeHead), st));
         HIP_TRY(c, hipMemsetAsync(B.pc.p, 0, (size_t)2 * T * (W + 1) * 4, st));
         HIP_TRY(c, hipMemsetAsync(B.nz.p, 0, (size_t)2 * T * (W + 1) * 4, st));
         HIP_TRY(c, hipMemsetAsync(B.ph.p, 0, (size_t)2 * T * (W + 1) * 8, st));
@@ -1089,27 +1118,6 @@ int mmp_snapshot_commit(mmp_ctx *c)
                     "PLACEMENT_ORDER is not a total order on these rows (a full instance with lruTime <= "
                     "2*minChurnAgeMs next to differing instanceVersions); snapshot not published");
 
-    Snap S{};
-    S.P = P;
-    S.W = W;
-    S.T = T;
-    S.any_rs = n_rs > 0;
-    S.min_space = min_space;
-    S.lru = B.lru.as<int64_t>();
-    S.rem = B.rem.as<int64_t>();
-    S.cnt = B.cnt.as<int32_t>();
-    S.rpm = B.rpm.as<int32_t>();
-    S.orig = B.orig.as<int32_t>();
-    S.pos_of = B.pos_of.as<int32_t>();
-    S.elig = B.elig.as<uint64_t>();
-    S.elig_nors = B.elig_nors.as<uint64_t>();
-    S.pref = B.pref.as<uint64_t>();
-    S.has_pref = B.has_pref.as<uint8_t>();
-    S.fullw = B.fullw.as<uint64_t>();
-    S.ge = B.ge.as<uint64_t>();
-    S.pc = B.pc.as<int32_t>();
-    S.nz = B.nz.as<int32_t>();
-    S.ph = B.ph.as<uint64_t>();
     // a type only a few instances may host: its first candidate is usually beyond a lane scan's reach, and only the
     // long variant carries the prefix-table jump that finds it without the wave path
     if (c->long_mode < 0 && acc.sparse_types) next_long = true;
@@ -1739,6 +1747,7 @@ int mmp_shard_place_phase_dev(mmp_ctx *c, int32_t phase, const void *d_reqs, int
     A.reqs = static_cast<const mmp_place_req *>(d_reqs);
     A.models = c->models.as<mmp_model_row>();
     A.rmodels = nullptr;
+    A.heads = nullptr;
     A.ent_pod = c->ent_pod.as<int32_t>();
     A.extra = static_cast<const int32_t *>(d_extra);
     A.outs = static_cast<mmp_place_out *>(d_outs);
@@ -1780,6 +1789,7 @@ PlaceArgs shard_args(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_ex
     A.reqs = static_cast<const mmp_place_req *>(d_reqs);
     A.models = c->models.as<mmp_model_row>();
     A.rmodels = nullptr;
+    A.heads = nullptr;
     A.ent_pod = c->ent_pod.as<int32_t>();
     A.extra = static_cast<const int32_t *>(d_extra);
     A.outs = static_cast<mmp_place_out *>(d_outs);

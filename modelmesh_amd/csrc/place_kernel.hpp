@@ -23,6 +23,7 @@ namespace mmp {
 #define MMP_PLACE_WAVES 4  // measured on C3, 100k decisions per launch: see DESIGN.md §4.1 (workgroup size)
 #endif
 constexpr int kPlaceWaves = MMP_PLACE_WAVES;  // waves (decisions in flight) per workgroup
+constexpr int kPlaceBlock = kPlaceWaves * 64;
 
 // Phase clock (tools/phase_clock.py builds a second library with -DMMP_PHASE_CLOCK; the product build carries
 // none of it): wave-level s_memtime deltas between the markers of lane_decide / place_block, one row per wavefront.
@@ -74,10 +75,41 @@ struct __attribute__((aligned(16))) ResolvedModel {
 };
 static_assert(sizeof(ResolvedModel) == 32, "ResolvedModel is 32 bytes");
 
+// ---- per-type head records ------------------------------------------------------------------------
+// Everything getNext derives from the TYPE alone — the first eligible pod (bestEntry), the preference step
+// (case (a), MM.java:4828-4852), bestInst's row, bestIsFull, the count-break position of :4925-4926 and the
+// words of the candidate bitmap behind the best position — is the same for every request of that type whose own
+// exclusions and own instance do not touch those few positions.  commit() evaluates it once per type
+// (build_heads_kernel) into a 128-byte record; place_block stages the records of the first kHeadLds types into
+// LDS, and a decision then runs request -> resolved model row -> LDS -> orig[] instead of walking the bitmap
+// row, four columns, the preference row and a threshold row through L2 one dependent load after the other
+// (profiles/r1/phase_clock_place_batch_C3.txt: six such levels of 0.5-1.3 us).  Anything the record cannot
+// answer (an exclusion or the caller itself ON the best / count-break position, a shortlist that leaves the
+// record's window, case (b), the replica-set retry ...) falls through to lane_decide_r, which stays the
+// implementation of record.
+constexpr int kHeadWords = 6;  // 64-pod words of the candidate bitmap kept per type, starting at the best position's word
+constexpr int kHeadLds = 32;   // type rows staged in LDS (types beyond take lane_decide_r)
+struct __attribute__((aligned(16))) TypeHead {
+    int32_t valid;    // 0: every decision of this type takes lane_decide_r
+    int32_t best0;    // first eligible position (bestEntry, :4806)
+    int32_t bestpos;  // == best0, or the first preferred position behind it (case (a))
+    int32_t pcnt;     // first position > bestpos of D with count >= 10 && count > f + f/4 (kNoPos: none); kNoPos when bestIsFull
+    int64_t b_lru, b_rem;  // bestInst = the row at bestpos
+    int64_t e_lru, e_rem;  // bestEntry.getValue() = the row at best0 (curInst of the caller's own entry, :4909)
+    int32_t b_cnt, b_rpm, e_rpm;
+    int32_t best_idx;      // orig[bestpos]
+    uint32_t flags;        // bit 0 bestIsFull (:4811), bit 1 the type has preferred instances
+    int32_t nw;            // words of D[] that exist (the window is cut at the end of the table)
+    int32_t pad[2];
+    uint64_t D[kHeadWords];  // (elig & pref-if-any) words [bestpos >> 6, +nw): the shortlist's bitmap, no exclusions applied
+};
+static_assert(sizeof(TypeHead) == 128, "TypeHead is 128 bytes");
+
 struct PlaceArgs {
     const mmp_place_req *reqs;
     const mmp_model_row *models;
     const ResolvedModel *rmodels;  // null: not built (pod-axis shard contexts)
+    const TypeHead *heads;         // null: not built (pod-axis shard contexts, MMP_NO_HEADS=1)
     const int32_t *ent_pod;  // model entries: loaded ids then failed ids
     const int32_t *extra;    // per-request extra exclusions
     mmp_place_out *outs;
@@ -187,6 +219,88 @@ __device__ __forceinline__ int first_lru_break(const uint64_t *ew, int start, in
         if (b) return g * 64 + (__ffsll((unsigned long long)b) - 1);
     }
     return kNoPos;
+}
+
+// One wavefront per type row: the type-level part of getNext with no exclusions and no caller (see TypeHead).
+__global__ __launch_bounds__(64) void build_heads_kernel(Snap S, TypeHead *__restrict__ heads)
+{
+    const int t = blockIdx.x, lane = lane_id();
+    const int P = S.P, W = S.W;
+    const uint64_t *E = S.elig + (size_t)t * W;
+    TypeHead h;
+    h.valid = 0;
+    h.best0 = h.bestpos = -1;
+    h.pcnt = kNoPos;
+    h.b_lru = h.b_rem = h.e_lru = h.e_rem = 0;
+    h.b_cnt = h.b_rpm = h.e_rpm = 0;
+    h.best_idx = -1;
+    h.flags = 0;
+    h.nw = 0;
+    h.pad[0] = h.pad[1] = 0;
+#pragma unroll
+    for (int j = 0; j < kHeadWords; j++) h.D[j] = 0;
+    do {
+        const int best0 = first_set_from(E, nullptr, 0, W);
+        if (best0 == kNoPos) break;  // null, or the retry without excludeReplicaSets (:4797-4804): lane_decide_r / the wave path
+        h.best0 = best0;
+        h.e_lru = S.lru[best0];
+        h.e_rem = S.rem[best0];
+        h.e_rpm = S.rpm[best0];
+        const bool best_is_full = h.e_rem < S.min_space;  // :4811 with bestInst = bestEntry's row (the caller is not the best here)
+        const bool has_pm = S.has_pref[t] != 0;
+        const uint64_t *Pm = S.pref + (size_t)t * W;
+        int bestpos = best0;
+        if (has_pm && !test_bit(Pm, best0)) {
+            if (best_is_full) break;  // case (b): per-candidate rpm, the wave path
+            const int q1 = first_set_from(E, Pm, best0 + 1, W);
+            if (q1 == kNoPos) break;  // no preferred instance: the replay list (wave path)
+            const int q2 = first_set_from(E, S.fullw, best0 + 1, W);
+            if (q2 < q1) break;  // a full instance before the first preferred one
+            bestpos = q1;
+        }
+        h.bestpos = bestpos;
+        h.b_lru = S.lru[bestpos];
+        h.b_rem = S.rem[bestpos];
+        h.b_cnt = S.cnt[bestpos];
+        h.b_rpm = S.rpm[bestpos];
+        h.best_idx = S.orig[bestpos];
+        h.flags = (best_is_full ? 1u : 0u) | (has_pm ? 2u : 0u);
+        const int w0 = bestpos >> 6;
+        h.nw = W - w0 < kHeadWords ? W - w0 : kHeadWords;
+#pragma unroll
+        for (int j = 0; j < kHeadWords; j++)
+            if (j < h.nw) h.D[j] = has_pm ? (E[w0 + j] & Pm[w0 + j]) : E[w0 + j];
+        if (!best_is_full) {
+            const int32_t thr = (int32_t)((uint32_t)h.b_cnt + (uint32_t)(h.b_cnt >> 2));  // :4926
+            const int64_t T = thr < kGeBase - 1 ? (int64_t)kGeBase : (int64_t)thr + 1;
+            if (T >= kGeBase + kGeRows) break;  // beyond the threshold rows: the count column scan of the wave path
+            const uint64_t *G = S.ge + (size_t)(T - kGeBase) * W;
+            // first position > bestpos in D & G
+            const int start = bestpos + 1;
+            int found = kNoPos;
+            if (start < W * 64) {
+                const int ws = start >> 6;
+                for (int base = ws; base < W && found == kNoPos; base += 64) {
+                    const int w = base + lane;
+                    uint64_t v = 0;
+                    if (w < W) {
+                        v = E[w] & G[w];
+                        if (has_pm) v &= Pm[w];
+                        if (w == ws) v &= (~0ull) << (start & 63);
+                    }
+                    const uint64_t b = __ballot(v != 0);
+                    if (b) {
+                        const int l = __ffsll((unsigned long long)b) - 1;
+                        const uint64_t vv = readlane_u64(v, l);
+                        found = (base + l) * 64 + (__ffsll((unsigned long long)vv) - 1);
+                    }
+                }
+            }
+            h.pcnt = found;
+        }
+        h.valid = (P > 0) ? 1 : 0;
+    } while (false);
+    if (lane == 0) heads[t] = h;
 }
 
 struct RpmRule {
@@ -537,16 +651,24 @@ __device__ __forceinline__ int lane_first(F f, int start, int stop, bool &far, c
 // kLaneLong: the shortlist spans more than kLaneSpan words — decided by the LONG instantiation of this same
 // function (a later phase of the kernel), which counts / hashes / selects through the prefix tables of Snap
 // instead of walking the words.
-enum { kLaneDone = 0, kLaneWave = 1, kLaneNoneHere = 2, kLaneIncomplete = 3, kLaneLong = 4 };
+enum { kLaneDone = 0, kLaneWave = 1, kLaneNoneHere = 2, kLaneIncomplete = 3, kLaneLong = 4, kLaneHeadMiss = 5 };
 // (a scan given up after kLaneSpan words also reports kLaneLong when the snapshot has prefix tables: the LONG
 // instantiation's scans jump through them)
 
 template <bool VIEW, bool LONG = false>
+__device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, mmp_place_out &o);
+
+template <bool VIEW, bool LONG = false>
 __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, int d, mmp_place_out &o)
 {
-    PHASE_T0();
     const ResolvedReq r = resolve_one<VIEW>(S, A, d);
-    PHASE(0);  // request + model row resolved
+    return lane_decide_r<VIEW, LONG>(S, A, r, o);
+}
+
+template <bool VIEW, bool LONG>
+__device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, mmp_place_out &o)
+{
+    PHASE_T0();
     o.chosen = MMP_NONE;
     o.best = -1;
     o.n_candidates = 0;
@@ -831,6 +953,152 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
     return fb ? (VIEW ? kLaneIncomplete : (far && !LONG && S.pc ? kLaneLong : kLaneWave)) : kLaneDone;
 }
 
+// getNext answered from the type's head record (TypeHead): Hs = the records in LDS, scr = this lane's column
+// of the workgroup's window scratch (word j at scr[j * kPlaceBlock]).  kLaneHeadMiss: the record cannot answer
+// this request — the caller runs lane_decide_r on the same resolved request.  The steps and their order are those
+// of lane_decide_r's simple case with `us` false (the caller is neither bestEntry nor bestInst here).
+__device__ __forceinline__ int lane_decide_head(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, const TypeHead *Hs,
+                                                uint64_t *scr, mmp_place_out &o)
+{
+    PHASE_T0();
+    if (r.type < 0 || r.type >= kHeadLds || r.n_excl > kInlineExcl || A.force_wave) return kLaneHeadMiss;
+    const TypeHead &H = Hs[r.type];
+    if (!H.valid) return kLaneHeadMiss;
+    const int best0 = H.best0, bestpos = H.bestpos, pcnt = H.pcnt;
+    const int selfpos = r.selfpos;
+    // the record was built without exclusions and without a caller: none of them may sit ON a position it depends on
+    bool miss = selfpos == best0 || selfpos == bestpos;
+#pragma unroll
+    for (int i = 0; i < kInlineExcl; i++) {
+        const int e = r.excl_pos[i];  // -1 (not in the table) matches nothing; pcnt == kNoPos neither
+        miss |= e == best0 || e == bestpos || e == pcnt;
+    }
+    if (miss) return kLaneHeadMiss;
+    const int P = S.P;
+    const int w0 = bestpos >> 6, nw = H.nw;
+    const int win_end = (w0 + nw) * 64 < P ? (w0 + nw) * 64 : P;  // the record answers for positions below this
+    // the window's words with this request's exclusions cleared (CacheMissExcludeSet, :4740-4743)
+#pragma unroll
+    for (int j = 0; j < kHeadWords; j++) scr[j * kPlaceBlock] = H.D[j];
+#pragma unroll
+    for (int i = 0; i < kInlineExcl; i++) {
+        const int e = r.excl_pos[i], j = (e >> 6) - w0;
+        if (e >= 0 && j >= 0 && j < nw) scr[j * kPlaceBlock] &= ~(1ull << (e & 63));
+    }
+    auto dw = [&](int w) { return scr[(w - w0) * kPlaceBlock]; };  // w0 <= w < w0 + nw
+    PHASE(1);
+    const bool favour = (r.flags & MMP_REQ_FAVOUR_SELF) != 0;
+    const bool best_is_full = (H.flags & 1u) != 0;
+    const int64_t f_lru = r.fresh_lru, f_rem = r.f_rem;
+    const int32_t f_rpm = r.fresh_rpm;
+    const int64_t e_lru = H.e_lru, e_rem = H.e_rem, b_lru = H.b_lru, b_rem = H.b_rem;
+    const int32_t e_rpm = H.e_rpm, b_rpm = H.b_rpm;
+    bool ns_break, self_break;
+    if (best_is_full) {
+        const int64_t rel = age_of(b_lru, A.now) / 10;
+        const int64_t d1 = jsub64(f_lru, b_lru), d2 = jsub64(e_lru, b_lru);
+        ns_break = d1 > 45000LL && d1 > rel;  // :4913-4917
+        self_break = d2 > 45000LL && d2 > rel;
+    } else {
+        const int64_t q = b_rem >> 2;  // :4922
+        ns_break = f_rem < S.min_space || f_rem < q;
+        self_break = e_rem < S.min_space || e_rem < q;
+    }
+    PHASE(2);
+    const int start = bestpos + 1;
+    // the caller's own entry beyond the window cannot be in a shortlist that ends inside it (checked below)
+    const bool self_in_d = selfpos >= start && selfpos < win_end && ((dw(selfpos >> 6) >> (selfpos & 63)) & 1ull);
+    int end = P;
+    if (ns_break) {  // the first candidate that is not the caller's own entry ends the list
+        int p1 = kNoPos;
+        if (start < win_end) {
+            const int ws = start >> 6, wl = (win_end - 1) >> 6;
+            for (int w = ws; w <= wl; w++) {
+                uint64_t v = dw(w);
+                if ((selfpos >> 6) == w) v &= ~(1ull << (selfpos & 63));
+                if (w == ws) v &= (~0ull) << (start & 63);
+                if (v) {
+                    p1 = w * 64 + (__ffsll((unsigned long long)v) - 1);
+                    break;
+                }
+            }
+        }
+        if (p1 == kNoPos && win_end < P) return kLaneHeadMiss;  // the scan leaves the window
+        end = p1 < end ? p1 : end;
+    }
+    if (self_in_d && self_break) end = selfpos < end ? selfpos : end;
+    if (!best_is_full) end = pcnt < end ? pcnt : end;  // :4925-4926, the type's threshold row at commit
+    PHASE(3);
+    if (end > win_end) return kLaneHeadMiss;  // the shortlist leaves the window
+    o.best = H.best_idx;
+    o.n_candidates = 0;
+    o.hash = 0;
+    o.chosen = MMP_NONE;
+    const bool self_in_c = self_in_d && selfpos < end;
+    if (self_in_c && favour) {  // :4931-4933
+        o.chosen = MMP_SELF;
+        return kLaneDone;
+    }
+    const int wlo = w0, whi = end > start ? (end - 1) >> 6 : wlo;
+    auto cand = [&](int w) {
+        uint64_t v = clip_word(dw(w), w, start, end);
+        if (w == wlo) v |= 1ull << (bestpos & 63);
+        return v;
+    };
+    int ccount = 0;
+    uint64_t hsum = 0;
+    for (int w = wlo; w <= whi; w++) {
+        const uint64_t v = cand(w);
+        ccount += __popcll((unsigned long long)v);
+        if (v) hsum += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)(w + 1)));
+    }
+    PHASE(4);
+    int remaining = ccount;
+    bool null0 = false, null_s = false, null_o = false;
+    if (ccount >= 2) {  // rpm filter, :4951-4980 (quirks B#2/B#3: three rpm classes)
+        const int n_others = ccount - 1 - (self_in_c ? 1 : 0);
+        int32_t mn = b_rpm;
+        if (self_in_c && e_rpm < mn) mn = e_rpm;
+        if (n_others > 0 && f_rpm < mn) mn = f_rpm;
+        RpmRule rule;
+        rule.init(age_of(r.last_used, A.now), mn);
+        null0 = rule.nulls(b_rpm);
+        null_s = self_in_c && rule.nulls(e_rpm);
+        null_o = n_others > 0 && rule.nulls(f_rpm);
+        remaining = ccount - (null0 ? 1 : 0) - (null_s ? 1 : 0) - (null_o ? n_others : 0);
+    }
+    PHASE(5);
+    const int index = remaining <= 1 ? 0 : (int)(((uint64_t)r.pick * (uint64_t)(uint32_t)remaining) >> 32);
+    int cpos = kNoPos;
+    if (remaining >= 1) {
+        const int sw = self_in_c ? (selfpos >> 6) : -1;
+        int running = 0;
+        for (int w = wlo; w <= whi; w++) {
+            uint64_t v = cand(w);  // the word's candidates that the rpm filter left in
+            uint64_t special = 0;
+            if (w == wlo) special |= 1ull << (bestpos & 63);
+            if (w == sw) special |= 1ull << (selfpos & 63);
+            if (null_o) v &= special;
+            if (null0 && w == wlo) v &= ~(1ull << (bestpos & 63));
+            if (null_s && w == sw) v &= ~(1ull << (selfpos & 63));
+            const int c = __popcll((unsigned long long)v);
+            if (index < running + c) {
+                cpos = w * 64 + select_kth_bit(v, index - running);
+                break;
+            }
+            running += c;
+        }
+    }
+    o.n_candidates = ccount;
+    o.hash = (uint32_t)(hsum ^ (hsum >> 32)) ^ ((uint32_t)remaining * 0x9E3779B1u);
+    if (cpos != kNoPos) {
+        o.chosen = cpos == bestpos ? H.best_idx : S.orig[cpos];
+        if (!favour && cpos == selfpos) o.chosen = MMP_SELF;  // :4989-4991
+    }
+    PHASE(6);
+    return kLaneDone;
+}
+
 __device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int d, uint64_t *ew, uint64_t *fw)
 {
     const int lane = lane_id();
@@ -1105,7 +1373,6 @@ __device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int
 // The load-target kernel: 256 decisions per workgroup, one per lane (lane_decide); the decisions that
 // leave the common shape are collected in LDS and then taken one wavefront at a time by the general
 // path (place_one) inside the same launch.  LDS: kPlaceWaves × 2 bitmaps × wpad words for that path.
-constexpr int kPlaceBlock = kPlaceWaves * 64;
 // WITH_LONG: the kernel carries the phase that decides whole-table shortlists on single lanes through the
 // prefix tables (lane_decide<…, LONG>).  That phase needs 108 VGPRs against 94 (4 instead of 5 wavefronts per
 // SIMD: -5 % on a lone 100k launch, -14 % saturated), so it is compiled into a kernel of its own which the host
@@ -1117,13 +1384,40 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
 {
     __shared__ int32_t fb_list[kPlaceBlock], lr_list[kPlaceBlock];
     __shared__ int32_t fb_n, lr_n;
+    __shared__ __attribute__((aligned(16))) TypeHead s_heads[kHeadLds];
+    __shared__ uint64_t s_scr[kHeadWords * kPlaceBlock];  // per lane: the head window with the request's exclusions cleared
     if (threadIdx.x == 0) fb_n = lr_n = 0;
-    __syncthreads();
     const int d = blockIdx.x * kPlaceBlock + threadIdx.x;
     PHASE_T0();
+    // The head records are fetched beside the request (they depend on nothing) and parked in LDS while the
+    // request -> model row chain is in flight; the barrier below is the one the lists needed anyway.
+    const bool use_heads = A.heads != nullptr;  // wave-uniform
+    constexpr int kHeadVecs = (int)(sizeof(TypeHead) / sizeof(uint4));
+    const int head_vecs = (S.T < kHeadLds ? S.T : kHeadLds) * kHeadVecs;
+    uint4 hv[(kHeadLds * kHeadVecs + kPlaceBlock - 1) / kPlaceBlock];
+    if (use_heads) {
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof hv / sizeof hv[0]); k++) {
+            const int i = k * kPlaceBlock + (int)threadIdx.x;
+            if (i < head_vecs) hv[k] = reinterpret_cast<const uint4 *>(A.heads)[i];
+        }
+    }
+    ResolvedReq r;
+    if (d < A.n) r = resolve_one<false>(S, A, d);
+    PHASE(0);  // request + model row resolved
+    if (use_heads) {
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof hv / sizeof hv[0]); k++) {
+            const int i = k * kPlaceBlock + (int)threadIdx.x;
+            if (i < head_vecs) reinterpret_cast<uint4 *>(s_heads)[i] = hv[k];
+        }
+    }
+    __syncthreads();
     if (d < A.n) {
         mmp_place_out o;
-        const int code = lane_decide<false>(S, A, d, o);
+        int code = kLaneHeadMiss;
+        if (use_heads) code = lane_decide_head(S, A, r, s_heads, s_scr + threadIdx.x, o);
+        if (code == kLaneHeadMiss) code = lane_decide_r<false>(S, A, r, o);
         if (WITH_LONG && code == kLaneLong)
             lr_list[atomicAdd(&lr_n, 1)] = d;
         else if (code != kLaneDone)
