@@ -129,7 +129,7 @@ struct mmp_ctx {
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     double last_kernel_ms = -1.0;
     int32_t force_wave = 0;  // MMP_FORCE_WAVE=1: every decision takes the wave-per-decision kernel (tests)
-    int32_t no_heads = 0;    // MMP_NO_HEADS=1: decisions do not use the per-type head records (tests: lane_decide_r alone)
+    int32_t no_heads = 0;    // MMP_NO_HEADS=1: decisions do not use the per-type head windows (tests: lane_decide_r alone)
 
     // host staging (inputs of the next commit)
     std::vector<mmp_pod_row> pods;
@@ -336,7 +336,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     A.reqs = static_cast<const mmp_place_req *>(d_reqs);
     A.models = c->models.as<mmp_model_row>();
     A.rmodels = cur_side(c).rmodels_ok ? cur_side(c).rmodels.as<ResolvedModel>() : nullptr;
-    A.heads = (c->no_heads || c->n_shards > 0) ? nullptr : c->sb[c->cur].heads.as<TypeHead>();
+    A.wins = (c->no_heads || c->n_shards > 0) ? nullptr : c->sb[c->cur].heads.as<TypeWin>();
     A.ent_pod = c->ent_pod.as<int32_t>();
     A.extra = static_cast<const int32_t *>(d_extra);
     A.outs = static_cast<mmp_place_out *>(d_outs);
@@ -964,7 +964,9 @@ int mmp_snapshot_commit(mmp_ctx *c)
     HIP_TRY(c, B.pc.ensure((size_t)2 * T * (W + 1) * 4));
     HIP_TRY(c, B.nz.ensure((size_t)2 * T * (W + 1) * 4));
     HIP_TRY(c, B.ph.ensure((size_t)2 * T * (W + 1) * 8));
-    HIP_TRY(c, B.heads.ensure((size_t)T * sizeof(TypeHead)));
+    // rounded up to the 1 KB chunks place_block stages (rows beyond T are never read as windows)
+    const size_t wins_bytes = (((size_t)std::max(T, kWinLds) * sizeof(TypeWin) + 1023) / 1024) * 1024;
+    HIP_TRY(c, B.heads.ensure(wins_bytes));
     HIP_TRY(c, c->rank.ensure(padded * 4));
     HIP_TRY(c, c->occupancy.ensure(padded * 4));
     HIP_TRY(c, c->flag.ensure(sizeof(int32_t)));
@@ -1088,11 +1090,11 @@ int mmp_snapshot_commit(mmp_ctx *c)
                            B.pc.as<int32_t>(), B.ph.as<uint64_t>(), B.nz.as<int32_t>(), N.stats_acc.as<StatsAcc>());
         hipLaunchKernelGGL(cluster_stats_kernel, dim3(std::min(div_up(P, 256), 512)), dim3(256), 0, st,
                            B.pods.as<mmp_pod_row>(), P, min_space, N.stats_acc.as<StatsAcc>());
-        // the type-level part of getNext, once per type row (place_kernel.hpp: TypeHead)
-        hipLaunchKernelGGL(build_heads_kernel, dim3(T), dim3(64), 0, st, S, B.heads.as<TypeHead>());
+        // the head window of every type row (place_kernel.hpp: TypeWin)
+        hipLaunchKernelGGL(build_wins_kernel, dim3(T), dim3(64), 0, st, S, B.heads.as<TypeWin>());
         HIP_TRY(c, hipGetLastError());
     } else {
-        HIP_TRY(c, hipMemsetAsync(B.heads.p, 0, (size_t)T * sizeof(TypeHead), st));
+        HIP_TRY(c, hipMemsetAsync(B.heads.p, 0, wins_bytes, st));
         HIP_TRY(c, hipMemsetAsync(B.pc.p, 0, (size_t)2 * T * (W + 1) * 4, st));
         HIP_TRY(c, hipMemsetAsync(B.nz.p, 0, (size_t)2 * T * (W + 1) * 4, st));
         HIP_TRY(c, hipMemsetAsync(B.ph.p, 0, (size_t)2 * T * (W + 1) * 8, st));
@@ -1747,7 +1749,7 @@ int mmp_shard_place_phase_dev(mmp_ctx *c, int32_t phase, const void *d_reqs, int
     A.reqs = static_cast<const mmp_place_req *>(d_reqs);
     A.models = c->models.as<mmp_model_row>();
     A.rmodels = nullptr;
-    A.heads = nullptr;
+    A.wins = nullptr;
     A.ent_pod = c->ent_pod.as<int32_t>();
     A.extra = static_cast<const int32_t *>(d_extra);
     A.outs = static_cast<mmp_place_out *>(d_outs);
@@ -1789,7 +1791,7 @@ PlaceArgs shard_args(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_ex
     A.reqs = static_cast<const mmp_place_req *>(d_reqs);
     A.models = c->models.as<mmp_model_row>();
     A.rmodels = nullptr;
-    A.heads = nullptr;
+    A.wins = nullptr;
     A.ent_pod = c->ent_pod.as<int32_t>();
     A.extra = static_cast<const int32_t *>(d_extra);
     A.outs = static_cast<mmp_place_out *>(d_outs);

@@ -75,41 +75,50 @@ struct __attribute__((aligned(16))) ResolvedModel {
 };
 static_assert(sizeof(ResolvedModel) == 32, "ResolvedModel is 32 bytes");
 
-// ---- per-type head records ------------------------------------------------------------------------
-// Everything getNext derives from the TYPE alone — the first eligible pod (bestEntry), the preference step
-// (case (a), MM.java:4828-4852), bestInst's row, bestIsFull, the count-break position of :4925-4926 and the
-// words of the candidate bitmap behind the best position — is the same for every request of that type whose own
-// exclusions and own instance do not touch those few positions.  commit() evaluates it once per type
-// (build_heads_kernel) into a 128-byte record; place_block stages the records of the first kHeadLds types into
-// LDS, and a decision then runs request -> resolved model row -> LDS -> orig[] instead of walking the bitmap
-// row, four columns, the preference row and a threshold row through L2 one dependent load after the other
-// (profiles/r1/phase_clock_place_batch_C3.txt: six such levels of 0.5-1.3 us).  Anything the record cannot
-// answer (an exclusion or the caller itself ON the best / count-break position, a shortlist that leaves the
-// record's window, case (b), the replica-set retry ...) falls through to lane_decide_r, which stays the
-// implementation of record.
-constexpr int kHeadWords = 6;  // 64-pod words of the candidate bitmap kept per type, starting at the best position's word
-constexpr int kHeadLds = 32;   // type rows staged in LDS (types beyond take lane_decide_r)
-struct __attribute__((aligned(16))) TypeHead {
-    int32_t valid;    // 0: every decision of this type takes lane_decide_r
-    int32_t best0;    // first eligible position (bestEntry, :4806)
-    int32_t bestpos;  // == best0, or the first preferred position behind it (case (a))
-    int32_t pcnt;     // first position > bestpos of D with count >= 10 && count > f + f/4 (kNoPos: none); kNoPos when bestIsFull
-    int64_t b_lru, b_rem;  // bestInst = the row at bestpos
-    int64_t e_lru, e_rem;  // bestEntry.getValue() = the row at best0 (curInst of the caller's own entry, :4909)
-    int32_t b_cnt, b_rpm, e_rpm;
-    int32_t best_idx;      // orig[bestpos]
-    uint32_t flags;        // bit 0 bestIsFull (:4811), bit 1 the type has preferred instances
-    int32_t nw;            // words of D[] that exist (the window is cut at the end of the table)
-    int32_t pad[2];
-    uint64_t D[kHeadWords];  // (elig & pref-if-any) words [bestpos >> 6, +nw): the shortlist's bitmap, no exclusions applied
+// ---- per-type head windows ------------------------------------------------------------------------
+// getNext reads, for one request, a few 64-pod words of the type's candidate bitmap right behind the type's first
+// eligible position, the rows of one or two instances there, and one threshold word — and lane_decide_r fetches them
+// through L2 one dependent load after the other (profiles/r1/phase_clock_place_batch_C3.txt).  All of it is the
+// same few hundred bytes for every request of a type, so commit() packs it once per type (build_wins_kernel) into
+// a TypeWin: the eligibility / preference / fullness words of a kWinWords-word window that starts at the type's
+// first eligible word, the rows (lruTime, remaining, count, rpm, pod index) of the first kWinRows eligible and
+// of the first kWinRows preferred-and-eligible positions in it, and — counts being non-decreasing along the
+// window, which PLACEMENT_ORDER guarantees for non-full instances of one version (MM.java:4669-4677) and the build
+// checks — for every count threshold the window position from which it holds.  place_block stages the windows
+// of the first kWinLds types into LDS beside the request fetch; lane_decide_win is lane_decide_r's simple case
+// (MM.java:4806-4991) on that window, with the request's exclusions and the caller's own entry applied, and
+// reports kLaneHeadMiss — lane_decide_r then decides on the same resolved request — whenever an answer would need a
+// bit, a row or a threshold from outside the window (case (b), the replay list, the replica-set retry, a shortlist
+// that runs past the window ...).
+constexpr int kWinWords = 6;   // 64-pod words per window
+constexpr int kWinRows = 12;   // rows kept per list: with <= kInlineExcl exclusions the best position is among the first 9
+constexpr int kWinLds = 16;    // type rows staged in LDS (types beyond take lane_decide_r)
+struct __attribute__((aligned(16))) WinRow {
+    int64_t lru, rem;
+    int32_t cnt, rpm, orig, pos;
 };
-static_assert(sizeof(TypeHead) == 128, "TypeHead is 128 bytes");
+static_assert(sizeof(WinRow) == 32, "WinRow is 32 bytes");
+struct __attribute__((aligned(16))) TypeWin {
+    int32_t valid;   // 0: every decision of this type takes lane_decide_r
+    int32_t w0;      // first word of the window (the word of the type's first eligible position)
+    int32_t nw;      // words of the window that exist (it is cut at the end of the table)
+    uint32_t flags;  // bit 1: the type has preferred instances (getPreferredInstances(type) != null)
+    uint64_t E[kWinWords];   // elig words
+    uint64_t Pm[kWinWords];  // pref words; all ones when the type has no preferred instances (D = E & Pm either way)
+    uint64_t F[kWinWords];   // fullw words
+    uint16_t ct[kGeRows];    // ct[r]: window positions with count < kGeBase + r == first window position with count >= kGeBase + r
+    uint16_t pad_[2];
+    WinRow rowsE[kWinRows];  // rows of the first eligible positions of the window
+    WinRow rowsP[kWinRows];  // rows of the first preferred eligible positions (types with preferred instances)
+};
+static_assert(sizeof(TypeWin) % 16 == 0, "TypeWin is staged in 16-byte pieces");
+static_assert(kGeRows % 2 == 0, "ct + pad_ keep the rows 16-byte aligned");
 
 struct PlaceArgs {
     const mmp_place_req *reqs;
     const mmp_model_row *models;
     const ResolvedModel *rmodels;  // null: not built (pod-axis shard contexts)
-    const TypeHead *heads;         // null: not built (pod-axis shard contexts, MMP_NO_HEADS=1)
+    const TypeWin *wins;           // null: not built (pod-axis shard contexts, MMP_NO_HEADS=1)
     const int32_t *ent_pod;  // model entries: loaded ids then failed ids
     const int32_t *extra;    // per-request extra exclusions
     mmp_place_out *outs;
@@ -221,86 +230,83 @@ __device__ __forceinline__ int first_lru_break(const uint64_t *ew, int start, in
     return kNoPos;
 }
 
-// One wavefront per type row: the type-level part of getNext with no exclusions and no caller (see TypeHead).
-__global__ __launch_bounds__(64) void build_heads_kernel(Snap S, TypeHead *__restrict__ heads)
+// One wavefront per type row (see TypeWin).
+__global__ __launch_bounds__(64) void build_wins_kernel(Snap S, TypeWin *__restrict__ wins)
 {
     const int t = blockIdx.x, lane = lane_id();
     const int P = S.P, W = S.W;
     const uint64_t *E = S.elig + (size_t)t * W;
-    TypeHead h;
-    h.valid = 0;
-    h.best0 = h.bestpos = -1;
-    h.pcnt = kNoPos;
-    h.b_lru = h.b_rem = h.e_lru = h.e_rem = 0;
-    h.b_cnt = h.b_rpm = h.e_rpm = 0;
-    h.best_idx = -1;
-    h.flags = 0;
-    h.nw = 0;
-    h.pad[0] = h.pad[1] = 0;
-#pragma unroll
-    for (int j = 0; j < kHeadWords; j++) h.D[j] = 0;
-    do {
-        const int best0 = first_set_from(E, nullptr, 0, W);
-        if (best0 == kNoPos) break;  // null, or the retry without excludeReplicaSets (:4797-4804): lane_decide_r / the wave path
-        h.best0 = best0;
-        h.e_lru = S.lru[best0];
-        h.e_rem = S.rem[best0];
-        h.e_rpm = S.rpm[best0];
-        const bool best_is_full = h.e_rem < S.min_space;  // :4811 with bestInst = bestEntry's row (the caller is not the best here)
-        const bool has_pm = S.has_pref[t] != 0;
-        const uint64_t *Pm = S.pref + (size_t)t * W;
-        int bestpos = best0;
-        if (has_pm && !test_bit(Pm, best0)) {
-            if (best_is_full) break;  // case (b): per-candidate rpm, the wave path
-            const int q1 = first_set_from(E, Pm, best0 + 1, W);
-            if (q1 == kNoPos) break;  // no preferred instance: the replay list (wave path)
-            const int q2 = first_set_from(E, S.fullw, best0 + 1, W);
-            if (q2 < q1) break;  // a full instance before the first preferred one
-            bestpos = q1;
+    const uint64_t *Pm = S.pref + (size_t)t * W;
+    const bool has_pm = S.has_pref[t] != 0;
+    TypeWin *out = &wins[t];
+    const int best0 = first_set_from(E, nullptr, 0, W);
+    const int w0 = best0 == kNoPos ? 0 : best0 >> 6;
+    const int nw = best0 == kNoPos ? 0 : (W - w0 < kWinWords ? W - w0 : kWinWords);
+    const int lo = w0 * 64, hi = (w0 + nw) * 64 < P ? (w0 + nw) * 64 : P;  // window positions [lo, hi)
+    // counts must not decrease along the window: then "count >= T" holds exactly from position lo + ct[T - kGeBase] on
+    bool mono = true;
+    for (int base = lo; base < hi; base += 64) {
+        const int p = base + lane;
+        const bool bad = p + 1 < hi && S.cnt[p] > S.cnt[p + 1];
+        if (__ballot(bad)) mono = false;
+    }
+    if (lane < kWinWords) {
+        const bool in = lane < nw;
+        out->E[lane] = in ? E[w0 + lane] : 0ull;
+        out->Pm[lane] = in ? (has_pm ? Pm[w0 + lane] : ~0ull) : 0ull;
+        out->F[lane] = in ? S.fullw[w0 + lane] : 0ull;
+    }
+    if (lane < kGeRows) {
+        // first window position whose count reaches kGeBase + lane (binary search on the non-decreasing counts)
+        const int32_t T = kGeBase + lane;
+        int a = lo, b = hi;
+        while (a < b) {
+            const int m = (a + b) >> 1;
+            if (mono && S.cnt[m] < T)
+                a = m + 1;
+            else
+                b = m;
         }
-        h.bestpos = bestpos;
-        h.b_lru = S.lru[bestpos];
-        h.b_rem = S.rem[bestpos];
-        h.b_cnt = S.cnt[bestpos];
-        h.b_rpm = S.rpm[bestpos];
-        h.best_idx = S.orig[bestpos];
-        h.flags = (best_is_full ? 1u : 0u) | (has_pm ? 2u : 0u);
-        const int w0 = bestpos >> 6;
-        h.nw = W - w0 < kHeadWords ? W - w0 : kHeadWords;
-#pragma unroll
-        for (int j = 0; j < kHeadWords; j++)
-            if (j < h.nw) h.D[j] = has_pm ? (E[w0 + j] & Pm[w0 + j]) : E[w0 + j];
-        if (!best_is_full) {
-            const int32_t thr = (int32_t)((uint32_t)h.b_cnt + (uint32_t)(h.b_cnt >> 2));  // :4926
-            const int64_t T = thr < kGeBase - 1 ? (int64_t)kGeBase : (int64_t)thr + 1;
-            if (T >= kGeBase + kGeRows) break;  // beyond the threshold rows: the count column scan of the wave path
-            const uint64_t *G = S.ge + (size_t)(T - kGeBase) * W;
-            // first position > bestpos in D & G
-            const int start = bestpos + 1;
-            int found = kNoPos;
-            if (start < W * 64) {
-                const int ws = start >> 6;
-                for (int base = ws; base < W && found == kNoPos; base += 64) {
-                    const int w = base + lane;
-                    uint64_t v = 0;
-                    if (w < W) {
-                        v = E[w] & G[w];
-                        if (has_pm) v &= Pm[w];
-                        if (w == ws) v &= (~0ull) << (start & 63);
-                    }
-                    const uint64_t b = __ballot(v != 0);
-                    if (b) {
-                        const int l = __ffsll((unsigned long long)b) - 1;
-                        const uint64_t vv = readlane_u64(v, l);
-                        found = (base + l) * 64 + (__ffsll((unsigned long long)vv) - 1);
-                    }
-                }
+        out->ct[lane] = (uint16_t)(a - lo);
+    }
+    if (lane < 2) out->pad_[lane] = 0;
+    // rows of the first kWinRows set bits of E (lanes 0..kWinRows-1) and of E & Pm (lanes 32..32+kWinRows-1)
+    {
+        const bool second = lane >= 32;
+        const int k = lane & 31;
+        if (k < kWinRows) {
+            int pos = -1, left = k;
+            for (int j = 0; j < nw && pos < 0; j++) {
+                uint64_t v = E[w0 + j];
+                if (second) v = has_pm ? (v & Pm[w0 + j]) : 0ull;
+                const int c = __popcll((unsigned long long)v);
+                if (left < c)
+                    pos = (w0 + j) * 64 + select_kth_bit(v, left);
+                else
+                    left -= c;
             }
-            h.pcnt = found;
+            WinRow r;
+            r.lru = r.rem = 0;
+            r.cnt = r.rpm = 0;
+            r.orig = -1;
+            r.pos = -1;
+            if (pos >= 0) {
+                r.lru = S.lru[pos];
+                r.rem = S.rem[pos];
+                r.cnt = S.cnt[pos];
+                r.rpm = S.rpm[pos];
+                r.orig = S.orig[pos];
+                r.pos = pos;
+            }
+            (second ? out->rowsP : out->rowsE)[k] = r;
         }
-        h.valid = (P > 0) ? 1 : 0;
-    } while (false);
-    if (lane == 0) heads[t] = h;
+    }
+    if (lane == 0) {
+        out->valid = (best0 != kNoPos && mono && nw > 0) ? 1 : 0;
+        out->w0 = w0;
+        out->nw = nw;
+        out->flags = has_pm ? 2u : 0u;
+    }
 }
 
 struct RpmRule {
@@ -953,50 +959,115 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
     return fb ? (VIEW ? kLaneIncomplete : (far && !LONG && S.pc ? kLaneLong : kLaneWave)) : kLaneDone;
 }
 
-// getNext answered from the type's head record (TypeHead): Hs = the records in LDS, scr = this lane's column
-// of the workgroup's window scratch (word j at scr[j * kPlaceBlock]).  kLaneHeadMiss: the record cannot answer
-// this request — the caller runs lane_decide_r on the same resolved request.  The steps and their order are those
-// of lane_decide_r's simple case with `us` false (the caller is neither bestEntry nor bestInst here).
-__device__ __forceinline__ int lane_decide_head(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, const TypeHead *Hs,
-                                                uint64_t *scr, mmp_place_out &o)
+// getNext on the type's head window (TypeWin): Ws = the windows in LDS, scr = this lane's column of the workgroup's
+// scratch (word j at scr[j * kPlaceBlock]).  Step for step lane_decide_r's simple case; kLaneHeadMiss whenever
+// the window cannot answer — the caller then runs lane_decide_r on the same resolved request.
+// (Measured against a variant that keeps 4 or 6 window words per bitmap in registers and replaces every loop below
+// by unrolled 64-bit arithmetic: 1059 instead of 784 VALU instructions per wavefront, 8.6 / 9.9 us per launch
+// instead of 7.9 — the loops here run one or two trips, and a trip is one LDS read.)
+__device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, const TypeWin *Ws,
+                                               uint64_t *scr, mmp_place_out &o)
 {
     PHASE_T0();
-    if (r.type < 0 || r.type >= kHeadLds || r.n_excl > kInlineExcl || A.force_wave) return kLaneHeadMiss;
-    const TypeHead &H = Hs[r.type];
-    if (!H.valid) return kLaneHeadMiss;
-    const int best0 = H.best0, bestpos = H.bestpos, pcnt = H.pcnt;
-    const int selfpos = r.selfpos;
-    // the record was built without exclusions and without a caller: none of them may sit ON a position it depends on
-    bool miss = selfpos == best0 || selfpos == bestpos;
+    if (r.type < 0 || r.type >= kWinLds || r.n_excl > kInlineExcl || A.force_wave) return kLaneHeadMiss;
+    const TypeWin &Wn = Ws[r.type];
+    const int4 hdr = *reinterpret_cast<const int4 *>(&Wn);  // valid, w0, nw, flags
+    // the window's eligibility words with this request's exclusions cleared (CacheMissExcludeSet, :4740-4743):
+    // six reads in flight, six writes, then one LDS and-operation per exclusion that falls into the window
+    {
+        uint64_t e6[kWinWords];
 #pragma unroll
-    for (int i = 0; i < kInlineExcl; i++) {
-        const int e = r.excl_pos[i];  // -1 (not in the table) matches nothing; pcnt == kNoPos neither
-        miss |= e == best0 || e == bestpos || e == pcnt;
+        for (int j = 0; j < kWinWords; j++) e6[j] = Wn.E[j];  // words beyond nw are zero in the record
+#pragma unroll
+        for (int j = 0; j < kWinWords; j++) scr[j * kPlaceBlock] = e6[j];
     }
-    if (miss) return kLaneHeadMiss;
+    if (!hdr.x) return kLaneHeadMiss;
     const int P = S.P;
-    const int w0 = bestpos >> 6, nw = H.nw;
-    const int win_end = (w0 + nw) * 64 < P ? (w0 + nw) * 64 : P;  // the record answers for positions below this
-    // the window's words with this request's exclusions cleared (CacheMissExcludeSet, :4740-4743)
-#pragma unroll
-    for (int j = 0; j < kHeadWords; j++) scr[j * kPlaceBlock] = H.D[j];
+    const int w0 = hdr.y, nw = hdr.z;
+    const int win_lo = w0 * 64;
+    const int win_end = (w0 + nw) * 64 < P ? (w0 + nw) * 64 : P;  // the window answers for positions [win_lo, win_end)
 #pragma unroll
     for (int i = 0; i < kInlineExcl; i++) {
         const int e = r.excl_pos[i], j = (e >> 6) - w0;
-        if (e >= 0 && j >= 0 && j < nw) scr[j * kPlaceBlock] &= ~(1ull << (e & 63));
+        if (e >= 0 && j >= 0 && j < nw) atomicAnd((unsigned long long *)&scr[j * kPlaceBlock], ~(1ull << (e & 63)));
     }
-    auto dw = [&](int w) { return scr[(w - w0) * kPlaceBlock]; };  // w0 <= w < w0 + nw
-    PHASE(1);
+    auto ew = [&](int w) { return scr[(w - w0) * kPlaceBlock]; };  // w0 <= w < w0 + nw
+    auto dw = [&](int w) { return scr[(w - w0) * kPlaceBlock] & Wn.Pm[w - w0]; };  // preference treated as required (:4905)
+    // first set bit of f(w) at a position in [from, to) of the window (to <= win_end); kNoPos if none
+    auto first_in = [&](auto f, int from, int to) {
+        if (from >= to) return (int)kNoPos;
+        const int ws = from >> 6, wl = (to - 1) >> 6;
+        for (int w = ws; w <= wl; w++) {
+            uint64_t v = f(w);
+            if (w == ws) v &= (~0ull) << (from & 63);
+            if (w == wl && (to & 63)) v &= (1ull << (to & 63)) - 1ull;
+            if (v) return w * 64 + (__ffsll((unsigned long long)v) - 1);
+        }
+        return (int)kNoPos;
+    };
+    // row index of a window position: the number of (unmasked) bits of `words` below it
+    auto rank_in = [&](const uint64_t *words, int pos, bool and_pm) {
+        const int jb = (pos >> 6) - w0;
+        int k = 0;
+        for (int j = 0; j <= jb; j++) {
+            uint64_t v = words[j];
+            if (and_pm) v &= Wn.Pm[j];
+            if (j == jb) v &= (1ull << (pos & 63)) - 1ull;
+            k += __popcll((unsigned long long)v);
+        }
+        return k;
+    };
+    const int best0 = first_in(ew, win_lo, win_end);
+    if (best0 == kNoPos) return kLaneHeadMiss;  // null, or the retry without excludeReplicaSets (:4797-4804)
+    // every eligible position before best0 is excluded; none unless an exclusion removed the type's first instance
+    const int i0 = best0 == Wn.rowsE[0].pos ? 0 : rank_in(Wn.E, best0, false);
+    if (i0 >= kWinRows) return kLaneHeadMiss;
+    PHASE(1);  // first eligible pod
+    const int selfpos = r.selfpos;
     const bool favour = (r.flags & MMP_REQ_FAVOUR_SELF) != 0;
-    const bool best_is_full = (H.flags & 1u) != 0;
     const int64_t f_lru = r.fresh_lru, f_rem = r.f_rem;
     const int32_t f_rpm = r.fresh_rpm;
-    const int64_t e_lru = H.e_lru, e_rem = H.e_rem, b_lru = H.b_lru, b_rem = H.b_rem;
-    const int32_t e_rpm = H.e_rpm, b_rpm = H.b_rpm;
+    const WinRow r0 = Wn.rowsE[i0];
+    const int64_t e_lru = r0.lru, e_rem = r0.rem;
+    const int32_t e_rpm = r0.rpm;
+    bool us = best0 == selfpos;
+    int64_t b_lru = us ? f_lru : e_lru, b_rem = us ? f_rem : e_rem;
+    int32_t b_cnt = us ? r.fresh_count : r0.cnt, b_rpm = us ? f_rpm : e_rpm;
+    const bool best_is_full = b_rem < S.min_space;  // :4811, never recomputed
+    int bestpos = best0;
+    int32_t best_idx = r0.orig;
+    if ((hdr.w & 2) && !((Wn.Pm[(best0 >> 6) - w0] >> (best0 & 63)) & 1ull)) {
+        if (best_is_full) return kLaneHeadMiss;  // case (b): per-candidate rpm, the wave path
+        // case (a): the first preferred pod, provided no full pod comes before it
+        const int q1 = first_in(dw, best0 + 1, win_end);
+        if (q1 == kNoPos) return kLaneHeadMiss;  // none in the window (or none at all: the replay list)
+        auto ewf = [&](int w) { return ew(w) & Wn.F[w - w0]; };
+        if (first_in(ewf, best0 + 1, q1) != kNoPos) return kLaneHeadMiss;
+        const int iq = rank_in(Wn.E, q1, true);
+        if (iq >= kWinRows) return kLaneHeadMiss;
+        const WinRow rq = Wn.rowsP[iq];
+        bestpos = q1;
+        b_lru = rq.lru;
+        b_rem = rq.rem;
+        b_cnt = rq.cnt;
+        b_rpm = rq.rpm;
+        best_idx = rq.orig;
+        us = q1 == selfpos;
+    }
+    PHASE(2);  // best row + preference step
+    o.chosen = MMP_NONE;
+    o.best = best_idx;
+    o.n_candidates = 0;
+    o.hash = 0;
+    if (us && favour) {  // :4891-4895
+        o.chosen = MMP_SELF;
+        return kLaneDone;
+    }
+    const int64_t oldest = b_lru;
     bool ns_break, self_break;
     if (best_is_full) {
-        const int64_t rel = age_of(b_lru, A.now) / 10;
-        const int64_t d1 = jsub64(f_lru, b_lru), d2 = jsub64(e_lru, b_lru);
+        const int64_t rel = age_of(oldest, A.now) / 10;
+        const int64_t d1 = jsub64(f_lru, oldest), d2 = jsub64(e_lru, oldest);
         ns_break = d1 > 45000LL && d1 > rel;  // :4913-4917
         self_break = d2 > 45000LL && d2 > rel;
     } else {
@@ -1004,55 +1075,50 @@ __device__ __forceinline__ int lane_decide_head(const Snap &S, const PlaceArgs &
         ns_break = f_rem < S.min_space || f_rem < q;
         self_break = e_rem < S.min_space || e_rem < q;
     }
-    PHASE(2);
     const int start = bestpos + 1;
     // the caller's own entry beyond the window cannot be in a shortlist that ends inside it (checked below)
     const bool self_in_d = selfpos >= start && selfpos < win_end && ((dw(selfpos >> 6) >> (selfpos & 63)) & 1ull);
     int end = P;
     if (ns_break) {  // the first candidate that is not the caller's own entry ends the list
-        int p1 = kNoPos;
-        if (start < win_end) {
-            const int ws = start >> 6, wl = (win_end - 1) >> 6;
-            for (int w = ws; w <= wl; w++) {
-                uint64_t v = dw(w);
-                if ((selfpos >> 6) == w) v &= ~(1ull << (selfpos & 63));
-                if (w == ws) v &= (~0ull) << (start & 63);
-                if (v) {
-                    p1 = w * 64 + (__ffsll((unsigned long long)v) - 1);
-                    break;
-                }
-            }
-        }
+        auto dns = [&](int w) {
+            uint64_t v = dw(w);
+            if ((selfpos >> 6) == w) v &= ~(1ull << (selfpos & 63));
+            return v;
+        };
+        const int p1 = first_in(dns, start, win_end);
         if (p1 == kNoPos && win_end < P) return kLaneHeadMiss;  // the scan leaves the window
         end = p1 < end ? p1 : end;
     }
     if (self_in_d && self_break) end = selfpos < end ? selfpos : end;
-    if (!best_is_full) end = pcnt < end ? pcnt : end;  // :4925-4926, the type's threshold row at commit
-    PHASE(3);
+    if (!best_is_full) {
+        const int32_t thr = (int32_t)((uint32_t)b_cnt + (uint32_t)(b_cnt >> 2));  // :4926
+        const int64_t T = thr < kGeBase - 1 ? (int64_t)kGeBase : (int64_t)thr + 1;  // count >= 10 && count > thr
+        if (T >= kGeBase + kGeRows) return kLaneHeadMiss;
+        const int from_t = win_lo + (int)Wn.ct[T - kGeBase];  // counts do not decrease along the window
+        const int lim = end < win_end ? end : win_end;
+        const int pc = first_in(dw, from_t > start ? from_t : start, lim);
+        if (pc == kNoPos && end > win_end) return kLaneHeadMiss;  // the break, if any, lies beyond the window
+        end = pc < end ? pc : end;
+    }
+    PHASE(3);  // break scans
     if (end > win_end) return kLaneHeadMiss;  // the shortlist leaves the window
-    o.best = H.best_idx;
-    o.n_candidates = 0;
-    o.hash = 0;
-    o.chosen = MMP_NONE;
     const bool self_in_c = self_in_d && selfpos < end;
     if (self_in_c && favour) {  // :4931-4933
         o.chosen = MMP_SELF;
         return kLaneDone;
     }
-    const int wlo = w0, whi = end > start ? (end - 1) >> 6 : wlo;
-    auto cand = [&](int w) {
-        uint64_t v = clip_word(dw(w), w, start, end);
-        if (w == wlo) v |= 1ull << (bestpos & 63);
-        return v;
-    };
+    // candidates = {best} ∪ D∩[start,end): count + hash; the words stay in this lane's scratch column for the select
+    const int wlo = bestpos >> 6, whi = end > start ? (end - 1) >> 6 : wlo;
     int ccount = 0;
     uint64_t hsum = 0;
     for (int w = wlo; w <= whi; w++) {
-        const uint64_t v = cand(w);
+        uint64_t v = clip_word(dw(w), w, start, end);
+        if (w == wlo) v |= 1ull << (bestpos & 63);
+        scr[(w - w0) * kPlaceBlock] = v;
         ccount += __popcll((unsigned long long)v);
         if (v) hsum += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)(w + 1)));
     }
-    PHASE(4);
+    PHASE(4);  // count + audit hash
     int remaining = ccount;
     bool null0 = false, null_s = false, null_o = false;
     if (ccount >= 2) {  // rpm filter, :4951-4980 (quirks B#2/B#3: three rpm classes)
@@ -1067,14 +1133,14 @@ __device__ __forceinline__ int lane_decide_head(const Snap &S, const PlaceArgs &
         null_o = n_others > 0 && rule.nulls(f_rpm);
         remaining = ccount - (null0 ? 1 : 0) - (null_s ? 1 : 0) - (null_o ? n_others : 0);
     }
-    PHASE(5);
+    PHASE(5);  // rpm rule
     const int index = remaining <= 1 ? 0 : (int)(((uint64_t)r.pick * (uint64_t)(uint32_t)remaining) >> 32);
     int cpos = kNoPos;
     if (remaining >= 1) {
         const int sw = self_in_c ? (selfpos >> 6) : -1;
         int running = 0;
         for (int w = wlo; w <= whi; w++) {
-            uint64_t v = cand(w);  // the word's candidates that the rpm filter left in
+            uint64_t v = scr[(w - w0) * kPlaceBlock];  // the word's candidates; those the rpm filter left in:
             uint64_t special = 0;
             if (w == wlo) special |= 1ull << (bestpos & 63);
             if (w == sw) special |= 1ull << (selfpos & 63);
@@ -1092,10 +1158,10 @@ __device__ __forceinline__ int lane_decide_head(const Snap &S, const PlaceArgs &
     o.n_candidates = ccount;
     o.hash = (uint32_t)(hsum ^ (hsum >> 32)) ^ ((uint32_t)remaining * 0x9E3779B1u);
     if (cpos != kNoPos) {
-        o.chosen = cpos == bestpos ? H.best_idx : S.orig[cpos];
+        o.chosen = cpos == bestpos ? best_idx : S.orig[cpos];
         if (!favour && cpos == selfpos) o.chosen = MMP_SELF;  // :4989-4991
     }
-    PHASE(6);
+    PHASE(6);  // survivor select + translation
     return kLaneDone;
 }
 
@@ -1384,39 +1450,38 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
 {
     __shared__ int32_t fb_list[kPlaceBlock], lr_list[kPlaceBlock];
     __shared__ int32_t fb_n, lr_n;
-    __shared__ __attribute__((aligned(16))) TypeHead s_heads[kHeadLds];
-    __shared__ uint64_t s_scr[kHeadWords * kPlaceBlock];  // per lane: the head window with the request's exclusions cleared
+    constexpr int kWinLdsBytes = ((kWinLds * (int)sizeof(TypeWin) + 1023) / 1024) * 1024;  // staged in whole 1 KB chunks
+    __shared__ __attribute__((aligned(16))) unsigned char s_wins_raw[kWinLdsBytes];
+    TypeWin *s_wins = reinterpret_cast<TypeWin *>(s_wins_raw);
+    __shared__ uint64_t s_scr[kWinWords * kPlaceBlock];  // per lane: the window's eligibility words with the request's exclusions cleared
     if (threadIdx.x == 0) fb_n = lr_n = 0;
     const int d = blockIdx.x * kPlaceBlock + threadIdx.x;
     PHASE_T0();
-    // The head records are fetched beside the request (they depend on nothing) and parked in LDS while the
+    // The windows are fetched beside the request (they depend on nothing) and parked in LDS while the
     // request -> model row chain is in flight; the barrier below is the one the lists needed anyway.
-    const bool use_heads = A.heads != nullptr;  // wave-uniform
-    constexpr int kHeadVecs = (int)(sizeof(TypeHead) / sizeof(uint4));
-    const int head_vecs = (S.T < kHeadLds ? S.T : kHeadLds) * kHeadVecs;
-    uint4 hv[(kHeadLds * kHeadVecs + kPlaceBlock - 1) / kPlaceBlock];
-    if (use_heads) {
-#pragma unroll
-        for (int k = 0; k < (int)(sizeof hv / sizeof hv[0]); k++) {
-            const int i = k * kPlaceBlock + (int)threadIdx.x;
-            if (i < head_vecs) hv[k] = reinterpret_cast<const uint4 *>(A.heads)[i];
-        }
+    const bool use_wins = A.wins != nullptr;  // wave-uniform
+    // global -> LDS directly (global_load_lds_dwordx4: no staging registers), one 1 KB chunk per wavefront and
+    // trip: lane l of the wavefront that takes chunk c moves bytes [1024 c + 16 l, +16).  The window table is
+    // allocated for kWinLds rows, so whole chunks are always in bounds.
+    constexpr int kWinBytes = (int)sizeof(TypeWin);
+    if (use_wins) {
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int chunks = ((S.T < kWinLds ? S.T : kWinLds) * kWinBytes + 1023) >> 10;
+        const char *src = reinterpret_cast<const char *>(A.wins);
+        char *dst = reinterpret_cast<char *>(s_wins);
+        for (int c = wave; c < chunks; c += kPlaceWaves)
+            __builtin_amdgcn_global_load_lds(src + (size_t)c * 1024 + lane_id() * 16,
+                                             (__attribute__((address_space(3))) void *)(dst + c * 1024), 16, 0, 0);
     }
     ResolvedReq r;
     if (d < A.n) r = resolve_one<false>(S, A, d);
     PHASE(0);  // request + model row resolved
-    if (use_heads) {
-#pragma unroll
-        for (int k = 0; k < (int)(sizeof hv / sizeof hv[0]); k++) {
-            const int i = k * kPlaceBlock + (int)threadIdx.x;
-            if (i < head_vecs) reinterpret_cast<uint4 *>(s_heads)[i] = hv[k];
-        }
-    }
+    if (use_wins) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-bound copies have landed before the barrier releases
     __syncthreads();
     if (d < A.n) {
         mmp_place_out o;
         int code = kLaneHeadMiss;
-        if (use_heads) code = lane_decide_head(S, A, r, s_heads, s_scr + threadIdx.x, o);
+        if (use_wins) code = lane_decide_win(S, A, r, s_wins, s_scr + threadIdx.x, o);
         if (code == kLaneHeadMiss) code = lane_decide_r<false>(S, A, r, o);
         if (WITH_LONG && code == kLaneLong)
             lr_list[atomicAdd(&lr_n, 1)] = d;
