@@ -79,10 +79,14 @@ def cpu_baseline(fleet, reqs, extra, budget_s: float = 6.0):
         flags = pool.flags
         try:
             pool(reqs[:2000], extra, fleet.now)  # threads started, code and tables touched
+            # one pool call = one wake-up of every worker: give each at least ~8k decisions per call (the 100k batch
+            # repeated), or the condition-variable round trip is what gets timed on a many-core host
+            rep = max(1, -(-th * 8192 // len(reqs)))
+            work = np.tile(reqs, rep) if rep > 1 else reqs
             n_done, t0 = 0, time.perf_counter()
             while True:
-                pool(reqs, extra, fleet.now)
-                n_done += len(reqs)
+                pool(work, extra, fleet.now)
+                n_done += len(work)
                 dt = time.perf_counter() - t0
                 if dt >= budget_s:
                     break
@@ -94,7 +98,7 @@ def cpu_baseline(fleet, reqs, extra, budget_s: float = 6.0):
     return {
         "value": out["all"], "unit": "decisions/s", "cores": cores, "kind": "port",
         "sample": f"{len(reqs)} C3 decisions repeated for ~{budget_s:.0f}s per leg (1 thread, then {cores} threads on a "
-                  f"persistent pool); CPU port of the reference algorithm (oracle/mm_oracle.c:orc_place_lean, gcc {flags}), "
+                  f"persistent pool, >= 8k decisions per thread per call); CPU port of the reference algorithm (oracle/mm_oracle.c:orc_place_lean, gcc {flags}), "
                   "not the JVM",
         "single_thread_value": out["single"],
         "p50_us": float(np.percentile(lat, 50) / 1e3), "p99_us": float(np.percentile(lat, 99) / 1e3),
@@ -443,10 +447,11 @@ def main():
                     help="distinct request batches the steps rotate through (48 x (6.4 + 1.6) MB = 384 MB > the 256 MiB "
                          "Infinity Cache: a timed step reads its requests from HBM)")
     ap.add_argument("--issuers", type=int, default=1, help="host threads issuing the timed steps")
-    ap.add_argument("--streams", type=int, default=16,
+    ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the timed steps are issued on round-robin (a 100k-decision batch is 1564 "
-                         "wavefronts — too few to cover HBM latency on 256 CUs — so independent batches overlap; "
-                         "measured per step: 8 streams 4.63 us, 12: 4.44, 16: 4.29, 24 / 32: the same as 16)")
+                         "wavefronts — too few to cover its own latency chain on 256 CUs — so independent batches "
+                         "overlap; round 2, tools/sync_cost.py: 4 streams 3.9 us per step over 200 steps, 8: 4.3, 16: 5.1 — the "
+                         "closing synchronize costs ~10 us per stream — and one issuing host thread needs 3.45 us per launch)")
     ap.add_argument("--leg-timeout", type=float, default=420.0,
                     help="watchdog for the additional legs (pod axis, latency, churn, per-kernel, cpu baseline): when "
                          "it fires rank 0 prints the line with the legs completed so far and every rank exits 0")
@@ -515,7 +520,17 @@ def main():
     period = n_batches * n_streams // math.gcd(n_batches, n_streams)
     _args = [call_args(i % n_batches, streams[i % n_streams]) for i in range(period)]
 
+    _done = [torch.cuda.Event() for _ in streams]
+
     def fence():
+        # torch.cuda.synchronize() parks the host thread on one completion signal per stream (measured: 62 us behind
+        # 20 steps on 4 streams, 200 us on 16); polling one event per stream first gets the host there in 41 us.
+        # The synchronize below is still what closes the region.
+        for e_, st_ in zip(_done, streams):
+            e_.record(st_)
+        for e_ in _done:
+            while not e_.query():
+                pass
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()

@@ -78,4 +78,52 @@ for ns in (4, 16):
             us = many_streams(ns, rot, steps)
             print(f"{name} {tag} {ns:2d} streams, {'rotating' if rot else 'one batch per stream':>20}, {steps:4d} steps: {us:7.2f} us per step "
                   f"({n / us / 1e3:6.2f} G/s)", flush=True)
-s.close()
+pass
+
+
+def graph_steps(ns, steps, reps=5):
+    """the same schedule captured once as a hipGraph (ns branches forked from / joined into the capturing stream) and
+    replayed: no host launch per step"""
+    s2 = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    s2.load_fleet(fleet)
+    fn2 = s2.lib.mmp_place_batch_dev
+    main = torch.cuda.Stream(dev)
+    side = [torch.cuda.Stream(dev) for _ in range(ns)]
+
+    def args2(b, st):
+        r_, e_, o_ = bufs[b]
+        return (s2.h, C.c_void_p(r_.data_ptr()), C.c_int32(n), C.c_void_p(e_.data_ptr()), C.c_int64(fleet.now),
+                C.c_void_p(o_.data_ptr()), C.c_void_p(st.cuda_stream))
+    for i in range(2 * ns):
+        fn2(*args2(i % R, side[i % ns]))
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=main):
+        for st in side:
+            st.wait_stream(main)
+        for i in range(steps):
+            rc = fn2(*args2(i % R, side[i % ns]))
+            assert rc == 0, rc
+        for st in side:
+            main.wait_stream(st)
+    g.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        g.replay()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / steps * 1e6)
+    s2.close()
+    return min(ts), float(np.median(ts))
+
+
+if os.environ.get("KT_GRAPH", "1") == "1":
+    for ns in (2, 4, 8):
+        for steps in (20, 200, 1000):
+            try:
+                best, med = graph_steps(ns, steps)
+                print(f"{name} {tag} hipGraph, {ns} branches, {steps:4d} steps: best {best:7.2f} median {med:7.2f} us per step "
+                      f"({n / med / 1e3:6.2f} G/s)", flush=True)
+            except Exception as e:  # noqa: BLE001
+                print(f"{name} {tag} hipGraph, {ns} branches, {steps} steps: failed: {type(e).__name__}: {e}", flush=True)
