@@ -323,7 +323,9 @@ typedef struct {
 int mmp_abi_version(void);
 int mmp_create(const mmp_config *cfg, mmp_ctx **out);
 void mmp_destroy(mmp_ctx *ctx);
-const char *mmp_last_error(mmp_ctx *ctx); /* ctx may be NULL: last create() error */
+/* Text of the CALLING THREAD's last failure in this library (any context; ctx may be NULL).  The pointer stays
+ * valid until the same thread fails again: concurrent callers never see each other's message. */
+const char *mmp_last_error(mmp_ctx *ctx);
 /* 1 = hip (single device). There is no host backend. */
 int mmp_backend(mmp_ctx *ctx);
 
@@ -381,10 +383,13 @@ int mmp_models_upsert(mmp_ctx *ctx, const int32_t *idx, const mmp_model_row *row
                       const int64_t *ent_time, int32_t n_entries);
 /* Rank pods by PLACEMENT_ORDER (MM.java:4646-4703) on the device and publish
  * the new immutable snapshot. MMP_EORDER if the comparator is inconsistent.
- * Wait-free for decisions: the snapshot is built beside the published one and
- * published with a pointer swap; concurrent mmp_place_batch / _serve / _gate /
- * _evict calls keep answering for the published snapshot until then.  Loaders
- * of the commit's inputs and other commits serialise with it. */
+ * Wait-free for the latency path: the snapshot is built beside the published one and published with a
+ * pointer swap; concurrent calls that ride the latency slots — mmp_place_batch up to 4096 decisions,
+ * mmp_gate_batch up to 1820 requests, mmp_evict_batch up to 2048 evaluations — and mmp_place_batch_dev
+ * launches keep answering for the published snapshot until then.  Calls that stage through the context's
+ * batch stream (larger host-pointer batches, mmp_serve_batch, the plan calls, mmp_cache_replay) share that
+ * stream and its scratch with the commit and therefore queue behind a running one; so do loaders of the
+ * commit's inputs and other commits. */
 int mmp_snapshot_commit(mmp_ctx *ctx);
 /* clusterState iteration order (the `getCacheState` dump, MM.java:5552-5608).
  * order_out has room for n_pods ints; *n_out = rows actually in the set. */
@@ -413,9 +418,15 @@ int mmp_pod_partitions(mmp_ctx *ctx, int32_t *partition_out, int32_t max_pods, i
 int mmp_place_batch(mmp_ctx *ctx, const mmp_place_req *reqs, int32_t n, const int32_t *extra_pool,
                     int32_t n_extra_pool, int64_t now_ms, mmp_place_out *outs);
 /* Same, with every buffer already in device memory and launched on `stream`
- * (a hipStream_t, NULL = default) without synchronising. */
+ * (a hipStream_t, NULL = default) without synchronising.  The library remembers every stream it was handed:
+ * before it rewrites state such a launch may still be reading (the second commit after it, registry loads
+ * and events, cache-table loads) it waits for those streams as it waits for its own.  A stream must
+ * therefore stay valid until mmp_stream_retire() or mmp_destroy(). */
 int mmp_place_batch_dev(mmp_ctx *ctx, const void *d_reqs, int32_t n, const void *d_extra_pool,
                         int64_t now_ms, void *d_outs, void *stream);
+/* Forget a caller-owned stream (waits for what was enqueued on it first); call before destroying a stream
+ * that was passed to a *_dev entry point. */
+int mmp_stream_retire(mmp_ctx *ctx, void *stream);
 
 /* n serve-target decisions = n × ForwardingLB.getNext (MM.java:4315-4392).
  * in_use / last_used: ServiceInstance.getInUseCount / getLastUsedTime per pod

@@ -40,7 +40,9 @@ using namespace mmp;
 
 namespace {
 
-thread_local std::string g_create_err;
+// mmp_last_error() returns the calling thread's own last message: the library is entered concurrently (latency
+// slots) and the JNI veneer hands this pointer to ThrowNew, so it must not be a string another thread can rewrite.
+thread_local std::string g_thread_err;
 
 struct DevBuf {
     void *p = nullptr;
@@ -120,7 +122,10 @@ struct mmp_ctx {
     // table, type table, replica-set list, registry — for a whole call) -> mu (the published snapshot pointers +
     // host staging as readers see it; decision paths hold it only while they capture the pointers and enqueue,
     // loaders hold it for the whole call, a commit only for its final pointer swap)
-    std::mutex batch_mu, mu, err_mu;
+    std::mutex batch_mu, mu, err_mu, cs_mu;
+    // caller-owned streams that *_dev calls were enqueued on (leaf lock cs_mu): whoever rewrites state a decision
+    // kernel reads waits for them as well as for the library's own streams (quiesce_decisions)
+    std::vector<hipStream_t> caller_streams;
     std::string err;
     FastSlot fast[kFastSlots];
     std::atomic<uint32_t> fast_rr{0};
@@ -210,11 +215,11 @@ int fail(mmp_ctx *c, int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
+    g_thread_err = buf;
     if (c) {
         std::lock_guard<std::mutex> g(c->err_mu);
-        c->err = buf;
-    } else
-        g_create_err = buf;
+        c->err = buf;  // kept for debuggers; readers go through the thread-local copy
+    }
     return code;
 }
 
@@ -273,7 +278,26 @@ hipError_t quiesce_decisions(mmp_ctx *c)
         hipError_t e = hipStreamSynchronize(f.stream);
         if (e != hipSuccess) return e;
     }
+    std::vector<hipStream_t> cs;
+    {
+        std::lock_guard<std::mutex> g(c->cs_mu);
+        cs = c->caller_streams;
+    }
+    for (hipStream_t st : cs) {
+        hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return e;
+    }
     return hipStreamSynchronize(c->stream);
+}
+
+// a *_dev call was enqueued on `st` (called with c->mu held)
+void note_caller_stream(mmp_ctx *c, hipStream_t st)
+{
+    if (st == c->stream) return;
+    std::lock_guard<std::mutex> g(c->cs_mu);
+    for (hipStream_t k : c->caller_streams)
+        if (k == st) return;
+    c->caller_streams.push_back(st);
 }
 
 // Re-resolve every model's entry list against a snapshot's rank positions, into that snapshot's side state.
@@ -464,12 +488,12 @@ void mmp_destroy(mmp_ctx *c)
     delete c;
 }
 
-const char *mmp_last_error(mmp_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+const char *mmp_last_error(mmp_ctx *) { return g_thread_err.c_str(); }
 
 int mmp_backend(mmp_ctx *c) { return c ? 1 : 0; }
 
 int mmp_profile(mmp_ctx *c, int enable)
-{
+try {
     if (!c) return MMP_EINVAL;
     std::lock_guard<std::mutex> gb(c->batch_mu);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
@@ -480,30 +504,42 @@ int mmp_profile(mmp_ctx *c, int enable)
     c->prof = enable != 0;
     c->last_kernel_ms = -1.0;
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_backend");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_backend", e.what());
 }
 
 double mmp_last_kernel_ms(mmp_ctx *c) { return c ? c->last_kernel_ms : -1.0; }
 
 int mmp_sync(mmp_ctx *c)
-{
+try {
     if (!c) return MMP_EINVAL;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_sync");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_sync", e.what());
 }
 
 /* ---- staging of the instance table -------------------------------------- */
 
 int mmp_pods_load(mmp_ctx *c, const mmp_pod_row *rows, int32_t n)
-{
+try {
     if (!c || n < 0 || (n > 0 && !rows)) return fail(c, MMP_EINVAL, "mmp_pods_load: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     c->pods.assign(rows, rows + n);
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_pods_load");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_pods_load", e.what());
 }
 
 int mmp_pods_upsert(mmp_ctx *c, const int32_t *idx, const mmp_pod_row *rows, int32_t n)
-{
+try {
     if (!c || n < 0 || (n > 0 && (!rows || !idx))) return fail(c, MMP_EINVAL, "mmp_pods_upsert: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
@@ -516,10 +552,14 @@ int mmp_pods_upsert(mmp_ctx *c, const int32_t *idx, const mmp_pod_row *rows, int
             c->pods[k] = rows[i];
     }
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_pods_upsert");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_pods_upsert", e.what());
 }
 
 int mmp_pods_remove(mmp_ctx *c, const int32_t *idx, int32_t n)
-{
+try {
     if (!c || n < 0 || (n > 0 && !idx)) return fail(c, MMP_EINVAL, "mmp_pods_remove: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
@@ -530,11 +570,15 @@ int mmp_pods_remove(mmp_ctx *c, const int32_t *idx, int32_t n)
         c->pods[k].flags &= ~MMP_POD_LIVE;
     }
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_pods_remove");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_pods_remove", e.what());
 }
 
 int mmp_types_load(mmp_ctx *c, int32_t n_types, const uint64_t *allowed, const uint64_t *prefer,
                    const uint8_t *has_allowed, const uint8_t *has_prefer)
-{
+try {
     if (!c || n_types < 0) return fail(c, MMP_EINVAL, "mmp_types_load: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
@@ -559,12 +603,16 @@ int mmp_types_load(mmp_ctx *c, int32_t n_types, const uint64_t *allowed, const u
         }
     }
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_types_load");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_types_load", e.what());
 }
 
 int mmp_types_from_labels(mmp_ctx *c, int32_t n_types, const uint64_t *required, const uint64_t *preferred,
                           const uint64_t *pod_labels, uint64_t *allowed_out, uint64_t *prefer_out,
                           uint8_t *has_allowed_out, uint8_t *has_prefer_out)
-{
+try {
     if (!c || n_types < 0 || (n_types > 0 && (!required || !preferred)))
         return fail(c, MMP_EINVAL, "mmp_types_from_labels: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
@@ -619,15 +667,23 @@ int mmp_types_from_labels(mmp_ctx *c, int32_t n_types, const uint64_t *required,
     if (has_allowed_out) memcpy(has_allowed_out, c->has_allowed.data(), R);
     if (has_prefer_out) memcpy(has_prefer_out, c->has_prefer.data(), R);
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_types_from_labels");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_types_from_labels", e.what());
 }
 
 int mmp_replaced_rs_load(mmp_ctx *c, const int32_t *rs, int32_t n)
-{
+try {
     if (!c || n < 0 || (n > 0 && !rs)) return fail(c, MMP_EINVAL, "mmp_replaced_rs_load: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     c->replaced_rs.assign(rs, rs + n);
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_replaced_rs_load");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_replaced_rs_load", e.what());
 }
 
 static void publish_upgrades(mmp_ctx *c)
@@ -637,37 +693,49 @@ static void publish_upgrades(mmp_ctx *c)
 }
 
 int mmp_upgrade_instance_added(mmp_ctx *c, int64_t labels_key, int32_t rs, int64_t start_time, int64_t now)
-{
+try {
     if (!c) return MMP_EINVAL;
     std::lock_guard<std::mutex> gb(c->batch_mu);  // replaced_rs is an input of the commit
     std::lock_guard<std::mutex> g(c->mu);
     c->upgrades.instance_added(labels_key, rs, start_time, now);
     publish_upgrades(c);
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_upgrade_instance_added");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_upgrade_instance_added", e.what());
 }
 
 int mmp_upgrade_instance_removed(mmp_ctx *c, int64_t labels_key, int32_t rs, int64_t now)
-{
+try {
     if (!c) return MMP_EINVAL;
     std::lock_guard<std::mutex> gb(c->batch_mu);  // replaced_rs is an input of the commit
     std::lock_guard<std::mutex> g(c->mu);
     c->upgrades.instance_removed(labels_key, rs, now);
     publish_upgrades(c);
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_upgrade_instance_removed");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_upgrade_instance_removed", e.what());
 }
 
 int mmp_upgrade_housekeeping(mmp_ctx *c, int64_t now)
-{
+try {
     if (!c) return MMP_EINVAL;
     std::lock_guard<std::mutex> gb(c->batch_mu);  // replaced_rs is an input of the commit
     std::lock_guard<std::mutex> g(c->mu);
     c->upgrades.housekeeping(now);
     publish_upgrades(c);
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_upgrade_housekeeping");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_upgrade_housekeeping", e.what());
 }
 
 int mmp_upgrade_replaced(mmp_ctx *c, int32_t *rs_out, int64_t *expiry_out, int32_t max, int32_t *n_out)
-{
+try {
     if (!c || !n_out || max < 0 || (max > 0 && (!rs_out || !expiry_out))) return fail(c, MMP_EINVAL, "mmp_upgrade_replaced: bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     int32_t i = 0;
@@ -680,11 +748,15 @@ int mmp_upgrade_replaced(mmp_ctx *c, int32_t *rs_out, int64_t *expiry_out, int32
     }
     *n_out = i;
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_upgrade_replaced");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_upgrade_replaced", e.what());
 }
 
 int mmp_models_load(mmp_ctx *c, const mmp_model_row *rows, int32_t n_models, const int32_t *ent_pod,
                     const int64_t *ent_time, int32_t n_entries)
-{
+try {
     if (!c || n_models < 0 || n_entries < 0 || (n_models > 0 && !rows) || (n_entries > 0 && (!ent_pod || !ent_time)))
         return fail(c, MMP_EINVAL, "mmp_models_load: bad argument");
     for (int32_t i = 0; i < n_models; i++) {
@@ -715,6 +787,10 @@ int mmp_models_load(mmp_ctx *c, const mmp_model_row *rows, int32_t n_models, con
         c->ent_live += c->m_cnt[i];
     }
     return rebuild_resolved(c);
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_models_load");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_models_load", e.what());
 }
 
 namespace {
@@ -778,7 +854,7 @@ int compact_registry(mmp_ctx *c)
 
 int mmp_models_upsert(mmp_ctx *c, const int32_t *idx, const mmp_model_row *rows, int32_t n, const int32_t *ent_pod,
                       const int64_t *ent_time, int32_t n_entries)
-{
+try {
     if (!c || n < 0 || n_entries < 0 || (n > 0 && (!idx || !rows)) || (n_entries > 0 && (!ent_pod || !ent_time)))
         return fail(c, MMP_EINVAL, "mmp_models_upsert: bad argument");
     if (n == 0) return MMP_OK;
@@ -864,6 +940,10 @@ int mmp_models_upsert(mmp_ctx *c, const int32_t *idx, const mmp_model_row *rows,
         if ((int64_t)c->n_entries - c->ent_live > std::max<int64_t>(c->ent_live, 1 << 16)) return compact_registry(c);
     }
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_models_upsert");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_models_upsert", e.what());
 }
 
 /* ---- commit: rank + permute + bitmaps + stats, all on the device --------- */
@@ -923,7 +1003,7 @@ int build_subset_stats(mmp_ctx *c, SnapSide &N, const mmp_pod_row *d_pods, int32
 }  // namespace
 
 int mmp_snapshot_commit(mmp_ctx *c)
-{
+try {
     if (!c) return MMP_EINVAL;
     // Wait-free for decisions (SURVEY.md §8b "Threading"): the whole build runs with batch_mu only.  batch_mu keeps
     // the inputs still — every loader of the instance table, the type table, the registry and the replica-set list
@@ -1140,10 +1220,14 @@ int mmp_snapshot_commit(mmp_ctx *c)
     c->stats.instance_count = acc.instance_count;
     c->stats.model_copy_count = acc.model_copy_count;
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_snapshot_commit");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_snapshot_commit", e.what());
 }
 
 int mmp_get_order(mmp_ctx *c, int32_t *order_out, int32_t *n_out)
-{
+try {
     if (!c || !order_out || !n_out) return fail(c, MMP_EINVAL, "mmp_get_order: null argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
@@ -1154,16 +1238,24 @@ int mmp_get_order(mmp_ctx *c, int32_t *order_out, int32_t *n_out)
     if (n) HIP_TRY(c, copy_sync(c, order_out, c->snap.orig, (size_t)n * 4, hipMemcpyDeviceToHost));
     *n_out = n;
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_get_order");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_get_order", e.what());
 }
 
 int mmp_cluster_stats(mmp_ctx *c, mmp_stats *out)
-{
+try {
     if (!c || !out) return fail(c, MMP_EINVAL, "mmp_cluster_stats: null argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     *out = c->stats;
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_cluster_stats");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_cluster_stats", e.what());
 }
 
 namespace {
@@ -1180,26 +1272,34 @@ mmp_stats stats_of(const StatsAcc &a)
 }  // namespace
 
 int mmp_type_stats(mmp_ctx *c, int32_t type, mmp_stats *out)
-{
+try {
     if (!c || !out) return fail(c, MMP_EINVAL, "mmp_type_stats: null argument");
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     const int32_t T = (int32_t)cur_side(c).tstats_h.size();
     *out = stats_of(cur_side(c).tstats_h[(type < 0 || type >= T) ? 0 : type]);
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_type_stats");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_type_stats", e.what());
 }
 
 int mmp_partition_count(mmp_ctx *c, int32_t *n_out)
-{
+try {
     if (!c || !n_out) return fail(c, MMP_EINVAL, "mmp_partition_count: null argument");
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     *n_out = cur_side(c).n_pts;
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_partition_count");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_partition_count", e.what());
 }
 
 int mmp_partition_stats(mmp_ctx *c, int32_t partition, mmp_stats *out, uint64_t *prohibited_out, int32_t max_words)
-{
+try {
     if (!c || !out || max_words < 0 || (max_words > 0 && !prohibited_out))
         return fail(c, MMP_EINVAL, "mmp_partition_stats: bad argument");
     std::lock_guard<std::mutex> g(c->mu);
@@ -1209,10 +1309,14 @@ int mmp_partition_stats(mmp_ctx *c, int32_t partition, mmp_stats *out, uint64_t 
     for (int32_t w = 0; w < max_words; w++)
         prohibited_out[w] = w < cur_side(c).pts_tw ? cur_side(c).pts_prohib[(size_t)partition * cur_side(c).pts_tw + w] : 0;
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_partition_stats");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_partition_stats", e.what());
 }
 
 int mmp_pod_partitions(mmp_ctx *c, int32_t *partition_out, int32_t max_pods, int32_t *n_out)
-{
+try {
     if (!c || !n_out || max_pods < 0 || (max_pods > 0 && !partition_out))
         return fail(c, MMP_EINVAL, "mmp_pod_partitions: bad argument");
     std::lock_guard<std::mutex> g(c->mu);
@@ -1221,6 +1325,10 @@ int mmp_pod_partitions(mmp_ctx *c, int32_t *partition_out, int32_t max_pods, int
     const int32_t m = std::min(*n_out, max_pods);
     if (m > 0) memcpy(partition_out, cur_side(c).pts_of.data(), (size_t)m * 4);
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_pod_partitions");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_pod_partitions", e.what());
 }
 
 /* ---- wire-format ingestion (§8f-1) ------------------------------------------ */
@@ -1270,7 +1378,7 @@ int build_hash_table(mmp_ctx *c, const char *strs, const int32_t *off, int32_t n
 
 int mmp_pod_ids_load(mmp_ctx *c, const char *ids, const int32_t *id_off, int32_t n_pods, uint32_t *id_order_out,
                      int32_t *replica_set_out)
-{
+try {
     if (!c || n_pods < 0 || !id_off || (n_pods > 0 && !ids)) return fail(c, MMP_EINVAL, "mmp_pod_ids_load: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
@@ -1311,11 +1419,15 @@ int mmp_pod_ids_load(mmp_ctx *c, const char *ids, const int32_t *id_off, int32_t
     if (id_order_out && n_pods) memcpy(id_order_out, c->id_order_v.data(), (size_t)n_pods * 4);
     if (replica_set_out && n_pods) memcpy(replica_set_out, c->replica_set_v.data(), (size_t)n_pods * 4);
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_pod_ids_load");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_pod_ids_load", e.what());
 }
 
 int mmp_pods_ingest_json(mmp_ctx *c, const char *buf, const int64_t *off, int32_t n, const int32_t *pod_idx,
                          const uint8_t *live, int64_t *start_time_out, int32_t *status_out)
-{
+try {
     if (!c || n < 0 || (n > 0 && (!buf || !off || !pod_idx || !status_out)))
         return fail(c, MMP_EINVAL, "mmp_pods_ingest_json: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
@@ -1365,10 +1477,14 @@ int mmp_pods_ingest_json(mmp_ctx *c, const char *buf, const int64_t *off, int32_
         if (start_time_out) start_time_out[i] = stt[i];
     }
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_pods_ingest_json");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_pods_ingest_json", e.what());
 }
 
 int mmp_type_names_load(mmp_ctx *c, const char *names, const int32_t *name_off, int32_t n_types, int32_t unknown_type)
-{
+try {
     if (!c || n_types < 0 || !name_off || (n_types > 0 && !names)) return fail(c, MMP_EINVAL, "mmp_type_names_load: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
@@ -1384,11 +1500,15 @@ int mmp_type_names_load(mmp_ctx *c, const char *names, const int32_t *name_off, 
             c->default_type = i;
     c->have_types = true;
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_type_names_load");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_type_names_load", e.what());
 }
 
 int mmp_models_ingest_json(mmp_ctx *c, const char *buf, const int64_t *off, int32_t n_models, int64_t *last_unload_out,
                            int32_t *status_out)
-{
+try {
     if (!c || n_models < 0 || (n_models > 0 && (!buf || !off || !status_out)))
         return fail(c, MMP_EINVAL, "mmp_models_ingest_json: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
@@ -1469,21 +1589,29 @@ int mmp_models_ingest_json(mmp_ctx *c, const char *buf, const int64_t *off, int3
     c->n_entries = total;
     c->ent_live = total;
     return rebuild_resolved(c);
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_models_ingest_json");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_models_ingest_json", e.what());
 }
 
 int mmp_pods_get(mmp_ctx *c, mmp_pod_row *rows_out, int32_t max_rows, int32_t *n_out)
-{
+try {
     if (!c || !n_out || max_rows < 0 || (max_rows > 0 && !rows_out)) return fail(c, MMP_EINVAL, "mmp_pods_get: bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     *n_out = (int32_t)c->pods.size();
     const int32_t m = std::min(*n_out, max_rows);
     if (m > 0) memcpy(rows_out, c->pods.data(), (size_t)m * sizeof(mmp_pod_row));
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_pods_get");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_pods_get", e.what());
 }
 
 int mmp_models_get(mmp_ctx *c, mmp_model_row *rows_out, int32_t max_models, int32_t *ent_pod_out, int64_t *ent_time_out,
                    int32_t max_entries, int32_t *n_models_out, int32_t *n_entries_out)
-{
+try {
     if (!c || !n_models_out || !n_entries_out || max_models < 0 || max_entries < 0)
         return fail(c, MMP_EINVAL, "mmp_models_get: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
@@ -1497,12 +1625,16 @@ int mmp_models_get(mmp_ctx *c, mmp_model_row *rows_out, int32_t max_models, int3
     if (e > 0 && ent_pod_out) HIP_TRY(c, copy_sync(c, ent_pod_out, c->ent_pod.p, (size_t)e * 4, hipMemcpyDeviceToHost));
     if (e > 0 && ent_time_out) HIP_TRY(c, copy_sync(c, ent_time_out, c->ent_time.p, (size_t)e * 8, hipMemcpyDeviceToHost));
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_models_get");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_models_get", e.what());
 }
 
 /* ---- pod-axis sharding --------------------------------- */
 
 int mmp_shard_configure(mmp_ctx *c, int32_t shard, int32_t n_shards)
-{
+try {
     if (!c || n_shards < 1 || n_shards > kMaxShards || shard < 0 || shard >= n_shards)
         return fail(c, MMP_EINVAL, "mmp_shard_configure: need 0 <= shard < n_shards <= %d", kMaxShards);
     std::lock_guard<std::mutex> gb(c->batch_mu);
@@ -1512,6 +1644,10 @@ int mmp_shard_configure(mmp_ctx *c, int32_t shard, int32_t n_shards)
     c->committed = false;
     c->rank_pending = false;
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shard_configure");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_shard_configure", e.what());
 }
 
 int32_t mmp_shard_xchg_slots(int32_t phase, int32_t n_shards)
@@ -1530,7 +1666,7 @@ int32_t mmp_shard_xchg_slots(int32_t phase, int32_t n_shards)
 int32_t mmp_shard_xchg_is_sum(int32_t phase) { return phase == 5 ? 1 : 0; }
 
 int mmp_shard_rank_dev(mmp_ctx *c, void *d_rank)
-{
+try {
     if (!c || !d_rank) return fail(c, MMP_EINVAL, "mmp_shard_rank_dev: null argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
@@ -1559,10 +1695,14 @@ int mmp_shard_rank_dev(mmp_ctx *c, void *d_rank)
     HIP_TRY(c, hipStreamSynchronize(st));
     c->rank_pending = true;
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shard_rank_dev");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_shard_rank_dev", e.what());
 }
 
 int mmp_shard_commit_dev(mmp_ctx *c, const void *d_rank)
-{
+try {
     if (!c || !d_rank) return fail(c, MMP_EINVAL, "mmp_shard_commit_dev: null argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
@@ -1733,11 +1873,15 @@ int mmp_shard_commit_dev(mmp_ctx *c, const void *d_rank)
     c->stats.instance_count = acc.instance_count;
     c->stats.model_copy_count = acc.model_copy_count;
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shard_commit_dev");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_shard_commit_dev", e.what());
 }
 
 int mmp_shard_place_phase_dev(mmp_ctx *c, int32_t phase, const void *d_reqs, int32_t n, const void *d_extra, int64_t now,
                               void *const *d_xchg, void *d_outs, void *stream)
-{
+try {
     if (!c || phase < 1 || phase > 7 || n < 0 || !d_xchg || (n > 0 && (!d_reqs || (phase == 7 && !d_outs))))
         return fail(c, MMP_EINVAL, "mmp_shard_place_phase_dev: bad argument");
     for (int i = 0; i < 6; i++)
@@ -1763,6 +1907,7 @@ int mmp_shard_place_phase_dev(mmp_ctx *c, int32_t phase, const void *d_reqs, int
     XchgPtrs X{static_cast<int64_t *>(d_xchg[0]), static_cast<int64_t *>(d_xchg[1]), static_cast<int64_t *>(d_xchg[2]),
                static_cast<int64_t *>(d_xchg[3]), static_cast<int64_t *>(d_xchg[4]), static_cast<int64_t *>(d_xchg[5])};
     hipStream_t st = static_cast<hipStream_t>(stream);
+    note_caller_stream(c, st);
     const ShardSnap &S = c->ssnap;
     const int wpad = (std::max(S.Wn, 1) + 1) & ~1;
     const size_t lds = (size_t)kPlaceWaves * 2 * wpad * sizeof(uint64_t);
@@ -1780,6 +1925,10 @@ int mmp_shard_place_phase_dev(mmp_ctx *c, int32_t phase, const void *d_reqs, int
     }
     HIP_TRY(c, hipGetLastError());
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shard_place_phase_dev");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_shard_place_phase_dev", e.what());
 }
 
 int32_t mmp_shard_fast_slots(void) { return kXF; }
@@ -1808,21 +1957,26 @@ PlaceArgs shard_args(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_ex
 
 int mmp_shard_place_fast_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_xf,
                              void *stream)
-{
+try {
     if (!c || n < 0 || (n > 0 && (!d_reqs || !d_xf))) return fail(c, MMP_EINVAL, "mmp_shard_place_fast_dev: bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     if (c->n_shards < 1 || !c->committed) return fail(c, MMP_ESTATE, "no committed shard snapshot");
     if (n == 0) return MMP_OK;
     const PlaceArgs A = shard_args(c, d_reqs, n, d_extra, now, nullptr);
+    note_caller_stream(c, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(place_shard_fast_kernel, dim3(div_up(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), c->sview, A,
                        c->shard, static_cast<int64_t *>(d_xf));
     HIP_TRY(c, hipGetLastError());
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shard_place_fast_dev");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_shard_place_fast_dev", e.what());
 }
 
 int mmp_shard_place_fast_finish_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_xf, void *d_outs, void *stream,
                                     int32_t *n_rest_out, void **d_rest_reqs_out, void **d_rest_outs_out)
-{
+try {
     if (!c || n < 0 || !n_rest_out || !d_rest_reqs_out || !d_rest_outs_out || (n > 0 && (!d_reqs || !d_xf || !d_outs)))
         return fail(c, MMP_EINVAL, "mmp_shard_place_fast_finish_dev: bad argument");
     std::lock_guard<std::mutex> g(c->mu);
@@ -1832,6 +1986,7 @@ int mmp_shard_place_fast_finish_dev(mmp_ctx *c, const void *d_reqs, int32_t n, c
     if (n == 0) return MMP_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    note_caller_stream(c, st);
     HIP_TRY(c, c->f_flags.ensure((size_t)(n + 1) * 4));
     HIP_TRY(c, c->f_offs.ensure((size_t)(n + 1) * 4));
     HIP_TRY(c, c->f_idx.ensure((size_t)n * 4));
@@ -1855,10 +2010,14 @@ int mmp_shard_place_fast_finish_dev(mmp_ctx *c, const void *d_reqs, int32_t n, c
     *d_rest_reqs_out = c->f_reqs.p;
     *d_rest_outs_out = c->f_outs.p;
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shard_place_fast_finish_dev");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_shard_place_fast_finish_dev", e.what());
 }
 
 int mmp_shard_place_fast_scatter_dev(mmp_ctx *c, int32_t n_rest, void *d_outs, void *stream)
-{
+try {
     if (!c || n_rest < 0 || (n_rest > 0 && !d_outs)) return fail(c, MMP_EINVAL, "mmp_shard_place_fast_scatter_dev: bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     if (c->n_shards < 1 || !c->committed) return fail(c, MMP_ESTATE, "no committed shard snapshot");
@@ -1867,23 +2026,51 @@ int mmp_shard_place_fast_scatter_dev(mmp_ctx *c, int32_t n_rest, void *d_outs, v
                        c->f_outs.as<mmp_place_out>(), c->f_idx.as<int32_t>(), n_rest, static_cast<mmp_place_out *>(d_outs));
     HIP_TRY(c, hipGetLastError());
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shard_place_fast_scatter_dev");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_shard_place_fast_scatter_dev", e.what());
 }
 
 /* ---- decisions ---------------------------------------------------------- */
 
 int mmp_place_batch_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs,
                         void *stream)
-{
+try {
     if (!c || n < 0 || (n > 0 && (!d_reqs || !d_outs))) return fail(c, MMP_EINVAL, "mmp_place_batch_dev: bad argument");
     std::lock_guard<std::mutex> g(c->mu);  // capture the published snapshot + enqueue; no wait
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
+    note_caller_stream(c, static_cast<hipStream_t>(stream));
     return place_launch(c, d_reqs, n, d_extra, now, d_outs, static_cast<hipStream_t>(stream));
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_place_batch_dev");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_place_batch_dev", e.what());
+}
+
+int mmp_stream_retire(mmp_ctx *c, void *stream)
+try {
+    if (!c) return MMP_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    {
+        std::lock_guard<std::mutex> g(c->cs_mu);
+        auto it = std::find(c->caller_streams.begin(), c->caller_streams.end(), st);
+        if (it == c->caller_streams.end()) return MMP_OK;
+        c->caller_streams.erase(it);
+    }
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, hipStreamSynchronize(st));  // what was enqueued on it has finished reading the library's tables
+    return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_stream_retire");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_stream_retire", e.what());
 }
 
 int mmp_place_batch(mmp_ctx *c, const mmp_place_req *reqs, int32_t n, const int32_t *extra_pool, int32_t n_extra,
                     int64_t now, mmp_place_out *outs)
-{
+try {
     if (!c || n < 0 || n_extra < 0 || (n > 0 && (!reqs || !outs)) || (n_extra > 0 && !extra_pool))
         return fail(c, MMP_EINVAL, "mmp_place_batch: bad argument");
     for (int32_t i = 0; i < n; i++)
@@ -1937,19 +2124,25 @@ int mmp_place_batch(mmp_ctx *c, const mmp_place_req *reqs, int32_t n, const int3
     HIP_TRY(c, hipStreamSynchronize(st));
     kt_collect(c);
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_place_batch");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_place_batch", e.what());
 }
 
 int mmp_serve_batch(mmp_ctx *c, const mmp_serve_req *reqs, int32_t n, const int32_t *in_use, const int64_t *last_used,
                     const int32_t *excl_pod, const int64_t *excl_time, int32_t n_excl, int64_t now, mmp_serve_out *outs)
-{
+try {
     if (!c || n < 0 || n_excl < 0 || (n > 0 && (!reqs || !outs || !in_use || !last_used)) ||
         (n_excl > 0 && (!excl_pod || !excl_time)))
         return fail(c, MMP_EINVAL, "mmp_serve_batch: bad argument");
     for (int32_t i = 0; i < n; i++)
         if (reqs[i].n_excl < 0 || reqs[i].excl_off < 0 || (int64_t)reqs[i].excl_off + reqs[i].n_excl > n_excl)
             return fail(c, MMP_EINVAL, "mmp_serve_batch: request %d exclude range out of bounds", i);
+    // batch_mu owns c->stream and the scratch for the whole call, and every writer of the state this call reads
+    // (commit, the loaders, registry events) takes it too: the published snapshot cannot change underneath.  The
+    // state lock c->mu is NOT held: latency-path calls (mmp_place_batch / _gate / _evict on the slots) keep flowing.
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     if (n == 0) return MMP_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
@@ -1993,6 +2186,10 @@ int mmp_serve_batch(mmp_ctx *c, const mmp_serve_req *reqs, int32_t n, const int3
     HIP_TRY(c, hipStreamSynchronize(st));
     kt_collect(c);
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_serve_batch");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_serve_batch", e.what());
 }
 
 namespace {
@@ -2025,7 +2222,7 @@ GateArgs gate_args(mmp_ctx *c, int32_t n, int64_t now, int64_t in_use_expiry)
 int mmp_gate_batch(mmp_ctx *c, const mmp_gate_req *reqs, int32_t n, const int32_t *excl_pod, const int64_t *excl_time,
                    int32_t n_excl, const int32_t *explicit_pool, int32_t n_explicit, int64_t now, int64_t in_use_expiry,
                    mmp_gate_out *outs)
-{
+try {
     if (!c || n < 0 || n_excl < 0 || n_explicit < 0 || (n > 0 && (!reqs || !outs)) ||
         (n_excl > 0 && (!excl_pod || !excl_time)) || (n_explicit > 0 && !explicit_pool))
         return fail(c, MMP_EINVAL, "mmp_gate_batch: bad argument");
@@ -2066,8 +2263,10 @@ int mmp_gate_batch(mmp_ctx *c, const mmp_gate_req *reqs, int32_t n, const int32_
         memcpy(outs, f->outs, (size_t)n * sizeof(mmp_gate_out));
         return MMP_OK;
     }
+    // batch_mu owns c->stream and the scratch for the whole call, and every writer of the state this call reads
+    // (commit, the loaders, registry events) takes it too: the published snapshot cannot change underneath.  The
+    // state lock c->mu is NOT held: latency-path calls (mmp_place_batch / _gate / _evict on the slots) keep flowing.
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     if (n == 0) return MMP_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
@@ -2097,22 +2296,32 @@ int mmp_gate_batch(mmp_ctx *c, const mmp_gate_req *reqs, int32_t n, const int32_
     HIP_TRY(c, hipStreamSynchronize(st));
     kt_collect(c);
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_gate_batch");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_gate_batch", e.what());
 }
 
 int mmp_proactive_plan(mmp_ctx *c, int32_t default_units, int64_t now, int32_t max_out, int32_t *out_model,
                        int64_t *out_last_used, mmp_proactive_info *info)
-{
+try {
     return mmp_proactive_plan_subset(c, -1, nullptr, 0, default_units, now, max_out, out_model, out_last_used, info);
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_proactive_plan");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_proactive_plan", e.what());
 }
 
 int mmp_proactive_plan_subset(mmp_ctx *c, int32_t partition, const int32_t *skip_models, int32_t n_skip, int32_t default_units,
                               int64_t now, int32_t max_out, int32_t *out_model, int64_t *out_last_used,
                               mmp_proactive_info *info)
-{
+try {
     if (!c || !info || max_out < 0 || n_skip < 0 || (n_skip > 0 && !skip_models) || (max_out > 0 && (!out_model || !out_last_used)))
         return fail(c, MMP_EINVAL, "mmp_proactive_plan: bad argument");
+    // batch_mu owns c->stream and the scratch for the whole call, and every writer of the state this call reads
+    // (commit, the loaders, registry events) takes it too: the published snapshot cannot change underneath.  The
+    // state lock c->mu is NOT held: latency-path calls (mmp_place_batch / _gate / _evict on the slots) keep flowing.
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     if (partition >= cur_side(c).n_pts || partition < -1) return fail(c, MMP_EINVAL, "mmp_proactive_plan: no partition %d", partition);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
@@ -2203,15 +2412,21 @@ int mmp_proactive_plan_subset(mmp_ctx *c, int32_t partition, const int32_t *skip
     info->space_to_fill = h.space_to_fill;
     info->cutoff = h.cutoff;
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_proactive_plan_subset");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_proactive_plan_subset", e.what());
 }
 
 int mmp_scaleup_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, const mmp_scaleup_params *p,
                      mmp_scaleup_out *outs, uint8_t *overloaded_out, int32_t *skipped)
-{
+try {
     if (!c || !p || !skipped || n < 0 || (n > 0 && (!entries || !outs)))
         return fail(c, MMP_EINVAL, "mmp_scaleup_plan: bad argument");
+    // batch_mu owns c->stream and the scratch for the whole call, and every writer of the state this call reads
+    // (commit, the loaders, registry events) takes it too: the published snapshot cannot change underneath.  The
+    // state lock c->mu is NOT held: latency-path calls (mmp_place_batch / _gate / _evict on the slots) keep flowing.
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     const int32_t P = c->snap.P;
     if (P > 0 && !overloaded_out) return fail(c, MMP_EINVAL, "mmp_scaleup_plan: overloaded_out is null");
@@ -2264,15 +2479,21 @@ int mmp_scaleup_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, cons
     HIP_TRY(c, hipStreamSynchronize(st));
     kt_collect(c);
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_scaleup_plan");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_scaleup_plan", e.what());
 }
 
 int mmp_scaledown_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, const mmp_scaledown_params *p,
                        uint8_t *removed_out)
-{
+try {
     if (!c || !p || n < 0 || (n > 0 && (!entries || !removed_out)))
         return fail(c, MMP_EINVAL, "mmp_scaledown_plan: bad argument");
+    // batch_mu owns c->stream and the scratch for the whole call, and every writer of the state this call reads
+    // (commit, the loaders, registry events) takes it too: the published snapshot cannot change underneath.  The
+    // state lock c->mu is NOT held: latency-path calls (mmp_place_batch / _gate / _evict on the slots) keep flowing.
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     if (n == 0) return MMP_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
@@ -2310,15 +2531,21 @@ int mmp_scaledown_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, co
     HIP_TRY(c, hipStreamSynchronize(st));
     kt_collect(c);
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_scaledown_plan");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_scaledown_plan", e.what());
 }
 
 int mmp_migration_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, int32_t self_pod, int64_t now,
                        int64_t cutoff_age_ms, uint8_t *action_out, uint8_t *wait_out)
-{
+try {
     if (!c || n < 0 || (n > 0 && (!entries || !action_out || !wait_out)))
         return fail(c, MMP_EINVAL, "mmp_migration_plan: bad argument");
+    // batch_mu owns c->stream and the scratch for the whole call, and every writer of the state this call reads
+    // (commit, the loaders, registry events) takes it too: the published snapshot cannot change underneath.  The
+    // state lock c->mu is NOT held: latency-path calls (mmp_place_batch / _gate / _evict on the slots) keep flowing.
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     if (n == 0) return MMP_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
@@ -2338,13 +2565,17 @@ int mmp_migration_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, in
     HIP_TRY(c, hipStreamSynchronize(st));
     kt_collect(c);
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_migration_plan");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_migration_plan", e.what());
 }
 
 /* ---- stateful keyed caches (a12 + a13) ------------------------------------- */
 
 int mmp_caches_load_keyed(mmp_ctx *c, int32_t n_caches, const int32_t *seg_off, const int64_t *last_used,
                           const int32_t *weight, const int32_t *key, const int64_t *capacity, const mmp_ubm_state *ubm)
-{
+try {
     if (!c || n_caches < 0 || !seg_off || (n_caches > 0 && !capacity)) return fail(c, MMP_EINVAL, "mmp_caches_load_keyed: bad argument");
     if (seg_off[0] != 0) return fail(c, MMP_EINVAL, "mmp_caches_load_keyed: seg_off[0] must be 0");
     for (int32_t i = 0; i < n_caches; i++)
@@ -2391,11 +2622,15 @@ int mmp_caches_load_keyed(mmp_ctx *c, int32_t n_caches, const int32_t *seg_off, 
     }
     c->k_caches = n_caches;
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_caches_load_keyed");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_caches_load_keyed", e.what());
 }
 
 int mmp_cache_replay(mmp_ctx *c, const mmp_cache_op *ops, int32_t n_ops, int64_t now, mmp_cache_op_out *outs,
                      int32_t *evicted_keys, int32_t max_evicted, int32_t *n_evicted_slots)
-{
+try {
     if (!c || n_ops < 0 || max_evicted < 0 || (n_ops > 0 && (!ops || !outs)) || (max_evicted > 0 && !evicted_keys) ||
         !n_evicted_slots)
         return fail(c, MMP_EINVAL, "mmp_cache_replay: bad argument");
@@ -2477,11 +2712,15 @@ int mmp_cache_replay(mmp_ctx *c, const mmp_cache_op *ops, int32_t n_ops, int64_t
     c->ks_cur = 1 - c->ks_cur;
     *n_evicted_slots = ev_off[NC];
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_cache_replay");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_cache_replay", e.what());
 }
 
 int mmp_cache_read(mmp_ctx *c, int32_t cache, int32_t max_entries, int64_t *last_used, int32_t *weight, int32_t *key,
                    int32_t *n_out, int64_t *capacity, int64_t *weighted_size, mmp_ubm_state *ubm)
-{
+try {
     if (!c || !n_out || max_entries < 0) return fail(c, MMP_EINVAL, "mmp_cache_read: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::mutex> g(c->mu);
@@ -2503,11 +2742,15 @@ int mmp_cache_read(mmp_ctx *c, int32_t cache, int32_t max_entries, int64_t *last
     if (weighted_size) HIP_TRY(c, copy_sync(c, weighted_size, c->k_wsize.as<int64_t>() + cache, 8, hipMemcpyDeviceToHost));
     if (ubm) HIP_TRY(c, copy_sync(c, ubm, c->k_ubm.as<mmp_ubm_state>() + cache, sizeof(mmp_ubm_state), hipMemcpyDeviceToHost));
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_cache_read");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_cache_read", e.what());
 }
 
 int mmp_caches_load(mmp_ctx *c, int32_t n_caches, const int32_t *seg_off, const int64_t *last_used,
                     const int32_t *weight, const int64_t *capacity)
-{
+try {
     if (!c || n_caches < 0 || !seg_off || (n_caches > 0 && !capacity)) return fail(c, MMP_EINVAL, "mmp_caches_load: bad argument");
     if (seg_off[0] != 0) return fail(c, MMP_EINVAL, "mmp_caches_load: seg_off[0] must be 0");
     for (int32_t i = 0; i < n_caches; i++)
@@ -2530,10 +2773,14 @@ int mmp_caches_load(mmp_ctx *c, int32_t n_caches, const int32_t *seg_off, const 
     if (n_caches) HIP_TRY(c, copy_sync(c, c->c_cap.p, capacity, (size_t)n_caches * 8, hipMemcpyHostToDevice));
     c->n_caches = n_caches;
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_caches_load");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_caches_load", e.what());
 }
 
 int mmp_evict_batch(mmp_ctx *c, const mmp_evict_req *reqs, int32_t n, int64_t now, mmp_evict_out *outs)
-{
+try {
     if (!c || n < 0 || (n > 0 && (!reqs || !outs))) return fail(c, MMP_EINVAL, "mmp_evict_batch: bad argument");
     if (n > 0 && (size_t)n * sizeof(mmp_evict_out) <= kFastN * sizeof(mmp_place_out)) {
         // latency path (see slot_acquire): one launch on a slot stream, no staging copies, no batch lock
@@ -2562,8 +2809,10 @@ int mmp_evict_batch(mmp_ctx *c, const mmp_evict_req *reqs, int32_t n, int64_t no
         memcpy(outs, f->outs, (size_t)n * sizeof(mmp_evict_out));
         return MMP_OK;
     }
+    // batch_mu owns c->stream and the scratch for the whole call, and every writer of the state this call reads
+    // (commit, the loaders, registry events) takes it too: the published snapshot cannot change underneath.  The
+    // state lock c->mu is NOT held: latency-path calls (mmp_place_batch / _gate / _evict on the slots) keep flowing.
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
     if (c->n_caches <= 0 && n > 0) return fail(c, MMP_ESTATE, "no caches loaded");
     if (n == 0) return MMP_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
@@ -2590,6 +2839,10 @@ int mmp_evict_batch(mmp_ctx *c, const mmp_evict_req *reqs, int32_t n, int64_t no
     HIP_TRY(c, hipStreamSynchronize(st));
     kt_collect(c);
     return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_evict_batch");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_evict_batch", e.what());
 }
 
 }  // extern "C"

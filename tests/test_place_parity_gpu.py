@@ -4,6 +4,8 @@ Every comparison goes through the C ABI (modelmesh_amd.solver -> libmmplace).
 Reference semantics: CacheMissForwardingLB.getNext, MM.java:4776-5005, and
 PLACEMENT_ORDER, MM.java:4646-4703.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -197,6 +199,43 @@ def _two_tables():
     for f in ("lru_time", "capacity", "used", "count", "rpm", "loading_in_progress"):
         b.pods[f] = b.pods[f][perm]
     return a, b
+
+
+def test_device_launches_on_a_caller_stream_are_retired_before_their_snapshot_is_rewritten():
+    """mmp_place_batch_dev enqueues on a stream the CALLER owns and returns.  Two commits later the snapshot those
+    kernels captured is rewritten, and a registry load frees the model table they read: the library waits for every
+    caller stream it was handed first (it only waited for its own streams).  A deep queue of launches on
+    one torch stream, then commits with another table and a registry reload, must leave every queued launch with
+    the answer of the table that was published when it was enqueued."""
+    import torch
+    from modelmesh_amd._lib import PLACE_OUT
+    a, b = _two_tables()
+    reqs, extra = wl.make_requests(a, 17, n=60_000, extra_frac=0.02)
+    wa = OracleFleet(a).place(reqs, extra, a.now, threads=8)
+    dev = torch.device("cuda", 0)
+    d_reqs = torch.from_numpy(reqs.view(np.uint8).reshape(-1)).to(dev)
+    d_extra = torch.from_numpy(np.ascontiguousarray(extra if len(extra) else np.zeros(1, np.int32))).to(dev)
+    n_launch = 300
+    d_outs = [torch.zeros(len(reqs) * 16, dtype=torch.uint8, device=dev) for _ in range(n_launch)]
+    st = torch.cuda.Stream(dev)
+    s = Solver(a.min_space_units, a.min_churn_age_ms)
+    try:
+        s.load_fleet(a)
+        torch.cuda.synchronize()
+        for o in d_outs:  # ~300 x 60k decisions queued on the caller's stream, none waited for
+            s.place_dev(d_reqs.data_ptr(), len(reqs), d_extra.data_ptr(), a.now, o.data_ptr(), st.cuda_stream)
+        for _ in range(2):  # the second commit rewrites the buffers the queued kernels captured
+            s.load_pods(b.pods)
+            s.commit()
+        s.load_models(b.models[::-1].copy(), b.ent_pod, b.ent_time)  # frees / replaces the registry view in place
+        torch.cuda.synchronize()
+        for k in (0, n_launch // 2, n_launch - 1):
+            got = np.frombuffer(d_outs[k].cpu().numpy().tobytes(), dtype=PLACE_OUT)
+            for f in ("chosen", "best", "n_candidates", "hash"):
+                assert np.array_equal(got[f], wa[f]), (k, f)
+        assert s.lib.mmp_stream_retire(s.h, C.c_void_p(st.cuda_stream)) == 0
+    finally:
+        s.close()
 
 
 def test_decisions_see_one_snapshot_or_the_other_while_commits_alternate():
