@@ -574,6 +574,41 @@ int mmp_shard_place_fast_finish_dev(mmp_ctx *ctx, const void *d_reqs, int32_t n,
                                     void *stream, int32_t *n_rest_out, void **d_rest_reqs_out, void **d_rest_outs_out);
 int mmp_shard_place_fast_scatter_dev(mmp_ctx *ctx, int32_t n_rest, void *d_outs, void *stream);
 
+/* ---- the pod-axis group with RCCL inside the boundary (north star: "the pod axis shards naturally across the 8
+ * GPUs of one node with an RCCL allreduce over xGMI of per-shard best-candidate scores") -------------------------
+ * One context per GPU (one process per GPU, or one thread per context).  The calls above leave the collectives to
+ * the host (a torch.distributed process group in modelmesh_amd/dist.py); the calls below run them themselves, on
+ * the context's own stream, through librccl (bound at run time), so that a host that holds no RCCL handles — the
+ * Java mesh — reaches the multi-GPU layout through host pointers alone:
+ *   rank 0:      mmp_shard_unique_id(id)                     128 bytes, handed to the other ranks out of band
+ *                                                            (the mesh's KV store, litelinks, a file ...)
+ *   every rank:  mmp_shard_group_init(ctx, id, rank, world)  ncclCommInitRank + mmp_shard_configure(rank, world)
+ *                load the instance table / types / registry as for an unsharded context
+ *                mmp_shard_commit(ctx)                       collective: rank slice -> ncclAllReduce(SUM) -> scatter
+ *                mmp_shard_place_batch(ctx, reqs, n, ...)    collective: every rank passes the SAME batch and gets
+ *                                                            the same result rows (bit-identical to mmp_place_batch)
+ * A batch is: place_shard_fast_kernel -> ncclAllReduce(MIN, 2 int64 per decision) -> decided rows + compaction of
+ * the undecided rest -> the six exchange phases (5 x MIN, 1 x SUM) over a sub-batch of fixed capacity
+ * max(1024, n / 16) whose real row count stays on the device (no host round trip between the kernels) -> scatter;
+ * only if more decisions than that capacity need the six phases are they run again at their exact size
+ * (*n_rest_out = how many took the six phases).  unique_id may be NULL for world == 1: a group of one shard
+ * without a communicator (no RCCL needed). */
+#define MMP_SHARD_UNIQUE_ID_BYTES 128
+int mmp_shard_unique_id(void *id_out);
+/* A host that moves the exchange words itself (another transport than RCCL; several shards driven from one process)
+ * installs a callback BEFORE mmp_shard_group_init and passes unique_id = NULL there.  The callback must all-reduce
+ * `count` elements at device pointer `dev_buf` in place across the group — elem64: 0 = int32, 1 = int64; op_min:
+ * 0 = SUM, 1 = MIN — ordered after everything already queued on `stream` (the context's hipStream_t), and return 0. */
+typedef int (*mmp_exchange_fn)(void *user, void *dev_buf, int64_t count, int32_t elem64, int32_t op_min, void *stream);
+int mmp_shard_group_set_exchange(mmp_ctx *ctx, mmp_exchange_fn fn, void *user);
+int mmp_shard_group_init(mmp_ctx *ctx, const void *unique_id, int32_t rank, int32_t world);
+int mmp_shard_group_destroy(mmp_ctx *ctx);
+int mmp_shard_commit(mmp_ctx *ctx);
+int mmp_shard_place_batch(mmp_ctx *ctx, const mmp_place_req *reqs, int32_t n, const int32_t *extra_pool,
+                          int32_t n_extra_pool, int64_t now_ms, mmp_place_out *outs, int32_t *n_rest_out);
+int mmp_shard_place_batch_dev(mmp_ctx *ctx, const void *d_reqs, int32_t n, const void *d_extra_pool, int64_t now_ms,
+                              void *d_outs, int32_t *n_rest_out);
+
 /* Wait for everything queued on the context's own stream. */
 int mmp_sync(mmp_ctx *ctx);
 

@@ -27,6 +27,19 @@ jint check(JNIEnv *env, mmp_ctx *c, int rc)
 }
 template <class T>
 T *buf(JNIEnv *env, jobject bb) { return bb ? static_cast<T *>(env->GetDirectBufferAddress(bb)) : nullptr; }
+
+// A direct buffer that must hold `count` elements of T: the C ABI trusts its sizes, the JVM must not (a short buffer
+// would be read or written past its end by the library).  Throws IllegalArgumentException and returns false.
+template <class T>
+bool holds(JNIEnv *env, jobject bb, jlong count, const char *what)
+{
+    if (count <= 0) return true;
+    const jlong cap = bb ? env->GetDirectBufferCapacity(bb) : -1;
+    if (cap >= 0 && cap >= count * static_cast<jlong>(sizeof(T))) return true;
+    jclass ex = env->FindClass("java/lang/IllegalArgumentException");
+    if (ex) env->ThrowNew(ex, what);
+    return false;
+}
 }  // namespace
 
 extern "C" {
@@ -99,9 +112,47 @@ JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_placeBatch(JNIEnv *
                                                                         jint n, jobject extraPool, jint nExtra,
                                                                         jlong nowMs, jobject outs)
 {
+    if (!holds<mmp_place_req>(env, reqs, n, "placeBatch: reqs shorter than n requests") ||
+        !holds<int32_t>(env, extraPool, nExtra, "placeBatch: extraPool shorter than nExtra entries") ||
+        !holds<mmp_place_out>(env, outs, n, "placeBatch: outs shorter than n results"))
+        return MMP_EINVAL;
     return check(env, ctx_of(h),
                  mmp_place_batch(ctx_of(h), buf<mmp_place_req>(env, reqs), n, buf<int32_t>(env, extraPool), nExtra,
                                  nowMs, buf<mmp_place_out>(env, outs)));
+}
+
+// ---- the pod-axis group (several GPUs of one node; RCCL runs inside libmmplace) ----
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_shardUniqueId(JNIEnv *env, jclass, jobject idOut)
+{
+    if (!holds<char>(env, idOut, MMP_SHARD_UNIQUE_ID_BYTES, "shardUniqueId: idOut shorter than 128 bytes")) return MMP_EINVAL;
+    return check(env, nullptr, mmp_shard_unique_id(buf<char>(env, idOut)));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_shardGroupInit(JNIEnv *env, jclass, jlong h, jobject id,
+                                                                            jint rank, jint world)
+{
+    if (id && !holds<char>(env, id, MMP_SHARD_UNIQUE_ID_BYTES, "shardGroupInit: id shorter than 128 bytes")) return MMP_EINVAL;
+    return check(env, ctx_of(h), mmp_shard_group_init(ctx_of(h), buf<char>(env, id), rank, world));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_shardGroupDestroy(JNIEnv *env, jclass, jlong h)
+{
+    return check(env, ctx_of(h), mmp_shard_group_destroy(ctx_of(h)));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_shardCommit(JNIEnv *env, jclass, jlong h)
+{
+    return check(env, ctx_of(h), mmp_shard_commit(ctx_of(h)));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_shardPlaceBatch(JNIEnv *env, jclass, jlong h, jobject reqs,
+                                                                             jint n, jobject extraPool, jint nExtra,
+                                                                             jlong nowMs, jobject outs, jobject nRestOut)
+{
+    if (!holds<mmp_place_req>(env, reqs, n, "shardPlaceBatch: reqs shorter than n requests") ||
+        !holds<int32_t>(env, extraPool, nExtra, "shardPlaceBatch: extraPool shorter than nExtra entries") ||
+        !holds<mmp_place_out>(env, outs, n, "shardPlaceBatch: outs shorter than n results") ||
+        (nRestOut && !holds<int32_t>(env, nRestOut, 1, "shardPlaceBatch: nRestOut shorter than one int")))
+        return MMP_EINVAL;
+    return check(env, ctx_of(h),
+                 mmp_shard_place_batch(ctx_of(h), buf<mmp_place_req>(env, reqs), n, buf<int32_t>(env, extraPool), nExtra,
+                                       nowMs, buf<mmp_place_out>(env, outs), buf<int32_t>(env, nRestOut)));
 }
 
 // ForwardingLB.getNext (MM.java:4315)

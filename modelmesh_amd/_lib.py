@@ -166,6 +166,13 @@ SYMBOLS = [
     ("mmp_shard_place_fast_finish_dev", C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_void_p),
                                                   C.POINTER(C.c_void_p)]),
     ("mmp_shard_place_fast_scatter_dev", C.c_int, [_P, C.c_int32, _P, _P]),
+    ("mmp_shard_unique_id", C.c_int, [_P]),
+    ("mmp_shard_group_set_exchange", C.c_int, [_P, _P, _P]),
+    ("mmp_shard_group_init", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    ("mmp_shard_group_destroy", C.c_int, [_P]),
+    ("mmp_shard_commit", C.c_int, [_P]),
+    ("mmp_shard_place_batch", C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int64, _P, C.POINTER(C.c_int32)]),
+    ("mmp_shard_place_batch_dev", C.c_int, [_P, _P, C.c_int32, _P, C.c_int64, _P, C.POINTER(C.c_int32)]),
     ("mmp_sync", C.c_int, [_P]),
     ("mmp_profile", C.c_int, [_P, C.c_int]),
     ("mmp_last_kernel_ms", C.c_double, [_P]),

@@ -6,6 +6,8 @@
 // shortlisting and victim selection runs in the kernels; there is no CPU
 // implementation of the path in this library.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enums only: the library is bound at run time (dlopen), not at link time
 #include <rocprim/device/device_radix_sort.hpp>
 #include <chrono>
 #include <rocprim/device/device_merge_sort.hpp>
@@ -164,6 +166,15 @@ struct mmp_ctx {
     Snap sview{};  // the lane path's view of this shard's slice (place_shard_fast_kernel)
     DevBuf f_flags, f_offs, f_idx, f_reqs, f_outs, f_scan_tmp;  // speculative form: the compacted rest of a batch
     bool rank_pending = false;
+
+    // RCCL group of the pod-axis shards (mmp_shard_group_init): collectives run on c->stream, inside the boundary
+    std::mutex group_mu;  // one group-level call at a time (taken before batch_mu / mu by the group entry points)
+    ncclComm_t comm = nullptr;
+    mmp_exchange_fn xfn = nullptr;  // a host-supplied transport instead of RCCL (mmp_shard_group_set_exchange)
+    void *xuser = nullptr;
+    bool group = false;
+    int32_t g_rank = 0, g_world = 1;
+    DevBuf g_rankbuf, g_xf, g_x[6];
 
     // commit scratch
     DevBuf rank, occupancy, flag, rs_list, rs_bad, d_prefer;
@@ -367,6 +378,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     A.n = n;
     A.n_models = c->n_models;
     A.now = now;
+    A.n_dev = nullptr;
     A.force_wave = c->force_wave;
     A.n_pods_all = c->snap.P;
     A.done_flag = done_flag;
@@ -448,6 +460,10 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     return MMP_OK;
 }
 
+namespace {
+void group_comm_destroy(ncclComm_t comm);  // defined with the RCCL binding below
+}
+
 void mmp_destroy(mmp_ctx *c)
 {
     if (!c) return;
@@ -464,10 +480,13 @@ void mmp_destroy(mmp_ctx *c)
         if (f.outs) (void)hipHostFree(f.outs);
     }
 
-    if (c->stream) {
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipStreamDestroy(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) {
+        group_comm_destroy(c->comm);
+        c->comm = nullptr;
     }
+    for (DevBuf *b : {&c->g_rankbuf, &c->g_xf, &c->g_x[0], &c->g_x[1], &c->g_x[2], &c->g_x[3], &c->g_x[4], &c->g_x[5]}) b->release();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->pe0) (void)hipEventDestroy(c->pe0);
     if (c->pe1) (void)hipEventDestroy(c->pe1);
     c->sb[0].release();
@@ -1879,16 +1898,11 @@ try {
     return fail(c, MMP_EHIP, "%s: %s", "mmp_shard_commit_dev", e.what());
 }
 
-int mmp_shard_place_phase_dev(mmp_ctx *c, int32_t phase, const void *d_reqs, int32_t n, const void *d_extra, int64_t now,
-                              void *const *d_xchg, void *d_outs, void *stream)
-try {
-    if (!c || phase < 1 || phase > 7 || n < 0 || !d_xchg || (n > 0 && (!d_reqs || (phase == 7 && !d_outs))))
-        return fail(c, MMP_EINVAL, "mmp_shard_place_phase_dev: bad argument");
-    for (int i = 0; i < 6; i++)
-        if (n > 0 && !d_xchg[i]) return fail(c, MMP_EINVAL, "mmp_shard_place_phase_dev: exchange buffer %d is null", i + 1);
-    std::lock_guard<std::mutex> g(c->mu);  // capture the published shard snapshot + enqueue; no wait
-    if (c->n_shards < 1 || !c->committed) return fail(c, MMP_ESTATE, "no committed shard snapshot");
-    if (n == 0) return MMP_OK;
+namespace {
+// one phase of the general protocol on `st` (called with c->mu held); n_dev: see PlaceArgs::n_dev
+int shard_phase_launch(mmp_ctx *c, int32_t phase, const void *d_reqs, int32_t n, const int32_t *n_dev, const void *d_extra,
+                       int64_t now, void *const *d_xchg, void *d_outs, hipStream_t st)
+{
     PlaceArgs A;
     A.reqs = static_cast<const mmp_place_req *>(d_reqs);
     A.models = c->models.as<mmp_model_row>();
@@ -1900,14 +1914,13 @@ try {
     A.n = n;
     A.n_models = c->n_models;
     A.now = now;
+    A.n_dev = n_dev;
     A.force_wave = 0;
     A.n_pods_all = c->ssnap.P;
     A.done_flag = nullptr;
     A.done_seq = 0;
     XchgPtrs X{static_cast<int64_t *>(d_xchg[0]), static_cast<int64_t *>(d_xchg[1]), static_cast<int64_t *>(d_xchg[2]),
                static_cast<int64_t *>(d_xchg[3]), static_cast<int64_t *>(d_xchg[4]), static_cast<int64_t *>(d_xchg[5])};
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    note_caller_stream(c, st);
     const ShardSnap &S = c->ssnap;
     const int wpad = (std::max(S.Wn, 1) + 1) & ~1;
     const size_t lds = (size_t)kPlaceWaves * 2 * wpad * sizeof(uint64_t);
@@ -1925,6 +1938,22 @@ try {
     }
     HIP_TRY(c, hipGetLastError());
     return MMP_OK;
+}
+}  // namespace
+
+int mmp_shard_place_phase_dev(mmp_ctx *c, int32_t phase, const void *d_reqs, int32_t n, const void *d_extra, int64_t now,
+                              void *const *d_xchg, void *d_outs, void *stream)
+try {
+    if (!c || phase < 1 || phase > 7 || n < 0 || !d_xchg || (n > 0 && (!d_reqs || (phase == 7 && !d_outs))))
+        return fail(c, MMP_EINVAL, "mmp_shard_place_phase_dev: bad argument");
+    for (int i = 0; i < 6; i++)
+        if (n > 0 && !d_xchg[i]) return fail(c, MMP_EINVAL, "mmp_shard_place_phase_dev: exchange buffer %d is null", i + 1);
+    std::lock_guard<std::mutex> g(c->mu);  // capture the published shard snapshot + enqueue; no wait
+    if (c->n_shards < 1 || !c->committed) return fail(c, MMP_ESTATE, "no committed shard snapshot");
+    if (n == 0) return MMP_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    note_caller_stream(c, st);
+    return shard_phase_launch(c, phase, d_reqs, n, nullptr, d_extra, now, d_xchg, d_outs, st);
 } catch (const std::bad_alloc &) {
     return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shard_place_phase_dev");
 } catch (const std::exception &e) {
@@ -1947,6 +1976,7 @@ PlaceArgs shard_args(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_ex
     A.n = n;
     A.n_models = c->n_models;
     A.now = now;
+    A.n_dev = nullptr;
     A.force_wave = 0;
     A.n_pods_all = c->ssnap.P;
     A.done_flag = nullptr;
@@ -1974,19 +2004,11 @@ try {
     return fail(c, MMP_EHIP, "%s: %s", "mmp_shard_place_fast_dev", e.what());
 }
 
-int mmp_shard_place_fast_finish_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_xf, void *d_outs, void *stream,
-                                    int32_t *n_rest_out, void **d_rest_reqs_out, void **d_rest_outs_out)
-try {
-    if (!c || n < 0 || !n_rest_out || !d_rest_reqs_out || !d_rest_outs_out || (n > 0 && (!d_reqs || !d_xf || !d_outs)))
-        return fail(c, MMP_EINVAL, "mmp_shard_place_fast_finish_dev: bad argument");
-    std::lock_guard<std::mutex> g(c->mu);
-    if (c->n_shards < 1 || !c->committed) return fail(c, MMP_ESTATE, "no committed shard snapshot");
-    *n_rest_out = 0;
-    *d_rest_reqs_out = *d_rest_outs_out = nullptr;
-    if (n == 0) return MMP_OK;
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    note_caller_stream(c, st);
+namespace {
+// flags -> exclusive scan -> gather of the undecided requests (decision order, identical on every shard); leaves
+// the number of them on the device at f_offs[n] (called with c->mu held)
+int shard_finish_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_xf, void *d_outs, hipStream_t st)
+{
     HIP_TRY(c, c->f_flags.ensure((size_t)(n + 1) * 4));
     HIP_TRY(c, c->f_offs.ensure((size_t)(n + 1) * 4));
     HIP_TRY(c, c->f_idx.ensure((size_t)n * 4));
@@ -2003,6 +2025,27 @@ try {
     hipLaunchKernelGGL(place_shard_gather_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, static_cast<const mmp_place_req *>(d_reqs),
                        n, c->f_flags.as<int32_t>(), c->f_offs.as<int32_t>(), c->f_reqs.as<mmp_place_req>(), c->f_idx.as<int32_t>());
     HIP_TRY(c, hipGetLastError());
+    return MMP_OK;
+}
+}  // namespace
+
+int mmp_shard_place_fast_finish_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_xf, void *d_outs, void *stream,
+                                    int32_t *n_rest_out, void **d_rest_reqs_out, void **d_rest_outs_out)
+try {
+    if (!c || n < 0 || !n_rest_out || !d_rest_reqs_out || !d_rest_outs_out || (n > 0 && (!d_reqs || !d_xf || !d_outs)))
+        return fail(c, MMP_EINVAL, "mmp_shard_place_fast_finish_dev: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->n_shards < 1 || !c->committed) return fail(c, MMP_ESTATE, "no committed shard snapshot");
+    *n_rest_out = 0;
+    *d_rest_reqs_out = *d_rest_outs_out = nullptr;
+    if (n == 0) return MMP_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    note_caller_stream(c, st);
+    {
+        const int rc = shard_finish_launch(c, d_reqs, n, d_xf, d_outs, st);
+        if (rc != MMP_OK) return rc;
+    }
     int32_t n_rest = 0;
     HIP_TRY(c, hipMemcpyAsync(&n_rest, c->f_offs.as<int32_t>() + n, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
@@ -2030,6 +2073,270 @@ try {
     return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shard_place_fast_scatter_dev");
 } catch (const std::exception &e) {
     return fail(c, MMP_EHIP, "%s: %s", "mmp_shard_place_fast_scatter_dev", e.what());
+}
+
+/* ---- RCCL inside the boundary: the pod-axis group ------------------------- */
+namespace {
+// librccl is bound at run time: a host without RCCL (or a CPU-only test box) still loads libmmplace, and a process
+// that already carries a copy (PyTorch bundles one) reuses it instead of mapping a second one.
+struct RcclApi {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+RcclApi *rccl_api()
+{
+    static std::mutex mu;
+    static RcclApi api;
+    std::lock_guard<std::mutex> g(mu);
+    if (api.h) return &api;
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (int pass = 0; pass < 2 && !api.h; pass++)
+        for (const char *nm : names) {
+            api.h = dlopen(nm, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+            if (api.h) break;
+        }
+    if (!api.h) api.h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!api.h) {
+        api.why = dlerror() ? dlerror() : "librccl.so not found";
+        return nullptr;
+    }
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.h, "ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.h, "ncclCommInitRank"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.h, "ncclAllReduce"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.h, "ncclCommDestroy"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.h, "ncclGetErrorString"));
+    if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) {
+        api.why = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy";
+        dlclose(api.h);
+        api.h = nullptr;
+        return nullptr;
+    }
+    return &api;
+}
+
+void group_comm_destroy(ncclComm_t comm)
+{
+    if (RcclApi *R = rccl_api()) (void)R->CommDestroy(comm);
+}
+
+#define RCCL_TRY(c, expr)                                                                                  \
+    do {                                                                                                   \
+        ncclResult_t r_ = (expr);                                                                          \
+        if (r_ != ncclSuccess)                                                                             \
+            return fail((c), MMP_EHIP, "%s failed: %s (%s:%d)", #expr,                                     \
+                        rccl_api()->GetErrorString ? rccl_api()->GetErrorString(r_) : "rccl error", __FILE__, __LINE__); \
+    } while (0)
+
+// all-reduce in place on the context's stream; a group of one without a communicator has nothing to exchange
+int group_allreduce(mmp_ctx *c, void *buf, size_t count, ncclDataType_t dt, ncclRedOp_t op)
+{
+    if (count == 0) return MMP_OK;
+    if (c->xfn) {
+        const int rc = c->xfn(c->xuser, buf, (int64_t)count, dt == ncclInt64 ? 1 : 0, op == ncclMin ? 1 : 0, c->stream);
+        return rc == 0 ? MMP_OK : fail(c, MMP_EHIP, "the host's exchange callback failed (%d)", rc);
+    }
+    if (!c->comm) return MMP_OK;
+    RCCL_TRY(c, rccl_api()->AllReduce(buf, buf, count, dt, op, c->comm, c->stream));
+    return MMP_OK;
+}
+
+// the six exchange phases + the result rows for `n` request rows (n_dev: the real row count on the device, or null)
+int group_general(mmp_ctx *c, const void *d_reqs, int32_t n, const int32_t *n_dev, const void *d_extra, int64_t now, void *d_outs)
+{
+    void *xs[6];
+    for (int ph = 1; ph <= 6; ph++) {
+        HIP_TRY(c, c->g_x[ph - 1].ensure((size_t)std::max(n, 1) * mmp_shard_xchg_slots(ph, c->n_shards) * 8));
+        xs[ph - 1] = c->g_x[ph - 1].p;
+    }
+    for (int ph = 1; ph <= 7; ph++) {
+        {
+            std::lock_guard<std::mutex> g(c->mu);
+            const int rc = shard_phase_launch(c, ph, d_reqs, n, n_dev, d_extra, now, xs, d_outs, c->stream);
+            if (rc != MMP_OK) return rc;
+        }
+        if (ph <= 6) {
+            const int rc = group_allreduce(c, xs[ph - 1], (size_t)n * mmp_shard_xchg_slots(ph, c->n_shards), ncclInt64,
+                                           mmp_shard_xchg_is_sum(ph) ? ncclSum : ncclMin);
+            if (rc != MMP_OK) return rc;
+        }
+    }
+    return MMP_OK;
+}
+}  // namespace
+
+int mmp_shard_unique_id(void *id_out)
+{
+    if (!id_out) return fail(nullptr, MMP_EINVAL, "mmp_shard_unique_id: null argument");
+    RcclApi *R = rccl_api();
+    if (!R) return fail(nullptr, MMP_ENODEVICE, "RCCL is not available: %s", RcclApi().why.c_str());
+    ncclUniqueId id;
+    RCCL_TRY(nullptr, R->GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return MMP_OK;
+}
+
+int mmp_shard_group_init(mmp_ctx *c, const void *unique_id, int32_t rank, int32_t world)
+try {
+    if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !unique_id && !c->xfn))
+        return fail(c, MMP_EINVAL, "mmp_shard_group_init: bad argument (a group of more than one shard needs a unique id or an exchange callback)");
+    std::lock_guard<std::mutex> gg(c->group_mu);
+    if (c->group) return fail(c, MMP_ESTATE, "mmp_shard_group_init: the context already belongs to a group");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (unique_id) {
+        RcclApi *R = rccl_api();
+        if (!R) return fail(c, MMP_ENODEVICE, "RCCL is not available on this host");
+        ncclUniqueId id;
+        memcpy(&id, unique_id, sizeof id);
+        RCCL_TRY(c, R->CommInitRank(&c->comm, world, id, rank));
+    }
+    const int rc = mmp_shard_configure(c, rank, world);
+    if (rc != MMP_OK) {
+        if (c->comm) (void)rccl_api()->CommDestroy(c->comm);
+        c->comm = nullptr;
+        return rc;
+    }
+    c->g_rank = rank;
+    c->g_world = world;
+    c->group = true;
+    return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shard_group_init");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_shard_group_init", e.what());
+}
+
+int mmp_shard_group_set_exchange(mmp_ctx *c, mmp_exchange_fn fn, void *user)
+{
+    if (!c) return MMP_EINVAL;
+    std::lock_guard<std::mutex> gg(c->group_mu);
+    if (c->group) return fail(c, MMP_ESTATE, "mmp_shard_group_set_exchange: set the callback before mmp_shard_group_init");
+    c->xfn = fn;
+    c->xuser = user;
+    return MMP_OK;
+}
+
+int mmp_shard_group_destroy(mmp_ctx *c)
+{
+    if (!c) return MMP_EINVAL;
+    std::lock_guard<std::mutex> gg(c->group_mu);
+    if (!c->group) return MMP_OK;
+    (void)hipSetDevice(c->cfg.device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)rccl_api()->CommDestroy(c->comm);
+    c->comm = nullptr;
+    c->group = false;
+    return MMP_OK;
+}
+
+/* Sharded commit, collective over the group: every shard ranks its slice of the instances against all of them,
+ * ncclAllReduce(SUM) of int32 rank[P] on the library's stream, every shard scatters the positions it owns. */
+int mmp_shard_commit(mmp_ctx *c)
+try {
+    if (!c) return MMP_EINVAL;
+    std::lock_guard<std::mutex> gg(c->group_mu);
+    if (!c->group) return fail(c, MMP_ESTATE, "mmp_shard_commit: call mmp_shard_group_init first");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    size_t P;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        P = c->pods.size();
+    }
+    HIP_TRY(c, c->g_rankbuf.ensure(std::max<size_t>(P, 1) * 4));
+    int rc = mmp_shard_rank_dev(c, c->g_rankbuf.p);  // synchronises c->stream
+    if (rc != MMP_OK) return rc;
+    rc = group_allreduce(c, c->g_rankbuf.p, P, ncclInt32, ncclSum);
+    if (rc != MMP_OK) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return mmp_shard_commit_dev(c, c->g_rankbuf.p);
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shard_commit");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_shard_commit", e.what());
+}
+
+/* One batch on the pod-axis group, device pointers, collective: returns when d_outs is complete on every shard.
+ * fast kernel -> ncclAllReduce(MIN, 2 int64 per decision) -> decided rows + compaction of the rest -> the six
+ * exchange phases over a sub-batch of fixed CAPACITY (max(1024, n / 16) rows; the real count stays on the device, so
+ * no host round trip sits between the kernels and every collective has a size the host knows) -> scatter.  Only
+ * when more decisions than that capacity need the six phases — the host learns it with the results — are they run
+ * again at their exact size. */
+int mmp_shard_place_batch_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs,
+                              int32_t *n_rest_out)
+try {
+    if (!c || n < 0 || (n > 0 && (!d_reqs || !d_outs))) return fail(c, MMP_EINVAL, "mmp_shard_place_batch_dev: bad argument");
+    std::lock_guard<std::mutex> gg(c->group_mu);
+    if (!c->group) return fail(c, MMP_ESTATE, "mmp_shard_place_batch_dev: call mmp_shard_group_init first");
+    if (n_rest_out) *n_rest_out = 0;
+    if (n == 0) return MMP_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = c->stream;
+    HIP_TRY(c, c->g_xf.ensure((size_t)n * kXF * 8));
+    int rc = mmp_shard_place_fast_dev(c, d_reqs, n, d_extra, now, c->g_xf.p, st);
+    if (rc != MMP_OK) return rc;
+    rc = group_allreduce(c, c->g_xf.p, (size_t)n * kXF, ncclInt64, ncclMin);
+    if (rc != MMP_OK) return rc;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        rc = shard_finish_launch(c, d_reqs, n, c->g_xf.p, d_outs, st);
+        if (rc != MMP_OK) return rc;
+    }
+    const int32_t *n_dev = c->f_offs.as<int32_t>() + n;  // written by the scan above
+    const int32_t cap = std::min(n, std::max(1024, n / 16));
+    rc = group_general(c, c->f_reqs.p, cap, n_dev, d_extra, now, c->f_outs.p);
+    if (rc != MMP_OK) return rc;
+    hipLaunchKernelGGL(place_shard_scatter_kernel, dim3(div_up(cap, 256)), dim3(256), 0, st, c->f_outs.as<mmp_place_out>(),
+                       c->f_idx.as<int32_t>(), cap, static_cast<mmp_place_out *>(d_outs), n_dev);
+    HIP_TRY(c, hipGetLastError());
+    int32_t n_rest = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n_rest, n_dev, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (n_rest > cap) {  // identical on every shard (the same reduced words): the group stays in step
+        rc = group_general(c, c->f_reqs.p, n_rest, nullptr, d_extra, now, c->f_outs.p);
+        if (rc != MMP_OK) return rc;
+        hipLaunchKernelGGL(place_shard_scatter_kernel, dim3(div_up(n_rest, 256)), dim3(256), 0, st, c->f_outs.as<mmp_place_out>(),
+                           c->f_idx.as<int32_t>(), n_rest, static_cast<mmp_place_out *>(d_outs), nullptr);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(st));
+    }
+    if (n_rest_out) *n_rest_out = n_rest;
+    return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shard_place_batch_dev");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_shard_place_batch_dev", e.what());
+}
+
+/* The same with host pointers (what a JVM holds): staged through the context's scratch. */
+int mmp_shard_place_batch(mmp_ctx *c, const mmp_place_req *reqs, int32_t n, const int32_t *extra_pool, int32_t n_extra,
+                          int64_t now, mmp_place_out *outs, int32_t *n_rest_out)
+try {
+    if (!c || n < 0 || n_extra < 0 || (n > 0 && (!reqs || !outs)) || (n_extra > 0 && !extra_pool))
+        return fail(c, MMP_EINVAL, "mmp_shard_place_batch: bad argument");
+    for (int32_t i = 0; i < n; i++)
+        if (reqs[i].n_extra < 0 || reqs[i].extra_off < 0 || (int64_t)reqs[i].extra_off + reqs[i].n_extra > n_extra)
+            return fail(c, MMP_EINVAL, "mmp_shard_place_batch: request %d extra range out of bounds", i);
+    if (n_rest_out) *n_rest_out = 0;
+    if (n == 0) return MMP_OK;
+    std::lock_guard<std::mutex> gb(c->batch_mu);  // the staging scratch
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    HIP_TRY(c, c->s_reqs.ensure((size_t)n * sizeof(mmp_place_req)));
+    HIP_TRY(c, c->s_outs.ensure((size_t)n * sizeof(mmp_place_out)));
+    HIP_TRY(c, c->s_extra.ensure((size_t)std::max(n_extra, 1) * 4));
+    HIP_TRY(c, hipMemcpyAsync(c->s_reqs.p, reqs, (size_t)n * sizeof(mmp_place_req), hipMemcpyHostToDevice, c->stream));
+    if (n_extra) HIP_TRY(c, hipMemcpyAsync(c->s_extra.p, extra_pool, (size_t)n_extra * 4, hipMemcpyHostToDevice, c->stream));
+    const int rc = mmp_shard_place_batch_dev(c, c->s_reqs.p, n, c->s_extra.p, now, c->s_outs.p, n_rest_out);
+    if (rc != MMP_OK) return rc;
+    HIP_TRY(c, copy_sync(c, outs, c->s_outs.p, (size_t)n * sizeof(mmp_place_out), hipMemcpyDeviceToHost));
+    return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shard_place_batch");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_shard_place_batch", e.what());
 }
 
 /* ---- decisions ---------------------------------------------------------- */

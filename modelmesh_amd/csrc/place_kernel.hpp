@@ -125,6 +125,7 @@ struct PlaceArgs {
     int32_t n;
     int32_t n_models;
     int64_t now;
+    const int32_t *n_dev;  // pod-axis rest sub-batch: the row count lives on the device (min(n, *n_dev) rows are real); null otherwise
     int32_t force_wave;  // diagnostics: hand every decision to the wave-per-decision kernel
     int32_t n_pods_all;  // pod slots of the whole table (bounds of pos_of; == Snap::P unless the Snap is a shard view)
     // Latency path only (wave.hpp: announce_done); nullptr otherwise.  The workgroup counter of launches with

@@ -549,7 +549,9 @@ __global__ __launch_bounds__(kPlaceWaves * 64) void place_shard_kernel(ShardSnap
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint64_t *ew = reinterpret_cast<uint64_t *>(smem) + (size_t)wave * 2 * wpad;
     uint64_t *fw = ew + wpad;
-    for (int d = blockIdx.x * kPlaceWaves + wave; d < A.n; d += gridDim.x * kPlaceWaves) {
+    // the rest sub-batch of the speculative form is launched for its CAPACITY; the number of real rows is on the device
+    const int n = A.n_dev ? min(A.n, __builtin_amdgcn_readfirstlane(*A.n_dev)) : A.n;
+    for (int d = blockIdx.x * kPlaceWaves + wave; d < n; d += gridDim.x * kPlaceWaves) {
         shard_phase<PH>(S, A, X, d, ew, fw);
         wave_sync();
     }
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(kPlaceWaves * 64) void place_shard_kernel(ShardSnap
 __global__ void place_shard_finish_kernel(ShardSnap S, PlaceArgs A, XchgPtrs X)
 {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= A.n) return;
+    if (d >= A.n || (A.n_dev && d >= *A.n_dev)) return;
     const int G = S.n_shards;
     const mmp_place_req rq = A.reqs[d];
     mmp_place_out o;
@@ -675,10 +677,10 @@ __global__ void place_shard_gather_kernel(const mmp_place_req *__restrict__ reqs
 }
 
 __global__ void place_shard_scatter_kernel(const mmp_place_out *__restrict__ rest_outs, const int32_t *__restrict__ rest_idx,
-                                           int32_t n_rest, mmp_place_out *__restrict__ outs)
+                                           int32_t n_rest, mmp_place_out *__restrict__ outs, const int32_t *__restrict__ n_dev = nullptr)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_rest) outs[rest_idx[i]] = rest_outs[i];
+    if (i < n_rest && (!n_dev || i < *n_dev)) outs[rest_idx[i]] = rest_outs[i];
 }
 
 // ---- sharded commit ---------------------------------------------------------------------------

@@ -455,6 +455,40 @@ class Solver:
     def shard_fast_scatter_dev(self, n_rest: int, d_outs: int, stream: int = 0):
         self._ck(self.lib.mmp_shard_place_fast_scatter_dev(self.h, int(n_rest), C.c_void_p(d_outs), C.c_void_p(stream or None)))
 
+    # ---- the pod-axis group with RCCL inside the library (include/mmplace.h) ----
+    def shard_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self._ck(self.lib.mmp_shard_unique_id(buf))
+        return buf.raw
+
+    def shard_group_init(self, unique_id: bytes | None, rank: int, world: int):
+        buf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
+        self._ck(self.lib.mmp_shard_group_init(self.h, buf, int(rank), int(world)))
+        self.n_shards = int(world)
+
+    def shard_group_destroy(self):
+        self._ck(self.lib.mmp_shard_group_destroy(self.h))
+
+    def shard_commit(self):
+        self._ck(self.lib.mmp_shard_commit(self.h))
+
+    def shard_place(self, reqs, extra, now: int):
+        """Collective over the group, host pointers -> (outs, n_rest)."""
+        reqs = np.ascontiguousarray(reqs, dtype=PLACE_REQ)
+        extra = np.ascontiguousarray(extra if extra is not None else np.zeros(0, np.int32), dtype=np.int32)
+        outs = np.zeros(len(reqs), dtype=PLACE_OUT)
+        n_rest = C.c_int32(0)
+        self._ck(self.lib.mmp_shard_place_batch(self.h, ptr(reqs), len(reqs), ptr(extra) if len(extra) else None, len(extra),
+                                                int(now), ptr(outs), C.byref(n_rest)))
+        return outs, n_rest.value
+
+    def shard_place_dev(self, d_reqs: int, n: int, d_extra: int, now: int, d_outs: int) -> int:
+        """Collective over the group, device pointers; returns when d_outs is complete -> n_rest."""
+        n_rest = C.c_int32(0)
+        self._ck(self.lib.mmp_shard_place_batch_dev(self.h, C.c_void_p(d_reqs), int(n), C.c_void_p(d_extra or None), int(now),
+                                                    C.c_void_p(d_outs), C.byref(n_rest)))
+        return n_rest.value
+
     def sync(self):
         self._ck(self.lib.mmp_sync(self.h))
 

@@ -1,0 +1,147 @@
+"""The pod-axis group with the collectives INSIDE the library (include/mmplace.h: mmp_shard_group_init,
+mmp_shard_commit, mmp_shard_place_batch): what a Java mesh — which holds no RCCL handles — calls.
+
+* RCCL itself: a group of ONE shard built from a real ncclUniqueId (ncclCommInitRank + every ncclAllReduce of the
+  protocol run on the library's stream; RCCL refuses two ranks on one device, and the GPU box has one).
+* The group protocol with G > 1 — fast kernel, exchange, device-side rest count over the fixed-capacity sub-batch,
+  the six phases, the rerun when the capacity is exceeded, the sharded commit — with G contexts on cuda:0 driven by
+  G host threads through the library's own transport callback (mmp_shard_group_set_exchange): the all-reduce is done
+  by the threads (D2H, numpy, H2D).  Results must be bit-identical to the CPU oracle on every shard.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from modelmesh_amd import workload as wl
+from modelmesh_amd.solver import Solver
+from oracle.bind import OracleFleet
+from tests.util import assert_same_decisions
+
+pytestmark = pytest.mark.gpu
+
+XFN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p)
+
+
+class ThreadExchange:
+    """An all-reduce among G host threads of one process over raw device pointers."""
+
+    def __init__(self, G):
+        import torch  # noqa: F401  (the HIP runtime torch loaded is the one the library uses)
+        self.G = G
+        self.bar = threading.Barrier(G)
+        self.parts = [None] * G
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.calls = 0
+
+    def fn_for(self, rank):
+        def fn(_user, dev_buf, count, elem64, op_min, stream):
+            try:
+                dt = np.int64 if elem64 else np.int32
+                host = np.empty(count, dtype=dt)
+                assert self.hip.hipStreamSynchronize(stream) == 0
+                assert self.hip.hipMemcpy(host.ctypes.data, dev_buf, host.nbytes, 2) == 0  # D2H
+                self.parts[rank] = host
+                self.bar.wait()
+                stack = np.stack(self.parts)
+                red = stack.min(axis=0) if op_min else stack.sum(axis=0, dtype=dt)
+                self.bar.wait()  # everyone has read every part before anyone overwrites its own
+                assert self.hip.hipMemcpy(dev_buf, red.ctypes.data, red.nbytes, 1) == 0  # H2D
+                if rank == 0:
+                    self.calls += 1
+                return 0
+            except Exception:  # noqa: BLE001
+                self.bar.abort()
+                return 1
+        return XFN(fn)
+
+
+def _group_place(fleet, batches, G, rccl=False):
+    """-> per batch (outs of shard 0, n_rest); asserts that every shard returns the same rows."""
+    xc = ThreadExchange(G) if G > 1 else None
+    results = [[None] * len(batches) for _ in range(G)]
+    errors = []
+    keep = []
+
+    def run(g):
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            if xc is not None:
+                cb = xc.fn_for(g)
+                keep.append(cb)
+                assert s.lib.mmp_shard_group_set_exchange(s.h, C.cast(cb, C.c_void_p), None) == 0
+                s.shard_group_init(None, g, G)
+            else:
+                s.shard_group_init(s.shard_unique_id() if rccl else None, 0, 1)
+            s.load_fleet(fleet, commit=False)
+            s.shard_commit()
+            for i, (reqs, extra) in enumerate(batches):
+                results[g][i] = s.shard_place(reqs, extra, fleet.now)
+            s.shard_group_destroy()
+        except Exception as e:  # noqa: BLE001
+            errors.append((g, repr(e)))
+            if xc is not None:
+                xc.bar.abort()
+        finally:
+            s.close()
+
+    ths = [threading.Thread(target=run, args=(g,)) for g in range(G)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    for g in range(1, G):
+        for i in range(len(batches)):
+            assert np.array_equal(results[g][i][0], results[0][i][0]) and results[g][i][1] == results[0][i][1]
+    return results[0]
+
+
+def _check(fleet, batches, G, rccl=False):
+    orc = OracleFleet(fleet)
+    got = _group_place(fleet, batches, G, rccl)
+    for (reqs, extra), (outs, n_rest) in zip(batches, got):
+        assert_same_decisions(fleet, reqs, outs, orc.place(reqs, extra, fleet.now, threads=8))
+    return [n for _, n in got]
+
+
+def test_rccl_group_of_one_shard_c2_and_fuzz():
+    """ncclGetUniqueId -> ncclCommInitRank(world 1) -> the sharded commit's ncclAllReduce(SUM) and every
+    ncclAllReduce(MIN / SUM) of a batch on the library's stream."""
+    fleet = wl.make_fleet("C2")
+    _check(fleet, [wl.make_requests(fleet, 3), wl.make_requests(fleet, 4, n=777)], 1, rccl=True)
+    for seed in range(4):
+        f = wl.fuzz_fleet(seed, profile=[None, "full"][seed % 2])
+        _check(f, [wl.fuzz_requests(f, seed, 500)], 1, rccl=True)
+
+
+@pytest.mark.parametrize("G", [2, 3, 8])
+def test_group_of_virtual_shards_equals_the_oracle(G):
+    fleet = wl.make_fleet("C2")
+    rest = _check(fleet, [wl.make_requests(fleet, 11), wl.make_requests(fleet, 12, n=5000)], G)
+    assert all(r < 1000 for r in rest), rest  # the single exchange decides almost everything
+    for seed in range(6):
+        f = wl.fuzz_fleet(100 + seed, pods=300, profile=[None, "full", "pref"][seed % 3])
+        _check(f, [wl.fuzz_requests(f, seed, 700), wl.fuzz_requests(f, seed + 50, 64)], G)
+
+
+def test_rest_beyond_the_sub_batch_capacity_is_rerun_at_its_exact_size():
+    """A cluster in which every instance is full sends most decisions through the six phases: far more than the
+    max(1024, n / 16) rows the first pass carries — the group reruns them at their exact size."""
+    fleet = wl.make_fleet("C2")
+    rng = np.random.default_rng(5)
+    P = fleet.n_pods
+    fleet.pods["used"] = fleet.pods["capacity"] - rng.integers(0, 4_000, P)
+    fleet.pods["lru_time"] = fleet.now - (36_000_000 * (1 + rng.uniform(-0.04, 0.04, P))).astype(np.int64)
+    reqs, extra = wl.make_requests(fleet, 21)
+    rest = _check(fleet, [(reqs, extra)], 2)
+    assert rest[0] > max(1024, len(reqs) // 16), rest
+
+
+def test_c3_group_of_two_full_size():
+    fleet = wl.make_fleet("C3")
+    rest = _check(fleet, [wl.make_requests(fleet, 0xBE7C0)], 2)
+    assert rest[0] < 1000, rest
