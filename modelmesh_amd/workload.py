@@ -319,6 +319,27 @@ def scenario_fleets():
     f.has_prefer[:] = 0
     yield "busy_best_is_filtered", f, reqs_of(f, np.array([-1, 1, 2, 0], np.int32),
                                             np.array([0, 0, 1, 0], np.uint32)), np.zeros(0, np.int32)
+    # S5 (round 2; branches of getNext that a gcov run over the fuzz fleets showed were never taken):
+    # case (b) with an OLD best: the next instance is more than 120 s younger but within a quarter of the best's age,
+    # so the absolute clause of :4864 holds and the relative one decides (no break); then a preferred instance, then a
+    # non-preferred one behind it (the `else if (have_replay)` edge with the replay list already dropped, :4877-4879);
+    # and a caller that excluded ITSELF while it is the preferred entry (`!excludeSelf` false at :4869).
+    day = 86_400_000
+    rows = pods_of([(3, 0, now - day, 10), (3, 0, now - day + 3_600_000, 500), (3, 0, now - day + 7_200_000, 30),
+                    (3, 0, now - day + 7_300_000, 40), (3, 0, now - day + 7_350_000, 45), (3, 0, now - 100_000, 50)])
+    f = fleet_of(rows, [2, 3])
+    r = reqs_of(f, np.array([1, 2, 2, 3, -1], np.int32), np.array([0, 0, 1, 0, 0], np.uint32))
+    r["extra_off"] = np.array([0, 0, 0, 0, 0])
+    r["n_extra"] = np.array([0, 1, 0, 0, 0])  # request 1: self (pod 2) is in its own exclusion list
+    yield "b_old_best_relative_window", f, r, np.array([2], np.int32)
+    # S6: the simple case in full mode with an old best: a candidate more than 45 s younger than the best but within a
+    # tenth of its age stays in the shortlist (:4915 absolute clause true, relative clause false)
+    rows = pods_of([(3, 0, now - day, 10), (3, 0, now - day + 600_000, 20), (3, 0, now - day + 8_000_000, 30),
+                    (3, 0, now - 50_000, 40)])
+    f = fleet_of(rows, [])
+    f.has_prefer[:] = 0
+    yield "full_mode_old_best_relative_window", f, reqs_of(f, np.array([1, 2, 3, -1], np.int32),
+                                                          np.array([0, 0, 0, 0], np.uint32)), np.zeros(0, np.int32)
 
 
 # --------------------------------------------------------------------------

@@ -37,6 +37,11 @@ FLEETS = [(0, None, 5), (1, None, 64), (2, None, 130), (3, "full", 40), (4, "ful
 
 def place_vectors():
     from tests.test_oracle_cross import _compare  # C restatement == Python restatement on these inputs
+    from tools.oracle_coverage import uncovered
+    miss = uncovered()  # gcov: every branch of the getNext restatement must be taken by the fleets the vectors come from
+    if miss:
+        raise SystemExit("place_fuzz.npz NOT written: branches of oracle/mm_oracle.c never taken:\n" +
+                         "\n".join(f"  :{ln}: {note}: {text}" for ln, text, note in miss))
     out = {}
     for i, (seed, profile, pods) in enumerate(FLEETS):
         fleet = wl.fuzz_fleet(seed, pods=pods, models=160, profile=profile)
@@ -137,6 +142,16 @@ REFERENCE_KATS = {
                   "clusterSize :558, wiggle room :340, expected ids :695-702",
         "cluster_size": 3, "multi_load": 9, "fits_models": 27, "beyond_capacity": 3, "wiggle_room": 6,
         "must_be_loaded_from_index": 9, "reuse": {"touch_first": 5, "add": 3}},
+    "failureExpiry": {
+        "source": "src/test/java/com/ibm/watson/modelmesh/ModelMeshFailureExpiryTest.java:52-128 (LOAD_FAILURE_EXPIRY 2000 :53, "
+                  "janitor 1 s :52; predicts at 0 / +1000 / +3000 ms :99-118; background predict every 400 ms :86-96); "
+                  "MM.java:219-221, :4607-4627, :6040-6052",
+        "load_failure_expiry_ms": 2000,
+        "janitor_period_ms": 1000,
+        "background_predict_period_ms": 400,
+        "asserted_predicts_ms": [0, 1400, 4400],
+        "asserted_outcomes": ["failed", "failed", "loaded"],
+    },
     "loadFailure": {
         "source": "src/test/java/com/ibm/watson/modelmesh/ModelMeshLoadFailureTest.java:432-492",
         "max_load_failures": 3, "failed_instances_never_retried_within_expiry": True},

@@ -166,3 +166,35 @@ def test_model_migration_and_destroyed_node_kat():
                 assert served["chosen"][m] in (4, -2)
     finally:
         s.close()
+
+
+def test_failure_expiry_kat_on_the_device():
+    """ModelMeshFailureExpiryTest.java:52-128 (see tests/test_failure_expiry_kat.py): the load-target decision and the
+    failure-count guard of every predict of the timeline on the device, each compared with the oracle's."""
+    from tests import test_failure_expiry_kat as fx
+    in_use = fx.KAT["load_failure_expiry_ms"] // 2
+    s = Solver(6553, 600_000)
+    try:
+        def place_dev(fleet, r, now):
+            s.load_fleet(fleet)
+            got = s.place(r, None, now)
+            want = ob.OracleFleet(fleet).place(r, None, now)
+            for f in ("chosen", "best", "n_candidates", "hash"):
+                assert got[f][0] == want[f][0], (now - NOW, f)
+            return int(got["chosen"][0])
+
+        def breached_dev(fails, now):
+            # the guard reads loadFailedInstanceIds of the registry view place_dev is about to load: evaluate it on a
+            # context of its own table
+            fleet = fx.single_instance_fleet(fails[0] if fails else None, now)
+            s.load_fleet(fleet)
+            g = np.zeros(1, dtype=_lib.GATE_REQ)
+            g["model"], g["self_pod"] = 0, 0
+            bits = int(s.gates(g, np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros(0, np.int32), now,
+                               in_use_failure_expiry_ms=in_use)[0]["bits"])
+            return bool(bits & _lib.GATE_FAILURES_BREACHED)
+
+        want = [(t, o) for t, o in zip(fx.KAT["asserted_predicts_ms"], fx.KAT["asserted_outcomes"])]
+        assert fx.run_timeline(place_dev, breached_dev) == want
+    finally:
+        s.close()
