@@ -33,6 +33,18 @@ __host__ __device__ constexpr uint64_t fnv1a(const char *s, int n)
     return h;
 }
 #define MMP_KEY(lit) fnv1a(lit, (int)sizeof(lit) - 1)
+// A field name is recognised by hash + length and then CONFIRMED byte for byte (kp = its first byte): an unknown
+// field whose name collides on both (FNV-1a is not collision resistant against a chosen name) is skipped like any
+// other unknown field instead of being parsed as the known one.
+template <class B>
+__device__ __forceinline__ bool key_bytes_equal(const B *kp, const char *lit, int n)
+{
+    for (int i = 0; i < n; i++)
+        if ((unsigned char)kp[i] != (unsigned char)lit[i]) return false;
+    return true;
+}
+#define KEY_IS(h, klen, kp, lit) \
+    ((h) == MMP_KEY(lit) && (klen) == (int)sizeof(lit) - 1 && key_bytes_equal((kp), lit, (int)sizeof(lit) - 1))
 
 struct JCur {
     const char *p, *e;
@@ -181,29 +193,30 @@ __device__ __forceinline__ bool pod_record_serial(const char *b, const char *e, 
         const char *k0 = c.p;
         const uint64_t h = j_string_hash(c);
         const int klen = (int)(c.p - k0) - 2;
+        const char *kp = k0 + 1;
         if (c.bad || !j_eat(c, ':')) {
             c.bad = true;
             break;
         }
-        if (h == MMP_KEY("lruTime") && klen == 7)
+        if (KEY_IS(h, klen, kp, "lruTime"))
             r.lru_time = j_int(c);
-        else if (h == MMP_KEY("count") && klen == 5)
+        else if (KEY_IS(h, klen, kp, "count"))
             r.count = (int32_t)j_int(c);
-        else if (h == MMP_KEY("cap") && klen == 3)
+        else if (KEY_IS(h, klen, kp, "cap"))
             r.capacity = j_int(c);
-        else if (h == MMP_KEY("used") && klen == 4)
+        else if (KEY_IS(h, klen, kp, "used"))
             r.used = j_int(c);
-        else if (h == MMP_KEY("lThreads") && klen == 8)
+        else if (KEY_IS(h, klen, kp, "lThreads"))
             r.loading_threads = (int32_t)j_int(c);
-        else if (h == MMP_KEY("lInProg") && klen == 7)
+        else if (KEY_IS(h, klen, kp, "lInProg"))
             r.loading_in_progress = (int32_t)j_int(c);
-        else if (h == MMP_KEY("rpm") && klen == 3)
+        else if (KEY_IS(h, klen, kp, "rpm"))
             r.rpm = (int32_t)j_int(c);
-        else if (h == MMP_KEY("shutdown") && klen == 8) {
+        else if (KEY_IS(h, klen, kp, "shutdown")) {
             if (j_bool(c)) r.flags |= MMP_POD_SHUTTING_DOWN;
-        } else if (h == MMP_KEY("startTime") && klen == 9)
+        } else if (KEY_IS(h, klen, kp, "startTime"))
             st = j_int(c);
-        else if (h == MMP_KEY("vers") && klen == 4)
+        else if (KEY_IS(h, klen, kp, "vers"))
             r.version = j_int(c);
         else
             j_skip_value(c);  // loc, zone, labels (interned on the host), anything newer
@@ -310,26 +323,27 @@ __device__ __forceinline__ bool model_record_serial(const IngestModelsArgs &A, c
         const char *k0 = c.p;
         const uint64_t h = j_string_hash(c);
         const int klen = (int)(c.p - k0) - 2;
+        const char *kp = k0 + 1;
         if (c.bad || !j_eat(c, ':')) {
             c.bad = true;
             break;
         }
-        if (h == MMP_KEY("instanceIds") && klen == 11) {
+        if (KEY_IS(h, klen, kp, "instanceIds")) {
             const int32_t k = j_id_map(c, A.ids, PASS ? A.ent_pod + r.ent_off : nullptr, PASS ? A.ent_time + r.ent_off : nullptr);
             if (PASS == 0) r.n_loaded = k;
-        } else if (h == MMP_KEY("failedIn") && klen == 8) {
+        } else if (KEY_IS(h, klen, kp, "failedIn")) {
             const int32_t k = j_id_map(c, A.ids, PASS ? A.ent_pod + r.ent_off + r.n_loaded : nullptr,
                                        PASS ? A.ent_time + r.ent_off + r.n_loaded : nullptr);
             if (PASS == 0) r.n_failed = k;
-        } else if (PASS == 0 && h == MMP_KEY("type") && klen == 4) {
+        } else if (PASS == 0 && KEY_IS(h, klen, kp, "type")) {
             j_ws(c);
             if (c.p < c.e && *c.p == '"')
                 r.type = tab_find(A.types, j_string_hash(c), A.unknown_type);
             else
                 j_skip_value(c);  // null -> DEFAULT_TYPE (ModelRecord.java:121)
-        } else if (PASS == 0 && h == MMP_KEY("lu") && klen == 2)
+        } else if (PASS == 0 && KEY_IS(h, klen, kp, "lu"))
             r.last_used = j_int(c);
-        else if (PASS == 0 && h == MMP_KEY("lul") && klen == 3)
+        else if (PASS == 0 && KEY_IS(h, klen, kp, "lul"))
             lul = j_int(c);
         else
             j_skip_value(c);
@@ -542,7 +556,7 @@ __device__ __forceinline__ int j_count(const uint64_t *m, int lo, int hi)
 // The key of the ':' at p — FNV-1a of the raw bytes between its quotes — and the separator before it:
 // the container's opener for the first member, a ',' of this level (`commas`) otherwise.
 __device__ __forceinline__ bool j_key(const JView &R, int p, const uint64_t *commas, int open_pos, bool first,
-                                      uint64_t &h, int &klen)
+                                      uint64_t &h, int &klen, const uint8_t *&kp)
 {
     int q = p - 1;
     while (q >= 0 && j_is_ws(R.by[q])) q--;
@@ -553,6 +567,7 @@ __device__ __forceinline__ bool j_key(const JView &R, int p, const uint64_t *com
     while (sp >= 0 && j_is_ws(R.by[sp])) sp--;
     if (sp < 0 || (first ? sp != open_pos : !j_bit(commas, sp))) return false;
     klen = q - ks - 1;
+    kp = R.by + ks + 1;
     h = 0xcbf29ce484222325ull;
     for (int i = ks + 1; i < q; i++) h = (h ^ (uint64_t)R.by[i]) * 0x100000001b3ull;
     return true;
@@ -702,19 +717,20 @@ __global__ __launch_bounds__(kJBlock) void ingest_pods_kernel(const char *__rest
                 const int p = j_nth_after(R.c1, R.nch, -1, j);
                 uint64_t h;
                 int klen;
-                if (!j_key(R, p, R.m1, R.f, j == 0, h, klen))
+                const uint8_t *kp = nullptr;
+                if (!j_key(R, p, R.m1, R.f, j == 0, h, klen, kp))
                     lbad = true;
                 else {
-                    if (h == MMP_KEY("lruTime") && klen == 7) fid = 0;
-                    else if (h == MMP_KEY("count") && klen == 5) fid = 1;
-                    else if (h == MMP_KEY("cap") && klen == 3) fid = 2;
-                    else if (h == MMP_KEY("used") && klen == 4) fid = 3;
-                    else if (h == MMP_KEY("lThreads") && klen == 8) fid = 4;
-                    else if (h == MMP_KEY("lInProg") && klen == 7) fid = 5;
-                    else if (h == MMP_KEY("rpm") && klen == 3) fid = 6;
-                    else if (h == MMP_KEY("shutdown") && klen == 8) fid = 7;
-                    else if (h == MMP_KEY("startTime") && klen == 9) fid = 8;
-                    else if (h == MMP_KEY("vers") && klen == 4) fid = 9;
+                    if (KEY_IS(h, klen, kp, "lruTime")) fid = 0;
+                    else if (KEY_IS(h, klen, kp, "count")) fid = 1;
+                    else if (KEY_IS(h, klen, kp, "cap")) fid = 2;
+                    else if (KEY_IS(h, klen, kp, "used")) fid = 3;
+                    else if (KEY_IS(h, klen, kp, "lThreads")) fid = 4;
+                    else if (KEY_IS(h, klen, kp, "lInProg")) fid = 5;
+                    else if (KEY_IS(h, klen, kp, "rpm")) fid = 6;
+                    else if (KEY_IS(h, klen, kp, "shutdown")) fid = 7;
+                    else if (KEY_IS(h, klen, kp, "startTime")) fid = 8;
+                    else if (KEY_IS(h, klen, kp, "vers")) fid = 9;
                     if (fid >= 0) {
                         int v = p + 1;
                         while (v < R.L && j_is_ws(R.by[v])) v++;
@@ -820,14 +836,15 @@ __global__ __launch_bounds__(kJBlock) void ingest_models_kernel(IngestModelsArgs
                 const int p = j_nth_after(R.c1, R.nch, -1, j);
                 uint64_t h;
                 int klen;
-                if (!j_key(R, p, R.m1, R.f, j == 0, h, klen))
+                const uint8_t *kp = nullptr;
+                if (!j_key(R, p, R.m1, R.f, j == 0, h, klen, kp))
                     lbad = true;
                 else {
-                    if (h == MMP_KEY("type") && klen == 4) fid = 0;
-                    else if (h == MMP_KEY("lu") && klen == 2) fid = 1;
-                    else if (h == MMP_KEY("lul") && klen == 3) fid = 2;
-                    else if (h == MMP_KEY("instanceIds") && klen == 11) fid = 3;
-                    else if (h == MMP_KEY("failedIn") && klen == 8) fid = 4;
+                    if (KEY_IS(h, klen, kp, "type")) fid = 0;
+                    else if (KEY_IS(h, klen, kp, "lu")) fid = 1;
+                    else if (KEY_IS(h, klen, kp, "lul")) fid = 2;
+                    else if (KEY_IS(h, klen, kp, "instanceIds")) fid = 3;
+                    else if (KEY_IS(h, klen, kp, "failedIn")) fid = 4;
                     int v = p + 1;
                     while (v < R.L && j_is_ws(R.by[v])) v++;
                     const bool last = j == R.n1 - 1;
@@ -896,7 +913,8 @@ __global__ __launch_bounds__(kJBlock) void ingest_models_kernel(IngestModelsArgs
                 int klen;
                 int64_t tm = 0;
                 bool lbad = false;
-                if (p < 0 || p > close || !j_key(R, p, R.m2, open, k == 0, h, klen))
+                const uint8_t *kp = nullptr;
+                if (p < 0 || p > close || !j_key(R, p, R.m2, open, k == 0, h, klen, kp))
                     lbad = true;
                 else {
                     int v = p + 1;

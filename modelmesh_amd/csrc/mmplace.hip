@@ -136,6 +136,8 @@ struct mmp_ctx {
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     double last_kernel_ms = -1.0;
     int32_t force_wave = 0;  // MMP_FORCE_WAVE=1: every decision takes the wave-per-decision kernel (tests)
+    size_t lds_limit = 64 * 1024;    // LDS a workgroup may use on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
+    size_t lds_granted = 48 * 1024;  // dynamic LDS the place kernels may be launched with so far
     int32_t no_heads = 0;    // MMP_NO_HEADS=1: decisions do not use the per-type head windows (tests: lane_decide_r alone)
 
     // host staging (inputs of the next commit)
@@ -385,7 +387,19 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     A.done_seq = done_seq;
     const int wpad = (c->snap.W + 1) & ~1;
     const size_t lds = (size_t)kPlaceWaves * 2 * wpad * sizeof(uint64_t);
-    if (lds > 60 * 1024) return fail(c, MMP_EINVAL, "instance table too large for the LDS staging tile (%d pods)", c->snap.P);
+    // the wave path's tile (two bitmaps of the whole table per wavefront) next to the static LDS of place_block;
+    // gfx950 gives a workgroup up to 160 KB (c->lds_limit is the device's answer), which admits ~120k instances
+    if (lds + kPlaceStaticLds > c->lds_limit)
+        return fail(c, MMP_EINVAL, "instance table too large for the LDS staging tile (%d pods: %zu + %d bytes of LDS, the device "
+                    "gives a workgroup %zu)", c->snap.P, lds, kPlaceStaticLds, c->lds_limit);
+    if (lds > c->lds_granted) {  // beyond the default dynamic-LDS grant: ask once per size class, for every variant
+        const int want = (int)(c->lds_limit - kPlaceStaticLds);
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_flag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_single_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        c->lds_granted = (size_t)want;
+    }
     if (inline_req)
         hipLaunchKernelGGL(place_single_kernel, dim3(1), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *inline_req);
     else if (done_flag && n > kPlaceBlock)
@@ -431,6 +445,10 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     mmp_ctx *c = new (std::nothrow) mmp_ctx();
     if (!c) return fail(nullptr, MMP_ENOMEM, "out of memory");
     c->cfg = *cfg;
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device) == hipSuccess && v > 0) c->lds_limit = (size_t)v;
+    }
     if (const char *fw = getenv("MMP_FORCE_WAVE")) c->force_wave = fw[0] == '1';
     if (const char *nh = getenv("MMP_NO_HEADS")) c->no_heads = nh[0] == '1';
     if (const char *rm = getenv("MMP_RANK_MODE")) c->rank_mode = atoi(rm);

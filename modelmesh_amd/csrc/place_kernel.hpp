@@ -1445,6 +1445,10 @@ __device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int
 // SIMD: -5 % on a lone 100k launch, -14 % saturated), so it is compiled into a kernel of its own which the host
 // launches only for snapshots in which (nearly) every instance is full — the only regime that produces such
 // shortlists in number; otherwise they take the wave path.
+// static LDS of place_block (lists, the staged windows, the per-lane scratch), rounded up: the host adds the wave path's
+// dynamic tile and checks the sum against the device's per-workgroup limit
+constexpr int kPlaceStaticLds = 2 * kPlaceBlock * 4 + 64 + ((kWinLds * (int)sizeof(TypeWin) + 1023) / 1024) * 1024 +
+                                kWinWords * kPlaceBlock * 8 + 256;
 template <bool WITH_LONG>
 __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, int32_t wpad, unsigned char *smem,
                                             uint32_t *done_blocks = nullptr)

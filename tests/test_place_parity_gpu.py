@@ -364,6 +364,20 @@ def test_general_wave_path_alone(seed, monkeypatch):
     _check_fleet(fleet, reqs, extra)
 
 
+@pytest.mark.parametrize("force_wave", [False, True])
+def test_100k_instances(force_wave, monkeypatch):
+    """Round 1 refused tables whose wave-path tile exceeded 60 KB of LDS (~61k instances, 20 % above C4); gfx950 gives
+    a workgroup 160 KB and the launcher now asks the device.  100k instances = 1563 words per bitmap row = a 100 KB
+    tile next to the 31 KB of static LDS; with MMP_FORCE_WAVE=1 every decision actually uses that tile."""
+    if force_wave:
+        monkeypatch.setenv("MMP_FORCE_WAVE", "1")
+    fleet = wl.make_fleet("C3", models=30_000, pods=100_000)
+    rng = np.random.default_rng(3)
+    fleet.pods["count"] = rng.poisson(12, fleet.n_pods)  # make_fleet's 2 M / P would leave most instances empty
+    reqs, extra = wl.make_requests(fleet, 77, n=4_000 if force_wave else 30_000)
+    _check_fleet(fleet, reqs, extra)
+
+
 def test_c4_1m_x_50k_sample():
     """BASELINE config C4's fleet on one device: 50k pods (782 words per bitmap row), 1M models; 250k of
     the 1M decisions are compared with the oracle to bound the CPU time."""
