@@ -59,9 +59,16 @@ struct __attribute__((aligned(16))) ResolvedReq {
     int32_t n_excl;   // |loaded ∪ failed ∪ tried ∪ explicit|; > kInlineExcl: left to the wave path
     int32_t model;
     int32_t excl_pos[kInlineExcl];  // rank positions of the excluded pods, -1 = not in the table
-    int32_t pad[2];
+    // Late-bound request exclusions (place_block only): the request's own exclusions (tried / explicit, <= kLateExtra)
+    // are kept apart from the model's, so that the pod -> position gather they need — a third dependent load
+    // level that 5 % of the requests, hence nearly every wavefront, has — is first USED after the workgroup barrier
+    // and the window staging of lane_decide_win instead of being waited for inside resolve_one.  n_late < 0: not
+    // late-bound, excl_pos already holds everything.  lane_decide_r's callers merge first (merge_late_extras).
+    int32_t n_late, n_model;
+    int32_t late_pos[4];
 };
-static_assert(sizeof(ResolvedReq) == 96, "ResolvedReq is 96 bytes");
+constexpr int kLateExtra = 4;
+static_assert(sizeof(ResolvedReq) == 112, "ResolvedReq is 112 bytes");
 
 // The registry view with its indirections followed once per (registry, snapshot) pair instead of once
 // per decision: model row -> instanceIds / failedIn -> rank positions.  Rebuilt by
@@ -93,9 +100,12 @@ static_assert(sizeof(ResolvedModel) == 32, "ResolvedModel is 32 bytes");
 constexpr int kWinWords = 6;   // 64-pod words per window
 constexpr int kWinRows = 12;   // rows kept per list: with <= kInlineExcl exclusions the best position is among the first 9
 constexpr int kWinLds = 16;    // type rows staged in LDS (types beyond take lane_decide_r)
+constexpr int32_t kWinPosPreferred = 1 << 30;  // WinRow::pos bit: the instance is one of the type's preferred instances
+constexpr int32_t kWinPosMask = kWinPosPreferred - 1;
 struct __attribute__((aligned(16))) WinRow {
     int64_t lru, rem;
-    int32_t cnt, rpm, orig, pos;
+    int32_t cnt, rpm, orig;
+    int32_t pos;  // rank position | kWinPosPreferred; -1: no such row
 };
 static_assert(sizeof(WinRow) == 32, "WinRow is 32 bytes");
 struct __attribute__((aligned(16))) TypeWin {
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(64) void build_wins_kernel(Snap S, TypeWin *__restr
                 r.cnt = S.cnt[pos];
                 r.rpm = S.rpm[pos];
                 r.orig = S.orig[pos];
-                r.pos = pos;
+                r.pos = pos | ((has_pm && ((Pm[pos >> 6] >> (pos & 63)) & 1ull)) ? kWinPosPreferred : 0);
             }
             (second ? out->rowsP : out->rowsE)[k] = r;
         }
@@ -338,6 +348,25 @@ struct RpmRule {
         return active && rpm >= 100 &&
                ((ago < -1000LL && rpm > m11) || (ago < 5000LL && rpm > m15) ||
                 (ago < 12LL * 60 * 1000 && rpm > m3) || (ago < 24LL * 3600 * 1000 && rpm > m4));
+    }
+    // The same rule as ONE threshold: the age clauses are nested (-1 s < 5 s < 12 min < 1 day), so the clauses that
+    // apply to this request are a suffix of the list and "some applicable clause has rpm > m_i" is rpm > the
+    // smallest applicable m_i (taken explicitly: 3x / 4x wrap like the Java's int products, so the m_i need not
+    // be ordered).  rpm nulls iff rpm >= 100 && rpm > limit(); limit() == INT32_MAX when no clause applies.
+    __device__ __forceinline__ int32_t limit() const
+    {
+        int32_t t = INT32_MAX;
+        if (active && ago < 24LL * 3600 * 1000) {
+            t = m4;
+            if (ago < 12LL * 60 * 1000) {
+                t = m3 < t ? m3 : t;
+                if (ago < 5000LL) {
+                    t = m15 < t ? m15 : t;
+                    if (ago < -1000LL) t = m11 < t ? m11 : t;
+                }
+            }
+        }
+        return t;
     }
 };
 
@@ -426,11 +455,20 @@ __device__ __forceinline__ int32_t pod_view_pos(const Snap &S, int32_t pod, int3
 
 // Follow request -> model row -> exclusion lists -> rank positions (one lane).  VIEW: S is a shard's view
 // of its slice (positions are translated into it, pos_of is bounded by the whole table's pod count).
-template <bool VIEW>
+template <bool VIEW, bool LATE = false>
+__device__ __forceinline__ ResolvedReq resolve_req(const Snap &S, const PlaceArgs &A, const mmp_place_req &rq);
+
+template <bool VIEW, bool LATE = false>
 __device__ __forceinline__ ResolvedReq resolve_one(const Snap &S, const PlaceArgs &A, int d)
 {
-    const int32_t P_all = VIEW ? A.n_pods_all : S.P;
     const mmp_place_req rq = A.reqs[d];
+    return resolve_req<VIEW, LATE>(S, A, rq);
+}
+
+template <bool VIEW, bool LATE>
+__device__ __forceinline__ ResolvedReq resolve_req(const Snap &S, const PlaceArgs &A, const mmp_place_req &rq)
+{
+    const int32_t P_all = VIEW ? A.n_pods_all : S.P;
     ResolvedReq r;
     r.flags = rq.flags;
     r.pick = rq.pick;
@@ -441,7 +479,10 @@ __device__ __forceinline__ ResolvedReq resolve_one(const Snap &S, const PlaceArg
     r.fresh_rpm = rq.fresh_rpm;
     r.model = rq.model;
     r.selfpos = pod_view_pos<VIEW>(S, rq.self_pod, P_all);
-    r.pad[0] = r.pad[1] = 0;
+    r.n_late = -1;
+    r.n_model = 0;
+#pragma unroll
+    for (int j = 0; j < kLateExtra; j++) r.late_pos[j] = -1;
 #pragma unroll
     for (int i = 0; i < kInlineExcl; i++) r.excl_pos[i] = -1;
     // The request's own exclusions (tried-this-request / explicit) depend on the request alone: their pool
@@ -467,7 +508,12 @@ __device__ __forceinline__ ResolvedReq resolve_one(const Snap &S, const PlaceArg
 #pragma unroll
             for (int i = 0; i < kResolvedInline; i++)
                 if (i < m.n_ents) r.excl_pos[i] = m.pos[i];
-            if (early_extra) {
+            if (LATE && (early_extra || rq.n_extra == 0)) {
+                r.n_model = m.n_ents;
+                r.n_late = rq.n_extra;
+#pragma unroll
+                for (int j = 0; j < kLateExtra; j++) r.late_pos[j] = xpos[j];  // first use of the gathered positions: by the caller
+            } else if (early_extra) {
 #pragma unroll
                 for (int i = 0; i < kInlineExcl; i++) {  // slot n_ents + j takes extra j
                     const int j = i - m.n_ents;
@@ -661,6 +707,25 @@ __device__ __forceinline__ int lane_first(F f, int start, int stop, bool &far, c
 enum { kLaneDone = 0, kLaneWave = 1, kLaneNoneHere = 2, kLaneIncomplete = 3, kLaneLong = 4, kLaneHeadMiss = 5 };
 // (a scan given up after kLaneSpan words also reports kLaneLong when the snapshot has prefix tables: the LONG
 // instantiation's scans jump through them)
+
+// excl_pos := the model's exclusions followed by the late-bound ones (what lane_decide_r expects)
+__device__ __forceinline__ void merge_late_extras(ResolvedReq &r)
+{
+    if (r.n_late <= 0) {
+        r.n_late = -1;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < kInlineExcl; i++) {
+        const int j = i - r.n_model;
+        int32_t v = r.excl_pos[i];
+#pragma unroll
+        for (int q = 0; q < kLateExtra; q++)
+            if (j == q && q < r.n_late) v = r.late_pos[q];
+        r.excl_pos[i] = v;
+    }
+    r.n_late = -1;
+}
 
 template <bool VIEW, bool LONG = false>
 __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, mmp_place_out &o);
@@ -960,40 +1025,61 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
     return fb ? (VIEW ? kLaneIncomplete : (far && !LONG && S.pc ? kLaneLong : kLaneWave)) : kLaneDone;
 }
 
-// getNext on the type's head window (TypeWin): Ws = the windows in LDS, scr = this lane's column of the workgroup's
-// scratch (word j at scr[j * kPlaceBlock]).  Step for step lane_decide_r's simple case; kLaneHeadMiss whenever
-// the window cannot answer — the caller then runs lane_decide_r on the same resolved request.
-// (Measured against a variant that keeps 4 or 6 window words per bitmap in registers and replaces every loop below
-// by unrolled 64-bit arithmetic: 1059 instead of 784 VALU instructions per wavefront, 8.6 / 9.9 us per launch
-// instead of 7.9 — the loops here run one or two trips, and a trip is one LDS read.)
+// getNext on the type's head window (TypeWin): Ws = the windows in LDS; scr = this lane's two columns of the
+// workgroup's scratch — word j of the window's eligibility words at scr[j * kPlaceBlock], of its candidate words
+// (eligible and preferred-if-the-type-prefers, :4905) at scr[(kWinWords + j) * kPlaceBlock] — both with the
+// request's exclusions cleared.  Step for step lane_decide_r's simple case; kLaneHeadMiss whenever the window cannot
+// answer — the caller then runs lane_decide_r on the same resolved request.
+// Shape of the code, from measurements (tools/phase_clock.py, SQ counters): a wavefront of this kernel is alone or
+// nearly alone on its SIMD, so what it pays for is every dependent LDS round trip (~0.1 us) and every instruction of
+// its one serial stream.  Hence: everything the first steps need (header, words, the likeliest row) is fetched in
+// one round; the break scans (:4909-4927), the candidate count and the audit hash are ONE walk over the candidate
+// words (a trip is one LDS read; one or two trips); the candidate words are parked for the final select; the rpm
+// rule is one threshold.  (A variant with 4 or 6 words per bitmap in registers and no loops at all was measured
+// too: 1059 instead of 744 VALU instructions per wavefront, 8.6 / 9.9 us per launch instead of 7.5.)
 __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, const TypeWin *Ws,
                                                uint64_t *scr, mmp_place_out &o)
 {
     PHASE_T0();
     if (r.type < 0 || r.type >= kWinLds || r.n_excl > kInlineExcl || A.force_wave) return kLaneHeadMiss;
     const TypeWin &Wn = Ws[r.type];
+    uint64_t *scrE = scr, *scrD = scr + kWinWords * kPlaceBlock;
+    // round 1: header, the words of both bitmaps, the first row
     const int4 hdr = *reinterpret_cast<const int4 *>(&Wn);  // valid, w0, nw, flags
-    // the window's eligibility words with this request's exclusions cleared (CacheMissExcludeSet, :4740-4743):
-    // six reads in flight, six writes, then one LDS and-operation per exclusion that falls into the window
     {
-        uint64_t e6[kWinWords];
+        uint64_t e6[kWinWords], p6[kWinWords];
 #pragma unroll
-        for (int j = 0; j < kWinWords; j++) e6[j] = Wn.E[j];  // words beyond nw are zero in the record
+        for (int j = 0; j < kWinWords; j++) {  // words beyond nw are zero in the record
+            e6[j] = Wn.E[j];
+            p6[j] = Wn.Pm[j];
+        }
 #pragma unroll
-        for (int j = 0; j < kWinWords; j++) scr[j * kPlaceBlock] = e6[j];
+        for (int j = 0; j < kWinWords; j++) {
+            scrE[j * kPlaceBlock] = e6[j];
+            scrD[j * kPlaceBlock] = e6[j] & p6[j];
+        }
     }
+    WinRow r0 = Wn.rowsE[0];
     if (!hdr.x) return kLaneHeadMiss;
     const int P = S.P;
     const int w0 = hdr.y, nw = hdr.z;
     const int win_lo = w0 * 64;
     const int win_end = (w0 + nw) * 64 < P ? (w0 + nw) * 64 : P;  // the window answers for positions [win_lo, win_end)
+    // the request's exclusions (CacheMissExcludeSet, :4740-4743): the model's, then the late-bound ones of the request
+    auto clear_at = [&](int e) {
+        const int j = (e >> 6) - w0;
+        if (e >= 0 && j >= 0 && j < nw) {
+            const unsigned long long m = ~(1ull << (e & 63));
+            atomicAnd((unsigned long long *)&scrE[j * kPlaceBlock], m);
+            atomicAnd((unsigned long long *)&scrD[j * kPlaceBlock], m);
+        }
+    };
 #pragma unroll
-    for (int i = 0; i < kInlineExcl; i++) {
-        const int e = r.excl_pos[i], j = (e >> 6) - w0;
-        if (e >= 0 && j >= 0 && j < nw) atomicAnd((unsigned long long *)&scr[j * kPlaceBlock], ~(1ull << (e & 63)));
-    }
-    auto ew = [&](int w) { return scr[(w - w0) * kPlaceBlock]; };  // w0 <= w < w0 + nw
-    auto dw = [&](int w) { return scr[(w - w0) * kPlaceBlock] & Wn.Pm[w - w0]; };  // preference treated as required (:4905)
+    for (int i = 0; i < kInlineExcl; i++) clear_at(r.excl_pos[i]);
+#pragma unroll
+    for (int i = 0; i < kLateExtra; i++) clear_at(r.late_pos[i]);  // -1 unless late-bound
+    auto ew = [&](int w) { return scrE[(w - w0) * kPlaceBlock]; };  // w0 <= w < w0 + nw
+    auto dw = [&](int w) { return scrD[(w - w0) * kPlaceBlock]; };
     // first set bit of f(w) at a position in [from, to) of the window (to <= win_end); kNoPos if none
     auto first_in = [&](auto f, int from, int to) {
         if (from >= to) return (int)kNoPos;
@@ -1021,14 +1107,16 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
     const int best0 = first_in(ew, win_lo, win_end);
     if (best0 == kNoPos) return kLaneHeadMiss;  // null, or the retry without excludeReplicaSets (:4797-4804)
     // every eligible position before best0 is excluded; none unless an exclusion removed the type's first instance
-    const int i0 = best0 == Wn.rowsE[0].pos ? 0 : rank_in(Wn.E, best0, false);
-    if (i0 >= kWinRows) return kLaneHeadMiss;
+    if (best0 != (r0.pos & kWinPosMask)) {
+        const int i0 = rank_in(Wn.E, best0, false);
+        if (i0 >= kWinRows) return kLaneHeadMiss;
+        r0 = Wn.rowsE[i0];
+    }
     PHASE(1);  // first eligible pod
     const int selfpos = r.selfpos;
     const bool favour = (r.flags & MMP_REQ_FAVOUR_SELF) != 0;
     const int64_t f_lru = r.fresh_lru, f_rem = r.f_rem;
     const int32_t f_rpm = r.fresh_rpm;
-    const WinRow r0 = Wn.rowsE[i0];
     const int64_t e_lru = r0.lru, e_rem = r0.rem;
     const int32_t e_rpm = r0.rpm;
     bool us = best0 == selfpos;
@@ -1037,7 +1125,7 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
     const bool best_is_full = b_rem < S.min_space;  // :4811, never recomputed
     int bestpos = best0;
     int32_t best_idx = r0.orig;
-    if ((hdr.w & 2) && !((Wn.Pm[(best0 >> 6) - w0] >> (best0 & 63)) & 1ull)) {
+    if ((hdr.w & 2) && !(r0.pos & kWinPosPreferred)) {
         if (best_is_full) return kLaneHeadMiss;  // case (b): per-candidate rpm, the wave path
         // case (a): the first preferred pod, provided no full pod comes before it
         const int q1 = first_in(dw, best0 + 1, win_end);
@@ -1066,6 +1154,7 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
     }
     const int64_t oldest = b_lru;
     bool ns_break, self_break;
+    int from_t = kNoPos;  // first window position whose count breaks the list (:4925-4926); none in full mode
     if (best_is_full) {
         const int64_t rel = age_of(oldest, A.now) / 10;
         const int64_t d1 = jsub64(f_lru, oldest), d2 = jsub64(e_lru, oldest);
@@ -1075,51 +1164,58 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
         const int64_t q = b_rem >> 2;  // :4922
         ns_break = f_rem < S.min_space || f_rem < q;
         self_break = e_rem < S.min_space || e_rem < q;
-    }
-    const int start = bestpos + 1;
-    // the caller's own entry beyond the window cannot be in a shortlist that ends inside it (checked below)
-    const bool self_in_d = selfpos >= start && selfpos < win_end && ((dw(selfpos >> 6) >> (selfpos & 63)) & 1ull);
-    int end = P;
-    if (ns_break) {  // the first candidate that is not the caller's own entry ends the list
-        auto dns = [&](int w) {
-            uint64_t v = dw(w);
-            if ((selfpos >> 6) == w) v &= ~(1ull << (selfpos & 63));
-            return v;
-        };
-        const int p1 = first_in(dns, start, win_end);
-        if (p1 == kNoPos && win_end < P) return kLaneHeadMiss;  // the scan leaves the window
-        end = p1 < end ? p1 : end;
-    }
-    if (self_in_d && self_break) end = selfpos < end ? selfpos : end;
-    if (!best_is_full) {
         const int32_t thr = (int32_t)((uint32_t)b_cnt + (uint32_t)(b_cnt >> 2));  // :4926
         const int64_t T = thr < kGeBase - 1 ? (int64_t)kGeBase : (int64_t)thr + 1;  // count >= 10 && count > thr
         if (T >= kGeBase + kGeRows) return kLaneHeadMiss;
-        const int from_t = win_lo + (int)Wn.ct[T - kGeBase];  // counts do not decrease along the window
-        const int lim = end < win_end ? end : win_end;
-        const int pc = first_in(dw, from_t > start ? from_t : start, lim);
-        if (pc == kNoPos && end > win_end) return kLaneHeadMiss;  // the break, if any, lies beyond the window
-        end = pc < end ? pc : end;
+        from_t = win_lo + (int)Wn.ct[T - kGeBase];  // counts do not decrease along the window
     }
-    PHASE(3);  // break scans
-    if (end > win_end) return kLaneHeadMiss;  // the shortlist leaves the window
-    const bool self_in_c = self_in_d && selfpos < end;
+    // ONE walk over the candidate words from the best position on: the first position that ends the list — the first
+    // candidate that is not the caller's own entry when the fresh-row rule fires, the caller's own entry when its rule
+    // fires, the first candidate whose count is past the threshold — and, up to it, the candidates' count and audit
+    // hash; the clipped words are parked in the eligibility column for the select below.
+    const int start = bestpos + 1;
+    const int wlo = bestpos >> 6, wend = (win_end - 1) >> 6;
+    const int lo_t = from_t > start ? from_t : start;
+    int end = kNoPos, whi = wlo, ccount = 0;
+    bool self_in_c = false;
+    uint64_t hsum = 0;
+    for (int w = wlo; w <= wend; w++) {
+        const uint64_t d = dw(w);
+        uint64_t v = d;
+        if (w == wlo) v &= (start & 63) ? (~0ull) << (start & 63) : ((start >> 6) == wlo ? ~0ull : 0ull);  // positions >= start
+        const bool self_here = (selfpos >> 6) == w && ((v >> (selfpos & 63)) & 1ull);
+        int e_w = kNoPos;
+        if (ns_break) {
+            const uint64_t x = self_here ? v & ~(1ull << (selfpos & 63)) : v;
+            if (x) e_w = w * 64 + (__ffsll((unsigned long long)x) - 1);
+        }
+        if (self_here && self_break && selfpos < e_w) e_w = selfpos;
+        if ((lo_t >> 6) <= w) {  // (from_t == kNoPos in full mode: never)
+            const uint64_t y = (lo_t >> 6) == w ? v & ((~0ull) << (lo_t & 63)) : v;
+            if (y) {
+                const int pc = w * 64 + (__ffsll((unsigned long long)y) - 1);
+                e_w = pc < e_w ? pc : e_w;
+            }
+        }
+        if (e_w != kNoPos) {
+            end = e_w;
+            v &= (1ull << (e_w & 63)) - 1ull;  // e_w lies in this word
+        }
+        if (self_here && (end == kNoPos || selfpos < end)) self_in_c = true;
+        if (w == wlo) v |= 1ull << (bestpos & 63);
+        scrE[(w - w0) * kPlaceBlock] = v;
+        whi = w;
+        ccount += __popcll((unsigned long long)v);
+        if (v) hsum += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)(w + 1)));
+        if (end != kNoPos) break;
+    }
+    if (end == kNoPos && win_end < P) return kLaneHeadMiss;  // the list runs past the window
+    PHASE(3);  // break scans + count + audit hash
     if (self_in_c && favour) {  // :4931-4933
         o.chosen = MMP_SELF;
         return kLaneDone;
     }
-    // candidates = {best} ∪ D∩[start,end): count + hash; the words stay in this lane's scratch column for the select
-    const int wlo = bestpos >> 6, whi = end > start ? (end - 1) >> 6 : wlo;
-    int ccount = 0;
-    uint64_t hsum = 0;
-    for (int w = wlo; w <= whi; w++) {
-        uint64_t v = clip_word(dw(w), w, start, end);
-        if (w == wlo) v |= 1ull << (bestpos & 63);
-        scr[(w - w0) * kPlaceBlock] = v;
-        ccount += __popcll((unsigned long long)v);
-        if (v) hsum += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)(w + 1)));
-    }
-    PHASE(4);  // count + audit hash
+    PHASE(4);
     int remaining = ccount;
     bool null0 = false, null_s = false, null_o = false;
     if (ccount >= 2) {  // rpm filter, :4951-4980 (quirks B#2/B#3: three rpm classes)
@@ -1129,9 +1225,10 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
         if (n_others > 0 && f_rpm < mn) mn = f_rpm;
         RpmRule rule;
         rule.init(age_of(r.last_used, A.now), mn);
-        null0 = rule.nulls(b_rpm);
-        null_s = self_in_c && rule.nulls(e_rpm);
-        null_o = n_others > 0 && rule.nulls(f_rpm);
+        const int32_t lim = rule.limit();
+        null0 = b_rpm >= 100 && b_rpm > lim;
+        null_s = self_in_c && e_rpm >= 100 && e_rpm > lim;
+        null_o = n_others > 0 && f_rpm >= 100 && f_rpm > lim;
         remaining = ccount - (null0 ? 1 : 0) - (null_s ? 1 : 0) - (null_o ? n_others : 0);
     }
     PHASE(5);  // rpm rule
@@ -1141,7 +1238,7 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
         const int sw = self_in_c ? (selfpos >> 6) : -1;
         int running = 0;
         for (int w = wlo; w <= whi; w++) {
-            uint64_t v = scr[(w - w0) * kPlaceBlock];  // the word's candidates; those the rpm filter left in:
+            uint64_t v = scrE[(w - w0) * kPlaceBlock];  // the word's candidates; those the rpm filter left in:
             uint64_t special = 0;
             if (w == wlo) special |= 1ull << (bestpos & 63);
             if (w == sw) special |= 1ull << (selfpos & 63);
@@ -1448,7 +1545,7 @@ __device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int
 // static LDS of place_block (lists, the staged windows, the per-lane scratch), rounded up: the host adds the wave path's
 // dynamic tile and checks the sum against the device's per-workgroup limit
 constexpr int kPlaceStaticLds = 2 * kPlaceBlock * 4 + 64 + ((kWinLds * (int)sizeof(TypeWin) + 1023) / 1024) * 1024 +
-                                kWinWords * kPlaceBlock * 8 + 256;
+                                2 * kWinWords * kPlaceBlock * 8 + 256;
 template <bool WITH_LONG>
 __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, int32_t wpad, unsigned char *smem,
                                             uint32_t *done_blocks = nullptr)
@@ -1458,7 +1555,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
     constexpr int kWinLdsBytes = ((kWinLds * (int)sizeof(TypeWin) + 1023) / 1024) * 1024;  // staged in whole 1 KB chunks
     __shared__ __attribute__((aligned(16))) unsigned char s_wins_raw[kWinLdsBytes];
     TypeWin *s_wins = reinterpret_cast<TypeWin *>(s_wins_raw);
-    __shared__ uint64_t s_scr[kWinWords * kPlaceBlock];  // per lane: the window's eligibility words with the request's exclusions cleared
+    __shared__ uint64_t s_scr[2 * kWinWords * kPlaceBlock];  // per lane: the window's eligibility and candidate words with the request's exclusions cleared
     if (threadIdx.x == 0) fb_n = lr_n = 0;
     const int d = blockIdx.x * kPlaceBlock + threadIdx.x;
     PHASE_T0();
@@ -1478,16 +1575,24 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
             __builtin_amdgcn_global_load_lds(src + (size_t)c * 1024 + lane_id() * 16,
                                              (__attribute__((address_space(3))) void *)(dst + c * 1024), 16, 0, 0);
     }
-    ResolvedReq r;
-    if (d < A.n) r = resolve_one<false>(S, A, d);
-    PHASE(0);  // request + model row resolved
-    if (use_wins) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-bound copies have landed before the barrier releases
+    // The workgroup barrier sits right behind the request fetch — the one load every decision needs first.  Loads
+    // return in order, so the LDS-bound copies issued before it have landed when it has; and nothing issued AFTER the
+    // barrier (the model row, the caller's position, the late-bound exclusions) has to be drained for it.
+    mmp_place_req rq{};
+    if (d < A.n) rq = A.reqs[d];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    ResolvedReq r;
+    if (d < A.n) r = resolve_req<false, true>(S, A, rq);
+    PHASE(0);  // request + model row resolved
     if (d < A.n) {
         mmp_place_out o;
         int code = kLaneHeadMiss;
         if (use_wins) code = lane_decide_win(S, A, r, s_wins, s_scr + threadIdx.x, o);
-        if (code == kLaneHeadMiss) code = lane_decide_r<false>(S, A, r, o);
+        if (code == kLaneHeadMiss) {
+            merge_late_extras(r);
+            code = lane_decide_r<false>(S, A, r, o);
+        }
         if (WITH_LONG && code == kLaneLong)
             lr_list[atomicAdd(&lr_n, 1)] = d;
         else if (code != kLaneDone)

@@ -1,0 +1,131 @@
+// Round-trip floor of a persistent decision kernel: the host rings a doorbell, one wavefront that never exits sees it
+// and answers into pinned host memory, the host spins on the answer.  Two doorbell placements:
+//   A  pinned host memory (hipHostMalloc): the device polls across PCIe
+//   B  fine-grained device memory (hipExtMallocWithFlags(hipDeviceMallocFinegrained)) written by the host through
+//      the BAR: the device polls its own memory
+// and, for scale, C: the same echo as one ordinary kernel launch per request + a completion flag (what
+// mmp_place_batch(n = 1) does today).
+// build+run on the GPU box:  hipcc --offload-arch=gfx950 -O3 tools/micro/doorbell.hip -o /tmp/doorbell && /tmp/doorbell
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <csetjmp>
+#include <csignal>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+__global__ void echo_persistent(volatile uint32_t *bell, volatile uint32_t *answer, volatile uint32_t *stop, const int32_t *tab,
+                                long long idle_ticks)
+{
+    if (threadIdx.x != 0) return;
+    uint32_t seen = 0;
+    long long last = wall_clock64();
+    for (;;) {
+        const uint32_t b = __hip_atomic_load(const_cast<uint32_t *>(bell), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (b != seen) {
+            seen = b;
+            int x = tab[b & 1023];          // a little dependent work standing in for the decision
+            x = tab[x & 1023];
+            __hip_atomic_store(const_cast<uint32_t *>(answer), b + (uint32_t)(x & 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            last = wall_clock64();
+        } else {
+            if (__hip_atomic_load(const_cast<uint32_t *>(stop), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;
+            if (wall_clock64() - last > idle_ticks) return;  // nobody rang for a while: give the CU back
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+
+__global__ void echo_once(uint32_t b, volatile uint32_t *answer, const int32_t *tab)
+{
+    if (threadIdx.x != 0) return;
+    int x = tab[b & 1023];
+    x = tab[x & 1023];
+    __hip_atomic_store(const_cast<uint32_t *>(answer), b + (uint32_t)(x & 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+static sigjmp_buf jb;
+static void on_segv(int) { siglongjmp(jb, 1); }
+
+static void report(const char *name, std::vector<double> &us)
+{
+    std::sort(us.begin(), us.end());
+    printf("%-58s p50 %6.2f us  p99 %6.2f us  min %6.2f us\n", name, us[us.size() / 2], us[us.size() * 99 / 100], us[0]);
+}
+
+int main()
+{
+    uint32_t *answer, *stop, *bellA, *bellB = nullptr;
+    int32_t *tab;
+    CK(hipHostMalloc((void **)&answer, 64, hipHostMallocDefault));
+    CK(hipHostMalloc((void **)&stop, 64, hipHostMallocDefault));
+    CK(hipHostMalloc((void **)&bellA, 64, hipHostMallocDefault));
+    CK(hipMalloc((void **)&tab, 4096));
+    CK(hipMemset(tab, 0, 4096));
+    hipError_t eb = hipExtMallocWithFlags((void **)&bellB, 4096, hipDeviceMallocFinegrained);
+    printf("hipExtMallocWithFlags(finegrained): %s\n", hipGetErrorString(eb));
+    bool b_ok = eb == hipSuccess;
+    if (b_ok) {
+        CK(hipMemset(bellB, 0, 4096));
+        CK(hipDeviceSynchronize());
+        signal(SIGSEGV, on_segv);
+        signal(SIGBUS, on_segv);
+        if (sigsetjmp(jb, 1) == 0) {
+            *(volatile uint32_t *)bellB = 0;  // can the host store through the BAR?
+            printf("host store to fine-grained device memory: ok\n");
+        } else {
+            printf("host store to fine-grained device memory: FAULT (no host-visible BAR mapping)\n");
+            b_ok = false;
+        }
+        signal(SIGSEGV, SIG_DFL);
+        signal(SIGBUS, SIG_DFL);
+    }
+    hipStream_t st;
+    CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    int clk_khz = 100000;
+    (void)hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeWallClockRate, 0);
+    const long long idle = (long long)clk_khz * 200;  // 200 ms
+    const int N = 20000;
+    for (int which = 0; which < 2; which++) {
+        volatile uint32_t *bell = which == 0 ? bellA : bellB;
+        if (which == 1 && !b_ok) continue;
+        *answer = 0;
+        *stop = 0;
+        *bell = 0;
+        hipLaunchKernelGGL(echo_persistent, dim3(1), dim3(64), 0, st, bell, answer, stop, tab, idle);
+        std::vector<double> us;
+        for (uint32_t i = 1; i <= (uint32_t)N; i++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            __atomic_store_n((uint32_t *)bell, i, __ATOMIC_RELEASE);
+            while (__atomic_load_n(answer, __ATOMIC_ACQUIRE) != i) __builtin_ia32_pause();
+            us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+        }
+        __atomic_store_n(stop, 1u, __ATOMIC_RELEASE);
+        CK(hipStreamSynchronize(st));
+        report(which == 0 ? "A persistent kernel, doorbell in pinned host memory" : "B persistent kernel, doorbell in fine-grained device memory", us);
+    }
+    {
+        std::vector<double> us;
+        *answer = 0;
+        for (uint32_t i = 1; i <= (uint32_t)N; i++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            hipLaunchKernelGGL(echo_once, dim3(1), dim3(64), 0, st, i, answer, tab);
+            while (__atomic_load_n(answer, __ATOMIC_ACQUIRE) != i) __builtin_ia32_pause();
+            us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+        }
+        CK(hipStreamSynchronize(st));
+        report("C one launch per request + completion flag in pinned memory", us);
+    }
+    {   // idle exit: nobody rings; the kernel must leave by itself
+        *stop = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(echo_persistent, dim3(1), dim3(64), 0, st, bellA, answer, stop, tab, idle);
+        CK(hipStreamSynchronize(st));
+        printf("idle persistent kernel left by itself after %.1f ms\n",
+               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+    return 0;
+}
