@@ -30,6 +30,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HIP maps streams onto a pool of hardware queues (4 by default), and the library's own streams take part in the
+# rotation: with the default pool the 4 streams of the timed region shared ~2 queues (4.86 us per step); with 8 queues
+# they each get one (3.64 us).  Must be in the environment before the HIP runtime initialises (measured, round 2:
+# pool 2 / 4 / 8 / 16 -> 4.88 / 4.86 / 3.64 / 3.67 us per step at 4 streams; INTEGRATION.md recommends the same to hosts).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -629,13 +635,16 @@ def main():
     sched = [_args[(pos + i) % period] for i in range(args.steps)]
     pos += args.steps
     n_issuers = max(1, min(args.issuers, args.steps))
+    issue_s = None
     if n_issuers == 1:
         rcs = 0
         t0 = time.perf_counter()
         for a in sched:
             rcs |= _fn(*a)
+        t_issued = time.perf_counter()
         fence()
         elapsed = time.perf_counter() - t0
+        issue_s = t_issued - t0
     else:
         import threading as _th
         parts = [sched[j::n_issuers] for j in range(n_issuers)]
@@ -733,7 +742,8 @@ def main():
                                    "decision per model per step (SURVEY.md §8d synthetic fleet)",
                        "decisions_per_step_per_gpu": n, "sharding": "model axis, no collective",
                        "streams": n_streams, "distinct_batches": n_batches, "issuers": n_issuers,
-                       "resident_input_bytes": int(n_batches * n * (64 + 16))},
+                       "resident_input_bytes": int(n_batches * n * (64 + 16)),
+                       "host_issue_us_per_step": None if issue_s is None else issue_s / args.steps * 1e6},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "place_batch_kernel", "kernel_ms": gpu_ms_per_step,

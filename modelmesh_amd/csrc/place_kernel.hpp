@@ -99,7 +99,13 @@ static_assert(sizeof(ResolvedModel) == 32, "ResolvedModel is 32 bytes");
 // that runs past the window ...).
 constexpr int kWinWords = 6;   // 64-pod words per window
 constexpr int kWinRows = 12;   // rows kept per list: with <= kInlineExcl exclusions the best position is among the first 9
-constexpr int kWinLds = 16;    // type rows staged in LDS (types beyond take lane_decide_r)
+#ifndef MMP_WIN_LDS
+#define MMP_WIN_LDS 12
+#endif
+// type rows staged in LDS (types beyond take lane_decide_r).  12: windows (13 KB) + per-lane scratch (24 KB) + lists keep a
+// workgroup under 40 KB, i.e. FOUR workgroups per CU for launches that overlap on several streams (measured, C3, 4
+// streams: 16 rows 3.70 us per step, 8 rows 3.20)
+constexpr int kWinLds = MMP_WIN_LDS;
 constexpr int32_t kWinPosPreferred = 1 << 30;  // WinRow::pos bit: the instance is one of the type's preferred instances
 constexpr int32_t kWinPosMask = kWinPosPreferred - 1;
 struct __attribute__((aligned(16))) WinRow {
@@ -1542,20 +1548,23 @@ __device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int
 // SIMD: -5 % on a lone 100k launch, -14 % saturated), so it is compiled into a kernel of its own which the host
 // launches only for snapshots in which (nearly) every instance is full — the only regime that produces such
 // shortlists in number; otherwise they take the wave path.
-// static LDS of place_block (lists, the staged windows, the per-lane scratch), rounded up: the host adds the wave path's
-// dynamic tile and checks the sum against the device's per-workgroup limit
-constexpr int kPlaceStaticLds = 2 * kPlaceBlock * 4 + 64 + ((kWinLds * (int)sizeof(TypeWin) + 1023) / 1024) * 1024 +
-                                2 * kWinWords * kPlaceBlock * 8 + 256;
+// LDS of place_block: static = the lists; dynamic = max(windows + per-lane scratch of the lane phase, the wave path's
+// tiles) — the host checks the sum against the device's per-workgroup limit
+constexpr int kWinLdsBytes = ((kWinLds * (int)sizeof(TypeWin) + 1023) / 1024) * 1024;  // staged in whole 1 KB chunks
+constexpr int kPlaceLaneLds = kWinLdsBytes + 2 * kWinWords * kPlaceBlock * 8;  // dynamic LDS of the lane phase: windows + scratch
+constexpr int kPlaceStaticLds = 2 * kPlaceBlock * 4 + 64 + 256;                // the lists (+ place_single_kernel's request)
 template <bool WITH_LONG>
 __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, int32_t wpad, unsigned char *smem,
                                             uint32_t *done_blocks = nullptr)
 {
     __shared__ int32_t fb_list[kPlaceBlock], lr_list[kPlaceBlock];
     __shared__ int32_t fb_n, lr_n;
-    constexpr int kWinLdsBytes = ((kWinLds * (int)sizeof(TypeWin) + 1023) / 1024) * 1024;  // staged in whole 1 KB chunks
-    __shared__ __attribute__((aligned(16))) unsigned char s_wins_raw[kWinLdsBytes];
-    TypeWin *s_wins = reinterpret_cast<TypeWin *>(s_wins_raw);
-    __shared__ uint64_t s_scr[2 * kWinWords * kPlaceBlock];  // per lane: the window's eligibility and candidate words with the request's exclusions cleared
+    // The staged windows and the per-lane scratch of the lane phase, and the wave path's bitmap tiles (kPlaceWaves x 2
+    // bitmaps x wpad words) of the phase behind it, share ONE dynamic LDS region (smem; the host sizes it for the
+    // larger of the two, kPlaceLaneLds / the tiles): a 50k-instance table's tiles are 50 KB, and next to 41 KB of
+    // windows + scratch they left room for one workgroup per CU (C4, round 2: 86 us per 1M decisions).
+    TypeWin *s_wins = reinterpret_cast<TypeWin *>(smem);
+    uint64_t *s_scr = reinterpret_cast<uint64_t *>(smem + kWinLdsBytes);  // per lane: the window's eligibility and candidate words with the request's exclusions cleared
     if (threadIdx.x == 0) fb_n = lr_n = 0;
     const int d = blockIdx.x * kPlaceBlock + threadIdx.x;
     PHASE_T0();
