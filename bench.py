@@ -520,6 +520,12 @@ def main():
                     help="distinct request batches the steps rotate through (48 x (6.4 + 1.6) MB = 384 MB > the 256 MiB "
                          "Infinity Cache: a timed step reads its requests from HBM)")
     ap.add_argument("--issuers", type=int, default=1, help="host threads issuing the timed steps")
+    ap.add_argument("--issue-threads", type=int, default=0,
+                    help="submission threads inside the library (mmp_issue_threads): the timed loop then only appends "
+                         "descriptors and the helpers launch in parallel, one per stream; 0 = the calling thread launches.  "
+                         "Measured (round 2): the host's share of a step drops from 3.15 to 0.4 us, the step time does not move "
+                         "(3.25 us: with the round-2 kernel the timed region is bound by the GPU, not by the launch path), so the "
+                         "default leaves the helpers off")
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the timed steps are issued on round-robin (a 100k-decision batch is 1564 "
                          "wavefronts — too few to cover its own latency chain on 256 CUs — so independent batches "
@@ -625,10 +631,15 @@ def main():
     for i in range(max(n_batches, n_streams)):
         check(_fn(*_args[i % period]))
     fence()
+    n_helpers = max(0, min(args.issue_threads, n_streams))
+    _flush = solver.lib.mmp_issue_flush
+    if n_helpers:
+        check(solver.lib.mmp_issue_threads(solver.h, n_helpers))
     pos = 0
     for i in range(args.warmup):
         check(_fn(*_args[pos % period]))
         pos += 1
+    check(_flush(solver.h))
     fence()
     # timed region: exactly K steps (the loop body is the bare C call: at ~4 us of launch work per step a Python
     # function frame is measurable); --issuers > 1 splits the schedule over host threads (ctypes drops the GIL)
@@ -642,6 +653,7 @@ def main():
         for a in sched:
             rcs |= _fn(*a)
         t_issued = time.perf_counter()
+        rcs |= _flush(solver.h)  # (submission threads) everything appended has been handed to the streams
         fence()
         elapsed = time.perf_counter() - t0
         issue_s = t_issued - t0
@@ -664,12 +676,15 @@ def main():
         gate.wait()
         for t_ in ths:
             t_.join()
+        rc_box.append(_flush(solver.h))
         fence()
         elapsed = time.perf_counter() - t0
         rcs = 0
         for v in rc_box:
             rcs |= v
     check(rcs)
+    if n_helpers:
+        check(solver.lib.mmp_issue_threads(solver.h, 0))  # the passes below bracket launches with events: issued in line
     # the kernel's own launch duration: K back-to-back launches on ONE stream (rotating through the batches like the
     # timed region) between a HIP event pair recorded on that stream — region time / K is what
     # rocprofv3 --kernel-trace reports as the kernel's average duration for the same single-stream command ...
@@ -742,6 +757,7 @@ def main():
                                    "decision per model per step (SURVEY.md §8d synthetic fleet)",
                        "decisions_per_step_per_gpu": n, "sharding": "model axis, no collective",
                        "streams": n_streams, "distinct_batches": n_batches, "issuers": n_issuers,
+                       "library_submission_threads": n_helpers,
                        "resident_input_bytes": int(n_batches * n * (64 + 16)),
                        "host_issue_us_per_step": None if issue_s is None else issue_s / args.steps * 1e6},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -424,6 +424,14 @@ int mmp_place_batch(mmp_ctx *ctx, const mmp_place_req *reqs, int32_t n, const in
  * therefore stay valid until mmp_stream_retire() or mmp_destroy(). */
 int mmp_place_batch_dev(mmp_ctx *ctx, const void *d_reqs, int32_t n, const void *d_extra_pool,
                         int64_t now_ms, void *d_outs, void *stream);
+/* Submission threads.  One host thread spends ~3 us in HIP's launch path per kernel — more than a 100k-decision batch
+ * takes the GPU when several are in flight.  mmp_issue_threads(ctx, n) starts n helper threads (they spin: use them for
+ * bursts) and mmp_place_batch_dev then only validates, appends a descriptor to the ring of the helper that owns the
+ * stream (launches on one stream keep their order) and returns; the helper captures the published snapshot and launches.
+ * mmp_issue_flush returns once everything submitted so far has been handed to the HIP stream (first launch error, if
+ * any); call it before synchronising the streams.  n = 0 stops the helpers. */
+int mmp_issue_threads(mmp_ctx *ctx, int32_t n);
+int mmp_issue_flush(mmp_ctx *ctx);
 /* Forget a caller-owned stream (waits for what was enqueued on it first); call before destroying a stream
  * that was passed to a *_dev entry point. */
 int mmp_stream_retire(mmp_ctx *ctx, void *stream);

@@ -21,6 +21,8 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <shared_mutex>
+#include <thread>
 #include <new>
 #include <string>
 #include <unordered_map>
@@ -124,7 +126,11 @@ struct mmp_ctx {
     // table, type table, replica-set list, registry — for a whole call) -> mu (the published snapshot pointers +
     // host staging as readers see it; decision paths hold it only while they capture the pointers and enqueue,
     // loaders hold it for the whole call, a commit only for its final pointer swap)
-    std::mutex batch_mu, mu, err_mu, cs_mu;
+    std::mutex batch_mu, err_mu, cs_mu;
+    // the state lock: decision paths that only capture the published pointers and enqueue take it SHARED (so that the
+    // submission threads of mmp_issue_threads launch concurrently), whoever changes what they capture takes it exclusive
+    std::shared_mutex mu;
+    struct IssuePool *pool = nullptr;  // submission threads (mmp_issue_threads); null: launches are issued by the caller
     // caller-owned streams that *_dev calls were enqueued on (leaf lock cs_mu): whoever rewrites state a decision
     // kernel reads waits for them as well as for the library's own streams (quiesce_decisions)
     std::vector<hipStream_t> caller_streams;
@@ -137,7 +143,7 @@ struct mmp_ctx {
     double last_kernel_ms = -1.0;
     int32_t force_wave = 0;  // MMP_FORCE_WAVE=1: every decision takes the wave-per-decision kernel (tests)
     size_t lds_limit = 64 * 1024;    // LDS a workgroup may use on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
-    size_t lds_granted = 48 * 1024;  // dynamic LDS the place kernels may be launched with so far
+    std::atomic<size_t> lds_granted{48 * 1024};  // dynamic LDS the place kernels may be launched with so far
     int32_t no_heads = 0;    // MMP_NO_HEADS=1: decisions do not use the per-type head windows (tests: lane_decide_r alone)
 
     // host staging (inputs of the next commit)
@@ -393,13 +399,15 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     if (lds + kPlaceStaticLds > c->lds_limit)
         return fail(c, MMP_EINVAL, "instance table too large for the LDS staging tile (%d pods: %zu + %d bytes of LDS, the device "
                     "gives a workgroup %zu)", c->snap.P, lds, kPlaceStaticLds, c->lds_limit);
-    if (lds > c->lds_granted) {  // beyond the default dynamic-LDS grant: ask once per size class, for every variant
+    if (lds > c->lds_granted.load(std::memory_order_acquire)) {  // beyond the default dynamic-LDS grant: ask once, for every variant
+        static std::mutex grant_mu;  // (decision paths hold the state lock shared)
+        std::lock_guard<std::mutex> gg(grant_mu);
         const int want = (int)(c->lds_limit - kPlaceStaticLds);
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_flag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_single_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
-        c->lds_granted = (size_t)want;
+        c->lds_granted.store((size_t)want, std::memory_order_release);
     }
     if (inline_req)
         hipLaunchKernelGGL(place_single_kernel, dim3(1), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *inline_req);
@@ -482,10 +490,12 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
 namespace {
 void group_comm_destroy(ncclComm_t comm);  // defined with the RCCL binding below
 }
+extern "C" int mmp_issue_threads(mmp_ctx *c, int32_t n);
 
 void mmp_destroy(mmp_ctx *c)
 {
     if (!c) return;
+    (void)mmp_issue_threads(c, 0);  // launches still in the rings are issued, the helpers join
     (void)hipSetDevice(c->cfg.device);
     for (FastSlot &f : c->fast) {
         if (f.stream) {
@@ -567,7 +577,7 @@ int mmp_pods_load(mmp_ctx *c, const mmp_pod_row *rows, int32_t n)
 try {
     if (!c || n < 0 || (n > 0 && !rows)) return fail(c, MMP_EINVAL, "mmp_pods_load: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     c->pods.assign(rows, rows + n);
     return MMP_OK;
 } catch (const std::bad_alloc &) {
@@ -580,7 +590,7 @@ int mmp_pods_upsert(mmp_ctx *c, const int32_t *idx, const mmp_pod_row *rows, int
 try {
     if (!c || n < 0 || (n > 0 && (!rows || !idx))) return fail(c, MMP_EINVAL, "mmp_pods_upsert: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     for (int32_t i = 0; i < n; i++) {
         const int32_t k = idx[i];
         if (k < 0 || k > (int32_t)c->pods.size()) return fail(c, MMP_EINVAL, "mmp_pods_upsert: index %d out of range", k);
@@ -600,7 +610,7 @@ int mmp_pods_remove(mmp_ctx *c, const int32_t *idx, int32_t n)
 try {
     if (!c || n < 0 || (n > 0 && !idx)) return fail(c, MMP_EINVAL, "mmp_pods_remove: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     for (int32_t i = 0; i < n; i++) {
         const int32_t k = idx[i];
         if (k < 0 || k >= (int32_t)c->pods.size()) return fail(c, MMP_EINVAL, "mmp_pods_remove: index %d out of range", k);
@@ -619,7 +629,7 @@ int mmp_types_load(mmp_ctx *c, int32_t n_types, const uint64_t *allowed, const u
 try {
     if (!c || n_types < 0) return fail(c, MMP_EINVAL, "mmp_types_load: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     const int32_t W = div_up((int)c->pods.size(), 64);
     c->n_types = n_types;
     c->types_w = W;
@@ -654,7 +664,7 @@ try {
     if (!c || n_types < 0 || (n_types > 0 && (!required || !preferred)))
         return fail(c, MMP_EINVAL, "mmp_types_from_labels: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     const int32_t P = (int32_t)c->pods.size();
     if (P > 0 && !pod_labels) return fail(c, MMP_EINVAL, "mmp_types_from_labels: pod_labels is null");
     const int32_t W = div_up(P, 64), T = n_types, R = T + 1;
@@ -715,7 +725,7 @@ int mmp_replaced_rs_load(mmp_ctx *c, const int32_t *rs, int32_t n)
 try {
     if (!c || n < 0 || (n > 0 && !rs)) return fail(c, MMP_EINVAL, "mmp_replaced_rs_load: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     c->replaced_rs.assign(rs, rs + n);
     return MMP_OK;
 } catch (const std::bad_alloc &) {
@@ -734,7 +744,7 @@ int mmp_upgrade_instance_added(mmp_ctx *c, int64_t labels_key, int32_t rs, int64
 try {
     if (!c) return MMP_EINVAL;
     std::lock_guard<std::mutex> gb(c->batch_mu);  // replaced_rs is an input of the commit
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     c->upgrades.instance_added(labels_key, rs, start_time, now);
     publish_upgrades(c);
     return MMP_OK;
@@ -748,7 +758,7 @@ int mmp_upgrade_instance_removed(mmp_ctx *c, int64_t labels_key, int32_t rs, int
 try {
     if (!c) return MMP_EINVAL;
     std::lock_guard<std::mutex> gb(c->batch_mu);  // replaced_rs is an input of the commit
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     c->upgrades.instance_removed(labels_key, rs, now);
     publish_upgrades(c);
     return MMP_OK;
@@ -762,7 +772,7 @@ int mmp_upgrade_housekeeping(mmp_ctx *c, int64_t now)
 try {
     if (!c) return MMP_EINVAL;
     std::lock_guard<std::mutex> gb(c->batch_mu);  // replaced_rs is an input of the commit
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     c->upgrades.housekeeping(now);
     publish_upgrades(c);
     return MMP_OK;
@@ -775,7 +785,7 @@ try {
 int mmp_upgrade_replaced(mmp_ctx *c, int32_t *rs_out, int64_t *expiry_out, int32_t max, int32_t *n_out)
 try {
     if (!c || !n_out || max < 0 || (max > 0 && (!rs_out || !expiry_out))) return fail(c, MMP_EINVAL, "mmp_upgrade_replaced: bad argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     int32_t i = 0;
     for (auto &e : c->upgrades.replaced) {
         if (i < max) {
@@ -804,7 +814,7 @@ try {
             return fail(c, MMP_EINVAL, "mmp_models_load: model %d entry range out of bounds", i);
     }
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, quiesce_decisions(c));  // the table is overwritten in place
     c->side[0].rmodels_ok = c->side[1].rmodels_ok = false;
@@ -941,7 +951,7 @@ try {
                        (size_t)(base + n_entries) * 8 > c->ent_time.cap ||
                        (cur_side(c).rmodels_ok && (size_t)count * sizeof(ResolvedModel) > cur_side(c).rmodels.cap);
     if (grows) {
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard<std::shared_mutex> g(c->mu);
         HIP_TRY(c, quiesce_decisions(c));
         int rc = grow_keep(c, c->models, (size_t)c->n_models * sizeof(mmp_model_row), (size_t)count * sizeof(mmp_model_row));
         if (rc == MMP_OK) rc = grow_keep(c, c->ent_pod, (size_t)base * 4, (size_t)(base + n_entries) * 4);
@@ -961,7 +971,7 @@ try {
     HIP_TRY(c, hipMemcpyAsync(c->u_rows.p, h_rows.data(), (size_t)k * sizeof(mmp_model_row), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipStreamSynchronize(st));  // the pageable sources above are this call's stack / the caller's arrays
     {
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard<std::shared_mutex> g(c->mu);
         HIP_TRY(c, quiesce_decisions(c));  // rows (and their resolved positions) are rewritten in place
         const bool resolved = cur_side(c).rmodels_ok && c->committed && c->n_shards == 0;
         KT_BEGIN(c, st);
@@ -1247,7 +1257,7 @@ try {
         if (rc != MMP_OK) return rc;
     }
     // publish: the only part of a commit a decision can ever wait for
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     c->snap_long = next_long;
     c->snap = S;
     c->cur = 1 - c->cur;
@@ -1268,7 +1278,7 @@ int mmp_get_order(mmp_ctx *c, int32_t *order_out, int32_t *n_out)
 try {
     if (!c || !order_out || !n_out) return fail(c, MMP_EINVAL, "mmp_get_order: null argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     if (c->n_shards > 0) return fail(c, MMP_ESTATE, "mmp_get_order: a pod-axis shard holds only its own slice of the order");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
@@ -1286,7 +1296,7 @@ int mmp_cluster_stats(mmp_ctx *c, mmp_stats *out)
 try {
     if (!c || !out) return fail(c, MMP_EINVAL, "mmp_cluster_stats: null argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     *out = c->stats;
     return MMP_OK;
@@ -1312,7 +1322,7 @@ mmp_stats stats_of(const StatsAcc &a)
 int mmp_type_stats(mmp_ctx *c, int32_t type, mmp_stats *out)
 try {
     if (!c || !out) return fail(c, MMP_EINVAL, "mmp_type_stats: null argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     const int32_t T = (int32_t)cur_side(c).tstats_h.size();
     *out = stats_of(cur_side(c).tstats_h[(type < 0 || type >= T) ? 0 : type]);
@@ -1326,7 +1336,7 @@ try {
 int mmp_partition_count(mmp_ctx *c, int32_t *n_out)
 try {
     if (!c || !n_out) return fail(c, MMP_EINVAL, "mmp_partition_count: null argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     *n_out = cur_side(c).n_pts;
     return MMP_OK;
@@ -1340,7 +1350,7 @@ int mmp_partition_stats(mmp_ctx *c, int32_t partition, mmp_stats *out, uint64_t 
 try {
     if (!c || !out || max_words < 0 || (max_words > 0 && !prohibited_out))
         return fail(c, MMP_EINVAL, "mmp_partition_stats: bad argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     if (partition < 0 || partition >= cur_side(c).n_pts) return fail(c, MMP_EINVAL, "mmp_partition_stats: no partition %d", partition);
     *out = stats_of(cur_side(c).pstats_h[partition]);
@@ -1357,7 +1367,7 @@ int mmp_pod_partitions(mmp_ctx *c, int32_t *partition_out, int32_t max_pods, int
 try {
     if (!c || !n_out || max_pods < 0 || (max_pods > 0 && !partition_out))
         return fail(c, MMP_EINVAL, "mmp_pod_partitions: bad argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     *n_out = (int32_t)cur_side(c).pts_of.size();
     const int32_t m = std::min(*n_out, max_pods);
@@ -1419,7 +1429,7 @@ int mmp_pod_ids_load(mmp_ctx *c, const char *ids, const int32_t *id_off, int32_t
 try {
     if (!c || n_pods < 0 || !id_off || (n_pods > 0 && !ids)) return fail(c, MMP_EINVAL, "mmp_pod_ids_load: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, quiesce_decisions(c));
     int rc = build_hash_table(c, ids, id_off, n_pods, c->idtab_hash, c->idtab_val, c->idtab_mask, "mmp_pod_ids_load");
@@ -1469,7 +1479,7 @@ try {
     if (!c || n < 0 || (n > 0 && (!buf || !off || !pod_idx || !status_out)))
         return fail(c, MMP_EINVAL, "mmp_pods_ingest_json: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     if (!c->have_ids) return fail(c, MMP_ESTATE, "mmp_pods_ingest_json: load the instance ids first (mmp_pod_ids_load)");
     if (n == 0) return MMP_OK;
     const int32_t P = (int32_t)c->pods.size();
@@ -1525,7 +1535,7 @@ int mmp_type_names_load(mmp_ctx *c, const char *names, const int32_t *name_off, 
 try {
     if (!c || n_types < 0 || !name_off || (n_types > 0 && !names)) return fail(c, MMP_EINVAL, "mmp_type_names_load: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     int rc = build_hash_table(c, names, name_off, n_types, c->tytab_hash, c->tytab_val, c->tytab_mask, "mmp_type_names_load");
@@ -1550,7 +1560,7 @@ try {
     if (!c || n_models < 0 || (n_models > 0 && (!buf || !off || !status_out)))
         return fail(c, MMP_EINVAL, "mmp_models_ingest_json: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     if (!c->have_ids) return fail(c, MMP_ESTATE, "mmp_models_ingest_json: load the instance ids first (mmp_pod_ids_load)");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, quiesce_decisions(c));  // the registry view is replaced in place
@@ -1636,7 +1646,7 @@ try {
 int mmp_pods_get(mmp_ctx *c, mmp_pod_row *rows_out, int32_t max_rows, int32_t *n_out)
 try {
     if (!c || !n_out || max_rows < 0 || (max_rows > 0 && !rows_out)) return fail(c, MMP_EINVAL, "mmp_pods_get: bad argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     *n_out = (int32_t)c->pods.size();
     const int32_t m = std::min(*n_out, max_rows);
     if (m > 0) memcpy(rows_out, c->pods.data(), (size_t)m * sizeof(mmp_pod_row));
@@ -1653,7 +1663,7 @@ try {
     if (!c || !n_models_out || !n_entries_out || max_models < 0 || max_entries < 0)
         return fail(c, MMP_EINVAL, "mmp_models_get: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     *n_models_out = c->n_models;
@@ -1676,7 +1686,7 @@ try {
     if (!c || n_shards < 1 || n_shards > kMaxShards || shard < 0 || shard >= n_shards)
         return fail(c, MMP_EINVAL, "mmp_shard_configure: need 0 <= shard < n_shards <= %d", kMaxShards);
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     c->shard = shard;
     c->n_shards = n_shards;
     c->committed = false;
@@ -1707,7 +1717,7 @@ int mmp_shard_rank_dev(mmp_ctx *c, void *d_rank)
 try {
     if (!c || !d_rank) return fail(c, MMP_EINVAL, "mmp_shard_rank_dev: null argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     if (c->n_shards < 1) return fail(c, MMP_ESTATE, "mmp_shard_configure has not been called");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const int32_t P = (int32_t)c->pods.size();
@@ -1743,7 +1753,7 @@ int mmp_shard_commit_dev(mmp_ctx *c, const void *d_rank)
 try {
     if (!c || !d_rank) return fail(c, MMP_EINVAL, "mmp_shard_commit_dev: null argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     if (c->n_shards < 1 || !c->rank_pending) return fail(c, MMP_ESTATE, "mmp_shard_commit_dev: call mmp_shard_rank_dev first");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, quiesce_decisions(c));
@@ -1967,7 +1977,7 @@ try {
         return fail(c, MMP_EINVAL, "mmp_shard_place_phase_dev: bad argument");
     for (int i = 0; i < 6; i++)
         if (n > 0 && !d_xchg[i]) return fail(c, MMP_EINVAL, "mmp_shard_place_phase_dev: exchange buffer %d is null", i + 1);
-    std::lock_guard<std::mutex> g(c->mu);  // capture the published shard snapshot + enqueue; no wait
+    std::shared_lock<std::shared_mutex> g(c->mu);  // capture the published shard snapshot + enqueue; no wait
     if (c->n_shards < 1 || !c->committed) return fail(c, MMP_ESTATE, "no committed shard snapshot");
     if (n == 0) return MMP_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -2008,7 +2018,7 @@ int mmp_shard_place_fast_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const vo
                              void *stream)
 try {
     if (!c || n < 0 || (n > 0 && (!d_reqs || !d_xf))) return fail(c, MMP_EINVAL, "mmp_shard_place_fast_dev: bad argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     if (c->n_shards < 1 || !c->committed) return fail(c, MMP_ESTATE, "no committed shard snapshot");
     if (n == 0) return MMP_OK;
     const PlaceArgs A = shard_args(c, d_reqs, n, d_extra, now, nullptr);
@@ -2053,7 +2063,7 @@ int mmp_shard_place_fast_finish_dev(mmp_ctx *c, const void *d_reqs, int32_t n, c
 try {
     if (!c || n < 0 || !n_rest_out || !d_rest_reqs_out || !d_rest_outs_out || (n > 0 && (!d_reqs || !d_xf || !d_outs)))
         return fail(c, MMP_EINVAL, "mmp_shard_place_fast_finish_dev: bad argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     if (c->n_shards < 1 || !c->committed) return fail(c, MMP_ESTATE, "no committed shard snapshot");
     *n_rest_out = 0;
     *d_rest_reqs_out = *d_rest_outs_out = nullptr;
@@ -2081,7 +2091,7 @@ try {
 int mmp_shard_place_fast_scatter_dev(mmp_ctx *c, int32_t n_rest, void *d_outs, void *stream)
 try {
     if (!c || n_rest < 0 || (n_rest > 0 && !d_outs)) return fail(c, MMP_EINVAL, "mmp_shard_place_fast_scatter_dev: bad argument");
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     if (c->n_shards < 1 || !c->committed) return fail(c, MMP_ESTATE, "no committed shard snapshot");
     if (n_rest == 0) return MMP_OK;
     hipLaunchKernelGGL(place_shard_scatter_kernel, dim3(div_up(n_rest, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
@@ -2174,7 +2184,7 @@ int group_general(mmp_ctx *c, const void *d_reqs, int32_t n, const int32_t *n_de
     }
     for (int ph = 1; ph <= 7; ph++) {
         {
-            std::lock_guard<std::mutex> g(c->mu);
+            std::lock_guard<std::shared_mutex> g(c->mu);
             const int rc = shard_phase_launch(c, ph, d_reqs, n, n_dev, d_extra, now, xs, d_outs, c->stream);
             if (rc != MMP_OK) return rc;
         }
@@ -2262,7 +2272,7 @@ try {
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     size_t P;
     {
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard<std::shared_mutex> g(c->mu);
         P = c->pods.size();
     }
     HIP_TRY(c, c->g_rankbuf.ensure(std::max<size_t>(P, 1) * 4));
@@ -2300,7 +2310,7 @@ try {
     rc = group_allreduce(c, c->g_xf.p, (size_t)n * kXF, ncclInt64, ncclMin);
     if (rc != MMP_OK) return rc;
     {
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard<std::shared_mutex> g(c->mu);
         rc = shard_finish_launch(c, d_reqs, n, c->g_xf.p, d_outs, st);
         if (rc != MMP_OK) return rc;
     }
@@ -2358,13 +2368,142 @@ try {
     return fail(c, MMP_EHIP, "%s: %s", "mmp_shard_place_batch", e.what());
 }
 
+/* ---- submission threads ---------------------------------------------------
+ * One host thread needs ~3 us per kernel launch (HIP's launch path), which is more than a 100k-decision batch takes the
+ * GPU when several are in flight.  mmp_issue_threads(ctx, n) starts n helper threads that spin on per-helper rings;
+ * while they run, mmp_place_batch_dev only validates, appends a descriptor (tens of ns) and returns, and the helpers
+ * launch in parallel — every caller stream is pinned to one helper, so launches on one stream keep their order.
+ * mmp_issue_flush waits until everything submitted so far has been launched (and reports the first launch error);
+ * every call that waits for decision streams (commit, registry events, mmp_stream_retire, mmp_destroy) flushes first. */
+struct IssueItem {
+    const void *d_reqs, *d_extra;
+    void *d_outs;
+    hipStream_t st;
+    int64_t now;
+    int32_t n;
+};
+struct IssueRing {
+    static constexpr uint32_t kCap = 4096;
+    IssueItem items[kCap];
+    alignas(64) std::atomic<uint32_t> tail{0};  // producers (under push_mu)
+    alignas(64) std::atomic<uint32_t> head{0};  // the helper
+    std::mutex push_mu;
+};
+struct IssuePool {
+    std::vector<std::thread> th;
+    std::vector<IssueRing *> rings;
+    std::atomic<bool> stop{false};
+    std::atomic<int> first_rc{MMP_OK};
+    std::mutex map_mu;
+    std::vector<std::pair<hipStream_t, int>> stream_ring;  // caller stream -> helper, assigned round-robin at first sight
+    int next_ring = 0;
+};
+
+namespace {
+void issue_helper(mmp_ctx *c, IssuePool *P, IssueRing *R)
+{
+    (void)hipSetDevice(c->cfg.device);
+    uint32_t idle = 0;
+    for (;;) {
+        const uint32_t h = R->head.load(std::memory_order_relaxed);
+        if (h == R->tail.load(std::memory_order_acquire)) {
+            if (P->stop.load(std::memory_order_acquire)) return;
+            if (++idle > 64) __builtin_ia32_pause();
+            continue;
+        }
+        idle = 0;
+        const IssueItem it = R->items[h % IssueRing::kCap];
+        int rc;
+        {
+            std::shared_lock<std::shared_mutex> g(c->mu);  // capture the published snapshot + enqueue
+            rc = !c->committed ? fail(c, MMP_ESTATE, "no committed snapshot")
+                               : place_launch(c, it.d_reqs, it.n, it.d_extra, it.now, it.d_outs, it.st);
+        }
+        if (rc != MMP_OK) {
+            int expect = MMP_OK;
+            (void)P->first_rc.compare_exchange_strong(expect, rc);
+        }
+        R->head.store(h + 1, std::memory_order_release);
+    }
+}
+
+int issue_ring_of(IssuePool *P, hipStream_t st)
+{
+    std::lock_guard<std::mutex> g(P->map_mu);
+    for (auto &kv : P->stream_ring)
+        if (kv.first == st) return kv.second;
+    const int r = P->next_ring++ % (int)P->rings.size();
+    P->stream_ring.emplace_back(st, r);
+    return r;
+}
+
+// everything submitted so far has been handed to HIP (called without the state lock)
+int issue_flush(mmp_ctx *c)
+{
+    IssuePool *P = c->pool;
+    if (!P) return MMP_OK;
+    for (IssueRing *R : P->rings)
+        while (R->head.load(std::memory_order_acquire) != R->tail.load(std::memory_order_acquire)) __builtin_ia32_pause();
+    return P->first_rc.exchange(MMP_OK);
+}
+}  // namespace
+
+int mmp_issue_threads(mmp_ctx *c, int32_t n)
+try {
+    if (!c || n < 0 || n > 64) return fail(c, MMP_EINVAL, "mmp_issue_threads: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
+    if (c->pool) {
+        const int rc = issue_flush(c);
+        c->pool->stop.store(true, std::memory_order_release);
+        for (std::thread &t : c->pool->th) t.join();
+        for (IssueRing *R : c->pool->rings) delete R;
+        delete c->pool;
+        c->pool = nullptr;
+        if (rc != MMP_OK) return rc;
+    }
+    if (n == 0) return MMP_OK;
+    IssuePool *P = new IssuePool();
+    for (int i = 0; i < n; i++) P->rings.push_back(new IssueRing());
+    for (int i = 0; i < n; i++) P->th.emplace_back(issue_helper, c, P, P->rings[i]);
+    c->pool = P;
+    return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_issue_threads");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_issue_threads", e.what());
+}
+
+int mmp_issue_flush(mmp_ctx *c)
+{
+    if (!c) return MMP_EINVAL;
+    const int rc = issue_flush(c);
+    return rc == MMP_OK ? MMP_OK : fail(c, rc, "a launch submitted through the issue threads failed (%d)", rc);
+}
+
 /* ---- decisions ---------------------------------------------------------- */
 
 int mmp_place_batch_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs,
                         void *stream)
 try {
     if (!c || n < 0 || (n > 0 && (!d_reqs || !d_outs))) return fail(c, MMP_EINVAL, "mmp_place_batch_dev: bad argument");
-    std::lock_guard<std::mutex> g(c->mu);  // capture the published snapshot + enqueue; no wait
+    if (IssuePool *P = c->pool) {  // submission threads: append and return
+        if (n == 0) return MMP_OK;
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        IssueRing *R = P->rings[issue_ring_of(P, st)];
+        {
+            std::shared_lock<std::shared_mutex> g(c->mu);
+            if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+            if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
+            note_caller_stream(c, st);
+        }
+        std::lock_guard<std::mutex> gp(R->push_mu);
+        const uint32_t t = R->tail.load(std::memory_order_relaxed);
+        while (t - R->head.load(std::memory_order_acquire) >= IssueRing::kCap) __builtin_ia32_pause();
+        R->items[t % IssueRing::kCap] = IssueItem{d_reqs, d_extra, d_outs, st, now, n};
+        R->tail.store(t + 1, std::memory_order_release);
+        return MMP_OK;
+    }
+    std::shared_lock<std::shared_mutex> g(c->mu);  // capture the published snapshot + enqueue; no wait
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
     note_caller_stream(c, static_cast<hipStream_t>(stream));
@@ -2379,6 +2518,7 @@ int mmp_stream_retire(mmp_ctx *c, void *stream)
 try {
     if (!c) return MMP_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    (void)issue_flush(c);  // launches submitted for this stream have reached it
     {
         std::lock_guard<std::mutex> g(c->cs_mu);
         auto it = std::find(c->caller_streams.begin(), c->caller_streams.end(), st);
@@ -2403,7 +2543,7 @@ try {
         if (reqs[i].n_extra < 0 || reqs[i].extra_off < 0 || (int64_t)reqs[i].extra_off + reqs[i].n_extra > n_extra)
             return fail(c, MMP_EINVAL, "mmp_place_batch: request %d extra range out of bounds", i);
     if (n == 0) {
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard<std::shared_mutex> g(c->mu);
         if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
         if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
         return MMP_OK;
@@ -2418,7 +2558,7 @@ try {
         memcpy(f->reqs, reqs, (size_t)n * sizeof(mmp_place_req));
         if (n_extra) memcpy(f->extra, extra_pool, (size_t)n_extra * sizeof(int32_t));
         {
-            std::lock_guard<std::mutex> g(c->mu);
+            std::shared_lock<std::shared_mutex> g(c->mu);
             if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
             if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
             const int rc = place_launch(c, f->reqs, n, f->extra, now, f->outs, f->stream, f->done, ++f->seq,
@@ -2438,7 +2578,7 @@ try {
     HIP_TRY(c, hipMemcpyAsync(c->s_reqs.p, reqs, (size_t)n * sizeof(mmp_place_req), hipMemcpyHostToDevice, st));
     if (n_extra) HIP_TRY(c, hipMemcpyAsync(c->s_extra.p, extra_pool, (size_t)n_extra * 4, hipMemcpyHostToDevice, st));
     {
-        std::lock_guard<std::mutex> g(c->mu);
+        std::lock_guard<std::shared_mutex> g(c->mu);
         if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
         if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
         KT_BEGIN(c, st);
@@ -2573,7 +2713,7 @@ try {
         }
         if (n_explicit) memcpy(pool + kGatePool, explicit_pool, (size_t)n_explicit * 4);
         {
-            std::lock_guard<std::mutex> g(c->mu);  // capture the published snapshot + enqueue
+            std::shared_lock<std::shared_mutex> g(c->mu);  // capture the published snapshot + enqueue
             if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
             GateArgs A = gate_args(c, n, now, in_use_expiry);
             A.reqs = reinterpret_cast<const mmp_gate_req *>(f->reqs);
@@ -2909,7 +3049,7 @@ try {
     const int32_t E = seg_off[n_caches];
     if (E > 0 && (!last_used || !weight || !key)) return fail(c, MMP_EINVAL, "mmp_caches_load_keyed: null entry arrays");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     mmp_ctx::KeyedStore &K = c->ks[c->ks_cur];
@@ -2961,7 +3101,7 @@ try {
         !n_evicted_slots)
         return fail(c, MMP_EINVAL, "mmp_cache_replay: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     const int32_t NC = c->k_caches;
     if (NC <= 0 && n_ops > 0) return fail(c, MMP_ESTATE, "no keyed caches loaded");
     *n_evicted_slots = 0;
@@ -3049,7 +3189,7 @@ int mmp_cache_read(mmp_ctx *c, int32_t cache, int32_t max_entries, int64_t *last
 try {
     if (!c || !n_out || max_entries < 0) return fail(c, MMP_EINVAL, "mmp_cache_read: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     if (cache < 0 || cache >= c->k_caches) return fail(c, MMP_EINVAL, "mmp_cache_read: cache %d out of range", cache);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -3084,7 +3224,7 @@ try {
     const int32_t E = seg_off[n_caches];
     if (E > 0 && (!last_used || !weight)) return fail(c, MMP_EINVAL, "mmp_caches_load: null entry arrays");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, quiesce_decisions(c));  // small eviction batches read these tables from the latency slots' streams
     HIP_TRY(c, c->c_seg.ensure((size_t)(n_caches + 1) * 4));
@@ -3115,7 +3255,7 @@ try {
         FastSlot *f = slot_acquire(c, fl);
         memcpy(f->reqs, reqs, (size_t)n * sizeof(mmp_evict_req));
         {
-            std::lock_guard<std::mutex> g(c->mu);  // capture the cache tables + enqueue
+            std::shared_lock<std::shared_mutex> g(c->mu);  // capture the cache tables + enqueue
             if (c->n_caches <= 0) return fail(c, MMP_ESTATE, "no caches loaded");
             EvictArgs A;
             A.reqs = reinterpret_cast<const mmp_evict_req *>(f->reqs);

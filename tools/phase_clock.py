@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "modelmesh_amd", "lib", "libmmplace_phase.so")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-function",
-                           os.path.join(ROOT, "tools", "micro", "phase_clock.hip"), "-o", LIB, "-ldl"])
+                           os.path.join(ROOT, "tools", "micro", "phase_clock.hip"), "-o", LIB, "-ldl", "-lpthread"])
     sys.exit(0)
 
 os.environ["MMP_LIB_PATH"] = LIB
