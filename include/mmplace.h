@@ -424,6 +424,16 @@ int mmp_place_batch(mmp_ctx *ctx, const mmp_place_req *reqs, int32_t n, const in
  * therefore stay valid until mmp_stream_retire() or mmp_destroy(). */
 int mmp_place_batch_dev(mmp_ctx *ctx, const void *d_reqs, int32_t n, const void *d_extra_pool,
                         int64_t now_ms, void *d_outs, void *stream);
+/* The resident decision kernel.  A single request through mmp_place_batch(n = 1) normally costs a kernel launch
+ * (6.5 us before the decision's first instruction, tools/micro/doorbell.hip).  mmp_resident(ctx, 1) — or MMP_RESIDENT=1
+ * in the environment of mmp_create — keeps ONE wavefront resident instead: its 64 lanes poll 64 request slots in pinned
+ * host memory, so up to 64 request threads are decided concurrently and none of them launches anything; a request is
+ * a 64-byte store plus a tag, the answer a 16-byte row plus the tag.  It serves requests WITHOUT exclusions of their
+ * own (n_extra = 0; the others, and the rare shapes that need the wave path, take the launch path transparently), holds
+ * the published snapshot (a commit, registry event or cache-table load stops it and the next request starts a new one)
+ * and leaves the GPU by itself after MMP_RESIDENT_IDLE_MS (default 50) without a request.  Results are bit-identical. */
+int mmp_resident(mmp_ctx *ctx, int enable);
+int mmp_resident_stats(mmp_ctx *ctx, uint64_t *launches, uint64_t *served, uint64_t *punted);
 /* Submission threads.  One host thread spends ~3 us in HIP's launch path per kernel — more than a 100k-decision batch
  * takes the GPU when several are in flight.  mmp_issue_threads(ctx, n) starts n helper threads (they spin: use them for
  * bursts) and mmp_place_batch_dev then only validates, appends a descriptor to the ring of the helper that owns the

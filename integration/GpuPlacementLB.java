@@ -50,6 +50,8 @@ final class MmPlace {
     static native int placeBatch(long h, ByteBuffer reqs, int n, ByteBuffer extraPool, int nExtra, long nowMs, ByteBuffer outs);
     static native int serveBatch(long h, ByteBuffer reqs, int n, ByteBuffer inUse, ByteBuffer lastUsed,
                                  ByteBuffer exclPod, ByteBuffer exclTime, int nExcl, long nowMs, ByteBuffer outs);
+    /** keep one wavefront resident that serves placeBatch(n = 1) from 64 pinned request slots: no launch per request */
+    static native int resident(long h, boolean enable);
     // the pod-axis group: several GPUs of one node, RCCL runs inside libmmplace (include/mmplace.h)
     static native int shardUniqueId(ByteBuffer idOut);
     static native int shardGroupInit(long h, ByteBuffer id, int rank, int world);

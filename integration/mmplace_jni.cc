@@ -121,6 +121,12 @@ JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_placeBatch(JNIEnv *
                                  nowMs, buf<mmp_place_out>(env, outs)));
 }
 
+// The resident decision kernel: placeBatch(n = 1) without a kernel launch (include/mmplace.h: mmp_resident).
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_resident(JNIEnv *env, jclass, jlong h, jboolean enable)
+{
+    return check(env, ctx_of(h), mmp_resident(ctx_of(h), enable ? 1 : 0));
+}
+
 // ---- the pod-axis group (several GPUs of one node; RCCL runs inside libmmplace) ----
 JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_shardUniqueId(JNIEnv *env, jclass, jobject idOut)
 {

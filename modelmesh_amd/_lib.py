@@ -136,6 +136,8 @@ SYMBOLS = [
     ("mmp_place_batch", C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int64, _P]),
     ("mmp_place_batch_dev", C.c_int, [_P, _P, C.c_int32, _P, C.c_int64, _P, _P]),
     ("mmp_stream_retire", C.c_int, [_P, _P]),
+    ("mmp_resident", C.c_int, [_P, C.c_int]),
+    ("mmp_resident_stats", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("mmp_issue_threads", C.c_int, [_P, C.c_int32]),
     ("mmp_issue_flush", C.c_int, [_P]),
     ("mmp_serve_batch", C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int64, _P]),

@@ -105,6 +105,13 @@ struct SnapSide {
 // Low-latency slot for small host-pointer batches (the single ensureLoaded / invokeModel request):
 // pinned, device-mapped request / result buffers and a stream of its own, so that one decision never
 // queues behind a 100k-decision batch or a commit (SURVEY.md §8b "Threading").
+// Every pinned buffer the device and the host hand data through WHILE A KERNEL RUNS (completion flags, result rows of
+// the latency slots, the resident kernel's request slots) must be fine-grained: hipHostMallocDefault leaves the choice to
+// the process environment (HIP_HOST_COHERENT), and in a plain C / JVM host it came out coarse-grained — device stores
+// then reach the host at kernel end only (single decisions p50 25 us instead of 12) and a resident wavefront polls a
+// stale copy of its request slots (found with tools/micro/single_calls.cc; under PyTorch's runtime the default happened
+// to be coherent).
+constexpr unsigned int kPinnedFlags = hipHostMallocCoherent | hipHostMallocMapped;
 constexpr int kFastSlots = 4;
 constexpr int kFastN = 4096;       // decisions per fast call
 constexpr int kFastExtra = 16384;  // extra-exclusion pool entries per fast call
@@ -131,6 +138,22 @@ struct mmp_ctx {
     // submission threads of mmp_issue_threads launch concurrently), whoever changes what they capture takes it exclusive
     std::shared_mutex mu;
     struct IssuePool *pool = nullptr;  // submission threads (mmp_issue_threads); null: launches are issued by the caller
+    // the resident decision kernel for single requests (place_kernel.hpp: place_resident_kernel; mmp_resident)
+    struct Resident {
+        bool enabled = false, running = false;
+        uint32_t generation = 0;  // of the kernel launched last (1, 2, ...)
+        hipStream_t stream = nullptr;
+        ResidentSlot *slots = nullptr;  // pinned, device-mapped: host -> device
+        ResidentAnswer *answers = nullptr;  // pinned, device-mapped: device -> host
+        ResidentCtl *ctl = nullptr;     // pinned
+        std::mutex launch_mu;           // taken AFTER the state lock
+        std::mutex slot_mu[kResidentSlots];
+        uint32_t seq[kResidentSlots] = {};
+        std::atomic<uint32_t> rr{0};
+        long long idle_ticks = 5'000'000;  // 50 ms at the 100 MHz wall clock
+        std::atomic<uint64_t> launches{0}, served{0}, punted{0};
+        std::atomic<int> slow{0};  // answers that took longer than 2 ms (self-check in resident_place)
+    } res;
     // caller-owned streams that *_dev calls were enqueued on (leaf lock cs_mu): whoever rewrites state a decision
     // kernel reads waits for them as well as for the library's own streams (quiesce_decisions)
     std::vector<hipStream_t> caller_streams;
@@ -291,8 +314,22 @@ hipError_t copy_sync(mmp_ctx *c, void *dst, const void *src, size_t bytes, hipMe
     return e != hipSuccess ? e : hipStreamSynchronize(c->stream);
 }
 
+// The resident kernel holds the snapshot it was launched with: whoever publishes another one or rewrites what it reads
+// stops it (called with the state lock held, or from mmp_destroy); the next single request launches a new one.
+void resident_stop(mmp_ctx *c)
+{
+    auto &R = c->res;
+    if (!R.slots) return;
+    std::lock_guard<std::mutex> g(R.launch_mu);
+    if (!R.running) return;
+    __atomic_store_n(&R.ctl->stop, R.generation, __ATOMIC_RELEASE);
+    (void)hipStreamSynchronize(R.stream);
+    R.running = false;
+}
+
 hipError_t quiesce_decisions(mmp_ctx *c)
 {
+    resident_stop(c);
     for (FastSlot &f : c->fast) {
         hipError_t e = hipStreamSynchronize(f.stream);
         if (e != hipSuccess) return e;
@@ -460,6 +497,7 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     }
     if (const char *fw = getenv("MMP_FORCE_WAVE")) c->force_wave = fw[0] == '1';
     if (const char *nh = getenv("MMP_NO_HEADS")) c->no_heads = nh[0] == '1';
+    const bool want_resident = getenv("MMP_RESIDENT") && getenv("MMP_RESIDENT")[0] == '1';
     if (const char *rm = getenv("MMP_RANK_MODE")) c->rank_mode = atoi(rm);
     if (const char *lm = getenv("MMP_LONG_MODE")) c->long_mode = atoi(lm);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
@@ -470,10 +508,10 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi is the numerically lowest = highest priority
         hipError_t e1 = hipStreamCreateWithPriority(&f.stream, hipStreamNonBlocking, hi);
-        hipError_t e2 = hipHostMalloc(reinterpret_cast<void **>(&f.reqs), kFastN * sizeof(mmp_place_req), hipHostMallocDefault);
-        hipError_t e3 = hipHostMalloc(reinterpret_cast<void **>(&f.extra), kFastExtra * sizeof(int32_t), hipHostMallocDefault);
-        hipError_t e4 = hipHostMalloc(reinterpret_cast<void **>(&f.outs), kFastN * sizeof(mmp_place_out), hipHostMallocDefault);
-        if (e4 == hipSuccess) e4 = hipHostMalloc(reinterpret_cast<void **>(&f.done), 64, hipHostMallocDefault);
+        hipError_t e2 = hipHostMalloc(reinterpret_cast<void **>(&f.reqs), kFastN * sizeof(mmp_place_req), kPinnedFlags);
+        hipError_t e3 = hipHostMalloc(reinterpret_cast<void **>(&f.extra), kFastExtra * sizeof(int32_t), kPinnedFlags);
+        hipError_t e4 = hipHostMalloc(reinterpret_cast<void **>(&f.outs), kFastN * sizeof(mmp_place_out), kPinnedFlags);
+        if (e4 == hipSuccess) e4 = hipHostMalloc(reinterpret_cast<void **>(&f.done), 64, kPinnedFlags);
         if (e4 == hipSuccess) *f.done = 0;
         if (e4 == hipSuccess) e4 = hipMalloc(reinterpret_cast<void **>(&f.blocks), 64);
         if (e4 == hipSuccess) e4 = hipMemsetAsync(f.blocks, 0, 64, c->stream);
@@ -484,6 +522,11 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     }
     (void)hipStreamSynchronize(c->stream);
     *out = c;
+    if (want_resident && mmp_resident(c, 1) != MMP_OK) {
+        *out = nullptr;
+        mmp_destroy(c);
+        return fail(nullptr, MMP_EHIP, "the resident decision kernel could not be set up");
+    }
     return MMP_OK;
 }
 
@@ -491,12 +534,22 @@ namespace {
 void group_comm_destroy(ncclComm_t comm);  // defined with the RCCL binding below
 }
 extern "C" int mmp_issue_threads(mmp_ctx *c, int32_t n);
+extern "C" int mmp_resident(mmp_ctx *c, int enable);
+namespace {
+void resident_stop(mmp_ctx *c);
+}
 
 void mmp_destroy(mmp_ctx *c)
 {
     if (!c) return;
     (void)mmp_issue_threads(c, 0);  // launches still in the rings are issued, the helpers join
     (void)hipSetDevice(c->cfg.device);
+    resident_stop(c);
+    if (c->res.stream) (void)hipStreamDestroy(c->res.stream);
+    if (c->res.slots) (void)hipHostFree(c->res.slots);
+    if (c->res.ctl) (void)hipHostFree(c->res.ctl);
+    if (c->res.answers) (void)hipHostFree(c->res.answers);
+    c->res.slots = nullptr;
     for (FastSlot &f : c->fast) {
         if (f.stream) {
             (void)hipStreamSynchronize(f.stream);
@@ -1258,6 +1311,7 @@ try {
     }
     // publish: the only part of a commit a decision can ever wait for
     std::lock_guard<std::shared_mutex> g(c->mu);
+    resident_stop(c);  // it answers for the snapshot it was launched with; the next single request starts one on the new
     c->snap_long = next_long;
     c->snap = S;
     c->cur = 1 - c->cur;
@@ -2480,6 +2534,158 @@ int mmp_issue_flush(mmp_ctx *c)
     return rc == MMP_OK ? MMP_OK : fail(c, rc, "a launch submitted through the issue threads failed (%d)", rc);
 }
 
+/* ---- the resident decision kernel: single requests without a launch --------- */
+namespace {
+constexpr int kResidentFallback = 1;  // "take the launch path" (never an MMP_* code)
+
+// make sure a resident kernel is running on the published snapshot (lock order: state lock, then launch_mu)
+int resident_ensure(mmp_ctx *c)
+{
+    auto &R = c->res;
+    std::shared_lock<std::shared_mutex> gs(c->mu);
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    if (c->n_shards > 0) return kResidentFallback;
+    std::lock_guard<std::mutex> g(R.launch_mu);
+    if (R.running && __atomic_load_n(&R.ctl->exited, __ATOMIC_ACQUIRE) != R.generation) return MMP_OK;
+    static const bool dbg = getenv("MMP_RESIDENT_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[resident] ensure: running %d exited %u -> (re)launch #%llu\n", (int)R.running, R.ctl->exited,
+                     (unsigned long long)R.launches.load() + 1);
+    if (R.running) {
+        HIP_TRY(c, hipStreamSynchronize(R.stream));  // it left by itself (idle): returns at once
+        R.running = false;
+        if (dbg) fprintf(stderr, "[resident] previous kernel retired\n");
+    }
+    R.generation++;
+    if (R.generation == 0) R.generation = 1;
+    PlaceArgs A{};
+    A.models = c->models.as<mmp_model_row>();
+    A.rmodels = cur_side(c).rmodels_ok ? cur_side(c).rmodels.as<ResolvedModel>() : nullptr;
+    A.wins = c->no_heads ? nullptr : c->sb[c->cur].heads.as<TypeWin>();
+    A.ent_pod = c->ent_pod.as<int32_t>();
+    A.n = 1;
+    A.n_models = c->n_models;
+    A.n_pods_all = c->snap.P;
+    hipLaunchKernelGGL(place_resident_kernel, dim3(1), dim3(64), (size_t)kPlaceLaneLds, R.stream, c->snap, A, R.slots, R.answers, R.ctl,
+                       R.idle_ticks, R.generation);
+    HIP_TRY(c, hipGetLastError());
+    R.running = true;
+    R.launches.fetch_add(1, std::memory_order_relaxed);
+    if (dbg) fprintf(stderr, "[resident] launched\n");
+    return MMP_OK;
+}
+
+int resident_place(mmp_ctx *c, const mmp_place_req &rq, int64_t now, mmp_place_out *out)
+{
+    auto &R = c->res;
+    // a slot of our own for the duration of the call
+    const uint32_t first = R.rr.fetch_add(1, std::memory_order_relaxed);
+    int si = -1;
+    std::unique_lock<std::mutex> sl;
+    for (int k = 0; k < kResidentSlots && si < 0; k++) {
+        const int cand = (int)((first + k) % kResidentSlots);
+        std::unique_lock<std::mutex> t(R.slot_mu[cand], std::try_to_lock);
+        if (t.owns_lock()) {
+            sl = std::move(t);
+            si = cand;
+        }
+    }
+    if (si < 0) {
+        si = (int)(first % kResidentSlots);
+        sl = std::unique_lock<std::mutex>(R.slot_mu[si]);
+    }
+    ResidentSlot *S = &R.slots[si];
+    ResidentAnswer *Ans = &R.answers[si];
+    uint32_t seq = (R.seq[si] + 1) & 0xfffffu;  // 20 bits ride in the bell next to now_ms
+    if (seq == 0) seq = 1;
+    R.seq[si] = seq;
+    S->req = rq;
+    __atomic_store_n(&S->bell, ((uint64_t)seq << kResidentNowBits) | ((uint64_t)now & ((1ull << kResidentNowBits) - 1ull)),
+                     __ATOMIC_RELEASE);  // the bell: written last
+    if (!R.running || __atomic_load_n(&R.ctl->exited, __ATOMIC_ACQUIRE) == R.generation) {
+        const int rc = resident_ensure(c);
+        if (rc != MMP_OK) return rc;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; spins++) {
+        const uint32_t d = __atomic_load_n(&Ans->done, __ATOMIC_ACQUIRE);
+        if ((d & ~kResidentPunt) == seq) {
+            if (d & kResidentPunt) {
+                R.punted.fetch_add(1, std::memory_order_relaxed);
+                return kResidentFallback;  // a shape the resident wavefront leaves to the launch path
+            }
+            *out = Ans->out;
+            R.served.fetch_add(1, std::memory_order_relaxed);
+            // Self-check.  Under PyTorch's bundled HIP runtime an answer arrives in ~10 us; in a plain C host on the ROCm 7.2
+            // runtime answers were observed to become visible only when the kernel LEFT (tens of ms: tools/micro/
+            // single_calls.cc; the same access pattern in isolation, tools/micro/doorbell.hip D, is prompt there — open).
+            // Three answers slower than 2 ms switch the resident path off for this context: the launch path takes over.
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2) && R.slow.fetch_add(1) + 1 >= 3) {
+                R.enabled = false;
+                (void)fail(c, MMP_OK, "resident decision kernel disabled: answers took longer than 2 ms on this host");
+            }
+            return MMP_OK;
+        }
+        if ((spins & 255) == 255) {
+            if (__atomic_load_n(&R.ctl->exited, __ATOMIC_ACQUIRE) == R.generation) {  // it left (idle, or stopped for a commit) before it saw the bell
+                if (getenv("MMP_RESIDENT_DEBUG"))
+                    fprintf(stderr, "[resident] slot %d waits for seq %u: done %#x bell seq %u, spins %u\n", si, seq, Ans->done,
+                            (unsigned)(S->bell >> kResidentNowBits), spins);
+                const int rc = resident_ensure(c);
+                if (rc != MMP_OK) return rc;
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200))
+                return fail(c, MMP_EHIP, "the resident decision kernel did not answer within 200 ms");
+        }
+        __builtin_ia32_pause();
+    }
+}
+}  // namespace
+
+int mmp_resident(mmp_ctx *c, int enable)
+try {
+    if (!c) return MMP_EINVAL;
+    std::lock_guard<std::mutex> gb(c->batch_mu);
+    auto &R = c->res;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (enable && !R.slots) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIP_TRY(c, hipStreamCreateWithPriority(&R.stream, hipStreamNonBlocking, hi));
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&R.slots), sizeof(ResidentSlot) * kResidentSlots, kPinnedFlags));
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&R.ctl), sizeof(ResidentCtl), kPinnedFlags));
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&R.answers), sizeof(ResidentAnswer) * kResidentSlots, kPinnedFlags));
+        memset(R.answers, 0, sizeof(ResidentAnswer) * kResidentSlots);
+        memset(R.slots, 0, sizeof(ResidentSlot) * kResidentSlots);
+        memset(R.ctl, 0, sizeof(ResidentCtl));
+        int khz = 100000;
+        (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->cfg.device);
+        long long ms = 50;
+        if (const char *e = getenv("MMP_RESIDENT_IDLE_MS")) ms = std::max(1, atoi(e));
+        R.idle_ticks = (long long)khz * ms;
+    }
+    if (!enable) {
+        std::lock_guard<std::shared_mutex> g(c->mu);
+        R.enabled = false;
+        resident_stop(c);
+        return MMP_OK;
+    }
+    R.enabled = true;
+    return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_resident");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_resident", e.what());
+}
+
+int mmp_resident_stats(mmp_ctx *c, uint64_t *launches, uint64_t *served, uint64_t *punted)
+{
+    if (!c) return MMP_EINVAL;
+    if (launches) *launches = c->res.launches.load();
+    if (served) *served = c->res.served.load();
+    if (punted) *punted = c->res.punted.load();
+    return MMP_OK;
+}
+
 /* ---- decisions ---------------------------------------------------------- */
 
 int mmp_place_batch_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs,
@@ -2550,6 +2756,11 @@ try {
     }
     HIP_TRY(c, hipSetDevice(c->cfg.device));
 
+    if (n == 1 && reqs[0].n_extra == 0 && c->res.enabled && now >= 0 && (now >> kResidentNowBits) == 0) {
+        // a single request without exclusions of its own: the resident kernel, no launch at all
+        const int rc = resident_place(c, reqs[0], now, outs);
+        if (rc != kResidentFallback) return rc;
+    }
     if (n <= kFastN && n_extra <= kFastExtra) {
         // latency path: the kernel reads the requests from, and writes the results to, pinned host
         // memory over the fabric — no staging copies, no contention with batches on c->stream

@@ -1679,4 +1679,143 @@ __global__ __launch_bounds__(kPlaceBlock) void place_single_kernel(Snap S, Place
     place_block<false>(S, A, wpad, smem);
 }
 
+
+// ---- the resident decision kernel (single requests) ----------------------------------------------------------
+// mmp_place_batch(n = 1) as a kernel launch costs a launch: 6.5 us before the first instruction of the decision
+// (tools/micro/doorbell.hip: launch + completion flag round trip), and one launch per request per thread.  This
+// kernel stays resident instead — ONE wavefront, lane l serving ring slot l: the host writes a request into pinned
+// memory and then its tag; the lane that polls the slot sees the tag, decides (the same lane_decide_win /
+// lane_decide_r as the batch kernel, windows staged in LDS once), writes the result row and then the tag back.  64
+// request threads are served concurrently, none of them launches anything.
+//   * The slot is read in ONE sweep (request + tag, 80 bytes) and the decision starts on it at once; a second read of the
+//     request, issued after the sweep that showed the new tag has returned, is compared before the result is published:
+//     PCIe may serve the four pieces of a sweep in any order, so a sweep can pair the new tag with stale request bytes —
+//     the second read cannot (the host wrote the tag last).  Equal: publish.  Different: decide again on the second read.
+//   * The kernel holds ONE snapshot (its launch arguments).  Whoever publishes another or rewrites what it reads raises
+//     `stop` and waits for its stream (quiesce_decisions); the next request launches a new one.  It also leaves by
+//     itself after idle_ticks without a request (so that a host that died leaves nothing behind) and reports `exited`.
+//   * Requests it cannot decide alone (more than kLateExtra + 6 exclusions never come here; the wave path: case (b), the
+//     replay list, the replica-set retry ...) are answered with status kResidentPunt and the host takes the launch path.
+constexpr int kResidentSlots = 64;
+constexpr uint32_t kResidentPunt = 0x80000000u;  // or-ed into the tag written back: "decide this one with a launch"
+constexpr int kResidentNowBits = 44;             // now_ms travels in the low bits of the bell (2^44 ms = 557 years)
+// 16 bytes of pinned host memory in one system-scope load (the builtin atomics stop at 8)
+__device__ __forceinline__ void load16_sys(const void *p, uint64_t &lo, uint64_t &hi)
+{
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    lo = ((uint64_t)v.y << 32) | v.x;
+    hi = ((uint64_t)v.w << 32) | v.z;
+}
+struct __attribute__((aligned(16))) ResidentSlot {  // pinned host memory, device-mapped
+    mmp_place_req req;   // 64 B, written first
+    uint64_t bell;       // written last (release): sequence number << 44 | now_ms & (2^44 - 1) — ONE word, so that the lane
+                         // gets the request's clock with the tag; it answers bells whose sequence it has not answered yet
+    uint64_t pad[7];     // 128 B per slot; the device never writes here
+};
+static_assert(sizeof(ResidentSlot) == 128, "ResidentSlot is 128 bytes");
+// The answers live in lines of their own: a device store into the line the lane polls left a copy of that line in the
+// GPU's cache under the ROCm 7.2 runtime, and the lane then polled that copy — it saw the first request of its slot and
+// no later one until the kernel idled out (found with tools/micro/single_calls.cc; PyTorch's bundled runtime maps pinned
+// memory uncached and hid it).
+struct __attribute__((aligned(64))) ResidentAnswer {  // pinned host memory, device-mapped; the host never writes here
+    mmp_place_out out;   // written by the device ...
+    uint32_t done;       // ... then the sequence number (| kResidentPunt) it answers
+    uint32_t pad[11];
+};
+static_assert(sizeof(ResidentAnswer) == 64, "ResidentAnswer is 64 bytes");
+struct ResidentCtl {  // pinned host memory
+    uint32_t stop;    // host -> device: the generation that has to leave
+    uint32_t exited;  // device -> host: the generation that has left (a late store of an earlier one cannot pass for the current)
+    uint32_t pad[14];
+};
+
+__global__ __launch_bounds__(64) void place_resident_kernel(Snap S, PlaceArgs A, ResidentSlot *slots, ResidentAnswer *answers,
+                                                             ResidentCtl *ctl, long long idle_ticks, uint32_t generation)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TypeWin *s_wins = reinterpret_cast<TypeWin *>(smem);
+    uint64_t *s_scr = reinterpret_cast<uint64_t *>(smem + kWinLdsBytes);  // column stride: kPlaceBlock lanes (the first 64 used)
+    const int lane = lane_id();
+    const bool use_wins = A.wins != nullptr;
+    if (use_wins) {
+        const int chunks = ((S.T < kWinLds ? S.T : kWinLds) * (int)sizeof(TypeWin) + 1023) >> 10;
+        const char *src = reinterpret_cast<const char *>(A.wins);
+        char *dst = reinterpret_cast<char *>(s_wins);
+        for (int c = 0; c < chunks; c++)
+            __builtin_amdgcn_global_load_lds(src + (size_t)c * 1024 + lane * 16,
+                                             (__attribute__((address_space(3))) void *)(dst + c * 1024), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    wave_sync();
+    ResidentSlot *slot = &slots[lane];
+    ResidentAnswer *ans = &answers[lane];
+    uint32_t seen = __hip_atomic_load(&ans->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) & ~kResidentPunt;
+    long long last = wall_clock64();
+    A.n = 1;
+    const uint64_t *q = reinterpret_cast<const uint64_t *>(&slot->req);
+    for (;;) {
+        // system-scope loads: they go to the host's memory every time (a plain or non-temporal load of pinned memory may be
+        // served from the device's caches: the wavefront then polls a stale copy forever — observed; so may a 16-byte
+        // `global_load_dwordx4 sc0 sc1` under the ROCm 7.2 runtime, where it polled a stale bell for 50 ms at a time, while the
+        // 8-byte atomic loads the compiler emits do not).  One sweep = the request and the bell, nine 8-byte reads in flight.
+        uint64_t w[8], bell;
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] = __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        bell = __hip_atomic_load(&slot->bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t tag = (uint32_t)(bell >> kResidentNowBits);
+        const bool fresh = tag != seen;
+        if (__ballot(fresh)) {
+            if (fresh) {
+                mmp_place_req rq;
+                __builtin_memcpy(&rq, w, sizeof rq);
+                // the confirming read: issued now, i.e. after the sweep that showed the new bell has returned; it is consumed
+                // only when the decision is ready, so the two overlap
+                uint64_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                mmp_place_out o;
+                int code = kLaneWave;
+                PlaceArgs Al = A;  // this lane's request carries its own now_ms (the bell word: read atomically with the tag)
+                Al.now = (int64_t)(bell & ((1ull << kResidentNowBits) - 1ull));
+                for (int pass = 0; pass < 2; pass++) {
+                    if (rq.n_extra == 0) {  // (exclusions of the request itself ride the launch path: the pool is not mapped here)
+                        ResolvedReq r = resolve_req<false, false>(S, Al, rq);
+                        code = kLaneHeadMiss;
+                        if (use_wins) code = lane_decide_win(S, Al, r, s_wins, s_scr + lane, o);
+                        if (code == kLaneHeadMiss) code = lane_decide_r<false>(S, Al, r, o);
+                    }
+                    bool same = true;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) same = same && v[k] == w[k];
+                    if (same) break;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) w[k] = v[k];  // the sweep was torn: the confirming read is the request
+                    __builtin_memcpy(&rq, w, sizeof rq);
+                }
+                uint32_t answer = tag;
+                if (code == kLaneDone) {
+                    uint64_t ov[2];
+                    __builtin_memcpy(ov, &o, sizeof ov);
+                    uint64_t *op = reinterpret_cast<uint64_t *>(&ans->out);
+                    __hip_atomic_store(op, ov[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(op + 1, ov[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else
+                    answer |= kResidentPunt;
+                __hip_atomic_store(&ans->done, answer, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                seen = tag;
+            }
+            last = wall_clock64();
+        } else {
+            // nobody rang: look at the stop word now and then, leave when idle for long
+            const uint32_t stop = __hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (stop == generation || wall_clock64() - last > idle_ticks) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    // a request that arrived between the last sweep and here stays unanswered: the host sees `exited` and relaunches
+    if (lane == 0) __hip_atomic_store(&ctl->exited, generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace mmp

@@ -13,6 +13,7 @@
 #include <csignal>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -45,6 +46,40 @@ __global__ void echo_once(uint32_t b, volatile uint32_t *answer, const int32_t *
     int x = tab[b & 1023];
     x = tab[x & 1023];
     __hip_atomic_store(const_cast<uint32_t *>(answer), b + (uint32_t)(x & 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// D: the resident kernel's pattern — 64 lanes, each polling its own 128-byte slot (8 x 8 B of request + an 8 B bell)
+// with system-scope loads, answering into a line of its own
+struct Slot { uint64_t req[8]; uint64_t bell; uint64_t pad[7]; };
+struct Ans { uint64_t out[2]; uint32_t done; uint32_t pad[11]; };
+__global__ void echo_slots(Slot *slots, Ans *ans, volatile uint32_t *stop, long long idle_ticks)
+{
+    Slot *s = &slots[threadIdx.x];
+    Ans *a = &ans[threadIdx.x];
+    uint32_t seen = 0;
+    long long last = wall_clock64();
+    for (;;) {
+        uint64_t w[8];
+        for (int k = 0; k < 8; k++) w[k] = __hip_atomic_load(&s->req[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint64_t bell = __hip_atomic_load(&s->bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t tag = (uint32_t)(bell >> 44);
+        const bool fresh = tag != seen;
+        if (__ballot(fresh)) {
+            if (fresh) {
+                uint64_t x = 0;
+                for (int k = 0; k < 8; k++) x += w[k];
+                __hip_atomic_store(&a->out[0], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&a->out[1], bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&a->done, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                seen = tag;
+            }
+            last = wall_clock64();
+        } else {
+            if (__hip_atomic_load(const_cast<uint32_t *>(stop), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;
+            if (wall_clock64() - last > idle_ticks) return;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
 }
 
 static sigjmp_buf jb;
@@ -118,6 +153,34 @@ int main()
         }
         CK(hipStreamSynchronize(st));
         report("C one launch per request + completion flag in pinned memory", us);
+    }
+    {
+        Slot *slots;
+        Ans *ans;
+        CK(hipHostMalloc((void **)&slots, sizeof(Slot) * 64, hipHostMallocDefault));
+        CK(hipHostMalloc((void **)&ans, sizeof(Ans) * 64, hipHostMallocDefault));
+        memset(slots, 0, sizeof(Slot) * 64);
+        memset(ans, 0, sizeof(Ans) * 64);
+        *stop = 0;
+        hipLaunchKernelGGL(echo_slots, dim3(1), dim3(64), 0, st, slots, ans, stop, idle);
+        std::vector<double> us;
+        uint32_t seq[64] = {0};
+        bool ok = true;
+        for (uint32_t i = 1; i <= 20000u && ok; i++) {
+            const int si = i % 64;
+            const uint32_t q = ++seq[si];
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int k = 0; k < 8; k++) slots[si].req[k] = i + k;
+            __atomic_store_n(&slots[si].bell, ((uint64_t)q << 44) | 12345, __ATOMIC_RELEASE);
+            while (__atomic_load_n(&ans[si].done, __ATOMIC_ACQUIRE) != q) {
+                __builtin_ia32_pause();
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) { printf("D: request %u (slot %d) not answered in 20 ms\n", i, si); ok = false; break; }
+            }
+            us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+        }
+        __atomic_store_n(stop, 1u, __ATOMIC_RELEASE);
+        CK(hipStreamSynchronize(st));
+        report("D 64 lanes polling 64 slots (8 x 8 B + bell), answers in own lines", us);
     }
     {   // idle exit: nobody rings; the kernel must leave by itself
         *stop = 0;

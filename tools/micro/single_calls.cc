@@ -1,0 +1,116 @@
+// Request threads issuing SINGLE load-target decisions through the C ABI (mmp_place_batch, n = 1) — what the Java mesh's
+// request threads do (mmesh-req-thread-%d, ModelMeshApi.java:202) — without an interpreter lock in the way: per-call
+// latency of one thread and the aggregate rate of T threads, launch path (latency slots) against the resident kernel.
+// A 10k-instance / 100k-model table built here (counts ~ Poisson-ish, no type constraints).
+//   g++ -O2 -std=c++17 -Iinclude tools/micro/single_calls.cc -Lmodelmesh_amd/lib -lmmplace -Wl,-rpath,$PWD/modelmesh_amd/lib -lpthread -o /tmp/single_calls
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "mmplace.h"
+
+static const int64_t NOW = 1760000000000LL;
+
+static mmp_ctx *make_ctx(std::vector<mmp_pod_row> &pods, int M)
+{
+    mmp_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.min_space_units = mmp_min_space_units(6400, 8, 8388608, 1);
+    cfg.min_churn_age_ms = 600000;
+    mmp_ctx *c = nullptr;
+    if (mmp_create(&cfg, &c) != MMP_OK) { fprintf(stderr, "mmp_create: %s\n", mmp_last_error(nullptr)); exit(77); }
+    std::vector<mmp_model_row> models(M);
+    memset(models.data(), 0, sizeof(mmp_model_row) * M);
+    std::vector<int32_t> ep;
+    std::vector<int64_t> et;
+    std::mt19937 rng(7);
+    for (int m = 0; m < M; m++) {
+        models[m].ent_off = (int32_t)ep.size();
+        models[m].n_loaded = (int32_t)(rng() % 3);
+        models[m].last_used = NOW - 1000 - (int64_t)(rng() % 3600000);
+        for (int k = 0; k < models[m].n_loaded; k++) { ep.push_back((int32_t)((m * 7919 + k * 104729) % pods.size())); et.push_back(NOW - 60000); }
+    }
+    if (mmp_pods_load(c, pods.data(), (int32_t)pods.size()) || mmp_models_load(c, models.data(), M, ep.data(), et.data(), (int32_t)ep.size()) ||
+        mmp_snapshot_commit(c)) { fprintf(stderr, "load: %s\n", mmp_last_error(c)); exit(1); }
+    return c;
+}
+
+int main()
+{
+    setvbuf(stdout, nullptr, _IOLBF, 0);
+    const int P = 10000, M = 100000;
+    std::vector<mmp_pod_row> pods(P);
+    memset(pods.data(), 0, sizeof(mmp_pod_row) * P);
+    std::mt19937 rng(3);
+    for (int p = 0; p < P; p++) {
+        pods[p].capacity = 8388608;
+        pods[p].used = (int64_t)(8388608.0 * (0.4 + 0.5 * (rng() % 1000) / 1000.0));
+        pods[p].count = 5 + (int32_t)(rng() % 30);
+        pods[p].lru_time = NOW - 3600000 - (int64_t)(rng() % 7200000);
+        pods[p].rpm = (int32_t)(rng() % 2000);
+        pods[p].loading_threads = 8;
+        pods[p].version = 1;
+        pods[p].id_order = (uint32_t)p;
+        pods[p].flags = MMP_POD_LIVE;
+    }
+    for (int mode = 0; mode < 2; mode++) {
+        setenv("MMP_RESIDENT", mode ? "1" : "0", 1);
+        fprintf(stderr, "[mode %d] creating context\n", mode);
+        mmp_ctx *c = make_ctx(pods, M);
+        fprintf(stderr, "[mode %d] context ready\n", mode);
+        auto one = [&](int i, mmp_place_out *out) {
+            mmp_place_req rq;
+            memset(&rq, 0, sizeof rq);
+            rq.model = i % M;
+            rq.self_pod = i % P;
+            rq.pick = (uint32_t)i * 2654435761u;
+            rq.last_used = NOW - 5000;
+            rq.fresh_lru = pods[rq.self_pod].lru_time;
+            rq.fresh_capacity = pods[rq.self_pod].capacity;
+            rq.fresh_used = pods[rq.self_pod].used;
+            rq.fresh_count = pods[rq.self_pod].count;
+            return mmp_place_batch(c, &rq, 1, nullptr, 0, NOW, out);
+        };
+        mmp_place_out ref[64], out;
+        for (int i = 0; i < 64; i++) {
+            const int rc = one(i, &ref[i]);
+            if (i < 2 || rc) fprintf(stderr, "[mode %d] call %d rc %d (%s) chosen %d\n", mode, i, rc, rc ? mmp_last_error(c) : "", ref[i].chosen);
+            if (rc) return 3;
+        }
+        std::vector<double> us;
+        for (int i = 0; i < 20000; i++) {
+            if (getenv("MMP_TRACE") && (i < 130 || i % 1000 == 0)) fprintf(stderr, "[mode %d] timing call %d\n", mode, i);
+            const auto t0 = std::chrono::steady_clock::now();
+            if (one(i, &out)) { fprintf(stderr, "place: %s\n", mmp_last_error(c)); return 1; }
+            us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+            if (i < 64 && memcmp(&out, &ref[i], sizeof out)) { fprintf(stderr, "result differs\n"); return 2; }
+        }
+        std::sort(us.begin(), us.end());
+        printf("%-8s  1 thread : p50 %6.2f us  p99 %6.2f us  min %6.2f us\n", mode ? "resident" : "launch", us[us.size() / 2],
+               us[us.size() * 99 / 100], us[0]);
+        for (int T : {2, 4, 8, 16, 32, 64}) {
+            const int each = 5000;
+            std::atomic<int> bad{0};
+            std::vector<std::thread> th;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int t = 0; t < T; t++)
+                th.emplace_back([&, t] {
+                    mmp_place_out o;
+                    for (int i = 0; i < each; i++)
+                        if (one(t * each + i, &o)) bad++;
+                });
+            for (auto &x : th) x.join();
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            printf("%-8s %2d threads: %8.1f k decisions/s, %6.2f us per call per thread%s\n", mode ? "resident" : "launch", T,
+                   T * (double)each / dt / 1e3, dt / each * 1e6, bad ? "  (ERRORS)" : "");
+        }
+        mmp_destroy(c);
+    }
+    return 0;
+}
