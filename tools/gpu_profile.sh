@@ -32,5 +32,6 @@ done
 timeout 600 python bench.py --workload C4 --steps 200 --warmup 10 --no-secondary > $OUT/bench_C4_n1.json.log 2> $OUT/bench_C4.err; echo "bench C4 exit $?"; python tools/benchline.py C4 < $OUT/bench_C4_n1.json.log
 timeout 200 python tools/phase_clock.py 30 2>&1 | grep -v amdgpu.ids > $OUT/phase_clock_place_batch_C3.txt; tail -12 $OUT/phase_clock_place_batch_C3.txt
 timeout 600 python tools/place_sweep.py C3 2> /dev/null > $OUT/place_sweep_C3.csv; cat $OUT/place_sweep_C3.csv
-KT_GRAPH=1 timeout 400 python tools/kernel_time.py C3 2>&1 | grep -v amdgpu.ids > $OUT/kernel_time_C3.txt
-timeout 300 python tools/sync_cost.py 2>&1 | grep -v amdgpu.ids > $OUT/sync_cost.txt
+KT_GRAPH=${KT_GRAPH:-0} timeout 400 python tools/kernel_time.py C3 2>&1 | grep -v amdgpu.ids > $OUT/kernel_time_C3.txt
+[ "${WITH_SYNC_COST:-0}" = 1 ] && timeout 300 python tools/sync_cost.py 2>&1 | grep -v amdgpu.ids > $OUT/sync_cost.txt
+timeout 120 python tools/resident_latency.py 2>&1 | grep -v amdgpu.ids > $OUT/resident_latency.txt; grep '1 thread' $OUT/resident_latency.txt

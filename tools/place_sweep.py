@@ -51,7 +51,7 @@ for n in (25_000, 50_000, 100_000, 200_000, 400_000, 800_000, 1_600_000):
         ex = np.concatenate(ex_parts) if off else np.zeros(1, np.int32)
         bufs.append((torch.from_numpy(rq.view(np.uint8).reshape(-1)).to(dev), torch.from_numpy(np.ascontiguousarray(ex)).to(dev),
                      torch.zeros(n * 16, dtype=torch.uint8, device=dev)))
-    for ns in (1, 2, 4, 8, 16):
+    for ns in tuple(int(x) for x in os.environ.get('SWEEP_STREAMS', '1,2,4,8').split(',')):
         streams = [torch.cuda.Stream(dev) for _ in range(ns)]
         period = n_b * ns
         args = []
