@@ -412,6 +412,35 @@ def test_general_wave_path_alone(seed, monkeypatch):
     _check_fleet(fleet, reqs, extra)
 
 
+def test_more_type_rows_than_windows_are_staged():
+    """The kernel stages the head windows of the first 12 type rows in LDS; requests of type rows beyond take
+    lane_decide_r directly.  A table with 20 type rows — unconstrained, required-label, preferred-label and a few sparse
+    ones spread over both halves of the row range — must answer like the oracle for every row, in one launch that mixes
+    both kinds of lanes in every wavefront."""
+    from modelmesh_amd.solver import bitmap_from_bool
+    fleet = wl.make_fleet("C2")
+    P, T = fleet.n_pods, 20
+    rng = np.random.default_rng(20)
+    group = rng.integers(0, 5, P)
+    al, pf = np.ones((T, P), bool), np.zeros((T, P), bool)
+    has_al, has_pf = np.zeros(T, np.uint8), np.zeros(T, np.uint8)
+    for t in range(1, T):
+        kind = t % 4
+        if kind == 1:
+            al[t], has_al[t] = group == (t % 5), 1
+        elif kind == 2:
+            pf[t], has_pf[t] = group == (t % 5), 1
+        elif kind == 3:
+            al[t], has_al[t] = rng.random(P) < 0.02, 1  # a type few instances may host
+            pf[t], has_pf[t] = al[t] & (rng.random(P) < 0.5), 1
+    fleet.n_types = T
+    fleet.allowed, fleet.prefer = bitmap_from_bool(al), bitmap_from_bool(pf)
+    fleet.has_allowed, fleet.has_prefer = has_al, has_pf
+    fleet.models["type"] = rng.integers(0, T, fleet.n_models)
+    reqs, extra = wl.make_requests(fleet, 44)
+    _check_fleet(fleet, reqs, extra)
+
+
 @pytest.mark.parametrize("force_wave", [False, True])
 def test_100k_instances(force_wave, monkeypatch):
     """Round 1 refused tables whose wave-path tile exceeded 60 KB of LDS (~61k instances, 20 % above C4); gfx950 gives
