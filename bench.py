@@ -798,6 +798,10 @@ def main():
         emit(f"an additional leg did not finish within {args.leg_timeout:.0f} s; the line carries the legs completed so far")
         os._exit(0)
 
+    # several ranks: a collective that hangs on one rank hangs all of them; keep the wait short so that the line (with the
+    # headline and the legs finished so far) still appears well inside any driver-side limit
+    if world > 1:
+        args.leg_timeout = min(args.leg_timeout, 240.0)
     dog = threading.Timer(args.leg_timeout, on_timeout)
     dog.daemon = True
     dog.start()
@@ -814,7 +818,13 @@ def main():
             if rank == 0:
                 line["pod_axis"] = list(pod_axis)
         pod_axis_lib = []
+        one_device = os.environ.get("MMP_BENCH_ONE_DEVICE") == "1" and world > 1
         for wname in legs:
+            if one_device:  # RCCL refuses two ranks on one device: the group leg needs one GPU per rank
+                pod_axis_lib.append({"workload": wname, "skipped": "several ranks share one device (MMP_BENCH_ONE_DEVICE=1)"})
+                if rank == 0:
+                    line["pod_axis_in_library_rccl"] = list(pod_axis_lib)
+                continue
             try:
                 pod_axis_lib.append(pod_axis_lib_leg(wname, rank, world, dev, min(max(args.steps // 10, 5), 40),
                                                      min(max(args.warmup // 10, 2), 5), fence))
