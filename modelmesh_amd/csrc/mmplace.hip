@@ -153,6 +153,7 @@ struct mmp_ctx {
         long long idle_ticks = 5'000'000;  // 50 ms at the 100 MHz wall clock
         std::atomic<uint64_t> launches{0}, served{0}, punted{0};
         std::atomic<int> slow{0};  // answers that took longer than 2 ms (self-check in resident_place)
+        std::atomic<int> punt_streak{0}, skip{0};  // hand-backs in a row; single requests still to be sent to the launch path directly
     } res;
     // caller-owned streams that *_dev calls were enqueued on (leaf lock cs_mu): whoever rewrites state a decision
     // kernel reads waits for them as well as for the library's own streams (quiesce_decisions)
@@ -2577,6 +2578,11 @@ int resident_ensure(mmp_ctx *c)
 int resident_place(mmp_ctx *c, const mmp_place_req &rq, int64_t now, mmp_place_out *out)
 {
     auto &R = c->res;
+    if (R.skip.load(std::memory_order_relaxed) > 0) {
+        R.skip.fetch_sub(1, std::memory_order_relaxed);
+        return kResidentFallback;
+    }
+    const auto t_entry = std::chrono::steady_clock::now();
     // a slot of our own for the duration of the call
     const uint32_t first = R.rr.fetch_add(1, std::memory_order_relaxed);
     int si = -1;
@@ -2611,15 +2617,21 @@ int resident_place(mmp_ctx *c, const mmp_place_req &rq, int64_t now, mmp_place_o
         if ((d & ~kResidentPunt) == seq) {
             if (d & kResidentPunt) {
                 R.punted.fetch_add(1, std::memory_order_relaxed);
+                // a table on which most decisions need the wave path (every instance a candidate ...) makes the resident
+                // attempt pure overhead: after 8 hand-backs in a row the next 4096 single requests go to the launch path directly
+                if (R.punt_streak.fetch_add(1, std::memory_order_relaxed) + 1 >= 8) {
+                    R.punt_streak.store(0, std::memory_order_relaxed);
+                    R.skip.store(4096, std::memory_order_relaxed);
+                }
                 return kResidentFallback;  // a shape the resident wavefront leaves to the launch path
             }
+            R.punt_streak.store(0, std::memory_order_relaxed);
             *out = Ans->out;
             R.served.fetch_add(1, std::memory_order_relaxed);
-            // Self-check.  Under PyTorch's bundled HIP runtime an answer arrives in ~10 us; in a plain C host on the ROCm 7.2
-            // runtime answers were observed to become visible only when the kernel LEFT (tens of ms: tools/micro/
-            // single_calls.cc; the same access pattern in isolation, tools/micro/doorbell.hip D, is prompt there — open).
-            // Three answers slower than 2 ms switch the resident path off for this context: the launch path takes over.
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2) && R.slow.fetch_add(1) + 1 >= 3) {
+            // Self-check: an answer takes ~10 us.  Three calls slower than 2 ms switch the resident path off for this context
+            // and the launch path takes over (what that looked like before the resident stream got a priority level of its
+            // own: 50 ms per call, the time the resident kernel needs to idle out of the way of a launch queued behind it).
+            if (std::chrono::steady_clock::now() - t_entry > std::chrono::milliseconds(2) && R.slow.fetch_add(1) + 1 >= 3) {
                 R.enabled = false;
                 (void)fail(c, MMP_OK, "resident decision kernel disabled: answers took longer than 2 ms on this host");
             }
@@ -2648,9 +2660,13 @@ try {
     auto &R = c->res;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     if (enable && !R.slots) {
+        // A stream of the LOWEST priority: HIP multiplexes the streams of one priority level onto a small pool of hardware
+        // queues, and a kernel that never ends blocks whatever else lands on its queue.  On the latency slots' level (highest)
+        // it held their launches back until it idled out — 50 ms per request that it had handed back to the launch path
+        // (tools/micro/single_calls.cc, SINGLE_CALLS_FLAT=1).  Nothing else in the library uses the lowest level.
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        HIP_TRY(c, hipStreamCreateWithPriority(&R.stream, hipStreamNonBlocking, hi));
+        HIP_TRY(c, hipStreamCreateWithPriority(&R.stream, hipStreamNonBlocking, lo));
         HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&R.slots), sizeof(ResidentSlot) * kResidentSlots, kPinnedFlags));
         HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&R.ctl), sizeof(ResidentCtl), kPinnedFlags));
         HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&R.answers), sizeof(ResidentAnswer) * kResidentSlots, kPinnedFlags));
@@ -2764,10 +2780,13 @@ try {
     if (n <= kFastN && n_extra <= kFastExtra) {
         // latency path: the kernel reads the requests from, and writes the results to, pinned host
         // memory over the fabric — no staging copies, no contention with batches on c->stream
+        static const bool trace = getenv("MMP_TRACE_SLOT") != nullptr;  // where a single decision's wall time goes (stderr)
+        const auto t0 = std::chrono::steady_clock::now();
         std::unique_lock<std::mutex> fl;
         FastSlot *f = slot_acquire(c, fl);
         memcpy(f->reqs, reqs, (size_t)n * sizeof(mmp_place_req));
         if (n_extra) memcpy(f->extra, extra_pool, (size_t)n_extra * sizeof(int32_t));
+        const auto t1 = std::chrono::steady_clock::now();
         {
             std::shared_lock<std::shared_mutex> g(c->mu);
             if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
@@ -2776,8 +2795,23 @@ try {
                                         (n == 1 && reqs[0].n_extra == 0) ? &reqs[0] : nullptr, f->blocks);
             if (rc != MMP_OK) return rc;
         }
+        const auto t2 = std::chrono::steady_clock::now();
         HIP_TRY(c, slot_wait(f));
         memcpy(outs, f->outs, (size_t)n * sizeof(mmp_place_out));
+        if (trace) {
+            static thread_local double acc[3] = {0, 0, 0};
+            static thread_local int cnt = 0;
+            const auto t3 = std::chrono::steady_clock::now();
+            acc[0] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+            acc[1] += std::chrono::duration<double, std::micro>(t2 - t1).count();
+            acc[2] += std::chrono::duration<double, std::micro>(t3 - t2).count();
+            if (++cnt == 2000) {
+                fprintf(stderr, "[slot path] per call: slot + copy %.2f us, lock + launch %.2f us, wait for the flag %.2f us\n", acc[0] / cnt,
+                        acc[1] / cnt, acc[2] / cnt);
+                acc[0] = acc[1] = acc[2] = 0;
+                cnt = 0;
+            }
+        }
         return MMP_OK;
     }
 

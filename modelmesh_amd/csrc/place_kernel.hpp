@@ -1715,10 +1715,7 @@ struct __attribute__((aligned(16))) ResidentSlot {  // pinned host memory, devic
     uint64_t pad[7];     // 128 B per slot; the device never writes here
 };
 static_assert(sizeof(ResidentSlot) == 128, "ResidentSlot is 128 bytes");
-// The answers live in lines of their own: a device store into the line the lane polls left a copy of that line in the
-// GPU's cache under the ROCm 7.2 runtime, and the lane then polled that copy — it saw the first request of its slot and
-// no later one until the kernel idled out (found with tools/micro/single_calls.cc; PyTorch's bundled runtime maps pinned
-// memory uncached and hid it).
+// The answers live in lines of their own (the device never writes into a line a lane polls).
 struct __attribute__((aligned(64))) ResidentAnswer {  // pinned host memory, device-mapped; the host never writes here
     mmp_place_out out;   // written by the device ...
     uint32_t done;       // ... then the sequence number (| kResidentPunt) it answers
@@ -1757,9 +1754,8 @@ __global__ __launch_bounds__(64) void place_resident_kernel(Snap S, PlaceArgs A,
     const uint64_t *q = reinterpret_cast<const uint64_t *>(&slot->req);
     for (;;) {
         // system-scope loads: they go to the host's memory every time (a plain or non-temporal load of pinned memory may be
-        // served from the device's caches: the wavefront then polls a stale copy forever — observed; so may a 16-byte
-        // `global_load_dwordx4 sc0 sc1` under the ROCm 7.2 runtime, where it polled a stale bell for 50 ms at a time, while the
-        // 8-byte atomic loads the compiler emits do not).  One sweep = the request and the bell, nine 8-byte reads in flight.
+        // served from the device's caches: the wavefront then polls a stale copy forever — observed).  One sweep = the request
+        // and the bell, nine 8-byte reads in flight.
         uint64_t w[8], bell;
 #pragma unroll
         for (int k = 0; k < 8; k++) w[k] = __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

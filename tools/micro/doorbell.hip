@@ -82,6 +82,19 @@ __global__ void echo_slots(Slot *slots, Ans *ans, volatile uint32_t *stop, long 
     }
 }
 
+// E: what makes a launch-per-request round trip slow?  The same echo with a ~400-byte by-value argument block (the size of
+// place_single_kernel's Snap + PlaceArgs + request) and with 38 KB of dynamic LDS.
+struct BigArgs { uint64_t w[50]; };
+__global__ void echo_once_big(BigArgs a, uint32_t b, volatile uint32_t *answer, const int32_t *tab)
+{
+    extern __shared__ unsigned char dyn[];
+    if (threadIdx.x != 0) return;
+    int x = tab[(b + (uint32_t)a.w[7]) & 1023];
+    x = tab[x & 1023];
+    if (a.w[3] == 12345) dyn[0] = 1;
+    __hip_atomic_store(const_cast<uint32_t *>(answer), b + (uint32_t)(x & 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 static sigjmp_buf jb;
 static void on_segv(int) { siglongjmp(jb, 1); }
 
@@ -153,6 +166,29 @@ int main()
         }
         CK(hipStreamSynchronize(st));
         report("C one launch per request + completion flag in pinned memory", us);
+    }
+    for (int variant = 0; variant < 4; variant++) {
+        // 0: big args, 64 threads, no LDS   1: big args + 38 KB dynamic LDS   2: big args, 256 threads + LDS   3: as 2 on a high-priority stream
+        hipStream_t sx = st;
+        if (variant == 3) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            CK(hipStreamCreateWithPriority(&sx, hipStreamNonBlocking, hi));
+        }
+        BigArgs ba;
+        memset(&ba, 0, sizeof ba);
+        std::vector<double> us;
+        *answer = 0;
+        for (uint32_t i = 1; i <= 5000u; i++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            hipLaunchKernelGGL(echo_once_big, dim3(1), dim3(variant >= 2 ? 256 : 64), variant >= 1 ? 38912 : 0, sx, ba, i, answer, tab);
+            while (__atomic_load_n(answer, __ATOMIC_ACQUIRE) != i) __builtin_ia32_pause();
+            us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+        }
+        CK(hipStreamSynchronize(sx));
+        const char *names[] = {"E0 launch per request, 400-byte argument block", "E1 ... + 38 KB dynamic LDS", "E2 ... + 256 threads",
+                               "E3 ... on a high-priority stream"};
+        report(names[variant], us);
     }
     {
         Slot *slots;

@@ -1,7 +1,7 @@
 // Request threads issuing SINGLE load-target decisions through the C ABI (mmp_place_batch, n = 1) — what the Java mesh's
 // request threads do (mmesh-req-thread-%d, ModelMeshApi.java:202) — without an interpreter lock in the way: per-call
 // latency of one thread and the aggregate rate of T threads, launch path (latency slots) against the resident kernel.
-// A 10k-instance / 100k-model table built here (counts ~ Poisson-ish, no type constraints).
+// A 10k-instance / 100k-model table built here (counts ~ Poisson(20) as in config C3, no type constraints).
 //   g++ -O2 -std=c++17 -Iinclude tools/micro/single_calls.cc -Lmodelmesh_amd/lib -lmmplace -Wl,-rpath,$PWD/modelmesh_amd/lib -lpthread -o /tmp/single_calls
 #include <algorithm>
 #include <atomic>
@@ -51,7 +51,11 @@ int main()
     for (int p = 0; p < P; p++) {
         pods[p].capacity = 8388608;
         pods[p].used = (int64_t)(8388608.0 * (0.4 + 0.5 * (rng() % 1000) / 1000.0));
-        pods[p].count = 5 + (int32_t)(rng() % 30);
+        // as config C3: few instances below the count break of 10.  SINGLE_CALLS_FLAT=1: counts spread evenly over 5..34 instead —
+        // a sixth of the table is then a candidate of every request, every decision needs the wave path (which the resident
+        // kernel hands back to the launch path), the regime in which round 2 found the resident stream blocking the latency
+        // slots' launches
+        pods[p].count = getenv("SINGLE_CALLS_FLAT") ? 5 + (int32_t)(rng() % 30) : std::poisson_distribution<int>(20)(rng);
         pods[p].lru_time = NOW - 3600000 - (int64_t)(rng() % 7200000);
         pods[p].rpm = (int32_t)(rng() % 2000);
         pods[p].loading_threads = 8;
@@ -77,6 +81,30 @@ int main()
             rq.fresh_count = pods[rq.self_pod].count;
             return mmp_place_batch(c, &rq, 1, nullptr, 0, NOW, out);
         };
+        if (mode == 0) {  // a 100k-decision batch through the host-pointer ABI (H2D + kernel + D2H), for the record
+            const int B = 100000;
+            std::vector<mmp_place_req> rb(B);
+            std::vector<mmp_place_out> ob(B);
+            memset(rb.data(), 0, sizeof(mmp_place_req) * B);
+            for (int i = 0; i < B; i++) {
+                rb[i].model = i % M;
+                rb[i].self_pod = i % P;
+                rb[i].pick = (uint32_t)i * 2654435761u;
+                rb[i].last_used = NOW - 5000;
+                rb[i].fresh_lru = pods[rb[i].self_pod].lru_time;
+                rb[i].fresh_capacity = pods[rb[i].self_pod].capacity;
+                rb[i].fresh_used = pods[rb[i].self_pod].used;
+                rb[i].fresh_count = pods[rb[i].self_pod].count;
+            }
+            mmp_profile(c, 1);
+            for (int k = 0; k < 3; k++) mmp_place_batch(c, rb.data(), B, nullptr, 0, NOW, ob.data());
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int k = 0; k < 10; k++) mmp_place_batch(c, rb.data(), B, nullptr, 0, NOW, ob.data());
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / 10;
+            printf("batch of %d through host pointers: %.1f us per call (%.1f M decisions/s), kernel %.2f us\n", B, dt * 1e6, B / dt / 1e6,
+                   mmp_last_kernel_ms(c) * 1e3);
+            mmp_profile(c, 0);
+        }
         mmp_place_out ref[64], out;
         for (int i = 0; i < 64; i++) {
             const int rc = one(i, &ref[i]);
