@@ -106,11 +106,8 @@ struct SnapSide {
 // pinned, device-mapped request / result buffers and a stream of its own, so that one decision never
 // queues behind a 100k-decision batch or a commit (SURVEY.md §8b "Threading").
 // Every pinned buffer the device and the host hand data through WHILE A KERNEL RUNS (completion flags, result rows of
-// the latency slots, the resident kernel's request slots) must be fine-grained: hipHostMallocDefault leaves the choice to
-// the process environment (HIP_HOST_COHERENT), and in a plain C / JVM host it came out coarse-grained — device stores
-// then reach the host at kernel end only (single decisions p50 25 us instead of 12) and a resident wavefront polls a
-// stale copy of its request slots (found with tools/micro/single_calls.cc; under PyTorch's runtime the default happened
-// to be coherent).
+// the latency slots, the resident kernel's request slots) is allocated fine-grained and device-mapped explicitly:
+// hipHostMallocDefault would leave the choice to the process environment (HIP_HOST_COHERENT).
 constexpr unsigned int kPinnedFlags = hipHostMallocCoherent | hipHostMallocMapped;
 constexpr int kFastSlots = 4;
 constexpr int kFastN = 4096;       // decisions per fast call
