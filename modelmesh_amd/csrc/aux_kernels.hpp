@@ -23,6 +23,12 @@ struct ServeArgs {
 
 // ForwardingLB.getNext (MM.java:4315-4392): k is tiny (1-3 copies), so one
 // lane runs the loop exactly as written; lanes = independent requests.
+// A launch lasts as long as its chain of dependent fetches (request -> model row -> copies -> the copies' instance
+// state), so the first kServePre copies and kServeExcl exclusions are fetched level by level, everything of a level
+// in flight together, before the loop runs on registers; copies / exclusions beyond that are fetched in the loop.
+constexpr int kServePre = 4;
+constexpr int kServeExcl = 4;
+
 __global__ void serve_batch_kernel(ServeArgs A)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -36,7 +42,31 @@ __global__ void serve_batch_kernel(ServeArgs A)
         A.outs[i] = o;
         return;
     }
+    // level 2: the model row and the request's first exclusions
     const mmp_model_row m = A.models[r.model];
+    int32_t x_pod[kServeExcl];
+    int64_t x_time[kServeExcl];
+#pragma unroll
+    for (int x = 0; x < kServeExcl; x++) {
+        x_pod[x] = x < r.n_excl ? A.excl_pod[r.excl_off + x] : -1;
+        x_time[x] = x < r.n_excl ? A.excl_time[r.excl_off + x] : 0;
+    }
+    // level 3: the first copies; level 4: the state of their instances
+    int32_t p_iid[kServePre], p_inuse[kServePre];
+    uint32_t p_flags[kServePre];
+    int64_t p_ts[kServePre], p_lu[kServePre];
+#pragma unroll
+    for (int e = 0; e < kServePre; e++) {
+        p_iid[e] = e < m.n_loaded ? A.ent_pod[m.ent_off + e] : -1;
+        p_ts[e] = e < m.n_loaded ? A.ent_time[m.ent_off + e] : 0;
+    }
+#pragma unroll
+    for (int e = 0; e < kServePre; e++) {
+        const bool in_table = p_iid[e] >= 0 && p_iid[e] < A.P;
+        p_flags[e] = in_table ? A.pods[p_iid[e]].flags : 0u;
+        p_inuse[e] = in_table ? A.in_use[p_iid[e]] : 0;
+        p_lu[e] = in_table ? A.last_used[p_iid[e]] : 0;
+    }
     const bool exclude_self = r.flags & MMP_SERVE_EXCLUDE_SELF, prefer_self = r.flags & MMP_SERVE_PREFER_SELF;
     bool seen_self = false;
     int32_t chosen = -1;
@@ -44,32 +74,34 @@ __global__ void serve_batch_kernel(ServeArgs A)
     int32_t mn = INT32_MAX;
     int64_t lru = INT64_MAX, first_started = INT64_MAX;
     const int64_t cutoff = (int64_t)((uint64_t)A.now - (uint64_t)r.assume_completed_ms);  // :4350
-    for (int e = 0; e < m.n_loaded; e++) {
-        const int32_t iid = A.ent_pod[m.ent_off + e];
-        const int64_t load_started = A.ent_time[m.ent_off + e];
+    // one copy of the loop body; flags = 0 for an instance id outside the table (sii == null)
+    auto visit = [&](int32_t iid, int64_t load_started, uint32_t flags, int32_t pod_in_use, int64_t pod_last_used) {
         // MapFilteringSet.apply (MM.java:4279-4283)
         bool filtered = false;
-        for (int x = 0; x < r.n_excl; x++) {
+#pragma unroll
+        for (int x = 0; x < kServeExcl; x++)
+            if (x < r.n_excl && x_pod[x] == iid && (x_time[x] == MMP_ANY_TIME || x_time[x] == load_started)) filtered = true;
+        for (int x = kServeExcl; x < r.n_excl; x++) {
             const int32_t xp = A.excl_pod[r.excl_off + x];
             const int64_t xt = A.excl_time[r.excl_off + x];
             if (xp == iid && (xt == MMP_ANY_TIME || xt == load_started)) filtered = true;
         }
-        if (filtered) continue;
+        if (filtered) return;
         bool us = false;
         if (!seen_self && iid == r.self_pod) {  // :4334-4342
             seen_self = true;
-            if (exclude_self) continue;
+            if (exclude_self) return;
             us = true;
         }
-        if (iid < 0 || iid >= A.P || !(A.pods[iid].flags & MMP_POD_LIVE)) continue;  // sii == null
+        if (!(flags & MMP_POD_LIVE)) return;  // sii == null
         if (load_started < cutoff) {  // :4352-4367
-            const int32_t inuse = us ? r.local_in_flight : A.in_use[iid];
-            if (inuse > mn) continue;
-            const int64_t nlu = us ? (prefer_self ? 0 : r.last_invoke_time) : A.last_used[iid];
+            const int32_t inuse = us ? r.local_in_flight : pod_in_use;
+            if (inuse > mn) return;
+            const int64_t nlu = us ? (prefer_self ? 0 : r.last_invoke_time) : pod_last_used;
             if (inuse < mn)
                 mn = inuse;
             else if (nlu >= lru)
-                continue;
+                return;
             chosen = iid;
             chosen_ts = load_started;
             lru = nlu;
@@ -78,6 +110,16 @@ __global__ void serve_batch_kernel(ServeArgs A)
             chosen_ts = load_started;
             first_started = load_started;
         }
+    };
+#pragma unroll
+    for (int e = 0; e < kServePre; e++)
+        if (e < m.n_loaded) visit(p_iid[e], p_ts[e], p_flags[e], p_inuse[e], p_lu[e]);
+    for (int e = kServePre; e < m.n_loaded; e++) {
+        const int32_t iid = A.ent_pod[m.ent_off + e];
+        const int64_t load_started = A.ent_time[m.ent_off + e];
+        const bool in_table = iid >= 0 && iid < A.P;
+        visit(iid, load_started, in_table ? A.pods[iid].flags : 0u, in_table ? A.in_use[iid] : 0,
+              in_table ? A.last_used[iid] : 0);
     }
     if (chosen >= 0) {
         o.chosen = (!exclude_self && chosen == r.self_pod) ? MMP_SELF : chosen;  // :4381-4385

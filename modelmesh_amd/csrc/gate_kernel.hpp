@@ -43,38 +43,95 @@ __device__ __forceinline__ bool load_change(int32_t cur_rpm, int32_t rpm)
     return diff >= 100 || (cur_rpm == 0 ? rpm != 0 : (100 * diff) / cur_rpm > 10);
 }
 
+// A launch lasts as long as its chain of dependent fetches, so everything a level of that chain needs is requested
+// together before anything is evaluated: (1) the request; (2) the model row, the caller's own instance row, the first
+// exclusions and the explicit pool; (3) the first copies and failure records, the type's stats row, its allowed bit;
+// (4) the copies' instance flags.  The rules then run on registers; entries beyond kGatePre are fetched where needed.
+constexpr int kGatePre = 4;
+
 __device__ __forceinline__ void gate_one(const GateArgs &A, int i)
 {
     const mmp_gate_req r = A.reqs[i];
     uint32_t bits = 0;
     int32_t initial = 0;
+    // ---- level 2
     const bool have_model = r.model >= 0 && r.model < A.n_models;
     mmp_model_row m{};
     if (have_model) m = A.models[r.model];
+    const bool self_in = r.self_pod >= 0 && r.self_pod < A.P;
+    mmp_pod_row cur{};  // the caller's published record (publishInstanceRecord below)
+    if (self_in) cur = A.pods[r.self_pod];
+    int32_t x_pod[kGatePre], g_pool[kGatePre];
+    int64_t x_time[kGatePre];
+#pragma unroll
+    for (int x = 0; x < kGatePre; x++) {
+        const bool hx = have_model && x < r.n_excl, hg = have_model && x < r.n_explicit;
+        x_pod[x] = hx ? A.excl_pod[r.excl_off + x] : -1;
+        x_time[x] = hx ? A.excl_time[r.excl_off + x] : 0;
+        g_pool[x] = hg ? A.explicit_pool[r.explicit_off + x] : -1;
+    }
+    // ---- level 3
     // typeSetStats(mr.getType()) at MM.java:5169 (loadLocal) and :2918 (onEviction); cluster-wide without a record
     const StatsAcc *st = have_model ? &A.tstats[(m.type < 0 || m.type >= A.T_rows) ? 0 : m.type] : A.stats;
     const int64_t total_cap = (int64_t)st->total_capacity, total_free = (int64_t)st->total_free;
     const int32_t copy_count = st->model_copy_count, inst_count = st->instance_count;
+    int32_t l_iid[kGatePre], f_iid[kGatePre];
+    int64_t l_t[kGatePre], f_t[kGatePre];
+    bool l_in_table[kGatePre];
+    bool typed = false;
+    if (have_model) {
+#pragma unroll
+        for (int e = 0; e < kGatePre; e++) {
+            l_iid[e] = e < m.n_loaded ? A.ent_pod[m.ent_off + e] : -1;
+            l_t[e] = e < m.n_loaded ? A.ent_time[m.ent_off + e] : 0;
+            f_iid[e] = e < m.n_failed ? A.ent_pod[m.ent_off + m.n_loaded + e] : -1;
+            f_t[e] = e < m.n_failed ? A.ent_time[m.ent_off + m.n_loaded + e] : 0;
+        }
+        typed = A.T > 0 && m.type >= 0 && m.type < A.T && A.has_allowed[m.type];
+        // ---- level 4
+#pragma unroll
+        for (int e = 0; e < kGatePre; e++)
+            l_in_table[e] = l_iid[e] >= 0 && l_iid[e] < A.P && !(A.pods[l_iid[e]].flags & MMP_POD_TOMBSTONE);
+    }
+    const bool self_allowed =
+        typed && self_in && ((A.allowed[(size_t)m.type * A.W + (r.self_pod >> 6)] >> (r.self_pod & 63)) & 1ull);
 
     if (have_model) {
-        // ---- goLocal, MM.java:3598-3626 over filteredInstances = copies minus MapFilteringSet excludes
-        int32_t n_f = 0;
-        bool has_local = false;
-        int64_t local_loaded = 0, oldest = INT64_MAX;
-        for (int e = 0; e < m.n_loaded; e++) {
-            const int32_t iid = A.ent_pod[m.ent_off + e];
-            const int64_t t = A.ent_time[m.ent_off + e];
+        auto filtered_out = [&](int32_t iid, int64_t t) {  // MapFilteringSet.apply (MM.java:4279-4283)
             bool filtered = false;
-            for (int x = 0; x < r.n_excl; x++) {
+#pragma unroll
+            for (int x = 0; x < kGatePre; x++)
+                if (x < r.n_excl && x_pod[x] == iid && (x_time[x] == MMP_ANY_TIME || x_time[x] == t)) filtered = true;
+            for (int x = kGatePre; x < r.n_excl; x++) {
                 const int32_t xp = A.excl_pod[r.excl_off + x];
                 const int64_t xt = A.excl_time[r.excl_off + x];
                 if (xp == iid && (xt == MMP_ANY_TIME || xt == t)) filtered = true;
             }
-            if (filtered) continue;
+            return filtered;
+        };
+        auto in_explicit_pool = [&](int32_t iid) {
+            bool hit = false;
+#pragma unroll
+            for (int x = 0; x < kGatePre; x++)
+                if (x < r.n_explicit && g_pool[x] == iid) hit = true;
+            for (int x = kGatePre; x < r.n_explicit; x++)
+                if (A.explicit_pool[r.explicit_off + x] == iid) hit = true;
+            return hit;
+        };
+        // ---- goLocal, MM.java:3598-3626 over filteredInstances = copies minus MapFilteringSet excludes
+        int32_t n_f = 0;
+        bool has_local = false;
+        int64_t local_loaded = 0, oldest = INT64_MAX;
+        auto go_local_visit = [&](int32_t iid, int64_t t) {
+            if (filtered_out(iid, t)) return;
             n_f++;
             if (t < oldest) oldest = t;
             if (iid == r.self_pod && !has_local) { has_local = true; local_loaded = t; }
-        }
+        };
+#pragma unroll
+        for (int e = 0; e < kGatePre; e++)
+            if (e < m.n_loaded) go_local_visit(l_iid[e], l_t[e]);
+        for (int e = kGatePre; e < m.n_loaded; e++) go_local_visit(A.ent_pod[m.ent_off + e], A.ent_time[m.ent_off + e]);
         bool go_local = false;
         if (n_f > 0 && has_local) {
             go_local = n_f == 1;
@@ -91,36 +148,39 @@ __device__ __forceinline__ void gate_one(const GateArgs &A, int i)
         {
             int count = 0;
             const int64_t cutoff = jsub64(A.now, A.in_use_expiry);
-            for (int e = 0; e < m.n_failed; e++) {
+#pragma unroll
+            for (int e = 0; e < kGatePre; e++)
+                if (e < m.n_failed && f_t[e] > cutoff) count++;
+            for (int e = kGatePre; e < m.n_failed && count < 3; e++)
                 if (A.ent_time[m.ent_off + m.n_loaded + e] > cutoff) count++;
-                if (count >= 3) { bits |= MMP_GATE_FAILURES_BREACHED; break; }
-            }
+            if (count >= 3) bits |= MMP_GATE_FAILURES_BREACHED;
         }
         // ---- checkLoadLocationCount, MM.java:4590-4604 (MAX_LOAD_LOCATIONS = 5)
         {
             int count = 0;
-            for (int e = 0; e < m.n_loaded; e++) {
+#pragma unroll
+            for (int e = 0; e < kGatePre; e++)
+                if (e < m.n_loaded && l_in_table[e] && !in_explicit_pool(l_iid[e])) count++;
+            for (int e = kGatePre; e < m.n_loaded && count < 5; e++) {
                 const int32_t iid = A.ent_pod[m.ent_off + e];
-                bool excl = false;
-                for (int x = 0; x < r.n_explicit; x++)
-                    if (A.explicit_pool[r.explicit_off + x] == iid) excl = true;
                 const bool in_table = iid >= 0 && iid < A.P && !(A.pods[iid].flags & MMP_POD_TOMBSTONE);
-                if (!excl && in_table && ++count >= 5) { bits |= MMP_GATE_LOCATIONS_BREACHED; break; }
+                if (in_table && !in_explicit_pool(iid)) count++;
             }
+            if (count >= 5) bits |= MMP_GATE_LOCATIONS_BREACHED;
         }
         // ---- throwIfLocalLoadNotAllowed, MM.java:4003-4017
         {
-            bool local_filtered = false;
-            for (int x = 0; x < r.n_explicit; x++)
-                if (A.explicit_pool[r.explicit_off + x] == r.self_pod) local_filtered = true;
-            for (int e = 0; e < m.n_loaded + m.n_failed; e++)
-                if (A.ent_pod[m.ent_off + e] == r.self_pod) local_filtered = true;
-            bool blocked = false;
-            int type = m.type;
-            if (A.T > 0 && type >= 0 && type < A.T && A.has_allowed[type]) {
-                blocked = !(r.self_pod >= 0 && r.self_pod < A.P &&
-                            ((A.allowed[(size_t)type * A.W + (r.self_pod >> 6)] >> (r.self_pod & 63)) & 1ull));
+            bool local_filtered = in_explicit_pool(r.self_pod);
+#pragma unroll
+            for (int e = 0; e < kGatePre; e++) {
+                if (e < m.n_loaded && l_iid[e] == r.self_pod) local_filtered = true;
+                if (e < m.n_failed && f_iid[e] == r.self_pod) local_filtered = true;
             }
+            for (int e = kGatePre; e < m.n_loaded; e++)
+                if (A.ent_pod[m.ent_off + e] == r.self_pod) local_filtered = true;
+            for (int e = kGatePre; e < m.n_failed; e++)
+                if (A.ent_pod[m.ent_off + m.n_loaded + e] == r.self_pod) local_filtered = true;
+            const bool blocked = typed && !self_allowed;
             if (local_filtered || blocked) bits |= MMP_GATE_LOCAL_NOT_ALLOWED;
         }
     }
@@ -172,9 +232,8 @@ __device__ __forceinline__ void gate_one(const GateArgs &A, int i)
             publish = false;
         } else {
             const bool old = last_done > FREQ * 4;
-            const bool have_cur = r.self_pod >= 0 && r.self_pod < A.P && !(A.pods[r.self_pod].flags & MMP_POD_TOMBSTONE);
+            const bool have_cur = self_in && !(cur.flags & MMP_POD_TOMBSTONE);
             if (have_cur) {
-                const mmp_pod_row cur = A.pods[r.self_pod];
                 const bool cur_sd = cur.flags & MMP_POD_SHUTTING_DOWN, sd = r.flags & MMP_GATE_FRESH_SHUTTING_DOWN;
                 const int64_t cap = r.fresh_capacity, used = r.fresh_used, oldest = r.fresh_lru;
                 const int32_t count = r.fresh_count;

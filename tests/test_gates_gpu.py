@@ -31,7 +31,7 @@ def test_gates_match_oracle(seed):
     big = np.nonzero(rng.random(len(m)) < 0.1)[0]
     ent_pod, ent_time = list(fleet.ent_pod), list(fleet.ent_time)
     for i in big:
-        k, f = int(rng.integers(4, min(8, P) + 1)) if P >= 5 else min(P, 2), int(rng.integers(0, min(5, P)))
+        k, f = int(rng.integers(4, min(8, P) + 1)) if P >= 5 else min(P, 2), int(rng.integers(0, min(8, P)))  # (the kernel prefetches 4 of each)
         f = min(f, P - k) if P - k > 0 else 0
         pods = rng.choice(P, size=k + f, replace=False)
         m["ent_off"][i], m["n_loaded"][i], m["n_failed"][i] = len(ent_pod), k, f
@@ -69,13 +69,13 @@ def test_gates_match_oracle(seed):
     r["fresh_in_progress"] = cur["loading_in_progress"] + rng.choice([0, 0, 1, 3], n)
     r["fresh_rpm"] = cur["rpm"] + rng.choice([0, 0, 5, 99, 100, 1000], n)
     r["last_published"] = now - rng.choice([500, 2_500, 38_000, 39_500, 100_000, 170_000], n)
-    ne = np.where(rng.random(n) < 0.3, rng.integers(1, 3, n), 0).astype(np.int32)
+    ne = np.where(rng.random(n) < 0.3, rng.integers(1, 8, n), 0).astype(np.int32)
     off = np.zeros(n + 1, np.int64)
     np.cumsum(ne, out=off[1:])
     r["excl_off"], r["n_excl"] = off[:-1], ne
     excl_pod = rng.integers(0, P, int(off[-1])).astype(np.int32)
     excl_time = np.full(int(off[-1]), _lib.ANY_TIME, np.int64)
-    nx = np.where(rng.random(n) < 0.4, rng.integers(1, 4, n), 0).astype(np.int32)
+    nx = np.where(rng.random(n) < 0.4, rng.integers(1, 8, n), 0).astype(np.int32)
     xoff = np.zeros(n + 1, np.int64)
     np.cumsum(nx, out=xoff[1:])
     r["explicit_off"], r["n_explicit"] = xoff[:-1], nx

@@ -19,6 +19,16 @@ def test_serve_target_matches_oracle(seed):
     P, now = fleet.n_pods, fleet.now
     # make load-start times straddle the "assume completed" cutoff and collide
     fleet.ent_time[:] = now - rng.choice([500, 2_999, 3_000, 3_001, 10_000, 10_000, 60_000], len(fleet.ent_time))
+    # some models with more copies than the kernel fetches up front (4)
+    if P >= 8:
+        ent_pod, ent_time = list(fleet.ent_pod), list(fleet.ent_time)
+        for i in np.nonzero(rng.random(fleet.n_models) < 0.1)[0]:
+            k = int(rng.integers(5, 9))
+            fleet.models["ent_off"][i], fleet.models["n_loaded"][i], fleet.models["n_failed"][i] = len(ent_pod), k, 0
+            ent_pod += list(rng.choice(P, size=k, replace=False))
+            ent_time += list(now - rng.choice([500, 2_999, 3_000, 3_001, 10_000, 60_000], k))
+        fleet.ent_pod = np.array(ent_pod, np.int32)
+        fleet.ent_time = np.array(ent_time, np.int64)
     n = 4000
     reqs = np.zeros(n, dtype=_lib.SERVE_REQ)
     reqs["model"] = rng.integers(0, fleet.n_models, n)
@@ -26,7 +36,7 @@ def test_serve_target_matches_oracle(seed):
     # make self one of the copies often
     m = fleet.models[reqs["model"]]
     has = m["n_loaded"] > 0
-    pickc = (m["ent_off"] + rng.integers(0, 4, n) % np.maximum(m["n_loaded"], 1)).clip(0, max(len(fleet.ent_pod) - 1, 0))
+    pickc = (m["ent_off"] + rng.integers(0, 8, n) % np.maximum(m["n_loaded"], 1)).clip(0, max(len(fleet.ent_pod) - 1, 0))
     if len(fleet.ent_pod):
         reqs["self_pod"] = np.where(has & (rng.random(n) < 0.5), fleet.ent_pod[pickc], reqs["self_pod"])
     reqs["flags"] = rng.integers(0, 4, n)
@@ -36,7 +46,7 @@ def test_serve_target_matches_oracle(seed):
     in_use = rng.integers(0, 3, P).astype(np.int32)
     last_used = (now - rng.choice([0, 5, 5, 100, 10_000], P)).astype(np.int64)
     # tried-this-request pairs / key excludes
-    ne = np.where(rng.random(n) < 0.3, rng.integers(1, 3, n), 0).astype(np.int32)
+    ne = np.where(rng.random(n) < 0.3, rng.integers(1, 8, n), 0).astype(np.int32)  # (the kernel prefetches 4)
     off = np.zeros(n + 1, np.int64)
     np.cumsum(ne, out=off[1:])
     reqs["excl_off"], reqs["n_excl"] = off[:-1], ne
