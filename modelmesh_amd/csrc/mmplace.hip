@@ -428,7 +428,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     A.done_seq = done_seq;
     const int wpad = (c->snap.W + 1) & ~1;
     // one dynamic region: the lane phase's windows + scratch, re-used by the wave path's tiles (place_block)
-    const size_t lds = std::max<size_t>((size_t)kPlaceWaves * 2 * wpad * sizeof(uint64_t), (size_t)kPlaceLaneLds);
+    const size_t lds = std::max<size_t>((size_t)kPlaceWaves * 2 * wpad * sizeof(uint64_t), (size_t)place_lane_lds(c->snap.T));
     // the wave path's tile (two bitmaps of the whole table per wavefront) next to the static LDS of place_block;
     // gfx950 gives a workgroup up to 160 KB (c->lds_limit is the device's answer), which admits ~120k instances
     if (lds + kPlaceStaticLds > c->lds_limit)

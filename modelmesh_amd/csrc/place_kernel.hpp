@@ -1031,10 +1031,11 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
     return fb ? (VIEW ? kLaneIncomplete : (far && !LONG && S.pc ? kLaneLong : kLaneWave)) : kLaneDone;
 }
 
-// getNext on the type's head window (TypeWin): Ws = the windows in LDS; scr = this lane's two columns of the
-// workgroup's scratch — word j of the window's eligibility words at scr[j * kPlaceBlock], of its candidate words
-// (eligible and preferred-if-the-type-prefers, :4905) at scr[(kWinWords + j) * kPlaceBlock] — both with the
-// request's exclusions cleared.  Step for step lane_decide_r's simple case; kLaneHeadMiss whenever the window cannot
+// getNext on the type's head window (TypeWin): Ws = the windows in LDS; scr = this lane's column of the
+// workgroup's scratch — word j of the window's eligibility words, the request's exclusions cleared, at
+// scr[j * kPlaceBlock]; the candidate words (eligible and preferred-if-the-type-prefers, :4905) are that column
+// and-ed with the window's preference words where they are read (a second column for them cost 12 KB of LDS per
+// workgroup and an LDS atomic per exclusion).  Step for step lane_decide_r's simple case; kLaneHeadMiss whenever the window cannot
 // answer — the caller then runs lane_decide_r on the same resolved request.
 // Shape of the code, from measurements (tools/phase_clock.py, SQ counters): a wavefront of this kernel is alone or
 // nearly alone on its SIMD, so what it pays for is every dependent LDS round trip (~0.1 us) and every instruction of
@@ -1049,21 +1050,15 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
     PHASE_T0();
     if (r.type < 0 || r.type >= kWinLds || r.n_excl > kInlineExcl || A.force_wave) return kLaneHeadMiss;
     const TypeWin &Wn = Ws[r.type];
-    uint64_t *scrE = scr, *scrD = scr + kWinWords * kPlaceBlock;
+    uint64_t *scrE = scr;  // one column per lane: the window's eligibility words, the request's exclusions cleared
     // round 1: header, the words of both bitmaps, the first row
     const int4 hdr = *reinterpret_cast<const int4 *>(&Wn);  // valid, w0, nw, flags
     {
-        uint64_t e6[kWinWords], p6[kWinWords];
+        uint64_t e6[kWinWords];
 #pragma unroll
-        for (int j = 0; j < kWinWords; j++) {  // words beyond nw are zero in the record
-            e6[j] = Wn.E[j];
-            p6[j] = Wn.Pm[j];
-        }
+        for (int j = 0; j < kWinWords; j++) e6[j] = Wn.E[j];  // words beyond nw are zero in the record
 #pragma unroll
-        for (int j = 0; j < kWinWords; j++) {
-            scrE[j * kPlaceBlock] = e6[j];
-            scrD[j * kPlaceBlock] = e6[j] & p6[j];
-        }
+        for (int j = 0; j < kWinWords; j++) scrE[j * kPlaceBlock] = e6[j];
     }
     WinRow r0 = Wn.rowsE[0];
     if (!hdr.x) return kLaneHeadMiss;
@@ -1077,7 +1072,6 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
         if (e >= 0 && j >= 0 && j < nw) {
             const unsigned long long m = ~(1ull << (e & 63));
             atomicAnd((unsigned long long *)&scrE[j * kPlaceBlock], m);
-            atomicAnd((unsigned long long *)&scrD[j * kPlaceBlock], m);
         }
     };
 #pragma unroll
@@ -1085,7 +1079,7 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
 #pragma unroll
     for (int i = 0; i < kLateExtra; i++) clear_at(r.late_pos[i]);  // -1 unless late-bound
     auto ew = [&](int w) { return scrE[(w - w0) * kPlaceBlock]; };  // w0 <= w < w0 + nw
-    auto dw = [&](int w) { return scrD[(w - w0) * kPlaceBlock]; };
+    auto dw = [&](int w) { return scrE[(w - w0) * kPlaceBlock] & Wn.Pm[w - w0]; };  // ... that may be chosen (preference mask)
     // first set bit of f(w) at a position in [from, to) of the window (to <= win_end); kNoPos if none
     auto first_in = [&](auto f, int from, int to) {
         if (from >= to) return (int)kNoPos;
@@ -1550,8 +1544,15 @@ __device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int
 // shortlists in number; otherwise they take the wave path.
 // LDS of place_block: static = the lists; dynamic = max(windows + per-lane scratch of the lane phase, the wave path's
 // tiles) — the host checks the sum against the device's per-workgroup limit
-constexpr int kWinLdsBytes = ((kWinLds * (int)sizeof(TypeWin) + 1023) / 1024) * 1024;  // staged in whole 1 KB chunks
-constexpr int kPlaceLaneLds = kWinLdsBytes + 2 * kWinWords * kPlaceBlock * 8;  // dynamic LDS of the lane phase: windows + scratch
+// windows are staged in whole 1 KB chunks, as many as the snapshot has type rows (at most kWinLds)
+__host__ __device__ constexpr int win_lds_bytes(int type_rows)
+{
+    return (((type_rows < kWinLds ? type_rows : kWinLds) * (int)sizeof(TypeWin) + 1023) / 1024) * 1024;
+}
+constexpr int kWinLdsBytes = win_lds_bytes(kWinLds);
+constexpr int kLaneScratchBytes = kWinWords * kPlaceBlock * 8;  // one column of kWinWords words per lane
+__host__ __device__ constexpr int place_lane_lds(int type_rows) { return win_lds_bytes(type_rows) + kLaneScratchBytes; }
+constexpr int kPlaceLaneLds = kWinLdsBytes + kLaneScratchBytes;  // the most the lane phase needs: windows + scratch
 constexpr int kPlaceStaticLds = 2 * kPlaceBlock * 4 + 64 + 256;                // the lists (+ place_single_kernel's request)
 template <bool WITH_LONG>
 __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, int32_t wpad, unsigned char *smem,
@@ -1561,10 +1562,10 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
     __shared__ int32_t fb_n, lr_n;
     // The staged windows and the per-lane scratch of the lane phase, and the wave path's bitmap tiles (kPlaceWaves x 2
     // bitmaps x wpad words) of the phase behind it, share ONE dynamic LDS region (smem; the host sizes it for the
-    // larger of the two, kPlaceLaneLds / the tiles): a 50k-instance table's tiles are 50 KB, and next to 41 KB of
+    // larger of the two, place_lane_lds(T) / the tiles): a 50k-instance table's tiles are 50 KB, and next to 41 KB of
     // windows + scratch they left room for one workgroup per CU (C4, round 2: 86 us per 1M decisions).
     TypeWin *s_wins = reinterpret_cast<TypeWin *>(smem);
-    uint64_t *s_scr = reinterpret_cast<uint64_t *>(smem + kWinLdsBytes);  // per lane: the window's eligibility and candidate words with the request's exclusions cleared
+    uint64_t *s_scr = reinterpret_cast<uint64_t *>(smem + win_lds_bytes(S.T));  // per lane: the window's eligibility words with the request's exclusions cleared
     if (threadIdx.x == 0) fb_n = lr_n = 0;
     const int d = blockIdx.x * kPlaceBlock + threadIdx.x;
     PHASE_T0();
