@@ -56,15 +56,18 @@ def kernel_bytes(fleet, reqs) -> int:
     return int(per.sum())
 
 
-def measured_traffic(workload: str):
+def measured_traffic(workload: str, decisions_per_launch: int):
     """HBM bytes per place_batch_kernel launch from the committed rocprofv3 PMC passes of this same
-    command (profiles/rNN/pmc_place_batch_<workload>.json, written by tools/pmc_summary.py); None if
-    no PMC pass has been recorded for this workload."""
+    command (profiles/rNN/pmc_place_batch_<workload>*.json, written by tools/pmc_summary.py); None if
+    no PMC pass has been recorded for this workload AT THIS LAUNCH SIZE (the summary's write bytes are the
+    16-byte result rows of one launch, which identifies the size)."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_place_batch_{workload}.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_place_batch_{workload}*.json"))):
         try:
-            best = json.load(open(f)).get("traffic_bytes_per_launch")
+            j = json.load(open(f))
+            if abs(j.get("write_bytes", 0) / 16 - decisions_per_launch) <= 0.02 * decisions_per_launch:
+                best = j.get("traffic_bytes_per_launch")
         except Exception:
             pass
     return best
@@ -516,9 +519,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pod-axis", action="store_true", help="skip the pod-axis sharded leg")
     ap.add_argument("--no-secondary", action="store_true", help="skip the per-kernel leg (evict / serve / gates / ...)")
-    ap.add_argument("--batches", type=int, default=48,
-                    help="distinct request batches the steps rotate through (48 x (6.4 + 1.6) MB = 384 MB > the 256 MiB "
-                         "Infinity Cache: a timed step reads its requests from HBM)")
+    ap.add_argument("--decisions-per-step", type=int, default=800_000,
+                    help="decisions of one step = one launch of place_batch_kernel, rounded to whole request sets of one "
+                         "decision per model (C3: 8 sets = 800k decisions = 3125 workgroups on 256 CUs; a 100k launch is "
+                         "1.5 workgroups per CU and latency-bound: DESIGN.md 11)")
+    ap.add_argument("--batches", type=int, default=0,
+                    help="distinct request batches the steps rotate through; 0 = as many as put requests + results above "
+                         "384 MB (> the 256 MiB Infinity Cache: a timed step reads its requests from HBM), at least 3")
+    ap.add_argument("--ramp", type=int, default=3000,
+                    help="untimed launches in setup that bring the device out of its idle power state (not warm-up steps)")
     ap.add_argument("--issuers", type=int, default=1, help="host threads issuing the timed steps")
     ap.add_argument("--issue-threads", type=int, default=0,
                     help="submission threads inside the library (mmp_issue_threads): the timed loop then only appends "
@@ -526,11 +535,12 @@ def main():
                          "Measured (round 2): the host's share of a step drops from 3.15 to 0.4 us, the step time does not move "
                          "(3.25 us: with the round-2 kernel the timed region is bound by the GPU, not by the launch path), so the "
                          "default leaves the helpers off")
-    ap.add_argument("--streams", type=int, default=4,
-                    help="HIP streams the timed steps are issued on round-robin (a 100k-decision batch is 1564 "
-                         "wavefronts — too few to cover its own latency chain on 256 CUs — so independent batches "
-                         "overlap; round 2, tools/sync_cost.py: 4 streams 3.9 us per step over 200 steps, 8: 4.3, 16: 5.1 — the "
-                         "closing synchronize costs ~10 us per stream — and one issuing host thread needs 3.45 us per launch)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="HIP streams the timed steps are issued on round-robin; 0 = 2 for launches of more than 200k "
+                         "decisions, else 4 (profiles/r2/place_sweep_C3.csv: a second launch in flight covers the first one's "
+                         "start-up and tail — 800k decisions: 27.5 us on one stream, 20.0 us per step on two, 20.6 on four; "
+                         "a 100k launch is 1564 wavefronts, too few to cover its own latency chain on 256 CUs: 8.2 us on one "
+                         "stream, 3.3 us per step on four; the closing synchronize costs per stream)")
     ap.add_argument("--leg-timeout", type=float, default=420.0,
                     help="watchdog for the additional legs (pod axis, latency, churn, per-kernel, cpu baseline): when "
                          "it fires rank 0 prints the line with the legs completed so far and every rank exits 0")
@@ -576,13 +586,24 @@ def main():
 
     # model-axis shard: every rank owns its own batches of one-decision-per-model requests.  R distinct batches
     # (their requests + results exceed the 256 MiB Infinity Cache) so that a timed step reads its requests from HBM.
-    n_batches = max(1, args.batches)
-    n_streams = max(1, args.streams)
+    sets_per_step = max(1, round(args.decisions_per_step / fleet.n_models))  # request sets (one decision per model) per step
+    n_batches = args.batches if args.batches > 0 else max(3, -(-384_000_000 // (sets_per_step * fleet.n_models * 80)))
+    n_streams = args.streams if args.streams > 0 else (2 if sets_per_step * fleet.n_models > 200_000 else 4)
     import ctypes as C
     batches = []  # (reqs, extra) on the host, for the parity gate
     d_bufs = []   # device tensors, kept alive
     for b in range(n_batches):
-        rq, ex = wl.make_requests(fleet, seed=0xBE7C0 + 1000 * rank + b)
+        parts, ex_parts, off = [], [], 0
+        for j in range(sets_per_step):  # every set has its own seed; its exclusion-pool offsets move behind the sets before it
+            rq, ex = wl.make_requests(fleet, seed=0xBE7C0 + 100_000 * rank + b * sets_per_step + j)
+            if off:
+                rq = rq.copy()
+                rq["extra_off"] += off
+            parts.append(rq)
+            ex_parts.append(ex)
+            off += len(ex)
+        rq = parts[0] if sets_per_step == 1 else np.concatenate(parts)
+        ex = ex_parts[0] if sets_per_step == 1 else np.concatenate(ex_parts)
         batches.append((rq, ex))
         d_bufs.append((torch.from_numpy(rq.view(np.uint8).reshape(-1)).to(dev),
                        torch.from_numpy(np.ascontiguousarray(ex if len(ex) else np.zeros(1, np.int32))).to(dev),
@@ -608,6 +629,7 @@ def main():
 
     _done = [torch.cuda.Event() for _ in streams]
     _last_stream = [n_streams - 1]  # index of the stream that got the most recent launch
+    _fence_t = [0.0]  # when the last fence knew the device was done (before its closing synchronize)
 
     def fence():
         # Closing a region (tools/region_anatomy.py, 20 steps on 4 streams, device-side span 73 us): torch.cuda.synchronize()
@@ -615,12 +637,15 @@ def main():
         # ISSUE order costs more (+83 us: every query of an unfinished event makes the runtime do work on that queue);
         # polling them in REVERSE order — the stream that got the last launch first, by then the others are done — gets the
         # host there in +26 us, and the synchronize that closes the region finds nothing left to wait for (+7 us).
-        for e_, st_ in zip(_done, streams):
-            e_.record(st_)
-        for k_ in range(len(_done)):
-            e_ = _done[(_last_stream[0] - k_) % len(_done)]
-            while not e_.query():
-                pass
+        _mode = os.environ.get("MMP_BENCH_FENCE", "last")  # (experiments: "sync" = synchronize only, "spin" = issue order)
+        if _mode != "sync":
+            for e_, st_ in zip(_done, streams):
+                e_.record(st_)
+            for k_ in range(len(_done)):
+                e_ = _done[k_] if _mode == "spin" else _done[(_last_stream[0] - k_) % len(_done)]
+                while not e_.query():
+                    pass
+        _fence_t[0] = time.perf_counter()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -635,11 +660,31 @@ def main():
     for i in range(max(n_batches, n_streams)):
         check(_fn(*_args[i % period]))
     fence()
+    # ... and the device brought out of its idle power state: the host spent seconds generating the batches above, and
+    # a 20-step region (~90 us) right after that was measured anywhere between 89 and 184 us.  ~10 ms of the same
+    # launches first; none of it is timed and none of it replaces a warm-up step.
+    import gc
+    gc.collect()
+    gc.disable()  # a collection inside a ~90 us region would be most of it (enabled again behind the region)
+    for i in range(args.ramp):
+        _fn(*_args[i % period])
+    fence()
+    # ... and the host: the first region of this shape a process runs was measured at 200 us against 86-93 us for the next
+    # ones (its 20 launches take the host 112 us instead of 56, the closing synchronize 43 us instead of 7) — code and
+    # data of the launch path are not in the host's caches yet.  Two untimed rehearsals of the region's shape.
+    for rep_ in range(2 if args.ramp else 0):
+        for i in range(args.steps):
+            _fn(*_args[i % period])
+        _last_stream[0] = (args.steps - 1) % n_streams
+        fence()
     n_helpers = max(0, min(args.issue_threads, n_streams))
     _flush = solver.lib.mmp_issue_flush
     if n_helpers:
         check(solver.lib.mmp_issue_threads(solver.h, n_helpers))
     pos = 0
+    # (the timed steps' argument tuples are picked before the warm-up so that nothing but the fence lies between the
+    # last warm-up step and the region)
+    sched = [_args[(args.warmup + i) % period] for i in range(args.steps)]
     for i in range(args.warmup):
         check(_fn(*_args[pos % period]))
         pos += 1
@@ -648,7 +693,6 @@ def main():
     fence()
     # timed region: exactly K steps (the loop body is the bare C call: at ~4 us of launch work per step a Python
     # function frame is measurable); --issuers > 1 splits the schedule over host threads (ctypes drops the GIL)
-    sched = [_args[(pos + i) % period] for i in range(args.steps)]
     pos += args.steps
     _last_stream[0] = (pos - 1) % n_streams
     n_issuers = max(1, min(args.issuers, args.steps))
@@ -663,6 +707,21 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         issue_s = t_issued - t0
+        if os.environ.get("MMP_BENCH_REPEAT"):  # experiments: the anatomy of this region and of further ones (stderr only)
+            print(f"region 0: issue {issue_s * 1e6:.1f} us, known done {(_fence_t[0] - t0) * 1e6:.1f} us, total {elapsed * 1e6:.1f} us",
+                  file=sys.stderr)
+            for rep_ in range(int(os.environ["MMP_BENCH_REPEAT"])):
+                sched_ = [_args[(pos + i) % period] for i in range(args.steps)]
+                pos += args.steps
+                _last_stream[0] = (pos - 1) % n_streams
+                t0_ = time.perf_counter()
+                for a in sched_:
+                    _fn(*a)
+                t1_ = time.perf_counter()
+                fence()
+                t2_ = time.perf_counter()
+                print(f"region {rep_ + 1}: issue {(t1_ - t0_) * 1e6:.1f} us, known done {(_fence_t[0] - t0_) * 1e6:.1f} us, "
+                      f"total {(t2_ - t0_) * 1e6:.1f} us", file=sys.stderr)
     else:
         import threading as _th
         parts = [sched[j::n_issuers] for j in range(n_issuers)]
@@ -688,6 +747,7 @@ def main():
         rcs = 0
         for v in rc_box:
             rcs |= v
+    gc.enable()
     check(rcs)
     if n_helpers:
         check(solver.lib.mmp_issue_threads(solver.h, 0))  # the passes below bracket launches with events: issued in line
@@ -717,6 +777,27 @@ def main():
         ends[i].record(stream)
     fence()
     kern_ms = float(np.mean([s_.elapsed_time(e_) for s_, e_ in zip(starts, ends)]))
+
+    # the same kernel on ONE request set per launch (one decision per model: the launch size rounds 1 and 2 quoted),
+    # rotating through every set of every batch (the same 384 MB, so still from HBM), one stream, one event pair
+    set_ms = None
+    if sets_per_step > 1 and not args.kernel_only:  # (--kernel-only is the command the rocprofv3 summaries are taken from: one launch size)
+        M_, rsz = fleet.n_models, batches[0][0].dtype.itemsize
+        set_args = []
+        for b in range(n_batches):
+            r_, e_, o_ = d_bufs[b]
+            for j in range(sets_per_step):
+                set_args.append((solver.h, C.c_void_p(r_.data_ptr() + j * M_ * rsz), C.c_int32(M_), C.c_void_p(e_.data_ptr()),
+                                 C.c_int64(fleet.now), C.c_void_p(o_.data_ptr() + j * M_ * 16), C.c_void_p(stream.cuda_stream)))
+        for i in range(20):
+            check(_fn(*set_args[i % len(set_args)]))
+        fence()
+        ev0.record(stream)
+        for i in range(400):
+            _fn(*set_args[i % len(set_args)])
+        ev1.record(stream)
+        fence()
+        set_ms = ev0.elapsed_time(ev1) / 400
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -749,7 +830,7 @@ def main():
         value = total / elapsed
         alg = int(np.mean([algorithmic_bytes(fleet, bq[0]) for bq in batches[:4]]))
         kb = int(np.mean([kernel_bytes(fleet, bq[0]) for bq in batches[:4]]))
-        traffic = measured_traffic(args.workload)
+        traffic = measured_traffic(args.workload, n)
         # roofline of the dominant kernel: bytes it has to move per launch (measured by the PMC passes when a
         # summary is committed, else the compulsory streams) / its average launch duration / the HBM peak
         moved = traffic if traffic else kb
@@ -759,9 +840,10 @@ def main():
             "value": value, "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {fleet.n_models} models x {fleet.n_pods} pods, one load-target "
-                                   "decision per model per step (SURVEY.md §8d synthetic fleet)",
-                       "decisions_per_step_per_gpu": n, "sharding": "model axis, no collective",
+            "config": {"workload": f"{args.workload}: {fleet.n_models} models x {fleet.n_pods} pods, {sets_per_step} load-target "
+                                   f"decision(s) per model per step = {n} decisions per launch (SURVEY.md §8d synthetic fleet)",
+                       "decisions_per_step_per_gpu": n, "request_sets_per_step": sets_per_step,
+                       "sharding": "model axis, no collective",
                        "streams": n_streams, "distinct_batches": n_batches, "issuers": n_issuers,
                        "library_submission_threads": n_helpers,
                        "resident_input_bytes": int(n_batches * n * (64 + 16)),
@@ -775,6 +857,12 @@ def main():
                                                     "compulsory streams (request 64 B + resolved model row + exclusions + result 16 B)",
                          "kernel_bytes_per_launch": kb,
                          "frac_timed_region": moved * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
+                         "launch_of_one_request_set": None if set_ms is None else (lambda tb: {
+                             "decisions": fleet.n_models, "kernel_ms": set_ms, "bytes_per_launch": tb,
+                             "frac": tb / (set_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "note": "one decision per model per launch (the launch size of rounds 1-2): 1564 wavefronts on "
+                                     "256 CUs, bound by its own latency chain, not by bandwidth — DESIGN.md 4.1 / 11"})(
+                             measured_traffic(args.workload, fleet.n_models) or kb // sets_per_step),
                          "scan_equivalent": {
                              "note": "SURVEY.md §8(d) algorithmic bytes (32 B x P per decision: the scan the reference "
                                      "logically performs over every pod); this kernel does not perform that scan, so the "
@@ -785,6 +873,13 @@ def main():
         }
         if parity is False:
             line["invalid"] = "parity_vs_oracle is false: the numbers of this line describe a wrong kernel"
+
+    # the additional legs below work on the first request set of batch 0 (one decision per model; its exclusion-pool
+    # offsets start at 0, so the batch's pool serves it unchanged)
+    reqs = reqs[:fleet.n_models]
+    n = len(reqs)
+    if rank == 0:
+        want = want[:n]
 
     import threading
     emit_lock = threading.Lock()

@@ -13,7 +13,7 @@ timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; tail -1 $OUT/
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_C3_n1_steps20.json.log 2> $OUT/bench_C3_steps20.err; echo "bench(20) exit $?"
 timeout 900 python bench.py > $OUT/bench_C3_n1.json.log 2> $OUT/bench_C3.err; echo "bench exit $?"
 python tools/benchline.py steps20 < $OUT/bench_C3_n1_steps20.json.log; python tools/benchline.py default < $OUT/bench_C3_n1.json.log
-for wl in C3 C4; do
+for wl in ${PROFILE_WORKLOADS:-C3 C4}; do
   for ns in 1 4; do
     rm -rf /tmp/prof_${wl}_$ns
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${wl}_$ns -- python bench.py --workload $wl --kernel-only --steps 200 --warmup 20 --streams $ns > $OUT/prof_${wl}_${ns}streams_bench.log 2>&1
@@ -29,7 +29,12 @@ for wl in C3 C4; do
   (python tools/sq_summary.py /tmp/sq1 place_batch_kernel; python tools/sq_summary.py /tmp/sq2 place_batch_kernel) > $OUT/sq_place_batch_$wl.jsonl; cat $OUT/sq_place_batch_$wl.jsonl | cut -c1-300
   grep "^{" $OUT/prof_${wl}_1streams_bench.log | tail -1 > $OUT/bench_${wl}_kernel_only_1stream.json.log
 done
-timeout 600 python bench.py --workload C4 --steps 200 --warmup 10 --no-secondary > $OUT/bench_C4_n1.json.log 2> $OUT/bench_C4.err; echo "bench C4 exit $?"; python tools/benchline.py C4 < $OUT/bench_C4_n1.json.log
+# the whole bench under the kernel trace: the secondary kernels' own durations (bench.py brackets each of their launches with an event pair, which adds the gap between marker and kernel)
+rm -rf /tmp/prof_full
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_full -- python bench.py --steps 20 --warmup 5 > $OUT/prof_full_bench.log 2>&1
+f=$(find /tmp/prof_full -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/bench_full_kernel_stats.csv && grep -E "serve_batch|gate_batch|evict_batch|cache_replay|ingest_" $OUT/bench_full_kernel_stats.csv | cut -c1-120
+timeout 200 python tools/region_anatomy.py 2>&1 | grep -v amdgpu.ids > $OUT/region_anatomy.txt; grep "helpers 0 4 streams" $OUT/region_anatomy.txt
+if [[ "${PROFILE_WORKLOADS:-C3 C4}" == *C4* ]]; then timeout 600 python bench.py --workload C4 --steps 200 --warmup 10 --no-secondary > $OUT/bench_C4_n1.json.log 2> $OUT/bench_C4.err; echo "bench C4 exit $?"; python tools/benchline.py C4 < $OUT/bench_C4_n1.json.log; fi
 timeout 200 python tools/phase_clock.py 30 2>&1 | grep -v amdgpu.ids > $OUT/phase_clock_place_batch_C3.txt; tail -12 $OUT/phase_clock_place_batch_C3.txt
 timeout 600 python tools/place_sweep.py C3 2> /dev/null > $OUT/place_sweep_C3.csv; cat $OUT/place_sweep_C3.csv
 KT_GRAPH=${KT_GRAPH:-0} timeout 400 python tools/kernel_time.py C3 2>&1 | grep -v amdgpu.ids > $OUT/kernel_time_C3.txt
