@@ -602,6 +602,8 @@ def main():
             parts.append(rq)
             ex_parts.append(ex)
             off += len(ex)
+        if b == 0:
+            first_set_pool = len(ex_parts[0])
         rq = parts[0] if sets_per_step == 1 else np.concatenate(parts)
         ex = ex_parts[0] if sets_per_step == 1 else np.concatenate(ex_parts)
         batches.append((rq, ex))
@@ -877,6 +879,7 @@ def main():
     # the additional legs below work on the first request set of batch 0 (one decision per model; its exclusion-pool
     # offsets start at 0, so the batch's pool serves it unchanged)
     reqs = reqs[:fleet.n_models]
+    extra = extra[:first_set_pool]
     n = len(reqs)
     if rank == 0:
         want = want[:n]

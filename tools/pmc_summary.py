@@ -41,7 +41,7 @@ def main():
         "write_bytes": None if w is None else w * 1024,
         "traffic_bytes_per_launch": None if f is None or w is None else 2 * f * 1024 + w * 1024,
         "note": "FETCH_SIZE doubled per the gfx950 calibration in MI355X_MICROARCH.md §HBM; WRITE_SIZE "
-                "matches the 16 B x 100k result stream exactly (1.6 MB), so it is used uncorrected",
+                "matches the 16 B per decision result stream exactly, so it is used uncorrected",
     }
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
