@@ -538,7 +538,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the timed steps are issued on round-robin; 0 = 2 for launches of more than 200k "
                          "decisions, else 4 (profiles/r2/place_sweep_C3.csv: a second launch in flight covers the first one's "
-                         "start-up and tail — 800k decisions: 27.5 us on one stream, 20.0 us per step on two, 20.6 on four; "
+                         "start-up and tail — 800k decisions: 26.2 us on one stream, 17.9 us per step on two, 17.9 on four, 20.2 on eight; "
                          "a 100k launch is 1564 wavefronts, too few to cover its own latency chain on 256 CUs: 8.2 us on one "
                          "stream, 3.3 us per step on four; the closing synchronize costs per stream)")
     ap.add_argument("--leg-timeout", type=float, default=420.0,

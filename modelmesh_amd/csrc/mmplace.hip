@@ -149,7 +149,7 @@ struct mmp_ctx {
         std::atomic<uint32_t> rr{0};
         long long idle_ticks = 5'000'000;  // 50 ms at the 100 MHz wall clock
         std::atomic<uint64_t> launches{0}, served{0}, punted{0};
-        std::atomic<int> slow{0};  // answers that took longer than 2 ms (self-check in resident_place)
+        std::atomic<int> slow{0};  // answers in a row that took longer than 20 ms (self-check in resident_place)
         std::atomic<int> punt_streak{0}, skip{0};  // hand-backs in a row; single requests still to be sent to the launch path directly
     } res;
     // caller-owned streams that *_dev calls were enqueued on (leaf lock cs_mu): whoever rewrites state a decision
@@ -2579,7 +2579,6 @@ int resident_place(mmp_ctx *c, const mmp_place_req &rq, int64_t now, mmp_place_o
         R.skip.fetch_sub(1, std::memory_order_relaxed);
         return kResidentFallback;
     }
-    const auto t_entry = std::chrono::steady_clock::now();
     // a slot of our own for the duration of the call
     const uint32_t first = R.rr.fetch_add(1, std::memory_order_relaxed);
     int si = -1;
@@ -2604,9 +2603,11 @@ int resident_place(mmp_ctx *c, const mmp_place_req &rq, int64_t now, mmp_place_o
     S->req = rq;
     __atomic_store_n(&S->bell, ((uint64_t)seq << kResidentNowBits) | ((uint64_t)now & ((1ull << kResidentNowBits) - 1ull)),
                      __ATOMIC_RELEASE);  // the bell: written last
+    bool restarted = false;  // this call (re)started the kernel, or waited for a commit to do so: not a sample for the self-check
     if (!R.running || __atomic_load_n(&R.ctl->exited, __ATOMIC_ACQUIRE) == R.generation) {
         const int rc = resident_ensure(c);
         if (rc != MMP_OK) return rc;
+        restarted = true;
     }
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t spins = 0;; spins++) {
@@ -2625,12 +2626,16 @@ int resident_place(mmp_ctx *c, const mmp_place_req &rq, int64_t now, mmp_place_o
             R.punt_streak.store(0, std::memory_order_relaxed);
             *out = Ans->out;
             R.served.fetch_add(1, std::memory_order_relaxed);
-            // Self-check: an answer takes ~10 us.  Three calls slower than 2 ms switch the resident path off for this context
-            // and the launch path takes over (what that looked like before the resident stream got a priority level of its
-            // own: 50 ms per call, the time the resident kernel needs to idle out of the way of a launch queued behind it).
-            if (std::chrono::steady_clock::now() - t_entry > std::chrono::milliseconds(2) && R.slow.fetch_add(1) + 1 >= 3) {
+            // Self-check: an answer takes ~10 us.  Three answers IN A ROW slower than 20 ms — from a kernel that was running
+            // when the request was posted and was not restarted while it waited (a commit stops it) — switch the resident path
+            // off for this context and the launch path takes over (what that looked like before the resident stream got a
+            // priority level of its own: 50 ms per call, the time the resident kernel needs to idle out of the way of a launch
+            // queued behind it).  A request thread that lost its core for a few milliseconds is not such a sample.
+            const bool slow_answer = !restarted && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20);
+            if (!slow_answer && !restarted) R.slow.store(0, std::memory_order_relaxed);
+            if (slow_answer && R.slow.fetch_add(1) + 1 >= 3) {
                 R.enabled = false;
-                (void)fail(c, MMP_OK, "resident decision kernel disabled: answers took longer than 2 ms on this host");
+                (void)fail(c, MMP_OK, "resident decision kernel disabled: three answers in a row took longer than 20 ms on this host");
             }
             return MMP_OK;
         }
@@ -2641,6 +2646,7 @@ int resident_place(mmp_ctx *c, const mmp_place_req &rq, int64_t now, mmp_place_o
                             (unsigned)(S->bell >> kResidentNowBits), spins);
                 const int rc = resident_ensure(c);
                 if (rc != MMP_OK) return rc;
+                restarted = true;
             }
             if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200))
                 return fail(c, MMP_EHIP, "the resident decision kernel did not answer within 200 ms");
