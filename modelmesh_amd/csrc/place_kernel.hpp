@@ -1068,6 +1068,7 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
     const int win_end = (w0 + nw) * 64 < P ? (w0 + nw) * 64 : P;  // the window answers for positions [win_lo, win_end)
     // the request's exclusions (CacheMissExcludeSet, :4740-4743): the model's, then the late-bound ones of the request
     auto clear_at = [&](int e) {
+        if (__ballot(e >= 0) == 0) return;  // a slot no decision of this wavefront uses (most of the ten): one compare
         const int j = (e >> 6) - w0;
         if (e >= 0 && j >= 0 && j < nw) {
             const unsigned long long m = ~(1ull << (e & 63));
