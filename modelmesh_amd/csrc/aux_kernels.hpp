@@ -143,25 +143,29 @@ struct EvictArgs {
 // AddTask.run → evictionDeque.insert → evict()
 // (clhm/ConcurrentLinkedHashMap.java:590-611,329-352; clhm/LinkedDeque.java:259-288).
 // A pod's deque holds ~2M/P entries (20 at C3), so a whole wavefront per evaluation leaves two thirds of
-// the lanes idle (measured: 39 us per 100k evaluations, VALU-issue bound).  Four evaluations share a
-// wavefront instead, 16 lanes each: the team's slice of a ballot finds the insertion point, a 16-lane
-// prefix sum of the merged weight sequence finds the victim count.
-constexpr int kEvTeam = 16;
+// the lanes idle (measured: 39 us per 100k evaluations, VALU-issue bound).  Several evaluations share a
+// wavefront instead, TEAM lanes each: the team's slice of a ballot finds the insertion point, a TEAM-lane
+// prefix sum of the merged weight sequence finds the victim count.  TEAM = 16 (four evaluations per wavefront)
+// or 8 (eight): the host picks 8 while the mean deque is short (<= 24 entries: three trips of 8 instead of two
+// of 16, for twice the evaluations per wavefront and a scan of three steps instead of four).
 constexpr int kEvBlock = 256;
-constexpr int kEvPerBlock = kEvBlock / kEvTeam;
 
+template <int TEAM>
 __device__ __forceinline__ int64_t team_sum_i64(int64_t v)
 {
     const int lane = lane_id();
 #pragma unroll
-    for (int o = kEvTeam / 2; o > 0; o >>= 1) v += (int64_t)shfl_u64((uint64_t)v, lane ^ o);
+    for (int o = TEAM / 2; o > 0; o >>= 1) v += (int64_t)shfl_u64((uint64_t)v, lane ^ o);
     return v;
 }
 
+template <int TEAM>
 __global__ __launch_bounds__(kEvBlock) void evict_batch_kernel(EvictArgs A)
 {
+    constexpr int kEvTeam = TEAM;
+    constexpr uint32_t kTeamMask = (1u << TEAM) - 1u;
     const int lane = lane_id();
-    const int team = lane >> 4, tl = lane & (kEvTeam - 1), tbase = team * kEvTeam;
+    const int team = lane / kEvTeam, tl = lane & (kEvTeam - 1), tbase = team * kEvTeam;
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) / kEvTeam;
     const bool in_range = i < A.n;
     mmp_evict_req r;
@@ -193,11 +197,11 @@ __global__ __launch_bounds__(kEvBlock) void evict_batch_kernel(EvictArgs A)
     for (int base = 0; base < emax; base += kEvTeam) {
         const int j = base + tl;
         const bool le = j < E && lu[j] <= ts;
-        const uint32_t tb = (uint32_t)(__ballot(le) >> tbase) & 0xffffu;
+        const uint32_t tb = (uint32_t)(__ballot(le) >> tbase) & kTeamMask;
         if (tb) pos = base + (31 - __clz(tb)) + 1;
         sum += j < E ? (int64_t)wt[j] : 0;
     }
-    sum = team_sum_i64(sum);
+    sum = team_sum_i64<TEAM>(sum);
     const int64_t total = sum + (int64_t)r.weight;  // weightedSize + weight, clhm :603
 
     // evict(): poll the head while weightedSize > capacity
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(kEvBlock) void evict_batch_kernel(EvictArgs A)
             if (tl >= o2) incl += t;
         }
         const int64_t left = total - (carry + incl);
-        const uint32_t tb = (uint32_t)(__ballot(!done && j <= E && left <= cap) >> tbase) & 0xffffu;
+        const uint32_t tb = (uint32_t)(__ballot(!done && j <= E && left <= cap) >> tbase) & kTeamMask;
         const int l = tb ? __ffs(tb) - 1 : 0;
         const int64_t left_at = (int64_t)shfl_u64((uint64_t)left, tbase + l);
         const int64_t last_incl = (int64_t)shfl_u64((uint64_t)incl, tbase + kEvTeam - 1);

@@ -221,6 +221,7 @@ struct mmp_ctx {
     // eviction caches
     DevBuf c_seg, c_lu, c_wt, c_cap;
     int32_t n_caches = 0;
+    int64_t cache_entries = 0;  // entries of all deques loaded by mmp_caches_load (picks the eviction kernel's team size)
 
     // stateful keyed caches (mmp_caches_load_keyed / mmp_cache_replay): two layouts, ping-pong
     struct KeyedStore {
@@ -3486,12 +3487,24 @@ try {
     }
     if (n_caches) HIP_TRY(c, copy_sync(c, c->c_cap.p, capacity, (size_t)n_caches * 8, hipMemcpyHostToDevice));
     c->n_caches = n_caches;
+    c->cache_entries = E;
     return MMP_OK;
 } catch (const std::bad_alloc &) {
     return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_caches_load");
 } catch (const std::exception &e) {
     return fail(c, MMP_EHIP, "%s: %s", "mmp_caches_load", e.what());
 }
+
+namespace {
+// eight lanes per evaluation while the deques are short, sixteen otherwise (aux_kernels.hpp)
+void evict_launch(mmp_ctx *c, const EvictArgs &A, int32_t n, hipStream_t st)
+{
+    if (c->cache_entries <= (int64_t)24 * std::max(c->n_caches, 1))
+        hipLaunchKernelGGL(evict_batch_kernel<8>, dim3(div_up(n, kEvBlock / 8)), dim3(kEvBlock), 0, st, A);
+    else
+        hipLaunchKernelGGL(evict_batch_kernel<16>, dim3(div_up(n, kEvBlock / 16)), dim3(kEvBlock), 0, st, A);
+}
+}  // namespace
 
 int mmp_evict_batch(mmp_ctx *c, const mmp_evict_req *reqs, int32_t n, int64_t now, mmp_evict_out *outs)
 try {
@@ -3516,7 +3529,7 @@ try {
             A.n_caches = c->n_caches;
             A.now = now;
             A.done = DoneFlag{f->done, f->blocks, ++f->seq};
-            hipLaunchKernelGGL(evict_batch_kernel, dim3(div_up(n, kEvPerBlock)), dim3(kEvBlock), 0, f->stream, A);
+            evict_launch(c, A, n, f->stream);
             HIP_TRY(c, hipGetLastError());
         }
         HIP_TRY(c, slot_wait(f));
@@ -3546,7 +3559,7 @@ try {
     A.now = now;
     A.done = DoneFlag{nullptr, nullptr, 0};
     KT_BEGIN(c, st);
-    hipLaunchKernelGGL(evict_batch_kernel, dim3(div_up(n, kEvPerBlock)), dim3(kEvBlock), 0, st, A);
+    evict_launch(c, A, n, st);
     KT_END(c, st);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(outs, c->s_outs.p, (size_t)n * sizeof(mmp_evict_out), hipMemcpyDeviceToHost, st));

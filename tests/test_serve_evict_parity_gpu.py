@@ -85,12 +85,15 @@ def test_serve_target_matches_oracle(seed):
             assert got[i]["chosen_load_start"] == ts, (i, got[i], ch, ts)
 
 
+@pytest.mark.parametrize("short", [False, True])
 @pytest.mark.parametrize("seed", range(4))
-def test_eviction_victims_match_oracle(seed):
+def test_eviction_victims_match_oracle(seed, short):
     rng = np.random.default_rng(2000 + seed)
     now = wl.NOW_MS
     n_caches = 40
-    sizes = rng.choice([0, 1, 2, 20, 63, 64, 65, 130, 400], n_caches)
+    # the kernel runs 16 lanes per evaluation, or 8 while the mean deque holds <= 24 entries: both, with deque lengths
+    # around the team sizes and their multiples
+    sizes = rng.choice([0, 1, 2, 7, 8, 9, 15, 16, 17, 20, 23, 33] if short else [0, 1, 2, 20, 63, 64, 65, 130, 400], n_caches)
     seg_off = np.zeros(n_caches + 1, np.int32)
     np.cumsum(sizes, out=seg_off[1:])
     lu = np.zeros(seg_off[-1], np.int64)
