@@ -56,6 +56,25 @@ def kernel_bytes(fleet, reqs) -> int:
     return int(per.sum())
 
 
+def make_step_batch(fleet, seeds):
+    """One step's batch: a request set (one load-target decision per model, wl.make_requests) per seed, concatenated;
+    the exclusion-pool offsets of a set move behind the pools of the sets before it.  Returns (requests, pool, length of
+    the first set's pool) — the first `fleet.n_models` requests with the first `length` pool entries are set 0 unchanged."""
+    from modelmesh_amd import workload as wl
+    parts, ex_parts, off = [], [], 0
+    for seed in seeds:
+        rq, ex = wl.make_requests(fleet, seed=seed)
+        if off:
+            rq = rq.copy()
+            rq["extra_off"] += off
+        parts.append(rq)
+        ex_parts.append(ex)
+        off += len(ex)
+    if len(parts) == 1:
+        return parts[0], ex_parts[0], len(ex_parts[0])
+    return np.concatenate(parts), np.concatenate(ex_parts), len(ex_parts[0])
+
+
 def measured_traffic(workload: str, decisions_per_launch: int):
     """HBM bytes per place_batch_kernel launch from the committed rocprofv3 PMC passes of this same
     command (profiles/rNN/pmc_place_batch_<workload>*.json, written by tools/pmc_summary.py); None if
@@ -593,19 +612,9 @@ def main():
     batches = []  # (reqs, extra) on the host, for the parity gate
     d_bufs = []   # device tensors, kept alive
     for b in range(n_batches):
-        parts, ex_parts, off = [], [], 0
-        for j in range(sets_per_step):  # every set has its own seed; its exclusion-pool offsets move behind the sets before it
-            rq, ex = wl.make_requests(fleet, seed=0xBE7C0 + 100_000 * rank + b * sets_per_step + j)
-            if off:
-                rq = rq.copy()
-                rq["extra_off"] += off
-            parts.append(rq)
-            ex_parts.append(ex)
-            off += len(ex)
+        rq, ex, pool0 = make_step_batch(fleet, [0xBE7C0 + 100_000 * rank + b * sets_per_step + j for j in range(sets_per_step)])
         if b == 0:
-            first_set_pool = len(ex_parts[0])
-        rq = parts[0] if sets_per_step == 1 else np.concatenate(parts)
-        ex = ex_parts[0] if sets_per_step == 1 else np.concatenate(ex_parts)
+            first_set_pool = pool0
         batches.append((rq, ex))
         d_bufs.append((torch.from_numpy(rq.view(np.uint8).reshape(-1)).to(dev),
                        torch.from_numpy(np.ascontiguousarray(ex if len(ex) else np.zeros(1, np.int32))).to(dev),

@@ -57,3 +57,26 @@ def test_algorithmic_bytes_follow_survey_8d():
     assert bench.algorithmic_bytes(fleet, reqs) == want
     assert bench.kernel_bytes(fleet, reqs) < want
     assert bench.HBM_PEAK_GBS == 8000.0
+
+
+def test_a_step_batch_of_several_request_sets_decides_like_its_sets():
+    """bench.make_step_batch concatenates request sets and moves their exclusion-pool offsets: the oracle's decisions on
+    the batch are the decisions on the sets, in order (what the GPU parity gate of bench.py then compares against)."""
+    import bench
+    from modelmesh_amd import workload as wl
+    from oracle.bind import OracleFleet
+    fleet = wl.make_fleet("C1")
+    seeds = [11, 12, 13]
+    rq, ex, pool0 = bench.make_step_batch(fleet, seeds)
+    assert len(rq) == 3 * fleet.n_models
+    orc = OracleFleet(fleet)
+    whole = orc.place(rq, ex, fleet.now)
+    for j, seed in enumerate(seeds):
+        r1, e1 = wl.make_requests(fleet, seed=seed)
+        if j == 0:
+            assert pool0 == len(e1) and np.array_equal(rq[:len(r1)], r1)
+        one = orc.place(r1, e1, fleet.now)
+        sl = whole[j * fleet.n_models:(j + 1) * fleet.n_models]
+        for f in ("chosen", "best", "n_candidates", "hash"):
+            assert np.array_equal(sl[f], one[f]), (j, f)
+    assert (rq["n_extra"] > 0).any(), "the sets carry late-bound exclusions, or the offsets were never exercised"
