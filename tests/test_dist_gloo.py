@@ -149,3 +149,55 @@ def test_two_rank_pod_axis_sharding_over_gloo():
         p.join(240)
         assert p.exitcode == 0
     assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, True), (1, True)]
+
+
+def _barrier_worker(rank, world, port, arr, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b = bench.NodeBarrier.create(rank, world, dist)
+        if b is None:
+            q.put((rank, "no barrier"))
+            return
+        bad = None
+        for i in range(1, 4001):
+            arr[rank] = i
+            if rank == i % world and i % 500 == 0:
+                import time
+                time.sleep(0.002)  # a straggler: the others have to wait for it
+            b.wait()
+            seen = [arr[r] for r in range(world)]
+            if min(seen) < i or max(seen) > i + 1:  # behind the barrier nobody is before it; nobody can be two ahead
+                bad = (i, seen)
+                break
+        dist.barrier()
+        b.close()
+        q.put((rank, bad))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_node_barrier_of_the_bench_holds_three_ranks_together():
+    """bench.NodeBarrier (the barrier of the timed region's brackets on one node): no rank passes barrier i before
+    every rank has reached it, over 4000 barriers with stragglers; the page in /dev/shm is gone afterwards."""
+    import glob
+
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, port = 3, _free_port()
+    arr = ctx.Array("q", world, lock=False)
+    procs = [ctx.Process(target=_barrier_worker, args=(r, world, port, arr, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert got == [(r, None) for r in range(world)], got
+    assert not glob.glob(f"/dev/shm/mmp_bench_barrier_{port}_*")
