@@ -74,7 +74,7 @@ class NodeBarrier:
         try:
             if int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) != world or not os.path.isdir("/dev/shm"):
                 return None
-            path = f"/dev/shm/mmp_bench_barrier_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+            path = f"/dev/shm/mmp_bench_barrier_{os.environ.get('MASTER_PORT', '0')}"  # one rendezvous port = one job on this node
             if rank == 0:
                 np.zeros(world * cls.STRIDE, np.int64).tofile(path)
             dist_mod.barrier()  # the file exists and is zeroed before anybody maps it
@@ -82,7 +82,11 @@ class NodeBarrier:
             mm = np.memmap(path, dtype=np.int64, mode="r+", shape=(world * cls.STRIDE,)) if ok else None
             flags = [None] * world
             dist_mod.all_gather_object(flags, bool(ok))  # all or nothing: a rank without the page sends everybody back to dist.barrier()
-            return cls(mm, rank, world, path) if all(flags) else None
+            if all(flags):
+                return cls(mm, rank, world, path)
+            if rank == 0 and ok:
+                os.unlink(path)
+            return None
         except Exception:
             return None
 

@@ -200,4 +200,4 @@ def test_node_barrier_of_the_bench_holds_three_ranks_together():
         assert p.exitcode == 0
     got = sorted(q.get(timeout=5) for _ in range(world))
     assert got == [(r, None) for r in range(world)], got
-    assert not glob.glob(f"/dev/shm/mmp_bench_barrier_{port}_*")
+    assert not glob.glob(f"/dev/shm/mmp_bench_barrier_{port}*")
