@@ -118,7 +118,8 @@ struct __attribute__((aligned(16))) TypeWin {
     int32_t valid;   // 0: every decision of this type takes lane_decide_r
     int32_t w0;      // first word of the window (the word of the type's first eligible position)
     int32_t nw;      // words of the window that exist (it is cut at the end of the table)
-    uint32_t flags;  // bit 1: the type has preferred instances (getPreferredInstances(type) != null)
+    uint32_t flags;  // bit 1: the type has preferred instances (getPreferredInstances(type) != null); bit 2: the precomputed
+                     // preference step does not apply (see build_wins_kernel)
     uint64_t E[kWinWords];   // elig words
     uint64_t Pm[kWinWords];  // pref words; all ones when the type has no preferred instances (D = E & Pm either way)
     uint64_t F[kWinWords];   // fullw words
@@ -322,7 +323,27 @@ __global__ __launch_bounds__(64) void build_wins_kernel(Snap S, TypeWin *__restr
         out->valid = (best0 != kNoPos && mono && nw > 0) ? 1 : 0;
         out->w0 = w0;
         out->nw = nw;
-        out->flags = has_pm ? 2u : 0u;
+        // The preference step of a decision whose best instance is not a preferred one (MM.java:4817-4888, case (a)) moves to
+        // the first preferred eligible position q provided no FULL eligible instance lies before it.  Without exclusions q is
+        // rowsP[0] for every decision of the type, and exclusions only remove instances: as long as rowsP[0] itself is not
+        // excluded it stays the first, and a stretch without full instances stays one.  Bit 2 says the shortcut does NOT
+        // hold for this type: no preferred eligible position in the window, or a full eligible instance before it.
+        uint32_t fl = has_pm ? 2u : 0u;
+        if (has_pm) {
+            int q = kNoPos;
+            for (int j = 0; j < nw && q == kNoPos; j++) {
+                const uint64_t v = E[w0 + j] & Pm[w0 + j];
+                if (v) q = (w0 + j) * 64 + (__ffsll((unsigned long long)v) - 1);
+            }
+            bool blocked = q == kNoPos || q >= hi;
+            for (int w = w0; !blocked && w <= (q >> 6); w++) {
+                uint64_t v = E[w] & S.fullw[w];
+                if (w == (q >> 6)) v &= (1ull << (q & 63)) - 1ull;  // positions before q
+                if (v) blocked = true;
+            }
+            if (blocked) fl |= 4u;
+        }
+        out->flags = fl;
     }
 }
 
@@ -1128,14 +1149,21 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
     int32_t best_idx = r0.orig;
     if ((hdr.w & 2) && !(r0.pos & kWinPosPreferred)) {
         if (best_is_full) return kLaneHeadMiss;  // case (b): per-candidate rpm, the wave path
-        // case (a): the first preferred pod, provided no full pod comes before it
-        const int q1 = first_in(dw, best0 + 1, win_end);
-        if (q1 == kNoPos) return kLaneHeadMiss;  // none in the window (or none at all: the replay list)
-        auto ewf = [&](int w) { return ew(w) & Wn.F[w - w0]; };
-        if (first_in(ewf, best0 + 1, q1) != kNoPos) return kLaneHeadMiss;
-        const int iq = rank_in(Wn.E, q1, true);
-        if (iq >= kWinRows) return kLaneHeadMiss;
-        const WinRow rq = Wn.rowsP[iq];
+        // case (a): the first preferred pod, provided no full pod comes before it.  The type's precomputed answer (rowsP[0],
+        // no full eligible instance before it: build_wins_kernel) holds unless this request excludes that very instance;
+        // the scans run only in wavefronts where some decision needs them.
+        WinRow rq = Wn.rowsP[0];
+        int q1 = rq.pos & kWinPosMask;
+        const bool pre = !(hdr.w & 4) && rq.pos >= 0 && q1 > best0 && q1 < win_end && ((ew(q1 >> 6) >> (q1 & 63)) & 1ull);
+        if (!pre) {
+            q1 = first_in(dw, best0 + 1, win_end);
+            if (q1 == kNoPos) return kLaneHeadMiss;  // none in the window (or none at all: the replay list)
+            auto ewf = [&](int w) { return ew(w) & Wn.F[w - w0]; };
+            if (first_in(ewf, best0 + 1, q1) != kNoPos) return kLaneHeadMiss;
+            const int iq = rank_in(Wn.E, q1, true);
+            if (iq >= kWinRows) return kLaneHeadMiss;
+            rq = Wn.rowsP[iq];
+        }
         bestpos = q1;
         b_lru = rq.lru;
         b_rem = rq.rem;
