@@ -431,7 +431,10 @@ int mmp_place_batch_dev(mmp_ctx *ctx, const void *d_reqs, int32_t n, const void 
  * a 64-byte store plus a tag, the answer a 16-byte row plus the tag.  It serves requests WITHOUT exclusions of their
  * own (n_extra = 0; the others, and the rare shapes that need the wave path, take the launch path transparently), holds
  * the published snapshot (a commit, registry event or cache-table load stops it and the next request starts a new one)
- * and leaves the GPU by itself after MMP_RESIDENT_IDLE_MS (default 50) without a request.  Results are bit-identical. */
+ * and leaves the GPU by itself after MMP_RESIDENT_IDLE_MS (default 50) without a request.  Results are bit-identical.
+ * Two guards: eight hand-backs to the launch path in a row send the next 4096 single requests there directly (a table on
+ * which most decisions need the wave path), and three answers in a row slower than 20 ms from a kernel that was not
+ * restarted meanwhile switch the resident path off for the context (mmp_last_error says so). */
 int mmp_resident(mmp_ctx *ctx, int enable);
 int mmp_resident_stats(mmp_ctx *ctx, uint64_t *launches, uint64_t *served, uint64_t *punted);
 /* Submission threads.  One host thread spends ~3 us in HIP's launch path per kernel — more than a 100k-decision batch
