@@ -187,7 +187,18 @@ def cpu_baseline(fleet, reqs, extra, budget_s: float = 6.0):
                   "not the JVM",
         "single_thread_value": out["single"],
         "p50_us": float(np.percentile(lat, 50) / 1e3), "p99_us": float(np.percentile(lat, 99) / 1e3),
+        # what the container may actually use of the box's hardware threads: the all-thread figure scales with THIS, not with `cores`
+        "cgroup_cpu_limit": _cgroup_cpu_limit(), "affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
     }
+
+
+def _cgroup_cpu_limit():
+    """CPUs' worth of time the container's cgroup grants (cpu.max quota / period); None: unlimited or not readable"""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except Exception:
+        return None
 
 
 def pod_axis_leg(workload: str, rank: int, world: int, dev, steps: int, warmup: int, fence):
