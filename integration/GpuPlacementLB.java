@@ -148,8 +148,13 @@ interface GpuMeshBinding {
 class GpuCacheMissLB extends ModelMesh.IdBasedLoadBalancer {
     static final int MAX_LIVE_RETRIES = 8;
     final GpuMeshBinding mesh;
-    /** filled by every call for the shadow harness: the result row of the last decision of this thread */
-    final int[] lastOut = new int[4];
+    /**
+     * The result row (chosen, best, n_candidates, hash) of the last decision OF THE CALLING THREAD, for the shadow harness.
+     * litelinks shares one LB instance across all request threads (which is why the reference keeps its request state in
+     * ThreadLocals, ModelMesh.java:4755), so nothing a decision produces may live in a field of the LB.
+     */
+    private static final ThreadLocal<int[]> LAST_OUT = ThreadLocal.withInitial(() -> new int[4]);
+    int[] lastOut() { return LAST_OUT.get(); }
 
     GpuCacheMissLB(GpuMeshBinding mesh) { this.mesh = mesh; }
 
@@ -191,8 +196,9 @@ class GpuCacheMissLB extends ModelMesh.IdBasedLoadBalancer {
 
         ByteBuffer o = OUT.get();
         MmPlace.placeBatch(mesh.handle(), q, 1, x, nExtra, nowMs, o); // throws IllegalStateException on error
-        for (int i = 0; i < 4; i++) lastOut[i] = o.getInt(4 * i);     // chosen, best, n_candidates, hash
-        return lastOut[0];
+        final int[] last = LAST_OUT.get();
+        for (int i = 0; i < 4; i++) last[i] = o.getInt(4 * i);        // chosen, best, n_candidates, hash
+        return o.getInt(0);  // read from this thread's own OUT buffer, never from shared state
     }
 
     @SuppressWarnings("unchecked")
@@ -235,7 +241,9 @@ class GpuCacheMissLB extends ModelMesh.IdBasedLoadBalancer {
  */
 class GpuForwardingLB extends ModelMesh.IdBasedLoadBalancer {
     final GpuMeshBinding mesh;
-    final long[] lastOut = new long[2];  // chosen, chosen_load_start of this thread's last decision
+    /** chosen, chosen_load_start of the calling thread's last decision (one LB instance serves every request thread) */
+    private static final ThreadLocal<long[]> LAST_OUT = ThreadLocal.withInitial(() -> new long[2]);
+    long[] lastOut() { return LAST_OUT.get(); }
 
     GpuForwardingLB(GpuMeshBinding mesh) { this.mesh = mesh; }
 
@@ -293,9 +301,10 @@ class GpuForwardingLB extends ModelMesh.IdBasedLoadBalancer {
         q.putInt(0); q.putInt(nExcl);                   // excl_off, n_excl
         ByteBuffer o = OUT.get();
         MmPlace.serveBatch(mesh.handle(), q, 1, inUse, lastUsed, ep, et, nExcl, nowMs, o);
-        lastOut[0] = o.getInt(0);
-        lastOut[1] = o.getLong(8);
-        return (int) lastOut[0];
+        final long[] last = LAST_OUT.get();
+        last[0] = o.getInt(0);
+        last[1] = o.getLong(8);
+        return o.getInt(0);
     }
 
     @SuppressWarnings("unchecked")
@@ -312,7 +321,7 @@ class GpuForwardingLB extends ModelMesh.IdBasedLoadBalancer {
         if (mesh.sendDestinationId()) {                                               // :4386-4388
             ModelMesh.ensureContextMapIsMutable(ThreadContext.getCurrentContext()).put(ModelMesh.DEST_INST_ID_KEY, chosenId);
         }
-        filtered.add(chosenId, lastOut[1]);                                           // :4389
+        filtered.add(chosenId, LAST_OUT.get()[1]);                                    // :4389 (this thread's own decision)
         return (T) siMap.get(chosenId);
     }
 }
@@ -363,7 +372,7 @@ class ShadowCacheMissLB extends ModelMesh.IdBasedLoadBalancer {
                 final long now = System.currentTimeMillis();
                 final Set<String> none = java.util.Collections.emptySet();
                 int first = gpu.decide(siMap, exclude, none, 0, now);
-                final int nCand = Math.max(gpu.lastOut[2], 1);
+                final int nCand = Math.max(gpu.lastOut()[2], 1);
                 possible = new HashSet<>();
                 for (int j = 0, picks = 4 * nCand; j < picks; j++) {
                     int c = j == 0 ? first : gpu.decide(siMap, exclude, none, (int) ((((long) j) << 32) / picks), now);

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <shared_mutex>
 #include <thread>
@@ -134,7 +135,11 @@ struct mmp_ctx {
     // the state lock: decision paths that only capture the published pointers and enqueue take it SHARED (so that the
     // submission threads of mmp_issue_threads launch concurrently), whoever changes what they capture takes it exclusive
     std::shared_mutex mu;
-    struct IssuePool *pool = nullptr;  // submission threads (mmp_issue_threads); null: launches are issued by the caller
+    // submission threads (mmp_issue_threads); null: launches are issued by the caller.  Read and swapped under pool_mu
+    // (a leaf lock): a submitter keeps its own reference for the duration of its call, so mmp_issue_threads(ctx, 0 / n)
+    // on another thread cannot free the rings underneath it
+    std::shared_ptr<struct IssuePool> pool;
+    std::mutex pool_mu;
     // the resident decision kernel for single requests (place_kernel.hpp: place_resident_kernel; mmp_resident)
     struct Resident {
         bool enabled = false, running = false;
@@ -2170,21 +2175,35 @@ struct RcclApi {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
 };
-RcclApi *rccl_api()
+// why_out: receives the reason when the call returns null (copied out under the binding's lock).
+// MMP_RCCL_PATH=<file> names the one library to bind (a host with its own RCCL build; also how the tests reach the
+// "no RCCL on this host" answer on a box that has one).
+RcclApi *rccl_api(std::string *why_out = nullptr)
 {
     static std::mutex mu;
     static RcclApi api;
     std::lock_guard<std::mutex> g(mu);
     if (api.h) return &api;
-    const char *names[] = {"librccl.so.1", "librccl.so"};
-    for (int pass = 0; pass < 2 && !api.h; pass++)
-        for (const char *nm : names) {
-            api.h = dlopen(nm, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
-            if (api.h) break;
-        }
-    if (!api.h) api.h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+    struct Why {  // the reason leaves with every null return, whichever one it is
+        RcclApi &a;
+        std::string *out;
+        ~Why() { if (out && !a.h) *out = a.why; }
+    } why_guard{api, why_out};
+    const char *only = getenv("MMP_RCCL_PATH");
+    if (only && *only) {
+        api.h = dlopen(only, RTLD_NOW | RTLD_LOCAL);
+    } else {
+        const char *names[] = {"librccl.so.1", "librccl.so"};
+        for (int pass = 0; pass < 2 && !api.h; pass++)
+            for (const char *nm : names) {
+                api.h = dlopen(nm, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                if (api.h) break;
+            }
+        if (!api.h) api.h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+    }
     if (!api.h) {
-        api.why = dlerror() ? dlerror() : "librccl.so not found";
+        const char *e = dlerror();  // ONE call: dlerror() clears the message it returns
+        api.why = e ? e : "librccl.so not found";
         return nullptr;
     }
     api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.h, "ncclGetUniqueId"));
@@ -2254,8 +2273,9 @@ int group_general(mmp_ctx *c, const void *d_reqs, int32_t n, const int32_t *n_de
 int mmp_shard_unique_id(void *id_out)
 {
     if (!id_out) return fail(nullptr, MMP_EINVAL, "mmp_shard_unique_id: null argument");
-    RcclApi *R = rccl_api();
-    if (!R) return fail(nullptr, MMP_ENODEVICE, "RCCL is not available: %s", RcclApi().why.c_str());
+    std::string why;
+    RcclApi *R = rccl_api(&why);
+    if (!R) return fail(nullptr, MMP_ENODEVICE, "RCCL is not available: %s", why.c_str());
     ncclUniqueId id;
     RCCL_TRY(nullptr, R->GetUniqueId(&id));
     memcpy(id_out, &id, sizeof id);
@@ -2270,8 +2290,9 @@ try {
     if (c->group) return fail(c, MMP_ESTATE, "mmp_shard_group_init: the context already belongs to a group");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     if (unique_id) {
-        RcclApi *R = rccl_api();
-        if (!R) return fail(c, MMP_ENODEVICE, "RCCL is not available on this host");
+        std::string why;
+        RcclApi *R = rccl_api(&why);
+        if (!R) return fail(c, MMP_ENODEVICE, "RCCL is not available on this host: %s", why.c_str());
         ncclUniqueId id;
         memcpy(&id, unique_id, sizeof id);
         RCCL_TRY(c, R->CommInitRank(&c->comm, world, id, rank));
@@ -2347,11 +2368,25 @@ try {
  * no host round trip sits between the kernels and every collective has a size the host knows) -> scatter.  Only
  * when more decisions than that capacity need the six phases — the host learns it with the results — are they run
  * again at their exact size. */
+namespace {
+int shard_place_batch_locked(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs, int32_t *n_rest_out);
+}
 int mmp_shard_place_batch_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs,
                               int32_t *n_rest_out)
 try {
     if (!c || n < 0 || (n > 0 && (!d_reqs || !d_outs))) return fail(c, MMP_EINVAL, "mmp_shard_place_batch_dev: bad argument");
     std::lock_guard<std::mutex> gg(c->group_mu);
+    return shard_place_batch_locked(c, d_reqs, n, d_extra, now, d_outs, n_rest_out);
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shard_place_batch_dev");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_shard_place_batch_dev", e.what());
+}
+
+namespace {
+// the body of mmp_shard_place_batch(_dev); the caller holds c->group_mu (and nothing that is ordered behind it)
+int shard_place_batch_locked(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs, int32_t *n_rest_out)
+{
     if (!c->group) return fail(c, MMP_ESTATE, "mmp_shard_place_batch_dev: call mmp_shard_group_init first");
     if (n_rest_out) *n_rest_out = 0;
     if (n == 0) return MMP_OK;
@@ -2387,11 +2422,8 @@ try {
     }
     if (n_rest_out) *n_rest_out = n_rest;
     return MMP_OK;
-} catch (const std::bad_alloc &) {
-    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shard_place_batch_dev");
-} catch (const std::exception &e) {
-    return fail(c, MMP_EHIP, "%s: %s", "mmp_shard_place_batch_dev", e.what());
 }
+}  // namespace
 
 /* The same with host pointers (what a JVM holds): staged through the context's scratch. */
 int mmp_shard_place_batch(mmp_ctx *c, const mmp_place_req *reqs, int32_t n, const int32_t *extra_pool, int32_t n_extra,
@@ -2404,6 +2436,9 @@ try {
             return fail(c, MMP_EINVAL, "mmp_shard_place_batch: request %d extra range out of bounds", i);
     if (n_rest_out) *n_rest_out = 0;
     if (n == 0) return MMP_OK;
+    // lock order of the group entry points: group_mu, then batch_mu (mmp_shard_commit and mmp_shard_group_init take
+    // batch_mu through the calls they make while holding group_mu)
+    std::lock_guard<std::mutex> gg(c->group_mu);
     std::lock_guard<std::mutex> gb(c->batch_mu);  // the staging scratch
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     HIP_TRY(c, c->s_reqs.ensure((size_t)n * sizeof(mmp_place_req)));
@@ -2411,7 +2446,7 @@ try {
     HIP_TRY(c, c->s_extra.ensure((size_t)std::max(n_extra, 1) * 4));
     HIP_TRY(c, hipMemcpyAsync(c->s_reqs.p, reqs, (size_t)n * sizeof(mmp_place_req), hipMemcpyHostToDevice, c->stream));
     if (n_extra) HIP_TRY(c, hipMemcpyAsync(c->s_extra.p, extra_pool, (size_t)n_extra * 4, hipMemcpyHostToDevice, c->stream));
-    const int rc = mmp_shard_place_batch_dev(c, c->s_reqs.p, n, c->s_extra.p, now, c->s_outs.p, n_rest_out);
+    const int rc = shard_place_batch_locked(c, c->s_reqs.p, n, c->s_extra.p, now, c->s_outs.p, n_rest_out);
     if (rc != MMP_OK) return rc;
     HIP_TRY(c, copy_sync(c, outs, c->s_outs.p, (size_t)n * sizeof(mmp_place_out), hipMemcpyDeviceToHost));
     return MMP_OK;
@@ -2427,7 +2462,10 @@ try {
  * while they run, mmp_place_batch_dev only validates, appends a descriptor (tens of ns) and returns, and the helpers
  * launch in parallel — every caller stream is pinned to one helper, so launches on one stream keep their order.
  * mmp_issue_flush waits until everything submitted so far has been launched (and reports the first launch error);
- * every call that waits for decision streams (commit, registry events, mmp_stream_retire, mmp_destroy) flushes first. */
+ * mmp_stream_retire, mmp_issue_threads and mmp_destroy flush first.  A commit or a registry event does NOT (it holds
+ * the state lock the helpers launch under, and it need not): a helper captures the published snapshot when it launches,
+ * so a descriptor that is still in a ring when another snapshot is published is decided against that one, and the
+ * stream it is bound for was noted at submission, so whoever rewrites state afterwards waits for it. */
 struct IssueItem {
     const void *d_reqs, *d_extra;
     void *d_outs;
@@ -2446,6 +2484,12 @@ struct IssuePool {
     std::vector<std::thread> th;
     std::vector<IssueRing *> rings;
     std::atomic<bool> stop{false};
+    std::atomic<bool> closed{false};  // set (then every push_mu taken once) before the helpers are told to stop: a submitter
+                                      // that still holds a reference launches by itself instead of appending
+    ~IssuePool()
+    {
+        for (IssueRing *R : rings) delete R;
+    }
     std::atomic<int> first_rc{MMP_OK};
     std::mutex map_mu;
     std::vector<std::pair<hipStream_t, int>> stream_ring;  // caller stream -> helper, assigned round-robin at first sight
@@ -2490,14 +2534,25 @@ int issue_ring_of(IssuePool *P, hipStream_t st)
     return r;
 }
 
-// everything submitted so far has been handed to HIP (called without the state lock)
-int issue_flush(mmp_ctx *c)
+void pool_get(mmp_ctx *c, std::shared_ptr<IssuePool> &out)
 {
-    IssuePool *P = c->pool;
+    std::lock_guard<std::mutex> g(c->pool_mu);
+    out = c->pool;
+}
+
+// everything submitted so far has been handed to HIP (called without the state lock)
+int issue_flush_pool(IssuePool *P)
+{
     if (!P) return MMP_OK;
     for (IssueRing *R : P->rings)
         while (R->head.load(std::memory_order_acquire) != R->tail.load(std::memory_order_acquire)) __builtin_ia32_pause();
     return P->first_rc.exchange(MMP_OK);
+}
+int issue_flush(mmp_ctx *c)
+{
+    std::shared_ptr<IssuePool> P;
+    pool_get(c, P);
+    return issue_flush_pool(P.get());
 }
 }  // namespace
 
@@ -2505,20 +2560,28 @@ int mmp_issue_threads(mmp_ctx *c, int32_t n)
 try {
     if (!c || n < 0 || n > 64) return fail(c, MMP_EINVAL, "mmp_issue_threads: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
-    if (c->pool) {
-        const int rc = issue_flush(c);
-        c->pool->stop.store(true, std::memory_order_release);
-        for (std::thread &t : c->pool->th) t.join();
-        for (IssueRing *R : c->pool->rings) delete R;
-        delete c->pool;
-        c->pool = nullptr;
+    std::shared_ptr<IssuePool> old;
+    {
+        std::lock_guard<std::mutex> g(c->pool_mu);
+        old.swap(c->pool);  // new submitters launch by themselves from here on
+    }
+    if (old) {
+        old->closed.store(true, std::memory_order_release);
+        for (IssueRing *R : old->rings) std::lock_guard<std::mutex> barrier(R->push_mu);  // appends in flight have landed
+        const int rc = issue_flush_pool(old.get());
+        old->stop.store(true, std::memory_order_release);
+        for (std::thread &t : old->th) t.join();
+        old.reset();  // the rings go with the last reference (a submitter may still hold one; it sees `closed`)
         if (rc != MMP_OK) return rc;
     }
     if (n == 0) return MMP_OK;
-    IssuePool *P = new IssuePool();
+    auto P = std::make_shared<IssuePool>();
     for (int i = 0; i < n; i++) P->rings.push_back(new IssueRing());
-    for (int i = 0; i < n; i++) P->th.emplace_back(issue_helper, c, P, P->rings[i]);
-    c->pool = P;
+    for (int i = 0; i < n; i++) P->th.emplace_back(issue_helper, c, P.get(), P->rings[i]);
+    {
+        std::lock_guard<std::mutex> g(c->pool_mu);
+        c->pool = P;
+    }
     return MMP_OK;
 } catch (const std::bad_alloc &) {
     return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_issue_threads");
@@ -2712,10 +2775,12 @@ int mmp_place_batch_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d
                         void *stream)
 try {
     if (!c || n < 0 || (n > 0 && (!d_reqs || !d_outs))) return fail(c, MMP_EINVAL, "mmp_place_batch_dev: bad argument");
-    if (IssuePool *P = c->pool) {  // submission threads: append and return
+    std::shared_ptr<IssuePool> P;
+    pool_get(c, P);
+    if (P) {  // submission threads: append and return
         if (n == 0) return MMP_OK;
         hipStream_t st = static_cast<hipStream_t>(stream);
-        IssueRing *R = P->rings[issue_ring_of(P, st)];
+        IssueRing *R = P->rings[issue_ring_of(P.get(), st)];
         {
             std::shared_lock<std::shared_mutex> g(c->mu);
             if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
@@ -2723,11 +2788,14 @@ try {
             note_caller_stream(c, st);
         }
         std::lock_guard<std::mutex> gp(R->push_mu);
-        const uint32_t t = R->tail.load(std::memory_order_relaxed);
-        while (t - R->head.load(std::memory_order_acquire) >= IssueRing::kCap) __builtin_ia32_pause();
-        R->items[t % IssueRing::kCap] = IssueItem{d_reqs, d_extra, d_outs, st, now, n};
-        R->tail.store(t + 1, std::memory_order_release);
-        return MMP_OK;
+        if (!P->closed.load(std::memory_order_acquire)) {
+            const uint32_t t = R->tail.load(std::memory_order_relaxed);
+            while (t - R->head.load(std::memory_order_acquire) >= IssueRing::kCap) __builtin_ia32_pause();
+            R->items[t % IssueRing::kCap] = IssueItem{d_reqs, d_extra, d_outs, st, now, n};
+            R->tail.store(t + 1, std::memory_order_release);
+            return MMP_OK;
+        }
+        // the pool was retired while this call held its reference: launch here, like a context without helpers
     }
     std::shared_lock<std::shared_mutex> g(c->mu);  // capture the published snapshot + enqueue; no wait
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");

@@ -1792,6 +1792,9 @@ __global__ __launch_bounds__(64) void place_resident_kernel(Snap S, PlaceArgs A,
 #pragma unroll
         for (int k = 0; k < 8; k++) w[k] = __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         bell = __hip_atomic_load(&slot->bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // the stop word rides in EVERY sweep (one more read in flight, the same address for all lanes): with request threads
+        // ringing back to back no sweep is ever empty, and a commit that waits for this kernel holds the state lock
+        const bool leave = __ballot(__hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == generation) != 0;  // wave-uniform
         const uint32_t tag = (uint32_t)(bell >> kResidentNowBits);
         const bool fresh = tag != seen;
         if (__ballot(fresh)) {
@@ -1835,10 +1838,10 @@ __global__ __launch_bounds__(64) void place_resident_kernel(Snap S, PlaceArgs A,
                 seen = tag;
             }
             last = wall_clock64();
+            if (leave) break;  // this sweep's requests are answered; whoever rings now sees `exited` and relaunches
         } else {
-            // nobody rang: look at the stop word now and then, leave when idle for long
-            const uint32_t stop = __hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (stop == generation || wall_clock64() - last > idle_ticks) break;
+            // nobody rang: leave when told to, or when idle for long
+            if (leave || wall_clock64() - last > idle_ticks) break;
             __builtin_amdgcn_s_sleep(1);
         }
     }
