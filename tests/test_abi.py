@@ -119,3 +119,26 @@ def test_c_host_places_one_model(tmp_path):
     r = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "best=1" in r.stdout
+
+
+def test_a_host_without_rccl_gets_an_error_code_and_the_reason():
+    """ADVICE r2: the dlopen binding used to read dlerror() twice (the second call returns NULL: std::string from
+    nullptr, a crash) and reported the reason of a fresh, empty object.  MMP_RCCL_PATH names the one library to bind;
+    a path that does not exist is a host without RCCL."""
+    import subprocess
+    import sys
+    _ensure_built()
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from modelmesh_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "buf = C.create_string_buffer(128)\n"
+        "rc = lib.mmp_shard_unique_id(buf)\n"
+        "print(rc, lib.mmp_last_error(None).decode())\n" % ROOT)
+    env = dict(os.environ, MMP_RCCL_PATH="/nonexistent/librccl-not-here.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rc, msg = out.stdout.strip().split(" ", 1)
+    assert int(rc) == _lib.MMP_ENODEVICE
+    assert "RCCL is not available" in msg and "librccl-not-here" in msg
