@@ -1,0 +1,13 @@
+#!/bin/bash
+# Builds oracle/_ref/ref_harness: the reference's own load-target / serve-target method bodies (extracted by line range
+# from /root/reference at build time, never committed) compiled against the stand-ins of javastub.hpp.
+# Needs the reference tree (this container; the GPU box has none and only consumes tests/golden/ref_*.npz).
+set -euo pipefail
+here=$(cd "$(dirname "$0")" && pwd)
+out="$here/../_ref"
+mkdir -p "$out/gen"
+python3 "$here/extract.py" > "$out/gen/extract.log"
+# -fwrapv: Java integer arithmetic wraps; -fno-strict-aliasing is not needed (no type punning in the stand-ins)
+g++ -std=c++17 -O1 -g -fwrapv -Wall -Wno-unused-variable -Wno-unused-function -Wno-parentheses -Wno-unused-but-set-variable \
+    "$here/harness.cc" -o "$out/ref_harness"
+echo "built $out/ref_harness from: $(tr '\n' ';' < "$out/gen/MANIFEST.txt")"

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Reference-text extractor of the `oracle/_ref` harness (test infrastructure, never shipped).
+
+The reference is Java and neither box has a JDK (profiles/r3/jdk_probe_*.txt), so its load-target / serve-target
+selection cannot be RUN as Java.  What can be done: take the reference's own method bodies, verbatim by line range, from
+where they lie under /root/reference, and compile THAT TEXT with g++ against a small header of stand-ins for the Java /
+Guava / eclipse-collections / litelinks types it names (javastub.hpp).  The decision logic that executes is then the
+reference's own statements, in its own order, with its own constants — not a restatement.
+
+Nothing of the reference is copied into the repository: this script writes the extracted text into oracle/_ref/gen/
+(git-ignored, rebuilt from /root/reference by build.sh each time).
+
+What the rewrite does to the text is TOKEN-LEVEL ONLY, listed exhaustively in RULES below; every rule is a syntax
+difference between Java and C++, none knows anything about placement.  After rewriting, the script checks that every
+non-blank source line of every range survives in the output up to those rules (same count of lines).
+"""
+import os
+import re
+import sys
+
+REF = os.environ.get("MMP_REFERENCE", "/root/reference")
+MM = "src/main/java/com/ibm/watson/modelmesh/ModelMesh.java"
+IR = "src/main/java/com/ibm/watson/modelmesh/InstanceRecord.java"
+UT = "src/main/java/com/ibm/watson/modelmesh/Utils.java"
+
+# (output name, file, first line, last line, first line must contain, last line must contain): bodies only —
+# the enclosing Java declaration (generics on methods, annotations, anonymous classes) is supplied by harness.cc
+RANGES = [
+    ("isFull_body", MM, 4641, 4641, "return availableUnits < minSpaceUnits;", "minSpaceUnits"),
+    ("placement_order_compare_body", MM, 4649, 4701, "InstanceRecord ir1 = e1.getValue()", ".result();"),
+    ("isExcluded_body", MM, 4741, 4742, "return contains(instanceId)", "explicit.contains(instanceId)"),
+    ("filter_body", MM, 4763, 4771, "return Iterators.filter(clusterState.iterator()", "});"),
+    ("cachemiss_getNext_body", MM, 4777, 5003, "final CacheMissExcludeSet exclude = cacheMissExcludeTl.get();",
+     "return (T) siMap.get(chosenInstId);"),
+    ("forwarding_getNext_body", MM, 4316, 4391, "final MapFilteringSet<String, Long> filtered", "return (T) chosen;"),
+    ("mapfilteringset_apply_body", MM, 4282, 4282, "return !containsKey(input)", "keyExcludes.contains"),
+    ("age_body", MM, 4163, 4163, "return timeMillis == 0 ? 0L", "currentTimeMillis() - timeMillis"),
+    ("getRemaining_body", IR, 204, 204, "return Math.max(0L, capacity - used);", "capacity - used"),
+    ("string_array_comp_body", UT, 26, 35, "int diff = l1.length - l2.length;", "return 0;"),
+    ("lb_constants", MM, 4751, 4753, "TWELVE_MIN_MS = MILLISECONDS.convert(12, MINUTES);", "FIVE_DAYS_MS = MILLISECONDS.convert(5, DAYS);"),
+]
+
+# token-level rewrites, applied in order to every extracted line
+RULES = [
+    # Java numeric literals may carry underscores: 120_000L -> 120000L
+    (re.compile(r"\b\d+(?:_\d+)+L?\b"), lambda m: m.group(0).replace("_", "")),
+    # `final` on locals has no C++ counterpart that matters here
+    (re.compile(r"\bfinal\s+"), ""),
+    # object creation: `new ArrayList<>(n)` / `new IntArrayList(n)` -> factory calls of the stand-ins (the diamond's type
+    # argument is inferred from the declaration on the left, as in Java)
+    (re.compile(r"\bnew\s+ArrayList<>\("), "ArrayList_new("),
+    (re.compile(r"\bnew\s+IntArrayList\("), "IntArrayList_new("),
+    # lambdas: `ent -> {` (a Java lambda captures effectively-final locals by value; here: copies of handles)
+    (re.compile(r"\b(\w+)\s*->\s*\{"), r"[=](auto \1) {"),
+    # wildcard generics do not exist in C++: ServiceInstance<?> -> ServiceInstance
+    (re.compile(r"<\?>"), ""),
+    # the narrowing primitive conversion (int) of a parenthesised double expression saturates in Java (JLS 5.1.3) and is
+    # undefined on overflow in C++: route it through a function with the Java semantics
+    (re.compile(r"\(int\)\s*\("), "J2I("),
+    # a Java array's length is a field, a C++ stand-in needs a call
+    (re.compile(r"\.length\b(?!\()"), ".length()"),
+    # `explicit` (a field of CacheMissExcludeSet) is a C++ keyword
+    (re.compile(r"\bexplicit\b"), "explicit_"),
+    # static members of the boxed types: Long.compare / Long.MAX_VALUE / Integer.MAX_VALUE (Long is also a type argument,
+    # Map<String, Long>, so it has to be a class on the C++ side)
+    (re.compile(r"\b(Long|Integer)\.(?=[A-Za-z])"), r"\1::"),
+    # member modifiers in front of the three constant declarations
+    (re.compile(r"^\s*protected\s+static\s+"), ""),
+]
+
+
+def extract():
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_ref", "gen")
+    os.makedirs(out_dir, exist_ok=True)
+    manifest = []
+    for name, rel, a, b, must_first, must_last in RANGES:
+        path = os.path.join(REF, rel)
+        lines = open(path, encoding="utf-8").read().split("\n")
+        body = lines[a - 1:b]
+        if must_first not in body[0] or must_last not in body[-1]:
+            sys.exit(f"extract.py: {rel}:{a}-{b} is not the text this harness was written against "
+                     f"(expected {must_first!r} ... {must_last!r}); the reference moved — fix RANGES")
+        out = []
+        for ln in body:
+            for rx, rep in RULES:
+                ln = rx.sub(rep, ln)
+            out.append(ln)
+        assert len(out) == len(body)
+        with open(os.path.join(out_dir, name + ".inc"), "w", encoding="utf-8") as f:
+            f.write(f"// GENERATED by oracle/ref_harness/extract.py from {rel}:{a}-{b} — reference text, do not commit\n")
+            f.write("\n".join(out) + "\n")
+        manifest.append(f"{name}: {rel}:{a}-{b} ({len(body)} lines)")
+    with open(os.path.join(out_dir, "MANIFEST.txt"), "w") as f:
+        f.write("\n".join(manifest) + "\n")
+    return manifest
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit(f"extract.py: no reference tree at {REF}")
+    for m in extract():
+        print(m)

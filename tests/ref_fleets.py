@@ -1,0 +1,158 @@
+"""Fleets and requests of the reference-text vectors (tests/golden/ref_getnext.npz): built here, deterministically from
+seeds, so that the generator (oracle/ref_harness/make_ref_vectors.py — needs /root/reference) and the tests that consume
+the committed vectors (CPU: the oracle; GPU: the HIP path) construct byte-identical inputs.  A digest of the inputs is stored
+with the vectors and checked by the tests.
+
+The harness runs the reference's own Java text, which orders instances by their id STRINGS (String.compareTo, MM.java:4696)
+and derives the replica set from id.substring(0, 6) (MM.java:4770).  The fuzz fleets of modelmesh_amd.workload draw
+`id_order` and `replica_set` independently, which no set of strings can realise — so every fleet here first gets real ids
+("%06x-..." prefixes per replica set, short ids for instances without one) and `id_order` := the rank of its id, and
+the registry entries (instanceIds / loadFailedInstanceIds iterate in id order) are re-sorted accordingly."""
+from __future__ import annotations
+
+import hashlib
+import struct
+
+import numpy as np
+
+from modelmesh_amd import _lib
+from modelmesh_amd import workload as wl
+
+B36 = "0123456789abcdefghijklmnopqrstuvwxyz"
+
+
+def _b36(i: int, width: int) -> str:
+    s = ""
+    for _ in range(width):
+        s = B36[i % 36] + s
+        i //= 36
+    return s
+
+
+def string_ids(fleet, seed: int):
+    """Give every instance an id consistent with its replica set; id_order := String.compareTo rank; registry entries re-sorted."""
+    rng = np.random.default_rng(0x1D5 + seed)
+    P = fleet.n_pods
+    tag = rng.permutation(P)  # decouples the id order from the pod index
+    ids = []
+    for p in range(P):
+        rs = int(fleet.pods["replica_set"][p])
+        ids.append(f"{rs:06x}-{_b36(int(tag[p]), 5)}" if rs >= 0 else "s" + _b36(int(tag[p]), 4))  # |id| < 7: no replica set (:4769)
+    assert len(set(ids)) == P
+    order = sorted(range(P), key=lambda p: ids[p])  # ASCII: Python's str order == String.compareTo's
+    rank = np.empty(P, np.uint32)
+    rank[order] = np.arange(P, dtype=np.uint32)
+    fleet.pods["id_order"] = rank
+    # instanceIds (a TreeMap) and loadFailedInstanceIds iterate in id order
+    ep, et = fleet.ent_pod.copy(), fleet.ent_time.copy()
+    for m in fleet.models:
+        for a, k in ((int(m["ent_off"]), int(m["n_loaded"])), (int(m["ent_off"] + m["n_loaded"]), int(m["n_failed"]))):
+            if k > 1:
+                o = np.argsort(rank[fleet.ent_pod[a:a + k]], kind="stable")
+                ep[a:a + k], et[a:a + k] = fleet.ent_pod[a:a + k][o], fleet.ent_time[a:a + k][o]
+    fleet.ent_pod, fleet.ent_time = ep, et
+    return ids
+
+
+def place_cases():
+    """(name, fleet, ids, reqs, extra): the fuzz fleets x profiles of the GPU parity tests, the scenario fleets, C1, C2."""
+    for profile in (None, "full", "prefer"):
+        for seed in range(16):
+            pods = int(np.random.default_rng(seed).choice([1, 7, 63, 64, 65, 200, 700, 5000]))
+            fleet = wl.fuzz_fleet(seed, pods=pods, profile=profile)
+            ids = string_ids(fleet, seed)
+            reqs, extra = wl.fuzz_requests(fleet, seed, 2000)
+            yield f"fuzz_{profile}_{seed}", fleet, ids, reqs, extra
+    for name, fleet, reqs, extra in wl.scenario_fleets():
+        ids = string_ids(fleet, 99)
+        yield f"scenario_{name}", fleet, ids, reqs, extra
+    for cfg, seed in (("C1", 11), ("C2", 12)):
+        fleet = wl.make_fleet(cfg)
+        ids = string_ids(fleet, seed)
+        reqs, extra = wl.make_requests(fleet, seed)
+        yield cfg, fleet, ids, reqs, extra
+
+
+def serve_cases():
+    """(name, fleet, ids, reqs, in_use, last_used, excl_pod, excl_time): serve-target requests on fuzz fleets — load-start times
+    that straddle the assume-completed cutoff and collide, models with many copies, tried pairs and key excludes."""
+    for seed in range(6):
+        rng = np.random.default_rng(1000 + seed)
+        fleet = wl.fuzz_fleet(seed, pods=int(rng.choice([8, 64, 300])), models=400)
+        P, now = fleet.n_pods, fleet.now
+        fleet.ent_time[:] = now - rng.choice([500, 2_999, 3_000, 3_001, 10_000, 10_000, 60_000], len(fleet.ent_time))
+        if P >= 8:
+            ent_pod, ent_time = list(fleet.ent_pod), list(fleet.ent_time)
+            for i in np.nonzero(rng.random(fleet.n_models) < 0.1)[0]:
+                k = int(rng.integers(5, 9))
+                fleet.models["ent_off"][i], fleet.models["n_loaded"][i], fleet.models["n_failed"][i] = len(ent_pod), k, 0
+                ent_pod += list(rng.choice(P, size=k, replace=False))
+                ent_time += list(now - rng.choice([500, 2_999, 3_000, 3_001, 10_000, 60_000], k))
+            fleet.ent_pod = np.array(ent_pod, np.int32)
+            fleet.ent_time = np.array(ent_time, np.int64)
+        ids = string_ids(fleet, 50 + seed)
+        n = 3000
+        reqs = np.zeros(n, dtype=_lib.SERVE_REQ)
+        reqs["model"] = rng.integers(0, fleet.n_models, n)
+        reqs["self_pod"] = np.where(rng.random(n) < 0.1, -1, rng.integers(0, P, n))
+        m = fleet.models[reqs["model"]]
+        has = m["n_loaded"] > 0
+        pickc = (m["ent_off"] + rng.integers(0, 8, n) % np.maximum(m["n_loaded"], 1)).clip(0, max(len(fleet.ent_pod) - 1, 0))
+        if len(fleet.ent_pod):
+            reqs["self_pod"] = np.where(has & (rng.random(n) < 0.5), fleet.ent_pod[pickc], reqs["self_pod"])
+        reqs["flags"] = rng.integers(0, 4, n)
+        reqs["local_in_flight"] = rng.integers(0, 3, n)
+        reqs["last_invoke_time"] = now - rng.choice([0, 10, 1000], n)
+        reqs["assume_completed_ms"] = rng.choice([3000, 30_000], n)
+        in_use = rng.integers(0, 3, P).astype(np.int32)
+        last_used = (now - rng.choice([0, 5, 5, 100, 10_000], P)).astype(np.int64)
+        ne = np.where(rng.random(n) < 0.3, rng.integers(1, 8, n), 0).astype(np.int32)
+        off = np.zeros(n + 1, np.int64)
+        np.cumsum(ne, out=off[1:])
+        reqs["excl_off"], reqs["n_excl"] = off[:-1], ne
+        excl_pod = np.zeros(int(off[-1]), np.int32)
+        excl_time = np.zeros(int(off[-1]), np.int64)
+        for i in np.nonzero(ne)[0]:
+            mm = fleet.models[reqs["model"][i]]
+            for j in range(ne[i]):
+                if mm["n_loaded"] > 0 and rng.random() < 0.8:
+                    e = mm["ent_off"] + rng.integers(0, mm["n_loaded"])
+                    excl_pod[off[i] + j] = fleet.ent_pod[e]
+                    excl_time[off[i] + j] = _lib.ANY_TIME if rng.random() < 0.5 else fleet.ent_time[e] + rng.integers(0, 2)
+                else:
+                    excl_pod[off[i] + j] = rng.integers(0, P)
+                    excl_time[off[i] + j] = _lib.ANY_TIME
+        yield f"serve_{seed}", fleet, ids, reqs, in_use, last_used, excl_pod, excl_time
+
+
+def input_blob(fleet, ids, reqs=None, extra=None, serve=None) -> bytes:
+    """The harness' input file (layout: oracle/ref_harness/harness.cc main())."""
+    P, M = fleet.n_pods, fleet.n_models
+    T = int(fleet.n_types)
+    W = (P + 63) // 64
+    reqs = np.zeros(0, _lib.PLACE_REQ) if reqs is None else np.ascontiguousarray(reqs)
+    extra = np.zeros(0, np.int32) if extra is None else np.ascontiguousarray(extra, dtype=np.int32)
+    if serve is None:
+        sreqs, in_use, last_used = np.zeros(0, _lib.SERVE_REQ), np.zeros(0, np.int32), np.zeros(0, np.int64)
+        sx_pod, sx_time = np.zeros(0, np.int32), np.zeros(0, np.int64)
+    else:
+        sreqs, in_use, last_used, sx_pod, sx_time = serve
+    repl = np.ascontiguousarray(fleet.replaced_rs, dtype=np.int32)
+    hdr = [P, M, len(fleet.ent_pod), T, W, len(repl), len(reqs), len(extra), int(fleet.min_space_units), int(fleet.min_churn_age_ms),
+           int(fleet.now), len(sreqs), len(sx_pod), 0, 0, 0]
+    idbuf = b"".join(s.encode("ascii").ljust(16, b"\0") for s in ids)
+    parts = [b"MMREF1\0\0", struct.pack("<16q", *hdr), np.ascontiguousarray(fleet.pods).tobytes(), idbuf,
+             np.ascontiguousarray(fleet.models).tobytes(), np.ascontiguousarray(fleet.ent_pod, dtype=np.int32).tobytes(),
+             np.ascontiguousarray(fleet.ent_time, dtype=np.int64).tobytes()]
+    if T:
+        parts += [np.ascontiguousarray(fleet.has_allowed, dtype=np.uint8).tobytes(), np.ascontiguousarray(fleet.has_prefer, dtype=np.uint8).tobytes(),
+                  np.ascontiguousarray(fleet.allowed, dtype=np.uint64).tobytes(), np.ascontiguousarray(fleet.prefer, dtype=np.uint64).tobytes()]
+    parts += [repl.tobytes(), reqs.tobytes(), extra.tobytes(), np.ascontiguousarray(sreqs).tobytes()]
+    if len(sreqs):
+        parts += [np.ascontiguousarray(in_use, dtype=np.int32).tobytes(), np.ascontiguousarray(last_used, dtype=np.int64).tobytes()]
+    parts += [np.ascontiguousarray(sx_pod, dtype=np.int32).tobytes(), np.ascontiguousarray(sx_time, dtype=np.int64).tobytes()]
+    return b"".join(parts)
+
+
+def digest(blob: bytes) -> str:
+    return hashlib.sha256(blob).hexdigest()[:16]

@@ -1,0 +1,49 @@
+"""GPU: the HIP path against the reference-text vectors (tests/golden/ref_getnext.npz, see tests/test_ref_vectors.py): the
+order of the instance table, every load-target decision (chosen, shortlist size, audit hash of the shortlist as the
+reference's own `candidates` list gives it) and every serve-target decision, through the C ABI, bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from modelmesh_amd.solver import Solver
+from tests import ref_fleets as rf
+from tests.test_ref_vectors import GOLDEN, check_place
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return np.load(GOLDEN)
+
+
+def test_hip_order_and_load_targets_equal_the_reference_text(ref):
+    n_dec = 0
+    for name, fleet, ids, reqs, extra in rf.place_cases():
+        assert rf.digest(rf.input_blob(fleet, ids, reqs, extra)) == bytes(ref[f"{name}/digest"]).decode(), name
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            s.load_fleet(fleet)
+            want_order = ref[f"{name}/order"]
+            assert np.array_equal(s.order()[: len(want_order)], want_order), name  # (absent rows sort behind the present ones)
+            got = s.place(reqs, extra, fleet.now)
+            check_place(name, fleet, reqs, got, ref[f"{name}/place"])
+            n_dec += len(reqs)
+        finally:
+            s.close()
+    assert n_dec >= 100_000
+
+
+def test_hip_serve_targets_equal_the_reference_text(ref):
+    for name, fleet, ids, reqs, in_use, last_used, xp, xt in rf.serve_cases():
+        want = ref[f"{name}/serve"]
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            s.load_fleet(fleet)
+            got = s.serve(reqs, in_use, last_used, xp, xt, fleet.now)
+        finally:
+            s.close()
+        assert np.array_equal(got["chosen"], want[:, 0]), (name, np.nonzero(got["chosen"] != want[:, 0])[0][:5])
+        remote = want[:, 0] >= 0  # (ABORT_REQUEST returns before filtered.add(chosenId, chosenTimeStamp), :4384-4389)
+        assert np.array_equal(got["chosen_load_start"][remote], want[remote, 1]), name
