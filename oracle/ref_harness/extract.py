@@ -38,6 +38,27 @@ RANGES = [
     ("getRemaining_body", IR, 204, 204, "return Math.max(0L, capacity - used);", "capacity - used"),
     ("string_array_comp_body", UT, 26, 35, "int diff = l1.length - l2.length;", "return 0;"),
     ("lb_constants", MM, 4751, 4753, "TWELVE_MIN_MS = MILLISECONDS.convert(12, MINUTES);", "FIVE_DAYS_MS = MILLISECONDS.convert(5, DAYS);"),
+    # ---- the request-level guards around the two selections
+    ("publish_constants", MM, 231, 232, "INSTANCE_REC_PUBLISH_FREQ_MS = 40_000L;", "INSTANCE_REC_PUBLISH_MIN_PERIOD_MS = 2_000L;"),
+    ("failure_constants", MM, 222, 224, "MAX_LOAD_FAILURES = 3;", "MAX_LOAD_LOCATIONS = 5;"),
+    ("goLocal_fragment", MM, 3599, 3626, "int filteredCount = filteredInstances.size();", "}"),
+    ("oldest_body", MM, 4167, 4167, "return Collections.min(instances.values());", "instances.values()"),
+    ("getMostRecent_body", MM, 4630, 4636, "Entry<String, Long> mostRecent = null;", "return mostRecent != null ? mostRecent.getKey() : null;"),
+    ("checkLoadLocationCount_body", MM, 4593, 4603, "int count = 0;", "}"),
+    ("checkLoadFailureCount_body", MM, 4609, 4626, "Map<String, Long> failedInInstances = mr.getLoadFailedInstanceIds();", "}"),
+    ("throwIfLocalLoadNotAllowed_body", MM, 4011, 4041, "boolean localFiltered = loadTargetFilter != null", "}"),
+    ("churn_fragment", MM, 3872, 3884, "if (minChurnAgeMs > 0) {", "}"),
+    ("weightPredictCutoff_body", MM, 5014, 5014, "return (loadingThreads + (loadingThreads / 3));", "loadingThreads / 3"),
+    ("loadLocal_sizing_fragment", MM, 5159, 5197, "int initialSize = 0;", "}"),
+    ("onEviction_attempt_fragment", MM, 2886, 2897, "boolean attemptReload = false, inRegistry = false, failed = ce.isFailed();", "}"),
+    ("onEviction_cluster_fragment", MM, 2918, 2920, "ClusterStats stats = typeSetStats(ce.modelInfo.getServiceType());",
+     "&& ((20L * stats.totalFree) / stats.totalCapacity) >= 1) {"),
+    # publishInstanceRecord's decision, without lines 5409-5422: `if (unloadManager != null) { lock; try {...} finally {...}; cap -= ...}`
+    # (C++ has no `finally`; the request's fresh_* fields ARE the values after that adjustment, include/mmplace.h mmp_gate_req)
+    ("publish_fragment_a", MM, 5395, 5408, "long now = currentTimeMillis(), lastDone = now - lastPublished;", "long totalCacheOccupancy = -1;"),
+    ("publish_fragment_b", MM, 5423, 5468, "if (oldest == -1L) {", "}"),
+    ("loadingChange_body", MM, 5537, 5542, "int curInProg = curRec.getLoadingInProgress();", "return Math.abs(loadInProg - curInProg) >= 3;"),
+    ("loadChange_body", MM, 5547, 5549, "int diff = Math.abs(curRecRpms - rpms);", "(100 * diff) / curRecRpms > 10);"),
 ]
 
 # token-level rewrites, applied in order to every extracted line
@@ -47,9 +68,15 @@ RULES = [
     # `final` on locals has no C++ counterpart that matters here
     (re.compile(r"\bfinal\s+"), ""),
     # object creation: `new ArrayList<>(n)` / `new IntArrayList(n)` -> factory calls of the stand-ins (the diamond's type
-    # argument is inferred from the declaration on the left, as in Java)
+    # argument is inferred from the declaration on the left, as in Java); any other `new X(...)` -> a value of the handle class X
     (re.compile(r"\bnew\s+ArrayList<>\("), "ArrayList_new("),
     (re.compile(r"\bnew\s+IntArrayList\("), "IntArrayList_new("),
+    (re.compile(r"\bnew\s+(\w+)\("), r"\1("),
+    # string literals are java.lang.String objects (they are concatenated with + into log / exception messages)
+    (re.compile(r'"(?:[^"\\]|\\.)*"'), lambda m: "String(" + m.group(0) + ")"),
+    # Java keeps methods and variables in separate name spaces (`long oldest = oldest(filteredInstances);`, :3617): the call
+    # gets the stand-in's name
+    (re.compile(r"\boldest\("), "oldest_of("),
     # lambdas: `ent -> {` (a Java lambda captures effectively-final locals by value; here: copies of handles)
     (re.compile(r"\b(\w+)\s*->\s*\{"), r"[=](auto \1) {"),
     # wildcard generics do not exist in C++: ServiceInstance<?> -> ServiceInstance
@@ -63,9 +90,9 @@ RULES = [
     (re.compile(r"\bexplicit\b"), "explicit_"),
     # static members of the boxed types: Long.compare / Long.MAX_VALUE / Integer.MAX_VALUE (Long is also a type argument,
     # Map<String, Long>, so it has to be a class on the C++ side)
-    (re.compile(r"\b(Long|Integer)\.(?=[A-Za-z])"), r"\1::"),
-    # member modifiers in front of the three constant declarations
-    (re.compile(r"^\s*protected\s+static\s+"), ""),
+    (re.compile(r"\b(Long|Integer|Collections)\.(?=[A-Za-z])"), r"\1::"),
+    # member modifiers in front of the constant declarations
+    (re.compile(r"^\s*(?:protected|public)\s+static\s+"), ""),
 ]
 
 

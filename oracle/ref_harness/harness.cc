@@ -30,6 +30,14 @@ public:
     InstanceRecord() {}
     InstanceRecord(long lru, long cap, long used_, long vers, int cnt, int lt, int lip, int rpm, boolean sd)
         : p(std::make_shared<Rep>(Rep{lru, cap, used_, vers, cnt, lt, lip, rpm, sd, StringArray()})) {}
+    // InstanceRecord.java:97-109 (startTime, version, location, zone, labels, lruTime, count, capacity, used, lThreads, lInProg, shuttingDown)
+    InstanceRecord(long, long vers, const String &, const String &, const StringArray &, long lru, int cnt, long cap, long used_, int lt, int lip,
+                   boolean sd)
+        : p(std::make_shared<Rep>(Rep{lru, cap, used_, vers, cnt, lt, lip, 0, sd, StringArray()})) {}
+    InstanceRecord(std::nullptr_t) {}
+    bool operator==(std::nullptr_t) const { return !p; }
+    bool operator!=(std::nullptr_t) const { return (bool)p; }
+    long getUsed() const { return p->used; }
     bool operator==(const InstanceRecord &o) const { return p == o.p; }  // Java `==` on references: identity
     long getLruTime() const { return p->lruTime; }
     long getCapacity() const { return p->capacity; }
@@ -95,7 +103,7 @@ static const struct {
     struct R { int nextInt(int n) const { return (int)(((uint64_t)g_pick * (uint64_t)(uint32_t)n) >> 32); } };
     R current() const { return R(); }
 } ThreadLocalRandom;  // :4981: the pick is an input of every restatement (SURVEY B#9)
-static const struct { void warn(const char *) const {} } logger;
+static const struct { void warn(const String &) const {} void info(const String &) const {} } logger;
 static const String CACHE_MISS_EXCLUDES_KEY("tas.cm_excludes"), DEST_INST_ID_KEY("tas.dest_iid");
 struct ThreadContextT { int getCurrentContext() const { return 0; } };
 static const ThreadContextT ThreadContext;
@@ -229,6 +237,180 @@ struct ForwardingLB {
     }
 };
 
+// ================================ the request-level guards ==============================
+// Each function below is the Java declaration around one extracted fragment of invokeModel / loadLocal / onEviction /
+// publishInstanceRecord; the locals and fields the fragment reads are declared from the request (mmp_gate_req).
+struct TException {
+    bool isnull = true;
+    TException() {}
+    TException(std::nullptr_t) {}
+    bool operator!=(std::nullptr_t) const { return !isnull; }
+};
+struct ModelLoadException : TException {
+    ModelLoadException() {}
+    ModelLoadException(std::nullptr_t) {}
+    ModelLoadException(const String &, const String &, long, std::nullptr_t) { isnull = false; }
+};
+static ModelLoadException newModelLoadException(const String &, long, std::nullptr_t) { return ModelLoadException(String(""), null, 0L, null); }
+static TException newInternalException(const String &, std::nullptr_t) { TException t; t.isnull = false; return t; }
+struct ClusterStats { long totalCapacity, totalFree, globalLru; int instanceCount, modelCopyCount; };
+static std::vector<ClusterStats> g_tstats;
+static ClusterStats typeSetStats(const String &type) { return g_tstats.at(std::min<size_t>(std::stoul(type.str().substr(1)), g_tstats.size() - 1)); }
+
+// ModelRecord (ModelRecord.java:61-114): type + the two id -> time maps
+struct ModelRecord {
+    String type;
+    Map<String, Long> instanceIds = Map<String, Long>::make(), failed = Map<String, Long>::make();
+    bool isnull = false;
+    ModelRecord() {}
+    ModelRecord(std::nullptr_t) : isnull(true) {}
+    bool operator!=(std::nullptr_t) const { return !isnull; }
+    String getType() const { return type; }
+    Map<String, Long> getInstanceIds() const { return instanceIds; }
+    Map<String, Long> getLoadFailedInstanceIds() const { return failed; }
+    boolean hasLoadFailure() const { return !failed.isEmpty(); }  // ModelRecord.java:203
+    String getLoadFailureMessage(const String &) const { return String(""); }
+};
+struct CacheEntry {  // what the fragments ask of a CacheEntry<?>
+    bool isnull = true, done = false, failed = false;
+    int predicted = 0;
+    String modelInfoType;
+    CacheEntry() {}
+    CacheEntry(std::nullptr_t) {}
+    bool operator==(std::nullptr_t) const { return isnull; }
+    bool operator!=(std::nullptr_t) const { return !isnull; }
+    boolean isDone() const { return done; }
+    boolean isFailed() const { return failed; }
+    int loaderPredictedWeight() const { return predicted; }
+    void remove() const {}
+    struct MI { String t; String getServiceType() const { return t; } } modelInfo;
+};
+static const mmp_gate_req *g_gq;  // the request whose fragment is running
+static CacheEntry g_cache_entry;
+static CacheEntry getFromCache(const String &, long) { return g_cache_entry; }  // MM.java:3609
+static const struct {
+    long capacity() const { return g_cap; }
+    long weightedSize() const { return g_wsize; }
+    long oldestTime() const { return g_oldest; }
+    int size() const { return g_size; }
+    mutable long g_cap = 0, g_wsize = 0, g_oldest = 0;
+    mutable int g_size = 0;
+} runtimeCache;
+static std::vector<uint8_t> g_in_table;
+static std::unordered_map<std::string, int> g_pod_of;
+static std::vector<InstanceRecord> g_table_rec;  // the table's record per pod (null: not in the table)
+static const struct {
+    boolean contains(const String &id) const { auto it = g_pod_of.find(id.str()); return it != g_pod_of.end() && g_in_table[it->second]; }
+    InstanceRecord getOrStrongIfAbsent(const String &id) const
+    {
+        auto it = g_pod_of.find(id.str());
+        return it == g_pod_of.end() ? InstanceRecord(null) : g_table_rec[it->second];
+    }
+    int keyIterable() const { return 0; }
+} instanceInfo;
+static const struct { String toString(int) const { return String(""); } } Iterables;
+static long IN_USE_LOAD_FAILURE_EXPIRY_MS;  // MM.java:221 (a parameter: LOAD_FAILURE_EXPIRY_MS / 2)
+#include "../_ref/gen/failure_constants.inc"
+#include "../_ref/gen/publish_constants.inc"
+
+static long oldest_of(Map<String, Long> instances)  // MM.java:4166 oldest()
+{
+#include "../_ref/gen/oldest_body.inc"
+}
+static String getMostRecent(Map<String, Long> instances)  // :4629
+{
+#include "../_ref/gen/getMostRecent_body.inc"
+}
+// invokeModel, the cache-hit branch (:3599-3626): is the hit served locally?
+static boolean frag_goLocal(Map<String, Long> filteredInstances, boolean favourSelfForHits, String modelId, long lastUsedTime)
+{
+    CacheEntry cacheEntry = null;
+    boolean result = false;
+#include "../_ref/gen/goLocal_fragment.inc"
+        result = goLocal;
+    }
+    return result;
+}
+static void checkLoadLocationCount(ModelRecord mr, Collection<String> explicitExcludes, TException internalFailureSeen)  // :4589
+{
+#include "../_ref/gen/checkLoadLocationCount_body.inc"
+}
+static void checkLoadFailureCount(ModelRecord mr, ModelLoadException loadFailureSeen)  // :4607
+{
+#include "../_ref/gen/checkLoadFailureCount_body.inc"
+}
+static void throwIfLocalLoadNotAllowed(String modelId, boolean externalReq, ModelRecord mr, CacheMissExcludeSet *loadTargetFilter_,
+                                       ModelLoadException loadFailureSeen, TException internalFailureSeen)  // :4003
+{
+    struct { CacheMissExcludeSet *p; bool operator!=(std::nullptr_t) const { return p != nullptr; } boolean isExcluded(const String &s) const { return p->isExcluded(s); } } loadTargetFilter{loadTargetFilter_};
+#include "../_ref/gen/throwIfLocalLoadNotAllowed_body.inc"
+}
+static void frag_churn(String modelId)  // invokeModel :3872-3884
+{
+#include "../_ref/gen/churn_fragment.inc"
+}
+static int loadingThreads;
+static const struct { int get() const { return g_v; } mutable int g_v = 0; } loadingCount;
+static int weightPredictCutoff()  // :5013 — the request carries the value (mmp_gate_req::weight_predict_cutoff); the body is compiled for the record
+{
+    if (g_gq) return g_gq->weight_predict_cutoff;
+#include "../_ref/gen/weightPredictCutoff_body.inc"
+}
+static const String KNOWN_SIZE_CXT_KEY("tas.known_size");
+static void logCacheFallthru(const String &, long, long, long, int) {}
+static int g_initial_size;
+// loadLocal :5159-5197: the initial size of the new entry, and the early reject (returns null)
+static CacheEntry frag_loadLocal_sizing(CacheEntry ce, ModelRecord mr, Map<String, String> contextMap, boolean weCreatedCacheEntry, long lastUsedTime,
+                                        String modelId, long now)
+{
+#include "../_ref/gen/loadLocal_sizing_fragment.inc"
+    g_initial_size = initialSize;
+    return ce;
+}
+static long loadTimeoutMs;
+static ModelRecord g_registry_mr;
+static const struct { ModelRecord get(const String &) const { return g_registry_mr; } } registry;
+// onEviction :2886-2897 and :2918-2920: is the evicted model re-placed elsewhere?
+static boolean frag_onEviction(CacheEntry ce, String key, long now)
+{
+    boolean reload = false;
+#include "../_ref/gen/onEviction_attempt_fragment.inc"
+    if (attemptReload) {
+#include "../_ref/gen/onEviction_cluster_fragment.inc"
+            reload = true;
+        }
+    }
+    return reload;
+}
+static boolean loadingChange(InstanceRecord curRec, int loadInProg)  // :5536
+{
+#include "../_ref/gen/loadingChange_body.inc"
+}
+static boolean loadChange(int curRecRpms, int rpms)  // :5546
+{
+#include "../_ref/gen/loadChange_body.inc"
+}
+static boolean shuttingDown;
+static long lastPublished, instanceStartTime, longVersion;
+static String instanceLocation, instanceZone;
+static StringArray instanceLabels;
+static const struct { int getBusyness() const { return g_v; } mutable int g_v = 0; } invokeCounter;
+static boolean g_publish;
+// publishInstanceRecord :5395-5468 (without :5409-5422, see extract.py): does the record get re-published?
+static void frag_publish(boolean force, boolean preShutdown)
+{
+    boolean isShuttingDown = shuttingDown;  // :5392
+    g_publish = false;
+#include "../_ref/gen/publish_fragment_a.inc"
+#include "../_ref/gen/publish_fragment_b.inc"
+            g_publish = true;  // :5470 the setters and the KV put follow
+            return;
+        }
+        g_publish = true;  // a new record was created (:5436): it is written
+        return;
+    }
+}
+
 // ======================================================== I/O ===============================================================
 // The audit hash of a shortlist (machinery of THIS repository, not of the reference): a function of the set of
 // rank positions in the shortlist and of the count that survived the rpm filter — computed here from the reference's own
@@ -273,7 +455,7 @@ int main(int argc, char **argv)
     minSpaceUnits = H[8];
     minChurnAgeMs = H[9];
     g_now = H[10];
-    const int64_t n_serve = H[11], n_sexcl = H[12];
+    const int64_t n_serve = H[11], n_sexcl = H[12], n_gate = H[13], n_gexcl = H[14], n_gexpl = H[15];
     auto pods = rd<mmp_pod_row>(f, P);
     auto idbuf = rd<char>(f, P * 16);
     auto models = rd<mmp_model_row>(f, M);
@@ -289,6 +471,13 @@ int main(int argc, char **argv)
     auto last_used = rd<int64_t>(f, n_serve ? P : 0);
     auto sx_pod = rd<int32_t>(f, n_sexcl);
     auto sx_time = rd<int64_t>(f, n_sexcl);
+    auto greqs = rd<mmp_gate_req>(f, n_gate);
+    auto gx_pod = rd<int32_t>(f, n_gexcl);
+    auto gx_time = rd<int64_t>(f, n_gexcl);
+    auto gexplicit = rd<int32_t>(f, n_gexpl);
+    auto gparams = rd<int64_t>(f, n_gate ? 1 : 0);  // IN_USE_LOAD_FAILURE_EXPIRY_MS
+    struct StatsRow { int64_t total_capacity, total_free, global_lru; int32_t instance_count, model_copy_count; };
+    auto tstats = rd<StatsRow>(f, n_gate ? std::max<int64_t>(Tn, 1) : 0);  // typeSetStats(type) per type row: an input here (rows a5 / a18)
     fclose(f);
 
     std::vector<String> ids(P);
@@ -429,6 +618,110 @@ int main(int argc, char **argv)
         sout[d * 2 + 1] = ts;
     }
     wr(o, sout);
+
+    // ---- the request-level guards: bits as in include/mmplace.h (MMP_GATE_*), and loadLocal's signed initial size
+    std::vector<int32_t> gout(n_gate * 2);
+    if (n_gate) {
+        IN_USE_LOAD_FAILURE_EXPIRY_MS = gparams[0];
+        for (auto &r : tstats) g_tstats.push_back(ClusterStats{r.total_capacity, r.total_free, r.global_lru, r.instance_count, r.model_copy_count});
+        g_pod_of = pod_of;
+        g_in_table.assign(P, 0);
+        g_table_rec.assign(P, InstanceRecord(null));
+        for (int64_t i = 0; i < P; i++) {
+            const mmp_pod_row &r = pods[i];
+            g_in_table[i] = !(r.flags & MMP_POD_TOMBSTONE);
+            if (g_in_table[i]) {
+                g_table_rec[i] = InstanceRecord(r.lru_time, r.capacity, r.used, r.version, r.count, r.loading_threads, r.loading_in_progress, r.rpm,
+                                                (r.flags & MMP_POD_SHUTTING_DOWN) != 0);
+            }
+        }
+    }
+    for (int64_t d = 0; d < n_gate; d++) {
+        const mmp_gate_req &q = greqs[d];
+        g_gq = &q;
+        uint32_t bits = 0;
+        const mmp_model_row &m = models[q.model];
+        const int type = (m.type < 0 || m.type >= Tn) ? 0 : m.type;
+        ModelRecord mr;
+        mr.type = String("t" + std::to_string(type));
+        for (int32_t k = 0; k < m.n_loaded + m.n_failed; k++) {
+            const int32_t pod = ent_pod[m.ent_off + k];
+            (k < m.n_loaded ? mr.instanceIds : mr.failed).put(ids[pod], Long(ent_time[m.ent_off + k]));
+        }
+        instanceId = ids[q.self_pod];
+        const String modelId("model");
+        // goLocal: filteredInstances = the copies minus the cache-hit excludes (MapFilteringSet, key excludes here)
+        {
+            Map<String, Long> filtered = Map<String, Long>::make();
+            for (auto &e : mr.instanceIds.entrySet()) {
+                bool ex = false;
+                for (int32_t k = 0; k < q.n_excl; k++)
+                    if (ids[gx_pod[q.excl_off + k]].str() == e.getKey().str() &&
+                        (gx_time[q.excl_off + k] == INT64_MIN || gx_time[q.excl_off + k] == (long)e.getValue()))
+                        ex = true;
+                if (!ex) filtered.put(e.getKey(), e.getValue());
+            }
+            g_cache_entry = CacheEntry();
+            if (q.flags & MMP_GATE_HAVE_CACHE_ENTRY) { g_cache_entry.isnull = false; g_cache_entry.done = (q.flags & MMP_GATE_ENTRY_DONE) != 0; }
+            if (frag_goLocal(filtered, (q.flags & MMP_GATE_FAVOUR_SELF_FOR_HITS) != 0, modelId, q.last_used_time)) bits |= MMP_GATE_GO_LOCAL;
+        }
+        Collection<String> explicitExcludes = Collection<String>::make();
+        for (int32_t k = 0; k < q.n_explicit; k++) explicitExcludes.add(ids[gexplicit[q.explicit_off + k]]);
+        try { checkLoadFailureCount(mr, null); } catch (const TException &) { bits |= MMP_GATE_FAILURES_BREACHED; }
+        try { checkLoadLocationCount(mr, explicitExcludes, null); } catch (const TException &) { bits |= MMP_GATE_LOCATIONS_BREACHED; }
+        {   // the load-target filter of the request: loaded / failed of the record + the explicit excludes (:4706-4715)
+            CacheMissExcludeSet ltf;
+            for (auto &e : mr.instanceIds.keySet()) ltf.loaded.add(e);
+            for (auto &e : mr.failed.keySet()) ltf.failed.add(e);
+            ltf.explicit_ = explicitExcludes;
+            try { throwIfLocalLoadNotAllowed(modelId, true, mr, &ltf, null, null); } catch (const TException &) { bits |= MMP_GATE_LOCAL_NOT_ALLOWED; }
+        }
+        runtimeCache.g_cap = q.cache_capacity;
+        runtimeCache.g_wsize = q.cache_weighted_size;
+        runtimeCache.g_oldest = q.cache_oldest_time;
+        g_fresh = InstanceRecord(q.fresh_lru, q.fresh_capacity, q.fresh_used, 0, q.fresh_count, q.fresh_loading_threads, q.fresh_in_progress, q.fresh_rpm, false);
+        try { frag_churn(modelId); } catch (const TException &) { bits |= MMP_GATE_CHURN_REJECT; }
+        {
+            CacheEntry ce;
+            ce.isnull = false;
+            ce.predicted = q.loader_predicted;
+            Map<String, String> contextMap = Map<String, String>::make();
+            if (q.flags & MMP_GATE_HAVE_SIZE_HINT) contextMap.put(KNOWN_SIZE_CXT_KEY, String(std::to_string(q.size_hint)));
+            loadingCount.g_v = q.loading_count;
+            g_initial_size = 0;
+            if (frag_loadLocal_sizing(ce, mr, contextMap, (q.flags & MMP_GATE_WE_CREATED_ENTRY) != 0, q.last_used_time, modelId, g_now) == null)
+                bits |= MMP_GATE_EARLY_REJECT;
+            else
+                gout[d * 2 + 1] = g_initial_size;
+        }
+        {
+            CacheEntry ce;
+            ce.isnull = false;
+            ce.failed = (q.flags & MMP_GATE_ENTRY_FAILED) != 0;
+            ce.modelInfo.t = mr.type;
+            g_registry_mr = ModelRecord();  // the registry's view for onEviction: our own load time only
+            g_registry_mr.type = mr.type;
+            if (q.loaded_time >= 0) g_registry_mr.instanceIds.put(instanceId, Long(q.loaded_time));
+            loadTimeoutMs = q.load_timeout_ms;
+            if (frag_onEviction(ce, modelId, g_now)) bits |= MMP_GATE_RELOAD_ELSEWHERE;
+        }
+        {
+            runtimeCache.g_cap = q.fresh_capacity;  // the values getFreshInstanceRecord() publishes (after the unload-buffer adjustment)
+            runtimeCache.g_wsize = q.fresh_used;
+            runtimeCache.g_oldest = q.fresh_lru;
+            runtimeCache.g_size = q.fresh_count;
+            loadingThreads = q.fresh_loading_threads;
+            loadingCount.g_v = q.fresh_in_progress;
+            invokeCounter.g_v = q.fresh_rpm;
+            shuttingDown = (q.flags & MMP_GATE_FRESH_SHUTTING_DOWN) != 0;
+            lastPublished = q.last_published;
+            frag_publish((q.flags & MMP_GATE_PUBLISH_FORCE) != 0, (q.flags & MMP_GATE_PRE_SHUTDOWN) != 0);
+            if (g_publish) bits |= MMP_GATE_SHOULD_PUBLISH;
+        }
+        g_gq = nullptr;
+        gout[d * 2] = (int32_t)bits;
+    }
+    wr(o, gout);
     fclose(o);
     return 0;
 }

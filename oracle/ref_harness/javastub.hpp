@@ -22,8 +22,9 @@
 typedef bool boolean;
 static_assert(sizeof(long) == 8 && sizeof(int) == 4, "Java long / int (build with -fwrapv: Java arithmetic wraps)");
 
-// (int) of a double: JLS 5.1.3 (NaN -> 0, saturating)
+// (int) of a double: JLS 5.1.3 (NaN -> 0, saturating); (int) of a long: the low 32 bits
 static inline int J2I(double d) { return d != d ? 0 : d >= 2147483647.0 ? INT_MAX : d <= -2147483648.0 ? INT_MIN : (int)d; }
+static inline int J2I(long v) { return (int)(uint32_t)(uint64_t)v; }
 
 // java.lang.String (nullable, immutable)
 class String {
@@ -52,6 +53,8 @@ public:
     struct Eq { bool operator()(const String &a, const String &b) const { return a.str() == b.str(); } };
     struct Less { bool operator()(const String &a, const String &b) const { return a.str() < b.str(); } };
 };
+// string concatenation builds log and exception messages only: no decision reads them
+template <class X> static inline String operator+(const String &, const X &) { return String(""); }
 // String[] (non-null here)
 struct StringArray {
     std::shared_ptr<std::vector<String>> p = std::make_shared<std::vector<String>>();
@@ -62,20 +65,28 @@ struct StringArray {
 // java.lang.Long / Integer: boxed value as a type argument (Map<String, Long>), static members via `::` (extract.py)
 struct Long {
     long v = 0;
+    bool isnull = false;
     Long() {}
     Long(long x) : v(x) {}
-    Long(std::nullptr_t) {}  // a null Long (Map.put returns the previous value)
-    operator long() const { return v; }
+    Long(std::nullptr_t) : isnull(true) {}  // a null Long (Map.get of an absent key)
+    operator long() const { return v; }  // unboxing
+    bool operator==(std::nullptr_t) const { return isnull; }
+    bool operator!=(std::nullptr_t) const { return !isnull; }
     static constexpr long MAX_VALUE = LONG_MAX;
     static int compare(long a, long b) { return a < b ? -1 : a > b ? 1 : 0; }
 };
-struct Integer { static constexpr int MAX_VALUE = INT_MAX; };
+struct Integer {
+    static constexpr int MAX_VALUE = INT_MAX;
+    static int parseInt(const String &s) { return (int)std::stol(s.str()); }
+};
 // java.util.concurrent.TimeUnit.MILLISECONDS.convert(n, unit)
 enum TimeUnitT : long { MINUTES = 60000L, DAYS = 86400000L };
 static const struct { long convert(long n, TimeUnitT u) const { return n * (long)u; } } MILLISECONDS;
 static const struct {
     int max(int a, int b) const { return a > b ? a : b; }
     long max(long a, long b) const { return a > b ? a : b; }
+    int abs(int a) const { return a < 0 ? (int)(0u - (unsigned)a) : a; }            // Math.abs(MIN_VALUE) == MIN_VALUE
+    long abs(long a) const { return a < 0 ? (long)(0ul - (unsigned long)a) : a; }
 } Math;
 
 // java.util.Map.Entry
@@ -202,6 +213,27 @@ public:
         std::vector<Entry<K, V>> es;
         for (auto &kv : *p) es.emplace_back(kv.first, kv.second);
         return es;
+    }
+    std::vector<K> keySet() const
+    {
+        std::vector<K> ks;
+        for (auto &kv : *p) ks.push_back(kv.first);
+        return ks;
+    }
+    std::vector<V> values() const
+    {
+        std::vector<V> vs;
+        for (auto &kv : *p) vs.push_back(kv.second);
+        return vs;
+    }
+};
+// java.util.Collections.min over boxed longs
+struct Collections {
+    static long min(const std::vector<Long> &v)
+    {
+        long m = v.at(0);
+        for (const Long &x : v) m = (long)x < m ? (long)x : m;
+        return m;
     }
 };
 // org.eclipse.collections ObjectLongMap<String>

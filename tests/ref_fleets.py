@@ -125,7 +125,71 @@ def serve_cases():
         yield f"serve_{seed}", fleet, ids, reqs, in_use, last_used, excl_pod, excl_time
 
 
-def input_blob(fleet, ids, reqs=None, extra=None, serve=None) -> bytes:
+def gate_cases():
+    """(name, fleet, ids, reqs, excl_pod, excl_time, explicit, in_use_expiry): the request-level guards (mmp_gate_req) on fuzz
+    fleets — models with many copies / failures so that the count guards trigger, fresh rows near and far from the table's."""
+    for seed in range(4):
+        rng = np.random.default_rng(3000 + seed)
+        fleet = wl.fuzz_fleet(seed + 40, pods=int(rng.choice([8, 64, 300])), models=300, profile=None if seed % 2 else "prefer")
+        P, now = fleet.n_pods, fleet.now
+        fleet.ent_time[:] = now - rng.choice([100, 1_400, 1_600, 449_000, 451_000, 3_000_000], len(fleet.ent_time))
+        m = fleet.models
+        big = np.nonzero(rng.random(len(m)) < 0.1)[0]
+        ent_pod, ent_time = list(fleet.ent_pod), list(fleet.ent_time)
+        for i in big:
+            k, f = int(rng.integers(4, min(8, P) + 1)) if P >= 5 else min(P, 2), int(rng.integers(0, min(8, P)))
+            f = min(f, P - k) if P - k > 0 else 0
+            pods = rng.choice(P, size=k + f, replace=False)
+            m["ent_off"][i], m["n_loaded"][i], m["n_failed"][i] = len(ent_pod), k, f
+            ent_pod += list(pods)
+            ent_time += list(now - rng.choice([100, 449_000, 451_000], k + f))
+        fleet.ent_pod = np.array(ent_pod, np.int32)
+        fleet.ent_time = np.array(ent_time, np.int64)
+        ids = string_ids(fleet, 70 + seed)
+        n = 3000
+        r = np.zeros(n, dtype=_lib.GATE_REQ)
+        r["model"] = rng.integers(0, fleet.n_models, n)
+        r["self_pod"] = rng.integers(0, P, n)
+        mm = m[r["model"]]
+        has = mm["n_loaded"] > 0
+        pick = (mm["ent_off"] + rng.integers(0, 8, n) % np.maximum(mm["n_loaded"], 1)).clip(0, len(fleet.ent_pod) - 1)
+        r["self_pod"] = np.where(has & (rng.random(n) < 0.6), fleet.ent_pod[pick], r["self_pod"])
+        r["flags"] = rng.integers(0, 512, n)
+        r["size_hint"] = rng.choice([0, 1, 6400, 2_000_000], n)
+        r["last_used_time"] = rng.choice([0, now - 5_000, now - 4_000_000], n)
+        r["cache_capacity"] = rng.choice([131072, 1_000_000], n)
+        r["cache_weighted_size"] = (r["cache_capacity"] * rng.choice([0.1, 0.96, 0.999, 1.0], n)).astype(np.int64)
+        r["cache_oldest_time"] = rng.choice([-1, _lib.JAVA_LONG_MAX, now - 1_000, now - 4_500_000, now - 700_000], n)
+        r["loader_predicted"] = rng.choice([6400, 1, 200_000], n)
+        r["loading_count"] = rng.integers(0, 20, n)
+        r["weight_predict_cutoff"] = 10
+        r["loaded_time"] = rng.choice([-1, now - 1_000, now - 200_000, now - 5_000_000], n)
+        r["load_timeout_ms"] = rng.choice([90_000, 720_000], n)
+        cur = fleet.pods[r["self_pod"]]
+        near = rng.random(n) < 0.6
+        r["fresh_lru"] = np.where(near, cur["lru_time"], cur["lru_time"] - rng.choice([0, 10_000, 30_000], n))
+        r["fresh_capacity"] = np.where(near, cur["capacity"], cur["capacity"] - rng.choice([0, 100, 50_000], n))
+        r["fresh_used"] = np.where(near, cur["used"], (cur["used"] * rng.choice([1.0, 1.1, 1.3], n)).astype(np.int64))
+        r["fresh_count"] = cur["count"] + rng.choice([0, 0, 1, 2, 10], n)
+        r["fresh_loading_threads"] = np.where(rng.random(n) < 0.9, cur["loading_threads"], 3)
+        r["fresh_in_progress"] = cur["loading_in_progress"] + rng.choice([0, 0, 1, 3], n)
+        r["fresh_rpm"] = cur["rpm"] + rng.choice([0, 0, 5, 99, 100, 1000], n)
+        r["last_published"] = now - rng.choice([500, 2_500, 38_000, 39_500, 100_000, 170_000], n)
+        ne = np.where(rng.random(n) < 0.3, rng.integers(1, 8, n), 0).astype(np.int32)
+        off = np.zeros(n + 1, np.int64)
+        np.cumsum(ne, out=off[1:])
+        r["excl_off"], r["n_excl"] = off[:-1], ne
+        excl_pod = rng.integers(0, P, int(off[-1])).astype(np.int32)
+        excl_time = np.full(int(off[-1]), _lib.ANY_TIME, np.int64)
+        nx = np.where(rng.random(n) < 0.4, rng.integers(1, 8, n), 0).astype(np.int32)
+        xoff = np.zeros(n + 1, np.int64)
+        np.cumsum(nx, out=xoff[1:])
+        r["explicit_off"], r["n_explicit"] = xoff[:-1], nx
+        explicit = rng.integers(0, P, int(xoff[-1])).astype(np.int32)
+        yield f"gates_{seed}", fleet, ids, r, excl_pod, excl_time, explicit, 450_000
+
+
+def input_blob(fleet, ids, reqs=None, extra=None, serve=None, gates=None) -> bytes:
     """The harness' input file (layout: oracle/ref_harness/harness.cc main())."""
     P, M = fleet.n_pods, fleet.n_models
     T = int(fleet.n_types)
@@ -138,8 +202,13 @@ def input_blob(fleet, ids, reqs=None, extra=None, serve=None) -> bytes:
     else:
         sreqs, in_use, last_used, sx_pod, sx_time = serve
     repl = np.ascontiguousarray(fleet.replaced_rs, dtype=np.int32)
+    if gates is None:
+        greqs, gx_pod, gx_time, gexpl, g_expiry, tstats = np.zeros(0, _lib.GATE_REQ), np.zeros(0, np.int32), np.zeros(0, np.int64), \
+            np.zeros(0, np.int32), 0, None
+    else:
+        greqs, gx_pod, gx_time, gexpl, g_expiry, tstats = gates  # tstats: typeSetStats(type) per type row (oracle.bind.ORC_STATS)
     hdr = [P, M, len(fleet.ent_pod), T, W, len(repl), len(reqs), len(extra), int(fleet.min_space_units), int(fleet.min_churn_age_ms),
-           int(fleet.now), len(sreqs), len(sx_pod), 0, 0, 0]
+           int(fleet.now), len(sreqs), len(sx_pod), len(greqs), len(gx_pod), len(gexpl)]
     idbuf = b"".join(s.encode("ascii").ljust(16, b"\0") for s in ids)
     parts = [b"MMREF1\0\0", struct.pack("<16q", *hdr), np.ascontiguousarray(fleet.pods).tobytes(), idbuf,
              np.ascontiguousarray(fleet.models).tobytes(), np.ascontiguousarray(fleet.ent_pod, dtype=np.int32).tobytes(),
@@ -151,6 +220,11 @@ def input_blob(fleet, ids, reqs=None, extra=None, serve=None) -> bytes:
     if len(sreqs):
         parts += [np.ascontiguousarray(in_use, dtype=np.int32).tobytes(), np.ascontiguousarray(last_used, dtype=np.int64).tobytes()]
     parts += [np.ascontiguousarray(sx_pod, dtype=np.int32).tobytes(), np.ascontiguousarray(sx_time, dtype=np.int64).tobytes()]
+    parts += [np.ascontiguousarray(greqs).tobytes(), np.ascontiguousarray(gx_pod, dtype=np.int32).tobytes(),
+              np.ascontiguousarray(gx_time, dtype=np.int64).tobytes(), np.ascontiguousarray(gexpl, dtype=np.int32).tobytes()]
+    if len(greqs):
+        assert tstats.dtype.itemsize == 32 and len(tstats) == max(T, 1)
+        parts += [struct.pack("<q", int(g_expiry)), np.ascontiguousarray(tstats).tobytes()]
     return b"".join(parts)
 
 

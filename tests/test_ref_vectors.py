@@ -86,3 +86,94 @@ def test_serve_targets_equal_the_reference_text(ref):
             assert ch == want[i, 0], (name, i, ch, ts, want[i], r)
             if ch >= 0:
                 assert ts == want[i, 1], (name, i, ch, ts, want[i])
+
+
+def oracle_gates(fleet, r, excl_pod, excl_time, explicit, in_use_expiry):
+    """The C restatements of the guards (oracle/mm_gates_oracle.c), request by request -> (bits, initial_size)."""
+    import ctypes as C
+
+    def _p(a):
+        return a.ctypes.data_as(C.c_void_p) if len(a) else None
+    lib = ob.load()
+    orc = OracleFleet(fleet)
+    P, now, m = fleet.n_pods, fleet.now, fleet.models
+    tstats = np.ascontiguousarray(ob.type_set_stats(fleet))
+    in_table = np.ascontiguousarray(((fleet.pods["flags"] & 4) == 0).astype(np.uint8))
+    al = ob.unpack_bitmap(fleet.allowed, P) if fleet.n_types else None
+    out = np.zeros((len(r), 2), np.int64)
+    for i in range(len(r)):
+        q = r[i]
+        mr = m[q["model"]]
+        lp = fleet.ent_pod[mr["ent_off"]: mr["ent_off"] + mr["n_loaded"]]
+        lt = fleet.ent_time[mr["ent_off"]: mr["ent_off"] + mr["n_loaded"]]
+        fp = fleet.ent_pod[mr["ent_off"] + mr["n_loaded"]: mr["ent_off"] + mr["n_loaded"] + mr["n_failed"]]
+        ft = fleet.ent_time[mr["ent_off"] + mr["n_loaded"]: mr["ent_off"] + mr["n_loaded"] + mr["n_failed"]]
+        keep = np.ones(len(lp), bool)
+        for j in range(q["n_excl"]):
+            keep &= lp != excl_pod[q["excl_off"] + j]
+        ex = np.ascontiguousarray(explicit[q["explicit_off"]: q["explicit_off"] + q["n_explicit"]])
+        fl, ty = int(q["flags"]), int(mr["type"])
+        stats = tstats[(0 if ty < 0 or ty >= len(tstats) else ty):][:1]
+        want = 0
+        cp, ct = np.ascontiguousarray(lp[keep]), np.ascontiguousarray(lt[keep])
+        if lib.orc_go_local(_p(cp), _p(ct), len(cp), int(q["self_pod"]), fl & 1, (fl >> 1) & 1, (fl >> 2) & 1, now):
+            want |= 1
+        ftc = np.ascontiguousarray(ft)
+        if lib.orc_load_failures_breached(_p(ftc), len(ftc), now, in_use_expiry):
+            want |= 2
+        lpc = np.ascontiguousarray(lp)
+        if lib.orc_load_locations_breached(_p(lpc), len(lpc), _p(ex), len(ex), _p(in_table)):
+            want |= 4
+        local_filtered = (q["self_pod"] in ex) or (q["self_pod"] in lp) or (q["self_pod"] in fp)
+        blocked = bool(fleet.n_types and fleet.has_allowed[mr["type"]] and not al[mr["type"]][q["self_pod"]])
+        if local_filtered or blocked:
+            want |= 8
+        if lib.orc_churn_reject(fleet.min_churn_age_ms, fleet.min_space_units, int(q["cache_capacity"]),
+                                int(q["cache_weighted_size"]), int(q["cache_oldest_time"]), now):
+            want |= 16
+        rej = C.c_int(0)
+        init = lib.orc_load_local_initial_size((fl >> 5) & 1, int(q["size_hint"]), int(q["loading_count"]),
+                                               int(q["weight_predict_cutoff"]), int(q["loader_predicted"]),
+                                               stats.ctypes.data_as(C.c_void_p), (fl >> 3) & 1,
+                                               int(q["last_used_time"]), int(q["cache_capacity"]),
+                                               int(q["cache_weighted_size"]), int(q["cache_oldest_time"]), C.byref(rej))
+        if rej.value:
+            want |= 32
+        if lib.orc_reload_elsewhere((fl >> 4) & 1, int(q["loaded_time"]), int(q["load_timeout_ms"]), now,
+                                    stats.ctypes.data_as(C.c_void_p)):
+            want |= 64
+        fresh = np.zeros(1, dtype=ob.ORC_POD)
+        fresh["lru_time"], fresh["capacity"], fresh["used"] = q["fresh_lru"], q["fresh_capacity"], q["fresh_used"]
+        fresh["count"], fresh["loading_threads"] = q["fresh_count"], q["fresh_loading_threads"]
+        fresh["loading_in_progress"], fresh["rpm"] = q["fresh_in_progress"], q["fresh_rpm"]
+        fresh["shutting_down"] = (fl >> 8) & 1
+        curp = np.ascontiguousarray(orc.pods[q["self_pod"]: q["self_pod"] + 1]).copy()
+        tomb = bool(fleet.pods["flags"][q["self_pod"]] & 4)
+        curp["shutting_down"] = bool(fleet.pods["flags"][q["self_pod"]] & 1)
+        if lib.orc_should_publish(None if tomb else curp.ctypes.data_as(C.c_void_p), fresh.ctypes.data_as(C.c_void_p),
+                                  now, int(q["last_published"]), (fl >> 6) & 1, (fl >> 7) & 1, fleet.min_space_units):
+            want |= 128
+        out[i] = want, init
+    return out
+
+
+def check_gates(name, got_bits, got_init, ref_gate):
+    """ref_gate: (MMP_GATE_* bits, initialSize) from the reference's fragments; the initial size is only observable where
+    loadLocal does not return early (:5195)."""
+    want_bits = ref_gate[:, 0].astype(np.uint32)
+    bad = np.nonzero(np.asarray(got_bits, np.uint32) != want_bits)[0]
+    assert len(bad) == 0, (name, len(bad), [(int(i), bin(int(got_bits[i])), bin(int(want_bits[i]))) for i in bad[:6]])
+    sized = (want_bits & 32) == 0
+    assert np.array_equal(np.asarray(got_init)[sized], ref_gate[sized, 1]), name
+    assert int(np.bitwise_or.reduce(want_bits)) == 255, "some guard never fired in the reference's run"
+
+
+def test_request_guards_equal_the_reference_text(ref):
+    """goLocal (:3599-3626), checkLoadFailureCount / checkLoadLocationCount (:4593-4626), throwIfLocalLoadNotAllowed (:4011-4041),
+    the churn guard (:3872-3884), loadLocal's sizing and early reject (:5159-5197), onEviction's reload rule (:2886-2897,
+    :2918-2920), publishInstanceRecord's hysteresis (:5395-5468) with loadingChange / loadChange (:5537-5549)."""
+    for name, fleet, ids, r, xp, xt, expl, expiry in rf.gate_cases():
+        tstats = np.ascontiguousarray(ob.type_set_stats(fleet))
+        assert rf.digest(rf.input_blob(fleet, ids, gates=(r, xp, xt, expl, expiry, tstats))) == bytes(ref[f"{name}/digest"]).decode(), name
+        got = oracle_gates(fleet, r, xp, xt, expl, expiry)
+        check_gates(name, got[:, 0], got[:, 1], ref[f"{name}/gate"])

@@ -47,3 +47,15 @@ def test_hip_serve_targets_equal_the_reference_text(ref):
         assert np.array_equal(got["chosen"], want[:, 0]), (name, np.nonzero(got["chosen"] != want[:, 0])[0][:5])
         remote = want[:, 0] >= 0  # (ABORT_REQUEST returns before filtered.add(chosenId, chosenTimeStamp), :4384-4389)
         assert np.array_equal(got["chosen_load_start"][remote], want[remote, 1]), name
+
+
+def test_hip_request_guards_equal_the_reference_text(ref):
+    from tests.test_ref_vectors import check_gates
+    for name, fleet, ids, r, xp, xt, expl, expiry in rf.gate_cases():
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            s.load_fleet(fleet)
+            got = s.gates(r, xp, xt, expl, fleet.now, expiry)
+        finally:
+            s.close()
+        check_gates(name, got["bits"], got["initial_size"], ref[f"{name}/gate"])
