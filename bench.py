@@ -519,9 +519,23 @@ def secondary_kernels_leg(fleet, solver, device: int, workload: str = "C3", reps
         last_used = (now - rng.integers(0, 10_000, P)).astype(np.int64)
         kk = m["n_loaded"][sr["model"]].astype(np.int64)
         z32, z64 = np.zeros(0, np.int32), np.zeros(0, np.int64)
-        timed("serve_batch_kernel", lambda: solver.serve(sr, in_use, last_used, z32, z64, now),
-              int((40 + 16 + 24 + 24 * kk).sum()), n, "serve-target decisions",
-              "request 40 B + model row 24 B + (entry 12 B + inUse/lastUsed 12 B) per copy + result 16 B")
+        srk, counters = solver.serve_counters(sr, in_use, last_used)  # what the host assembles: one entry per listed copy
+        timed("serve_batch_kernel", lambda: solver.serve_k(srk, counters, z32, z64, now),
+              int((48 + 16 + 24 + 28 * kk).sum()), n, "serve-target decisions",
+              "request 48 B + model row 24 B + (entry 12 B + counter 16 B) per copy + result 16 B; nothing indexed by the instance table")
+        # the seam the LB uses: one request per call (ForwardingLB.getNext, MM.java:4315) through a latency slot
+        one, cnt1 = srk[:1].copy(), counters[int(srk["cnt_off"][0]): int(srk["cnt_off"][0]) + int(srk["n_cnt"][0])].copy()
+        one["cnt_off"] = 0
+        lat = []
+        for _ in range(200):
+            solver.serve_k(one, cnt1, z32, z64, now)
+        for _ in range(3000):
+            t0 = time.perf_counter_ns()
+            solver.serve_k(one, cnt1, z32, z64, now)
+            lat.append(time.perf_counter_ns() - t0)
+        out.append({"kernel": "serve_single", "p50_us": float(np.percentile(lat, 50)) / 1e3, "p99_us": float(np.percentile(lat, 99)) / 1e3,
+                    "bytes_in": int(48 + 16 * len(cnt1)), "unit": "serve-target decision",
+                    "note": "mmp_serve_batch(n = 1) through a latency slot: 48 B + 16 B per listed copy cross the boundary (round 2: two P-sized arrays)"})
 
         # a10 / a11 / a14 / a20 request guards
         g = np.zeros(n, dtype=_lib.GATE_REQ)

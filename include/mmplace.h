@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MMP_ABI_VERSION 1
+#define MMP_ABI_VERSION 2
 
 /* return codes */
 #define MMP_OK 0
@@ -113,9 +113,19 @@ typedef struct {
     uint32_t hash;        /* shortlist bitmap hash (audit)      */
 } mmp_place_out;
 
-/* One ForwardingLB.getNext call (MM.java:4315) — cache-hit routing. */
+/* One ForwardingLB.getNext call (MM.java:4315) — cache-hit routing, 48 bytes.
+ * The reference reads litelinks' per-instance counters only for the instances that hold a copy of the model
+ * (si.getInUseCount() / si.getLastUsedTime(), MM.java:4356,4360, inside the loop over filteredInstances): the
+ * request brings exactly those — [cnt_off, cnt_off + n_cnt) of the call's mmp_serve_counter pool, one entry per
+ * copy whose instance litelinks lists (siMap.get(iid) != null, :4343).  A copy WITHOUT an entry is a copy litelinks
+ * does not list: it is skipped as at :4344-4347.  Nothing the size of the instance table crosses the boundary. */
 #define MMP_SERVE_EXCLUDE_SELF 1u
 #define MMP_SERVE_PREFER_SELF 2u
+typedef struct {
+    int32_t pod;       /* the instance (pod index)                         */
+    int32_t in_use;    /* ServiceInstance.getInUseCount(), MM.java:4356    */
+    int64_t last_used; /* ServiceInstance.getLastUsedTime(), MM.java:4360  */
+} mmp_serve_counter;
 typedef struct {
     int32_t model;
     int32_t self_pod;
@@ -125,6 +135,8 @@ typedef struct {
     int64_t assume_completed_ms; /* TimeStats.assumeCompletedAfterMillis        */
     int32_t excl_off;            /* (pod,loadStart) pairs already tried + keyExcludes */
     int32_t n_excl;
+    int32_t cnt_off;             /* this request's counters in the pool               */
+    int32_t n_cnt;
 } mmp_serve_req;
 
 typedef struct {
@@ -450,11 +462,12 @@ int mmp_issue_flush(mmp_ctx *ctx);
 int mmp_stream_retire(mmp_ctx *ctx, void *stream);
 
 /* n serve-target decisions = n × ForwardingLB.getNext (MM.java:4315-4392).
- * in_use / last_used: ServiceInstance.getInUseCount / getLastUsedTime per pod
- * (MM.java:4356,4360). excl_pod/excl_time: pairs referenced by excl_off. */
-int mmp_serve_batch(mmp_ctx *ctx, const mmp_serve_req *reqs, int32_t n, const int32_t *in_use,
-                    const int64_t *last_used, const int32_t *excl_pod, const int64_t *excl_time,
-                    int32_t n_excl_pool, int64_t now_ms, mmp_serve_out *outs);
+ * counters: the requests' mmp_serve_counter entries (see mmp_serve_req); excl_pod / excl_time: pairs referenced by
+ * excl_off.  O(copies) per request on both sides of the boundary; calls of up to 1024 requests (8192 counters, 4096
+ * exclusion pairs) ride the latency slots like mmp_place_batch's. */
+int mmp_serve_batch(mmp_ctx *ctx, const mmp_serve_req *reqs, int32_t n, const mmp_serve_counter *counters,
+                    int32_t n_counters, const int32_t *excl_pod, const int64_t *excl_time, int32_t n_excl_pool,
+                    int64_t now_ms, mmp_serve_out *outs);
 
 /* Per-pod cache segments for eviction: seg_off has n_caches+1 entries; entry i
  * of a segment is the i-th node of that cache's evictionDeque (oldest first). */

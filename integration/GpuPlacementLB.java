@@ -48,7 +48,7 @@ final class MmPlace {
     static native int modelsUpsert(long h, ByteBuffer idx, ByteBuffer rows, int n, ByteBuffer entPod, ByteBuffer entTime, int nEntries);
     static native int commit(long h);
     static native int placeBatch(long h, ByteBuffer reqs, int n, ByteBuffer extraPool, int nExtra, long nowMs, ByteBuffer outs);
-    static native int serveBatch(long h, ByteBuffer reqs, int n, ByteBuffer inUse, ByteBuffer lastUsed,
+    static native int serveBatch(long h, ByteBuffer reqs, int n, ByteBuffer counters, int nCounters,
                                  ByteBuffer exclPod, ByteBuffer exclTime, int nExcl, long nowMs, ByteBuffer outs);
     /** keep one wavefront resident that serves placeBatch(n = 1) from 64 pinned request slots: no launch per request */
     static native int resident(long h, boolean enable);
@@ -236,8 +236,8 @@ class GpuCacheMissLB extends ModelMesh.IdBasedLoadBalancer {
 
 /**
  * Replaces the BODY of ForwardingLB.getNext (ModelMesh.java:4315-4392), the cache-hit routing: one
- * mmp_serve_batch(n = 1) per request.  The copies of the model come from the library's registry view; the
- * per-instance litelinks counters (getInUseCount / getLastUsedTime, :4356, :4360) are passed per call.
+ * mmp_serve_batch(n = 1) per request.  The copies of the model come from the library's registry view; the litelinks
+ * counters (getInUseCount / getLastUsedTime, :4356, :4360) of THOSE copies ride in the request — O(copies) per call.
  */
 class GpuForwardingLB extends ModelMesh.IdBasedLoadBalancer {
     final GpuMeshBinding mesh;
@@ -247,7 +247,7 @@ class GpuForwardingLB extends ModelMesh.IdBasedLoadBalancer {
 
     GpuForwardingLB(GpuMeshBinding mesh) { this.mesh = mesh; }
 
-    private static final ThreadLocal<ByteBuffer> REQ = ThreadLocal.withInitial(() -> MmPlace.direct(40));
+    private static final ThreadLocal<ByteBuffer> REQ = ThreadLocal.withInitial(() -> MmPlace.direct(48));
     private static final ThreadLocal<ByteBuffer> OUT = ThreadLocal.withInitial(() -> MmPlace.direct(16));
     private static final ThreadLocal<ByteBuffer[]> POOLS = ThreadLocal.withInitial(() -> new ByteBuffer[4]);
 
@@ -259,23 +259,27 @@ class GpuForwardingLB extends ModelMesh.IdBasedLoadBalancer {
     }
 
     int decide(Map<String, ServiceInstanceInfo> siMap, ModelMesh.MapFilteringSet<String, Long> filtered, long nowMs) {
-        final int P = mesh.podCount();
-        // ServiceInstance counters of the instances litelinks knows; instances it does not know stay at 0 and are
-        // skipped by the kernel through the exclusion list below (sii == null -> continue, :4343-4347)
-        ByteBuffer inUse = pool(0, 4 * P), lastUsed = pool(1, 8 * P);
-        for (int p = 0; p < P; p++) { inUse.putInt(4 * p, 0); lastUsed.putLong(8 * p, 0L); }
-        for (ServiceInstanceInfo sii : siMap.values()) {
-            int p = mesh.podIndexOf(sii.getInstanceId());
+        // The reference touches litelinks' counters only for the model's copies (si.getInUseCount() / getLastUsedTime(),
+        // :4356, :4360, inside the loop over filteredInstances): one mmp_serve_counter per copy that siMap lists.  A copy
+        // without an entry is one litelinks does not list (sii == null -> continue, :4343-4347).  O(copies), nothing P-sized.
+        final Map<String, Long> copies = filtered.map();
+        ByteBuffer cnt = pool(0, 16 * Math.max(copies.size(), 1));
+        int nCnt = 0;
+        for (String iid : copies.keySet()) {
+            final ServiceInstanceInfo sii = siMap.get(iid);
+            if (sii == null) continue;
+            final int p = mesh.podIndexOf(iid);
             if (p < 0) continue;
-            ServiceInstance<?> si = (ServiceInstance<?>) sii;
-            inUse.putInt(4 * p, si.getInUseCount());
-            lastUsed.putLong(8 * p, si.getLastUsedTime());
+            final ServiceInstance<?> si = (ServiceInstance<?>) sii;
+            cnt.putInt(16 * nCnt, p);
+            cnt.putInt(16 * nCnt + 4, si.getInUseCount());
+            cnt.putLong(16 * nCnt + 8, si.getLastUsedTime());
+            nCnt++;
         }
         // already-tried (instance, loadStart) pairs — the MapFilteringSet's own keys — plus keyExcludes (:4278-4280);
         // an exclusion with load start Long.MIN_VALUE excludes the instance whatever its time stamp
-        final Map<String, Long> copies = filtered.map();
         final Collection<String> keyExcludes = mesh.cacheHitKeyExcludes();
-        final int bound = filtered.size() + copies.size() + (keyExcludes != null ? keyExcludes.size() : 0) + 1;
+        final int bound = filtered.size() + (keyExcludes != null ? keyExcludes.size() : 0) + 1;
         ByteBuffer ep = pool(2, 4 * bound), et = pool(3, 8 * bound);
         int nExcl = 0;
         if (keyExcludes != null) for (String iid : keyExcludes) {
@@ -286,12 +290,7 @@ class GpuForwardingLB extends ModelMesh.IdBasedLoadBalancer {
             int p = mesh.podIndexOf(tried.getKey());
             if (p >= 0) { ep.putInt(4 * nExcl, p); et.putLong(8 * nExcl, tried.getValue()); nExcl++; }
         }
-        for (String iid : copies.keySet()) {            // copies litelinks does not list: sii == null
-            if (siMap.containsKey(iid)) continue;
-            int p = mesh.podIndexOf(iid);
-            if (p >= 0) { ep.putInt(4 * nExcl, p); et.putLong(8 * nExcl, Long.MIN_VALUE); nExcl++; }
-        }
-        ByteBuffer q = REQ.get(); q.clear();            // mmp_serve_req, 40 bytes
+        ByteBuffer q = REQ.get(); q.clear();            // mmp_serve_req, 48 bytes
         q.putInt(mesh.modelIndexOf(mesh.currentModelId()));
         q.putInt(mesh.podIndexOf(mesh.selfInstanceId()));
         q.putInt((filtered.excludeSelf ? 1 : 0) | (filtered.preferSelf ? 2 : 0)); // MMP_SERVE_EXCLUDE_SELF | _PREFER_SELF
@@ -299,8 +298,9 @@ class GpuForwardingLB extends ModelMesh.IdBasedLoadBalancer {
         q.putLong(mesh.lastInvokeTime());
         q.putLong(mesh.assumeCompletedAfterMillis(filtered.modelType));
         q.putInt(0); q.putInt(nExcl);                   // excl_off, n_excl
+        q.putInt(0); q.putInt(nCnt);                    // cnt_off, n_cnt
         ByteBuffer o = OUT.get();
-        MmPlace.serveBatch(mesh.handle(), q, 1, inUse, lastUsed, ep, et, nExcl, nowMs, o);
+        MmPlace.serveBatch(mesh.handle(), q, 1, cnt, nCnt, ep, et, nExcl, nowMs, o);
         final long[] last = LAST_OUT.get();
         last[0] = o.getInt(0);
         last[1] = o.getLong(8);

@@ -161,16 +161,21 @@ JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_shardPlaceBatch(JNI
                                        nowMs, buf<mmp_place_out>(env, outs), buf<int32_t>(env, nRestOut)));
 }
 
-// ForwardingLB.getNext (MM.java:4315)
+// ForwardingLB.getNext (MM.java:4315): the request brings the counters of its own copies (O(copies), no table-sized buffer)
 JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_serveBatch(JNIEnv *env, jclass, jlong h, jobject reqs,
-                                                                        jint n, jobject inUse, jobject lastUsed,
+                                                                        jint n, jobject counters, jint nCounters,
                                                                         jobject exclPod, jobject exclTime, jint nExcl,
                                                                         jlong nowMs, jobject outs)
 {
+    if (!holds<mmp_serve_req>(env, reqs, n, "serveBatch: reqs shorter than n requests") ||
+        !holds<mmp_serve_counter>(env, counters, nCounters, "serveBatch: counters shorter than nCounters entries") ||
+        !holds<int32_t>(env, exclPod, nExcl, "serveBatch: exclPod shorter than nExcl entries") ||
+        !holds<int64_t>(env, exclTime, nExcl, "serveBatch: exclTime shorter than nExcl entries") ||
+        !holds<mmp_serve_out>(env, outs, n, "serveBatch: outs shorter than n results"))
+        return MMP_EINVAL;
     return check(env, ctx_of(h),
-                 mmp_serve_batch(ctx_of(h), buf<mmp_serve_req>(env, reqs), n, buf<int32_t>(env, inUse),
-                                 buf<int64_t>(env, lastUsed), buf<int32_t>(env, exclPod), buf<int64_t>(env, exclTime),
-                                 nExcl, nowMs, buf<mmp_serve_out>(env, outs)));
+                 mmp_serve_batch(ctx_of(h), buf<mmp_serve_req>(env, reqs), n, buf<mmp_serve_counter>(env, counters), nCounters,
+                                 buf<int32_t>(env, exclPod), buf<int64_t>(env, exclTime), nExcl, nowMs, buf<mmp_serve_out>(env, outs)));
 }
 
 JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_clusterStats(JNIEnv *env, jclass, jlong h, jobject out)

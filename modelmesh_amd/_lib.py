@@ -37,7 +37,9 @@ PLACE_REQ = np.dtype(
 PLACE_OUT = np.dtype([("chosen", "<i4"), ("best", "<i4"), ("n_candidates", "<i4"), ("hash", "<u4")])
 SERVE_REQ = np.dtype(
     [("model", "<i4"), ("self_pod", "<i4"), ("flags", "<u4"), ("local_in_flight", "<i4"),
-     ("last_invoke_time", "<i8"), ("assume_completed_ms", "<i8"), ("excl_off", "<i4"), ("n_excl", "<i4")])
+     ("last_invoke_time", "<i8"), ("assume_completed_ms", "<i8"), ("excl_off", "<i4"), ("n_excl", "<i4"),
+     ("cnt_off", "<i4"), ("n_cnt", "<i4")])
+SERVE_COUNTER = np.dtype([("pod", "<i4"), ("in_use", "<i4"), ("last_used", "<i8")])
 SERVE_OUT = np.dtype([("chosen", "<i4"), ("pad", "<i4"), ("chosen_load_start", "<i8")])
 STATS = np.dtype(
     [("total_capacity", "<i8"), ("total_free", "<i8"), ("global_lru", "<i8"),
@@ -96,7 +98,7 @@ UNLOADBUF_KEY = -1000000
  COP_UBM_DISCARD_FAILED, COP_UBM_INSERT_FAILED_PLACEHOLDER) = range(13)
 
 assert POD_ROW.itemsize == 64 and MODEL_ROW.itemsize == 24 and PLACE_REQ.itemsize == 64
-assert PLACE_OUT.itemsize == 16 and SERVE_REQ.itemsize == 40 and SERVE_OUT.itemsize == 16
+assert PLACE_OUT.itemsize == 16 and SERVE_REQ.itemsize == 48 and SERVE_COUNTER.itemsize == 16 and SERVE_OUT.itemsize == 16
 assert STATS.itemsize == 32 and EVICT_REQ.itemsize == 16 and EVICT_OUT.itemsize == 32
 
 
@@ -140,7 +142,7 @@ SYMBOLS = [
     ("mmp_resident_stats", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("mmp_issue_threads", C.c_int, [_P, C.c_int32]),
     ("mmp_issue_flush", C.c_int, [_P]),
-    ("mmp_serve_batch", C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int64, _P]),
+    ("mmp_serve_batch", C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, C.c_int64, _P]),
     ("mmp_caches_load", C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
     ("mmp_evict_batch", C.c_int, [_P, _P, C.c_int32, C.c_int64, _P]),
     ("mmp_caches_load_keyed", C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),

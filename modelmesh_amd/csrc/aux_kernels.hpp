@@ -11,121 +11,135 @@ struct ServeArgs {
     const mmp_model_row *models;
     const int32_t *ent_pod;
     const int64_t *ent_time;
-    const mmp_pod_row *pods;  // for the live flag
-    const int32_t *in_use;
-    const int64_t *last_used;
+    const mmp_serve_counter *counters;  // the requests' (instance, inUse, lastUsed) entries: the copies litelinks lists
     const int32_t *excl_pod;
     const int64_t *excl_time;
     mmp_serve_out *outs;
     int32_t n, n_models, P;
     int64_t now;
+    DoneFlag done;  // latency path (wave.hpp); {nullptr} otherwise
 };
 
 // ForwardingLB.getNext (MM.java:4315-4392): k is tiny (1-3 copies), so one
 // lane runs the loop exactly as written; lanes = independent requests.
-// A launch lasts as long as its chain of dependent fetches (request -> model row -> copies -> the copies' instance
-// state), so the first kServePre copies and kServeExcl exclusions are fetched level by level, everything of a level
-// in flight together, before the loop runs on registers; copies / exclusions beyond that are fetched in the loop.
+// A launch lasts as long as its chain of dependent fetches, and the request names everything but the copies themselves:
+// request -> { model row, the request's counters, its exclusions } -> copies.  The first kServePre copies / counters and
+// kServeExcl exclusions are fetched level by level, everything of a level in flight together, before the loop runs on
+// registers; what lies beyond is fetched in the loop.  The per-instance counters come WITH the request (one entry per copy
+// that litelinks lists, mmp_serve_req): nothing is indexed by the instance table (round 2 took two P-sized arrays per call).
 constexpr int kServePre = 4;
 constexpr int kServeExcl = 4;
 
 __global__ void serve_batch_kernel(ServeArgs A)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.n) return;
-    const mmp_serve_req r = A.reqs[i];
-    mmp_serve_out o;
-    o.chosen = MMP_NONE;
-    o.pad = 0;
-    o.chosen_load_start = 0;
-    if (r.model < 0 || r.model >= A.n_models) {
+    if (i < A.n) {
+        const mmp_serve_req r = A.reqs[i];
+        mmp_serve_out o;
+        o.chosen = MMP_NONE;
+        o.pad = 0;
+        o.chosen_load_start = 0;
+        if (r.model >= 0 && r.model < A.n_models) {
+            // level 2: the model row, the request's first counters and exclusions
+            const mmp_model_row m = A.models[r.model];
+            mmp_serve_counter c_pre[kServePre];
+#pragma unroll
+            for (int j = 0; j < kServePre; j++) {
+                c_pre[j].pod = -1;
+                c_pre[j].in_use = 0;
+                c_pre[j].last_used = 0;
+                if (j < r.n_cnt) c_pre[j] = A.counters[r.cnt_off + j];
+            }
+            int32_t x_pod[kServeExcl];
+            int64_t x_time[kServeExcl];
+#pragma unroll
+            for (int x = 0; x < kServeExcl; x++) {
+                x_pod[x] = x < r.n_excl ? A.excl_pod[r.excl_off + x] : -1;
+                x_time[x] = x < r.n_excl ? A.excl_time[r.excl_off + x] : 0;
+            }
+            // level 3: the first copies
+            int32_t p_iid[kServePre];
+            int64_t p_ts[kServePre];
+#pragma unroll
+            for (int e = 0; e < kServePre; e++) {
+                p_iid[e] = e < m.n_loaded ? A.ent_pod[m.ent_off + e] : -1;
+                p_ts[e] = e < m.n_loaded ? A.ent_time[m.ent_off + e] : 0;
+            }
+            const bool exclude_self = r.flags & MMP_SERVE_EXCLUDE_SELF, prefer_self = r.flags & MMP_SERVE_PREFER_SELF;
+            bool seen_self = false;
+            int32_t chosen = -1;
+            int64_t chosen_ts = 0;
+            int32_t mn = INT32_MAX;
+            int64_t lru = INT64_MAX, first_started = INT64_MAX;
+            const int64_t cutoff = (int64_t)((uint64_t)A.now - (uint64_t)r.assume_completed_ms);  // :4350
+            // one copy of the loop body
+            auto visit = [&](int32_t iid, int64_t load_started) {
+                // MapFilteringSet.apply (MM.java:4279-4283)
+                bool filtered = false;
+#pragma unroll
+                for (int x = 0; x < kServeExcl; x++)
+                    if (x < r.n_excl && x_pod[x] == iid && (x_time[x] == MMP_ANY_TIME || x_time[x] == load_started)) filtered = true;
+                for (int x = kServeExcl; x < r.n_excl; x++) {
+                    const int32_t xp = A.excl_pod[r.excl_off + x];
+                    const int64_t xt = A.excl_time[r.excl_off + x];
+                    if (xp == iid && (xt == MMP_ANY_TIME || xt == load_started)) filtered = true;
+                }
+                if (filtered) return;
+                bool us = false;
+                if (!seen_self && iid == r.self_pod) {  // :4334-4342
+                    seen_self = true;
+                    if (exclude_self) return;
+                    us = true;
+                }
+                // siMap.get(iid), :4343: the request's counter entry of this instance
+                bool listed = false;
+                int32_t pod_in_use = 0;
+                int64_t pod_last_used = 0;
+#pragma unroll
+                for (int j = 0; j < kServePre; j++)
+                    if (j < r.n_cnt && c_pre[j].pod == iid && !listed) {
+                        listed = true;
+                        pod_in_use = c_pre[j].in_use;
+                        pod_last_used = c_pre[j].last_used;
+                    }
+                for (int j = kServePre; j < r.n_cnt && !listed; j++) {
+                    const mmp_serve_counter cj = A.counters[r.cnt_off + j];
+                    if (cj.pod == iid) {
+                        listed = true;
+                        pod_in_use = cj.in_use;
+                        pod_last_used = cj.last_used;
+                    }
+                }
+                if (!listed || iid < 0) return;  // sii == null: litelinks does not list the instance
+                if (load_started < cutoff) {  // :4352-4367
+                    const int32_t inuse = us ? r.local_in_flight : pod_in_use;
+                    if (inuse > mn) return;
+                    const int64_t nlu = us ? (prefer_self ? 0 : r.last_invoke_time) : pod_last_used;
+                    if (inuse < mn)
+                        mn = inuse;
+                    else if (nlu >= lru)
+                        return;
+                    chosen = iid;
+                    chosen_ts = load_started;
+                    lru = nlu;
+                } else if (mn == INT32_MAX && load_started < first_started) {  // :4369-4376
+                    chosen = iid;
+                    chosen_ts = load_started;
+                    first_started = load_started;
+                }
+            };
+#pragma unroll
+            for (int e = 0; e < kServePre; e++)
+                if (e < m.n_loaded) visit(p_iid[e], p_ts[e]);
+            for (int e = kServePre; e < m.n_loaded; e++) visit(A.ent_pod[m.ent_off + e], A.ent_time[m.ent_off + e]);
+            if (chosen >= 0) {
+                o.chosen = (!exclude_self && chosen == r.self_pod) ? MMP_SELF : chosen;  // :4381-4385
+                o.chosen_load_start = chosen_ts;
+            }
+        }
         A.outs[i] = o;
-        return;
     }
-    // level 2: the model row and the request's first exclusions
-    const mmp_model_row m = A.models[r.model];
-    int32_t x_pod[kServeExcl];
-    int64_t x_time[kServeExcl];
-#pragma unroll
-    for (int x = 0; x < kServeExcl; x++) {
-        x_pod[x] = x < r.n_excl ? A.excl_pod[r.excl_off + x] : -1;
-        x_time[x] = x < r.n_excl ? A.excl_time[r.excl_off + x] : 0;
-    }
-    // level 3: the first copies; level 4: the state of their instances
-    int32_t p_iid[kServePre], p_inuse[kServePre];
-    uint32_t p_flags[kServePre];
-    int64_t p_ts[kServePre], p_lu[kServePre];
-#pragma unroll
-    for (int e = 0; e < kServePre; e++) {
-        p_iid[e] = e < m.n_loaded ? A.ent_pod[m.ent_off + e] : -1;
-        p_ts[e] = e < m.n_loaded ? A.ent_time[m.ent_off + e] : 0;
-    }
-#pragma unroll
-    for (int e = 0; e < kServePre; e++) {
-        const bool in_table = p_iid[e] >= 0 && p_iid[e] < A.P;
-        p_flags[e] = in_table ? A.pods[p_iid[e]].flags : 0u;
-        p_inuse[e] = in_table ? A.in_use[p_iid[e]] : 0;
-        p_lu[e] = in_table ? A.last_used[p_iid[e]] : 0;
-    }
-    const bool exclude_self = r.flags & MMP_SERVE_EXCLUDE_SELF, prefer_self = r.flags & MMP_SERVE_PREFER_SELF;
-    bool seen_self = false;
-    int32_t chosen = -1;
-    int64_t chosen_ts = 0;
-    int32_t mn = INT32_MAX;
-    int64_t lru = INT64_MAX, first_started = INT64_MAX;
-    const int64_t cutoff = (int64_t)((uint64_t)A.now - (uint64_t)r.assume_completed_ms);  // :4350
-    // one copy of the loop body; flags = 0 for an instance id outside the table (sii == null)
-    auto visit = [&](int32_t iid, int64_t load_started, uint32_t flags, int32_t pod_in_use, int64_t pod_last_used) {
-        // MapFilteringSet.apply (MM.java:4279-4283)
-        bool filtered = false;
-#pragma unroll
-        for (int x = 0; x < kServeExcl; x++)
-            if (x < r.n_excl && x_pod[x] == iid && (x_time[x] == MMP_ANY_TIME || x_time[x] == load_started)) filtered = true;
-        for (int x = kServeExcl; x < r.n_excl; x++) {
-            const int32_t xp = A.excl_pod[r.excl_off + x];
-            const int64_t xt = A.excl_time[r.excl_off + x];
-            if (xp == iid && (xt == MMP_ANY_TIME || xt == load_started)) filtered = true;
-        }
-        if (filtered) return;
-        bool us = false;
-        if (!seen_self && iid == r.self_pod) {  // :4334-4342
-            seen_self = true;
-            if (exclude_self) return;
-            us = true;
-        }
-        if (!(flags & MMP_POD_LIVE)) return;  // sii == null
-        if (load_started < cutoff) {  // :4352-4367
-            const int32_t inuse = us ? r.local_in_flight : pod_in_use;
-            if (inuse > mn) return;
-            const int64_t nlu = us ? (prefer_self ? 0 : r.last_invoke_time) : pod_last_used;
-            if (inuse < mn)
-                mn = inuse;
-            else if (nlu >= lru)
-                return;
-            chosen = iid;
-            chosen_ts = load_started;
-            lru = nlu;
-        } else if (mn == INT32_MAX && load_started < first_started) {  // :4369-4376
-            chosen = iid;
-            chosen_ts = load_started;
-            first_started = load_started;
-        }
-    };
-#pragma unroll
-    for (int e = 0; e < kServePre; e++)
-        if (e < m.n_loaded) visit(p_iid[e], p_ts[e], p_flags[e], p_inuse[e], p_lu[e]);
-    for (int e = kServePre; e < m.n_loaded; e++) {
-        const int32_t iid = A.ent_pod[m.ent_off + e];
-        const int64_t load_started = A.ent_time[m.ent_off + e];
-        const bool in_table = iid >= 0 && iid < A.P;
-        visit(iid, load_started, in_table ? A.pods[iid].flags : 0u, in_table ? A.in_use[iid] : 0,
-              in_table ? A.last_used[iid] : 0);
-    }
-    if (chosen >= 0) {
-        o.chosen = (!exclude_self && chosen == r.self_pod) ? MMP_SELF : chosen;  // :4381-4385
-        o.chosen_load_start = chosen_ts;
-    }
-    A.outs[i] = o;
+    announce_done(A.done);
 }
 
 struct EvictArgs {

@@ -2913,15 +2913,67 @@ try {
     return fail(c, MMP_EHIP, "%s: %s", "mmp_place_batch", e.what());
 }
 
-int mmp_serve_batch(mmp_ctx *c, const mmp_serve_req *reqs, int32_t n, const int32_t *in_use, const int64_t *last_used,
+int mmp_serve_batch(mmp_ctx *c, const mmp_serve_req *reqs, int32_t n, const mmp_serve_counter *counters, int32_t n_counters,
                     const int32_t *excl_pod, const int64_t *excl_time, int32_t n_excl, int64_t now, mmp_serve_out *outs)
 try {
-    if (!c || n < 0 || n_excl < 0 || (n > 0 && (!reqs || !outs || !in_use || !last_used)) ||
+    if (!c || n < 0 || n_excl < 0 || n_counters < 0 || (n > 0 && (!reqs || !outs)) || (n_counters > 0 && !counters) ||
         (n_excl > 0 && (!excl_pod || !excl_time)))
         return fail(c, MMP_EINVAL, "mmp_serve_batch: bad argument");
-    for (int32_t i = 0; i < n; i++)
+    for (int32_t i = 0; i < n; i++) {
         if (reqs[i].n_excl < 0 || reqs[i].excl_off < 0 || (int64_t)reqs[i].excl_off + reqs[i].n_excl > n_excl)
             return fail(c, MMP_EINVAL, "mmp_serve_batch: request %d exclude range out of bounds", i);
+        if (reqs[i].n_cnt < 0 || reqs[i].cnt_off < 0 || (int64_t)reqs[i].cnt_off + reqs[i].n_cnt > n_counters)
+            return fail(c, MMP_EINVAL, "mmp_serve_batch: request %d counter range out of bounds", i);
+    }
+    auto args = [&](int32_t cnt) {
+        ServeArgs A{};
+        A.models = c->models.as<mmp_model_row>();
+        A.ent_pod = c->ent_pod.as<int32_t>();
+        A.ent_time = c->ent_time.as<int64_t>();
+        A.n = cnt;
+        A.n_models = c->n_models;
+        A.P = c->snap.P;
+        A.now = now;
+        A.done = DoneFlag{nullptr, nullptr, 0};
+        return A;
+    };
+    // latency path (see slot_acquire): the slot's pinned buffers take the requests, the counters behind them, and the
+    // exclusion pairs in the int pool; one launch + the completion flag, no staging copies — what the LB's one call per
+    // request (MM.java:4315) needs.  Everything a call brings is O(copies): 48 B + 16 B per listed copy.
+    constexpr int kSlotReqs = 1024, kSlotCounters = 8192, kSlotExcl = kFastExtra / 4;
+    static_assert((size_t)kSlotReqs * sizeof(mmp_serve_req) + (size_t)kSlotCounters * sizeof(mmp_serve_counter) <= (size_t)kFastN * sizeof(mmp_place_req),
+                  "requests + counters fit the slot's request buffer");
+    static_assert((size_t)kSlotReqs * sizeof(mmp_serve_out) <= (size_t)kFastN * sizeof(mmp_place_out), "results fit the slot's result buffer");
+    if (n > 0 && n <= kSlotReqs && n_counters <= kSlotCounters && n_excl <= kSlotExcl) {
+        HIP_TRY(c, hipSetDevice(c->cfg.device));
+        std::unique_lock<std::mutex> fl;
+        FastSlot *f = slot_acquire(c, fl);
+        char *rb = reinterpret_cast<char *>(f->reqs);
+        memcpy(rb, reqs, (size_t)n * sizeof(mmp_serve_req));
+        mmp_serve_counter *cb = reinterpret_cast<mmp_serve_counter *>(rb + (size_t)kSlotReqs * sizeof(mmp_serve_req));
+        if (n_counters) memcpy(cb, counters, (size_t)n_counters * sizeof(mmp_serve_counter));
+        int32_t *pool = f->extra;
+        if (n_excl) {
+            memcpy(pool, excl_pod, (size_t)n_excl * 4);
+            memcpy(pool + 2 * kSlotExcl, excl_time, (size_t)n_excl * 8);
+        }
+        {
+            std::shared_lock<std::shared_mutex> g(c->mu);  // capture the registry view + enqueue
+            if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+            ServeArgs A = args(n);
+            A.reqs = reinterpret_cast<const mmp_serve_req *>(rb);
+            A.counters = cb;
+            A.excl_pod = pool;
+            A.excl_time = reinterpret_cast<const int64_t *>(pool + 2 * kSlotExcl);
+            A.outs = reinterpret_cast<mmp_serve_out *>(f->outs);
+            A.done = DoneFlag{f->done, f->blocks, ++f->seq};
+            hipLaunchKernelGGL(serve_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, f->stream, A);
+            HIP_TRY(c, hipGetLastError());
+        }
+        HIP_TRY(c, slot_wait(f));
+        memcpy(outs, f->outs, (size_t)n * sizeof(mmp_serve_out));
+        return MMP_OK;
+    }
     // batch_mu owns c->stream and the scratch for the whole call, and every writer of the state this call reads
     // (commit, the loaders, registry events) takes it too: the published snapshot cannot change underneath.  The
     // state lock c->mu is NOT held: latency-path calls (mmp_place_batch / _gate / _evict on the slots) keep flowing.
@@ -2930,37 +2982,23 @@ try {
     if (n == 0) return MMP_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     hipStream_t st = c->stream;
-    const int32_t P = c->snap.P;
     HIP_TRY(c, c->s_reqs.ensure((size_t)n * sizeof(mmp_serve_req)));
     HIP_TRY(c, c->s_outs.ensure((size_t)n * sizeof(mmp_serve_out)));
-    HIP_TRY(c, c->s_a.ensure((size_t)std::max(P, 1) * 4));
-    HIP_TRY(c, c->s_b.ensure((size_t)std::max(P, 1) * 8));
+    HIP_TRY(c, c->s_a.ensure((size_t)std::max(n_counters, 1) * sizeof(mmp_serve_counter)));
     HIP_TRY(c, c->s_c.ensure((size_t)std::max(n_excl, 1) * 4));
     HIP_TRY(c, c->s_d.ensure((size_t)std::max(n_excl, 1) * 8));
     HIP_TRY(c, hipMemcpyAsync(c->s_reqs.p, reqs, (size_t)n * sizeof(mmp_serve_req), hipMemcpyHostToDevice, st));
-    if (P) {
-        HIP_TRY(c, hipMemcpyAsync(c->s_a.p, in_use, (size_t)P * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(c, hipMemcpyAsync(c->s_b.p, last_used, (size_t)P * 8, hipMemcpyHostToDevice, st));
-    }
+    if (n_counters) HIP_TRY(c, hipMemcpyAsync(c->s_a.p, counters, (size_t)n_counters * sizeof(mmp_serve_counter), hipMemcpyHostToDevice, st));
     if (n_excl) {
         HIP_TRY(c, hipMemcpyAsync(c->s_c.p, excl_pod, (size_t)n_excl * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(c, hipMemcpyAsync(c->s_d.p, excl_time, (size_t)n_excl * 8, hipMemcpyHostToDevice, st));
     }
-    ServeArgs A;
+    ServeArgs A = args(n);
     A.reqs = c->s_reqs.as<mmp_serve_req>();
-    A.models = c->models.as<mmp_model_row>();
-    A.ent_pod = c->ent_pod.as<int32_t>();
-    A.ent_time = c->ent_time.as<int64_t>();
-    A.pods = c->sb[c->cur].pods.as<mmp_pod_row>();
-    A.in_use = c->s_a.as<int32_t>();
-    A.last_used = c->s_b.as<int64_t>();
+    A.counters = c->s_a.as<mmp_serve_counter>();
     A.excl_pod = c->s_c.as<int32_t>();
     A.excl_time = c->s_d.as<int64_t>();
     A.outs = c->s_outs.as<mmp_serve_out>();
-    A.n = n;
-    A.n_models = c->n_models;
-    A.P = P;
-    A.now = now;
     KT_BEGIN(c, st);
     hipLaunchKernelGGL(serve_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, A);
     KT_END(c, st);

@@ -16,7 +16,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
-from ._lib import (EVICT_OUT, EVICT_REQ, MODEL_ROW, PLACE_OUT, PLACE_REQ, POD_ROW, SERVE_OUT,
+from ._lib import (EVICT_OUT, EVICT_REQ, MODEL_ROW, PLACE_OUT, PLACE_REQ, POD_ROW, SERVE_COUNTER, SERVE_OUT,
                    SERVE_REQ, STATS, MmpConfig, ptr)
 
 
@@ -94,12 +94,19 @@ class Solver:
         pods = np.ascontiguousarray(pods, dtype=POD_ROW)
         self._ck(self.lib.mmp_pods_load(self.h, ptr(pods), len(pods)))
         self.n_pods = len(pods)
+        self._live = (pods["flags"] & 2) != 0  # host mirror for serve_counters (what litelinks' instance list would hold)
 
     def upsert_pods(self, idx: np.ndarray, rows: np.ndarray):
         idx = np.ascontiguousarray(idx, dtype=np.int32)
         rows = np.ascontiguousarray(rows, dtype=POD_ROW)
         self._ck(self.lib.mmp_pods_upsert(self.h, ptr(idx), ptr(rows), len(idx)))
         self.n_pods = max(self.n_pods, int(idx.max()) + 1 if len(idx) else 0)
+        if len(idx):
+            live = getattr(self, "_live", np.zeros(0, bool))
+            if self.n_pods > len(live):
+                live = np.concatenate([live, np.zeros(self.n_pods - len(live), bool)])
+            live[idx] = (rows["flags"] & 2) != 0
+            self._live = live
 
     def remove_pods(self, idx: np.ndarray):
         idx = np.ascontiguousarray(idx, dtype=np.int32)
@@ -220,6 +227,7 @@ class Solver:
                                           ptr(ent_pod) if len(ent_pod) else None,
                                           ptr(ent_time) if len(ent_time) else None, len(ent_pod)))
         self.n_models = len(models)
+        self._models, self._ent_pod = models.copy(), ent_pod.copy()  # host mirror for serve_counters
 
     def upsert_models(self, idx, rows, ent_pod, ent_time):
         """Registry events: rows[i] (its ent_off indexing ent_pod / ent_time of this call) replaces model idx[i]."""
@@ -231,6 +239,12 @@ class Solver:
                                             ptr(ent_time) if len(ent_time) else None, len(ent_pod)))
         if len(idx):
             self.n_models = max(getattr(self, "n_models", 0), int(idx.max()) + 1)
+            # the host mirror serve_counters reads: the changed records' entries are appended, their rows rewritten
+            if getattr(self, "_models", None) is not None and self.n_models <= len(self._models):
+                shifted = rows.copy()
+                shifted["ent_off"] += len(self._ent_pod)
+                self._ent_pod = np.concatenate([self._ent_pod, ent_pod])
+                self._models[idx] = shifted
 
     def commit(self):
         self._ck(self.lib.mmp_snapshot_commit(self.h))
@@ -291,14 +305,48 @@ class Solver:
         self._ck(self.lib.mmp_place_batch_dev(self.h, C.c_void_p(d_reqs), int(n), C.c_void_p(d_extra or None),
                                               int(now), C.c_void_p(d_outs), C.c_void_p(stream or None)))
 
-    def serve(self, reqs, in_use, last_used, excl_pod, excl_time, now) -> np.ndarray:
-        reqs = np.ascontiguousarray(reqs, dtype=SERVE_REQ)
+    def serve_counters(self, reqs, in_use, last_used):
+        """What a Java host assembles per request (MM.java:4343, :4356, :4360): for every copy of the request's model whose
+        instance litelinks lists (here: the table's live flag), one (instance, inUse, lastUsed) entry.  -> (reqs with
+        cnt_off / n_cnt filled, counters).  Needs the registry this Solver loaded (load_models)."""
+        reqs = np.ascontiguousarray(reqs, dtype=SERVE_REQ).copy()
         in_use = np.ascontiguousarray(in_use, dtype=np.int32)
         last_used = np.ascontiguousarray(last_used, dtype=np.int64)
+        models, ent_pod, live = self._models, self._ent_pod, self._live
+        ok = (reqs["model"] >= 0) & (reqs["model"] < len(models))
+        m = models[np.where(ok, reqs["model"], 0)]
+        k = np.where(ok, m["n_loaded"], 0).astype(np.int64)
+        off = np.zeros(len(reqs) + 1, np.int64)
+        np.cumsum(k, out=off[1:])
+        seg = np.repeat(np.arange(len(reqs)), k)
+        j = np.arange(int(off[-1])) - off[seg]
+        pod = ent_pod[m["ent_off"][seg] + j] if len(seg) else np.zeros(0, np.int32)
+        listed = (pod >= 0) & (pod < len(live))
+        listed[listed] &= live[pod[listed]]
+        n_cnt = np.bincount(seg[listed], minlength=len(reqs)).astype(np.int32) if len(seg) else np.zeros(len(reqs), np.int32)
+        c_off = np.zeros(len(reqs) + 1, np.int64)
+        np.cumsum(n_cnt, out=c_off[1:])
+        counters = np.zeros(int(c_off[-1]), dtype=SERVE_COUNTER)
+        counters["pod"] = pod[listed]
+        counters["in_use"] = in_use[pod[listed]]
+        counters["last_used"] = last_used[pod[listed]]
+        reqs["cnt_off"], reqs["n_cnt"] = c_off[:-1], n_cnt
+        return reqs, counters
+
+    def serve(self, reqs, in_use, last_used, excl_pod, excl_time, now) -> np.ndarray:
+        """Convenience form for tests / benchmarks that hold per-INSTANCE counter arrays: builds the per-request counter
+        entries (serve_counters) and calls serve_k."""
+        reqs, counters = self.serve_counters(reqs, in_use, last_used)
+        return self.serve_k(reqs, counters, excl_pod, excl_time, now)
+
+    def serve_k(self, reqs, counters, excl_pod, excl_time, now) -> np.ndarray:
+        """mmp_serve_batch: requests with their own (instance, inUse, lastUsed) entries — O(copies) per request."""
+        reqs = np.ascontiguousarray(reqs, dtype=SERVE_REQ)
+        counters = np.ascontiguousarray(counters, dtype=SERVE_COUNTER)
         excl_pod = np.ascontiguousarray(excl_pod, dtype=np.int32)
         excl_time = np.ascontiguousarray(excl_time, dtype=np.int64)
         outs = np.zeros(len(reqs), dtype=SERVE_OUT)
-        self._ck(self.lib.mmp_serve_batch(self.h, ptr(reqs), len(reqs), ptr(in_use), ptr(last_used),
+        self._ck(self.lib.mmp_serve_batch(self.h, ptr(reqs), len(reqs), ptr(counters) if len(counters) else None, len(counters),
                                           ptr(excl_pod) if len(excl_pod) else None,
                                           ptr(excl_time) if len(excl_time) else None, len(excl_pod),
                                           int(now), ptr(outs)))
