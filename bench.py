@@ -134,19 +134,30 @@ def make_step_batch(fleet, seeds):
 
 def measured_traffic(workload: str, decisions_per_launch: int):
     """HBM bytes per place_batch_kernel launch from the committed rocprofv3 PMC passes of this same
-    command (profiles/rNN/pmc_place_batch_<workload>*.json, written by tools/pmc_summary.py); None if
-    no PMC pass has been recorded for this workload AT THIS LAUNCH SIZE (the summary's write bytes are the
-    16-byte result rows of one launch, which identifies the size)."""
+    command (profiles/rNN/pmc_place_batch_<workload>*.json, written by tools/pmc_summary.py), and where the figure comes
+    from.  A summary counts only if (a) it was taken AT THIS LAUNCH SIZE (its write bytes are the 16-byte result rows of
+    one launch, which identifies the size) and (b) it is stamped with the hash of the kernel sources of THIS tree
+    (tools/kernel_hash.py): a kernel change that alters the traffic must not keep an old number.  -> (bytes | None, provenance)"""
     import glob
-    best = None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_hash import kernel_source_hash
+    now_hash = kernel_source_hash()
+    best, prov = None, f"no PMC summary for {workload} at {decisions_per_launch} decisions per launch under profiles/"
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_place_batch_{workload}*.json"))):
         try:
             j = json.load(open(f))
-            if abs(j.get("write_bytes", 0) / 16 - decisions_per_launch) <= 0.02 * decisions_per_launch:
-                best = j.get("traffic_bytes_per_launch")
         except Exception:
-            pass
-    return best
+            continue
+        if abs(j.get("write_bytes", 0) / 16 - decisions_per_launch) > 0.02 * decisions_per_launch:
+            continue
+        rel = os.path.relpath(f, ROOT)
+        if j.get("kernel_source_hash") != now_hash:
+            if best is None:
+                prov = (f"{rel} was taken on other kernel sources ({j.get('kernel_source_hash', 'unstamped')} != {now_hash}): "
+                        "not used, the compulsory streams stand in")
+            continue
+        best, prov = j.get("traffic_bytes_per_launch"), f"{rel} (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, kernel sources {now_hash})"
+    return best, prov
 
 
 def cpu_baseline(fleet, reqs, extra, budget_s: float = 6.0):
@@ -156,7 +167,12 @@ def cpu_baseline(fleet, reqs, extra, budget_s: float = 6.0):
     gcc -O2 -march=native, on a persistent worker pool (one thread / all cores).  Not the JVM."""
     from oracle.bind import OracleFleet
     orc = OracleFleet(fleet)
-    cores = os.cpu_count() or 1
+    hw_threads = os.cpu_count() or 1
+    # the threads this process may actually RUN: the affinity mask, capped by the CPU time its cgroup grants (the GPU box
+    # shows 256 hardware threads and grants 16 CPUs' worth: 256 workers fighting over that quota measured 5x one thread)
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else hw_threads
+    quota = _cgroup_cpu_limit()
+    cores = usable_cpus()
     out, flags = {}, ""
     lat = None
     for label, th in (("single", 1), ("all", cores)):
@@ -186,10 +202,18 @@ def cpu_baseline(fleet, reqs, extra, budget_s: float = 6.0):
                   f"persistent pool, >= 8k decisions per thread per call); CPU port of the reference algorithm (oracle/mm_oracle.c:orc_place_lean, gcc {flags}), "
                   "not the JVM",
         "single_thread_value": out["single"],
+        "scaling_vs_single_thread": out["all"] / out["single"] if out["single"] else None,
         "p50_us": float(np.percentile(lat, 50) / 1e3), "p99_us": float(np.percentile(lat, 99) / 1e3),
-        # what the container may actually use of the box's hardware threads: the all-thread figure scales with THIS, not with `cores`
-        "cgroup_cpu_limit": _cgroup_cpu_limit(), "affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+        # `cores` = worker threads used = min(affinity mask, cgroup CPU quota); the box's hardware threads are listed apart
+        "hw_threads": hw_threads, "cgroup_cpu_limit": quota, "affinity_cpus": affinity,
     }
+
+
+def usable_cpus() -> int:
+    """Threads this process can actually run at once: the affinity mask capped by the cgroup's CPU quota."""
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = _cgroup_cpu_limit()
+    return max(1, min(affinity, int(np.ceil(quota)) if quota else affinity))
 
 
 def _cgroup_cpu_limit():
@@ -422,15 +446,42 @@ def full_cluster_leg(workload: str, device: int, dev):
             "ms_per_step": dt * 1e3, "mean_shortlist": float(got["n_candidates"].mean()), "parity_vs_oracle": parity}
 
 
+def _single_prober():
+    """tools/micro/single_prober.c built with gcc (None when no compiler is at hand: the leg then reports no latencies)"""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "tools", "micro", "single_prober.c")
+    so = os.path.join(tempfile.gettempdir(), f"mmp_single_prober_{os.getpid()}.so")
+    try:
+        subprocess.run(["gcc", "-O2", "-shared", "-fPIC", src, "-o", so, "-lpthread"], check=True, capture_output=True, timeout=120)
+        lib = C.CDLL(so)
+    except Exception:
+        return None
+    lib.prober_start.restype = C.c_int
+    lib.prober_start.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64]
+    lib.prober_stop.restype = C.c_int64
+    lib.prober_stop.argtypes = [C.c_void_p, C.c_int64]
+    return lib
+
+
 def churn_leg(fleet, solver, slices: int = 8, events: int = 20_000):
     """Config C5 on this rank's solver: per 2 s slice of simulated time apply the changed InstanceRecords and
     the changed ModelRecords (mmp_pods_upsert / mmp_models_upsert), re-rank on the device, decide the slice's load targets and evaluate its
     cache evictions (host-pointer C ABI, PCIe inclusive).  Only the library calls are timed; the event
     generation / bookkeeping between slices (numpy) is not part of the path."""
+    import ctypes as C
     from modelmesh_amd import workload as wl
     cs = wl.ChurnStream(fleet, 0xC5)
     solver.load_caches(cs.seg_off, cs.cache_lu, cs.cache_wt, cs.cache_cap)
     busy, commit_s, n_ev = 0.0, 0.0, 0
+    # BASELINE.md config 5 asks for the p99 DECISION latency of the sustained stream: a second host thread (C:
+    # tools/micro/single_prober.c — a Python thread's samples would include its waits for the interpreter lock) issues single
+    # load-target decisions, mmp_place_batch(n = 1), back to back for the whole leg and records each call's wall time
+    single, _ = wl.make_requests(fleet, seed=0xC51, n=256)
+    single = np.ascontiguousarray(single)
+    single["n_extra"] = 0
+    prober = _single_prober()
     for it in range(slices + 1):
         f = cs.fleet
         ev = cs.model_events() if it else None  # building the event batch is the host mesh's work, not timed
@@ -447,8 +498,21 @@ def churn_leg(fleet, solver, slices: int = 8, events: int = 20_000):
         if it:  # slice 0 is the warm-up
             busy += time.perf_counter() - t0
             n_ev += events
+        elif prober is not None:  # (after the warm-up slice: a committed snapshot exists)
+            prober.prober_start(C.cast(solver.lib.mmp_place_batch, C.c_void_p), solver.h, single.ctypes.data_as(C.c_void_p), len(single),
+                                C.c_int64(int(fleet.now)), C.c_int64(4_000_000))
         cs.apply(sl, got)
-    return {"workload": f"C5: {events} events per 2 s slice (45% load decisions, 45% eviction evaluations, 10% "
+    lat = np.zeros(0)
+    if prober is not None:
+        buf = np.zeros(4_000_000, np.uint32)
+        got_n = int(prober.prober_stop(buf.ctypes.data_as(C.c_void_p), C.c_int64(len(buf))))
+        lat = buf[100:got_n].astype(np.float64) / 1e3 if got_n > 200 else np.zeros(0)
+    return {"single_decisions_during_churn": None if not len(lat) else {
+                "calls": int(len(lat)), "p50_us": float(np.percentile(lat, 50)), "p99_us": float(np.percentile(lat, 99)),
+                "p999_us": float(np.percentile(lat, 99.9)), "max_us": float(lat.max()),
+                "note": "mmp_place_batch(n = 1) from a second host thread (C, tools/micro/single_prober.c) for the whole leg, across its "
+                        "upserts, registry events and commits (a decision takes the published snapshot; a commit swaps a pointer)"},
+            "workload": f"C5: {events} events per 2 s slice (45% load decisions, 45% eviction evaluations, 10% "
                         f"republishes) over {fleet.n_models} models x {fleet.n_pods} pods, commit per slice",
             "events_per_s": n_ev / busy, "slices": slices, "ms_per_slice": busy / slices * 1e3,
             "commit_ms": commit_s / slices * 1e3,
@@ -911,8 +975,8 @@ def main():
     if rank == 0:
         from oracle.bind import OracleFleet
         orc0 = OracleFleet(fleet)
-        cores = os.cpu_count() or 1
-        n_check = n_batches if cores >= 32 else min(n_batches, 4)  # the checker makes ~20k decisions/s per core
+        cores = usable_cpus()
+        n_check = n_batches if cores >= 16 else min(n_batches, 4)  # the checker makes ~20k decisions/s per core
         parity = True
         for b in range(n_check):
             got_b = np.frombuffer(d_bufs[b][2].cpu().numpy().tobytes(), dtype=PLACE_OUT)
@@ -931,7 +995,7 @@ def main():
         value = total / elapsed
         alg = int(np.mean([algorithmic_bytes(fleet, bq[0]) for bq in batches[:4]]))
         kb = int(np.mean([kernel_bytes(fleet, bq[0]) for bq in batches[:4]]))
-        traffic = measured_traffic(args.workload, n)
+        traffic, traffic_prov = measured_traffic(args.workload, n)
         # roofline of the dominant kernel: bytes it has to move per launch (measured by the PMC passes when a
         # summary is committed, else the compulsory streams) / its average launch duration / the HBM peak
         moved = traffic if traffic else kb
@@ -952,7 +1016,7 @@ def main():
                        "resident_input_bytes": int(n_batches * n * (64 + 16)),
                        "host_issue_us_per_step": None if issue_s is None else issue_s / args.steps * 1e6},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_provenance": traffic_prov,
                          "kernel": "place_batch_kernel", "kernel_ms": gpu_ms_per_step,
                          "kernel_ms_per_launch_event_pairs": kern_ms,
                          "bytes_per_launch": moved,
@@ -965,7 +1029,7 @@ def main():
                              "frac": tb / (set_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "note": "one decision per model per launch (the launch size of rounds 1-2): 1564 wavefronts on "
                                      "256 CUs, bound by its own latency chain, not by bandwidth — DESIGN.md 4.1 / 11"})(
-                             measured_traffic(args.workload, fleet.n_models) or kb // sets_per_step),
+                             measured_traffic(args.workload, fleet.n_models)[0] or kb // sets_per_step),
                          "scan_equivalent": {
                              "note": "SURVEY.md §8(d) algorithmic bytes (32 B x P per decision: the scan the reference "
                                      "logically performs over every pod); this kernel does not perform that scan, so the "

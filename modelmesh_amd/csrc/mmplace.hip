@@ -76,10 +76,11 @@ struct DevBuf {
 
 // device storage of one committed snapshot
 struct SnapBufs {
-    DevBuf pods, lru, rem, cnt, rpm, orig, pos_of, elig, elig_nors, pref, has_pref, fullw, ge, pc, ph, nz, heads;
+    DevBuf pods, lru, rem, cnt, rpm, orig, pos_of, elig, elig_nors, pref, has_pref, fullw, ge, pc, ph, nz, heads, bslots, bpm, bwin, bsurv, bpcs;
+    int32_t n_bslots = 0;  // case (b) slots this snapshot has (place_kernel.hpp: BSlot), read back at commit
     void release()
     {
-        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge, &pc, &ph, &nz, &heads})
+        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge, &pc, &ph, &nz, &heads, &bslots, &bpm, &bwin, &bsurv, &bpcs})
             b->release();
     }
 };
@@ -170,6 +171,7 @@ struct mmp_ctx {
     int32_t force_wave = 0;  // MMP_FORCE_WAVE=1: every decision takes the wave-per-decision kernel (tests)
     size_t lds_limit = 64 * 1024;    // LDS a workgroup may use on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
     std::atomic<size_t> lds_granted{48 * 1024};  // dynamic LDS the place kernels may be launched with so far
+    int32_t no_caseb = 0;    // MMP_NO_CASEB=1: case (b) decisions never use the whole-window tables (tests: the wave path decides them)
     int32_t no_heads = 0;    // MMP_NO_HEADS=1: decisions do not use the per-type head windows (tests: lane_decide_r alone)
 
     // host staging (inputs of the next commit)
@@ -416,7 +418,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
                  uint32_t *done_blocks = nullptr)
 {
     if (n == 0) return MMP_OK;
-    PlaceArgs A;
+    PlaceArgs A{};
     A.reqs = static_cast<const mmp_place_req *>(d_reqs);
     A.models = c->models.as<mmp_model_row>();
     A.rmodels = cur_side(c).rmodels_ok ? cur_side(c).rmodels.as<ResolvedModel>() : nullptr;
@@ -435,6 +437,17 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     const int wpad = (c->snap.W + 1) & ~1;
     // one dynamic region: the lane phase's windows + scratch, re-used by the wave path's tiles (place_block)
     const size_t lds = std::max<size_t>((size_t)kPlaceWaves * 2 * wpad * sizeof(uint64_t), (size_t)place_lane_lds(c->snap.T));
+    // the long kernel on a full cluster: the case (b) tables of the snapshot's preferring types (place_kernel.hpp: BSlot)
+    if (c->snap_long && !inline_req && !done_flag && A.wins && !c->no_caseb) {
+        const SnapBufs &B = c->sb[c->cur];
+        if (B.n_bslots > 0) {
+            A.bslots = B.bslots.as<BSlot>();
+            A.n_bslots = std::min(B.n_bslots, kBSlots);
+            A.bwin = B.bwin.as<BLaunch>();
+            A.bsurv = B.bsurv.as<uint64_t>();
+            A.bpcs = B.bpcs.as<int32_t>();
+        }
+    }
     // the wave path's tile (two bitmaps of the whole table per wavefront) next to the static LDS of place_block;
     // gfx950 gives a workgroup up to 160 KB (c->lds_limit is the device's answer), which admits ~120k instances
     if (lds + kPlaceStaticLds > c->lds_limit)
@@ -501,6 +514,7 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     }
     if (const char *fw = getenv("MMP_FORCE_WAVE")) c->force_wave = fw[0] == '1';
     if (const char *nh = getenv("MMP_NO_HEADS")) c->no_heads = nh[0] == '1';
+    if (const char *nb = getenv("MMP_NO_CASEB")) c->no_caseb = nb[0] == '1';
     const bool want_resident = getenv("MMP_RESIDENT") && getenv("MMP_RESIDENT")[0] == '1';
     if (const char *rm = getenv("MMP_RANK_MODE")) c->rank_mode = atoi(rm);
     if (const char *lm = getenv("MMP_LONG_MODE")) c->long_mode = atoi(lm);
@@ -1152,6 +1166,11 @@ try {
     // rounded up to the 1 KB chunks place_block stages (rows beyond T are never read as windows)
     const size_t wins_bytes = (((size_t)std::max(T, kWinLds) * sizeof(TypeWin) + 1023) / 1024) * 1024;
     HIP_TRY(c, B.heads.ensure(wins_bytes));
+    HIP_TRY(c, B.bslots.ensure(kBSlots * sizeof(BSlot) + 16));
+    HIP_TRY(c, B.bpm.ensure((size_t)kBSlots * W * 64 * 4));
+    HIP_TRY(c, B.bwin.ensure(kBSlots * sizeof(BLaunch)));
+    HIP_TRY(c, B.bsurv.ensure((size_t)kBSlots * kBClasses * W * 8));
+    HIP_TRY(c, B.bpcs.ensure((size_t)kBSlots * kBClasses * (W + 1) * 4));
     HIP_TRY(c, c->rank.ensure(padded * 4));
     HIP_TRY(c, c->occupancy.ensure(padded * 4));
     HIP_TRY(c, c->flag.ensure(sizeof(int32_t)));
@@ -1277,9 +1296,18 @@ try {
                            B.pods.as<mmp_pod_row>(), P, min_space, N.stats_acc.as<StatsAcc>());
         // the head window of every type row (place_kernel.hpp: TypeWin)
         hipLaunchKernelGGL(build_wins_kernel, dim3(T), dim3(64), 0, st, S, B.heads.as<TypeWin>());
+        // case (b) on a full cluster: where it starts per preferring type, and the running minimum of the candidates' rpm
+        HIP_TRY(c, hipMemsetAsync(B.bslots.p, 0, kBSlots * sizeof(BSlot) + 16, st));
+        int32_t *n_bslots_dev = reinterpret_cast<int32_t *>(static_cast<char *>(B.bslots.p) + kBSlots * sizeof(BSlot));
+        hipLaunchKernelGGL(build_bslots_kernel, dim3(T), dim3(64), 0, st, S, B.pods.as<mmp_pod_row>(), B.bslots.as<BSlot>(), n_bslots_dev);
+        hipLaunchKernelGGL(prefix_min_rpm_kernel, dim3(kBSlots), dim3(64), 0, st, S, B.bslots.as<BSlot>(), n_bslots_dev, B.bpm.as<int32_t>(),
+                           (int32_t)(W * 64));
+        hipLaunchKernelGGL(build_bsurv_kernel, dim3(kBSlots), dim3(256), 0, st, S, B.bslots.as<BSlot>(), n_bslots_dev, B.bpm.as<int32_t>(),
+                           (int32_t)(W * 64), B.bwin.as<BLaunch>(), B.bsurv.as<uint64_t>(), B.bpcs.as<int32_t>());
         HIP_TRY(c, hipGetLastError());
     } else {
         HIP_TRY(c, hipMemsetAsync(B.heads.p, 0, wins_bytes, st));
+        HIP_TRY(c, hipMemsetAsync(B.bslots.p, 0, kBSlots * sizeof(BSlot) + 16, st));
         HIP_TRY(c, hipMemsetAsync(B.pc.p, 0, (size_t)2 * T * (W + 1) * 4, st));
         HIP_TRY(c, hipMemsetAsync(B.nz.p, 0, (size_t)2 * T * (W + 1) * 4, st));
         HIP_TRY(c, hipMemsetAsync(B.ph.p, 0, (size_t)2 * T * (W + 1) * 8, st));
@@ -1298,7 +1326,10 @@ try {
     StatsAcc acc{};
     HIP_TRY(c, hipMemcpyAsync(&bad, c->flag.p, sizeof bad, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(&acc, N.stats_acc.p, sizeof acc, hipMemcpyDeviceToHost, st));
+    int32_t n_bslots = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n_bslots, static_cast<char *>(B.bslots.p) + kBSlots * sizeof(BSlot), sizeof n_bslots, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    B.n_bslots = std::min(n_bslots, kBSlots);
     kt_collect(c);
     if (bad)
         return fail(c, MMP_EORDER,
@@ -1990,7 +2021,7 @@ namespace {
 int shard_phase_launch(mmp_ctx *c, int32_t phase, const void *d_reqs, int32_t n, const int32_t *n_dev, const void *d_extra,
                        int64_t now, void *const *d_xchg, void *d_outs, hipStream_t st)
 {
-    PlaceArgs A;
+    PlaceArgs A{};
     A.reqs = static_cast<const mmp_place_req *>(d_reqs);
     A.models = c->models.as<mmp_model_row>();
     A.rmodels = nullptr;
@@ -2052,7 +2083,7 @@ int32_t mmp_shard_fast_slots(void) { return kXF; }
 namespace {
 PlaceArgs shard_args(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs)
 {
-    PlaceArgs A;
+    PlaceArgs A{};
     A.reqs = static_cast<const mmp_place_req *>(d_reqs);
     A.models = c->models.as<mmp_model_row>();
     A.rmodels = nullptr;

@@ -136,6 +136,11 @@ struct PlaceArgs {
     const mmp_model_row *models;
     const ResolvedModel *rmodels;  // null: not built (pod-axis shard contexts)
     const TypeWin *wins;           // null: not built (pod-axis shard contexts, MMP_NO_HEADS=1)
+    const struct BSlot *bslots;    // case (b) slots of the snapshot (long kernel only; see BSlot), n_bslots of them,
+    const struct BLaunch *bwin;    // ... their whole-window tables (build_bsurv_kernel)
+    const uint64_t *bsurv;
+    const int32_t *bpcs;
+    int32_t n_bslots;
     const int32_t *ent_pod;  // model entries: loaded ids then failed ids
     const int32_t *extra;    // per-request extra exclusions
     mmp_place_out *outs;
@@ -346,6 +351,136 @@ __global__ __launch_bounds__(64) void build_wins_kernel(Snap S, TypeWin *__restr
         out->flags = fl;
     }
 }
+
+// ---- case (b) of getNext on a full cluster (round 3) --------------------------------------------------------------
+// A type with preferred instances whose most desirable eligible instance is FULL and not preferred takes the non-simple
+// case (b), MM.java:4853-4887: the shortlist is every preferred eligible instance whose lruTime lies within
+// max(120 s, age(oldest) / 4) of the oldest, each with its OWN rpm in the rpm rule (:4875).  On a cluster where every
+// instance is full and the caches are about equally old — the steady state of a mesh — that window is the whole table:
+// thousands of candidates per decision, which the wave path walked with two dependent rpm loads per candidate (40 us
+// per decision; 70 of the 90 us a 100k batch took on such a fleet).  Nearly all of it is the same for every request
+// of the type: full instances of one version stand in lruTime order, so the window is a position range (best0, lim)
+// that depends on the type and the launch's clock only; with it the smallest candidate rpm, hence minLoad and the four
+// rpm limits the rule can apply (:4957-4972), hence — per limit — the bitmap of candidates the rule leaves in.
+// commit() records per type where case (b) starts and checks the order (BSlot, build_bslots_kernel), builds the
+// running minimum of the candidates' rpm along the order (prefix_min_rpm_kernel) and, for the window that reaches the
+// last full instance, limits, the five survivor bitmaps and their running counts (build_bsurv_kernel); a decision
+// is then the LONG phase's arithmetic — range counts and hash terms from prefix tables, a correction per exclusion
+// that is a candidate, a binary search for the index-th survivor.  The tables are anchored at the type's first eligible
+// position p0; a request whose own first eligible instance lies behind it (it excludes p0 ...: every eligible position
+// before its first one is among its exclusions, so the candidates there fall out as excluded candidates do) uses them as
+// long as its window ends where the type's does.  The caller itself as the first instance, an excluded candidate that
+// may hold the minimum, a window that ends elsewhere: the wave path.  (Measured, C3 with every instance full and equally old:
+// the type's p0 happens to be preferred there, so case (b) is the ~10 requests per 100k that exclude it — and one such
+// decision on the wave path took 80 us, which was the whole launch: 90 us per 100k before, 20 us without them.)
+constexpr int kBSlots = 4;     // preferring types with a case (b) slot per snapshot (more: the wave path)
+constexpr int kBClasses = 5;   // which clauses of the rpm rule apply: none, < 1 day, < 12 min, < 5 s, < -1 s (:4964-4972)
+struct __attribute__((aligned(16))) BSlot {
+    int32_t type;       // bitmap row
+    int32_t best0;      // p0, the type's first eligible position: full
+    int32_t end;        // positions [best0, end) are present, full and in lruTime order
+    int32_t best_orig;  // pod index at best0
+    int64_t oldest;     // lruTime at best0
+    int32_t slot;       // row of the running-minimum table
+    int32_t pad;
+};
+static_assert(sizeof(BSlot) == 32, "BSlot is 32 bytes");
+
+// One wavefront per type row: the slot of a preferring type (valid: type >= 0), in the order of the type rows.
+// `slots` = kBSlots rows, `n_slots` = how many are valid (written by the last type's wavefront: one launch, T blocks, so
+// the slot index is assigned by an atomic ticket and the table is sorted by nothing — a decision finds its slot by type).
+__global__ __launch_bounds__(64) void build_bslots_kernel(Snap S, const mmp_pod_row *__restrict__ pods, BSlot *__restrict__ slots,
+                                                          int32_t *__restrict__ n_slots)
+{
+    const int t = blockIdx.x, lane = lane_id();
+    if (!S.has_pref[t]) return;
+    const int P = S.P, W = S.W;
+    const uint64_t *E = S.elig + (size_t)t * W, *Pm = S.pref + (size_t)t * W;
+    const int best0 = first_set_from(E, nullptr, 0, W);
+    if (best0 == kNoPos) return;
+    if (!test_bit(S.fullw, best0)) return;  // case (b) needs a full first instance (whether a request's first one is preferred is the request's)
+    // [best0, end): present rows; all full, lruTime non-decreasing (one version: PLACEMENT_ORDER :4669-4674)
+    int end = P;
+    bool ok = true;
+    for (int base = best0; base < P; base += 64) {
+        const int p = base + lane;
+        bool absent = false, bad = false;
+        if (p < P) {
+            absent = (pods[S.orig[p]].flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE)) != 0;
+            if (!absent) {
+                if (!test_bit(S.fullw, p)) bad = true;
+                if (p > best0 && jsub64(S.lru[p], S.lru[p - 1]) < 0) bad = true;
+            }
+        }
+        const uint64_t ab = __ballot(absent), bb = __ballot(bad);
+        const int first_absent = ab ? base + (__ffsll((unsigned long long)ab) - 1) : kNoPos;
+        if (bb && base + (__ffsll((unsigned long long)bb) - 1) < first_absent) ok = false;
+        if (first_absent != kNoPos) {
+            end = first_absent;
+            break;
+        }
+    }
+    if (!ok) return;
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(n_slots, 1);
+    slot = readlane_i32(slot, 0);
+    if (slot >= kBSlots) return;  // (n_slots may exceed kBSlots: readers clamp)
+    if (lane == 0) {
+        BSlot b;
+        b.type = t;
+        b.best0 = best0;
+        b.end = end;
+        b.best_orig = S.orig[best0];
+        b.oldest = S.lru[best0];
+        b.slot = slot;
+        b.pad = 0;
+        slots[slot] = b;
+    }
+}
+
+// pm[slot][p] = min rpm over the preferred eligible positions in (best0, p]; INT32_MAX before the first one.
+// One wavefront per slot, 64 positions per step.
+__global__ __launch_bounds__(64) void prefix_min_rpm_kernel(Snap S, const BSlot *__restrict__ slots, const int32_t *__restrict__ n_slots,
+                                                            int32_t *__restrict__ pm, int32_t stride)
+{
+    const int s = blockIdx.x, lane = lane_id();
+    const int n = *n_slots < kBSlots ? *n_slots : kBSlots;
+    if (s >= n) return;
+    const BSlot b = slots[s];
+    const uint64_t *E = S.elig + (size_t)b.type * S.W, *Pm = S.pref + (size_t)b.type * S.W;
+    int32_t *out = pm + (size_t)s * stride;
+    int32_t carry = INT32_MAX;
+    for (int base = (b.best0 >> 6) << 6; base < b.end; base += 64) {
+        const int p = base + lane;
+        int32_t v = INT32_MAX;
+        if (p > b.best0 && p < b.end && (((E[p >> 6] & Pm[p >> 6]) >> (p & 63)) & 1ull)) v = S.rpm[p];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {  // inclusive min-scan
+            const int32_t tv = __shfl_up(v, o, 64);
+            if (lane >= o && tv < v) v = tv;
+        }
+        v = v < carry ? v : carry;
+        if (p < S.W * 64) out[p] = v;
+        carry = readlane_i32(v, 63);
+    }
+}
+
+// Per slot, built at commit (build_bsurv_kernel): the whole-window tables.
+struct BLaunch {
+    int32_t lim;        // window = positions (best0, lim)
+    int32_t min_load;   // max(100, min rpm of the candidates); 0: no candidate in the window (the replay list, :4879-4884)
+    int32_t min_rpm;    // that minimum itself
+    int32_t limit[kBClasses];  // rpm limit of class c (c = 0: none applies -> INT32_MAX)
+    int32_t wlo, whi;   // words of the window
+};
+struct BLds {
+    const BSlot *slots;     // global
+    int32_t n_slots;
+    int32_t W;
+    const BLaunch *launch;  // [n_slots]
+    const uint64_t *surv;   // [n_slots][kBClasses][W]: candidates the rule of class c leaves in (class 0: all candidates)
+    const int32_t *pcs;     // [n_slots][kBClasses][W + 1]: running counts of surv
+};
 
 struct RpmRule {
     bool active;  // lastUsedAgo < FIVE_DAYS_MS
@@ -731,7 +866,8 @@ __device__ __forceinline__ int lane_first(F f, int start, int stop, bool &far, c
 // kLaneLong: the shortlist spans more than kLaneSpan words — decided by the LONG instantiation of this same
 // function (a later phase of the kernel), which counts / hashes / selects through the prefix tables of Snap
 // instead of walking the words.
-enum { kLaneDone = 0, kLaneWave = 1, kLaneNoneHere = 2, kLaneIncomplete = 3, kLaneLong = 4, kLaneHeadMiss = 5 };
+enum { kLaneDone = 0, kLaneWave = 1, kLaneNoneHere = 2, kLaneIncomplete = 3, kLaneLong = 4, kLaneHeadMiss = 5, kLaneCaseB = 6 };
+// kLaneCaseB: case (b) on a snapshot that has slots for it (BSlot): the LONG phase decides it from their tables
 // (a scan given up after kLaneSpan words also reports kLaneLong when the snapshot has prefix tables: the LONG
 // instantiation's scans jump through them)
 
@@ -754,18 +890,222 @@ __device__ __forceinline__ void merge_late_extras(ResolvedReq &r)
     r.n_late = -1;
 }
 
-template <bool VIEW, bool LONG = false>
-__device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, mmp_place_out &o);
-
-template <bool VIEW, bool LONG = false>
-__device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, int d, mmp_place_out &o)
+// commit(): per slot the whole-window tables — window = (p0, end), i.e. every full present instance behind p0 (what the
+// window of MM.java:4862-4866 is on a cluster whose caches are about equally old; a decision checks that ITS window does
+// reach `end`, lane_case_b) — the smallest candidate rpm, the rule's limits, the five survivor bitmaps and their running
+// counts.  One workgroup of 256 threads per slot.
+__global__ __launch_bounds__(256) void build_bsurv_kernel(Snap S, const BSlot *__restrict__ slots, const int32_t *__restrict__ n_slots,
+                                                          const int32_t *__restrict__ pm, int32_t pm_stride, BLaunch *__restrict__ launch,
+                                                          uint64_t *__restrict__ surv, int32_t *__restrict__ pcs)
 {
-    const ResolvedReq r = resolve_one<VIEW>(S, A, d);
-    return lane_decide_r<VIEW, LONG>(S, A, r, o);
+    const int s = blockIdx.x;
+    const int n = *n_slots < kBSlots ? *n_slots : kBSlots;
+    if (s >= n) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+    const int W = S.W, nwaves = (int)(blockDim.x >> 6);
+    const BSlot b = slots[s];
+    __shared__ BLaunch Ls;
+    if (threadIdx.x == 0) {
+        const int lim = b.end;
+        const int32_t mn = lim - 1 > b.best0 ? pm[(size_t)b.slot * pm_stride + (lim - 1)] : INT32_MAX;
+        BLaunch L;
+        L.lim = lim;
+        L.wlo = (b.best0 + 1) >> 6;
+        L.whi = lim - 1 > b.best0 ? (lim - 1) >> 6 : L.wlo;
+        L.min_load = 0;
+        L.min_rpm = mn;
+        L.limit[0] = INT32_MAX;
+        if (mn != INT32_MAX) {
+            RpmRule rule;
+            rule.init(0, mn);
+            L.min_load = rule.min_load;
+            const int32_t t1 = rule.m4, t2 = rule.m3 < t1 ? rule.m3 : t1, t3 = rule.m15 < t2 ? rule.m15 : t2,
+                          t4 = rule.m11 < t3 ? rule.m11 : t3;  // RpmRule::limit(): the applicable clauses are a suffix
+            L.limit[1] = t1;
+            L.limit[2] = t2;
+            L.limit[3] = t3;
+            L.limit[4] = t4;
+        } else {
+            L.limit[1] = L.limit[2] = L.limit[3] = L.limit[4] = INT32_MAX;
+        }
+        Ls = L;
+        launch[s] = L;
+    }
+    __syncthreads();
+    const int lim = Ls.lim;
+    int32_t limc[kBClasses];
+#pragma unroll
+    for (int c = 0; c < kBClasses; c++) limc[c] = Ls.limit[c];
+    const uint64_t *E = S.elig + (size_t)b.type * S.W, *Pm = S.pref + (size_t)b.type * S.W;
+    uint64_t *sv = surv + (size_t)s * kBClasses * W;
+    for (int w = wave; w < W; w += nwaves) {
+        const int p = w * 64 + lane;
+        const bool d = p > b.best0 && p < lim && (((E[w] & Pm[w]) >> lane) & 1ull);
+        const int32_t rp = S.rpm[p];  // (the column is padded to whole words)
+#pragma unroll
+        for (int c = 0; c < kBClasses; c++) {
+            const uint64_t keep = __ballot(d && !(rp >= 100 && rp > limc[c]));  // :4963 (class 0: no clause applies)
+            if (lane == 0) sv[(size_t)c * W + w] = keep;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    int32_t *pc = pcs + (size_t)s * kBClasses * (W + 1);
+    for (int c = wave; c < kBClasses; c += nwaves) {
+        int32_t carry = 0;
+        if (lane == 0) pc[(size_t)c * (W + 1)] = 0;
+        for (int base = 0; base < W; base += 64) {
+            const int w = base + lane;
+            const int32_t nb = w < W ? __popcll((unsigned long long)sv[(size_t)c * W + w]) : 0;
+            const int32_t incl = wave_incl_scan_i32(nb);
+            if (w < W) pc[(size_t)c * (W + 1) + w + 1] = carry + incl;
+            carry += readlane_i32(incl, 63);
+        }
+    }
 }
 
+// Case (b) for one decision (one lane) from the snapshot's whole-window tables.  ex[] = the request's excluded rank positions (-1: none).
+// kLaneDone, or kLaneWave when the request does not fit the slot (see BSlot).
+__device__ __forceinline__ int lane_case_b(const Snap &S, const ResolvedReq &r, const int32_t (&ex)[kInlineExcl], int type, int best0,
+                                           int64_t now, const BLds &B, mmp_place_out &o)
+{
+    int s = -1;
+    for (int i = 0; i < B.n_slots; i++)
+        if (B.slots[i].type == type) s = i;
+    if (s < 0) return kLaneWave;
+    const BSlot b = B.slots[s];
+    const BLaunch &L = B.launch[s];
+    const int selfpos = r.selfpos;
+    if (best0 < b.best0 || best0 >= L.lim || selfpos == best0 || L.min_load == 0 || L.min_load > 500000000) return kLaneWave;
+    const int W = B.W, lim = L.lim, wlo = L.wlo, whi = L.whi;
+    {
+        // the tables hold the window that reaches the last full present instance: this request's own window, from its own
+        // first instance's lruTime on this launch's clock, must reach it too (:4862-4866; the instances stand in lruTime order)
+        const int64_t oldest = best0 == b.best0 ? b.oldest : S.lru[best0];
+        if (oldest == 0) return kLaneWave;
+        const int64_t rel = age_of(oldest, now) / 4;
+        const int64_t win = rel > 120000LL ? rel : 120000LL;
+        if (lim - 1 > best0 && jsub64(S.lru[lim - 1], oldest) > win) return kLaneWave;
+    }
+    const uint64_t *sv = B.surv + (size_t)s * kBClasses * W;
+    const int32_t *pc = B.pcs + (size_t)s * kBClasses * (W + 1);
+    const bool favour = (r.flags & MMP_REQ_FAVOUR_SELF) != 0;
+    // class 0 = every candidate of the type's window (p0, lim); those before this request's own first instance are among its
+    // exclusions (they are eligible and lie before it) and fall out below like any excluded candidate
+    auto cand_bit = [&](int p) { return p > b.best0 && p < lim && ((sv[p >> 6] >> (p & 63)) & 1ull); };
+    // the request's exclusions that are candidates: each takes one off the counts behind it and changes its word's hash term
+    uint32_t xmask = 0;  // slots of ex[] that are distinct removed candidates
+    int n_removed = 0;
+#pragma unroll
+    for (int i = 0; i < kInlineExcl; i++) {
+        const int e = ex[i];
+        if (e < 0 || !cand_bit(e)) continue;
+        bool repeated = false;
+#pragma unroll
+        for (int j = 0; j < kInlineExcl; j++)
+            if (j < i && ex[j] == e) repeated = true;
+        if (repeated) continue;
+        if (S.rpm[e] <= L.min_rpm) return kLaneWave;  // it holds the minimum the limits were derived from (:4957)
+        xmask |= 1u << i;
+        n_removed++;
+    }
+    const bool self_in_c = selfpos >= 0 && cand_bit(selfpos);  // (an excluded caller is never `us`: a removed candidate above)
+    bool self_removed = false;
+#pragma unroll
+    for (int i = 0; i < kInlineExcl; i++)
+        if (((xmask >> i) & 1u) && ex[i] == selfpos) self_removed = true;
+    o.best = best0 == b.best0 ? b.best_orig : S.orig[best0];
+    o.n_candidates = 0;
+    o.hash = 0;
+    o.chosen = MMP_NONE;
+    if (self_in_c && !self_removed && favour) return kLaneDone;  // :4871-4873 return null: the caller itself is to load it
+    const int32_t *pc0 = pc;
+    const int ccount = pc0[whi + 1] - pc0[wlo] - n_removed;
+    if (ccount <= 0) return kLaneWave;  // no preferred instance left in the window: the replay list (:4879-4884)
+    auto term = [&](uint64_t v, int w) { return v ? splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)(w + 1))) : 0ull; };
+    // audit hash of the candidates: the words strictly inside the window are whole words of the type's candidate bitmap
+    // (prefix table ph, variant 1 = eligible & preferred), the two end words are the clipped ones of class 0
+    const uint64_t *PH = S.ph + ((size_t)S.T + type) * (size_t)(S.W + 1);
+    uint64_t hsum = term(sv[wlo], wlo);
+    if (whi > wlo) hsum += term(sv[whi], whi) + (PH[whi] - PH[wlo + 1]);
+#pragma unroll
+    for (int i = 0; i < kInlineExcl; i++) {
+        if (!((xmask >> i) & 1u)) continue;
+        const int w = ex[i] >> 6;
+        bool first_in_word = true;
+        uint64_t gone = 0;
+#pragma unroll
+        for (int j = 0; j < kInlineExcl; j++)
+            if (((xmask >> j) & 1u) && (ex[j] >> 6) == w) {
+                if (j < i) first_in_word = false;
+                gone |= 1ull << (ex[j] & 63);
+            }
+        if (first_in_word) hsum += term(sv[w] & ~gone, w) - term(sv[w], w);
+    }
+    // the rpm rule (:4951-4980): which clauses apply is the request's (lastUsedTime); the limits are the window's
+    const int64_t ago = age_of(r.last_used, now);
+    int c = 0;
+    if (ccount >= 2 && ago < 5LL * 24 * 3600 * 1000 && ago < 24LL * 3600 * 1000) {
+        c = 1;
+        if (ago < 12LL * 60 * 1000) {
+            c = 2;
+            if (ago < 5000LL) {
+                c = 3;
+                if (ago < -1000LL) c = 4;
+            }
+        }
+    }
+    const uint64_t *svc = sv + (size_t)c * W;
+    const int32_t *pcc = pc + (size_t)c * (W + 1);
+    int removed_surv = 0;
+#pragma unroll
+    for (int i = 0; i < kInlineExcl; i++)
+        if (((xmask >> i) & 1u) && ((svc[ex[i] >> 6] >> (ex[i] & 63)) & 1ull)) removed_surv++;
+    const int remaining = pcc[whi + 1] - pcc[wlo] - removed_surv;
+    if (remaining <= 0) return kLaneWave;  // (cannot happen: the instance with the smallest rpm is never filtered)
+    const int index = remaining <= 1 ? 0 : (int)(((uint64_t)r.pick * (uint64_t)(uint32_t)remaining) >> 32);
+    // survivors in words [wlo, w), wlo < w <= whi + 1
+    auto before = [&](int w) {
+        int n = pcc[w] - pcc[wlo];
+#pragma unroll
+        for (int i = 0; i < kInlineExcl; i++)
+            if (((xmask >> i) & 1u) && (ex[i] >> 6) < w && ((svc[ex[i] >> 6] >> (ex[i] & 63)) & 1ull)) n--;
+        return n;
+    };
+    int lo = wlo, hi = whi;  // the word that holds the index-th survivor: the first w with before(w + 1) > index
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (before(mid + 1) > index)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    uint64_t bits = svc[lo];
+#pragma unroll
+    for (int i = 0; i < kInlineExcl; i++)
+        if (((xmask >> i) & 1u) && (ex[i] >> 6) == lo) bits &= ~(1ull << (ex[i] & 63));
+    const int cpos = lo * 64 + select_kth_bit(bits, index - before(lo));
+    o.n_candidates = ccount;
+    o.hash = (uint32_t)(hsum ^ (hsum >> 32)) ^ ((uint32_t)remaining * 0x9E3779B1u);
+    o.chosen = S.orig[cpos];
+    if (!favour && cpos == selfpos) o.chosen = MMP_SELF;  // :4989-4991
+    return kLaneDone;
+}
+
+template <bool VIEW, bool LONG = false>
+__device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, mmp_place_out &o, const BLds *Bt = nullptr);
+
+template <bool VIEW, bool LONG = false>
+__device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, int d, mmp_place_out &o, const BLds *Bt = nullptr)
+{
+    const ResolvedReq r = resolve_one<VIEW>(S, A, d);
+    return lane_decide_r<VIEW, LONG>(S, A, r, o, Bt);
+}
+
+// Bt: the staged case (b) tables of the long kernel (null: case (b) is the wave path's).  The first lane phase (LONG = false)
+// answers kLaneLong for a case (b) decision when they exist, the LONG phase decides it from them.
 template <bool VIEW, bool LONG>
-__device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, mmp_place_out &o)
+__device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, mmp_place_out &o, const BLds *Bt)
 {
     PHASE_T0();
     o.chosen = MMP_NONE;
@@ -816,6 +1156,11 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
         int bestpos = best0;
         if (has_pm && !((Pm[best0 >> 6] >> (best0 & 63)) & 1ull)) {
             if (best_is_full) {  // case (b)
+                if (!VIEW && Bt && Bt->n_slots > 0) {
+                    if (!LONG) return kLaneCaseB;  // the LONG phase decides it from the staged tables
+                    const int code = lane_case_b(S, r, L.ex, type, best0, A.now, *Bt, o);
+                    if (code == kLaneDone) return kLaneDone;
+                }
                 fb = true;
                 break;
             }
@@ -1619,6 +1964,18 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
     // barrier (the model row, the caller's position, the late-bound exclusions) has to be drained for it.
     mmp_place_req rq{};
     if (d < A.n) rq = A.reqs[d];
+    // case (b) on a full cluster (long kernel): the snapshot's whole-window tables (BSlot)
+    BLds Bt{};
+    const BLds *Btp = nullptr;
+    if (WITH_LONG && A.n_bslots > 0) {  // wave-uniform
+        Bt.slots = A.bslots;
+        Bt.n_slots = A.n_bslots < kBSlots ? A.n_bslots : kBSlots;
+        Bt.W = S.W;
+        Bt.surv = A.bsurv;
+        Bt.pcs = A.bpcs;
+        Bt.launch = A.bwin;
+        Btp = &Bt;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     ResolvedReq r;
@@ -1630,9 +1987,9 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
         if (use_wins) code = lane_decide_win(S, A, r, s_wins, s_scr + threadIdx.x, o);
         if (code == kLaneHeadMiss) {
             merge_late_extras(r);
-            code = lane_decide_r<false>(S, A, r, o);
+            code = lane_decide_r<false>(S, A, r, o, Btp);
         }
-        if (WITH_LONG && code == kLaneLong)
+        if (WITH_LONG && (code == kLaneLong || code == kLaneCaseB))
             lr_list[atomicAdd(&lr_n, 1)] = d;
         else if (code != kLaneDone)
             fb_list[atomicAdd(&fb_n, 1)] = d;
@@ -1649,7 +2006,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
         if ((int)threadIdx.x < nlr) {
             const int ld = lr_list[threadIdx.x];
             mmp_place_out o;
-            if (lane_decide<false, true>(S, A, ld, o) != kLaneDone)
+            if (lane_decide<false, true>(S, A, ld, o, Btp) != kLaneDone)
                 fb_list[atomicAdd(&fb_n, 1)] = ld;
             else
                 A.outs[ld] = o;

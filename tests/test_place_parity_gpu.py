@@ -764,6 +764,50 @@ def test_full_cluster_c3(frac):
         assert got["n_candidates"].max() > 5000  # whole-table shortlists did occur
 
 
+@pytest.mark.parametrize("tables", [True, False])
+@pytest.mark.parametrize("spread", [0.04, 0.3])
+@pytest.mark.parametrize("seed", range(3))
+def test_case_b_on_a_full_cluster_from_the_whole_window_tables(seed, spread, tables, monkeypatch):
+    """Round 3: the non-simple case (b) of getNext (MM.java:4853-4887: a preferring type whose first eligible instance is full
+    and not preferred; candidates = the preferred instances inside the lruTime window, each with its own rpm in the rpm rule)
+    is decided by one lane from tables built at commit when the cluster is full and the window reaches its last instance
+    (place_kernel.hpp: BSlot, lane_case_b).  Here EVERY request of the preferring types takes it: the first instance of the
+    order is made non-preferred; requests exclude candidates (their models' copies), are the first instance themselves, or a
+    candidate with favourSelf; rpm values sit on the rule's thresholds so that every clause filters.  With spread 0.3 the window
+    of some requests ends before the table does: those must still answer like the oracle (the wave path).  tables = False
+    (MMP_NO_CASEB=1) keeps the tables out: the wave path decides the same requests."""
+    if not tables:
+        monkeypatch.setenv("MMP_NO_CASEB", "1")
+    rng = np.random.default_rng(7700 + seed)
+    fleet = wl.make_fleet("C3", models=30_000, pods=3_000)
+    P = fleet.n_pods
+    fleet.pods["used"] = fleet.pods["capacity"] - rng.integers(0, 40_000, P)
+    fleet.pods["lru_time"] = fleet.now - (36_000_000 * (1 + rng.uniform(-spread, spread, P))).astype(np.int64)
+    fleet.pods["rpm"] = rng.choice([0, 50, 99, 100, 101, 110, 111, 150, 151, 300, 301, 400, 401, 5000], P)
+    orc = OracleFleet(fleet)
+    # the preferring type(s): the most desirable instances are not preferred -> case (b) for every request of the type
+    from modelmesh_amd.solver import bitmap_from_bool
+    from oracle.bind import unpack_bitmap
+    pf = unpack_bitmap(fleet.prefer, P).astype(bool)
+    pf[:, orc.order[: 3 + seed]] = False
+    fleet.prefer = bitmap_from_bool(pf)
+    fleet.models["type"] = np.where(rng.random(fleet.n_models) < 0.5, 2, fleet.models["type"])  # half of the models prefer
+    reqs, extra = wl.make_requests(fleet, 40 + seed, favour_frac=0.3, extra_frac=0.3)
+    head = orc.order[:40]
+    reqs["self_pod"] = np.where(rng.random(len(reqs)) < 0.2, head[rng.integers(0, len(head), len(reqs))], reqs["self_pod"])
+    orc = OracleFleet(fleet)
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        got = s.place(reqs, extra, fleet.now)
+    finally:
+        s.close()
+    want = orc.place(reqs, extra, fleet.now, threads=16)
+    assert_same_decisions(fleet, reqs, got, want)
+    t2 = fleet.models["type"][reqs["model"]] == 2
+    assert t2.sum() > 10_000 and want["n_candidates"][t2].mean() > 100  # case (b) with long candidate lists did occur
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_types_only_a_few_instances_may_host(seed, monkeypatch):
     """A type whose label requirement a handful of instances in thousands satisfy (UpgradeTracker / TypeConstraintManager

@@ -11,7 +11,11 @@ usage: tools/pmc_summary.py <fetch_dir> <write_dir> <kernel-substring> <out.json
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_hash import kernel_source_hash  # noqa: E402
 
 
 def per_launch(d, counter, kernel, min_value):
@@ -34,7 +38,8 @@ def main():
     med = lambda v: v[len(v) // 2] if v else None  # noqa: E731
     f, w = med(fv), med(wv)
     res = {
-        "kernel": kernel, "launches_fetch_pass": len(fv), "launches_write_pass": len(wv),
+        "kernel": kernel, "kernel_source_hash": kernel_source_hash(),  # of the tree the passes ran on (tools/kernel_hash.py)
+        "launches_fetch_pass": len(fv), "launches_write_pass": len(wv),
         "FETCH_SIZE_median_raw": f, "WRITE_SIZE_median_raw": w,
         "fetch_bytes_raw": None if f is None else f * 1024,
         "fetch_bytes_corrected": None if f is None else 2 * f * 1024,
