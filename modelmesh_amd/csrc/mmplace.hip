@@ -198,6 +198,7 @@ struct mmp_ctx {
     DevBuf rk_rows, rk_idx, rk_tmp;  // ranking by sorting (snapshot.hpp)
     int32_t long_mode = -1;  // MMP_LONG_MODE: -1 auto (the long-shortlist kernel for snapshots whose instances are nearly all full), 0 never, 1 always (tests)
     bool snap_long = false;  // the committed snapshot takes place_batch_long_kernel
+    bool snap_full = false;  // ... because (nearly) all of its instances are full (not only because a type is sparse)
     int32_t rank_mode = 0;  // MMP_RANK_MODE: 0 auto (sort from kRankSortMinPods pods), 1 all-pairs, 2 sort whenever legal (tests)
     Snap sview{};  // the lane path's view of this shard's slice (place_shard_fast_kernel)
     DevBuf f_flags, f_offs, f_idx, f_reqs, f_outs, f_scan_tmp;  // speculative form: the compacted rest of a batch
@@ -438,6 +439,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     // one dynamic region: the lane phase's windows + scratch, re-used by the wave path's tiles (place_block)
     const size_t lds = std::max<size_t>((size_t)kPlaceWaves * 2 * wpad * sizeof(uint64_t), (size_t)place_lane_lds(c->snap.T));
     // the long kernel on a full cluster: the case (b) tables of the snapshot's preferring types (place_kernel.hpp: BSlot)
+    A.long_first = (c->snap_long && c->snap_full && A.rmodels) ? 1 : 0;
     if (c->snap_long && !inline_req && !done_flag && A.wins && !c->no_caseb) {
         const SnapBufs &B = c->sb[c->cur];
         if (B.n_bslots > 0) {
@@ -1234,7 +1236,7 @@ try {
     S.nz = B.nz.as<int32_t>();
     S.ph = B.ph.as<uint64_t>();
 
-    bool next_long = c->long_mode == 1;
+    bool next_long = c->long_mode == 1, next_full = false;
     KT_BEGIN(c, st);
     if (P > 0) {
         // is the literal comparator a strict total order on these rows?  (see snapshot.hpp "ranking by sorting")
@@ -1254,6 +1256,7 @@ try {
         }
         // (nearly) every instance full: getNext is in its LRU-window mode and whole-table shortlists are common
         next_long = c->long_mode == 1 || (c->long_mode != 0 && n_present > 0 && n_nonfull * 16 <= n_present);
+        next_full = n_present > 0 && n_nonfull * 16 <= n_present;
         // all-pairs is embarrassingly parallel and wins below ~8k pods (measured: 10k pods 172 us all-pairs vs 120 us
         // sort; 50k pods 4.3 ms vs 0.25 ms); a merge sort of a few thousand 64-byte keys is latency bound
         const bool want_sort = c->rank_mode == 2 || (c->rank_mode == 0 && P >= kRankSortMinPods);
@@ -1348,6 +1351,7 @@ try {
     std::lock_guard<std::shared_mutex> g(c->mu);
     resident_stop(c);  // it answers for the snapshot it was launched with; the next single request starts one on the new
     c->snap_long = next_long;
+    c->snap_full = next_full;
     c->snap = S;
     c->cur = 1 - c->cur;
     c->committed = true;

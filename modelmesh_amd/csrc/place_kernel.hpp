@@ -141,6 +141,8 @@ struct PlaceArgs {
     const uint64_t *bsurv;
     const int32_t *bpcs;
     int32_t n_bslots;
+    int32_t long_first;            // long kernel on a snapshot whose instances are (nearly) all full: most shortlists span the table, so the
+                                   // first lane phase runs the prefix-table instantiation at once instead of window -> lane -> long
     const int32_t *ent_pod;  // model entries: loaded ids then failed ids
     const int32_t *extra;    // per-request extra exclusions
     mmp_place_out *outs;
@@ -1984,10 +1986,15 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
     if (d < A.n) {
         mmp_place_out o;
         int code = kLaneHeadMiss;
-        if (use_wins) code = lane_decide_win(S, A, r, s_wins, s_scr + threadIdx.x, o);
-        if (code == kLaneHeadMiss) {
+        if (WITH_LONG && A.long_first) {  // (wave-uniform) a full cluster: nearly every decision would end in the long phase anyway
             merge_late_extras(r);
-            code = lane_decide_r<false>(S, A, r, o, Btp);
+            code = lane_decide_r<false, true>(S, A, r, o, Btp);
+        } else {
+            if (use_wins) code = lane_decide_win(S, A, r, s_wins, s_scr + threadIdx.x, o);
+            if (code == kLaneHeadMiss) {
+                merge_late_extras(r);
+                code = lane_decide_r<false>(S, A, r, o, Btp);
+            }
         }
         if (WITH_LONG && (code == kLaneLong || code == kLaneCaseB))
             lr_list[atomicAdd(&lr_n, 1)] = d;
