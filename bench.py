@@ -481,6 +481,7 @@ def churn_leg(fleet, solver, slices: int = 8, events: int = 20_000):
     single, _ = wl.make_requests(fleet, seed=0xC51, n=256)
     single = np.ascontiguousarray(single)
     single["n_extra"] = 0
+    single["extra_off"] = 0
     prober = _single_prober()
     for it in range(slices + 1):
         f = cs.fleet
@@ -502,12 +503,13 @@ def churn_leg(fleet, solver, slices: int = 8, events: int = 20_000):
             prober.prober_start(C.cast(solver.lib.mmp_place_batch, C.c_void_p), solver.h, single.ctypes.data_as(C.c_void_p), len(single),
                                 C.c_int64(int(fleet.now)), C.c_int64(4_000_000))
         cs.apply(sl, got)
-    lat = np.zeros(0)
+    lat, why_none = np.zeros(0), "tools/micro/single_prober.c could not be built (no gcc?)"
     if prober is not None:
         buf = np.zeros(4_000_000, np.uint32)
         got_n = int(prober.prober_stop(buf.ctypes.data_as(C.c_void_p), C.c_int64(len(buf))))
         lat = buf[100:got_n].astype(np.float64) / 1e3 if got_n > 200 else np.zeros(0)
-    return {"single_decisions_during_churn": None if not len(lat) else {
+        why_none = f"the prober thread returned {got_n} (negative: calls that failed; small: too few samples)"
+    return {"single_decisions_during_churn": {"error": why_none} if not len(lat) else {
                 "calls": int(len(lat)), "p50_us": float(np.percentile(lat, 50)), "p99_us": float(np.percentile(lat, 99)),
                 "p999_us": float(np.percentile(lat, 99.9)), "max_us": float(lat.max()),
                 "note": "mmp_place_batch(n = 1) from a second host thread (C, tools/micro/single_prober.c) for the whole leg, across its "
@@ -709,6 +711,9 @@ def main():
     ap.add_argument("--leg-timeout", type=float, default=420.0,
                     help="watchdog for the additional legs (pod axis, latency, churn, per-kernel, cpu baseline): when "
                          "it fires rank 0 prints the line with the legs completed so far and every rank exits 0")
+    ap.add_argument("--full-cluster", action="store_true",
+                    help="profiling variant: every instance full and all caches equally old (the fleet of the line's `full_cluster` "
+                         "object); use with --kernel-only")
     ap.add_argument("--kernel-only", action="store_true",
                     help="skip the n=1 latency / host-boundary legs (used under rocprofv3 so that every "
                          "place_batch_kernel dispatch in the trace is a full batch)")
@@ -750,6 +755,10 @@ def main():
         node_barrier = NodeBarrier.create(rank, world, dist)
 
     fleet = wl.make_fleet(args.workload)
+    if args.full_cluster:  # profiling variant (tools/gpu_profile.sh): the fleet of full_cluster_leg — every instance full, equally old
+        frng = np.random.default_rng(5)
+        fleet.pods["used"] = fleet.pods["capacity"] - frng.integers(0, 40_000, fleet.n_pods)
+        fleet.pods["lru_time"] = fleet.now - (36_000_000 * (1 + frng.uniform(-0.04, 0.04, fleet.n_pods))).astype(np.int64)
     solver = Solver(fleet.min_space_units, fleet.min_churn_age_ms, device=local_rank)
     solver.load_fleet(fleet)
     dev = torch.device("cuda", local_rank)

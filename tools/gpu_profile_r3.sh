@@ -1,0 +1,59 @@
+#!/bin/bash
+# Round 3: everything profiles/r3 holds, in one GPU-box visit (raw rocprofv3 traces stay in /tmp; these are the summaries).
+# usage (repo root on the GPU box): bash tools/gpu_profile_r3.sh [out_dir]
+set -u
+export TMPDIR=/tmp
+OUT=${1:-gpurun_out/prof_r3}
+mkdir -p $OUT
+python tools/kernel_hash.py > $OUT/kernel_source_hash.txt
+timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log; grep -E "passed|failed|exit" $OUT/pytest_gpu.log | tail -2
+timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
+
+# one profiled configuration: kernel stats (1 stream), the two HBM PMC passes, two SQ passes
+# $1 tag, $2 kernel-name substring, rest: bench.py arguments
+profile_one() {
+  local tag=$1 kern=$2; shift 2
+  rm -rf /tmp/p_$tag
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$tag/stats -- python bench.py --kernel-only --steps 200 --warmup 20 --streams 1 "$@" > $OUT/bench_${tag}_kernel_only_1stream.log 2>&1
+  f=$(find /tmp/p_$tag/stats -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/${tag}_kernel_stats_1stream.csv && grep "$kern" $OUT/${tag}_kernel_stats_1stream.csv | cut -c1-160
+  grep "^{" $OUT/bench_${tag}_kernel_only_1stream.log | tail -1 > $OUT/bench_${tag}_kernel_only_1stream.json.log
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_$tag/f -- python bench.py --kernel-only --steps 20 --warmup 2 --streams 1 "$@" > /dev/null 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_$tag/w -- python bench.py --kernel-only --steps 20 --warmup 2 --streams 1 "$@" > /dev/null 2>&1
+  python tools/pmc_summary.py /tmp/p_$tag/f /tmp/p_$tag/w $kern $OUT/pmc_place_batch_$tag.json > /dev/null; cut -c1-400 $OUT/pmc_place_batch_$tag.json | tr '\n' ' '; echo
+  timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d /tmp/p_$tag/sq1 -- python bench.py --kernel-only --steps 20 --warmup 2 --streams 1 "$@" > /dev/null 2>&1
+  timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM --kernel-trace --output-format csv -d /tmp/p_$tag/sq2 -- python bench.py --kernel-only --steps 20 --warmup 2 --streams 1 "$@" > /dev/null 2>&1
+  (python tools/sq_summary.py /tmp/p_$tag/sq1 $kern; python tools/sq_summary.py /tmp/p_$tag/sq2 $kern) > $OUT/sq_$tag.jsonl; cut -c1-260 $OUT/sq_$tag.jsonl
+}
+profile_one C3_800k place_batch_kernel --workload C3
+profile_one C3_100k place_batch_kernel --workload C3 --decisions-per-step 100000
+profile_one C3_full_cluster_100k place_batch_long_kernel --workload C3 --decisions-per-step 100000 --full-cluster
+profile_one C3_full_cluster_800k place_batch_long_kernel --workload C3 --full-cluster
+[[ "${PROFILE_WORKLOADS:-C3 C4}" == *C4* ]] && profile_one C4 place_batch_kernel --workload C4
+
+# two overlapping streams (the timed region's shape): kernel stats only
+rm -rf /tmp/p_2s
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_2s -- python bench.py --kernel-only --steps 200 --warmup 20 --streams 2 > $OUT/bench_C3_800k_kernel_only_2streams.log 2>&1
+f=$(find /tmp/p_2s -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/C3_800k_kernel_stats_2streams.csv
+
+# the secondary kernels: the whole bench under the kernel trace, then under the two SQ passes
+rm -rf /tmp/p_full
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_full/stats -- python bench.py --steps 20 --warmup 5 --no-pod-axis --no-cpu-baseline > $OUT/prof_full_bench.log 2>&1
+f=$(find /tmp/p_full/stats -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/bench_full_kernel_stats.csv && grep -E "serve_batch|gate_batch|evict_batch|cache_replay|ingest_|build_b|build_wins" $OUT/bench_full_kernel_stats.csv | cut -c1-140
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d /tmp/p_full/sq1 -- python bench.py --steps 20 --warmup 5 --no-pod-axis --no-cpu-baseline > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM --kernel-trace --output-format csv -d /tmp/p_full/sq2 -- python bench.py --steps 20 --warmup 5 --no-pod-axis --no-cpu-baseline > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_full/f -- python bench.py --steps 20 --warmup 5 --no-pod-axis --no-cpu-baseline > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_full/w -- python bench.py --steps 20 --warmup 5 --no-pod-axis --no-cpu-baseline > /dev/null 2>&1
+for k in serve_batch_kernel gate_batch_kernel evict_batch_kernel cache_replay_kernel; do
+  # (the 100k-unit launches of the `kernels` leg only: the run also makes single-request and mixed-size launches of these kernels)
+  (python tools/sq_summary.py /tmp/p_full/sq1 $k 50000; python tools/sq_summary.py /tmp/p_full/sq2 $k 50000) > $OUT/sq_$k.jsonl
+  python tools/pmc_summary.py /tmp/p_full/f /tmp/p_full/w $k $OUT/pmc_$k.json 1000 > /dev/null
+  echo "$k: $(cut -c1-200 $OUT/sq_$k.jsonl | head -1)"
+done
+
+# the bench lines: the driver's flags, then the defaults; C4
+timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_C3_n1_steps20.json.log 2> $OUT/bench_C3_steps20.err; echo "bench(20) exit $?"
+timeout 900 python bench.py > $OUT/bench_C3_n1.json.log 2> $OUT/bench_C3.err; echo "bench exit $?"
+python tools/benchline.py steps20 < $OUT/bench_C3_n1_steps20.json.log; python tools/benchline.py default < $OUT/bench_C3_n1.json.log
+if [[ "${PROFILE_WORKLOADS:-C3 C4}" == *C4* ]]; then timeout 600 python bench.py --workload C4 --steps 200 --warmup 10 --no-secondary > $OUT/bench_C4_n1.json.log 2> $OUT/bench_C4.err; echo "bench C4 exit $?"; python tools/benchline.py C4 < $OUT/bench_C4_n1.json.log; fi
+timeout 300 python tools/full_cluster_by_type.py 2>&1 | grep -v amdgpu.ids > $OUT/full_cluster_by_type.txt; cat $OUT/full_cluster_by_type.txt
+timeout 300 python tools/case_b_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/case_b_timing.txt; cat $OUT/case_b_timing.txt

@@ -8,11 +8,13 @@ import json
 import sys
 
 d, kernel = sys.argv[1:3]
+min_grid = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # only launches of at least this many work-items (a bench run mixes sizes)
 vals = collections.defaultdict(list)
 for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if kernel in r["Kernel_Name"]:
+        if kernel in r["Kernel_Name"] and int(float(r.get("Grid_Size", 0) or 0)) >= min_grid:
             vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {k: sorted(v)[len(v) // 2] for k, v in vals.items()}
 out["launches"] = max((len(v) for v in vals.values()), default=0)
+out["min_grid"] = min_grid
 print(json.dumps(out))
