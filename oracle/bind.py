@@ -571,13 +571,14 @@ def scaleup_plan(fleet, entries, params):
     return outs[: len(entries)], ov[: fleet.n_pods], sk
 
 
-def scaledown_plan(fleet, entries, params):
-    lib = load()
-    orc = OracleFleet(fleet)
+def instance_set_stats(fleet, self_pod, orc=None):
+    """instanceSetStats() (MM.java:1446): the cluster's stats, or with type constraints the stats of this instance's
+    partition (EMPTY_STATS when it is not in the table)."""
+    orc = orc or OracleFleet(fleet)
     stats = np.zeros(1, dtype=ORC_STATS)
     stats[0] = orc.stats()
-    if fleet.n_types:  # instanceSetStats(): this instance's partition (EMPTY_STATS when it is not in the table)
-        sp = int(np.asarray(params).reshape(-1)[0]["self_pod"])
+    if fleet.n_types:
+        sp = int(self_pod)
         pts, sets, pst = partition_stats(fleet)
         k = int(pts[sp]) if 0 <= sp < fleet.n_pods else -1
         if k >= 0:
@@ -585,6 +586,13 @@ def scaledown_plan(fleet, entries, params):
         else:
             stats[0] = np.zeros(1, dtype=ORC_STATS)[0]
             stats[0]["global_lru"] = 2**63 - 1
+    return stats
+
+
+def scaledown_plan(fleet, entries, params):
+    lib = load()
+    orc = OracleFleet(fleet)
+    stats = instance_set_stats(fleet, int(np.asarray(params).reshape(-1)[0]["self_pod"]), orc)
     pos_of = np.full(max(fleet.n_pods, 1), 2**31 - 1, np.int32)
     pos_of[orc.order] = np.arange(len(orc.order), dtype=np.int32)
     in_table = np.ascontiguousarray(((fleet.pods["flags"] & 4) == 0).astype(np.uint8))

@@ -59,6 +59,20 @@ RANGES = [
     ("publish_fragment_b", MM, 5423, 5468, "if (oldest == -1L) {", "}"),
     ("loadingChange_body", MM, 5537, 5542, "int curInProg = curRec.getLoadingInProgress();", "return Math.abs(loadInProg - curInProg) >= 3;"),
     ("loadChange_body", MM, 5547, 5549, "int diff = Math.abs(curRecRpms - rpms);", "(100 * diff) / curRecRpms > 10);"),
+    # ---- a15: rateTrackingTask (the scale-up planner), getExcludeSet, loadedSince.  The `try {` / `} catch ... finally {`
+    # lines around the loop body (5656, 5686-5687, 5807-5813) are Java plumbing with no C++ counterpart: the body is taken
+    # from inside them
+    ("ratetask_prologue_a", MM, 5641, 5654, "final long lastTime = lastCheckTime, now = currentTimeMillis();", "final int upper = iterationCounter - secondCopyMinAgeIters;"),
+    ("ratetask_prologue_b", MM, 5657, 5685, "int instCount = clusterStats.instanceCount;", "int modelParallelismSum = 0;"),
+    ("ratetask_loop_body", MM, 5688, 5806, "modelId = ent.getKey();", "copiesToLoad - 1);"),
+    ("getExcludeSet_body", MM, 5836, 5855, "int scaleUpRpms = limitModelConcurrency", "return excludeSet != null ? excludeSet : Collections.emptySet();"),
+    ("loadedSince_body", MM, 5861, 5870, "for (Entry<String, Long> entry : mr.getInstanceIds().entrySet()) {", "return false;"),
+    # ---- a16: the janitor's scale-down of model copies
+    ("janitor_scaledown_fragment", MM, 6111, 6140, "if (shuttingDown) {", "}"),
+    ("removeModelCopies_body", MM, 6199, 6309, "if (lastUsed == 0L) {", "return false;"),
+    ("removeSecondModelCopy_body", MM, 6318, 6334, "if (otherValidInstance == null) {", "return removeLocalModelCopyAsync(modelId, mr, ce, lastUsed);"),
+    ("getRpm_body", MM, 1739, 1740, "long countSinceLastTime = getIntervalCount();", "(60_000L * countSinceLastTime) / timeSinceLastCheck;"),
+    ("second_copy_remove_constant", MM, 257, 257, "SECOND_COPY_REMOVE_MAX_AGE_MS = 10 * 3600_000L;", "10hours"),
 ]
 
 # token-level rewrites, applied in order to every extracted line
@@ -70,6 +84,7 @@ RULES = [
     # object creation: `new ArrayList<>(n)` / `new IntArrayList(n)` -> factory calls of the stand-ins (the diamond's type
     # argument is inferred from the declaration on the left, as in Java); any other `new X(...)` -> a value of the handle class X
     (re.compile(r"\bnew\s+ArrayList<>\("), "ArrayList_new("),
+    (re.compile(r"\bnew\s+TreeSet<>\("), "TreeSet_new("),
     (re.compile(r"\bnew\s+IntArrayList\("), "IntArrayList_new("),
     (re.compile(r"\bnew\s+(\w+)\("), r"\1("),
     # string literals are java.lang.String objects (they are concatenated with + into log / exception messages)
@@ -91,6 +106,12 @@ RULES = [
     # static members of the boxed types: Long.compare / Long.MAX_VALUE / Integer.MAX_VALUE (Long is also a type argument,
     # Map<String, Long>, so it has to be a class on the C++ side)
     (re.compile(r"\b(Long|Integer|Collections)\.(?=[A-Za-z])"), r"\1::"),
+    # the Java array type Object[] as a type argument (Entry<Object[], Long>) -> the stand-in's name
+    (re.compile(r"\bObject\[\]"), "ObjectArr3"),
+    # `x instanceof T` -> a function of the stand-ins (C++ has no runtime type test on these handles)
+    (re.compile(r"\b(\w+)\s+instanceof\s+(\w+)"), r"instanceof_\2(\1)"),
+    # `union` (Guava's Sets.union) is a C++ keyword
+    (re.compile(r"\.union\("), ".union_("),
     # member modifiers in front of the constant declarations
     (re.compile(r"^\s*(?:protected|public)\s+static\s+"), ""),
 ]

@@ -103,14 +103,24 @@ static const struct {
     struct R { int nextInt(int n) const { return (int)(((uint64_t)g_pick * (uint64_t)(uint32_t)n) >> 32); } };
     R current() const { return R(); }
 } ThreadLocalRandom;  // :4981: the pick is an input of every restatement (SURVEY B#9)
-static const struct { void warn(const String &) const {} void info(const String &) const {} } logger;
+static const struct {
+    void warn(const String &) const {}
+    void info(const String &) const {}
+    void debug(const String &) const {}
+    boolean isDebugEnabled() const { return false; }
+} logger;
+static long nanoTime() { return 0; }
 static const String CACHE_MISS_EXCLUDES_KEY("tas.cm_excludes"), DEST_INST_ID_KEY("tas.dest_iid");
 struct ThreadContextT { int getCurrentContext() const { return 0; } };
 static const ThreadContextT ThreadContext;
 static Map<String, String> ensureContextMapIsMutable(int) { return Map<String, String>::make(); }
 
 static std::shared_ptr<std::vector<Entry<String, InstanceRecord>>> g_cluster;  // clusterState, kept in PLACEMENT_ORDER
-static const struct { Iterator<Entry<String, InstanceRecord>> iterator() const { return iterate(g_cluster); } } clusterState;
+static const struct {
+    Iterator<Entry<String, InstanceRecord>> iterator() const { return iterate(g_cluster); }
+    std::vector<Entry<String, InstanceRecord>>::const_iterator begin() const { return g_cluster->begin(); }
+    std::vector<Entry<String, InstanceRecord>>::const_iterator end() const { return g_cluster->end(); }
+} clusterState;
 static Map<String, ServiceInstanceInfo> g_simap;
 static Map<String, ServiceInstanceInfo> getMap(const ObjectArray &) { return g_simap; }  // MM.java:3301
 
@@ -255,7 +265,12 @@ static ModelLoadException newModelLoadException(const String &, long, std::nullp
 static TException newInternalException(const String &, std::nullptr_t) { TException t; t.isnull = false; return t; }
 struct ClusterStats { long totalCapacity, totalFree, globalLru; int instanceCount, modelCopyCount; };
 static std::vector<ClusterStats> g_tstats;
-static ClusterStats typeSetStats(const String &type) { return g_tstats.at(std::min<size_t>(std::stoul(type.str().substr(1)), g_tstats.size() - 1)); }
+static ClusterStats clusterStats;  // MM.java:1570 (the cluster-wide stats)
+static ClusterStats typeSetStats(const String &type)  // :1432 — "t<row>"; "t-1": an entry without a registry record (no type: the cluster's stats)
+{
+    const long row = std::stol(type.str().substr(1));
+    return row < 0 ? clusterStats : g_tstats.at(std::min<size_t>((size_t)row, g_tstats.size() - 1));
+}
 
 // ModelRecord (ModelRecord.java:61-114): type + the two id -> time maps
 struct ModelRecord {
@@ -265,11 +280,20 @@ struct ModelRecord {
     ModelRecord() {}
     ModelRecord(std::nullptr_t) : isnull(true) {}
     bool operator!=(std::nullptr_t) const { return !isnull; }
+    bool operator==(std::nullptr_t) const { return isnull; }
+    boolean loadFailedInInstance(const String &iid) const { return failed.containsKey(iid); }  // ModelRecord.java:208
+    long lastUnloadTime = 0;
+    long getLastUnloadTime() const { return lastUnloadTime; }
     String getType() const { return type; }
     Map<String, Long> getInstanceIds() const { return instanceIds; }
     Map<String, Long> getLoadFailedInstanceIds() const { return failed; }
     boolean hasLoadFailure() const { return !failed.isEmpty(); }  // ModelRecord.java:203
     String getLoadFailureMessage(const String &) const { return String(""); }
+};
+struct IntField {  // an assignable int field of an object with reference semantics (ce.earlierUseIteration = i2)
+    std::shared_ptr<int> p = std::make_shared<int>(0);
+    operator int() const { return *p; }
+    const IntField &operator=(int v) const { *p = v; return *this; }
 };
 struct CacheEntry {  // what the fragments ask of a CacheEntry<?>
     bool isnull = true, done = false, failed = false;
@@ -283,8 +307,34 @@ struct CacheEntry {  // what the fragments ask of a CacheEntry<?>
     boolean isFailed() const { return failed; }
     int loaderPredictedWeight() const { return predicted; }
     void remove() const {}
-    struct MI { String t; String getServiceType() const { return t; } } modelInfo;
+    struct MI { String t, serviceType; String getServiceType() const { return t; } } modelInfo;
+    // the rate-tracking fields (CacheEntry's usage slices, MM.java:5729-5741)
+    IntField earlierUseIteration, lastUsedIteration;
+    std::shared_ptr<long> heavy = std::make_shared<long>(0);  // lastHeavyTime as set by this run (0: untouched)
+    long intervalCount = 0;
+    int weight = 0;
+    long getAndResetIntervalCount() const { return intervalCount; }
+    long getIntervalCount() const { return intervalCount; }
+    long lastHeavyTimeIn = 0;
+    long getLastHeavyTime() const { return lastHeavyTimeIn; }
+    long getRpm(long timeSinceLastCheck) const  // MM.java:1738
+    {
+#include "../_ref/gen/getRpm_body.inc"
+    }
+    void setLastHeavyTime(long t) const { *heavy = t; }
+    int getWeight() const { return weight; }
 };
+struct MaxConcCacheEntry {  // limitModelConcurrency == false here: compiled, never executed
+    int maxConc = 1;
+    bool isnull = false;
+    MaxConcCacheEntry(const CacheEntry &) {}
+    MaxConcCacheEntry(std::nullptr_t) : isnull(true) {}
+    bool operator==(std::nullptr_t) const { return isnull; }
+    bool operator!=(std::nullptr_t) const { return !isnull; }
+    int getRpmScaleThreshold(boolean) const { return 0; }
+    int queuedRequestCount() const { return 0; }
+};
+static boolean instanceof_MaxConcCacheEntry(const CacheEntry &) { return false; }  // (plain CacheEntry objects only)
 static const mmp_gate_req *g_gq;  // the request whose fragment is running
 static CacheEntry g_cache_entry;
 static CacheEntry getFromCache(const String &, long) { return g_cache_entry; }  // MM.java:3609
@@ -306,6 +356,7 @@ static const struct {
         auto it = g_pod_of.find(id.str());
         return it == g_pod_of.end() ? InstanceRecord(null) : g_table_rec[it->second];
     }
+    InstanceRecord get(const String &id) const { return getOrStrongIfAbsent(id); }  // instanceInfo.get(iid): null when not in the table
     int keyIterable() const { return 0; }
 } instanceInfo;
 static const struct { String toString(int) const { return String(""); } } Iterables;
@@ -411,6 +462,96 @@ static void frag_publish(boolean force, boolean preShutdown)
     }
 }
 
+// =================================== a15: rateTrackingTask, the scale-up planner (MM.java:5619-5871) =========================
+static long lastCheckTime, RATE_CHECK_INTERVAL_MS;      // :5617, :238
+static int iterationCounter, secondCopyMaxAgeIters, secondCopyMinAgeIters, secondCopyLruThresholdMillis, scaleUpRpmThreshold;
+static boolean limitModelConcurrency = false;
+static double averageModelParallelism = 1.0;
+static const struct { bool operator!=(std::nullptr_t) const { return false; } void removeUnloadBufferEntry(const Map<String, CacheEntry> &) const {} } unloadManager;
+static Map<String, CacheEntry> g_used_since_last_run;
+static const struct RuntimeCacheScale { Map<String, CacheEntry> descendingMapWithCutoff(long) const { return g_used_since_last_run; } } runtimeCacheScale;
+static List<String> excludeThisInstance;
+struct AsyncLoad { std::string model; long ts; int weight; int extra; std::vector<std::string> exclude; };
+static std::vector<AsyncLoad> g_async_loads;
+static void ensureLoadedInternalAsync(const String &modelId, long ts, int weight, const List<String> &exclude, int extraCopies)  // :6940
+{
+    AsyncLoad a{modelId.str(), ts, weight, extraCopies, {}};
+    for (int i = 0; i < exclude.size(); i++) a.exclude.push_back(exclude.get(i).str());
+    g_async_loads.push_back(a);
+}
+static std::map<std::string, ModelRecord> g_registry_all;
+static const struct { ModelRecord get(const String &id) const { auto it = g_registry_all.find(id.str()); return it == g_registry_all.end() ? ModelRecord(null) : it->second; } } registryAll;
+static boolean loadedSince(ModelRecord mr, long recentLoadCutoff, String ignoreInstance)  // :5860
+{
+#include "../_ref/gen/loadedSince_body.inc"
+}
+static Set<String> g_exclude_set_seen;
+static Set<String> getExcludeSet_()  // :5835
+{
+#include "../_ref/gen/getExcludeSet_body.inc"
+}
+static Set<String> getExcludeSet()
+{
+    g_exclude_set_seen = getExcludeSet_();
+    return g_exclude_set_seen;
+}
+// Runnable.run of rateTrackingTask (:5636): prologue, then the loop body per entry of usedSinceLastRun
+static void rateTrackingTask_run()
+{
+    const auto &runtimeCache = runtimeCacheScale;  // (the fragment's `runtimeCache` is the scale-up view here)
+    const auto &registry = registryAll;
+#include "../_ref/gen/ratetask_prologue_a.inc"
+#include "../_ref/gen/ratetask_prologue_b.inc"
+    for (Entry<String, CacheEntry> ent : usedSinceLastRun.entrySet()) {  // :5686 (the try / catch / finally around the body: plumbing)
+#include "../_ref/gen/ratetask_loop_body.inc"
+    }
+}
+
+// ================================ a16: the janitor's scale-down of model copies (MM.java:6110-6335) ===========================
+#include "../_ref/gen/second_copy_remove_constant.inc"
+static ClusterStats g_instance_set_stats;
+static ClusterStats instanceSetStats() { return g_instance_set_stats; }  // :1446 (this instance's partition: an input)
+static const struct { template <class K, class V> Entry<K, V> immutableEntry(const K &k, const V &v) const { return Entry<K, V>(k, v); } } Maps;
+static const struct { int compare(Entry<String, InstanceRecord> a, Entry<String, InstanceRecord> b) const { return placement_order_compare(a, b); } } PLACEMENT_ORDER;
+static std::vector<std::string> g_removed_local;
+static boolean removeLocalModelCopyAsync(const String &modelId, const ModelRecord &, const CacheEntry &, long)  // :6345
+{
+    g_removed_local.push_back(modelId.str());
+    return true;
+}
+static boolean removeSecondModelCopy(String modelId, ModelRecord mr, CacheEntry ce, long lastUsed, Entry<String, InstanceRecord> otherValidInstance)  // :6314
+{
+#include "../_ref/gen/removeSecondModelCopy_body.inc"
+}
+static boolean removeModelCopies(String modelId, ModelRecord mr, CacheEntry ce, long lastUsed, long nowMillis, boolean canRemove)  // :6197
+{
+#include "../_ref/gen/removeModelCopies_body.inc"
+}
+// an element of scaleCopiesCandidates' key arrays, (String) / (ModelRecord) / (CacheEntry<?>) cast by the loop (:6123-6126)
+struct AnyRef {
+    String s;
+    ModelRecord mr;
+    CacheEntry ce;
+    operator String() const { return s; }
+    operator ModelRecord() const { return mr; }
+    operator CacheEntry() const { return ce; }
+};
+struct ObjectArr3 {
+    std::shared_ptr<std::vector<AnyRef>> p = std::make_shared<std::vector<AnyRef>>(3);
+    const AnyRef &operator[](int i) const { return (*p)[i]; }
+};
+struct Exception {};
+static std::vector<Entry<ObjectArr3, Long>> g_scale_candidates;
+static long g_adjusted_capacity;
+static long getAdjustedCacheCapacity() { return g_adjusted_capacity; }  // :5363
+static void janitor_scaledown(long now)
+{
+    const struct { void error(const String &, const Exception &) const {} void info(const String &) const {} } logger;
+    String modelId = null;
+    const std::vector<Entry<ObjectArr3, Long>> &scaleCopiesCandidates = g_scale_candidates;
+#include "../_ref/gen/janitor_scaledown_fragment.inc"
+}
+
 // ======================================================== I/O ===============================================================
 // The audit hash of a shortlist (machinery of THIS repository, not of the reference): a function of the set of
 // rank positions in the shortlist and of the count that survived the rpm filter — computed here from the reference's own
@@ -478,6 +619,18 @@ int main(int argc, char **argv)
     auto gparams = rd<int64_t>(f, n_gate ? 1 : 0);  // IN_USE_LOAD_FAILURE_EXPIRY_MS
     struct StatsRow { int64_t total_capacity, total_free, global_lru; int32_t instance_count, model_copy_count; };
     auto tstats = rd<StatsRow>(f, n_gate ? std::max<int64_t>(Tn, 1) : 0);  // typeSetStats(type) per type row: an input here (rows a5 / a18)
+    // a15: one run of the rate-tracking task: params, the entries of usedSinceLastRun in its order, cluster + per-type stats
+    auto n_scale_v = rd<int64_t>(f, 1);
+    const int64_t n_scale = n_scale_v[0];
+    auto sparams = rd<mmp_scaleup_params>(f, n_scale >= 0 ? 1 : 0);
+    auto sentries = rd<mmp_cache_entry>(f, n_scale > 0 ? n_scale : 0);
+    auto sstats = rd<StatsRow>(f, n_scale >= 0 ? 1 + std::max<int64_t>(Tn, 1) : 0);  // [0] = clusterStats, then typeSetStats rows
+    // a16: one janitor pass over scaleCopiesCandidates (oldest first): params, entries, instanceSetStats()
+    auto n_sd_v = rd<int64_t>(f, 1);
+    const int64_t n_sd = n_sd_v[0];
+    auto dparams = rd<mmp_scaledown_params>(f, n_sd >= 0 ? 1 : 0);
+    auto dentries = rd<mmp_cache_entry>(f, n_sd > 0 ? n_sd : 0);
+    auto dstats = rd<StatsRow>(f, n_sd >= 0 ? 1 : 0);
     fclose(f);
 
     std::vector<String> ids(P);
@@ -722,6 +875,134 @@ int main(int argc, char **argv)
         gout[d * 2] = (int32_t)bits;
     }
     wr(o, gout);
+
+    // ---- a15: the scale-up plan of one rateTrackingTask run.  Per entry: action (0 none, 1 second copy, 2 scale-up), copies,
+    // timestamp passed to the load, earlierUseIteration / lastUsedIteration afterwards, lastHeavyTime touched; then getExcludeSet()
+    if (n_scale >= 0) {
+        const mmp_scaleup_params &sp = sparams[0];
+        clusterStats = ClusterStats{sstats[0].total_capacity, sstats[0].total_free, sstats[0].global_lru, sstats[0].instance_count, sstats[0].model_copy_count};
+        g_tstats.clear();
+        for (size_t i = 1; i < sstats.size(); i++)
+            g_tstats.push_back(ClusterStats{sstats[i].total_capacity, sstats[i].total_free, sstats[i].global_lru, sstats[i].instance_count, sstats[i].model_copy_count});
+        instanceId = (sp.self_pod >= 0 && sp.self_pod < P) ? ids[sp.self_pod] : String("(this instance is not in the table)");
+        g_now = sp.now;
+        lastCheckTime = sp.last_check_time;
+        RATE_CHECK_INTERVAL_MS = sp.rate_check_interval_ms;
+        iterationCounter = sp.iteration_counter;
+        secondCopyMaxAgeIters = sp.second_copy_max_age_iters;
+        secondCopyMinAgeIters = sp.second_copy_min_age_iters;
+        secondCopyLruThresholdMillis = (int)sp.second_copy_lru_threshold_ms;
+        scaleUpRpmThreshold = sp.scale_up_rpm_threshold;
+        invokeCounter.g_v = sp.our_rpm;
+        g_assume_completed = sp.assume_completed_ms;
+        excludeThisInstance = ArrayList_new();
+        excludeThisInstance.add(instanceId);
+        g_used_since_last_run = Map<String, CacheEntry>::make();
+        g_registry_all.clear();
+        std::vector<CacheEntry> ces;
+        for (int64_t e = 0; e < n_scale; e++) {
+            const mmp_cache_entry &x = sentries[e];
+            CacheEntry ce;
+            ce.isnull = false;
+            ce.intervalCount = x.interval_count;
+            ce.weight = x.weight;
+            ce.earlierUseIteration = x.earlier_use_iteration;
+            ce.lastUsedIteration = x.last_used_iteration;
+            char key[32];
+            snprintf(key, sizeof key, "m%09lld", (long long)e);  // the map iterates in key order = the entries' order
+            int type = -1;
+            if (x.model >= 0 && x.model < M) {
+                const mmp_model_row &m = models[x.model];
+                type = (m.type < 0 || m.type >= Tn) ? 0 : m.type;
+                ModelRecord mr;
+                mr.type = String("t" + std::to_string(type));
+                for (int32_t k = 0; k < m.n_loaded + m.n_failed; k++) {
+                    const int32_t pod = ent_pod[m.ent_off + k];
+                    (k < m.n_loaded ? mr.instanceIds : mr.failed).put(ids[pod], Long(ent_time[m.ent_off + k]));
+                }
+                g_registry_all[key] = mr;
+            }
+            ce.modelInfo.serviceType = String("t" + std::to_string(type));
+            ce.modelInfo.t = ce.modelInfo.serviceType;
+            g_used_since_last_run.put(String(key), ce);
+            ces.push_back(ce);
+        }
+        g_async_loads.clear();
+        g_exclude_set_seen = Set<String>(null);
+        rateTrackingTask_run();
+        std::vector<int64_t> so(n_scale * 6, 0);
+        for (int64_t e = 0; e < n_scale; e++) {
+            so[e * 6 + 3] = (int)ces[e].earlierUseIteration;
+            so[e * 6 + 4] = (int)ces[e].lastUsedIteration;
+            so[e * 6 + 5] = *ces[e].heavy != 0;
+        }
+        for (auto &a : g_async_loads) {
+            const int64_t e = std::stoll(a.model.substr(1));
+            so[e * 6 + 0] = a.ts == sp.last_check_time && a.extra == 0 && a.exclude.size() == 1 ? 1 : 2;
+            so[e * 6 + 1] = a.extra + 1;
+            so[e * 6 + 2] = a.ts;
+        }
+        std::vector<uint8_t> ov(P, 0);
+        std::vector<int64_t> flag = {g_exclude_set_seen != null ? 1 : 0};  // was getExcludeSet() called at all (it is lazy, :5771)
+        if (g_exclude_set_seen != null)
+            for (auto &id : g_exclude_set_seen) ov[pod_of[id.str()]] = 1;
+        wr(o, so);
+        wr(o, flag);
+        wr(o, ov);
+    }
+
+    // ---- a16: which local copies the janitor removes (removeLocalModelCopyAsync calls), per candidate
+    if (n_sd >= 0) {
+        const mmp_scaledown_params &dp = dparams[0];
+        g_instance_set_stats = ClusterStats{dstats[0].total_capacity, dstats[0].total_free, dstats[0].global_lru, dstats[0].instance_count, dstats[0].model_copy_count};
+        instanceId = (dp.self_pod >= 0 && dp.self_pod < P) ? ids[dp.self_pod] : String("(this instance is not in the table)");
+        g_now = dp.now;
+        shuttingDown = dp.shutting_down != 0;
+        lastCheckTime = dp.last_check_time;
+        RATE_CHECK_INTERVAL_MS = dp.rate_check_interval_ms;
+        scaleUpRpmThreshold = dp.scale_up_rpm_threshold;
+        g_adjusted_capacity = dp.adjusted_cache_capacity;
+        g_pod_of = pod_of;
+        g_in_table.assign(P, 0);
+        g_table_rec.assign(P, InstanceRecord(null));
+        for (int64_t i = 0; i < P; i++) {
+            const mmp_pod_row &r = pods[i];
+            g_in_table[i] = !(r.flags & MMP_POD_TOMBSTONE);
+            if (g_in_table[i])
+                g_table_rec[i] = InstanceRecord(r.lru_time, r.capacity, r.used, r.version, r.count, r.loading_threads, r.loading_in_progress, r.rpm,
+                                                (r.flags & MMP_POD_SHUTTING_DOWN) != 0);
+        }
+        g_scale_candidates.clear();
+        g_removed_local.clear();
+        for (int64_t e = 0; e < n_sd; e++) {
+            const mmp_cache_entry &x = dentries[e];
+            if (x.model < 0 || x.model >= M) continue;  // no ModelRecord: the janitor never lists it (MM.java:6076-6090)
+            const mmp_model_row &m = models[x.model];
+            ModelRecord mr;
+            mr.type = String("t0");
+            mr.lastUnloadTime = x.last_unload_time;
+            for (int32_t k = 0; k < m.n_loaded + m.n_failed; k++) {
+                const int32_t pod = ent_pod[m.ent_off + k];
+                (k < m.n_loaded ? mr.instanceIds : mr.failed).put(ids[pod], Long(ent_time[m.ent_off + k]));
+            }
+            CacheEntry ce;
+            ce.isnull = false;
+            ce.intervalCount = x.interval_count;
+            ce.weight = x.weight;
+            ce.lastHeavyTimeIn = x.last_heavy_time;
+            char key[32];
+            snprintf(key, sizeof key, "m%09lld", (long long)e);
+            ObjectArr3 arr;
+            (*arr.p)[0].s = String(key);
+            (*arr.p)[1].mr = mr;
+            (*arr.p)[2].ce = ce;
+            g_scale_candidates.emplace_back(arr, Long(x.last_used));
+        }
+        janitor_scaledown(dp.now);
+        std::vector<uint8_t> removed(n_sd, 0);
+        for (auto &id : g_removed_local) removed[std::stoll(id.substr(1))] = 1;
+        wr(o, removed);
+    }
     fclose(o);
     return 0;
 }

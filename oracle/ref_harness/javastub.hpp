@@ -85,6 +85,9 @@ static const struct { long convert(long n, TimeUnitT u) const { return n * (long
 static const struct {
     int max(int a, int b) const { return a > b ? a : b; }
     long max(long a, long b) const { return a > b ? a : b; }
+    double max(double a, double b) const { return a > b ? a : b; }
+    int min(int a, int b) const { return a < b ? a : b; }
+    long min(long a, long b) const { return a < b ? a : b; }
     int abs(int a) const { return a < 0 ? (int)(0u - (unsigned)a) : a; }            // Math.abs(MIN_VALUE) == MIN_VALUE
     long abs(long a) const { return a < 0 ? (long)(0ul - (unsigned long)a) : a; }
 } Math;
@@ -160,13 +163,21 @@ public:
     }
 };
 extern std::vector<std::shared_ptr<void>> g_lists_created;  // in creation order, per call (harness.cc clears it)
-struct ArrayList_new {  // `new ArrayList<>(n)`: the element type comes from the declaration it initialises
+struct ArrayList_new {  // `new ArrayList<>(n)` / `new ArrayList<>(collection)`: the element type comes from the declaration it initialises
+    std::vector<String> init;
     ArrayList_new(int = 0) {}
+    template <class C, class = decltype(std::declval<C>().begin())> ArrayList_new(const C &c)
+    {
+        for (auto &x : c) init.push_back(x);
+    }
     template <class T> operator List<T>() const
     {
         auto r = std::make_shared<typename List<T>::Rep>();
         g_lists_created.push_back(r);
-        return List<T>(r);
+        List<T> l(r);
+        if constexpr (std::is_same<T, String>::value)
+            for (auto &x : init) l.add(x);
+        return l;
     }
 };
 // org.eclipse.collections MutableIntList / IntArrayList
@@ -180,19 +191,35 @@ public:
 };
 static inline MutableIntList IntArrayList_new(int = 0) { return MutableIntList(); }
 
-// java.util.Set<String> / Collection<String> (nullable)
+// java.util.Set<String> / Collection<String> (nullable).  Ordered by the string (a TreeSet; where the Java has a HashSet
+// nothing that decides anything depends on its iteration order), iterable with a range-for
 template <class T> class Set {
 public:
-    std::shared_ptr<std::unordered_set<String, String::Hash, String::Eq>> p;
+    typedef std::set<String, String::Less> Rep;
+    std::shared_ptr<Rep> p;
     Set() {}
     Set(std::nullptr_t) {}
-    static Set make() { Set s; s.p = std::make_shared<std::unordered_set<String, String::Hash, String::Eq>>(); return s; }
+    static Set make() { Set s; s.p = std::make_shared<Rep>(); return s; }
     bool operator==(std::nullptr_t) const { return !p; }
     bool operator!=(std::nullptr_t) const { return (bool)p; }
     boolean contains(const T &t) const { return p->count(t) != 0; }
     boolean isEmpty() const { return p->empty(); }
     boolean add(const T &t) const { return p->insert(t).second; }
+    int size() const { return (int)p->size(); }
+    Rep::const_iterator begin() const { return p->begin(); }
+    Rep::const_iterator end() const { return p->end(); }
 };
+static inline Set<String> TreeSet_new() { return Set<String>::make(); }
+// com.google.common.collect.Sets.union (a view in Guava; a copy here: nothing mutates the operands afterwards)
+static const struct {
+    Set<String> union_(const Set<String> &a, const Set<String> &b) const
+    {
+        Set<String> u = Set<String>::make();
+        for (auto &x : a) u.add(x);
+        for (auto &x : b) u.add(x);
+        return u;
+    }
+} Sets;
 template <class T> using Collection = Set<T>;
 // java.util.Map<String, V>: key-ordered (the one map whose iteration order matters, ModelRecord.instanceIds, is a TreeMap)
 template <class K, class V> class Map {
@@ -214,10 +241,10 @@ public:
         for (auto &kv : *p) es.emplace_back(kv.first, kv.second);
         return es;
     }
-    std::vector<K> keySet() const
+    Set<K> keySet() const
     {
-        std::vector<K> ks;
-        for (auto &kv : *p) ks.push_back(kv.first);
+        Set<K> ks = Set<K>::make();
+        for (auto &kv : *p) ks.add(kv.first);
         return ks;
     }
     std::vector<V> values() const
@@ -229,6 +256,7 @@ public:
 };
 // java.util.Collections.min over boxed longs
 struct Collections {
+    static Set<String> emptySet() { return Set<String>::make(); }
     static long min(const std::vector<Long> &v)
     {
         long m = v.at(0);

@@ -18,11 +18,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from tests import ref_fleets as rf  # noqa: E402
 
-HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
-OUT = os.path.join(ROOT, "tests", "golden", "ref_getnext.npz")
+# MMP_REF_HARNESS / MMP_REF_OUT: run another build of the harness (tools/ref_coverage.sh: the --coverage build) without
+# touching the committed vectors
+HARNESS = os.environ.get("MMP_REF_HARNESS") or os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+OUT = os.environ.get("MMP_REF_OUT") or os.path.join(ROOT, "tests", "golden", "ref_getnext.npz")
 
 
-def run(blob: bytes, n_place: int, n_serve: int, n_gate: int = 0):
+def run(blob: bytes, n_place: int, n_serve: int, n_gate: int = 0, n_scale: int = -1, n_pods: int = 0, n_sd: int = -1):
     with tempfile.TemporaryDirectory() as td:
         fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
         open(fin, "wb").write(blob)
@@ -37,12 +39,26 @@ def run(blob: bytes, n_place: int, n_serve: int, n_gate: int = 0):
     serve = np.frombuffer(raw, "<i8", 2 * n_serve, off).reshape(n_serve, 2).copy()
     off += 16 * n_serve
     gate = np.frombuffer(raw, "<i4", 2 * n_gate, off).reshape(n_gate, 2).copy()
-    assert off + 8 * n_gate == len(raw)
-    return order, place, serve, gate
+    off += 8 * n_gate
+    if n_sd >= 0:
+        removed = np.frombuffer(raw, "u1", n_sd, off).copy()
+        assert off + n_sd == len(raw)
+        return removed
+    if n_scale < 0:
+        assert off == len(raw)
+        return order, place, serve, gate
+    scale = np.frombuffer(raw, "<i8", 6 * n_scale, off).reshape(n_scale, 6).copy()
+    off += 48 * n_scale
+    called = int(np.frombuffer(raw, "<i8", 1, off)[0])
+    off += 8
+    ov = np.frombuffer(raw, "u1", n_pods, off).copy()
+    assert off + n_pods == len(raw)
+    return order, place, serve, gate, scale, called, ov
 
 
 def main():
-    subprocess.run(["bash", os.path.join(ROOT, "oracle", "ref_harness", "build.sh")], check=True)
+    if not os.environ.get("MMP_REF_HARNESS"):
+        subprocess.run(["bash", os.path.join(ROOT, "oracle", "ref_harness", "build.sh")], check=True)
     out = {}
     names = []
     for name, fleet, ids, reqs, extra in rf.place_cases():
@@ -72,6 +88,25 @@ def main():
         bits = gate[:, 0].astype(np.uint32)
         print(f"{name}: {len(reqs)} guard evaluations; fired: " + " ".join(f"{b}:{int(((bits >> k) & 1).sum())}" for k, b in enumerate(
             ["goLocal", "failures", "locations", "notAllowed", "churn", "earlyReject", "reload", "publish"])))
+    for name, fleet, ids, entries, sp in rf.scaleup_cases():
+        cstats = np.zeros(1, dtype=ob.ORC_STATS)
+        cstats[0] = ob.OracleFleet(fleet).stats()  # clusterStats / typeSetStats: INPUTS of the planner (rows a5 / a18)
+        blob = rf.input_blob(fleet, ids, scaleup=(entries, sp, cstats, np.ascontiguousarray(ob.type_set_stats(fleet))))
+        *_, scale, called, ov = run(blob, 0, 0, 0, len(entries), fleet.n_pods)
+        out[f"{name}/scale"], out[f"{name}/overloaded"] = scale, ov
+        out[f"{name}/exclude_set_built"] = np.array([called])
+        out[f"{name}/digest"] = np.frombuffer(rf.digest(blob).encode(), np.uint8)
+        names.append(name)
+        print(f"{name}: {len(entries)} cache entries: {int((scale[:, 0] == 1).sum())} second copies, {int((scale[:, 0] == 2).sum())} scale-ups, "
+              f"{int(scale[:, 5].sum())} heavy, {int(ov.sum())} overloaded instances")
+    for name, fleet, ids, entries, dp in rf.scaledown_cases():
+        istats = ob.instance_set_stats(fleet, int(dp["self_pod"][0]))  # instanceSetStats(): an INPUT (rows a5 / a18)
+        blob = rf.input_blob(fleet, ids, scaledown=(entries, dp, istats))
+        removed = run(blob, 0, 0, 0, -1, 0, len(entries))
+        out[f"{name}/removed"] = removed
+        out[f"{name}/digest"] = np.frombuffer(rf.digest(blob).encode(), np.uint8)
+        names.append(name)
+        print(f"{name}: {len(entries)} candidates: {int(removed.sum())} local copies removed")
     out["names"] = np.array(names)
     out["manifest"] = np.array(open(os.path.join(ROOT, "oracle", "_ref", "gen", "MANIFEST.txt")).read())
     np.savez_compressed(OUT, **out)

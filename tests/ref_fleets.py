@@ -189,7 +189,86 @@ def gate_cases():
         yield f"gates_{seed}", fleet, ids, r, excl_pod, excl_time, explicit, 450_000
 
 
-def input_blob(fleet, ids, reqs=None, extra=None, serve=None, gates=None) -> bytes:
+def _rebalance_fleet(seed, pods, models, used):
+    """Fleet where many models have 1-4 copies, often including self_pod = 0 (as tests/test_rebalance_gpu.py builds it)."""
+    rng = np.random.default_rng(8000 + seed)
+    fleet = wl.fuzz_fleet(seed + 70, pods=pods, models=models)
+    now = fleet.now
+    p = fleet.pods
+    p["flags"] = np.where(rng.random(pods) < 0.05, 1, 2)
+    p["flags"][0] = 2
+    p["used"] = (p["capacity"] * np.clip(rng.normal(used, 0.02, pods), 0, 1.0)).astype(np.int64)
+    p["rpm"] = rng.choice([0, 100, 3000, 9000, 50_000], pods)
+    m = fleet.models
+    k = rng.choice([0, 1, 1, 2, 2, 3, 4], models).clip(0, pods)
+    f = rng.choice([0, 0, 0, 1], models).clip(0, max(pods - 4, 0))
+    m["n_loaded"], m["n_failed"] = k, f
+    off = np.zeros(models + 1, np.int64)
+    np.cumsum(k + f, out=off[1:])
+    m["ent_off"] = off[:-1]
+    ent = np.zeros(int(off[-1]), np.int32)
+    for i in range(models):
+        c = rng.choice(pods, size=k[i] + f[i], replace=False)
+        if k[i] and rng.random() < 0.7 and 0 not in c:
+            c[0] = 0
+        ent[off[i]: off[i + 1]] = c
+    fleet.ent_pod = ent
+    fleet.ent_time = (now - rng.choice([1_000, 25_000, 2_000_000, 90_000_000], len(ent))).astype(np.int64)
+    return fleet, rng
+
+
+def _local_entries(fleet, rng, n):
+    e = np.zeros(n, dtype=_lib.CACHE_ENTRY)
+    e["model"] = rng.integers(0, fleet.n_models, n)
+    e["model"] = np.where(rng.random(n) < 0.03, -1, e["model"])
+    e["weight"] = rng.choice([1, 2560, 6400, 60_000], n)
+    e["last_used"] = np.where(rng.random(n) < 0.05, 0, fleet.now - rng.choice([500, 30_000, 4_000_000, 50_000_000], n))
+    e["interval_count"] = rng.choice([0, 1, 50, 400, 5000], n)
+    e["last_heavy_time"] = np.where(rng.random(n) < 0.4, 0, fleet.now - rng.choice([1_000, 700_000, 30_000_000], n))
+    e["last_unload_time"] = np.where(rng.random(n) < 0.6, 0, fleet.now - rng.choice([10_000, 100_000], n))
+    e["earlier_use_iteration"] = rng.integers(0, 120, n)
+    e["last_used_iteration"] = e["earlier_use_iteration"] + rng.integers(0, 60, n)
+    e["flags"] = (rng.random(n) < 0.05).astype(np.uint32)
+    return e
+
+
+def scaleup_cases():
+    """(name, fleet, ids, entries, params): runs of the rate-tracking task (rateTrackingTask, MM.java:5636-5832) over the local
+    cache entries of instance 0 — thresholds and clocks that reach the second-copy rule, the scale-up rule with and without
+    overloaded instances, and the early returns."""
+    for seed, pods, used in ((0, 12, 0.5), (1, 200, 0.97), (2, 200, 0.2), (3, 1, 0.5)):
+        fleet, rng = _rebalance_fleet(seed, pods, 600, used)
+        ids = string_ids(fleet, 80 + seed)
+        now = fleet.now
+        entries = _local_entries(fleet, rng, 800)
+        for j, (thr, our_rpm, last_check) in enumerate(((2000, 100, now - 10_000), (100, 50_000, now - 9_000), (0, 0, now - 10_000),
+                                                        (2000, 0, now - 1_000))):
+            sp = np.zeros(1, dtype=_lib.SCALEUP_PARAMS)
+            sp["self_pod"], sp["iteration_counter"] = 0, 130
+            sp["second_copy_max_age_iters"], sp["second_copy_min_age_iters"] = 240, 42
+            sp["scale_up_rpm_threshold"], sp["our_rpm"] = thr, our_rpm
+            sp["now"], sp["last_check_time"], sp["rate_check_interval_ms"] = now, last_check, 10_000
+            sp["second_copy_lru_threshold_ms"], sp["assume_completed_ms"] = 72_000_000, 30_000
+            yield f"scaleup_{seed}_{j}", fleet, ids, entries, sp
+
+
+def scaledown_cases():
+    """(name, fleet, ids, entries, params): janitor passes over scaleCopiesCandidates (MM.java:6110-6140 -> removeModelCopies
+    :6197-6310 -> removeSecondModelCopy :6314-6335) for the local cache entries of instance 0."""
+    for seed, pods, used in ((0, 12, 0.5), (1, 200, 0.97), (2, 200, 0.2), (3, 1, 0.5), (4, 300, 0.99)):
+        fleet, rng = _rebalance_fleet(seed, pods, 600, used)
+        ids = string_ids(fleet, 80 + seed)
+        now = fleet.now
+        entries = _local_entries(fleet, rng, 800)
+        for j, (thr, cap, sd) in enumerate(((2000, 200_000, 0), (2000, 1_000, 0), (10, 10_000_000, 0), (2000, 200_000, 1))):
+            dp = np.zeros(1, dtype=_lib.SCALEDOWN_PARAMS)
+            dp["self_pod"], dp["shutting_down"], dp["now"] = 0, sd, now
+            dp["last_check_time"], dp["rate_check_interval_ms"] = now - 7_000, 10_000
+            dp["adjusted_cache_capacity"], dp["scale_up_rpm_threshold"] = cap, thr
+            yield f"scaledown_{seed}_{j}", fleet, ids, entries, dp
+
+
+def input_blob(fleet, ids, reqs=None, extra=None, serve=None, gates=None, scaleup=None, scaledown=None) -> bytes:
     """The harness' input file (layout: oracle/ref_harness/harness.cc main())."""
     P, M = fleet.n_pods, fleet.n_models
     T = int(fleet.n_types)
@@ -225,6 +304,20 @@ def input_blob(fleet, ids, reqs=None, extra=None, serve=None, gates=None) -> byt
     if len(greqs):
         assert tstats.dtype.itemsize == 32 and len(tstats) == max(T, 1)
         parts += [struct.pack("<q", int(g_expiry)), np.ascontiguousarray(tstats).tobytes()]
+    if scaleup is None:
+        parts += [struct.pack("<q", -1)]
+    else:
+        entries, sp, cstats, ststats = scaleup  # cstats: the cluster's stats (1 ORC_STATS row); ststats: typeSetStats per type row
+        assert cstats.dtype.itemsize == 32 and len(cstats) == 1 and len(ststats) == max(T, 1)
+        parts += [struct.pack("<q", len(entries)), np.ascontiguousarray(sp).tobytes(), np.ascontiguousarray(entries).tobytes(),
+                  np.ascontiguousarray(cstats).tobytes(), np.ascontiguousarray(ststats).tobytes()]
+    if scaledown is None:
+        parts += [struct.pack("<q", -1)]
+    else:
+        entries, dp, istats = scaledown  # istats: instanceSetStats() (1 ORC_STATS row)
+        assert istats.dtype.itemsize == 32 and len(istats) == 1
+        parts += [struct.pack("<q", len(entries)), np.ascontiguousarray(dp).tobytes(), np.ascontiguousarray(entries).tobytes(),
+                  np.ascontiguousarray(istats).tobytes()]
     return b"".join(parts)
 
 

@@ -177,3 +177,46 @@ def test_request_guards_equal_the_reference_text(ref):
         assert rf.digest(rf.input_blob(fleet, ids, gates=(r, xp, xt, expl, expiry, tstats))) == bytes(ref[f"{name}/digest"]).decode(), name
         got = oracle_gates(fleet, r, xp, xt, expl, expiry)
         check_gates(name, got[:, 0], got[:, 1], ref[f"{name}/gate"])
+
+
+def check_scaleup(name, out, ov, ref_scale, ref_ov):
+    for k, f in enumerate(("action", "copies", "timestamp", "new_i1", "new_i2", "heavy")):
+        got = np.asarray(out[f]).astype(np.int64)
+        bad = np.nonzero(got != ref_scale[:, k])[0]
+        assert len(bad) == 0, (name, f, len(bad), [(int(i), int(got[i]), int(ref_scale[i, k])) for i in bad[:5]])
+    # getExcludeSet() (:5835) fills a LOCAL of the task: it is observable only through the exclude lists of the scale-ups it
+    # feeds (:5787-5805), so it is compared when the run scaled something up (with a zero threshold the reference builds the set
+    # and then dies on rpm / scaleUpRpms, :5792, caught at :5807 — no load, nothing to observe)
+    if np.any(ref_scale[:, 0] == 2):
+        assert np.array_equal(np.asarray(ov).astype(np.uint8), ref_ov), name
+
+
+def test_scaleup_plan_equals_the_reference_text(ref):
+    """rateTrackingTask (MM.java:5641-5806: the second-copy rule, the scale-up rule), getExcludeSet (:5836-5855), loadedSince
+    (:5861-5870): per cache entry the load the reference's own loop body triggers (which, how many copies, with what timestamp),
+    the usage-slice markers it leaves, lastHeavyTime touched; and the overloaded-instance set."""
+    seen = set()
+    for name, fleet, ids, entries, sp in rf.scaleup_cases():
+        cstats = np.zeros(1, dtype=ob.ORC_STATS)
+        cstats[0] = OracleFleet(fleet).stats()
+        blob = rf.input_blob(fleet, ids, scaleup=(entries, sp, cstats, np.ascontiguousarray(ob.type_set_stats(fleet))))
+        assert rf.digest(blob) == bytes(ref[f"{name}/digest"]).decode(), name
+        out, ov, _ = ob.scaleup_plan(fleet, entries, sp.view(ob.ORC_SCALEUP_PARAMS))
+        check_scaleup(name, out, ov, ref[f"{name}/scale"], ref[f"{name}/overloaded"])
+        seen |= set(np.unique(ref[f"{name}/scale"][:, 0]))
+    assert seen >= {0, 1, 2}
+
+
+def test_scaledown_plan_equals_the_reference_text(ref):
+    """The janitor's pass over scaleCopiesCandidates (MM.java:6110-6140), removeModelCopies (:6197-6310) and
+    removeSecondModelCopy (:6314-6335): per candidate, whether the reference's own text removes the LOCAL copy."""
+    total = 0
+    for name, fleet, ids, entries, dp in rf.scaledown_cases():
+        istats = ob.instance_set_stats(fleet, int(dp["self_pod"][0]))
+        blob = rf.input_blob(fleet, ids, scaledown=(entries, dp, istats))
+        assert rf.digest(blob) == bytes(ref[f"{name}/digest"]).decode(), name
+        rem = ob.scaledown_plan(fleet, entries, dp.view(ob.ORC_SCALEDOWN_PARAMS))
+        bad = np.flatnonzero(rem != ref[f"{name}/removed"])
+        assert bad.size == 0, (name, bad[:8], entries[bad[:8]])
+        total += int(rem.sum())
+    assert total >= 40

@@ -59,3 +59,27 @@ def test_hip_request_guards_equal_the_reference_text(ref):
         finally:
             s.close()
         check_gates(name, got["bits"], got["initial_size"], ref[f"{name}/gate"])
+
+
+def test_hip_scaleup_plan_equals_the_reference_text(ref):
+    from tests.test_ref_vectors import check_scaleup
+    for name, fleet, ids, entries, sp in rf.scaleup_cases():
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            s.load_fleet(fleet)
+            out, ov, _ = s.scaleup_plan(entries, sp)
+        finally:
+            s.close()
+        check_scaleup(name, out, ov, ref[f"{name}/scale"], ref[f"{name}/overloaded"])
+
+
+def test_hip_scaledown_plan_equals_the_reference_text(ref):
+    for name, fleet, ids, entries, dp in rf.scaledown_cases():
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            s.load_fleet(fleet)
+            rem = s.scaledown_plan(entries, dp)
+        finally:
+            s.close()
+        bad = np.flatnonzero(rem != ref[f"{name}/removed"])
+        assert bad.size == 0, (name, bad[:8], entries[bad[:8]])
