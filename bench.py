@@ -132,7 +132,7 @@ def make_step_batch(fleet, seeds):
     return np.concatenate(parts), np.concatenate(ex_parts), len(ex_parts[0])
 
 
-def measured_traffic(workload: str, decisions_per_launch: int):
+def measured_traffic(workload: str, decisions_per_launch: int, kernel: str = "place_batch_kernel", tag: str = ""):
     """HBM bytes per place_batch_kernel launch from the committed rocprofv3 PMC passes of this same
     command (profiles/rNN/pmc_place_batch_<workload>*.json, written by tools/pmc_summary.py), and where the figure comes
     from.  A summary counts only if (a) it was taken AT THIS LAUNCH SIZE (its write bytes are the 16-byte result rows of
@@ -143,12 +143,17 @@ def measured_traffic(workload: str, decisions_per_launch: int):
     from kernel_hash import kernel_source_hash
     now_hash = kernel_source_hash()
     best, prov = None, f"no PMC summary for {workload} at {decisions_per_launch} decisions per launch under profiles/"
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_place_batch_{workload}*.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_place_batch_{workload}{tag}*.json"))):
         try:
             j = json.load(open(f))
         except Exception:
             continue
-        if abs(j.get("write_bytes", 0) / 16 - decisions_per_launch) > 0.02 * decisions_per_launch:
+        if j.get("kernel", kernel) != kernel:
+            continue
+        if tag:  # a tagged summary names its launch size itself (its writes are not only result rows)
+            if not f.endswith(f"{tag}_{decisions_per_launch // 1000}k.json"):
+                continue
+        elif abs(j.get("write_bytes", 0) / 16 - decisions_per_launch) > 0.02 * decisions_per_launch:
             continue
         rel = os.path.relpath(f, ROOT)
         if j.get("kernel_source_hash") != now_hash:
@@ -440,10 +445,21 @@ def full_cluster_leg(workload: str, device: int, dev):
         got = np.frombuffer(d_outs.cpu().numpy().tobytes(), dtype=PLACE_OUT)
     finally:
         s.close()
-    want = OracleFleet(fleet).place(reqs, extra, fleet.now, threads=os.cpu_count() or 1)
+    want = OracleFleet(fleet).place(reqs, extra, fleet.now, threads=usable_cpus())
     parity = bool(all(np.array_equal(got[f], want[f]) for f in ("chosen", "best", "n_candidates", "hash")))
+    # roofline of place_batch_long_kernel on this fleet.  What a decision MUST move is what it moves on any fleet (request, model
+    # row, its lists, result): the shortlist's per-type prefix tables (candidate count, hash sum, rpm-rule survivors over the
+    # shortlist order; built at commit) are shared by all decisions and L2-resident.  The walk they replace would have read a
+    # 16 B record per shortlisted instance (MM.java:4880-4935): kept beside it as `walk_equivalent_bytes`, not as traffic.
+    comp = kernel_bytes(fleet, reqs)
+    traffic, prov = measured_traffic(workload, n, "place_batch_long_kernel", "_full_cluster")
+    use = traffic or comp
+    roof = {"bound": "hbm", "kernel": "place_batch_long_kernel", "achieved": use / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
+            "frac": use / dt / 8e12, "traffic": traffic, "traffic_provenance": prov, "bytes_per_launch": use,
+            "compulsory_bytes_per_launch": comp, "walk_equivalent_bytes": int(got["n_candidates"].astype(np.int64).sum()) * 16,
+            "note": "launch time here = wall time of 20 back-to-back launches on one stream / 20"}
     return {"workload": f"{workload} with every instance full, lruTimes within +-4 % of 10 h", "value": n / dt, "unit": "decisions/s",
-            "ms_per_step": dt * 1e3, "mean_shortlist": float(got["n_candidates"].mean()), "parity_vs_oracle": parity}
+            "ms_per_step": dt * 1e3, "mean_shortlist": float(got["n_candidates"].mean()), "parity_vs_oracle": parity, "roofline": roof}
 
 
 def _single_prober():
@@ -1170,6 +1186,9 @@ def main():
         if not args.kernel_only:
             try:
                 line["churn"] = churn_leg(fleet, solver)
+                sd = line["churn"].get("single_decisions_during_churn", {})
+                if "p99_us" in sd:  # BASELINE.md's second criterion: decision latency while the mesh churns
+                    line["p50_decision_latency_us_under_churn"], line["p99_decision_latency_us_under_churn"] = sd["p50_us"], sd["p99_us"]
             except Exception as e:
                 line["churn"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.kernel_only:

@@ -465,6 +465,30 @@ def test_c4_1m_x_50k_sample():
     _check_fleet(fleet, sub, extra)
 
 
+def test_c4_all_1m_decisions_against_the_lean_port():
+    """Every one of C4's 1M decisions: chosen / best / n_candidates against orc_place_lean (the checker's getNext body
+    without its per-call audit machinery; tests/test_lean_port.py holds it to the checker).  The audit hash of the
+    shortlist is compared on the 250k sample above."""
+    import os
+    fleet = wl.make_fleet("C4")
+    reqs, extra = wl.make_requests(fleet, 14)
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        got = s.place(reqs, extra, fleet.now)
+    finally:
+        s.close()
+    pool = OracleFleet(fleet).lean_pool(max(1, min(16, len(os.sched_getaffinity(0)))))
+    try:
+        want = pool(reqs, extra, fleet.now)
+    finally:
+        pool.close()
+    assert len(got) == 1_000_000
+    for f in ("chosen", "best", "n_candidates"):
+        bad = np.flatnonzero(got[f] != want[f])
+        assert bad.size == 0, (f, bad[:8], got[bad[:8]], want[bad[:8]])
+
+
 def test_c4_full_size_relabelling_and_batch_split():
     """All 1M decisions of C4 through two size-independent properties (the oracle takes a sample above):
     * batch split: deciding the batch in seven uneven pieces gives the same rows as deciding it at once;
