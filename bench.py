@@ -342,15 +342,14 @@ def pod_axis_lib_leg(workload: str, rank: int, world: int, dev, steps: int, warm
             from oracle.bind import OracleFleet
             want = OracleFleet(fleet).place(reqs, extra, fleet.now, threads=os.cpu_count() or 1)
             parity = bool(all(np.array_equal(got[f], want[f]) for f in ("chosen", "best", "n_candidates", "hash")))
-            cap = min(n, max(1024, n // 16))
             slots = sum(s.shard_xchg_slots(ph) for ph in range(1, 7))
             out = {"workload": f"{workload}: {fleet.n_models} models x {fleet.n_pods} pods", "n_shards": world,
                    "value": n * steps / elapsed, "unit": "decisions/s", "ms_per_step": elapsed / steps * 1e3,
                    "decisions_per_step": n, "scaling": "strong (pod table split, batch replicated)",
-                   "collective": "inside libmmplace on its own stream: ncclAllReduce(MIN, 2 int64 per decision) + 5 x MIN + 1 x SUM over a "
-                                 f"{cap}-row rest sub-batch whose row count stays on the device (RCCL bound at run time)",
-                   "took_the_six_phase_protocol": int(n_rest), "rest_capacity": cap,
-                   "allreduce_bytes_per_step": 8 * s.shard_fast_slots() * n + 8 * slots * cap,
+                   "collective": "inside libmmplace on its own stream: ncclAllReduce(MIN, 2 int64 per decision), then 5 x MIN + 1 x SUM over "
+                                 "the undecided rest only when the (host-read) count of it is not zero (RCCL bound at run time)",
+                   "took_the_six_phase_protocol": int(n_rest),
+                   "allreduce_bytes_per_step": 8 * s.shard_fast_slots() * n + 8 * slots * int(n_rest),
                    "sharded_commit_ms": commit_ms, "parity_vs_oracle": parity}
         s.shard_group_destroy()
         return out

@@ -594,8 +594,9 @@ int mmp_shard_place_phase_dev(mmp_ctx *ctx, int32_t phase, const void *d_reqs, i
  *
  *   mmp_shard_place_fast_dev(ctx, d_reqs, n, d_extra, now, d_xf, stream)        -> all-reduce MIN d_xf
  *   mmp_shard_place_fast_finish_dev(..., &n_rest, &d_rest_reqs, &d_rest_outs)      writes the decided rows of
- *        d_outs, compacts the undecided requests (same order on every shard) into library-owned device
- *        buffers and synchronises `stream` to return their number
+ *        d_outs, counts the undecided requests (the count reaches the host in pinned memory; `stream` is
+ *        synchronised) and, only when there are any, compacts them (same order on every shard) into
+ *        library-owned device buffers
  *   if n_rest: phases 1..7 of mmp_shard_place_phase_dev on (d_rest_reqs, n_rest, d_rest_outs), then
  *        mmp_shard_place_fast_scatter_dev(ctx, n_rest, d_outs, stream)             rows back into d_outs
  *
@@ -621,11 +622,12 @@ int mmp_shard_place_fast_scatter_dev(mmp_ctx *ctx, int32_t n_rest, void *d_outs,
  *                mmp_shard_commit(ctx)                       collective: rank slice -> ncclAllReduce(SUM) -> scatter
  *                mmp_shard_place_batch(ctx, reqs, n, ...)    collective: every rank passes the SAME batch and gets
  *                                                            the same result rows (bit-identical to mmp_place_batch)
- * A batch is: place_shard_fast_kernel -> ncclAllReduce(MIN, 2 int64 per decision) -> decided rows + compaction of
- * the undecided rest -> the six exchange phases (5 x MIN, 1 x SUM) over a sub-batch of fixed capacity
- * max(1024, n / 16) whose real row count stays on the device (no host round trip between the kernels) -> scatter;
- * only if more decisions than that capacity need the six phases are they run again at their exact size
- * (*n_rest_out = how many took the six phases).  unique_id may be NULL for world == 1: a group of one shard
+ * A batch is: place_shard_fast_kernel (the slice's head windows + resolved registry rows, as the unsharded kernel) ->
+ * ncclAllReduce(MIN, 2 int64 per decision) -> decided rows + the COUNT of the undecided rest, which the host reads
+ * (identical on every shard: the words are the reduced ones) -> only when it is not zero: compaction, the six exchange
+ * phases (5 x MIN, 1 x SUM) over exactly those rows, scatter (*n_rest_out = how many took the six phases).  (Round 2
+ * kept the count on the device and always ran the six phases over a fixed-capacity sub-batch: seven launches and six
+ * collectives per batch that mostly found no rows.)  unique_id may be NULL for world == 1: a group of one shard
  * without a communicator (no RCCL needed). */
 #define MMP_SHARD_UNIQUE_ID_BYTES 128
 int mmp_shard_unique_id(void *id_out);

@@ -202,6 +202,9 @@ struct mmp_ctx {
     int32_t rank_mode = 0;  // MMP_RANK_MODE: 0 auto (sort from kRankSortMinPods pods), 1 all-pairs, 2 sort whenever legal (tests)
     Snap sview{};  // the lane path's view of this shard's slice (place_shard_fast_kernel)
     DevBuf f_flags, f_offs, f_idx, f_reqs, f_outs, f_scan_tmp;  // speculative form: the compacted rest of a batch
+    DevBuf f_cnt;                  // finished workgroups << 32 | flagged decisions of the finish launch in flight (zero between launches)
+    uint64_t *f_done = nullptr;    // pinned: seq << 32 | flagged decisions, stored by the finish kernel's last workgroup
+    uint32_t f_seq = 0;
     bool rank_pending = false;
 
     // RCCL group of the pod-axis shards (mmp_shard_group_init): collectives run on c->stream, inside the boundary
@@ -370,7 +373,7 @@ void note_caller_stream(mmp_ctx *c, hipStream_t st)
 int rebuild_resolved(mmp_ctx *c, SnapSide &sd, const Snap &snap, bool committed)
 {
     sd.rmodels_ok = false;
-    if (!committed || c->n_shards > 0 || c->n_models <= 0) return MMP_OK;
+    if (!committed || c->n_models <= 0) return MMP_OK;  // (shard contexts: `snap` carries the whole table's pos_of — resolved positions are GLOBAL)
     HIP_TRY(c, sd.rmodels.ensure((size_t)c->n_models * sizeof(ResolvedModel)));
     hipLaunchKernelGGL(resolve_models_kernel, dim3(div_up(c->n_models, 256)), dim3(256), 0, c->stream, snap,
                        c->models.as<mmp_model_row>(), c->ent_pod.as<int32_t>(), c->n_models,
@@ -461,6 +464,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
         const int want = (int)(c->lds_limit - kPlaceStaticLds);
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_long4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_flag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_single_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         c->lds_granted.store((size_t)want, std::memory_order_release);
@@ -470,6 +474,8 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     else if (done_flag && n > kPlaceBlock)
         hipLaunchKernelGGL(place_batch_flag_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad,
                            done_blocks);
+    else if (c->snap_long && n >= kLongDenseFrom)
+        hipLaunchKernelGGL(place_batch_long4_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad);
     else if (c->snap_long)
         hipLaunchKernelGGL(place_batch_long_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad);
     else
@@ -566,6 +572,7 @@ void mmp_destroy(mmp_ctx *c)
     (void)hipSetDevice(c->cfg.device);
     resident_stop(c);
     if (c->res.stream) (void)hipStreamDestroy(c->res.stream);
+    if (c->f_done) (void)hipHostFree(c->f_done);
     if (c->res.slots) (void)hipHostFree(c->res.slots);
     if (c->res.ctl) (void)hipHostFree(c->res.ctl);
     if (c->res.answers) (void)hipHostFree(c->res.answers);
@@ -602,7 +609,7 @@ void mmp_destroy(mmp_ctx *c)
                       &c->r_tmp, &c->r_out_model, &c->r_out_lu, &c->k_cap, &c->k_wsize, &c->k_ubm, &c->k_ops, &c->k_order,
                       &c->k_opoff, &c->k_outs, &c->k_ev, &c->k_evoff, &c->idtab_hash, &c->idtab_val, &c->tytab_hash,
                       &c->tytab_val, &c->j_buf, &c->j_off, &c->j_rows, &c->j_aux, &c->j_status, &c->j_cnt, &c->j_offs, &c->j_tmp_pod,
-                      &c->j_tmp_time, &c->j_scan_tmp, &c->rk_rows, &c->rk_idx, &c->rk_tmp, &c->u_idx, &c->u_rows, &c->u_cnt, &c->u_offs, &c->u_tmp, &c->f_flags, &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp,
+                      &c->j_tmp_time, &c->j_scan_tmp, &c->rk_rows, &c->rk_idx, &c->rk_tmp, &c->u_idx, &c->u_rows, &c->u_cnt, &c->u_offs, &c->u_tmp, &c->f_flags, &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp, &c->f_cnt,
                       &c->ks[0].off, &c->ks[0].lu, &c->ks[0].wt,
                       &c->ks[0].key, &c->ks[0].n, &c->ks[1].off, &c->ks[1].lu, &c->ks[1].wt, &c->ks[1].key, &c->ks[1].n})
         b->release();
@@ -1046,7 +1053,7 @@ try {
     {
         std::lock_guard<std::shared_mutex> g(c->mu);
         HIP_TRY(c, quiesce_decisions(c));  // rows (and their resolved positions) are rewritten in place
-        const bool resolved = cur_side(c).rmodels_ok && c->committed && c->n_shards == 0;
+        const bool resolved = cur_side(c).rmodels_ok && c->committed;
         KT_BEGIN(c, st);
         hipLaunchKernelGGL(upsert_models_kernel, dim3(div_up(k, 256)), dim3(256), 0, st, c->snap, c->u_idx.as<int32_t>(),
                            c->u_rows.as<mmp_model_row>(), k, c->ent_pod.as<int32_t>(), c->models.as<mmp_model_row>(),
@@ -1997,7 +2004,6 @@ try {
     V.pos_base = w_lo * 64;
     V.w_base = w_lo;
     V.more_after = (w_lo + Wn) * 64 < P ? 1 : 0;
-    c->sview = V;
     Snap M{};  // what the non-placement entry points read in shard mode
     M.P = P;
     M.W = W;
@@ -2005,6 +2011,18 @@ try {
     M.any_rs = S.any_rs;
     M.min_space = min_space;
     M.pos_of = S.pos_of;
+    {
+        // the slice's per-type head windows (place_kernel.hpp: TypeWin, built over the VIEW) and the registry's resolved rows
+        // (global rank positions; resolve_req<true> translates them): what place_shard_fast_kernel decides from
+        const size_t wins_bytes = (size_t)std::max(T, kWinLds) * sizeof(TypeWin);
+        HIP_TRY(c, B.heads.ensure(wins_bytes));
+        HIP_TRY(c, hipMemsetAsync(B.heads.p, 0, wins_bytes, st));
+        if (V.P > 0 && V.W > 0) hipLaunchKernelGGL(build_wins_kernel, dim3(T), dim3(64), 0, st, V, B.heads.as<TypeWin>());
+        HIP_TRY(c, hipGetLastError());
+        const int rc = rebuild_resolved(c, N, M, true);  // (synchronizes the stream)
+        if (rc != MMP_OK) return rc;
+    }
+    c->sview = V;
     c->snap = M;
     c->cur = 1 - c->cur;
     c->committed = true;
@@ -2090,8 +2108,8 @@ PlaceArgs shard_args(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_ex
     PlaceArgs A{};
     A.reqs = static_cast<const mmp_place_req *>(d_reqs);
     A.models = c->models.as<mmp_model_row>();
-    A.rmodels = nullptr;
-    A.wins = nullptr;
+    A.rmodels = cur_side(c).rmodels_ok ? cur_side(c).rmodels.as<ResolvedModel>() : nullptr;
+    A.wins = (c->no_heads || c->sview.P <= 0) ? nullptr : c->sb[c->cur].heads.as<TypeWin>();
     A.ent_pod = c->ent_pod.as<int32_t>();
     A.extra = static_cast<const int32_t *>(d_extra);
     A.outs = static_cast<mmp_place_out *>(d_outs);
@@ -2116,8 +2134,8 @@ try {
     if (n == 0) return MMP_OK;
     const PlaceArgs A = shard_args(c, d_reqs, n, d_extra, now, nullptr);
     note_caller_stream(c, static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(place_shard_fast_kernel, dim3(div_up(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), c->sview, A,
-                       c->shard, static_cast<int64_t *>(d_xf));
+    hipLaunchKernelGGL(place_shard_fast_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), (size_t)place_lane_lds(c->sview.T),
+                       static_cast<hipStream_t>(stream), c->sview, A, c->shard, static_cast<int64_t *>(d_xf));
     HIP_TRY(c, hipGetLastError());
     return MMP_OK;
 } catch (const std::bad_alloc &) {
@@ -2127,21 +2145,40 @@ try {
 }
 
 namespace {
-// flags -> exclusive scan -> gather of the undecided requests (decision order, identical on every shard); leaves
-// the number of them on the device at f_offs[n] (called with c->mu held)
-int shard_finish_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_xf, void *d_outs, hipStream_t st)
+// After the all-reduce: the decided rows are written, the rest flagged and COUNTED; the count reaches the host through a
+// pinned word (place_shard_fast_finish_kernel).  Only when it is not zero: flags -> exclusive scan -> gather of the undecided
+// requests (decision order, identical on every shard).  Called with c->mu held; returns with the finish kernel complete.
+int shard_finish_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_xf, void *d_outs, hipStream_t st, int32_t *n_rest_out)
 {
     HIP_TRY(c, c->f_flags.ensure((size_t)(n + 1) * 4));
+    if (!c->f_cnt.p) {
+        HIP_TRY(c, c->f_cnt.ensure(16));
+        HIP_TRY(c, hipMemsetAsync(c->f_cnt.p, 0, 16, st));
+    }
+    if (!c->f_done) {
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->f_done), 64, kPinnedFlags));
+        *c->f_done = 0;
+    }
+    const uint32_t seq = ++c->f_seq;
+    hipLaunchKernelGGL(place_shard_fast_finish_kernel, dim3(div_up(n + 1, 256)), dim3(256), 0, st, static_cast<const int64_t *>(d_xf),
+                       n, c->ssnap.any_rs, static_cast<mmp_place_out *>(d_outs), c->f_flags.as<int32_t>(), c->f_cnt.as<unsigned long long>(),
+                       c->f_done, seq);
+    HIP_TRY(c, hipGetLastError());
+    // the count arrives in pinned memory with the kernel's end: one stream synchronisation, no copy
+    HIP_TRY(c, hipStreamSynchronize(st));
+    const uint64_t word = __atomic_load_n(c->f_done, __ATOMIC_ACQUIRE);
+    if ((uint32_t)(word >> 32) != seq) return fail(c, MMP_EHIP, "shard finish kernel did not report its count");
+    const int32_t n_rest = (int32_t)(uint32_t)word;
+    *n_rest_out = n_rest;
+    if (n_rest == 0) return MMP_OK;
     HIP_TRY(c, c->f_offs.ensure((size_t)(n + 1) * 4));
-    HIP_TRY(c, c->f_idx.ensure((size_t)n * 4));
-    HIP_TRY(c, c->f_reqs.ensure((size_t)n * sizeof(mmp_place_req)));
-    HIP_TRY(c, c->f_outs.ensure((size_t)n * sizeof(mmp_place_out)));
+    HIP_TRY(c, c->f_idx.ensure((size_t)n_rest * 4));
+    HIP_TRY(c, c->f_reqs.ensure((size_t)n_rest * sizeof(mmp_place_req)));
+    HIP_TRY(c, c->f_outs.ensure((size_t)n_rest * sizeof(mmp_place_out)));
     size_t scan_bytes = 0;
     HIP_TRY(c, rocprim::exclusive_scan(nullptr, scan_bytes, c->f_flags.as<int32_t>(), c->f_offs.as<int32_t>(), (int32_t)0,
                                        (size_t)n + 1, rocprim::plus<int32_t>(), st));
     HIP_TRY(c, c->f_scan_tmp.ensure(std::max<size_t>(scan_bytes, 16)));
-    hipLaunchKernelGGL(place_shard_fast_finish_kernel, dim3(div_up(n + 1, 256)), dim3(256), 0, st, static_cast<const int64_t *>(d_xf),
-                       n, c->ssnap.any_rs, static_cast<mmp_place_out *>(d_outs), c->f_flags.as<int32_t>());
     HIP_TRY(c, rocprim::exclusive_scan(c->f_scan_tmp.p, scan_bytes, c->f_flags.as<int32_t>(), c->f_offs.as<int32_t>(), (int32_t)0,
                                        (size_t)n + 1, rocprim::plus<int32_t>(), st));
     hipLaunchKernelGGL(place_shard_gather_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, static_cast<const mmp_place_req *>(d_reqs),
@@ -2164,16 +2201,16 @@ try {
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     note_caller_stream(c, st);
+    int32_t n_rest = 0;
     {
-        const int rc = shard_finish_launch(c, d_reqs, n, d_xf, d_outs, st);
+        const int rc = shard_finish_launch(c, d_reqs, n, d_xf, d_outs, st, &n_rest);
         if (rc != MMP_OK) return rc;
     }
-    int32_t n_rest = 0;
-    HIP_TRY(c, hipMemcpyAsync(&n_rest, c->f_offs.as<int32_t>() + n, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
     *n_rest_out = n_rest;
-    *d_rest_reqs_out = c->f_reqs.p;
-    *d_rest_outs_out = c->f_outs.p;
+    if (n_rest) {
+        *d_rest_reqs_out = c->f_reqs.p;
+        *d_rest_outs_out = c->f_outs.p;
+    }
     return MMP_OK;
 } catch (const std::bad_alloc &) {
     return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shard_place_fast_finish_dev");
@@ -2432,22 +2469,16 @@ int shard_place_batch_locked(mmp_ctx *c, const void *d_reqs, int32_t n, const vo
     if (rc != MMP_OK) return rc;
     rc = group_allreduce(c, c->g_xf.p, (size_t)n * kXF, ncclInt64, ncclMin);
     if (rc != MMP_OK) return rc;
+    int32_t n_rest = 0;
     {
         std::lock_guard<std::shared_mutex> g(c->mu);
-        rc = shard_finish_launch(c, d_reqs, n, c->g_xf.p, d_outs, st);
+        rc = shard_finish_launch(c, d_reqs, n, c->g_xf.p, d_outs, st, &n_rest);
         if (rc != MMP_OK) return rc;
     }
-    const int32_t *n_dev = c->f_offs.as<int32_t>() + n;  // written by the scan above
-    const int32_t cap = std::min(n, std::max(1024, n / 16));
-    rc = group_general(c, c->f_reqs.p, cap, n_dev, d_extra, now, c->f_outs.p);
-    if (rc != MMP_OK) return rc;
-    hipLaunchKernelGGL(place_shard_scatter_kernel, dim3(div_up(cap, 256)), dim3(256), 0, st, c->f_outs.as<mmp_place_out>(),
-                       c->f_idx.as<int32_t>(), cap, static_cast<mmp_place_out *>(d_outs), n_dev);
-    HIP_TRY(c, hipGetLastError());
-    int32_t n_rest = 0;
-    HIP_TRY(c, hipMemcpyAsync(&n_rest, n_dev, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    if (n_rest > cap) {  // identical on every shard (the same reduced words): the group stays in step
+    // n_rest is identical on every shard (the same reduced words): the group stays in step.  Round 2 kept the count on the
+    // device and ALWAYS ran the six-exchange protocol over a fixed-capacity sub-batch (seven launches and six collectives
+    // that mostly found no rows): 99 us per 100k decisions at one shard against 50 us for the form that asks.
+    if (n_rest > 0) {
         rc = group_general(c, c->f_reqs.p, n_rest, nullptr, d_extra, now, c->f_outs.p);
         if (rc != MMP_OK) return rc;
         hipLaunchKernelGGL(place_shard_scatter_kernel, dim3(div_up(n_rest, 256)), dim3(256), 0, st, c->f_outs.as<mmp_place_out>(),

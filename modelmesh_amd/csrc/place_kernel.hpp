@@ -671,7 +671,7 @@ __device__ __forceinline__ ResolvedReq resolve_req(const Snap &S, const PlaceArg
         if (r.n_excl <= kInlineExcl) {
 #pragma unroll
             for (int i = 0; i < kResolvedInline; i++)
-                if (i < m.n_ents) r.excl_pos[i] = m.pos[i];
+                if (i < m.n_ents) r.excl_pos[i] = VIEW ? (m.pos[i] < 0 ? -1 : view_pos(S, m.pos[i])) : m.pos[i];  // resolved = GLOBAL rank positions
             if (LATE && (early_extra || rq.n_extra == 0)) {
                 r.n_model = m.n_ents;
                 r.n_late = rq.n_extra;
@@ -1412,6 +1412,10 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
 // words (a trip is one LDS read; one or two trips); the candidate words are parked for the final select; the rpm
 // rule is one threshold.  (A variant with 4 or 6 words per bitmap in registers and no loops at all was measured
 // too: 1059 instead of 744 VALU instructions per wavefront, 8.6 / 9.9 us per launch instead of 7.5.)
+// VIEW: S is a pod-axis shard's view of its slice (windows built over the view by the sharded commit): positions are local, the
+// audit hash takes the GLOBAL word index, and a shortlist that reaches the end of a slice with more slices behind it is not the
+// window's to answer (kLaneHeadMiss; lane_decide_r<true> then reports kLaneIncomplete).
+template <bool VIEW = false>
 __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, const TypeWin *Ws,
                                                uint64_t *scr, mmp_place_out &o)
 {
@@ -1582,10 +1586,10 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
         scrE[(w - w0) * kPlaceBlock] = v;
         whi = w;
         ccount += __popcll((unsigned long long)v);
-        if (v) hsum += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)(w + 1)));
+        if (v) hsum += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)((VIEW ? S.w_base : 0) + w + 1)));
         if (end != kNoPos) break;
     }
-    if (end == kNoPos && win_end < P) return kLaneHeadMiss;  // the list runs past the window
+    if (end == kNoPos && (win_end < P || (VIEW && S.more_after))) return kLaneHeadMiss;  // the list runs past the window (or the slice)
     PHASE(3);  // break scans + count + audit hash
     if (self_in_c && favour) {  // :4931-4933
         o.chosen = MMP_SELF;
@@ -2045,8 +2049,18 @@ __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(6, 
     place_block<false>(S, A, wpad, smem);
 }
 
-// the same with the long-shortlist phase (see place_block)
+// the same with the long-shortlist phase (see place_block): 144 VGPRs, 3 wavefronts per SIMD
 __global__ __launch_bounds__(kPlaceBlock) void place_batch_long_kernel(Snap S, PlaceArgs A, int32_t wpad)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    place_block<true>(S, A, wpad, smem);
+}
+
+// ... for launches that put more than three wavefronts on a SIMD: 128 VGPRs (88 instead of 48 bytes of spill per lane), 4
+// per SIMD.  Measured on the full cluster (C3): 800k decisions per launch 78.5 -> 71.2 us, 100k (1.5 wavefronts per SIMD:
+// occupancy is not what limits it) 20.3 -> 21.0 us — hence two instantiations, chosen by the launch's size.
+constexpr int kLongDenseFrom = 3 * 4 * 256 * 64;  // decisions from which a launch fills 3 wavefronts on each of the 1024 SIMDs
+__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void place_batch_long4_kernel(Snap S, PlaceArgs A, int32_t wpad)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     place_block<true>(S, A, wpad, smem);

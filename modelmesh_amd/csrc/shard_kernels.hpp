@@ -617,12 +617,41 @@ __global__ void place_shard_finish_kernel(ShardSnap S, PlaceArgs A, XchgPtrs X)
 constexpr int kXF = 2;
 constexpr int kShardMaxPods = 1 << 24;
 
-__global__ __launch_bounds__(256) void place_shard_fast_kernel(Snap V, PlaceArgs A, int32_t shard, int64_t *__restrict__ xf)
+// The kernel is place_block's lane phase on the view: the slice's per-type head windows (built by the sharded commit over the
+// view) staged in LDS beside the request fetch, the model's entries from the resolved rows (global rank positions, translated
+// into the view), lane_decide_win<true>, and lane_decide_r<true> for what the window cannot answer.  Dynamic LDS:
+// place_lane_lds(T).  (Round 2 ran lane_decide_r alone here, through models -> ent_pod -> pos_of: 6.8x the unsharded launch at
+// one shard.)
+__global__ __launch_bounds__(kPlaceBlock) void place_shard_fast_kernel(Snap V, PlaceArgs A, int32_t shard, int64_t *__restrict__ xf)
 {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TypeWin *s_wins = reinterpret_cast<TypeWin *>(smem);
+    uint64_t *s_scr = reinterpret_cast<uint64_t *>(smem + win_lds_bytes(V.T));
+    const int d = blockIdx.x * kPlaceBlock + threadIdx.x;
+    const bool use_wins = A.wins != nullptr;  // wave-uniform
+    if (use_wins) {
+        constexpr int kWinBytes = (int)sizeof(TypeWin);
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int chunks = ((V.T < kWinLds ? V.T : kWinLds) * kWinBytes + 1023) >> 10;
+        const char *src = reinterpret_cast<const char *>(A.wins);
+        char *dst = reinterpret_cast<char *>(s_wins);
+        for (int c = wave; c < chunks; c += kPlaceWaves)
+            __builtin_amdgcn_global_load_lds(src + (size_t)c * 1024 + lane_id() * 16,
+                                             (__attribute__((address_space(3))) void *)(dst + c * 1024), 16, 0, 0);
+    }
+    mmp_place_req rq{};
+    if (d < A.n) rq = A.reqs[d];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (d >= A.n) return;
+    ResolvedReq r = resolve_req<true, true>(V, A, rq);
     mmp_place_out o;
-    const int code = lane_decide<true>(V, A, d, o);
+    int code = kLaneHeadMiss;
+    if (use_wins) code = lane_decide_win<true>(V, A, r, s_wins, s_scr + threadIdx.x, o);
+    if (code == kLaneHeadMiss) {
+        merge_late_extras(r);
+        code = lane_decide_r<true>(V, A, r, o);
+    }
     int64_t k0 = kXMax, k1 = kXMax;
     if (code != kLaneNoneHere) {
         const int64_t key = (int64_t)shard << 56;
@@ -635,35 +664,54 @@ __global__ __launch_bounds__(256) void place_shard_fast_kernel(Snap V, PlaceArgs
 }
 
 // after the all-reduce: write the decided rows, flag the rest
-__global__ void place_shard_fast_finish_kernel(const int64_t *__restrict__ xf, int32_t n, int32_t any_rs,
-                                               mmp_place_out *__restrict__ outs, int32_t *__restrict__ flags)
+// cnt: one device word, zero between launches: finished workgroups << 32 | flagged decisions.  Every workgroup adds its own
+// pair with ONE relaxed returning atomic (no fence: a device-scope release per wavefront made this kernel 34 us per 100k
+// decisions — on eight XCDs it is an L2 write-back each); the workgroup that sees the others' count complete stores
+// seq << 32 | flagged into the pinned word `done`, where the host finds it after synchronising the stream (no device-to-host
+// copy); it runs scan + gather + the general protocol only when the count is not zero (the usual batch has none).
+__global__ __launch_bounds__(256) void place_shard_fast_finish_kernel(const int64_t *__restrict__ xf, int32_t n, int32_t any_rs,
+                                                                      mmp_place_out *__restrict__ outs, int32_t *__restrict__ flags,
+                                                                      unsigned long long *__restrict__ cnt, uint64_t *__restrict__ done, uint32_t seq)
 {
+    __shared__ uint32_t s_rest;
+    if (threadIdx.x == 0) s_rest = 0;
+    __syncthreads();
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d > n) return;
-    if (d == n) {
-        flags[n] = 0;  // the scan runs over n + 1 items: offs[n] = number of flagged decisions
-        return;
-    }
-    const int64_t *x = xf + (size_t)d * kXF;
-    const int64_t k0 = x[0], k1 = x[1];
-    mmp_place_out o;
-    o.chosen = MMP_NONE;
-    o.best = -1;
-    o.n_candidates = 0;
-    o.hash = 0;
     int32_t rest = 0;
-    if (k0 == kXMax)
-        rest = any_rs ? 1 : 0;  // nowhere eligible: null, unless the excludeReplicaSets retry has to run
-    else if ((k0 >> 55) & 1)
-        rest = 1;
-    else {
-        o.chosen = (int32_t)((k0 >> 28) & 0x7ffffffll) - 2;
-        o.best = (int32_t)(k0 & 0xfffffffll) - 1;
-        o.n_candidates = (int32_t)((k1 >> 32) & 0xffffffll);
-        o.hash = (uint32_t)(k1 & 0xffffffffll);
+    if (d == n) flags[n] = 0;  // the scan runs over n + 1 items: offs[n] = number of flagged decisions
+    if (d < n) {
+        const int64_t *x = xf + (size_t)d * kXF;
+        const int64_t k0 = x[0], k1 = x[1];
+        mmp_place_out o;
+        o.chosen = MMP_NONE;
+        o.best = -1;
+        o.n_candidates = 0;
+        o.hash = 0;
+        if (k0 == kXMax)
+            rest = any_rs ? 1 : 0;  // nowhere eligible: null, unless the excludeReplicaSets retry has to run
+        else if ((k0 >> 55) & 1)
+            rest = 1;
+        else {
+            o.chosen = (int32_t)((k0 >> 28) & 0x7ffffffll) - 2;
+            o.best = (int32_t)(k0 & 0xfffffffll) - 1;
+            o.n_candidates = (int32_t)((k1 >> 32) & 0xffffffll);
+            o.hash = (uint32_t)(k1 & 0xffffffffll);
+        }
+        flags[d] = rest;
+        if (!rest) outs[d] = o;
     }
-    flags[d] = rest;
-    if (!rest) outs[d] = o;
+    const uint64_t m = __ballot(rest != 0);
+    if (m && (int)__builtin_ctzll(m) == lane_id()) atomicAdd(&s_rest, (uint32_t)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long mine = (1ull << 32) | s_rest;
+        const unsigned long long prev = __hip_atomic_fetch_add(cnt, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(prev >> 32) == gridDim.x - 1) {
+            const uint32_t total = (uint32_t)prev + s_rest;
+            __hip_atomic_store(cnt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done, ((uint64_t)seq << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 __global__ void place_shard_gather_kernel(const mmp_place_req *__restrict__ reqs, int32_t n, const int32_t *__restrict__ flags,

@@ -317,7 +317,7 @@ class OracleFleet:
 
         place.close = lambda: lib.orc_pool_destroy(pool)
         place.flags = flags
-        place.keep = (models, ent)
+        place.keep = (models, ent, self)  # the snapshot's pointers live in this object's arrays
         return place
 
     def stats(self):
