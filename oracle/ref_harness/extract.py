@@ -73,6 +73,12 @@ RANGES = [
     ("removeSecondModelCopy_body", MM, 6318, 6334, "if (otherValidInstance == null) {", "return removeLocalModelCopyAsync(modelId, mr, ce, lastUsed);"),
     ("getRpm_body", MM, 1739, 1740, "long countSinceLastTime = getIntervalCount();", "(60_000L * countSinceLastTime) / timeSinceLastCheck;"),
     ("second_copy_remove_constant", MM, 257, 257, "SECOND_COPY_REMOVE_MAX_AGE_MS = 10 * 3600_000L;", "10hours"),
+    # ---- a17: the leader's reaper — proactive loading of unloaded models
+    ("modeltoload_compareTo_body", MM, 6407, 6407, "return Long.compare(m.lastUsed, lastUsed);", "lastUsed);"),
+    ("reaper_candidates_prologue", MM, 6456, 6463, "ClusterStats globalStats = clusterStats;", "}"),
+    ("reaper_candidate_rule", MM, 6574, 6577, "if (proactiveLoadCandidates != null && insts.isEmpty() && failInsts.size() < 2", "}"),
+    ("reaper_dispatch_fragment", MM, 6473, 6489, "if (typeConstraints == null) {", "}"),
+    ("triggerProactiveLoads_body", MM, 6619, 6746, "// get free units", "}"),
 ]
 
 # token-level rewrites, applied in order to every extracted line
@@ -93,6 +99,8 @@ RULES = [
     # gets the stand-in's name
     (re.compile(r"\boldest\("), "oldest_of("),
     # lambdas: `ent -> {` (a Java lambda captures effectively-final locals by value; here: copies of handles)
+    # `() -> {` (a Runnable): a lambda without parameters
+    (re.compile(r"\(\)\s*->\s*\{"), "[=]() {"),
     (re.compile(r"\b(\w+)\s*->\s*\{"), r"[=](auto \1) {"),
     # wildcard generics do not exist in C++: ServiceInstance<?> -> ServiceInstance
     (re.compile(r"<\?>"), ""),
@@ -112,6 +120,10 @@ RULES = [
     (re.compile(r"\b(\w+)\s+instanceof\s+(\w+)"), r"instanceof_\2(\1)"),
     # `union` (Guava's Sets.union) is a C++ keyword
     (re.compile(r"\.union\("), ".union_("),
+    # `register` is a C++ keyword (Phaser.register()); try/catch/finally: the finally block becomes a plain block behind the
+    # try statement (equivalent whenever no exception leaves the catch clauses, which is the case for the stubs' calls)
+    (re.compile(r"\.register\("), ".register_("),
+    (re.compile(r"\}\s*finally\s*\{"), "} {"),
     # member modifiers in front of the constant declarations
     (re.compile(r"^\s*(?:protected|public)\s+static\s+"), ""),
 ]

@@ -16,6 +16,21 @@
 
 std::vector<std::shared_ptr<void>> g_lists_created;
 
+// ---- TypeConstraintManager.ProhibitedTypeSet (TypeConstraintManager.java:295-333): a sorted array of type names with
+// contains() and equals() ------------------------------------------------------------------------------------------------
+class ProhibitedTypeSet {
+    std::shared_ptr<std::vector<std::string>> p;  // sorted
+
+public:
+    ProhibitedTypeSet() {}
+    ProhibitedTypeSet(std::nullptr_t) {}
+    explicit ProhibitedTypeSet(std::vector<std::string> types) : p(std::make_shared<std::vector<std::string>>(std::move(types))) { std::sort(p->begin(), p->end()); }
+    bool operator==(std::nullptr_t) const { return !p; }
+    bool operator!=(std::nullptr_t) const { return (bool)p; }
+    boolean contains(const String &type) const { return std::binary_search(p->begin(), p->end(), type.str()); }  // :309-311
+    boolean equals(const ProhibitedTypeSet &o) const { return o.p && *p == *o.p; }                                  // :314-317
+};
+
 // ---- com.ibm.watson.modelmesh.InstanceRecord (InstanceRecord.java:37-69): a record with getters -------------------
 class InstanceRecord {
     struct Rep {
@@ -27,6 +42,7 @@ class InstanceRecord {
     std::shared_ptr<Rep> p;
 
 public:
+    ProhibitedTypeSet prohibitedTypes;  // InstanceRecord.java: transient, set by the TypeConstraintManager (only row a17 reads it here)
     InstanceRecord() {}
     InstanceRecord(long lru, long cap, long used_, long vers, int cnt, int lt, int lip, int rpm, boolean sd)
         : p(std::make_shared<Rep>(Rep{lru, cap, used_, vers, cnt, lt, lip, rpm, sd, StringArray()})) {}
@@ -282,8 +298,9 @@ struct ModelRecord {
     bool operator!=(std::nullptr_t) const { return !isnull; }
     bool operator==(std::nullptr_t) const { return isnull; }
     boolean loadFailedInInstance(const String &iid) const { return failed.containsKey(iid); }  // ModelRecord.java:208
-    long lastUnloadTime = 0;
+    long lastUnloadTime = 0, lastUsed = 0;
     long getLastUnloadTime() const { return lastUnloadTime; }
+    long getLastUsed() const { return lastUsed; }
     String getType() const { return type; }
     Map<String, Long> getInstanceIds() const { return instanceIds; }
     Map<String, Long> getLoadFailedInstanceIds() const { return failed; }
@@ -552,6 +569,86 @@ static void janitor_scaledown(long now)
 #include "../_ref/gen/janitor_scaledown_fragment.inc"
 }
 
+// ======================= a17: the leader's reaper — proactive loading (MM.java:6456-6490, :6574-6577, :6616-6747) ===============
+struct ModelToLoad {  // :6393-6409
+    String modelId;
+    long lastUsed;
+    int index;
+    ModelToLoad(const String &m, long l, int i) : modelId(m), lastUsed(l), index(i) {}
+    int compareTo(const ModelToLoad &m) const
+    {
+#include "../_ref/gen/modeltoload_compareTo_body.inc"
+    }
+};
+// java.util.TreeSet under the element's own compareTo: add() of an element that compares equal to one in the set is a no-op
+template <class X> class NavigableSet {
+    struct Less { bool operator()(const X &a, const X &b) const { return a.compareTo(b) < 0; } };
+    typedef std::set<X, Less> Rep;
+    std::shared_ptr<Rep> p;
+
+public:
+    NavigableSet() {}
+    NavigableSet(std::nullptr_t) {}
+    NavigableSet &operator=(const Set<String> &) { p = std::make_shared<Rep>(); return *this; }  // `toLoad = new TreeSet<>()` (extract.py: TreeSet_new())
+    bool operator==(std::nullptr_t) const { return !p; }
+    int size() const { return (int)p->size(); }
+    boolean isEmpty() const { return p->empty(); }
+    const X &last() const { return *p->rbegin(); }
+    boolean add(const X &x) const { return p->insert(x).second; }
+    void pollLast() const { p->erase(std::prev(p->end())); }
+    typename Rep::const_iterator begin() const { return p->begin(); }
+    typename Rep::const_iterator end() const { return p->end(); }
+};
+struct InterruptedException {};
+struct Phaser {
+    explicit Phaser(int) {}
+    int register_() const { return 0; }
+    int arrive() const { return 0; }
+    void awaitAdvanceInterruptibly(int) const {}
+};
+static const struct { template <class F> void execute(F f) const { f(); } } taskPool;  // the pool's thread: here, at once
+static const struct { void sleep(long) const {} } Thread;
+static long msSince(long) { return 0; }
+static String readableTime(long) { return String(""); }
+static boolean DISABLE_PROACTIVE_LOADING = false;
+static int defaultModelSizeUnits;
+struct ProactiveCall { std::string model; long ts; int partition; };
+static std::vector<ProactiveCall> g_proactive_calls;
+static int g_proactive_partition;
+static void ensureLoadedInternal(const String &modelId, long lastUsedTime, int, std::nullptr_t, int, boolean) { g_proactive_calls.push_back({modelId.str(), lastUsedTime, g_proactive_partition}); }  // :6727
+static void triggerProactiveLoadsForInstanceSubset(ClusterStats stats, List<Entry<String, ModelRecord>> allCandidates, ProhibitedTypeSet excludeTypes)
+{
+    const struct {
+        void warn(const String &) const {}
+        void warn(const String &, const Exception &) const {}
+        void info(const String &) const {}
+        void debug(const String &) const {}
+        boolean isDebugEnabled() const { return false; }
+    } logger;
+    g_proactive_partition++;
+#include "../_ref/gen/triggerProactiveLoads_body.inc"
+}
+struct InstanceSetStatsTracker { ClusterStats currentStats; ProhibitedTypeSet prohibitedTypesSet; };  // TypeConstraintManager.java (the two fields read here)
+struct ReaperTypeConstraints {
+    std::shared_ptr<std::vector<InstanceSetStatsTracker>> p;
+    bool operator==(std::nullptr_t) const { return !p; }
+    const std::vector<InstanceSetStatsTracker> &getPartitionStats() const { return *p; }
+};
+// the reaper's run as far as proactive loading goes: candidate collection over the registry (in its iteration order), then the
+// dispatch per instance subset
+static void reaper_proactive(const std::vector<Entry<String, ModelRecord>> &registryIterable, const ReaperTypeConstraints &typeConstraints)
+{
+#include "../_ref/gen/reaper_candidates_prologue.inc"
+    for (const Entry<String, ModelRecord> &ent : registryIterable) {
+        ModelRecord mr = ent.getValue();
+        Map<String, Long> insts = mr.getInstanceIds(), failInsts = mr.getLoadFailedInstanceIds();  // :6542-6543
+#include "../_ref/gen/reaper_candidate_rule.inc"
+    }
+    if (proactiveLoadCandidates != null && !proactiveLoadCandidates.isEmpty()) {  // :6471
+#include "../_ref/gen/reaper_dispatch_fragment.inc"
+    }
+}
+
 // ======================================================== I/O ===============================================================
 // The audit hash of a shortlist (machinery of THIS repository, not of the reference): a function of the set of
 // rank positions in the shortlist and of the count that survived the rpm filter — computed here from the reference's own
@@ -631,6 +728,20 @@ int main(int argc, char **argv)
     auto dparams = rd<mmp_scaledown_params>(f, n_sd >= 0 ? 1 : 0);
     auto dentries = rd<mmp_cache_entry>(f, n_sd > 0 ? n_sd : 0);
     auto dstats = rd<StatsRow>(f, n_sd >= 0 ? 1 : 0);
+    // a17: one reaper run: defaultModelSizeUnits, clusterStats, then per instance partition (0 partitions: typeConstraints == null)
+    // its stats (InstanceSetStatsTracker.currentStats: an input, rows a5 / a18) and prohibited type rows, then the partition of every instance
+    auto n_pro_v = rd<int64_t>(f, 1);
+    const int64_t n_pro = n_pro_v[0];
+    auto pro_units = rd<int64_t>(f, n_pro >= 0 ? 1 : 0);
+    auto pro_gstats = rd<StatsRow>(f, n_pro >= 0 ? 1 : 0);
+    std::vector<StatsRow> pro_pstats;
+    std::vector<std::vector<int32_t>> pro_types;
+    for (int64_t k = 0; k < n_pro; k++) {
+        pro_pstats.push_back(rd<StatsRow>(f, 1)[0]);
+        const int64_t nt = rd<int64_t>(f, 1)[0];
+        pro_types.push_back(rd<int32_t>(f, (size_t)nt));
+    }
+    auto pro_pod_part = rd<int32_t>(f, n_pro > 0 ? (size_t)P : 0);
     fclose(f);
 
     std::vector<String> ids(P);
@@ -1002,6 +1113,56 @@ int main(int argc, char **argv)
         std::vector<uint8_t> removed(n_sd, 0);
         for (auto &id : g_removed_local) removed[std::stoll(id.substr(1))] = 1;
         wr(o, removed);
+    }
+    // ---- a17: the ensureLoadedInternal calls of one reaper run, in call order: (registry row, lastUsed, subset number)
+    if (n_pro >= 0) {
+        auto stats_of = [](const StatsRow &r) { return ClusterStats{r.total_capacity, r.total_free, r.global_lru, r.instance_count, r.model_copy_count}; };
+        defaultModelSizeUnits = (int)pro_units[0];
+        clusterStats = stats_of(pro_gstats[0]);
+        auto type_name = [](int t) { return "t" + std::to_string(t); };
+        ReaperTypeConstraints tc;
+        std::vector<ProhibitedTypeSet> sets;
+        if (n_pro > 0) {
+            tc.p = std::make_shared<std::vector<InstanceSetStatsTracker>>();
+            for (int64_t k = 0; k < n_pro; k++) {
+                std::vector<std::string> names;
+                for (int32_t t : pro_types[k]) names.push_back(type_name(t));
+                sets.push_back(ProhibitedTypeSet(names));
+                tc.p->push_back(InstanceSetStatsTracker{stats_of(pro_pstats[k]), sets.back()});
+            }
+            // clusterState with every record's prohibitedTypes set (TypeConstraintManager does this as records arrive)
+            auto withsets = std::make_shared<std::vector<Entry<String, InstanceRecord>>>();
+            for (const auto &e : *g_cluster) {
+                InstanceRecord ir = e.getValue();
+                const int32_t part = pro_pod_part[pod_of[e.getKey().str()]];
+                // an instance outside every partition carries a set no partition equals
+                ir.prohibitedTypes = part >= 0 ? ProhibitedTypeSet(std::vector<std::string>(1, "")) : ProhibitedTypeSet(std::vector<std::string>(1, "\x01none"));
+                if (part >= 0) ir.prohibitedTypes = sets[part];
+                withsets->push_back(Entry<String, InstanceRecord>(e.getKey(), ir));
+            }
+            g_cluster = withsets;
+        }
+        std::vector<Entry<String, ModelRecord>> reg;
+        for (int64_t mi = 0; mi < M; mi++) {
+            const mmp_model_row &m = models[mi];
+            ModelRecord mr;
+            mr.type = String(type_name((m.type < 0 || m.type >= Tn) ? 0 : m.type));
+            mr.lastUsed = m.last_used;
+            for (int32_t k = 0; k < m.n_loaded + m.n_failed; k++)
+                (k < m.n_loaded ? mr.instanceIds : mr.failed).put(ids[ent_pod[m.ent_off + k]], Long(ent_time[m.ent_off + k]));
+            reg.push_back(Entry<String, ModelRecord>(String("m" + std::to_string(mi)), mr));
+        }
+        g_proactive_calls.clear();
+        g_proactive_partition = -1;
+        reaper_proactive(reg, tc);
+        std::vector<int64_t> po;
+        po.push_back((int64_t)g_proactive_calls.size());
+        for (const auto &c : g_proactive_calls) {
+            po.push_back(std::stoll(c.model.substr(1)));
+            po.push_back(c.ts);
+            po.push_back(c.partition);
+        }
+        wr(o, po);
     }
     fclose(o);
     return 0;

@@ -88,6 +88,7 @@ static const struct {
     double max(double a, double b) const { return a > b ? a : b; }
     int min(int a, int b) const { return a < b ? a : b; }
     long min(long a, long b) const { return a < b ? a : b; }
+    long min(long a, int b) const { return a < b ? a : (long)b; }  // Java widens the int
     int abs(int a) const { return a < 0 ? (int)(0u - (unsigned)a) : a; }            // Math.abs(MIN_VALUE) == MIN_VALUE
     long abs(long a) const { return a < 0 ? (long)(0ul - (unsigned long)a) : a; }
 } Math;
@@ -155,6 +156,7 @@ public:
     const T &get(int i) const { return p->v[i]; }
     void set(int i, const T &t) const { p->v[i] = t; }
     int size() const { return (int)p->v.size(); }
+    boolean isEmpty() const { return p->v.empty(); }
     Iterator<T> iterator() const
     {
         auto r = p;

@@ -24,7 +24,19 @@ HARNESS = os.environ.get("MMP_REF_HARNESS") or os.path.join(ROOT, "oracle", "_re
 OUT = os.environ.get("MMP_REF_OUT") or os.path.join(ROOT, "tests", "golden", "ref_getnext.npz")
 
 
-def run(blob: bytes, n_place: int, n_serve: int, n_gate: int = 0, n_scale: int = -1, n_pods: int = 0, n_sd: int = -1):
+def proactive_inputs(fleet, units, partitioned):
+    """What the harness is GIVEN for a reaper run (rows a5 / a18 produce them in a mesh): the cluster's stats and, with type
+    constraints, per ProhibitedTypeSet partition its stats, its prohibited type rows and its instances."""
+    from oracle import bind as ob
+    g = np.zeros(1, dtype=ob.ORC_STATS)
+    g[0] = ob.OracleFleet(fleet).stats()
+    if not partitioned:
+        return units, g, np.zeros(0, dtype=ob.ORC_STATS), [], None
+    pts, sets, pst = ob.partition_stats(fleet)
+    return units, g, pst, [sorted(s) for s in sets], pts
+
+
+def run(blob: bytes, n_place: int, n_serve: int, n_gate: int = 0, n_scale: int = -1, n_pods: int = 0, n_sd: int = -1, proactive: bool = False):
     with tempfile.TemporaryDirectory() as td:
         fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
         open(fin, "wb").write(blob)
@@ -40,6 +52,11 @@ def run(blob: bytes, n_place: int, n_serve: int, n_gate: int = 0, n_scale: int =
     off += 16 * n_serve
     gate = np.frombuffer(raw, "<i4", 2 * n_gate, off).reshape(n_gate, 2).copy()
     off += 8 * n_gate
+    if proactive:
+        n_calls = int(np.frombuffer(raw, "<i8", 1, off)[0])
+        calls = np.frombuffer(raw, "<i8", 3 * n_calls, off + 8).reshape(n_calls, 3).copy()
+        assert off + 8 + 24 * n_calls == len(raw)
+        return calls
     if n_sd >= 0:
         removed = np.frombuffer(raw, "u1", n_sd, off).copy()
         assert off + n_sd == len(raw)
@@ -107,6 +124,13 @@ def main():
         out[f"{name}/digest"] = np.frombuffer(rf.digest(blob).encode(), np.uint8)
         names.append(name)
         print(f"{name}: {len(entries)} candidates: {int(removed.sum())} local copies removed")
+    for name, fleet, ids, units, partitioned in rf.proactive_cases():
+        blob = rf.input_blob(fleet, ids, proactive=proactive_inputs(fleet, units, partitioned))
+        calls = run(blob, 0, 0, proactive=True)
+        out[f"{name}/proactive"] = calls
+        out[f"{name}/digest"] = np.frombuffer(rf.digest(blob).encode(), np.uint8)
+        names.append(name)
+        print(f"{name}: {fleet.n_models} registry rows: {len(calls)} proactive loads over {len(np.unique(calls[:, 2])) if len(calls) else 0} instance subset(s)")
     out["names"] = np.array(names)
     out["manifest"] = np.array(open(os.path.join(ROOT, "oracle", "_ref", "gen", "MANIFEST.txt")).read())
     np.savez_compressed(OUT, **out)

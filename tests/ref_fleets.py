@@ -268,7 +268,72 @@ def scaledown_cases():
             yield f"scaledown_{seed}_{j}", fleet, ids, entries, dp
 
 
-def input_blob(fleet, ids, reqs=None, extra=None, serve=None, gates=None, scaleup=None, scaledown=None) -> bytes:
+def _plan_fleet(seed, pods, models, used_frac, dup_frac=0.3):
+    """Mostly unloaded models, many sharing a lastUsed value (the reaper's TreeSet keeps the first of them); instances with
+    and without loading capacity (as tests/test_rebalance_gpu.py builds it)."""
+    rng = np.random.default_rng(7000 + seed)
+    fleet = wl.fuzz_fleet(seed, pods=pods, models=models)
+    now = fleet.now
+    p = fleet.pods
+    p["flags"] = np.where(rng.random(pods) < 0.05, 1, 2)  # a few shutting down
+    p["capacity"] = rng.choice([131072, 1_000_000], pods)
+    p["used"] = (p["capacity"] * np.clip(rng.normal(used_frac, 0.1, pods), 0, 1.02)).astype(np.int64)
+    p["loading_threads"] = rng.choice([0, 1, 8], pods)
+    p["loading_in_progress"] = rng.choice([0, 1, 60, 500], pods)
+    p["count"] = rng.integers(0, 40, pods)
+    p["lru_time"] = np.where(p["count"] == 0, 2**63 - 1, now - rng.integers(1_000, 50_000_000, pods))
+    m = fleet.models
+    unloaded = rng.random(models) < 0.8
+    m["n_loaded"] = np.where(unloaded, 0, m["n_loaded"])
+    m["n_failed"] = np.where(rng.random(models) < 0.1, 2, np.minimum(m["n_failed"], 1))
+    lu = now - rng.integers(1_000, 60_000_000, models)
+    dup = rng.random(models) < dup_frac
+    lu = np.where(dup, now - rng.choice([5_000, 900_000, 30_000_000], models), lu)
+    m["last_used"] = lu
+    m["n_loaded"] = np.minimum(m["n_loaded"], max(pods - 2, 0))
+    tot = m["n_loaded"] + m["n_failed"]
+    off = np.zeros(models + 1, np.int64)
+    np.cumsum(tot, out=off[1:])
+    m["ent_off"] = off[:-1]
+    # instanceIds / loadFailedInstanceIds are MAPS keyed by the instance id: a model's entries name distinct instances
+    ent = np.zeros(int(off[-1]), np.int32)
+    for i in np.flatnonzero(tot):
+        ent[off[i]: off[i + 1]] = rng.choice(pods, size=int(tot[i]), replace=False)
+    fleet.ent_pod = ent
+    fleet.ent_time = (now - rng.integers(1_000, 1_000_000, int(off[-1]))).astype(np.int64)
+    return fleet
+
+
+def proactive_cases():
+    """(name, fleet, ids, defaultModelSizeUnits, partitioned): one run of the leader's reaper as far as proactive loading goes
+    (MM.java:6456-6490, :6574-6577, :6616-6747); partitioned: with type constraints, one pass per ProhibitedTypeSet partition."""
+    from modelmesh_amd.solver import bitmap_from_bool
+    for seed, pods, models, used in ((0, 8, 300, 0.5), (1, 64, 3000, 0.2), (2, 300, 12000, 0.9), (3, 300, 12000, 0.99), (5, 5, 50, 0.0)):
+        fleet = _plan_fleet(seed, pods, models, used)
+        ids = string_ids(fleet, 90 + seed)
+        for units in (6400, 1):
+            yield f"proactive_{seed}_{units}", fleet, ids, units, False
+    for seed, total_copies in ((6, 2), (7, 8)):  # modelCopyCount < 3: defaultModelSizeUnits; <= 10: averaged with it (:6622-6629)
+        fleet = _plan_fleet(seed, 6, 400, 0.3)
+        fleet.pods["flags"] = 2
+        fleet.pods["count"] = 0
+        fleet.pods["count"][:2] = [total_copies // 2, total_copies - total_copies // 2]
+        fleet.pods["lru_time"] = np.where(fleet.pods["count"] == 0, 2**63 - 1, fleet.pods["lru_time"])
+        for units in (6400, 100):
+            yield f"proactive_{seed}_{units}", fleet, string_ids(fleet, 90 + seed), units, False
+    for seed in (0, 1, 2):
+        fleet = _plan_fleet(seed + 20, 300, 6000, [0.5, 0.9, 0.2][seed])
+        if not fleet.n_types:
+            rng = np.random.default_rng(seed)
+            fleet.n_types = 3
+            al = rng.random((3, fleet.n_pods)) < np.array([[1.0], [0.4], [0.7]])
+            fleet.allowed, fleet.prefer = bitmap_from_bool(al), bitmap_from_bool(np.zeros_like(al))
+            fleet.has_allowed, fleet.has_prefer = np.array([0, 1, 1], np.uint8), np.zeros(3, np.uint8)
+            fleet.models["type"] = rng.integers(0, 3, fleet.n_models)
+        yield f"proactive_parts_{seed}", fleet, string_ids(fleet, 95 + seed), 6400, True
+
+
+def input_blob(fleet, ids, reqs=None, extra=None, serve=None, gates=None, scaleup=None, scaledown=None, proactive=None) -> bytes:
     """The harness' input file (layout: oracle/ref_harness/harness.cc main())."""
     P, M = fleet.n_pods, fleet.n_models
     T = int(fleet.n_types)
@@ -318,6 +383,17 @@ def input_blob(fleet, ids, reqs=None, extra=None, serve=None, gates=None, scaleu
         assert istats.dtype.itemsize == 32 and len(istats) == 1
         parts += [struct.pack("<q", len(entries)), np.ascontiguousarray(dp).tobytes(), np.ascontiguousarray(entries).tobytes(),
                   np.ascontiguousarray(istats).tobytes()]
+    if proactive is None:
+        parts += [struct.pack("<q", -1)]
+    else:
+        units, gstats, pstats, ptypes, pod_part = proactive  # cluster stats; per partition: its stats + prohibited type rows; pod -> partition
+        assert gstats.dtype.itemsize == 32 and len(gstats) == 1 and len(pstats) == len(ptypes)
+        parts += [struct.pack("<qq", len(ptypes), int(units)), np.ascontiguousarray(gstats).tobytes()]
+        for k in range(len(ptypes)):
+            t = np.ascontiguousarray(sorted(ptypes[k]), dtype=np.int32)
+            parts += [np.ascontiguousarray(pstats[k: k + 1]).tobytes(), struct.pack("<q", len(t)), t.tobytes()]
+        if len(ptypes):
+            parts += [np.ascontiguousarray(pod_part, dtype=np.int32).tobytes()]
     return b"".join(parts)
 
 

@@ -220,3 +220,37 @@ def test_scaledown_plan_equals_the_reference_text(ref):
         assert bad.size == 0, (name, bad[:8], entries[bad[:8]])
         total += int(rem.sum())
     assert total >= 40
+
+
+def plan_calls(plan, fleet, units, partitioned, n_parts):
+    """The reaper's ensureLoadedInternal calls (model, lastUsed, subset) from a per-subset plan function
+    plan(partition, skip_models) -> (models, last_used, info): one pass for the whole cluster, or one per partition in
+    typeConstraints.getPartitionStats() order, each skipping what the earlier ones took (:6724)."""
+    rows = []
+    if not partitioned:
+        m, lu, _ = plan(-1, None)
+        return np.stack([m, lu, np.zeros_like(lu)], 1).astype(np.int64).reshape(-1, 3)
+    taken = np.zeros(0, np.int32)
+    for k in range(n_parts):
+        m, lu, _ = plan(k, taken)
+        rows.append(np.stack([m, lu, np.full_like(lu, k)], 1).astype(np.int64).reshape(-1, 3))
+        taken = np.concatenate([taken, m.astype(np.int32)])
+    return np.concatenate(rows) if rows else np.zeros((0, 3), np.int64)
+
+
+def test_proactive_plan_equals_the_reference_text(ref):
+    """The leader's reaper (MM.java:6456-6463 candidate switch, :6574-6577 candidate rule, :6473-6489 dispatch per instance
+    subset, :6619-6746 triggerProactiveLoadsForInstanceSubset, ModelToLoad.compareTo :6407): the ensureLoadedInternal calls the
+    reference's own text makes, in order, with their timestamps."""
+    from oracle.ref_harness.make_ref_vectors import proactive_inputs
+    total = 0
+    for name, fleet, ids, units, partitioned in rf.proactive_cases():
+        inp = proactive_inputs(fleet, units, partitioned)
+        blob = rf.input_blob(fleet, ids, proactive=inp)
+        assert rf.digest(blob) == bytes(ref[f"{name}/digest"]).decode(), name
+        got = plan_calls(lambda k, skip: ob.proactive_plan(fleet, units, fleet.now, fleet.n_models, partition=k, skip_models=skip),
+                         fleet, units, partitioned, len(inp[3]))
+        want = ref[f"{name}/proactive"]
+        assert got.shape == want.shape and np.array_equal(got, want), (name, got[:5], want[:5])
+        total += len(want)
+    assert total > 3000

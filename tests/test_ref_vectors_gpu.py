@@ -83,3 +83,18 @@ def test_hip_scaledown_plan_equals_the_reference_text(ref):
             s.close()
         bad = np.flatnonzero(rem != ref[f"{name}/removed"])
         assert bad.size == 0, (name, bad[:8], entries[bad[:8]])
+
+
+def test_hip_proactive_plan_equals_the_reference_text(ref):
+    from tests.test_ref_vectors import plan_calls
+    for name, fleet, ids, units, partitioned in rf.proactive_cases():
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            s.load_fleet(fleet)
+            n_parts = len(s.partitions()[1]) if partitioned else 0
+            got = plan_calls(lambda k, skip: s.proactive_plan(units, fleet.now, fleet.n_models, partition=k, skip_models=skip),
+                             fleet, units, partitioned, n_parts)
+        finally:
+            s.close()
+        want = ref[f"{name}/proactive"]
+        assert got.shape == want.shape and np.array_equal(got, want), (name, got[:5], want[:5])
