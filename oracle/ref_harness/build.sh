@@ -8,6 +8,7 @@ out="$here/../_ref"
 mkdir -p "$out/gen"
 python3 "$here/extract.py" > "$out/gen/extract.log"
 # -fwrapv: Java integer arithmetic wraps; -fno-strict-aliasing is not needed (no type punning in the stand-ins)
+#: the listener's switch (MM.java:1474-1563) declares locals in one case and falls through to the next; Java
 g++ -std=c++17 -O1 -g -fwrapv -Wall -Wno-unused-variable -Wno-unused-function -Wno-parentheses -Wno-unused-but-set-variable \
     "$here/harness.cc" -o "$out/ref_harness"
 echo "built $out/ref_harness from: $(tr '\n' ';' < "$out/gen/MANIFEST.txt")"

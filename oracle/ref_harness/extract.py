@@ -73,6 +73,13 @@ RANGES = [
     ("removeSecondModelCopy_body", MM, 6318, 6334, "if (otherValidInstance == null) {", "return removeLocalModelCopyAsync(modelId, mr, ce, lastUsed);"),
     ("getRpm_body", MM, 1739, 1740, "long countSinceLastTime = getIntervalCount();", "(60_000L * countSinceLastTime) / timeSinceLastCheck;"),
     ("second_copy_remove_constant", MM, 257, 257, "SECOND_COPY_REMOVE_MAX_AGE_MS = 10 * 3600_000L;", "10hours"),
+    # ---- a5: the instance-table listener and the cluster's aggregate stats
+    ("ist_resetLru_body", "src/main/java/com/ibm/watson/modelmesh/InstanceSetStatsTracker.java", 54, 54, "lru = Long.MAX_VALUE;", "MAX_VALUE;"),
+    ("ist_addLru_body", "src/main/java/com/ibm/watson/modelmesh/InstanceSetStatsTracker.java", 58, 60, "if (lru > 0L && lru < this.lru) {", "}"),
+    ("ist_add_body", "src/main/java/com/ibm/watson/modelmesh/InstanceSetStatsTracker.java", 64, 71, "count++;", "}"),
+    ("ist_remove_body", "src/main/java/com/ibm/watson/modelmesh/InstanceSetStatsTracker.java", 75, 83, "count--;", "return count <= 0;"),
+    ("ist_update_body", "src/main/java/com/ibm/watson/modelmesh/InstanceSetStatsTracker.java", 87, 91, "ClusterStats newStats = new ClusterStats(totalCapacity, totalFree, lru, count, modelCount);", "return newStats;"),
+    ("handleInstanceTableChange_body", MM, 1456, 1567, "if (logger.isDebugEnabled()) {", "}", "LISTENER_SWITCH"),
     # ---- a17: the leader's reaper — proactive loading of unloaded models
     ("modeltoload_compareTo_body", MM, 6407, 6407, "return Long.compare(m.lastUsed, lastUsed);", "lastUsed);"),
     ("reaper_candidates_prologue", MM, 6456, 6463, "ClusterStats globalStats = clusterStats;", "}"),
@@ -80,6 +87,21 @@ RANGES = [
     ("reaper_dispatch_fragment", MM, 6473, 6489, "if (typeConstraints == null) {", "}"),
     ("triggerProactiveLoads_body", MM, 6619, 6746, "// get free units", "}"),
 ]
+
+# The one control-flow rewrite: the listener's `switch (type)` (MM.java:1474-1563) declares locals in `case ENTRY_UPDATED` and
+# falls through into `case ENTRY_DELETED`; C++ forbids the jump past those initialisations that a direct entry at the second
+# label would be.  Its four label lines become the equivalent if-chain (ADDED/UPDATED run both blocks, DELETED the second,
+# anything else nothing); every statement between them stays the reference's text.
+EXTRA_RULES = {
+    "LISTENER_SWITCH": [
+        (re.compile(r"^(\s*)switch \(type\) \{\s*$"), r"\1const EventType sw_type = type;  // switch (type) {"),
+        (re.compile(r"^(\s*)case ENTRY_ADDED:\s*$"), r"\1if (sw_type == ENTRY_ADDED || sw_type == ENTRY_UPDATED) {  // case ENTRY_ADDED:"),
+        (re.compile(r"^(\s*)case ENTRY_UPDATED:\s*$"), r"\1// case ENTRY_UPDATED:"),
+        (re.compile(r"^(\s*)case ENTRY_DELETED:\s*$"), r"\1} if (sw_type == ENTRY_ADDED || sw_type == ENTRY_UPDATED || sw_type == ENTRY_DELETED) {  // case ENTRY_DELETED: (also by fall-through)"),
+        (re.compile(r"^(\s*)default:\s*$"), r"\1} if (false) {  // default:"),
+        (re.compile(r"^(\s*)break;\s*$"), r"\1;  // break;"),
+    ],
+}
 
 # token-level rewrites, applied in order to every extracted line
 RULES = [
@@ -122,6 +144,7 @@ RULES = [
     (re.compile(r"\.union\("), ".union_("),
     # `register` is a C++ keyword (Phaser.register()); try/catch/finally: the finally block becomes a plain block behind the
     # try statement (equivalent whenever no exception leaves the catch clauses, which is the case for the stubs' calls)
+    (re.compile(r"\bthis\."), "this->"),
     (re.compile(r"\.register\("), ".register_("),
     (re.compile(r"\}\s*finally\s*\{"), "} {"),
     # member modifiers in front of the constant declarations
@@ -133,7 +156,7 @@ def extract():
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_ref", "gen")
     os.makedirs(out_dir, exist_ok=True)
     manifest = []
-    for name, rel, a, b, must_first, must_last in RANGES:
+    for name, rel, a, b, must_first, must_last, *extra in RANGES:
         path = os.path.join(REF, rel)
         lines = open(path, encoding="utf-8").read().split("\n")
         body = lines[a - 1:b]
@@ -142,7 +165,7 @@ def extract():
                      f"(expected {must_first!r} ... {must_last!r}); the reference moved — fix RANGES")
         out = []
         for ln in body:
-            for rx, rep in RULES:
+            for rx, rep in (EXTRA_RULES[extra[0]] if extra else []) + RULES:
                 ln = rx.sub(rep, ln)
             out.append(ln)
         assert len(out) == len(body)

@@ -279,7 +279,12 @@ struct ModelLoadException : TException {
 };
 static ModelLoadException newModelLoadException(const String &, long, std::nullptr_t) { return ModelLoadException(String(""), null, 0L, null); }
 static TException newInternalException(const String &, std::nullptr_t) { TException t; t.isnull = false; return t; }
-struct ClusterStats { long totalCapacity, totalFree, globalLru; int instanceCount, modelCopyCount; };
+struct ClusterStats {  // MM.java:1570-1590
+    long totalCapacity = 0, totalFree = 0, globalLru = 0;
+    int instanceCount = 0, modelCopyCount = 0;
+    ClusterStats() {}
+    ClusterStats(long cap, long free_, long lru, int n, int copies) : totalCapacity(cap), totalFree(free_), globalLru(lru), instanceCount(n), modelCopyCount(copies) {}
+};
 static std::vector<ClusterStats> g_tstats;
 static ClusterStats clusterStats;  // MM.java:1570 (the cluster-wide stats)
 static ClusterStats typeSetStats(const String &type)  // :1432 — "t<row>"; "t-1": an entry without a registry record (no type: the cluster's stats)
@@ -569,6 +574,62 @@ static void janitor_scaledown(long now)
 #include "../_ref/gen/janitor_scaledown_fragment.inc"
 }
 
+// ======================= a5: the instance-table listener (MM.java:1455-1568) and InstanceSetStatsTracker ======================
+static boolean isFull(long availableUnits);
+struct LongPredicate { boolean test(long v) const { return isFull(v); } };  // this::isFull, MM.java:1451
+class InstanceSetStatsTracker {  // InstanceSetStatsTracker.java:31-93; the method bodies are the reference's text
+    bool isnull = false;
+
+public:
+    LongPredicate isFull;
+    ProhibitedTypeSet prohibitedTypesSet;
+    long totalCapacity = 0, totalFree = 0, lru = Long::MAX_VALUE;
+    int count = 0, modelCount = 0;
+    ClusterStats currentStats = ClusterStats(0L, 0L, Long::MAX_VALUE, 0, 0);  // EMPTY_STATS, :33
+    InstanceSetStatsTracker() {}
+    InstanceSetStatsTracker(std::nullptr_t) : isnull(true) {}
+    bool operator==(std::nullptr_t) const { return isnull; }
+    bool operator!=(std::nullptr_t) const { return !isnull; }
+    void resetLru()
+    {
+#include "../_ref/gen/ist_resetLru_body.inc"
+    }
+    void addLru(long lru)
+    {
+#include "../_ref/gen/ist_addLru_body.inc"
+    }
+    void add(const String &iid, const InstanceRecord &ir)
+    {
+#include "../_ref/gen/ist_add_body.inc"
+    }
+    boolean remove(const String &iid, const InstanceRecord &ir)
+    {
+#include "../_ref/gen/ist_remove_body.inc"
+    }
+    ClusterStats update()
+    {
+#include "../_ref/gen/ist_update_body.inc"
+    }
+};
+enum EventType { ENTRY_ADDED, ENTRY_UPDATED, ENTRY_DELETED };
+// clusterState = new ConcurrentSkipListSet<>(PLACEMENT_ORDER) (MM.java:774) as the listener uses it: add() refuses an element
+// that compares equal to one in the set, the iterator runs in the comparator's order and can remove
+struct SortedClusterState {
+    std::shared_ptr<std::vector<Entry<String, InstanceRecord>>> v = std::make_shared<std::vector<Entry<String, InstanceRecord>>>();
+    boolean add(const Entry<String, InstanceRecord> &e) const;
+    Iterator<Entry<String, InstanceRecord>> iterator() const
+    {
+        auto vv = v;
+        auto i = std::make_shared<size_t>(0);
+        return Iterator<Entry<String, InstanceRecord>>([vv, i] { return *i < vv->size(); }, [vv, i] { return (*vv)[(*i)++]; },
+                                                       [vv, i] { vv->erase(vv->begin() + (long)--*i); });
+    }
+};
+static InstanceSetStatsTracker clusterStatsTracker;  // :1451
+static int changeCounter;
+static int g_upgrade_added, g_upgrade_removed, g_housekeepings, g_republish;
+static void handleInstanceTableChange(const SortedClusterState &clusterState, EventType type, const String &key, InstanceRecord record);
+
 // ======================= a17: the leader's reaper — proactive loading (MM.java:6456-6490, :6574-6577, :6616-6747) ===============
 struct ModelToLoad {  // :6393-6409
     String modelId;
@@ -628,7 +689,6 @@ static void triggerProactiveLoadsForInstanceSubset(ClusterStats stats, List<Entr
     g_proactive_partition++;
 #include "../_ref/gen/triggerProactiveLoads_body.inc"
 }
-struct InstanceSetStatsTracker { ClusterStats currentStats; ProhibitedTypeSet prohibitedTypesSet; };  // TypeConstraintManager.java (the two fields read here)
 struct ReaperTypeConstraints {
     std::shared_ptr<std::vector<InstanceSetStatsTracker>> p;
     bool operator==(std::nullptr_t) const { return !p; }
@@ -647,6 +707,46 @@ static void reaper_proactive(const std::vector<Entry<String, ModelRecord>> &regi
     if (proactiveLoadCandidates != null && !proactiveLoadCandidates.isEmpty()) {  // :6471
 #include "../_ref/gen/reaper_dispatch_fragment.inc"
     }
+}
+
+// ---- a5, continued (needs PLACEMENT_ORDER and Maps from above)
+boolean SortedClusterState::add(const Entry<String, InstanceRecord> &e) const
+{
+    auto it = std::lower_bound(v->begin(), v->end(), e, [](const Entry<String, InstanceRecord> &a, const Entry<String, InstanceRecord> &b) { return placement_order_compare(a, b) < 0; });
+    if (it != v->end() && placement_order_compare(*it, e) == 0) return false;
+    v->insert(it, e);
+    return true;
+}
+static void handleInstanceTableChange(const SortedClusterState &clusterState, EventType type, const String &key, InstanceRecord record)
+{
+    // typeConstraints == null here (the subset-stats branches compile against these and are not run: rows a18 / f-4)
+    const struct {
+        bool operator!=(std::nullptr_t) const { return false; }
+        InstanceSetStatsTracker getStatsForLabels(const StringArray &) const { return null; }
+        InstanceSetStatsTracker instanceAdded(const String &, const StringArray &, boolean) const { return null; }
+        void instanceRemoved(const String &, const StringArray &) const {}
+    } typeConstraints;
+    const struct {
+        void instanceRemoved(const String &, const InstanceRecord &) const { g_upgrade_removed++; }
+        void instanceAdded(const String &, const InstanceRecord &) const { g_upgrade_added++; }
+        void doHousekeeping() const { g_housekeepings++; }
+    } upgradeTracker;
+    struct LeaderElection {
+        LeaderElection() {}
+        LeaderElection(std::nullptr_t) {}
+        bool operator!=(std::nullptr_t) const { return false; }
+        boolean isLeader() const { return false; }
+    };
+    const LeaderElection leaderLatch;
+    const struct { void remove(const String &) const {} } missings;
+    const struct { boolean equals(const String &a, const String &b) const { return a == null ? b == null : (b != null && a.equals(b)); } } Objects;  // java.util.Objects.equals
+    auto publishInstanceRecordAsync = [] { g_republish++; };
+    const struct {
+        void warn(const String &) const {}
+        void debug(const String &) const {}
+        boolean isDebugEnabled() const { return false; }
+    } logger;
+#include "../_ref/gen/handleInstanceTableChange_body.inc"
 }
 
 // ======================================================== I/O ===============================================================
@@ -742,6 +842,13 @@ int main(int argc, char **argv)
         pro_types.push_back(rd<int32_t>(f, (size_t)nt));
     }
     auto pro_pod_part = rd<int32_t>(f, n_pro > 0 ? (size_t)P : 0);
+    // a5: a stream of instance-table listener events from an empty table: (type, instance, its new record); the cluster's stats
+    // and clusterState's order are written every `ck` events and at the end
+    struct TableEvent { int32_t type, pod; mmp_pod_row row; };
+    auto n_ev_v = rd<int64_t>(f, 1);
+    const int64_t n_ev = n_ev_v[0];
+    auto ev_ck = rd<int64_t>(f, n_ev >= 0 ? 1 : 0);
+    auto events = rd<TableEvent>(f, n_ev > 0 ? (size_t)n_ev : 0);
     fclose(f);
 
     std::vector<String> ids(P);
@@ -1128,7 +1235,10 @@ int main(int argc, char **argv)
                 std::vector<std::string> names;
                 for (int32_t t : pro_types[k]) names.push_back(type_name(t));
                 sets.push_back(ProhibitedTypeSet(names));
-                tc.p->push_back(InstanceSetStatsTracker{stats_of(pro_pstats[k]), sets.back()});
+                InstanceSetStatsTracker isst;
+                isst.currentStats = stats_of(pro_pstats[k]);
+                isst.prohibitedTypesSet = sets.back();
+                tc.p->push_back(isst);
             }
             // clusterState with every record's prohibitedTypes set (TypeConstraintManager does this as records arrive)
             auto withsets = std::make_shared<std::vector<Entry<String, InstanceRecord>>>();
@@ -1163,6 +1273,43 @@ int main(int argc, char **argv)
             po.push_back(c.partition);
         }
         wr(o, po);
+    }
+    // ---- a5: clusterStats + clusterState after every checkpoint of the event stream
+    if (n_ev >= 0) {
+        SortedClusterState cs;
+        clusterStatsTracker = InstanceSetStatsTracker();
+        changeCounter = 0;
+        g_upgrade_added = g_upgrade_removed = g_housekeepings = g_republish = 0;
+        clusterStats = ClusterStats(0L, 0L, Long::MAX_VALUE, 0, 0);
+        std::vector<int64_t> co;
+        int64_t n_ck = 0;
+        co.push_back(0);
+        auto checkpoint = [&] {
+            n_ck++;
+            co.push_back(clusterStats.totalCapacity);
+            co.push_back(clusterStats.totalFree);
+            co.push_back(clusterStats.globalLru);
+            co.push_back(clusterStats.instanceCount);
+            co.push_back(clusterStats.modelCopyCount);
+            co.push_back((int64_t)cs.v->size());
+            for (const auto &e : *cs.v) co.push_back(pod_of[e.getKey().str()]);
+        };
+        for (int64_t e = 0; e < n_ev; e++) {
+            const TableEvent &x = events[e];
+            const mmp_pod_row &r = x.row;
+            InstanceRecord rec = x.type == ENTRY_DELETED
+                                     ? InstanceRecord(null)
+                                     : InstanceRecord(r.lru_time, r.capacity, r.used, r.version, r.count, r.loading_threads, r.loading_in_progress, r.rpm,
+                                                      (r.flags & MMP_POD_SHUTTING_DOWN) != 0);
+            handleInstanceTableChange(cs, (EventType)x.type, ids[x.pod], rec);
+            if ((e + 1) % ev_ck[0] == 0 || e + 1 == n_ev) checkpoint();
+        }
+        co[0] = n_ck;
+        co.push_back(g_upgrade_added);
+        co.push_back(g_upgrade_removed);
+        co.push_back(g_housekeepings);
+        co.push_back(g_republish);
+        wr(o, co);
     }
     fclose(o);
     return 0;

@@ -110,14 +110,16 @@ public:
 
 // java.util.Iterator (type-erased)
 template <class T> class Iterator {
-    struct Rep { std::function<bool()> has; std::function<T()> nxt; };
+    struct Rep { std::function<bool()> has; std::function<T()> nxt; std::function<void()> rem; };
     std::shared_ptr<Rep> p;
 
 public:
     Iterator() {}
-    Iterator(std::function<bool()> h, std::function<T()> n) : p(std::make_shared<Rep>(Rep{std::move(h), std::move(n)})) {}
+    Iterator(std::function<bool()> h, std::function<T()> n, std::function<void()> r = nullptr)
+        : p(std::make_shared<Rep>(Rep{std::move(h), std::move(n), std::move(r)})) {}
     boolean hasNext() const { return p->has(); }
     T next() const { return p->nxt(); }
+    void remove() const { p->rem(); }  // removes the element next() returned last
 };
 template <class C, class T = typename C::value_type> static Iterator<T> iterate(std::shared_ptr<C> c)
 {

@@ -36,7 +36,8 @@ def proactive_inputs(fleet, units, partitioned):
     return units, g, pst, [sorted(s) for s in sets], pts
 
 
-def run(blob: bytes, n_place: int, n_serve: int, n_gate: int = 0, n_scale: int = -1, n_pods: int = 0, n_sd: int = -1, proactive: bool = False):
+def run(blob: bytes, n_place: int, n_serve: int, n_gate: int = 0, n_scale: int = -1, n_pods: int = 0, n_sd: int = -1, proactive: bool = False,
+        events: bool = False):
     with tempfile.TemporaryDirectory() as td:
         fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
         open(fin, "wb").write(blob)
@@ -52,6 +53,17 @@ def run(blob: bytes, n_place: int, n_serve: int, n_gate: int = 0, n_scale: int =
     off += 16 * n_serve
     gate = np.frombuffer(raw, "<i4", 2 * n_gate, off).reshape(n_gate, 2).copy()
     off += 8 * n_gate
+    if events:  # per checkpoint: 5 stats words, n, n instance indices (clusterState order); then 4 counters
+        w = np.frombuffer(raw, "<i8", (len(raw) - off) // 8, off)
+        n_ck, i = int(w[0]), 1
+        stats, orders = [], []
+        for _ in range(n_ck):
+            stats.append(w[i: i + 5].copy())
+            n = int(w[i + 5])
+            orders.append(w[i + 6: i + 6 + n].astype(np.int32))
+            i += 6 + n
+        assert i + 4 == len(w)
+        return np.array(stats).reshape(n_ck, 5), orders, w[i: i + 4].copy()
     if proactive:
         n_calls = int(np.frombuffer(raw, "<i8", 1, off)[0])
         calls = np.frombuffer(raw, "<i8", 3 * n_calls, off + 8).reshape(n_calls, 3).copy()
@@ -131,6 +143,18 @@ def main():
         out[f"{name}/digest"] = np.frombuffer(rf.digest(blob).encode(), np.uint8)
         names.append(name)
         print(f"{name}: {fleet.n_models} registry rows: {len(calls)} proactive loads over {len(np.unique(calls[:, 2])) if len(calls) else 0} instance subset(s)")
+    for name, fleet, ids, ev, ck, tables in rf.table_event_cases():
+        blob = rf.input_blob(fleet, ids, events=(ev, ck))
+        stats, orders, counters = run(blob, 0, 0, events=True)
+        assert len(orders) == len(tables)
+        out[f"{name}/stats"] = stats
+        out[f"{name}/order_len"] = np.array([len(o) for o in orders], np.int32)
+        out[f"{name}/orders"] = np.concatenate(orders) if orders else np.zeros(0, np.int32)
+        out[f"{name}/counters"] = counters
+        out[f"{name}/digest"] = np.frombuffer(rf.digest(blob).encode(), np.uint8)
+        names.append(name)
+        print(f"{name}: {len(ev)} listener events, {len(orders)} checkpoints; upgradeTracker added/removed {counters[0]}/{counters[1]}, "
+              f"housekeepings {counters[2]}")
     out["names"] = np.array(names)
     out["manifest"] = np.array(open(os.path.join(ROOT, "oracle", "_ref", "gen", "MANIFEST.txt")).read())
     np.savez_compressed(OUT, **out)

@@ -333,7 +333,92 @@ def proactive_cases():
         yield f"proactive_parts_{seed}", fleet, string_ids(fleet, 95 + seed), 6400, True
 
 
-def input_blob(fleet, ids, reqs=None, extra=None, serve=None, gates=None, scaleup=None, scaledown=None, proactive=None) -> bytes:
+TABLE_EVENT = np.dtype([("type", "<i4"), ("pod", "<i4"), ("row", _lib.POD_ROW)])  # type: 0 ENTRY_ADDED, 1 ENTRY_UPDATED, 2 ENTRY_DELETED
+
+
+def table_event_cases():
+    """(name, fleet, ids, events, checkpoint_every, tables): a stream of instance-table listener events (MM.java:1455-1568) from
+    an empty table — every instance added, then records republished (load / used / count / lruTime change, an emptied cache,
+    shutdown announcements), instances deleted and re-added.  tables[k] = the instance table (rows + flags) as it stands at
+    checkpoint k, for the implementations that take a table rather than events."""
+    for seed, pods, n_ev, ck in ((0, 6, 60, 1), (1, 40, 600, 7), (2, 300, 3000, 100), (3, 300, 3000, 250)):
+        rng = np.random.default_rng(400 + seed)
+        fleet = wl.fuzz_fleet(seed + 30, pods=pods, models=50, profile=[None, "full", "pref", None][seed])
+        fleet.n_types, fleet.allowed, fleet.prefer = 0, None, None
+        fleet.has_allowed = fleet.has_prefer = None
+        ids = string_ids(fleet, 60 + seed)
+        now = fleet.now
+        rows = fleet.pods.copy()
+        rows["flags"] = _lib_flag_live()
+        cur = rows.copy()
+        present = np.zeros(pods, bool)
+        ev = np.zeros(pods + n_ev, dtype=TABLE_EVENT)
+        tables = []
+
+        def snapshot():
+            t = cur.copy()
+            t["flags"] = np.where(present, t["flags"], 4)  # absent: tombstone
+            tables.append(t)
+        k = 0
+        for i in rng.permutation(pods):
+            ev[k] = (0, i, cur[i])
+            present[i] = True
+            k += 1
+            if k % ck == 0:
+                snapshot()
+        while k < len(ev):
+            i = int(rng.integers(0, pods))
+            u = rng.random()
+            if not present[i]:
+                r = rows[i].copy()
+                r["flags"] = _lib_flag_live()
+                cur[i] = r
+                ev[k] = (0, i, r)
+                present[i] = True
+            elif u < 0.12:
+                ev[k] = (2, i, cur[i])
+                present[i] = False
+            elif u < 0.18:  # announces its shutdown: the listener treats the update as a delete (:1462-1464)
+                r = cur[i].copy()
+                r["flags"] = r["flags"] | 1
+                ev[k] = (1, i, r)
+                present[i] = False
+            elif u < 0.22:  # republished unchanged: "Identical instance record already exists" (:1505-1509)
+                ev[k] = (1, i, cur[i])
+            else:
+                r = cur[i].copy()
+                what = rng.integers(0, 6)
+                if what == 0:
+                    r["used"] = min(int(r["capacity"]), max(0, int(r["used"]) + int(rng.integers(-40_000, 40_000))))
+                elif what == 1:
+                    r["count"] = max(0, int(r["count"]) + int(rng.integers(-3, 4)))
+                elif what == 2:
+                    r["lru_time"] = now - int(rng.integers(1_000, 80_000_000))
+                elif what == 3:
+                    r["count"], r["used"], r["lru_time"] = 0, 0, 2**63 - 1  # emptied cache
+                elif what == 4:
+                    r["loading_in_progress"] = int(rng.integers(0, 9))
+                    r["rpm"] = int(rng.choice([0, 50, 400, 9000]))
+                else:
+                    r["lru_time"] = 0  # a record that never reported one: not counted in the global LRU (InstanceSetStatsTracker:58)
+                # (a FULL record without an lruTime does not occur — a full cache has an oldest entry — and it is the one shape
+                # under which PLACEMENT_ORDER's version rule, :4654-4660, is not transitive: a skip-list set then keeps whatever
+                # order its insertion history produced, and libmmplace refuses such a table with MMP_EORDER)
+                if int(r["lru_time"]) == 0 and int(r["capacity"]) - int(r["used"]) < fleet.min_space_units:
+                    r["lru_time"] = now - int(rng.integers(1_000, 80_000_000))
+                cur[i] = r
+                ev[k] = (1, i, r)
+            k += 1
+            if k % ck == 0 or k == len(ev):
+                snapshot()
+        yield f"table_events_{seed}", fleet, ids, ev, ck, tables
+
+
+def _lib_flag_live():
+    return 2  # MMP_POD_LIVE
+
+
+def input_blob(fleet, ids, reqs=None, extra=None, serve=None, gates=None, scaleup=None, scaledown=None, proactive=None, events=None) -> bytes:
     """The harness' input file (layout: oracle/ref_harness/harness.cc main())."""
     P, M = fleet.n_pods, fleet.n_models
     T = int(fleet.n_types)
@@ -394,6 +479,12 @@ def input_blob(fleet, ids, reqs=None, extra=None, serve=None, gates=None, scaleu
             parts += [np.ascontiguousarray(pstats[k: k + 1]).tobytes(), struct.pack("<q", len(t)), t.tobytes()]
         if len(ptypes):
             parts += [np.ascontiguousarray(pod_part, dtype=np.int32).tobytes()]
+    if events is None:
+        parts += [struct.pack("<q", -1)]
+    else:
+        ev, ck = events
+        assert ev.dtype.itemsize == 72
+        parts += [struct.pack("<qq", len(ev), int(ck)), np.ascontiguousarray(ev).tobytes()]
     return b"".join(parts)
 
 

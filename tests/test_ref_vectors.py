@@ -254,3 +254,33 @@ def test_proactive_plan_equals_the_reference_text(ref):
         assert got.shape == want.shape and np.array_equal(got, want), (name, got[:5], want[:5])
         total += len(want)
     assert total > 3000
+
+
+STAT_FIELDS = ("total_capacity", "total_free", "global_lru", "instance_count", "model_copy_count")
+
+
+def ref_checkpoints(ref, name):
+    stats, lens, flat = ref[f"{name}/stats"], ref[f"{name}/order_len"], ref[f"{name}/orders"]
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    return [(stats[k], flat[offs[k]: offs[k + 1]]) for k in range(len(lens))]
+
+
+def test_instance_table_listener_equals_the_reference_text(ref):
+    """handleInstanceTableChange (MM.java:1456-1567) + InstanceSetStatsTracker (:54, :58-60, :64-71, :75-83, :87-91) fed an event
+    stream: after every checkpoint, clusterStats (maintained by deltas, the LRU rescanned) and clusterState's order (a skip-list
+    set under PLACEMENT_ORDER, updated entry by entry) equal what the oracle computes from the TABLE as it then stands."""
+    import copy
+    n = 0
+    for name, fleet, ids, ev, ck, tables in rf.table_event_cases():
+        assert rf.digest(rf.input_blob(fleet, ids, events=(ev, ck))) == bytes(ref[f"{name}/digest"]).decode(), name
+        cps = ref_checkpoints(ref, name)
+        assert len(cps) == len(tables)
+        for k, (want_stats, want_order) in enumerate(cps):
+            f = copy.copy(fleet)
+            f.pods = tables[k]
+            orc = OracleFleet(f)
+            assert np.array_equal(orc.order, want_order), (name, k)
+            st = orc.stats()
+            assert [int(st[x]) for x in STAT_FIELDS] == [int(v) for v in want_stats], (name, k, st, want_stats)
+            n += 1
+    assert n > 150

@@ -98,3 +98,33 @@ def test_hip_proactive_plan_equals_the_reference_text(ref):
             s.close()
         want = ref[f"{name}/proactive"]
         assert got.shape == want.shape and np.array_equal(got, want), (name, got[:5], want[:5])
+
+
+def test_hip_instance_table_equals_the_reference_text(ref):
+    """The listener's event stream against the library's table: per checkpoint the rows that changed since the last one go in
+    through mmp_pods_upsert / mmp_pods_remove, a commit re-ranks; order and ClusterStats equal the reference text's."""
+    from tests.test_ref_vectors import STAT_FIELDS, ref_checkpoints
+    for name, fleet, ids, ev, ck, tables in rf.table_event_cases():
+        cps = ref_checkpoints(ref, name)
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            prev = None
+            for k, (want_stats, want_order) in enumerate(cps):
+                t = tables[k]
+                if prev is None:
+                    s.load_pods(t)
+                else:
+                    ch = np.flatnonzero(t != prev).astype(np.int32)
+                    gone = ch[(t["flags"][ch] & 4) != 0]
+                    upd = ch[(t["flags"][ch] & 4) == 0]
+                    if len(upd):
+                        s.upsert_pods(upd, t[upd])
+                    if len(gone):
+                        s.remove_pods(gone)
+                s.commit()
+                prev = t
+                assert np.array_equal(s.order(), want_order), (name, k)
+                st = s.stats()
+                assert [int(st[x]) for x in STAT_FIELDS] == [int(v) for v in want_stats], (name, k, st, want_stats)
+        finally:
+            s.close()
