@@ -1,8 +1,8 @@
 /*
  * mm_gates_oracle.c — CPU restatement of the request-level guards around instance selection
  * (SURVEY.md §8 rows a10, a11, a14, a20).  TEST INFRASTRUCTURE ONLY (parity checker).
- * Parity unpinned by the reference's tests except indirectly (ModelMeshLoadFailureTest:432-492
- * pins MAX_LOAD_FAILURES); cross-checked by tests/test_gates.py.
+ * Pinning: held to the reference's own text (oracle/ref_harness -> tests/golden/ref_getnext.npz, tests/test_ref_vectors.py:
+ * 12 000 guarded requests); ModelMeshLoadFailureTest:432-492 pins MAX_LOAD_FAILURES; cross-checked by tests/test_gates.py.
  */
 #include <stdlib.h>
 #include <string.h>

@@ -13,11 +13,13 @@
  *   - eviction / capacity arithmetic: pinned against the reference's own
  *     known-answer tests (EvictionsModelMeshTest.java:36-125,
  *     ModelMeshEvictionsTest.java:156-280) — see tests/test_oracle_kat.py.
- *   - PLACEMENT_ORDER, load-target shortlist, rpm filter, serve-target choice:
- *     PARITY UNPINNED — the reference has no test that names them and the
- *     reference (Java 21 + un-vendored kv-utils/litelinks + etcd) cannot be
- *     built or run here.  Pinned only by a second, independently written
- *     restatement (oracle/py_oracle.py) that must agree on random snapshots.
+ *   - PLACEMENT_ORDER, the filter, the load-target shortlist, the rpm filter, the
+ *     serve-target choice, ClusterStats: no reference test names them and no JVM
+ *     exists here; PINNED TO THE REFERENCE'S OWN TEXT since round 3 — the Java
+ *     method bodies, cut from /root/reference at build time, run compiled against
+ *     stand-ins (oracle/ref_harness -> tests/golden/ref_getnext.npz) and
+ *     tests/test_ref_vectors.py holds this restatement to those vectors.  A second,
+ *     independently written restatement (oracle/py_oracle.py) must agree too.
  *
  * All arithmetic is Java semantics: int64/int32 two's-complement wrap, '/'
  * truncating toward zero, '>>' arithmetic.
