@@ -579,68 +579,74 @@ def secondary_kernels_leg(fleet, solver, device: int, workload: str = "C3", reps
         # a12 stateless eviction evaluations over one clhm deque per pod
         cs = wl.ChurnStream(fleet, 0xC5)
         solver.load_caches(cs.seg_off, cs.cache_lu, cs.cache_wt, cs.cache_cap)
-        n = 100_000
-        ev = np.zeros(n, dtype=_lib.EVICT_REQ)
-        ev["cache"] = rng.integers(0, P, n)
-        ev["weight"] = np.minimum(cs.size_units[rng.integers(0, M, n)], 2**31 - 1)
-        ev["last_used"] = np.where(rng.random(n) < 0.7, 0, now - rng.integers(1, 7_200_000, n))
-        e_of = np.diff(cs.seg_off).astype(np.int64)[ev["cache"]]
-        timed("evict_batch_kernel", lambda: solver.evict(ev, now), int((12 * e_of + 16).sum()), n,
-              "eviction evaluations", "SURVEY 8(d): 12*E + 16 bytes per evaluation; the deques (2.4 MB) are L2 resident")
+        # the same three kernels at two launch sizes: 100k units (391 workgroups: the launch lasts one dependent chain, like the
+        # 100k place launch) and 800k (3125 workgroups: the size of a bench step, which covers the chip)
+        def per_request_kernels(n, tag):
+            ev = np.zeros(n, dtype=_lib.EVICT_REQ)
+            ev["cache"] = rng.integers(0, P, n)
+            ev["weight"] = np.minimum(cs.size_units[rng.integers(0, M, n)], 2**31 - 1)
+            ev["last_used"] = np.where(rng.random(n) < 0.7, 0, now - rng.integers(1, 7_200_000, n))
+            e_of = np.diff(cs.seg_off).astype(np.int64)[ev["cache"]]
+            timed("evict_batch_kernel" + tag, lambda: solver.evict(ev, now), int((12 * e_of + 16).sum()), n,
+                  "eviction evaluations", "SURVEY 8(d): 12*E + 16 bytes per evaluation; the deques (2.4 MB) are L2 resident")
 
-        # a9 serve-target decisions
-        sr = np.zeros(n, dtype=_lib.SERVE_REQ)
-        sr["model"] = rng.integers(0, M, n)
-        sr["self_pod"] = rng.integers(0, P, n)
-        sr["flags"] = rng.integers(0, 4, n)
-        sr["local_in_flight"] = rng.integers(0, 3, n)
-        sr["last_invoke_time"] = now - rng.choice([0, 10, 1000], n)
-        sr["assume_completed_ms"] = 3000
-        in_use = rng.integers(0, 3, P).astype(np.int32)
-        last_used = (now - rng.integers(0, 10_000, P)).astype(np.int64)
-        kk = m["n_loaded"][sr["model"]].astype(np.int64)
-        z32, z64 = np.zeros(0, np.int32), np.zeros(0, np.int64)
-        srk, counters = solver.serve_counters(sr, in_use, last_used)  # what the host assembles: one entry per listed copy
-        timed("serve_batch_kernel", lambda: solver.serve_k(srk, counters, z32, z64, now),
-              int((48 + 16 + 24 + 28 * kk).sum()), n, "serve-target decisions",
-              "request 48 B + model row 24 B + (entry 12 B + counter 16 B) per copy + result 16 B; nothing indexed by the instance table")
-        # the seam the LB uses: one request per call (ForwardingLB.getNext, MM.java:4315) through a latency slot
-        one, cnt1 = srk[:1].copy(), counters[int(srk["cnt_off"][0]): int(srk["cnt_off"][0]) + int(srk["n_cnt"][0])].copy()
-        one["cnt_off"] = 0
-        lat = []
-        for _ in range(200):
-            solver.serve_k(one, cnt1, z32, z64, now)
-        for _ in range(3000):
-            t0 = time.perf_counter_ns()
-            solver.serve_k(one, cnt1, z32, z64, now)
-            lat.append(time.perf_counter_ns() - t0)
-        out.append({"kernel": "serve_single", "p50_us": float(np.percentile(lat, 50)) / 1e3, "p99_us": float(np.percentile(lat, 99)) / 1e3,
-                    "bytes_in": int(48 + 16 * len(cnt1)), "unit": "serve-target decision",
-                    "note": "mmp_serve_batch(n = 1) through a latency slot: 48 B + 16 B per listed copy cross the boundary (round 2: two P-sized arrays)"})
+            # a9 serve-target decisions
+            sr = np.zeros(n, dtype=_lib.SERVE_REQ)
+            sr["model"] = rng.integers(0, M, n)
+            sr["self_pod"] = rng.integers(0, P, n)
+            sr["flags"] = rng.integers(0, 4, n)
+            sr["local_in_flight"] = rng.integers(0, 3, n)
+            sr["last_invoke_time"] = now - rng.choice([0, 10, 1000], n)
+            sr["assume_completed_ms"] = 3000
+            in_use = rng.integers(0, 3, P).astype(np.int32)
+            last_used = (now - rng.integers(0, 10_000, P)).astype(np.int64)
+            kk = m["n_loaded"][sr["model"]].astype(np.int64)
+            z32, z64 = np.zeros(0, np.int32), np.zeros(0, np.int64)
+            srk, counters = solver.serve_counters(sr, in_use, last_used)  # what the host assembles: one entry per listed copy
+            timed("serve_batch_kernel" + tag, lambda: solver.serve_k(srk, counters, z32, z64, now),
+                  int((48 + 16 + 24 + 28 * kk).sum()), n, "serve-target decisions",
+                  "request 48 B + model row 24 B + (entry 12 B + counter 16 B) per copy + result 16 B; nothing indexed by the instance table")
+            # the seam the LB uses: one request per call (ForwardingLB.getNext, MM.java:4315) through a latency slot
+            lat = []
+            one, cnt1 = srk[:1].copy(), counters[int(srk["cnt_off"][0]): int(srk["cnt_off"][0]) + int(srk["n_cnt"][0])].copy()
+            one["cnt_off"] = 0
+            for _ in range(200 if not tag else 0):
+                solver.serve_k(one, cnt1, z32, z64, now)
+            for _ in range(3000 if not tag else 0):
+                t0 = time.perf_counter_ns()
+                solver.serve_k(one, cnt1, z32, z64, now)
+                lat.append(time.perf_counter_ns() - t0)
+            if lat:
+                out.append({"kernel": "serve_single", "p50_us": float(np.percentile(lat, 50)) / 1e3, "p99_us": float(np.percentile(lat, 99)) / 1e3,
+                            "bytes_in": int(48 + 16 * len(cnt1)), "unit": "serve-target decision",
+                            "note": "mmp_serve_batch(n = 1) through a latency slot: 48 B + 16 B per listed copy cross the boundary (round 2: two P-sized arrays)"})
 
-        # a10 / a11 / a14 / a20 request guards
-        g = np.zeros(n, dtype=_lib.GATE_REQ)
-        g["model"] = rng.integers(0, M, n)
-        g["self_pod"] = rng.integers(0, P, n)
-        g["flags"] = rng.integers(0, 512, n)
-        g["size_hint"] = rng.choice([0, 6400], n)
-        g["cache_capacity"] = 8_388_608
-        g["cache_weighted_size"] = rng.integers(0, 8_388_608, n)
-        g["cache_oldest_time"] = now - rng.integers(1, 5_000_000, n)
-        g["loader_predicted"] = 6400
-        g["loading_count"] = rng.integers(0, 20, n)
-        g["weight_predict_cutoff"] = 10
-        g["loaded_time"] = now - rng.integers(1, 5_000_000, n)
-        g["load_timeout_ms"] = 90_000
-        cur = fleet.pods[g["self_pod"]]
-        for a, b in (("fresh_lru", "lru_time"), ("fresh_capacity", "capacity"), ("fresh_used", "used"),
-                     ("fresh_count", "count"), ("fresh_loading_threads", "loading_threads"),
-                     ("fresh_in_progress", "loading_in_progress"), ("fresh_rpm", "rpm")):
-            g[a] = cur[b]
-        g["last_published"] = now - rng.integers(500, 170_000, n)
-        timed("gate_batch_kernel", lambda: solver.gates(g, z32, z64, z32, now),
-              int((144 + 8 + 24 + 12 * k_of[g["model"]]).sum()), n, "guarded requests",
-              "request 144 B + model row 24 B + 12 B per entry + result 8 B")
+            # a10 / a11 / a14 / a20 request guards
+            g = np.zeros(n, dtype=_lib.GATE_REQ)
+            g["model"] = rng.integers(0, M, n)
+            g["self_pod"] = rng.integers(0, P, n)
+            g["flags"] = rng.integers(0, 512, n)
+            g["size_hint"] = rng.choice([0, 6400], n)
+            g["cache_capacity"] = 8_388_608
+            g["cache_weighted_size"] = rng.integers(0, 8_388_608, n)
+            g["cache_oldest_time"] = now - rng.integers(1, 5_000_000, n)
+            g["loader_predicted"] = 6400
+            g["loading_count"] = rng.integers(0, 20, n)
+            g["weight_predict_cutoff"] = 10
+            g["loaded_time"] = now - rng.integers(1, 5_000_000, n)
+            g["load_timeout_ms"] = 90_000
+            cur = fleet.pods[g["self_pod"]]
+            for a, b in (("fresh_lru", "lru_time"), ("fresh_capacity", "capacity"), ("fresh_used", "used"),
+                         ("fresh_count", "count"), ("fresh_loading_threads", "loading_threads"),
+                         ("fresh_in_progress", "loading_in_progress"), ("fresh_rpm", "rpm")):
+                g[a] = cur[b]
+            g["last_published"] = now - rng.integers(500, 170_000, n)
+            timed("gate_batch_kernel" + tag, lambda: solver.gates(g, z32, z64, z32, now),
+                  int((144 + 8 + 24 + 12 * k_of[g["model"]]).sum()), n, "guarded requests",
+                  "request 144 B + model row 24 B + 12 B per entry + result 8 B")
+
+        per_request_kernels(100_000, "")
+        per_request_kernels(800_000, " (800k per launch)")
 
         # a17 leader proactive-load plan over the whole registry
         timed("proactive_plan (space reduction + compaction + radix sort + distinct top-K)",
