@@ -43,12 +43,21 @@ timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY S
 timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM --kernel-trace --output-format csv -d /tmp/p_full/sq2 -- python bench.py --steps 20 --warmup 5 --no-pod-axis --no-cpu-baseline > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_full/f -- python bench.py --steps 20 --warmup 5 --no-pod-axis --no-cpu-baseline > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_full/w -- python bench.py --steps 20 --warmup 5 --no-pod-axis --no-cpu-baseline > /dev/null 2>&1
-for k in serve_batch_kernel gate_batch_kernel evict_batch_kernel cache_replay_kernel; do
-  # (the 100k-unit launches of the `kernels` leg only: the run also makes single-request and mixed-size launches of these kernels)
-  (python tools/sq_summary.py /tmp/p_full/sq1 $k 50000; python tools/sq_summary.py /tmp/p_full/sq2 $k 50000) > $OUT/sq_$k.jsonl
-  python tools/pmc_summary.py /tmp/p_full/f /tmp/p_full/w $k $OUT/pmc_$k.json 1000 > /dev/null
-  echo "$k: $(cut -c1-200 $OUT/sq_$k.jsonl | head -1)"
-done
+# per-kernel digests by launch size in WORK-ITEMS (the run launches these kernels for single requests, for the churn leg's mixed
+# sizes, and for the `kernels` leg at 100k and 800k units): serve / gate one lane per unit, evict 8 lanes per evaluation, cache
+# replay one wavefront per cache (10k caches)
+digest() {  # $1 kernel, $2 file tag, $3 min work-items, $4 max work-items
+  (python tools/sq_summary.py /tmp/p_full/sq1 $1 $3 $4; python tools/sq_summary.py /tmp/p_full/sq2 $1 $3 $4) > $OUT/sq_$2.jsonl
+  python tools/pmc_summary.py /tmp/p_full/f /tmp/p_full/w $1 $OUT/pmc_$2.json 0 $3 $4 > /dev/null
+  echo "$2: $(cut -c1-160 $OUT/sq_$2.jsonl | head -1) | $(python -c "import json; d=json.load(open('$OUT/pmc_$2.json')); print(d['launches_fetch_pass'], d['traffic_bytes_per_launch'])")"
+}
+digest serve_batch_kernel serve_batch_kernel 50000 400000
+digest gate_batch_kernel gate_batch_kernel 50000 400000
+digest evict_batch_kernel evict_batch_kernel 500000 2000000
+digest cache_replay_kernel cache_replay_kernel 50000 2000000
+digest serve_batch_kernel serve_batch_kernel_800k 500000 2000000
+digest gate_batch_kernel gate_batch_kernel_800k 500000 2000000
+digest evict_batch_kernel evict_batch_kernel_800k 3000000 1000000000
 
 # the bench lines: the driver's flags, then the defaults; C4
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_C3_n1_steps20.json.log 2> $OUT/bench_C3_steps20.err; echo "bench(20) exit $?"
