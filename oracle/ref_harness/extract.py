@@ -80,6 +80,11 @@ RANGES = [
     ("ist_remove_body", "src/main/java/com/ibm/watson/modelmesh/InstanceSetStatsTracker.java", 75, 83, "count--;", "return count <= 0;"),
     ("ist_update_body", "src/main/java/com/ibm/watson/modelmesh/InstanceSetStatsTracker.java", 87, 91, "ClusterStats newStats = new ClusterStats(totalCapacity, totalFree, lru, count, modelCount);", "return newStats;"),
     ("handleInstanceTableChange_body", MM, 1456, 1567, "if (logger.isDebugEnabled()) {", "}", "LISTENER_SWITCH"),
+    # ---- a19: UpgradeTracker (replica sets that a rolling update is replacing)
+    ("upgrade_constants", "src/main/java/com/ibm/watson/modelmesh/UpgradeTracker.java", 48, 50, "TEN_MINS = 600_000L;", "TWENTY_MINS = 1200_000L;"),
+    ("upgrade_instanceRemoved_body", "src/main/java/com/ibm/watson/modelmesh/UpgradeTracker.java", 86, 114, "if (iid.length() < 7) {", "}", "STREAMS"),
+    ("upgrade_instanceAdded_body", "src/main/java/com/ibm/watson/modelmesh/UpgradeTracker.java", 121, 186, "if (iid.length() < 7) {", "}", "STREAMS"),
+    ("upgrade_doHousekeeping_body", "src/main/java/com/ibm/watson/modelmesh/UpgradeTracker.java", 193, 200, "// Check for and remove expired entries", "}", "STREAMS"),
     # ---- a17: the leader's reaper — proactive loading of unloaded models
     ("modeltoload_compareTo_body", MM, 6407, 6407, "return Long.compare(m.lastUsed, lastUsed);", "lastUsed);"),
     ("reaper_candidates_prologue", MM, 6456, 6463, "ClusterStats globalStats = clusterStats;", "}"),
@@ -102,6 +107,24 @@ EXTRA_RULES = {
         (re.compile(r"^(\s*)break;\s*$"), r"\1;  // break;"),
     ],
 }
+
+# Java streams and expression lambdas of UpgradeTracker (:141-154, :196-197): lambda SYNTAX only — `(a, b)` / `x ->` become C++
+# lambda heads, an expression body gets its `return` and braces (where the expression spans lines, on the line it ends on),
+# `Entry::getKey` / `Collectors.toSet()` become methods of the stand-in stream
+EXTRA_RULES["STREAMS"] = [
+    (re.compile(r"\.max\(\(rs1, rs2\)\s*$"), ".max([=](auto rs1, auto rs2)"),
+    (re.compile(r"^(\s*)->\s*(Long\.compare\(rs1\.earliestStartTime, rs2\.earliestStartTime\))\)\.get\(\);"), r"\1{ return \2; }).get();"),
+    (re.compile(r"\.filter\(e -> "), ".filter([=](auto e) { return "),
+    (re.compile(r"(\|\| e\.getValue\(\)\.lastChangeTime > now - FIFTEEN_MINS\))\)\s*$"), r"\1; })"),
+    (re.compile(r"\.map\(Entry::getKey\)\.collect\(Collectors\.toSet\(\)\)"), ".map_getKey().collect_toSet()"),
+    (re.compile(r"anySatisfy\(expires -> now >= expires\)"), "anySatisfy([=](auto expires) { return now >= expires; })"),
+    (re.compile(r"reject\(\(r, expires\) -> now >= expires\)"), "reject([=](auto r, auto expires) { return now >= expires; })"),
+    (re.compile(r"\bnew ObjectLongHashMap<>\("), "ObjectLongHashMap_new("),
+    (re.compile(r"\bnew PerTypeLabelStats\(\)"), "PerTypeLabelStats::make()"),
+    (re.compile(r"\bnew ReplicaSetStats\(\)"), "ReplicaSetStats::make()"),
+    (re.compile(r"\bMap\.Entry\b"), "Entry"),
+    (re.compile(r"\bSystem\.currentTimeMillis\(\)"), "currentTimeMillis()"),
+]
 
 # token-level rewrites, applied in order to every extracted line
 RULES = [

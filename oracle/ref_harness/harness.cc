@@ -54,6 +54,8 @@ public:
     bool operator==(std::nullptr_t) const { return !p; }
     bool operator!=(std::nullptr_t) const { return (bool)p; }
     long getUsed() const { return p->used; }
+    long a19_startTime = 0;  // InstanceRecord.startTime (row a19 reads it; the record's other users never do)
+    long getStartTime() const { return a19_startTime; }
     bool operator==(const InstanceRecord &o) const { return p == o.p; }  // Java `==` on references: identity
     long getLruTime() const { return p->lruTime; }
     long getCapacity() const { return p->capacity; }
@@ -630,6 +632,116 @@ static int changeCounter;
 static int g_upgrade_added, g_upgrade_removed, g_housekeepings, g_republish;
 static void handleInstanceTableChange(const SortedClusterState &clusterState, EventType type, const String &key, InstanceRecord record);
 
+// ======================= a19: UpgradeTracker (UpgradeTracker.java:45-201) ============================================================
+namespace a19 {
+#include "../_ref/gen/upgrade_constants.inc"
+struct LongField {  // an assignable long field of an object with reference semantics
+    std::shared_ptr<long> p;
+    explicit LongField(long v = 0) : p(std::make_shared<long>(v)) {}
+    operator long() const { return *p; }
+    const LongField &operator=(long v) const { *p = v; return *this; }
+};
+struct CountField {
+    std::shared_ptr<int> p = std::make_shared<int>(0);
+    operator int() const { return *p; }
+    int operator--(int) const { return (*p)--; }
+    int operator++(int) const { return (*p)++; }
+};
+struct ReplicaSetStats {  // :52-57
+    bool isnull = true;
+    CountField size;
+    LongField earliestStartTime{Long::MAX_VALUE}, latestStartTime, lastChangeTime;
+    ReplicaSetStats() {}
+    ReplicaSetStats(std::nullptr_t) {}
+    static ReplicaSetStats make() { ReplicaSetStats r; r.isnull = false; return r; }
+    bool operator==(std::nullptr_t) const { return isnull; }
+    bool operator!=(std::nullptr_t) const { return !isnull; }
+};
+template <class X> struct Optional { X v; X get() const { return v; } };
+template <class X> struct StreamOf {
+    std::vector<X> v;
+    template <class C> Optional<X> max(C cmp) const  // Stream.max == reduce(BinaryOperator.maxBy(cmp)): of equals, the first
+    {
+        X best = v[0];
+        for (size_t i = 1; i < v.size(); i++)
+            if (!(cmp(best, v[i]) >= 0)) best = v[i];
+        return Optional<X>{best};
+    }
+    template <class P> StreamOf filter(P pred) const
+    {
+        StreamOf out;
+        for (auto &x : v)
+            if (pred(x)) out.v.push_back(x);
+        return out;
+    }
+    struct Keys {
+        std::vector<String> k;
+        Set<String> collect_toSet() const
+        {
+            Set<String> s = Set<String>::make();
+            for (auto &x : k) s.add(x);
+            return s;
+        }
+    };
+    Keys map_getKey() const
+    {
+        Keys out;
+        for (auto &x : v) out.k.push_back(x.getKey());
+        return out;
+    }
+};
+template <class X> struct CollectionOf { std::vector<X> v; StreamOf<X> stream() const { return StreamOf<X>{v}; }
+                                         typename std::vector<X>::const_iterator begin() const { return v.begin(); }
+                                         typename std::vector<X>::const_iterator end() const { return v.end(); } };
+// PerTypeLabelStats extends HashMap<String, ReplicaSetStats> (:59-64).  Iteration order: by key here (a HashMap's is by hash;
+// the one place the order could matter is Stream.max among replica sets with EQUAL earliestStartTime)
+struct PerTypeLabelStats {
+    std::shared_ptr<std::map<std::string, ReplicaSetStats>> p;
+    PerTypeLabelStats() {}
+    PerTypeLabelStats(std::nullptr_t) {}
+    static PerTypeLabelStats make() { PerTypeLabelStats m; m.p = std::make_shared<std::map<std::string, ReplicaSetStats>>(); return m; }
+    bool operator==(std::nullptr_t) const { return !p; }
+    ReplicaSetStats get(const String &k) const { auto it = p->find(k.str()); return it == p->end() ? ReplicaSetStats(null) : it->second; }
+    void put(const String &k, const ReplicaSetStats &v) const { (*p)[k.str()] = v; }
+    void remove(const String &k) const { p->erase(k.str()); }
+    int size() const { return (int)p->size(); }
+    CollectionOf<ReplicaSetStats> values() const { CollectionOf<ReplicaSetStats> c; for (auto &e : *p) c.v.push_back(e.second); return c; }
+    CollectionOf<Entry<String, ReplicaSetStats>> entrySet() const
+    {
+        CollectionOf<Entry<String, ReplicaSetStats>> c;
+        for (auto &e : *p) c.v.push_back(Entry<String, ReplicaSetStats>(String(e.first), e.second));
+        return c;
+    }
+};
+// Map<String[], PerTypeLabelStats> upgradeTracker = new HashMap<>(1) (:67): arrays hash by IDENTITY — the key is the labels
+// array object (here: the label-set id the event carries; records with the same label set share one interned array)
+static long g_labels_key;
+struct LabelsKey { long id; };
+static struct {
+    std::map<long, PerTypeLabelStats> m;
+    PerTypeLabelStats get(const LabelsKey &k) { auto it = m.find(k.id); return it == m.end() ? PerTypeLabelStats(null) : it->second; }
+    void put(const LabelsKey &k, const PerTypeLabelStats &v) { m[k.id] = v; }
+} upgradeTracker;
+static ObjectLongMap<String> likelyReplacedReplicaSets;  // :71 (= ObjectLongMaps.immutable.empty())
+struct Ir {  // what the tracker reads of an InstanceRecord
+    long startTime;
+    LabelsKey getLabels() const { return LabelsKey{g_labels_key}; }
+    long getStartTime() const { return startTime; }
+};
+static void instanceRemoved(String iid, Ir ir)
+{
+#include "../_ref/gen/upgrade_instanceRemoved_body.inc"
+}
+static void instanceAdded(String iid, Ir ir)
+{
+#include "../_ref/gen/upgrade_instanceAdded_body.inc"
+}
+static void doHousekeeping()
+{
+#include "../_ref/gen/upgrade_doHousekeeping_body.inc"
+}
+}  // namespace a19
+
 // ======================= a17: the leader's reaper — proactive loading (MM.java:6456-6490, :6574-6577, :6616-6747) ===============
 struct ModelToLoad {  // :6393-6409
     String modelId;
@@ -849,6 +961,12 @@ int main(int argc, char **argv)
     const int64_t n_ev = n_ev_v[0];
     auto ev_ck = rd<int64_t>(f, n_ev >= 0 ? 1 : 0);
     auto events = rd<TableEvent>(f, n_ev > 0 ? (size_t)n_ev : 0);
+    // a19: a stream of UpgradeTracker calls: kind 0 instanceAdded, 1 instanceRemoved, 2 doHousekeeping; the likely-replaced map is
+    // written after every call
+    struct UpgradeEvent { int32_t kind, replica_set; int64_t labels_key, start_time, now; };
+    auto n_up_v = rd<int64_t>(f, 1);
+    const int64_t n_up = n_up_v[0];
+    auto upevents = rd<UpgradeEvent>(f, n_up > 0 ? (size_t)n_up : 0);
     fclose(f);
 
     std::vector<String> ids(P);
@@ -889,7 +1007,7 @@ int main(int argc, char **argv)
         std::string key = "~rs" + std::to_string(rs);  // a set no instance belongs to still makes the map non-empty
         for (int64_t i = 0; i < P; i++)
             if (pods[i].replica_set == rs && ids[i].length() >= 7) { key = ids[i].str().substr(0, 6); break; }
-        (*g_replaced.p)[String(key)] = 0;
+        (*g_replaced.p)[key] = 0;
     }
 
     FILE *o = fopen(argv[2], "wb");
@@ -1310,6 +1428,35 @@ int main(int argc, char **argv)
         co.push_back(g_housekeepings);
         co.push_back(g_republish);
         wr(o, co);
+    }
+    // ---- a19: getLikelyReplacedReplicaSets() after every call: n, then (replica set, expiry) by replica set
+    if (n_up >= 0) {
+        a19::upgradeTracker.m.clear();
+        a19::likelyReplacedReplicaSets = ObjectLongMap<String>();
+        std::vector<int64_t> uo;
+        for (int64_t e = 0; e < n_up; e++) {
+            const UpgradeEvent &x = upevents[e];
+            g_now = x.now;
+            a19::g_labels_key = x.labels_key;
+            char idb[32];
+            if (x.replica_set >= 0)
+                snprintf(idb, sizeof idb, "%06d-%03d", x.replica_set, (int)(e % 1000));  // first 6 characters = the replica set (:98, :131)
+            else
+                snprintf(idb, sizeof idb, "i%d", (int)(e % 1000));  // an id of non-standard format (< 7 characters, :86, :121)
+            if (x.kind == 0)
+                a19::instanceAdded(String(idb), a19::Ir{x.start_time});
+            else if (x.kind == 1)
+                a19::instanceRemoved(String(idb), a19::Ir{x.start_time});
+            else
+                a19::doHousekeeping();
+            const auto &m = *a19::likelyReplacedReplicaSets.p;
+            uo.push_back((int64_t)m.size());
+            for (const auto &kv : m) {
+                uo.push_back(std::stoll(kv.first));
+                uo.push_back(kv.second);
+            }
+        }
+        wr(o, uo);
     }
     fclose(o);
     return 0;

@@ -268,14 +268,41 @@ struct Collections {
         return m;
     }
 };
-// org.eclipse.collections ObjectLongMap<String>
+// org.eclipse.collections ObjectLongMap<String> / MutableObjectLongMap / ObjectLongHashMap (one nullable handle class: the
+// immutable views are only ever read)
 template <class K> class ObjectLongMap {
 public:
-    std::shared_ptr<std::unordered_map<String, long, String::Hash, String::Eq>> p =
-        std::make_shared<std::unordered_map<String, long, String::Hash, String::Eq>>();
+    typedef std::map<std::string, long> Rep;
+    std::shared_ptr<Rep> p = std::make_shared<Rep>();
+    ObjectLongMap() {}
+    ObjectLongMap(std::nullptr_t) : p() {}
+    bool operator==(std::nullptr_t) const { return !p; }
+    bool operator!=(std::nullptr_t) const { return (bool)p; }
     boolean isEmpty() const { return p->empty(); }
-    boolean containsKey(const K &k) const { return p->count(k) != 0; }
+    boolean containsKey(const K &k) const { return p->count(k.str()) != 0; }
+    void put(const K &k, long v) const { (*p)[k.str()] = v; }
+    void remove(const K &k) const { p->erase(k.str()); }
+    template <class P> boolean anySatisfy(P pred) const
+    {
+        for (auto &e : *p)
+            if (pred(e.second)) return true;
+        return false;
+    }
+    template <class P> ObjectLongMap reject(P pred) const  // a new map without the rejected entries
+    {
+        ObjectLongMap out;
+        for (auto &e : *p)
+            if (!pred(String(e.first), e.second)) (*out.p)[e.first] = e.second;
+        return out;
+    }
 };
+template <class K> using MutableObjectLongMap = ObjectLongMap<K>;
+template <class K> static ObjectLongMap<K> ObjectLongHashMap_new(const ObjectLongMap<K> &src)  // `new ObjectLongHashMap<>(src)`: a copy
+{
+    ObjectLongMap<K> out;
+    *out.p = *src.p;
+    return out;
+}
 static const struct { struct { ObjectLongMap<String> empty() const { return ObjectLongMap<String>(); } } immutable; } ObjectLongMaps;
 
 // com.google.common.collect.ComparisonChain + Ordering.natural().nullsLast()

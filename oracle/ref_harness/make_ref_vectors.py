@@ -37,7 +37,7 @@ def proactive_inputs(fleet, units, partitioned):
 
 
 def run(blob: bytes, n_place: int, n_serve: int, n_gate: int = 0, n_scale: int = -1, n_pods: int = 0, n_sd: int = -1, proactive: bool = False,
-        events: bool = False):
+        events: bool = False, upgrade: int = -1):
     with tempfile.TemporaryDirectory() as td:
         fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
         open(fin, "wb").write(blob)
@@ -53,6 +53,15 @@ def run(blob: bytes, n_place: int, n_serve: int, n_gate: int = 0, n_scale: int =
     off += 16 * n_serve
     gate = np.frombuffer(raw, "<i4", 2 * n_gate, off).reshape(n_gate, 2).copy()
     off += 8 * n_gate
+    if upgrade >= 0:  # after every call: n, then n x (replica set, expiry)
+        w = np.frombuffer(raw, "<i8", (len(raw) - off) // 8, off)
+        maps, i = [], 0
+        for _ in range(upgrade):
+            n = int(w[i])
+            maps.append(w[i + 1: i + 1 + 2 * n].reshape(n, 2).copy())
+            i += 1 + 2 * n
+        assert i == len(w)
+        return maps
     if events:  # per checkpoint: 5 stats words, n, n instance indices (clusterState order); then 4 counters
         w = np.frombuffer(raw, "<i8", (len(raw) - off) // 8, off)
         n_ck, i = int(w[0]), 1
@@ -155,6 +164,17 @@ def main():
         names.append(name)
         print(f"{name}: {len(ev)} listener events, {len(orders)} checkpoints; upgradeTracker added/removed {counters[0]}/{counters[1]}, "
               f"housekeepings {counters[2]}")
+    small = rf.wl.fuzz_fleet(1, pods=4, models=4)  # the harness wants a fleet in every input; the tracker never looks at it
+    small_ids = rf.string_ids(small, 1)
+    for name, ev in rf.upgrade_event_cases():
+        blob = rf.input_blob(small, small_ids, upgrade=ev)
+        maps = run(blob, 0, 0, upgrade=len(ev))
+        out[f"{name}/map_len"] = np.array([len(m) for m in maps], np.int32)
+        out[f"{name}/maps"] = np.concatenate(maps) if maps else np.zeros((0, 2), np.int64)
+        out[f"{name}/digest"] = np.frombuffer(rf.digest(blob).encode(), np.uint8)
+        names.append(name)
+        print(f"{name}: {len(ev)} tracker calls; the likely-replaced map is non-empty after {int((out[f'{name}/map_len'] > 0).sum())} of them, "
+              f"up to {int(out[f'{name}/map_len'].max())} replica sets")
     out["names"] = np.array(names)
     out["manifest"] = np.array(open(os.path.join(ROOT, "oracle", "_ref", "gen", "MANIFEST.txt")).read())
     np.savez_compressed(OUT, **out)

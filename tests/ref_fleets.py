@@ -414,11 +414,75 @@ def table_event_cases():
         yield f"table_events_{seed}", fleet, ids, ev, ck, tables
 
 
+UPGRADE_EVENT = np.dtype([("kind", "<i4"), ("replica_set", "<i4"), ("labels_key", "<i8"), ("start_time", "<i8"), ("now", "<i8")])
+
+
+def upgrade_event_cases():
+    """(name, events): rolling-update streams for UpgradeTracker (UpgradeTracker.java:85-200; as tests/test_upgrade_gpu.py draws
+    them): instances of a few replica sets under two label sets come and go while the clock advances by 50 ms ... 7 min, with
+    housekeeping passes in between.  kind 0 instanceAdded, 1 instanceRemoved, 2 doHousekeeping."""
+    for seed in range(6):
+        rng = np.random.default_rng(300 + seed)
+        now = 1_760_000_000_000
+        starts, members = {}, []
+        ev = np.zeros(500, dtype=UPGRADE_EVENT)
+        for step in range(500):
+            now += int(rng.choice([50, 5_000, 60_000, 400_000]))
+            r = rng.random()
+            if r < 0.55 or not members:
+                lk = int(rng.choice([0, 0, 0, 7]))
+                rs = int(rng.choice([-1, 0, 1, 2, 3, 4]))
+                if rs not in starts:
+                    starts[rs] = now - int(rng.integers(0, 3_000_000)) * 7 - rs  # distinct per set: no ties in Stream.max
+                st = starts[rs] + int(rng.integers(0, 100_000)) * 11
+                ev[step] = (0, rs, lk, st, now)
+                members.append((lk, rs))
+            elif r < 0.9:
+                lk, rs = members.pop(int(rng.integers(0, len(members))))
+                if rng.random() < 0.1:
+                    lk += 100  # a re-deserialised record: another labels array identity
+                ev[step] = (1, rs, lk, 0, now)
+            else:
+                ev[step] = (2, -1, 0, 0, now)
+        yield f"upgrade_events_{seed}", ev
+    # rolling updates proper: a deployment's old replica set is replaced member by member by a new one (start times now),
+    # a second deployment (other labels) follows with a lag, housekeeping runs every minute, then everything ages out
+    for seed in range(6):
+        rng = np.random.default_rng(900 + seed)
+        now = 1_760_000_000_000
+        rows = []
+        n_old = int(rng.integers(3, 9))
+        for lk, rs_old in ((0, 0), (7, 2)):
+            for _ in range(n_old):
+                rows.append((0, rs_old, lk, now - 86_400_000 - int(rng.integers(0, 3_600_000)), now))
+                now += int(rng.integers(10, 2_000))
+        live = {(0, 0): n_old, (7, 2): n_old}
+        plan = [(0, 0, 1)] * n_old + [(7, 2, 3)] * n_old
+        order = rng.permutation(len(plan)) if seed % 2 else np.arange(len(plan))
+        for j in order:
+            lk, rs_old, rs_new = plan[j]
+            now += int(rng.choice([5_000, 20_000, 45_000, 200_000]))
+            rows.append((0, rs_new, lk, now - int(rng.integers(1_000, 9_000)), now))
+            now += int(rng.integers(500, 30_000))
+            if live[(lk, rs_old)] > 0:
+                rows.append((1, rs_old, lk, 0, now))
+                live[(lk, rs_old)] -= 1
+            if rng.random() < 0.4:
+                now += 60_000
+                rows.append((2, -1, 0, 0, now))
+        for _ in range(6):  # ... and the aftermath: the map's entries expire 15 min after the last change
+            now += int(rng.choice([240_000, 600_000]))
+            rows.append((2, -1, 0, 0, now))
+            rows.append((0, int(rng.choice([1, 3])), int(rng.choice([0, 7])), now - 2_000, now))
+        yield f"upgrade_rolling_{seed}", np.array(rows, dtype=UPGRADE_EVENT)
+
+
 def _lib_flag_live():
     return 2  # MMP_POD_LIVE
 
 
-def input_blob(fleet, ids, reqs=None, extra=None, serve=None, gates=None, scaleup=None, scaledown=None, proactive=None, events=None) -> bytes:
+def input_blob(fleet, ids, reqs=None, extra=None, serve=None, gates=None, scaleup=None, scaledown=None, proactive=None, events=None,
+               upgrade=None) -> bytes:
     """The harness' input file (layout: oracle/ref_harness/harness.cc main())."""
     P, M = fleet.n_pods, fleet.n_models
     T = int(fleet.n_types)
@@ -485,6 +549,11 @@ def input_blob(fleet, ids, reqs=None, extra=None, serve=None, gates=None, scaleu
         ev, ck = events
         assert ev.dtype.itemsize == 72
         parts += [struct.pack("<qq", len(ev), int(ck)), np.ascontiguousarray(ev).tobytes()]
+    if upgrade is None:
+        parts += [struct.pack("<q", -1)]
+    else:
+        assert upgrade.dtype.itemsize == 32
+        parts += [struct.pack("<q", len(upgrade)), np.ascontiguousarray(upgrade).tobytes()]
     return b"".join(parts)
 
 

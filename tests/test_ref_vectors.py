@@ -284,3 +284,30 @@ def test_instance_table_listener_equals_the_reference_text(ref):
             assert [int(st[x]) for x in STAT_FIELDS] == [int(v) for v in want_stats], (name, k, st, want_stats)
             n += 1
     assert n > 150
+
+
+def ref_upgrade_maps(ref, name):
+    lens, flat = ref[f"{name}/map_len"], ref[f"{name}/maps"]
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    return [{int(k): int(v) for k, v in flat[offs[i]: offs[i + 1]]} for i in range(len(lens))]
+
+
+def test_upgrade_tracker_equals_the_reference_text(ref):
+    """UpgradeTracker.instanceAdded / instanceRemoved / doHousekeeping (UpgradeTracker.java:86-114, :121-186, :193-200) from the
+    reference's text: getLikelyReplacedReplicaSets() after every call of six rolling-update streams, against the Python
+    restatement the library's tracker is tested with (oracle/py_upgrade.py)."""
+    from oracle.py_upgrade import UpgradeTracker
+    nonempty = 0
+    for name, ev in rf.upgrade_event_cases():
+        want = ref_upgrade_maps(ref, name)
+        t = UpgradeTracker()
+        for i, e in enumerate(ev):
+            if e["kind"] == 0:
+                t.instanceAdded(int(e["labels_key"]), int(e["replica_set"]), int(e["start_time"]), int(e["now"]))
+            elif e["kind"] == 1:
+                t.instanceRemoved(int(e["labels_key"]), int(e["replica_set"]), int(e["now"]))
+            else:
+                t.doHousekeeping(int(e["now"]))
+            assert t.likelyReplacedReplicaSets == want[i], (name, i, t.likelyReplacedReplicaSets, want[i])
+            nonempty += bool(want[i])
+    assert nonempty > 200

@@ -128,3 +128,22 @@ def test_hip_instance_table_equals_the_reference_text(ref):
                 assert [int(st[x]) for x in STAT_FIELDS] == [int(v) for v in want_stats], (name, k, st, want_stats)
         finally:
             s.close()
+
+
+def test_hip_library_upgrade_tracker_equals_the_reference_text(ref):
+    """(host-side state of the context: no kernel — row a19)"""
+    from tests.test_ref_vectors import ref_upgrade_maps
+    for name, ev in rf.upgrade_event_cases():
+        want = ref_upgrade_maps(ref, name)
+        s = Solver(100, 1000)
+        try:
+            for i, e in enumerate(ev):
+                if e["kind"] == 0:
+                    s.upgrade_instance_added(int(e["labels_key"]), int(e["replica_set"]), int(e["start_time"]), int(e["now"]))
+                elif e["kind"] == 1:
+                    s.upgrade_instance_removed(int(e["labels_key"]), int(e["replica_set"]), int(e["now"]))
+                else:
+                    s.upgrade_housekeeping(int(e["now"]))
+                assert s.upgrade_replaced() == want[i], (name, i)
+        finally:
+            s.close()
