@@ -24,10 +24,14 @@ profile_one() {
   timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM --kernel-trace --output-format csv -d /tmp/p_$tag/sq2 -- python bench.py --kernel-only --steps 20 --warmup 2 --streams 1 "$@" > /dev/null 2>&1
   (python tools/sq_summary.py /tmp/p_$tag/sq1 $kern; python tools/sq_summary.py /tmp/p_$tag/sq2 $kern) > $OUT/sq_$tag.jsonl; cut -c1-260 $OUT/sq_$tag.jsonl
 }
+if [ -n "${PROFILE_ONLY:-}" ]; then  # one configuration again (after a script fix): PROFILE_ONLY="<tag> <kernel> <bench args...>"
+  profile_one $PROFILE_ONLY
+  exit 0
+fi
 profile_one C3_800k place_batch_kernel --workload C3
 profile_one C3_100k place_batch_kernel --workload C3 --decisions-per-step 100000
 profile_one C3_full_cluster_100k place_batch_long_kernel --workload C3 --decisions-per-step 100000 --full-cluster
-profile_one C3_full_cluster_800k place_batch_long_kernel --workload C3 --full-cluster
+profile_one C3_full_cluster_800k place_batch_long4_kernel --workload C3 --full-cluster   # (launches of >= 196 608 decisions take the 4-wavefront instantiation)
 [[ "${PROFILE_WORKLOADS:-C3 C4}" == *C4* ]] && profile_one C4 place_batch_kernel --workload C4
 
 # two overlapping streams (the timed region's shape): kernel stats only
