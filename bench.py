@@ -332,10 +332,19 @@ def pod_axis_lib_leg(workload: str, rank: int, world: int, dev, steps: int, warm
             n_rest = s.shard_place_dev(d_reqs.data_ptr(), n, d_extra.data_ptr(), fleet.now, d_outs.data_ptr())
         fence()
         elapsed = time.perf_counter() - t0
+        # the same batches without the host synchronisation at the end of each (mmp_shard_place_batch_async_dev: a batch is
+        # completed — its rest count read, the six phases run if there is a rest — when the next one is issued; one wait at the end)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            s.shard_place_async_dev(d_reqs.data_ptr(), n, d_extra.data_ptr(), fleet.now, d_outs.data_ptr())
+        n_rest_async = s.shard_wait()
+        fence()
+        elapsed_async = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed, elapsed_async], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            elapsed, elapsed_async = float(t[0].item()), float(t[1].item())
         got = np.frombuffer(d_outs.cpu().numpy().tobytes(), dtype=PLACE_OUT)
         out = None
         if rank == 0:
@@ -349,6 +358,8 @@ def pod_axis_lib_leg(workload: str, rank: int, world: int, dev, steps: int, warm
                    "collective": "inside libmmplace on its own stream: ncclAllReduce(MIN, 2 int64 per decision), then 5 x MIN + 1 x SUM over "
                                  "the undecided rest only when the (host-read) count of it is not zero (RCCL bound at run time)",
                    "took_the_six_phase_protocol": int(n_rest),
+                   "ms_per_step_async": elapsed_async / steps * 1e3, "value_async": n * steps / elapsed_async,
+                   "took_the_six_phase_protocol_async": int(n_rest_async),
                    "allreduce_bytes_per_step": 8 * s.shard_fast_slots() * n + 8 * slots * int(n_rest),
                    "sharded_commit_ms": commit_ms, "parity_vs_oracle": parity}
         s.shard_group_destroy()

@@ -179,6 +179,8 @@ SYMBOLS = [
     ("mmp_shard_commit", C.c_int, [_P]),
     ("mmp_shard_place_batch", C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int64, _P, C.POINTER(C.c_int32)]),
     ("mmp_shard_place_batch_dev", C.c_int, [_P, _P, C.c_int32, _P, C.c_int64, _P, C.POINTER(C.c_int32)]),
+    ("mmp_shard_place_batch_async_dev", C.c_int, [_P, _P, C.c_int32, _P, C.c_int64, _P]),
+    ("mmp_shard_wait", C.c_int, [_P, C.POINTER(C.c_int32)]),
     ("mmp_sync", C.c_int, [_P]),
     ("mmp_profile", C.c_int, [_P, C.c_int]),
     ("mmp_last_kernel_ms", C.c_double, [_P]),

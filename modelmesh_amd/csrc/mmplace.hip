@@ -201,10 +201,24 @@ struct mmp_ctx {
     bool snap_full = false;  // ... because (nearly) all of its instances are full (not only because a type is sparse)
     int32_t rank_mode = 0;  // MMP_RANK_MODE: 0 auto (sort from kRankSortMinPods pods), 1 all-pairs, 2 sort whenever legal (tests)
     Snap sview{};  // the lane path's view of this shard's slice (place_shard_fast_kernel)
-    DevBuf f_flags, f_offs, f_idx, f_reqs, f_outs, f_scan_tmp;  // speculative form: the compacted rest of a batch
-    DevBuf f_cnt;                  // finished workgroups << 32 | flagged decisions of the finish launch in flight (zero between launches)
-    uint64_t *f_done = nullptr;    // pinned: seq << 32 | flagged decisions, stored by the finish kernel's last workgroup
+    DevBuf f_offs, f_idx, f_reqs, f_outs, f_scan_tmp;  // speculative form: the compacted rest of a batch
+    // ... and what ONE batch in flight owns until its rest count has been read, twice (slot = batch parity): an asynchronous
+    // batch is completed after the NEXT one has been enqueued, so the two must not share flags, counter, word or exchange words
+    DevBuf f_flags[2];             // per decision: undecided by the single exchange
+    DevBuf f_cnt[2];               // finished workgroups << 32 | flagged decisions of the finish launch in flight (zero between launches)
+    uint64_t *f_done = nullptr;    // pinned, words [0] and [8]: seq << 32 | flagged decisions, stored by the finish kernel's last workgroup
+    uint32_t f_slot = 0;
     uint32_t f_seq = 0;
+    // mmp_shard_place_batch_async_dev: the batch whose finish kernel is enqueued and whose rest count has not been read yet
+    struct ShardPending {
+        bool active = false;
+        const void *d_reqs = nullptr, *d_extra = nullptr;
+        void *d_outs = nullptr;
+        int32_t n = 0;
+        int64_t now = 0;
+        uint32_t seq = 0, slot = 0;
+    } pend;
+    int32_t last_n_rest = 0;
     bool rank_pending = false;
 
     // RCCL group of the pod-axis shards (mmp_shard_group_init): collectives run on c->stream, inside the boundary
@@ -214,7 +228,7 @@ struct mmp_ctx {
     void *xuser = nullptr;
     bool group = false;
     int32_t g_rank = 0, g_world = 1;
-    DevBuf g_rankbuf, g_xf, g_x[6];
+    DevBuf g_rankbuf, g_xf[2], g_x[6];
 
     // commit scratch
     DevBuf rank, occupancy, flag, rs_list, rs_bad, d_prefer;
@@ -594,7 +608,7 @@ void mmp_destroy(mmp_ctx *c)
         group_comm_destroy(c->comm);
         c->comm = nullptr;
     }
-    for (DevBuf *b : {&c->g_rankbuf, &c->g_xf, &c->g_x[0], &c->g_x[1], &c->g_x[2], &c->g_x[3], &c->g_x[4], &c->g_x[5]}) b->release();
+    for (DevBuf *b : {&c->g_rankbuf, &c->g_xf[0], &c->g_xf[1], &c->g_x[0], &c->g_x[1], &c->g_x[2], &c->g_x[3], &c->g_x[4], &c->g_x[5]}) b->release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->pe0) (void)hipEventDestroy(c->pe0);
     if (c->pe1) (void)hipEventDestroy(c->pe1);
@@ -609,7 +623,7 @@ void mmp_destroy(mmp_ctx *c)
                       &c->r_tmp, &c->r_out_model, &c->r_out_lu, &c->k_cap, &c->k_wsize, &c->k_ubm, &c->k_ops, &c->k_order,
                       &c->k_opoff, &c->k_outs, &c->k_ev, &c->k_evoff, &c->idtab_hash, &c->idtab_val, &c->tytab_hash,
                       &c->tytab_val, &c->j_buf, &c->j_off, &c->j_rows, &c->j_aux, &c->j_status, &c->j_cnt, &c->j_offs, &c->j_tmp_pod,
-                      &c->j_tmp_time, &c->j_scan_tmp, &c->rk_rows, &c->rk_idx, &c->rk_tmp, &c->u_idx, &c->u_rows, &c->u_cnt, &c->u_offs, &c->u_tmp, &c->f_flags, &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp, &c->f_cnt,
+                      &c->j_tmp_time, &c->j_scan_tmp, &c->rk_rows, &c->rk_idx, &c->rk_tmp, &c->u_idx, &c->u_rows, &c->u_cnt, &c->u_offs, &c->u_tmp, &c->f_flags[0], &c->f_flags[1], &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp, &c->f_cnt[0], &c->f_cnt[1],
                       &c->ks[0].off, &c->ks[0].lu, &c->ks[0].wt,
                       &c->ks[0].key, &c->ks[0].n, &c->ks[1].off, &c->ks[1].lu, &c->ks[1].wt, &c->ks[1].key, &c->ks[1].n})
         b->release();
@@ -2146,45 +2160,75 @@ try {
 
 namespace {
 // After the all-reduce: the decided rows are written, the rest flagged and COUNTED; the count reaches the host through a
-// pinned word (place_shard_fast_finish_kernel).  Only when it is not zero: flags -> exclusive scan -> gather of the undecided
-// requests (decision order, identical on every shard).  Called with c->mu held; returns with the finish kernel complete.
-int shard_finish_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_xf, void *d_outs, hipStream_t st, int32_t *n_rest_out)
+// pinned word (place_shard_fast_finish_kernel).  Three steps so that a caller may leave between the first and the second
+// (mmp_shard_place_batch_async_dev): enqueue the kernel; synchronise and read the count; only when it is not zero, flags ->
+// exclusive scan -> gather of the undecided requests (decision order, identical on every shard).  Called with c->mu held.
+int shard_finish_enqueue(mmp_ctx *c, uint32_t slot, int32_t n, const void *d_xf, void *d_outs, hipStream_t st, uint32_t *seq_out)
 {
-    HIP_TRY(c, c->f_flags.ensure((size_t)(n + 1) * 4));
-    if (!c->f_cnt.p) {
-        HIP_TRY(c, c->f_cnt.ensure(16));
-        HIP_TRY(c, hipMemsetAsync(c->f_cnt.p, 0, 16, st));
+    HIP_TRY(c, c->f_flags[slot].ensure((size_t)(n + 1) * 4));
+    if (!c->f_cnt[slot].p) {
+        HIP_TRY(c, c->f_cnt[slot].ensure(16));
+        HIP_TRY(c, hipMemsetAsync(c->f_cnt[slot].p, 0, 16, st));
     }
     if (!c->f_done) {
-        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->f_done), 64, kPinnedFlags));
-        *c->f_done = 0;
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->f_done), 128, kPinnedFlags));
+        c->f_done[0] = c->f_done[8] = 0;
     }
     const uint32_t seq = ++c->f_seq;
     hipLaunchKernelGGL(place_shard_fast_finish_kernel, dim3(div_up(n + 1, 256)), dim3(256), 0, st, static_cast<const int64_t *>(d_xf),
-                       n, c->ssnap.any_rs, static_cast<mmp_place_out *>(d_outs), c->f_flags.as<int32_t>(), c->f_cnt.as<unsigned long long>(),
-                       c->f_done, seq);
+                       n, c->ssnap.any_rs, static_cast<mmp_place_out *>(d_outs), c->f_flags[slot].as<int32_t>(),
+                       c->f_cnt[slot].as<unsigned long long>(), c->f_done + 8 * slot, seq);
     HIP_TRY(c, hipGetLastError());
-    // the count arrives in pinned memory with the kernel's end: one stream synchronisation, no copy
-    HIP_TRY(c, hipStreamSynchronize(st));
-    const uint64_t word = __atomic_load_n(c->f_done, __ATOMIC_ACQUIRE);
-    if ((uint32_t)(word >> 32) != seq) return fail(c, MMP_EHIP, "shard finish kernel did not report its count");
-    const int32_t n_rest = (int32_t)(uint32_t)word;
-    *n_rest_out = n_rest;
-    if (n_rest == 0) return MMP_OK;
+    *seq_out = seq;
+    return MMP_OK;
+}
+// The count arrives in pinned memory with the finish kernel's last workgroup: the host polls the word (no copy, and no wait for
+// whatever a later batch has enqueued behind that kernel); a word that stays away for 2 ms is waited for with the stream.
+// Everything the host does with the count afterwards is enqueued on the same stream, i.e. ordered behind the kernel.
+int shard_finish_collect(mmp_ctx *c, uint32_t slot, hipStream_t st, uint32_t seq, int32_t *n_rest_out)
+{
+    const uint64_t *w = c->f_done + 8 * slot;
+    uint64_t word = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; spins++) {
+        word = __atomic_load_n(w, __ATOMIC_ACQUIRE);
+        if ((uint32_t)(word >> 32) == seq) break;
+        if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+            HIP_TRY(c, hipStreamSynchronize(st));
+            word = __atomic_load_n(w, __ATOMIC_ACQUIRE);
+            if ((uint32_t)(word >> 32) != seq) return fail(c, MMP_EHIP, "shard finish kernel did not report its count");
+            break;
+        }
+        __builtin_ia32_pause();
+    }
+    *n_rest_out = (int32_t)(uint32_t)word;
+    return MMP_OK;
+}
+int shard_rest_gather(mmp_ctx *c, uint32_t slot, const void *d_reqs, int32_t n, int32_t n_rest, hipStream_t st)
+{
     HIP_TRY(c, c->f_offs.ensure((size_t)(n + 1) * 4));
     HIP_TRY(c, c->f_idx.ensure((size_t)n_rest * 4));
     HIP_TRY(c, c->f_reqs.ensure((size_t)n_rest * sizeof(mmp_place_req)));
     HIP_TRY(c, c->f_outs.ensure((size_t)n_rest * sizeof(mmp_place_out)));
+    const int32_t *flags = c->f_flags[slot].as<int32_t>();
     size_t scan_bytes = 0;
-    HIP_TRY(c, rocprim::exclusive_scan(nullptr, scan_bytes, c->f_flags.as<int32_t>(), c->f_offs.as<int32_t>(), (int32_t)0,
-                                       (size_t)n + 1, rocprim::plus<int32_t>(), st));
+    HIP_TRY(c, rocprim::exclusive_scan(nullptr, scan_bytes, flags, c->f_offs.as<int32_t>(), (int32_t)0, (size_t)n + 1, rocprim::plus<int32_t>(), st));
     HIP_TRY(c, c->f_scan_tmp.ensure(std::max<size_t>(scan_bytes, 16)));
-    HIP_TRY(c, rocprim::exclusive_scan(c->f_scan_tmp.p, scan_bytes, c->f_flags.as<int32_t>(), c->f_offs.as<int32_t>(), (int32_t)0,
-                                       (size_t)n + 1, rocprim::plus<int32_t>(), st));
+    HIP_TRY(c, rocprim::exclusive_scan(c->f_scan_tmp.p, scan_bytes, flags, c->f_offs.as<int32_t>(), (int32_t)0, (size_t)n + 1,
+                                       rocprim::plus<int32_t>(), st));
     hipLaunchKernelGGL(place_shard_gather_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, static_cast<const mmp_place_req *>(d_reqs),
-                       n, c->f_flags.as<int32_t>(), c->f_offs.as<int32_t>(), c->f_reqs.as<mmp_place_req>(), c->f_idx.as<int32_t>());
+                       n, flags, c->f_offs.as<int32_t>(), c->f_reqs.as<mmp_place_req>(), c->f_idx.as<int32_t>());
     HIP_TRY(c, hipGetLastError());
     return MMP_OK;
+}
+int shard_finish_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_xf, void *d_outs, hipStream_t st, int32_t *n_rest_out)
+{
+    uint32_t seq = 0;  // (the step-wise calls: one batch at a time, slot 0; the caller reads d_outs next: synchronise)
+    int rc = shard_finish_enqueue(c, 0, n, d_xf, d_outs, st, &seq);
+    if (rc == MMP_OK) rc = shard_finish_collect(c, 0, st, seq, n_rest_out);
+    if (rc == MMP_OK && *n_rest_out > 0) rc = shard_rest_gather(c, 0, d_reqs, n, *n_rest_out, st);
+    if (rc == MMP_OK) HIP_TRY(c, hipStreamSynchronize(st));
+    return rc;
 }
 }  // namespace
 
@@ -2395,12 +2439,16 @@ int mmp_shard_group_set_exchange(mmp_ctx *c, mmp_exchange_fn fn, void *user)
     return MMP_OK;
 }
 
+namespace {
+int shard_resolve_pending(mmp_ctx *c);
+}
 int mmp_shard_group_destroy(mmp_ctx *c)
 {
     if (!c) return MMP_EINVAL;
     std::lock_guard<std::mutex> gg(c->group_mu);
     if (!c->group) return MMP_OK;
     (void)hipSetDevice(c->cfg.device);
+    (void)shard_resolve_pending(c);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)rccl_api()->CommDestroy(c->comm);
     c->comm = nullptr;
@@ -2416,6 +2464,10 @@ try {
     std::lock_guard<std::mutex> gg(c->group_mu);
     if (!c->group) return fail(c, MMP_ESTATE, "mmp_shard_commit: call mmp_shard_group_init first");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
+    {
+        const int rc0 = shard_resolve_pending(c);  // an open asynchronous batch is decided against the snapshot it was issued on
+        if (rc0 != MMP_OK) return rc0;
+    }
     size_t P;
     {
         std::lock_guard<std::shared_mutex> g(c->mu);
@@ -2441,14 +2493,16 @@ try {
  * when more decisions than that capacity need the six phases — the host learns it with the results — are they run
  * again at their exact size. */
 namespace {
-int shard_place_batch_locked(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs, int32_t *n_rest_out);
+int shard_place_batch_locked(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs, int32_t *n_rest_out,
+                             bool wait);
+int shard_resolve_pending(mmp_ctx *c);
 }
 int mmp_shard_place_batch_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs,
                               int32_t *n_rest_out)
 try {
     if (!c || n < 0 || (n > 0 && (!d_reqs || !d_outs))) return fail(c, MMP_EINVAL, "mmp_shard_place_batch_dev: bad argument");
     std::lock_guard<std::mutex> gg(c->group_mu);
-    return shard_place_batch_locked(c, d_reqs, n, d_extra, now, d_outs, n_rest_out);
+    return shard_place_batch_locked(c, d_reqs, n, d_extra, now, d_outs, n_rest_out, true);
 } catch (const std::bad_alloc &) {
     return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shard_place_batch_dev");
 } catch (const std::exception &e) {
@@ -2456,40 +2510,113 @@ try {
 }
 
 namespace {
-// the body of mmp_shard_place_batch(_dev); the caller holds c->group_mu (and nothing that is ordered behind it)
-int shard_place_batch_locked(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs, int32_t *n_rest_out)
+// the batch of mmp_shard_place_batch_async_dev that is still open: wait for its finish kernel, read the rest count, run the six
+// phases over the rest if there is one.  The caller holds c->group_mu.  n_rest identical on every shard (the same reduced
+// words): the group stays in step.
+int shard_resolve_pending(mmp_ctx *c)
 {
-    if (!c->group) return fail(c, MMP_ESTATE, "mmp_shard_place_batch_dev: call mmp_shard_group_init first");
-    if (n_rest_out) *n_rest_out = 0;
-    if (n == 0) return MMP_OK;
-    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    if (!c->pend.active) return MMP_OK;
+    const mmp_ctx::ShardPending P = c->pend;
+    c->pend.active = false;
     hipStream_t st = c->stream;
-    HIP_TRY(c, c->g_xf.ensure((size_t)n * kXF * 8));
-    int rc = mmp_shard_place_fast_dev(c, d_reqs, n, d_extra, now, c->g_xf.p, st);
-    if (rc != MMP_OK) return rc;
-    rc = group_allreduce(c, c->g_xf.p, (size_t)n * kXF, ncclInt64, ncclMin);
-    if (rc != MMP_OK) return rc;
     int32_t n_rest = 0;
+    int rc;
     {
         std::lock_guard<std::shared_mutex> g(c->mu);
-        rc = shard_finish_launch(c, d_reqs, n, c->g_xf.p, d_outs, st, &n_rest);
-        if (rc != MMP_OK) return rc;
+        rc = shard_finish_collect(c, P.slot, st, P.seq, &n_rest);
+        if (rc == MMP_OK && n_rest > 0) rc = shard_rest_gather(c, P.slot, P.d_reqs, P.n, n_rest, st);
     }
-    // n_rest is identical on every shard (the same reduced words): the group stays in step.  Round 2 kept the count on the
-    // device and ALWAYS ran the six-exchange protocol over a fixed-capacity sub-batch (seven launches and six collectives
-    // that mostly found no rows): 99 us per 100k decisions at one shard against 50 us for the form that asks.
+    if (rc != MMP_OK) return rc;
+    c->last_n_rest = n_rest;
     if (n_rest > 0) {
-        rc = group_general(c, c->f_reqs.p, n_rest, nullptr, d_extra, now, c->f_outs.p);
+        rc = group_general(c, c->f_reqs.p, n_rest, nullptr, P.d_extra, P.now, c->f_outs.p);
         if (rc != MMP_OK) return rc;
         hipLaunchKernelGGL(place_shard_scatter_kernel, dim3(div_up(n_rest, 256)), dim3(256), 0, st, c->f_outs.as<mmp_place_out>(),
-                           c->f_idx.as<int32_t>(), n_rest, static_cast<mmp_place_out *>(d_outs), nullptr);
+                           c->f_idx.as<int32_t>(), n_rest, static_cast<mmp_place_out *>(P.d_outs), nullptr);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(st));
     }
-    if (n_rest_out) *n_rest_out = n_rest;
+    return MMP_OK;
+}
+
+// the body of the group's batch calls; the caller holds c->group_mu (and nothing that is ordered behind it).  wait = false:
+// returns with the fast kernel, the all-reduce and the finish kernel enqueued (mmp_shard_place_batch_async_dev)
+int shard_place_batch_locked(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs, int32_t *n_rest_out,
+                             bool wait = true)
+{
+    if (!c->group) return fail(c, MMP_ESTATE, "mmp_shard_place_batch_dev: call mmp_shard_group_init first");
+    if (n_rest_out) *n_rest_out = 0;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    int rc;
+    if (n == 0) {
+        rc = shard_resolve_pending(c);
+        c->last_n_rest = rc == MMP_OK ? 0 : c->last_n_rest;
+        return rc;
+    }
+    // This batch is enqueued FIRST, on the buffers of the other slot; the batch before it — whose finish kernel has had the time
+    // of these three launches to end — is completed afterwards, and whatever its rest needs is enqueued behind this batch.
+    hipStream_t st = c->stream;
+    const uint32_t slot = c->f_slot ^= 1u;
+    HIP_TRY(c, c->g_xf[slot].ensure((size_t)n * kXF * 8));
+    rc = mmp_shard_place_fast_dev(c, d_reqs, n, d_extra, now, c->g_xf[slot].p, st);
+    if (rc != MMP_OK) return rc;
+    rc = group_allreduce(c, c->g_xf[slot].p, (size_t)n * kXF, ncclInt64, ncclMin);
+    if (rc != MMP_OK) return rc;
+    uint32_t seq = 0;
+    {
+        std::lock_guard<std::shared_mutex> g(c->mu);
+        rc = shard_finish_enqueue(c, slot, n, c->g_xf[slot].p, d_outs, st, &seq);
+        if (rc != MMP_OK) return rc;
+    }
+    rc = shard_resolve_pending(c);
+    if (rc != MMP_OK) return rc;
+    c->pend.slot = slot;
+    c->pend.active = true;
+    c->pend.d_reqs = d_reqs;
+    c->pend.d_extra = d_extra;
+    c->pend.d_outs = d_outs;
+    c->pend.n = n;
+    c->pend.now = now;
+    c->pend.seq = seq;
+    if (!wait) return MMP_OK;
+    // Round 2 kept the rest count on the device and ALWAYS ran the six-exchange protocol over a fixed-capacity sub-batch (seven
+    // launches and six collectives that mostly found no rows): 99 us per 100k decisions at one shard against 50 us for the form
+    // that asks.
+    rc = shard_resolve_pending(c);
+    if (rc != MMP_OK) return rc;
+    HIP_TRY(c, hipStreamSynchronize(st));  // the caller reads d_outs next
+    if (n_rest_out) *n_rest_out = c->last_n_rest;
     return MMP_OK;
 }
 }  // namespace
+
+int mmp_shard_place_batch_async_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs)
+try {
+    if (!c || n < 0 || (n > 0 && (!d_reqs || !d_outs))) return fail(c, MMP_EINVAL, "mmp_shard_place_batch_async_dev: bad argument");
+    std::lock_guard<std::mutex> gg(c->group_mu);
+    return shard_place_batch_locked(c, d_reqs, n, d_extra, now, d_outs, nullptr, false);
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shard_place_batch_async_dev");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_shard_place_batch_async_dev", e.what());
+}
+
+int mmp_shard_wait(mmp_ctx *c, int32_t *n_rest_out)
+try {
+    if (!c) return MMP_EINVAL;
+    std::lock_guard<std::mutex> gg(c->group_mu);
+    if (!c->group) return fail(c, MMP_ESTATE, "mmp_shard_wait: call mmp_shard_group_init first");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int rc = shard_resolve_pending(c);
+    if (rc != MMP_OK) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n_rest_out) *n_rest_out = c->last_n_rest;
+    return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shard_wait");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_shard_wait", e.what());
+}
 
 /* The same with host pointers (what a JVM holds): staged through the context's scratch. */
 int mmp_shard_place_batch(mmp_ctx *c, const mmp_place_req *reqs, int32_t n, const int32_t *extra_pool, int32_t n_extra,
@@ -2512,7 +2639,7 @@ try {
     HIP_TRY(c, c->s_extra.ensure((size_t)std::max(n_extra, 1) * 4));
     HIP_TRY(c, hipMemcpyAsync(c->s_reqs.p, reqs, (size_t)n * sizeof(mmp_place_req), hipMemcpyHostToDevice, c->stream));
     if (n_extra) HIP_TRY(c, hipMemcpyAsync(c->s_extra.p, extra_pool, (size_t)n_extra * 4, hipMemcpyHostToDevice, c->stream));
-    const int rc = shard_place_batch_locked(c, c->s_reqs.p, n, c->s_extra.p, now, c->s_outs.p, n_rest_out);
+    const int rc = shard_place_batch_locked(c, c->s_reqs.p, n, c->s_extra.p, now, c->s_outs.p, n_rest_out, true);
     if (rc != MMP_OK) return rc;
     HIP_TRY(c, copy_sync(c, outs, c->s_outs.p, (size_t)n * sizeof(mmp_place_out), hipMemcpyDeviceToHost));
     return MMP_OK;

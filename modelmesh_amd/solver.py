@@ -537,6 +537,16 @@ class Solver:
                                                     C.c_void_p(d_outs), C.byref(n_rest)))
         return n_rest.value
 
+    def shard_place_async_dev(self, d_reqs: int, n: int, d_extra: int, now: int, d_outs: int):
+        """The same without the synchronisation at the end: completed by the next group call or by shard_wait()."""
+        self._ck(self.lib.mmp_shard_place_batch_async_dev(self.h, C.c_void_p(d_reqs), int(n), C.c_void_p(d_extra or None), int(now),
+                                                          C.c_void_p(d_outs)))
+
+    def shard_wait(self) -> int:
+        n_rest = C.c_int32(0)
+        self._ck(self.lib.mmp_shard_wait(self.h, C.byref(n_rest)))
+        return n_rest.value
+
     def sync(self):
         self._ck(self.lib.mmp_sync(self.h))
 

@@ -145,3 +145,99 @@ def test_c3_group_of_two_full_size():
     fleet = wl.make_fleet("C3")
     rest = _check(fleet, [wl.make_requests(fleet, 0xBE7C0)], 2)
     assert rest[0] < 1000, rest
+
+
+def _async_run(s, fleet, batches, commit_between=False):
+    """Issue every batch with mmp_shard_place_batch_async_dev (each into its own result buffer), wait once at the end."""
+    import torch
+    from modelmesh_amd._lib import PLACE_OUT
+    dev = torch.device("cuda:0")
+    bufs = []
+    for reqs, extra in batches:
+        d_reqs = torch.from_numpy(np.ascontiguousarray(reqs).view(np.uint8).reshape(-1)).to(dev)
+        d_extra = torch.from_numpy(np.ascontiguousarray(extra if len(extra) else np.zeros(1, np.int32))).to(dev)
+        d_outs = torch.zeros(len(reqs) * 16, dtype=torch.uint8, device=dev)
+        bufs.append((d_reqs, d_extra, d_outs))
+    torch.cuda.synchronize(dev)
+    for i, ((reqs, _), (d_reqs, d_extra, d_outs)) in enumerate(zip(batches, bufs)):
+        s.shard_place_async_dev(d_reqs.data_ptr(), len(reqs), d_extra.data_ptr(), fleet.now, d_outs.data_ptr())
+        if commit_between and i == 0:
+            s.shard_commit()  # completes the open batch first (against the snapshot it was issued on), then re-ranks
+    last_rest = s.shard_wait()
+    return [np.frombuffer(d_outs.cpu().numpy().tobytes(), dtype=PLACE_OUT) for _, _, d_outs in bufs], last_rest
+
+
+def _many_exclusions(fleet, reqs, extra, rng, k=40):
+    """Requests with more exclusions than a lane carries: the shard's kernel leaves them to the six phases (a rest > 0)."""
+    reqs, extra = reqs.copy(), np.ascontiguousarray(extra, dtype=np.int32)
+    pool = [extra]
+    off = len(extra)
+    for i in rng.choice(len(reqs), size=min(k, len(reqs)), replace=False):
+        ex = rng.choice(fleet.n_pods, size=12, replace=False).astype(np.int32)
+        reqs["extra_off"][i], reqs["n_extra"][i] = off, len(ex)
+        pool.append(ex)
+        off += len(ex)
+    return reqs, np.concatenate(pool)
+
+
+@pytest.mark.parametrize("rccl", [False, True])
+def test_async_batches_on_a_group_of_one_are_completed_by_the_next_call_and_by_wait(rccl):
+    fleet = wl.make_fleet("C2")
+    rng = np.random.default_rng(9)
+    b0 = wl.make_requests(fleet, 31)
+    b1 = _many_exclusions(fleet, *wl.make_requests(fleet, 32, n=3000), rng)  # leaves a rest: resolved when b2 is issued
+    b2 = wl.make_requests(fleet, 33, n=500)
+    b3 = _many_exclusions(fleet, *wl.make_requests(fleet, 34, n=900), rng)  # ... resolved by the wait
+    batches = [b0, b1, b2, b3]
+    orc = OracleFleet(fleet)
+    for commit_between in (False, True):
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            s.shard_group_init(s.shard_unique_id() if rccl else None, 0, 1)
+            s.load_fleet(fleet, commit=False)
+            s.shard_commit()
+            outs, last_rest = _async_run(s, fleet, batches, commit_between)
+            assert last_rest > 0  # b3's
+            for (reqs, extra), got in zip(batches, outs):
+                assert_same_decisions(fleet, reqs, got, orc.place(reqs, extra, fleet.now, threads=8))
+            assert s.shard_wait() == last_rest  # nothing open: the last count again
+            s.shard_group_destroy()
+        finally:
+            s.close()
+
+
+def test_async_batches_on_two_virtual_shards():
+    fleet = wl.fuzz_fleet(140, pods=300, profile="pref")
+    rng = np.random.default_rng(10)
+    batches = [wl.fuzz_requests(fleet, 1, 700), _many_exclusions(fleet, *wl.fuzz_requests(fleet, 2, 600), rng), wl.fuzz_requests(fleet, 3, 64)]
+    orc = OracleFleet(fleet)
+    G = 2
+    xc = ThreadExchange(G)
+    results, errors, keep = [None] * G, [], []
+
+    def run(g):
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            cb = xc.fn_for(g)
+            keep.append(cb)
+            assert s.lib.mmp_shard_group_set_exchange(s.h, C.cast(cb, C.c_void_p), None) == 0
+            s.shard_group_init(None, g, G)
+            s.load_fleet(fleet, commit=False)
+            s.shard_commit()
+            results[g] = _async_run(s, fleet, batches)
+            s.shard_group_destroy()
+        except Exception as e:  # noqa: BLE001
+            errors.append((g, repr(e)))
+            xc.bar.abort()
+        finally:
+            s.close()
+
+    ths = [threading.Thread(target=run, args=(g,)) for g in range(G)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    for (reqs, extra), a, b in zip(batches, results[0][0], results[1][0]):
+        assert np.array_equal(a, b)
+        assert_same_decisions(fleet, reqs, a, orc.place(reqs, extra, fleet.now, threads=8))
