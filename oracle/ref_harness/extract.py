@@ -80,6 +80,17 @@ RANGES = [
     ("ist_remove_body", "src/main/java/com/ibm/watson/modelmesh/InstanceSetStatsTracker.java", 75, 83, "count--;", "return count <= 0;"),
     ("ist_update_body", "src/main/java/com/ibm/watson/modelmesh/InstanceSetStatsTracker.java", 87, 91, "ClusterStats newStats = new ClusterStats(totalCapacity, totalFree, lru, count, modelCount);", "return newStats;"),
     ("handleInstanceTableChange_body", MM, 1456, 1567, "if (logger.isDebugEnabled()) {", "}", "LISTENER_SWITCH"),
+    # ---- a18: TypeConstraintManager — the per-type instance sets, the instance partitions and their stats (the static computation:
+    # typeMappingsUpdated's building blocks; the incremental updateInstance path is not extracted)
+    ("tcm_partition_stats_comp_body", "src/main/java/com/ibm/watson/modelmesh/TypeConstraintManager.java", 265, 270, "ClusterStats cs1 = isst1.currentStats, cs2 = isst2.currentStats;", "return Long.compare(cs2.totalCapacity, cs1.totalCapacity);", "TCM"),
+    ("tcm_candidateSubsetStats_body", "src/main/java/com/ibm/watson/modelmesh/TypeConstraintManager.java", 357, 375, "if (instanceSetStats == null) {", "return new ClusterStats(capacity, free, lru, count, modelCopyCount);", "TCM"),
+    ("tcm_fromInstanceSet_body", "src/main/java/com/ibm/watson/modelmesh/TypeConstraintManager.java", 419, 447, "// assumption is that requiredLabels and preferredLabels are already sorted", "requiredInstances, preferredSet, instanceSetStats, preferredSet);", "TCM"),
+    ("tcm_allowedOnInstance_body", "src/main/java/com/ibm/watson/modelmesh/TypeConstraintManager.java", 451, 451, "return allowedInstances == null || allowedInstances.contains(iid);", "contains(iid);", "TCM"),
+    ("tcm_instanceMatches_body", "src/main/java/com/ibm/watson/modelmesh/TypeConstraintManager.java", 480, 485, "if (instanceLabels.length == 0 || typeLabels.length == 0) {", "labelStream.anyMatch(hasLabel);", "TCM"),
+    ("tcm_prohibited_types_fragment", "src/main/java/com/ibm/watson/modelmesh/TypeConstraintManager.java", 561, 567, "ArrayList<String> newPts = new ArrayList<>(tcMap.size());", "ProhibitedTypeSet pts = new ProhibitedTypeSet(newPts);", "TCM"),
+    ("tcm_scores_fragment", "src/main/java/com/ibm/watson/modelmesh/TypeConstraintManager.java", 684, 699, "MutableObjectIntMap<String> instanceScores", "Set<String> defaultPreferred = inferPreferredInstances(instanceScores, null);", "TCM"),
+    ("tcm_per_type_fragment", "src/main/java/com/ibm/watson/modelmesh/TypeConstraintManager.java", 707, 723, "for (Map.Entry<String, ModelTypeConstraints> ent : mtcMap.entrySet()) {", "}", "TCM"),
+    ("tcm_inferPreferredInstances_body", "src/main/java/com/ibm/watson/modelmesh/TypeConstraintManager.java", 728, 746, "Set<String> instanceIds = new HashSet<>(include != null ? include.size() : 8);", "return min < max ? ImmutableSet.copyOf(instanceIds) : null;", "TCM"),
     # ---- a19: UpgradeTracker (replica sets that a rolling update is replacing)
     ("upgrade_constants", "src/main/java/com/ibm/watson/modelmesh/UpgradeTracker.java", 48, 50, "TEN_MINS = 600_000L;", "TWENTY_MINS = 1200_000L;"),
     ("upgrade_instanceRemoved_body", "src/main/java/com/ibm/watson/modelmesh/UpgradeTracker.java", 86, 114, "if (iid.length() < 7) {", "}", "STREAMS"),
@@ -124,6 +135,18 @@ EXTRA_RULES["STREAMS"] = [
     (re.compile(r"\bnew ReplicaSetStats\(\)"), "ReplicaSetStats::make()"),
     (re.compile(r"\bMap\.Entry\b"), "Entry"),
     (re.compile(r"\bSystem\.currentTimeMillis\(\)"), "currentTimeMillis()"),
+]
+
+# TypeConstraintManager: library type names with dots / generics / arrays, its one expression lambda, field reads through a
+# tracker reference (the stand-in is a handle: `->`)
+EXTRA_RULES["TCM"] = [
+    (re.compile(r"\bImmutableSet\.Builder<String>"), "ImmutableSetBuilder"),
+    (re.compile(r"\bMap\.Entry\b"), "Entry"),
+    (re.compile(r"l -> Arrays\.binarySearch\(instanceLabels, l\) >= 0;"), "[=](const String &l) { return Arrays.binarySearch(instanceLabels, l) >= 0; };"),
+    (re.compile(r"\bnew ObjectIntHashMap<String>\("), "ObjectIntHashMap_new("),
+    (re.compile(r"\bnew HashSet<>\("), "HashSet_new("),
+    (re.compile(r"\.currentStats\b"), "->currentStats"),
+    (re.compile(r"\bString\[\]"), "StringArray"),
 ]
 
 # token-level rewrites, applied in order to every extracted line

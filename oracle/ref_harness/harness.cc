@@ -27,6 +27,14 @@ public:
     explicit ProhibitedTypeSet(std::vector<std::string> types) : p(std::make_shared<std::vector<std::string>>(std::move(types))) { std::sort(p->begin(), p->end()); }
     bool operator==(std::nullptr_t) const { return !p; }
     bool operator!=(std::nullptr_t) const { return (bool)p; }
+    template <class L, class = decltype(std::declval<L>().size()), class = decltype(std::declval<L>().get(0))>
+    explicit ProhibitedTypeSet(const L &types) : p(std::make_shared<std::vector<std::string>>())  // ProhibitedTypeSet(Collection<String>), :299-303
+    {
+        for (int i = 0; i < types.size(); i++) p->push_back(types.get(i).str());
+        std::sort(p->begin(), p->end());
+    }
+    int size() const { return (int)p->size(); }                                                              // :305-307
+    const std::vector<std::string> &types() const { return *p; }
     boolean contains(const String &type) const { return std::binary_search(p->begin(), p->end(), type.str()); }  // :309-311
     boolean equals(const ProhibitedTypeSet &o) const { return o.p && *p == *o.p; }                                  // :314-317
 };
@@ -68,6 +76,7 @@ public:
     String getLocation() const { return null; }
     String getZone() const { return null; }
     StringArray getLabels() const { return p->labels; }
+    void a18_setLabels(const StringArray &l) const { p->labels = l; }
     long getRemaining() const  // InstanceRecord.java:203
     {
         const long capacity = p->capacity, used = p->used;
@@ -632,6 +641,170 @@ static int changeCounter;
 static int g_upgrade_added, g_upgrade_removed, g_housekeepings, g_republish;
 static void handleInstanceTableChange(const SortedClusterState &clusterState, EventType type, const String &key, InstanceRecord record);
 
+// ======================= a18: TypeConstraintManager (TypeConstraintManager.java:264-270, :337-451, :478-486, :557-567, :680-747) ===============
+// The static computation — what typeMappingsUpdated (:602-667) assembles from these pieces for a given clusterState and
+// configuration: per type the allowed / configured-preferred instances (fromInstanceSet + instanceMatches), per instance its
+// ProhibitedTypeSet (getInstanceSetStats :561-567) hence the partitions, the instance scores and the inferred preferred
+// instances (refreshPerTypeInstanceSets :684-723, inferPreferredInstances), the per-type subset stats (candidateSubsetStats) and
+// the partitions' order (PARTITION_STATS_COMP).  The glue between the pieces is the harness's (the maps of trackers by labels /
+// by ProhibitedTypeSet, :575-580, :655-664); the incremental path (updateInstance, updateInstanceSet) is not run.
+namespace a18 {
+struct TrackerObj {
+    ::InstanceSetStatsTracker sums;  // add() / addLru() / update(): the reference's text (row a5)
+    ClusterStats currentStats = ClusterStats(0L, 0L, Long::MAX_VALUE, 0, 0);
+    ProhibitedTypeSet prohibitedTypesSet;
+    int id = -1;
+};
+struct InstanceSetStatsTracker {  // a reference to one tracker
+    std::shared_ptr<TrackerObj> p;
+    InstanceSetStatsTracker() {}
+    InstanceSetStatsTracker(std::nullptr_t) {}
+    TrackerObj *operator->() const { return p.get(); }
+    bool operator==(const InstanceSetStatsTracker &o) const { return p == o.p; }
+};
+struct TrackerArray {  // InstanceSetStatsTracker[] (nullable)
+    std::shared_ptr<std::vector<InstanceSetStatsTracker>> p;
+    TrackerArray() {}
+    TrackerArray(std::nullptr_t) {}
+    bool operator==(std::nullptr_t) const { return !p; }
+    int length() const { return (int)p->size(); }
+    const InstanceSetStatsTracker &operator[](int i) const { return (*p)[i]; }
+    std::vector<InstanceSetStatsTracker>::const_iterator begin() const { return p->begin(); }
+    std::vector<InstanceSetStatsTracker>::const_iterator end() const { return p->end(); }
+};
+struct TrackerSet {  // Set<InstanceSetStatsTracker> statSet = new HashSet<>(...) (:706): by identity
+    std::vector<InstanceSetStatsTracker> v;
+    void clear() { v.clear(); }
+    void add(const InstanceSetStatsTracker &t) { if (std::find(v.begin(), v.end(), t) == v.end()) v.push_back(t); }
+};
+struct NullableStats {  // ClusterStats or null (candidateSubsetStats: null = "use the cluster's stats")
+    bool isnull = true;
+    ClusterStats v;
+    NullableStats(std::nullptr_t) {}
+    NullableStats(const ClusterStats &c) : isnull(false), v(c) {}
+};
+template <class X> using Predicate = std::function<bool(const X &)>;
+template <class X> struct Stream {
+    std::vector<X> v;
+    boolean allMatch(const Predicate<X> &f) const { for (auto &x : v) if (!f(x)) return false; return true; }
+    boolean anyMatch(const Predicate<X> &f) const { for (auto &x : v) if (f(x)) return true; return false; }
+};
+static const struct {
+    int binarySearch(const StringArray &a, const String &key) const  // java.util.Arrays.binarySearch on a sorted array
+    {
+        int lo = 0, hi = a.length() - 1;
+        while (lo <= hi) {
+            const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+            const int c = a[mid].compareTo(key);
+            if (c < 0) lo = mid + 1; else if (c > 0) hi = mid - 1; else return mid;
+        }
+        return -(lo + 1);
+    }
+    Stream<String> stream(const StringArray &a) const { Stream<String> s; for (int i = 0; i < a.length(); i++) s.v.push_back(a[i]); return s; }
+    String toString(const StringArray &) const { return String(""); }
+} Arrays;
+struct ImmutableSetBuilder {  // com.google.common.collect.ImmutableSet.Builder<String> (nullable)
+    Set<String> s;
+    ImmutableSetBuilder() {}
+    ImmutableSetBuilder(std::nullptr_t) {}
+    bool operator==(std::nullptr_t) const { return s == null; }
+    bool operator!=(std::nullptr_t) const { return s != null; }
+    void add(const String &x) const { s.add(x); }
+    Set<String> build() const { return s; }
+};
+static const struct {
+    ImmutableSetBuilder builder() const { ImmutableSetBuilder b; b.s = Set<String>::make(); return b; }
+    Set<String> copyOf(const Set<String> &src) const { Set<String> c = Set<String>::make(); for (auto &x : src) c.add(x); return c; }
+} ImmutableSet;
+template <class T> using ArrayList = List<T>;
+template <class K> struct ObjectIntPair { K k; int v; K getOne() const { return k; } int getTwo() const { return v; } };
+template <class K> struct ObjectIntMap {  // org.eclipse.collections ObjectIntMap<String> (iteration: by key; the result is a SET of ids)
+    std::shared_ptr<std::map<std::string, int>> p = std::make_shared<std::map<std::string, int>>();
+    void put(const K &k, int v) const { (*p)[k.str()] = v; }
+    boolean containsKey(const K &k) const { return p->count(k.str()) != 0; }
+    void addToValue(const K &k, int d) const { (*p)[k.str()] += d; }
+    std::vector<ObjectIntPair<K>> keyValuesView() const { std::vector<ObjectIntPair<K>> o; for (auto &e : *p) o.push_back({String(e.first), e.second}); return o; }
+};
+template <class K> using MutableObjectIntMap = ObjectIntMap<K>;
+static ObjectIntMap<String> ObjectIntHashMap_new(int) { return ObjectIntMap<String>(); }
+static const struct { void warn(const String &) const {} void info(const String &) const {} } logger;
+
+static boolean instanceMatches(StringArray instanceLabels, StringArray typeLabels, boolean matchAll)  // :478
+{
+#include "../_ref/gen/tcm_instanceMatches_body.inc"
+}
+struct ModelTypeConstraints {  // :337-355: immutable; the fields the fragments read
+    bool isnull = true;
+    StringArray requiredLabels, preferredLabels;
+    Set<String> allowedInstances, preferredInstances, configuredPreferredInstances;
+    TrackerArray instanceSetStats;
+    ModelTypeConstraints() {}
+    ModelTypeConstraints(std::nullptr_t) {}
+    ModelTypeConstraints(const StringArray &req, const StringArray &pref, const Set<String> &allowed, const Set<String> &configured,
+                         const TrackerArray &stats, const Set<String> &resolved)  // :377-388
+        : isnull(false), requiredLabels(req), preferredLabels(pref), allowedInstances(allowed), preferredInstances(resolved),
+          configuredPreferredInstances(configured), instanceSetStats(stats) {}
+    boolean allowedOnInstance(const String &iid) const
+    {
+#include "../_ref/gen/tcm_allowedOnInstance_body.inc"
+    }
+    NullableStats candidateSubsetStats() const
+    {
+#include "../_ref/gen/tcm_candidateSubsetStats_body.inc"
+    }
+    // updateInstanceSetStats (:394-413) returns this or a copy that differs in instanceSetStats / preferredInstances: the copy
+    ModelTypeConstraints updateInstanceSetStats(std::nullptr_t, const Set<String> &newInferredPreferred) const
+    {
+        return ModelTypeConstraints(requiredLabels, preferredLabels, allowedInstances, configuredPreferredInstances, TrackerArray(null), newInferredPreferred);
+    }
+    ModelTypeConstraints updateInstanceSetStats(const TrackerSet &newStats, const Set<String> &newInferredPreferred) const
+    {
+        TrackerArray a;
+        a.p = std::make_shared<std::vector<InstanceSetStatsTracker>>(newStats.v);
+        return ModelTypeConstraints(requiredLabels, preferredLabels, allowedInstances, configuredPreferredInstances, a, newInferredPreferred);
+    }
+};
+static ModelTypeConstraints fromInstanceSet(StringArray requiredLabels, StringArray preferredLabels, const std::vector<Entry<String, InstanceRecord>> &instances,
+                                            String typeName, TrackerArray instanceSetStats)  // :416
+{
+#include "../_ref/gen/tcm_fromInstanceSet_body.inc"
+}
+static Set<String> inferPreferredInstances(ObjectIntMap<String> instanceScores, Set<String> include)  // :727
+{
+#include "../_ref/gen/tcm_inferPreferredInstances_body.inc"
+}
+struct MtcMap {  // Map<String, ModelTypeConstraints> whose entries write through (ent.setValue, :709, :720)
+    std::vector<Entry<String, ModelTypeConstraints>> es;
+    const std::vector<Entry<String, ModelTypeConstraints>> &entrySet() const { return es; }
+    int size() const { return (int)es.size(); }
+};
+static ProhibitedTypeSet prohibitedTypesOf(const String &iid, const MtcMap &tcMap)  // getInstanceSetStats, :561-567
+{
+#include "../_ref/gen/tcm_prohibited_types_fragment.inc"
+    return pts;
+}
+struct PtsMap {  // Map<ProhibitedTypeSet, InstanceSetStatsTracker> ptsToInstanceSetStats (:132), in creation order
+    std::vector<Entry<ProhibitedTypeSet, InstanceSetStatsTracker>> es;
+    const std::vector<Entry<ProhibitedTypeSet, InstanceSetStatsTracker>> &entrySet() const { return es; }
+    int size() const { return (int)es.size(); }
+};
+static Set<String> g_defaultPreferred;
+static void refreshPerTypeInstanceSets(MtcMap &mtcMap, const PtsMap &ptsToInstanceSetStats)  // :680-725 (the logging of :700-704 left out)
+{
+    const struct { int size() const { return (int)g_cluster->size(); }
+                   std::vector<Entry<String, InstanceRecord>>::const_iterator begin() const { return g_cluster->begin(); }
+                   std::vector<Entry<String, InstanceRecord>>::const_iterator end() const { return g_cluster->end(); } } clusterState;
+#include "../_ref/gen/tcm_scores_fragment.inc"
+    g_defaultPreferred = defaultPreferred;
+    TrackerSet statSet;  // :706
+#include "../_ref/gen/tcm_per_type_fragment.inc"
+}
+static int partition_stats_comp(const InstanceSetStatsTracker &isst1, const InstanceSetStatsTracker &isst2)  // :264
+{
+#include "../_ref/gen/tcm_partition_stats_comp_body.inc"
+}
+}  // namespace a18
+
 // ======================= a19: UpgradeTracker (UpgradeTracker.java:45-201) ============================================================
 namespace a19 {
 #include "../_ref/gen/upgrade_constants.inc"
@@ -967,6 +1140,13 @@ int main(int argc, char **argv)
     auto n_up_v = rd<int64_t>(f, 1);
     const int64_t n_up = n_up_v[0];
     auto upevents = rd<UpgradeEvent>(f, n_up > 0 ? (size_t)n_up : 0);
+    // a18: a type-constraint configuration over the instance table: T types, the label bitset of every instance and the required /
+    // preferred label bitsets of every type (bit i = label "l<i, two digits>")
+    auto n_tc_v = rd<int64_t>(f, 1);
+    const int64_t n_tc = n_tc_v[0];
+    auto tc_pod_bits = rd<uint64_t>(f, n_tc >= 0 ? (size_t)P : 0);
+    auto tc_req_bits = rd<uint64_t>(f, n_tc > 0 ? (size_t)n_tc : 0);
+    auto tc_pref_bits = rd<uint64_t>(f, n_tc > 0 ? (size_t)n_tc : 0);
     fclose(f);
 
     std::vector<String> ids(P);
@@ -1457,6 +1637,99 @@ int main(int argc, char **argv)
             }
         }
         wr(o, uo);
+    }
+    // ---- a18: per type row (T configured types + the row of unconfigured types) has_allowed, has_prefer, the two instance sets as
+    // bitmaps over the instance index; every instance's partition; per partition its prohibited type rows and stats; the partitions
+    // in the reaper's order; per type candidateSubsetStats
+    if (n_tc >= 0) {
+        auto labels_of = [](uint64_t bits) {
+            StringArray a;
+            for (int i = 0; i < 64; i++)
+                if ((bits >> i) & 1ull) {
+                    char b[8];
+                    snprintf(b, sizeof b, "l%02d", i);
+                    a.p->push_back(String(b));
+                }
+            return a;  // sorted: two-digit indices
+        };
+        auto type_name = [](int64_t t) { char b[16]; snprintf(b, sizeof b, "t%03d", (int)t); return String(b); };
+        for (const auto &e : *g_cluster) e.getValue().a18_setLabels(labels_of(tc_pod_bits[pod_of[e.getKey().str()]]));
+        a18::MtcMap mtcMap;
+        for (int64_t t = 0; t < n_tc; t++)  // typeMappingsUpdated, new types (:641-653)
+            mtcMap.es.push_back(Entry<String, a18::ModelTypeConstraints>(
+                type_name(t), a18::fromInstanceSet(labels_of(tc_req_bits[t]), labels_of(tc_pref_bits[t]), *g_cluster, type_name(t), a18::TrackerArray(null))));
+        // :655-664: every instance into the tracker of its ProhibitedTypeSet, its record marked with the set
+        a18::PtsMap ptsMap;
+        std::vector<int64_t> pod_part(P, -1);
+        auto marked = std::make_shared<std::vector<Entry<String, InstanceRecord>>>();
+        for (const auto &e : *g_cluster) {
+            const ProhibitedTypeSet pts = a18::prohibitedTypesOf(e.getKey(), mtcMap);
+            a18::InstanceSetStatsTracker tr(null);
+            for (const auto &pe : ptsMap.es)
+                if (pe.getKey().equals(pts)) tr = pe.getValue();
+            if (!tr.p) {
+                tr.p = std::make_shared<a18::TrackerObj>();
+                tr->prohibitedTypesSet = pts;
+                tr->id = (int)ptsMap.es.size();
+                ptsMap.es.push_back(Entry<ProhibitedTypeSet, a18::InstanceSetStatsTracker>(pts, tr));
+            }
+            InstanceRecord ir = e.getValue();
+            tr->sums.add(e.getKey(), ir);
+            ir.prohibitedTypes = tr->prohibitedTypesSet;
+            pod_part[pod_of[e.getKey().str()]] = tr->id;
+            marked->push_back(Entry<String, InstanceRecord>(e.getKey(), ir));
+        }
+        g_cluster = marked;
+        // the trackers' LRU is not set by typeMappingsUpdated; the listener re-accumulates it over ALL of clusterState on the next
+        // table event of a member (MM.java:1515-1542: resetLru, then addLru for every remaining entry) — applied here
+        for (const auto &pe : ptsMap.es) {
+            a18::InstanceSetStatsTracker tr = pe.getValue();
+            tr->sums.resetLru();
+            for (const auto &e : *g_cluster) tr->sums.addLru(e.getValue().getLruTime());
+            tr->currentStats = tr->sums.update();
+        }
+        a18::refreshPerTypeInstanceSets(mtcMap, ptsMap);
+        const int64_t Wd = (P + 63) / 64;
+        std::vector<int64_t> to;
+        auto put_set = [&](const Set<String> &st) {
+            std::vector<uint64_t> w((size_t)Wd, 0);
+            if (st != null)
+                for (const auto &id : st) { const int p_ = pod_of[id.str()]; w[p_ >> 6] |= 1ull << (p_ & 63); }
+            for (uint64_t x : w) to.push_back((int64_t)x);
+        };
+        for (int64_t t = 0; t <= n_tc; t++) {
+            Set<String> al(null), pf = a18::g_defaultPreferred;  // getCandidateInstances / getPreferredInstances of an unconfigured type (:241-251)
+            if (t < n_tc) {
+                const a18::ModelTypeConstraints m = mtcMap.es[(size_t)t].getValue();
+                al = m.allowedInstances;
+                pf = m.preferredInstances;
+            }
+            to.push_back(al != null);
+            to.push_back(pf != null);
+            put_set(al);
+            put_set(pf);
+        }
+        for (int64_t v : pod_part) to.push_back(v);
+        auto put_stats = [&](const ClusterStats &c) {
+            to.push_back(c.totalCapacity); to.push_back(c.totalFree); to.push_back(c.globalLru); to.push_back(c.instanceCount); to.push_back(c.modelCopyCount);
+        };
+        to.push_back((int64_t)ptsMap.es.size());
+        for (const auto &pe : ptsMap.es) {
+            const auto &ty = pe.getKey().types();
+            to.push_back((int64_t)ty.size());
+            for (const auto &nm : ty) to.push_back(std::stoll(nm.substr(1)));
+            put_stats(pe.getValue()->currentStats);
+        }
+        std::vector<a18::InstanceSetStatsTracker> order;  // getPartitionStats (:279-289): the list sorted by PARTITION_STATS_COMP
+        for (const auto &pe : ptsMap.es) order.push_back(pe.getValue());
+        std::stable_sort(order.begin(), order.end(), [](const a18::InstanceSetStatsTracker &a, const a18::InstanceSetStatsTracker &b) { return a18::partition_stats_comp(a, b) < 0; });
+        for (const auto &tr : order) to.push_back(tr->id);
+        for (int64_t t = 0; t < n_tc; t++) {  // getTypeSetStats(type) (:228-231)
+            const a18::NullableStats ns = mtcMap.es[(size_t)t].getValue().candidateSubsetStats();
+            to.push_back(ns.isnull ? 0 : 1);
+            put_stats(ns.isnull ? ClusterStats() : ns.v);
+        }
+        wr(o, to);
     }
     fclose(o);
     return 0;

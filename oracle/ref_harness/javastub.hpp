@@ -104,6 +104,7 @@ public:
     Entry(const K &k, const V &v) : p(std::make_shared<Rep>(Rep{k, v})) {}
     const K &getKey() const { return p->k; }
     const V &getValue() const { return p->v; }
+    void setValue(const V &v) const { p->v = v; }  // writes through: the entries a map hands out share their storage with it
     bool operator==(std::nullptr_t) const { return !p; }
     bool operator!=(std::nullptr_t) const { return (bool)p; }
 };
@@ -209,11 +210,13 @@ public:
     boolean contains(const T &t) const { return p->count(t) != 0; }
     boolean isEmpty() const { return p->empty(); }
     boolean add(const T &t) const { return p->insert(t).second; }
+    void clear() const { p->clear(); }
     int size() const { return (int)p->size(); }
     Rep::const_iterator begin() const { return p->begin(); }
     Rep::const_iterator end() const { return p->end(); }
 };
 static inline Set<String> TreeSet_new() { return Set<String>::make(); }
+static inline Set<String> HashSet_new(int = 0) { return Set<String>::make(); }  // `new HashSet<>(n)` of strings (iteration order: by string)
 // com.google.common.collect.Sets.union (a view in Guava; a copy here: nothing mutates the operands afterwards)
 static const struct {
     Set<String> union_(const Set<String> &a, const Set<String> &b) const

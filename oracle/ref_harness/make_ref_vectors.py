@@ -37,7 +37,7 @@ def proactive_inputs(fleet, units, partitioned):
 
 
 def run(blob: bytes, n_place: int, n_serve: int, n_gate: int = 0, n_scale: int = -1, n_pods: int = 0, n_sd: int = -1, proactive: bool = False,
-        events: bool = False, upgrade: int = -1):
+        events: bool = False, upgrade: int = -1, types=None):
     with tempfile.TemporaryDirectory() as td:
         fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
         open(fin, "wb").write(blob)
@@ -53,6 +53,30 @@ def run(blob: bytes, n_place: int, n_serve: int, n_gate: int = 0, n_scale: int =
     off += 16 * n_serve
     gate = np.frombuffer(raw, "<i4", 2 * n_gate, off).reshape(n_gate, 2).copy()
     off += 8 * n_gate
+    if types is not None:  # (T, P): see harness.cc "a18"
+        T, P = types
+        W = (P + 63) // 64
+        w = np.frombuffer(raw, "<i8", (len(raw) - off) // 8, off)
+        i = 0
+        rows = np.zeros((T + 1, 2 + 2 * W), np.int64)
+        for t in range(T + 1):
+            rows[t] = w[i: i + 2 + 2 * W]
+            i += 2 + 2 * W
+        pod_part = w[i: i + P].copy()
+        i += P
+        n_part = int(w[i])
+        i += 1
+        part_types, part_stats = [], []
+        for _ in range(n_part):
+            k = int(w[i])
+            part_types.append(w[i + 1: i + 1 + k].copy())
+            part_stats.append(w[i + 1 + k: i + 6 + k].copy())
+            i += 6 + k
+        order = w[i: i + n_part].copy()
+        i += n_part
+        tstats = w[i: i + 6 * T].reshape(T, 6).copy()
+        assert i + 6 * T == len(w)
+        return rows, pod_part, part_types, np.array(part_stats).reshape(n_part, 5), order, tstats
     if upgrade >= 0:  # after every call: n, then n x (replica set, expiry)
         w = np.frombuffer(raw, "<i8", (len(raw) - off) // 8, off)
         maps, i = [], 0
@@ -164,6 +188,17 @@ def main():
         names.append(name)
         print(f"{name}: {len(ev)} listener events, {len(orders)} checkpoints; upgradeTracker added/removed {counters[0]}/{counters[1]}, "
               f"housekeepings {counters[2]}")
+    for name, fleet, ids, pod_bits, req_bits, pref_bits in rf.type_constraint_cases():
+        blob = rf.input_blob(fleet, ids, types=(pod_bits, req_bits, pref_bits))
+        rows, pod_part, part_types, part_stats, order, tstats = run(blob, 0, 0, types=(len(req_bits), fleet.n_pods))
+        out[f"{name}/rows"], out[f"{name}/pod_part"], out[f"{name}/part_stats"] = rows, pod_part, part_stats
+        out[f"{name}/part_types_len"] = np.array([len(x) for x in part_types], np.int32)
+        out[f"{name}/part_types"] = np.concatenate(part_types) if part_types else np.zeros(0, np.int64)
+        out[f"{name}/order"], out[f"{name}/tstats"] = order, tstats
+        out[f"{name}/digest"] = np.frombuffer(rf.digest(blob).encode(), np.uint8)
+        names.append(name)
+        print(f"{name}: {len(req_bits)} types over {fleet.n_pods} instances: {len(part_types)} ProhibitedTypeSet partitions, "
+              f"{int(rows[:-1, 0].sum())} types with requirements, {int(rows[:, 1].sum())} rows with preferred instances")
     small = rf.wl.fuzz_fleet(1, pods=4, models=4)  # the harness wants a fleet in every input; the tracker never looks at it
     small_ids = rf.string_ids(small, 1)
     for name, ev in rf.upgrade_event_cases():

@@ -414,6 +414,28 @@ def table_event_cases():
         yield f"table_events_{seed}", fleet, ids, ev, ck, tables
 
 
+def type_constraint_cases():
+    """(name, fleet, ids, pod_bits, req_bits, pref_bits): a type-constraint configuration over an instance table (as
+    tests/test_types_gpu.py draws them): bit i of an instance's word = it carries label i; per type the required and preferred labels."""
+    for seed, P, T, n_labels, label_p in ((0, 5, 2, 2, 0.5), (1, 64, 4, 3, 0.4), (2, 200, 6, 5, 0.3), (3, 700, 8, 6, 0.15), (4, 65, 3, 2, 0.0),
+                                           (5, 130, 5, 4, 0.9), (6, 300, 12, 8, 0.5), (7, 40, 1, 1, 0.5)):
+        rng = np.random.default_rng(9000 + seed)
+        fleet = wl.fuzz_fleet(seed, pods=P, models=50)
+        fleet.n_types, fleet.allowed, fleet.prefer = 0, None, None
+        fleet.has_allowed = fleet.has_prefer = None
+        pod_bits = np.zeros(P, np.uint64)
+        for p in range(P):
+            pod_bits[p] = sum(1 << i for i in range(n_labels) if rng.random() < label_p)
+        req_bits, pref_bits = np.zeros(T, np.uint64), np.zeros(T, np.uint64)
+        for t in range(T):
+            nr, nf = int(rng.choice([0, 0, 1, 2])), int(rng.choice([0, 1, 2]))
+            req = rng.choice(n_labels, size=min(nr, n_labels), replace=False) if nr else []
+            pref = [l for l in (rng.choice(n_labels, size=min(nf, n_labels), replace=False) if nf else []) if l not in req]  # kept disjoint (:96-99)
+            req_bits[t] = sum(1 << int(l) for l in req)
+            pref_bits[t] = sum(1 << int(l) for l in pref)
+        yield f"type_constraints_{seed}", fleet, string_ids(fleet, 70 + seed), pod_bits, req_bits, pref_bits
+
+
 UPGRADE_EVENT = np.dtype([("kind", "<i4"), ("replica_set", "<i4"), ("labels_key", "<i8"), ("start_time", "<i8"), ("now", "<i8")])
 
 
@@ -482,7 +504,7 @@ def _lib_flag_live():
 
 
 def input_blob(fleet, ids, reqs=None, extra=None, serve=None, gates=None, scaleup=None, scaledown=None, proactive=None, events=None,
-               upgrade=None) -> bytes:
+               upgrade=None, types=None) -> bytes:
     """The harness' input file (layout: oracle/ref_harness/harness.cc main())."""
     P, M = fleet.n_pods, fleet.n_models
     T = int(fleet.n_types)
@@ -554,6 +576,13 @@ def input_blob(fleet, ids, reqs=None, extra=None, serve=None, gates=None, scaleu
     else:
         assert upgrade.dtype.itemsize == 32
         parts += [struct.pack("<q", len(upgrade)), np.ascontiguousarray(upgrade).tobytes()]
+    if types is None:
+        parts += [struct.pack("<q", -1)]
+    else:
+        pod_bits, req_bits, pref_bits = types
+        assert len(pod_bits) == fleet.n_pods and len(req_bits) == len(pref_bits)
+        parts += [struct.pack("<q", len(req_bits)), np.ascontiguousarray(pod_bits, dtype=np.uint64).tobytes(),
+                  np.ascontiguousarray(req_bits, dtype=np.uint64).tobytes(), np.ascontiguousarray(pref_bits, dtype=np.uint64).tobytes()]
     return b"".join(parts)
 
 

@@ -311,3 +311,78 @@ def test_upgrade_tracker_equals_the_reference_text(ref):
             assert t.likelyReplacedReplicaSets == want[i], (name, i, t.likelyReplacedReplicaSets, want[i])
             nonempty += bool(want[i])
     assert nonempty > 200
+
+
+def _bits_to_set(words):
+    return {64 * j + b for j, w in enumerate(words) for b in range(64) if (int(w) >> b) & 1}
+
+
+def check_type_tables(name, ref, fleet, n_types, tables, partitions, type_stats):
+    """tables(t) -> (allowed set | None, preferred set | None) for t in 0..T (row T: an unconfigured type);
+    partitions -> (pod -> partition, [(5 stats, set of prohibited type rows)] per partition); type_stats(t) -> 5 stats."""
+    P = fleet.n_pods
+    W = (P + 63) // 64
+    rows = ref[f"{name}/rows"]
+    for t in range(n_types + 1):
+        al, pf = tables(t)
+        r = rows[t].astype(np.uint64)
+        want_al = _bits_to_set(r[2: 2 + W]) if rows[t][0] else None
+        want_pf = _bits_to_set(r[2 + W: 2 + 2 * W]) if rows[t][1] else None
+        assert al == want_al, (name, t, "allowed")
+        assert pf == want_pf, (name, t, "preferred", pf, want_pf)
+    lens, flat = ref[f"{name}/part_types_len"], ref[f"{name}/part_types"]
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    ref_sig = [frozenset(int(x) for x in flat[offs[k]: offs[k + 1]]) for k in range(len(lens))]
+    ref_stats = {ref_sig[k]: tuple(int(x) for x in ref[f"{name}/part_stats"][k]) for k in range(len(lens))}
+    pts, parts = partitions
+    got_stats = {sig: st for st, sig in parts}
+    assert got_stats == ref_stats, (name, got_stats, ref_stats)
+    ref_part = ref[f"{name}/pod_part"]
+    for p in range(P):  # every instance in the partition with the same ProhibitedTypeSet
+        if ref_part[p] < 0:
+            assert pts[p] < 0, (name, p)
+        else:
+            assert parts[pts[p]][1] == ref_sig[int(ref_part[p])], (name, p)
+    # the reaper's order (PARTITION_STATS_COMP: free desc, lru asc, capacity desc): the key sequence is what the comparator fixes
+    key = lambda st: (-st[1], st[2], -st[0])  # noqa: E731
+    want_keys = [key(ref_stats[ref_sig[int(k)]]) for k in ref[f"{name}/order"]]
+    assert want_keys == sorted(key(st) for st in got_stats.values()), name
+    for t in range(n_types):
+        flag, *st = (int(x) for x in ref[f"{name}/tstats"][t])
+        assert tuple(type_stats(t)) == (tuple(st) if flag else tuple(type_stats(None))), (name, t, "typeSetStats")
+
+
+def test_type_constraint_tables_equal_the_reference_text(ref):
+    """TypeConstraintManager's static computation from the reference's text (fromInstanceSet, instanceMatches, the
+    ProhibitedTypeSet of every instance, the instance scores, inferPreferredInstances, candidateSubsetStats, the partitions'
+    order) against the restatements the device tables are tested with: oracle/py_types.py for the per-type instance sets,
+    oracle/bind.py's partitions / subset stats."""
+    from oracle import py_types
+    from modelmesh_amd.solver import bitmap_from_bool
+    for name, fleet, ids, pod_bits, req_bits, pref_bits in rf.type_constraint_cases():
+        assert rf.digest(rf.input_blob(fleet, ids, types=(pod_bits, req_bits, pref_bits))) == bytes(ref[f"{name}/digest"]).decode(), name
+        P, T = fleet.n_pods, len(req_bits)
+        labels = lambda bits: [i for i in range(64) if (int(bits) >> i) & 1]  # noqa: E731
+        present = {p: set(labels(pod_bits[p])) for p in range(P) if not (fleet.pods["flags"][p] & 5)}
+        cfg = {t: (labels(req_bits[t]), labels(pref_bits[t])) for t in range(T)}
+        want, want_default = py_types.type_tables(present, cfg)
+        tables = lambda t: ((None if want[t][0] is None else set(want[t][0]), None if want[t][1] is None else set(want[t][1]))  # noqa: E731
+                            if t < T else (None, None if want_default is None else set(want_default)))
+        # the tables installed in a fleet: partitions and stats as the oracle derives them
+        import copy
+        f = copy.copy(fleet)
+        al = np.zeros((T + 1, P), bool)
+        pf = np.zeros((T + 1, P), bool)
+        ha, hp = np.zeros(T + 1, np.uint8), np.zeros(T + 1, np.uint8)
+        for t in range(T + 1):
+            a, b = tables(t)
+            ha[t], hp[t] = a is not None, b is not None
+            al[t, list(a or [])] = True
+            pf[t, list(b or [])] = True
+        f.n_types, f.allowed, f.prefer, f.has_allowed, f.has_prefer = T + 1, bitmap_from_bool(al), bitmap_from_bool(pf), ha, hp
+        pts, sets, pst = ob.partition_stats(f)
+        parts = [(tuple(int(pst[k][x]) for x in STAT_FIELDS), frozenset(int(t) for t in sets[k])) for k in range(len(sets))]
+        tss = ob.type_set_stats(f)
+        g = OracleFleet(f).stats()
+        type_stats = lambda t: tuple(int((g if t is None else tss[t])[x]) for x in STAT_FIELDS)  # noqa: E731
+        check_type_tables(name, ref, fleet, T, tables, (pts, parts), type_stats)

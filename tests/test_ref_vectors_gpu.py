@@ -147,3 +147,28 @@ def test_hip_library_upgrade_tracker_equals_the_reference_text(ref):
                 assert s.upgrade_replaced() == want[i], (name, i)
         finally:
             s.close()
+
+
+def test_hip_type_constraint_tables_equal_the_reference_text(ref):
+    """mmp_types_from_labels (type_sets_kernel / type_prefer_kernel), the partitions and the subset stats of the device against
+    TypeConstraintManager's text."""
+    from oracle.bind import unpack_bitmap
+    from tests.test_ref_vectors import STAT_FIELDS, check_type_tables
+    for name, fleet, ids, pod_bits, req_bits, pref_bits in rf.type_constraint_cases():
+        P, T = fleet.n_pods, len(req_bits)
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            s.load_pods(fleet.pods)
+            al, pf, ha, hp = s.types_from_labels(req_bits, pref_bits, pod_bits)
+            s.load_replaced_rs(fleet.replaced_rs)
+            s.load_models(fleet.models, fleet.ent_pod, fleet.ent_time)
+            s.commit()
+            A, F = unpack_bitmap(al, P).astype(bool), unpack_bitmap(pf, P).astype(bool)
+            tables = lambda t: (set(np.nonzero(A[t])[0].tolist()) if ha[t] else None, set(np.nonzero(F[t])[0].tolist()) if hp[t] else None)  # noqa: E731
+            pts, parts = s.partitions()
+            parts = [(tuple(int(st[x]) for x in STAT_FIELDS), frozenset(t for t in range(T + 1) if (pr >> t) & 1)) for st, pr in parts]
+            g = s.stats()
+            type_stats = lambda t: tuple(int((g if t is None else s.type_stats(t))[x]) for x in STAT_FIELDS)  # noqa: E731
+            check_type_tables(name, ref, fleet, T, tables, (pts, parts), type_stats)
+        finally:
+            s.close()
