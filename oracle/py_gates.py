@@ -1,7 +1,8 @@
 """Second, independent restatement of the request-level guards (test infrastructure, never imported by the
 product).  Written from the Java text alone — not from oracle/mm_gates_oracle.c — so that the two readings can be
 compared on random inputs (tests/test_oracle_cross.py): none of these guards is named by a reference test
-(SURVEY.md §8c "parity unpinned"), two readings that agree are the mitigation.
+(SURVEY.md §8c); since round 3 the C restatement is ALSO held to the reference's own text (oracle/ref_harness,
+tests/test_ref_vectors.py).
 
 Java arithmetic is kept literally: `long` / `int` wrap, `/` truncates toward zero, Math.abs(MIN_VALUE) stays negative.
 """

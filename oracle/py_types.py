@@ -1,7 +1,8 @@
 """py_types.py — CPU restatement of TypeConstraintManager's per-type instance sets
 (TypeConstraintManager.java:416-447 fromInstanceSet, :478-486 instanceMatches, :680-725
 refreshPerTypeInstanceSets, :727-747 inferPreferredInstances).  TEST INFRASTRUCTURE ONLY.
-Parity unpinned by the reference's tests except C.4 (ModelMeshErrorPropagationTest.java:52-95:
+Pinning: held to the reference's own text since round 3 (oracle/ref_harness -> tests/golden/ref_getnext.npz,
+tests/test_ref_vectors.py: 8 configurations); the reference's own test C.4 (ModelMeshErrorPropagationTest.java:52-95:
 a type that requires a label only one instance has is placed on exactly that instance)."""
 from __future__ import annotations
 

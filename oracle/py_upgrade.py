@@ -2,7 +2,8 @@
 
 `labels_key` plays the role of the identity of the record's labels array: the reference's
 `HashMap<String[], PerTypeLabelStats>` (:67) hashes arrays by identity (NO_LABELS is shared,
-InstanceRecord.java:35,89).  parity unpinned: no reference test names this class."""
+InstanceRecord.java:35,89).  No reference test names this class; held to the
+reference's own text since round 3 (oracle/ref_harness, tests/test_ref_vectors.py: twelve rolling-update streams)."""
 TEN_MINS, FIFTEEN_MINS, TWENTY_MINS = 600_000, 900_000, 1_200_000
 LONG_MAX = 2**63 - 1
 
