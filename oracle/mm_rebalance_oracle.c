@@ -3,7 +3,7 @@
  * load-target decisions.  TEST INFRASTRUCTURE ONLY.
  * Pinning: a15 (rate-tracking task), a16 (janitor scale-down) and a17 (reaper) are held to the reference's own text
  * (oracle/ref_harness -> tests/golden/ref_getnext.npz, tests/test_ref_vectors.py); C.3's second-copy timing window is the
- * reference's own test; a21 (preShutdown) is unpinned.
+ * reference's own test; a21 (preShutdown's migration loop) is held to the text too.
  */
 #include <stdlib.h>
 #include <string.h>

@@ -80,6 +80,9 @@ RANGES = [
     ("ist_remove_body", "src/main/java/com/ibm/watson/modelmesh/InstanceSetStatsTracker.java", 75, 83, "count--;", "return count <= 0;"),
     ("ist_update_body", "src/main/java/com/ibm/watson/modelmesh/InstanceSetStatsTracker.java", 87, 91, "ClusterStats newStats = new ClusterStats(totalCapacity, totalFree, lru, count, modelCount);", "return newStats;"),
     ("handleInstanceTableChange_body", MM, 1456, 1567, "if (logger.isDebugEnabled()) {", "}", "LISTENER_SWITCH"),
+    # ---- a21: preShutdown — which local copies get a new copy elsewhere, and which of those the shutdown waits for
+    ("preshutdown_cutoff_constant", MM, 276, 276, "CUTOFF_AGE_MS = 60 * 60_000L;", "1 hour"),
+    ("preshutdown_migration_fragment", MM, 6998, 7046, "List<Future<Entry<String, Long>>> waitFor = new ArrayList<>(cacheEntries.size());", "}", "SHUTDOWN"),
     # ---- a18: TypeConstraintManager — the per-type instance sets, the instance partitions and their stats (the static computation:
     # typeMappingsUpdated's building blocks; the incremental updateInstance path is not extracted)
     ("tcm_partition_stats_comp_body", "src/main/java/com/ibm/watson/modelmesh/TypeConstraintManager.java", 265, 270, "ClusterStats cs1 = isst1.currentStats, cs2 = isst2.currentStats;", "return Long.compare(cs2.totalCapacity, cs1.totalCapacity);", "TCM"),
@@ -147,6 +150,13 @@ EXTRA_RULES["TCM"] = [
     (re.compile(r"\bnew HashSet<>\("), "HashSet_new("),
     (re.compile(r"\.currentStats\b"), "->currentStats"),
     (re.compile(r"\bString\[\]"), "StringArray"),
+]
+
+# preShutdown (:7015): the task's lambda returns an entry or null — C++ wants the return type named; Java enum constants
+EXTRA_RULES["SHUTDOWN"] = [
+    (re.compile(r"taskPool\.submit\(\(\) -> \{"), "taskPool.submit([=]() -> Entry<String, Long> {"),
+    (re.compile(r"\bStatus\.(LOADING_FAILED|LOADING)\b"), r"Status::\1"),
+    (re.compile(r"\bConcurrentHashMap\.newKeySet\(\)"), "ConcurrentHashMap_newKeySet()"),
 ]
 
 # token-level rewrites, applied in order to every extracted line

@@ -641,6 +641,52 @@ static int changeCounter;
 static int g_upgrade_added, g_upgrade_removed, g_housekeepings, g_republish;
 static void handleInstanceTableChange(const SortedClusterState &clusterState, EventType type, const String &key, InstanceRecord record);
 
+// ======================= a21: preShutdown's migration loop (MM.java:6998-7046; triggerNewModelCopyElsewhere :6913-6928) ===========
+namespace a21 {
+#include "../_ref/gen/preshutdown_cutoff_constant.inc"
+template <class X> struct Future { X v; };
+static const struct { template <class F> auto submit(F f) const -> Future<decltype(f())> { return Future<decltype(f())>{f()}; } } taskPool;  // the pool's thread: here, at once
+enum class Status { LOADING, LOADING_FAILED, LOADED };
+struct StatusInfo { Status s; Status getStatus() const { return s; } String getErrorMessages() const { return null; } };
+struct ShutdownCacheEntry : ::CacheEntry {  // + what the loop reads (the entry's removal and abort state: the cache's business)
+    long loadTimestamp = 0, loadCompleteTimestamp = 0;
+    boolean isAborted() const { return false; }
+    using ::CacheEntry::CacheEntry;
+};
+static std::map<std::string, ShutdownCacheEntry> g_cache;  // runtimeCache.getQuietly
+static const struct {
+    ShutdownCacheEntry getQuietly(const String &id) const { auto it = g_cache.find(id.str()); return it == g_cache.end() ? ShutdownCacheEntry(null) : it->second; }
+    long getLastUsedTime(const String &) const { return -1L; }  // (only asked when the descending map carried 0: an entry gone meanwhile)
+} runtimeCache;
+static std::vector<std::string> g_triggered;
+static StatusInfo triggerNewModelCopyElsewhere(const String &modelId, const ModelRecord &, long, int) { g_triggered.push_back(modelId.str()); return StatusInfo{Status::LOADING}; }
+static void deregisterModelAsync(const String &, long, long, long) {}
+static Set<String> ConcurrentHashMap_newKeySet() { return Set<String>::make(); }
+static const struct {
+    void warn(const String &) const {}
+    void warn(const String &, const TException &) const {}
+} logger;
+// -> per cache entry (in the map's order): bit 0 = a copy elsewhere was triggered, bit 1 = the shutdown waits for it
+static std::vector<uint8_t> migration(const std::vector<Entry<String, Long>> &entries)
+{
+    const struct { const std::vector<Entry<String, Long>> &e; const std::vector<Entry<String, Long>> &entrySet() const { return e; } int size() const { return (int)e.size(); } } cacheEntries{entries};
+    const auto &registry = registryAll;
+    g_triggered.clear();
+#define CacheEntry ShutdownCacheEntry  /* `CacheEntry<?> ce = runtimeCache.getQuietly(modelId)` */
+#include "../_ref/gen/preshutdown_migration_fragment.inc"
+#undef CacheEntry
+    std::vector<uint8_t> out(entries.size(), 0);
+    std::map<std::string, size_t> at;
+    for (size_t i = 0; i < entries.size(); i++) at[entries[i].getKey().str()] = i;
+    for (const auto &id : g_triggered) out[at[id]] |= 1;
+    for (int i = 0; i < waitFor.size(); i++) {
+        const Entry<String, Long> w = waitFor.get(i).v;
+        if (w != null) out[at[w.getKey().str()]] |= 2;
+    }
+    return out;
+}
+}  // namespace a21
+
 // ======================= a18: TypeConstraintManager (TypeConstraintManager.java:264-270, :337-451, :478-486, :557-567, :680-747) ===============
 // The static computation — what typeMappingsUpdated (:602-667) assembles from these pieces for a given clusterState and
 // configuration: per type the allowed / configured-preferred instances (fromInstanceSet + instanceMatches), per instance its
@@ -1147,6 +1193,11 @@ int main(int argc, char **argv)
     auto tc_pod_bits = rd<uint64_t>(f, n_tc >= 0 ? (size_t)P : 0);
     auto tc_req_bits = rd<uint64_t>(f, n_tc > 0 ? (size_t)n_tc : 0);
     auto tc_pref_bits = rd<uint64_t>(f, n_tc > 0 ? (size_t)n_tc : 0);
+    // a21: preShutdown of one instance: its cache entries in descendingLruMap() order
+    auto n_mig_v = rd<int64_t>(f, 1);
+    const int64_t n_mig = n_mig_v[0];
+    auto mig_hdr = rd<int64_t>(f, n_mig >= 0 ? 2 : 0);  // self instance, now
+    auto mig_entries = rd<mmp_cache_entry>(f, n_mig > 0 ? (size_t)n_mig : 0);
     fclose(f);
 
     std::vector<String> ids(P);
@@ -1730,6 +1781,33 @@ int main(int argc, char **argv)
             put_stats(ns.isnull ? ClusterStats() : ns.v);
         }
         wr(o, to);
+    }
+    // ---- a21: per cache entry bit 0 = triggerNewModelCopyElsewhere was called, bit 1 = the shutdown waits for that copy
+    if (n_mig >= 0) {
+        instanceId = ids[mig_hdr[0]];
+        g_now = mig_hdr[1];
+        g_registry_all.clear();
+        a21::g_cache.clear();
+        std::vector<Entry<String, Long>> cache;
+        for (int64_t e = 0; e < n_mig; e++) {
+            const mmp_cache_entry &x = mig_entries[e];
+            char key[32];
+            snprintf(key, sizeof key, "m%09lld", (long long)e);
+            if (x.model >= 0 && x.model < M) {
+                const mmp_model_row &m = models[x.model];
+                ModelRecord mr;
+                for (int32_t k = 0; k < m.n_loaded + m.n_failed; k++)
+                    (k < m.n_loaded ? mr.instanceIds : mr.failed).put(ids[ent_pod[m.ent_off + k]], Long(ent_time[m.ent_off + k]));
+                g_registry_all[key] = mr;
+            }
+            a21::ShutdownCacheEntry ce;
+            ce.isnull = false;
+            ce.failed = (x.flags & MMP_CE_FAILED) != 0;  // ce == null || ce.isFailed()
+            ce.weight = x.weight;
+            a21::g_cache[key] = ce;
+            cache.push_back(Entry<String, Long>(String(key), Long(x.last_used)));
+        }
+        wr(o, a21::migration(cache));
     }
     fclose(o);
     return 0;

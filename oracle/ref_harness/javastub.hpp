@@ -264,6 +264,7 @@ public:
 // java.util.Collections.min over boxed longs
 struct Collections {
     static Set<String> emptySet() { return Set<String>::make(); }
+    static List<String> singletonList(const String &x) { List<String> l = ArrayList_new(1); l.add(x); return l; }
     static long min(const std::vector<Long> &v)
     {
         long m = v.at(0);

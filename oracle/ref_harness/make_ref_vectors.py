@@ -37,7 +37,7 @@ def proactive_inputs(fleet, units, partitioned):
 
 
 def run(blob: bytes, n_place: int, n_serve: int, n_gate: int = 0, n_scale: int = -1, n_pods: int = 0, n_sd: int = -1, proactive: bool = False,
-        events: bool = False, upgrade: int = -1, types=None):
+        events: bool = False, upgrade: int = -1, types=None, migration: int = -1):
     with tempfile.TemporaryDirectory() as td:
         fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
         open(fin, "wb").write(blob)
@@ -53,6 +53,10 @@ def run(blob: bytes, n_place: int, n_serve: int, n_gate: int = 0, n_scale: int =
     off += 16 * n_serve
     gate = np.frombuffer(raw, "<i4", 2 * n_gate, off).reshape(n_gate, 2).copy()
     off += 8 * n_gate
+    if migration >= 0:
+        bits = np.frombuffer(raw, "u1", migration, off).copy()
+        assert off + migration == len(raw)
+        return bits
     if types is not None:  # (T, P): see harness.cc "a18"
         T, P = types
         W = (P + 63) // 64
@@ -199,6 +203,13 @@ def main():
         names.append(name)
         print(f"{name}: {len(req_bits)} types over {fleet.n_pods} instances: {len(part_types)} ProhibitedTypeSet partitions, "
               f"{int(rows[:-1, 0].sum())} types with requirements, {int(rows[:, 1].sum())} rows with preferred instances")
+    for name, fleet, ids, entries, self_pod, now in rf.migration_cases():
+        blob = rf.input_blob(fleet, ids, migration=(entries, self_pod, now))
+        bits = run(blob, 0, 0, migration=len(entries))
+        out[f"{name}/migration"] = bits
+        out[f"{name}/digest"] = np.frombuffer(rf.digest(blob).encode(), np.uint8)
+        names.append(name)
+        print(f"{name}: {len(entries)} cache entries: {int((bits & 1).sum())} copies triggered elsewhere, the shutdown waits for {int((bits >> 1).sum())}")
     small = rf.wl.fuzz_fleet(1, pods=4, models=4)  # the harness wants a fleet in every input; the tracker never looks at it
     small_ids = rf.string_ids(small, 1)
     for name, ev in rf.upgrade_event_cases():

@@ -414,6 +414,19 @@ def table_event_cases():
         yield f"table_events_{seed}", fleet, ids, ev, ck, tables
 
 
+def migration_cases():
+    """(name, fleet, ids, entries, self_pod, now): preShutdown of instance 0 (MM.java:6998-7046): its cache entries in
+    descendingLruMap() order — held and not held by it according to the registry, failed, never used (lastUsed 0), older and
+    younger than CUTOFF_AGE_MS."""
+    for seed, pods, used in ((0, 12, 0.5), (1, 200, 0.97), (2, 200, 0.2), (3, 1, 0.5), (4, 300, 0.99)):
+        fleet, rng = _rebalance_fleet(seed, pods, 600, used)
+        entries = _local_entries(fleet, rng, 800)
+        entries["last_used"] = np.where(rng.random(800) < 0.3, fleet.now - rng.choice([3_599_999, 3_600_000, 3_600_001, 7_000_000], 800),
+                                        entries["last_used"])  # the cutoff's edges
+        entries = entries[np.argsort(-entries["last_used"], kind="stable")]  # most recently used first
+        yield f"migration_{seed}", fleet, string_ids(fleet, 50 + seed), entries, 0, fleet.now
+
+
 def type_constraint_cases():
     """(name, fleet, ids, pod_bits, req_bits, pref_bits): a type-constraint configuration over an instance table (as
     tests/test_types_gpu.py draws them): bit i of an instance's word = it carries label i; per type the required and preferred labels."""
@@ -504,7 +517,7 @@ def _lib_flag_live():
 
 
 def input_blob(fleet, ids, reqs=None, extra=None, serve=None, gates=None, scaleup=None, scaledown=None, proactive=None, events=None,
-               upgrade=None, types=None) -> bytes:
+               upgrade=None, types=None, migration=None) -> bytes:
     """The harness' input file (layout: oracle/ref_harness/harness.cc main())."""
     P, M = fleet.n_pods, fleet.n_models
     T = int(fleet.n_types)
@@ -583,6 +596,11 @@ def input_blob(fleet, ids, reqs=None, extra=None, serve=None, gates=None, scaleu
         assert len(pod_bits) == fleet.n_pods and len(req_bits) == len(pref_bits)
         parts += [struct.pack("<q", len(req_bits)), np.ascontiguousarray(pod_bits, dtype=np.uint64).tobytes(),
                   np.ascontiguousarray(req_bits, dtype=np.uint64).tobytes(), np.ascontiguousarray(pref_bits, dtype=np.uint64).tobytes()]
+    if migration is None:
+        parts += [struct.pack("<q", -1)]
+    else:
+        entries, self_pod, now = migration
+        parts += [struct.pack("<qqq", len(entries), int(self_pod), int(now)), np.ascontiguousarray(entries).tobytes()]
     return b"".join(parts)
 
 

@@ -386,3 +386,16 @@ def test_type_constraint_tables_equal_the_reference_text(ref):
         g = OracleFleet(f).stats()
         type_stats = lambda t: tuple(int((g if t is None else tss[t])[x]) for x in STAT_FIELDS)  # noqa: E731
         check_type_tables(name, ref, fleet, T, tables, (pts, parts), type_stats)
+
+
+def test_preshutdown_migration_equals_the_reference_text(ref):
+    """preShutdown's loop over the local cache (MM.java:6998-7046): for which entries triggerNewModelCopyElsewhere is called and
+    which of those the shutdown waits for (CUTOFF_AGE_MS, :276), from the reference's text."""
+    n_act = n_wait = 0
+    for name, fleet, ids, entries, self_pod, now in rf.migration_cases():
+        assert rf.digest(rf.input_blob(fleet, ids, migration=(entries, self_pod, now))) == bytes(ref[f"{name}/digest"]).decode(), name
+        act, wait = ob.migration_plan(fleet, entries, self_pod, now)
+        bits = ref[f"{name}/migration"]
+        assert np.array_equal(act, bits & 1) and np.array_equal(wait, bits >> 1), name
+        n_act, n_wait = n_act + int(act.sum()), n_wait + int(wait.sum())
+    assert n_act > 500 and 0 < n_wait < n_act

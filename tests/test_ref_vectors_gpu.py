@@ -172,3 +172,15 @@ def test_hip_type_constraint_tables_equal_the_reference_text(ref):
             check_type_tables(name, ref, fleet, T, tables, (pts, parts), type_stats)
         finally:
             s.close()
+
+
+def test_hip_preshutdown_migration_equals_the_reference_text(ref):
+    for name, fleet, ids, entries, self_pod, now in rf.migration_cases():
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            s.load_fleet(fleet)
+            act, wait = s.migration_plan(entries, self_pod, now)
+        finally:
+            s.close()
+        bits = ref[f"{name}/migration"]
+        assert np.array_equal(act, bits & 1) and np.array_equal(wait, bits >> 1), name
