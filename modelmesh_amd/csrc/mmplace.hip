@@ -586,7 +586,6 @@ void mmp_destroy(mmp_ctx *c)
     (void)hipSetDevice(c->cfg.device);
     resident_stop(c);
     if (c->res.stream) (void)hipStreamDestroy(c->res.stream);
-    if (c->f_done) (void)hipHostFree(c->f_done);
     if (c->res.slots) (void)hipHostFree(c->res.slots);
     if (c->res.ctl) (void)hipHostFree(c->res.ctl);
     if (c->res.answers) (void)hipHostFree(c->res.answers);
@@ -603,7 +602,8 @@ void mmp_destroy(mmp_ctx *c)
         if (f.outs) (void)hipHostFree(f.outs);
     }
 
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);  // (an asynchronous pod-axis batch may still be writing its count)
+    if (c->f_done) (void)hipHostFree(c->f_done);
     if (c->comm) {
         group_comm_destroy(c->comm);
         c->comm = nullptr;
