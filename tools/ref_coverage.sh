@@ -9,7 +9,8 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 out=${1:-/dev/stdout}; case "$out" in /*) ;; *) out="$PWD/$out";; esac
 tmp=$(mktemp -d)
 trap 'rm -rf "$tmp"' EXIT
-bash "$root/oracle/ref_harness/build.sh" > /dev/null   # (re)extracts oracle/_ref/gen/*.inc
+KEEP_GEN=1 bash "$root/oracle/ref_harness/build.sh" > /dev/null   # (re)extracts oracle/_ref/gen/*.inc and keeps them for the second compile
+trap 'rm -rf "$tmp"; rm -f "$root"/oracle/_ref/gen/*.inc' EXIT
 cd "$tmp"
 g++ -std=c++17 -O0 -g -fwrapv --coverage -w "$root/oracle/ref_harness/harness.cc" -o ref_harness_cov
 MMP_REF_HARNESS="$tmp/ref_harness_cov" MMP_REF_OUT="$tmp/out.npz" python3 "$root/oracle/ref_harness/make_ref_vectors.py" > gen.log
