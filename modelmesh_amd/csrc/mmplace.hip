@@ -172,6 +172,7 @@ struct mmp_ctx {
     size_t lds_limit = 64 * 1024;    // LDS a workgroup may use on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
     std::atomic<size_t> lds_granted{48 * 1024};  // dynamic LDS the place kernels may be launched with so far
     int32_t no_caseb = 0;    // MMP_NO_CASEB=1: case (b) decisions never use the whole-window tables (tests: the wave path decides them)
+    int32_t no_long_lds = 0; // MMP_NO_LONG_LDS=1: the long path reads its per-type tables from global memory (tests, comparison)
     int32_t no_heads = 0;    // MMP_NO_HEADS=1: decisions do not use the per-type head windows (tests: lane_decide_r alone)
 
     // host staging (inputs of the next commit)
@@ -454,9 +455,19 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     A.done_seq = done_seq;
     const int wpad = (c->snap.W + 1) & ~1;
     // one dynamic region: the lane phase's windows + scratch, re-used by the wave path's tiles (place_block)
-    const size_t lds = std::max<size_t>((size_t)kPlaceWaves * 2 * wpad * sizeof(uint64_t), (size_t)place_lane_lds(c->snap.T));
+    size_t lds = std::max<size_t>((size_t)kPlaceWaves * 2 * wpad * sizeof(uint64_t), (size_t)place_lane_lds(c->snap.T));
     // the long kernel on a full cluster: the case (b) tables of the snapshot's preferring types (place_kernel.hpp: BSlot)
     A.long_first = (c->snap_long && c->snap_full && A.rmodels) ? 1 : 0;
+    // the long path's per-type tables in LDS when they are small (C3: 20 KB) and the launch fills the chip: measured on the full
+    // cluster, 800k decisions per launch 70.8 -> 67.1 us; at 100k (1.5 wavefronts per SIMD) 20.4 -> 21.0 us, hence the size condition
+    if (A.long_first && !inline_req && !done_flag && !c->no_long_lds && n >= kLongDenseFrom) {
+        const size_t tb = long_tables_bytes(c->snap.T, c->snap.W);
+        if (tb <= 24 * 1024) {
+            const size_t off = (lds + 15) & ~(size_t)15;
+            A.long_first = 1 + (int32_t)off;
+            lds = off + tb;
+        }
+    }
     if (c->snap_long && !inline_req && !done_flag && A.wins && !c->no_caseb) {
         const SnapBufs &B = c->sb[c->cur];
         if (B.n_bslots > 0) {
@@ -536,6 +547,7 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     }
     if (const char *fw = getenv("MMP_FORCE_WAVE")) c->force_wave = fw[0] == '1';
     if (const char *nh = getenv("MMP_NO_HEADS")) c->no_heads = nh[0] == '1';
+    if (const char *nl = getenv("MMP_NO_LONG_LDS")) c->no_long_lds = nl[0] == '1';
     if (const char *nb = getenv("MMP_NO_CASEB")) c->no_caseb = nb[0] == '1';
     const bool want_resident = getenv("MMP_RESIDENT") && getenv("MMP_RESIDENT")[0] == '1';
     if (const char *rm = getenv("MMP_RANK_MODE")) c->rank_mode = atoi(rm);

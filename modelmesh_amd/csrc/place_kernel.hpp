@@ -141,7 +141,9 @@ struct PlaceArgs {
     const uint64_t *bsurv;
     const int32_t *bpcs;
     int32_t n_bslots;
-    int32_t long_first;            // long kernel on a snapshot whose instances are (nearly) all full: most shortlists span the table, so the
+    int32_t long_first;            // (0: no; 1 + o: yes, and with o != 0 the per-type tables the lanes search — elig, pref, pc, nz — are staged in
+                                   // LDS at byte offset o of the dynamic region: long_tables_bytes(T, W))
+                                   // long kernel on a snapshot whose instances are (nearly) all full: most shortlists span the table, so the
                                    // first lane phase runs the prefix-table instantiation at once instead of window -> lane -> long
     const int32_t *ent_pod;  // model entries: loaded ids then failed ids
     const int32_t *extra;    // per-request extra exclusions
@@ -1934,6 +1936,8 @@ constexpr int kLaneScratchBytes = kWinWords * kPlaceBlock * 8;  // one column of
 __host__ __device__ constexpr int place_lane_lds(int type_rows) { return win_lds_bytes(type_rows) + kLaneScratchBytes; }
 constexpr int kPlaceLaneLds = kWinLdsBytes + kLaneScratchBytes;  // the most the lane phase needs: windows + scratch
 constexpr int kPlaceStaticLds = 2 * kPlaceBlock * 4 + 64 + 256;                // the lists (+ place_single_kernel's request)
+// bytes of the long path's per-type tables when they are staged in LDS: elig + pref ([T][W] words each), pc + nz ([2][T][W + 1] ints each)
+__host__ __device__ constexpr size_t long_tables_bytes(int T, int W) { return (size_t)T * W * 16 + (size_t)4 * T * (W + 1) * 4; }
 template <bool WITH_LONG>
 __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, int32_t wpad, unsigned char *smem,
                                             uint32_t *done_blocks = nullptr)
@@ -1970,6 +1974,29 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
     // barrier (the model row, the caller's position, the late-bound exclusions) has to be drained for it.
     mmp_place_req rq{};
     if (d < A.n) rq = A.reqs[d];
+    // The long path on a full cluster reads, per decision, ~57 words of tables every decision shares — the type's eligibility /
+    // preference rows (the scans), the prefix counts (8 binary-search steps), the next-non-empty-word rows: 20 KB on C3.  Staged
+    // here (beside the request fetch, before the barrier) for launches that fill the chip, where they relieve L2 (-5 % at 800k;
+    // a 100k launch is not faster with them: the host decides, PlaceArgs::long_first).
+    Snap Sl = S;
+    if (WITH_LONG && A.long_first > 1) {  // wave-uniform
+        unsigned char *tb = smem + (A.long_first - 1);
+        const int nE = S.T * S.W, nPC = 2 * S.T * (S.W + 1);
+        uint64_t *lE = reinterpret_cast<uint64_t *>(tb), *lP = lE + nE;
+        int32_t *lpc = reinterpret_cast<int32_t *>(lP + nE), *lnz = lpc + nPC;
+        for (int i = threadIdx.x; i < nE; i += kPlaceBlock) {
+            lE[i] = S.elig[i];
+            lP[i] = S.pref[i];
+        }
+        for (int i = threadIdx.x; i < nPC; i += kPlaceBlock) {
+            lpc[i] = S.pc[i];
+            lnz[i] = S.nz[i];
+        }
+        Sl.elig = lE;
+        Sl.pref = lP;
+        Sl.pc = lpc;
+        Sl.nz = lnz;
+    }
     // case (b) on a full cluster (long kernel): the snapshot's whole-window tables (BSlot)
     BLds Bt{};
     const BLds *Btp = nullptr;
@@ -1992,7 +2019,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
         int code = kLaneHeadMiss;
         if (WITH_LONG && A.long_first) {  // (wave-uniform) a full cluster: nearly every decision would end in the long phase anyway
             merge_late_extras(r);
-            code = lane_decide_r<false, true>(S, A, r, o, Btp);
+            code = lane_decide_r<false, true>(Sl, A, r, o, Btp);
         } else {
             if (use_wins) code = lane_decide_win(S, A, r, s_wins, s_scr + threadIdx.x, o);
             if (code == kLaneHeadMiss) {
@@ -2017,7 +2044,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
         if ((int)threadIdx.x < nlr) {
             const int ld = lr_list[threadIdx.x];
             mmp_place_out o;
-            if (lane_decide<false, true>(S, A, ld, o, Btp) != kLaneDone)
+            if (lane_decide<false, true>(Sl, A, ld, o, Btp) != kLaneDone)
                 fb_list[atomicAdd(&fb_n, 1)] = ld;
             else
                 A.outs[ld] = o;

@@ -26,6 +26,10 @@ from modelmesh_amd.solver import Solver  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 fleet = wl.make_fleet("C3")
+if os.environ.get("MMP_PHASE_FULL") == "1":  # every instance full, all caches about equally old (bench.py: full_cluster_leg): the long path
+    rng = np.random.default_rng(5)
+    fleet.pods["used"] = fleet.pods["capacity"] - rng.integers(0, 40_000, fleet.n_pods)
+    fleet.pods["lru_time"] = fleet.now - (36_000_000 * (1 + rng.uniform(-0.04, 0.04, fleet.n_pods))).astype(np.int64)
 reqs, extra = wl.make_requests(fleet, seed=0xBE7C0)
 n = len(reqs)
 s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
