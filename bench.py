@@ -453,10 +453,26 @@ def full_cluster_leg(workload: str, device: int, dev):
         torch.cuda.synchronize(dev)
         dt = (time.perf_counter() - t0) / 20
         got = np.frombuffer(d_outs.cpu().numpy().tobytes(), dtype=PLACE_OUT)
+        # the same launches alternating on two streams (the shape of the headline's timed region: one launch's ramp-up and tail
+        # under the other's body), each stream with its own result buffer
+        st2 = torch.cuda.Stream(dev)
+        d_outs2 = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+        pairs = ((st, d_outs), (st2, d_outs2))
+        for i in range(4):
+            q, o = pairs[i & 1]
+            s.place_dev(d_reqs.data_ptr(), n, d_extra.data_ptr(), fleet.now, o.data_ptr(), q.cuda_stream)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(40):
+            q, o = pairs[i & 1]
+            s.place_dev(d_reqs.data_ptr(), n, d_extra.data_ptr(), fleet.now, o.data_ptr(), q.cuda_stream)
+        torch.cuda.synchronize(dev)
+        dt2 = (time.perf_counter() - t0) / 40
+        got2 = np.frombuffer(d_outs2.cpu().numpy().tobytes(), dtype=PLACE_OUT)
     finally:
         s.close()
     want = OracleFleet(fleet).place(reqs, extra, fleet.now, threads=usable_cpus())
-    parity = bool(all(np.array_equal(got[f], want[f]) for f in ("chosen", "best", "n_candidates", "hash")))
+    parity = bool(all(np.array_equal(g[f], want[f]) for g in (got, got2) for f in ("chosen", "best", "n_candidates", "hash")))
     # roofline of place_batch_long_kernel on this fleet.  What a decision MUST move is what it moves on any fleet (request, model
     # row, its lists, result): the shortlist's per-type prefix tables (candidate count, hash sum, rpm-rule survivors over the
     # shortlist order; built at commit) are shared by all decisions and L2-resident.  The walk they replace would have read a
@@ -469,7 +485,9 @@ def full_cluster_leg(workload: str, device: int, dev):
             "compulsory_bytes_per_launch": comp, "walk_equivalent_bytes": int(got["n_candidates"].astype(np.int64).sum()) * 16,
             "note": "launch time here = wall time of 20 back-to-back launches on one stream / 20"}
     return {"workload": f"{workload} with every instance full, lruTimes within +-4 % of 10 h", "value": n / dt, "unit": "decisions/s",
-            "ms_per_step": dt * 1e3, "mean_shortlist": float(got["n_candidates"].mean()), "parity_vs_oracle": parity, "roofline": roof}
+            "ms_per_step": dt * 1e3, "note": "value / ms_per_step: launches back to back on ONE stream (what rounds 1-2 reported)",
+            "value_two_streams": n / dt2, "ms_per_step_two_streams": dt2 * 1e3,
+            "mean_shortlist": float(got["n_candidates"].mean()), "parity_vs_oracle": parity, "roofline": roof}
 
 
 def _single_prober():
