@@ -35,6 +35,7 @@ struct ReplayArgs {
     CacheStore src, dst;       // the call re-lays the store out (room for this call's inserts)
     int64_t *capacity;         // [n_caches] clhm capacity (unloadComplete(failure) shrinks it)
     int64_t *weighted_size;    // [n_caches]
+    int64_t *oldest;           // [n_caches] the map's `oldestTime` FIELD (clhm :1120): refreshed by afterWrite / the read drain only
     mmp_ubm_state *ubm;        // [n_caches]
     const mmp_cache_op *ops;   // all operations of the call, caller order
     const int32_t *op_order;   // operation indices grouped by cache, caller order within a cache
@@ -53,6 +54,8 @@ struct Deque {
     int32_t *stk_key, *stk_wt;  // pending victims (LIFO)
     int head, n, sp;
     int64_t wsize, cap;
+    int64_t oldest;  // clhm `oldestTime`: what updateOldestTime() last stored (afterWrite :444, tryToDrainBuffers :463) — setCapacity's
+                     // own evict (:305-316) does not store it, so it can be stale after a failed unload (unloadComplete :318-338)
     // manager
     int32_t reserved, tu, deficit;
     int64_t occ;
@@ -179,6 +182,9 @@ __device__ __forceinline__ void dq_set_wt(Deque &D, int i, int32_t w)
     wave_sync();
 }
 
+// updateOldestTime, clhm :1129-1133
+__device__ __forceinline__ void dq_refresh_oldest(Deque &D) { D.oldest = D.n ? D.lu[D.head] : -1; }
+
 __device__ __forceinline__ void record_evicted(Deque &D, int32_t k)
 {
     if (lane_id() == 0) D.ev[D.nev] = k;
@@ -240,6 +246,7 @@ __device__ __forceinline__ void ubm_set_weight_nodrain(Deque &D, int32_t k, int3
     dq_set_wt(D, i, w);
     D.wsize += diff;
     dq_evict(D, true);
+    dq_refresh_oldest(D);  // afterWrite(UpdateTask)
 }
 
 // adjustAggregateUnloadingWeight, ModelCacheUnloadBufManager.java:375-392 (listener not yet run)
@@ -316,11 +323,13 @@ __device__ __forceinline__ int32_t apply_op(Deque &D, const mmp_cache_op &o, int
         if (i >= 0) {
             dq_touch(D, i, o.time, now);
             dq_reposition(D, i);
+            dq_refresh_oldest(D);  // the reader drains its own read buffer: tryToDrainBuffers :458-469
             return 0;
         }
         D.wsize += o.arg;
         dq_insert(D, o.time == 0 ? now : o.time, o.arg, o.key);
         dq_evict(D, false);
+        dq_refresh_oldest(D);
         return 1;
     }
     case MMP_COP_GET: {  // clhm :726-733, applyRead :503-521
@@ -328,6 +337,7 @@ __device__ __forceinline__ int32_t apply_op(Deque &D, const mmp_cache_op &o, int
         if (i < 0) return 0;
         dq_touch(D, i, o.time, now);
         dq_reposition(D, i);
+        dq_refresh_oldest(D);
         return 1;
     }
     case MMP_COP_UPDATE_WEIGHT: {  // clhm :902-985, UpdateTask :629-652; time -1 = quiet
@@ -339,6 +349,7 @@ __device__ __forceinline__ int32_t apply_op(Deque &D, const mmp_cache_op &o, int
             if (o.time >= 0) {
                 dq_touch(D, i, o.time, now);
                 dq_reposition(D, i);
+                dq_refresh_oldest(D);
             }
             return 1;
         }
@@ -348,6 +359,7 @@ __device__ __forceinline__ int32_t apply_op(Deque &D, const mmp_cache_op &o, int
             dq_reposition(D, i);
         }
         dq_evict(D, false);
+        dq_refresh_oldest(D);
         return 1;
     }
     case MMP_COP_REMOVE: {  // clhm :861-870, RemovalTask :614-627
@@ -357,6 +369,7 @@ __device__ __forceinline__ int32_t apply_op(Deque &D, const mmp_cache_op &o, int
         int32_t w, k;
         dq_unlink(D, i, ts, w, k);
         D.wsize -= w < 0 ? -(int64_t)w : (int64_t)w;
+        dq_refresh_oldest(D);
         return 1;
     }
     case MMP_COP_UBM_INSERT_NEW_ENTRY: {  // :130-145
@@ -365,6 +378,7 @@ __device__ __forceinline__ int32_t apply_op(Deque &D, const mmp_cache_op &o, int
         if (i >= 0) {
             dq_touch(D, i, o.time, now);
             dq_reposition(D, i);
+            dq_refresh_oldest(D);
             ubm_adjust_agg(D, o.arg);
             return 0;
         }
@@ -372,6 +386,7 @@ __device__ __forceinline__ int32_t apply_op(Deque &D, const mmp_cache_op &o, int
         dq_insert(D, o.time == 0 ? now : o.time, o.arg, o.key);
         D.occ += o.arg;
         dq_evict(D, true);
+        dq_refresh_oldest(D);
         ubm_drain(D);
         return 1;
     }
@@ -414,7 +429,7 @@ __device__ __forceinline__ int32_t apply_op(Deque &D, const mmp_cache_op &o, int
         const int64_t cap = D.cap;
         ubm_adjust_agg(D, -o.arg);
         D.cap = cap - o.arg > 1 ? cap - o.arg : 1;
-        dq_evict(D, true);  // setCapacity evicts and notifies under the lock, clhm :305-316
+        dq_evict(D, true);  // setCapacity evicts and notifies under the lock, clhm :305-316 — and does NOT updateOldestTime()
         ubm_drain(D);
         return 0;
     }
@@ -425,6 +440,7 @@ __device__ __forceinline__ int32_t apply_op(Deque &D, const mmp_cache_op &o, int
         int32_t w, k;
         dq_unlink(D, i, ts, w, k);
         D.wsize -= w < 0 ? -(int64_t)w : (int64_t)w;
+        dq_refresh_oldest(D);
         D.occ -= w;
         ubm_adjust_agg(D, w);
         return w;
@@ -441,12 +457,14 @@ __device__ __forceinline__ int32_t apply_op(Deque &D, const mmp_cache_op &o, int
         if (i >= 0) {
             dq_touch(D, i, o.time, now);
             dq_reposition(D, i);
+            dq_refresh_oldest(D);
             if (deficit > 0) ubm_adjust_agg(D, deficit);
             return 0;
         }
         D.wsize += o.arg;
         dq_insert(D, o.time == 0 ? now : o.time, o.arg, o.key);
         dq_evict(D, true);
+        dq_refresh_oldest(D);
         ubm_drain(D);
         D.occ += o.arg;
         if (deficit > 0) D.deficit += deficit;
@@ -489,6 +507,7 @@ __global__ __launch_bounds__(64) void cache_replay_kernel(ReplayArgs A)
     }
     wave_sync();
     D.wsize = A.weighted_size[c];
+    D.oldest = A.oldest[c];
     D.cap = A.capacity[c];
     const mmp_ubm_state u = A.ubm[c];
     D.reserved = u.reserved;
@@ -510,7 +529,7 @@ __global__ __launch_bounds__(64) void cache_replay_kernel(ReplayArgs A)
             r.evicted_off = A.ev_off[c] + ev0;
             r.buffer_weight = ubi >= 0 ? D.wt[D.head + ubi] : 0;
             r.weighted_size = D.wsize;
-            r.oldest_time = D.n ? D.lu[D.head] : -1;
+            r.oldest_time = D.oldest;
             A.outs[oi] = r;
         }
         wave_sync();
@@ -523,6 +542,7 @@ __global__ __launch_bounds__(64) void cache_replay_kernel(ReplayArgs A)
     if (lane == 0) {
         A.dst.n[c] = D.n;
         A.weighted_size[c] = D.wsize;
+        A.oldest[c] = D.oldest;
         A.capacity[c] = D.cap;
         mmp_ubm_state v = u;
         v.total_unloading = D.tu;

@@ -256,7 +256,7 @@ struct mmp_ctx {
     int ks_cur = 0;
     int32_t k_caches = 0;
     std::vector<int32_t> k_n;  // host mirror of the live entry counts
-    DevBuf k_cap, k_wsize, k_ubm, k_ops, k_order, k_opoff, k_outs, k_ev, k_evoff;
+    DevBuf k_cap, k_wsize, k_oldest, k_ubm, k_ops, k_order, k_opoff, k_outs, k_ev, k_evoff;
 
     // wire-format ingestion: per-pod id attributes and the hash tables the parsers probe
     std::vector<uint32_t> id_order_v;
@@ -632,7 +632,7 @@ void mmp_destroy(mmp_ctx *c)
                       &c->models, &c->ent_pod, &c->ent_time, &c->c_seg,
                       &c->c_lu, &c->c_wt, &c->c_cap, &c->s_reqs, &c->s_outs, &c->s_extra, &c->s_a, &c->s_b,
                       &c->s_c, &c->s_d, &c->r_ps, &c->r_counts, &c->r_keys, &c->r_vals, &c->r_keys2, &c->r_vals2,
-                      &c->r_tmp, &c->r_out_model, &c->r_out_lu, &c->k_cap, &c->k_wsize, &c->k_ubm, &c->k_ops, &c->k_order,
+                      &c->r_tmp, &c->r_out_model, &c->r_out_lu, &c->k_cap, &c->k_wsize, &c->k_oldest, &c->k_ubm, &c->k_ops, &c->k_order,
                       &c->k_opoff, &c->k_outs, &c->k_ev, &c->k_evoff, &c->idtab_hash, &c->idtab_val, &c->tytab_hash,
                       &c->tytab_val, &c->j_buf, &c->j_off, &c->j_rows, &c->j_aux, &c->j_status, &c->j_cnt, &c->j_offs, &c->j_tmp_pod,
                       &c->j_tmp_time, &c->j_scan_tmp, &c->rk_rows, &c->rk_idx, &c->rk_tmp, &c->u_idx, &c->u_rows, &c->u_cnt, &c->u_offs, &c->u_tmp, &c->f_flags[0], &c->f_flags[1], &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp, &c->f_cnt[0], &c->f_cnt[1],
@@ -3620,12 +3620,14 @@ try {
     HIP_TRY(c, K.n.ensure((size_t)std::max(n_caches, 1) * 4));
     HIP_TRY(c, c->k_cap.ensure((size_t)std::max(n_caches, 1) * 8));
     HIP_TRY(c, c->k_wsize.ensure((size_t)std::max(n_caches, 1) * 8));
+    HIP_TRY(c, c->k_oldest.ensure((size_t)std::max(n_caches, 1) * 8));
     HIP_TRY(c, c->k_ubm.ensure((size_t)std::max(n_caches, 1) * sizeof(mmp_ubm_state)));
     c->k_n.assign(n_caches, 0);
-    std::vector<int64_t> ws(std::max(n_caches, 1), 0);
+    std::vector<int64_t> ws(std::max(n_caches, 1), 0), old(std::max(n_caches, 1), -1);
     std::vector<mmp_ubm_state> us(std::max(n_caches, 1));
     for (int32_t i = 0; i < n_caches; i++) {
         c->k_n[i] = seg_off[i + 1] - seg_off[i];
+        if (c->k_n[i] > 0) old[i] = last_used[seg_off[i]];  // oldestTime as the last write left it (clhm :1129-1133)
         for (int32_t e = seg_off[i]; e < seg_off[i + 1]; e++) ws[i] += weight[e] < 0 ? -(int64_t)weight[e] : weight[e];
         if (ubm)
             us[i] = ubm[i];
@@ -3644,6 +3646,7 @@ try {
         HIP_TRY(c, copy_sync(c, K.n.p, c->k_n.data(), (size_t)n_caches * 4, hipMemcpyHostToDevice));
         HIP_TRY(c, copy_sync(c, c->k_cap.p, capacity, (size_t)n_caches * 8, hipMemcpyHostToDevice));
         HIP_TRY(c, copy_sync(c, c->k_wsize.p, ws.data(), (size_t)n_caches * 8, hipMemcpyHostToDevice));
+        HIP_TRY(c, copy_sync(c, c->k_oldest.p, old.data(), (size_t)n_caches * 8, hipMemcpyHostToDevice));
         HIP_TRY(c, copy_sync(c, c->k_ubm.p, us.data(), (size_t)n_caches * sizeof(mmp_ubm_state), hipMemcpyHostToDevice));
     }
     c->k_caches = n_caches;
@@ -3715,6 +3718,7 @@ try {
     A.dst = CacheStore{D.off.as<int32_t>(), D.lu.as<int64_t>(), D.wt.as<int32_t>(), D.key.as<int32_t>(), D.n.as<int32_t>()};
     A.capacity = c->k_cap.as<int64_t>();
     A.weighted_size = c->k_wsize.as<int64_t>();
+    A.oldest = c->k_oldest.as<int64_t>();
     A.ubm = c->k_ubm.as<mmp_ubm_state>();
     A.ops = c->k_ops.as<mmp_cache_op>();
     A.op_order = c->k_order.as<int32_t>();

@@ -40,7 +40,7 @@ class OrcServeReq(C.Structure):
 
 class OrcCache(C.Structure):
     _fields_ = [("nodes", C.c_void_p), ("n", C.c_int32), ("cap_nodes", C.c_int32),
-                ("weighted_size", C.c_int64), ("capacity", C.c_int64)]
+                ("weighted_size", C.c_int64), ("capacity", C.c_int64), ("oldest_time", C.c_int64)]
 
 
 class OrcUbm(C.Structure):

@@ -6,8 +6,13 @@
  * TEST INFRASTRUCTURE ONLY (parity checker).  Models the drained ("strict",
  * single-threaded) order — SURVEY.md Appendix B#11.
  *
- * Pinned by the reference's own known-answer tests: EvictionsModelMeshTest.java
- * :36-125 and ModelMeshEvictionsTest.java:156-280 (tests/test_oracle_kat.py).
+ * Pinned by the reference's own TEXT: the clhm / LinkedDeque / ModelCacheUnloadBufManager method bodies compiled as they
+ * stand (oracle/ref_harness/clhm_harness.cc) and run over random operation streams -> tests/golden/ref_clhm.npz, which this
+ * file reproduces operation by operation (tests/test_ref_clhm.py); and by the reference's own known-answer tests:
+ * EvictionsModelMeshTest.java:36-125 and ModelMeshEvictionsTest.java:156-280 (tests/test_oracle_kat.py).
+ *
+ * Domain (what ModelMesh itself guarantees, MM.java:1766 "maybe ensure != 0"): entry weights stay >= 1, the unload reserve
+ * is > 0 and the pinned unload-buffer entry is never evicted (capacity > reserve).
  */
 #include <stdlib.h>
 #include <string.h>
@@ -18,6 +23,7 @@ void orc_cache_init(orc_cache *c, int64_t capacity)
 {
     memset(c, 0, sizeof *c);
     c->capacity = capacity;
+    c->oldest_time = -1; /* EMPTY_OLDEST_TIME, clhm :1117 */
 }
 
 void orc_cache_free(orc_cache *c)
@@ -41,6 +47,9 @@ int32_t orc_cache_find(const orc_cache *c, int32_t key)
         if (c->nodes[i].key == key) return i;
     return -1;
 }
+
+/* updateOldestTime, clhm :1129-1133: runs at the end of afterWrite (:444) and of the read drain (:463) */
+static void refresh_oldest(orc_cache *c) { c->oldest_time = c->n ? c->nodes[0].last_used : -1; }
 
 /* Node.touch, clhm :1357-1360 */
 static void touch(orc_node *nd, int64_t time, int64_t now)
@@ -107,6 +116,7 @@ int32_t orc_cache_put_if_absent(orc_cache *c, int32_t key, int32_t weight, int64
     if (i >= 0) { /* afterRead(prior, lastUsed), clhm :829 */
         touch(&c->nodes[i], last_used, now);
         deque_reposition(c, i);
+        refresh_oldest(c);
         return -1;
     }
     orc_node nd;
@@ -117,7 +127,9 @@ int32_t orc_cache_put_if_absent(orc_cache *c, int32_t key, int32_t weight, int64
     c->weighted_size += weight; /* AddTask.run :603 */
     int32_t pos = deque_insert(c, nd);
     if (insert_pos) *insert_pos = pos;
-    return evict(c, victims, max_victims);
+    int32_t nv = evict(c, victims, max_victims);
+    refresh_oldest(c);
+    return nv;
 }
 
 /* get(key, lastUsed), clhm :726-733 → afterRead → touch + applyRead :503-521 */
@@ -127,6 +139,7 @@ int orc_cache_get(orc_cache *c, int32_t key, int64_t last_used, int64_t now)
     if (i < 0) return 0;
     touch(&c->nodes[i], last_used, now);
     deque_reposition(c, i);
+    refresh_oldest(c);
     return 1;
 }
 
@@ -143,6 +156,7 @@ int32_t orc_cache_update_weight(orc_cache *c, int32_t key, int32_t new_weight, i
         if (new_time >= 0) { /* afterRead */
             touch(&c->nodes[i], new_time, now);
             deque_reposition(c, i);
+            refresh_oldest(c);
         }
         return 0;
     }
@@ -151,7 +165,9 @@ int32_t orc_cache_update_weight(orc_cache *c, int32_t key, int32_t new_weight, i
         touch(&c->nodes[i], new_time, now);
         deque_reposition(c, i);
     }
-    return evict(c, victims, max_victims);
+    int32_t nv = evict(c, victims, max_victims);
+    refresh_oldest(c);
+    return nv;
 }
 
 /* remove(key), clhm :861-870 + RemovalTask :614-627 */
@@ -161,11 +177,12 @@ int orc_cache_remove(orc_cache *c, int32_t key)
     if (i < 0) return 0;
     orc_node e = deque_unlink(c, i);
     c->weighted_size -= e.weight < 0 ? -e.weight : e.weight;
+    refresh_oldest(c);
     return 1;
 }
 
-/* oldestTime(), clhm :1125-1133 */
-int64_t orc_cache_oldest_time(const orc_cache *c) { return c->n ? c->nodes[0].last_used : -1; }
+/* oldestTime(), clhm :1125-1127: the field, not the head (equal except after setCapacity, see orc_ubm_unload_complete) */
+int64_t orc_cache_oldest_time(const orc_cache *c) { return c->oldest_time; }
 
 /* Convenience for the parity tests: rebuild a cache whose deque is exactly
  * (lu[i], wt[i]) oldest-first, then run one putIfAbsent of a new key. */
@@ -184,6 +201,7 @@ void orc_evict_eval(const int64_t *lu, const int32_t *wt, int32_t n, int64_t cap
         c.weighted_size += wt[i];
     }
     c.capacity = capacity;
+    refresh_oldest(&c);
     int32_t pos = 0;
     int32_t *victims = (int32_t *)malloc((size_t)(n + 2) * sizeof(int32_t));
     int32_t nv = orc_cache_put_if_absent(&c, n /* new key */, weight, last_used, now, victims, n + 2, &pos);
@@ -255,6 +273,10 @@ static void ubm_set_weight(orc_ubm *u, int32_t key, int32_t w, int64_t now)
     c->nodes[i].weight = w;
     c->weighted_size += diff;
     ubm_evict(u, now);
+    /* afterWrite(UpdateTask) stores oldestTime after the task's evict() and before the listener runs (:443-447); the listener's
+       nested writes store it again.  Evictions only happen inside such tasks, so the LAST store always sees the final head: storing
+       it here, after the nested notifications, leaves the same value */
+    refresh_oldest(c);
 }
 
 /* adjustAggregateUnloadingWeight, :375-392 */
@@ -313,6 +335,7 @@ int orc_ubm_insert_new_entry(orc_ubm *u, int32_t key, int32_t weight, int64_t la
     c->n++;
     u->total_occupancy += weight;
     ubm_evict(u, now);
+    refresh_oldest(c);
     return 1;
 }
 
@@ -383,7 +406,8 @@ void orc_ubm_unload_complete(orc_ubm *u, int32_t weight, int success, int64_t no
     int64_t cap = u->cache->capacity;
     ubm_adjust_agg(u, -weight, now);
     u->cache->capacity = cap - weight > 1 ? cap - weight : 1;
-    ubm_evict(u, now); /* setCapacity evicts and notifies under the lock, clhm :305-316 */
+    ubm_evict(u, now); /* setCapacity evicts and notifies under the lock, clhm :305-316 — without updateOldestTime(): the field
+                          keeps the value of the last write unless a notification changes the buffer's weight */
 }
 
 /* removeEntry :281-298 with entryRemoved :311-316; returns the weight at removal or -1 */
@@ -429,6 +453,7 @@ int orc_ubm_insert_failed_placeholder_entry(orc_ubm *u, int32_t key, int32_t wei
     c->nodes[l + 1] = nd;
     c->n++;
     ubm_evict(u, now);
+    refresh_oldest(c);
     u->total_occupancy += weight;
     if (deficit > 0) u->cache_deficit += deficit;
     return 1;

@@ -204,6 +204,8 @@ typedef struct {
     int32_t n, cap_nodes;
     int64_t weighted_size;
     int64_t capacity;
+    int64_t oldest_time; /* the map's oldestTime FIELD (clhm :1120): stored by updateOldestTime() only (afterWrite :444,
+                            tryToDrainBuffers :463) — setCapacity (:305-316) evicts without storing it */
 } orc_cache;
 
 void orc_cache_init(orc_cache *c, int64_t capacity);

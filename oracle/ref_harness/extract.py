@@ -107,6 +107,87 @@ RANGES = [
     ("triggerProactiveLoads_body", MM, 6619, 6746, "// get free units", "}"),
 ]
 
+# ---- a12 / a13: the local cache — clhm (the timestamp-ordered weighted LRU) and ModelCacheUnloadBufManager, plus the three
+# ModelMesh fragments that tie them together (CacheEntry's weight, the internal entry, the eviction callback's accounting).
+# Compiled by clhm_harness.cc (a second binary: the cache is self-contained).  Single-threaded: the read buffers are drained
+# by the reading thread itself (tryLock succeeds), which is the reference's own code path, not an assumption of the harness
+CL = "src/main/java/com/ibm/watson/modelmesh/clhm/ConcurrentLinkedHashMap.java"
+LD = "src/main/java/com/ibm/watson/modelmesh/clhm/LinkedDeque.java"
+UB = "src/main/java/com/ibm/watson/modelmesh/ModelCacheUnloadBufManager.java"
+CLHM_RANGES = [
+    ("clhm_constants", CL, 164, 182, "MAXIMUM_CAPACITY = Long.MAX_VALUE - Integer.MAX_VALUE;", "READ_BUFFER_INDEX_MASK = READ_BUFFER_SIZE - 1;", "CLHM"),
+    ("clhm_capacity_body", CL, 295, 295, "return capacity.get();", "capacity.get();", "CLHM"),
+    ("clhm_setCapacity_body", CL, 306, 315, "checkArgument(capacity >= 0);", "}", "CLHM"),
+    ("clhm_hasOverflowed_body", CL, 321, 321, "return weightedSize.get() > capacity.get();", "capacity.get();", "CLHM"),
+    ("clhm_evict_body", CL, 336, 351, "while (hasOverflowed()) {", "}", "CLHM"),
+    ("clhm_afterRead_body", CL, 383, 386, "final Object record = lastUsed > 0L ? new ReadRecord(node, lastUsed) : node;", "drainOnReadIfNeeded(bufferIndex, writeCount);", "CLHM"),
+    ("clhm_readBufferIndex_body", CL, 394, 394, "return ((int) Thread.currentThread().getId()) & READ_BUFFERS_MASK;", "READ_BUFFERS_MASK;", "CLHM"),
+    ("clhm_recordRead_body", CL, 408, 415, "final AtomicLong counter = readBufferWriteCount[bufferIndex];", "return writeCount;", "CLHM"),
+    ("clhm_drainOnReadIfNeeded_body", CL, 426, 430, "final long pending = (writeCount - readBufferDrainAtWriteCount[bufferIndex].get());", "}", "CLHM"),
+    ("clhm_afterWrite_body", CL, 439, 451, "evictionLock.lock();", "}", "CLHM"),
+    ("clhm_tryToDrainBuffers_body", CL, 459, 468, "if (evictionLock.tryLock()) {", "}", "CLHM"),
+    ("clhm_drainBuffers_body", CL, 474, 478, "final int start = (int) Thread.currentThread().getId();", "}", "CLHM"),
+    ("clhm_drainReadBuffer_body", CL, 484, 508, "final long writeCount = readBufferWriteCount[bufferIndex].get();", "readBufferDrainAtWriteCount[bufferIndex].lazySet(writeCount);", "CLHM"),
+    ("clhm_applyRead_body", CL, 514, 521, "// An entry may be scheduled for reordering despite having been removed.", "}", "CLHM"),
+    ("clhm_tryToRetire_body", CL, 533, 537, "if (expect.isAlive()) {", "return false;", "CLHM"),
+    ("clhm_makeRetired_body", CL, 547, 556, "for (;;) {", "}", "CLHM"),
+    ("clhm_makeDead_body", CL, 567, 574, "for (;;) {", "}", "CLHM"),
+    ("clhm_notifyListener_body", CL, 579, 586, "Node<K, V> node;", "}", "CLHM"),
+    ("clhm_AddTask_run_body", CL, 602, 609, "weightedSize.lazySet(weightedSize.get() + weight);", "}", "CLHM"),
+    ("clhm_RemovalTask_run_body", CL, 624, 626, "// add may not have been processed yet", "makeDead(node);", "CLHM"),
+    ("clhm_UpdateTask_run_body", CL, 645, 650, "weightedSize.lazySet(weightedSize.get() + weightDifference);", "evict();", "CLHM"),
+    ("clhm_weightedSize_body", CL, 672, 672, "return Math.max(0, weightedSize.get());", "weightedSize.get());", "CLHM"),
+    ("clhm_get_body", CL, 729, 734, "final Node<K, V> node = data.get(key);", "return node.getValue();", "CLHM"),
+    ("clhm_getQuietly_body", CL, 785, 786, "final Node<K, V> node = data.get(key);", "return (node == null) ? null : node.getValue();", "CLHM"),
+    ("clhm_putIfAbsent3_body", CL, 807, 807, "return put(key, value, lastUsed, true);", "true);", "CLHM"),
+    ("clhm_put_body", CL, 822, 857, "checkNotNull(key);", "}", "CLHM"),
+    ("clhm_remove_body", CL, 862, 869, "final Node<K, V> node = data.remove(key);", "return node.getValue();", "CLHM"),
+    ("clhm_remove2_body", CL, 874, 897, "final Node<K, V> node = data.get(key);", "}", "CLHM"),
+    ("clhm_replaceQuietly_body", CL, 961, 984, "checkNotNull(key);", "}", "CLHM"),
+    ("clhm_oldestTime_body", CL, 1126, 1126, "return oldestTime;", "oldestTime;", "CLHM"),
+    ("clhm_updateOldestTime_body", CL, 1131, 1132, "final Node<K, V> first = evictionDeque.peekFirst();", "EMPTY_OLDEST_TIME;", "CLHM"),
+    ("clhm_wv_contains_body", CL, 1307, 1307, "return (o == value) || value.equals(o);", "value.equals(o);", "CLHM"),
+    ("clhm_wv_isAlive_body", CL, 1314, 1314, "return weight > 0;", "weight > 0;", "CLHM"),
+    ("clhm_node_touch_body", CL, 1358, 1359, "lastUsed = time == 0L ? System.currentTimeMillis()", ": Math.max(lastUsed, time);", "CLHM"),
+    ("clhm_node_getLastUsed_body", CL, 1364, 1364, "return lastUsed;", "lastUsed;", "CLHM"),
+    ("clhm_node_getValue_body", CL, 1393, 1393, "return get().value;", "get().value;", "CLHM"),
+    ("deque_linkFirst_body", LD, 89, 97, "final E f = first;", "}", "CLHM"),
+    ("deque_unlinkFirst_body", LD, 120, 130, "final E f = first;", "return f;", "CLHM"),
+    ("deque_unlink_body", LD, 149, 164, "final E prev = e.getPrevious();", "}", "CLHM"),
+    ("deque_isEmpty_body", LD, 169, 169, "return (first == null);", "null);", "CLHM"),
+    ("deque_contains_body", LD, 211, 213, "return (e.getPrevious() != null)", "|| (e == first);", "CLHM"),
+    ("deque_reposition_body", LD, 244, 254, "final long lu = e.getLastUsed();", "insert(e);", "CLHM"),
+    ("deque_insert_body", LD, 259, 287, "if(contains(e)) return false;", "}", "CLHM"),
+    ("deque_peekFirst_body", LD, 299, 299, "return first;", "first;", "CLHM"),
+    ("deque_poll_body", LD, 369, 369, "return pollFirst();", "pollFirst();", "CLHM"),
+    ("deque_pollFirst_body", LD, 374, 374, "return isEmpty() ? null : unlinkFirst();", "unlinkFirst();", "CLHM"),
+    ("deque_remove_body", LD, 395, 399, "if (contains(e)) {", "return false;", "CLHM"),
+    ("ubm_key_constant", UB, 41, 41, 'UNLOAD_BUFFER_CACHE_KEY = "___UNLOADBUF";', "___UNLOADBUF", "CLHM"),
+    ("ubm_ctor_body", UB, 83, 87, "this.runtimeCache = cache;", "this.cacheLockCondition = cacheLock.newCondition();", "CLHM"),
+    ("ubm_getAdjustedCacheCapacity_body", UB, 91, 91, "return runtimeCache.capacity() - UNLOAD_BUFF.getWeight();", "getWeight();", "CLHM"),
+    ("ubm_getUnloadBufferWeight_body", UB, 95, 95, "return UNLOAD_BUFF.getWeight();", "getWeight();", "CLHM"),
+    ("ubm_insertNewEntry_body", UB, 131, 144, "final int weight = ce.getWeight();", "}", "CLHM"),
+    ("ubm_adjustNewEntrySpaceRequest_body", UB, 153, 165, "final int newWeight = entry.getWeight() + increase;", "}", "CLHM"),
+    ("ubm_claimRequestedSpaceIfReady_body", UB, 204, 213, "cacheLock.lock();", "return false;", "CLHM"),
+    ("ubm_adjustWeightAfterLoad_body", UB, 225, 245, "if (delta == 0) return;", "}", "CLHM"),
+    ("ubm_insertFailedPlaceholderEntry_body", UB, 250, 273, "final int weight = ce.getWeight();", "}", "CLHM"),
+    ("ubm_removeEntry_body", UB, 282, 296, "String modelId = entry.modelId;", "}", "CLHM"),
+    ("ubm_entryRemoved_body", UB, 307, 309, "assert weight > 0;", "adjustAggregateUnloadingWeight(weight);", "CLHM"),
+    ("ubm_unloadComplete_body", UB, 313, 331, "assert weight > 0;", "+ newCapacity);", "CLHM"),
+    ("ubm_discardFailedEntry_body", UB, 335, 341, "cacheLock.lock();", "}", "CLHM"),
+    ("ubm_cacheRemaining_body", UB, 348, 348, "return (int) Math.min(runtimeCache.capacity() - runtimeCache.weightedSize(), Integer.MAX_VALUE);", "MAX_VALUE);", "CLHM"),
+    ("ubm_payDownDeficit_body", UB, 353, 366, "assert weight > 0;", "}", "CLHM"),
+    ("ubm_adjustTotalModelCacheOccupancy_body", UB, 371, 371, "totalModelCacheOccupancy += delta;", "delta;", "CLHM"),
+    ("ubm_adjustAggregateUnloadingWeight_body", UB, 376, 391, "if (delta == 0) return;", "UNLOAD_BUFF.updateWeightLocked(newWeight);", "CLHM"),
+    ("ubm_cacheSpaceIsReady_body", UB, 396, 401, "int newTuw = totalUnloadingWeight + required;", "return totalRequired <= runtimeCache.capacity();", "CLHM"),
+    ("mm_ce_getWeight_body", MM, 1759, 1759, "return Math.abs(weight);", "abs(weight);", "CLHM"),
+    ("mm_ce_updateWeightLocked_body", MM, 1779, 1786, "int oldWeight = this.weight;", "}", "CLHM"),
+    ("mm_newInternalCacheEntry_body", MM, 1618, 1621, "CacheEntry<?> ce = new CacheEntry(id, weight);", "return ce;", "CLHM"),
+    ("mm_onEviction_weight_fragment", MM, 2871, 2871, "int removalWeight = ce.getWeight();", "getWeight();", "CLHM"),
+    ("mm_onEviction_manager_fragment", MM, 2876, 2878, "if (unloadManager != null) {", "}", "CLHM"),
+]
+
+
 # The one control-flow rewrite: the listener's `switch (type)` (MM.java:1474-1563) declares locals in `case ENTRY_UPDATED` and
 # falls through into `case ENTRY_DELETED`; C++ forbids the jump past those initialisations that a direct entry at the second
 # label would be.  Its four label lines become the equivalent if-chain (ADDED/UPDATED run both blocks, DELETED the second,
@@ -157,6 +238,19 @@ EXTRA_RULES["SHUTDOWN"] = [
     (re.compile(r"taskPool\.submit\(\(\) -> \{"), "taskPool.submit([=]() -> Entry<String, Long> {"),
     (re.compile(r"\bStatus\.(LOADING_FAILED|LOADING)\b"), r"Status::\1"),
     (re.compile(r"\bConcurrentHashMap\.newKeySet\(\)"), "ConcurrentHashMap_newKeySet()"),
+]
+
+# clhm / ModelCacheUnloadBufManager: generic object creation (`new WeightedValue<V>(..)`), `try { .. } finally { .. }` without a
+# catch clause (every try of these ranges: the finally blocks release the lock / reset the drain status and no `return` inside a
+# try skips anything but an unlock, which is a no-op here) becomes two plain blocks, Java's `assert`, member modifiers
+EXTRA_RULES["CLHM"] = [
+    (re.compile(r"\bnew\s+(\w+)<([\w, ]*)>\("), r"\1<\2>("),
+    (re.compile(r"^(\s*)try \{\s*$"), r"\1{  // try {"),
+    (re.compile(r"^(\s*)assert ([^;]*);"), r"\1JAVA_ASSERT(\2);"),
+    (re.compile(r"^\s*(?:/\*\*.*\*/\s*)?(?:private\s+)?static\s+"), "static "),
+    (re.compile(r"\bDrainStatus\.IDLE\b"), "IDLE"),
+    (re.compile(r"\bSystem\.currentTimeMillis\(\)"), "currentTimeMillis()"),
+    (re.compile(r"\bThread\.currentThread\(\)\.getId\(\)"), "Thread_currentThread_getId()"),
 ]
 
 # token-level rewrites, applied in order to every extracted line
@@ -212,7 +306,7 @@ def extract():
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_ref", "gen")
     os.makedirs(out_dir, exist_ok=True)
     manifest = []
-    for name, rel, a, b, must_first, must_last, *extra in RANGES:
+    for name, rel, a, b, must_first, must_last, *extra in RANGES + CLHM_RANGES:
         path = os.path.join(REF, rel)
         lines = open(path, encoding="utf-8").read().split("\n")
         body = lines[a - 1:b]
