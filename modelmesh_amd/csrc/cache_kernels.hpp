@@ -119,14 +119,17 @@ __device__ __forceinline__ int dq_insert(Deque &D, int64_t ts, int32_t w, int32_
     return pos;
 }
 
-__device__ __forceinline__ void dq_unlink(Deque &D, int i, int64_t &ts, int32_t &w, int32_t &k)
+// `pop`: the head leaves by moving the window (eviction, removal: the slot is never needed again).  A node that is unlinked to be
+// re-inserted (reposition) must NOT move the window: head + n would grow by one per repositioned head and walk off the tile the
+// host sized as entries + inserts
+__device__ __forceinline__ void dq_unlink(Deque &D, int i, int64_t &ts, int32_t &w, int32_t &k, bool pop = true)
 {
     const int lane = lane_id();
     ts = D.lu[D.head + i];
     w = D.wt[D.head + i];
     k = D.key[D.head + i];
     wave_sync();
-    if (i == 0) {
+    if (i == 0 && pop) {
         D.head++;
         D.n--;
         return;
@@ -171,7 +174,7 @@ __device__ __forceinline__ void dq_reposition(Deque &D, int i)
     }
     int64_t ts;
     int32_t w, k;
-    dq_unlink(D, i, ts, w, k);
+    dq_unlink(D, i, ts, w, k, false);
     dq_insert(D, ts, w, k);
 }
 

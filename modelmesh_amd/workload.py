@@ -158,6 +158,45 @@ def make_requests(fleet: Fleet, seed: int, n: int | None = None, *, favour_frac=
     return reqs, extra
 
 
+def make_full_cluster(fleet: Fleet, seed: int = 5, spread: float = 0.04) -> Fleet:
+    """The steady state of a mesh (in place): EVERY instance full and all caches about equally old (global LRU eviction) —
+    getNext is then in its LRU-window mode (MM.java:4911-4917) and most shortlists are the whole table."""
+    rng = np.random.default_rng(seed)
+    P = fleet.n_pods
+    fleet.pods["used"] = fleet.pods["capacity"] - rng.integers(0, 40_000, P)
+    fleet.pods["lru_time"] = fleet.now - (36_000_000 * (1 + rng.uniform(-spread, spread, P))).astype(np.int64)
+    return fleet
+
+
+def add_sparse_types(fleet: Fleet, share: float = 0.1, k: int = 12, n_new: int = 4, seed: int = 11) -> Fleet:
+    """`n_new` more types (in place) that only `k` instances each may host — a label requirement few instances satisfy puts the
+    type's candidates ~P/k positions apart in the placement order; `share` of the models move to them."""
+    rng = np.random.default_rng(seed)
+    P, T0 = fleet.n_pods, fleet.n_types
+    T = T0 + n_new
+    al = np.ones((T, P), bool)
+    pf = np.zeros((T, P), bool)
+    if T0:
+        al[:T0] = np.unpackbits(fleet.allowed.view(np.uint8), bitorder="little").reshape(T0, -1)[:, :P].astype(bool)
+        pf[:T0] = np.unpackbits(fleet.prefer.view(np.uint8), bitorder="little").reshape(T0, -1)[:, :P].astype(bool)
+    for t in range(T0, T):
+        al[t] = False
+        al[t, rng.choice(P, k, replace=False)] = True
+    fleet.allowed, fleet.prefer = bitmap_from_bool(al), bitmap_from_bool(pf)
+    fleet.has_allowed = np.concatenate([fleet.has_allowed if T0 else np.zeros(0, np.uint8), np.ones(n_new, np.uint8)])
+    fleet.has_prefer = np.concatenate([fleet.has_prefer if T0 else np.zeros(0, np.uint8), np.zeros(n_new, np.uint8)])
+    fleet.n_types = T
+    sparse = rng.random(fleet.n_models) < share
+    fleet.models["type"] = np.where(sparse, rng.integers(T0, T, fleet.n_models), fleet.models["type"])
+    return fleet
+
+
+def sample_requests(reqs, k: int, seed: int):
+    """A seeded sample of a batch, in batch order (the `extra` pool stays whole: offsets still index it)."""
+    idx = np.sort(np.random.default_rng(seed).choice(len(reqs), min(k, len(reqs)), replace=False))
+    return np.ascontiguousarray(reqs[idx])
+
+
 # --------------------------------------------------------------------------
 def fuzz_fleet(seed: int, pods: int = 200, models: int = 300, profile: str | None = None) -> Fleet:
     """Adversarial small fleet: ties everywhere, full pods, Long.MAX lru, dead /

@@ -109,10 +109,24 @@ def kat_standalone_lru():
     return np.array([25600], np.int64), np.array([2560], np.int32), np.array(rows, dtype=CACHE_OP)
 
 
+def head_reads():
+    """A cache in use: every read is of the least recently used entry (a round-robin client), which moves the deque's head to
+    its tail each time (LinkedDeque.reposition :243-255) — 30 entries, 900 reads, no insert in between; one managed, one not."""
+    rows = []
+    for c, op in ((0, 4), (1, 0)):
+        for m in range(30):
+            rows.append((c, op, 1000 * c + m, 100, NOW - 10_000 + m, 0, 0))
+    for r in range(30):
+        for c in (0, 1):
+            for m in range(30):
+                rows.append((c, 1, 1000 * c + m, 0, 0 if r % 2 else NOW + 1 + 30 * r + m, 0, 0))
+    return np.array([100_000, 100_000], np.int64), np.array([2_560, -1], np.int32), np.array(rows, dtype=CACHE_OP)
+
+
 def cases():
     """(name, capacities, reserves, ops)"""
     out = [("kat_basic_eviction",) + kat_basic_eviction(), ("kat_concurrent_eviction",) + kat_concurrent_eviction(),
-           ("kat_standalone_lru",) + kat_standalone_lru()]
+           ("kat_standalone_lru",) + kat_standalone_lru(), ("head_reads",) + head_reads()]
     rng = np.random.default_rng(0xC1A)
     for k in range(36):
         n_caches = int(rng.choice([1, 3, 8, 24]))

@@ -71,6 +71,32 @@ def place_cases():
         ids = string_ids(fleet, seed)
         reqs, extra = wl.make_requests(fleet, seed)
         yield cfg, fleet, ids, reqs, extra
+    yield from big_place_cases()
+
+
+def big_place_cases():
+    """The configurations the bench quotes (BASELINE.json configs[2], [3]) and the two regimes with paths of their own on the
+    device: the whole 10k / 50k-instance order and a seeded sample of the one-decision-per-model batch.  C3 as it is (window
+    path); C3 with every instance full — the bench's `full_cluster` fleet and batch (prefix tables, case (b) from the whole-window
+    tables); C3 with types only a dozen instances may host (next-non-empty-word tables); C4's 50k-instance table."""
+    fleet = wl.make_fleet("C3")
+    ids = string_ids(fleet, 13)
+    reqs, extra = wl.make_requests(fleet, 13)
+    yield "C3_table", fleet, ids, wl.sample_requests(reqs, 20000, 1), extra
+    fleet = wl.make_full_cluster(wl.make_fleet("C3"))
+    ids = string_ids(fleet, 14)
+    reqs, extra = wl.make_requests(fleet, seed=0xBE7C0)
+    yield "C3_full_cluster", fleet, ids, wl.sample_requests(reqs, 6000, 2), extra
+    fleet = wl.add_sparse_types(wl.make_fleet("C3"))
+    ids = string_ids(fleet, 15)
+    reqs, extra = wl.make_requests(fleet, seed=0xBE7C0)
+    sparse = np.nonzero(fleet.models["type"][reqs["model"]] >= 4)[0]
+    pick = np.sort(np.concatenate([sparse[:: max(1, len(sparse) // 2000)][:2000], np.random.default_rng(3).choice(len(reqs), 2000, replace=False)]))
+    yield "C3_sparse_types", fleet, ids, np.ascontiguousarray(reqs[np.unique(pick)]), extra
+    fleet = wl.make_fleet("C4")
+    ids = string_ids(fleet, 16)
+    reqs, extra = wl.make_requests(fleet, 16)
+    yield "C4_table", fleet, ids, wl.sample_requests(reqs, 10000, 4), extra
 
 
 def serve_cases():

@@ -64,7 +64,9 @@ def test_placement_order_and_load_targets_equal_the_reference_text(ref):
         check_place(name, fleet, reqs, got, ref[f"{name}/place"])
         n_cases += 1
         n_dec += len(reqs)
-    assert n_cases >= 56 and n_dec >= 100_000
+    assert n_cases >= 60 and n_dec >= 140_000
+    assert len(ref["C3_table/order"]) == 10_000 and len(ref["C4_table/order"]) == 50_000  # the bench's configurations, whole tables
+    assert ref["C3_full_cluster/place"][:, 1].max() == 10_000  # whole-table shortlists under the reference's own text
 
 
 def test_serve_targets_equal_the_reference_text(ref):

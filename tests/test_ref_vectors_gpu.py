@@ -35,6 +35,29 @@ def test_hip_order_and_load_targets_equal_the_reference_text(ref):
     assert n_dec >= 100_000
 
 
+@pytest.mark.parametrize("env", [{"MMP_LONG_MODE": "1"}, {"MMP_LONG_MODE": "0"}, {"MMP_NO_CASEB": "1"}, {"MMP_NO_LONG_LDS": "1"},
+                                 {"MMP_FORCE_WAVE": "1"}], ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
+def test_every_device_path_equals_the_reference_text_on_the_bench_configurations(ref, env, monkeypatch):
+    """C3 / C3 with every instance full / C3 with sparse types / C4 (tests/ref_fleets.py:big_place_cases) through each path the
+    library can take for them: the prefix-table kernel forced on (MMP_LONG_MODE=1) and off (0: window + lane + wave paths), case
+    (b) without its whole-window tables (MMP_NO_CASEB=1), the long path's tables read from global memory, and the general
+    wave-per-decision path alone (MMP_FORCE_WAVE=1; the full-cluster case there on a sample: whole-table shortlists take ~3 us
+    each on it) — all equal to what the reference's own getNext text decided."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name, fleet, ids, reqs, extra in rf.big_place_cases():
+        want = ref[f"{name}/place"]
+        if "MMP_FORCE_WAVE" in env and name == "C3_full_cluster":
+            reqs, want = reqs[:1500], want[:1500]
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            s.load_fleet(fleet)
+            got = s.place(reqs, extra, fleet.now)
+        finally:
+            s.close()
+        check_place(name, fleet, reqs, got, want)
+
+
 def test_hip_serve_targets_equal_the_reference_text(ref):
     for name, fleet, ids, reqs, in_use, last_used, xp, xt in rf.serve_cases():
         want = ref[f"{name}/serve"]
