@@ -14,7 +14,10 @@ g++ -std=c++17 -O1 -g -fwrapv -Wall -Wno-unused-variable -Wno-unused-function -W
 # the local cache (clhm + ModelCacheUnloadBufManager): a second binary, same recipe
 g++ -std=c++17 -O1 -g -fwrapv -Wall -Wno-unused-variable -Wno-unused-function -Wno-parentheses -Wno-unused-but-set-variable \
     "$here/clhm_harness.cc" -o "$out/clhm_harness"
+# the instance-table listener with type constraints + TypeConstraintManager's incremental path: a third binary
+g++ -std=c++17 -O1 -g -fwrapv -Wall -Wno-unused-variable -Wno-unused-function -Wno-parentheses -Wno-unused-but-set-variable \
+    "$here/tcm_harness.cc" -o "$out/tcm_harness"
 # the extracted reference text is an intermediate of this build: it does not stay in the tree (nor travel to the GPU box);
 # MANIFEST.txt (file:line ranges) and extract.log do.  KEEP_GEN=1 keeps it (tools/ref_coverage.sh compiles a second time)
 if [ -z "${KEEP_GEN:-}" ]; then rm -f "$out"/gen/*.inc; fi
-echo "built $out/ref_harness and $out/clhm_harness from: $(tr '\n' ';' < "$out/gen/MANIFEST.txt")"
+echo "built $out/ref_harness, $out/clhm_harness and $out/tcm_harness from: $(tr '\n' ';' < "$out/gen/MANIFEST.txt")"

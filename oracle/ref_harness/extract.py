@@ -188,6 +188,44 @@ CLHM_RANGES = [
 ]
 
 
+# ---- a18 (incremental) + a5 with type constraints: TypeConstraintManager as the instance-table listener drives it — instanceAdded /
+# instanceRemoved / instanceUpdated / updateInstance / updateInstanceSet / getInstanceSetStats / refreshPerTypeInstanceSets /
+# updateInstanceSetStats / typeMappingsUpdated and the accessors the mesh reads — compiled by tcm_harness.cc (a third binary)
+TC = "src/main/java/com/ibm/watson/modelmesh/TypeConstraintManager.java"
+IS = "src/main/java/com/ibm/watson/modelmesh/InstanceSetStatsTracker.java"
+TCMI_RANGES = [
+    ("tcmi_default_type_constant", TC, 67, 67, 'DEFAULT_TYPE_MAPPING = "_default";', "_default", "TCMI"),
+    ("tcmi_cfg_isEmpty_body", TC, 85, 85, "return empty(required) && empty(preferred);", "empty(preferred);", "TCMI"),
+    ("tcmi_getTypeSetStats_body", TC, 231, 232, "ModelTypeConstraints mtc = typeConstraintsMap.get(type);", "return mtc != null ? mtc.candidateSubsetStats() : null;", "TCMI"),
+    ("tcmi_getLocalInstanceSetStats_body", TC, 237, 238, "InstanceSetStatsTracker liss = localInstanceSetStats;", "EMPTY_STATS;", "TCMI"),
+    ("tcmi_getCandidateInstances_body", TC, 243, 244, "ModelTypeConstraints mtc = getTypeConstraints(type);", "return mtc != null ? mtc.allowedInstances : null;", "TCMI"),
+    ("tcmi_getPreferredInstances_body", TC, 249, 250, "ModelTypeConstraints mtc = getTypeConstraints(type);", "defaultPreferredInstances;", "TCMI"),
+    ("tcmi_getTypeConstraints_body", TC, 259, 261, "final Map<String, ModelTypeConstraints> tcm = typeConstraintsMap;", "tcm.get(DEFAULT_TYPE_MAPPING);", "TCMI"),
+    ("tcmi_candidateSubsetStats_body", TC, 357, 375, "if (instanceSetStats == null) {", "return new ClusterStats(capacity, free, lru, count, modelCopyCount);", "TCMI"),
+    ("tcmi_mtc_ctor_body", TC, 382, 387, "this.requiredLabels = requiredLabels;", "this.instanceSetStats = instanceSetStats;", "TCMI"),
+    ("tcmi_updateInstanceSetStats_body", TC, 397, 413, "boolean inferredMatch = Objects.equal(preferredInstances, newInferredPreferred);", "allowedInstances, configuredPreferredInstances, newStatArray, newInferredPreferred);", "TCMI"),
+    ("tcmi_fromInstanceSet_body", TC, 419, 447, "// assumption is that requiredLabels and preferredLabels are already sorted", "requiredInstances, preferredSet, instanceSetStats, preferredSet);", "TCMI"),
+    ("tcmi_allowedOnInstance_body", TC, 451, 451, "return allowedInstances == null || allowedInstances.contains(iid);", "contains(iid);", "TCMI"),
+    ("tcmi_labelsMatch_body", TC, 458, 459, "return Arrays.equals(requiredLabels, required)", "&& Arrays.equals(preferredLabels, preferred);", "TCMI"),
+    ("tcmi_updateInstance_body", TC, 464, 474, "Set<String> newReqInstances = allowedInstances;", "newReqInstances, newPrefInstances, instanceSetStats, newPrefInstances);", "TCMI"),
+    ("tcmi_instanceMatches_body", TC, 480, 485, "if (instanceLabels.length == 0 || typeLabels.length == 0) {", "labelStream.anyMatch(hasLabel);", "TCMI"),
+    ("tcmi_updateInstanceSet_body", TC, 491, 504, "boolean curMatch = instanceSet != null && instanceSet.contains(iid);", "return instanceSet;", "TCMI"),
+    ("tcmi_getStatsForLabels_body", TC, 509, 509, "return labelsToInstanceSetStats.get(labels);", "get(labels);", "TCMI"),
+    ("tcmi_instanceAdded_body", TC, 514, 524, "assert labels != null;", "return instanceSetStats;", "TCMI"),
+    ("tcmi_instanceRemoved_body", TC, 528, 548, "final Map<String, ModelTypeConstraints> mtcMap = typeConstraintsMap;", "}", "TCMI"),
+    ("tcmi_getInstanceSetStats_body", TC, 559, 578, "InstanceSetStatsTracker instanceSetStats = labelsToInstanceSetStats.get(labels);", "return instanceSetStats;", "TCMI"),
+    ("tcmi_instanceUpdated_body", TC, 583, 599, "HashMap<String, ModelTypeConstraints> newMap = null;", "return newMap != null ? newMap : mtcMap;", "TCMI"),
+    ("tcmi_typeMappingsUpdated_body", TC, 608, 667, "Map<String, ModelTypeConstraints> mtcMap = typeConstraintsMap, newMap = null;", "}", "TCMI"),
+    ("tcmi_refreshPerTypeInstanceSets_body", TC, 684, 724, "MutableObjectIntMap<String> instanceScores", "return mtcMap;", "TCMI"),
+    ("tcmi_inferPreferredInstances_body", TC, 728, 746, "Set<String> instanceIds = new HashSet<>(include != null ? include.size() : 8);", "return min < max ? ImmutableSet.copyOf(instanceIds) : null;", "TCMI"),
+    ("tcmi_ist_getInstanceCount_body", IS, 50, 50, "return count;", "count;", "TCMI"),
+    ("tcmi_ist_ctor_body", IS, 45, 46, "this.prohibitedTypesSet = prohibitedTypesSet;", "this.isFull = isFull;", "TCMI"),
+    ("tcmi_typeSetStats_body", MM, 1433, 1437, "if (typeConstraints == null) {", "return stats != null ? stats : clusterStats;", "TCMI"),
+    ("tcmi_instanceSetStats_body", MM, 1447, 1447, "return typeConstraints != null ? typeConstraints.getLocalInstanceSetStats() : clusterStats;", "clusterStats;", "TCMI"),
+    ("tcmi_listener_body", MM, 1456, 1567, "if (logger.isDebugEnabled()) {", "}", "TCMI_LISTENER"),
+]
+
+
 # The one control-flow rewrite: the listener's `switch (type)` (MM.java:1474-1563) declares locals in `case ENTRY_UPDATED` and
 # falls through into `case ENTRY_DELETED`; C++ forbids the jump past those initialisations that a direct entry at the second
 # label would be.  Its four label lines become the equivalent if-chain (ADDED/UPDATED run both blocks, DELETED the second,
@@ -253,6 +291,27 @@ EXTRA_RULES["CLHM"] = [
     (re.compile(r"\bThread\.currentThread\(\)\.getId\(\)"), "Thread_currentThread_getId()"),
 ]
 
+# TypeConstraintManager's incremental path: the TCM rules plus method references, the generic-method call syntax of Guava's
+# builders, `new X[0]`-style array creation and the array constructor reference
+EXTRA_RULES["TCMI"] = EXTRA_RULES["TCM"] + [
+    (re.compile(r"\bnewStats::contains\b"), "[=](auto x) { return newStats.contains(x); }"),
+    (re.compile(r"\.toArray\(InstanceSetStatsTracker\[\]::new\)"), ".toArray_()"),
+    (re.compile(r"ImmutableSet\.<String>builder"), "ImmutableSet.builder"),
+    (re.compile(r"e -> !e\.equals\(iid\)"), "[=](auto e) { return !e.equals(iid); }"),
+    (re.compile(r"\.forEach\(InstanceSetStatsTracker::update\)"), ".forEach_update()"),
+    (re.compile(r"\bnew HashMap<>\("), "HashMap_new("),
+    (re.compile(r"\bnew ArrayList<>\("), "ArrayList_new("),
+    (re.compile(r"^(\s*)assert ([^;]*);"), r"\1JAVA_ASSERT(\2);"),
+    (re.compile(r"^\s*private\s+static\s+"), "static "),
+    (re.compile(r'\.map\(e -> e\.getKey\(\) \+ ": " \+ e\.getValue\(\)\.getInstanceCount\(\)\)'), ".map_log()"),
+    (re.compile(r'\.collect\(Collectors\.joining\(", ", "\{", "\}"\)\)'), ".collect_joining()"),
+    (re.compile(r'\(defaultPreferred != null \? defaultPreferred : "<none>"\)'), "LOGSTR(defaultPreferred)"),
+    (re.compile(r"\bInstanceSetStatsTracker\[\]"), "TrackerArray"),
+    (re.compile(r"\bModelTypeConstraints\.fromInstanceSet\("), "ModelTypeConstraints::fromInstanceSet("),
+    (re.compile(r"\bInstanceSetStatsTracker\.EMPTY_STATS\b"), "EMPTY_STATS"),
+]
+EXTRA_RULES["TCMI_LISTENER"] = EXTRA_RULES["LISTENER_SWITCH"]
+
 # token-level rewrites, applied in order to every extracted line
 RULES = [
     # Java numeric literals may carry underscores: 120_000L -> 120000L
@@ -306,7 +365,7 @@ def extract():
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_ref", "gen")
     os.makedirs(out_dir, exist_ok=True)
     manifest = []
-    for name, rel, a, b, must_first, must_last, *extra in RANGES + CLHM_RANGES:
+    for name, rel, a, b, must_first, must_last, *extra in RANGES + CLHM_RANGES + TCMI_RANGES:
         path = os.path.join(REF, rel)
         lines = open(path, encoding="utf-8").read().split("\n")
         body = lines[a - 1:b]

@@ -60,6 +60,7 @@ struct StringArray {
     std::shared_ptr<std::vector<String>> p = std::make_shared<std::vector<String>>();
     int length() const { return (int)p->size(); }
     const String &operator[](int i) const { return (*p)[i]; }
+    bool operator!=(std::nullptr_t) const { return (bool)p; }
 };
 
 // java.lang.Long / Integer: boxed value as a type argument (Map<String, Long>), static members via `::` (extract.py)
@@ -207,6 +208,8 @@ public:
     static Set make() { Set s; s.p = std::make_shared<Rep>(); return s; }
     bool operator==(std::nullptr_t) const { return !p; }
     bool operator!=(std::nullptr_t) const { return (bool)p; }
+    bool operator==(const Set &o) const { return p == o.p; }  // Java `==` on references: identity
+    bool operator!=(const Set &o) const { return p != o.p; }
     boolean contains(const T &t) const { return p->count(t) != 0; }
     boolean isEmpty() const { return p->empty(); }
     boolean add(const T &t) const { return p->insert(t).second; }
@@ -264,6 +267,7 @@ public:
 // java.util.Collections.min over boxed longs
 struct Collections {
     static Set<String> emptySet() { return Set<String>::make(); }
+    static Set<String> singleton(const String &x) { Set<String> s = Set<String>::make(); s.add(x); return s; }
     static List<String> singletonList(const String &x) { List<String> l = ArrayList_new(1); l.add(x); return l; }
     static long min(const std::vector<Long> &v)
     {

@@ -15,8 +15,12 @@ cd "$tmp"
 g++ -std=c++17 -O0 -g -fwrapv --coverage -w "$root/oracle/ref_harness/harness.cc" -o ref_harness_cov
 MMP_REF_HARNESS="$tmp/ref_harness_cov" MMP_REF_OUT="$tmp/out.npz" python3 "$root/oracle/ref_harness/make_ref_vectors.py" > gen.log
 gcov ref_harness_cov-harness.gcda > gcov.log 2>&1
+# the local cache's text (clhm + ModelCacheUnloadBufManager): the second binary, the streams of tests/golden/ref_clhm.npz
+g++ -std=c++17 -O0 -g -fwrapv --coverage -w "$root/oracle/ref_harness/clhm_harness.cc" -o clhm_harness_cov
+MMP_CLHM_HARNESS="$tmp/clhm_harness_cov" MMP_CLHM_OUT="$tmp/out_clhm.npz" python3 "$root/oracle/ref_harness/make_clhm_vectors.py" > gen_clhm.log
+gcov clhm_harness_cov-clhm_harness.gcda >> gcov.log 2>&1
 {
-  echo "# reference text executed by tests/golden/ref_getnext.npz ($(tail -1 gen.log | sed 's/.*: //'))"
+  echo "# reference text executed by tests/golden/ref_getnext.npz ($(tail -1 gen.log | sed 's/.*: //')) and tests/golden/ref_clhm.npz ($(tail -1 gen_clhm.log | sed 's/.*: //'))"
   echo "# body (oracle/_ref/gen/<name>.inc; source range in oracle/ref_harness/extract.py)   executed/executable lines"
   tot=0; hit=0
   for f in *.inc.gcov; do
