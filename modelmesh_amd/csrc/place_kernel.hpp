@@ -894,6 +894,26 @@ __device__ __forceinline__ void merge_late_extras(ResolvedReq &r)
     r.n_late = -1;
 }
 
+// The request's <= kInlineExcl excluded rank positions in ascending order (none = INT32_MAX, behind every position): a 19-comparator
+// network.  The long path's corrections (which exclusions are candidates, the words whose hash term changes, how many candidates
+// lie before the index-th survivor) are then ONE pass each over neighbours instead of all-pairs loops.
+__device__ __forceinline__ void sort_excl(const int32_t (&ex)[kInlineExcl], int32_t (&sx)[kInlineExcl])
+{
+    static_assert(kInlineExcl == 8, "the network sorts 8 values");
+#pragma unroll
+    for (int i = 0; i < kInlineExcl; i++) sx[i] = ex[i] < 0 ? INT32_MAX : ex[i];
+#define MMP_CE(a, b) do { const int32_t lo_ = sx[a] < sx[b] ? sx[a] : sx[b], hi_ = sx[a] < sx[b] ? sx[b] : sx[a]; sx[a] = lo_; sx[b] = hi_; } while (0)
+    MMP_CE(0, 1); MMP_CE(2, 3); MMP_CE(4, 5); MMP_CE(6, 7);
+    MMP_CE(0, 2); MMP_CE(1, 3); MMP_CE(4, 6); MMP_CE(5, 7);
+    MMP_CE(1, 2); MMP_CE(5, 6); MMP_CE(0, 4); MMP_CE(3, 7);
+    MMP_CE(1, 5); MMP_CE(2, 6);
+    MMP_CE(1, 4); MMP_CE(3, 6);
+    MMP_CE(2, 4); MMP_CE(3, 5);
+    MMP_CE(3, 4);
+#undef MMP_CE
+}
+__device__ __forceinline__ uint64_t bits_below(int pos) { return (1ull << (pos & 63)) - 1ull; }
+
 // commit(): per slot the whole-window tables — window = (p0, end), i.e. every full present instance behind p0 (what the
 // window of MM.java:4862-4866 is on a cluster whose caches are about equally old; a decision checks that ITS window does
 // reach `end`, lane_case_b) — the smallest candidate rpm, the rule's limits, the five survivor bitmaps and their running
@@ -997,27 +1017,32 @@ __device__ __forceinline__ int lane_case_b(const Snap &S, const ResolvedReq &r, 
     // class 0 = every candidate of the type's window (p0, lim); those before this request's own first instance are among its
     // exclusions (they are eligible and lie before it) and fall out below like any excluded candidate
     auto cand_bit = [&](int p) { return p > b.best0 && p < lim && ((sv[p >> 6] >> (p & 63)) & 1ull); };
-    // the request's exclusions that are candidates: each takes one off the counts behind it and changes its word's hash term
-    uint32_t xmask = 0;  // slots of ex[] that are distinct removed candidates
-    int n_removed = 0;
+    // the request's exclusions that are candidates: each takes one off the counts behind it and changes its word's hash term.
+    // In ascending position order (sort_excl), with everything they read fetched together: the candidate word and the rpm of each
+    int32_t sx[kInlineExcl];
+    sort_excl(ex, sx);
+    uint64_t cw[kInlineExcl];   // the class-0 (all candidates) word of the slot's position, 0 if it lies outside the window
+    int32_t erpm[kInlineExcl];
 #pragma unroll
     for (int i = 0; i < kInlineExcl; i++) {
-        const int e = ex[i];
-        if (e < 0 || !cand_bit(e)) continue;
-        bool repeated = false;
-#pragma unroll
-        for (int j = 0; j < kInlineExcl; j++)
-            if (j < i && ex[j] == e) repeated = true;
-        if (repeated) continue;
-        if (S.rpm[e] <= L.min_rpm) return kLaneWave;  // it holds the minimum the limits were derived from (:4957)
-        xmask |= 1u << i;
-        n_removed++;
+        const int e = sx[i];
+        const bool in = e > b.best0 && e < lim;  // (INT32_MAX, the padding, is not)
+        cw[i] = in ? sv[e >> 6] : 0ull;
+        erpm[i] = in ? S.rpm[e] : INT32_MAX;
     }
-    const bool self_in_c = selfpos >= 0 && cand_bit(selfpos);  // (an excluded caller is never `us`: a removed candidate above)
-    bool self_removed = false;
+    uint32_t xmask = 0;  // slots of sx[] that are distinct removed candidates
+    bool holds_min = false, self_removed = false;
 #pragma unroll
-    for (int i = 0; i < kInlineExcl; i++)
-        if (((xmask >> i) & 1u) && ex[i] == selfpos) self_removed = true;
+    for (int i = 0; i < kInlineExcl; i++) {
+        const bool dup = i > 0 && sx[i - 1] == sx[i];
+        const uint32_t bit = dup ? 0u : (uint32_t)((cw[i] >> (sx[i] & 63)) & 1ull);
+        xmask |= bit << i;
+        holds_min |= bit && erpm[i] <= L.min_rpm;  // it holds the minimum the limits were derived from (:4957)
+        self_removed |= bit && sx[i] == selfpos;
+    }
+    if (holds_min) return kLaneWave;
+    const int n_removed = __popc(xmask);
+    const bool self_in_c = selfpos >= 0 && cand_bit(selfpos);  // (an excluded caller is never `us`: a removed candidate above)
     o.best = best0 == b.best0 ? b.best_orig : S.orig[best0];
     o.n_candidates = 0;
     o.hash = 0;
@@ -1032,20 +1057,6 @@ __device__ __forceinline__ int lane_case_b(const Snap &S, const ResolvedReq &r, 
     const uint64_t *PH = S.ph + ((size_t)S.T + type) * (size_t)(S.W + 1);
     uint64_t hsum = term(sv[wlo], wlo);
     if (whi > wlo) hsum += term(sv[whi], whi) + (PH[whi] - PH[wlo + 1]);
-#pragma unroll
-    for (int i = 0; i < kInlineExcl; i++) {
-        if (!((xmask >> i) & 1u)) continue;
-        const int w = ex[i] >> 6;
-        bool first_in_word = true;
-        uint64_t gone = 0;
-#pragma unroll
-        for (int j = 0; j < kInlineExcl; j++)
-            if (((xmask >> j) & 1u) && (ex[j] >> 6) == w) {
-                if (j < i) first_in_word = false;
-                gone |= 1ull << (ex[j] & 63);
-            }
-        if (first_in_word) hsum += term(sv[w] & ~gone, w) - term(sv[w], w);
-    }
     // the rpm rule (:4951-4980): which clauses apply is the request's (lastUsedTime); the limits are the window's
     const int64_t ago = age_of(r.last_used, now);
     int c = 0;
@@ -1061,34 +1072,52 @@ __device__ __forceinline__ int lane_case_b(const Snap &S, const ResolvedReq &r, 
     }
     const uint64_t *svc = sv + (size_t)c * W;
     const int32_t *pcc = pc + (size_t)c * (W + 1);
-    int removed_surv = 0;
+    // per removed candidate: its word among the class-c survivors and the running count in front of that word (fetched together)
+    uint64_t sw_[kInlineExcl];
+    int32_t pw_[kInlineExcl];
 #pragma unroll
-    for (int i = 0; i < kInlineExcl; i++)
-        if (((xmask >> i) & 1u) && ((svc[ex[i] >> 6] >> (ex[i] & 63)) & 1ull)) removed_surv++;
-    const int remaining = pcc[whi + 1] - pcc[wlo] - removed_surv;
+    for (int i = 0; i < kInlineExcl; i++) {
+        const bool on = (xmask >> i) & 1u;
+        sw_[i] = on ? svc[sx[i] >> 6] : 0ull;
+        pw_[i] = on ? pcc[sx[i] >> 6] : 0;
+    }
+    uint64_t gone = 0;
+    int removed_surv = 0;
+    const int p0c = pcc[wlo];
+    // one ascending pass: the hash term of every word that loses candidates is replaced once; t = the rank the index-th survivor
+    // has among the class-c bits once the removed ones at or before it are skipped (first pass counts them, second applies)
+#pragma unroll
+    for (int i = 0; i < kInlineExcl; i++) {
+        const int e = sx[i], w = e >> 6;
+        if (i > 0 && (sx[i - 1] >> 6) != w) gone = 0;
+        const uint64_t bit = (uint64_t)((xmask >> i) & 1u);
+        gone |= bit << (e & 63);
+        const bool last = i == kInlineExcl - 1 || (sx[i + 1] >> 6) != w;
+        if (last && gone) hsum += term(cw[i] & ~gone, w) - term(cw[i], w);
+        removed_surv += (int)(bit & (sw_[i] >> (e & 63)));
+    }
+    const int remaining = pcc[whi + 1] - p0c - removed_surv;
     if (remaining <= 0) return kLaneWave;  // (cannot happen: the instance with the smallest rpm is never filtered)
     const int index = remaining <= 1 ? 0 : (int)(((uint64_t)r.pick * (uint64_t)(uint32_t)remaining) >> 32);
-    // survivors in words [wlo, w), wlo < w <= whi + 1
-    auto before = [&](int w) {
-        int n = pcc[w] - pcc[wlo];
+    int t = index;
 #pragma unroll
-        for (int i = 0; i < kInlineExcl; i++)
-            if (((xmask >> i) & 1u) && (ex[i] >> 6) < w && ((svc[ex[i] >> 6] >> (ex[i] & 63)) & 1ull)) n--;
-        return n;
-    };
-    int lo = wlo, hi = whi;  // the word that holds the index-th survivor: the first w with before(w + 1) > index
+    for (int i = 0; i < kInlineExcl; i++) {
+        const int e = sx[i];
+        if (((xmask >> i) & 1u) && ((sw_[i] >> (e & 63)) & 1ull)) {
+            const int rho = (pw_[i] - p0c) + __popcll((unsigned long long)(sw_[i] & bits_below(e)));
+            if (rho <= t) t++;
+        }
+    }
+    const int T = t + p0c;  // the word that holds it: the first w in [wlo, whi] with pcc[w + 1] > T
+    int lo = wlo, hi = whi;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (before(mid + 1) > index)
+        if (pcc[mid + 1] > T)
             hi = mid;
         else
             lo = mid + 1;
     }
-    uint64_t bits = svc[lo];
-#pragma unroll
-    for (int i = 0; i < kInlineExcl; i++)
-        if (((xmask >> i) & 1u) && (ex[i] >> 6) == lo) bits &= ~(1ull << (ex[i] & 63));
-    const int cpos = lo * 64 + select_kth_bit(bits, index - before(lo));
+    const int cpos = lo * 64 + select_kth_bit(svc[lo], T - pcc[lo]);
     o.n_candidates = ccount;
     o.hash = (uint32_t)(hsum ^ (hsum >> 32)) ^ ((uint32_t)remaining * 0x9E3779B1u);
     o.chosen = S.orig[cpos];
@@ -1097,10 +1126,10 @@ __device__ __forceinline__ int lane_case_b(const Snap &S, const ResolvedReq &r, 
 }
 
 template <bool VIEW, bool LONG = false>
-__device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, mmp_place_out &o, const BLds *Bt = nullptr);
+__device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, mmp_place_out &o, const BLds Bt = BLds{});
 
 template <bool VIEW, bool LONG = false>
-__device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, int d, mmp_place_out &o, const BLds *Bt = nullptr)
+__device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, int d, mmp_place_out &o, const BLds Bt = BLds{})
 {
     const ResolvedReq r = resolve_one<VIEW>(S, A, d);
     return lane_decide_r<VIEW, LONG>(S, A, r, o, Bt);
@@ -1109,7 +1138,7 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
 // Bt: the staged case (b) tables of the long kernel (null: case (b) is the wave path's).  The first lane phase (LONG = false)
 // answers kLaneLong for a case (b) decision when they exist, the LONG phase decides it from them.
 template <bool VIEW, bool LONG>
-__device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, mmp_place_out &o, const BLds *Bt)
+__device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, mmp_place_out &o, const BLds Bt)
 {
     PHASE_T0();
     o.chosen = MMP_NONE;
@@ -1160,9 +1189,9 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
         int bestpos = best0;
         if (has_pm && !((Pm[best0 >> 6] >> (best0 & 63)) & 1ull)) {
             if (best_is_full) {  // case (b)
-                if (!VIEW && Bt && Bt->n_slots > 0) {
+                if (!VIEW && Bt.n_slots > 0) {
                     if (!LONG) return kLaneCaseB;  // the LONG phase decides it from the staged tables
-                    const int code = lane_case_b(S, r, L.ex, type, best0, A.now, *Bt, o);
+                    const int code = lane_case_b(S, r, L.ex, type, best0, A.now, Bt, o);
                     if (code == kLaneDone) return kLaneDone;
                 }
                 fb = true;
@@ -1273,7 +1302,10 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
         // of the <= 8 exclusions those are — and changes that word's hash term
         const int32_t *PC = nullptr;
         const uint64_t *PH = nullptr;
-        uint32_t xmask = 0;
+        uint32_t xmask = 0;             // slots of sx[] that are distinct candidates in a word strictly between wlo and whi
+        int32_t sx[kInlineExcl];        // the exclusions in ascending position order (LONG only)
+        uint64_t rv[kInlineExcl];       // per slot: the raw candidate word it falls into (0 unless that is a middle word)
+        int32_t pcw[kInlineExcl];       // per slot: the prefix count in front of that word
         if (LONG && is_long) {
             const size_t tb = ((size_t)(has_pm ? 1 : 0) * S.T + type) * (size_t)(W + 1);
             PC = S.pc + tb;
@@ -1283,28 +1315,32 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
                 if (has_pm) v &= Pm[w];
                 return v;
             };
+            sort_excl(L.ex, sx);
+            // everything the corrections read is fetched here, together (the slots are independent of one another): one load
+            // latency instead of one per exclusion
+#pragma unroll
+            for (int i = 0; i < kInlineExcl; i++) {
+                const int w = sx[i] >> 6;
+                const bool mid = w > wlo && w < whi;
+                rv[i] = mid ? raw(w) : 0ull;
+                pcw[i] = mid ? PC[w] : 0;
+            }
             const uint64_t c_lo = cand(wlo), c_hi = cand(whi);
             ccount = __popcll((unsigned long long)c_lo) + __popcll((unsigned long long)c_hi) + (PC[whi] - PC[wlo + 1]);
             hsum = term(c_lo, wlo) + term(c_hi, whi) + (PH[whi] - PH[wlo + 1]);
+            uint64_t gone = 0;  // the candidates the exclusions take out of the word the pass is in
 #pragma unroll
             for (int i = 0; i < kInlineExcl; i++) {
-                const int e = L.ex[i], w = e >> 6;  // -1 >> 6 == -1: never a middle word
-                if (w <= wlo || w >= whi) continue;
-                const uint64_t rv = raw(w);
-                if (!((rv >> (e & 63)) & 1ull)) continue;  // not a candidate anyway
-                bool repeated = false;  // the same pod twice among the exclusions (tried and loaded, say)
-#pragma unroll
-                for (int j = 0; j < kInlineExcl; j++)
-                    if (j < i && L.ex[j] == e) repeated = true;
-                if (repeated) continue;
-                bool first_in_word = true;  // the word's hash term is replaced once, by its first effective exclusion
-#pragma unroll
-                for (int j = 0; j < kInlineExcl; j++)
-                    if (j < i && ((xmask >> j) & 1u) && (L.ex[j] >> 6) == w) first_in_word = false;
-                xmask |= 1u << i;
-                ccount--;
-                if (first_in_word) hsum += term(dw(w), w) - term(rv, w);
+                const int e = sx[i], w = e >> 6;
+                if (i > 0 && (sx[i - 1] >> 6) != w) gone = 0;
+                const bool dup = i > 0 && sx[i - 1] == e;  // the same pod twice among the exclusions (tried and loaded, say)
+                const uint64_t bit = dup ? 0ull : (rv[i] >> (e & 63)) & 1ull;  // rv is 0 outside the middle words
+                gone |= bit << (e & 63);
+                xmask |= (uint32_t)bit << i;
+                const bool last = i == kInlineExcl - 1 || (sx[i + 1] >> 6) != w;
+                if (last && gone) hsum += term(rv[i] & ~gone, w) - term(rv[i], w);  // the word's hash term, replaced once
             }
+            ccount -= __popc(xmask);
         } else {
             for (int w = wlo; w <= whi; w++) {
                 const uint64_t v = cand(w);
@@ -1352,29 +1388,54 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
                     if (cpos == kNoPos && self_in_c && !null_s && k == 0) cpos = selfpos;
                 } else {
                     const int n_lo = __popcll((unsigned long long)surv(wlo));
-                    // survivors in words [wlo, w), wlo < w <= whi
-                    auto before = [&](int w) {
-                        int c = n_lo + (PC[w] - PC[wlo + 1]);
+                    if (index < n_lo) {
+                        cpos = wlo * 64 + select_kth_bit(surv(wlo), index);
+                    } else {
+                        // The candidates behind word wlo, in order, are the bits of the raw words wlo+1 .. whi-1 and then of
+                        // surv(whi), minus the REMOVED ones: the effective exclusions (xmask) and, if the rpm rule nulls it and it
+                        // stands in a middle word, the caller's own entry.  t = the rank the index-th survivor has among the raw
+                        // bits: every removed candidate at or before it pushes it one further (ascending pass).  The search over
+                        // the prefix counts is then the plain one — nothing per step but a load and a compare.
+                        const int pbase = PC[wlo + 1];
+                        const bool self_mid = null_s && sw > wlo && sw < whi;
+                        int rho_s = 0;
+                        if (self_mid) {
+                            uint64_t v = L.E[sw];
+                            if (has_pm) v &= Pm[sw];
+                            rho_s = n_lo + (PC[sw] - pbase) + __popcll((unsigned long long)(v & bits_below(selfpos)));
+                        }
+                        bool self_pending = self_mid;
+                        int t = index;
 #pragma unroll
-                        for (int i = 0; i < kInlineExcl; i++)
-                            if (((xmask >> i) & 1u) && (L.ex[i] >> 6) < w) c--;
-                        if (null_s && sw > wlo && sw < w && sw < whi) c -= 1;
-                        return c;
-                    };
-                    int word = wlo, base = 0;
-                    if (index >= n_lo) {
+                        for (int i = 0; i < kInlineExcl; i++) {
+                            if (self_pending && selfpos < sx[i]) {
+                                if (rho_s <= t) t++;
+                                self_pending = false;
+                            }
+                            if ((xmask >> i) & 1u) {
+                                const int rho = n_lo + (pcw[i] - pbase) + __popcll((unsigned long long)(rv[i] & bits_below(sx[i])));
+                                if (rho <= t) t++;
+                            }
+                        }
+                        if (self_pending && rho_s <= t) t++;
+                        const int T = t - n_lo + pbase;  // the word: the first w in (wlo, whi) with PC[w + 1] > T, else whi
                         int lo = wlo + 1, hi = whi;
                         while (lo < hi) {
                             const int mid = (lo + hi) >> 1;
-                            if (before(mid + 1) > index)
+                            if (PC[mid + 1] > T)
                                 hi = mid;
                             else
                                 lo = mid + 1;
                         }
-                        word = lo;
-                        base = before(word);
+                        if (lo < whi) {
+                            uint64_t v = L.E[lo];
+                            if (has_pm) v &= Pm[lo];
+                            cpos = lo * 64 + select_kth_bit(v, T - PC[lo]);
+                        } else {
+                            const int base = n_lo + (PC[whi] - pbase) - __popc(xmask) - (self_mid ? 1 : 0);
+                            cpos = whi * 64 + select_kth_bit(surv(whi), index - base);
+                        }
                     }
-                    cpos = word * 64 + select_kth_bit(surv(word), index - base);
                 }
             } else {
                 int running = 0;
@@ -1998,8 +2059,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
         Sl.nz = lnz;
     }
     // case (b) on a full cluster (long kernel): the snapshot's whole-window tables (BSlot)
-    BLds Bt{};
-    const BLds *Btp = nullptr;
+    BLds Bt{};  // (by value, n_slots == 0 = none: a pointer to it kept the struct in scratch memory — 40 bytes written per decision)
     if (WITH_LONG && A.n_bslots > 0) {  // wave-uniform
         Bt.slots = A.bslots;
         Bt.n_slots = A.n_bslots < kBSlots ? A.n_bslots : kBSlots;
@@ -2007,7 +2067,6 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
         Bt.surv = A.bsurv;
         Bt.pcs = A.bpcs;
         Bt.launch = A.bwin;
-        Btp = &Bt;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -2019,12 +2078,12 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
         int code = kLaneHeadMiss;
         if (WITH_LONG && A.long_first) {  // (wave-uniform) a full cluster: nearly every decision would end in the long phase anyway
             merge_late_extras(r);
-            code = lane_decide_r<false, true>(Sl, A, r, o, Btp);
+            code = lane_decide_r<false, true>(Sl, A, r, o, Bt);
         } else {
             if (use_wins) code = lane_decide_win(S, A, r, s_wins, s_scr + threadIdx.x, o);
             if (code == kLaneHeadMiss) {
                 merge_late_extras(r);
-                code = lane_decide_r<false>(S, A, r, o, Btp);
+                code = lane_decide_r<false>(S, A, r, o, Bt);
             }
         }
         if (WITH_LONG && (code == kLaneLong || code == kLaneCaseB))
@@ -2044,7 +2103,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
         if ((int)threadIdx.x < nlr) {
             const int ld = lr_list[threadIdx.x];
             mmp_place_out o;
-            if (lane_decide<false, true>(Sl, A, ld, o, Btp) != kLaneDone)
+            if (lane_decide<false, true>(Sl, A, ld, o, Bt) != kLaneDone)
                 fb_list[atomicAdd(&fb_n, 1)] = ld;
             else
                 A.outs[ld] = o;

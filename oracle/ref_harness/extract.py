@@ -201,14 +201,10 @@ TCMI_RANGES = [
     ("tcmi_getCandidateInstances_body", TC, 243, 244, "ModelTypeConstraints mtc = getTypeConstraints(type);", "return mtc != null ? mtc.allowedInstances : null;", "TCMI"),
     ("tcmi_getPreferredInstances_body", TC, 249, 250, "ModelTypeConstraints mtc = getTypeConstraints(type);", "defaultPreferredInstances;", "TCMI"),
     ("tcmi_getTypeConstraints_body", TC, 259, 261, "final Map<String, ModelTypeConstraints> tcm = typeConstraintsMap;", "tcm.get(DEFAULT_TYPE_MAPPING);", "TCMI"),
-    ("tcmi_candidateSubsetStats_body", TC, 357, 375, "if (instanceSetStats == null) {", "return new ClusterStats(capacity, free, lru, count, modelCopyCount);", "TCMI"),
     ("tcmi_mtc_ctor_body", TC, 382, 387, "this.requiredLabels = requiredLabels;", "this.instanceSetStats = instanceSetStats;", "TCMI"),
     ("tcmi_updateInstanceSetStats_body", TC, 397, 413, "boolean inferredMatch = Objects.equal(preferredInstances, newInferredPreferred);", "allowedInstances, configuredPreferredInstances, newStatArray, newInferredPreferred);", "TCMI"),
-    ("tcmi_fromInstanceSet_body", TC, 419, 447, "// assumption is that requiredLabels and preferredLabels are already sorted", "requiredInstances, preferredSet, instanceSetStats, preferredSet);", "TCMI"),
-    ("tcmi_allowedOnInstance_body", TC, 451, 451, "return allowedInstances == null || allowedInstances.contains(iid);", "contains(iid);", "TCMI"),
     ("tcmi_labelsMatch_body", TC, 458, 459, "return Arrays.equals(requiredLabels, required)", "&& Arrays.equals(preferredLabels, preferred);", "TCMI"),
     ("tcmi_updateInstance_body", TC, 464, 474, "Set<String> newReqInstances = allowedInstances;", "newReqInstances, newPrefInstances, instanceSetStats, newPrefInstances);", "TCMI"),
-    ("tcmi_instanceMatches_body", TC, 480, 485, "if (instanceLabels.length == 0 || typeLabels.length == 0) {", "labelStream.anyMatch(hasLabel);", "TCMI"),
     ("tcmi_updateInstanceSet_body", TC, 491, 504, "boolean curMatch = instanceSet != null && instanceSet.contains(iid);", "return instanceSet;", "TCMI"),
     ("tcmi_getStatsForLabels_body", TC, 509, 509, "return labelsToInstanceSetStats.get(labels);", "get(labels);", "TCMI"),
     ("tcmi_instanceAdded_body", TC, 514, 524, "assert labels != null;", "return instanceSetStats;", "TCMI"),
@@ -217,12 +213,10 @@ TCMI_RANGES = [
     ("tcmi_instanceUpdated_body", TC, 583, 599, "HashMap<String, ModelTypeConstraints> newMap = null;", "return newMap != null ? newMap : mtcMap;", "TCMI"),
     ("tcmi_typeMappingsUpdated_body", TC, 608, 667, "Map<String, ModelTypeConstraints> mtcMap = typeConstraintsMap, newMap = null;", "}", "TCMI"),
     ("tcmi_refreshPerTypeInstanceSets_body", TC, 684, 724, "MutableObjectIntMap<String> instanceScores", "return mtcMap;", "TCMI"),
-    ("tcmi_inferPreferredInstances_body", TC, 728, 746, "Set<String> instanceIds = new HashSet<>(include != null ? include.size() : 8);", "return min < max ? ImmutableSet.copyOf(instanceIds) : null;", "TCMI"),
     ("tcmi_ist_getInstanceCount_body", IS, 50, 50, "return count;", "count;", "TCMI"),
     ("tcmi_ist_ctor_body", IS, 45, 46, "this.prohibitedTypesSet = prohibitedTypesSet;", "this.isFull = isFull;", "TCMI"),
     ("tcmi_typeSetStats_body", MM, 1433, 1437, "if (typeConstraints == null) {", "return stats != null ? stats : clusterStats;", "TCMI"),
     ("tcmi_instanceSetStats_body", MM, 1447, 1447, "return typeConstraints != null ? typeConstraints.getLocalInstanceSetStats() : clusterStats;", "clusterStats;", "TCMI"),
-    ("tcmi_listener_body", MM, 1456, 1567, "if (logger.isDebugEnabled()) {", "}", "TCMI_LISTENER"),
 ]
 
 
@@ -310,7 +304,6 @@ EXTRA_RULES["TCMI"] = EXTRA_RULES["TCM"] + [
     (re.compile(r"\bModelTypeConstraints\.fromInstanceSet\("), "ModelTypeConstraints::fromInstanceSet("),
     (re.compile(r"\bInstanceSetStatsTracker\.EMPTY_STATS\b"), "EMPTY_STATS"),
 ]
-EXTRA_RULES["TCMI_LISTENER"] = EXTRA_RULES["LISTENER_SWITCH"]
 
 # token-level rewrites, applied in order to every extracted line
 RULES = [

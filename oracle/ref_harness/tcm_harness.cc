@@ -316,7 +316,7 @@ struct NullableStats {
 };
 static boolean instanceMatches(StringArray instanceLabels, StringArray typeLabels, boolean matchAll)
 {
-#include "../_ref/gen/tcmi_instanceMatches_body.inc"
+#include "../_ref/gen/tcm_instanceMatches_body.inc"
 }
 static Set<String> updateInstanceSet(String iid, StringArray instanceLabels, StringArray typeLabels, Set<String> instanceSet, boolean matchAll)
 {
@@ -344,7 +344,7 @@ public:
     bool operator!=(const ModelTypeConstraints &o) const { return id != o.id; }
     NullableStats candidateSubsetStats() const
     {
-#include "../_ref/gen/tcmi_candidateSubsetStats_body.inc"
+#include "../_ref/gen/tcm_candidateSubsetStats_body.inc"
     }
     ModelTypeConstraints updateInstanceSetStats(Set<InstanceSetStatsTracker> newStats, Set<String> newInferredPreferred) const
     {
@@ -353,11 +353,11 @@ public:
     static ModelTypeConstraints fromInstanceSet(StringArray requiredLabels, StringArray preferredLabels, const SortedClusterState &instances, String typeName,
                                                 TrackerArray instanceSetStats)
     {
-#include "../_ref/gen/tcmi_fromInstanceSet_body.inc"
+#include "../_ref/gen/tcm_fromInstanceSet_body.inc"
     }
     boolean allowedOnInstance(String iid) const
     {
-#include "../_ref/gen/tcmi_allowedOnInstance_body.inc"
+#include "../_ref/gen/tcm_allowedOnInstance_body.inc"
     }
     boolean labelsMatch(StringArray required, StringArray preferred) const
     {
@@ -453,7 +453,7 @@ struct PtsMap {  // new HashMap<ProhibitedTypeSet, InstanceSetStatsTracker>(), :
 };
 static Set<String> inferPreferredInstances(ObjectIntMap<String> instanceScores, Set<String> include)
 {
-#include "../_ref/gen/tcmi_inferPreferredInstances_body.inc"
+#include "../_ref/gen/tcm_inferPreferredInstances_body.inc"
 }
 class TypeConstraintManager {
 public:
@@ -559,7 +559,7 @@ static void handleInstanceTableChange(EventType type, String key, InstanceRecord
     const LeaderElection leaderLatch;
     const struct { void remove(const String &) const {} } missings;
     auto publishInstanceRecordAsync = [] { g_republish++; };
-#include "../_ref/gen/tcmi_listener_body.inc"
+#include "../_ref/gen/handleInstanceTableChange_body.inc"
 }
 
 // =================================================== driver + I/O ===========================================================
@@ -619,9 +619,8 @@ int main(int argc, char **argv)
     std::vector<std::pair<uint64_t, uint64_t>> cfg((size_t)T);
     auto apply_config = [&] {  // TypeConstraintManager.updateTypeMappings → typeMappingsUpdated(config): the whole configuration, as parsed
         Map<String, ConfigTypeConstraints> m;
-        for (int64_t t = 0; t < T; t++)
-            if (cfg[(size_t)t].first || cfg[(size_t)t].second)
-                m.put(type_name((int)t), ConfigTypeConstraints(labels_of(cfg[(size_t)t].first), labels_of(cfg[(size_t)t].second & ~cfg[(size_t)t].first)));
+        for (int64_t t = 0; t < T; t++)  // (a type configured with no labels at all is in the map too: the manager warns and drops it)
+            m.put(type_name((int)t), ConfigTypeConstraints(labels_of(cfg[(size_t)t].first), labels_of(cfg[(size_t)t].second & ~cfg[(size_t)t].first)));
         tcm.typeMappingsUpdated(m);
     };
     for (int64_t t = 0; t < T; t++) cfg[(size_t)t] = {req_bits[(size_t)t], pref_bits[(size_t)t]};
