@@ -1051,7 +1051,7 @@ __device__ __forceinline__ int lane_case_b(const Snap &S, const ResolvedReq &r, 
     const int32_t *pc0 = pc;
     const int ccount = pc0[whi + 1] - pc0[wlo] - n_removed;
     if (ccount <= 0) return kLaneWave;  // no preferred instance left in the window: the replay list (:4879-4884)
-    auto term = [&](uint64_t v, int w) { return v ? splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)(w + 1))) : 0ull; };
+    auto term = [&](uint64_t v, int w) { return audit_term(v, (uint64_t)w); };
     // audit hash of the candidates: the words strictly inside the window are whole words of the type's candidate bitmap
     // (prefix table ph, variant 1 = eligible & preferred), the two end words are the clipped ones of class 0
     const uint64_t *PH = S.ph + ((size_t)S.T + type) * (size_t)(S.W + 1);
@@ -1081,19 +1081,15 @@ __device__ __forceinline__ int lane_case_b(const Snap &S, const ResolvedReq &r, 
         sw_[i] = on ? svc[sx[i] >> 6] : 0ull;
         pw_[i] = on ? pcc[sx[i] >> 6] : 0;
     }
-    uint64_t gone = 0;
     int removed_surv = 0;
     const int p0c = pcc[wlo];
-    // one ascending pass: the hash term of every word that loses candidates is replaced once; t = the rank the index-th survivor
-    // has among the class-c bits once the removed ones at or before it are skipped (first pass counts them, second applies)
+    // every removed candidate takes its own term out of the audit hash (linear in the candidate bits, wave.hpp) and, if the rule
+    // of this class left it in, one off the survivors
 #pragma unroll
     for (int i = 0; i < kInlineExcl; i++) {
-        const int e = sx[i], w = e >> 6;
-        if (i > 0 && (sx[i - 1] >> 6) != w) gone = 0;
+        const int e = sx[i];
         const uint64_t bit = (uint64_t)((xmask >> i) & 1u);
-        gone |= bit << (e & 63);
-        const bool last = i == kInlineExcl - 1 || (sx[i + 1] >> 6) != w;
-        if (last && gone) hsum += term(cw[i] & ~gone, w) - term(cw[i], w);
+        if (bit) hsum -= audit_mul((uint64_t)(e >> 6)) << (e & 63);
         removed_surv += (int)(bit & (sw_[i] >> (e & 63)));
     }
     const int remaining = pcc[whi + 1] - p0c - removed_surv;
@@ -1294,9 +1290,7 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
         };
         int ccount = 0;
         uint64_t hsum = 0;
-        auto term = [&](uint64_t v, int w) {
-            return v ? splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)((VIEW ? S.w_base : 0) + w + 1))) : 0ull;
-        };
+        auto term = [&](uint64_t v, int w) { return audit_term(v, (uint64_t)((VIEW ? S.w_base : 0) + w)); };
         // LONG: the words strictly between wlo and whi come from the prefix tables; an exclusion that falls into
         // one of them (and whose bit is set there) takes one off every count behind it — xmask remembers which
         // of the <= 8 exclusions those are — and changes that word's hash term
@@ -1328,17 +1322,13 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
             const uint64_t c_lo = cand(wlo), c_hi = cand(whi);
             ccount = __popcll((unsigned long long)c_lo) + __popcll((unsigned long long)c_hi) + (PC[whi] - PC[wlo + 1]);
             hsum = term(c_lo, wlo) + term(c_hi, whi) + (PH[whi] - PH[wlo + 1]);
-            uint64_t gone = 0;  // the candidates the exclusions take out of the word the pass is in
 #pragma unroll
             for (int i = 0; i < kInlineExcl; i++) {
-                const int e = sx[i], w = e >> 6;
-                if (i > 0 && (sx[i - 1] >> 6) != w) gone = 0;
+                const int e = sx[i];
                 const bool dup = i > 0 && sx[i - 1] == e;  // the same pod twice among the exclusions (tried and loaded, say)
                 const uint64_t bit = dup ? 0ull : (rv[i] >> (e & 63)) & 1ull;  // rv is 0 outside the middle words
-                gone |= bit << (e & 63);
                 xmask |= (uint32_t)bit << i;
-                const bool last = i == kInlineExcl - 1 || (sx[i + 1] >> 6) != w;
-                if (last && gone) hsum += term(rv[i] & ~gone, w) - term(rv[i], w);  // the word's hash term, replaced once
+                if (bit) hsum -= audit_mul((uint64_t)(e >> 6)) << (e & 63);  // the audit hash is linear in the candidate bits (wave.hpp)
             }
             ccount -= __popc(xmask);
         } else {
@@ -1649,7 +1639,7 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
         scrE[(w - w0) * kPlaceBlock] = v;
         whi = w;
         ccount += __popcll((unsigned long long)v);
-        if (v) hsum += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)((VIEW ? S.w_base : 0) + w + 1)));
+        hsum += audit_term(v, (uint64_t)((VIEW ? S.w_base : 0) + w));
         if (end != kNoPos) break;
     }
     if (end == kNoPos && (win_end < P || (VIEW && S.more_after))) return kLaneHeadMiss;  // the list runs past the window (or the slice)
@@ -1814,7 +1804,7 @@ __device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int
                 fw[w] = v;
             }
             cc += __popcll((unsigned long long)v);
-            if (v) h += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)(w + 1)));
+            h += audit_term(v, (uint64_t)w);
             for (uint64_t t = v; t; t &= t - 1) {
                 const int32_t r = S.rpm[w * 64 + (__ffsll((unsigned long long)t) - 1)];
                 mn = r < mn ? r : mn;
@@ -1911,12 +1901,12 @@ __device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int
                     nz &= nz - 1;
                     const uint64_t vv = readlane_u64(v, l);
                     cc_s += __popcll((unsigned long long)vv);
-                    h_s += splitmix64(vv ^ (0x9E3779B97F4A7C15ull * (uint64_t)(base + l + 1)));
+                    h_s += audit_term(vv, (uint64_t)(base + l));
                 }
             } else {
                 dense = true;
                 cc += __popcll((unsigned long long)v);
-                if (v) h += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)(w + 1)));
+                h += audit_term(v, (uint64_t)w);
             }
         }
         ccount = cc_s;

@@ -481,7 +481,7 @@ __device__ __forceinline__ void shard_phase(const ShardSnap &S, const PlaceArgs 
                 if (w < S.Wn) {
                     const uint64_t v = cand_word(S, D, ew, Pm, w);
                     cc += __popcll((unsigned long long)v);
-                    if (v) h += splitmix64(v ^ (0x9E3779B97F4A7C15ull * (uint64_t)(S.w_lo + w + 1)));
+                    h += audit_term(v, (uint64_t)(S.w_lo + w));
                     if (D.mode_b) {
                         for (uint64_t t = v; t; t &= t - 1)
                             if (!rb.nulls(S.rpm[w * 64 + (__ffsll((unsigned long long)t) - 1)])) nn++;

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(64) void build_prefix_kernel(const uint64_t *__rest
         uint64_t word = 0;
         if (w < W) word = v ? (E[w] & Pm[w]) : E[w];
         int32_t c = __popcll((unsigned long long)word);
-        uint64_t h = word ? splitmix64(word ^ (0x9E3779B97F4A7C15ull * (uint64_t)(w + 1))) : 0ull;
+        uint64_t h = audit_term(word, (uint64_t)w);
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {  // inclusive scans across the wavefront
             const int32_t tc = __shfl_up(c, o, 64);

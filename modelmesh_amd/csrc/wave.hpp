@@ -155,4 +155,20 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
     return x ^ (x >> 31);
 }
 
+// The audit hash of a shortlist (machinery of this repository, not of the reference): the candidates as a bitmap
+// over rank positions, H = sum over 64-position words of  bits(word) * audit_mul(global word index)  (mod 2^64), folded to 32
+// bits.  Linear in the bits on purpose: the candidate at bit b of word w contributes audit_mul(w) << b, so taking ONE candidate
+// out (an exclusion) is one subtraction, partial sums over words add up across prefix tables and across pod-axis shards, and a
+// word's term is one multiply.  audit_mul is odd (a word's term determines its bits) and non-linear in w (sums of multipliers
+// of different words do not coincide).
+__host__ __device__ __forceinline__ uint64_t audit_mul(uint64_t global_word)
+{
+    uint64_t x = (global_word + 1ull) * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 29;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 32;
+    return x | 1ull;
+}
+__host__ __device__ __forceinline__ uint64_t audit_term(uint64_t bits, uint64_t global_word) { return bits * audit_mul(global_word); }
+
 }  // namespace mmp

@@ -196,27 +196,26 @@ static void it_init(pod_iter *it, const orc_snapshot *s, const orc_place_req *r,
     it->use_rs = use_rs;
 }
 
-static uint64_t splitmix64(uint64_t x)
+/* The audit hash (csrc/wave.hpp): H = sum over 64-position words of bits(word) * audit_mul(word index) mod 2^64.
+ * Linear in the candidate bits — the candidate at rank position p contributes audit_mul(p >> 6) << (p & 63). */
+static uint64_t audit_mul(uint64_t word)
 {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
+    uint64_t x = (word + 1ull) * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 29;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 32;
+    return x | 1ull;
 }
 
 uint32_t orc_shortlist_hash(const int32_t *pos_of, const int32_t *cand, int32_t n,
                             int32_t n_remaining, int32_t n_pods)
 {
-    int32_t nw = (n_pods + 63) / 64;
-    uint64_t *bits = (uint64_t *)calloc((size_t)(nw > 0 ? nw : 1), sizeof(uint64_t));
-    for (int32_t i = 0; i < n; i++) {
-        int32_t p = pos_of[cand[i]];
-        bits[p >> 6] |= 1ull << (p & 63);
-    }
+    (void)n_pods;
     uint64_t h = 0;
-    for (int32_t w = 0; w < nw; w++)
-        if (bits[w]) h += splitmix64(bits[w] ^ (0x9E3779B97F4A7C15ull * (uint64_t)(w + 1)));
-    free(bits);
+    for (int32_t i = 0; i < n; i++) { /* the candidates are distinct pods: one term each */
+        int32_t p = pos_of[cand[i]];
+        h += audit_mul((uint64_t)(p >> 6)) << (p & 63);
+    }
     return (uint32_t)(h ^ (h >> 32)) ^ ((uint32_t)n_remaining * 0x9E3779B1u);
 }
 

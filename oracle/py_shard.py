@@ -32,11 +32,13 @@ def _age(t, now):
     return 0 if t == 0 else _w64(now - t)
 
 
-def _splitmix64(x):
-    x = (x + 0x9E3779B97F4A7C15) & M64
-    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M64
-    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M64
-    return x ^ (x >> 31)
+def _audit_mul(word):
+    """csrc/wave.hpp audit_mul: the audit hash is H = sum over words of bits * audit_mul(word) mod 2^64 (linear in the bits)."""
+    x = ((word + 1) * 0x9E3779B97F4A7C15) & M64
+    x ^= x >> 29
+    x = (x * 0xBF58476D1CE4E5B9) & M64
+    x ^= x >> 32
+    return x | 1
 
 
 def _i32(v):
@@ -456,7 +458,7 @@ class EmulShardBackend:
                     for p in c:
                         words[p >> 6] = words.get(p >> 6, 0) | (1 << (p & 63))
                     for w, bits in words.items():
-                        h = (h + _splitmix64(bits ^ ((0x9E3779B97F4A7C15 * (w + 1)) & M64))) & M64
+                        h = (h + bits * _audit_mul(w)) & M64
                     if D["mode_b"]:
                         rb = _Rule(D["ago"], D["mn_b"])
                         nn = sum(1 for p in c if not rb.nulls(self.row[p][3]))

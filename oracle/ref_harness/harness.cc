@@ -1084,20 +1084,24 @@ static void handleInstanceTableChange(const SortedClusterState &clusterState, Ev
 // The audit hash of a shortlist (machinery of THIS repository, not of the reference): a function of the set of
 // rank positions in the shortlist and of the count that survived the rpm filter — computed here from the reference's own
 // candidate list and the reference's own clusterState order, so that a fixture row is 16 bytes instead of a ragged list.
-static uint64_t splitmix64(uint64_t x)
+static uint64_t audit_mul(uint64_t word)  // csrc/wave.hpp: the audit hash is linear in the candidate bits
 {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
+    uint64_t x = (word + 1ull) * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 29;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 32;
+    return x | 1ull;
 }
 static uint32_t shortlist_hash(const std::vector<int32_t> &pos_of, const int32_t *cand, int32_t n, int32_t remaining, int64_t n_pods)
 {
-    std::vector<uint64_t> bits((size_t)((n_pods + 63) / 64) + 1, 0);
-    for (int32_t i = 0; i < n; i++) bits[pos_of[cand[i]] >> 6] |= 1ull << (pos_of[cand[i]] & 63);
     uint64_t h = 0;
-    for (size_t w = 0; w < bits.size(); w++)
-        if (bits[w]) h += splitmix64(bits[w] ^ (0x9E3779B97F4A7C15ull * (uint64_t)(w + 1)));
+    std::vector<uint8_t> seen((size_t)n_pods + 1, 0);  // (a set of positions: an instance listed twice counts once)
+    for (int32_t i = 0; i < n; i++) {
+        const int32_t p = pos_of[cand[i]];
+        if (seen[(size_t)p]) continue;
+        seen[(size_t)p] = 1;
+        h += audit_mul((uint64_t)(p >> 6)) << (p & 63);
+    }
     return (uint32_t)(h ^ (h >> 32)) ^ ((uint32_t)remaining * 0x9E3779B1u);
 }
 

@@ -27,14 +27,15 @@ def _py_hash(order, shortlist, remaining):
         words[pos[c] >> 6] = words.get(pos[c] >> 6, 0) | (1 << (pos[c] & 63))
     M = (1 << 64) - 1
 
-    def sm(x):
-        x = (x + 0x9E3779B97F4A7C15) & M
-        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
-        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
-        return x ^ (x >> 31)
+    def mul(w):  # csrc/wave.hpp audit_mul
+        x = ((w + 1) * 0x9E3779B97F4A7C15) & M
+        x ^= x >> 29
+        x = (x * 0xBF58476D1CE4E5B9) & M
+        x ^= x >> 32
+        return x | 1
     h = 0
     for w, b in words.items():
-        h = (h + sm(b ^ ((0x9E3779B97F4A7C15 * (w + 1)) & M))) & M
+        h = (h + b * mul(w)) & M
     return ((h ^ (h >> 32)) & 0xFFFFFFFF) ^ ((remaining * 0x9E3779B1) & 0xFFFFFFFF)
 
 
