@@ -462,7 +462,9 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     // cluster, 800k decisions per launch 70.8 -> 67.1 us; at 100k (1.5 wavefronts per SIMD) 20.4 -> 21.0 us, hence the size condition
     if (A.long_first && !inline_req && !done_flag && !c->no_long_lds && n >= kLongDenseFrom) {
         const size_t tb = long_tables_bytes(c->snap.T, c->snap.W);
-        if (tb <= 24 * 1024) {
+        // (only where they fit beside the wave tile and the static part: a device with 64 KB of LDS per workgroup keeps reading
+        // them from global memory instead of failing the launch)
+        if (tb <= 24 * 1024 && ((lds + 15) & ~(size_t)15) + tb + kPlaceStaticLds <= c->lds_limit) {
             const size_t off = (lds + 15) & ~(size_t)15;
             A.long_first = 1 + (int32_t)off;
             lds = off + tb;

@@ -914,6 +914,21 @@ __device__ __forceinline__ void sort_excl(const int32_t (&ex)[kInlineExcl], int3
 }
 __device__ __forceinline__ uint64_t bits_below(int pos) { return (1ull << (pos & 63)) - 1ull; }
 
+// The first word w in [lo, hi) with pc[w + 1] > T, else hi (pc non-decreasing: running counts).  (A 16-way search — 15
+// independent probes per round, two rounds instead of eight dependent loads — was measured on the 100k launch, round 4: 15.2 us
+// against 14.3: the table rows are L1-resident and the extra instructions cost more than the round trips.)
+__device__ __forceinline__ int first_word_over(const int32_t *pc, int lo, int hi, int T)
+{
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (pc[mid + 1] > T)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return lo;
+}
+
 // commit(): per slot the whole-window tables — window = (p0, end), i.e. every full present instance behind p0 (what the
 // window of MM.java:4862-4866 is on a cluster whose caches are about equally old; a decision checks that ITS window does
 // reach `end`, lane_case_b) — the smallest candidate rpm, the rule's limits, the five survivor bitmaps and their running
@@ -1105,14 +1120,7 @@ __device__ __forceinline__ int lane_case_b(const Snap &S, const ResolvedReq &r, 
         }
     }
     const int T = t + p0c;  // the word that holds it: the first w in [wlo, whi] with pcc[w + 1] > T
-    int lo = wlo, hi = whi;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (pcc[mid + 1] > T)
-            hi = mid;
-        else
-            lo = mid + 1;
-    }
+    const int lo = first_word_over(pcc, wlo, whi, T);
     const int cpos = lo * 64 + select_kth_bit(svc[lo], T - pcc[lo]);
     o.n_candidates = ccount;
     o.hash = (uint32_t)(hsum ^ (hsum >> 32)) ^ ((uint32_t)remaining * 0x9E3779B1u);
@@ -1291,15 +1299,18 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
         int ccount = 0;
         uint64_t hsum = 0;
         auto term = [&](uint64_t v, int w) { return audit_term(v, (uint64_t)((VIEW ? S.w_base : 0) + w)); };
-        // LONG: the words strictly between wlo and whi come from the prefix tables; an exclusion that falls into
-        // one of them (and whose bit is set there) takes one off every count behind it — xmask remembers which
-        // of the <= 8 exclusions those are — and changes that word's hash term
+        // LONG: the shortlist is the best instance and the RAW candidate bits (eligible, and preferred if the type prefers) of
+        // [start, end) minus the request's exclusions that are among them.  Counts and audit-hash sums of the raw bits come from the
+        // prefix tables (whole words strictly between wlo and whi) and the two clipped end words; every effective exclusion then
+        // takes one off the count and its own term off the hash (linear, wave.hpp) — no word is rebuilt with exclusions cleared.
         const int32_t *PC = nullptr;
         const uint64_t *PH = nullptr;
-        uint32_t xmask = 0;             // slots of sx[] that are distinct candidates in a word strictly between wlo and whi
+        uint32_t xmask = 0;             // slots of sx[] that are distinct candidates inside [start, end)
         int32_t sx[kInlineExcl];        // the exclusions in ascending position order (LONG only)
-        uint64_t rv[kInlineExcl];       // per slot: the raw candidate word it falls into (0 unless that is a middle word)
+        uint64_t rv[kInlineExcl];       // per slot: the raw candidate word it falls into (0 if outside [start, end))
         int32_t pcw[kInlineExcl];       // per slot: the prefix count in front of that word
+        uint64_t r_lo = 0, r_hi = 0;    // the raw end words clipped to [start, end)
+        int n_rlo = 0, pbase = 0;
         if (LONG && is_long) {
             const size_t tb = ((size_t)(has_pm ? 1 : 0) * S.T + type) * (size_t)(W + 1);
             PC = S.pc + tb;
@@ -1314,21 +1325,26 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
             // latency instead of one per exclusion
 #pragma unroll
             for (int i = 0; i < kInlineExcl; i++) {
-                const int w = sx[i] >> 6;
-                const bool mid = w > wlo && w < whi;
-                rv[i] = mid ? raw(w) : 0ull;
-                pcw[i] = mid ? PC[w] : 0;
+                const int e = sx[i];
+                const bool in = e >= start && e < end;  // (the padding, INT32_MAX, is not)
+                rv[i] = in ? raw(e >> 6) : 0ull;
+                pcw[i] = in ? PC[e >> 6] : 0;
             }
-            const uint64_t c_lo = cand(wlo), c_hi = cand(whi);
-            ccount = __popcll((unsigned long long)c_lo) + __popcll((unsigned long long)c_hi) + (PC[whi] - PC[wlo + 1]);
-            hsum = term(c_lo, wlo) + term(c_hi, whi) + (PH[whi] - PH[wlo + 1]);
+            r_lo = raw(wlo) & ((~0ull) << (start & 63));                 // start lies in wlo or is the first bit of wlo + 1
+            if ((start >> 6) != wlo) r_lo = 0;
+            r_hi = raw(whi) & ((end & 63) ? bits_below(end) : ~0ull);    // end - 1 lies in whi
+            n_rlo = __popcll((unsigned long long)r_lo);
+            pbase = PC[wlo + 1];
+            ccount = 1 + n_rlo + __popcll((unsigned long long)r_hi) + (PC[whi] - pbase);
+            const uint64_t m_lo = audit_mul((uint64_t)wlo);
+            hsum = (m_lo << (bestpos & 63)) + r_lo * m_lo + audit_term(r_hi, (uint64_t)whi) + (PH[whi] - PH[wlo + 1]);
 #pragma unroll
             for (int i = 0; i < kInlineExcl; i++) {
                 const int e = sx[i];
                 const bool dup = i > 0 && sx[i - 1] == e;  // the same pod twice among the exclusions (tried and loaded, say)
-                const uint64_t bit = dup ? 0ull : (rv[i] >> (e & 63)) & 1ull;  // rv is 0 outside the middle words
+                const uint64_t bit = dup ? 0ull : (rv[i] >> (e & 63)) & 1ull;  // rv is 0 outside [start, end)
                 xmask |= (uint32_t)bit << i;
-                if (bit) hsum -= audit_mul((uint64_t)(e >> 6)) << (e & 63);  // the audit hash is linear in the candidate bits (wave.hpp)
+                if (bit) hsum -= audit_mul((uint64_t)(e >> 6)) << (e & 63);
             }
             ccount -= __popc(xmask);
         } else {
@@ -1377,54 +1393,45 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
                     }
                     if (cpos == kNoPos && self_in_c && !null_s && k == 0) cpos = selfpos;
                 } else {
-                    const int n_lo = __popcll((unsigned long long)surv(wlo));
-                    if (index < n_lo) {
-                        cpos = wlo * 64 + select_kth_bit(surv(wlo), index);
-                    } else {
-                        // The candidates behind word wlo, in order, are the bits of the raw words wlo+1 .. whi-1 and then of
-                        // surv(whi), minus the REMOVED ones: the effective exclusions (xmask) and, if the rpm rule nulls it and it
-                        // stands in a middle word, the caller's own entry.  t = the rank the index-th survivor has among the raw
-                        // bits: every removed candidate at or before it pushes it one further (ascending pass).  The search over
-                        // the prefix counts is then the plain one — nothing per step but a load and a compare.
-                        const int pbase = PC[wlo + 1];
-                        const bool self_mid = null_s && sw > wlo && sw < whi;
-                        int rho_s = 0;
-                        if (self_mid) {
-                            uint64_t v = L.E[sw];
-                            if (has_pm) v &= Pm[sw];
-                            rho_s = n_lo + (PC[sw] - pbase) + __popcll((unsigned long long)(v & bits_below(selfpos)));
-                        }
-                        bool self_pending = self_mid;
-                        int t = index;
+                    // The shortlist in order: the best instance (raw rank 0), then the raw candidate bits of [start, end).  REMOVED
+                    // from it: the best if the rpm rule nulls it, the caller's own entry if the rule nulls it, the effective
+                    // exclusions.  t = the raw rank of the index-th survivor: every removed entry at or before it pushes it one
+                    // further (one ascending pass).  The search over the prefix counts is then the plain one.
+                    auto rank_at = [&](uint64_t word, int pc_before, int pos) {  // raw rank of the candidate at `pos` (>= start)
+                        return 1 + n_rlo + (pc_before - pbase) + __popcll((unsigned long long)(word & bits_below(pos)));
+                    };
+                    int rho_s = 0;
+                    if (null_s) {  // (self_in_c: the caller's entry is a candidate inside [start, end))
+                        uint64_t v = L.E[sw];
+                        if (has_pm) v &= Pm[sw];
+                        rho_s = rank_at(v, PC[sw], selfpos);
+                    }
+                    bool self_pending = null_s;
+                    int t = index + (null0 ? 1 : 0);
 #pragma unroll
-                        for (int i = 0; i < kInlineExcl; i++) {
-                            if (self_pending && selfpos < sx[i]) {
-                                if (rho_s <= t) t++;
-                                self_pending = false;
-                            }
-                            if ((xmask >> i) & 1u) {
-                                const int rho = n_lo + (pcw[i] - pbase) + __popcll((unsigned long long)(rv[i] & bits_below(sx[i])));
-                                if (rho <= t) t++;
-                            }
+                    for (int i = 0; i < kInlineExcl; i++) {
+                        if (self_pending && selfpos < sx[i]) {
+                            if (rho_s <= t) t++;
+                            self_pending = false;
                         }
-                        if (self_pending && rho_s <= t) t++;
-                        const int T = t - n_lo + pbase;  // the word: the first w in (wlo, whi) with PC[w + 1] > T, else whi
-                        int lo = wlo + 1, hi = whi;
-                        while (lo < hi) {
-                            const int mid = (lo + hi) >> 1;
-                            if (PC[mid + 1] > T)
-                                hi = mid;
-                            else
-                                lo = mid + 1;
+                        if ((xmask >> i) & 1u) {
+                            if (rank_at(rv[i], pcw[i], sx[i]) <= t) t++;
                         }
+                    }
+                    if (self_pending && rho_s <= t) t++;
+                    if (t == 0) {
+                        cpos = bestpos;
+                    } else if (t - 1 < n_rlo) {
+                        cpos = wlo * 64 + select_kth_bit(r_lo, t - 1);
+                    } else {
+                        const int T = t - 1 - n_rlo + pbase;  // the word: the first w in (wlo, whi) with PC[w + 1] > T, else whi
+                        const int lo = first_word_over(PC, wlo + 1, whi, T);
+                        uint64_t v = r_hi;
                         if (lo < whi) {
-                            uint64_t v = L.E[lo];
+                            v = L.E[lo];
                             if (has_pm) v &= Pm[lo];
-                            cpos = lo * 64 + select_kth_bit(v, T - PC[lo]);
-                        } else {
-                            const int base = n_lo + (PC[whi] - pbase) - __popc(xmask) - (self_mid ? 1 : 0);
-                            cpos = whi * 64 + select_kth_bit(surv(whi), index - base);
                         }
+                        cpos = lo * 64 + select_kth_bit(v, T - PC[lo]);
                     }
                 }
             } else {
@@ -2136,6 +2143,8 @@ __global__ __launch_bounds__(kPlaceBlock) void place_batch_long_kernel(Snap S, P
 // per SIMD.  Measured on the full cluster (C3): 800k decisions per launch 78.5 -> 71.2 us, 100k (1.5 wavefronts per SIMD:
 // occupancy is not what limits it) 20.3 -> 21.0 us — hence two instantiations, chosen by the launch's size.
 constexpr int kLongDenseFrom = 3 * 4 * 256 * 64;  // decisions from which a launch fills 3 wavefronts on each of the 1024 SIMDs
+// (Measured and not kept, round 4: case (b) as a phase of its own in these launches — collected per workgroup, one wavefront
+// instead of four runs it — 49.3 against 48.9 us per 800k; five wavefronts per SIMD — 96 VGPRs, 244 bytes of spill — 105 us.)
 __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void place_batch_long4_kernel(Snap S, PlaceArgs A, int32_t wpad)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
