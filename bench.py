@@ -291,7 +291,33 @@ def pod_axis_leg(workload: str, rank: int, world: int, dev, steps: int, warmup: 
     return out
 
 
-def pod_axis_lib_leg(workload: str, rank: int, world: int, dev, steps: int, warmup: int, fence):
+def _gloo_exchange_callback():
+    """mmp_exchange_fn over torch.distributed's (gloo) process group: what lets SEVERAL ranks on ONE device run the in-library
+    group protocol (RCCL refuses two ranks on one device) — the driver's 8-GPU run takes RCCL instead; this exists so that every
+    other line of the N-rank control flow has executed on a 1-GPU box before it."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    xfn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p)
+
+    def fn(_user, dev_buf, count, elem64, op_min, stream):
+        try:
+            t = torch.empty(int(count), dtype=torch.int64 if elem64 else torch.int32)
+            nbytes = t.numel() * t.element_size()
+            if hip.hipStreamSynchronize(stream) != 0 or hip.hipMemcpy(t.data_ptr(), dev_buf, nbytes, 2) != 0:
+                return 1
+            dist.all_reduce(t, op=dist.ReduceOp.MIN if op_min else dist.ReduceOp.SUM)
+            return 0 if hip.hipMemcpy(dev_buf, t.data_ptr(), nbytes, 1) == 0 else 1
+        except Exception:  # noqa: BLE001 (a C callback must not raise)
+            return 1
+    return xfn(fn)
+
+
+def pod_axis_lib_leg(workload: str, rank: int, world: int, dev, steps: int, warmup: int, fence, exchange: str = "rccl"):
     """The same pod-axis batch with the collectives INSIDE libmmplace (include/mmplace.h: mmp_shard_group_init /
     mmp_shard_commit / mmp_shard_place_batch_dev): ncclCommInitRank from a unique id that rank 0 creates through the
     library and torch.distributed only broadcasts; every ncclAllReduce runs on the library's own stream, and the rest
@@ -307,14 +333,23 @@ def pod_axis_lib_leg(workload: str, rank: int, world: int, dev, steps: int, warm
     reqs, extra = wl.make_requests(fleet, seed=0xBE7C0)  # identical on every rank
     n = len(reqs)
     s = Solver(fleet.min_space_units, fleet.min_churn_age_ms, device=dev.index)
+    cb = None
     try:
-        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(s.shard_unique_id()), dtype=torch.uint8))
-        if world > 1:
-            dist.broadcast(idt, src=0)
-        torch.cuda.synchronize(dev)
-        s.shard_group_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+        if exchange == "gloo":  # the host moves the exchange words (mmp_shard_group_set_exchange): several ranks on one device
+            import ctypes as C
+            cb = _gloo_exchange_callback()
+            rc = s.lib.mmp_shard_group_set_exchange(s.h, C.cast(cb, C.c_void_p), None)
+            if rc != 0:
+                raise RuntimeError(f"mmp_shard_group_set_exchange: {rc}")
+            s.shard_group_init(None, rank, world)
+        else:
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(s.shard_unique_id()), dtype=torch.uint8))
+            if world > 1:
+                dist.broadcast(idt, src=0)
+            torch.cuda.synchronize(dev)
+            s.shard_group_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
         s.load_fleet(fleet, commit=False)
         t0 = time.perf_counter()
         s.shard_commit()
@@ -355,8 +390,9 @@ def pod_axis_lib_leg(workload: str, rank: int, world: int, dev, steps: int, warm
             out = {"workload": f"{workload}: {fleet.n_models} models x {fleet.n_pods} pods", "n_shards": world,
                    "value": n * steps / elapsed, "unit": "decisions/s", "ms_per_step": elapsed / steps * 1e3,
                    "decisions_per_step": n, "scaling": "strong (pod table split, batch replicated)",
-                   "collective": "inside libmmplace on its own stream: ncclAllReduce(MIN, 2 int64 per decision), then 5 x MIN + 1 x SUM over "
-                                 "the undecided rest only when the (host-read) count of it is not zero (RCCL bound at run time)",
+                   "collective": ("inside libmmplace on its own stream: ncclAllReduce(MIN, 2 int64 per decision), then 5 x MIN + 1 x SUM over "
+                                  "the undecided rest only when the (host-read) count of it is not zero (RCCL bound at run time)") if exchange == "rccl"
+                   else "the library's group protocol with the exchange words moved by the host (mmp_shard_group_set_exchange): gloo, through host memory",
                    "took_the_six_phase_protocol": int(n_rest),
                    "ms_per_step_async": elapsed_async / steps * 1e3, "value_async": n * steps / elapsed_async,
                    "took_the_six_phase_protocol_async": int(n_rest_async),
@@ -1140,7 +1176,7 @@ def main():
         legs = [args.workload] + (["C4"] if world >= 8 and args.workload != "C4" else [])
         for wname in legs:
             try:
-                pod_axis.append(pod_axis_leg(wname, rank, world, dev, min(max(args.steps // 10, 5), 40), min(max(args.warmup // 10, 2), 5), fence))
+                pod_axis.append(pod_axis_leg(wname, rank, world, dev, min(max(args.steps, 20), 200), min(max(args.warmup // 10, 2), 5), fence))
             except Exception as e:  # the headline line must still be printed
                 pod_axis.append({"workload": wname, "error": f"{type(e).__name__}: {e}"})
             if rank == 0:
@@ -1148,14 +1184,9 @@ def main():
         pod_axis_lib = []
         one_device = os.environ.get("MMP_BENCH_ONE_DEVICE") == "1" and world > 1
         for wname in legs:
-            if one_device:  # RCCL refuses two ranks on one device: the group leg needs one GPU per rank
-                pod_axis_lib.append({"workload": wname, "skipped": "several ranks share one device (MMP_BENCH_ONE_DEVICE=1)"})
-                if rank == 0:
-                    line["pod_axis_in_library_rccl"] = list(pod_axis_lib)
-                continue
-            try:
-                pod_axis_lib.append(pod_axis_lib_leg(wname, rank, world, dev, min(max(args.steps // 10, 5), 40),
-                                                     min(max(args.warmup // 10, 2), 5), fence))
+            try:  # (RCCL refuses two ranks on one device: there the group's exchange goes through the host's gloo group)
+                pod_axis_lib.append(pod_axis_lib_leg(wname, rank, world, dev, min(max(args.steps, 20), 200),
+                                                     min(max(args.warmup // 10, 2), 5), fence, exchange="gloo" if one_device else "rccl"))
             except Exception as e:  # the headline line must still be printed
                 pod_axis_lib.append({"workload": wname, "error": f"{type(e).__name__}: {e}"})
             if rank == 0:

@@ -2177,7 +2177,7 @@ namespace {
 // pinned word (place_shard_fast_finish_kernel).  Three steps so that a caller may leave between the first and the second
 // (mmp_shard_place_batch_async_dev): enqueue the kernel; synchronise and read the count; only when it is not zero, flags ->
 // exclusive scan -> gather of the undecided requests (decision order, identical on every shard).  Called with c->mu held.
-int shard_finish_enqueue(mmp_ctx *c, uint32_t slot, int32_t n, const void *d_xf, void *d_outs, hipStream_t st, uint32_t *seq_out)
+int shard_finish_prepare(mmp_ctx *c, uint32_t slot, int32_t n, hipStream_t st, uint32_t *seq_out)
 {
     HIP_TRY(c, c->f_flags[slot].ensure((size_t)(n + 1) * 4));
     if (!c->f_cnt[slot].p) {
@@ -2188,7 +2188,14 @@ int shard_finish_enqueue(mmp_ctx *c, uint32_t slot, int32_t n, const void *d_xf,
         HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->f_done), 128, kPinnedFlags));
         c->f_done[0] = c->f_done[8] = 0;
     }
-    const uint32_t seq = ++c->f_seq;
+    *seq_out = ++c->f_seq;
+    return MMP_OK;
+}
+int shard_finish_enqueue(mmp_ctx *c, uint32_t slot, int32_t n, const void *d_xf, void *d_outs, hipStream_t st, uint32_t *seq_out)
+{
+    uint32_t seq = 0;
+    const int prc = shard_finish_prepare(c, slot, n, st, &seq);
+    if (prc != MMP_OK) return prc;
     hipLaunchKernelGGL(place_shard_fast_finish_kernel, dim3(div_up(n + 1, 256)), dim3(256), 0, st, static_cast<const int64_t *>(d_xf),
                        n, c->ssnap.any_rs, static_cast<mmp_place_out *>(d_outs), c->f_flags[slot].as<int32_t>(),
                        c->f_cnt[slot].as<unsigned long long>(), c->f_done + 8 * slot, seq);
@@ -2534,11 +2541,12 @@ int shard_resolve_pending(mmp_ctx *c)
     c->pend.active = false;
     hipStream_t st = c->stream;
     int32_t n_rest = 0;
-    int rc;
-    {
+    // the count is polled WITHOUT the state lock (every decision path holds it shared: a spin under the exclusive lock stalled them
+    // for the whole wait); only the gather's buffers need it
+    int rc = shard_finish_collect(c, P.slot, st, P.seq, &n_rest);
+    if (rc == MMP_OK && n_rest > 0) {
         std::lock_guard<std::shared_mutex> g(c->mu);
-        rc = shard_finish_collect(c, P.slot, st, P.seq, &n_rest);
-        if (rc == MMP_OK && n_rest > 0) rc = shard_rest_gather(c, P.slot, P.d_reqs, P.n, n_rest, st);
+        rc = shard_rest_gather(c, P.slot, P.d_reqs, P.n, n_rest, st);
     }
     if (rc != MMP_OK) return rc;
     c->last_n_rest = n_rest;
@@ -2571,13 +2579,25 @@ int shard_place_batch_locked(mmp_ctx *c, const void *d_reqs, int32_t n, const vo
     // of these three launches to end — is completed afterwards, and whatever its rest needs is enqueued behind this batch.
     hipStream_t st = c->stream;
     const uint32_t slot = c->f_slot ^= 1u;
-    HIP_TRY(c, c->g_xf[slot].ensure((size_t)n * kXF * 8));
-    rc = mmp_shard_place_fast_dev(c, d_reqs, n, d_extra, now, c->g_xf[slot].p, st);
-    if (rc != MMP_OK) return rc;
-    rc = group_allreduce(c, c->g_xf[slot].p, (size_t)n * kXF, ncclInt64, ncclMin);
-    if (rc != MMP_OK) return rc;
     uint32_t seq = 0;
-    {
+    if (c->n_shards == 1) {
+        // a group of one shard: the slice's answer IS the answer — one launch writes rows, rest flags and count (no exchange words,
+        // no all-reduce, no finish kernel)
+        std::lock_guard<std::shared_mutex> g(c->mu);
+        if (!c->committed) return fail(c, MMP_ESTATE, "no committed shard snapshot");
+        rc = shard_finish_prepare(c, slot, n, st, &seq);
+        if (rc != MMP_OK) return rc;
+        const PlaceArgs A = shard_args(c, d_reqs, n, d_extra, now, d_outs);
+        hipLaunchKernelGGL(place_shard_fast_direct_kernel, dim3(div_up(n + 1, kPlaceBlock)), dim3(kPlaceBlock), (size_t)place_lane_lds(c->sview.T),
+                           st, c->sview, A, c->shard, c->ssnap.any_rs, c->f_flags[slot].as<int32_t>(), c->f_cnt[slot].as<unsigned long long>(),
+                           c->f_done + 8 * slot, seq);
+        HIP_TRY(c, hipGetLastError());
+    } else {
+        HIP_TRY(c, c->g_xf[slot].ensure((size_t)n * kXF * 8));
+        rc = mmp_shard_place_fast_dev(c, d_reqs, n, d_extra, now, c->g_xf[slot].p, st);
+        if (rc != MMP_OK) return rc;
+        rc = group_allreduce(c, c->g_xf[slot].p, (size_t)n * kXF, ncclInt64, ncclMin);
+        if (rc != MMP_OK) return rc;
         std::lock_guard<std::shared_mutex> g(c->mu);
         rc = shard_finish_enqueue(c, slot, n, c->g_xf[slot].p, d_outs, st, &seq);
         if (rc != MMP_OK) return rc;

@@ -622,12 +622,11 @@ constexpr int kShardMaxPods = 1 << 24;
 // into the view), lane_decide_win<true>, and lane_decide_r<true> for what the window cannot answer.  Dynamic LDS:
 // place_lane_lds(T).  (Round 2 ran lane_decide_r alone here, through models -> ent_pod -> pos_of: 6.8x the unsharded launch at
 // one shard.)
-__global__ __launch_bounds__(kPlaceBlock) void place_shard_fast_kernel(Snap V, PlaceArgs A, int32_t shard, int64_t *__restrict__ xf)
+// the slice's answer for decision d as the two exchange words (kXMax, kXMax: no eligible pod here)
+__device__ __forceinline__ void shard_fast_words(const Snap &V, const PlaceArgs &A, int32_t shard, unsigned char *smem, int d, int64_t &k0, int64_t &k1)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TypeWin *s_wins = reinterpret_cast<TypeWin *>(smem);
     uint64_t *s_scr = reinterpret_cast<uint64_t *>(smem + win_lds_bytes(V.T));
-    const int d = blockIdx.x * kPlaceBlock + threadIdx.x;
     const bool use_wins = A.wins != nullptr;  // wave-uniform
     if (use_wins) {
         constexpr int kWinBytes = (int)sizeof(TypeWin);
@@ -643,6 +642,7 @@ __global__ __launch_bounds__(kPlaceBlock) void place_shard_fast_kernel(Snap V, P
     if (d < A.n) rq = A.reqs[d];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    k0 = k1 = kXMax;
     if (d >= A.n) return;
     ResolvedReq r = resolve_req<true, true>(V, A, rq);
     mmp_place_out o;
@@ -652,12 +652,20 @@ __global__ __launch_bounds__(kPlaceBlock) void place_shard_fast_kernel(Snap V, P
         merge_late_extras(r);
         code = lane_decide_r<true>(V, A, r, o);
     }
-    int64_t k0 = kXMax, k1 = kXMax;
     if (code != kLaneNoneHere) {
         const int64_t key = (int64_t)shard << 56;
         k0 = key | ((int64_t)(code != kLaneDone) << 55) | ((int64_t)(uint32_t)(o.chosen + 2) << 28) | (int64_t)(uint32_t)(o.best + 1);
         k1 = key | ((int64_t)(uint32_t)o.n_candidates << 32) | (int64_t)o.hash;
     }
+}
+
+__global__ __launch_bounds__(kPlaceBlock) void place_shard_fast_kernel(Snap V, PlaceArgs A, int32_t shard, int64_t *__restrict__ xf)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int d = blockIdx.x * kPlaceBlock + threadIdx.x;
+    int64_t k0, k1;
+    shard_fast_words(V, A, shard, smem, d, k0, k1);
+    if (d >= A.n) return;
     int64_t *x = xf + (size_t)d * kXF;
     x[0] = k0;
     x[1] = k1;
@@ -669,6 +677,47 @@ __global__ __launch_bounds__(kPlaceBlock) void place_shard_fast_kernel(Snap V, P
 // decisions — on eight XCDs it is an L2 write-back each); the workgroup that sees the others' count complete stores
 // seq << 32 | flagged into the pinned word `done`, where the host finds it after synchronising the stream (no device-to-host
 // copy); it runs scan + gather + the general protocol only when the count is not zero (the usual batch has none).
+// one decision's reduced words -> its result row or its "rest" flag
+__device__ __forceinline__ int32_t shard_finish_row(int64_t k0, int64_t k1, int32_t any_rs, int d, mmp_place_out *__restrict__ outs,
+                                                    int32_t *__restrict__ flags)
+{
+    int32_t rest = 0;
+    mmp_place_out o;
+    o.chosen = MMP_NONE;
+    o.best = -1;
+    o.n_candidates = 0;
+    o.hash = 0;
+    if (k0 == kXMax)
+        rest = any_rs ? 1 : 0;  // nowhere eligible: null, unless the excludeReplicaSets retry has to run
+    else if ((k0 >> 55) & 1)
+        rest = 1;
+    else {
+        o.chosen = (int32_t)((k0 >> 28) & 0x7ffffffll) - 2;
+        o.best = (int32_t)(k0 & 0xfffffffll) - 1;
+        o.n_candidates = (int32_t)((k1 >> 32) & 0xffffffll);
+        o.hash = (uint32_t)(k1 & 0xffffffffll);
+    }
+    flags[d] = rest;
+    if (!rest) outs[d] = o;
+    return rest;
+}
+// the workgroup's flagged decisions into the launch's count; the last workgroup publishes seq << 32 | total in pinned memory
+__device__ __forceinline__ void shard_finish_count(int32_t rest, uint32_t *s_rest, unsigned long long *__restrict__ cnt,
+                                                   uint64_t *__restrict__ done, uint32_t seq)
+{
+    const uint64_t m = __ballot(rest != 0);
+    if (m && (int)__builtin_ctzll(m) == lane_id()) atomicAdd(s_rest, (uint32_t)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long mine = (1ull << 32) | *s_rest;
+        const unsigned long long prev = __hip_atomic_fetch_add(cnt, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(prev >> 32) == gridDim.x - 1) {
+            const uint32_t total = (uint32_t)prev + *s_rest;
+            __hip_atomic_store(cnt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done, ((uint64_t)seq << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
 __global__ __launch_bounds__(256) void place_shard_fast_finish_kernel(const int64_t *__restrict__ xf, int32_t n, int32_t any_rs,
                                                                       mmp_place_out *__restrict__ outs, int32_t *__restrict__ flags,
                                                                       unsigned long long *__restrict__ cnt, uint64_t *__restrict__ done, uint32_t seq)
@@ -681,37 +730,28 @@ __global__ __launch_bounds__(256) void place_shard_fast_finish_kernel(const int6
     if (d == n) flags[n] = 0;  // the scan runs over n + 1 items: offs[n] = number of flagged decisions
     if (d < n) {
         const int64_t *x = xf + (size_t)d * kXF;
-        const int64_t k0 = x[0], k1 = x[1];
-        mmp_place_out o;
-        o.chosen = MMP_NONE;
-        o.best = -1;
-        o.n_candidates = 0;
-        o.hash = 0;
-        if (k0 == kXMax)
-            rest = any_rs ? 1 : 0;  // nowhere eligible: null, unless the excludeReplicaSets retry has to run
-        else if ((k0 >> 55) & 1)
-            rest = 1;
-        else {
-            o.chosen = (int32_t)((k0 >> 28) & 0x7ffffffll) - 2;
-            o.best = (int32_t)(k0 & 0xfffffffll) - 1;
-            o.n_candidates = (int32_t)((k1 >> 32) & 0xffffffll);
-            o.hash = (uint32_t)(k1 & 0xffffffffll);
-        }
-        flags[d] = rest;
-        if (!rest) outs[d] = o;
+        rest = shard_finish_row(x[0], x[1], any_rs, d, outs, flags);
     }
-    const uint64_t m = __ballot(rest != 0);
-    if (m && (int)__builtin_ctzll(m) == lane_id()) atomicAdd(&s_rest, (uint32_t)__popcll(m));
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long mine = (1ull << 32) | s_rest;
-        const unsigned long long prev = __hip_atomic_fetch_add(cnt, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(prev >> 32) == gridDim.x - 1) {
-            const uint32_t total = (uint32_t)prev + s_rest;
-            __hip_atomic_store(cnt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(done, ((uint64_t)seq << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    shard_finish_count(rest, &s_rest, cnt, done, seq);
+}
+
+// A group of ONE shard: there is nothing to exchange, so the slice's answer is the answer — the fast kernel writes the result
+// rows, the rest flags and the count itself (no exchange words, no all-reduce, no finish kernel: one launch per batch, as the
+// unsharded context has).
+__global__ __launch_bounds__(kPlaceBlock) void place_shard_fast_direct_kernel(Snap V, PlaceArgs A, int32_t shard, int32_t any_rs,
+                                                                             int32_t *__restrict__ flags, unsigned long long *__restrict__ cnt,
+                                                                             uint64_t *__restrict__ done, uint32_t seq)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t s_rest;
+    if (threadIdx.x == 0) s_rest = 0;
+    const int d = blockIdx.x * kPlaceBlock + threadIdx.x;
+    int64_t k0, k1;
+    shard_fast_words(V, A, shard, smem, d, k0, k1);  // (its barrier orders the s_rest store)
+    int32_t rest = 0;
+    if (d == A.n) flags[A.n] = 0;
+    if (d < A.n) rest = shard_finish_row(k0, k1, any_rs, d, A.outs, flags);
+    shard_finish_count(rest, &s_rest, cnt, done, seq);
 }
 
 __global__ void place_shard_gather_kernel(const mmp_place_req *__restrict__ reqs, int32_t n, const int32_t *__restrict__ flags,

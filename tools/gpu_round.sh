@@ -21,6 +21,12 @@ bench2)
   MMP_BENCH_ONE_DEVICE=1 MMP_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
     --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 50 --warmup 5 > $OUT/bench2.json.log 2> $OUT/bench2.err; echo "bench2 exit $?"
   tail -1 $OUT/bench2.json.log | cut -c1-600 ;;
+bench8)
+  # the driver's 8-GPU control flow on a 1-GPU box: eight ranks share cuda:0 over gloo, every leg runs (the in-library group with the
+  # exchange words moved by the host's gloo group), the driver's flags
+  MMP_BENCH_ONE_DEVICE=1 MMP_BENCH_BACKEND=gloo timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
+    --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 8 --steps 20 --warmup 5 > $OUT/bench8.json.log 2> $OUT/bench8.err; echo "bench8 exit $?"
+  tail -1 $OUT/bench8.json.log | cut -c1-800; tail -3 $OUT/bench8.err | cut -c1-300 ;;
 prof)
   # kernel stats of the bench command; --streams 1 so that every dispatch is back to back on one stream and the
   # average duration is the one bench.py reports as roofline.kernel_ms (overlapping streams stretch dispatches)
