@@ -77,10 +77,11 @@ struct DevBuf {
 // device storage of one committed snapshot
 struct SnapBufs {
     DevBuf pods, lru, rem, cnt, rpm, orig, pos_of, elig, elig_nors, pref, has_pref, fullw, ge, pc, ph, nz, heads, bslots, bpm, bwin, bsurv, bpcs;
+    DevBuf ctpos;  // Snap::ctpos
     int32_t n_bslots = 0;  // case (b) slots this snapshot has (place_kernel.hpp: BSlot), read back at commit
     void release()
     {
-        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge, &pc, &ph, &nz, &heads, &bslots, &bpm, &bwin, &bsurv, &bpcs})
+        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge, &pc, &ph, &nz, &heads, &bslots, &bpm, &bwin, &bsurv, &bpcs, &ctpos})
             b->release();
     }
 };
@@ -170,6 +171,10 @@ struct mmp_ctx {
     double last_kernel_ms = -1.0;
     int32_t force_wave = 0;  // MMP_FORCE_WAVE=1: every decision takes the wave-per-decision kernel (tests)
     size_t lds_limit = 64 * 1024;    // LDS a workgroup may use on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
+    // a registry event's in-place rewrite is enqueued under the state lock and finishes after it: kernels that read the registry
+    // from other streams are ordered behind reg_event while reg_pending (order_after_registry)
+    hipEvent_t reg_event = nullptr;
+    std::atomic<bool> reg_pending{false};
     std::atomic<size_t> lds_granted{48 * 1024};  // dynamic LDS the place kernels may be launched with so far
     int32_t no_caseb = 0;    // MMP_NO_CASEB=1: case (b) decisions never use the whole-window tables (tests: the wave path decides them)
     int32_t no_long_lds = 0; // MMP_NO_LONG_LDS=1: the long path reads its per-type tables from global memory (tests, comparison)
@@ -352,11 +357,16 @@ void resident_stop(mmp_ctx *c)
     R.running = false;
 }
 
+hipError_t slot_wait(FastSlot *f);
 hipError_t quiesce_decisions(mmp_ctx *c)
 {
     resident_stop(c);
+    // A latency slot has a kernel in flight only while its completion word lags its sequence number (the kernel stores the word
+    // last; the owner bumps the number under the state lock, which the caller of this function holds or which no launch can pass
+    // any more): an idle slot costs a load here, not a hipStreamSynchronize (16 of them were 50-100 us under the exclusive lock)
     for (FastSlot &f : c->fast) {
-        hipError_t e = hipStreamSynchronize(f.stream);
+        if (!f.done || __atomic_load_n(f.done, __ATOMIC_ACQUIRE) == f.seq) continue;
+        hipError_t e = slot_wait(&f);
         if (e != hipSuccess) return e;
     }
     std::vector<hipStream_t> cs;
@@ -432,6 +442,7 @@ hipError_t slot_wait(FastSlot *f)
     return hipStreamSynchronize(f->stream);
 }
 
+hipError_t order_after_registry(mmp_ctx *c, hipStream_t st);
 int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs,
                  hipStream_t st, uint32_t *done_flag = nullptr, uint32_t done_seq = 0, const mmp_place_req *inline_req = nullptr,
                  uint32_t *done_blocks = nullptr)
@@ -496,6 +507,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_single_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         c->lds_granted.store((size_t)want, std::memory_order_release);
     }
+    HIP_TRY(c, order_after_registry(c, st));
     if (inline_req)
         hipLaunchKernelGGL(place_single_kernel, dim3(1), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *inline_req);
     else if (done_flag && n > kPlaceBlock)
@@ -557,6 +569,11 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete c;
         return fail(nullptr, MMP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    if ((e = hipEventCreateWithFlags(&c->reg_event, hipEventDisableTiming)) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail(nullptr, MMP_EHIP, "hipEventCreate: %s", hipGetErrorString(e));
     }
     for (FastSlot &f : c->fast) {
         int lo = 0, hi = 0;
@@ -624,6 +641,7 @@ void mmp_destroy(mmp_ctx *c)
     }
     for (DevBuf *b : {&c->g_rankbuf, &c->g_xf[0], &c->g_xf[1], &c->g_x[0], &c->g_x[1], &c->g_x[2], &c->g_x[3], &c->g_x[4], &c->g_x[5]}) b->release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->reg_event) (void)hipEventDestroy(c->reg_event);
     if (c->pe0) (void)hipEventDestroy(c->pe0);
     if (c->pe1) (void)hipEventDestroy(c->pe1);
     c->sb[0].release();
@@ -951,6 +969,25 @@ try {
 
 namespace {
 // grow a device buffer, keeping its first `used` bytes
+// Called with c->mu held (shared) right before a kernel that reads the registry (models / resolved rows / entry arena) is
+// enqueued on `st`: a registry event whose rewrite kernel is still running on the context's stream is waited for ON THE DEVICE.
+hipError_t order_after_registry(mmp_ctx *c, hipStream_t st)
+{
+    if (!c->reg_pending.load(std::memory_order_acquire) || st == c->stream) return hipSuccess;
+    return hipStreamWaitEvent(st, c->reg_event, 0);
+}
+
+// Growing a table decisions read, without holding them off for the copy: the new allocation is filled beside the old one
+// (batch_mu keeps other writers away), the pointer is swapped under the state lock, and the old allocation is freed once the
+// kernels that captured it have drained.  `old_out` receives the old allocation (released by the caller after quiesce).
+int grow_cow(mmp_ctx *c, DevBuf &b, size_t used, size_t want, DevBuf &fresh)
+{
+    if (want <= b.cap) return MMP_OK;
+    HIP_TRY(c, fresh.ensure(std::max(want, b.cap * 2)));
+    if (used && b.p) HIP_TRY(c, hipMemcpyAsync(fresh.p, b.p, used, hipMemcpyDeviceToDevice, c->stream));
+    return MMP_OK;
+}
+
 int grow_keep(mmp_ctx *c, DevBuf &b, size_t used, size_t want)
 {
     if (want <= b.cap) return MMP_OK;
@@ -968,7 +1005,11 @@ int grow_keep(mmp_ctx *c, DevBuf &b, size_t used, size_t want)
     return MMP_OK;
 }
 
-// squeeze the garbage out of the entry arena (rows keep their order, entries their order inside a row)
+// squeeze the garbage out of the entry arena (rows keep their order, entries their order inside a row).  Copy-on-write: the rows
+// with their new offsets and the squeezed arena are built BESIDE the published ones (called with batch_mu, without the state
+// lock: decisions keep reading the old tables), swapped in under the state lock, and the old ones freed when the kernels that
+// captured them have drained.  (In place under the lock this held every decision off for the whole rebuild: the 0.4-0.6 ms
+// maximum of a single decision under churn in round 3.)
 int compact_registry(mmp_ctx *c)
 {
     const int32_t n = c->n_models;
@@ -979,31 +1020,42 @@ int compact_registry(mmp_ctx *c)
     HIP_TRY(c, rocprim::exclusive_scan(nullptr, tmp, c->u_cnt.as<int32_t>(), c->u_offs.as<int32_t>(), (int32_t)0, (size_t)n + 1,
                                        rocprim::plus<int32_t>(), st));
     HIP_TRY(c, c->u_tmp.ensure(std::max<size_t>(tmp, 16)));
-    DevBuf np, nt;
+    DevBuf nm, np, nt;
     const size_t cap = (size_t)std::max<int64_t>(c->ent_live + c->ent_live / 2, 1024);
-    HIP_TRY(c, np.ensure(cap * 4));
-    if (nt.ensure(cap * 8) != hipSuccess) {
-        np.release();
+    auto drop = [&] { nm.release(); np.release(); nt.release(); };
+    if (nm.ensure(std::max<size_t>(c->models.cap, 16)) != hipSuccess || np.ensure(cap * 4) != hipSuccess || nt.ensure(cap * 8) != hipSuccess) {
+        drop();
         return fail(c, MMP_ENOMEM, "compact_registry: out of device memory");
     }
+    hipError_t e = hipMemcpyAsync(nm.p, c->models.p, (size_t)n * sizeof(mmp_model_row), hipMemcpyDeviceToDevice, st);
     hipLaunchKernelGGL(model_counts_kernel, dim3(div_up(n + 1, 256)), dim3(256), 0, st, c->models.as<mmp_model_row>(), n,
                        c->u_cnt.as<int32_t>());
     (void)rocprim::exclusive_scan(c->u_tmp.p, tmp, c->u_cnt.as<int32_t>(), c->u_offs.as<int32_t>(), (int32_t)0, (size_t)n + 1,
                                   rocprim::plus<int32_t>(), st);
-    hipLaunchKernelGGL(move_entries_kernel, dim3(div_up(std::max(n, 1), 256)), dim3(256), 0, st, c->models.as<mmp_model_row>(), n,
+    hipLaunchKernelGGL(move_entries_kernel, dim3(div_up(std::max(n, 1), 256)), dim3(256), 0, st, nm.as<mmp_model_row>(), n,
                        c->u_offs.as<int32_t>(), c->ent_pod.as<int32_t>(), c->ent_time.as<int64_t>(), np.as<int32_t>(),
                        nt.as<int64_t>());
-    const hipError_t e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
-        np.release();
-        nt.release();
+        drop();
         HIP_TRY(c, e);
     }
-    c->ent_pod.release();
-    c->ent_time.release();
-    c->ent_pod = np;
-    c->ent_time = nt;
-    c->n_entries = (int32_t)c->ent_live;
+    DevBuf om, op, ot;
+    {
+        std::lock_guard<std::shared_mutex> g(c->mu);  // the swap: three pointers
+        om = c->models;
+        op = c->ent_pod;
+        ot = c->ent_time;
+        c->models = nm;
+        c->ent_pod = np;
+        c->ent_time = nt;
+        c->n_entries = (int32_t)c->ent_live;
+    }
+    const hipError_t q = quiesce_decisions(c);  // kernels that captured the old tables
+    om.release();
+    op.release();
+    ot.release();
+    HIP_TRY(c, q);
     return MMP_OK;
 }
 }  // namespace
@@ -1058,16 +1110,31 @@ try {
     const bool grows = (size_t)count * sizeof(mmp_model_row) > c->models.cap || (size_t)(base + n_entries) * 4 > c->ent_pod.cap ||
                        (size_t)(base + n_entries) * 8 > c->ent_time.cap ||
                        (cur_side(c).rmodels_ok && (size_t)count * sizeof(ResolvedModel) > cur_side(c).rmodels.cap);
-    if (grows) {
-        std::lock_guard<std::shared_mutex> g(c->mu);
-        HIP_TRY(c, quiesce_decisions(c));
-        int rc = grow_keep(c, c->models, (size_t)c->n_models * sizeof(mmp_model_row), (size_t)count * sizeof(mmp_model_row));
-        if (rc == MMP_OK) rc = grow_keep(c, c->ent_pod, (size_t)base * 4, (size_t)(base + n_entries) * 4);
-        if (rc == MMP_OK) rc = grow_keep(c, c->ent_time, (size_t)base * 8, (size_t)(base + n_entries) * 8);
+    if (grows) {  // copy-on-write (grow_cow): decisions are held off for the pointer swap only
+        DevBuf fm, fp, ft, fr;
+        auto drop = [&] { fm.release(); fp.release(); ft.release(); fr.release(); };
+        int rc = grow_cow(c, c->models, (size_t)c->n_models * sizeof(mmp_model_row), (size_t)count * sizeof(mmp_model_row), fm);
+        if (rc == MMP_OK) rc = grow_cow(c, c->ent_pod, (size_t)base * 4, (size_t)(base + n_entries) * 4, fp);
+        if (rc == MMP_OK) rc = grow_cow(c, c->ent_time, (size_t)base * 8, (size_t)(base + n_entries) * 8, ft);
         // (the unpublished side's view is rebuilt from the model table by the next commit)
         if (rc == MMP_OK && cur_side(c).rmodels_ok)
-            rc = grow_keep(c, cur_side(c).rmodels, (size_t)c->n_models * sizeof(ResolvedModel), (size_t)count * sizeof(ResolvedModel));
-        if (rc != MMP_OK) return rc;
+            rc = grow_cow(c, cur_side(c).rmodels, (size_t)c->n_models * sizeof(ResolvedModel), (size_t)count * sizeof(ResolvedModel), fr);
+        if (rc == MMP_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(c, MMP_EHIP, "mmp_models_upsert: growing the registry tables failed");
+        if (rc != MMP_OK) {
+            drop();
+            return rc;
+        }
+        DevBuf olds[4];
+        {
+            std::lock_guard<std::shared_mutex> g(c->mu);
+            if (fm.p) { olds[0] = c->models; c->models = fm; }
+            if (fp.p) { olds[1] = c->ent_pod; c->ent_pod = fp; }
+            if (ft.p) { olds[2] = c->ent_time; c->ent_time = ft; }
+            if (fr.p) { olds[3] = cur_side(c).rmodels; cur_side(c).rmodels = fr; }
+        }
+        const hipError_t q = quiesce_decisions(c);  // kernels that captured the old allocations
+        for (DevBuf &o : olds) o.release();
+        HIP_TRY(c, q);
     }
     HIP_TRY(c, c->u_idx.ensure((size_t)k * 4));
     HIP_TRY(c, c->u_rows.ensure((size_t)k * sizeof(mmp_model_row)));
@@ -1079,8 +1146,11 @@ try {
     HIP_TRY(c, hipMemcpyAsync(c->u_rows.p, h_rows.data(), (size_t)k * sizeof(mmp_model_row), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipStreamSynchronize(st));  // the pageable sources above are this call's stack / the caller's arrays
     {
+        // Rows (and their resolved positions) are rewritten in place.  Under the state lock: the decisions in flight drain, the
+        // rewrite kernel is ENQUEUED and an event recorded behind it; decisions launched from now on order themselves behind that
+        // event on the device (order_after_registry).  The lock is not held while the kernel runs.
         std::lock_guard<std::shared_mutex> g(c->mu);
-        HIP_TRY(c, quiesce_decisions(c));  // rows (and their resolved positions) are rewritten in place
+        HIP_TRY(c, quiesce_decisions(c));
         const bool resolved = cur_side(c).rmodels_ok && c->committed;
         KT_BEGIN(c, st);
         hipLaunchKernelGGL(upsert_models_kernel, dim3(div_up(k, 256)), dim3(256), 0, st, c->snap, c->u_idx.as<int32_t>(),
@@ -1088,13 +1158,17 @@ try {
                            resolved ? cur_side(c).rmodels.as<ResolvedModel>() : nullptr);
         KT_END(c, st);
         HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipStreamSynchronize(st));
-        kt_collect(c);
+        HIP_TRY(c, hipEventRecord(c->reg_event, st));
+        c->reg_pending.store(true, std::memory_order_release);
         c->n_models = count;
         c->n_entries = base + n_entries;
-        // more garbage than live entries (and enough to matter): squeeze the arena
-        if ((int64_t)c->n_entries - c->ent_live > std::max<int64_t>(c->ent_live, 1 << 16)) return compact_registry(c);
     }
+    const hipError_t se = hipStreamSynchronize(st);
+    c->reg_pending.store(false, std::memory_order_release);
+    HIP_TRY(c, se);
+    kt_collect(c);
+    // more garbage than live entries (and enough to matter): squeeze the arena
+    if ((int64_t)c->n_entries - c->ent_live > std::max<int64_t>(c->ent_live, 1 << 16)) return compact_registry(c);
     return MMP_OK;
 } catch (const std::bad_alloc &) {
     return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_models_upsert");
@@ -1197,6 +1271,7 @@ try {
     HIP_TRY(c, B.has_pref.ensure(T));
     HIP_TRY(c, B.fullw.ensure((size_t)W * 8));
     HIP_TRY(c, B.ge.ensure((size_t)kGeRows * W * 8));
+    HIP_TRY(c, B.ctpos.ensure((size_t)(kGeRows + 1) * 4));
     HIP_TRY(c, B.pc.ensure((size_t)2 * T * (W + 1) * 4));
     HIP_TRY(c, B.nz.ensure((size_t)2 * T * (W + 1) * 4));
     HIP_TRY(c, B.ph.ensure((size_t)2 * T * (W + 1) * 8));
@@ -1270,6 +1345,7 @@ try {
     S.pc = B.pc.as<int32_t>();
     S.nz = B.nz.as<int32_t>();
     S.ph = B.ph.as<uint64_t>();
+    S.ctpos = P > 0 ? B.ctpos.as<int32_t>() : nullptr;
 
     bool next_long = c->long_mode == 1, next_full = false;
     KT_BEGIN(c, st);
@@ -1319,6 +1395,7 @@ try {
                            B.pos_of.as<int32_t>(), c->flag.as<int32_t>());
         hipLaunchKernelGGL(build_ge_kernel, dim3(div_up(kGeRows * W, 4)), dim3(256), 0, st, B.cnt.as<int32_t>(), P, W,
                            B.ge.as<uint64_t>());
+        hipLaunchKernelGGL(build_ctpos_kernel, dim3(1), dim3(64), 0, st, B.cnt.as<int32_t>(), P, B.ctpos.as<int32_t>());
         if (n_rs)
             hipLaunchKernelGGL(mark_replaced_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(),
                                P, c->rs_list.as<int32_t>(), n_rs, c->rs_bad.as<uint8_t>());
@@ -2071,6 +2148,7 @@ namespace {
 int shard_phase_launch(mmp_ctx *c, int32_t phase, const void *d_reqs, int32_t n, const int32_t *n_dev, const void *d_extra,
                        int64_t now, void *const *d_xchg, void *d_outs, hipStream_t st)
 {
+    HIP_TRY(c, order_after_registry(c, st));
     PlaceArgs A{};
     A.reqs = static_cast<const mmp_place_req *>(d_reqs);
     A.models = c->models.as<mmp_model_row>();
@@ -2162,6 +2240,7 @@ try {
     if (n == 0) return MMP_OK;
     const PlaceArgs A = shard_args(c, d_reqs, n, d_extra, now, nullptr);
     note_caller_stream(c, static_cast<hipStream_t>(stream));
+    HIP_TRY(c, order_after_registry(c, static_cast<hipStream_t>(stream)));
     hipLaunchKernelGGL(place_shard_fast_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), (size_t)place_lane_lds(c->sview.T),
                        static_cast<hipStream_t>(stream), c->sview, A, c->shard, static_cast<int64_t *>(d_xf));
     HIP_TRY(c, hipGetLastError());
@@ -2854,6 +2933,7 @@ int resident_ensure(mmp_ctx *c)
     A.n = 1;
     A.n_models = c->n_models;
     A.n_pods_all = c->snap.P;
+    HIP_TRY(c, order_after_registry(c, R.stream));
     hipLaunchKernelGGL(place_resident_kernel, dim3(1), dim3(64), (size_t)kPlaceLaneLds, R.stream, c->snap, A, R.slots, R.answers, R.ctl,
                        R.idle_ticks, R.generation);
     HIP_TRY(c, hipGetLastError());
@@ -3194,6 +3274,7 @@ try {
             A.excl_time = reinterpret_cast<const int64_t *>(pool + 2 * kSlotExcl);
             A.outs = reinterpret_cast<mmp_serve_out *>(f->outs);
             A.done = DoneFlag{f->done, f->blocks, ++f->seq};
+            HIP_TRY(c, order_after_registry(c, f->stream));
             hipLaunchKernelGGL(serve_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, f->stream, A);
             HIP_TRY(c, hipGetLastError());
         }
@@ -3304,6 +3385,7 @@ try {
             A.excl_time = reinterpret_cast<const int64_t *>(pool + 2 * kGatePool);
             A.outs = reinterpret_cast<mmp_gate_out *>(f->outs);
             A.done = DoneFlag{f->done, f->blocks, ++f->seq};
+            HIP_TRY(c, order_after_registry(c, f->stream));
             hipLaunchKernelGGL(gate_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, f->stream, A);
             HIP_TRY(c, hipGetLastError());
         }

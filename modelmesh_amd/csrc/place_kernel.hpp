@@ -239,6 +239,33 @@ __device__ __forceinline__ int first_count_break(const uint64_t *ew, const uint6
     return kNoPos;
 }
 
+// The count break (MM.java:4925-4926) of the wave path through the snapshot's threshold bitmaps (Snap::ge, as the lane path):
+// the first position in [start, end) set in ew & andmask & G — 64 WORDS per step instead of 64 pods per step of the count
+// column.  (On a churned C3 fleet the single-decision path met shortlists of ~2700 instances: eleven dependent trips through
+// the count column, 40-60 us per decision; one step here.)
+__device__ __forceinline__ int first_ge_break(const uint64_t *ew, const uint64_t *andmask, const uint64_t *G, int start, int end)
+{
+    const int lane = lane_id();
+    if (start >= end) return kNoPos;
+    const int w0 = start >> 6, w1 = (end - 1) >> 6;
+    for (int base = w0; base <= w1; base += 64) {
+        const int w = base + lane;
+        uint64_t v = 0;
+        if (w <= w1) {
+            v = ew[w] & G[w];
+            if (andmask) v &= andmask[w];
+            v = clip_word(v, w, start, end);
+        }
+        const uint64_t b = __ballot(v != 0);
+        if (b) {
+            const int l = __ffsll((unsigned long long)b) - 1;
+            const uint64_t vv = readlane_u64(v, l);
+            return (base + l) * 64 + (__ffsll((unsigned long long)vv) - 1);
+        }
+    }
+    return kNoPos;
+}
+
 // first position >= start with bit set in ew and
 // (lru - oldest) > abs_ms && (lru - oldest) > rel   (MM.java:4862-4866)
 __device__ __forceinline__ int first_lru_break(const uint64_t *ew, int start, int W, const int64_t *lru,
@@ -1266,7 +1293,20 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
             }
             const uint64_t *G = S.ge + (size_t)(T - kGeBase) * W;
             auto dc = [&](int w) { return dw(w) & G[w]; };
-            const int pc = lane_first(dc, start, end, far, LONG ? S.nz : nullptr, has_pm ? pc_ep : pc_e, kFarWords);
+            // Inside the non-decreasing head of the count column (Snap::ctpos) the threshold holds from one position on: the
+            // break is the first CANDIDATE at or behind it — no walk over the words in front of it (a shortlist of thousands of
+            // instances with counts below the threshold made that walk give up: the wave path, 40 us for a single decision)
+            int pc = kNoPos, from2 = start;
+            if (!VIEW && S.ctpos) {
+                const int mono_end = S.ctpos[kGeRows], first_ge = S.ctpos[T - kGeBase];
+                if (start < mono_end) {
+                    const int lo = first_ge > start ? first_ge : start, hi = mono_end < end ? mono_end : end;
+                    pc = lane_first(dw, lo, hi, far, LONG ? S.nz : nullptr, has_pm ? pc_ep : pc_e);
+                    from2 = mono_end;
+                }
+            }
+            if (pc == kNoPos && !far && from2 < end)
+                pc = lane_first(dc, from2, end, far, LONG ? S.nz : nullptr, has_pm ? pc_ep : pc_e, kFarWords);
             end = pc < end ? pc : end;
         }
         PHASE(3);  // break scans
@@ -1875,7 +1915,9 @@ __device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int
         if (self_in_d && self_break) end = selfpos < end ? selfpos : end;
         if (!best_is_full) {
             const int32_t thr = (int32_t)((uint32_t)b_cnt + (uint32_t)(b_cnt >> 2));  // :4926
-            const int pc = first_count_break(ew, Dm, start, end, S.cnt, thr);
+            const int64_t Tg = thr < kGeBase - 1 ? (int64_t)kGeBase : (int64_t)thr + 1;  // count >= 10 && count > thr
+            const int pc = (S.ge && Tg < kGeBase + kGeRows) ? first_ge_break(ew, Dm, S.ge + (size_t)(Tg - kGeBase) * W, start, end)
+                                                           : first_count_break(ew, Dm, start, end, S.cnt, thr);
             end = pc < end ? pc : end;
         }
         const bool self_in_c = self_in_d && selfpos < end;
@@ -2155,10 +2197,13 @@ __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(4, 
 // workgroups (left at zero); the last one to finish announces completion (PlaceArgs::done_flag).  A kernel of
 // its own so that the throughput kernel's argument block stays as small as it was (measured: the launch
 // path of this runtime is sensitive to it).
+// (WITH_LONG: on the latency path occupancy is nothing — a handful of workgroups — and a shortlist that spans the table must not
+// fall to the wave path: one wavefront sweeping thousands of candidates took 40-60 us per single decision on a churned C3 fleet,
+// the whole of the 49 us p99 under churn of round 3; through the prefix tables it is a few us.)
 __global__ __launch_bounds__(kPlaceBlock) void place_batch_flag_kernel(Snap S, PlaceArgs A, int32_t wpad, uint32_t *done_blocks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    place_block<false>(S, A, wpad, smem, done_blocks);
+    place_block<true>(S, A, wpad, smem, done_blocks);
 }
 
 // One decision whose request rides in the kernel arguments (the latency path's n = 1 call without extra
@@ -2171,7 +2216,7 @@ __global__ __launch_bounds__(kPlaceBlock) void place_single_kernel(Snap S, Place
     __syncthreads();
     A.reqs = &srq;
     A.n = 1;
-    place_block<false>(S, A, wpad, smem);
+    place_block<true>(S, A, wpad, smem);
 }
 
 

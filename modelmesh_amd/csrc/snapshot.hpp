@@ -49,6 +49,10 @@ struct Snap {
     const int32_t *pc;
     const uint64_t *ph;
     const int32_t *nz;
+    // Where the count break (MM.java:4925-4926) can first fire, without a scan: counts do not decrease along the head of the order
+    // (non-full instances of one version stand in count order, PLACEMENT_ORDER :4676) — ctpos[kGeRows] = the end of that
+    // non-decreasing head, ctpos[r] = its first position with count >= kGeBase + r (the end if none).  Null on shard views.
+    const int32_t *ctpos;
 };
 
 // count >= 10 is a fixed clause of the shortlist's count break (MM.java:4925-4926); the other clause,
@@ -264,6 +268,36 @@ __global__ void build_ge_kernel(const int32_t *__restrict__ cnt, int32_t P, int3
     const int pos = w * 64 + lane;
     const uint64_t b = __ballot(pos < P && cnt[pos] >= kGeBase + r);
     if (lane == 0) ge[(size_t)r * W + w] = b;
+}
+
+// Snap::ctpos: one wavefront.  The end of the non-decreasing head of the count column, then per threshold row a binary search
+// in it (lane r: threshold kGeBase + r).
+__global__ __launch_bounds__(64) void build_ctpos_kernel(const int32_t *__restrict__ cnt, int32_t P, int32_t *__restrict__ ctpos)
+{
+    const int lane = threadIdx.x;
+    int mono_end = P;
+    for (int base = 0; base < P; base += 64) {
+        const int p = base + lane;
+        const bool viol = p >= 1 && p < P && cnt[p] < cnt[p - 1];
+        const uint64_t b = __ballot(viol);
+        if (b) {
+            mono_end = base + (__ffsll((unsigned long long)b) - 1);
+            break;
+        }
+    }
+    if (lane < kGeRows) {
+        const int32_t thr = kGeBase + lane;
+        int lo = 0, hi = mono_end;  // first p in [0, mono_end) with cnt[p] >= thr
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cnt[mid] >= thr)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        ctpos[lane] = lo;
+    }
+    if (lane == 0) ctpos[kGeRows] = mono_end;
 }
 
 // rs_bad[p] = pod p's replica set is in the replaced list (MM.java:4769-4770)
