@@ -709,6 +709,16 @@ def secondary_kernels_leg(fleet, solver, device: int, workload: str = "C3", reps
             timed("gate_batch_kernel" + tag, lambda: solver.gates(g, z32, z64, z32, now),
                   int((144 + 8 + 24 + 12 * k_of[g["model"]]).sum()), n, "guarded requests",
                   "request 144 B + model row 24 B + 12 B per entry + result 8 B")
+            # the cache-hit route of one request = its guards + its serve target: ONE launch (mmp_route_batch) for what the two
+            # kernels above do in two (the serve half on the gate requests' models)
+            sr2 = srk.copy()
+            sr2["model"], sr2["self_pod"] = g["model"], g["self_pod"]
+            sr2, counters2 = solver.serve_counters(sr2, in_use, last_used)
+            kk2 = m["n_loaded"][sr2["model"]].astype(np.int64)
+            timed("route_batch_kernel (guards + serve target, one launch)" + tag,
+                  lambda: solver.route(g, sr2, counters2, z32, z64, z32, now),
+                  int((144 + 48 + 24 + 8 + 16 + 12 * k_of[g["model"]] + 16 * kk2).sum()), n, "routed requests",
+                  "both requests 144 + 48 B + model row 24 B + 12 B per entry + 16 B per listed copy's counter + both results 24 B")
 
         per_request_kernels(100_000, "")
         per_request_kernels(800_000, " (800k per launch)")

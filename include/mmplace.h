@@ -495,6 +495,15 @@ int mmp_gate_batch(mmp_ctx *ctx, const mmp_gate_req *reqs, int32_t n, const int3
                    const int64_t *excl_time, int32_t n_excl_pool, const int32_t *explicit_pool,
                    int32_t n_explicit_pool, int64_t now_ms, int64_t in_use_failure_expiry_ms,
                    mmp_gate_out *outs);
+/* The cache-hit route of invokeModel in one call and ONE launch: request i's guards (gate_reqs[i], as mmp_gate_batch) and its
+ * serve target among the model's copies (serve_reqs[i], as mmp_serve_batch; serve_reqs[i].model == gate_reqs[i].model).  The two
+ * request arrays index the SAME (excl_pod, excl_time) pool — cacheHitExcludeTl's MapFilteringSet is one object for goLocal and
+ * for ForwardingLB.getNext (MM.java:3634, :4316) — and the serve requests their counters as in mmp_serve_batch.  Results equal
+ * those of the two separate calls. */
+int mmp_route_batch(mmp_ctx *ctx, const mmp_gate_req *gate_reqs, const mmp_serve_req *serve_reqs, int32_t n,
+                    const mmp_serve_counter *counters, int32_t n_counters, const int32_t *excl_pod, const int64_t *excl_time,
+                    int32_t n_excl, const int32_t *explicit_pool, int32_t n_explicit, int64_t now_ms,
+                    int64_t in_use_failure_expiry_ms, mmp_gate_out *gate_outs, mmp_serve_out *serve_outs);
 
 /* triggerProactiveLoadsForInstanceSubset (MM.java:6616-6747, excludeTypes == null) over the
  * committed snapshot and the loaded model table (models in registry iteration order): which

@@ -78,6 +78,9 @@ final class MmPlace {
     static native int gateBatch(long h, ByteBuffer reqs, int n, ByteBuffer exclPod, ByteBuffer exclTime, int nExcl,
                                 ByteBuffer explicitPool, int nExplicit, long nowMs, long inUseFailureExpiryMs,
                                 ByteBuffer outs);
+    static native int routeBatch(long h, ByteBuffer gateReqs, ByteBuffer serveReqs, int n, ByteBuffer counters, int nCounters,
+                                 ByteBuffer exclPod, ByteBuffer exclTime, int nExcl, ByteBuffer explicitPool, int nExplicit,
+                                 long nowMs, long inUseFailureExpiryMs, ByteBuffer gateOuts, ByteBuffer serveOuts);
     static native int proactivePlan(long h, int defaultModelSizeUnits, long nowMs, int maxOut, ByteBuffer outModel,
                                     ByteBuffer outLastUsed, ByteBuffer info);
     static native int proactivePlanSubset(long h, int partition, ByteBuffer skipModels, int nSkip, int defaultModelSizeUnits,

@@ -273,6 +273,21 @@ JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_gateBatch(JNIEnv *e
                                 inUseFailureExpiryMs, buf<mmp_gate_out>(env, outs)));
 }
 
+// ---- the cache-hit route in one launch: the guards + the serve target of every request (include/mmplace.h: mmp_route_batch)
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_routeBatch(JNIEnv *env, jclass, jlong h, jobject gateReqs,
+                                                                        jobject serveReqs, jint n, jobject counters,
+                                                                        jint nCounters, jobject exclPod, jobject exclTime,
+                                                                        jint nExcl, jobject explicitPool, jint nExplicit,
+                                                                        jlong nowMs, jlong inUseFailureExpiryMs,
+                                                                        jobject gateOuts, jobject serveOuts)
+{
+    return check(env, ctx_of(h),
+                 mmp_route_batch(ctx_of(h), buf<mmp_gate_req>(env, gateReqs), buf<mmp_serve_req>(env, serveReqs), n,
+                                 buf<mmp_serve_counter>(env, counters), nCounters, buf<int32_t>(env, exclPod),
+                                 buf<int64_t>(env, exclTime), nExcl, buf<int32_t>(env, explicitPool), nExplicit, nowMs,
+                                 inUseFailureExpiryMs, buf<mmp_gate_out>(env, gateOuts), buf<mmp_serve_out>(env, serveOuts)));
+}
+
 // ---- rebalancers (MM.java:5636-5871, 6110-6335, 6616-6747, 6959-7147) ---------------------------------
 JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_proactivePlan(JNIEnv *env, jclass, jlong h,
                                                                            jint defaultModelSizeUnits, jlong nowMs,

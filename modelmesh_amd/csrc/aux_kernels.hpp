@@ -30,114 +30,120 @@ struct ServeArgs {
 constexpr int kServePre = 4;
 constexpr int kServeExcl = 4;
 
+// one request (see serve_batch_kernel)
+__device__ __forceinline__ mmp_serve_out serve_eval(const ServeArgs &A, const mmp_serve_req &r)
+{
+    mmp_serve_out o;
+    o.chosen = MMP_NONE;
+    o.pad = 0;
+    o.chosen_load_start = 0;
+    if (r.model >= 0 && r.model < A.n_models) {
+        // level 2: the model row, the request's first counters and exclusions
+        const mmp_model_row m = A.models[r.model];
+        mmp_serve_counter c_pre[kServePre];
+#pragma unroll
+        for (int j = 0; j < kServePre; j++) {
+            c_pre[j].pod = -1;
+            c_pre[j].in_use = 0;
+            c_pre[j].last_used = 0;
+            if (j < r.n_cnt) c_pre[j] = A.counters[r.cnt_off + j];
+        }
+        int32_t x_pod[kServeExcl];
+        int64_t x_time[kServeExcl];
+#pragma unroll
+        for (int x = 0; x < kServeExcl; x++) {
+            x_pod[x] = x < r.n_excl ? A.excl_pod[r.excl_off + x] : -1;
+            x_time[x] = x < r.n_excl ? A.excl_time[r.excl_off + x] : 0;
+        }
+        // level 3: the first copies
+        int32_t p_iid[kServePre];
+        int64_t p_ts[kServePre];
+#pragma unroll
+        for (int e = 0; e < kServePre; e++) {
+            p_iid[e] = e < m.n_loaded ? A.ent_pod[m.ent_off + e] : -1;
+            p_ts[e] = e < m.n_loaded ? A.ent_time[m.ent_off + e] : 0;
+        }
+        const bool exclude_self = r.flags & MMP_SERVE_EXCLUDE_SELF, prefer_self = r.flags & MMP_SERVE_PREFER_SELF;
+        bool seen_self = false;
+        int32_t chosen = -1;
+        int64_t chosen_ts = 0;
+        int32_t mn = INT32_MAX;
+        int64_t lru = INT64_MAX, first_started = INT64_MAX;
+        const int64_t cutoff = (int64_t)((uint64_t)A.now - (uint64_t)r.assume_completed_ms);  // :4350
+        // one copy of the loop body
+        auto visit = [&](int32_t iid, int64_t load_started) {
+            // MapFilteringSet.apply (MM.java:4279-4283)
+            bool filtered = false;
+#pragma unroll
+            for (int x = 0; x < kServeExcl; x++)
+                if (x < r.n_excl && x_pod[x] == iid && (x_time[x] == MMP_ANY_TIME || x_time[x] == load_started)) filtered = true;
+            for (int x = kServeExcl; x < r.n_excl; x++) {
+                const int32_t xp = A.excl_pod[r.excl_off + x];
+                const int64_t xt = A.excl_time[r.excl_off + x];
+                if (xp == iid && (xt == MMP_ANY_TIME || xt == load_started)) filtered = true;
+            }
+            if (filtered) return;
+            bool us = false;
+            if (!seen_self && iid == r.self_pod) {  // :4334-4342
+                seen_self = true;
+                if (exclude_self) return;
+                us = true;
+            }
+            // siMap.get(iid), :4343: the request's counter entry of this instance
+            bool listed = false;
+            int32_t pod_in_use = 0;
+            int64_t pod_last_used = 0;
+#pragma unroll
+            for (int j = 0; j < kServePre; j++)
+                if (j < r.n_cnt && c_pre[j].pod == iid && !listed) {
+                    listed = true;
+                    pod_in_use = c_pre[j].in_use;
+                    pod_last_used = c_pre[j].last_used;
+                }
+            for (int j = kServePre; j < r.n_cnt && !listed; j++) {
+                const mmp_serve_counter cj = A.counters[r.cnt_off + j];
+                if (cj.pod == iid) {
+                    listed = true;
+                    pod_in_use = cj.in_use;
+                    pod_last_used = cj.last_used;
+                }
+            }
+            if (!listed || iid < 0) return;  // sii == null: litelinks does not list the instance
+            if (load_started < cutoff) {  // :4352-4367
+                const int32_t inuse = us ? r.local_in_flight : pod_in_use;
+                if (inuse > mn) return;
+                const int64_t nlu = us ? (prefer_self ? 0 : r.last_invoke_time) : pod_last_used;
+                if (inuse < mn)
+                    mn = inuse;
+                else if (nlu >= lru)
+                    return;
+                chosen = iid;
+                chosen_ts = load_started;
+                lru = nlu;
+            } else if (mn == INT32_MAX && load_started < first_started) {  // :4369-4376
+                chosen = iid;
+                chosen_ts = load_started;
+                first_started = load_started;
+            }
+        };
+#pragma unroll
+        for (int e = 0; e < kServePre; e++)
+            if (e < m.n_loaded) visit(p_iid[e], p_ts[e]);
+        for (int e = kServePre; e < m.n_loaded; e++) visit(A.ent_pod[m.ent_off + e], A.ent_time[m.ent_off + e]);
+        if (chosen >= 0) {
+            o.chosen = (!exclude_self && chosen == r.self_pod) ? MMP_SELF : chosen;  // :4381-4385
+            o.chosen_load_start = chosen_ts;
+        }
+    }
+    return o;
+}
+
 __global__ void serve_batch_kernel(ServeArgs A)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < A.n) {
         const mmp_serve_req r = A.reqs[i];
-        mmp_serve_out o;
-        o.chosen = MMP_NONE;
-        o.pad = 0;
-        o.chosen_load_start = 0;
-        if (r.model >= 0 && r.model < A.n_models) {
-            // level 2: the model row, the request's first counters and exclusions
-            const mmp_model_row m = A.models[r.model];
-            mmp_serve_counter c_pre[kServePre];
-#pragma unroll
-            for (int j = 0; j < kServePre; j++) {
-                c_pre[j].pod = -1;
-                c_pre[j].in_use = 0;
-                c_pre[j].last_used = 0;
-                if (j < r.n_cnt) c_pre[j] = A.counters[r.cnt_off + j];
-            }
-            int32_t x_pod[kServeExcl];
-            int64_t x_time[kServeExcl];
-#pragma unroll
-            for (int x = 0; x < kServeExcl; x++) {
-                x_pod[x] = x < r.n_excl ? A.excl_pod[r.excl_off + x] : -1;
-                x_time[x] = x < r.n_excl ? A.excl_time[r.excl_off + x] : 0;
-            }
-            // level 3: the first copies
-            int32_t p_iid[kServePre];
-            int64_t p_ts[kServePre];
-#pragma unroll
-            for (int e = 0; e < kServePre; e++) {
-                p_iid[e] = e < m.n_loaded ? A.ent_pod[m.ent_off + e] : -1;
-                p_ts[e] = e < m.n_loaded ? A.ent_time[m.ent_off + e] : 0;
-            }
-            const bool exclude_self = r.flags & MMP_SERVE_EXCLUDE_SELF, prefer_self = r.flags & MMP_SERVE_PREFER_SELF;
-            bool seen_self = false;
-            int32_t chosen = -1;
-            int64_t chosen_ts = 0;
-            int32_t mn = INT32_MAX;
-            int64_t lru = INT64_MAX, first_started = INT64_MAX;
-            const int64_t cutoff = (int64_t)((uint64_t)A.now - (uint64_t)r.assume_completed_ms);  // :4350
-            // one copy of the loop body
-            auto visit = [&](int32_t iid, int64_t load_started) {
-                // MapFilteringSet.apply (MM.java:4279-4283)
-                bool filtered = false;
-#pragma unroll
-                for (int x = 0; x < kServeExcl; x++)
-                    if (x < r.n_excl && x_pod[x] == iid && (x_time[x] == MMP_ANY_TIME || x_time[x] == load_started)) filtered = true;
-                for (int x = kServeExcl; x < r.n_excl; x++) {
-                    const int32_t xp = A.excl_pod[r.excl_off + x];
-                    const int64_t xt = A.excl_time[r.excl_off + x];
-                    if (xp == iid && (xt == MMP_ANY_TIME || xt == load_started)) filtered = true;
-                }
-                if (filtered) return;
-                bool us = false;
-                if (!seen_self && iid == r.self_pod) {  // :4334-4342
-                    seen_self = true;
-                    if (exclude_self) return;
-                    us = true;
-                }
-                // siMap.get(iid), :4343: the request's counter entry of this instance
-                bool listed = false;
-                int32_t pod_in_use = 0;
-                int64_t pod_last_used = 0;
-#pragma unroll
-                for (int j = 0; j < kServePre; j++)
-                    if (j < r.n_cnt && c_pre[j].pod == iid && !listed) {
-                        listed = true;
-                        pod_in_use = c_pre[j].in_use;
-                        pod_last_used = c_pre[j].last_used;
-                    }
-                for (int j = kServePre; j < r.n_cnt && !listed; j++) {
-                    const mmp_serve_counter cj = A.counters[r.cnt_off + j];
-                    if (cj.pod == iid) {
-                        listed = true;
-                        pod_in_use = cj.in_use;
-                        pod_last_used = cj.last_used;
-                    }
-                }
-                if (!listed || iid < 0) return;  // sii == null: litelinks does not list the instance
-                if (load_started < cutoff) {  // :4352-4367
-                    const int32_t inuse = us ? r.local_in_flight : pod_in_use;
-                    if (inuse > mn) return;
-                    const int64_t nlu = us ? (prefer_self ? 0 : r.last_invoke_time) : pod_last_used;
-                    if (inuse < mn)
-                        mn = inuse;
-                    else if (nlu >= lru)
-                        return;
-                    chosen = iid;
-                    chosen_ts = load_started;
-                    lru = nlu;
-                } else if (mn == INT32_MAX && load_started < first_started) {  // :4369-4376
-                    chosen = iid;
-                    chosen_ts = load_started;
-                    first_started = load_started;
-                }
-            };
-#pragma unroll
-            for (int e = 0; e < kServePre; e++)
-                if (e < m.n_loaded) visit(p_iid[e], p_ts[e]);
-            for (int e = kServePre; e < m.n_loaded; e++) visit(A.ent_pod[m.ent_off + e], A.ent_time[m.ent_off + e]);
-            if (chosen >= 0) {
-                o.chosen = (!exclude_self && chosen == r.self_pod) ? MMP_SELF : chosen;  // :4381-4385
-                o.chosen_load_start = chosen_ts;
-            }
-        }
-        A.outs[i] = o;
+        A.outs[i] = serve_eval(A, r);
     }
     announce_done(A.done);
 }

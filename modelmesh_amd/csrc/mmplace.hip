@@ -173,6 +173,7 @@ struct mmp_ctx {
     size_t lds_limit = 64 * 1024;    // LDS a workgroup may use on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
     // a registry event's in-place rewrite is enqueued under the state lock and finishes after it: kernels that read the registry
     // from other streams are ordered behind reg_event while reg_pending (order_after_registry)
+    DevBuf rt_sreqs, rt_souts, rt_cnt;  // mmp_route_batch: the serve half's staging (the gate half uses s_reqs / s_outs / s_a / s_c / s_d)
     hipEvent_t reg_event = nullptr;
     std::atomic<bool> reg_pending{false};
     std::atomic<size_t> lds_granted{48 * 1024};  // dynamic LDS the place kernels may be launched with so far
@@ -652,7 +653,7 @@ void mmp_destroy(mmp_ctx *c)
                       &c->models, &c->ent_pod, &c->ent_time, &c->c_seg,
                       &c->c_lu, &c->c_wt, &c->c_cap, &c->s_reqs, &c->s_outs, &c->s_extra, &c->s_a, &c->s_b,
                       &c->s_c, &c->s_d, &c->r_ps, &c->r_counts, &c->r_keys, &c->r_vals, &c->r_keys2, &c->r_vals2,
-                      &c->r_tmp, &c->r_out_model, &c->r_out_lu, &c->k_cap, &c->k_wsize, &c->k_oldest, &c->k_ubm, &c->k_ops, &c->k_order,
+                      &c->r_tmp, &c->r_out_model, &c->r_out_lu, &c->rt_sreqs, &c->rt_souts, &c->rt_cnt, &c->k_cap, &c->k_wsize, &c->k_oldest, &c->k_ubm, &c->k_ops, &c->k_order,
                       &c->k_opoff, &c->k_outs, &c->k_ev, &c->k_evoff, &c->idtab_hash, &c->idtab_val, &c->tytab_hash,
                       &c->tytab_val, &c->j_buf, &c->j_off, &c->j_rows, &c->j_aux, &c->j_status, &c->j_cnt, &c->j_offs, &c->j_tmp_pod,
                       &c->j_tmp_time, &c->j_scan_tmp, &c->rk_rows, &c->rk_idx, &c->rk_tmp, &c->u_idx, &c->u_rows, &c->u_cnt, &c->u_offs, &c->u_tmp, &c->f_flags[0], &c->f_flags[1], &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp, &c->f_cnt[0], &c->f_cnt[1],
@@ -3430,6 +3431,79 @@ try {
     return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_gate_batch");
 } catch (const std::exception &e) {
     return fail(c, MMP_EHIP, "%s: %s", "mmp_gate_batch", e.what());
+}
+
+int mmp_route_batch(mmp_ctx *c, const mmp_gate_req *greqs, const mmp_serve_req *sreqs, int32_t n, const mmp_serve_counter *counters,
+                    int32_t n_counters, const int32_t *excl_pod, const int64_t *excl_time, int32_t n_excl,
+                    const int32_t *explicit_pool, int32_t n_explicit, int64_t now, int64_t in_use_expiry, mmp_gate_out *gouts,
+                    mmp_serve_out *souts)
+try {
+    if (!c || n < 0 || n_counters < 0 || n_excl < 0 || n_explicit < 0 || (n > 0 && (!greqs || !sreqs || !gouts || !souts)) ||
+        (n_counters > 0 && !counters) || (n_excl > 0 && (!excl_pod || !excl_time)) || (n_explicit > 0 && !explicit_pool))
+        return fail(c, MMP_EINVAL, "mmp_route_batch: bad argument");
+    for (int32_t i = 0; i < n; i++) {
+        const mmp_gate_req &g = greqs[i];
+        const mmp_serve_req &r = sreqs[i];
+        if (g.n_excl < 0 || g.excl_off < 0 || (int64_t)g.excl_off + g.n_excl > n_excl || g.n_explicit < 0 || g.explicit_off < 0 ||
+            (int64_t)g.explicit_off + g.n_explicit > n_explicit || r.n_excl < 0 || r.excl_off < 0 ||
+            (int64_t)r.excl_off + r.n_excl > n_excl || r.n_cnt < 0 || r.cnt_off < 0 || (int64_t)r.cnt_off + r.n_cnt > n_counters)
+            return fail(c, MMP_EINVAL, "mmp_route_batch: request %d pool range out of bounds", i);
+        if (g.model != r.model) return fail(c, MMP_EINVAL, "mmp_route_batch: request %d names two models", i);
+    }
+    std::lock_guard<std::mutex> gb(c->batch_mu);  // (as mmp_gate_batch's batch path: owns c->stream and the scratch)
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    if (n == 0) return MMP_OK;
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    hipStream_t st = c->stream;
+    HIP_TRY(c, c->s_reqs.ensure((size_t)n * sizeof(mmp_gate_req)));
+    HIP_TRY(c, c->s_outs.ensure((size_t)n * sizeof(mmp_gate_out)));
+    HIP_TRY(c, c->rt_sreqs.ensure((size_t)n * sizeof(mmp_serve_req)));
+    HIP_TRY(c, c->rt_souts.ensure((size_t)n * sizeof(mmp_serve_out)));
+    HIP_TRY(c, c->rt_cnt.ensure((size_t)std::max(n_counters, 1) * sizeof(mmp_serve_counter)));
+    HIP_TRY(c, c->s_a.ensure((size_t)std::max(n_explicit, 1) * 4));
+    HIP_TRY(c, c->s_c.ensure((size_t)std::max(n_excl, 1) * 4));
+    HIP_TRY(c, c->s_d.ensure((size_t)std::max(n_excl, 1) * 8));
+    HIP_TRY(c, hipMemcpyAsync(c->s_reqs.p, greqs, (size_t)n * sizeof(mmp_gate_req), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->rt_sreqs.p, sreqs, (size_t)n * sizeof(mmp_serve_req), hipMemcpyHostToDevice, st));
+    if (n_counters) HIP_TRY(c, hipMemcpyAsync(c->rt_cnt.p, counters, (size_t)n_counters * sizeof(mmp_serve_counter), hipMemcpyHostToDevice, st));
+    if (n_explicit) HIP_TRY(c, hipMemcpyAsync(c->s_a.p, explicit_pool, (size_t)n_explicit * 4, hipMemcpyHostToDevice, st));
+    if (n_excl) {
+        HIP_TRY(c, hipMemcpyAsync(c->s_c.p, excl_pod, (size_t)n_excl * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(c->s_d.p, excl_time, (size_t)n_excl * 8, hipMemcpyHostToDevice, st));
+    }
+    GateArgs G = gate_args(c, n, now, in_use_expiry);
+    G.reqs = c->s_reqs.as<mmp_gate_req>();
+    G.excl_pod = c->s_c.as<int32_t>();
+    G.excl_time = c->s_d.as<int64_t>();
+    G.explicit_pool = c->s_a.as<int32_t>();
+    G.outs = c->s_outs.as<mmp_gate_out>();
+    ServeArgs S{};
+    S.reqs = c->rt_sreqs.as<mmp_serve_req>();
+    S.models = c->models.as<mmp_model_row>();
+    S.ent_pod = c->ent_pod.as<int32_t>();
+    S.ent_time = c->ent_time.as<int64_t>();
+    S.counters = c->rt_cnt.as<mmp_serve_counter>();
+    S.excl_pod = c->s_c.as<int32_t>();
+    S.excl_time = c->s_d.as<int64_t>();
+    S.outs = c->rt_souts.as<mmp_serve_out>();
+    S.n = n;
+    S.n_models = c->n_models;
+    S.P = c->snap.P;
+    S.now = now;
+    S.done = DoneFlag{nullptr, nullptr, 0};
+    KT_BEGIN(c, st);
+    hipLaunchKernelGGL(route_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, G, S);
+    KT_END(c, st);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(gouts, c->s_outs.p, (size_t)n * sizeof(mmp_gate_out), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(souts, c->rt_souts.p, (size_t)n * sizeof(mmp_serve_out), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    kt_collect(c);
+    return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_route_batch");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_route_batch", e.what());
 }
 
 int mmp_proactive_plan(mmp_ctx *c, int32_t default_units, int64_t now, int32_t max_out, int32_t *out_model,

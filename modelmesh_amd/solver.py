@@ -420,6 +420,26 @@ class Solver:
                                          int(now), int(in_use_failure_expiry_ms), ptr(outs)))
         return outs
 
+    def route(self, gate_reqs, serve_reqs, counters, excl_pod, excl_time, explicit_pool, now, in_use_failure_expiry_ms=450_000):
+        """The cache-hit route in one launch (mmp_route_batch): -> (gate outs, serve outs)."""
+        from ._lib import GATE_OUT, GATE_REQ, SERVE_COUNTER, SERVE_OUT, SERVE_REQ
+        gate_reqs = np.ascontiguousarray(gate_reqs, dtype=GATE_REQ)
+        serve_reqs = np.ascontiguousarray(serve_reqs, dtype=SERVE_REQ)
+        counters = np.ascontiguousarray(counters, dtype=SERVE_COUNTER)
+        excl_pod = np.ascontiguousarray(excl_pod, dtype=np.int32)
+        excl_time = np.ascontiguousarray(excl_time, dtype=np.int64)
+        explicit_pool = np.ascontiguousarray(explicit_pool, dtype=np.int32)
+        n = len(gate_reqs)
+        gouts = np.zeros(n, dtype=GATE_OUT)
+        souts = np.zeros(n, dtype=SERVE_OUT)
+        self._ck(self.lib.mmp_route_batch(self.h, ptr(gate_reqs) if n else None, ptr(serve_reqs) if n else None, n,
+                                          ptr(counters) if len(counters) else None, len(counters),
+                                          ptr(excl_pod) if len(excl_pod) else None, ptr(excl_time) if len(excl_time) else None,
+                                          len(excl_pod), ptr(explicit_pool) if len(explicit_pool) else None, len(explicit_pool),
+                                          C.c_int64(int(now)), C.c_int64(int(in_use_failure_expiry_ms)),
+                                          ptr(gouts) if n else None, ptr(souts) if n else None))
+        return gouts, souts
+
     def proactive_plan(self, default_model_size_units: int, now: int, max_out: int, partition: int = -1, skip_models=None):
         """a17: (models, last_used, info) the leader would proactively load, MRU first; partition >= 0: for that
         ProhibitedTypeSet partition only (one reaper call per partition when type constraints exist)."""
