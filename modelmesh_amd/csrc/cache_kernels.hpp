@@ -37,8 +37,8 @@ struct ReplayArgs {
     int64_t *weighted_size;    // [n_caches]
     int64_t *oldest;           // [n_caches] the map's `oldestTime` FIELD (clhm :1120): refreshed by afterWrite / the read drain only
     mmp_ubm_state *ubm;        // [n_caches]
-    const mmp_cache_op *ops;   // all operations of the call, caller order
-    const int32_t *op_order;   // operation indices grouped by cache, caller order within a cache
+    const mmp_cache_op *ops;   // all operations of the call GROUPED BY CACHE (caller order within a cache): one load per operation
+    const int32_t *op_order;   // the caller's index of each grouped operation (where its result goes)
     const int32_t *op_off;     // [n_caches+1] ranges of op_order
     mmp_cache_op_out *outs;    // by caller operation index
     int32_t *evicted;          // evicted keys; cache c writes from ev_off[c]
@@ -47,6 +47,19 @@ struct ReplayArgs {
     int32_t tile;              // LDS slots per column
     int64_t now;
 };
+
+// A cache is replayed by a TEAM of TW lanes (TW = 64: the whole wavefront; 8 or 16: several small caches per wavefront, each
+// with its own slice of the LDS tile).  Control flow is uniform inside a team, so a ballot taken anywhere below has all of the
+// team's lanes active; lanes of other teams may be elsewhere and simply do not contribute.
+template <int TW>
+__device__ __forceinline__ int team_lane() { return lane_id() & (TW - 1); }
+template <int TW>
+__device__ __forceinline__ uint64_t team_ballot(bool p)
+{
+    const uint64_t b = __ballot(p);
+    if (TW == 64) return b;
+    return (b >> (lane_id() & ~(TW - 1))) & ((1ull << (TW & 63)) - 1ull);
+}
 
 struct Deque {
     int64_t *lu;
@@ -64,12 +77,13 @@ struct Deque {
     int nev;
 };
 
+template <int TW>
 __device__ __forceinline__ int dq_find(const Deque &D, int32_t k)
 {
-    const int lane = lane_id();
-    for (int base = 0; base < D.n; base += 64) {
+    const int lane = team_lane<TW>();
+    for (int base = 0; base < D.n; base += TW) {
         const int i = base + lane;
-        const uint64_t b = __ballot(i < D.n && D.key[D.head + i] == k);
+        const uint64_t b = team_ballot<TW>(i < D.n && D.key[D.head + i] == k);
         if (b) return base + (__ffsll((unsigned long long)b) - 1);
     }
     return -1;
@@ -77,21 +91,22 @@ __device__ __forceinline__ int dq_find(const Deque &D, int32_t k)
 
 // LinkedDeque.insert, LinkedDeque.java:259-288: walk from the tail to the first node with
 // lastUsed <= ts and link the new node after it.  Returns the position.
+template <int TW>
 __device__ __forceinline__ int dq_insert(Deque &D, int64_t ts, int32_t w, int32_t k)
 {
-    const int lane = lane_id();
+    const int lane = team_lane<TW>();
     int l = -1;
-    for (int base = D.n > 0 ? ((D.n - 1) >> 6) << 6 : -1; base >= 0; base -= 64) {
+    for (int base = D.n > 0 ? (D.n - 1) & ~(TW - 1) : -1; base >= 0; base -= TW) {
         const int i = base + lane;
-        const uint64_t b = __ballot(i < D.n && D.lu[D.head + i] <= ts);
+        const uint64_t b = team_ballot<TW>(i < D.n && D.lu[D.head + i] <= ts);
         if (b) {
             l = base + 63 - __clzll((unsigned long long)b);
             break;
         }
     }
     const int pos = l + 1;
-    for (int hi = D.n; hi > pos; hi -= 64) {  // shift [pos, n) one slot towards the tail, tail chunk first
-        const int lo = hi - 64 > pos ? hi - 64 : pos;
+    for (int hi = D.n; hi > pos; hi -= TW) {  // shift [pos, n) one slot towards the tail, tail chunk first
+        const int lo = hi - TW > pos ? hi - TW : pos;
         const int i = lo + lane;
         const bool v = i < hi;
         int64_t a = 0;
@@ -122,9 +137,10 @@ __device__ __forceinline__ int dq_insert(Deque &D, int64_t ts, int32_t w, int32_
 // `pop`: the head leaves by moving the window (eviction, removal: the slot is never needed again).  A node that is unlinked to be
 // re-inserted (reposition) must NOT move the window: head + n would grow by one per repositioned head and walk off the tile the
 // host sized as entries + inserts
+template <int TW>
 __device__ __forceinline__ void dq_unlink(Deque &D, int i, int64_t &ts, int32_t &w, int32_t &k, bool pop = true)
 {
-    const int lane = lane_id();
+    const int lane = team_lane<TW>();
     ts = D.lu[D.head + i];
     w = D.wt[D.head + i];
     k = D.key[D.head + i];
@@ -134,7 +150,7 @@ __device__ __forceinline__ void dq_unlink(Deque &D, int i, int64_t &ts, int32_t 
         D.n--;
         return;
     }
-    for (int lo = i + 1; lo < D.n; lo += 64) {  // shift (i, n) one slot towards the head, head chunk first
+    for (int lo = i + 1; lo < D.n; lo += TW) {  // shift (i, n) one slot towards the head, head chunk first
         const int idx = lo + lane;
         const bool v = idx < D.n;
         int64_t a = 0;
@@ -156,16 +172,18 @@ __device__ __forceinline__ void dq_unlink(Deque &D, int i, int64_t &ts, int32_t 
 }
 
 // Node.touch, clhm :1357-1360
+template <int TW>
 __device__ __forceinline__ void dq_touch(Deque &D, int i, int64_t time, int64_t now)
 {
     const int64_t old = D.lu[D.head + i];
     const int64_t nv = time == 0 ? now : (old > time ? old : time);
     wave_sync();
-    if (lane_id() == 0) D.lu[D.head + i] = nv;
+    if (team_lane<TW>() == 0) D.lu[D.head + i] = nv;
     wave_sync();
 }
 
 // LinkedDeque.reposition, LinkedDeque.java:243-256
+template <int TW>
 __device__ __forceinline__ void dq_reposition(Deque &D, int i)
 {
     const int64_t lu = D.lu[D.head + i];
@@ -174,50 +192,53 @@ __device__ __forceinline__ void dq_reposition(Deque &D, int i)
     }
     int64_t ts;
     int32_t w, k;
-    dq_unlink(D, i, ts, w, k, false);
-    dq_insert(D, ts, w, k);
+    dq_unlink<TW>(D, i, ts, w, k, false);
+    dq_insert<TW>(D, ts, w, k);
 }
 
+template <int TW>
 __device__ __forceinline__ void dq_set_wt(Deque &D, int i, int32_t w)
 {
     wave_sync();
-    if (lane_id() == 0) D.wt[D.head + i] = w;
+    if (team_lane<TW>() == 0) D.wt[D.head + i] = w;
     wave_sync();
 }
 
 // updateOldestTime, clhm :1129-1133
 __device__ __forceinline__ void dq_refresh_oldest(Deque &D) { D.oldest = D.n ? D.lu[D.head] : -1; }
 
+template <int TW>
 __device__ __forceinline__ void record_evicted(Deque &D, int32_t k)
 {
-    if (lane_id() == 0) D.ev[D.nev] = k;
+    if (team_lane<TW>() == 0) D.ev[D.nev] = k;
     D.nev++;
 }
 
 // evict(), clhm :329-352 (makeDead subtracts |weight|, :566-575).  Plain caches record the victims
 // directly; with a manager they go onto the pending LIFO, oldest on top.
+template <int TW>
 __device__ __forceinline__ void dq_evict(Deque &D, bool managed)
 {
     const int first = D.sp;
     while (D.wsize > D.cap && D.n > 0) {
         int64_t ts;
         int32_t w, k;
-        dq_unlink(D, 0, ts, w, k);
+        dq_unlink<TW>(D, 0, ts, w, k);
         D.wsize -= w < 0 ? -(int64_t)w : (int64_t)w;
         if (managed) {
-            if (lane_id() == 0) {
+            if (team_lane<TW>() == 0) {
                 D.stk_key[D.sp] = k;
                 D.stk_wt[D.sp] = w;
             }
             D.sp++;
         } else
-            record_evicted(D, k);
+            record_evicted<TW>(D, k);
     }
     if (managed && D.sp - first > 1) {  // reverse the new run so the oldest victim is popped first
         wave_sync();
         const int cnt = D.sp - first;
-        for (int base = 0; base < cnt / 2; base += 64) {
-            const int i = base + lane_id();
+        for (int base = 0; base < cnt / 2; base += TW) {
+            const int i = base + team_lane<TW>();
             const bool v = i < cnt / 2;
             int32_t k1 = 0, w1 = 0, k2 = 0, w2 = 0;
             if (v) {
@@ -240,19 +261,21 @@ __device__ __forceinline__ void dq_evict(Deque &D, bool managed)
 }
 
 // CacheEntry.updateWeightLocked -> replaceQuietly -> UpdateTask(quiet), without running the listener
+template <int TW>
 __device__ __forceinline__ void ubm_set_weight_nodrain(Deque &D, int32_t k, int32_t w)
 {
-    const int i = dq_find(D, k);
+    const int i = dq_find<TW>(D, k);
     if (i < 0) return;
     const int32_t diff = (int32_t)((uint32_t)w - (uint32_t)D.wt[D.head + i]);
     if (diff == 0) return;
-    dq_set_wt(D, i, w);
+    dq_set_wt<TW>(D, i, w);
     D.wsize += diff;
-    dq_evict(D, true);
+    dq_evict<TW>(D, true);
     dq_refresh_oldest(D);  // afterWrite(UpdateTask)
 }
 
 // adjustAggregateUnloadingWeight, ModelCacheUnloadBufManager.java:375-392 (listener not yet run)
+template <int TW>
 __device__ __forceinline__ void ubm_adjust_agg_nodrain(Deque &D, int32_t delta)
 {
     if (delta == 0) return;
@@ -264,32 +287,35 @@ __device__ __forceinline__ void ubm_adjust_agg_nodrain(Deque &D, int32_t delta)
         const int32_t cap = D.cap > INT32_MAX ? INT32_MAX : (int32_t)D.cap;
         if (cap < nw) nw = cap;
     }
-    ubm_set_weight_nodrain(D, MMP_UNLOADBUF_KEY_C, nw);
+    ubm_set_weight_nodrain<TW>(D, MMP_UNLOADBUF_KEY_C, nw);
 }
 
 // the eviction listener: ModelMesh.onEviction -> entryRemoved (:311-316) per victim, depth first
+template <int TW>
 __device__ __forceinline__ void ubm_drain(Deque &D)
 {
     while (D.sp > 0) {
         D.sp--;
         const int32_t k = D.stk_key[D.sp], w = D.stk_wt[D.sp];
         wave_sync();
-        record_evicted(D, k);
+        record_evicted<TW>(D, k);
         D.occ -= w;
-        ubm_adjust_agg_nodrain(D, w);
+        ubm_adjust_agg_nodrain<TW>(D, w);
     }
 }
 
+template <int TW>
 __device__ __forceinline__ void ubm_adjust_agg(Deque &D, int32_t delta)
 {
-    ubm_adjust_agg_nodrain(D, delta);
-    ubm_drain(D);
+    ubm_adjust_agg_nodrain<TW>(D, delta);
+    ubm_drain<TW>(D);
 }
 
+template <int TW>
 __device__ __forceinline__ void ubm_set_weight(Deque &D, int32_t k, int32_t w)
 {
-    ubm_set_weight_nodrain(D, k, w);
-    ubm_drain(D);
+    ubm_set_weight_nodrain<TW>(D, k, w);
+    ubm_drain<TW>(D);
 }
 
 // cacheSpaceIsReady, :395-402
@@ -301,6 +327,7 @@ __device__ __forceinline__ bool ubm_space_ready(const Deque &D, int32_t required
 }
 
 // payDownDeficitAndNotifyWaiters, :351-366
+template <int TW>
 __device__ __forceinline__ void ubm_pay_down(Deque &D, int32_t weight, bool release)
 {
     const int32_t reduction = weight < D.deficit ? weight : D.deficit;
@@ -308,7 +335,7 @@ __device__ __forceinline__ void ubm_pay_down(Deque &D, int32_t weight, bool rele
         D.deficit -= reduction;
         weight -= reduction;
     }
-    ubm_adjust_agg(D, release ? -weight : reduction);
+    ubm_adjust_agg<TW>(D, release ? -weight : reduction);
 }
 
 // cacheRemaining, :340-342
@@ -318,94 +345,95 @@ __device__ __forceinline__ int32_t ubm_cache_remaining(const Deque &D)
     return r > INT32_MAX ? INT32_MAX : (int32_t)r;
 }
 
+template <int TW>
 __device__ __forceinline__ int32_t apply_op(Deque &D, const mmp_cache_op &o, int64_t now)
 {
     switch (o.op) {
     case MMP_COP_PUT_IF_ABSENT: {  // clhm :804-834, AddTask :590-611
-        const int i = dq_find(D, o.key);
+        const int i = dq_find<TW>(D, o.key);
         if (i >= 0) {
-            dq_touch(D, i, o.time, now);
-            dq_reposition(D, i);
+            dq_touch<TW>(D, i, o.time, now);
+            dq_reposition<TW>(D, i);
             dq_refresh_oldest(D);  // the reader drains its own read buffer: tryToDrainBuffers :458-469
             return 0;
         }
         D.wsize += o.arg;
-        dq_insert(D, o.time == 0 ? now : o.time, o.arg, o.key);
-        dq_evict(D, false);
+        dq_insert<TW>(D, o.time == 0 ? now : o.time, o.arg, o.key);
+        dq_evict<TW>(D, false);
         dq_refresh_oldest(D);
         return 1;
     }
     case MMP_COP_GET: {  // clhm :726-733, applyRead :503-521
-        const int i = dq_find(D, o.key);
+        const int i = dq_find<TW>(D, o.key);
         if (i < 0) return 0;
-        dq_touch(D, i, o.time, now);
-        dq_reposition(D, i);
+        dq_touch<TW>(D, i, o.time, now);
+        dq_reposition<TW>(D, i);
         dq_refresh_oldest(D);
         return 1;
     }
     case MMP_COP_UPDATE_WEIGHT: {  // clhm :902-985, UpdateTask :629-652; time -1 = quiet
-        const int i = dq_find(D, o.key);
+        const int i = dq_find<TW>(D, o.key);
         if (i < 0) return 0;
         const int32_t diff = (int32_t)((uint32_t)o.arg - (uint32_t)D.wt[D.head + i]);
-        dq_set_wt(D, i, o.arg);
+        dq_set_wt<TW>(D, i, o.arg);
         if (diff == 0) {
             if (o.time >= 0) {
-                dq_touch(D, i, o.time, now);
-                dq_reposition(D, i);
+                dq_touch<TW>(D, i, o.time, now);
+                dq_reposition<TW>(D, i);
                 dq_refresh_oldest(D);
             }
             return 1;
         }
         D.wsize += diff;
         if (o.time >= 0 && o.time != D.lu[D.head + i]) {
-            dq_touch(D, i, o.time, now);
-            dq_reposition(D, i);
+            dq_touch<TW>(D, i, o.time, now);
+            dq_reposition<TW>(D, i);
         }
-        dq_evict(D, false);
+        dq_evict<TW>(D, false);
         dq_refresh_oldest(D);
         return 1;
     }
     case MMP_COP_REMOVE: {  // clhm :861-870, RemovalTask :614-627
-        const int i = dq_find(D, o.key);
+        const int i = dq_find<TW>(D, o.key);
         if (i < 0) return 0;
         int64_t ts;
         int32_t w, k;
-        dq_unlink(D, i, ts, w, k);
+        dq_unlink<TW>(D, i, ts, w, k);
         D.wsize -= w < 0 ? -(int64_t)w : (int64_t)w;
         dq_refresh_oldest(D);
         return 1;
     }
     case MMP_COP_UBM_INSERT_NEW_ENTRY: {  // :130-145
-        ubm_adjust_agg(D, -o.arg);
-        const int i = dq_find(D, o.key);
+        ubm_adjust_agg<TW>(D, -o.arg);
+        const int i = dq_find<TW>(D, o.key);
         if (i >= 0) {
-            dq_touch(D, i, o.time, now);
-            dq_reposition(D, i);
+            dq_touch<TW>(D, i, o.time, now);
+            dq_reposition<TW>(D, i);
             dq_refresh_oldest(D);
-            ubm_adjust_agg(D, o.arg);
+            ubm_adjust_agg<TW>(D, o.arg);
             return 0;
         }
         D.wsize += o.arg;
-        dq_insert(D, o.time == 0 ? now : o.time, o.arg, o.key);
+        dq_insert<TW>(D, o.time == 0 ? now : o.time, o.arg, o.key);
         D.occ += o.arg;
-        dq_evict(D, true);
+        dq_evict<TW>(D, true);
         dq_refresh_oldest(D);
-        ubm_drain(D);
+        ubm_drain<TW>(D);
         return 1;
     }
     case MMP_COP_UBM_ADJUST_SPACE_REQUEST: {  // adjustNewEntrySpaceRequest, :152-166
-        const int i = dq_find(D, o.key);
+        const int i = dq_find<TW>(D, o.key);
         if (i < 0) return 0;
         const int32_t nw = (int32_t)((uint32_t)D.wt[D.head + i] + (uint32_t)o.arg);
         D.occ += o.arg;
-        ubm_adjust_agg(D, -o.arg);
-        ubm_set_weight(D, o.key, nw);
+        ubm_adjust_agg<TW>(D, -o.arg);
+        ubm_set_weight<TW>(D, o.key, nw);
         return 1;
     }
     case MMP_COP_UBM_SPACE_IS_READY: return ubm_space_ready(D, o.arg) ? 1 : 0;
     case MMP_COP_UBM_CLAIM_SPACE: {  // claimRequestedSpaceIfReady, :190-202
         if (!ubm_space_ready(D, o.arg)) return 0;
-        ubm_adjust_agg(D, o.arg);
+        ubm_adjust_agg<TW>(D, o.arg);
         return 1;
     }
     case MMP_COP_UBM_ADJUST_AFTER_LOAD: {  // adjustWeightAfterLoad, :224-246
@@ -414,61 +442,61 @@ __device__ __forceinline__ int32_t apply_op(Deque &D, const mmp_cache_op &o, int
         if (delta > 0) {
             const int32_t deficit = (int32_t)((uint32_t)delta - (uint32_t)ubm_cache_remaining(D));
             if (deficit > 0) {
-                ubm_adjust_agg(D, -deficit);
+                ubm_adjust_agg<TW>(D, -deficit);
                 D.deficit += deficit;
             }
         }
         D.occ += delta;
-        const int i = dq_find(D, o.key);
-        if (i >= 0) ubm_set_weight(D, o.key, (int32_t)((uint32_t)D.wt[D.head + i] + (uint32_t)delta));
-        if (delta < 0) ubm_pay_down(D, -delta, false);
+        const int i = dq_find<TW>(D, o.key);
+        if (i >= 0) ubm_set_weight<TW>(D, o.key, (int32_t)((uint32_t)D.wt[D.head + i] + (uint32_t)delta));
+        if (delta < 0) ubm_pay_down<TW>(D, -delta, false);
         return i >= 0 ? 1 : 0;
     }
     case MMP_COP_UBM_UNLOAD_COMPLETE: {  // :318-338
         if (o.flag) {
-            ubm_pay_down(D, o.arg, true);
+            ubm_pay_down<TW>(D, o.arg, true);
             return 1;
         }
         const int64_t cap = D.cap;
-        ubm_adjust_agg(D, -o.arg);
+        ubm_adjust_agg<TW>(D, -o.arg);
         D.cap = cap - o.arg > 1 ? cap - o.arg : 1;
-        dq_evict(D, true);  // setCapacity evicts and notifies under the lock, clhm :305-316 — and does NOT updateOldestTime()
-        ubm_drain(D);
+        dq_evict<TW>(D, true);  // setCapacity evicts and notifies under the lock, clhm :305-316 — and does NOT updateOldestTime()
+        ubm_drain<TW>(D);
         return 0;
     }
     case MMP_COP_UBM_REMOVE_ENTRY: {  // removeEntry :281-298 + entryRemoved :311-316; result = weight or -1
-        const int i = dq_find(D, o.key);
+        const int i = dq_find<TW>(D, o.key);
         if (i < 0) return -1;
         int64_t ts;
         int32_t w, k;
-        dq_unlink(D, i, ts, w, k);
+        dq_unlink<TW>(D, i, ts, w, k);
         D.wsize -= w < 0 ? -(int64_t)w : (int64_t)w;
         dq_refresh_oldest(D);
         D.occ -= w;
-        ubm_adjust_agg(D, w);
+        ubm_adjust_agg<TW>(D, w);
         return w;
     }
     case MMP_COP_UBM_DISCARD_FAILED: {  // discardFailedEntry, :343-349
         D.occ -= o.arg;
-        ubm_pay_down(D, o.arg, false);
+        ubm_pay_down<TW>(D, o.arg, false);
         return 1;
     }
     case MMP_COP_UBM_INSERT_FAILED_PLACEHOLDER: {  // insertFailedPlaceholderEntry, :250-274
         const int32_t deficit = (int32_t)((uint32_t)o.arg - (uint32_t)ubm_cache_remaining(D));
-        if (deficit > 0) ubm_adjust_agg(D, -deficit);
-        const int i = dq_find(D, o.key);
+        if (deficit > 0) ubm_adjust_agg<TW>(D, -deficit);
+        const int i = dq_find<TW>(D, o.key);
         if (i >= 0) {
-            dq_touch(D, i, o.time, now);
-            dq_reposition(D, i);
+            dq_touch<TW>(D, i, o.time, now);
+            dq_reposition<TW>(D, i);
             dq_refresh_oldest(D);
-            if (deficit > 0) ubm_adjust_agg(D, deficit);
+            if (deficit > 0) ubm_adjust_agg<TW>(D, deficit);
             return 0;
         }
         D.wsize += o.arg;
-        dq_insert(D, o.time == 0 ? now : o.time, o.arg, o.key);
-        dq_evict(D, true);
+        dq_insert<TW>(D, o.time == 0 ? now : o.time, o.arg, o.key);
+        dq_evict<TW>(D, true);
         dq_refresh_oldest(D);
-        ubm_drain(D);
+        ubm_drain<TW>(D);
         D.occ += o.arg;
         if (deficit > 0) D.deficit += deficit;
         return 1;
@@ -477,15 +505,22 @@ __device__ __forceinline__ int32_t apply_op(Deque &D, const mmp_cache_op &o, int
     }
 }
 
-__global__ __launch_bounds__(64) void cache_replay_kernel(ReplayArgs A)
+// One launch per team width: `ids` lists the caches this launch replays (the host sorts them by the deque slots they need:
+// small caches to 8- or 16-lane teams, 8 or 4 caches per wavefront; caches above kTeam16Slots to a wavefront each).
+constexpr int kTeam8Slots = 48, kTeam16Slots = 160;
+
+template <int TW>
+__global__ __launch_bounds__(64) void cache_replay_kernel(ReplayArgs A, const int32_t *__restrict__ ids, int32_t n_ids)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int c = blockIdx.x;
-    if (c >= A.n_caches) return;
-    const int lane = lane_id();
+    constexpr int kTeams = 64 / TW;
+    const int team = threadIdx.x / TW, which = blockIdx.x * kTeams + team;
+    if (which >= n_ids) return;
+    const int c = ids ? ids[which] : which;  // (null: every cache of the store, in order)
+    const int lane = team_lane<TW>();
     Deque D;
-    D.lu = reinterpret_cast<int64_t *>(smem);
-    D.wt = reinterpret_cast<int32_t *>(D.lu + A.tile);
+    D.lu = reinterpret_cast<int64_t *>(smem) + (size_t)team * A.tile;  // columns of all teams side by side: 8-byte column first
+    D.wt = reinterpret_cast<int32_t *>(reinterpret_cast<int64_t *>(smem) + (size_t)kTeams * A.tile) + (size_t)team * 4 * A.tile;
     D.key = D.wt + A.tile;
     D.stk_key = D.key + A.tile;
     D.stk_wt = D.stk_key + A.tile;
@@ -495,7 +530,7 @@ __global__ __launch_bounds__(64) void cache_replay_kernel(ReplayArgs A)
     const int so = A.src.off[c], dn = A.dst.off[c];
     const int o0 = A.op_off[c], o1 = A.op_off[c + 1];
     if (o0 == o1) {  // untouched cache: just move it into the new layout
-        for (int i = lane; i < D.n; i += 64) {
+        for (int i = lane; i < D.n; i += TW) {
             A.dst.lu[dn + i] = A.src.lu[so + i];
             A.dst.wt[dn + i] = A.src.wt[so + i];
             A.dst.key[dn + i] = A.src.key[so + i];
@@ -503,7 +538,7 @@ __global__ __launch_bounds__(64) void cache_replay_kernel(ReplayArgs A)
         if (lane == 0) A.dst.n[c] = D.n;
         return;
     }
-    for (int i = lane; i < D.n; i += 64) {
+    for (int i = lane; i < D.n; i += TW) {
         D.lu[i] = A.src.lu[so + i];
         D.wt[i] = A.src.wt[so + i];
         D.key[i] = A.src.key[so + i];
@@ -520,11 +555,11 @@ __global__ __launch_bounds__(64) void cache_replay_kernel(ReplayArgs A)
     D.ev = A.evicted + A.ev_off[c];
     D.nev = 0;
     for (int q = o0; q < o1; q++) {
+        const mmp_cache_op o = A.ops[q];
         const int oi = A.op_order[q];
-        const mmp_cache_op o = A.ops[oi];
         const int ev0 = D.nev;
-        const int32_t res = apply_op(D, o, A.now);
-        const int ubi = u.reserved >= 0 ? dq_find(D, MMP_UNLOADBUF_KEY_C) : -1;
+        const int32_t res = apply_op<TW>(D, o, A.now);
+        const int ubi = u.reserved >= 0 ? dq_find<TW>(D, MMP_UNLOADBUF_KEY_C) : -1;
         if (lane == 0) {
             mmp_cache_op_out r;
             r.result = res;
@@ -537,7 +572,7 @@ __global__ __launch_bounds__(64) void cache_replay_kernel(ReplayArgs A)
         }
         wave_sync();
     }
-    for (int i = lane; i < D.n; i += 64) {
+    for (int i = lane; i < D.n; i += TW) {
         A.dst.lu[dn + i] = D.lu[D.head + i];
         A.dst.wt[dn + i] = D.wt[D.head + i];
         A.dst.key[dn + i] = D.key[D.head + i];

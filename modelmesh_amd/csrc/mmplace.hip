@@ -178,6 +178,7 @@ struct mmp_ctx {
     std::atomic<bool> reg_pending{false};
     std::atomic<size_t> lds_granted{48 * 1024};  // dynamic LDS the place kernels may be launched with so far
     int32_t no_caseb = 0;    // MMP_NO_CASEB=1: case (b) decisions never use the whole-window tables (tests: the wave path decides them)
+    int32_t cfg_plan_sorted = 0;  // MMP_PLAN_SORTED=1: mmp_proactive_plan takes its sorted (fallback) path on every input; 2: never (tests)
     int32_t no_long_lds = 0; // MMP_NO_LONG_LDS=1: the long path reads its per-type tables from global memory (tests, comparison)
     int32_t no_heads = 0;    // MMP_NO_HEADS=1: decisions do not use the per-type head windows (tests: lane_decide_r alone)
 
@@ -262,7 +263,7 @@ struct mmp_ctx {
     int ks_cur = 0;
     int32_t k_caches = 0;
     std::vector<int32_t> k_n;  // host mirror of the live entry counts
-    DevBuf k_cap, k_wsize, k_oldest, k_ubm, k_ops, k_order, k_opoff, k_outs, k_ev, k_evoff;
+    DevBuf k_cap, k_wsize, k_oldest, k_ubm, k_ops, k_order, k_opoff, k_outs, k_ev, k_evoff, k_ids;  // k_ids: cache ids grouped by replay team width
 
     // wire-format ingestion: per-pod id attributes and the hash tables the parsers probe
     std::vector<uint32_t> id_order_v;
@@ -567,6 +568,7 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     const bool want_resident = getenv("MMP_RESIDENT") && getenv("MMP_RESIDENT")[0] == '1';
     if (const char *rm = getenv("MMP_RANK_MODE")) c->rank_mode = atoi(rm);
     if (const char *lm = getenv("MMP_LONG_MODE")) c->long_mode = atoi(lm);
+    if (const char *sp = getenv("MMP_PLAN_SORTED")) c->cfg_plan_sorted = atoi(sp);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete c;
         return fail(nullptr, MMP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
@@ -653,7 +655,7 @@ void mmp_destroy(mmp_ctx *c)
                       &c->models, &c->ent_pod, &c->ent_time, &c->c_seg,
                       &c->c_lu, &c->c_wt, &c->c_cap, &c->s_reqs, &c->s_outs, &c->s_extra, &c->s_a, &c->s_b,
                       &c->s_c, &c->s_d, &c->r_ps, &c->r_counts, &c->r_keys, &c->r_vals, &c->r_keys2, &c->r_vals2,
-                      &c->r_tmp, &c->r_out_model, &c->r_out_lu, &c->rt_sreqs, &c->rt_souts, &c->rt_cnt, &c->k_cap, &c->k_wsize, &c->k_oldest, &c->k_ubm, &c->k_ops, &c->k_order,
+                      &c->r_tmp, &c->r_out_model, &c->r_out_lu, &c->rt_sreqs, &c->rt_souts, &c->rt_cnt, &c->k_ids, &c->k_cap, &c->k_wsize, &c->k_oldest, &c->k_ubm, &c->k_ops, &c->k_order,
                       &c->k_opoff, &c->k_outs, &c->k_ev, &c->k_evoff, &c->idtab_hash, &c->idtab_val, &c->tytab_hash,
                       &c->tytab_val, &c->j_buf, &c->j_off, &c->j_rows, &c->j_aux, &c->j_status, &c->j_cnt, &c->j_offs, &c->j_tmp_pod,
                       &c->j_tmp_time, &c->j_scan_tmp, &c->rk_rows, &c->rk_idx, &c->rk_tmp, &c->u_idx, &c->u_rows, &c->u_cnt, &c->u_offs, &c->u_tmp, &c->f_flags[0], &c->f_flags[1], &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp, &c->f_cnt[0], &c->f_cnt[1],
@@ -2338,10 +2340,12 @@ int mmp_shard_place_fast_finish_dev(mmp_ctx *c, const void *d_reqs, int32_t n, c
 try {
     if (!c || n < 0 || !n_rest_out || !d_rest_reqs_out || !d_rest_outs_out || (n > 0 && (!d_reqs || !d_xf || !d_outs)))
         return fail(c, MMP_EINVAL, "mmp_shard_place_fast_finish_dev: bad argument");
-    std::lock_guard<std::shared_mutex> g(c->mu);
-    if (c->n_shards < 1 || !c->committed) return fail(c, MMP_ESTATE, "no committed shard snapshot");
     *n_rest_out = 0;
     *d_rest_reqs_out = *d_rest_outs_out = nullptr;
+    std::lock_guard<std::shared_mutex> g(c->mu);
+    if (c->n_shards < 1 || !c->committed) return fail(c, MMP_ESTATE, "no committed shard snapshot");
+    // the step-wise calls use count slot 0 and the context's rest buffers, which an asynchronous batch still in flight may own
+    if (c->pend.active) return fail(c, MMP_ESTATE, "mmp_shard_place_fast_finish_dev: an asynchronous batch is pending (mmp_shard_wait first)");
     if (n == 0) return MMP_OK;
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -3544,7 +3548,7 @@ try {
     const StatsAcc *stats = cur_side(c).stats_acc.as<StatsAcc>();
     const mmp_pod_row *pods = c->sb[c->cur].pods.as<mmp_pod_row>();
     const mmp_model_row *models = c->models.as<mmp_model_row>();
-    int32_t *counts = c->r_counts.as<int32_t>();
+    int32_t *counts = nullptr;
     HIP_TRY(c, hipMemsetAsync(ps, 0, sizeof(PlanScalars), st));
     PlanSubset U{};
     U.global = stats;
@@ -3563,48 +3567,83 @@ try {
         HIP_TRY(c, hipStreamSynchronize(st));  // `mask` leaves scope
         U.skip = c->s_d.as<uint8_t>();
     }
-    KT_BEGIN(c, st);  // device span of the whole plan, including the host round trip for n_qualified
-    hipLaunchKernelGGL(proactive_space_kernel, dim3(std::min(std::max(div_up(P, 256), 1), 512)), dim3(256), 0, st, pods, P,
-                       U, default_units, ps);
-    hipLaunchKernelGGL(proactive_scalars_kernel, dim3(1), dim3(64), 0, st, U, default_units, now, ps);
-    hipLaunchKernelGGL(proactive_count_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps, counts,
-                       &ps->n_candidates);
-    hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(256), 0, st, counts, nb, &ps->n_qualified);
+    // The bucketed plan: six dependent launches, every size read on the device, ONE read of the result at the end.
+    const int32_t n_cnt_words = 3 * (kPlanBuckets + 1) + 3 * kPlanBuckets;
+    HIP_TRY(c, c->r_counts.ensure((size_t)std::max(n_cnt_words, nb + 1) * 4));
+    counts = c->r_counts.as<int32_t>();
+    int32_t *hist = counts, *hist2 = hist + kPlanBuckets, *off = hist2 + kPlanBuckets, *cur = off + kPlanBuckets + 1,
+            *dcnt = cur + kPlanBuckets + 1, *doff = dcnt + kPlanBuckets;
+    KT_BEGIN(c, st);  // device span of the whole plan
+    HIP_TRY(c, hipMemsetAsync(hist, 0, (size_t)2 * kPlanBuckets * 4, st));
+    hipLaunchKernelGGL(proactive_space_scalars_kernel, dim3(std::min(std::max(div_up(P, 256), 1), 512)), dim3(256), 0, st, pods, P,
+                       U, default_units, now, ps);
+    hipLaunchKernelGGL(proactive_qualify_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps);
+    hipLaunchKernelGGL(proactive_hist_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps, hist, hist2, off, cur);
+    hipLaunchKernelGGL(proactive_bin_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps, cur, c->r_keys.as<int64_t>(),
+                       c->r_vals.as<int32_t>());
+    hipLaunchKernelGGL(proactive_bucket_rank_kernel, dim3(kPlanBuckets / 4), dim3(256), 0, st, c->r_keys.as<int64_t>(),
+                       c->r_vals.as<int32_t>(), off, ps, c->r_vals2.as<int32_t>(), dcnt, doff);
+    hipLaunchKernelGGL(proactive_emit_kernel, dim3(nb), dim3(kCompactBlock), 0, st, c->r_keys.as<int64_t>(), c->r_vals.as<int32_t>(),
+                       c->r_vals2.as<int32_t>(), doff, ps, max_out, c->r_out_model.as<int32_t>(), c->r_out_lu.as<int64_t>());
+    KT_END(c, st);
     HIP_TRY(c, hipGetLastError());
     PlanScalars h{};
     HIP_TRY(c, hipMemcpyAsync(&h, ps, sizeof h, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
-    const int32_t nq = h.n_qualified;
-    if (nq <= 0) {
-        KT_END(c, st);
-        HIP_TRY(c, hipStreamSynchronize(st));
-        kt_collect(c);
-    } else {
-        hipLaunchKernelGGL(proactive_scatter_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps, counts,
-                           c->r_keys.as<int64_t>(), c->r_vals.as<int32_t>());
-        // stable descending radix sort: equal lastUsed keep registry order, so the first one seen wins
-        size_t tmp_bytes = 0;
-        HIP_TRY(c, rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, c->r_keys.as<int64_t>(), c->r_keys2.as<int64_t>(),
-                                                  c->r_vals.as<int32_t>(), c->r_vals2.as<int32_t>(), (size_t)nq, 0, 64, st));
-        HIP_TRY(c, c->r_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
-        HIP_TRY(c, rocprim::radix_sort_pairs_desc(c->r_tmp.p, tmp_bytes, c->r_keys.as<int64_t>(), c->r_keys2.as<int64_t>(),
-                                                  c->r_vals.as<int32_t>(), c->r_vals2.as<int32_t>(), (size_t)nq, 0, 64, st));
-        const int nb2 = div_up(nq, kCompactBlock);
-        hipLaunchKernelGGL(distinct_count_kernel, dim3(nb2), dim3(kCompactBlock), 0, st, c->r_keys2.as<int64_t>(), nq, counts);
-        hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(256), 0, st, counts, nb2, &ps->n_distinct);
-        hipLaunchKernelGGL(distinct_scatter_kernel, dim3(nb2), dim3(kCompactBlock), 0, st, c->r_keys2.as<int64_t>(),
-                           c->r_vals2.as<int32_t>(), nq, counts, ps, max_out, c->r_out_model.as<int32_t>(),
-                           c->r_out_lu.as<int64_t>());
-        hipLaunchKernelGGL(proactive_final_kernel, dim3(1), dim3(64), 0, st, ps);
-        KT_END(c, st);
-        HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipMemcpyAsync(&h, ps, sizeof h, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        kt_collect(c);
+    kt_collect(c);
+    if (h.overflow && c->cfg_plan_sorted == 2) return fail(c, MMP_ESTATE, "mmp_proactive_plan: a key bucket overflowed and MMP_PLAN_SORTED=2 forbids the sorted path");
+    if (!h.overflow && c->cfg_plan_sorted != 1) {
         const int32_t n_copy = std::min(h.n_selected, max_out);
         if (n_copy > 0) {
             HIP_TRY(c, copy_sync(c, out_model, c->r_out_model.p, (size_t)n_copy * 4, hipMemcpyDeviceToHost));
             HIP_TRY(c, copy_sync(c, out_last_used, c->r_out_lu.p, (size_t)n_copy * 8, hipMemcpyDeviceToHost));
+        }
+    } else {
+        // lastUsed values piled on a few milliseconds (a bucket above kPlanBucketMax): the general path — order-preserving
+        // compaction, a stable descending radix sort sized by the qualified count the host has just read, run starts
+        HIP_TRY(c, hipMemsetAsync(ps, 0, sizeof(PlanScalars), st));
+        KT_BEGIN(c, st);
+        hipLaunchKernelGGL(proactive_space_kernel, dim3(std::min(std::max(div_up(P, 256), 1), 512)), dim3(256), 0, st, pods, P,
+                           U, default_units, ps);
+        hipLaunchKernelGGL(proactive_scalars_kernel, dim3(1), dim3(64), 0, st, U, default_units, now, ps);
+        hipLaunchKernelGGL(proactive_count_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps, counts,
+                           &ps->n_candidates);
+        hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(256), 0, st, counts, nb, &ps->n_qualified);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(&h, ps, sizeof h, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        const int32_t nq = h.n_qualified;
+        if (nq <= 0) {
+            KT_END(c, st);
+            HIP_TRY(c, hipStreamSynchronize(st));
+            kt_collect(c);
+        } else {
+            hipLaunchKernelGGL(proactive_scatter_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps, counts,
+                               c->r_keys.as<int64_t>(), c->r_vals.as<int32_t>());
+            // stable descending radix sort: equal lastUsed keep registry order, so the first one seen wins
+            size_t tmp_bytes = 0;
+            HIP_TRY(c, rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, c->r_keys.as<int64_t>(), c->r_keys2.as<int64_t>(),
+                                                      c->r_vals.as<int32_t>(), c->r_vals2.as<int32_t>(), (size_t)nq, 0, 64, st));
+            HIP_TRY(c, c->r_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
+            HIP_TRY(c, rocprim::radix_sort_pairs_desc(c->r_tmp.p, tmp_bytes, c->r_keys.as<int64_t>(), c->r_keys2.as<int64_t>(),
+                                                      c->r_vals.as<int32_t>(), c->r_vals2.as<int32_t>(), (size_t)nq, 0, 64, st));
+            const int nb2 = div_up(nq, kCompactBlock);
+            hipLaunchKernelGGL(distinct_count_kernel, dim3(nb2), dim3(kCompactBlock), 0, st, c->r_keys2.as<int64_t>(), nq, counts);
+            hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(256), 0, st, counts, nb2, &ps->n_distinct);
+            hipLaunchKernelGGL(distinct_scatter_kernel, dim3(nb2), dim3(kCompactBlock), 0, st, c->r_keys2.as<int64_t>(),
+                               c->r_vals2.as<int32_t>(), nq, counts, ps, max_out, c->r_out_model.as<int32_t>(),
+                               c->r_out_lu.as<int64_t>());
+            hipLaunchKernelGGL(proactive_final_kernel, dim3(1), dim3(64), 0, st, ps);
+            KT_END(c, st);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(&h, ps, sizeof h, hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            kt_collect(c);
+            const int32_t n_copy = std::min(h.n_selected, max_out);
+            if (n_copy > 0) {
+                HIP_TRY(c, copy_sync(c, out_model, c->r_out_model.p, (size_t)n_copy * 4, hipMemcpyDeviceToHost));
+                HIP_TRY(c, copy_sync(c, out_last_used, c->r_out_lu.p, (size_t)n_copy * 8, hipMemcpyDeviceToHost));
+            }
         }
     }
     info->size_estimate = h.size_estimate;
@@ -3858,18 +3897,27 @@ try {
             ins[o.cache]++;
     }
     std::vector<int32_t> op_off(NC + 1, 0), new_off(NC + 1, 0), ev_off(NC + 1, 0);
-    int32_t tile = 1;
+    // team width per cache by the deque slots its replay needs: [0] 8 lanes, [1] 16 lanes, [2] the whole wavefront
+    int32_t tile = 1, tiles[3] = {1, 1, 1};
+    std::vector<int32_t> ids[3];
     for (int32_t k = 0; k < NC; k++) {
         op_off[k + 1] = op_off[k] + cnt[k + 1];
         const int32_t slots = c->k_n[k] + ins[k];
         new_off[k + 1] = new_off[k] + slots;
         ev_off[k + 1] = ev_off[k] + (cnt[k + 1] ? slots : 0);  // a cache cannot evict more than it ever held
-        if (cnt[k + 1]) tile = std::max(tile, slots + 1);
+        const int w = slots + 1 <= kTeam8Slots ? 0 : slots + 1 <= kTeam16Slots ? 1 : 2;
+        ids[w].push_back(k);
+        if (cnt[k + 1]) {
+            tile = std::max(tile, slots + 1);
+            tiles[w] = std::max(tiles[w], slots + 1);
+        }
     }
     if (tile > kCacheTile) return fail(c, MMP_EINVAL, "mmp_cache_replay: a cache needs %d deque slots, the tile holds %d", tile, kCacheTile);
     if (ev_off[NC] > max_evicted) return fail(c, MMP_EINVAL, "mmp_cache_replay: evicted_keys needs room for %d keys", ev_off[NC]);
     std::vector<int32_t> order(n_ops), fill(op_off.begin(), op_off.end() - 1);
     for (int32_t i = 0; i < n_ops; i++) order[fill[ops[i].cache]++] = i;
+    std::vector<mmp_cache_op> grouped((size_t)n_ops);  // the kernel reads an operation with ONE load (no index in between)
+    for (int32_t q = 0; q < n_ops; q++) grouped[q] = ops[order[q]];
 
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     hipStream_t st = c->stream;
@@ -3887,7 +3935,7 @@ try {
     HIP_TRY(c, c->k_ev.ensure((size_t)std::max(ev_off[NC], 1) * 4));
     HIP_TRY(c, c->k_evoff.ensure((size_t)(NC + 1) * 4));
     HIP_TRY(c, hipMemcpyAsync(D.off.p, new_off.data(), (size_t)(NC + 1) * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->k_ops.p, ops, (size_t)n_ops * sizeof(mmp_cache_op), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->k_ops.p, grouped.data(), (size_t)n_ops * sizeof(mmp_cache_op), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->k_order.p, order.data(), (size_t)n_ops * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->k_opoff.p, op_off.data(), (size_t)(NC + 1) * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->k_evoff.p, ev_off.data(), (size_t)(NC + 1) * 4, hipMemcpyHostToDevice, st));
@@ -3907,9 +3955,33 @@ try {
     A.n_caches = NC;
     A.tile = tile;
     A.now = now;
-    const size_t lds = (size_t)tile * 24;
+    HIP_TRY(c, c->k_ids.ensure((size_t)NC * 4));
+    {
+        std::vector<int32_t> all;
+        all.reserve(NC);
+        for (auto &v : ids) all.insert(all.end(), v.begin(), v.end());
+        HIP_TRY(c, hipMemcpyAsync(c->k_ids.p, all.data(), (size_t)NC * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipStreamSynchronize(st));  // `all` leaves scope (the other uploads above are from vectors that live to the end)
+    }
     KT_BEGIN(c, st);
-    hipLaunchKernelGGL(cache_replay_kernel, dim3(NC), dim3(64), lds, st, A);
+    const int32_t *d_ids = c->k_ids.as<int32_t>();
+    for (int w = 0; w < 3; w++)
+        if ((int32_t)ids[w].size() == NC) d_ids = nullptr;  // one width for every cache: the list is the identity
+    if (!ids[0].empty()) {
+        A.tile = tiles[0];
+        hipLaunchKernelGGL(cache_replay_kernel<8>, dim3(div_up((int)ids[0].size(), 8)), dim3(64), (size_t)tiles[0] * 24 * 8, st, A, d_ids,
+                           (int32_t)ids[0].size());
+    }
+    if (!ids[1].empty()) {
+        A.tile = tiles[1];
+        hipLaunchKernelGGL(cache_replay_kernel<16>, dim3(div_up((int)ids[1].size(), 4)), dim3(64), (size_t)tiles[1] * 24 * 4, st, A,
+                           d_ids ? d_ids + ids[0].size() : nullptr, (int32_t)ids[1].size());
+    }
+    if (!ids[2].empty()) {
+        A.tile = tiles[2];
+        hipLaunchKernelGGL(cache_replay_kernel<64>, dim3((int)ids[2].size()), dim3(64), (size_t)tiles[2] * 24, st, A,
+                           d_ids ? d_ids + ids[0].size() + ids[1].size() : nullptr, (int32_t)ids[2].size());
+    }
     KT_END(c, st);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(outs, c->k_outs.p, (size_t)n_ops * sizeof(mmp_cache_op_out), hipMemcpyDeviceToHost, st));

@@ -20,6 +20,11 @@ struct PlanScalars {  // mirrors mmp_proactive_info + work counters
     int32_t n_ge_cutoff;           // selected entries with lastUsed >= cutoff
     int32_t cand_enabled;          // proactiveLoadCandidates != null (globalStats.totalCapacity > 0, MM.java:6459)
     int64_t cand_glru;             // the reaper's globalLru: 0 <=> the cluster has free space (:6462)
+    // the bucketed plan (no host round trip): key range of the qualified candidates, launch tickets, the fallback flag
+    long long kmin, kmax;
+    unsigned int ticket[4];
+    int32_t overflow;              // a bucket holds more than kPlanBucketMax candidates: the host takes the sorted path
+    int32_t bucket_map;            // 0: linear in age, 1: floating (exponent + mantissa of age)
 };
 
 // The instance subset a plan is made for (triggerProactiveLoadsForInstanceSubset, MM.java:6616: one call per
@@ -77,9 +82,9 @@ __global__ void proactive_space_kernel(const mmp_pod_row *__restrict__ pods, int
 }
 
 // the scalar part of :6621-6664, one lane
-__global__ void proactive_scalars_kernel(PlanSubset U, int32_t default_units, int64_t now, PlanScalars *ps)
+__device__ __forceinline__ void proactive_scalars(const PlanSubset &U, int32_t default_units, int64_t now, PlanScalars *ps,
+                                                  unsigned long long space_acc)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const StatsAcc *st = U.stats;
     ps->cand_enabled = (int64_t)U.global->total_capacity > 0 ? 1 : 0;
     ps->cand_glru = (int64_t)U.global->total_free > 0 ? 0 : U.global->global_lru;
@@ -93,7 +98,7 @@ __global__ void proactive_scalars_kernel(PlanSubset U, int32_t default_units, in
         if (se == 0) {
             ps->error = 1;  // the Java throws ArithmeticException at :6651
         } else {
-            const int64_t space = (int64_t)ps->space_acc / 2;
+            const int64_t space = (int64_t)space_acc / 2;
             ps->space_to_fill = space;
             free_count = (int32_t)(space / se);
             const int32_t by_cap = (int32_t)((int64_t)st->total_capacity / (20LL * se));
@@ -109,6 +114,11 @@ __global__ void proactive_scalars_kernel(PlanSubset U, int32_t default_units, in
         cutoff = (int64_t)((uint64_t)glru + (uint64_t)(third > 1200000 ? third : 1200000));
     }
     ps->cutoff = cutoff;
+}
+
+__global__ void proactive_scalars_kernel(PlanSubset U, int32_t default_units, int64_t now, PlanScalars *ps)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) proactive_scalars(U, default_units, now, ps, ps->space_acc);
 }
 
 // candidate predicate = registry rule :6574-6577 ∧ per-candidate test :6683-6685
@@ -250,6 +260,296 @@ __global__ __launch_bounds__(kCompactBlock) void distinct_scatter_kernel(const i
     }
     const int nge = __popcll(__ballot(ge));
     if (lane == 0 && nge) atomicAdd(&ps->n_ge_cutoff, nge);
+}
+
+// ---- the same plan WITHOUT the sort and without the host reading the qualified count in the middle ---------------------------
+// The TreeSet keeps, per distinct lastUsed, the first model seen, and toLoad is its totalProactiveLoadCount largest values.  A
+// model's place in that order is (number of distinct qualified lastUsed values above its own), and equal values are neighbours
+// under ANY monotone partition of the key range: so the qualified candidates are binned into kPlanBuckets key-range buckets
+// (bucket 0 = the newest), each bucket resolves its own ties and local ranks by counting (all pairs, in LDS, one wavefront per
+// bucket), and a scan of the buckets' distinct counts turns local ranks into global ones.  lastUsed values are timestamps: dense
+// near `now`, a long tail behind — so two monotone maps of age = newest - lastUsed are histogrammed side by side, a LINEAR one
+// (age >> shift) and a FLOATING one (exponent + 8 mantissa bits of age: buckets 1/256 of their age wide), and the launch
+// that scans the histograms picks the map with the smaller fullest bucket.  Six dependent launches, every size read on the device:
+//   space (+ scalars) -> qualify: count, key range -> histograms (+ choice, scan) -> bin -> per-bucket rank (+ scan) -> emit (+ final)
+// A bucket above kPlanBucketMax under both maps (thousands of models on one millisecond) raises `overflow`: the sorted path runs.
+constexpr int kPlanBuckets = 16384, kPlanLinBits = 14, kPlanMantBits = 8, kPlanBucketMax = 512;
+
+// true in exactly one workgroup of the launch: the one that arrives last (its view includes every other workgroup's writes)
+__device__ __forceinline__ bool last_workgroup(unsigned int *ticket)
+{
+    __shared__ unsigned int s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (s_last) __threadfence();
+    return s_last != 0;
+}
+
+__global__ __launch_bounds__(256) void proactive_space_scalars_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, PlanSubset U,
+                                                                      int32_t default_units, int64_t now, PlanScalars *ps)
+{
+    const StatsAcc *st = U.stats;
+    const bool active = (int64_t)st->total_capacity > 0 && (int64_t)st->total_free > 0;
+    int64_t sum = 0;
+    if (active) {
+        const int32_t se = size_estimate_of(st, default_units);
+        if (se != 0) {
+            for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+                const mmp_pod_row r = pods[p];
+                if (r.flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE)) continue;
+                if (U.pts >= 0 && U.pod_pts[p] != U.pts) continue;
+                const int32_t max_loads = (int32_t)((uint32_t)r.loading_threads * 50u - (uint32_t)r.loading_in_progress);
+                if (max_loads <= 0) continue;
+                const int64_t avail = jsub64(remaining_of(r.capacity, r.used), r.capacity / 8);
+                if (avail > 0) {
+                    const int64_t by_loads = (int64_t)(int32_t)((uint32_t)max_loads * (uint32_t)se);
+                    sum = (int64_t)((uint64_t)sum + (uint64_t)(avail < by_loads ? avail : by_loads));
+                }
+            }
+        }
+    }
+    sum = wave_sum_i64(sum);
+    if (lane_id() == 0 && sum != 0) atomicAdd(&ps->space_acc, (unsigned long long)sum);
+    if (last_workgroup(&ps->ticket[0]) && threadIdx.x == 0) {
+        const unsigned long long acc = __hip_atomic_load(&ps->space_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        proactive_scalars(U, default_units, now, ps, acc);
+        ps->kmin = INT64_MAX;
+        ps->kmax = INT64_MIN;
+    }
+}
+
+__device__ __forceinline__ bool proactive_qualifies(const mmp_model_row &m, int i, const PlanSubset &U, const PlanScalars *ps)
+{
+    return proactive_candidate(m, ps) && !plan_excluded(U, i, m.type) && ps->total_count > 0 &&
+           (ps->free_count > 0 || m.last_used > ps->cutoff);
+}
+
+__device__ __forceinline__ int64_t wave_max_i64(int64_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int64_t t = (int64_t)shfl_u64((uint64_t)v, lane_id() ^ o);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+// pass 1 over the registry: how many candidates / qualified, and the qualified keys' range
+__global__ __launch_bounds__(kCompactBlock) void proactive_qualify_kernel(const mmp_model_row *__restrict__ models, int32_t M,
+                                                                          PlanSubset U, PlanScalars *ps)
+{
+    const int i = blockIdx.x * kCompactBlock + threadIdx.x;
+    bool cand = false, q = false;
+    int64_t lu = 0;
+    if (i < M) {
+        const mmp_model_row m = models[i];
+        lu = m.last_used;
+        cand = proactive_candidate(m, ps);
+        q = cand && proactive_qualifies(m, i, U, ps);
+    }
+    const uint64_t bq = __ballot(q);
+    const int nc = __popcll(__ballot(cand));
+    const int64_t lo = wave_min_i64(q ? lu : INT64_MAX), hi = wave_max_i64(q ? lu : INT64_MIN);
+    if (lane_id() == 0) {
+        if (nc) atomicAdd(&ps->n_candidates, nc);
+        if (bq) {
+            atomicAdd(&ps->n_qualified, __popcll(bq));
+            atomicMin(&ps->kmin, (long long)lo);
+            atomicMax(&ps->kmax, (long long)hi);
+        }
+    }
+}
+
+// buckets of a qualified key, 0 = the newest; both monotone in the key, so equal keys share a bucket and the buckets are in
+// TreeSet order
+__device__ __forceinline__ int plan_bucket_linear(uint64_t age, uint64_t range)
+{
+    const int bits = range ? 64 - __builtin_clzll(range) : 0;
+    return (int)(age >> (bits > kPlanLinBits ? bits - kPlanLinBits : 0));
+}
+__device__ __forceinline__ int plan_bucket_floating(uint64_t age)
+{
+    constexpr int m = kPlanMantBits;
+    if (age < (1ull << m)) return (int)age;
+    const int e = 63 - __builtin_clzll(age);  // >= m
+    return ((e - m + 1) << m) + (int)((age >> (e - m)) & ((1u << m) - 1));  // < (64 - m + 1) << m = 14592
+}
+__device__ __forceinline__ int plan_bucket(int64_t key, const PlanScalars *ps)
+{
+    const uint64_t age = (uint64_t)ps->kmax - (uint64_t)key;
+    return ps->bucket_map ? plan_bucket_floating(age) : plan_bucket_linear(age, (uint64_t)ps->kmax - (uint64_t)ps->kmin);
+}
+
+// exclusive scan of kPlanBuckets counts by one workgroup of 256; off[kPlanBuckets] = total, returned in every thread
+__device__ __forceinline__ int32_t bucket_scan(const int32_t *__restrict__ cnt, int32_t *__restrict__ off, int32_t *__restrict__ off2)
+{
+    __shared__ int32_t wtot[4];
+    constexpr int per = kPlanBuckets / 256;
+    int32_t mine = 0;
+    for (int k = 0; k < per; k++) mine += cnt[threadIdx.x * per + k];
+    const int32_t incl = wave_incl_scan_i32(mine);
+    __syncthreads();
+    if (lane_id() == 63) wtot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int32_t before = incl - mine, total = 0;
+    for (int w = 0; w < 4; w++) {
+        if (w < (int)(threadIdx.x >> 6)) before += wtot[w];
+        total += wtot[w];
+    }
+    for (int k = 0; k < per; k++) {
+        const int32_t v = cnt[threadIdx.x * per + k];
+        off[threadIdx.x * per + k] = before;
+        if (off2) off2[threadIdx.x * per + k] = before;
+        before += v;
+    }
+    if (threadIdx.x == 255) off[kPlanBuckets] = total;
+    return total;
+}
+
+// pass 2: both histograms; the last workgroup picks the map and scans its histogram (off = bucket starts, cur = bin cursors)
+__global__ __launch_bounds__(kCompactBlock) void proactive_hist_kernel(const mmp_model_row *__restrict__ models, int32_t M, PlanSubset U,
+                                                                       PlanScalars *ps, int32_t *__restrict__ hist_lin,
+                                                                       int32_t *__restrict__ hist_flt, int32_t *__restrict__ off,
+                                                                       int32_t *__restrict__ cur)
+{
+    __shared__ int32_t s_max[2];
+    const int i = blockIdx.x * kCompactBlock + threadIdx.x;
+    if (ps->n_qualified > 0 && i < M) {
+        const mmp_model_row m = models[i];
+        if (proactive_qualifies(m, i, U, ps)) {
+            const uint64_t age = (uint64_t)ps->kmax - (uint64_t)m.last_used;
+            atomicAdd(&hist_lin[plan_bucket_linear(age, (uint64_t)ps->kmax - (uint64_t)ps->kmin)], 1);
+            atomicAdd(&hist_flt[plan_bucket_floating(age)], 1);
+        }
+    }
+    if (last_workgroup(&ps->ticket[1])) {
+        if (threadIdx.x < 2) s_max[threadIdx.x] = 0;
+        __syncthreads();
+        int32_t a = 0, b = 0;
+        for (int k = threadIdx.x; k < kPlanBuckets; k += kCompactBlock) {
+            a = max(a, hist_lin[k]);
+            b = max(b, hist_flt[k]);
+        }
+        atomicMax(&s_max[0], a);
+        atomicMax(&s_max[1], b);
+        __syncthreads();
+        const int map = s_max[1] < s_max[0] ? 1 : 0;
+        if (threadIdx.x == 0) ps->bucket_map = map;
+        bucket_scan(map ? hist_flt : hist_lin, off, cur);
+    }
+}
+
+// pass 3: the qualified (lastUsed, model) pairs into their buckets (any order inside a bucket: ranks are counted, not sorted)
+__global__ __launch_bounds__(kCompactBlock) void proactive_bin_kernel(const mmp_model_row *__restrict__ models, int32_t M, PlanSubset U,
+                                                                      const PlanScalars *ps, int32_t *__restrict__ cur,
+                                                                      int64_t *__restrict__ keys, int32_t *__restrict__ vals)
+{
+    const int i = blockIdx.x * kCompactBlock + threadIdx.x;
+    if (ps->n_qualified <= 0 || i >= M) return;
+    const mmp_model_row m = models[i];
+    if (!proactive_qualifies(m, i, U, ps)) return;
+    const int dst = atomicAdd(&cur[plan_bucket(m.last_used, ps)], 1);
+    keys[dst] = m.last_used;
+    vals[dst] = i;
+}
+
+// one WAVEFRONT per bucket (four buckets per workgroup): an entry is a run start if no equal key has a lower model index (the
+// TreeSet's first one seen); its local rank = run starts of the bucket with a larger key.  rank[pos] = local rank, -1 = duplicate.
+__global__ __launch_bounds__(256) void proactive_bucket_rank_kernel(const int64_t *__restrict__ keys, const int32_t *__restrict__ vals,
+                                                                    const int32_t *__restrict__ off, PlanScalars *ps,
+                                                                    int32_t *__restrict__ rank, int32_t *__restrict__ dcnt,
+                                                                    int32_t *__restrict__ doff)
+{
+    __shared__ int64_t s_key_all[4][kPlanBucketMax];
+    __shared__ int32_t s_val_all[4][kPlanBucketMax];
+    const int wv = threadIdx.x >> 6, lane = lane_id();
+    int64_t *s_key = s_key_all[wv];
+    int32_t *s_val = s_val_all[wv];
+    const int b = blockIdx.x * 4 + wv, lo = off[b], cnt = off[b + 1] - lo;
+    int32_t starts = 0;
+    if (cnt > kPlanBucketMax) {
+        if (lane == 0) ps->overflow = 1;
+    } else if (cnt == 1) {
+        if (lane == 0) rank[lo] = 0;
+        starts = lane == 0;
+    } else if (cnt > 1) {
+        for (int j = lane; j < cnt; j += 64) {
+            s_key[j] = keys[lo + j];
+            s_val[j] = vals[lo + j];
+        }
+        wave_sync();
+        constexpr int per = kPlanBucketMax / 64;
+        uint32_t first = 0;
+        for (int k = 0; k < per && k * 64 < cnt; k++) {
+            const int e = lane + k * 64;
+            if (e < cnt) {
+                const int64_t key = s_key[e];
+                const int32_t val = s_val[e];
+                bool f = true;
+                for (int j = 0; j < cnt; j++) f &= !(s_key[j] == key && s_val[j] < val);
+                first |= (uint32_t)f << k;
+            }
+        }
+        wave_sync();
+        for (int k = 0; k < per && k * 64 < cnt; k++) {  // a duplicate leaves the counting: its index becomes -1
+            const int e = lane + k * 64;
+            if (e < cnt && !((first >> k) & 1)) s_val[e] = -1;
+        }
+        wave_sync();
+        for (int k = 0; k < per && k * 64 < cnt; k++) {
+            const int e = lane + k * 64;
+            if (e >= cnt) continue;
+            int32_t r = -1;
+            if ((first >> k) & 1) {
+                const int64_t key = s_key[e];
+                r = 0;
+                for (int j = 0; j < cnt; j++) r += (s_val[j] >= 0 && s_key[j] > key) ? 1 : 0;
+                starts++;
+            }
+            rank[lo + e] = r;
+        }
+    }
+    starts = (int32_t)wave_sum_u64((uint64_t)(uint32_t)starts);
+    if (lane == 0) dcnt[b] = starts;
+    if (last_workgroup(&ps->ticket[2])) {
+        const int32_t total = bucket_scan(dcnt, doff, nullptr);
+        if (threadIdx.x == 0) ps->n_distinct = total;
+    }
+}
+
+// global rank = distinct values in newer buckets + local rank; the first totalProactiveLoadCount of them are toLoad
+__global__ __launch_bounds__(kCompactBlock) void proactive_emit_kernel(const int64_t *__restrict__ keys, const int32_t *__restrict__ vals,
+                                                                       const int32_t *__restrict__ rank, const int32_t *__restrict__ doff,
+                                                                       PlanScalars *ps, int32_t max_out, int32_t *__restrict__ out_model,
+                                                                       int64_t *__restrict__ out_lu)
+{
+    const int i = blockIdx.x * kCompactBlock + threadIdx.x;
+    bool ge = false;
+    if (i < ps->n_qualified && !ps->overflow) {
+        const int32_t lr = rank[i];
+        if (lr >= 0) {
+            const int64_t key = keys[i];
+            const int32_t dst = doff[plan_bucket(key, ps)] + lr;
+            if (dst < ps->total_count) {
+                if (dst < max_out) {
+                    out_model[dst] = vals[i];
+                    out_lu[dst] = key;
+                }
+                ge = key >= ps->cutoff;
+            }
+        }
+    }
+    const int nge = __popcll(__ballot(ge));
+    if (lane_id() == 0 && nge) atomicAdd(&ps->n_ge_cutoff, nge);
+    if (last_workgroup(&ps->ticket[3]) && threadIdx.x == 0) {
+        const int32_t n_ge = __hip_atomic_load(&ps->n_ge_cutoff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int32_t n_sel = ps->n_distinct < ps->total_count ? ps->n_distinct : ps->total_count;
+        const int32_t by_free = ps->free_count < n_sel ? (ps->free_count > 0 ? ps->free_count : 0) : n_sel;
+        const int32_t by_cut = n_ge < n_sel ? n_ge : n_sel;
+        ps->n_selected = by_free > by_cut ? by_free : by_cut;
+    }
 }
 
 // :6709-6734 — free space first, then only entries at or above the cutoff (a prefix, the list is descending)

@@ -111,6 +111,9 @@ class Solver:
     def remove_pods(self, idx: np.ndarray):
         idx = np.ascontiguousarray(idx, dtype=np.int32)
         self._ck(self.lib.mmp_pods_remove(self.h, ptr(idx), len(idx)))
+        live = getattr(self, "_live", None)
+        if live is not None and len(idx):
+            live[idx[(idx >= 0) & (idx < len(live))]] = False  # a removed row leaves litelinks' list too
 
     def load_types(self, n_types, allowed=None, prefer=None, has_allowed=None, has_prefer=None):
         def u64(a):
@@ -240,11 +243,21 @@ class Solver:
         if len(idx):
             self.n_models = max(getattr(self, "n_models", 0), int(idx.max()) + 1)
             # the host mirror serve_counters reads: the changed records' entries are appended, their rows rewritten
-            if getattr(self, "_models", None) is not None and self.n_models <= len(self._models):
+            if getattr(self, "_models", None) is not None:
+                if self.n_models > len(self._models):  # new records: the mirror grows with the registry
+                    self._models = np.concatenate([self._models, np.zeros(self.n_models - len(self._models), MODEL_ROW)])
                 shifted = rows.copy()
                 shifted["ent_off"] += len(self._ent_pod)
                 self._ent_pod = np.concatenate([self._ent_pod, ent_pod])
                 self._models[idx] = shifted
+                live_entries = int(self._models["n_loaded"].sum())
+                if len(self._ent_pod) > 2 * live_entries + 1024:  # the replaced records' entries: compact, as the device pool does
+                    k = self._models["n_loaded"].astype(np.int64)
+                    off = np.zeros(len(k) + 1, np.int64)
+                    np.cumsum(k, out=off[1:])
+                    seg = np.repeat(np.arange(len(k)), k)
+                    self._ent_pod = self._ent_pod[self._models["ent_off"][seg] + (np.arange(int(off[-1])) - off[seg])]
+                    self._models["ent_off"] = off[:-1]
 
     def commit(self):
         self._ck(self.lib.mmp_snapshot_commit(self.h))

@@ -245,3 +245,45 @@ def test_proactive_plan_per_partition_matches_oracle(seed):
         assert n_sel > 0
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("mode", ["2", "1"])  # 2: the bucketed plan only (an overflow would raise); 1: the sorted path only
+@pytest.mark.parametrize("seed,pods,models,used,dup,keys", [
+    (11, 300, 20000, 0.2, 0.02, "ms"), (12, 300, 20000, 0.95, 0.0, "ms"), (13, 1000, 100_000, 0.6, 0.02, "ms"),
+    (14, 64, 3000, 0.3, 0.5, "few"), (15, 300, 20000, 0.3, 0.0, "wide"), (16, 64, 600, 0.3, 1.0, "one")])
+def test_proactive_plan_bucketed_and_sorted_paths(monkeypatch, mode, seed, pods, models, used, dup, keys):
+    """The plan without the sort (key-range buckets, ranks by counting) and the sorted path it falls back to, each forced on the
+    same registries: ties (the TreeSet keeps the first model seen), one single lastUsed value, keys across the whole int64 range."""
+    monkeypatch.setenv("MMP_PLAN_SORTED", mode)
+    fleet = _plan_fleet(seed, pods, models, used, dup_frac=dup)
+    rng = np.random.default_rng(seed)
+    m = fleet.models
+    if keys == "few":   # <= 1024 qualified per value: 3000 models over 8 values
+        m["last_used"] = fleet.now - rng.choice(np.arange(1, 9) * 700_000, models)
+    elif keys == "wide":
+        m["last_used"] = rng.integers(-2**62, 2**62, models)
+    elif keys == "one":
+        m["last_used"] = fleet.now - 5_000
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        for default_units in (6400, 1):
+            gm, gl, gi = s.proactive_plan(default_units, fleet.now, models)
+            wm, wl_, wi = ob.proactive_plan(fleet, default_units, fleet.now, models)
+            for f in ("size_estimate", "free_count", "total_count", "n_candidates", "n_selected", "error", "space_to_fill", "cutoff"):
+                assert int(gi[f]) == int(wi[f]), (f, gi, wi)
+            assert np.array_equal(gm, wm) and np.array_equal(gl, wl_)
+    finally:
+        s.close()
+
+
+def test_proactive_plan_falls_back_when_a_bucket_overflows():
+    fleet = _plan_fleet(3, 300, 20000, 0.2, dup_frac=0.6)  # thousands of unloaded models share three lastUsed values
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        gm, gl, gi = s.proactive_plan(6400, fleet.now, 20000)
+        wm, wl_, wi = ob.proactive_plan(fleet, 6400, fleet.now, 20000)
+        assert int(gi["n_selected"]) == int(wi["n_selected"]) and np.array_equal(gm, wm) and np.array_equal(gl, wl_)
+    finally:
+        s.close()

@@ -65,3 +65,31 @@ def test_route_serve_half_equals_the_reference_text():
         assert np.array_equal(got["chosen"], want[:, 0]), (name, np.nonzero(got["chosen"] != want[:, 0])[0][:5])
         remote = want[:, 0] >= 0
         assert np.array_equal(got["chosen_load_start"][remote], want[remote, 1]), name
+
+
+def test_the_host_mirror_follows_removed_pods_and_new_registry_records():
+    """Solver.serve_counters reads a host mirror of the instance list and the registry (what a Java host holds anyway): a
+    removed row leaves it, a record upserted beyond the loaded registry extends it, and replaced entries do not pile up."""
+    name, fleet, ids, reqs, in_use, last_used, xp, xt = next(iter(rf.serve_cases()))
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        _, c0 = s.serve_counters(reqs, in_use, last_used)
+        gone = np.unique(c0["pod"])[:3].astype(np.int32)
+        s.remove_pods(gone)
+        _, c1 = s.serve_counters(reqs, in_use, last_used)
+        assert len(gone) and not np.isin(c1["pod"], gone).any() and len(c1) < len(c0)
+        # a new record past the end of the loaded registry, with one copy on a listed instance
+        M = s.n_models
+        keep = int(np.setdiff1d(np.unique(c0["pod"]), gone)[0])
+        row = np.zeros(1, dtype=_lib.MODEL_ROW)
+        row["n_loaded"], row["last_used"] = 1, fleet.now
+        for rep in range(3000):  # (and the same record again and again: the mirror's entry pool stays bounded)
+            s.upsert_models(np.array([M], np.int32), row, np.array([keep], np.int32), np.array([fleet.now], np.int64))
+        assert len(s._ent_pod) < len(fleet.ent_pod) * 2 + 2100
+        q = reqs[:1].copy()
+        q["model"] = M
+        q2, c2 = s.serve_counters(q, in_use, last_used)
+        assert q2["n_cnt"][0] == 1 and c2["pod"][0] == keep
+    finally:
+        s.close()
