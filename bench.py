@@ -617,13 +617,15 @@ def secondary_kernels_leg(fleet, solver, device: int, workload: str = "C3", reps
     out = []
 
     def timed(name, fn, alg_bytes, units, unit_name, note=None, s=solver):
-        ms = []
+        ms, wall = [], []
         for i in range(reps + 1):
+            t0 = time.perf_counter()
             fn()
             if i:
+                wall.append((time.perf_counter() - t0) * 1e3)
                 ms.append(s.last_kernel_ms())
         t = float(np.median(ms))
-        row = {"kernel": name, "kernel_ms": t, "units": int(units), "unit": unit_name,
+        row = {"kernel": name, "kernel_ms": t, "call_wall_ms": float(np.median(wall)), "units": int(units), "unit": unit_name,
                "units_per_s": units / (t * 1e-3) if t > 0 else None}
         if alg_bytes is not None:
             row["algorithmic_bytes"] = int(alg_bytes)
@@ -637,9 +639,31 @@ def secondary_kernels_leg(fleet, solver, device: int, workload: str = "C3", reps
     solver.profile(True)
     try:
         # a5 / a4: commit = rank (all pairs, literal comparator) + scatter + bitmaps + stats
-        timed("snapshot_commit (rank + scatter + build_ge + build_masks + cluster_stats)", solver.commit,
+        def commit_from_scratch():
+            solver.load_pods(fleet.pods)  # a replaced table: the commit ranks every row
+            solver.commit()
+        timed("snapshot_commit (rank + scatter + build_ge + build_masks + cluster_stats)", commit_from_scratch,
               None, P, "pods ranked", "rank = rocprim::merge_sort of the 64-byte rank rows with the literal PLACEMENT_ORDER "
               "comparator from 8192 pods on (all-pairs kernel below that, or when the order is not provably total)")
+        # the same commit after 16 republished InstanceRecords: re-rank by insertion (delta_scatter_kernel), same tables after it
+        d_rng = np.random.default_rng(16)
+        d_idx = np.sort(d_rng.choice(P, size=min(16, P), replace=False)).astype(np.int32)
+        flip = [0]
+
+        def commit_after_16_rows():
+            rows = fleet.pods[d_idx].copy()
+            flip[0] ^= 1
+            rows["count"] += flip[0]          # each of the 16 rows moves in the order, and back on the next repetition
+            rows["rpm"] += 7 * flip[0]
+            solver.upsert_pods(d_idx, rows)
+            solver.commit()
+        n0 = solver.delta_commits()
+        timed("snapshot_commit after 16 changed rows (insertion re-rank + the same table builds)", commit_after_16_rows,
+              None, P, "pods in the table", "the K <= 16 changed rows are placed by binary search with the literal comparator "
+              "on the host's mirror of the order; one kernel re-ranks and scatters every row; bitmaps / windows / stats as above")
+        out[-1]["commits_by_insertion"] = solver.delta_commits() - n0
+        solver.load_pods(fleet.pods)
+        solver.commit()
 
         # a12 stateless eviction evaluations over one clhm deque per pod
         cs = wl.ChurnStream(fleet, 0xC5)
@@ -1278,6 +1302,14 @@ def main():
                 line["kernels"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline and not args.kernel_only:
             line["cpu_baseline"] = cpu_baseline(fleet, reqs, extra)
+        # the three regimes of the load-target kernel, read together: 8 request sets per launch (`value`),
+        # one request set per launch, and the full cluster (getNext's LRU-window mode, whole-table shortlists)
+        one_set = (line.get("roofline") or {}).get("launch_of_one_request_set") or {}
+        fc = line.get("full_cluster") if isinstance(line.get("full_cluster"), dict) else {}
+        line["roofline_frac_by_regime"] = {
+            "value_launch": (line.get("roofline") or {}).get("frac"),
+            "launch_of_one_request_set": one_set.get("frac"),
+            "full_cluster": (fc.get("roofline") or {}).get("frac")}
     emit()
     if world > 1:
         # the other ranks wait for rank 0's single-process legs here, still under the watchdog

@@ -403,6 +403,12 @@ int mmp_models_upsert(mmp_ctx *ctx, const int32_t *idx, const mmp_model_row *row
  * stream and its scratch with the commit and therefore queue behind a running one; so do loaders of the
  * commit's inputs and other commits. */
 int mmp_snapshot_commit(mmp_ctx *ctx);
+/* handleInstanceTableChange delivers ONE InstanceRecord per event (MM.java:1455-1568): when at most 16 rows were written
+ * (mmp_pods_upsert / _remove / _ingest_json) since the published snapshot and PLACEMENT_ORDER is a total order on the table
+ * before and after, the commit re-ranks by insertion — the unchanged rows keep their relative order, the changed ones are
+ * placed by binary search with the literal comparator — instead of sorting; the result is the same snapshot.
+ * *n_commits_out = commits that took that path on this context (diagnostics; MMP_NO_DELTA=1 in the environment disables it). */
+int mmp_delta_commits(mmp_ctx *ctx, int64_t *n_commits_out);
 /* clusterState iteration order (the `getCacheState` dump, MM.java:5552-5608).
  * order_out has room for n_pods ints; *n_out = rows actually in the set. */
 int mmp_get_order(mmp_ctx *ctx, int32_t *order_out, int32_t *n_out);

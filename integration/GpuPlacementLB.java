@@ -110,6 +110,7 @@ final class MmPlace {
     static native long minSpaceUnits(int defaultModelSizeUnits, int loadingThreads, long capacityUnits,
                                      boolean haveUnloadManager);
     static native int getOrder(long h, ByteBuffer orderOut, ByteBuffer nOut);
+    static native int deltaCommits(long h, ByteBuffer nOut);
     static native int profile(long h, boolean enable);
     static native double lastKernelMs(long h);
     static native int abiVersion();

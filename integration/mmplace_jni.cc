@@ -427,6 +427,10 @@ JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_getOrder(JNIEnv *en
 {
     return check(env, ctx_of(h), mmp_get_order(ctx_of(h), buf<int32_t>(env, orderOut), buf<int32_t>(env, nOut)));
 }
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_deltaCommits(JNIEnv *env, jclass, jlong h, jobject nOut)
+{
+    return check(env, ctx_of(h), mmp_delta_commits(ctx_of(h), buf<int64_t>(env, nOut)));
+}
 JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_profile(JNIEnv *env, jclass, jlong h, jboolean enable)
 {
     return check(env, ctx_of(h), mmp_profile(ctx_of(h), enable ? 1 : 0));

@@ -130,6 +130,7 @@ SYMBOLS = [
     ("mmp_models_upsert", C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.c_int32]),
     ("mmp_snapshot_commit", C.c_int, [_P]),
     ("mmp_get_order", C.c_int, [_P, _P, C.POINTER(C.c_int32)]),
+    ("mmp_delta_commits", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("mmp_cluster_stats", C.c_int, [_P, _P]),
     ("mmp_type_stats", C.c_int, [_P, C.c_int32, _P]),
     ("mmp_partition_count", C.c_int, [_P, _P]),

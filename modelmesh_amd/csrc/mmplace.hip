@@ -207,6 +207,14 @@ struct mmp_ctx {
     int32_t long_mode = -1;  // MMP_LONG_MODE: -1 auto (the long-shortlist kernel for snapshots whose instances are nearly all full), 0 never, 1 always (tests)
     bool snap_long = false;  // the committed snapshot takes place_batch_long_kernel
     bool snap_full = false;  // ... because (nearly) all of its instances are full (not only because a type is sparse)
+    // the rows written since the last commit (a commit of a few changed rows re-ranks by insertion: delta_scatter_kernel)
+    std::vector<int32_t> dirty;
+    bool dirty_all = true;          // the table was replaced / grew: the next commit ranks from scratch
+    bool order_total = false;       // the published order came from a total order (sort-legal rows): unchanged rows keep their order
+    std::vector<int32_t> h_order, h_pos;  // host mirror of the published order (position -> row, row -> position), fetched lazily
+    bool h_order_valid = false;
+    int32_t no_delta = 0;           // MMP_NO_DELTA=1: every commit ranks from scratch (tests)
+    int64_t n_delta_commits = 0;
     int32_t rank_mode = 0;  // MMP_RANK_MODE: 0 auto (sort from kRankSortMinPods pods), 1 all-pairs, 2 sort whenever legal (tests)
     Snap sview{};  // the lane path's view of this shard's slice (place_shard_fast_kernel)
     DevBuf f_offs, f_idx, f_reqs, f_outs, f_scan_tmp;  // speculative form: the compacted rest of a batch
@@ -568,6 +576,7 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     const bool want_resident = getenv("MMP_RESIDENT") && getenv("MMP_RESIDENT")[0] == '1';
     if (const char *rm = getenv("MMP_RANK_MODE")) c->rank_mode = atoi(rm);
     if (const char *lm = getenv("MMP_LONG_MODE")) c->long_mode = atoi(lm);
+    if (const char *nd = getenv("MMP_NO_DELTA")) c->no_delta = nd[0] == '1';
     if (const char *sp = getenv("MMP_PLAN_SORTED")) c->cfg_plan_sorted = atoi(sp);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete c;
@@ -702,12 +711,27 @@ try {
 
 /* ---- staging of the instance table -------------------------------------- */
 
+namespace {
+// a row written since the last commit; a long list is as good as "everything" (a context that never commits must not grow it)
+inline void note_dirty(mmp_ctx *c, int32_t k)
+{
+    if (c->dirty_all) return;
+    if (c->dirty.size() >= (size_t)8 * kDeltaRows) {
+        c->dirty_all = true;
+        c->dirty.clear();
+        return;
+    }
+    c->dirty.push_back(k);
+}
+}  // namespace
+
 int mmp_pods_load(mmp_ctx *c, const mmp_pod_row *rows, int32_t n)
 try {
     if (!c || n < 0 || (n > 0 && !rows)) return fail(c, MMP_EINVAL, "mmp_pods_load: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::shared_mutex> g(c->mu);
     c->pods.assign(rows, rows + n);
+    c->dirty_all = true;
     return MMP_OK;
 } catch (const std::bad_alloc &) {
     return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_pods_load");
@@ -723,10 +747,13 @@ try {
     for (int32_t i = 0; i < n; i++) {
         const int32_t k = idx[i];
         if (k < 0 || k > (int32_t)c->pods.size()) return fail(c, MMP_EINVAL, "mmp_pods_upsert: index %d out of range", k);
-        if (k == (int32_t)c->pods.size())
+        if (k == (int32_t)c->pods.size()) {
             c->pods.push_back(rows[i]);
-        else
+            c->dirty_all = true;
+        } else {
             c->pods[k] = rows[i];
+            note_dirty(c, k);
+        }
     }
     return MMP_OK;
 } catch (const std::bad_alloc &) {
@@ -745,6 +772,7 @@ try {
         if (k < 0 || k >= (int32_t)c->pods.size()) return fail(c, MMP_EINVAL, "mmp_pods_remove: index %d out of range", k);
         c->pods[k].flags |= MMP_POD_TOMBSTONE;
         c->pods[k].flags &= ~MMP_POD_LIVE;
+        note_dirty(c, k);
     }
     return MMP_OK;
 } catch (const std::bad_alloc &) {
@@ -1186,51 +1214,60 @@ namespace {
 // ClusterStats of the snapshot being committed (snapshot.hpp "instance partitions").  Enqueues on st; the
 // host mirrors are valid once the caller has synchronised st.  Call after cluster_stats_kernel.  N = the side
 // state of the snapshot being built (its d_has_allowed / stats_acc are already filled).
-int build_subset_stats(mmp_ctx *c, SnapSide &N, const mmp_pod_row *d_pods, int32_t P, int64_t min_space, hipStream_t st)
+// part 0: the host's interning of the partitions + the uploads; part 1: the kernels + the results back; 2: the results only; -1: all
+int build_subset_stats(mmp_ctx *c, SnapSide &N, const mmp_pod_row *d_pods, int32_t P, int64_t min_space, hipStream_t st, int part = -1)
 {
     const int32_t T = std::max(c->n_types, 1), Tw = div_up(T, 64);
-    N.pts_of.assign(P, -1);
-    N.pts_prohib.clear();
-    N.n_pts = 0;
-    N.pts_tw = Tw;
-    if (c->n_types > 0) {
-        std::map<std::vector<uint64_t>, int32_t> intern;
-        std::vector<uint64_t> sig(Tw);
-        const int32_t Wf = c->types_w;
-        for (int32_t p = 0; p < P; p++) {
-            if (c->pods[p].flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE)) continue;
-            std::fill(sig.begin(), sig.end(), 0);
-            for (int32_t t = 0; t < c->n_types; t++)
-                if (c->has_allowed[t] && !((c->allowed[(size_t)t * Wf + (p >> 6)] >> (p & 63)) & 1ull))
-                    sig[t >> 6] |= 1ull << (t & 63);
-            auto it = intern.find(sig);
-            if (it == intern.end()) {
-                it = intern.emplace(sig, N.n_pts++).first;
-                N.pts_prohib.insert(N.pts_prohib.end(), sig.begin(), sig.end());
+    if (part <= 0) {
+        N.pts_of.assign(P, -1);
+        N.pts_prohib.clear();
+        N.n_pts = 0;
+        N.pts_tw = Tw;
+        if (c->n_types > 0) {
+            std::map<std::vector<uint64_t>, int32_t> intern;
+            std::vector<uint64_t> sig(Tw);
+            const int32_t Wf = c->types_w;
+            for (int32_t p = 0; p < P; p++) {
+                if (c->pods[p].flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE)) continue;
+                std::fill(sig.begin(), sig.end(), 0);
+                for (int32_t t = 0; t < c->n_types; t++)
+                    if (c->has_allowed[t] && !((c->allowed[(size_t)t * Wf + (p >> 6)] >> (p & 63)) & 1ull))
+                        sig[t >> 6] |= 1ull << (t & 63);
+                auto it = intern.find(sig);
+                if (it == intern.end()) {
+                    it = intern.emplace(sig, N.n_pts++).first;
+                    N.pts_prohib.insert(N.pts_prohib.end(), sig.begin(), sig.end());
+                }
+                N.pts_of[p] = it->second;
             }
-            N.pts_of[p] = it->second;
         }
+        const int32_t NP = N.n_pts;
+        N.pstats_h.assign(NP + 1, StatsAcc{});
+        N.pstats_h[NP].global_lru = INT64_MAX;  // InstanceSetStatsTracker.EMPTY_STATS
+        N.tstats_h.assign(T, StatsAcc{});
+        HIP_TRY(c, N.d_pts.ensure(std::max<size_t>(P, 1) * 4));
+        HIP_TRY(c, N.d_prohib.ensure(std::max<size_t>((size_t)NP * Tw, 1) * 8));
+        HIP_TRY(c, N.pstats.ensure((size_t)(NP + 1) * sizeof(StatsAcc)));
+        HIP_TRY(c, N.tstats.ensure((size_t)T * sizeof(StatsAcc)));
+        if (P) HIP_TRY(c, hipMemcpyAsync(N.d_pts.p, N.pts_of.data(), (size_t)P * 4, hipMemcpyHostToDevice, st));
+        if (NP) HIP_TRY(c, hipMemcpyAsync(N.d_prohib.p, N.pts_prohib.data(), (size_t)NP * Tw * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipMemcpyAsync(N.pstats.p, N.pstats_h.data(), (size_t)(NP + 1) * sizeof(StatsAcc), hipMemcpyHostToDevice, st));
     }
-    const int32_t NP = N.n_pts;
-    N.pstats_h.assign(NP + 1, StatsAcc{});
-    N.pstats_h[NP].global_lru = INT64_MAX;  // InstanceSetStatsTracker.EMPTY_STATS
-    N.tstats_h.assign(T, StatsAcc{});
-    HIP_TRY(c, N.d_pts.ensure(std::max<size_t>(P, 1) * 4));
-    HIP_TRY(c, N.d_prohib.ensure(std::max<size_t>((size_t)NP * Tw, 1) * 8));
-    HIP_TRY(c, N.pstats.ensure((size_t)(NP + 1) * sizeof(StatsAcc)));
-    HIP_TRY(c, N.tstats.ensure((size_t)T * sizeof(StatsAcc)));
-    if (P) HIP_TRY(c, hipMemcpyAsync(N.d_pts.p, N.pts_of.data(), (size_t)P * 4, hipMemcpyHostToDevice, st));
-    if (NP) HIP_TRY(c, hipMemcpyAsync(N.d_prohib.p, N.pts_prohib.data(), (size_t)NP * Tw * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(N.pstats.p, N.pstats_h.data(), (size_t)(NP + 1) * sizeof(StatsAcc), hipMemcpyHostToDevice, st));
-    if (NP > 0 && P > 0)
-        hipLaunchKernelGGL(partition_stats_kernel, dim3(std::min(div_up(P, 256), 64)), dim3(256), 0, st, d_pods, P, min_space,
-                           N.d_pts.as<int32_t>(), NP, N.pstats.as<StatsAcc>());
-    hipLaunchKernelGGL(subset_stats_finish_kernel, dim3(div_up(std::max(NP, T), 256)), dim3(256), 0, st,
-                       N.stats_acc.as<StatsAcc>(), N.pstats.as<StatsAcc>(), NP, N.d_prohib.as<uint64_t>(), Tw, T,
-                       c->n_types > 0 ? N.d_has_allowed.as<uint8_t>() : nullptr, N.tstats.as<StatsAcc>());
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(N.pstats_h.data(), N.pstats.p, (size_t)(NP + 1) * sizeof(StatsAcc), hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(N.tstats_h.data(), N.tstats.p, (size_t)T * sizeof(StatsAcc), hipMemcpyDeviceToHost, st));
+    if (part != 0) {
+        const int32_t NP = N.n_pts;
+        if (part == 2) {
+            // (the kernels ran inside the commit's level launches)
+        } else if (NP > 0 && P > 0)
+            hipLaunchKernelGGL(partition_stats_kernel, dim3(std::min(div_up(P, 256), 64)), dim3(256), 0, st, d_pods, P, min_space,
+                               N.d_pts.as<int32_t>(), NP, N.pstats.as<StatsAcc>());
+        if (part != 2)
+            hipLaunchKernelGGL(subset_stats_finish_kernel, dim3(div_up(std::max(NP, T), 256)), dim3(256), 0, st,
+                               N.stats_acc.as<StatsAcc>(), N.pstats.as<StatsAcc>(), NP, N.d_prohib.as<uint64_t>(), Tw, T,
+                               c->n_types > 0 ? N.d_has_allowed.as<uint8_t>() : nullptr, N.tstats.as<StatsAcc>());
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(N.pstats_h.data(), N.pstats.p, (size_t)(NP + 1) * sizeof(StatsAcc), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(N.tstats_h.data(), N.tstats.p, (size_t)T * sizeof(StatsAcc), hipMemcpyDeviceToHost, st));
+    }
     return MMP_OK;
 }
 }  // namespace
@@ -1296,7 +1333,91 @@ try {
     HIP_TRY(c, c->d_prefer.ensure(std::max<size_t>((size_t)T * W, 1) * 8));
     HIP_TRY(c, N.d_has_allowed.ensure(T));
 
-    if (P) HIP_TRY(c, hipMemcpyAsync(B.pods.p, c->pods.data(), (size_t)P * sizeof(mmp_pod_row), hipMemcpyHostToDevice, st));
+    const int64_t min_space = c->cfg.min_space_units;
+    const int64_t churn2 = (int64_t)((uint64_t)c->cfg.min_churn_age_ms * 2u);
+    // is the literal comparator a strict total order on these rows?  (see snapshot.hpp "ranking by sorting")
+    bool versions_differ = false, full_low_lru = false, wide_count = false;
+    int32_t n_present = 0, n_nonfull = 0;
+    for (int32_t p = 0; p < P; p++) {
+        const mmp_pod_row &r = c->pods[p];
+        if (r.version != c->pods[0].version) versions_differ = true;
+        if (r.count > (1 << 30) || r.count < -(1 << 30)) wide_count = true;  // :4676 is an int subtraction
+        const uint64_t d = (uint64_t)r.capacity - (uint64_t)r.used;
+        const int64_t rem = (int64_t)d > 0 ? (int64_t)d : 0;
+        if (rem < min_space && r.lru_time <= churn2) full_low_lru = true;
+        if (!(r.flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE))) {
+            n_present++;
+            if (!(rem < min_space)) n_nonfull++;
+        }
+    }
+    const bool sort_legal = !(versions_differ && full_low_lru) && !wide_count;
+    // A few rows changed since the published snapshot, and both orders are total: re-rank by insertion (snapshot.hpp
+    // "a commit whose table differs ... in a few rows").  The unpublished set is rebuilt from the PUBLISHED one.
+    DeltaRows dl{};
+    std::vector<int32_t> new_order;
+    bool delta = false;
+    if (c->committed && !c->dirty_all && !c->no_delta && sort_legal && c->order_total && P >= 2 && P == c->snap.P) {
+        std::vector<int32_t> chg(c->dirty);
+        std::sort(chg.begin(), chg.end());
+        chg.erase(std::unique(chg.begin(), chg.end()), chg.end());
+        if ((int32_t)chg.size() <= kDeltaRows) {
+            const SnapBufs &A = c->sb[c->cur];
+            if (!c->h_order_valid) {  // the host's mirror of the published order, fetched when a delta first needs it
+                c->h_order.resize(P);
+                c->h_pos.resize(P);
+                HIP_TRY(c, copy_sync(c, c->h_order.data(), A.orig.p, (size_t)P * 4, hipMemcpyDeviceToHost));
+                for (int32_t q = 0; q < P; q++) c->h_pos[c->h_order[q]] = q;
+                c->h_order_valid = true;
+            }
+            const int32_t K = (int32_t)chg.size();
+            dl.K = K;
+            std::vector<int32_t> rem_sorted(K);
+            for (int32_t k = 0; k < K; k++) rem_sorted[k] = c->h_pos[chg[k]];
+            std::sort(rem_sorted.begin(), rem_sorted.end());
+            auto unchanged_at = [&](int32_t j) {  // the j-th row of the old order with the changed rows taken out
+                int32_t pos = j;
+                for (int32_t k = 0; k < K; k++)
+                    if (rem_sorted[k] <= pos) pos++;
+                return c->h_order[pos];
+            };
+            RankRow rr[kDeltaRows];
+            for (int32_t k = 0; k < K; k++) rr[k] = make_rank_row(c->pods[chg[k]], min_space);
+            for (int32_t k = 0; k < K; k++) {
+                int32_t lo = 0, hi = P - K;
+                while (lo < hi) {
+                    const int32_t mid = (lo + hi) >> 1;
+                    if (placement_less(make_rank_row(c->pods[unchanged_at(mid)], min_space), rr[k], churn2))
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                int32_t before = 0;
+                for (int32_t k2 = 0; k2 < K; k2++)
+                    if (k2 != k && placement_less(rr[k2], rr[k], churn2)) before++;
+                dl.pod[k] = chg[k];
+                dl.removed[k] = rem_sorted[k];
+                dl.ins[k] = lo;
+                dl.newrank[k] = lo + before;
+                dl.rows[k] = c->pods[chg[k]];
+            }
+            // the host mirror of the NEW order (published with the snapshot below)
+            new_order.assign(P, -1);
+            std::vector<uint8_t> is_chg(P, 0);
+            for (int32_t k = 0; k < K; k++) {
+                new_order[dl.newrank[k]] = chg[k];
+                is_chg[chg[k]] = 1;
+            }
+            int32_t w = 0;
+            for (int32_t q = 0; q < P; q++) {
+                const int32_t pod = c->h_order[q];
+                if (is_chg[pod]) continue;
+                while (new_order[w] >= 0) w++;
+                new_order[w++] = pod;
+            }
+            delta = true;
+        }
+    }
+    if (P && !delta) HIP_TRY(c, hipMemcpyAsync(B.pods.p, c->pods.data(), (size_t)P * sizeof(mmp_pod_row), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemsetAsync(c->rank.p, 0, padded * 4, st));
     HIP_TRY(c, hipMemsetAsync(c->occupancy.p, 0, padded * 4, st));
     HIP_TRY(c, hipMemsetAsync(c->flag.p, 0, sizeof(int32_t), st));
@@ -1321,8 +1442,6 @@ try {
     const int32_t n_rs = (int32_t)c->replaced_rs.size();
     if (n_rs) HIP_TRY(c, hipMemcpyAsync(c->rs_list.p, c->replaced_rs.data(), (size_t)n_rs * 4, hipMemcpyHostToDevice, st));
 
-    const int64_t min_space = c->cfg.min_space_units;
-    const int64_t churn2 = (int64_t)((uint64_t)c->cfg.min_churn_age_ms * 2u);
     StatsAcc init{};
     init.global_lru = INT64_MAX;
     HIP_TRY(c, hipMemcpyAsync(N.stats_acc.p, &init, sizeof init, hipMemcpyHostToDevice, st));
@@ -1351,30 +1470,25 @@ try {
     S.ctpos = P > 0 ? B.ctpos.as<int32_t>() : nullptr;
 
     bool next_long = c->long_mode == 1, next_full = false;
+    {  // the partitions of the type constraints (host) and their uploads: inputs, like the table itself
+        const int rc = build_subset_stats(c, N, B.pods.as<mmp_pod_row>(), P, min_space, st, 0);
+        if (rc != MMP_OK) return rc;
+    }
+    HIP_TRY(c, hipMemsetAsync(B.bslots.p, 0, kBSlots * sizeof(BSlot) + 16, st));
     KT_BEGIN(c, st);
     if (P > 0) {
-        // is the literal comparator a strict total order on these rows?  (see snapshot.hpp "ranking by sorting")
-        bool versions_differ = false, full_low_lru = false, wide_count = false;
-        int32_t n_present = 0, n_nonfull = 0;
-        for (int32_t p = 0; p < P; p++) {
-            const mmp_pod_row &r = c->pods[p];
-            if (r.version != c->pods[0].version) versions_differ = true;
-            if (r.count > (1 << 30) || r.count < -(1 << 30)) wide_count = true;  // :4676 is an int subtraction
-            const uint64_t d = (uint64_t)r.capacity - (uint64_t)r.used;
-            const int64_t rem = (int64_t)d > 0 ? (int64_t)d : 0;
-            if (rem < min_space && r.lru_time <= churn2) full_low_lru = true;
-            if (!(r.flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE))) {
-                n_present++;
-                if (!(rem < min_space)) n_nonfull++;
-            }
-        }
         // (nearly) every instance full: getNext is in its LRU-window mode and whole-table shortlists are common
         next_long = c->long_mode == 1 || (c->long_mode != 0 && n_present > 0 && n_nonfull * 16 <= n_present);
         next_full = n_present > 0 && n_nonfull * 16 <= n_present;
         // all-pairs is embarrassingly parallel and wins below ~8k pods (measured: 10k pods 172 us all-pairs vs 120 us
         // sort; 50k pods 4.3 ms vs 0.25 ms); a merge sort of a few thousand 64-byte keys is latency bound
         const bool want_sort = c->rank_mode == 2 || (c->rank_mode == 0 && P >= kRankSortMinPods);
-        if (want_sort && P >= 2 && !(versions_differ && full_low_lru) && !wide_count) {
+        if (delta) {
+            const SnapBufs &A = c->sb[c->cur];
+            hipLaunchKernelGGL(delta_scatter_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, A.pods.as<mmp_pod_row>(), A.pos_of.as<int32_t>(),
+                               P, dl, B.pods.as<mmp_pod_row>(), c->rank.as<int32_t>(), B.lru.as<int64_t>(), B.rem.as<int64_t>(),
+                               B.cnt.as<int32_t>(), B.rpm.as<int32_t>(), B.orig.as<int32_t>(), B.pos_of.as<int32_t>());
+        } else if (want_sort && P >= 2 && sort_legal) {
             HIP_TRY(c, c->rk_rows.ensure((size_t)P * sizeof(RankRow)));
             HIP_TRY(c, c->rk_idx.ensure((size_t)P * sizeof(RankRow)));
             const PlacementRowLess less{churn2};
@@ -1392,32 +1506,62 @@ try {
             hipLaunchKernelGGL(rank_pods_kernel, dim3(pb, slices), dim3(kRankBlock), 0, st, B.pods.as<mmp_pod_row>(), P,
                                min_space, churn2, slices, 0, P, c->rank.as<int32_t>());
         }
-        hipLaunchKernelGGL(scatter_pods_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(), P,
-                           min_space, c->rank.as<int32_t>(), c->occupancy.as<int32_t>(), B.lru.as<int64_t>(),
-                           B.rem.as<int64_t>(), B.cnt.as<int32_t>(), B.rpm.as<int32_t>(), B.orig.as<int32_t>(),
-                           B.pos_of.as<int32_t>(), c->flag.as<int32_t>());
-        hipLaunchKernelGGL(build_ge_kernel, dim3(div_up(kGeRows * W, 4)), dim3(256), 0, st, B.cnt.as<int32_t>(), P, W,
-                           B.ge.as<uint64_t>());
-        hipLaunchKernelGGL(build_ctpos_kernel, dim3(1), dim3(64), 0, st, B.cnt.as<int32_t>(), P, B.ctpos.as<int32_t>());
+        if (!delta)
+            hipLaunchKernelGGL(scatter_pods_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(), P,
+                               min_space, c->rank.as<int32_t>(), c->occupancy.as<int32_t>(), B.lru.as<int64_t>(),
+                               B.rem.as<int64_t>(), B.cnt.as<int32_t>(), B.rpm.as<int32_t>(), B.orig.as<int32_t>(),
+                               B.pos_of.as<int32_t>(), c->flag.as<int32_t>());
         if (n_rs)
             hipLaunchKernelGGL(mark_replaced_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(),
                                P, c->rs_list.as<int32_t>(), n_rs, c->rs_bad.as<uint8_t>());
-        const int waves = T * W;
-        hipLaunchKernelGGL(build_masks_kernel, dim3(div_up(waves, 4)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(), P,
-                           W, T, min_space, B.orig.as<int32_t>(), N.d_allowed.as<uint64_t>(),
-                           N.d_has_allowed.as<uint8_t>(), c->d_prefer.as<uint64_t>(), B.has_pref.as<uint8_t>(),
-                           n_rs ? c->rs_bad.as<uint8_t>() : nullptr, B.elig.as<uint64_t>(),
-                           B.elig_nors.as<uint64_t>(), B.pref.as<uint64_t>(), B.fullw.as<uint64_t>());
-        hipLaunchKernelGGL(build_prefix_kernel, dim3(2 * T), dim3(64), 0, st, B.elig.as<uint64_t>(), B.pref.as<uint64_t>(), T, W,
-                           B.pc.as<int32_t>(), B.ph.as<uint64_t>(), B.nz.as<int32_t>(), N.stats_acc.as<StatsAcc>());
-        hipLaunchKernelGGL(cluster_stats_kernel, dim3(std::min(div_up(P, 256), 512)), dim3(256), 0, st,
-                           B.pods.as<mmp_pod_row>(), P, min_space, N.stats_acc.as<StatsAcc>());
-        // the head window of every type row (place_kernel.hpp: TypeWin)
-        hipLaunchKernelGGL(build_wins_kernel, dim3(T), dim3(64), 0, st, S, B.heads.as<TypeWin>());
-        // case (b) on a full cluster: where it starts per preferring type, and the running minimum of the candidates' rpm
-        HIP_TRY(c, hipMemsetAsync(B.bslots.p, 0, kBSlots * sizeof(BSlot) + 16, st));
+        // level 1: everything that needs only the table and the rank-ordered columns, in ONE launch (place_kernel.hpp CommitL1)
+        CommitL1 L1{};
+        L1.pods = B.pods.as<mmp_pod_row>();
+        L1.P = P;
+        L1.W = W;
+        L1.T = T;
+        L1.min_space = min_space;
+        L1.orig = B.orig.as<int32_t>();
+        L1.cnt = B.cnt.as<int32_t>();
+        L1.allowed = N.d_allowed.as<uint64_t>();
+        L1.prefer = c->d_prefer.as<uint64_t>();
+        L1.has_allowed = N.d_has_allowed.as<uint8_t>();
+        L1.has_prefer = B.has_pref.as<uint8_t>();
+        L1.rs_bad = n_rs ? c->rs_bad.as<uint8_t>() : nullptr;
+        L1.elig = B.elig.as<uint64_t>();
+        L1.elig_nors = B.elig_nors.as<uint64_t>();
+        L1.pref = B.pref.as<uint64_t>();
+        L1.fullw = B.fullw.as<uint64_t>();
+        L1.ge = B.ge.as<uint64_t>();
+        L1.ctpos = B.ctpos.as<int32_t>();
+        L1.acc = N.stats_acc.as<StatsAcc>();
+        L1.pod_pts = N.d_pts.as<int32_t>();
+        L1.NP = N.n_pts;
+        L1.pstats = N.pstats.as<StatsAcc>();
+        L1.nb_masks = div_up(T * W, 4);
+        L1.nb_ge = div_up(kGeRows * W, 4);
+        L1.nb_stats = std::min(div_up(P, 256), 512);
+        L1.nb_pstats = N.n_pts > 0 ? std::min(div_up(P, 256), 64) : 0;
+        hipLaunchKernelGGL(commit_level1_kernel, dim3(L1.nb_stats + L1.nb_pstats + 1 + L1.nb_masks + L1.nb_ge), dim3(256), 0, st, L1);
+        // level 2: what needs the bitmaps / the stats: prefix tables, head windows (place_kernel.hpp: TypeWin), case (b) slots
+        // (where case (b) starts per preferring type), partition / type subset stats
         int32_t *n_bslots_dev = reinterpret_cast<int32_t *>(static_cast<char *>(B.bslots.p) + kBSlots * sizeof(BSlot));
-        hipLaunchKernelGGL(build_bslots_kernel, dim3(T), dim3(64), 0, st, S, B.pods.as<mmp_pod_row>(), B.bslots.as<BSlot>(), n_bslots_dev);
+        CommitL2 L2{};
+        L2.S = S;
+        L2.pods = B.pods.as<mmp_pod_row>();
+        L2.wins = B.heads.as<TypeWin>();
+        L2.slots = B.bslots.as<BSlot>();
+        L2.n_slots = n_bslots_dev;
+        L2.acc = N.stats_acc.as<StatsAcc>();
+        L2.pstats = N.pstats.as<StatsAcc>();
+        L2.NP = N.n_pts;
+        L2.Tw = N.pts_tw;
+        L2.prohib = N.d_prohib.as<uint64_t>();
+        L2.has_allowed = c->n_types > 0 ? N.d_has_allowed.as<uint8_t>() : nullptr;
+        L2.tstats = N.tstats.as<StatsAcc>();
+        L2.nb_finish = div_up(std::max(N.n_pts, T), 64);
+        hipLaunchKernelGGL(commit_level2_kernel, dim3(4 * T + L2.nb_finish), dim3(64), 0, st, L2);
+        // the running minimum of the case (b) candidates' rpm, then the survivor bitmaps of the rpm rule's four limits
         hipLaunchKernelGGL(prefix_min_rpm_kernel, dim3(kBSlots), dim3(64), 0, st, S, B.bslots.as<BSlot>(), n_bslots_dev, B.bpm.as<int32_t>(),
                            (int32_t)(W * 64));
         hipLaunchKernelGGL(build_bsurv_kernel, dim3(kBSlots), dim3(256), 0, st, S, B.bslots.as<BSlot>(), n_bslots_dev, B.bpm.as<int32_t>(),
@@ -1425,7 +1569,6 @@ try {
         HIP_TRY(c, hipGetLastError());
     } else {
         HIP_TRY(c, hipMemsetAsync(B.heads.p, 0, wins_bytes, st));
-        HIP_TRY(c, hipMemsetAsync(B.bslots.p, 0, kBSlots * sizeof(BSlot) + 16, st));
         HIP_TRY(c, hipMemsetAsync(B.pc.p, 0, (size_t)2 * T * (W + 1) * 4, st));
         HIP_TRY(c, hipMemsetAsync(B.nz.p, 0, (size_t)2 * T * (W + 1) * 4, st));
         HIP_TRY(c, hipMemsetAsync(B.ph.p, 0, (size_t)2 * T * (W + 1) * 8, st));
@@ -1436,7 +1579,7 @@ try {
         HIP_TRY(c, hipMemsetAsync(B.ge.p, 0, (size_t)kGeRows * W * 8, st));
     }
     {
-        const int rc = build_subset_stats(c, N, B.pods.as<mmp_pod_row>(), P, min_space, st);
+        const int rc = build_subset_stats(c, N, B.pods.as<mmp_pod_row>(), P, min_space, st, P > 0 ? 2 : 1);
         if (rc != MMP_OK) return rc;
     }
     KT_END(c, st);
@@ -1465,6 +1608,15 @@ try {
     // publish: the only part of a commit a decision can ever wait for
     std::lock_guard<std::shared_mutex> g(c->mu);
     resident_stop(c);  // it answers for the snapshot it was launched with; the next single request starts one on the new
+    c->order_total = sort_legal;
+    if (delta) {
+        c->h_order.swap(new_order);
+        for (int32_t q = 0; q < P; q++) c->h_pos[c->h_order[q]] = q;
+        c->n_delta_commits++;
+    } else
+        c->h_order_valid = false;
+    c->dirty.clear();
+    c->dirty_all = false;
     c->snap_long = next_long;
     c->snap_full = next_full;
     c->snap = S;
@@ -1480,6 +1632,14 @@ try {
     return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_snapshot_commit");
 } catch (const std::exception &e) {
     return fail(c, MMP_EHIP, "%s: %s", "mmp_snapshot_commit", e.what());
+}
+
+int mmp_delta_commits(mmp_ctx *c, int64_t *n_out)
+{
+    if (!c || !n_out) return fail(c, MMP_EINVAL, "mmp_delta_commits: null argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
+    *n_out = c->n_delta_commits;
+    return MMP_OK;
 }
 
 int mmp_get_order(mmp_ctx *c, int32_t *order_out, int32_t *n_out)
@@ -1663,6 +1823,7 @@ try {
     }
     const size_t old = c->pods.size();
     c->pods.resize(n_pods);
+    c->dirty_all = true;
     for (size_t i = 0; i < (size_t)n_pods; i++) {
         if (i >= old) {
             c->pods[i] = mmp_pod_row{};
@@ -1729,7 +1890,10 @@ try {
     HIP_TRY(c, hipStreamSynchronize(st));
     kt_collect(c);
     for (int32_t i = 0; i < n; i++) {
-        if (status_out[i] == 0) c->pods[pod_idx[i]] = rows[i];
+        if (status_out[i] == 0) {
+            c->pods[pod_idx[i]] = rows[i];
+            note_dirty(c, pod_idx[i]);
+        }
         if (start_time_out) start_time_out[i] = stt[i];
     }
     return MMP_OK;

@@ -285,9 +285,9 @@ __device__ __forceinline__ int first_lru_break(const uint64_t *ew, int start, in
 }
 
 // One wavefront per type row (see TypeWin).
-__global__ __launch_bounds__(64) void build_wins_kernel(Snap S, TypeWin *__restrict__ wins)
+__device__ __forceinline__ void build_wins_kernel_body(int bid, int nblk, Snap S, TypeWin *__restrict__ wins)
 {
-    const int t = blockIdx.x, lane = lane_id();
+    const int t = bid, lane = lane_id();
     const int P = S.P, W = S.W;
     const uint64_t *E = S.elig + (size_t)t * W;
     const uint64_t *Pm = S.pref + (size_t)t * W;
@@ -382,6 +382,10 @@ __global__ __launch_bounds__(64) void build_wins_kernel(Snap S, TypeWin *__restr
         out->flags = fl;
     }
 }
+__global__ __launch_bounds__(64) void build_wins_kernel(Snap S, TypeWin *__restrict__ wins)
+{
+    build_wins_kernel_body((int)blockIdx.x, (int)gridDim.x, S, wins);
+}
 
 // ---- case (b) of getNext on a full cluster (round 3) --------------------------------------------------------------
 // A type with preferred instances whose most desirable eligible instance is FULL and not preferred takes the non-simple
@@ -420,10 +424,10 @@ static_assert(sizeof(BSlot) == 32, "BSlot is 32 bytes");
 // One wavefront per type row: the slot of a preferring type (valid: type >= 0), in the order of the type rows.
 // `slots` = kBSlots rows, `n_slots` = how many are valid (written by the last type's wavefront: one launch, T blocks, so
 // the slot index is assigned by an atomic ticket and the table is sorted by nothing — a decision finds its slot by type).
-__global__ __launch_bounds__(64) void build_bslots_kernel(Snap S, const mmp_pod_row *__restrict__ pods, BSlot *__restrict__ slots,
+__device__ __forceinline__ void build_bslots_kernel_body(int bid, int nblk, Snap S, const mmp_pod_row *__restrict__ pods, BSlot *__restrict__ slots,
                                                           int32_t *__restrict__ n_slots)
 {
-    const int t = blockIdx.x, lane = lane_id();
+    const int t = bid, lane = lane_id();
     if (!S.has_pref[t]) return;
     const int P = S.P, W = S.W;
     const uint64_t *E = S.elig + (size_t)t * W, *Pm = S.pref + (size_t)t * W;
@@ -467,6 +471,95 @@ __global__ __launch_bounds__(64) void build_bslots_kernel(Snap S, const mmp_pod_
         b.pad = 0;
         slots[slot] = b;
     }
+}
+__global__ __launch_bounds__(64) void build_bslots_kernel(Snap S, const mmp_pod_row *__restrict__ pods, BSlot *__restrict__ slots,
+                                                          int32_t *__restrict__ n_slots)
+{
+    build_bslots_kernel_body((int)blockIdx.x, (int)gridDim.x, S, pods, slots, n_slots);
+}
+
+// ---- a commit as LEVELS of its dependency graph: every table build that needs only the rank-ordered columns runs in one launch,
+// every build that needs only those tables in the next (a commit is a dozen small builds, each a few microseconds of launch
+// latency when they queue one behind the other: 94 of the 170 us of a commit after a few changed rows) ----------------------------
+struct CommitL1 {
+    const mmp_pod_row *pods;
+    int32_t P, W, T;
+    int64_t min_space;
+    const int32_t *orig, *cnt;
+    const uint64_t *allowed, *prefer;
+    const uint8_t *has_allowed, *has_prefer, *rs_bad;
+    uint64_t *elig, *elig_nors, *pref, *fullw, *ge;
+    int32_t *ctpos;
+    StatsAcc *acc;
+    const int32_t *pod_pts;
+    int32_t NP;
+    StatsAcc *pstats;
+    int32_t nb_masks, nb_ge, nb_stats, nb_pstats;  // workgroups per part; one more builds ctpos
+};
+// level 1 (needs the scattered columns + the table): type bitmaps, count-threshold bitmaps, ctpos, cluster stats, partition stats
+__global__ __launch_bounds__(256) void commit_level1_kernel(CommitL1 A)
+{
+    int b = blockIdx.x;
+    if (b < A.nb_stats) {  // (the longest part first)
+        cluster_stats_kernel_body(b, A.nb_stats, A.pods, A.P, A.min_space, A.acc);
+        return;
+    }
+    b -= A.nb_stats;
+    if (b < A.nb_pstats) {
+        partition_stats_kernel_body(b, A.nb_pstats, A.pods, A.P, A.min_space, A.pod_pts, A.NP, A.pstats);
+        return;
+    }
+    b -= A.nb_pstats;
+    if (b == 0) {
+        build_ctpos_block(A.cnt, A.P, A.ctpos);
+        return;
+    }
+    b -= 1;
+    if (b < A.nb_masks) {
+        build_masks_kernel_body(b, A.nb_masks, A.pods, A.P, A.W, A.T, A.min_space, A.orig, A.allowed, A.has_allowed, A.prefer,
+                                A.has_prefer, A.rs_bad, A.elig, A.elig_nors, A.pref, A.fullw);
+        return;
+    }
+    b -= A.nb_masks;
+    build_ge_kernel_body(b, A.nb_ge, A.cnt, A.P, A.W, A.ge);
+}
+
+struct CommitL2 {
+    Snap S;
+    const mmp_pod_row *pods;
+    TypeWin *wins;
+    BSlot *slots;
+    int32_t *n_slots;
+    StatsAcc *acc;
+    StatsAcc *pstats;
+    int32_t NP, Tw;
+    const uint64_t *prohib;
+    const uint8_t *has_allowed;
+    StatsAcc *tstats;
+    int32_t nb_finish;
+};
+// level 2 (needs level 1): prefix tables (2T wavefronts), head windows (T), case-(b) slots (T), subset stats (partitions / types)
+__global__ __launch_bounds__(64) void commit_level2_kernel(CommitL2 A)
+{
+    int b = blockIdx.x;
+    const int T = A.S.T;
+    if (b < 2 * T) {
+        build_prefix_kernel_body(b, 2 * T, A.S.elig, A.S.pref, T, A.S.W, const_cast<int32_t *>(A.S.pc), const_cast<uint64_t *>(A.S.ph),
+                                 const_cast<int32_t *>(A.S.nz), A.acc);
+        return;
+    }
+    b -= 2 * T;
+    if (b < T) {
+        build_wins_kernel_body(b, T, A.S, A.wins);
+        return;
+    }
+    b -= T;
+    if (b < T) {
+        build_bslots_kernel_body(b, T, A.S, A.pods, A.slots, A.n_slots);
+        return;
+    }
+    b -= T;
+    subset_stats_finish_kernel_body(b, A.nb_finish, A.acc, A.pstats, A.NP, A.prohib, A.Tw, T, A.has_allowed, A.tstats);
 }
 
 // pm[slot][p] = min rpm over the preferred eligible positions in (best0, p]; INT32_MAX before the first one.

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kCompactBlock) void distinct_scatter_kernel(const i
 // that scans the histograms picks the map with the smaller fullest bucket.  Six dependent launches, every size read on the device:
 //   space (+ scalars) -> qualify: count, key range -> histograms (+ choice, scan) -> bin -> per-bucket rank (+ scan) -> emit (+ final)
 // A bucket above kPlanBucketMax under both maps (thousands of models on one millisecond) raises `overflow`: the sorted path runs.
-constexpr int kPlanBuckets = 16384, kPlanLinBits = 14, kPlanMantBits = 8, kPlanBucketMax = 512;
+constexpr int kPlanBuckets = 16384, kPlanLinBits = 14, kPlanMantBits = 8, kPlanBucketMax = 1024;
 
 // true in exactly one workgroup of the launch: the one that arrives last (its view includes every other workgroup's writes)
 __device__ __forceinline__ bool last_workgroup(unsigned int *ticket)
@@ -382,6 +382,20 @@ __device__ __forceinline__ int plan_bucket(int64_t key, const PlanScalars *ps)
     return ps->bucket_map ? plan_bucket_floating(age) : plan_bucket_linear(age, (uint64_t)ps->kmax - (uint64_t)ps->kmin);
 }
 
+// hist[b] += 1 for every lane with `on`, one atomic per DISTINCT bucket of the wavefront (a dense run of timestamps puts most
+// of a wavefront — under the losing map most of the registry — into one bucket: 30k same-address atomics took 0.5 ms)
+__device__ __forceinline__ void wave_hist_add(int32_t *__restrict__ hist, int b, bool on)
+{
+    uint64_t todo = __ballot(on);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const int b0 = __shfl(b, leader, 64);
+        const uint64_t same = __ballot(on && b == b0) & todo;
+        if (lane_id() == leader) atomicAdd(&hist[b0], (int32_t)__popcll(same));
+        todo &= ~same;
+    }
+}
+
 // exclusive scan of kPlanBuckets counts by one workgroup of 256; off[kPlanBuckets] = total, returned in every thread
 __device__ __forceinline__ int32_t bucket_scan(const int32_t *__restrict__ cnt, int32_t *__restrict__ off, int32_t *__restrict__ off2)
 {
@@ -416,14 +430,17 @@ __global__ __launch_bounds__(kCompactBlock) void proactive_hist_kernel(const mmp
 {
     __shared__ int32_t s_max[2];
     const int i = blockIdx.x * kCompactBlock + threadIdx.x;
+    bool q = false;
+    int bl = 0, bf = 0;
     if (ps->n_qualified > 0 && i < M) {
         const mmp_model_row m = models[i];
-        if (proactive_qualifies(m, i, U, ps)) {
-            const uint64_t age = (uint64_t)ps->kmax - (uint64_t)m.last_used;
-            atomicAdd(&hist_lin[plan_bucket_linear(age, (uint64_t)ps->kmax - (uint64_t)ps->kmin)], 1);
-            atomicAdd(&hist_flt[plan_bucket_floating(age)], 1);
-        }
+        q = proactive_qualifies(m, i, U, ps);
+        const uint64_t age = (uint64_t)ps->kmax - (uint64_t)m.last_used;
+        bl = q ? plan_bucket_linear(age, (uint64_t)ps->kmax - (uint64_t)ps->kmin) : 0;
+        bf = q ? plan_bucket_floating(age) : 0;
     }
+    wave_hist_add(hist_lin, bl, q);
+    wave_hist_add(hist_flt, bf, q);
     if (last_workgroup(&ps->ticket[1])) {
         if (threadIdx.x < 2) s_max[threadIdx.x] = 0;
         __syncthreads();
@@ -436,7 +453,10 @@ __global__ __launch_bounds__(kCompactBlock) void proactive_hist_kernel(const mmp
         atomicMax(&s_max[1], b);
         __syncthreads();
         const int map = s_max[1] < s_max[0] ? 1 : 0;
-        if (threadIdx.x == 0) ps->bucket_map = map;
+        if (threadIdx.x == 0) {
+            ps->bucket_map = map;
+            if (s_max[map] > kPlanBucketMax) ps->overflow = 1;  // the launches behind this one return at once
+        }
         bucket_scan(map ? hist_flt : hist_lin, off, cur);
     }
 }
@@ -447,7 +467,7 @@ __global__ __launch_bounds__(kCompactBlock) void proactive_bin_kernel(const mmp_
                                                                       int64_t *__restrict__ keys, int32_t *__restrict__ vals)
 {
     const int i = blockIdx.x * kCompactBlock + threadIdx.x;
-    if (ps->n_qualified <= 0 || i >= M) return;
+    if (ps->n_qualified <= 0 || ps->overflow || i >= M) return;
     const mmp_model_row m = models[i];
     if (!proactive_qualifies(m, i, U, ps)) return;
     const int dst = atomicAdd(&cur[plan_bucket(m.last_used, ps)], 1);
@@ -467,6 +487,7 @@ __global__ __launch_bounds__(256) void proactive_bucket_rank_kernel(const int64_
     const int wv = threadIdx.x >> 6, lane = lane_id();
     int64_t *s_key = s_key_all[wv];
     int32_t *s_val = s_val_all[wv];
+    if (ps->overflow) return;  // (uniform: set by the histogram launch)
     const int b = blockIdx.x * 4 + wv, lo = off[b], cnt = off[b + 1] - lo;
     int32_t starts = 0;
     if (cnt > kPlanBucketMax) {

@@ -73,13 +73,13 @@ static_assert(sizeof(RankRow) == 64, "RankRow is 64 bytes");
 __device__ __forceinline__ int64_t jsub64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
 __device__ __forceinline__ int64_t age_of(int64_t t, int64_t now) { return t == 0 ? 0 : jsub64(now, t); }
 
-__device__ __forceinline__ int64_t remaining_of(int64_t cap, int64_t used)
+__host__ __device__ __forceinline__ int64_t remaining_of(int64_t cap, int64_t used)
 {
     int64_t d = (int64_t)((uint64_t)cap - (uint64_t)used);
     return d > 0 ? d : 0;  // InstanceRecord.java:203-205
 }
 
-__device__ __forceinline__ RankRow make_rank_row(const mmp_pod_row &r, int64_t min_space)
+__host__ __device__ __forceinline__ RankRow make_rank_row(const mmp_pod_row &r, int64_t min_space)
 {
     RankRow o;
     o.vers = r.version;
@@ -217,11 +217,76 @@ __global__ void scatter_pods_kernel(const mmp_pod_row *__restrict__ pods, int32_
     pos_of[p] = pos;
 }
 
+// ---- a commit whose table differs from the published one in a few rows (handleInstanceTableChange: one InstanceRecord per
+// event, MM.java:1455-1568; the rate task republishes this instance's own row, :232) ------------------------------------------
+// PLACEMENT_ORDER compares two rows by their own fields, so the rows that did not change keep their relative order: the new
+// order = the old one with the K changed rows taken out and put back where the literal comparator places them.  The HOST does
+// the K binary searches against its mirror of the order (K * log2 P comparator calls, no dependent device loads) and hands
+// the kernel, by value: the old positions taken out (ascending), the insertion points among the unchanged rows, the changed
+// rows and their final ranks.  The kernel is the sort AND the scatter of a full commit in one pass over the table:
+//   unchanged row at old position q:  j = q - #{removed < q},  rank = j + #{insertion points <= j}
+constexpr int kDeltaRows = 16;
+struct DeltaRows {
+    int32_t K;
+    int32_t pod[kDeltaRows];      // the changed rows
+    int32_t removed[kDeltaRows];  // their old positions, ascending
+    int32_t ins[kDeltaRows];      // per changed row: how many UNCHANGED rows sort before it
+    int32_t newrank[kDeltaRows];  // per changed row: its position in the new order
+    mmp_pod_row rows[kDeltaRows];
+};
+
+__global__ __launch_bounds__(256) void delta_scatter_kernel(const mmp_pod_row *__restrict__ old_pods, const int32_t *__restrict__ old_pos_of,
+                                                            int32_t P, DeltaRows D, mmp_pod_row *__restrict__ pods,
+                                                            int32_t *__restrict__ rank, int64_t *__restrict__ lru,
+                                                            int64_t *__restrict__ rem, int32_t *__restrict__ cnt, int32_t *__restrict__ rpm,
+                                                            int32_t *__restrict__ orig, int32_t *__restrict__ pos_of)
+{
+    __shared__ int32_t s_pod[kDeltaRows], s_removed[kDeltaRows], s_ins[kDeltaRows];
+    if (threadIdx.x < kDeltaRows) {
+        const int k = threadIdx.x;
+        s_pod[k] = k < D.K ? D.pod[k] : -1;
+        s_removed[k] = k < D.K ? D.removed[k] : INT32_MAX;  // (never below a position)
+        s_ins[k] = k < D.K ? D.ins[k] : INT32_MAX;          // (never at or before a row)
+    }
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    mmp_pod_row r = old_pods[p];
+    const int q = old_pos_of[p];
+    int below = 0, mine = -1;
+#pragma unroll
+    for (int k = 0; k < kDeltaRows; k++) {
+        below += s_removed[k] < q ? 1 : 0;
+        mine = s_pod[k] == p ? k : mine;
+    }
+    int pos;
+    if (mine >= 0) {  // (a handful of threads of the launch)
+        for (int k = 0; k < D.K; k++)
+            if (k == mine) {
+                r = D.rows[k];
+                pos = D.newrank[k];
+            }
+    } else {
+        const int j = q - below;
+        pos = j;
+#pragma unroll
+        for (int k = 0; k < kDeltaRows; k++) pos += s_ins[k] <= j ? 1 : 0;
+    }
+    pods[p] = r;
+    rank[p] = pos;
+    lru[pos] = r.lru_time;
+    rem[pos] = remaining_of(r.capacity, r.used);
+    cnt[pos] = r.count;
+    rpm[pos] = r.rpm;
+    orig[pos] = p;
+    pos_of[p] = pos;
+}
+
 // One wave per (bitmap row, word): gather 64 per-pod predicates through the
 // rank permutation and ballot them into one rank-ordered word.
 //   allowed/prefer: [T][W] over pod index (or null = all / none)
 //   rs_bad: per pod, 1 if its replica set is "likely replaced"
-__global__ void build_masks_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int32_t W, int32_t T,
+__device__ __forceinline__ void build_masks_kernel_body(int bid, int nblk, const mmp_pod_row *__restrict__ pods, int32_t P, int32_t W, int32_t T,
                                    int64_t min_space, const int32_t *__restrict__ orig,
                                    const uint64_t *__restrict__ allowed,
                                    const uint8_t *__restrict__ has_allowed,
@@ -231,7 +296,7 @@ __global__ void build_masks_kernel(const mmp_pod_row *__restrict__ pods, int32_t
                                    uint64_t *__restrict__ elig_nors, uint64_t *__restrict__ pref,
                                    uint64_t *__restrict__ fullw)
 {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int wave = (bid * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= T * W) return;
     const int t = wave / W, w = wave - t * W;
@@ -257,11 +322,23 @@ __global__ void build_masks_kernel(const mmp_pod_row *__restrict__ pods, int32_t
         if (t == 0) fullw[w] = bf;
     }
 }
+__global__ void build_masks_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int32_t W, int32_t T,
+                                   int64_t min_space, const int32_t *__restrict__ orig,
+                                   const uint64_t *__restrict__ allowed,
+                                   const uint8_t *__restrict__ has_allowed,
+                                   const uint64_t *__restrict__ prefer,
+                                   const uint8_t *__restrict__ has_prefer,
+                                   const uint8_t *__restrict__ rs_bad, uint64_t *__restrict__ elig,
+                                   uint64_t *__restrict__ elig_nors, uint64_t *__restrict__ pref,
+                                   uint64_t *__restrict__ fullw)
+{
+    build_masks_kernel_body((int)blockIdx.x, (int)gridDim.x, pods, P, W, T, min_space, orig, allowed, has_allowed, prefer, has_prefer, rs_bad, elig, elig_nors, pref, fullw);
+}
 
 // ge[r][w] = ballot over the 64 rank positions of word w of (count >= kGeBase + r): one wave per (r, w)
-__global__ void build_ge_kernel(const int32_t *__restrict__ cnt, int32_t P, int32_t W, uint64_t *__restrict__ ge)
+__device__ __forceinline__ void build_ge_kernel_body(int bid, int nblk, const int32_t *__restrict__ cnt, int32_t P, int32_t W, uint64_t *__restrict__ ge)
 {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int wave = (bid * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= kGeRows * W) return;
     const int r = wave / W, w = wave - r * W;
@@ -269,24 +346,30 @@ __global__ void build_ge_kernel(const int32_t *__restrict__ cnt, int32_t P, int3
     const uint64_t b = __ballot(pos < P && cnt[pos] >= kGeBase + r);
     if (lane == 0) ge[(size_t)r * W + w] = b;
 }
-
-// Snap::ctpos: one wavefront.  The end of the non-decreasing head of the count column, then per threshold row a binary search
-// in it (lane r: threshold kGeBase + r).
-__global__ __launch_bounds__(64) void build_ctpos_kernel(const int32_t *__restrict__ cnt, int32_t P, int32_t *__restrict__ ctpos)
+__global__ void build_ge_kernel(const int32_t *__restrict__ cnt, int32_t P, int32_t W, uint64_t *__restrict__ ge)
 {
-    const int lane = threadIdx.x;
-    int mono_end = P;
-    for (int base = 0; base < P; base += 64) {
-        const int p = base + lane;
-        const bool viol = p >= 1 && p < P && cnt[p] < cnt[p - 1];
-        const uint64_t b = __ballot(viol);
-        if (b) {
-            mono_end = base + (__ffsll((unsigned long long)b) - 1);
+    build_ge_kernel_body((int)blockIdx.x, (int)gridDim.x, cnt, P, W, ge);
+}
+
+// Snap::ctpos: one workgroup.  The end of the non-decreasing head of the count column (first descent: a minimum over all
+// positions, every chunk of the column read at once), then per threshold row a binary search in it (thread r: kGeBase + r).
+constexpr int kCtposBlock = 1024;
+__device__ __forceinline__ void build_ctpos_block(const int32_t *__restrict__ cnt, int32_t P, int32_t *__restrict__ ctpos)
+{
+    __shared__ int32_t s_end;
+    if (threadIdx.x == 0) s_end = P;
+    __syncthreads();
+    int32_t first = P;
+    for (int p = 1 + (int)threadIdx.x; p < P; p += blockDim.x)
+        if (cnt[p] < cnt[p - 1]) {
+            first = p;  // (this thread's later positions are larger)
             break;
         }
-    }
-    if (lane < kGeRows) {
-        const int32_t thr = kGeBase + lane;
+    if (first < P) atomicMin(&s_end, first);
+    __syncthreads();
+    const int mono_end = s_end;
+    if (threadIdx.x < kGeRows) {
+        const int32_t thr = kGeBase + threadIdx.x;
         int lo = 0, hi = mono_end;  // first p in [0, mono_end) with cnt[p] >= thr
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
@@ -295,9 +378,13 @@ __global__ __launch_bounds__(64) void build_ctpos_kernel(const int32_t *__restri
             else
                 lo = mid + 1;
         }
-        ctpos[lane] = lo;
+        ctpos[threadIdx.x] = lo;
     }
-    if (lane == 0) ctpos[kGeRows] = mono_end;
+    if (threadIdx.x == 0) ctpos[kGeRows] = mono_end;
+}
+__global__ __launch_bounds__(kCtposBlock) void build_ctpos_kernel(const int32_t *__restrict__ cnt, int32_t P, int32_t *__restrict__ ctpos)
+{
+    build_ctpos_block(cnt, P, ctpos);
 }
 
 // rs_bad[p] = pod p's replica set is in the replaced list (MM.java:4769-4770)
@@ -323,12 +410,12 @@ struct StatsAcc {
     int32_t sparse_types;  // set by build_prefix_kernel: some type's eligible instances lie further apart than a lane scan reaches
 };
 
-__global__ void cluster_stats_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int64_t min_space,
+__device__ __forceinline__ void cluster_stats_kernel_body(int bid, int nblk, const mmp_pod_row *__restrict__ pods, int32_t P, int64_t min_space,
                                      StatsAcc *__restrict__ acc)
 {
     int64_t cap = 0, fre = 0, lru = INT64_MAX;
     int32_t n = 0, mc = 0;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+    for (int p = bid * blockDim.x + threadIdx.x; p < P; p += nblk * blockDim.x) {
         const mmp_pod_row r = pods[p];
         if (r.flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE)) continue;
         n++;
@@ -351,6 +438,11 @@ __global__ void cluster_stats_kernel(const mmp_pod_row *__restrict__ pods, int32
         atomicAdd(&acc->model_copy_count, mc);
     }
 }
+__global__ void cluster_stats_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int64_t min_space,
+                                     StatsAcc *__restrict__ acc)
+{
+    cluster_stats_kernel_body((int)blockIdx.x, (int)gridDim.x, pods, P, min_space, acc);
+}
 
 // ---- instance partitions and per-type subset stats (TypeConstraintManager) ---------------------------
 // With type constraints configured, ModelMesh does not use the cluster-wide ClusterStats everywhere:
@@ -366,7 +458,7 @@ __global__ void cluster_stats_kernel(const mmp_pod_row *__restrict__ pods, int32
 // Accumulated in LDS per workgroup first (a few partitions receive every pod: global atomics on the same
 // four words from 10k lanes were measured at 221 us), then one global atomic per touched partition and field.
 constexpr int kPtsLds = 512;  // partitions accumulated in LDS; beyond that, global atomics
-__global__ __launch_bounds__(256) void partition_stats_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int64_t min_space,
+__device__ __forceinline__ void partition_stats_kernel_body(int bid, int nblk, const mmp_pod_row *__restrict__ pods, int32_t P, int64_t min_space,
                                                               const int32_t *__restrict__ pod_pts, int32_t NP,
                                                               StatsAcc *__restrict__ pstats)
 {
@@ -380,7 +472,7 @@ __global__ __launch_bounds__(256) void partition_stats_kernel(const mmp_pod_row 
         }
         __syncthreads();
     }
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+    for (int p = bid * blockDim.x + threadIdx.x; p < P; p += nblk * blockDim.x) {
         const mmp_pod_row r = pods[p];
         if (r.flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE)) continue;
         const int k = pod_pts[p];
@@ -411,13 +503,19 @@ __global__ __launch_bounds__(256) void partition_stats_kernel(const mmp_pod_row 
         }
     }
 }
+__global__ __launch_bounds__(256) void partition_stats_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int64_t min_space,
+                                                              const int32_t *__restrict__ pod_pts, int32_t NP,
+                                                              StatsAcc *__restrict__ pstats)
+{
+    partition_stats_kernel_body((int)blockIdx.x, (int)gridDim.x, pods, P, min_space, pod_pts, NP, pstats);
+}
 
 // one thread per partition / per type row; global = the cluster-wide stats of the same snapshot
-__global__ void subset_stats_finish_kernel(const StatsAcc *__restrict__ global, StatsAcc *__restrict__ pstats, int32_t NP,
+__device__ __forceinline__ void subset_stats_finish_kernel_body(int bid, int nblk, const StatsAcc *__restrict__ global, StatsAcc *__restrict__ pstats, int32_t NP,
                                            const uint64_t *__restrict__ prohib, int32_t Tw, int32_t T,
                                            const uint8_t *__restrict__ has_allowed, StatsAcc *__restrict__ tstats)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = bid * blockDim.x + threadIdx.x;
     if (i < NP) pstats[i].global_lru = pstats[i].instance_count > 0 ? global->global_lru : INT64_MAX;
     if (i < T) {
         StatsAcc t = *global;
@@ -436,14 +534,20 @@ __global__ void subset_stats_finish_kernel(const StatsAcc *__restrict__ global, 
         tstats[i] = t;
     }
 }
+__global__ void subset_stats_finish_kernel(const StatsAcc *__restrict__ global, StatsAcc *__restrict__ pstats, int32_t NP,
+                                           const uint64_t *__restrict__ prohib, int32_t Tw, int32_t T,
+                                           const uint8_t *__restrict__ has_allowed, StatsAcc *__restrict__ tstats)
+{
+    subset_stats_finish_kernel_body((int)blockIdx.x, (int)gridDim.x, global, pstats, NP, prohib, Tw, T, has_allowed, tstats);
+}
 
 // pc / ph of Snap: one wavefront per (variant, type row), 64 words per step
-__global__ __launch_bounds__(64) void build_prefix_kernel(const uint64_t *__restrict__ elig, const uint64_t *__restrict__ pref,
+__device__ __forceinline__ void build_prefix_kernel_body(int bid, int nblk, const uint64_t *__restrict__ elig, const uint64_t *__restrict__ pref,
                                                           int32_t T, int32_t W, int32_t *__restrict__ pc,
                                                           uint64_t *__restrict__ ph, int32_t *__restrict__ nz,
                                                           StatsAcc *__restrict__ acc)
 {
-    const int v = blockIdx.x / T, t = blockIdx.x - v * T, lane = threadIdx.x;
+    const int v = bid / T, t = bid - v * T, lane = threadIdx.x;
     const uint64_t *E = elig + (size_t)t * W, *Pm = pref + (size_t)t * W;
     int32_t *PC = pc + ((size_t)v * T + t) * (W + 1);
     uint64_t *PH = ph + ((size_t)v * T + t) * (W + 1);
@@ -495,6 +599,13 @@ __global__ __launch_bounds__(64) void build_prefix_kernel(const uint64_t *__rest
         if (w < W) NZ[w] = m;
         carry_n = readlane_i32(m, 0);
     }
+}
+__global__ __launch_bounds__(64) void build_prefix_kernel(const uint64_t *__restrict__ elig, const uint64_t *__restrict__ pref,
+                                                          int32_t T, int32_t W, int32_t *__restrict__ pc,
+                                                          uint64_t *__restrict__ ph, int32_t *__restrict__ nz,
+                                                          StatsAcc *__restrict__ acc)
+{
+    build_prefix_kernel_body((int)blockIdx.x, (int)gridDim.x, elig, pref, T, W, pc, ph, nz, acc);
 }
 
 }  // namespace mmp

@@ -277,6 +277,12 @@ class Solver:
         self._ck(self.lib.mmp_get_order(self.h, ptr(out), C.byref(n)))
         return out[: n.value].copy()
 
+    def delta_commits(self) -> int:
+        """Commits of this context that re-ranked by insertion (a few changed rows) instead of sorting."""
+        n = C.c_int64(0)
+        self._ck(self.lib.mmp_delta_commits(self.h, C.byref(n)))
+        return n.value
+
     def stats(self) -> np.ndarray:
         out = np.zeros(1, dtype=STATS)
         self._ck(self.lib.mmp_cluster_stats(self.h, ptr(out)))

@@ -1,0 +1,84 @@
+"""GPU: a commit after a few changed rows re-ranks by insertion (delta_scatter_kernel: handleInstanceTableChange delivers one
+InstanceRecord per event, MM.java:1455-1568) — the same snapshot as ranking from scratch.  Two contexts take the same stream of
+table writes; one has the insertion path switched off (MMP_NO_DELTA=1).  After every commit: clusterState's order, the
+cluster stats and a batch of load-target decisions (chosen instance and audit hash) are equal."""
+import numpy as np
+import pytest
+
+from modelmesh_amd import _lib
+from modelmesh_amd import workload as wl
+from modelmesh_amd.solver import Solver
+
+pytestmark = pytest.mark.gpu
+
+
+def _mutate(rng, fleet, rows):
+    """A republished InstanceRecord: some of its fields move (sometimes across the full / not-full line, sometimes out of the set)."""
+    n = len(rows)
+    now = fleet.now
+    what = rng.integers(0, 8, n)
+    rows["used"] = np.where(what == 0, (rows["capacity"] * rng.choice([0.1, 0.5, 0.98, 1.02], n)).astype(np.int64), rows["used"])
+    rows["count"] = np.where(what == 1, rng.choice([0, 1, 9, 10, 11, 40], n), rows["count"])
+    rows["lru_time"] = np.where(what == 2, now - rng.choice([1_000, 46_000, 600_000, 86_400_000], n) - rng.integers(0, 3, n),
+                                rows["lru_time"])
+    rows["rpm"] = np.where(what == 3, rng.choice([0, 99, 100, 101, 1000], n), rows["rpm"])
+    rows["loading_in_progress"] = np.where(what == 4, rng.integers(0, 3, n), rows["loading_in_progress"])
+    fl = rows["flags"].copy()
+    fl = np.where(what == 5, fl ^ np.uint32(_lib.POD_SHUTTING_DOWN), fl)
+    rows["flags"] = fl
+    rows["capacity"] = np.where(what == 6, rows["capacity"] // 2 + 1, rows["capacity"])
+    # what == 7: the record is rewritten unchanged (a row that compares equal to its old self stays where it was)
+    return rows
+
+
+@pytest.mark.parametrize("seed,pods,models,versions", [(1, 300, 400, False), (2, 9000, 2000, False), (3, 700, 500, True),
+                                                      (4, 64, 100, False), (5, 9000, 1000, True)])
+def test_insertion_rerank_equals_ranking_from_scratch(monkeypatch, seed, pods, models, versions):
+    fleet = wl.fuzz_fleet(seed, pods=pods, models=models)
+    if not versions:
+        fleet.pods["version"] = 7  # one instanceVersion: PLACEMENT_ORDER is a total order whatever the rows hold
+    rng = np.random.default_rng(seed)
+    monkeypatch.setenv("MMP_NO_DELTA", "1")
+    full = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    monkeypatch.delenv("MMP_NO_DELTA")
+    ins = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        full.load_fleet(fleet)
+        ins.load_fleet(fleet)
+        reqs, extra = wl.make_requests(fleet, seed, n=min(models, 400))
+        table = fleet.pods.copy()
+        for step in range(60):
+            k = int(rng.choice([1, 1, 2, 5, 16, 17, 40])) if step % 7 else 1
+            idx = rng.choice(pods, size=min(k, pods), replace=False).astype(np.int32)
+            if step % 11 == 5:
+                idx = np.concatenate([idx, idx[:1]])  # the same row written twice between two commits
+            rows = _mutate(rng, fleet, table[idx].copy())
+            if versions and step % 9 == 3:
+                rows["version"] = rng.choice([1, 2, 3], len(rows))
+            table[idx] = rows
+            for s in (full, ins):
+                if step % 13 == 8:
+                    s.remove_pods(idx[:1])
+                s.upsert_pods(idx[1:] if step % 13 == 8 else idx, rows[1:] if step % 13 == 8 else rows)
+            if step % 13 == 8:
+                table["flags"][idx[0]] = (table["flags"][idx[0]] | _lib.POD_TOMBSTONE) & ~np.uint32(_lib.POD_LIVE)
+            rc = []
+            for s in (full, ins):
+                try:
+                    s.commit()
+                    rc.append(0)
+                except Exception as e:  # MMP_EORDER: both must refuse the same tables
+                    rc.append(getattr(e, "code", -1))
+            assert rc[0] == rc[1], (step, rc)
+            if rc[0]:
+                continue
+            assert np.array_equal(full.order(), ins.order()), step
+            assert full.stats().tobytes() == ins.stats().tobytes(), step
+            a = full.place(reqs, extra, fleet.now)
+            b = ins.place(reqs, extra, fleet.now)
+            assert np.array_equal(a["chosen"], b["chosen"]) and np.array_equal(a["hash"], b["hash"]), step
+        assert full.delta_commits() == 0
+        assert ins.delta_commits() >= (20 if not versions else 1), ins.delta_commits()
+    finally:
+        full.close()
+        ins.close()

@@ -41,6 +41,14 @@ pmc)
   timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python bench.py --kernel-only --steps 20 --warmup 2 --streams 1 > $OUT/pmc_fetch.log 2>&1
   timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python bench.py --kernel-only --steps 20 --warmup 2 --streams 1 > $OUT/pmc_write.log 2>&1
   python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write place_batch_kernel $OUT/pmc_place_batch_C3.json; cat $OUT/pmc_place_batch_C3.json ;;
+commit)
+  # per-kernel time of a commit after 16 changed rows and of a commit from scratch (C3, C4)
+  for wk in C3 C4; do for kind in delta full; do
+    rm -rf $OUT/commit_$wk$kind
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/commit_$wk$kind -- python tools/commit_breakdown.py $wk $kind 40 > $OUT/commit_${wk}_$kind.log 2>&1
+    f=$(find $OUT/commit_$wk$kind -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/commit_${wk}_${kind}_kernel_stats.csv
+    grep "commits" $OUT/commit_${wk}_$kind.log
+  done; done ;;
 sq)
   # SQ counters of one kernel of an arbitrary command: SQ_KERNEL=<substring> SQ_CMD="python ..." bash tools/gpu_round.sh sq
   rm -rf $OUT/sq1 $OUT/sq2
