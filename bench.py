@@ -748,9 +748,10 @@ def secondary_kernels_leg(fleet, solver, device: int, workload: str = "C3", reps
         per_request_kernels(800_000, " (800k per launch)")
 
         # a17 leader proactive-load plan over the whole registry
-        timed("proactive_plan (space reduction + compaction + radix sort + distinct top-K)",
-              lambda: solver.proactive_plan(6400, now, 4096), 24 * M, M, "registry rows scanned",
-              "device span incl. one host round trip for the qualified count; bytes = one pass over the model rows")
+        timed("proactive_plan (space reduction + key-range buckets + ranks by counting + distinct top-K)",
+              lambda: solver.proactive_plan(6400, now, 4096), 3 * 24 * M, M, "registry rows scanned",
+              "device span of eight dependent launches, no host read in the middle (round 3: 102 us with one); bytes = the three "
+              "passes over the model rows (qualify, histogram, bin)")
 
         # a12 + a13 stateful keyed caches: one clhm put + one read per cache (10k caches)
         keys = np.concatenate([np.arange(c, dtype=np.int32) for c in np.diff(cs.seg_off)]) if len(cs.cache_lu) else z32
@@ -767,7 +768,9 @@ def secondary_kernels_leg(fleet, solver, device: int, workload: str = "C3", reps
             solver.load_caches_keyed(cs.seg_off, cs.cache_lu, cs.cache_wt, keys, cs.cache_cap)
             solver.cache_replay(ops, now)
         timed("cache_replay_kernel", replay, int((32 * e_cache + 16).sum() + 64 * len(ops)), len(ops),
-              "cache operations", "16 B per deque entry read + 16 B written, 32 B per operation in + 32 B out")
+              "cache operations", "16 B per deque entry read + 16 B written, 32 B per operation in + 32 B out; caches of up to 48 / 160 "
+              "deque slots are replayed by 8- / 16-lane teams (8 / 4 caches per wavefront), larger ones by a wavefront each: a chain of "
+              "dependent steps per cache (table row -> entries + operation -> LDS deque -> result), not a stream")
 
         # f-1 KV wire format: Jackson JSON of the instance table and of the registry, parsed on device
         ids = wire.make_ids(rng, P)

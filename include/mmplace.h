@@ -649,7 +649,8 @@ int mmp_shard_place_fast_scatter_dev(mmp_ctx *ctx, int32_t n_rest, void *d_outs,
  * all-reduce and the finish kernel are enqueued on the context's stream and the call returns.  The batch is completed (its
  * rest count read, the six phases run if there is a rest) by the NEXT group call on the context — another batch, a commit —
  * or by mmp_shard_wait, which also returns the rest count.  Until then d_reqs / d_extra_pool / d_outs must stay valid and
- * d_outs must not be read.  Every shard of the group must issue the same sequence of calls.  (One shard, 100k decisions:
+ * d_outs must not be read: its rows are defined only once mmp_shard_wait (or a synchronous group call) has returned — those
+ * synchronise the context's stream; the rest count the library polls in between carries no ordering for the rows.  Every shard of the group must issue the same sequence of calls.  (One shard, 100k decisions:
  * 26 us per batch with the synchronisation, 14 us without: the device's own time.  The exchange words, flags and count of a
  * batch live in one of two slots, so the batch before is completed AFTER this one has been enqueued.) */
 int mmp_shard_unique_id(void *id_out);

@@ -554,9 +554,17 @@ __global__ __launch_bounds__(64) void cache_replay_kernel(ReplayArgs A, const in
     D.deficit = u.cache_deficit;
     D.ev = A.evicted + A.ev_off[c];
     D.nev = 0;
+    mmp_cache_op o = A.ops[o0];
+    int oi = A.op_order[o0];
     for (int q = o0; q < o1; q++) {
-        const mmp_cache_op o = A.ops[q];
-        const int oi = A.op_order[q];
+        // the next operation is fetched while this one runs on the LDS tile (a replay is a chain of dependent steps per cache:
+        // what can be taken off the chain is the global loads)
+        mmp_cache_op o_next = o;
+        int oi_next = oi;
+        if (q + 1 < o1) {
+            o_next = A.ops[q + 1];
+            oi_next = A.op_order[q + 1];
+        }
         const int ev0 = D.nev;
         const int32_t res = apply_op<TW>(D, o, A.now);
         const int ubi = u.reserved >= 0 ? dq_find<TW>(D, MMP_UNLOADBUF_KEY_C) : -1;
@@ -571,6 +579,8 @@ __global__ __launch_bounds__(64) void cache_replay_kernel(ReplayArgs A, const in
             A.outs[oi] = r;
         }
         wave_sync();
+        o = o_next;
+        oi = oi_next;
     }
     for (int i = lane; i < D.n; i += TW) {
         A.dst.lu[dn + i] = D.lu[D.head + i];

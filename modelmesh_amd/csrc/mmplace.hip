@@ -208,6 +208,9 @@ struct mmp_ctx {
     bool snap_long = false;  // the committed snapshot takes place_batch_long_kernel
     bool snap_full = false;  // ... because (nearly) all of its instances are full (not only because a type is sparse)
     // the rows written since the last commit (a commit of a few changed rows re-ranks by insertion: delta_scatter_kernel)
+    std::vector<int32_t> sig_of;    // per instance: id of its ProhibitedTypeSet among the distinct ones (valid while the type table stands)
+    std::vector<uint64_t> sig_rows;
+    bool sig_valid = false;
     std::vector<int32_t> dirty;
     bool dirty_all = true;          // the table was replaced / grew: the next commit ranks from scratch
     bool order_total = false;       // the published order came from a total order (sort-legal rows): unchanged rows keep their order
@@ -271,6 +274,7 @@ struct mmp_ctx {
     int ks_cur = 0;
     int32_t k_caches = 0;
     std::vector<int32_t> k_n;  // host mirror of the live entry counts
+    DevBuf r_part;  // per-workgroup partials of the proactive plan's first pass
     DevBuf k_cap, k_wsize, k_oldest, k_ubm, k_ops, k_order, k_opoff, k_outs, k_ev, k_evoff, k_ids;  // k_ids: cache ids grouped by replay team width
 
     // wire-format ingestion: per-pod id attributes and the hash tables the parsers probe
@@ -664,7 +668,7 @@ void mmp_destroy(mmp_ctx *c)
                       &c->models, &c->ent_pod, &c->ent_time, &c->c_seg,
                       &c->c_lu, &c->c_wt, &c->c_cap, &c->s_reqs, &c->s_outs, &c->s_extra, &c->s_a, &c->s_b,
                       &c->s_c, &c->s_d, &c->r_ps, &c->r_counts, &c->r_keys, &c->r_vals, &c->r_keys2, &c->r_vals2,
-                      &c->r_tmp, &c->r_out_model, &c->r_out_lu, &c->rt_sreqs, &c->rt_souts, &c->rt_cnt, &c->k_ids, &c->k_cap, &c->k_wsize, &c->k_oldest, &c->k_ubm, &c->k_ops, &c->k_order,
+                      &c->r_tmp, &c->r_part, &c->r_out_model, &c->r_out_lu, &c->rt_sreqs, &c->rt_souts, &c->rt_cnt, &c->k_ids, &c->k_cap, &c->k_wsize, &c->k_oldest, &c->k_ubm, &c->k_ops, &c->k_order,
                       &c->k_opoff, &c->k_outs, &c->k_ev, &c->k_evoff, &c->idtab_hash, &c->idtab_val, &c->tytab_hash,
                       &c->tytab_val, &c->j_buf, &c->j_off, &c->j_rows, &c->j_aux, &c->j_status, &c->j_cnt, &c->j_offs, &c->j_tmp_pod,
                       &c->j_tmp_time, &c->j_scan_tmp, &c->rk_rows, &c->rk_idx, &c->rk_tmp, &c->u_idx, &c->u_rows, &c->u_cnt, &c->u_offs, &c->u_tmp, &c->f_flags[0], &c->f_flags[1], &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp, &c->f_cnt[0], &c->f_cnt[1],
@@ -790,6 +794,7 @@ try {
     const int32_t W = div_up((int)c->pods.size(), 64);
     c->n_types = n_types;
     c->types_w = W;
+    c->sig_valid = false;
     const size_t words = (size_t)n_types * W;
     c->allowed.assign(words, 0);
     c->prefer.assign(words, 0);
@@ -856,6 +861,7 @@ try {
     // install as the type table of the next commit (same staging the host-bitmap entry point fills)
     c->n_types = R;
     c->types_w = W;
+    c->sig_valid = false;
     c->allowed.assign((size_t)R * W, 0);
     c->prefer.assign((size_t)R * W, 0);
     c->has_allowed.assign(R, 0);
@@ -1224,21 +1230,38 @@ int build_subset_stats(mmp_ctx *c, SnapSide &N, const mmp_pod_row *d_pods, int32
         N.n_pts = 0;
         N.pts_tw = Tw;
         if (c->n_types > 0) {
-            std::map<std::vector<uint64_t>, int32_t> intern;
-            std::vector<uint64_t> sig(Tw);
-            const int32_t Wf = c->types_w;
+            // every instance's ProhibitedTypeSet as an id of the distinct sets: a function of the type table alone, kept until
+            // that table is reloaded (interning P signatures of T bits through a map was most of a small commit's host time)
+            if (!c->sig_valid || (int32_t)c->sig_of.size() != P) {
+                std::map<std::vector<uint64_t>, int32_t> intern;
+                std::vector<uint64_t> sig(Tw);
+                const int32_t Wf = c->types_w;
+                c->sig_of.assign(P, 0);
+                c->sig_rows.clear();
+                for (int32_t p = 0; p < P; p++) {
+                    std::fill(sig.begin(), sig.end(), 0);
+                    for (int32_t t = 0; t < c->n_types; t++)
+                        if (c->has_allowed[t] && !((c->allowed[(size_t)t * Wf + (p >> 6)] >> (p & 63)) & 1ull))
+                            sig[t >> 6] |= 1ull << (t & 63);
+                    auto it = intern.find(sig);
+                    if (it == intern.end()) {
+                        it = intern.emplace(sig, (int32_t)intern.size()).first;
+                        c->sig_rows.insert(c->sig_rows.end(), sig.begin(), sig.end());
+                    }
+                    c->sig_of[p] = it->second;
+                }
+                c->sig_valid = true;
+            }
+            // partitions are numbered by first appearance among the instances PRESENT in this table
+            std::vector<int32_t> number(c->sig_rows.size() / std::max(Tw, 1), -1);
             for (int32_t p = 0; p < P; p++) {
                 if (c->pods[p].flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE)) continue;
-                std::fill(sig.begin(), sig.end(), 0);
-                for (int32_t t = 0; t < c->n_types; t++)
-                    if (c->has_allowed[t] && !((c->allowed[(size_t)t * Wf + (p >> 6)] >> (p & 63)) & 1ull))
-                        sig[t >> 6] |= 1ull << (t & 63);
-                auto it = intern.find(sig);
-                if (it == intern.end()) {
-                    it = intern.emplace(sig, N.n_pts++).first;
-                    N.pts_prohib.insert(N.pts_prohib.end(), sig.begin(), sig.end());
+                const int32_t sid = c->sig_of[p];
+                if (number[sid] < 0) {
+                    number[sid] = N.n_pts++;
+                    N.pts_prohib.insert(N.pts_prohib.end(), c->sig_rows.begin() + (size_t)sid * Tw, c->sig_rows.begin() + (size_t)(sid + 1) * Tw);
                 }
-                N.pts_of[p] = it->second;
+                N.pts_of[p] = number[sid];
             }
         }
         const int32_t NP = N.n_pts;
@@ -3734,19 +3757,22 @@ try {
     // The bucketed plan: six dependent launches, every size read on the device, ONE read of the result at the end.
     const int32_t n_cnt_words = 3 * (kPlanBuckets + 1) + 3 * kPlanBuckets;
     HIP_TRY(c, c->r_counts.ensure((size_t)std::max(n_cnt_words, nb + 1) * 4));
+    HIP_TRY(c, c->r_part.ensure((size_t)nb * sizeof(PlanPartial)));
     counts = c->r_counts.as<int32_t>();
-    int32_t *hist = counts, *hist2 = hist + kPlanBuckets, *off = hist2 + kPlanBuckets, *cur = off + kPlanBuckets + 1,
-            *dcnt = cur + kPlanBuckets + 1, *doff = dcnt + kPlanBuckets;
+    int32_t *hist = counts, *dcnt = hist + kPlanBuckets, *dge = dcnt + kPlanBuckets, *off = dge + kPlanBuckets,
+            *cur = off + kPlanBuckets + 1, *doff = cur + kPlanBuckets + 1;
+    PlanPartial *part = c->r_part.as<PlanPartial>();
     KT_BEGIN(c, st);  // device span of the whole plan
-    HIP_TRY(c, hipMemsetAsync(hist, 0, (size_t)2 * kPlanBuckets * 4, st));
     hipLaunchKernelGGL(proactive_space_scalars_kernel, dim3(std::min(std::max(div_up(P, 256), 1), 512)), dim3(256), 0, st, pods, P,
                        U, default_units, now, ps);
-    hipLaunchKernelGGL(proactive_qualify_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps);
-    hipLaunchKernelGGL(proactive_hist_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps, hist, hist2, off, cur);
+    hipLaunchKernelGGL(proactive_qualify_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps, part, hist);
+    hipLaunchKernelGGL(proactive_hist_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps, part, nb, hist);
+    hipLaunchKernelGGL(proactive_scan_kernel, dim3(1), dim3(kPlanScanBlock), 0, st, ps, hist, off, cur);
     hipLaunchKernelGGL(proactive_bin_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps, cur, c->r_keys.as<int64_t>(),
                        c->r_vals.as<int32_t>());
     hipLaunchKernelGGL(proactive_bucket_rank_kernel, dim3(kPlanBuckets / 4), dim3(256), 0, st, c->r_keys.as<int64_t>(),
-                       c->r_vals.as<int32_t>(), off, ps, c->r_vals2.as<int32_t>(), dcnt, doff);
+                       c->r_vals.as<int32_t>(), off, ps, c->r_vals2.as<int32_t>(), dcnt, dge);
+    hipLaunchKernelGGL(proactive_scan2_kernel, dim3(1), dim3(kPlanScanBlock), 0, st, ps, dcnt, dge, doff);
     hipLaunchKernelGGL(proactive_emit_kernel, dim3(nb), dim3(kCompactBlock), 0, st, c->r_keys.as<int64_t>(), c->r_vals.as<int32_t>(),
                        c->r_vals2.as<int32_t>(), doff, ps, max_out, c->r_out_model.as<int32_t>(), c->r_out_lu.as<int64_t>());
     KT_END(c, st);

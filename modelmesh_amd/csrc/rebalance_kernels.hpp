@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kCompactBlock) void distinct_scatter_kernel(const i
 // that scans the histograms picks the map with the smaller fullest bucket.  Six dependent launches, every size read on the device:
 //   space (+ scalars) -> qualify: count, key range -> histograms (+ choice, scan) -> bin -> per-bucket rank (+ scan) -> emit (+ final)
 // A bucket above kPlanBucketMax under both maps (thousands of models on one millisecond) raises `overflow`: the sorted path runs.
-constexpr int kPlanBuckets = 16384, kPlanLinBits = 14, kPlanMantBits = 8, kPlanBucketMax = 1024;
+constexpr int kPlanBuckets = 16384, kPlanLinBits = 14, kPlanMantBits = 8, kPlanBucketMax = 1024, kPlanLdsBucket = 256;
 
 // true in exactly one workgroup of the launch: the one that arrives last (its view includes every other workgroup's writes)
 __device__ __forceinline__ bool last_workgroup(unsigned int *ticket)
@@ -315,8 +315,6 @@ __global__ __launch_bounds__(256) void proactive_space_scalars_kernel(const mmp_
     if (last_workgroup(&ps->ticket[0]) && threadIdx.x == 0) {
         const unsigned long long acc = __hip_atomic_load(&ps->space_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         proactive_scalars(U, default_units, now, ps, acc);
-        ps->kmin = INT64_MAX;
-        ps->kmax = INT64_MIN;
     }
 }
 
@@ -336,11 +334,21 @@ __device__ __forceinline__ int64_t wave_max_i64(int64_t v)
     return v;
 }
 
-// pass 1 over the registry: how many candidates / qualified, and the qualified keys' range
+// Per-workgroup partials of pass 1 (no atomics: a few thousand wavefronts adding into one cache line serialise at ~7 ns each)
+struct PlanPartial {
+    int32_t n_cand, n_qual;
+    long long kmin, kmax;
+    double key_sum;  // of the qualified keys (only to choose the bucket map)
+};
+
+// pass 1 over the registry: how many candidates / qualified, and the qualified keys' range — per workgroup
 __global__ __launch_bounds__(kCompactBlock) void proactive_qualify_kernel(const mmp_model_row *__restrict__ models, int32_t M,
-                                                                          PlanSubset U, PlanScalars *ps)
+                                                                          PlanSubset U, const PlanScalars *ps, PlanPartial *__restrict__ part,
+                                                                          int32_t *__restrict__ hist)
 {
+    __shared__ PlanPartial s_w[kCompactBlock / 64];
     const int i = blockIdx.x * kCompactBlock + threadIdx.x;
+    for (int k = i; k < kPlanBuckets; k += gridDim.x * kCompactBlock) hist[k] = 0;  // (the next launch's histogram)
     bool cand = false, q = false;
     int64_t lu = 0;
     if (i < M) {
@@ -349,17 +357,79 @@ __global__ __launch_bounds__(kCompactBlock) void proactive_qualify_kernel(const 
         cand = proactive_candidate(m, ps);
         q = cand && proactive_qualifies(m, i, U, ps);
     }
-    const uint64_t bq = __ballot(q);
-    const int nc = __popcll(__ballot(cand));
+    const int nq = __popcll(__ballot(q)), nc = __popcll(__ballot(cand));
     const int64_t lo = wave_min_i64(q ? lu : INT64_MAX), hi = wave_max_i64(q ? lu : INT64_MIN);
-    if (lane_id() == 0) {
-        if (nc) atomicAdd(&ps->n_candidates, nc);
-        if (bq) {
-            atomicAdd(&ps->n_qualified, __popcll(bq));
-            atomicMin(&ps->kmin, (long long)lo);
-            atomicMax(&ps->kmax, (long long)hi);
+    double sum = q ? (double)lu : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane_id() == 0) s_w[threadIdx.x >> 6] = PlanPartial{nc, nq, lo, hi, sum};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        PlanPartial t = s_w[0];
+        for (int w = 1; w < kCompactBlock / 64; w++) {
+            t.n_cand += s_w[w].n_cand;
+            t.n_qual += s_w[w].n_qual;
+            t.kmin = s_w[w].kmin < t.kmin ? s_w[w].kmin : t.kmin;
+            t.kmax = s_w[w].kmax > t.kmax ? s_w[w].kmax : t.kmax;
+            t.key_sum += s_w[w].key_sum;
+        }
+        part[blockIdx.x] = t;
+    }
+}
+
+// Every workgroup of the next launch folds the partials itself (a few hundred rows from L2: cheaper than a launch of its own);
+// workgroup 0 also stores the totals and the map choice in `ps`.  The map: timestamps dense near the newest with a long tail
+// (mean age far below half the range) -> floating; spread over the range -> linear.
+struct PlanRange {
+    int64_t kmin, kmax;
+    int32_t n_qual, map;
+};
+__device__ __forceinline__ PlanRange plan_fold(const PlanPartial *__restrict__ part, int nb, PlanScalars *ps, bool store)
+{
+    __shared__ PlanPartial s_f[kCompactBlock / 64];
+    __shared__ PlanRange s_r;
+    PlanPartial t{0, 0, INT64_MAX, INT64_MIN, 0.0};
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) {
+        const PlanPartial v = part[k];
+        t.n_cand += v.n_cand;
+        t.n_qual += v.n_qual;
+        t.kmin = v.kmin < t.kmin ? v.kmin : t.kmin;
+        t.kmax = v.kmax > t.kmax ? v.kmax : t.kmax;
+        t.key_sum += v.key_sum;
+    }
+    t.n_cand = wave_sum_i32(t.n_cand);
+    t.n_qual = wave_sum_i32(t.n_qual);
+    t.kmin = wave_min_i64(t.kmin);
+    t.kmax = wave_max_i64(t.kmax);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t.key_sum += __shfl_xor(t.key_sum, o, 64);
+    if (lane_id() == 0) s_f[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) {
+            t.n_cand += s_f[w].n_cand;
+            t.n_qual += s_f[w].n_qual;
+            t.kmin = s_f[w].kmin < t.kmin ? s_f[w].kmin : t.kmin;
+            t.kmax = s_f[w].kmax > t.kmax ? s_f[w].kmax : t.kmax;
+            t.key_sum += s_f[w].key_sum;
+        }
+        int map = 0;
+        if (t.n_qual > 0) {
+            const double range = (double)((uint64_t)t.kmax - (uint64_t)t.kmin);
+            const double mean_age = (double)t.kmax - t.key_sum / (double)t.n_qual;
+            map = mean_age * 8.0 < range ? 1 : 0;
+        }
+        s_r = PlanRange{t.kmin, t.kmax, t.n_qual, map};
+        if (store) {
+            ps->n_candidates = t.n_cand;
+            ps->n_qualified = t.n_qual;
+            ps->kmin = t.kmin;
+            ps->kmax = t.kmax;
+            ps->bucket_map = map;
         }
     }
+    __syncthreads();
+    return s_r;
 }
 
 // buckets of a qualified key, 0 = the newest; both monotone in the key, so equal keys share a bucket and the buckets are in
@@ -376,14 +446,14 @@ __device__ __forceinline__ int plan_bucket_floating(uint64_t age)
     const int e = 63 - __builtin_clzll(age);  // >= m
     return ((e - m + 1) << m) + (int)((age >> (e - m)) & ((1u << m) - 1));  // < (64 - m + 1) << m = 14592
 }
-__device__ __forceinline__ int plan_bucket(int64_t key, const PlanScalars *ps)
+__device__ __forceinline__ int plan_bucket_of(int64_t key, int64_t kmin, int64_t kmax, int map)
 {
-    const uint64_t age = (uint64_t)ps->kmax - (uint64_t)key;
-    return ps->bucket_map ? plan_bucket_floating(age) : plan_bucket_linear(age, (uint64_t)ps->kmax - (uint64_t)ps->kmin);
+    const uint64_t age = (uint64_t)kmax - (uint64_t)key;
+    return map ? plan_bucket_floating(age) : plan_bucket_linear(age, (uint64_t)kmax - (uint64_t)kmin);
 }
+__device__ __forceinline__ int plan_bucket(int64_t key, const PlanScalars *ps) { return plan_bucket_of(key, ps->kmin, ps->kmax, ps->bucket_map); }
 
-// hist[b] += 1 for every lane with `on`, one atomic per DISTINCT bucket of the wavefront (a dense run of timestamps puts most
-// of a wavefront — under the losing map most of the registry — into one bucket: 30k same-address atomics took 0.5 ms)
+// hist[b] += 1 for every lane with `on`, one atomic per DISTINCT bucket of the wavefront
 __device__ __forceinline__ void wave_hist_add(int32_t *__restrict__ hist, int b, bool on)
 {
     uint64_t todo = __ballot(on);
@@ -396,69 +466,79 @@ __device__ __forceinline__ void wave_hist_add(int32_t *__restrict__ hist, int b,
     }
 }
 
-// exclusive scan of kPlanBuckets counts by one workgroup of 256; off[kPlanBuckets] = total, returned in every thread
-__device__ __forceinline__ int32_t bucket_scan(const int32_t *__restrict__ cnt, int32_t *__restrict__ off, int32_t *__restrict__ off2)
-{
-    __shared__ int32_t wtot[4];
-    constexpr int per = kPlanBuckets / 256;
-    int32_t mine = 0;
-    for (int k = 0; k < per; k++) mine += cnt[threadIdx.x * per + k];
-    const int32_t incl = wave_incl_scan_i32(mine);
-    __syncthreads();
-    if (lane_id() == 63) wtot[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    int32_t before = incl - mine, total = 0;
-    for (int w = 0; w < 4; w++) {
-        if (w < (int)(threadIdx.x >> 6)) before += wtot[w];
-        total += wtot[w];
-    }
-    for (int k = 0; k < per; k++) {
-        const int32_t v = cnt[threadIdx.x * per + k];
-        off[threadIdx.x * per + k] = before;
-        if (off2) off2[threadIdx.x * per + k] = before;
-        before += v;
-    }
-    if (threadIdx.x == 255) off[kPlanBuckets] = total;
-    return total;
-}
-
-// pass 2: both histograms; the last workgroup picks the map and scans its histogram (off = bucket starts, cur = bin cursors)
+// pass 2: the histogram of the chosen map
 __global__ __launch_bounds__(kCompactBlock) void proactive_hist_kernel(const mmp_model_row *__restrict__ models, int32_t M, PlanSubset U,
-                                                                       PlanScalars *ps, int32_t *__restrict__ hist_lin,
-                                                                       int32_t *__restrict__ hist_flt, int32_t *__restrict__ off,
-                                                                       int32_t *__restrict__ cur)
+                                                                       PlanScalars *ps, const PlanPartial *__restrict__ part, int nb,
+                                                                       int32_t *__restrict__ hist)
 {
-    __shared__ int32_t s_max[2];
+    const PlanRange R = plan_fold(part, nb, ps, blockIdx.x == 0);
+    if (R.n_qual <= 0) return;
     const int i = blockIdx.x * kCompactBlock + threadIdx.x;
     bool q = false;
-    int bl = 0, bf = 0;
-    if (ps->n_qualified > 0 && i < M) {
+    int b = 0;
+    if (i < M) {
         const mmp_model_row m = models[i];
         q = proactive_qualifies(m, i, U, ps);
-        const uint64_t age = (uint64_t)ps->kmax - (uint64_t)m.last_used;
-        bl = q ? plan_bucket_linear(age, (uint64_t)ps->kmax - (uint64_t)ps->kmin) : 0;
-        bf = q ? plan_bucket_floating(age) : 0;
+        b = q ? plan_bucket_of(m.last_used, R.kmin, R.kmax, R.map) : 0;
     }
-    wave_hist_add(hist_lin, bl, q);
-    wave_hist_add(hist_flt, bf, q);
-    if (last_workgroup(&ps->ticket[1])) {
-        if (threadIdx.x < 2) s_max[threadIdx.x] = 0;
-        __syncthreads();
-        int32_t a = 0, b = 0;
-        for (int k = threadIdx.x; k < kPlanBuckets; k += kCompactBlock) {
-            a = max(a, hist_lin[k]);
-            b = max(b, hist_flt[k]);
-        }
-        atomicMax(&s_max[0], a);
-        atomicMax(&s_max[1], b);
-        __syncthreads();
-        const int map = s_max[1] < s_max[0] ? 1 : 0;
-        if (threadIdx.x == 0) {
-            ps->bucket_map = map;
-            if (s_max[map] > kPlanBucketMax) ps->overflow = 1;  // the launches behind this one return at once
-        }
-        bucket_scan(map ? hist_flt : hist_lin, off, cur);
+    wave_hist_add(hist, b, q);
+}
+
+// exclusive scan of kPlanBuckets counts by ONE workgroup of 1024; off[kPlanBuckets] = total, returned in every thread;
+// *max_out = the fullest bucket
+constexpr int kPlanScanBlock = 1024;
+__device__ __forceinline__ int32_t bucket_scan(const int32_t *__restrict__ cnt, int32_t *__restrict__ off, int32_t *__restrict__ off2,
+                                               int32_t *max_out)
+{
+    __shared__ int32_t wtot[kPlanScanBlock / 64], wmax[kPlanScanBlock / 64];
+    constexpr int per = kPlanBuckets / kPlanScanBlock;
+    static_assert(per % 4 == 0, "a thread's counts are read as int4");
+    int32_t v[per], mine = 0, mx = 0;
+#pragma unroll
+    for (int k = 0; k < per; k += 4) {
+        const int4 x = reinterpret_cast<const int4 *>(cnt)[(threadIdx.x * per + k) >> 2];
+        v[k] = x.x;
+        v[k + 1] = x.y;
+        v[k + 2] = x.z;
+        v[k + 3] = x.w;
     }
+#pragma unroll
+    for (int k = 0; k < per; k++) {
+        mine += v[k];
+        mx = v[k] > mx ? v[k] : mx;
+    }
+    const int32_t incl = wave_incl_scan_i32(mine);
+    mx = (int32_t)wave_max_i64(mx);
+    if (lane_id() == 63) wtot[threadIdx.x >> 6] = incl;
+    if (lane_id() == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    int32_t before = incl - mine, total = 0, m2 = 0;
+    for (int w = 0; w < kPlanScanBlock / 64; w++) {
+        if (w < (int)(threadIdx.x >> 6)) before += wtot[w];
+        total += wtot[w];
+        m2 = wmax[w] > m2 ? wmax[w] : m2;
+    }
+#pragma unroll
+    for (int k = 0; k < per; k += 4) {
+        int4 o;
+        o.x = before;
+        o.y = o.x + v[k];
+        o.z = o.y + v[k + 1];
+        o.w = o.z + v[k + 2];
+        before = o.w + v[k + 3];
+        reinterpret_cast<int4 *>(off)[(threadIdx.x * per + k) >> 2] = o;
+        if (off2) reinterpret_cast<int4 *>(off2)[(threadIdx.x * per + k) >> 2] = o;
+    }
+    if (threadIdx.x == kPlanScanBlock - 1) off[kPlanBuckets] = total;
+    if (max_out) *max_out = m2;
+    return total;
+}
+__global__ __launch_bounds__(kPlanScanBlock) void proactive_scan_kernel(PlanScalars *ps, const int32_t *__restrict__ hist,
+                                                                        int32_t *__restrict__ off, int32_t *__restrict__ cur)
+{
+    int32_t fullest = 0;
+    bucket_scan(hist, off, cur, &fullest);
+    if (threadIdx.x == 0 && fullest > kPlanBucketMax) ps->overflow = 1;  // the launches behind this one return at once
 }
 
 // pass 3: the qualified (lastUsed, model) pairs into their buckets (any order inside a bucket: ranks are counted, not sorted)
@@ -475,33 +555,75 @@ __global__ __launch_bounds__(kCompactBlock) void proactive_bin_kernel(const mmp_
     vals[dst] = i;
 }
 
+// a bucket above the LDS tile: one wavefront, the pairs read from global memory (L2) on every pass; rank[] carries the
+// run-start flags between the two passes (-1 = duplicate; a run start's rank is >= 0 before and after it is counted)
+__device__ __forceinline__ void rank_heavy_bucket(const int64_t *__restrict__ keys, const int32_t *__restrict__ vals, int cnt, int64_t cutoff,
+                                                  int32_t *rank, int32_t *__restrict__ dcnt, int32_t *__restrict__ dge)
+{
+    const int lane = lane_id();
+    int32_t starts = 0, ge = 0;
+    for (int e = lane; e < cnt; e += 64) {
+        const int64_t key = keys[e];
+        const int32_t val = vals[e];
+        bool first = true;
+        for (int j = 0; j < cnt; j++) first &= !(keys[j] == key && vals[j] < val);
+        rank[e] = first ? 0 : -1;
+        starts += first ? 1 : 0;
+        ge += (first && key >= cutoff) ? 1 : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int e = lane; e < cnt; e += 64) {
+        if (__hip_atomic_load(&rank[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 0) continue;
+        const int64_t key = keys[e];
+        int32_t r = 0;
+        for (int j = 0; j < cnt; j++)
+            r += (keys[j] > key && __hip_atomic_load(&rank[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= 0) ? 1 : 0;
+        __hip_atomic_store(&rank[e], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    starts = wave_sum_i32(starts);
+    ge = wave_sum_i32(ge);
+    if (lane == 0) {
+        *dcnt = starts;
+        *dge = ge;
+    }
+}
+
 // one WAVEFRONT per bucket (four buckets per workgroup): an entry is a run start if no equal key has a lower model index (the
 // TreeSet's first one seen); its local rank = run starts of the bucket with a larger key.  rank[pos] = local rank, -1 = duplicate.
+// dcnt[b] = run starts of the bucket, dge[b] = those of them at or above the cutoff.
 __global__ __launch_bounds__(256) void proactive_bucket_rank_kernel(const int64_t *__restrict__ keys, const int32_t *__restrict__ vals,
-                                                                    const int32_t *__restrict__ off, PlanScalars *ps,
+                                                                    const int32_t *__restrict__ off, const PlanScalars *ps,
                                                                     int32_t *__restrict__ rank, int32_t *__restrict__ dcnt,
-                                                                    int32_t *__restrict__ doff)
+                                                                    int32_t *__restrict__ dge)
 {
-    __shared__ int64_t s_key_all[4][kPlanBucketMax];
-    __shared__ int32_t s_val_all[4][kPlanBucketMax];
+    __shared__ int64_t s_key_all[4][kPlanLdsBucket];
+    __shared__ int32_t s_val_all[4][kPlanLdsBucket];
+    if (ps->overflow) return;
     const int wv = threadIdx.x >> 6, lane = lane_id();
     int64_t *s_key = s_key_all[wv];
     int32_t *s_val = s_val_all[wv];
-    if (ps->overflow) return;  // (uniform: set by the histogram launch)
     const int b = blockIdx.x * 4 + wv, lo = off[b], cnt = off[b + 1] - lo;
-    int32_t starts = 0;
-    if (cnt > kPlanBucketMax) {
-        if (lane == 0) ps->overflow = 1;
-    } else if (cnt == 1) {
-        if (lane == 0) rank[lo] = 0;
-        starts = lane == 0;
-    } else if (cnt > 1) {
+    if (cnt > kPlanLdsBucket && cnt <= kPlanBucketMax) {  // a heavy bucket (rare): the same counting, the bucket read from L2
+        rank_heavy_bucket(keys + lo, vals + lo, cnt, ps->cutoff, rank + lo, dcnt + b, dge + b);
+        return;
+    }
+    const int64_t cutoff = ps->cutoff;
+    int32_t starts = 0, ge = 0;
+    if (cnt == 1) {
+        if (lane == 0) {
+            rank[lo] = 0;
+            starts = 1;
+            ge = keys[lo] >= cutoff;
+        }
+    } else if (cnt > 1 && cnt <= kPlanLdsBucket) {
         for (int j = lane; j < cnt; j += 64) {
             s_key[j] = keys[lo + j];
             s_val[j] = vals[lo + j];
         }
         wave_sync();
-        constexpr int per = kPlanBucketMax / 64;
+        constexpr int per = kPlanLdsBucket / 64;
         uint32_t first = 0;
         for (int k = 0; k < per && k * 64 < cnt; k++) {
             const int e = lane + k * 64;
@@ -528,48 +650,65 @@ __global__ __launch_bounds__(256) void proactive_bucket_rank_kernel(const int64_
                 r = 0;
                 for (int j = 0; j < cnt; j++) r += (s_val[j] >= 0 && s_key[j] > key) ? 1 : 0;
                 starts++;
+                ge += key >= cutoff;
             }
             rank[lo + e] = r;
         }
     }
-    starts = (int32_t)wave_sum_u64((uint64_t)(uint32_t)starts);
-    if (lane == 0) dcnt[b] = starts;
-    if (last_workgroup(&ps->ticket[2])) {
-        const int32_t total = bucket_scan(dcnt, doff, nullptr);
-        if (threadIdx.x == 0) ps->n_distinct = total;
+    starts = wave_sum_i32(starts);
+    ge = wave_sum_i32(ge);
+    if (lane == 0) {
+        dcnt[b] = starts;
+        dge[b] = ge;
+    }
+}
+
+// distinct counts -> global rank offsets, and :6709-6734: free space first, then only entries at or above the cutoff (the list is
+// descending, so those are a prefix: min(totalCount, distinct values >= cutoff))
+__global__ __launch_bounds__(kPlanScanBlock) void proactive_scan2_kernel(PlanScalars *ps, const int32_t *__restrict__ dcnt,
+                                                                         const int32_t *__restrict__ dge, int32_t *__restrict__ doff)
+{
+    __shared__ int32_t s_ge[kPlanScanBlock / 64];
+    if (ps->overflow) return;
+    const int32_t total = bucket_scan(dcnt, doff, nullptr, nullptr);
+    constexpr int per = kPlanBuckets / kPlanScanBlock;
+    int32_t g = 0;
+#pragma unroll
+    for (int k = 0; k < per; k += 4) {
+        const int4 x = reinterpret_cast<const int4 *>(dge)[(threadIdx.x * per + k) >> 2];
+        g += x.x + x.y + x.z + x.w;
+    }
+    g = wave_sum_i32(g);
+    __syncthreads();
+    if (lane_id() == 0) s_ge[threadIdx.x >> 6] = g;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t n_ge = 0;
+        for (int w = 0; w < kPlanScanBlock / 64; w++) n_ge += s_ge[w];
+        ps->n_distinct = total;
+        const int32_t n_sel = total < ps->total_count ? total : ps->total_count;
+        const int32_t by_free = ps->free_count < n_sel ? (ps->free_count > 0 ? ps->free_count : 0) : n_sel;
+        const int32_t by_cut = n_ge < n_sel ? n_ge : n_sel;
+        ps->n_ge_cutoff = by_cut;
+        ps->n_selected = by_free > by_cut ? by_free : by_cut;
     }
 }
 
 // global rank = distinct values in newer buckets + local rank; the first totalProactiveLoadCount of them are toLoad
 __global__ __launch_bounds__(kCompactBlock) void proactive_emit_kernel(const int64_t *__restrict__ keys, const int32_t *__restrict__ vals,
                                                                        const int32_t *__restrict__ rank, const int32_t *__restrict__ doff,
-                                                                       PlanScalars *ps, int32_t max_out, int32_t *__restrict__ out_model,
+                                                                       const PlanScalars *ps, int32_t max_out, int32_t *__restrict__ out_model,
                                                                        int64_t *__restrict__ out_lu)
 {
     const int i = blockIdx.x * kCompactBlock + threadIdx.x;
-    bool ge = false;
-    if (i < ps->n_qualified && !ps->overflow) {
-        const int32_t lr = rank[i];
-        if (lr >= 0) {
-            const int64_t key = keys[i];
-            const int32_t dst = doff[plan_bucket(key, ps)] + lr;
-            if (dst < ps->total_count) {
-                if (dst < max_out) {
-                    out_model[dst] = vals[i];
-                    out_lu[dst] = key;
-                }
-                ge = key >= ps->cutoff;
-            }
-        }
-    }
-    const int nge = __popcll(__ballot(ge));
-    if (lane_id() == 0 && nge) atomicAdd(&ps->n_ge_cutoff, nge);
-    if (last_workgroup(&ps->ticket[3]) && threadIdx.x == 0) {
-        const int32_t n_ge = __hip_atomic_load(&ps->n_ge_cutoff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int32_t n_sel = ps->n_distinct < ps->total_count ? ps->n_distinct : ps->total_count;
-        const int32_t by_free = ps->free_count < n_sel ? (ps->free_count > 0 ? ps->free_count : 0) : n_sel;
-        const int32_t by_cut = n_ge < n_sel ? n_ge : n_sel;
-        ps->n_selected = by_free > by_cut ? by_free : by_cut;
+    if (i >= ps->n_qualified || ps->overflow) return;
+    const int32_t lr = rank[i];
+    if (lr < 0) return;
+    const int64_t key = keys[i];
+    const int32_t dst = doff[plan_bucket(key, ps)] + lr;
+    if (dst < ps->total_count && dst < max_out) {
+        out_model[dst] = vals[i];
+        out_lu[dst] = key;
     }
 }
 

@@ -702,9 +702,10 @@ __device__ __forceinline__ int32_t shard_finish_row(int64_t k0, int64_t k1, int3
     return rest;
 }
 // the workgroup's flagged decisions into the launch's count; the last workgroup publishes seq << 32 | total in pinned memory.
-// The per-workgroup add is a release (this workgroup's result rows and flags, ordered by the barrier before it) + acquire (the
-// last workgroup takes every other workgroup's), and the pinned word is a system-scope release: whoever has seen the word may
-// read the launch's rows and flags from any stream.
+// Relaxed on purpose: the word tells the host HOW MANY decisions are left, nothing about the rows — the host only enqueues further
+// work on the same stream with it, and result rows are read after the stream is synchronised (mmp_shard_wait / the synchronous
+// calls do that).  A release per workgroup (agent scope = an L2 write-back per workgroup on this multi-XCD part) was measured:
+// 12.6 -> 17.5 us per 100k-decision batch.
 __device__ __forceinline__ void shard_finish_count(int32_t rest, uint32_t *s_rest, unsigned long long *__restrict__ cnt,
                                                    uint64_t *__restrict__ done, uint32_t seq)
 {
@@ -713,11 +714,11 @@ __device__ __forceinline__ void shard_finish_count(int32_t rest, uint32_t *s_res
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long mine = (1ull << 32) | *s_rest;
-        const unsigned long long prev = __hip_atomic_fetch_add(cnt, mine, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long prev = __hip_atomic_fetch_add(cnt, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((uint32_t)(prev >> 32) == gridDim.x - 1) {
             const uint32_t total = (uint32_t)prev + *s_rest;
             __hip_atomic_store(cnt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(done, ((uint64_t)seq << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(done, ((uint64_t)seq << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
