@@ -78,6 +78,7 @@ struct DevBuf {
 struct SnapBufs {
     DevBuf pods, lru, rem, cnt, rpm, orig, pos_of, elig, elig_nors, pref, has_pref, fullw, ge, pc, ph, nz, heads, bslots, bpm, bwin, bsurv, bpcs;
     DevBuf ctpos;  // Snap::ctpos
+    uint64_t types_gen = 0;  // has_pref holds the type table of this generation
     int32_t n_bslots = 0;  // case (b) slots this snapshot has (place_kernel.hpp: BSlot), read back at commit
     void release()
     {
@@ -92,6 +93,7 @@ struct SnapBufs {
 // registry view resolved against THIS snapshot's rank positions.
 struct SnapSide {
     DevBuf d_allowed, d_has_allowed, stats_acc, d_pts, d_prohib, pstats, tstats, rmodels;
+    uint64_t types_gen = 0;  // d_allowed / d_has_allowed hold the type table of this generation
     bool rmodels_ok = false;
     std::vector<int32_t> pts_of;        // pod -> partition (-1: not in the table)
     std::vector<uint64_t> pts_prohib;   // [n_pts][tw] prohibited type rows
@@ -208,6 +210,8 @@ struct mmp_ctx {
     bool snap_long = false;  // the committed snapshot takes place_batch_long_kernel
     bool snap_full = false;  // ... because (nearly) all of its instances are full (not only because a type is sparse)
     // the rows written since the last commit (a commit of a few changed rows re-ranks by insertion: delta_scatter_kernel)
+    uint64_t types_gen = 1;       // bumped by every load of the type table; device copies remember the one they hold
+    uint64_t d_prefer_gen = 0;
     std::vector<int32_t> sig_of;    // per instance: id of its ProhibitedTypeSet among the distinct ones (valid while the type table stands)
     std::vector<uint64_t> sig_rows;
     bool sig_valid = false;
@@ -409,7 +413,7 @@ void note_caller_stream(mmp_ctx *c, hipStream_t st)
 // For the PUBLISHED snapshot (after the model table changed): call with c->mu held and the decision streams idle.
 // For the snapshot a commit is building: the side is not visible to decisions yet; the caller owns c->batch_mu,
 // which keeps the model table still.
-int rebuild_resolved(mmp_ctx *c, SnapSide &sd, const Snap &snap, bool committed)
+int rebuild_resolved(mmp_ctx *c, SnapSide &sd, const Snap &snap, bool committed, bool sync = true)
 {
     sd.rmodels_ok = false;
     if (!committed || c->n_models <= 0) return MMP_OK;  // (shard contexts: `snap` carries the whole table's pos_of — resolved positions are GLOBAL)
@@ -418,7 +422,7 @@ int rebuild_resolved(mmp_ctx *c, SnapSide &sd, const Snap &snap, bool committed)
                        c->models.as<mmp_model_row>(), c->ent_pod.as<int32_t>(), c->n_models,
                        sd.rmodels.as<ResolvedModel>());
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
     sd.rmodels_ok = true;
     return MMP_OK;
 }
@@ -795,6 +799,7 @@ try {
     c->n_types = n_types;
     c->types_w = W;
     c->sig_valid = false;
+    c->types_gen++;
     const size_t words = (size_t)n_types * W;
     c->allowed.assign(words, 0);
     c->prefer.assign(words, 0);
@@ -862,6 +867,7 @@ try {
     c->n_types = R;
     c->types_w = W;
     c->sig_valid = false;
+    c->types_gen++;
     c->allowed.assign((size_t)R * W, 0);
     c->prefer.assign((size_t)R * W, 0);
     c->has_allowed.assign(R, 0);
@@ -1444,24 +1450,24 @@ try {
     HIP_TRY(c, hipMemsetAsync(c->rank.p, 0, padded * 4, st));
     HIP_TRY(c, hipMemsetAsync(c->occupancy.p, 0, padded * 4, st));
     HIP_TRY(c, hipMemsetAsync(c->flag.p, 0, sizeof(int32_t), st));
-    HIP_TRY(c, hipMemsetAsync(B.lru.p, 0, padded * 8, st));
-    HIP_TRY(c, hipMemsetAsync(B.rem.p, 0, padded * 8, st));
-    HIP_TRY(c, hipMemsetAsync(B.cnt.p, 0, padded * 4, st));
-    HIP_TRY(c, hipMemsetAsync(B.rpm.p, 0, padded * 4, st));
-    HIP_TRY(c, hipMemsetAsync(B.orig.p, 0, padded * 4, st));
-    HIP_TRY(c, hipMemsetAsync(B.pos_of.p, 0, padded * 4, st));
+    hipLaunchKernelGGL(zero_tails_kernel, dim3(1), dim3(64), 0, st, B.lru.as<int64_t>(), B.rem.as<int64_t>(), B.cnt.as<int32_t>(),
+                       B.rpm.as<int32_t>(), B.orig.as<int32_t>(), B.pos_of.as<int32_t>(), P, (int32_t)padded);
 
+    // the type table goes up only when it was reloaded since this buffer set / side / the staging copy last took it
     std::vector<uint8_t> hp(T, 0), ha(T, 0);
     for (int32_t t = 0; t < c->n_types; t++) {
         hp[t] = c->has_prefer[t];
         ha[t] = c->has_allowed[t];
     }
-    HIP_TRY(c, hipMemcpyAsync(B.has_pref.p, hp.data(), T, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(N.d_has_allowed.p, ha.data(), T, hipMemcpyHostToDevice, st));
+    if (B.types_gen != c->types_gen) HIP_TRY(c, hipMemcpyAsync(B.has_pref.p, hp.data(), T, hipMemcpyHostToDevice, st));
+    if (N.types_gen != c->types_gen) HIP_TRY(c, hipMemcpyAsync(N.d_has_allowed.p, ha.data(), T, hipMemcpyHostToDevice, st));
     if (c->n_types > 0 && !c->allowed.empty()) {
-        HIP_TRY(c, hipMemcpyAsync(N.d_allowed.p, c->allowed.data(), c->allowed.size() * 8, hipMemcpyHostToDevice, st));
-        HIP_TRY(c, hipMemcpyAsync(c->d_prefer.p, c->prefer.data(), c->prefer.size() * 8, hipMemcpyHostToDevice, st));
+        if (N.types_gen != c->types_gen)
+            HIP_TRY(c, hipMemcpyAsync(N.d_allowed.p, c->allowed.data(), c->allowed.size() * 8, hipMemcpyHostToDevice, st));
+        if (c->d_prefer_gen != c->types_gen)
+            HIP_TRY(c, hipMemcpyAsync(c->d_prefer.p, c->prefer.data(), c->prefer.size() * 8, hipMemcpyHostToDevice, st));
     }
+    B.types_gen = N.types_gen = c->d_prefer_gen = c->types_gen;
     const int32_t n_rs = (int32_t)c->replaced_rs.size();
     if (n_rs) HIP_TRY(c, hipMemcpyAsync(c->rs_list.p, c->replaced_rs.data(), (size_t)n_rs * 4, hipMemcpyHostToDevice, st));
 
@@ -1606,6 +1612,11 @@ try {
         if (rc != MMP_OK) return rc;
     }
     KT_END(c, st);
+    // the registry view resolved against the new order (still invisible to decisions), queued before the one synchronisation
+    {
+        const int rc = rebuild_resolved(c, N, S, true, false);
+        if (rc != MMP_OK) return rc;
+    }
     int32_t bad = 0;
     StatsAcc acc{};
     HIP_TRY(c, hipMemcpyAsync(&bad, c->flag.p, sizeof bad, hipMemcpyDeviceToHost, st));
@@ -1623,11 +1634,6 @@ try {
     // a type only a few instances may host: its first candidate is usually beyond a lane scan's reach, and only the
     // long variant carries the prefix-table jump that finds it without the wave path
     if (c->long_mode < 0 && acc.sparse_types) next_long = true;
-    // the registry view resolved against the new order, still invisible to decisions
-    {
-        const int rc = rebuild_resolved(c, N, S, true);
-        if (rc != MMP_OK) return rc;
-    }
     // publish: the only part of a commit a decision can ever wait for
     std::lock_guard<std::shared_mutex> g(c->mu);
     resident_stop(c);  // it answers for the snapshot it was launched with; the next single request starts one on the new
@@ -2213,6 +2219,7 @@ try {
         HIP_TRY(c, hipMemcpyAsync(N.d_allowed.p, c->allowed.data(), c->allowed.size() * 8, hipMemcpyHostToDevice, st));
         HIP_TRY(c, hipMemcpyAsync(c->d_prefer.p, c->prefer.data(), c->prefer.size() * 8, hipMemcpyHostToDevice, st));
     }
+    B.types_gen = N.types_gen = c->d_prefer_gen = c->types_gen;
     const int32_t n_rs = (int32_t)c->replaced_rs.size();
     if (n_rs) HIP_TRY(c, hipMemcpyAsync(c->rs_list.p, c->replaced_rs.data(), (size_t)n_rs * 4, hipMemcpyHostToDevice, st));
     const int64_t min_space = c->cfg.min_space_units;

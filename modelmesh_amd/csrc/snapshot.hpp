@@ -217,6 +217,22 @@ __global__ void scatter_pods_kernel(const mmp_pod_row *__restrict__ pods, int32_
     pos_of[p] = pos;
 }
 
+// the rank-ordered columns are padded to whole 64-position words: positions [P, padded) read as an absent row
+__global__ __launch_bounds__(64) void zero_tails_kernel(int64_t *__restrict__ lru, int64_t *__restrict__ rem, int32_t *__restrict__ cnt,
+                                                        int32_t *__restrict__ rpm, int32_t *__restrict__ orig, int32_t *__restrict__ pos_of,
+                                                        int32_t P, int32_t padded)
+{
+    const int i = P + (int)threadIdx.x;
+    if (i < padded) {
+        lru[i] = 0;
+        rem[i] = 0;
+        cnt[i] = 0;
+        rpm[i] = 0;
+        orig[i] = 0;
+        pos_of[i] = 0;
+    }
+}
+
 // ---- a commit whose table differs from the published one in a few rows (handleInstanceTableChange: one InstanceRecord per
 // event, MM.java:1455-1568; the rate task republishes this instance's own row, :232) ------------------------------------------
 // PLACEMENT_ORDER compares two rows by their own fields, so the rows that did not change keep their relative order: the new
