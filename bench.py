@@ -526,6 +526,47 @@ def full_cluster_leg(workload: str, device: int, dev):
             "mean_shortlist": float(got["n_candidates"].mean()), "parity_vs_oracle": parity, "roofline": roof}
 
 
+def multi_entry_leg(fleet, solver, dev, k: int = 8):
+    """A host that holds k batches the size of ONE request set (one decision per model): k launches (mmp_place_batch_dev each)
+    against one launch over the k arrays (mmp_place_multi_dev), same stream, same buffers, results compared."""
+    import torch
+
+    from modelmesh_amd import workload as wl
+    from modelmesh_amd._lib import PLACE_OUT
+    solver.load_fleet(fleet)  # (the churn leg left its own fleet in the context)
+    sets = [wl.make_requests(fleet, seed=0x3A00 + i) for i in range(k)]
+    n = len(sets[0][0])
+    d_reqs = [torch.from_numpy(r.view(np.uint8).reshape(-1)).to(dev) for r, _ in sets]
+    d_extra = [torch.from_numpy(np.ascontiguousarray(x if len(x) else np.zeros(1, np.int32))).to(dev) for _, x in sets]
+    d_a = [torch.zeros(n * 16, dtype=torch.uint8, device=dev) for _ in range(k)]
+    d_b = [torch.zeros(n * 16, dtype=torch.uint8, device=dev) for _ in range(k)]
+    st = torch.cuda.Stream(dev)
+    rp, xp = [t.data_ptr() for t in d_reqs], [t.data_ptr() for t in d_extra]
+    ap, bp = [t.data_ptr() for t in d_a], [t.data_ptr() for t in d_b]
+
+    def separate():
+        for i in range(k):
+            solver.place_dev(rp[i], n, xp[i], fleet.now, ap[i], st.cuda_stream)
+
+    def one_launch():
+        solver.place_multi_dev(rp, [n] * k, xp, fleet.now, bp, st.cuda_stream)
+    out = {}
+    for name, fn in (("separate_launches", separate), ("one_launch", one_launch)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize(dev)
+        out[name + "_us"] = (time.perf_counter() - t0) / 20 * 1e6
+    same = all(bool((a == b).all().item()) for a, b in zip(d_a, d_b))
+    return {"arrays": k, "decisions_per_array": n, **out, "decisions_per_s_one_launch": k * n / (out["one_launch_us"] * 1e-6),
+            "identical_results": same,
+            "note": "k x mmp_place_batch_dev vs one mmp_place_multi_dev over the same k request arrays, one stream, wall time of 20 "
+                    "repetitions incl. the host's issue time"}
+
+
 def _single_prober():
     """tools/micro/single_prober.c built with gcc (None when no compiler is at hand: the leg then reports no latencies)"""
     import ctypes as C
@@ -1298,6 +1339,11 @@ def main():
                 line["full_cluster"] = full_cluster_leg(args.workload, local_rank, dev)
             except Exception as e:
                 line["full_cluster"] = {"error": f"{type(e).__name__}: {e}"}
+        if not args.kernel_only:
+            try:
+                line["multi_batch_entry"] = multi_entry_leg(fleet, solver, dev)
+            except Exception as e:
+                line["multi_batch_entry"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.kernel_only and not args.no_secondary:
             try:
                 line["kernels"] = secondary_kernels_leg(fleet, solver, local_rank, args.workload)

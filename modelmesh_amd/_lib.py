@@ -138,6 +138,7 @@ SYMBOLS = [
     ("mmp_pod_partitions", C.c_int, [_P, _P, C.c_int32, _P]),
     ("mmp_place_batch", C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int64, _P]),
     ("mmp_place_batch_dev", C.c_int, [_P, _P, C.c_int32, _P, C.c_int64, _P, _P]),
+    ("mmp_place_multi_dev", C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int64, _P, _P]),
     ("mmp_stream_retire", C.c_int, [_P, _P]),
     ("mmp_resident", C.c_int, [_P, C.c_int]),
     ("mmp_resident_stats", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

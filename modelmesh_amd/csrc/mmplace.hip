@@ -37,6 +37,7 @@
 #include "place_kernel.hpp"
 #include "rebalance_kernels.hpp"
 #include "shard_kernels.hpp"
+#include "multi_kernel.hpp"
 #include "snapshot.hpp"
 #include "types_kernel.hpp"
 #include "upgrade_tracker.hpp"
@@ -463,7 +464,7 @@ hipError_t slot_wait(FastSlot *f)
 hipError_t order_after_registry(mmp_ctx *c, hipStream_t st);
 int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs,
                  hipStream_t st, uint32_t *done_flag = nullptr, uint32_t done_seq = 0, const mmp_place_req *inline_req = nullptr,
-                 uint32_t *done_blocks = nullptr)
+                 uint32_t *done_blocks = nullptr, const PlaceSegs *segs = nullptr, int32_t seg_blocks = 0)
 {
     if (n == 0) return MMP_OK;
     PlaceArgs A{};
@@ -523,10 +524,20 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_long4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_flag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_single_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_multi_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_multi_long4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         c->lds_granted.store((size_t)want, std::memory_order_release);
     }
     HIP_TRY(c, order_after_registry(c, st));
-    if (inline_req)
+    if (segs) {  // several request arrays, one launch (multi_kernel.hpp); n = the decisions of all of them
+        if (c->snap_long && n >= kLongDenseFrom)
+            hipLaunchKernelGGL(place_multi_long4_kernel, dim3(seg_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *segs);
+        else if (c->snap_long)
+            hipLaunchKernelGGL(place_multi_long_kernel, dim3(seg_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *segs);
+        else
+            hipLaunchKernelGGL(place_multi_kernel, dim3(seg_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *segs);
+    } else if (inline_req)
         hipLaunchKernelGGL(place_single_kernel, dim3(1), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *inline_req);
     else if (done_flag && n > kPlaceBlock)
         hipLaunchKernelGGL(place_batch_flag_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad,
@@ -3276,6 +3287,46 @@ int mmp_resident_stats(mmp_ctx *c, uint64_t *launches, uint64_t *served, uint64_
 }
 
 /* ---- decisions ---------------------------------------------------------- */
+
+int mmp_place_multi_dev(mmp_ctx *c, int32_t k, const void *const *d_reqs, const int32_t *n, const void *const *d_extra, int64_t now,
+                        void *const *d_outs, void *stream)
+try {
+    if (!c || k < 0 || (k > 0 && (!d_reqs || !n || !d_outs))) return fail(c, MMP_EINVAL, "mmp_place_multi_dev: bad argument");
+    for (int32_t i = 0; i < k; i++)
+        if (n[i] < 0 || (n[i] > 0 && (!d_reqs[i] || !d_outs[i]))) return fail(c, MMP_EINVAL, "mmp_place_multi_dev: bad argument (array %d)", i);
+    std::shared_lock<std::shared_mutex> g(c->mu);  // capture the published snapshot + enqueue; no wait
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    note_caller_stream(c, st);
+    for (int32_t i0 = 0; i0 < k;) {  // kMaxSegs arrays per launch
+        PlaceSegs G{};
+        int32_t blocks = 0;
+        int64_t total = 0;
+        int32_t i = i0;
+        for (; i < k && G.n_segs < kMaxSegs; i++) {
+            if (n[i] == 0) continue;
+            PlaceSeg &sg = G.seg[G.n_segs++];
+            sg.reqs = static_cast<const mmp_place_req *>(d_reqs[i]);
+            sg.outs = static_cast<mmp_place_out *>(d_outs[i]);
+            sg.extra = d_extra ? static_cast<const int32_t *>(d_extra[i]) : nullptr;
+            sg.first_block = blocks;
+            sg.n = n[i];
+            blocks += div_up(n[i], kPlaceBlock);
+            total += n[i];
+        }
+        i0 = i;
+        if (G.n_segs == 0) continue;
+        if (total > INT32_MAX - kPlaceBlock * (int64_t)kMaxSegs) return fail(c, MMP_EINVAL, "mmp_place_multi_dev: more than 2^31 decisions in one launch");
+        const int rc = place_launch(c, G.seg[0].reqs, (int32_t)total, G.seg[0].extra, now, G.seg[0].outs, st, nullptr, 0, nullptr, nullptr, &G, blocks);
+        if (rc != MMP_OK) return rc;
+    }
+    return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_place_multi_dev");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_place_multi_dev", e.what());
+}
 
 int mmp_place_batch_dev(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs,
                         void *stream)

@@ -324,6 +324,16 @@ class Solver:
         self._ck(self.lib.mmp_place_batch_dev(self.h, C.c_void_p(d_reqs), int(n), C.c_void_p(d_extra or None),
                                               int(now), C.c_void_p(d_outs), C.c_void_p(stream or None)))
 
+    def place_multi_dev(self, d_reqs, ns, d_extras, now: int, d_outs, stream: int = 0):
+        """Several request arrays (raw device pointers), ONE launch, no sync: the same as place_dev per array."""
+        k = len(d_reqs)
+        arr = C.c_void_p * k
+        r = arr(*[C.c_void_p(int(p)) for p in d_reqs])
+        x = arr(*[C.c_void_p(int(p) or None) for p in d_extras])
+        o = arr(*[C.c_void_p(int(p)) for p in d_outs])
+        n = (C.c_int32 * k)(*[int(v) for v in ns])
+        self._ck(self.lib.mmp_place_multi_dev(self.h, k, r, n, x, int(now), o, C.c_void_p(stream or None)))
+
     def serve_counters(self, reqs, in_use, last_used):
         """What a Java host assembles per request (MM.java:4343, :4356, :4360): for every copy of the request's model whose
         instance litelinks lists (here: the table's live flag), one (instance, inUse, lastUsed) entry.  -> (reqs with
