@@ -2144,11 +2144,39 @@ try {
         const int per = div_up(P, c->n_shards);
         const int p_lo = std::min(P, c->shard * per), p_hi = std::min(P, p_lo + per);
         if (p_hi > p_lo) {
-            const int pb = div_up(p_hi - p_lo, kRankBlock);
-            const int slices = std::max(1, std::min(64, 2048 / pb));
             const int64_t churn2 = (int64_t)((uint64_t)c->cfg.min_churn_age_ms * 2u);
-            hipLaunchKernelGGL(rank_pods_kernel, dim3(pb, slices), dim3(kRankBlock), 0, st, B.pods.as<mmp_pod_row>(), P,
-                               c->cfg.min_space_units, churn2, slices, p_lo, p_hi, static_cast<int32_t *>(d_rank));
+            const int64_t min_space = c->cfg.min_space_units;
+            // the slice against all rows is (P / shards) x P comparator calls; from where an unsharded commit sorts (8192^2 pairs)
+            // sorting the whole table is cheaper — when the comparator is a total order on it (snapshot.hpp "ranking by sorting")
+            bool versions_differ = false, full_low_lru = false, wide_count = false;
+            for (int32_t p = 0; p < P; p++) {
+                const mmp_pod_row &r = c->pods[p];
+                if (r.version != c->pods[0].version) versions_differ = true;
+                if (r.count > (1 << 30) || r.count < -(1 << 30)) wide_count = true;
+                const uint64_t d = (uint64_t)r.capacity - (uint64_t)r.used;
+                const int64_t rem = (int64_t)d > 0 ? (int64_t)d : 0;
+                if (rem < min_space && r.lru_time <= churn2) full_low_lru = true;
+            }
+            const bool sort_legal = !(versions_differ && full_low_lru) && !wide_count;
+            const bool want_sort = c->rank_mode == 2 || (c->rank_mode == 0 && (int64_t)(p_hi - p_lo) * P >= (int64_t)kRankSortMinPods * kRankSortMinPods);
+            if (want_sort && sort_legal && P >= 2) {
+                HIP_TRY(c, c->rk_rows.ensure((size_t)P * sizeof(RankRow)));
+                HIP_TRY(c, c->rk_idx.ensure((size_t)P * sizeof(RankRow)));
+                const PlacementRowLess less{churn2};
+                size_t tmp_bytes = 0;
+                HIP_TRY(c, rocprim::merge_sort(nullptr, tmp_bytes, c->rk_rows.as<RankRow>(), c->rk_idx.as<RankRow>(), (size_t)P, less, st));
+                HIP_TRY(c, c->rk_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
+                hipLaunchKernelGGL(rank_rows_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, B.pods.as<mmp_pod_row>(), P, min_space,
+                                   c->rk_rows.as<RankRow>());
+                HIP_TRY(c, rocprim::merge_sort(c->rk_tmp.p, tmp_bytes, c->rk_rows.as<RankRow>(), c->rk_idx.as<RankRow>(), (size_t)P, less, st));
+                hipLaunchKernelGGL(rank_from_order_range_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, c->rk_idx.as<RankRow>(), P, p_lo, p_hi,
+                                   static_cast<int32_t *>(d_rank));
+            } else {
+                const int pb = div_up(p_hi - p_lo, kRankBlock);
+                const int slices = std::max(1, std::min(64, 2048 / pb));
+                hipLaunchKernelGGL(rank_pods_kernel, dim3(pb, slices), dim3(kRankBlock), 0, st, B.pods.as<mmp_pod_row>(), P,
+                                   min_space, churn2, slices, p_lo, p_hi, static_cast<int32_t *>(d_rank));
+            }
             HIP_TRY(c, hipGetLastError());
         }
     }

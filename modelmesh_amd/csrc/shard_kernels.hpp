@@ -701,6 +701,17 @@ __device__ __forceinline__ int32_t shard_finish_row(int64_t k0, int64_t k1, int3
     if (!rest) outs[d] = o;
     return rest;
 }
+// a shard that ranked by sorting the WHOLE table (cheaper than its slice against all rows from ~67M pairs on) keeps only its own
+// slice's ranks: the other rows stay zero, so the SUM all-reduce over the shards still assembles the one rank vector
+__global__ void rank_from_order_range_kernel(const RankRow *__restrict__ sorted, int32_t P, int32_t p_lo, int32_t p_hi,
+                                             int32_t *__restrict__ rank)
+{
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= P) return;
+    const int32_t pod = (int32_t)sorted[pos].pad0;
+    if (pod >= p_lo && pod < p_hi) rank[pod] = pos;
+}
+
 // the workgroup's flagged decisions into the launch's count; the last workgroup publishes seq << 32 | total in pinned memory.
 // Relaxed on purpose: the word tells the host HOW MANY decisions are left, nothing about the rows — the host only enqueues further
 // work on the same stream with it, and result rows are read after the stream is synchronised (mmp_shard_wait / the synchronous
