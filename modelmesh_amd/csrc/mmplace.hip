@@ -221,6 +221,7 @@ struct mmp_ctx {
     bool order_total = false;       // the published order came from a total order (sort-legal rows): unchanged rows keep their order
     std::vector<int32_t> h_order, h_pos;  // host mirror of the published order (position -> row, row -> position), fetched lazily
     bool h_order_valid = false;
+    int32_t single_block = 0;       // MMP_SINGLE_BLOCK=1: a single decision runs the batch kernel's workgroup (place_single_kernel)
     int32_t no_delta = 0;           // MMP_NO_DELTA=1: every commit ranks from scratch (tests)
     int64_t n_delta_commits = 0;
     int32_t rank_mode = 0;  // MMP_RANK_MODE: 0 auto (sort from kRankSortMinPods pods), 1 all-pairs, 2 sort whenever legal (tests)
@@ -524,6 +525,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_long4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_flag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_single_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_single_lean_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_multi_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_multi_long4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
@@ -537,7 +539,9 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
             hipLaunchKernelGGL(place_multi_long_kernel, dim3(seg_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *segs);
         else
             hipLaunchKernelGGL(place_multi_kernel, dim3(seg_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *segs);
-    } else if (inline_req)
+    } else if (inline_req && !c->single_block)
+        hipLaunchKernelGGL(place_single_lean_kernel, dim3(1), dim3(64), lds, st, c->snap, A, wpad, *inline_req);
+    else if (inline_req)
         hipLaunchKernelGGL(place_single_kernel, dim3(1), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *inline_req);
     else if (done_flag && n > kPlaceBlock)
         hipLaunchKernelGGL(place_batch_flag_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad,
@@ -596,6 +600,7 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     if (const char *rm = getenv("MMP_RANK_MODE")) c->rank_mode = atoi(rm);
     if (const char *lm = getenv("MMP_LONG_MODE")) c->long_mode = atoi(lm);
     if (const char *nd = getenv("MMP_NO_DELTA")) c->no_delta = nd[0] == '1';
+    if (const char *sb = getenv("MMP_SINGLE_BLOCK")) c->single_block = sb[0] == '1';
     if (const char *sp = getenv("MMP_PLAN_SORTED")) c->cfg_plan_sorted = atoi(sp);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete c;

@@ -59,4 +59,67 @@ __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(4, 
     place_block<true>(S, As, wpad, smem);
 }
 
+// ---- one decision, one wavefront ------------------------------------------------------------------------------------------------
+// mmp_place_batch(n = 1) through a launch is launch latency + this kernel + the completion flag's way to the host.  place_single_kernel
+// is the batch kernel's workgroup (256 lanes, three workgroup barriers, a system-scope fence by every wavefront before the flag) run
+// for ONE lane's work: 5.6-6.9 us in the kernel trace.  The same decision code on one wavefront: the request comes in the kernel
+// arguments, the windows are staged by the one wavefront, lane 0 decides (lane_decide_win -> lane_decide_r -> the prefix-table
+// phase), the wave path runs on the same wavefront if it is needed, ONE fence, the flag.
+__global__ __launch_bounds__(64) void place_single_lean_kernel(Snap S, PlaceArgs A, int32_t wpad, mmp_place_req rq)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ mmp_place_req srq;  // (the prefix-table phase and the wave path read the request through A.reqs)
+    __shared__ int32_t s_code;
+    TypeWin *s_wins = reinterpret_cast<TypeWin *>(smem);
+    uint64_t *s_scr = reinterpret_cast<uint64_t *>(smem + win_lds_bytes(S.T));
+    const int lane = lane_id();
+    const bool use_wins = A.wins != nullptr;
+    if (use_wins) {
+        const int chunks = ((S.T < kWinLds ? S.T : kWinLds) * (int)sizeof(TypeWin) + 1023) >> 10;
+        const char *src = reinterpret_cast<const char *>(A.wins);
+        char *dst = reinterpret_cast<char *>(s_wins);
+        for (int c = 0; c < chunks; c++)
+            __builtin_amdgcn_global_load_lds(src + (size_t)c * 1024 + lane * 16, (__attribute__((address_space(3))) void *)(dst + c * 1024), 16,
+                                             0, 0);
+    }
+    if (lane == 0) {
+        srq = rq;
+        s_code = kLaneDone;
+    }
+    A.reqs = &srq;
+    A.n = 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_sync();
+    if (lane == 0) {
+        ResolvedReq r = resolve_req<false, true>(S, A, rq);
+        mmp_place_out o;
+        int code = kLaneHeadMiss;
+        if (A.long_first) {
+            merge_late_extras(r);
+            code = lane_decide_r<false, true>(S, A, r, o, BLds{});
+        } else {
+            if (use_wins) code = lane_decide_win(S, A, r, s_wins, s_scr, o);
+            if (code == kLaneHeadMiss) {
+                merge_late_extras(r);
+                code = lane_decide_r<false>(S, A, r, o, BLds{});
+            }
+            if (code == kLaneLong || code == kLaneCaseB) code = lane_decide<false, true>(S, A, 0, o, BLds{});
+        }
+        if (code == kLaneDone)
+            A.outs[0] = o;
+        else
+            s_code = code;
+    }
+    wave_sync();
+    if (s_code != kLaneDone) {  // (wave-uniform) the general path: the whole wavefront sweeps the table
+        uint64_t *ew = reinterpret_cast<uint64_t *>(smem), *fw = ew + wpad;
+        place_one(S, A, 0, ew, fw);
+    }
+    if (A.done_flag) {
+        __threadfence_system();  // the result row (whichever lane wrote it) before the flag
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) __hip_atomic_store(A.done_flag, A.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 }  // namespace mmp
