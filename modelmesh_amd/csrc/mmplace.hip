@@ -3327,6 +3327,14 @@ try {
     if (!c || k < 0 || (k > 0 && (!d_reqs || !n || !d_outs))) return fail(c, MMP_EINVAL, "mmp_place_multi_dev: bad argument");
     for (int32_t i = 0; i < k; i++)
         if (n[i] < 0 || (n[i] > 0 && (!d_reqs[i] || !d_outs[i]))) return fail(c, MMP_EINVAL, "mmp_place_multi_dev: bad argument (array %d)", i);
+    {  // launches handed to submission threads earlier are issued first: this call launches from the calling thread, in stream order
+        std::shared_ptr<IssuePool> P;
+        pool_get(c, P);
+        if (P) {
+            const int rc = issue_flush(c);
+            if (rc != MMP_OK) return fail(c, rc, "a launch submitted through the issue threads failed (%d)", rc);
+        }
+    }
     std::shared_lock<std::shared_mutex> g(c->mu);  // capture the published snapshot + enqueue; no wait
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
