@@ -1242,6 +1242,26 @@ namespace {
 // ClusterStats of the snapshot being committed (snapshot.hpp "instance partitions").  Enqueues on st; the
 // host mirrors are valid once the caller has synchronised st.  Call after cluster_stats_kernel.  N = the side
 // state of the snapshot being built (its d_has_allowed / stats_acc are already filled).
+struct ZeroBatch {  // collects buffers, clears them with one zero_regions_kernel launch
+    ZeroList Z{};
+    size_t most = 0;
+    void add(void *p, size_t bytes)
+    {
+        if (!p || bytes == 0) return;
+        Z.p[Z.n] = p;
+        Z.bytes[Z.n] = (bytes + 3) & ~(size_t)3;  // (DevBuf allocations are rounded up: the tail bytes exist)
+        most = std::max(most, bytes);
+        Z.n++;
+    }
+    void launch(hipStream_t st)
+    {
+        if (Z.n == 0) return;
+        const int blocks = (int)std::min<size_t>(std::max<size_t>(most / (256 * 4 * 4), 1), 256);
+        hipLaunchKernelGGL(zero_regions_kernel, dim3(blocks), dim3(256), 0, st, Z);
+        Z.n = 0;
+        most = 0;
+    }
+};
 // part 0: the host's interning of the partitions + the uploads; part 1: the kernels + the results back; 2: the results only; -1: all
 int build_subset_stats(mmp_ctx *c, SnapSide &N, const mmp_pod_row *d_pods, int32_t P, int64_t min_space, hipStream_t st, int part = -1)
 {
@@ -1463,9 +1483,14 @@ try {
         }
     }
     if (P && !delta) HIP_TRY(c, hipMemcpyAsync(B.pods.p, c->pods.data(), (size_t)P * sizeof(mmp_pod_row), hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemsetAsync(c->rank.p, 0, padded * 4, st));
-    HIP_TRY(c, hipMemsetAsync(c->occupancy.p, 0, padded * 4, st));
-    HIP_TRY(c, hipMemsetAsync(c->flag.p, 0, sizeof(int32_t), st));
+    {
+        ZeroBatch zb;
+        zb.add(c->rank.p, padded * 4);
+        zb.add(c->occupancy.p, padded * 4);
+        zb.add(c->flag.p, sizeof(int32_t));
+        zb.add(B.bslots.p, kBSlots * sizeof(BSlot) + 16);
+        zb.launch(st);
+    }
     hipLaunchKernelGGL(zero_tails_kernel, dim3(1), dim3(64), 0, st, B.lru.as<int64_t>(), B.rem.as<int64_t>(), B.cnt.as<int32_t>(),
                        B.rpm.as<int32_t>(), B.orig.as<int32_t>(), B.pos_of.as<int32_t>(), P, (int32_t)padded);
 
@@ -1519,7 +1544,6 @@ try {
         const int rc = build_subset_stats(c, N, B.pods.as<mmp_pod_row>(), P, min_space, st, 0);
         if (rc != MMP_OK) return rc;
     }
-    HIP_TRY(c, hipMemsetAsync(B.bslots.p, 0, kBSlots * sizeof(BSlot) + 16, st));
     KT_BEGIN(c, st);
     if (P > 0) {
         // (nearly) every instance full: getNext is in its LRU-window mode and whole-table shortlists are common
@@ -2238,19 +2262,24 @@ try {
     HIP_TRY(c, c->d_prefer.ensure(std::max<size_t>((size_t)T * W, 1) * 8));
     HIP_TRY(c, N.d_has_allowed.ensure(T));
 
-    HIP_TRY(c, hipMemsetAsync(c->occupancy.p, 0, padded_full * 4, st));
-    HIP_TRY(c, hipMemsetAsync(c->flag.p, 0, sizeof(int32_t), st));
-    HIP_TRY(c, hipMemsetAsync(B.lru.p, 0, padded * 8, st));
-    HIP_TRY(c, hipMemsetAsync(B.rem.p, 0, padded * 8, st));
-    HIP_TRY(c, hipMemsetAsync(B.cnt.p, 0, padded * 4, st));
-    HIP_TRY(c, hipMemsetAsync(B.rpm.p, 0, padded * 4, st));
-    HIP_TRY(c, hipMemsetAsync(B.orig.p, 0, padded * 4, st));
-    HIP_TRY(c, hipMemsetAsync(B.pos_of.p, 0, padded_full * 4, st));
-    HIP_TRY(c, hipMemsetAsync(B.elig.p, 0, (size_t)T * Wn1 * 8, st));
-    HIP_TRY(c, hipMemsetAsync(B.elig_nors.p, 0, (size_t)T * Wn1 * 8, st));
-    HIP_TRY(c, hipMemsetAsync(B.pref.p, 0, (size_t)T * Wn1 * 8, st));
-    HIP_TRY(c, hipMemsetAsync(B.fullw.p, 0, (size_t)Wn1 * 8, st));
-    HIP_TRY(c, hipMemsetAsync(B.ge.p, 0, (size_t)kGeRows * Wn1 * 8, st));
+    {
+        ZeroBatch zb;
+        zb.add(c->occupancy.p, padded_full * 4);
+        zb.add(c->flag.p, sizeof(int32_t));
+        zb.add(B.lru.p, padded * 8);
+        zb.add(B.rem.p, padded * 8);
+        zb.add(B.cnt.p, padded * 4);
+        zb.add(B.rpm.p, padded * 4);
+        zb.add(B.orig.p, padded * 4);
+        zb.add(B.pos_of.p, padded_full * 4);
+        zb.add(B.elig.p, (size_t)T * Wn1 * 8);
+        zb.add(B.elig_nors.p, (size_t)T * Wn1 * 8);
+        zb.add(B.pref.p, (size_t)T * Wn1 * 8);
+        zb.add(B.fullw.p, (size_t)Wn1 * 8);
+        zb.add(B.ge.p, (size_t)kGeRows * Wn1 * 8);
+        zb.launch(st);
+        HIP_TRY(c, hipGetLastError());
+    }
 
     std::vector<uint8_t> hp(T, 0), ha(T, 0);
     for (int32_t t = 0; t < c->n_types; t++) {
