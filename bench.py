@@ -867,9 +867,10 @@ def main():
                          "(3.25 us: with the round-2 kernel the timed region is bound by the GPU, not by the launch path), so the "
                          "default leaves the helpers off")
     ap.add_argument("--streams", type=int, default=0,
-                    help="HIP streams the timed steps are issued on round-robin; 0 = 2 for launches of more than 200k "
-                         "decisions, else 4 (profiles/r2/place_sweep_C3.csv: a second launch in flight covers the first one's "
-                         "start-up and tail — 800k decisions: 26.2 us on one stream, 17.9 us per step on two, 17.9 on four, 20.2 on eight; "
+                    help="HIP streams the timed steps are issued on round-robin; 0 = 4 (profiles/r2/place_sweep_C3.csv: a second "
+                         "launch in flight covers the first one's start-up and tail — 800k decisions: 26.2 us on one stream, 17.9 us per "
+                         "step on two, 17.9 on four, 20.2 on eight over long regions; round 4, the driver's 20-step region, six alternating "
+                         "runs each: two streams 38.6-41.3 G decisions/s (median 40.4), four 37.6-44.0 (median 43.2); "
                          "a 100k launch is 1564 wavefronts, too few to cover its own latency chain on 256 CUs: 8.2 us on one "
                          "stream, 3.3 us per step on four; the closing synchronize costs per stream)")
     ap.add_argument("--leg-timeout", type=float, default=420.0,
@@ -931,7 +932,7 @@ def main():
     # (their requests + results exceed the 256 MiB Infinity Cache) so that a timed step reads its requests from HBM.
     sets_per_step = max(1, round(args.decisions_per_step / fleet.n_models))  # request sets (one decision per model) per step
     n_batches = args.batches if args.batches > 0 else max(3, -(-384_000_000 // (sets_per_step * fleet.n_models * 80)))
-    n_streams = args.streams if args.streams > 0 else (2 if sets_per_step * fleet.n_models > 200_000 else 4)
+    n_streams = args.streams if args.streams > 0 else 4
     import ctypes as C
     batches = []  # (reqs, extra) on the host, for the parity gate
     d_bufs = []   # device tensors, kept alive
