@@ -455,20 +455,19 @@ def test_100k_instances(force_wave, monkeypatch):
     _check_fleet(fleet, reqs, extra)
 
 
-def test_c4_1m_x_50k_sample():
-    """BASELINE config C4's fleet on one device: 50k pods (782 words per bitmap row), 1M models; 250k of
-    the 1M decisions are compared with the oracle to bound the CPU time."""
+def test_c4_1m_x_50k_every_decision_against_the_checker():
+    """BASELINE config C4's fleet on one device: 50k pods (782 words per bitmap row), 1M models; ALL 1M decisions against the
+    checker — chosen, best, shortlist size and the audit hash of the shortlist (round 3 compared a 250k sample: the checker
+    takes ~2 s per 250k decisions on 8 cores)."""
     fleet = wl.make_fleet("C4")
     reqs, extra = wl.make_requests(fleet, 14)
-    sel = np.arange(0, len(reqs), 4)
-    sub = reqs[sel].copy()
-    _check_fleet(fleet, sub, extra)
+    _check_fleet(fleet, reqs, extra)
 
 
 def test_c4_all_1m_decisions_against_the_lean_port():
     """Every one of C4's 1M decisions: chosen / best / n_candidates against orc_place_lean (the checker's getNext body
     without its per-call audit machinery; tests/test_lean_port.py holds it to the checker).  The audit hash of the
-    shortlist is compared on the 250k sample above."""
+    shortlist is compared by the test above."""
     import os
     fleet = wl.make_fleet("C4")
     reqs, extra = wl.make_requests(fleet, 14)
