@@ -99,11 +99,10 @@ __global__ __launch_bounds__(64) void place_single_lean_kernel(Snap S, PlaceArgs
             code = lane_decide_r<false, true>(S, A, r, o, BLds{});
         } else {
             if (use_wins) code = lane_decide_win(S, A, r, s_wins, s_scr, o);
-            if (code == kLaneHeadMiss) {
-                merge_late_extras(r);
-                code = lane_decide_r<false>(S, A, r, o, BLds{});
+            if (code == kLaneHeadMiss) {  // straight to the instantiation with the prefix-table phase: occupancy is nothing here, and a
+                merge_late_extras(r);     // shortlist that spans the table would otherwise be walked twice (first pass: "long", second: decide)
+                code = lane_decide_r<false, true>(S, A, r, o, BLds{});
             }
-            if (code == kLaneLong || code == kLaneCaseB) code = lane_decide<false, true>(S, A, 0, o, BLds{});
         }
         if (code == kLaneDone)
             A.outs[0] = o;
