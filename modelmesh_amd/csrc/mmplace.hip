@@ -3769,6 +3769,63 @@ try {
             return fail(c, MMP_EINVAL, "mmp_route_batch: request %d pool range out of bounds", i);
         if (g.model != r.model) return fail(c, MMP_EINVAL, "mmp_route_batch: request %d names two models", i);
     }
+    // The per-request seam (invokeModel asks for ONE route at a time): a latency slot, as mmp_gate_batch / mmp_serve_batch take
+    // for small calls — pinned, device-mapped buffers on the slot's own stream, one launch, completion through the pinned flag;
+    // nothing is staged and the call never queues behind a commit or a large batch.
+    constexpr int kRouteN = 256, kRouteCnt = 4096, kRoutePool = kFastExtra / 4;
+    constexpr size_t kRouteSreqOff = (size_t)kRouteN * sizeof(mmp_gate_req), kRouteCntOff = kRouteSreqOff + (size_t)kRouteN * sizeof(mmp_serve_req),
+                     kRouteSoutOff = (((size_t)kRouteN * sizeof(mmp_gate_out)) + 15) & ~(size_t)15;
+    static_assert(kRouteCntOff + (size_t)kRouteCnt * sizeof(mmp_serve_counter) <= (size_t)kFastN * sizeof(mmp_place_req), "route slot layout");
+    static_assert(kRouteSoutOff + (size_t)kRouteN * sizeof(mmp_serve_out) <= (size_t)kFastN * sizeof(mmp_place_out), "route slot results");
+    static_assert(kRouteSreqOff % 16 == 0 && kRouteCntOff % 16 == 0, "route slot alignment");
+    if (n > 0 && n <= kRouteN && n_counters <= kRouteCnt && n_excl <= kRoutePool && n_explicit <= kRoutePool) {
+        HIP_TRY(c, hipSetDevice(c->cfg.device));
+        std::unique_lock<std::mutex> fl;
+        FastSlot *f = slot_acquire(c, fl);
+        char *base = reinterpret_cast<char *>(f->reqs);
+        memcpy(base, greqs, (size_t)n * sizeof(mmp_gate_req));
+        memcpy(base + kRouteSreqOff, sreqs, (size_t)n * sizeof(mmp_serve_req));
+        if (n_counters) memcpy(base + kRouteCntOff, counters, (size_t)n_counters * sizeof(mmp_serve_counter));
+        int32_t *pool = f->extra;
+        if (n_excl) {
+            memcpy(pool, excl_pod, (size_t)n_excl * 4);
+            memcpy(pool + 2 * kRoutePool, excl_time, (size_t)n_excl * 8);
+        }
+        if (n_explicit) memcpy(pool + kRoutePool, explicit_pool, (size_t)n_explicit * 4);
+        char *obase = reinterpret_cast<char *>(f->outs);
+        {
+            std::shared_lock<std::shared_mutex> g(c->mu);  // capture the published snapshot + enqueue
+            if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+            GateArgs G = gate_args(c, n, now, in_use_expiry);
+            G.reqs = reinterpret_cast<const mmp_gate_req *>(base);
+            G.excl_pod = pool;
+            G.explicit_pool = pool + kRoutePool;
+            G.excl_time = reinterpret_cast<const int64_t *>(pool + 2 * kRoutePool);
+            G.outs = reinterpret_cast<mmp_gate_out *>(obase);
+            G.done = DoneFlag{f->done, f->blocks, ++f->seq};
+            ServeArgs S{};
+            S.reqs = reinterpret_cast<const mmp_serve_req *>(base + kRouteSreqOff);
+            S.models = c->models.as<mmp_model_row>();
+            S.ent_pod = c->ent_pod.as<int32_t>();
+            S.ent_time = c->ent_time.as<int64_t>();
+            S.counters = reinterpret_cast<const mmp_serve_counter *>(base + kRouteCntOff);
+            S.excl_pod = G.excl_pod;
+            S.excl_time = G.excl_time;
+            S.outs = reinterpret_cast<mmp_serve_out *>(obase + kRouteSoutOff);
+            S.n = n;
+            S.n_models = c->n_models;
+            S.P = c->snap.P;
+            S.now = now;
+            S.done = DoneFlag{nullptr, nullptr, 0};
+            HIP_TRY(c, order_after_registry(c, f->stream));
+            hipLaunchKernelGGL(route_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, f->stream, G, S);
+            HIP_TRY(c, hipGetLastError());
+        }
+        HIP_TRY(c, slot_wait(f));
+        memcpy(gouts, obase, (size_t)n * sizeof(mmp_gate_out));
+        memcpy(souts, obase + kRouteSoutOff, (size_t)n * sizeof(mmp_serve_out));
+        return MMP_OK;
+    }
     std::lock_guard<std::mutex> gb(c->batch_mu);  // (as mmp_gate_batch's batch path: owns c->stream and the scratch)
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     if (n == 0) return MMP_OK;

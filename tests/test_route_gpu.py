@@ -93,3 +93,28 @@ def test_the_host_mirror_follows_removed_pods_and_new_registry_records():
         assert q2["n_cnt"][0] == 1 and c2["pod"][0] == keep
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("n", [1, 5, 256, 257])
+def test_small_route_calls_take_a_latency_slot_and_equal_the_two_calls(n):
+    """invokeModel asks for one route at a time: calls of up to 256 requests ride a latency slot (pinned buffers, one launch, the
+    pinned completion flag) — same rows as the staged path (257) and as the two separate calls."""
+    name, fleet, ids, r, xp, xt, expl, expiry = next(iter(rf.gate_cases()))
+    rng = np.random.default_rng(n)
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        P = fleet.n_pods
+        in_use = rng.integers(0, 3, P).astype(np.int32)
+        last_used = (fleet.now - rng.choice([0, 5, 5, 100, 10_000], P)).astype(np.int64)
+        for rep in range(3):  # (the slot is reused: sequence numbers, stale rows)
+            sel = rng.choice(len(r), size=min(n, len(r)), replace=False)
+            g = r[sel].copy()
+            sreqs, counters = s.serve_counters(_serve_reqs_for(rng, fleet, g), in_use, last_used)
+            g1 = s.gates(g, xp, xt, expl, fleet.now, expiry)
+            s1 = s.serve_k(sreqs, counters, xp, xt, fleet.now)
+            g2, s2 = s.route(g, sreqs, counters, xp, xt, expl, fleet.now, expiry)
+            assert np.array_equal(g1["bits"], g2["bits"]) and np.array_equal(g1["initial_size"], g2["initial_size"]), (n, rep)
+            assert np.array_equal(s1["chosen"], s2["chosen"]) and np.array_equal(s1["chosen_load_start"], s2["chosen_load_start"]), (n, rep)
+    finally:
+        s.close()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Wall time of the small host-pointer calls a mesh instance makes around one model load: the request guards
-(mmp_gate_batch), the load target (mmp_place_batch) and the cache-eviction evaluation (mmp_evict_batch), n = 1
-and n = 256, arguments marshalled once."""
+(mmp_gate_batch), the load target (mmp_place_batch), the cache-eviction evaluation (mmp_evict_batch), the serve target
+(mmp_serve_batch) and the cache-hit route in one call (mmp_route_batch), n = 1 and n = 256, arguments marshalled once."""
 import ctypes as C
 import os
 import sys
@@ -51,4 +51,21 @@ for n in (1, 256):
     g["loader_predicted"] = 6400
     go = np.zeros(n, dtype=_lib.GATE_OUT)
     print(f"n={n:4d} gates  p50 %.1f us  p99 %.1f us" % timed(s.lib.mmp_gate_batch, (s.h, ptr(g), C.c_int32(n), None, None, C.c_int32(0), None, C.c_int32(0), C.c_int64(now), C.c_int64(450_000), ptr(go))))
+    # the cache-hit route: guards + serve target — two calls (mmp_gate_batch, mmp_serve_batch) against one (mmp_route_batch)
+    rng = np.random.default_rng(n)
+    sr = np.zeros(n, dtype=_lib.SERVE_REQ)
+    sr["model"], sr["self_pod"] = g["model"], g["self_pod"]
+    sr["assume_completed_ms"] = 3000
+    in_use = rng.integers(0, 3, fleet.n_pods).astype(np.int32)
+    last_used = (now - rng.integers(0, 10_000, fleet.n_pods)).astype(np.int64)
+    sr, cnt = s.serve_counters(sr, in_use, last_used)
+    if len(cnt) == 0:
+        cnt = np.zeros(1, dtype=_lib.SERVE_COUNTER)
+    so = np.zeros(n, dtype=_lib.SERVE_OUT)
+    nc = C.c_int32(int(sr["n_cnt"].sum()))
+    serve_args = (s.h, ptr(sr), C.c_int32(n), ptr(cnt), nc, None, None, C.c_int32(0), C.c_int64(now), ptr(so))
+    print(f"n={n:4d} serve  p50 %.1f us  p99 %.1f us" % timed(s.lib.mmp_serve_batch, serve_args))
+    route_args = (s.h, ptr(g), ptr(sr), C.c_int32(n), ptr(cnt), nc, None, None, C.c_int32(0), None, C.c_int32(0), C.c_int64(now), C.c_int64(450_000),
+                  ptr(go), ptr(so))
+    print(f"n={n:4d} route  p50 %.1f us  p99 %.1f us   (guards + serve target in one call)" % timed(s.lib.mmp_route_batch, route_args))
 s.close()
