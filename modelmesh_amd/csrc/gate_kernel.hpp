@@ -298,4 +298,34 @@ __global__ void route_batch_kernel(GateArgs G, ServeArgs S)
     announce_done(G.done);
 }
 
+// ONE route (what invokeModel asks per request): both requests and the request's own counter rows ride in the kernel arguments —
+// nothing is fetched from the slot's pinned memory over the fabric before the decision can start (the exclusion pools, empty on a
+// first try, stay where they are) — one wavefront, lane 0 evaluates, one fence, the flag.
+constexpr int kRouteInlineCnt = 4;
+struct RouteInline {
+    mmp_gate_req g;
+    mmp_serve_req s;
+    mmp_serve_counter cnt[kRouteInlineCnt];
+};
+__global__ __launch_bounds__(64) void route_single_kernel(GateArgs G, ServeArgs S, RouteInline R)
+{
+    __shared__ mmp_serve_counter s_cnt[kRouteInlineCnt];
+    if (threadIdx.x < kRouteInlineCnt) s_cnt[threadIdx.x] = R.cnt[threadIdx.x];
+    wave_sync();
+    if (threadIdx.x == 0) {
+        mmp_serve_req sr = R.s;
+        sr.cnt_off = 0;
+        S.counters = s_cnt;
+        const mmp_serve_out so = serve_eval(S, sr);
+        const mmp_gate_out go = gate_eval(G, R.g);
+        S.outs[0] = so;
+        G.outs[0] = go;
+    }
+    if (G.done.flag) {
+        __threadfence_system();
+        __builtin_amdgcn_wave_barrier();
+        if (threadIdx.x == 0) __hip_atomic_store(G.done.flag, G.done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 }  // namespace mmp

@@ -3818,7 +3818,14 @@ try {
             S.now = now;
             S.done = DoneFlag{nullptr, nullptr, 0};
             HIP_TRY(c, order_after_registry(c, f->stream));
-            hipLaunchKernelGGL(route_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, f->stream, G, S);
+            if (n == 1 && n_counters <= kRouteInlineCnt && sreqs[0].n_cnt <= kRouteInlineCnt) {  // ONE route: the requests ride in the kernel arguments
+                RouteInline R{};
+                R.g = greqs[0];
+                R.s = sreqs[0];
+                for (int32_t j = 0; j < sreqs[0].n_cnt; j++) R.cnt[j] = counters[sreqs[0].cnt_off + j];
+                hipLaunchKernelGGL(route_single_kernel, dim3(1), dim3(64), 0, f->stream, G, S, R);
+            } else
+                hipLaunchKernelGGL(route_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, f->stream, G, S);
             HIP_TRY(c, hipGetLastError());
         }
         HIP_TRY(c, slot_wait(f));
