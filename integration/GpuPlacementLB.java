@@ -78,6 +78,9 @@ final class MmPlace {
     static native int gateBatch(long h, ByteBuffer reqs, int n, ByteBuffer exclPod, ByteBuffer exclTime, int nExcl,
                                 ByteBuffer explicitPool, int nExplicit, long nowMs, long inUseFailureExpiryMs,
                                 ByteBuffer outs);
+    static native int missBatch(long h, ByteBuffer gateReqs, ByteBuffer placeReqs, int n, ByteBuffer exclPod, ByteBuffer exclTime, int nExcl,
+                                ByteBuffer explicitPool, int nExplicit, ByteBuffer extraPool, int nExtra, long nowMs,
+                                long inUseFailureExpiryMs, ByteBuffer gateOuts, ByteBuffer placeOuts);
     static native int routeBatch(long h, ByteBuffer gateReqs, ByteBuffer serveReqs, int n, ByteBuffer counters, int nCounters,
                                  ByteBuffer exclPod, ByteBuffer exclTime, int nExcl, ByteBuffer explicitPool, int nExplicit,
                                  long nowMs, long inUseFailureExpiryMs, ByteBuffer gateOuts, ByteBuffer serveOuts);

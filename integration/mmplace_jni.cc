@@ -274,6 +274,18 @@ JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_gateBatch(JNIEnv *e
 }
 
 // ---- the cache-hit route in one launch: the guards + the serve target of every request (include/mmplace.h: mmp_route_batch)
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_missBatch(JNIEnv *env, jclass, jlong h, jobject gateReqs,
+                                                                       jobject placeReqs, jint n, jobject exclPod, jobject exclTime,
+                                                                       jint nExcl, jobject explicitPool, jint nExplicit,
+                                                                       jobject extraPool, jint nExtra, jlong nowMs,
+                                                                       jlong inUseFailureExpiryMs, jobject gateOuts, jobject placeOuts)
+{
+    return check(env, ctx_of(h),
+                 mmp_miss_batch(ctx_of(h), buf<mmp_gate_req>(env, gateReqs), buf<mmp_place_req>(env, placeReqs), n,
+                                buf<int32_t>(env, exclPod), buf<int64_t>(env, exclTime), nExcl, buf<int32_t>(env, explicitPool), nExplicit,
+                                buf<int32_t>(env, extraPool), nExtra, nowMs, inUseFailureExpiryMs, buf<mmp_gate_out>(env, gateOuts),
+                                buf<mmp_place_out>(env, placeOuts)));
+}
 JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_routeBatch(JNIEnv *env, jclass, jlong h, jobject gateReqs,
                                                                         jobject serveReqs, jint n, jobject counters,
                                                                         jint nCounters, jobject exclPod, jobject exclTime,

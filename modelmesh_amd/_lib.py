@@ -152,6 +152,7 @@ SYMBOLS = [
     ("mmp_cache_read", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                  C.POINTER(C.c_int64), _P]),
     ("mmp_gate_batch", C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int32, _P, C.c_int32, C.c_int64, C.c_int64, _P]),
+    ("mmp_miss_batch", C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.c_int64, C.c_int64, _P, _P]),
     ("mmp_route_batch", C.c_int, [_P, _P, _P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, _P, C.c_int32, C.c_int64, C.c_int64, _P, _P]),
     ("mmp_proactive_plan", C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P]),
     ("mmp_proactive_plan_subset", C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P]),

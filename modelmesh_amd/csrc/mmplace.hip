@@ -465,7 +465,8 @@ hipError_t slot_wait(FastSlot *f)
 hipError_t order_after_registry(mmp_ctx *c, hipStream_t st);
 int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs,
                  hipStream_t st, uint32_t *done_flag = nullptr, uint32_t done_seq = 0, const mmp_place_req *inline_req = nullptr,
-                 uint32_t *done_blocks = nullptr, const PlaceSegs *segs = nullptr, int32_t seg_blocks = 0)
+                 uint32_t *done_blocks = nullptr, const PlaceSegs *segs = nullptr, int32_t seg_blocks = 0, const GateArgs *fused_gate = nullptr,
+                 const mmp_gate_req *fused_greq = nullptr)
 {
     if (n == 0) return MMP_OK;
     PlaceArgs A{};
@@ -526,6 +527,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_flag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_single_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_single_lean_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(miss_single_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_multi_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_multi_long4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
@@ -539,7 +541,9 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
             hipLaunchKernelGGL(place_multi_long_kernel, dim3(seg_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *segs);
         else
             hipLaunchKernelGGL(place_multi_kernel, dim3(seg_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *segs);
-    } else if (inline_req && !c->single_block)
+    } else if (inline_req && fused_gate)  // one cache-miss route: the guards beside the load target (multi_kernel.hpp)
+        hipLaunchKernelGGL(miss_single_kernel, dim3(1), dim3(128), lds, st, c->snap, A, wpad, *inline_req, *fused_gate, *fused_greq);
+    else if (inline_req && !c->single_block)
         hipLaunchKernelGGL(place_single_lean_kernel, dim3(1), dim3(64), lds, st, c->snap, A, wpad, *inline_req);
     else if (inline_req)
         hipLaunchKernelGGL(place_single_kernel, dim3(1), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *inline_req);
@@ -3750,6 +3754,82 @@ try {
     return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_gate_batch");
 } catch (const std::exception &e) {
     return fail(c, MMP_EHIP, "%s: %s", "mmp_gate_batch", e.what());
+}
+
+int mmp_miss_batch(mmp_ctx *c, const mmp_gate_req *greqs, const mmp_place_req *preqs, int32_t n, const int32_t *excl_pod,
+                   const int64_t *excl_time, int32_t n_excl, const int32_t *explicit_pool, int32_t n_explicit, const int32_t *extra_pool,
+                   int32_t n_extra, int64_t now, int64_t in_use_expiry, mmp_gate_out *gouts, mmp_place_out *pouts)
+try {
+    if (!c || n < 0 || n_excl < 0 || n_explicit < 0 || n_extra < 0 || (n > 0 && (!greqs || !preqs || !gouts || !pouts)) ||
+        (n_excl > 0 && (!excl_pod || !excl_time)) || (n_explicit > 0 && !explicit_pool) || (n_extra > 0 && !extra_pool))
+        return fail(c, MMP_EINVAL, "mmp_miss_batch: bad argument");
+    for (int32_t i = 0; i < n; i++) {
+        const mmp_gate_req &g = greqs[i];
+        const mmp_place_req &r = preqs[i];
+        if (g.n_excl < 0 || g.excl_off < 0 || (int64_t)g.excl_off + g.n_excl > n_excl || g.n_explicit < 0 || g.explicit_off < 0 ||
+            (int64_t)g.explicit_off + g.n_explicit > n_explicit)
+            return fail(c, MMP_EINVAL, "mmp_miss_batch: request %d pool range out of bounds", i);
+        if (r.n_extra < 0 || r.extra_off < 0 || (int64_t)r.extra_off + r.n_extra > n_extra)
+            return fail(c, MMP_EINVAL, "mmp_miss_batch: request %d extra range [%d, +%d) outside the pool of %d", i, r.extra_off, r.n_extra, n_extra);
+        if (g.model != r.model) return fail(c, MMP_EINVAL, "mmp_miss_batch: request %d names two models", i);
+    }
+    if (n == 0) return MMP_OK;
+    // One latency slot, TWO launches on its stream (the guards, then the load targets: in stream order, so the second kernel's
+    // completion flag covers both), ONE wait: what two calls did in two launch-wait-return round trips.
+    constexpr int kMissN = 256, kMissPool = kFastExtra / 8;  // place extras | gate excl_pod | gate explicit | gate excl_time (2 ints each)
+    constexpr size_t kMissGreqOff = (size_t)kMissN * sizeof(mmp_place_req), kMissGoutOff = (size_t)kMissN * sizeof(mmp_place_out);
+    static_assert(kMissGreqOff + (size_t)kMissN * sizeof(mmp_gate_req) <= (size_t)kFastN * sizeof(mmp_place_req), "miss slot layout");
+    static_assert(kMissGoutOff + (size_t)kMissN * sizeof(mmp_gate_out) <= (size_t)kFastN * sizeof(mmp_place_out), "miss slot results");
+    if (n > kMissN || n_extra > kMissPool || n_excl > kMissPool || n_explicit > kMissPool) {  // large batches: the two calls
+        const int rc = mmp_gate_batch(c, greqs, n, excl_pod, excl_time, n_excl, explicit_pool, n_explicit, now, in_use_expiry, gouts);
+        return rc != MMP_OK ? rc : mmp_place_batch(c, preqs, n, extra_pool, n_extra, now, pouts);
+    }
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    std::unique_lock<std::mutex> fl;
+    FastSlot *f = slot_acquire(c, fl);
+    char *base = reinterpret_cast<char *>(f->reqs), *obase = reinterpret_cast<char *>(f->outs);
+    memcpy(base, preqs, (size_t)n * sizeof(mmp_place_req));
+    memcpy(base + kMissGreqOff, greqs, (size_t)n * sizeof(mmp_gate_req));
+    int32_t *pool = f->extra;
+    if (n_extra) memcpy(pool, extra_pool, (size_t)n_extra * 4);
+    if (n_excl) {
+        memcpy(pool + kMissPool, excl_pod, (size_t)n_excl * 4);
+        memcpy(pool + 3 * kMissPool, excl_time, (size_t)n_excl * 8);
+    }
+    if (n_explicit) memcpy(pool + 2 * kMissPool, explicit_pool, (size_t)n_explicit * 4);
+    {
+        std::shared_lock<std::shared_mutex> g(c->mu);  // capture the published snapshot + enqueue
+        if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+        if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard");
+        GateArgs G = gate_args(c, n, now, in_use_expiry);
+        G.reqs = reinterpret_cast<const mmp_gate_req *>(base + kMissGreqOff);
+        G.excl_pod = pool + kMissPool;
+        G.explicit_pool = pool + 2 * kMissPool;
+        G.excl_time = reinterpret_cast<const int64_t *>(pool + 3 * kMissPool);
+        G.outs = reinterpret_cast<mmp_gate_out *>(obase + kMissGoutOff);
+        G.done = DoneFlag{nullptr, nullptr, 0};
+        const bool one = n == 1 && preqs[0].n_extra == 0;
+        if (one) {  // ONE launch: both requests in the kernel arguments, guards and load target on two wavefronts
+            const int rc = place_launch(c, f->reqs, n, pool, now, f->outs, f->stream, f->done, ++f->seq, &preqs[0], f->blocks, nullptr, 0, &G,
+                                        &greqs[0]);
+            if (rc != MMP_OK) return rc;
+        } else {
+            HIP_TRY(c, order_after_registry(c, f->stream));
+            hipLaunchKernelGGL(gate_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, f->stream, G);
+            HIP_TRY(c, hipGetLastError());
+            const int rc = place_launch(c, f->reqs, n, pool, now, f->outs, f->stream, f->done, ++f->seq,
+                                        (n == 1 && preqs[0].n_extra == 0) ? &preqs[0] : nullptr, f->blocks);
+            if (rc != MMP_OK) return rc;
+        }
+    }
+    HIP_TRY(c, slot_wait(f));
+    memcpy(pouts, obase, (size_t)n * sizeof(mmp_place_out));
+    memcpy(gouts, obase + kMissGoutOff, (size_t)n * sizeof(mmp_gate_out));
+    return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_miss_batch");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_miss_batch", e.what());
 }
 
 int mmp_route_batch(mmp_ctx *c, const mmp_gate_req *greqs, const mmp_serve_req *sreqs, int32_t n, const mmp_serve_counter *counters,

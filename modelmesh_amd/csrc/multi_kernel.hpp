@@ -65,11 +65,11 @@ __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(4, 
 // for ONE lane's work: 5.6-6.9 us in the kernel trace.  The same decision code on one wavefront: the request comes in the kernel
 // arguments, the windows are staged by the one wavefront, lane 0 decides (lane_decide_win -> lane_decide_r -> the prefix-table
 // phase), the wave path runs on the same wavefront if it is needed, ONE fence, the flag.
-__global__ __launch_bounds__(64) void place_single_lean_kernel(Snap S, PlaceArgs A, int32_t wpad, mmp_place_req rq)
+// the decision of ONE request by the calling wavefront (no workgroup barrier inside: other wavefronts of the workgroup may do
+// something else meanwhile); writes A.outs[0]
+__device__ __forceinline__ void single_place_wave(const Snap &S, PlaceArgs A, int32_t wpad, const mmp_place_req &rq, unsigned char *smem,
+                                                  mmp_place_req *srq, int32_t *s_code)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ mmp_place_req srq;  // (the prefix-table phase and the wave path read the request through A.reqs)
-    __shared__ int32_t s_code;
     TypeWin *s_wins = reinterpret_cast<TypeWin *>(smem);
     uint64_t *s_scr = reinterpret_cast<uint64_t *>(smem + win_lds_bytes(S.T));
     const int lane = lane_id();
@@ -83,10 +83,10 @@ __global__ __launch_bounds__(64) void place_single_lean_kernel(Snap S, PlaceArgs
                                              0, 0);
     }
     if (lane == 0) {
-        srq = rq;
-        s_code = kLaneDone;
+        *srq = rq;  // (the prefix-table phase and the wave path read the request through A.reqs)
+        *s_code = kLaneDone;
     }
-    A.reqs = &srq;
+    A.reqs = srq;
     A.n = 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_sync();
@@ -107,18 +107,42 @@ __global__ __launch_bounds__(64) void place_single_lean_kernel(Snap S, PlaceArgs
         if (code == kLaneDone)
             A.outs[0] = o;
         else
-            s_code = code;
+            *s_code = code;
     }
     wave_sync();
-    if (s_code != kLaneDone) {  // (wave-uniform) the general path: the whole wavefront sweeps the table
+    if (*s_code != kLaneDone) {  // (wave-uniform) the general path: the whole wavefront sweeps the table
         uint64_t *ew = reinterpret_cast<uint64_t *>(smem), *fw = ew + wpad;
         place_one(S, A, 0, ew, fw);
     }
+}
+
+__global__ __launch_bounds__(64) void place_single_lean_kernel(Snap S, PlaceArgs A, int32_t wpad, mmp_place_req rq)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ mmp_place_req srq;
+    __shared__ int32_t s_code;
+    single_place_wave(S, A, wpad, rq, smem, &srq, &s_code);
     if (A.done_flag) {
         __threadfence_system();  // the result row (whichever lane wrote it) before the flag
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) __hip_atomic_store(A.done_flag, A.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane_id() == 0) __hip_atomic_store(A.done_flag, A.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// The cache-MISS route of ONE request (mmp_miss_batch, n = 1): the load target on wavefront 0, the request guards on lane 0 of
+// wavefront 1 — side by side, both requests in the kernel arguments — one fence, the flag.
+__global__ __launch_bounds__(128) void miss_single_kernel(Snap S, PlaceArgs A, int32_t wpad, mmp_place_req rq, GateArgs G, mmp_gate_req gr)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ mmp_place_req srq;
+    __shared__ int32_t s_code;
+    if (threadIdx.x < 64)
+        single_place_wave(S, A, wpad, rq, smem, &srq, &s_code);
+    else if (threadIdx.x == 64)
+        G.outs[0] = gate_eval(G, gr);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 && A.done_flag) __hip_atomic_store(A.done_flag, A.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace mmp

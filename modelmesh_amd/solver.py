@@ -469,6 +469,26 @@ class Solver:
                                           ptr(gouts) if n else None, ptr(souts) if n else None))
         return gouts, souts
 
+    def miss(self, gate_reqs, place_reqs, excl_pod, excl_time, explicit_pool, extra_pool, now, in_use_failure_expiry_ms=450_000):
+        """The cache-miss route in one call (mmp_miss_batch): the request guards + the load target -> (gate outs, place outs)."""
+        from ._lib import GATE_OUT, GATE_REQ, PLACE_OUT, PLACE_REQ
+        gate_reqs = np.ascontiguousarray(gate_reqs, dtype=GATE_REQ)
+        place_reqs = np.ascontiguousarray(place_reqs, dtype=PLACE_REQ)
+        excl_pod = np.ascontiguousarray(excl_pod, dtype=np.int32)
+        excl_time = np.ascontiguousarray(excl_time, dtype=np.int64)
+        explicit_pool = np.ascontiguousarray(explicit_pool, dtype=np.int32)
+        extra_pool = np.ascontiguousarray(extra_pool, dtype=np.int32)
+        n = len(gate_reqs)
+        gouts = np.zeros(n, dtype=GATE_OUT)
+        pouts = np.zeros(n, dtype=PLACE_OUT)
+        self._ck(self.lib.mmp_miss_batch(self.h, ptr(gate_reqs) if n else None, ptr(place_reqs) if n else None, n,
+                                         ptr(excl_pod) if len(excl_pod) else None, ptr(excl_time) if len(excl_time) else None,
+                                         len(excl_pod), ptr(explicit_pool) if len(explicit_pool) else None, len(explicit_pool),
+                                         ptr(extra_pool) if len(extra_pool) else None, len(extra_pool),
+                                         C.c_int64(int(now)), C.c_int64(int(in_use_failure_expiry_ms)),
+                                         ptr(gouts) if n else None, ptr(pouts) if n else None))
+        return gouts, pouts
+
     def proactive_plan(self, default_model_size_units: int, now: int, max_out: int, partition: int = -1, skip_models=None):
         """a17: (models, last_used, info) the leader would proactively load, MRU first; partition >= 0: for that
         ProhibitedTypeSet partition only (one reaper call per partition when type constraints exist)."""

@@ -68,4 +68,9 @@ for n in (1, 256):
     route_args = (s.h, ptr(g), ptr(sr), C.c_int32(n), ptr(cnt), nc, None, None, C.c_int32(0), None, C.c_int32(0), C.c_int64(now), C.c_int64(450_000),
                   ptr(go), ptr(so))
     print(f"n={n:4d} route  p50 %.1f us  p99 %.1f us   (guards + serve target in one call)" % timed(s.lib.mmp_route_batch, route_args))
+    # the cache-miss route: guards + load target — two calls against one (mmp_miss_batch)
+    miss_args = (s.h, ptr(g), ptr(r), C.c_int32(n), None, None, C.c_int32(0), None, C.c_int32(0), None, C.c_int32(0), C.c_int64(now),
+                 C.c_int64(450_000), ptr(go), ptr(po))
+    r["model"] = g["model"]
+    print(f"n={n:4d} miss   p50 %.1f us  p99 %.1f us   (guards + load target in one call)" % timed(s.lib.mmp_miss_batch, miss_args))
 s.close()
