@@ -567,6 +567,69 @@ def multi_entry_leg(fleet, solver, dev, k: int = 8):
                     "repetitions incl. the host's issue time"}
 
 
+def seam_latency_leg(fleet, solver, reps: int = 2000):
+    """What invokeModel costs per request at the boundary: the cache-hit route (guards + serve target) and the cache-miss route
+    (guards + load target), each as ONE call (mmp_route_batch / mmp_miss_batch, n = 1) and as the two calls it replaces.
+    Arguments marshalled once; wall time per call through ctypes."""
+    import ctypes as C
+
+    from modelmesh_amd import _lib
+    from modelmesh_amd._lib import ptr
+    solver.load_fleet(fleet)
+    now = fleet.now
+    lib, h = solver.lib, solver.h
+    rng = np.random.default_rng(7)
+    g = np.zeros(1, dtype=_lib.GATE_REQ)
+    g["model"], g["self_pod"], g["cache_capacity"], g["loader_predicted"] = 12345 % fleet.n_models, 17 % fleet.n_pods, 8_388_608, 6400
+    go = np.zeros(1, dtype=_lib.GATE_OUT)
+    sr = np.zeros(1, dtype=_lib.SERVE_REQ)
+    sr["model"], sr["self_pod"], sr["assume_completed_ms"] = g["model"], g["self_pod"], 3000
+    in_use = rng.integers(0, 3, fleet.n_pods).astype(np.int32)
+    last_used = (now - rng.integers(0, 10_000, fleet.n_pods)).astype(np.int64)
+    sr, cnt = solver.serve_counters(sr, in_use, last_used)
+    if len(cnt) == 0:
+        cnt = np.zeros(1, dtype=_lib.SERVE_COUNTER)
+    so = np.zeros(1, dtype=_lib.SERVE_OUT)
+    nc = C.c_int32(int(sr["n_cnt"].sum()))
+    pr, _ = wl_requests(fleet, 1)
+    pr["model"], pr["self_pod"] = g["model"], g["self_pod"]
+    po = np.zeros(1, dtype=_lib.PLACE_OUT)
+    one = C.c_int32(1)
+    z = C.c_int32(0)
+    calls = {
+        "gates": (lib.mmp_gate_batch, (h, ptr(g), one, None, None, z, None, z, C.c_int64(now), C.c_int64(450_000), ptr(go))),
+        "serve": (lib.mmp_serve_batch, (h, ptr(sr), one, ptr(cnt), nc, None, None, z, C.c_int64(now), ptr(so))),
+        "place": (lib.mmp_place_batch, (h, ptr(pr), one, None, z, C.c_int64(now), ptr(po))),
+        "route": (lib.mmp_route_batch, (h, ptr(g), ptr(sr), one, ptr(cnt), nc, None, None, z, None, z, C.c_int64(now), C.c_int64(450_000),
+                                        ptr(go), ptr(so))),
+        "miss": (lib.mmp_miss_batch, (h, ptr(g), ptr(pr), one, None, None, z, None, z, None, z, C.c_int64(now), C.c_int64(450_000), ptr(go),
+                                      ptr(po))),
+    }
+    out = {}
+    for name, (fn, a) in calls.items():
+        for _ in range(200):
+            fn(*a)
+        t = np.zeros(reps)
+        for i in range(reps):
+            t0 = time.perf_counter()
+            rc = fn(*a)
+            t[i] = time.perf_counter() - t0
+            if rc != 0:
+                raise RuntimeError(f"{name}: rc {rc}")
+        out[name] = {"p50_us": float(np.percentile(t, 50) * 1e6), "p99_us": float(np.percentile(t, 99) * 1e6)}
+    return {"cache_hit_route_one_call": out["route"], "cache_hit_as_two_calls_p50_us": out["gates"]["p50_us"] + out["serve"]["p50_us"],
+            "cache_miss_route_one_call": out["miss"], "cache_miss_as_two_calls_p50_us": out["gates"]["p50_us"] + out["place"]["p50_us"],
+            "single_calls": {k: out[k] for k in ("gates", "serve", "place")},
+            "note": "n = 1 through the C ABI (ctypes, arguments marshalled once): mmp_route_batch = request guards + serve target, "
+                    "mmp_miss_batch = request guards + load target, one launch each"}
+
+
+def wl_requests(fleet, n):
+    from modelmesh_amd import workload as wl
+    r, x = wl.make_requests(fleet, 3, n=max(n, 1), extra_frac=0.0)
+    return r[:n].copy(), x
+
+
 def _single_prober():
     """tools/micro/single_prober.c built with gcc (None when no compiler is at hand: the leg then reports no latencies)"""
     import ctypes as C
@@ -1345,6 +1408,11 @@ def main():
                 line["multi_batch_entry"] = multi_entry_leg(fleet, solver, dev)
             except Exception as e:
                 line["multi_batch_entry"] = {"error": f"{type(e).__name__}: {e}"}
+        if not args.kernel_only:
+            try:
+                line["per_request_seams"] = seam_latency_leg(fleet, solver)
+            except Exception as e:
+                line["per_request_seams"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.kernel_only and not args.no_secondary:
             try:
                 line["kernels"] = secondary_kernels_leg(fleet, solver, local_rank, args.workload)
