@@ -307,23 +307,26 @@ struct RouteInline {
     mmp_serve_req s;
     mmp_serve_counter cnt[kRouteInlineCnt];
 };
-__global__ __launch_bounds__(64) void route_single_kernel(GateArgs G, ServeArgs S, RouteInline R)
+__global__ __launch_bounds__(128) void route_single_kernel(GateArgs G, ServeArgs S, RouteInline R)
 {
+    // the two evaluations are two dependent-load chains: side by side on two wavefronts (lane 0 of each)
     __shared__ mmp_serve_counter s_cnt[kRouteInlineCnt];
-    if (threadIdx.x < kRouteInlineCnt) s_cnt[threadIdx.x] = R.cnt[threadIdx.x];
-    wave_sync();
     if (threadIdx.x == 0) {
-        mmp_serve_req sr = R.s;
-        sr.cnt_off = 0;
-        S.counters = s_cnt;
-        const mmp_serve_out so = serve_eval(S, sr);
-        const mmp_gate_out go = gate_eval(G, R.g);
-        S.outs[0] = so;
-        G.outs[0] = go;
+        G.outs[0] = gate_eval(G, R.g);
+    } else if (threadIdx.x >= 64) {
+        const int t = threadIdx.x - 64;
+        if (t < kRouteInlineCnt) s_cnt[t] = R.cnt[t];
+        wave_sync();
+        if (t == 0) {
+            mmp_serve_req sr = R.s;
+            sr.cnt_off = 0;
+            S.counters = s_cnt;
+            S.outs[0] = serve_eval(S, sr);
+        }
     }
     if (G.done.flag) {
         __threadfence_system();
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(G.done.flag, G.done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

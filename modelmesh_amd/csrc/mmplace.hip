@@ -3903,7 +3903,7 @@ try {
                 R.g = greqs[0];
                 R.s = sreqs[0];
                 for (int32_t j = 0; j < sreqs[0].n_cnt; j++) R.cnt[j] = counters[sreqs[0].cnt_off + j];
-                hipLaunchKernelGGL(route_single_kernel, dim3(1), dim3(64), 0, f->stream, G, S, R);
+                hipLaunchKernelGGL(route_single_kernel, dim3(1), dim3(128), 0, f->stream, G, S, R);
             } else
                 hipLaunchKernelGGL(route_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, f->stream, G, S);
             HIP_TRY(c, hipGetLastError());

@@ -123,8 +123,11 @@ __global__ __launch_bounds__(64) void place_single_lean_kernel(Snap S, PlaceArgs
     __shared__ int32_t s_code;
     single_place_wave(S, A, wpad, rq, smem, &srq, &s_code);
     if (A.done_flag) {
-        __threadfence_system();  // the result row (whichever lane wrote it) before the flag
-        __builtin_amdgcn_wave_barrier();
+        if (s_code != kLaneDone) {  // (wave-uniform) the wave path: whichever lane wrote the row, before the flag
+            __threadfence_system();
+            __builtin_amdgcn_wave_barrier();
+        }
+        // lane 0 wrote the row itself: its release store orders the row before the flag (one fence, not two)
         if (lane_id() == 0) __hip_atomic_store(A.done_flag, A.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
