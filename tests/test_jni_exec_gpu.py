@@ -118,3 +118,55 @@ def test_serve_and_gates_through_the_veneer_equal_the_c_abi(veneer):
         finally:
             veneer.call("destroy", h)
         break
+
+
+def test_route_miss_and_delta_commits_through_the_veneer_equal_the_c_abi(veneer):
+    """Round 4's natives: routeBatch (guards + serve target), missBatch (guards + load target) — one request at a time, as
+    invokeModel asks — and deltaCommits."""
+    name, fleet, ids, r, xp, xt, expl, expiry = next(iter(rf.gate_cases()))
+    rng = np.random.default_rng(3)
+    P = fleet.n_pods
+    in_use = rng.integers(0, 3, P).astype(np.int32)
+    last_used = (fleet.now - rng.choice([0, 5, 100, 10_000], P)).astype(np.int64)
+    g = r[:24].copy()
+    sr = np.zeros(len(g), dtype=_lib.SERVE_REQ)
+    sr["model"], sr["self_pod"], sr["assume_completed_ms"] = g["model"], g["self_pod"], 3000
+    sr["excl_off"], sr["n_excl"] = g["excl_off"], g["n_excl"]
+    preqs, extra = wl.make_requests(fleet, 9, n=len(g), extra_frac=0.0)
+    preqs["model"], preqs["self_pod"] = g["model"], g["self_pod"]
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        sr2, counters = s.serve_counters(sr, in_use, last_used)
+        want_g = s.gates(g, xp, xt, expl, fleet.now, expiry)
+        want_s = s.serve_k(sr2, counters, xp, xt, fleet.now)
+        want_p = s.place(preqs, extra, fleet.now)
+    finally:
+        s.close()
+    h = _stage(veneer, fleet)
+    try:
+        nb = jm.ByteBuffer(np.zeros(1, np.int64))
+        assert veneer.call("deltaCommits", h, nb) == 0 and int(nb.arr[0]) == 0
+        for i in range(len(g)):
+            go = jm.ByteBuffer(np.zeros(1, dtype=_lib.GATE_OUT))
+            so = jm.ByteBuffer(np.zeros(1, dtype=_lib.SERVE_OUT))
+            g1, s1 = g[i:i + 1].copy(), sr2[i:i + 1].copy()
+            c1 = counters[int(s1["cnt_off"][0]): int(s1["cnt_off"][0]) + int(s1["n_cnt"][0])].copy()
+            s1["cnt_off"] = 0
+            rc = veneer.call("routeBatch", h, _bb(g1), _bb(s1), 1, _bb(c1), len(c1), _bb(xp, np.int32), _bb(xt, np.int64), len(xp),
+                             _bb(expl, np.int32), len(expl), int(fleet.now), int(expiry), go, so)
+            assert rc == 0 and veneer.env.pending() is None, veneer.env.pending()
+            assert go.arr[0] == want_g[i] and so.arr[0] == want_s[i], i
+            po = jm.ByteBuffer(np.zeros(1, dtype=_lib.PLACE_OUT))
+            rc = veneer.call("missBatch", h, _bb(g1), _bb(preqs[i:i + 1].copy()), 1, _bb(xp, np.int32), _bb(xt, np.int64), len(xp),
+                             _bb(expl, np.int32), len(expl), None, 0, int(fleet.now), int(expiry), go, po)
+            assert rc == 0 and veneer.env.pending() is None, veneer.env.pending()
+            assert go.arr[0] == want_g[i] and po.arr[0] == want_p[i], i
+        # a republished record, a commit: the insertion path through the veneer's podsUpsert / commit
+        row = fleet.pods[:1].copy()
+        row["count"] += 1
+        assert veneer.call("podsUpsert", h, _bb(np.zeros(1, np.int32)), _bb(row), 1) == 0
+        assert veneer.call("commit", h) == 0
+        assert veneer.call("deltaCommits", h, nb) == 0 and int(nb.arr[0]) in (0, 1)
+    finally:
+        veneer.call("destroy", h)
