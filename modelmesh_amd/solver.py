@@ -172,6 +172,15 @@ class Solver:
         st = np.zeros(max(n, 1), np.int64)
         status = np.zeros(max(n, 1), np.int32)
         self._ck(self.lib.mmp_pods_ingest_json(self.h, blob, ptr(off), n, ptr(pod_idx), ptr(live), ptr(st), ptr(status)))
+        # the host mirror serve_counters reads (what litelinks' instance list would hold): the ingested rows' live flags
+        mirror = getattr(self, "_live", None)
+        if mirror is not None and n:
+            top = int(pod_idx.max()) + 1
+            if top > len(mirror):
+                mirror = np.concatenate([mirror, np.zeros(top - len(mirror), bool)])
+            ok = status[:n] == 0
+            mirror[pod_idx[ok]] = True if live is None else live[ok].astype(bool)
+            self._live = mirror
         return status[:n], st[:n]
 
     def load_type_names(self, names, unknown_type):
@@ -187,6 +196,7 @@ class Solver:
         status = np.zeros(max(n, 1), np.int32)
         self._ck(self.lib.mmp_models_ingest_json(self.h, blob, ptr(off), n, ptr(lul), ptr(status)))
         self.n_models = n
+        self._models = self._ent_pod = None  # (the registry now lives on the device only: serve_counters needs load_models / upsert_models)
         return status[:n], lul[:n]
 
     def get_pods(self) -> np.ndarray:
@@ -341,7 +351,10 @@ class Solver:
         reqs = np.ascontiguousarray(reqs, dtype=SERVE_REQ).copy()
         in_use = np.ascontiguousarray(in_use, dtype=np.int32)
         last_used = np.ascontiguousarray(last_used, dtype=np.int64)
-        models, ent_pod, live = self._models, self._ent_pod, self._live
+        models, ent_pod, live = getattr(self, "_models", None), getattr(self, "_ent_pod", None), getattr(self, "_live", None)
+        if models is None or ent_pod is None or live is None:
+            raise RuntimeError("serve_counters needs the host mirror of the registry and the instance list: load_models / load_pods "
+                               "on this Solver (a registry ingested from JSON lives on the device only)")
         ok = (reqs["model"] >= 0) & (reqs["model"] < len(models))
         m = models[np.where(ok, reqs["model"], 0)]
         k = np.where(ok, m["n_loaded"], 0).astype(np.int64)
