@@ -1249,9 +1249,12 @@ namespace {
 struct ZeroBatch {  // collects buffers, clears them with one zero_regions_kernel launch
     ZeroList Z{};
     size_t most = 0;
+    hipStream_t stream = nullptr;
+    explicit ZeroBatch(hipStream_t st) : stream(st) {}
     void add(void *p, size_t bytes)
     {
         if (!p || bytes == 0) return;
+        if (Z.n == kZeroRegions) launch(stream);  // (a full table goes out; the rest follows in another launch)
         Z.p[Z.n] = p;
         Z.bytes[Z.n] = (bytes + 3) & ~(size_t)3;  // (DevBuf allocations are rounded up: the tail bytes exist)
         most = std::max(most, bytes);
@@ -1488,7 +1491,7 @@ try {
     }
     if (P && !delta) HIP_TRY(c, hipMemcpyAsync(B.pods.p, c->pods.data(), (size_t)P * sizeof(mmp_pod_row), hipMemcpyHostToDevice, st));
     {
-        ZeroBatch zb;
+        ZeroBatch zb(st);
         zb.add(c->rank.p, padded * 4);
         zb.add(c->occupancy.p, padded * 4);
         zb.add(c->flag.p, sizeof(int32_t));
@@ -2267,7 +2270,7 @@ try {
     HIP_TRY(c, N.d_has_allowed.ensure(T));
 
     {
-        ZeroBatch zb;
+        ZeroBatch zb(st);
         zb.add(c->occupancy.p, padded_full * 4);
         zb.add(c->flag.p, sizeof(int32_t));
         zb.add(B.lru.p, padded * 8);
