@@ -38,6 +38,7 @@
 #include "rebalance_kernels.hpp"
 #include "shard_kernels.hpp"
 #include "multi_kernel.hpp"
+#include "rank_sample.hpp"
 #include "snapshot.hpp"
 #include "types_kernel.hpp"
 #include "upgrade_tracker.hpp"
@@ -224,7 +225,7 @@ struct mmp_ctx {
     int32_t single_block = 0;       // MMP_SINGLE_BLOCK=1: a single decision runs the batch kernel's workgroup (place_single_kernel)
     int32_t no_delta = 0;           // MMP_NO_DELTA=1: every commit ranks from scratch (tests)
     int64_t n_delta_commits = 0;
-    int32_t rank_mode = 0;  // MMP_RANK_MODE: 0 auto (sort from kRankSortMinPods pods), 1 all-pairs, 2 sort whenever legal (tests)
+    int32_t rank_mode = 0;  // MMP_RANK_MODE: 0 auto (rank by sampling from kRankSortMinPods pods), 1 all-pairs, 2 by sampling whenever legal, 3 merge sort whenever legal (tests)
     Snap sview{};  // the lane path's view of this shard's slice (place_shard_fast_kernel)
     DevBuf f_offs, f_idx, f_reqs, f_outs, f_scan_tmp;  // speculative form: the compacted rest of a batch
     // ... and what ONE batch in flight owns until its rest count has been read, twice (slot = batch parity): an asynchronous
@@ -281,6 +282,7 @@ struct mmp_ctx {
     int32_t k_caches = 0;
     std::vector<int32_t> k_n;  // host mirror of the live entry counts
     DevBuf r_part;  // per-workgroup partials of the proactive plan's first pass
+    DevBuf rs_split, rs_int;  // rank_sample.hpp: the sorted samples; range_of[P] | idx[P] | hist | cur | off
     DevBuf k_cap, k_wsize, k_oldest, k_ubm, k_ops, k_order, k_opoff, k_outs, k_ev, k_evoff, k_ids;  // k_ids: cache ids grouped by replay team width
 
     // wire-format ingestion: per-pod id attributes and the hash tables the parsers probe
@@ -335,6 +337,7 @@ inline SnapSide &cur_side(mmp_ctx *c) { return c->side[c->cur]; }
 // tests/test_abi.py::test_library_never_uses_the_null_stream keeps it that way.
 hipError_t copy_sync(mmp_ctx *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
 constexpr int kRankSortMinPods = 8192;
+constexpr int kSampleMinPods = 1024;  // (the sample path needs P >= its 512 samples; MMP_RANK_MODE=3: the merge sort instead)
 
 // Kernel-time bracket of a host-pointer entry point (owner of c->batch_mu): KT_BEGIN after the H2D
 // copies are enqueued, KT_END after the last kernel, kt_collect() once the stream has been synchronised.
@@ -692,7 +695,7 @@ void mmp_destroy(mmp_ctx *c)
                       &c->models, &c->ent_pod, &c->ent_time, &c->c_seg,
                       &c->c_lu, &c->c_wt, &c->c_cap, &c->s_reqs, &c->s_outs, &c->s_extra, &c->s_a, &c->s_b,
                       &c->s_c, &c->s_d, &c->r_ps, &c->r_counts, &c->r_keys, &c->r_vals, &c->r_keys2, &c->r_vals2,
-                      &c->r_tmp, &c->r_part, &c->r_out_model, &c->r_out_lu, &c->rt_sreqs, &c->rt_souts, &c->rt_cnt, &c->k_ids, &c->k_cap, &c->k_wsize, &c->k_oldest, &c->k_ubm, &c->k_ops, &c->k_order,
+                      &c->r_tmp, &c->r_part, &c->rs_split, &c->rs_int, &c->r_out_model, &c->r_out_lu, &c->rt_sreqs, &c->rt_souts, &c->rt_cnt, &c->k_ids, &c->k_cap, &c->k_wsize, &c->k_oldest, &c->k_ubm, &c->k_ops, &c->k_order,
                       &c->k_opoff, &c->k_outs, &c->k_ev, &c->k_evoff, &c->idtab_hash, &c->idtab_val, &c->tytab_hash,
                       &c->tytab_val, &c->j_buf, &c->j_off, &c->j_rows, &c->j_aux, &c->j_status, &c->j_cnt, &c->j_offs, &c->j_tmp_pod,
                       &c->j_tmp_time, &c->j_scan_tmp, &c->rk_rows, &c->rk_idx, &c->rk_tmp, &c->u_idx, &c->u_rows, &c->u_cnt, &c->u_offs, &c->u_tmp, &c->f_flags[0], &c->f_flags[1], &c->f_offs, &c->f_idx, &c->f_reqs, &c->f_outs, &c->f_scan_tmp, &c->f_cnt[0], &c->f_cnt[1],
@@ -1246,6 +1249,27 @@ namespace {
 // ClusterStats of the snapshot being committed (snapshot.hpp "instance partitions").  Enqueues on st; the
 // host mirrors are valid once the caller has synchronised st.  Call after cluster_stats_kernel.  N = the side
 // state of the snapshot being built (its d_has_allowed / stats_acc are already filled).
+// Rank the table from scratch by sampling (rank_sample.hpp): ranks of the rows [p_lo, p_hi) into `rank` (the others untouched).
+// Only for a table on which the comparator is a strict total order (the caller's O(P) check).
+int rank_by_sampling(mmp_ctx *c, const mmp_pod_row *d_pods, int32_t P, int64_t min_space, int64_t churn2, int32_t p_lo, int32_t p_hi,
+                     int32_t *d_rank, hipStream_t st)
+{
+    const int32_t S = P >= 32768 ? 512 : 256;
+    HIP_TRY(c, c->rs_split.ensure((size_t)2 * S * sizeof(RankRow)));
+    HIP_TRY(c, c->rs_int.ensure(((size_t)2 * P + 3 * (size_t)(S + 2)) * 4));
+    RankRow *split = c->rs_split.as<RankRow>();
+    int32_t *range_of = c->rs_int.as<int32_t>(), *idx = range_of + P, *hist = idx + P, *cur = hist + (S + 2), *off = cur + (S + 2);
+    RankRow *srows = split + S;
+    hipLaunchKernelGGL(sample_gather_kernel, dim3(div_up(S + 1, 256)), dim3(256), 0, st, d_pods, P, S, min_space, srows, hist, cur);
+    hipLaunchKernelGGL(sample_sort_kernel, dim3(S), dim3(256), 0, st, srows, S, churn2, split);
+    hipLaunchKernelGGL(sample_range_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, d_pods, P, S, min_space, churn2, split, range_of, hist);
+    hipLaunchKernelGGL(sample_scatter_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, P, S, range_of, hist, cur, off, idx);
+    hipLaunchKernelGGL(sample_rank_kernel, dim3(div_up(p_hi - p_lo, 4)), dim3(256), 0, st, d_pods, min_space, churn2, range_of, off, idx, p_lo, p_hi,
+                       d_rank);
+    HIP_TRY(c, hipGetLastError());
+    return MMP_OK;
+}
+
 struct ZeroBatch {  // collects buffers, clears them with one zero_regions_kernel launch
     ZeroList Z{};
     size_t most = 0;
@@ -1558,12 +1582,15 @@ try {
         next_full = n_present > 0 && n_nonfull * 16 <= n_present;
         // all-pairs is embarrassingly parallel and wins below ~8k pods (measured: 10k pods 172 us all-pairs vs 120 us
         // sort; 50k pods 4.3 ms vs 0.25 ms); a merge sort of a few thousand 64-byte keys is latency bound
-        const bool want_sort = c->rank_mode == 2 || (c->rank_mode == 0 && P >= kRankSortMinPods);
+        const bool want_sort = c->rank_mode == 2 || c->rank_mode == 3 || (c->rank_mode == 0 && P >= kRankSortMinPods);
         if (delta) {
             const SnapBufs &A = c->sb[c->cur];
             hipLaunchKernelGGL(delta_scatter_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, A.pods.as<mmp_pod_row>(), A.pos_of.as<int32_t>(),
                                P, dl, B.pods.as<mmp_pod_row>(), c->rank.as<int32_t>(), B.lru.as<int64_t>(), B.rem.as<int64_t>(),
                                B.cnt.as<int32_t>(), B.rpm.as<int32_t>(), B.orig.as<int32_t>(), B.pos_of.as<int32_t>());
+        } else if (want_sort && P >= kSampleMinPods && sort_legal && c->rank_mode != 3) {
+            const int rc = rank_by_sampling(c, B.pods.as<mmp_pod_row>(), P, min_space, churn2, 0, P, c->rank.as<int32_t>(), st);
+            if (rc != MMP_OK) return rc;
         } else if (want_sort && P >= 2 && sort_legal) {
             HIP_TRY(c, c->rk_rows.ensure((size_t)P * sizeof(RankRow)));
             HIP_TRY(c, c->rk_idx.ensure((size_t)P * sizeof(RankRow)));
@@ -2194,8 +2221,11 @@ try {
                 if (rem < min_space && r.lru_time <= churn2) full_low_lru = true;
             }
             const bool sort_legal = !(versions_differ && full_low_lru) && !wide_count;
-            const bool want_sort = c->rank_mode == 2 || (c->rank_mode == 0 && (int64_t)(p_hi - p_lo) * P >= (int64_t)kRankSortMinPods * kRankSortMinPods);
-            if (want_sort && sort_legal && P >= 2) {
+            const bool want_sort = c->rank_mode == 2 || c->rank_mode == 3 || (c->rank_mode == 0 && (int64_t)(p_hi - p_lo) * P >= (int64_t)kRankSortMinPods * kRankSortMinPods);
+            if (want_sort && sort_legal && P >= kSampleMinPods && c->rank_mode != 3) {
+                const int rc = rank_by_sampling(c, B.pods.as<mmp_pod_row>(), P, min_space, churn2, p_lo, p_hi, static_cast<int32_t *>(d_rank), st);
+                if (rc != MMP_OK) return rc;
+            } else if (want_sort && sort_legal && P >= 2) {
                 HIP_TRY(c, c->rk_rows.ensure((size_t)P * sizeof(RankRow)));
                 HIP_TRY(c, c->rk_idx.ensure((size_t)P * sizeof(RankRow)));
                 const PlacementRowLess less{churn2};

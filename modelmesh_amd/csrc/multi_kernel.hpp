@@ -123,11 +123,11 @@ __global__ __launch_bounds__(64) void place_single_lean_kernel(Snap S, PlaceArgs
     __shared__ int32_t s_code;
     single_place_wave(S, A, wpad, rq, smem, &srq, &s_code);
     if (A.done_flag) {
-        if (s_code != kLaneDone) {  // (wave-uniform) the wave path: whichever lane wrote the row, before the flag
-            __threadfence_system();
-            __builtin_amdgcn_wave_barrier();
-        }
-        // lane 0 wrote the row itself: its release store orders the row before the flag (one fence, not two)
+        // the result row (whichever lane wrote it) before the flag.  (Relying on lane 0's release store alone for a row lane 0 wrote
+        // itself was tried: the host then saw the flag before the row now and then — test_single_decisions_complete_while_a_commit_
+        // is_running caught stale rows.)
+        __threadfence_system();
+        __builtin_amdgcn_wave_barrier();
         if (lane_id() == 0) __hip_atomic_store(A.done_flag, A.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

@@ -612,16 +612,22 @@ def test_kernel_time_bracket():
         s.close()
 
 
-@pytest.mark.parametrize("seed", range(4))
-def test_rank_by_sorting_equals_all_pairs_ranking(seed, monkeypatch):
-    """From 8192 pods on, commit ranks by rocprim::merge_sort with the literal comparator whenever
-    PLACEMENT_ORDER is provably a strict total order on the table, and by the all-pairs kernel otherwise
-    (MMP_RANK_MODE=1 forces all-pairs, 2 forces the sort whenever it is legal): same order, element for
-    element, and the oracle's."""
-    pods = [2, 63, 300, 9000][seed]
+@pytest.mark.parametrize("seed", range(7))
+def test_rank_by_sampling_and_by_sorting_equal_all_pairs_ranking(seed, monkeypatch):
+    """From 8192 pods on, commit ranks WITHOUT a comparison sort whenever PLACEMENT_ORDER is provably a strict total order on the
+    table — sampled splitters, binary search, all pairs inside a range (rank_sample.hpp) — and by the all-pairs kernel otherwise
+    (MMP_RANK_MODE=1 forces all-pairs, 2 the sampling path whenever it is legal and the table has >= 1024 rows, 3
+    rocprim::merge_sort with the literal comparator): same order, element for element, and the oracle's.  Tables: tiny, ragged,
+    9000 / 33000 rows (256 / 512 samples), one where nearly every row falls between two samples (a range of thousands)."""
+    pods = [2, 63, 300, 1024, 9000, 33000, 5000][seed]
     fleet = wl.fuzz_fleet(seed + 300, pods=pods)
+    if seed == 6:  # a skewed table: sampled rows (every P/256-th) all full, the rest not -> almost every row in the first range
+        fleet.pods["version"] = 7
+        stride = np.arange(256) * pods // 256
+        fleet.pods["used"] = fleet.pods["capacity"] // 10
+        fleet.pods["used"][stride] = fleet.pods["capacity"][stride]
     orders = []
-    for mode in ("1", "2"):
+    for mode in ("1", "2", "3"):
         monkeypatch.setenv("MMP_RANK_MODE", mode)
         s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
         try:
@@ -629,7 +635,7 @@ def test_rank_by_sorting_equals_all_pairs_ranking(seed, monkeypatch):
             orders.append(s.order())
         finally:
             s.close()
-    assert np.array_equal(orders[0], orders[1])
+    assert np.array_equal(orders[0], orders[1]) and np.array_equal(orders[0], orders[2])
     assert np.array_equal(orders[0], OracleFleet(fleet).order)
 
 
