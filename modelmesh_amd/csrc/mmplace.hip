@@ -1256,15 +1256,16 @@ int rank_by_sampling(mmp_ctx *c, const mmp_pod_row *d_pods, int32_t P, int64_t m
 {
     const int32_t S = P >= 32768 ? 512 : 256;
     HIP_TRY(c, c->rs_split.ensure((size_t)2 * S * sizeof(RankRow)));
-    HIP_TRY(c, c->rs_int.ensure(((size_t)2 * P + 3 * (size_t)(S + 2)) * 4));
+    HIP_TRY(c, c->rs_int.ensure(((size_t)2 * P + (2 * kCtrStride + 1) * (size_t)(S + 2)) * 4));
     RankRow *split = c->rs_split.as<RankRow>();
-    int32_t *range_of = c->rs_int.as<int32_t>(), *idx = range_of + P, *hist = idx + P, *cur = hist + (S + 2), *off = cur + (S + 2);
+    int32_t *range_of = c->rs_int.as<int32_t>(), *idx = range_of + P, *hist = idx + P, *cur = hist + (S + 2) * kCtrStride,
+            *off = cur + (S + 2) * kCtrStride;
     RankRow *srows = split + S;
     hipLaunchKernelGGL(sample_gather_kernel, dim3(div_up(S + 1, 256)), dim3(256), 0, st, d_pods, P, S, min_space, srows, hist, cur);
     hipLaunchKernelGGL(sample_sort_kernel, dim3(S), dim3(256), 0, st, srows, S, churn2, split);
     hipLaunchKernelGGL(sample_range_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, d_pods, P, S, min_space, churn2, split, range_of, hist);
     hipLaunchKernelGGL(sample_scatter_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, P, S, range_of, hist, cur, off, idx);
-    hipLaunchKernelGGL(sample_rank_kernel, dim3(div_up(p_hi - p_lo, 4)), dim3(256), 0, st, d_pods, min_space, churn2, range_of, off, idx, p_lo, p_hi,
+    hipLaunchKernelGGL(sample_rank_kernel, dim3(div_up(P, 16)), dim3(1024), 0, st, d_pods, P, min_space, churn2, range_of, off, idx, p_lo, p_hi,
                        d_rank);
     HIP_TRY(c, hipGetLastError());
     return MMP_OK;

@@ -13,6 +13,7 @@
 namespace mmp {
 
 constexpr int kSampleMax = 512;   // splitters (256 below 32k rows)
+constexpr int kCtrStride = 16;    // the range counters one per 64-byte line: P atomics into a few dozen lines serialise (~7 ns each)
 
 // the S sample rows (every P/S-th row of the table) + cleared range counters
 __global__ __launch_bounds__(256) void sample_gather_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int32_t S, int64_t min_space,
@@ -25,7 +26,7 @@ __global__ __launch_bounds__(256) void sample_gather_kernel(const mmp_pod_row *_
         r.pad0 = (uint32_t)p;
         srows[i] = r;
     }
-    if (i <= S) hist[i] = cur[i] = 0;
+    if (i <= S) hist[i * kCtrStride] = cur[i * kCtrStride] = 0;
 }
 
 // one workgroup per sample, one LANE per pair: its rank among the samples = how many sort before it; written in place
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void sample_range_kernel(const mmp_pod_row *__
             hi = mid;
     }
     range_of[p] = lo;
-    atomicAdd(&hist[lo], 1);
+    atomicAdd(&hist[lo * kCtrStride], 1);
 }
 
 // exclusive scan of the S + 1 range sizes by every workgroup for itself (513 integers: cheaper than a launch of its own)
@@ -74,7 +75,7 @@ __device__ __forceinline__ void range_offsets(const int32_t *__restrict__ hist, 
     __syncthreads();
     for (int base = 0; base <= S; base += blockDim.x) {
         const int i = base + threadIdx.x;
-        const int32_t v = i <= S ? hist[i] : 0;
+        const int32_t v = i <= S ? hist[i * kCtrStride] : 0;
         // (blockDim.x is a multiple of 64: wave scans + per-wave totals through LDS)
         __shared__ int32_t s_wt[16];
         const int32_t incl = wave_incl_scan_i32(v);
@@ -102,17 +103,20 @@ __global__ __launch_bounds__(256) void sample_scatter_kernel(int32_t P, int32_t 
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;
     const int b = range_of[p];
-    idx[s_off[b] + atomicAdd(&cur[b], 1)] = p;
+    idx[s_off[b] + atomicAdd(&cur[b * kCtrStride], 1)] = p;
 }
 
 // one WAVEFRONT per row: rank = rows in earlier ranges + rows of its own range that sort before it (one lane per pair, the range's
-// rows gathered 64 at a time) — the cost of a row is its range's size, spread over the chip, whatever the sample made of the ranges
-__global__ __launch_bounds__(256) void sample_rank_kernel(const mmp_pod_row *__restrict__ pods, int64_t min_space, int64_t churn2,
-                                                          const int32_t *__restrict__ range_of, const int32_t *__restrict__ off,
-                                                          const int32_t *__restrict__ idx, int32_t p_lo, int32_t p_hi, int32_t *__restrict__ rank)
+// rows gathered 64 at a time) — the cost of a row is its range's size, spread over the chip, whatever the sample made of the ranges.
+// Rows are taken in RANGE order, sixteen per workgroup: neighbours gather the same rows, from the CU's L1 instead of L2.
+__global__ __launch_bounds__(1024) void sample_rank_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int64_t min_space, int64_t churn2,
+                                                           const int32_t *__restrict__ range_of, const int32_t *__restrict__ off,
+                                                           const int32_t *__restrict__ idx, int32_t p_lo, int32_t p_hi, int32_t *__restrict__ rank)
 {
-    const int p = p_lo + blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = lane_id();
-    if (p >= p_hi) return;
+    const int pos = blockIdx.x * 16 + (int)(threadIdx.x >> 6), lane = lane_id();
+    if (pos >= P) return;
+    const int p = idx[pos];
+    if (p < p_lo || p >= p_hi) return;  // (a pod-axis shard keeps its own slice's ranks)
     const int b = range_of[p], lo = off[b], n = off[b + 1] - lo;
     const RankRow me = make_rank_row(pods[p], min_space);
     int32_t cnt = 0;
