@@ -293,7 +293,40 @@ typedef struct {
     int32_t reserved;
 } mmp_cache_entry;
 
-/* rateTrackingTask (MM.java:5636-5832), limitModelConcurrency == false. */
+/* MaxConcCacheEntry (MM.java:2641-2797): what a mesh that runs with limitModelConcurrency == true keeps per loaded model — one
+ * row per cache entry, in the order of the entries.  The rate task evaluates getRpmScaleThreshold(true) on it (the row's own
+ * threshold replaces scale_up_rpm_threshold: "latency-based" scaling, MM.java:5677, :5702-5707), the janitor
+ * getRpmScaleThreshold(false) and queuedRequestCount() (:6294-6305). */
+#define MMP_CONC_COUNT_BITS 21 /* MM.java:2653: completed invocations in the low bits of countAndTimeSum, the sum of their
+                                  durations in 1/10 ms above */
+typedef struct {
+    int64_t count_and_time_sum; /* countAndTimeSum.sum()                      */
+    int64_t prior_sum;          /* priorSum                                   */
+    int32_t prior_count;        /* priorCount                                 */
+    int32_t max_conc;           /* maxConc                                    */
+    int32_t queued_requests;    /* queuedRequestCount() (the janitor, :6303)  */
+    int32_t reserved;
+} mmp_conc_entry;
+typedef struct {
+    int32_t threshold;       /* getRpmScaleThreshold(true) as the task got it; 0 for an entry it skipped before the call (:5697) */
+    int32_t reset;           /* 1: the call took countAndTimeSum.sumThenReset() (:2771): the caller resets its adder and stores: */
+    int64_t new_prior_sum;   /*    priorSum   (unchanged when reset == 0)                                                        */
+    int32_t new_prior_count; /*    priorCount                                                                                    */
+    int32_t reserved;
+} mmp_conc_out;
+typedef struct {
+    int64_t dynamic_rpm_scale_constant; /* 600 000 * percentage / 100, MM.java:370, :732                           */
+    double average_model_parallelism;   /* the task's field going into this run (:5634; 1.0 before the first run)   */
+} mmp_conc_params;
+typedef struct {
+    double average_model_parallelism; /* after this run: max(1.0, (double) modelParallelismSum / entries), :5815-5818 — the
+                                         input value when the run returned early.  The path's only floating-point value: a sum
+                                         of ints, one IEEE division, one comparison — compared EXACTLY with the reference's    */
+    int32_t exclude_set_rpms;         /* (int) (900.0 * averageModelParallelism) of the INPUT value: getExcludeSet's threshold, :5836 */
+    int32_t model_parallelism_sum;    /* modelParallelismSum, :5706                                                          */
+} mmp_conc_result;
+
+/* rateTrackingTask (MM.java:5636-5832).  mmp_scaleup_plan: limitModelConcurrency == false; mmp_scaleup_plan_conc: true. */
 typedef struct {
     int32_t self_pod;
     int32_t iteration_counter;
@@ -553,9 +586,21 @@ int mmp_proactive_plan_subset(mmp_ctx *ctx, int32_t partition, const int32_t *sk
  * *skipped = 1 when the task returns before looking at the entries (MM.java:5646, :5658). */
 int mmp_scaleup_plan(mmp_ctx *ctx, const mmp_cache_entry *entries, int32_t n, const mmp_scaleup_params *params,
                      mmp_scaleup_out *outs, uint8_t *overloaded_out, int32_t *skipped);
+/* a15 with limitModelConcurrency == true (MM.java:5677: latencyBased): conc[i] = the MaxConcCacheEntry state of entries[i].  Per
+ * entry the threshold is mcce.getRpmScaleThreshold(true) (:5704, :2766-2796; params->scale_up_rpm_threshold is what that
+ * returns for an entry without enough samples, :2781), heavyRpms three quarters of it, and maxConc adds to modelParallelismSum;
+ * getExcludeSet() uses (int) (900.0 * averageModelParallelism) of the PREVIOUS run (:5836).  conc_outs[i] = the threshold and the
+ * counter reset the call made; *result = the task's averageModelParallelism afterwards. */
+int mmp_scaleup_plan_conc(mmp_ctx *ctx, const mmp_cache_entry *entries, const mmp_conc_entry *conc, int32_t n,
+                          const mmp_scaleup_params *params, const mmp_conc_params *conc_params, mmp_scaleup_out *outs,
+                          mmp_conc_out *conc_outs, uint8_t *overloaded_out, int32_t *skipped, mmp_conc_result *result);
 /* a16: entries = scaleCopiesCandidates, oldest first; removed_out[i] = this copy is removed. */
 int mmp_scaledown_plan(mmp_ctx *ctx, const mmp_cache_entry *entries, int32_t n,
                        const mmp_scaledown_params *params, uint8_t *removed_out);
+/* a16 with MaxConcCacheEntry entries (MM.java:6294-6305): the threshold of a model with three or more copies is
+ * mcce.getRpmScaleThreshold(false), and a copy with more than one queued request stays. */
+int mmp_scaledown_plan_conc(mmp_ctx *ctx, const mmp_cache_entry *entries, const mmp_conc_entry *conc, int32_t n,
+                            const mmp_scaledown_params *params, int64_t dynamic_rpm_scale_constant, uint8_t *removed_out);
 /* a21: entries = runtimeCache.descendingLruMap() (MRU first). action_out[i] = 1:
  * triggerNewModelCopyElsewhere (MM.java:6913-6928) is issued with lastUsedTime = entry.last_used
  * and excludes = current holders ∪ self; wait_out[i] = 1: shutdown waits for it (CUTOFF_AGE_MS). */

@@ -91,6 +91,14 @@ final class MmPlace {
     static native int scaleupPlan(long h, ByteBuffer entries, int n, ByteBuffer params, ByteBuffer outs,
                                   ByteBuffer overloadedOut, ByteBuffer skipped);
     static native int scaledownPlan(long h, ByteBuffer entries, int n, ByteBuffer params, ByteBuffer removedOut);
+    // limitModelConcurrency == true: mmp_conc_entry rows (MaxConcCacheEntry: countAndTimeSum.sum(), priorSum, priorCount, maxConc,
+    // queuedRequestCount()) beside the entries; concOuts tell the caller which entries to sumThenReset() and what to store in
+    // priorSum / priorCount, result carries the task's averageModelParallelism after the run (a double at offset 0)
+    static native int scaleupPlanConc(long h, ByteBuffer entries, ByteBuffer conc, int n, ByteBuffer params, ByteBuffer concParams,
+                                      ByteBuffer outs, ByteBuffer concOuts, ByteBuffer overloadedOut, ByteBuffer skipped,
+                                      ByteBuffer result);
+    static native int scaledownPlanConc(long h, ByteBuffer entries, ByteBuffer conc, int n, ByteBuffer params,
+                                        long dynamicRpmScaleConstant, ByteBuffer removedOut);
     static native int migrationPlan(long h, ByteBuffer entries, int n, int selfPod, long nowMs, long cutoffAgeMs,
                                     ByteBuffer actionOut, ByteBuffer waitOut);
     // type constraints, upgrade tracker

@@ -338,6 +338,28 @@ JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_scaledownPlan(JNIEn
                  mmp_scaledown_plan(ctx_of(h), buf<mmp_cache_entry>(env, entries), n,
                                     buf<mmp_scaledown_params>(env, params), buf<uint8_t>(env, removedOut)));
 }
+// the rate task / the janitor of a mesh that runs with limitModelConcurrency == true (MaxConcCacheEntry rows beside the entries)
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_scaleupPlanConc(JNIEnv *env, jclass, jlong h, jobject entries,
+                                                                             jobject conc, jint n, jobject params,
+                                                                             jobject concParams, jobject outs, jobject concOuts,
+                                                                             jobject overloadedOut, jobject skipped, jobject result)
+{
+    return check(env, ctx_of(h),
+                 mmp_scaleup_plan_conc(ctx_of(h), buf<mmp_cache_entry>(env, entries), buf<mmp_conc_entry>(env, conc), n,
+                                       buf<mmp_scaleup_params>(env, params), buf<mmp_conc_params>(env, concParams),
+                                       buf<mmp_scaleup_out>(env, outs), buf<mmp_conc_out>(env, concOuts),
+                                       buf<uint8_t>(env, overloadedOut), buf<int32_t>(env, skipped),
+                                       buf<mmp_conc_result>(env, result)));
+}
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_scaledownPlanConc(JNIEnv *env, jclass, jlong h, jobject entries,
+                                                                               jobject conc, jint n, jobject params,
+                                                                               jlong dynamicRpmScaleConstant, jobject removedOut)
+{
+    return check(env, ctx_of(h),
+                 mmp_scaledown_plan_conc(ctx_of(h), buf<mmp_cache_entry>(env, entries), buf<mmp_conc_entry>(env, conc), n,
+                                         buf<mmp_scaledown_params>(env, params), dynamicRpmScaleConstant,
+                                         buf<uint8_t>(env, removedOut)));
+}
 JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_migrationPlan(JNIEnv *env, jclass, jlong h,
                                                                            jobject entries, jint n, jint selfPod,
                                                                            jlong nowMs, jlong cutoffAgeMs,

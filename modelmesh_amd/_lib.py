@@ -76,6 +76,13 @@ SCALEUP_PARAMS = np.dtype(
      ("second_copy_min_age_iters", "<i4"), ("scale_up_rpm_threshold", "<i4"), ("our_rpm", "<i4"), ("now", "<i8"),
      ("last_check_time", "<i8"), ("rate_check_interval_ms", "<i8"), ("second_copy_lru_threshold_ms", "<i8"),
      ("assume_completed_ms", "<i8")])
+CONC_ENTRY = np.dtype([("count_and_time_sum", "<i8"), ("prior_sum", "<i8"), ("prior_count", "<i4"), ("max_conc", "<i4"),
+                       ("queued_requests", "<i4"), ("reserved", "<i4")])
+CONC_OUT = np.dtype([("threshold", "<i4"), ("reset", "<i4"), ("new_prior_sum", "<i8"), ("new_prior_count", "<i4"), ("reserved", "<i4")])
+CONC_PARAMS = np.dtype([("dynamic_rpm_scale_constant", "<i8"), ("average_model_parallelism", "<f8")])
+CONC_RESULT = np.dtype([("average_model_parallelism", "<f8"), ("exclude_set_rpms", "<i4"), ("model_parallelism_sum", "<i4")])
+assert CONC_ENTRY.itemsize == 32 and CONC_OUT.itemsize == 24 and CONC_PARAMS.itemsize == 16 and CONC_RESULT.itemsize == 16
+CONC_COUNT_BITS = 21
 SCALEUP_OUT = np.dtype([("action", "<i4"), ("copies", "<i4"), ("timestamp", "<i8"), ("new_i1", "<i4"),
                         ("new_i2", "<i4"), ("heavy", "<i4"), ("rpm", "<i4")])
 SCALEDOWN_PARAMS = np.dtype(
@@ -158,6 +165,8 @@ SYMBOLS = [
     ("mmp_proactive_plan_subset", C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P]),
     ("mmp_scaleup_plan", C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32)]),
     ("mmp_scaledown_plan", C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    ("mmp_scaleup_plan_conc", C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, C.POINTER(C.c_int32), _P]),
+    ("mmp_scaledown_plan_conc", C.c_int, [_P, _P, _P, C.c_int32, _P, C.c_int64, _P]),
     ("mmp_migration_plan", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _P, _P]),
     ("mmp_pod_ids_load", C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
     ("mmp_pods_ingest_json", C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, _P]),

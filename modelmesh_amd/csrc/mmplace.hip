@@ -4157,23 +4157,35 @@ try {
     return fail(c, MMP_EHIP, "%s: %s", "mmp_proactive_plan_subset", e.what());
 }
 
-int mmp_scaleup_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, const mmp_scaleup_params *p,
-                     mmp_scaleup_out *outs, uint8_t *overloaded_out, int32_t *skipped)
-try {
-    if (!c || !p || !skipped || n < 0 || (n > 0 && (!entries || !outs)))
-        return fail(c, MMP_EINVAL, "mmp_scaleup_plan: bad argument");
+// rateTrackingTask: the one body of mmp_scaleup_plan (conc == null) and mmp_scaleup_plan_conc
+static int scaleup_plan_impl(mmp_ctx *c, const char *fn, const mmp_cache_entry *entries, const mmp_conc_entry *conc, int32_t n,
+                             const mmp_scaleup_params *p, const mmp_conc_params *cp, mmp_scaleup_out *outs, mmp_conc_out *conc_outs,
+                             uint8_t *overloaded_out, int32_t *skipped, mmp_conc_result *result)
+{
+    const bool latency = cp != nullptr;
+    if (!c || !p || !skipped || n < 0 || (n > 0 && (!entries || !outs)) || (latency && (!result || (n > 0 && (!conc || !conc_outs)))))
+        return fail(c, MMP_EINVAL, "%s: bad argument", fn);
     // batch_mu owns c->stream and the scratch for the whole call, and every writer of the state this call reads
     // (commit, the loaders, registry events) takes it too: the published snapshot cannot change underneath.  The
     // state lock c->mu is NOT held: latency-path calls (mmp_place_batch / _gate / _evict on the slots) keep flowing.
     std::lock_guard<std::mutex> gb(c->batch_mu);
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     const int32_t P = c->snap.P;
-    if (P > 0 && !overloaded_out) return fail(c, MMP_EINVAL, "mmp_scaleup_plan: overloaded_out is null");
+    if (P > 0 && !overloaded_out) return fail(c, MMP_EINVAL, "%s: overloaded_out is null", fn);
     if (P > 0) memset(overloaded_out, 0, (size_t)P);
     for (int32_t i = 0; i < n; i++) {
         outs[i] = mmp_scaleup_out{};
         outs[i].new_i1 = entries[i].earlier_use_iteration;
         outs[i].new_i2 = entries[i].last_used_iteration;
+        if (latency) {
+            conc_outs[i] = mmp_conc_out{};
+            conc_outs[i].new_prior_sum = conc[i].prior_sum;
+            conc_outs[i].new_prior_count = conc[i].prior_count;
+        }
+    }
+    if (latency) {  // (a run that returns early leaves the task's field as it was)
+        *result = mmp_conc_result{};
+        result->average_model_parallelism = cp->average_model_parallelism;
     }
     // the three early returns of the task, MM.java:5646-5648, :5658-5660, :5667-5669
     const int64_t time_delta = (int64_t)((uint64_t)p->now - (uint64_t)p->last_check_time);
@@ -4184,16 +4196,25 @@ try {
     HIP_TRY(c, c->s_reqs.ensure((size_t)n * sizeof(mmp_cache_entry)));
     HIP_TRY(c, c->s_outs.ensure((size_t)n * sizeof(mmp_scaleup_out)));
     HIP_TRY(c, c->s_a.ensure((size_t)std::max(P, 1)));
-    HIP_TRY(c, c->s_b.ensure(sizeof(int32_t)));
+    HIP_TRY(c, c->s_b.ensure(2 * sizeof(int32_t)));  // [0] overloaded instances, [1] latency-based: getExcludeSet's maxRpm
     HIP_TRY(c, hipMemcpyAsync(c->s_reqs.p, entries, (size_t)n * sizeof(mmp_cache_entry), hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemsetAsync(c->s_b.p, 0, sizeof(int32_t), st));
+    HIP_TRY(c, hipMemsetAsync(c->s_b.p, 0, 2 * sizeof(int32_t), st));
+    if (latency) {
+        HIP_TRY(c, c->s_c.ensure((size_t)n * sizeof(mmp_conc_entry)));
+        HIP_TRY(c, c->s_d.ensure((size_t)n * sizeof(mmp_conc_out) + sizeof(mmp_conc_result)));
+        HIP_TRY(c, hipMemcpyAsync(c->s_c.p, conc, (size_t)n * sizeof(mmp_conc_entry), hipMemcpyHostToDevice, st));
+    }
+    mmp_conc_result *d_res = latency ? reinterpret_cast<mmp_conc_result *>(static_cast<char *>(c->s_d.p) + (size_t)n * sizeof(mmp_conc_out)) : nullptr;
     const int32_t a = (int32_t)((uint32_t)p->scale_up_rpm_threshold * 4u);
     const int32_t b = (int32_t)((uint32_t)p->our_rpm - 2u * (uint32_t)p->scale_up_rpm_threshold);
     const mmp_pod_row *pods = c->sb[c->cur].pods.as<mmp_pod_row>();
     KT_BEGIN(c, st);
+    if (latency)  // getExcludeSet's threshold comes from the task's averageModelParallelism (:5836)
+        hipLaunchKernelGGL(conc_exclude_rpms_kernel, dim3(1), dim3(64), 0, st, cp->average_model_parallelism, p->our_rpm,
+                           c->s_b.as<int32_t>() + 1, d_res);
     if (P > 0)
         hipLaunchKernelGGL(overloaded_pods_kernel, dim3(div_up(P, 256)), dim3(256), 0, st, pods, P, p->self_pod,
-                           a > b ? a : b, c->s_a.as<uint8_t>(), c->s_b.as<int32_t>());
+                           a > b ? a : b, latency ? c->s_b.as<int32_t>() + 1 : nullptr, c->s_a.as<uint8_t>(), c->s_b.as<int32_t>());
     ScaleupArgs A;
     A.entries = c->s_reqs.as<mmp_cache_entry>();
     A.models = c->models.as<mmp_model_row>();
@@ -4210,25 +4231,53 @@ try {
     A.n = n;
     A.n_models = c->n_models;
     A.P = P;
+    A.conc = latency ? c->s_c.as<mmp_conc_entry>() : nullptr;
+    A.conc_outs = latency ? c->s_d.as<mmp_conc_out>() : nullptr;
+    A.conc_res = d_res;
+    A.dyn_const = latency ? cp->dynamic_rpm_scale_constant : 0;
     hipLaunchKernelGGL(scaleup_plan_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, A);
+    if (latency) hipLaunchKernelGGL(conc_average_kernel, dim3(1), dim3(64), 0, st, n, d_res);
     KT_END(c, st);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(outs, c->s_outs.p, (size_t)n * sizeof(mmp_scaleup_out), hipMemcpyDeviceToHost, st));
     if (P > 0) HIP_TRY(c, hipMemcpyAsync(overloaded_out, c->s_a.p, (size_t)P, hipMemcpyDeviceToHost, st));
+    if (latency) {
+        HIP_TRY(c, hipMemcpyAsync(conc_outs, c->s_d.p, (size_t)n * sizeof(mmp_conc_out), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(result, d_res, sizeof(mmp_conc_result), hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(c, hipStreamSynchronize(st));
     kt_collect(c);
     return MMP_OK;
+}
+
+int mmp_scaleup_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, const mmp_scaleup_params *p,
+                     mmp_scaleup_out *outs, uint8_t *overloaded_out, int32_t *skipped)
+try {
+    return scaleup_plan_impl(c, "mmp_scaleup_plan", entries, nullptr, n, p, nullptr, outs, nullptr, overloaded_out, skipped, nullptr);
 } catch (const std::bad_alloc &) {
     return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_scaleup_plan");
 } catch (const std::exception &e) {
     return fail(c, MMP_EHIP, "%s: %s", "mmp_scaleup_plan", e.what());
 }
 
-int mmp_scaledown_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, const mmp_scaledown_params *p,
-                       uint8_t *removed_out)
+int mmp_scaleup_plan_conc(mmp_ctx *c, const mmp_cache_entry *entries, const mmp_conc_entry *conc, int32_t n,
+                          const mmp_scaleup_params *p, const mmp_conc_params *cp, mmp_scaleup_out *outs, mmp_conc_out *conc_outs,
+                          uint8_t *overloaded_out, int32_t *skipped, mmp_conc_result *result)
 try {
+    if (!cp) return fail(c, MMP_EINVAL, "mmp_scaleup_plan_conc: conc_params is null");
+    return scaleup_plan_impl(c, "mmp_scaleup_plan_conc", entries, conc, n, p, cp, outs, conc_outs, overloaded_out, skipped, result);
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_scaleup_plan");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_scaleup_plan", e.what());
+}
+
+// the janitor's scale-down: the one body of mmp_scaledown_plan (conc == null) and mmp_scaledown_plan_conc
+static int scaledown_plan_impl(mmp_ctx *c, const char *fn, const mmp_cache_entry *entries, const mmp_conc_entry *conc, int32_t n,
+                               const mmp_scaledown_params *p, int64_t dyn_const, uint8_t *removed_out)
+{
     if (!c || !p || n < 0 || (n > 0 && (!entries || !removed_out)))
-        return fail(c, MMP_EINVAL, "mmp_scaledown_plan: bad argument");
+        return fail(c, MMP_EINVAL, "%s: bad argument", fn);
     // batch_mu owns c->stream and the scratch for the whole call, and every writer of the state this call reads
     // (commit, the loaders, registry events) takes it too: the published snapshot cannot change underneath.  The
     // state lock c->mu is NOT held: latency-path calls (mmp_place_batch / _gate / _evict on the slots) keep flowing.
@@ -4241,6 +4290,10 @@ try {
     HIP_TRY(c, c->s_a.ensure((size_t)n));
     HIP_TRY(c, c->s_b.ensure((size_t)n));
     HIP_TRY(c, hipMemcpyAsync(c->s_reqs.p, entries, (size_t)n * sizeof(mmp_cache_entry), hipMemcpyHostToDevice, st));
+    if (conc) {
+        HIP_TRY(c, c->s_c.ensure((size_t)n * sizeof(mmp_conc_entry)));
+        HIP_TRY(c, hipMemcpyAsync(c->s_c.p, conc, (size_t)n * sizeof(mmp_conc_entry), hipMemcpyHostToDevice, st));
+    }
     ScaledownArgs A;
     A.entries = c->s_reqs.as<mmp_cache_entry>();
     A.models = c->models.as<mmp_model_row>();
@@ -4261,6 +4314,8 @@ try {
     A.n = n;
     A.n_models = c->n_models;
     A.P = c->snap.P;
+    A.conc = conc ? c->s_c.as<mmp_conc_entry>() : nullptr;
+    A.dyn_const = dyn_const;
     KT_BEGIN(c, st);
     hipLaunchKernelGGL(scaledown_decide_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, A);
     hipLaunchKernelGGL(scaledown_budget_kernel, dim3(1), dim3(64), 0, st, A);
@@ -4270,6 +4325,23 @@ try {
     HIP_TRY(c, hipStreamSynchronize(st));
     kt_collect(c);
     return MMP_OK;
+}
+
+int mmp_scaledown_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, const mmp_scaledown_params *p,
+                       uint8_t *removed_out)
+try {
+    return scaledown_plan_impl(c, "mmp_scaledown_plan", entries, nullptr, n, p, 0, removed_out);
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_scaledown_plan");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_scaledown_plan", e.what());
+}
+
+int mmp_scaledown_plan_conc(mmp_ctx *c, const mmp_cache_entry *entries, const mmp_conc_entry *conc, int32_t n,
+                            const mmp_scaledown_params *p, int64_t dynamic_rpm_scale_constant, uint8_t *removed_out)
+try {
+    if (n > 0 && !conc) return fail(c, MMP_EINVAL, "mmp_scaledown_plan_conc: conc is null");
+    return scaledown_plan_impl(c, "mmp_scaledown_plan_conc", entries, conc, n, p, dynamic_rpm_scale_constant, removed_out);
 } catch (const std::bad_alloc &) {
     return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_scaledown_plan");
 } catch (const std::exception &e) {

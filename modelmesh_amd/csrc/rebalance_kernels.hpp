@@ -729,9 +729,64 @@ namespace mmp {
 // ---- a15 ---------------------------------------------------------------------------------------
 // getExcludeSet(), MM.java:5835-5856: pods of clusterState (present rows) other than self whose
 // published rpm exceeds max(4*threshold, ourRpm - 2*threshold)
-__global__ void overloaded_pods_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int32_t self_pod,
-                                       int32_t max_rpm, uint8_t *__restrict__ overloaded, int32_t *__restrict__ count)
+// ---- limitModelConcurrency == true ("latency-based" scaling): MaxConcCacheEntry, MM.java:2641-2797 ------------------
+// mcce.getRpmScaleThreshold(andReset), :2766-2796, on one mmp_conc_entry row.  Java long / int arithmetic (wrapping products,
+// `>>>`, division truncating toward zero, (int) of a long = its low 32 bits).  o (may be null): the reset the call makes.
+__device__ __forceinline__ int32_t rpm_scale_threshold(const mmp_conc_entry &m, bool and_reset, int32_t scale_up_rpm_threshold,
+                                                       int64_t dyn_const, mmp_conc_out *o)
 {
+    constexpr uint64_t kMask = (1ull << MMP_CONC_COUNT_BITS) - 1;
+    const uint64_t cur = (uint64_t)m.count_and_time_sum;
+    int64_t time_sum;
+    int32_t count = (int32_t)(cur & kMask);
+    if (count >= 64) {
+        time_sum = (int64_t)(cur >> MMP_CONC_COUNT_BITS);
+        if (and_reset && o) {  // sumThenReset(): priorSum = timeSum, priorCount = count
+            o->reset = 1;
+            o->new_prior_sum = time_sum;
+            o->new_prior_count = count;
+        }
+    } else {
+        const int32_t pc = m.prior_count;
+        if (pc <= 0 && count < 8) return scale_up_rpm_threshold;
+        time_sum = (int64_t)((uint64_t)m.prior_sum + (count > 0 ? (cur >> MMP_CONC_COUNT_BITS) : 0ull));
+        count = (int32_t)((uint32_t)count + (uint32_t)pc);
+    }
+    if (time_sum == 0) return INT32_MAX;
+    const int64_t num = (int64_t)((uint64_t)(int64_t)m.max_conc * ((uint64_t)(int64_t)count * (uint64_t)dyn_const));
+    if (num == INT64_MIN && time_sum == -1) return 0;  // Java: Long.MIN_VALUE / -1 == Long.MIN_VALUE, whose low 32 bits are 0
+    return (int32_t)(uint32_t)(uint64_t)(num / time_sum);
+}
+
+// the scalars of a latency-based run: getExcludeSet's threshold from the task's averageModelParallelism (:5836) -> the most
+// an instance may serve before it is excluded (:5841); one thread
+__global__ void conc_exclude_rpms_kernel(double average_model_parallelism, int32_t our_rpm, int32_t *__restrict__ max_rpm,
+                                         mmp_conc_result *__restrict__ res)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const double d = 900.0 * average_model_parallelism;
+    // (int) of a double, JLS 5.1.3: NaN -> 0, saturating
+    const int32_t rpms = d != d ? 0 : d >= 2147483647.0 ? INT32_MAX : d <= -2147483648.0 ? INT32_MIN : (int32_t)d;
+    const int32_t a = (int32_t)((uint32_t)rpms * 4u), b = (int32_t)((uint32_t)our_rpm - 2u * (uint32_t)rpms);
+    *max_rpm = a > b ? a : b;
+    res->exclude_set_rpms = rpms;
+    res->model_parallelism_sum = 0;
+    res->average_model_parallelism = average_model_parallelism;
+}
+// averageModelParallelism = Math.max(1.0, ((double) modelParallelismSum) / usedSinceLastRun.size()), :5815-5818; one thread
+__global__ void conc_average_kernel(int32_t n_entries, mmp_conc_result *__restrict__ res)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const double q = (double)res->model_parallelism_sum / (double)n_entries;
+    res->average_model_parallelism = 1.0 >= q ? 1.0 : q;  // Math.max(1.0, q) (q is never NaN: n_entries > 0)
+}
+
+// max_rpm_dev (latency-based runs): the threshold conc_exclude_rpms_kernel computed, else max_rpm
+__global__ void overloaded_pods_kernel(const mmp_pod_row *__restrict__ pods, int32_t P, int32_t self_pod,
+                                       int32_t max_rpm, const int32_t *__restrict__ max_rpm_dev, uint8_t *__restrict__ overloaded,
+                                       int32_t *__restrict__ count)
+{
+    if (max_rpm_dev) max_rpm = *max_rpm_dev;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     bool ov = false;
     if (p < P) {
@@ -756,6 +811,12 @@ struct ScaleupArgs {
     mmp_scaleup_params p;
     int32_t n, n_models, P;
     int32_t T_rows, has_tc;  // has_tc: typeConstraints != null
+    // limitModelConcurrency == true (null otherwise): the entries' MaxConcCacheEntry rows, what getRpmScaleThreshold(true) did to
+    // them, modelParallelismSum
+    const mmp_conc_entry *conc;
+    mmp_conc_out *conc_outs;
+    mmp_conc_result *conc_res;
+    int64_t dyn_const;
 };
 
 // loadedSince, MM.java:5860-5871
@@ -792,15 +853,28 @@ __global__ void scaleup_plan_kernel(ScaleupArgs A)
     // typeSetStats(ce.modelInfo.serviceType), MM.java:5691 (cluster-wide for an entry without a registry record)
     const StatsAcc *st = (A.has_tc && have_model) ? &A.tstats[(mr.type < 0 || mr.type >= A.T_rows) ? 0 : mr.type] : A.stats;
     int32_t suitable = A.stats->instance_count;  // instCount, :5692
+    mmp_conc_out co{};
+    if (A.conc) {  // what an untouched row keeps
+        co.new_prior_sum = A.conc[e].prior_sum;
+        co.new_prior_count = A.conc[e].prior_count;
+    }
     if (A.has_tc) {                              // :5693-5700: a type confined to one instance is skipped outright
         suitable = st->instance_count;
         if (suitable < 2) {
             o.rpm = 0;
             A.outs[e] = o;
+            if (A.conc) A.conc_outs[e] = co;
             return;
         }
     }
-    const int32_t scale_up = p.scale_up_rpm_threshold;
+    int32_t scale_up = p.scale_up_rpm_threshold;
+    if (A.conc) {  // latencyBased, :5702-5707
+        const mmp_conc_entry m = A.conc[e];
+        scale_up = rpm_scale_threshold(m, true, p.scale_up_rpm_threshold, A.dyn_const, &co);
+        co.threshold = scale_up;
+        A.conc_outs[e] = co;
+        atomicAdd(&A.conc_res->model_parallelism_sum, m.max_conc);  // (int addition wraps: any order gives the Java's sum)
+    }
     const int32_t heavy = (int32_t)((uint32_t)scale_up * 3u) / 4;
     const int32_t rpm = (int32_t)((ce.interval_count * 60000) / time_delta);
     o.rpm = rpm;
@@ -870,6 +944,8 @@ struct ScaledownArgs {
     uint8_t *removed;  // final
     mmp_scaledown_params p;
     int32_t n, n_models, P;
+    const mmp_conc_entry *conc;  // MaxConcCacheEntry rows (mcce != null, :6294), null otherwise
+    int64_t dyn_const;
 };
 
 // removeModelCopies with canRemove == true, MM.java:6197-6310 — everything except the running budget
@@ -921,7 +997,10 @@ __global__ void scaledown_decide_kernel(ScaledownArgs A)
             const int64_t since = jsub64(p.now, p.last_check_time);
             if (since < p.rate_check_interval_ms / 10) break;
             const int64_t rpm = ce.interval_count == 0 ? 0 : (60000 * ce.interval_count) / since;
-            if (rpm > ((int64_t)p.scale_up_rpm_threshold * 2) / 3) break;
+            int64_t threshold = p.scale_up_rpm_threshold;  // :6295
+            if (A.conc) threshold = rpm_scale_threshold(A.conc[e], false, p.scale_up_rpm_threshold, A.dyn_const, nullptr);
+            if (rpm > (threshold * 2) / 3) break;
+            if (A.conc && A.conc[e].queued_requests > 1) break;  // :6303
             removed = true;
         }
     } while (false);

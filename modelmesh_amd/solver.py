@@ -528,6 +528,37 @@ class Solver:
                                            ptr(outs) if len(entries) else None, ptr(ov), C.byref(sk)))
         return outs, ov[: self.n_pods], sk.value
 
+    def scaleup_plan_conc(self, entries, conc, params, conc_params):
+        """a15 with limitModelConcurrency == true (latency-based): (outs, conc_outs, overloaded[P], skipped, result)"""
+        from ._lib import CACHE_ENTRY, CONC_ENTRY, CONC_OUT, CONC_PARAMS, CONC_RESULT, SCALEUP_OUT, SCALEUP_PARAMS
+        entries = np.ascontiguousarray(entries, dtype=CACHE_ENTRY)
+        conc = np.ascontiguousarray(conc, dtype=CONC_ENTRY)
+        assert len(conc) == len(entries)
+        params = np.ascontiguousarray(params, dtype=SCALEUP_PARAMS).reshape(1)
+        cparams = np.ascontiguousarray(conc_params, dtype=CONC_PARAMS).reshape(1)
+        outs = np.zeros(len(entries), dtype=SCALEUP_OUT)
+        couts = np.zeros(len(entries), dtype=CONC_OUT)
+        res = np.zeros(1, dtype=CONC_RESULT)
+        ov = np.zeros(max(self.n_pods, 1), np.uint8)
+        sk = C.c_int32(0)
+        n = len(entries)
+        self._ck(self.lib.mmp_scaleup_plan_conc(self.h, ptr(entries) if n else None, ptr(conc) if n else None, n, ptr(params),
+                                                ptr(cparams), ptr(outs) if n else None, ptr(couts) if n else None, ptr(ov),
+                                                C.byref(sk), ptr(res)))
+        return outs, couts, ov[: self.n_pods], sk.value, res[0]
+
+    def scaledown_plan_conc(self, entries, conc, params, dynamic_rpm_scale_constant):
+        from ._lib import CACHE_ENTRY, CONC_ENTRY, SCALEDOWN_PARAMS
+        entries = np.ascontiguousarray(entries, dtype=CACHE_ENTRY)
+        conc = np.ascontiguousarray(conc, dtype=CONC_ENTRY)
+        assert len(conc) == len(entries)
+        params = np.ascontiguousarray(params, dtype=SCALEDOWN_PARAMS).reshape(1)
+        rem = np.zeros(max(len(entries), 1), np.uint8)
+        n = len(entries)
+        self._ck(self.lib.mmp_scaledown_plan_conc(self.h, ptr(entries) if n else None, ptr(conc) if n else None, n, ptr(params),
+                                                  int(dynamic_rpm_scale_constant), ptr(rem)))
+        return rem[:n]
+
     def scaledown_plan(self, entries, params):
         from ._lib import CACHE_ENTRY, SCALEDOWN_PARAMS
         entries = np.ascontiguousarray(entries, dtype=CACHE_ENTRY)

@@ -158,6 +158,10 @@ def load() -> C.CDLL:
         lib.orc_scaleup_plan.argtypes = [VP, I32, VP, I32, VP, VP, I32, C.c_int, VP, VP, VP, VP, I32, VP, VP, VP]
         lib.orc_scaledown_plan.restype = None
         lib.orc_scaledown_plan.argtypes = [VP, VP, VP, VP, VP, VP, VP, VP, I32, VP, VP]
+        lib.orc_scaleup_plan_conc.restype = C.c_int
+        lib.orc_scaleup_plan_conc.argtypes = [VP, I32, VP, I32, VP, VP, I32, C.c_int, VP, VP, VP, VP, VP, I32, VP, VP, VP, VP, VP, VP]
+        lib.orc_scaledown_plan_conc.restype = None
+        lib.orc_scaledown_plan_conc.argtypes = [VP, VP, VP, VP, VP, VP, VP, VP, VP, I32, VP, C.c_int64, VP]
         lib.orc_migration_plan.restype = None
         lib.orc_migration_plan.argtypes = [VP, VP, VP, I32, I32, I64, I64, VP, VP]
         lib.orc_evict_eval.restype = None
@@ -569,6 +573,52 @@ def scaleup_plan(fleet, entries, params):
                               1 if fleet.n_types else 0, _p(models), _p(ep),
                               _p(et), _p(entries) if len(entries) else None, len(entries), _p(params), _p(outs), _p(ov))
     return outs[: len(entries)], ov[: fleet.n_pods], sk
+
+
+def scaleup_plan_conc(fleet, entries, conc, params, conc_params):
+    """The rate task with limitModelConcurrency == true: (outs, conc_outs, overloaded, returned_early, result)."""
+    from modelmesh_amd._lib import CONC_OUT, CONC_RESULT, SCALEUP_OUT
+    lib = load()
+    orc = OracleFleet(fleet)
+    stats = np.zeros(1, dtype=ORC_STATS)
+    stats[0] = orc.stats()
+    entries = np.ascontiguousarray(entries)
+    conc = np.ascontiguousarray(conc)
+    params = np.ascontiguousarray(params).reshape(1)
+    cparams = np.ascontiguousarray(conc_params).reshape(1)
+    n = len(entries)
+    outs = np.zeros(max(n, 1), dtype=SCALEUP_OUT)
+    couts = np.zeros(max(n, 1), dtype=CONC_OUT)
+    res = np.zeros(1, dtype=CONC_RESULT)
+    ov = np.zeros(max(fleet.n_pods, 1), np.uint8)
+    ep, et = _ent(fleet)
+    models = np.ascontiguousarray(fleet.models)
+    tstats = np.ascontiguousarray(type_set_stats(fleet))
+    sk = lib.orc_scaleup_plan_conc(_p(orc.pods), fleet.n_pods, _p(orc.order), len(orc.order), _p(stats), _p(tstats), len(tstats),
+                                   1 if fleet.n_types else 0, _p(models), _p(ep), _p(et), _p(entries) if n else None,
+                                   _p(conc) if n else None, n, _p(params), _p(cparams), _p(outs), _p(couts), _p(ov), _p(res))
+    return outs[:n], couts[:n], ov[: fleet.n_pods], sk, res[0]
+
+
+def scaledown_plan_conc(fleet, entries, conc, params, dyn_const):
+    lib = load()
+    orc = OracleFleet(fleet)
+    stats = instance_set_stats(fleet, int(np.asarray(params).reshape(-1)[0]["self_pod"]), orc)
+    pos_of = np.full(max(fleet.n_pods, 1), 2**31 - 1, np.int32)
+    pos_of[orc.order] = np.arange(len(orc.order), dtype=np.int32)
+    in_table = np.ascontiguousarray(((fleet.pods["flags"] & 4) == 0).astype(np.uint8))
+    opods = orc.pods.copy()
+    opods["shutting_down"] = (fleet.pods["flags"] & 1) != 0
+    entries = np.ascontiguousarray(entries)
+    conc = np.ascontiguousarray(conc)
+    params = np.ascontiguousarray(params).reshape(1)
+    n = len(entries)
+    rem = np.zeros(max(n, 1), np.uint8)
+    ep, et = _ent(fleet)
+    models = np.ascontiguousarray(fleet.models)
+    lib.orc_scaledown_plan_conc(_p(opods), _p(pos_of), _p(in_table), _p(stats), _p(models), _p(ep), _p(et),
+                                _p(entries) if n else None, _p(conc) if n else None, n, _p(params), int(dyn_const), _p(rem))
+    return rem[:n]
 
 
 def instance_set_stats(fleet, self_pod, orc=None):

@@ -293,11 +293,50 @@ int orc_scaleup_plan(const orc_pod *pods, int32_t n_pods, const int32_t *order, 
                      const orc_flat_model *models, const int32_t *ent_pod,
                      const int64_t *ent_time, const orc_cache_entry *entries, int32_t n, const orc_scaleup_params *p,
                      orc_scaleup_out *outs, uint8_t *overloaded_out);
+/* limitModelConcurrency == true: MaxConcCacheEntry (MM.java:2641-2797), one row per cache entry */
+#define ORC_CONC_COUNT_BITS 21 /* MM.java:2653 */
+typedef struct {
+    int64_t count_and_time_sum; /* countAndTimeSum.sum() */
+    int64_t prior_sum;          /* priorSum */
+    int32_t prior_count;        /* priorCount */
+    int32_t max_conc;           /* maxConc */
+    int32_t queued_requests;    /* queuedRequestCount() */
+    int32_t pad_;
+} orc_conc_entry;
+typedef struct {
+    int32_t threshold; /* getRpmScaleThreshold(true) as evaluated, 0 if the entry was skipped before the call */
+    int32_t reset;     /* the call took sumThenReset() */
+    int64_t new_prior_sum;
+    int32_t new_prior_count, pad_;
+} orc_conc_out;
+typedef struct {
+    int64_t dynamic_rpm_scale_constant; /* MM.java:370 */
+    double average_model_parallelism;   /* the task's field before the run, MM.java:5634 */
+} orc_conc_params;
+typedef struct {
+    double average_model_parallelism; /* after the run, MM.java:5815-5818 */
+    int32_t exclude_set_rpms;         /* (int) (900.0 * averageModelParallelism), MM.java:5836 */
+    int32_t model_parallelism_sum;    /* MM.java:5706 */
+} orc_conc_result;
+/* MaxConcCacheEntry.getRpmScaleThreshold, MM.java:2766-2796 */
+int32_t orc_rpm_scale_threshold(const orc_conc_entry *m, int and_reset, int32_t scale_up_rpm_threshold, int64_t dyn_const, orc_conc_out *o);
+/* the rate task with limitModelConcurrency == true (latencyBased, MM.java:5677) */
+int orc_scaleup_plan_conc(const orc_pod *pods, int32_t n_pods, const int32_t *order, int32_t n_order,
+                          const orc_cluster_stats *stats, const orc_cluster_stats *type_stats, int32_t t_rows, int has_tc,
+                          const orc_flat_model *models, const int32_t *ent_pod,
+                          const int64_t *ent_time, const orc_cache_entry *entries, const orc_conc_entry *conc, int32_t n,
+                          const orc_scaleup_params *p, const orc_conc_params *cp, orc_scaleup_out *outs, orc_conc_out *conc_outs,
+                          uint8_t *overloaded_out, orc_conc_result *result);
 typedef struct {
     int32_t self_pod, shutting_down;
     int64_t now, last_check_time, rate_check_interval_ms, adjusted_cache_capacity;
     int32_t scale_up_rpm_threshold, pad_;
 } orc_scaledown_params;
+/* the janitor with MaxConcCacheEntry entries (MM.java:6294-6305) */
+void orc_scaledown_plan_conc(const orc_pod *pods, const int32_t *pos_of, const uint8_t *in_table,
+                             const orc_cluster_stats *stats, const orc_flat_model *models, const int32_t *ent_pod,
+                             const int64_t *ent_time, const orc_cache_entry *entries, const orc_conc_entry *conc, int32_t n,
+                             const orc_scaledown_params *p, int64_t dyn_const, uint8_t *removed_out);
 void orc_scaledown_plan(const orc_pod *pods, const int32_t *pos_of, const uint8_t *in_table,
                         const orc_cluster_stats *stats, const orc_flat_model *models, const int32_t *ent_pod,
                         const int64_t *ent_time, const orc_cache_entry *entries, int32_t n,

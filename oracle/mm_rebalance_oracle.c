@@ -141,12 +141,53 @@ static int loaded_since(const int32_t *pods, const int64_t *times, int32_t n, in
     return 0;
 }
 
-int orc_scaleup_plan(const orc_pod *pods, int32_t n_pods, const int32_t *order, int32_t n_order,
-                     const orc_cluster_stats *stats, const orc_cluster_stats *type_stats, int32_t t_rows, int has_tc,
-                     const orc_flat_model *models, const int32_t *ent_pod,
-                     const int64_t *ent_time, const orc_cache_entry *entries, int32_t n, const orc_scaleup_params *p,
-                     orc_scaleup_out *outs, uint8_t *overloaded_out)
+/* MaxConcCacheEntry.getRpmScaleThreshold(andReset), MM.java:2766-2796.  Java arithmetic: `>>>` on the long, int additions and
+ * long products wrap, `/` truncates toward zero, (int) of a long keeps the low 32 bits.  o: what a reset stores (:2771-2773). */
+int32_t orc_rpm_scale_threshold(const orc_conc_entry *m, int and_reset, int32_t scale_up_rpm_threshold, int64_t dyn_const, orc_conc_out *o)
 {
+    const uint64_t count_mask = ((uint64_t)1 << ORC_CONC_COUNT_BITS) - 1; /* :2760 */
+    const uint64_t cur_val = (uint64_t)m->count_and_time_sum;             /* :2767 */
+    int64_t time_sum;
+    int32_t count = (int32_t)(cur_val & count_mask);
+    if (count >= 64) { /* :2769 */
+        time_sum = (int64_t)(cur_val >> ORC_CONC_COUNT_BITS);
+        if (and_reset && o) { /* sumThenReset(): priorSum = timeSum, priorCount = count */
+            o->reset = 1;
+            o->new_prior_sum = time_sum;
+            o->new_prior_count = count;
+        }
+    } else { /* supplement with prior count, :2778-2785 */
+        const int32_t pc = m->prior_count;
+        if (pc <= 0 && count < 8) return scale_up_rpm_threshold;
+        time_sum = (int64_t)((uint64_t)m->prior_sum + (count > 0 ? (cur_val >> ORC_CONC_COUNT_BITS) : 0));
+        count = (int32_t)((uint32_t)count + (uint32_t)pc);
+    }
+    if (time_sum == 0) return INT32_MAX; /* :2787 */
+    const int64_t num = (int64_t)((uint64_t)(int64_t)m->max_conc * ((uint64_t)(int64_t)count * (uint64_t)dyn_const)); /* :2795 */
+    if (num == INT64_MIN && time_sum == -1) return 0; /* Long.MIN_VALUE / -1 == Long.MIN_VALUE in Java */
+    return (int32_t)(uint32_t)(uint64_t)(num / time_sum);
+}
+
+/* (int) of a double, JLS 5.1.3 */
+static int32_t jd2i(double d) { return d != d ? 0 : d >= 2147483647.0 ? INT32_MAX : d <= -2147483648.0 ? INT32_MIN : (int32_t)d; }
+
+static int scaleup_plan_impl(const orc_pod *pods, int32_t n_pods, const int32_t *order, int32_t n_order,
+                             const orc_cluster_stats *stats, const orc_cluster_stats *type_stats, int32_t t_rows, int has_tc,
+                             const orc_flat_model *models, const int32_t *ent_pod,
+                             const int64_t *ent_time, const orc_cache_entry *entries, const orc_conc_entry *conc, int32_t n,
+                             const orc_scaleup_params *p, const orc_conc_params *cp, orc_scaleup_out *outs, orc_conc_out *conc_outs,
+                             uint8_t *overloaded_out, orc_conc_result *result)
+{
+    const int latency_based = cp != NULL; /* boolean latencyBased = limitModelConcurrency, :5677 */
+    if (latency_based) {
+        memset(result, 0, sizeof *result);
+        result->average_model_parallelism = cp->average_model_parallelism;
+        for (int32_t i = 0; i < n; i++) {
+            memset(&conc_outs[i], 0, sizeof conc_outs[i]);
+            conc_outs[i].new_prior_sum = conc[i].prior_sum;
+            conc_outs[i].new_prior_count = conc[i].prior_count;
+        }
+    }
     memset(outs, 0, (size_t)n * sizeof *outs);
     memset(overloaded_out, 0, (size_t)n_pods);
     for (int32_t i = 0; i < n; i++) { /* untouched entries keep their iteration markers */
@@ -162,10 +203,14 @@ int orc_scaleup_plan(const orc_pod *pods, int32_t n_pods, const int32_t *order, 
     if (inst_count < 2) return 1; /* :5658 */
     if (n == 0) return 1;         /* :5667 */
     const int64_t new_copies_ts = now + 20000; /* :5675 */
-    const int32_t scale_up_rpms = p->scale_up_rpm_threshold;
-    const int32_t heavy_rpms = (int32_t)((uint32_t)scale_up_rpms * 3u) / 4;
+    int32_t scale_up_rpms = 0, heavy_rpms = 0;
+    if (!latency_based) { /* :5679-5682 */
+        scale_up_rpms = p->scale_up_rpm_threshold;
+        heavy_rpms = (int32_t)((uint32_t)scale_up_rpms * 3u) / 4;
+    }
     int have_exclude_set = 0;
     int32_t excluded_count = 0;
+    int32_t model_parallelism_sum = 0;
     for (int32_t e = 0; e < n; e++) {
         const orc_cache_entry *ce = &entries[e];
         orc_scaleup_out *o = &outs[e];
@@ -181,6 +226,12 @@ int orc_scaleup_plan(const orc_pod *pods, int32_t n_pods, const int32_t *order, 
         if (has_tc) { /* :5693-5700 */
             suitable = cst->instance_count;
             if (suitable < 2) continue;
+        }
+        if (latency_based) { /* :5702-5707 */
+            scale_up_rpms = orc_rpm_scale_threshold(&conc[e], 1, p->scale_up_rpm_threshold, cp->dynamic_rpm_scale_constant, &conc_outs[e]);
+            conc_outs[e].threshold = scale_up_rpms;
+            heavy_rpms = (int32_t)((uint32_t)scale_up_rpms * 3u) / 4;
+            model_parallelism_sum = (int32_t)((uint32_t)model_parallelism_sum + (uint32_t)conc[e].max_conc);
         }
         const int32_t rpm = (int32_t)((count * 60000) / time_delta);
         o->rpm = rpm;
@@ -220,8 +271,11 @@ int orc_scaleup_plan(const orc_pod *pods, int32_t n_pods, const int32_t *order, 
         if (loaded_since(lp, lt, loaded_count, recent_cutoff, p->self_pod)) continue; /* :5769 */
         if (!have_exclude_set) { /* getExcludeSet(), :5835-5856 */
             have_exclude_set = 1;
-            const int32_t a = (int32_t)((uint32_t)scale_up_rpms * 4u);
-            const int32_t b = (int32_t)((uint32_t)p->our_rpm - 2u * (uint32_t)scale_up_rpms);
+            /* getExcludeSet has its OWN scaleUpRpms (:5836): the configured threshold, or 900 x the task's averageModelParallelism */
+            const int32_t x_rpms = latency_based ? jd2i(900.0 * cp->average_model_parallelism) : p->scale_up_rpm_threshold;
+            if (latency_based) result->exclude_set_rpms = x_rpms;
+            const int32_t a = (int32_t)((uint32_t)x_rpms * 4u);
+            const int32_t b = (int32_t)((uint32_t)p->our_rpm - 2u * (uint32_t)x_rpms);
             const int32_t max_rpm = a > b ? a : b;
             for (int32_t k = 0; k < n_order; k++) {
                 const int32_t iid = order[k];
@@ -249,17 +303,44 @@ int orc_scaleup_plan(const orc_pod *pods, int32_t n_pods, const int32_t *order, 
         o->copies = copies;
         o->timestamp = new_copies_ts;
     }
+    if (latency_based) { /* :5815-5818 */
+        const double q = ((double)model_parallelism_sum) / n;
+        result->average_model_parallelism = 1.0 >= q ? 1.0 : q; /* Math.max(1.0, q) */
+        result->model_parallelism_sum = model_parallelism_sum;
+        if (!have_exclude_set) result->exclude_set_rpms = jd2i(900.0 * cp->average_model_parallelism); /* (what it WOULD use: informative) */
+    }
     return 0;
+}
+
+int orc_scaleup_plan(const orc_pod *pods, int32_t n_pods, const int32_t *order, int32_t n_order,
+                     const orc_cluster_stats *stats, const orc_cluster_stats *type_stats, int32_t t_rows, int has_tc,
+                     const orc_flat_model *models, const int32_t *ent_pod,
+                     const int64_t *ent_time, const orc_cache_entry *entries, int32_t n, const orc_scaleup_params *p,
+                     orc_scaleup_out *outs, uint8_t *overloaded_out)
+{
+    return scaleup_plan_impl(pods, n_pods, order, n_order, stats, type_stats, t_rows, has_tc, models, ent_pod, ent_time, entries, NULL, n, p,
+                             NULL, outs, NULL, overloaded_out, NULL);
+}
+
+int orc_scaleup_plan_conc(const orc_pod *pods, int32_t n_pods, const int32_t *order, int32_t n_order,
+                          const orc_cluster_stats *stats, const orc_cluster_stats *type_stats, int32_t t_rows, int has_tc,
+                          const orc_flat_model *models, const int32_t *ent_pod,
+                          const int64_t *ent_time, const orc_cache_entry *entries, const orc_conc_entry *conc, int32_t n,
+                          const orc_scaleup_params *p, const orc_conc_params *cp, orc_scaleup_out *outs, orc_conc_out *conc_outs,
+                          uint8_t *overloaded_out, orc_conc_result *result)
+{
+    return scaleup_plan_impl(pods, n_pods, order, n_order, stats, type_stats, t_rows, has_tc, models, ent_pod, ent_time, entries, conc, n, p,
+                             cp, outs, conc_outs, overloaded_out, result);
 }
 
 /* a16 — janitor scale-down, MM.java:6110-6145 with removeModelCopies :6197-6310 and
  * removeSecondModelCopy :6314-6335 (mcce == null).  entries = scaleCopiesCandidates, oldest first;
  * entry.interval_count carries ce.getRpm(timeSinceLastCheck) inputs (the count). in_table[p] =
  * instanceInfo.get(iid) != null. pos_of = PLACEMENT_ORDER position of every present pod. */
-void orc_scaledown_plan(const orc_pod *pods, const int32_t *pos_of, const uint8_t *in_table,
-                        const orc_cluster_stats *stats, const orc_flat_model *models, const int32_t *ent_pod,
-                        const int64_t *ent_time, const orc_cache_entry *entries, int32_t n,
-                        const orc_scaledown_params *p, uint8_t *removed_out)
+static void scaledown_plan_impl(const orc_pod *pods, const int32_t *pos_of, const uint8_t *in_table,
+                                const orc_cluster_stats *stats, const orc_flat_model *models, const int32_t *ent_pod,
+                                const int64_t *ent_time, const orc_cache_entry *entries, const orc_conc_entry *conc, int32_t n,
+                                const orc_scaledown_params *p, int64_t dyn_const, uint8_t *removed_out)
 {
     memset(removed_out, 0, (size_t)n);
     if (p->shutting_down) return; /* :6111 */
@@ -309,8 +390,11 @@ void orc_scaledown_plan(const orc_pod *pods, const int32_t *pos_of, const uint8_
                 const int64_t since = jsub64(now, p->last_check_time);
                 if (since < p->rate_check_interval_ms / 10) break;
                 const int64_t rpm = ce->interval_count == 0 ? 0 : (60000 * ce->interval_count) / since;
-                const int64_t threshold = p->scale_up_rpm_threshold;
+                /* :6294-6295: mcce == null ? scaleUpRpmThreshold : mcce.getRpmScaleThreshold(false) */
+                const int64_t threshold = conc ? orc_rpm_scale_threshold(&conc[e], 0, p->scale_up_rpm_threshold, dyn_const, NULL)
+                                               : p->scale_up_rpm_threshold;
                 if (rpm > (threshold * 2) / 3) break;
+                if (conc && conc[e].queued_requests > 1) break; /* :6303 */
                 removed = 1;
             }
         } while (0);
@@ -320,6 +404,22 @@ void orc_scaledown_plan(const orc_pod *pods, const int32_t *pos_of, const uint8_
             max_weight -= weight;
         }
     }
+}
+
+void orc_scaledown_plan(const orc_pod *pods, const int32_t *pos_of, const uint8_t *in_table,
+                        const orc_cluster_stats *stats, const orc_flat_model *models, const int32_t *ent_pod,
+                        const int64_t *ent_time, const orc_cache_entry *entries, int32_t n,
+                        const orc_scaledown_params *p, uint8_t *removed_out)
+{
+    scaledown_plan_impl(pods, pos_of, in_table, stats, models, ent_pod, ent_time, entries, NULL, n, p, 0, removed_out);
+}
+
+void orc_scaledown_plan_conc(const orc_pod *pods, const int32_t *pos_of, const uint8_t *in_table,
+                             const orc_cluster_stats *stats, const orc_flat_model *models, const int32_t *ent_pod,
+                             const int64_t *ent_time, const orc_cache_entry *entries, const orc_conc_entry *conc, int32_t n,
+                             const orc_scaledown_params *p, int64_t dyn_const, uint8_t *removed_out)
+{
+    scaledown_plan_impl(pods, pos_of, in_table, stats, models, ent_pod, ent_time, entries, conc, n, p, dyn_const, removed_out);
 }
 
 /* a21 — preShutdown migration order, MM.java:7000-7040 with triggerNewModelCopyElsewhere

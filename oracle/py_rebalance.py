@@ -26,27 +26,83 @@ def _loaded_since(mr, cutoff, ignore):  # MM.java:5860-5871
     return False
 
 
-def scaleup(pods, order, stats, type_stats, has_type_constraints, models, entries, p):
+CONC_COUNT_BITS = 21  # MM.java:2653
+INT_MAX = 2**31 - 1
+
+
+def rpm_scale_threshold(m, and_reset, scale_up_rpm_threshold, dyn_const):
+    """MaxConcCacheEntry.getRpmScaleThreshold(andReset), MM.java:2766-2796, on
+    m = dict(count_and_time_sum, prior_sum, prior_count, max_conc) -> (threshold, reset, new_prior_sum, new_prior_count)."""
+    cur_val = m["count_and_time_sum"] & (2**64 - 1)
+    count = _i(cur_val & ((1 << CONC_COUNT_BITS) - 1))
+    prior_sum, prior_count, reset = m["prior_sum"], m["prior_count"], 0
+    if count >= 64:
+        time_sum = _l(cur_val >> CONC_COUNT_BITS)              # `>>>`
+        if and_reset:                                          # sumThenReset(), :2771-2773
+            prior_sum, prior_count, reset = time_sum, count, 1
+    else:
+        pc = m["prior_count"]
+        if pc <= 0 and count < 8:
+            return scale_up_rpm_threshold, reset, prior_sum, prior_count
+        time_sum = _l(m["prior_sum"] + ((cur_val >> CONC_COUNT_BITS) if count > 0 else 0))
+        count = _i(count + pc)
+    if time_sum == 0:
+        return INT_MAX, reset, prior_sum, prior_count
+    num = _l(m["max_conc"] * _l(count * dyn_const))
+    return _i(_jdiv(num, time_sum)), reset, prior_sum, prior_count
+
+
+def _j2i_double(d):
+    """(int) of a double, JLS 5.1.3"""
+    if d != d:
+        return 0
+    if d >= 2147483647.0:
+        return INT_MAX
+    if d <= -2147483648.0:
+        return -2**31
+    return int(d)
+
+
+def scaleup(pods, order, stats, type_stats, has_type_constraints, models, entries, p, conc=None, conc_params=None):
     """-> (list of dict(action, copies, timestamp, new_i1, new_i2, heavy, rpm), overloaded set, returned_early).
     action 0 none, 1 second copy (ensureLoadedInternalAsync(id, lastTime, weight, excludeThisInstance, 0)),
-    2 scale up by `copies` (timestamp = now + 20 s)."""
+    2 scale up by `copies` (timestamp = now + 20 s).
+    conc / conc_params (limitModelConcurrency == true, latencyBased :5677): per entry dict(count_and_time_sum, prior_sum,
+    prior_count, max_conc), dict(dynamic_rpm_scale_constant, average_model_parallelism); the outs then carry threshold / reset /
+    new_prior_sum / new_prior_count and a fourth value is returned: dict(average_model_parallelism, model_parallelism_sum)."""
+    latency_based = conc is not None
     outs = [dict(action=0, copies=0, timestamp=0, new_i1=e["earlier_use_iteration"], new_i2=e["last_used_iteration"],
                  heavy=0, rpm=0) for e in entries]
+    if latency_based:
+        for o, m in zip(outs, conc):
+            o.update(threshold=0, reset=0, new_prior_sum=m["prior_sum"], new_prior_count=m["prior_count"])
+        res = dict(average_model_parallelism=conc_params["average_model_parallelism"], model_parallelism_sum=0)
+        early = scaleup_body(pods, order, stats, type_stats, has_type_constraints, models, entries, p, conc, conc_params, outs, res)
+        return outs, early[0], early[1], res
+    ov, early = scaleup_body(pods, order, stats, type_stats, has_type_constraints, models, entries, p, None, None, outs, None)
+    return outs, ov, early
+
+
+def scaleup_body(pods, order, stats, type_stats, has_type_constraints, models, entries, p, conc, conc_params, outs, res):
+    latency_based = conc is not None
     now, last_time = p["now"], p["last_check_time"]
     time_delta = _l(now - last_time)
     if _l(time_delta * 5) < _l(p["rate_check_interval_ms"] * 3):
-        return outs, set(), True
+        return set(), True
     lower = _i(p["iteration_counter"] - p["second_copy_max_age_iters"])
     upper = _i(p["iteration_counter"] - p["second_copy_min_age_iters"])
     inst_count = stats["instance_count"]
     if inst_count < 2:
-        return outs, set(), True
+        return set(), True
     if not entries:                                    # usedSinceLastRun.isEmpty()
-        return outs, set(), True
+        return set(), True
     new_copies_timestamp = _l(now + 20_000)
-    scale_up_rpms = p["scale_up_rpm_threshold"]
-    heavy_rpms = _jdiv(_i(scale_up_rpms * 3), 4)
+    scale_up_rpms = heavy_rpms = 0
+    if not latency_based:                              # :5679-5682
+        scale_up_rpms = p["scale_up_rpm_threshold"]
+        heavy_rpms = _jdiv(_i(scale_up_rpms * 3), 4)
     exclude_set = None
+    model_parallelism_sum = 0
     for e, ce in enumerate(entries):
         o = outs[e]
         try:
@@ -61,6 +117,12 @@ def scaleup(pods, order, stats, type_stats, has_type_constraints, models, entrie
                 suitable = cluster_stats["instance_count"]
                 if suitable < 2:
                     continue
+            if latency_based:                           # :5702-5707
+                scale_up_rpms, o["reset"], o["new_prior_sum"], o["new_prior_count"] = rpm_scale_threshold(
+                    conc[e], True, p["scale_up_rpm_threshold"], conc_params["dynamic_rpm_scale_constant"])
+                o["threshold"] = scale_up_rpms
+                heavy_rpms = _jdiv(_i(scale_up_rpms * 3), 4)
+                model_parallelism_sum = _i(model_parallelism_sum + conc[e]["max_conc"])
             rpm = _i(_jdiv(_l(count * 60_000), time_delta))
             o["rpm"] = rpm
             if rpm > heavy_rpms:
@@ -96,7 +158,9 @@ def scaleup(pods, order, stats, type_stats, has_type_constraints, models, entrie
             if _loaded_since(mr, recent_cutoff, p["self_pod"]):
                 continue
             if exclude_set is None:                     # getExcludeSet(), :5835-5856
-                max_rpm = max(_i(scale_up_rpms * 4), _i(p["our_rpm"] - _i(2 * scale_up_rpms)))
+                # getExcludeSet's OWN scaleUpRpms, :5836
+                x_rpms = _j2i_double(900.0 * conc_params["average_model_parallelism"]) if latency_based else p["scale_up_rpm_threshold"]
+                max_rpm = max(_i(x_rpms * 4), _i(p["our_rpm"] - _i(2 * x_rpms)))
                 exclude_set = set()
                 for iid in order:
                     if iid == p["self_pod"]:
@@ -120,11 +184,16 @@ def scaleup(pods, order, stats, type_stats, has_type_constraints, models, entrie
             o["action"], o["copies"], o["timestamp"] = 2, copies, new_copies_timestamp
         except ZeroDivisionError:
             continue
-    return outs, (exclude_set or set()), False
+    if latency_based:                                   # :5815-5818
+        res["average_model_parallelism"] = max(1.0, float(model_parallelism_sum) / len(entries))
+        res["model_parallelism_sum"] = model_parallelism_sum
+    return (exclude_set or set()), False
 
 
-def scaledown(pods, pos_of, stats, models, entries, p):
-    """-> list of bool (removeModelCopies returned true).  entries = scaleCopiesCandidates, oldest first."""
+def scaledown(pods, pos_of, stats, models, entries, p, conc=None, dyn_const=0):
+    """-> list of bool (removeModelCopies returned true).  entries = scaleCopiesCandidates, oldest first.
+    conc: the entries are MaxConcCacheEntry objects (per entry dict(count_and_time_sum, prior_sum, prior_count, max_conc,
+    queued_requests)), MM.java:6294-6305."""
     removed_out = [False] * len(entries)
     if p["shutting_down"]:
         return removed_out
@@ -134,7 +203,8 @@ def scaledown(pods, pos_of, stats, models, entries, p):
     for e, ce in enumerate(entries):
         weight = ce["weight"]
         can_remove = removed_count == 0 or weight <= max_weight
-        removed = _remove_model_copies(pods, pos_of, stats, models, ce, ce["last_used"], now, can_remove, p)
+        removed = _remove_model_copies(pods, pos_of, stats, models, ce, ce["last_used"], now, can_remove, p,
+                                       conc[e] if conc is not None else None, dyn_const)
         if removed:
             removed_out[e] = True
             removed_count += 1
@@ -142,7 +212,7 @@ def scaledown(pods, pos_of, stats, models, entries, p):
     return removed_out
 
 
-def _remove_model_copies(pods, pos_of, stats, models, ce, last_used, now, can_remove, p):
+def _remove_model_copies(pods, pos_of, stats, models, ce, last_used, now, can_remove, p, mcce=None, dyn_const=0):
     if last_used == 0:
         return False
     if ce["model"] < 0:
@@ -194,8 +264,10 @@ def _remove_model_copies(pods, pos_of, stats, models, ce, last_used, now, can_re
         return False
     cnt = ce["interval_count"]
     rpm = 0 if cnt == 0 else _jdiv(_l(60_000 * cnt), since)
-    threshold = p["scale_up_rpm_threshold"]
-    if rpm > _jdiv(threshold * 2, 3):
+    threshold = p["scale_up_rpm_threshold"] if mcce is None else rpm_scale_threshold(mcce, False, p["scale_up_rpm_threshold"], dyn_const)[0]
+    if rpm > _jdiv(_l(threshold * 2), 3):
+        return False
+    if mcce is not None and mcce["queued_requests"] > 1:   # :6303
         return False
     return True
 

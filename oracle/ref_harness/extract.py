@@ -62,9 +62,16 @@ RANGES = [
     # ---- a15: rateTrackingTask (the scale-up planner), getExcludeSet, loadedSince.  The `try {` / `} catch ... finally {`
     # lines around the loop body (5656, 5686-5687, 5807-5813) are Java plumbing with no C++ counterpart: the body is taken
     # from inside them
+    # MaxConcCacheEntry.getRpmScaleThreshold (limitModelConcurrency == true: the per-model threshold of the latency-based rate task, :5704,
+    # and of the janitor, :6295) and the constants it reads
+    ("mcce_count_bits", MM, 2653, 2653, "private static final int COUNT_BITS = 21;", "COUNT_BITS = 21;", "member_consts"),
+    ("mcce_count_mask", MM, 2760, 2760, "static final long COUNT_MASK = (1 << COUNT_BITS) - 1;", "COUNT_MASK", "member_consts"),
+    ("mcce_getRpmScaleThreshold_body", MM, 2767, 2795, "long curVal = countAndTimeSum.sum(), timeSum;",
+     "return (int) ((maxConc * (count * dynamicRpmScaleConstant)) / timeSum);", "ushr"),
     ("ratetask_prologue_a", MM, 5641, 5654, "final long lastTime = lastCheckTime, now = currentTimeMillis();", "final int upper = iterationCounter - secondCopyMinAgeIters;"),
     ("ratetask_prologue_b", MM, 5657, 5685, "int instCount = clusterStats.instanceCount;", "int modelParallelismSum = 0;"),
     ("ratetask_loop_body", MM, 5688, 5806, "modelId = ent.getKey();", "copiesToLoad - 1);"),
+    ("ratetask_epilogue", MM, 5815, 5818, "if (latencyBased) {", "}"),
     ("getExcludeSet_body", MM, 5836, 5855, "int scaleUpRpms = limitModelConcurrency", "return excludeSet != null ? excludeSet : Collections.emptySet();"),
     ("loadedSince_body", MM, 5861, 5870, "for (Entry<String, Long> entry : mr.getInstanceIds().entrySet()) {", "return false;"),
     # ---- a16: the janitor's scale-down of model copies
@@ -225,6 +232,15 @@ TCMI_RANGES = [
 # label would be.  Its four label lines become the equivalent if-chain (ADDED/UPDATED run both blocks, DELETED the second,
 # anything else nothing); every statement between them stays the reference's text.
 EXTRA_RULES = {
+    # constant declarations of a nested class: the member modifiers in front of them
+    "member_consts": [
+        (re.compile(r"^\s*(?:private\s+)?static\s+final\s+"), "static const "),
+    ],
+    # the unsigned right shift of a long does not exist in C++: `x >>> n` -> JUSHR(x, n)  (only in the body that uses it: elsewhere
+    # `>>>` closes three generic brackets)
+    "ushr": [
+        (re.compile(r"\b(\w+)\s*>>>\s*(\w+)\b"), r"JUSHR(\1, \2)"),
+    ],
     "LISTENER_SWITCH": [
         (re.compile(r"^(\s*)switch \(type\) \{\s*$"), r"\1const EventType sw_type = type;  // switch (type) {"),
         (re.compile(r"^(\s*)case ENTRY_ADDED:\s*$"), r"\1if (sw_type == ENTRY_ADDED || sw_type == ENTRY_UPDATED) {  // case ENTRY_ADDED:"),

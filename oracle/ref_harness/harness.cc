@@ -328,7 +328,13 @@ struct IntField {  // an assignable int field of an object with reference semant
     operator int() const { return *p; }
     const IntField &operator=(int v) const { *p = v; return *this; }
 };
+struct ConcState {  // MaxConcCacheEntry's own fields (see below)
+    long countAndTimeSum = 0, priorSum = 0;
+    int priorCount = 0, maxConc = 1, queued = 0;
+    int resets = 0, lastThreshold = 0;  // observed: sumThenReset() calls, what getRpmScaleThreshold returned last
+};
 struct CacheEntry {  // what the fragments ask of a CacheEntry<?>
+    std::shared_ptr<ConcState> conc;  // non-null: the object is a MaxConcCacheEntry
     bool isnull = true, done = false, failed = false;
     int predicted = 0;
     String modelInfoType;
@@ -357,17 +363,44 @@ struct CacheEntry {  // what the fragments ask of a CacheEntry<?>
     void setLastHeavyTime(long t) const { *heavy = t; }
     int getWeight() const { return weight; }
 };
-struct MaxConcCacheEntry {  // limitModelConcurrency == false here: compiled, never executed
-    int maxConc = 1;
-    bool isnull = false;
-    MaxConcCacheEntry(const CacheEntry &) {}
-    MaxConcCacheEntry(std::nullptr_t) : isnull(true) {}
-    bool operator==(std::nullptr_t) const { return isnull; }
-    bool operator!=(std::nullptr_t) const { return !isnull; }
-    int getRpmScaleThreshold(boolean) const { return 0; }
-    int queuedRequestCount() const { return 0; }
+// MaxConcCacheEntry (MM.java:2641-2797), limitModelConcurrency == true: the cache entries of such a mesh ARE MaxConcCacheEntry objects.
+// The state the rate task and the janitor read lives in the CacheEntry stand-in (ConcState, shared by the handle copies); this
+// class is the `(MaxConcCacheEntry<?>) ce` view of it, and getRpmScaleThreshold's body is the reference's text.
+static int scaleUpRpmThreshold;                 // MM.java:240 / :369 (read by getRpmScaleThreshold, :2781, and the rate task)
+static long dynamicRpmScaleConstant;            // MM.java:370
+struct LongAdderStub {  // java.util.concurrent.atomic.LongAdder, single-threaded
+    std::shared_ptr<ConcState> st;
+    long sum() const { return st->countAndTimeSum; }
+    long sumThenReset() const { const long v = st->countAndTimeSum; st->countAndTimeSum = 0; st->resets++; return v; }
 };
-static boolean instanceof_MaxConcCacheEntry(const CacheEntry &) { return false; }  // (plain CacheEntry objects only)
+struct MaxConcCacheEntry {
+#include "../_ref/gen/mcce_count_bits.inc"
+#include "../_ref/gen/mcce_count_mask.inc"
+    std::shared_ptr<ConcState> st;
+    int maxConc = 1;
+    LongAdderStub countAndTimeSum;
+    int &priorCount;
+    long &priorSum;
+    static ConcState &dummy() { static ConcState d; return d; }
+    MaxConcCacheEntry(const CacheEntry &ce) : st(ce.conc), maxConc(ce.conc ? ce.conc->maxConc : 1), countAndTimeSum{ce.conc},
+                                              priorCount(ce.conc ? ce.conc->priorCount : dummy().priorCount),
+                                              priorSum(ce.conc ? ce.conc->priorSum : dummy().priorSum) {}
+    MaxConcCacheEntry(std::nullptr_t) : priorCount(dummy().priorCount), priorSum(dummy().priorSum) {}
+    bool operator==(std::nullptr_t) const { return !st; }
+    bool operator!=(std::nullptr_t) const { return (bool)st; }
+    int getRpmScaleThreshold(boolean andReset)  // :2766
+    {
+        const int rc = getRpmScaleThreshold_(andReset);
+        st->lastThreshold = rc;
+        return rc;
+    }
+    int getRpmScaleThreshold_(boolean andReset)
+    {
+#include "../_ref/gen/mcce_getRpmScaleThreshold_body.inc"
+    }
+    int queuedRequestCount() const { return st->queued; }  // :2746 (limiter.getQueueLength(): an input)
+};
+static boolean instanceof_MaxConcCacheEntry(const CacheEntry &ce) { return (bool)ce.conc; }
 static const mmp_gate_req *g_gq;  // the request whose fragment is running
 static CacheEntry g_cache_entry;
 static CacheEntry getFromCache(const String &, long) { return g_cache_entry; }  // MM.java:3609
@@ -497,10 +530,12 @@ static void frag_publish(boolean force, boolean preShutdown)
 
 // =================================== a15: rateTrackingTask, the scale-up planner (MM.java:5619-5871) =========================
 static long lastCheckTime, RATE_CHECK_INTERVAL_MS;      // :5617, :238
-static int iterationCounter, secondCopyMaxAgeIters, secondCopyMinAgeIters, secondCopyLruThresholdMillis, scaleUpRpmThreshold;
+static int iterationCounter, secondCopyMaxAgeIters, secondCopyMinAgeIters, secondCopyLruThresholdMillis;
 static boolean limitModelConcurrency = false;
 static double averageModelParallelism = 1.0;
-static const struct { bool operator!=(std::nullptr_t) const { return false; } void removeUnloadBufferEntry(const Map<String, CacheEntry> &) const {} } unloadManager;
+// (unloadManager != null whenever the runtime can unload — the default; removeUnloadBufferEntry drops the unload-buffer's own entry,
+// which is not a model and which the inputs here never contain)
+static const struct { bool operator!=(std::nullptr_t) const { return true; } void removeUnloadBufferEntry(const Map<String, CacheEntry> &) const {} } unloadManager;
 static Map<String, CacheEntry> g_used_since_last_run;
 static const struct RuntimeCacheScale { Map<String, CacheEntry> descendingMapWithCutoff(long) const { return g_used_since_last_run; } } runtimeCacheScale;
 static List<String> excludeThisInstance;
@@ -538,6 +573,7 @@ static void rateTrackingTask_run()
     for (Entry<String, CacheEntry> ent : usedSinceLastRun.entrySet()) {  // :5686 (the try / catch / finally around the body: plumbing)
 #include "../_ref/gen/ratetask_loop_body.inc"
     }
+#include "../_ref/gen/ratetask_epilogue.inc"
 }
 
 // ================================ a16: the janitor's scale-down of model copies (MM.java:6110-6335) ===========================
@@ -1202,7 +1238,31 @@ int main(int argc, char **argv)
     const int64_t n_mig = n_mig_v[0];
     auto mig_hdr = rd<int64_t>(f, n_mig >= 0 ? 2 : 0);  // self instance, now
     auto mig_entries = rd<mmp_cache_entry>(f, n_mig > 0 ? (size_t)n_mig : 0);
+    // optional trailer (absent in the inputs of rounds 3-4, whose digests therefore stand): limitModelConcurrency == true — the
+    // MaxConcCacheEntry row of every cache entry of the a15 / a16 section of this input, dynamicRpmScaleConstant, and the rate
+    // task's averageModelParallelism going into the run
+    int64_t n_conc = -1;
+    std::vector<mmp_conc_params> conc_params;
+    std::vector<mmp_conc_entry> conc_rows;
+    {
+        int64_t v = 0;
+        if (fread(&v, sizeof v, 1, f) == 1) {
+            n_conc = v;
+            conc_params = rd<mmp_conc_params>(f, 1);
+            conc_rows = rd<mmp_conc_entry>(f, (size_t)n_conc);
+        }
+    }
     fclose(f);
+    auto conc_state = [&](int64_t e) {
+        auto st = std::make_shared<ConcState>();
+        const mmp_conc_entry &m = conc_rows[(size_t)e];
+        st->countAndTimeSum = m.count_and_time_sum;
+        st->priorSum = m.prior_sum;
+        st->priorCount = m.prior_count;
+        st->maxConc = m.max_conc;
+        st->queued = m.queued_requests;
+        return st;
+    };
 
     std::vector<String> ids(P);
     std::unordered_map<std::string, int> pod_of;
@@ -1464,6 +1524,13 @@ int main(int argc, char **argv)
         secondCopyMinAgeIters = sp.second_copy_min_age_iters;
         secondCopyLruThresholdMillis = (int)sp.second_copy_lru_threshold_ms;
         scaleUpRpmThreshold = sp.scale_up_rpm_threshold;
+        limitModelConcurrency = n_conc >= 0;
+        averageModelParallelism = 1.0;
+        if (n_conc >= 0) {
+            if (n_conc != n_scale) { fprintf(stderr, "ref_harness: %lld MaxConcCacheEntry rows for %lld cache entries\n", (long long)n_conc, (long long)n_scale); return 2; }
+            dynamicRpmScaleConstant = conc_params[0].dynamic_rpm_scale_constant;
+            averageModelParallelism = conc_params[0].average_model_parallelism;
+        }
         invokeCounter.g_v = sp.our_rpm;
         g_assume_completed = sp.assume_completed_ms;
         excludeThisInstance = ArrayList_new();
@@ -1479,6 +1546,7 @@ int main(int argc, char **argv)
             ce.weight = x.weight;
             ce.earlierUseIteration = x.earlier_use_iteration;
             ce.lastUsedIteration = x.last_used_iteration;
+            if (n_conc >= 0) ce.conc = conc_state(e);
             char key[32];
             snprintf(key, sizeof key, "m%09lld", (long long)e);  // the map iterates in key order = the entries' order
             int type = -1;
@@ -1520,6 +1588,20 @@ int main(int argc, char **argv)
         wr(o, so);
         wr(o, flag);
         wr(o, ov);
+        if (n_conc >= 0) {  // per entry: what getRpmScaleThreshold(true) returned (0: never called), whether it reset the adder, priorSum /
+                            // priorCount afterwards; then the bits of averageModelParallelism after the run
+            std::vector<int64_t> co(n_scale * 4 + 1, 0);
+            for (int64_t e = 0; e < n_scale; e++) {
+                const ConcState &st = *ces[e].conc;
+                co[e * 4 + 0] = st.lastThreshold;
+                co[e * 4 + 1] = st.resets;
+                co[e * 4 + 2] = st.priorSum;
+                co[e * 4 + 3] = st.priorCount;
+            }
+            static_assert(sizeof(double) == sizeof(int64_t), "the double travels as its bits");
+            memcpy(&co[n_scale * 4], &averageModelParallelism, sizeof(double));
+            wr(o, co);
+        }
     }
 
     // ---- a16: which local copies the janitor removes (removeLocalModelCopyAsync calls), per candidate
@@ -1532,6 +1614,10 @@ int main(int argc, char **argv)
         lastCheckTime = dp.last_check_time;
         RATE_CHECK_INTERVAL_MS = dp.rate_check_interval_ms;
         scaleUpRpmThreshold = dp.scale_up_rpm_threshold;
+        if (n_conc >= 0) {
+            if (n_conc != n_sd) { fprintf(stderr, "ref_harness: %lld MaxConcCacheEntry rows for %lld candidates\n", (long long)n_conc, (long long)n_sd); return 2; }
+            dynamicRpmScaleConstant = conc_params[0].dynamic_rpm_scale_constant;
+        }
         g_adjusted_capacity = dp.adjusted_cache_capacity;
         g_pod_of = pod_of;
         g_in_table.assign(P, 0);
@@ -1561,6 +1647,7 @@ int main(int argc, char **argv)
             ce.intervalCount = x.interval_count;
             ce.weight = x.weight;
             ce.lastHeavyTimeIn = x.last_heavy_time;
+            if (n_conc >= 0) ce.conc = conc_state(e);
             char key[32];
             snprintf(key, sizeof key, "m%09lld", (long long)e);
             ObjectArr3 arr;

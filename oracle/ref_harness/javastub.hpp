@@ -25,6 +25,8 @@ static_assert(sizeof(long) == 8 && sizeof(int) == 4, "Java long / int (build wit
 // (int) of a double: JLS 5.1.3 (NaN -> 0, saturating); (int) of a long: the low 32 bits
 static inline int J2I(double d) { return d != d ? 0 : d >= 2147483647.0 ? INT_MAX : d <= -2147483648.0 ? INT_MIN : (int)d; }
 static inline int J2I(long v) { return (int)(uint32_t)(uint64_t)v; }
+// `x >>> n` on a long (JLS 15.19)
+static inline long JUSHR(long x, int n) { return (long)((uint64_t)x >> (n & 63)); }
 
 // java.lang.String (nullable, immutable)
 class String {

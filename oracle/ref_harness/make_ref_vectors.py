@@ -37,7 +37,7 @@ def proactive_inputs(fleet, units, partitioned):
 
 
 def run(blob: bytes, n_place: int, n_serve: int, n_gate: int = 0, n_scale: int = -1, n_pods: int = 0, n_sd: int = -1, proactive: bool = False,
-        events: bool = False, upgrade: int = -1, types=None, migration: int = -1):
+        events: bool = False, upgrade: int = -1, types=None, migration: int = -1, conc: bool = False):
     with tempfile.TemporaryDirectory() as td:
         fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
         open(fin, "wb").write(blob)
@@ -118,7 +118,12 @@ def run(blob: bytes, n_place: int, n_serve: int, n_gate: int = 0, n_scale: int =
     called = int(np.frombuffer(raw, "<i8", 1, off)[0])
     off += 8
     ov = np.frombuffer(raw, "u1", n_pods, off).copy()
-    assert off + n_pods == len(raw)
+    off += n_pods
+    if conc:  # per entry (threshold, resets, priorSum, priorCount), then the bits of averageModelParallelism
+        co = np.frombuffer(raw, "<i8", 4 * n_scale + 1, off).copy()
+        assert off + 8 * (4 * n_scale + 1) == len(raw)
+        return order, place, serve, gate, scale, called, ov, co[:-1].reshape(n_scale, 4), co[-1:].view(np.float64)
+    assert off == len(raw)
     return order, place, serve, gate, scale, called, ov
 
 
@@ -165,6 +170,48 @@ def main():
         names.append(name)
         print(f"{name}: {len(entries)} cache entries: {int((scale[:, 0] == 1).sum())} second copies, {int((scale[:, 0] == 2).sum())} scale-ups, "
               f"{int(scale[:, 5].sum())} heavy, {int(ov.sum())} overloaded instances")
+    for name, fleet, ids, entries, sp in rf.scaleup_edge_cases():
+        cstats = np.zeros(1, dtype=ob.ORC_STATS)
+        cstats[0] = ob.OracleFleet(fleet).stats()
+        blob = rf.input_blob(fleet, ids, scaleup=(entries, sp, cstats, np.ascontiguousarray(ob.type_set_stats(fleet))))
+        *_, scale, called, ov = run(blob, 0, 0, 0, len(entries), fleet.n_pods)
+        out[f"{name}/scale"], out[f"{name}/overloaded"] = scale, ov
+        out[f"{name}/exclude_set_built"] = np.array([called])
+        out[f"{name}/digest"] = np.frombuffer(rf.digest(blob).encode(), np.uint8)
+        names.append(name)
+        print(f"{name}: {len(entries)} cache entries: {int((scale[:, 0] == 1).sum())} second copies, {int((scale[:, 0] == 2).sum())} scale-ups, "
+              f"{int(ov.sum())} overloaded instances, exclude set built: {called}")
+    for name, fleet, ids, entries, conc, sp, cp in rf.scaleup_conc_cases():
+        cstats = np.zeros(1, dtype=ob.ORC_STATS)
+        cstats[0] = ob.OracleFleet(fleet).stats()
+        blob = rf.input_blob(fleet, ids, scaleup=(entries, sp, cstats, np.ascontiguousarray(ob.type_set_stats(fleet))), conc=(conc, cp))
+        *_, scale, called, ov, cout, avg = run(blob, 0, 0, 0, len(entries), fleet.n_pods, conc=True)
+        out[f"{name}/scale"], out[f"{name}/overloaded"] = scale, ov
+        out[f"{name}/exclude_set_built"] = np.array([called])
+        out[f"{name}/conc"], out[f"{name}/average_model_parallelism"] = cout, avg
+        out[f"{name}/digest"] = np.frombuffer(rf.digest(blob).encode(), np.uint8)
+        names.append(name)
+        print(f"{name}: {len(entries)} MaxConcCacheEntry entries: {int((scale[:, 0] == 1).sum())} second copies, {int((scale[:, 0] == 2).sum())} scale-ups, "
+              f"{int(scale[:, 5].sum())} heavy, {int(cout[:, 1].sum())} counter resets, {len(np.unique(cout[:, 0]))} distinct thresholds, "
+              f"{int(ov.sum())} overloaded instances; averageModelParallelism {float(cp['average_model_parallelism'][0])} -> {float(avg[0])!r}")
+    for name, fleet, ids, entries, conc, dp, dyn in rf.scaledown_conc_cases():
+        istats = ob.instance_set_stats(fleet, int(dp["self_pod"][0]))
+        cp = np.zeros(1, dtype=rf._lib.CONC_PARAMS)
+        cp["dynamic_rpm_scale_constant"], cp["average_model_parallelism"] = dyn, 1.0
+        blob = rf.input_blob(fleet, ids, scaledown=(entries, dp, istats), conc=(conc, cp))
+        removed = run(blob, 0, 0, 0, -1, 0, len(entries))
+        out[f"{name}/removed"] = removed
+        out[f"{name}/digest"] = np.frombuffer(rf.digest(blob).encode(), np.uint8)
+        names.append(name)
+        print(f"{name}: {len(entries)} MaxConcCacheEntry candidates: {int(removed.sum())} local copies removed")
+    for name, fleet, ids, entries, dp in rf.scaledown_edge_cases():
+        istats = ob.instance_set_stats(fleet, int(dp["self_pod"][0]))
+        blob = rf.input_blob(fleet, ids, scaledown=(entries, dp, istats))
+        removed = run(blob, 0, 0, 0, -1, 0, len(entries))
+        out[f"{name}/removed"] = removed
+        out[f"{name}/digest"] = np.frombuffer(rf.digest(blob).encode(), np.uint8)
+        names.append(name)
+        print(f"{name}: {len(entries)} candidates: {int(removed.sum())} local copies removed")
     for name, fleet, ids, entries, dp in rf.scaledown_cases():
         istats = ob.instance_set_stats(fleet, int(dp["self_pod"][0]))  # instanceSetStats(): an INPUT (rows a5 / a18)
         blob = rf.input_blob(fleet, ids, scaledown=(entries, dp, istats))

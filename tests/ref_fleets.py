@@ -278,6 +278,111 @@ def scaleup_cases():
             yield f"scaleup_{seed}_{j}", fleet, ids, entries, sp
 
 
+def conc_rows(rng, n):
+    """MaxConcCacheEntry state per cache entry (MM.java:2641-2797): countAndTimeSum with counts on both sides of the 64 / 8
+    limits of getRpmScaleThreshold (:2769, :2780), with and without prior samples, zero time sums, a few queued requests."""
+    c = np.zeros(n, dtype=_lib.CONC_ENTRY)
+    count = rng.choice([0, 1, 7, 8, 30, 63, 64, 65, 500, 20_000], n)
+    per_call = rng.choice([0, 1, 8, 50, 400, 30_000], n)  # mean duration in 1/10 ms
+    c["count_and_time_sum"] = (count * per_call) * (1 << _lib.CONC_COUNT_BITS) + count
+    c["prior_count"] = rng.choice([0, 0, 5, 64, 900, -1], n)
+    c["prior_sum"] = np.where(c["prior_count"] > 0, c["prior_count"] * rng.choice([0, 2, 60, 500], n), rng.choice([0, 0, 7], n))
+    c["max_conc"] = rng.choice([1, 1, 2, 4, 8, 16, 64], n)
+    c["queued_requests"] = rng.choice([0, 0, 0, 1, 2, 9], n)
+    return c
+
+
+def scaleup_conc_cases():
+    """(name, fleet, ids, entries, conc, params, conc_params): the rate task of a mesh that limits model concurrency (latencyBased,
+    MM.java:5677): every entry's threshold is mcce.getRpmScaleThreshold(true) (:5704), averageModelParallelism feeds getExcludeSet
+    (:5836) and is recomputed after the loop (:5815-5818)."""
+    for seed, pods, used in ((0, 12, 0.5), (1, 200, 0.97), (2, 200, 0.2), (4, 64, 0.9)):
+        fleet, rng = _rebalance_fleet(seed, pods, 600, used)
+        ids = string_ids(fleet, 80 + seed)
+        now = fleet.now
+        entries = _local_entries(fleet, rng, 800)
+        conc = conc_rows(rng, len(entries))
+        for j, (thr, our_rpm, last_check, avg, pct) in enumerate(((2000, 100, now - 10_000, 1.0, 90), (300, 50_000, now - 9_000, 3.75, 90),
+                                                                  (2000, 0, now - 1_000, 2.5, 90), (50, 9_000, now - 12_000, 11.3, 50))):
+            sp = np.zeros(1, dtype=_lib.SCALEUP_PARAMS)
+            sp["self_pod"], sp["iteration_counter"] = 0, 130
+            sp["second_copy_max_age_iters"], sp["second_copy_min_age_iters"] = 240, 42
+            sp["scale_up_rpm_threshold"], sp["our_rpm"] = thr, our_rpm
+            sp["now"], sp["last_check_time"], sp["rate_check_interval_ms"] = now, last_check, 10_000
+            sp["second_copy_lru_threshold_ms"], sp["assume_completed_ms"] = 72_000_000, 30_000
+            cp = np.zeros(1, dtype=_lib.CONC_PARAMS)
+            cp["dynamic_rpm_scale_constant"], cp["average_model_parallelism"] = 600_000 * pct // 100, avg
+            yield f"scaleup_conc_{seed}_{j}", fleet, ids, entries, conc, sp, cp
+
+
+def scaleup_edge_cases():
+    """(name, fleet, ids, entries, params): rate-task runs that reach the lines the fleets above do not: no invocations since the
+    last check (MM.java:5667-5669), a type confined to a single instance (:5697-5699), a scale-up with nothing overloaded (the
+    exclude set stays the model's own instances, :5789)."""
+    fleet, rng = _rebalance_fleet(5, 40, 300, 0.5)
+    ids = string_ids(fleet, 91)
+    now = fleet.now
+    sp = np.zeros(1, dtype=_lib.SCALEUP_PARAMS)
+    sp["self_pod"], sp["iteration_counter"] = 0, 130
+    sp["second_copy_max_age_iters"], sp["second_copy_min_age_iters"] = 240, 42
+    sp["scale_up_rpm_threshold"], sp["our_rpm"] = 100, 10**9
+    sp["now"], sp["last_check_time"], sp["rate_check_interval_ms"] = now, now - 10_000, 10_000
+    sp["second_copy_lru_threshold_ms"], sp["assume_completed_ms"] = 72_000_000, 1_000
+    yield "scaleup_edge_empty", fleet, ids, _local_entries(fleet, rng, 0), sp
+    # nothing overloaded (our own rpm is far above everyone's), loads old enough, plenty of candidates: scale-ups with an empty exclude set
+    f2, rng2 = _rebalance_fleet(6, 60, 300, 0.3)
+    f2.ent_time[:] = now - 90_000_000
+    e2 = _local_entries(f2, rng2, 400)
+    e2["interval_count"] = rng2.choice([400, 5000, 90_000], len(e2))
+    yield "scaleup_edge_nothing_overloaded", f2, string_ids(f2, 92), e2, sp
+    # type constraints under which one type may only run on instance 0 and another nowhere: typeSetStats(type).instanceCount < 2
+    f3, rng3 = _rebalance_fleet(7, 30, 200, 0.4)
+    T = 3
+    al = np.ones((T, f3.n_pods), bool)
+    al[1, 1:] = False
+    al[2, :] = False
+    f3.n_types = T
+    f3.allowed, f3.prefer = wl.bitmap_from_bool(al), wl.bitmap_from_bool(np.zeros((T, f3.n_pods), bool))
+    f3.has_allowed, f3.has_prefer = np.array([0, 1, 1], np.uint8), np.zeros(T, np.uint8)
+    f3.models["type"] = rng3.integers(0, T, f3.n_models)
+    yield "scaleup_edge_confined_types", f3, string_ids(f3, 93), _local_entries(f3, rng3, 300), sp
+
+
+def scaledown_conc_cases():
+    """(name, fleet, ids, entries, conc, params, dyn_const): janitor passes over MaxConcCacheEntry candidates (MM.java:6294-6305): the
+    threshold of a model with three or more copies is mcce.getRpmScaleThreshold(false), a copy with queued requests stays."""
+    for seed, pods, used in ((1, 200, 0.97), (4, 300, 0.99)):
+        fleet, rng = _rebalance_fleet(seed, pods, 600, used)
+        ids = string_ids(fleet, 80 + seed)
+        now = fleet.now
+        entries = _local_entries(fleet, rng, 800)
+        entries["last_heavy_time"] = np.where(rng.random(len(entries)) < 0.5, 0, entries["last_heavy_time"])
+        fleet.ent_time[:] = now - 90_000_000  # no copy loaded within the last 30 minutes (:6269)
+        conc = conc_rows(rng, len(entries))
+        for j, (thr, cap, pct) in enumerate(((2000, 10_000_000, 90), (10, 10_000_000, 10))):
+            dp = np.zeros(1, dtype=_lib.SCALEDOWN_PARAMS)
+            dp["self_pod"], dp["shutting_down"], dp["now"] = 0, 0, now
+            dp["last_check_time"], dp["rate_check_interval_ms"] = now - 7_000, 10_000
+            dp["adjusted_cache_capacity"], dp["scale_up_rpm_threshold"] = cap, thr
+            yield f"scaledown_conc_{seed}_{j}", fleet, ids, entries, conc, dp, 600_000 * pct // 100
+
+
+def scaledown_edge_cases():
+    """(name, fleet, ids, entries, params): the sample period too small to judge a model's load (MM.java:6286-6289), and this
+    instance shutting down / not in the table when a second copy is old enough to go (removeSecondModelCopy, :6322-6324)."""
+    for k, (self_flags, last_check_ago) in enumerate(((2, 500), (1, 7_000), (4, 7_000))):
+        fleet, rng = _rebalance_fleet(4, 300, 600, 0.99)
+        fleet.pods["flags"][0] = self_flags
+        fleet.ent_time[:] = fleet.now - 90_000_000
+        entries = _local_entries(fleet, rng, 800)
+        entries["last_heavy_time"] = 0
+        dp = np.zeros(1, dtype=_lib.SCALEDOWN_PARAMS)
+        dp["self_pod"], dp["shutting_down"], dp["now"] = 0, 0, fleet.now
+        dp["last_check_time"], dp["rate_check_interval_ms"] = fleet.now - last_check_ago, 10_000
+        dp["adjusted_cache_capacity"], dp["scale_up_rpm_threshold"] = 10_000_000, 2000
+        yield f"scaledown_edge_{k}", fleet, string_ids(fleet, 95 + k), entries, dp
+
+
 def scaledown_cases():
     """(name, fleet, ids, entries, params): janitor passes over scaleCopiesCandidates (MM.java:6110-6140 -> removeModelCopies
     :6197-6310 -> removeSecondModelCopy :6314-6335) for the local cache entries of instance 0."""
@@ -543,7 +648,7 @@ def _lib_flag_live():
 
 
 def input_blob(fleet, ids, reqs=None, extra=None, serve=None, gates=None, scaleup=None, scaledown=None, proactive=None, events=None,
-               upgrade=None, types=None, migration=None) -> bytes:
+               upgrade=None, types=None, migration=None, conc=None) -> bytes:
     """The harness' input file (layout: oracle/ref_harness/harness.cc main())."""
     P, M = fleet.n_pods, fleet.n_models
     T = int(fleet.n_types)
@@ -627,6 +732,10 @@ def input_blob(fleet, ids, reqs=None, extra=None, serve=None, gates=None, scaleu
     else:
         entries, self_pod, now = migration
         parts += [struct.pack("<qqq", len(entries), int(self_pod), int(now)), np.ascontiguousarray(entries).tobytes()]
+    if conc is not None:  # optional trailer: limitModelConcurrency == true (the inputs without it keep their round-3/4 digests)
+        rows, cparams = conc  # CONC_ENTRY per cache entry of the a15 / a16 section; 1 CONC_PARAMS row
+        assert rows.dtype.itemsize == 32 and cparams.dtype.itemsize == 16 and len(cparams) == 1
+        parts += [struct.pack("<q", len(rows)), np.ascontiguousarray(cparams).tobytes(), np.ascontiguousarray(rows).tobytes()]
     return b"".join(parts)
 
 

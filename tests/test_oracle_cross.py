@@ -428,6 +428,85 @@ def test_rebalancers_c_vs_python(seed, pods, used):
     assert np.array_equal(np.array(ga, np.uint8), wa) and np.array_equal(np.array(gw, np.uint8), ww)
 
 
+def test_latency_based_rebalancers_c_vs_python():
+    """limitModelConcurrency == true: getRpmScaleThreshold (MM.java:2766-2796) on random MaxConcCacheEntry rows — including
+    extreme counters, negative prior counts and wrapping products —, the latency-based rate task (:5677-5818, :5836) and the
+    janitor over MaxConcCacheEntry candidates (:6294-6305), in both restatements (the reference-text vectors of
+    tests/test_ref_vectors.py pin the C one; this keeps the second, independent one equal to it)."""
+    from modelmesh_amd import _lib
+    from oracle import py_rebalance as pr
+    import ctypes as C
+    from tests import ref_fleets as rf
+    lib = ob.load()
+    rng = np.random.default_rng(77)
+    n = 4000
+    rows = rf.conc_rows(rng, n)
+    wild = rng.random(n) < 0.3  # beyond anything a mesh produces: the arithmetic must still be Java's
+    rows["count_and_time_sum"] = np.where(wild, rng.integers(-2**63, 2**63 - 1, n), rows["count_and_time_sum"])
+    rows["prior_sum"] = np.where(wild, rng.integers(-2**40, 2**62, n), rows["prior_sum"])
+    rows["max_conc"] = np.where(wild, rng.integers(-5, 2**31 - 1, n), rows["max_conc"])
+    lib.orc_rpm_scale_threshold.restype = C.c_int32
+    lib.orc_rpm_scale_threshold.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_void_p]
+    for i in range(n):
+        for and_reset in (0, 1):
+            dyn = int(rng.choice([540_000, 60_000, 1, 2**40]))
+            co = np.zeros(1, dtype=_lib.CONC_OUT)
+            co["new_prior_sum"], co["new_prior_count"] = rows["prior_sum"][i], rows["prior_count"][i]
+            got = lib.orc_rpm_scale_threshold(rows[i:i + 1].ctypes.data_as(C.c_void_p), and_reset, 2000, dyn, co.ctypes.data_as(C.c_void_p))
+            m = {k: int(rows[k][i]) for k in rows.dtype.names}
+            want = pr.rpm_scale_threshold(m, bool(and_reset), 2000, dyn)
+            assert (got, int(co["reset"][0]), int(co["new_prior_sum"][0]), int(co["new_prior_count"][0])) == want, (m, and_reset, dyn)
+
+    for name, fleet, ids, entries, conc, sp, cp in rf.scaleup_conc_cases():
+        if not name.endswith(("_1", "_3")):
+            continue
+        orc = ob.OracleFleet(fleet)
+        order = [int(x) for x in orc.order]
+        ppods = [dict(rpm=int(r["rpm"]), shutting_down=bool(r["flags"] & 1), in_table=not bool(r["flags"] & 4)) for r in fleet.pods]
+        pmodels = []
+        for m in fleet.models:
+            o, k, f = int(m["ent_off"]), int(m["n_loaded"]), int(m["n_failed"])
+            pmodels.append(dict(type=int(m["type"]), last_used=int(m["last_used"]),
+                                loaded=[(int(fleet.ent_pod[o + i]), int(fleet.ent_time[o + i])) for i in range(k)],
+                                failed=[(int(fleet.ent_pod[o + k + i]), int(fleet.ent_time[o + k + i])) for i in range(f)]))
+        pent = [{f: int(e[f]) for f in ("model", "weight", "last_used", "interval_count", "last_heavy_time", "last_unload_time",
+                                        "earlier_use_iteration", "last_used_iteration")} for e in entries]
+        pconc = [{k: int(r[k]) for k in conc.dtype.names} for r in conc]
+        sd = lambda st: {n_: int(st[n_]) for n_ in st.dtype.names}  # noqa: E731
+        w_out, w_co, w_ov, w_sk, w_res = ob.scaleup_plan_conc(fleet, entries, conc, sp.view(ob.ORC_SCALEUP_PARAMS), cp)
+        g_out, g_ov, g_sk, g_res = pr.scaleup(ppods, order, sd(orc.stats()), [sd(t) for t in ob.type_set_stats(fleet)], bool(fleet.n_types),
+                                              pmodels, pent, {n_: int(sp[n_][0]) for n_ in sp.dtype.names}, pconc,
+                                              dict(dynamic_rpm_scale_constant=int(cp["dynamic_rpm_scale_constant"][0]),
+                                                   average_model_parallelism=float(cp["average_model_parallelism"][0])))
+        assert bool(w_sk) == g_sk, name
+        for f in ("action", "copies", "timestamp", "new_i1", "new_i2", "heavy", "rpm"):
+            assert np.array_equal(np.array([o[f] for o in g_out]), w_out[f]), (name, f)
+        for f in ("threshold", "reset", "new_prior_sum", "new_prior_count"):
+            assert np.array_equal(np.array([o[f] for o in g_out]), w_co[f]), (name, f)
+        assert g_res["average_model_parallelism"] == float(w_res["average_model_parallelism"]), name
+        assert g_res["model_parallelism_sum"] == int(w_res["model_parallelism_sum"]), name
+        if np.any(w_out["action"] == 2):
+            assert set(np.nonzero(w_ov)[0]) == g_ov, name
+    for name, fleet, ids, entries, conc, dp, dyn in rf.scaledown_conc_cases():
+        orc = ob.OracleFleet(fleet)
+        pos_of = {int(p): i for i, p in enumerate(orc.order)}
+        ppods = [dict(rpm=int(r["rpm"]), shutting_down=bool(r["flags"] & 1), in_table=not bool(r["flags"] & 4)) for r in fleet.pods]
+        pmodels = []
+        for m in fleet.models:
+            o, k, f = int(m["ent_off"]), int(m["n_loaded"]), int(m["n_failed"])
+            pmodels.append(dict(type=int(m["type"]), last_used=int(m["last_used"]),
+                                loaded=[(int(fleet.ent_pod[o + i]), int(fleet.ent_time[o + i])) for i in range(k)],
+                                failed=[(int(fleet.ent_pod[o + k + i]), int(fleet.ent_time[o + k + i])) for i in range(f)]))
+        pent = [{f: int(e[f]) for f in ("model", "weight", "last_used", "interval_count", "last_heavy_time", "last_unload_time",
+                                        "earlier_use_iteration", "last_used_iteration")} for e in entries]
+        pconc = [{k: int(r[k]) for k in conc.dtype.names} for r in conc]
+        st = {n_: int(v) for n_, v in zip(ob.ORC_STATS.names, ob.instance_set_stats(fleet, 0, orc)[0])}
+        want = ob.scaledown_plan_conc(fleet, entries, conc, dp.view(ob.ORC_SCALEDOWN_PARAMS), dyn)
+        got = pr.scaledown(ppods, {p: pos_of.get(p, 2**31 - 1) for p in range(fleet.n_pods)}, st, pmodels, pent,
+                           {n_: int(dp[n_][0]) for n_ in dp.dtype.names}, pconc, dyn)
+        assert np.array_equal(np.array(got, np.uint8), want), name
+
+
 @pytest.mark.parametrize("seed,pods,models,used", [(0, 8, 300, 0.5), (1, 64, 3000, 0.2), (2, 300, 4000, 0.9), (3, 300, 4000, 0.99),
                                                   (5, 5, 50, 0.0)])
 def test_proactive_plan_c_vs_python(seed, pods, models, used):

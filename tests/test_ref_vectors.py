@@ -209,6 +209,75 @@ def test_scaleup_plan_equals_the_reference_text(ref):
     assert seen >= {0, 1, 2}
 
 
+def test_scaleup_edge_cases_equal_the_reference_text(ref):
+    """The rate task's remaining exits: no invocations since the last check (MM.java:5667-5669), a type confined to one instance
+    (:5697-5699), a scale-up with nobody overloaded (ourExcludeSet = the model's own instances, :5789)."""
+    for name, fleet, ids, entries, sp in rf.scaleup_edge_cases():
+        cstats = np.zeros(1, dtype=ob.ORC_STATS)
+        cstats[0] = OracleFleet(fleet).stats()
+        blob = rf.input_blob(fleet, ids, scaleup=(entries, sp, cstats, np.ascontiguousarray(ob.type_set_stats(fleet))))
+        assert rf.digest(blob) == bytes(ref[f"{name}/digest"]).decode(), name
+        out, ov, sk = ob.scaleup_plan(fleet, entries, sp.view(ob.ORC_SCALEUP_PARAMS))
+        check_scaleup(name, out, ov, ref[f"{name}/scale"], ref[f"{name}/overloaded"])
+        assert bool(sk) == (len(entries) == 0), name
+    assert np.any(ref["scaleup_edge_nothing_overloaded/scale"][:, 0] == 2) and not ref["scaleup_edge_nothing_overloaded/overloaded"].any()
+
+
+def check_conc(name, couts, res, ref_conc, ref_avg, skipped):
+    """Per MaxConcCacheEntry: what getRpmScaleThreshold(true) returned (MM.java:2766-2796; 0 = never called), whether it reset the
+    counters (:2771-2773), priorSum / priorCount afterwards; and the task's averageModelParallelism after the run (:5815-5818) —
+    a double, compared EXACTLY (it is a sum of ints, one IEEE division and a max; BASELINE's 1e-6 would be slack)."""
+    for k, f in enumerate(("threshold", "reset", "new_prior_sum", "new_prior_count")):
+        got = np.asarray(couts[f]).astype(np.int64)
+        bad = np.nonzero(got != ref_conc[:, k])[0]
+        assert len(bad) == 0, (name, f, len(bad), [(int(i), int(got[i]), int(ref_conc[i, k])) for i in bad[:5]])
+    a, b = float(res["average_model_parallelism"]), float(ref_avg[0])
+    assert a == b and abs(a - b) <= 1e-6, (name, a, b, skipped)
+
+
+def test_scaleup_plan_latency_based_equals_the_reference_text(ref):
+    """rateTrackingTask with limitModelConcurrency == true (latencyBased, MM.java:5677, :5702-5707, :5815-5818, :5836) over
+    MaxConcCacheEntry entries whose getRpmScaleThreshold body (:2767-2795) is the reference's text too."""
+    seen, resets, thresholds = set(), 0, set()
+    for name, fleet, ids, entries, conc, sp, cp in rf.scaleup_conc_cases():
+        cstats = np.zeros(1, dtype=ob.ORC_STATS)
+        cstats[0] = OracleFleet(fleet).stats()
+        blob = rf.input_blob(fleet, ids, scaleup=(entries, sp, cstats, np.ascontiguousarray(ob.type_set_stats(fleet))), conc=(conc, cp))
+        assert rf.digest(blob) == bytes(ref[f"{name}/digest"]).decode(), name
+        out, couts, ov, sk, res = ob.scaleup_plan_conc(fleet, entries, conc, sp.view(ob.ORC_SCALEUP_PARAMS), cp)
+        check_scaleup(name, out, ov, ref[f"{name}/scale"], ref[f"{name}/overloaded"])
+        check_conc(name, couts, res, ref[f"{name}/conc"], ref[f"{name}/average_model_parallelism"], sk)
+        seen |= set(np.unique(ref[f"{name}/scale"][:, 0]))
+        resets += int(ref[f"{name}/conc"][:, 1].sum())
+        thresholds |= set(np.unique(ref[f"{name}/conc"][:, 0]))
+    assert seen >= {0, 1, 2} and resets > 1000 and 2**31 - 1 in thresholds and len(thresholds) > 200
+
+
+def test_scaledown_plan_conc_and_edge_cases_equal_the_reference_text(ref):
+    """The janitor over MaxConcCacheEntry candidates (MM.java:6294-6305: getRpmScaleThreshold(false), queued requests), with a
+    sample period too short to judge (:6286-6289), and with this instance shutting down / gone (removeSecondModelCopy :6322-6324)."""
+    total = 0
+    for name, fleet, ids, entries, conc, dp, dyn in rf.scaledown_conc_cases():
+        istats = ob.instance_set_stats(fleet, int(dp["self_pod"][0]))
+        cp = np.zeros(1, dtype=rf._lib.CONC_PARAMS)
+        cp["dynamic_rpm_scale_constant"], cp["average_model_parallelism"] = dyn, 1.0
+        blob = rf.input_blob(fleet, ids, scaledown=(entries, dp, istats), conc=(conc, cp))
+        assert rf.digest(blob) == bytes(ref[f"{name}/digest"]).decode(), name
+        rem = ob.scaledown_plan_conc(fleet, entries, conc, dp.view(ob.ORC_SCALEDOWN_PARAMS), dyn)
+        bad = np.flatnonzero(rem != ref[f"{name}/removed"])
+        assert bad.size == 0, (name, bad[:8], entries[bad[:8]], conc[bad[:8]])
+        plain = ob.scaledown_plan(fleet, entries, dp.view(ob.ORC_SCALEDOWN_PARAMS))
+        assert not np.array_equal(plain, rem), name  # (the MaxConcCacheEntry rows matter on these fleets)
+        total += int(rem.sum())
+    for name, fleet, ids, entries, dp in rf.scaledown_edge_cases():
+        istats = ob.instance_set_stats(fleet, int(dp["self_pod"][0]))
+        blob = rf.input_blob(fleet, ids, scaledown=(entries, dp, istats))
+        assert rf.digest(blob) == bytes(ref[f"{name}/digest"]).decode(), name
+        rem = ob.scaledown_plan(fleet, entries, dp.view(ob.ORC_SCALEDOWN_PARAMS))
+        assert np.array_equal(rem, ref[f"{name}/removed"]), name
+    assert total >= 100
+
+
 def test_scaledown_plan_equals_the_reference_text(ref):
     """The janitor's pass over scaleCopiesCandidates (MM.java:6110-6140), removeModelCopies (:6197-6310) and
     removeSecondModelCopy (:6314-6335): per candidate, whether the reference's own text removes the LOCAL copy."""

@@ -96,6 +96,54 @@ def test_hip_scaleup_plan_equals_the_reference_text(ref):
         check_scaleup(name, out, ov, ref[f"{name}/scale"], ref[f"{name}/overloaded"])
 
 
+def test_hip_scaleup_edge_cases_equal_the_reference_text(ref):
+    from tests.test_ref_vectors import check_scaleup
+    for name, fleet, ids, entries, sp in rf.scaleup_edge_cases():
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            s.load_fleet(fleet)
+            out, ov, sk = s.scaleup_plan(entries, sp)
+        finally:
+            s.close()
+        check_scaleup(name, out, ov, ref[f"{name}/scale"], ref[f"{name}/overloaded"])
+        assert bool(sk) == (len(entries) == 0), name
+
+
+def test_hip_scaleup_plan_latency_based_equals_the_reference_text(ref):
+    """mmp_scaleup_plan_conc: the rate task of a mesh that limits model concurrency — thresholds, counter resets and
+    averageModelParallelism (the path's one double: exact) against the reference's own text."""
+    from tests.test_ref_vectors import check_conc, check_scaleup
+    for name, fleet, ids, entries, conc, sp, cp in rf.scaleup_conc_cases():
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            s.load_fleet(fleet)
+            out, couts, ov, sk, res = s.scaleup_plan_conc(entries, conc, sp, cp)
+        finally:
+            s.close()
+        check_scaleup(name, out, ov, ref[f"{name}/scale"], ref[f"{name}/overloaded"])
+        check_conc(name, couts, res, ref[f"{name}/conc"], ref[f"{name}/average_model_parallelism"], sk)
+
+
+def test_hip_scaledown_plan_conc_and_edge_cases_equal_the_reference_text(ref):
+    for name, fleet, ids, entries, conc, dp, dyn in rf.scaledown_conc_cases():
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            s.load_fleet(fleet)
+            rem = s.scaledown_plan_conc(entries, conc, dp, dyn)
+        finally:
+            s.close()
+        bad = np.flatnonzero(rem != ref[f"{name}/removed"])
+        assert bad.size == 0, (name, bad[:8], entries[bad[:8]], conc[bad[:8]])
+    for name, fleet, ids, entries, dp in rf.scaledown_edge_cases():
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            s.load_fleet(fleet)
+            rem = s.scaledown_plan(entries, dp)
+        finally:
+            s.close()
+        assert np.array_equal(rem, ref[f"{name}/removed"]), name
+
+
 def test_hip_scaledown_plan_equals_the_reference_text(ref):
     for name, fleet, ids, entries, dp in rf.scaledown_cases():
         s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
