@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MMP_ABI_VERSION 2
+#define MMP_ABI_VERSION 3 /* 3: latency-based rebalancers (mmp_*_plan_conc), the single-caller request form, bounded device-pointer calls */
 
 /* return codes */
 #define MMP_OK 0
@@ -103,6 +103,32 @@ typedef struct {
     int32_t fresh_count;
     int32_t fresh_rpm;
 } mmp_place_req;
+
+/* The single-caller form of a batch of load-target decisions.  `self` and getFreshInstanceRecord() (MM.java:5369-5386) belong
+ * to the CALLING INSTANCE, not to the request, and every batch the reference itself produces is issued by one instance: the rate
+ * task (:5636), the janitor (:6110), the reaper (:6616), preShutdown (:6959), an instance's own request threads.  The caller's
+ * side travels once per call (mmp_place_caller, 40 bytes), a decision is 24 bytes instead of 64: mmp_place_batch_c.  The
+ * decision is the one of mmp_place_req {model, caller.self_pod, caller.flags, pick, last_used, extra_off, n_extra, caller.fresh_*}. */
+typedef struct {
+    int32_t self_pod; /* the calling instance, -1 if not in the table */
+    uint32_t flags;   /* MMP_REQ_FAVOUR_SELF                          */
+    int64_t fresh_lru;
+    int64_t fresh_capacity;
+    int64_t fresh_used;
+    int32_t fresh_count;
+    int32_t fresh_rpm;
+} mmp_place_caller;
+typedef struct {
+    int32_t model;
+    uint32_t pick;
+    int64_t last_used;
+    int32_t extra_off;
+    int32_t n_extra;
+} mmp_place_req_c;
+
+/* mmp_place_out::best of a decision whose request the library refused to follow (bounded device-pointer calls: an exclusion
+ * range outside the pool the caller declared); its chosen is MMP_NONE, n_candidates and hash are 0. */
+#define MMP_BAD_REQUEST (-3)
 
 /* 16 bytes per decision. On early returns (no eligible pod, or the immediate
  * "choose self" returns at MM.java:4872,4894,4932) n_candidates = hash = 0. */
@@ -475,6 +501,18 @@ int mmp_place_batch(mmp_ctx *ctx, const mmp_place_req *reqs, int32_t n, const in
  * therefore stay valid until mmp_stream_retire() or mmp_destroy(). */
 int mmp_place_batch_dev(mmp_ctx *ctx, const void *d_reqs, int32_t n, const void *d_extra_pool,
                         int64_t now_ms, void *d_outs, void *stream);
+/* mmp_place_batch_dev with the pool's length (entries): a request whose exclusion range [extra_off, extra_off + n_extra) does not
+ * lie inside the pool is not followed — its result row is {MMP_NONE, MMP_BAD_REQUEST, 0, 0} — instead of being read wherever it
+ * points (mmp_place_batch_dev cannot check: it is not told the length).  d_extra_pool may be NULL when n_extra_pool == 0. */
+int mmp_place_batch_dev2(mmp_ctx *ctx, const void *d_reqs, int32_t n, const void *d_extra_pool, int32_t n_extra_pool,
+                         int64_t now_ms, void *d_outs, void *stream);
+/* The single-caller form (mmp_place_caller + mmp_place_req_c, above): host pointers / device pointers.  `caller` is host memory
+ * in both (it rides in the kernel's arguments).  The device-pointer call is bounded like mmp_place_batch_dev2.  Results are
+ * bit-identical to the same decisions as mmp_place_req rows. */
+int mmp_place_batch_c(mmp_ctx *ctx, const mmp_place_caller *caller, const mmp_place_req_c *reqs, int32_t n,
+                      const int32_t *extra_pool, int32_t n_extra_pool, int64_t now_ms, mmp_place_out *outs);
+int mmp_place_batch_c_dev(mmp_ctx *ctx, const mmp_place_caller *caller, const void *d_reqs, int32_t n, const void *d_extra_pool,
+                          int32_t n_extra_pool, int64_t now_ms, void *d_outs, void *stream);
 /* k request arrays decided by ONE launch: the same as k calls of mmp_place_batch_dev on `stream` (array i: n[i] requests at
  * d_reqs[i], its own exclusion pool d_extra_pool[i] — the array may be NULL when no request carries extras —, results to
  * d_outs[i]), for a host that holds many batches the size of one request set: a 100k-decision launch lasts an empty launch + one

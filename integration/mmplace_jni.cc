@@ -273,7 +273,7 @@ JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_gateBatch(JNIEnv *e
                                 inUseFailureExpiryMs, buf<mmp_gate_out>(env, outs)));
 }
 
-// ---- the cache-hit route in one launch: the guards + the serve target of every request (include/mmplace.h: mmp_route_batch)
+// ---- the cache-MISS route in one launch: the guards + the load target of every request (include/mmplace.h: mmp_miss_batch)
 JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_missBatch(JNIEnv *env, jclass, jlong h, jobject gateReqs,
                                                                        jobject placeReqs, jint n, jobject exclPod, jobject exclTime,
                                                                        jint nExcl, jobject explicitPool, jint nExplicit,
@@ -286,6 +286,7 @@ JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_missBatch(JNIEnv *e
                                 buf<int32_t>(env, extraPool), nExtra, nowMs, inUseFailureExpiryMs, buf<mmp_gate_out>(env, gateOuts),
                                 buf<mmp_place_out>(env, placeOuts)));
 }
+// ---- the cache-HIT route in one launch: the guards + the serve target of every request (include/mmplace.h: mmp_route_batch)
 JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_routeBatch(JNIEnv *env, jclass, jlong h, jobject gateReqs,
                                                                         jobject serveReqs, jint n, jobject counters,
                                                                         jint nCounters, jobject exclPod, jobject exclTime,

@@ -35,6 +35,37 @@ PLACE_REQ = np.dtype(
      ("extra_off", "<i4"), ("n_extra", "<i4"), ("fresh_lru", "<i8"), ("fresh_capacity", "<i8"),
      ("fresh_used", "<i8"), ("fresh_count", "<i4"), ("fresh_rpm", "<i4")])
 PLACE_OUT = np.dtype([("chosen", "<i4"), ("best", "<i4"), ("n_candidates", "<i4"), ("hash", "<u4")])
+# the single-caller form: the caller's side once per call, 24 bytes per decision
+PLACE_CALLER = np.dtype([("self_pod", "<i4"), ("flags", "<u4"), ("fresh_lru", "<i8"), ("fresh_capacity", "<i8"), ("fresh_used", "<i8"),
+                         ("fresh_count", "<i4"), ("fresh_rpm", "<i4")])
+PLACE_REQ_C = np.dtype([("model", "<i4"), ("pick", "<u4"), ("last_used", "<i8"), ("extra_off", "<i4"), ("n_extra", "<i4")])
+assert PLACE_CALLER.itemsize == 40 and PLACE_REQ_C.itemsize == 24
+MMP_BAD_REQUEST = -3
+
+
+def split_caller(reqs):
+    """mmp_place_req rows that share one caller -> (PLACE_CALLER[1], PLACE_REQ_C[n]); asserts that they do."""
+    reqs = np.ascontiguousarray(reqs, dtype=PLACE_REQ)
+    caller = np.zeros(1, dtype=PLACE_CALLER)
+    for f in PLACE_CALLER.names:
+        assert len(reqs) == 0 or np.all(reqs[f] == reqs[f][0]), f
+        if len(reqs):
+            caller[f] = reqs[f][0]
+    rc = np.zeros(len(reqs), dtype=PLACE_REQ_C)
+    for f in PLACE_REQ_C.names:
+        rc[f] = reqs[f]
+    return caller, rc
+
+
+def join_caller(caller, reqs_c):
+    """The same decisions as mmp_place_req rows."""
+    caller = np.asarray(caller).reshape(-1)[0]
+    out = np.zeros(len(reqs_c), dtype=PLACE_REQ)
+    for f in PLACE_REQ_C.names:
+        out[f] = reqs_c[f]
+    for f in PLACE_CALLER.names:
+        out[f] = caller[f]
+    return out
 SERVE_REQ = np.dtype(
     [("model", "<i4"), ("self_pod", "<i4"), ("flags", "<u4"), ("local_in_flight", "<i4"),
      ("last_invoke_time", "<i8"), ("assume_completed_ms", "<i8"), ("excl_off", "<i4"), ("n_excl", "<i4"),
@@ -138,6 +169,9 @@ SYMBOLS = [
     ("mmp_snapshot_commit", C.c_int, [_P]),
     ("mmp_get_order", C.c_int, [_P, _P, C.POINTER(C.c_int32)]),
     ("mmp_delta_commits", C.c_int, [_P, C.POINTER(C.c_int64)]),
+    ("mmp_place_batch_dev2", C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int64, _P, _P]),
+    ("mmp_place_batch_c", C.c_int, [_P, _P, _P, C.c_int32, _P, C.c_int32, C.c_int64, _P]),
+    ("mmp_place_batch_c_dev", C.c_int, [_P, _P, _P, C.c_int32, _P, C.c_int32, C.c_int64, _P, _P]),
     ("mmp_cluster_stats", C.c_int, [_P, _P]),
     ("mmp_type_stats", C.c_int, [_P, C.c_int32, _P]),
     ("mmp_partition_count", C.c_int, [_P, _P]),

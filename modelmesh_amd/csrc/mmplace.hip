@@ -127,7 +127,9 @@ struct FastSlot {
     mmp_place_out *outs = nullptr;
     uint32_t *done = nullptr;  // pinned: the kernel stores the call's sequence number here when its results are visible
     uint32_t *blocks = nullptr;  // device: finished-workgroup counter of the call in flight
-    uint32_t seq = 0;
+    // sequence number of the slot's last launch: bumped by the owner (under f.mu and the shared state lock), read by
+    // quiesce_decisions without either — hence atomic
+    std::atomic<uint32_t> seq{0};
 };
 
 struct mmp_ctx {
@@ -380,16 +382,20 @@ void resident_stop(mmp_ctx *c)
     R.running = false;
 }
 
-hipError_t slot_wait(FastSlot *f);
+hipError_t slot_wait(FastSlot *f, uint32_t seq);
 hipError_t quiesce_decisions(mmp_ctx *c)
 {
     resident_stop(c);
     // A latency slot has a kernel in flight only while its completion word lags its sequence number (the kernel stores the word
     // last; the owner bumps the number under the state lock, which the caller of this function holds or which no launch can pass
-    // any more): an idle slot costs a load here, not a hipStreamSynchronize (16 of them were 50-100 us under the exclusive lock)
+    // any more): an idle slot costs a load here, not a hipStreamSynchronize (the slots' synchronisations were 50-100 us under the
+    // exclusive lock).  The number is read ONCE per slot: the quiescer waits for the launches that existed when it came, not for
+    // the ones a busy owner keeps adding behind them (sequence numbers wrap: compare by difference).
     for (FastSlot &f : c->fast) {
-        if (!f.done || __atomic_load_n(f.done, __ATOMIC_ACQUIRE) == f.seq) continue;
-        hipError_t e = slot_wait(&f);
+        if (!f.done) continue;
+        const uint32_t snap = f.seq.load(std::memory_order_acquire);
+        if ((int32_t)(__atomic_load_n(f.done, __ATOMIC_ACQUIRE) - snap) >= 0) continue;
+        hipError_t e = slot_wait(&f, snap);
         if (e != hipSuccess) return e;
     }
     std::vector<hipStream_t> cs;
@@ -453,12 +459,13 @@ FastSlot *slot_acquire(mmp_ctx *c, std::unique_lock<std::mutex> &lock)
     return f;
 }
 
-// Spin on the slot's flag; the ordinary stream synchronisation is the fallback when it is late.
-hipError_t slot_wait(FastSlot *f)
+// Spin on the slot's flag until launch number `seq` has completed (the owner passes its own launch's number, a quiescer the
+// number it read when it came); the ordinary stream synchronisation is the fallback when it is late.
+hipError_t slot_wait(FastSlot *f, uint32_t seq)
 {
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t spins = 0;; spins++) {
-        if (__atomic_load_n(f->done, __ATOMIC_ACQUIRE) == f->seq) return hipSuccess;
+        if ((int32_t)(__atomic_load_n(f->done, __ATOMIC_ACQUIRE) - seq) >= 0) return hipSuccess;
         if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) break;
         __builtin_ia32_pause();
     }
@@ -466,10 +473,16 @@ hipError_t slot_wait(FastSlot *f)
 }
 
 hipError_t order_after_registry(mmp_ctx *c, hipStream_t st);
+// what only some callers of place_launch bring: the caller's side of the single-caller form (d_reqs are mmp_place_req_c rows then),
+// the declared length of the exclusion pool (bounded calls; extra_bound = 1 + entries, 0 = not declared)
+struct PlaceOpts {
+    const mmp_place_caller *caller = nullptr;
+    int32_t extra_bound = 0;
+};
 int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int64_t now, void *d_outs,
                  hipStream_t st, uint32_t *done_flag = nullptr, uint32_t done_seq = 0, const mmp_place_req *inline_req = nullptr,
                  uint32_t *done_blocks = nullptr, const PlaceSegs *segs = nullptr, int32_t seg_blocks = 0, const GateArgs *fused_gate = nullptr,
-                 const mmp_gate_req *fused_greq = nullptr)
+                 const mmp_gate_req *fused_greq = nullptr, const PlaceOpts *opts = nullptr)
 {
     if (n == 0) return MMP_OK;
     PlaceArgs A{};
@@ -488,6 +501,9 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     A.n_pods_all = c->snap.P;
     A.done_flag = done_flag;
     A.done_seq = done_seq;
+    A.extra_bound = opts ? opts->extra_bound : 0;
+    const mmp_place_caller *caller = opts ? opts->caller : nullptr;
+    if (caller && (segs || inline_req || done_flag)) return fail(c, MMP_EINVAL, "the single-caller form takes the batch kernels only");
     const int wpad = (c->snap.W + 1) & ~1;
     // one dynamic region: the lane phase's windows + scratch, re-used by the wave path's tiles (place_block)
     size_t lds = std::max<size_t>((size_t)kPlaceWaves * 2 * wpad * sizeof(uint64_t), (size_t)place_lane_lds(c->snap.T));
@@ -534,6 +550,9 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_multi_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_multi_long4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_long_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_long4_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         c->lds_granted.store((size_t)want, std::memory_order_release);
     }
     HIP_TRY(c, order_after_registry(c, st));
@@ -553,6 +572,12 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     else if (done_flag && n > kPlaceBlock)
         hipLaunchKernelGGL(place_batch_flag_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad,
                            done_blocks);
+    else if (caller && c->snap_long && n >= kLongDenseFrom)
+        hipLaunchKernelGGL(place_batch_long4_c_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *caller);
+    else if (caller && c->snap_long)
+        hipLaunchKernelGGL(place_batch_long_c_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *caller);
+    else if (caller)
+        hipLaunchKernelGGL(place_batch_c_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *caller);
     else if (c->snap_long && n >= kLongDenseFrom)
         hipLaunchKernelGGL(place_batch_long4_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad);
     else if (c->snap_long)
@@ -1223,14 +1248,21 @@ try {
                            c->u_rows.as<mmp_model_row>(), k, c->ent_pod.as<int32_t>(), c->models.as<mmp_model_row>(),
                            resolved ? cur_side(c).rmodels.as<ResolvedModel>() : nullptr);
         KT_END(c, st);
-        HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipEventRecord(c->reg_event, st));
+        // From here on the rewrite may be running.  Nothing may leave this block with the lock released, the rewrite enqueued
+        // and no way for later decisions to order themselves behind it: a launch or event error drains the stream first, and
+        // the new counts are published only once the event stands.
+        hipError_t le = hipGetLastError();
+        if (le == hipSuccess) le = hipEventRecord(c->reg_event, st);
+        if (le != hipSuccess) {
+            (void)hipStreamSynchronize(st);
+            HIP_TRY(c, le);
+        }
         c->reg_pending.store(true, std::memory_order_release);
         c->n_models = count;
         c->n_entries = base + n_entries;
     }
     const hipError_t se = hipStreamSynchronize(st);
-    c->reg_pending.store(false, std::memory_order_release);
+    if (se == hipSuccess) c->reg_pending.store(false, std::memory_order_release);  // (a failed wait leaves later launches ordered behind the event)
     HIP_TRY(c, se);
     kt_collect(c);
     // more garbage than live entries (and enough to matter): squeeze the arena
@@ -1479,6 +1511,10 @@ try {
             };
             RankRow rr[kDeltaRows];
             for (int32_t k = 0; k < K; k++) rr[k] = make_rank_row(c->pods[chg[k]], min_space);
+            // The order this path publishes must be STRICT, as the one from scratch is (scatter_pods_kernel reports two rows
+            // of one rank as MMP_EORDER): a changed row that now ties with its neighbour or with another changed row — a
+            // duplicate or unset id_order, every other field equal — sends the commit down the full path, which reports it.
+            bool strict = true;
             for (int32_t k = 0; k < K; k++) {
                 int32_t lo = 0, hi = P - K;
                 while (lo < hi) {
@@ -1488,9 +1524,15 @@ try {
                     else
                         hi = mid;
                 }
+                // (every unchanged row before lo is less than the row by the search; the one at lo must be greater, not equal)
+                if (lo < P - K && !placement_less(rr[k], make_rank_row(c->pods[unchanged_at(lo)], min_space), churn2)) strict = false;
                 int32_t before = 0;
-                for (int32_t k2 = 0; k2 < K; k2++)
-                    if (k2 != k && placement_less(rr[k2], rr[k], churn2)) before++;
+                for (int32_t k2 = 0; k2 < K; k2++) {
+                    if (k2 == k) continue;
+                    const bool lt = placement_less(rr[k2], rr[k], churn2);
+                    if (lt) before++;
+                    else if (!placement_less(rr[k], rr[k2], churn2)) strict = false;  // neither before the other: a tie
+                }
                 dl.pod[k] = chg[k];
                 dl.removed[k] = rem_sorted[k];
                 dl.ins[k] = lo;
@@ -1498,20 +1540,22 @@ try {
                 dl.rows[k] = c->pods[chg[k]];
             }
             // the host mirror of the NEW order (published with the snapshot below)
-            new_order.assign(P, -1);
-            std::vector<uint8_t> is_chg(P, 0);
-            for (int32_t k = 0; k < K; k++) {
-                new_order[dl.newrank[k]] = chg[k];
-                is_chg[chg[k]] = 1;
+            if (strict) {
+                new_order.assign(P, -1);
+                std::vector<uint8_t> is_chg(P, 0);
+                for (int32_t k = 0; k < K; k++) {
+                    new_order[dl.newrank[k]] = chg[k];
+                    is_chg[chg[k]] = 1;
+                }
+                int32_t w = 0;
+                for (int32_t q = 0; q < P; q++) {
+                    const int32_t pod = c->h_order[q];
+                    if (is_chg[pod]) continue;
+                    while (new_order[w] >= 0) w++;
+                    new_order[w++] = pod;
+                }
             }
-            int32_t w = 0;
-            for (int32_t q = 0; q < P; q++) {
-                const int32_t pod = c->h_order[q];
-                if (is_chg[pod]) continue;
-                while (new_order[w] >= 0) w++;
-                new_order[w++] = pod;
-            }
-            delta = true;
+            delta = strict;
         }
     }
     if (P && !delta) HIP_TRY(c, hipMemcpyAsync(B.pods.p, c->pods.data(), (size_t)P * sizeof(mmp_pod_row), hipMemcpyHostToDevice, st));
@@ -1540,7 +1584,7 @@ try {
         if (c->d_prefer_gen != c->types_gen)
             HIP_TRY(c, hipMemcpyAsync(c->d_prefer.p, c->prefer.data(), c->prefer.size() * 8, hipMemcpyHostToDevice, st));
     }
-    B.types_gen = N.types_gen = c->d_prefer_gen = c->types_gen;
+    const uint64_t types_gen_uploaded = c->types_gen;  // (marked current once the copies have landed: behind the synchronisation)
     const int32_t n_rs = (int32_t)c->replaced_rs.size();
     if (n_rs) HIP_TRY(c, hipMemcpyAsync(c->rs_list.p, c->replaced_rs.data(), (size_t)n_rs * 4, hipMemcpyHostToDevice, st));
 
@@ -1699,6 +1743,7 @@ try {
     int32_t n_bslots = 0;
     HIP_TRY(c, hipMemcpyAsync(&n_bslots, static_cast<char *>(B.bslots.p) + kBSlots * sizeof(BSlot), sizeof n_bslots, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    B.types_gen = N.types_gen = c->d_prefer_gen = types_gen_uploaded;
     B.n_bslots = std::min(n_bslots, kBSlots);
     kt_collect(c);
     if (bad)
@@ -2330,7 +2375,7 @@ try {
         HIP_TRY(c, hipMemcpyAsync(N.d_allowed.p, c->allowed.data(), c->allowed.size() * 8, hipMemcpyHostToDevice, st));
         HIP_TRY(c, hipMemcpyAsync(c->d_prefer.p, c->prefer.data(), c->prefer.size() * 8, hipMemcpyHostToDevice, st));
     }
-    B.types_gen = N.types_gen = c->d_prefer_gen = c->types_gen;
+    B.types_gen = N.types_gen = c->d_prefer_gen = 0;  // (uploaded unconditionally here; "unknown" makes an ordinary commit upload again)
     const int32_t n_rs = (int32_t)c->replaced_rs.size();
     if (n_rs) HIP_TRY(c, hipMemcpyAsync(c->rs_list.p, c->replaced_rs.data(), (size_t)n_rs * 4, hipMemcpyHostToDevice, st));
     const int64_t min_space = c->cfg.min_space_units;
@@ -3493,6 +3538,106 @@ try {
     return fail(c, MMP_EHIP, "%s: %s", "mmp_stream_retire", e.what());
 }
 
+int mmp_place_batch_dev2(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra, int32_t n_extra_pool, int64_t now,
+                         void *d_outs, void *stream)
+try {
+    if (!c || n < 0 || n_extra_pool < 0 || (n > 0 && (!d_reqs || !d_outs)) || (n_extra_pool > 0 && !d_extra))
+        return fail(c, MMP_EINVAL, "mmp_place_batch_dev2: bad argument");
+    std::shared_lock<std::shared_mutex> g(c->mu);  // capture the published snapshot + enqueue; no wait
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
+    note_caller_stream(c, static_cast<hipStream_t>(stream));
+    PlaceOpts o;
+    o.extra_bound = n_extra_pool + 1;
+    return place_launch(c, d_reqs, n, d_extra, now, d_outs, static_cast<hipStream_t>(stream), nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr,
+                        nullptr, &o);
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_place_batch_dev2");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_place_batch_dev2", e.what());
+}
+
+int mmp_place_batch_c_dev(mmp_ctx *c, const mmp_place_caller *caller, const void *d_reqs, int32_t n, const void *d_extra,
+                          int32_t n_extra_pool, int64_t now, void *d_outs, void *stream)
+try {
+    if (!c || !caller || n < 0 || n_extra_pool < 0 || (n > 0 && (!d_reqs || !d_outs)) || (n_extra_pool > 0 && !d_extra))
+        return fail(c, MMP_EINVAL, "mmp_place_batch_c_dev: bad argument");
+    std::shared_lock<std::shared_mutex> g(c->mu);
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
+    note_caller_stream(c, static_cast<hipStream_t>(stream));
+    PlaceOpts o;
+    o.caller = caller;
+    o.extra_bound = n_extra_pool + 1;
+    return place_launch(c, d_reqs, n, d_extra, now, d_outs, static_cast<hipStream_t>(stream), nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr,
+                        nullptr, &o);
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_place_batch_c_dev");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_place_batch_c_dev", e.what());
+}
+
+int mmp_place_batch(mmp_ctx *c, const mmp_place_req *reqs, int32_t n, const int32_t *extra_pool, int32_t n_extra,
+                    int64_t now, mmp_place_out *outs);
+int mmp_place_batch_c(mmp_ctx *c, const mmp_place_caller *caller, const mmp_place_req_c *reqs, int32_t n, const int32_t *extra_pool,
+                      int32_t n_extra, int64_t now, mmp_place_out *outs)
+try {
+    if (!c || !caller || n < 0 || n_extra < 0 || (n > 0 && (!reqs || !outs)) || (n_extra > 0 && !extra_pool))
+        return fail(c, MMP_EINVAL, "mmp_place_batch_c: bad argument");
+    for (int32_t i = 0; i < n; i++)
+        if (reqs[i].n_extra < 0 || reqs[i].extra_off < 0 || (int64_t)reqs[i].extra_off + reqs[i].n_extra > n_extra)
+            return fail(c, MMP_EINVAL, "mmp_place_batch_c: request %d extra range out of bounds", i);
+    if (n <= kFastN && n_extra <= kFastExtra) {
+        // a handful of requests: the latency path of mmp_place_batch (slots, the single-decision kernels, the resident kernel) on
+        // the same decisions written out as mmp_place_req rows
+        std::vector<mmp_place_req> full((size_t)n);
+        for (int32_t i = 0; i < n; i++) {
+            mmp_place_req &r = full[(size_t)i];
+            r.model = reqs[i].model;
+            r.self_pod = caller->self_pod;
+            r.flags = caller->flags;
+            r.pick = reqs[i].pick;
+            r.last_used = reqs[i].last_used;
+            r.extra_off = reqs[i].extra_off;
+            r.n_extra = reqs[i].n_extra;
+            r.fresh_lru = caller->fresh_lru;
+            r.fresh_capacity = caller->fresh_capacity;
+            r.fresh_used = caller->fresh_used;
+            r.fresh_count = caller->fresh_count;
+            r.fresh_rpm = caller->fresh_rpm;
+        }
+        return mmp_place_batch(c, full.data(), n, extra_pool, n_extra, now, outs);
+    }
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    std::lock_guard<std::mutex> gb(c->batch_mu);
+    hipStream_t st = c->stream;
+    HIP_TRY(c, c->s_reqs.ensure((size_t)n * sizeof(mmp_place_req_c)));
+    HIP_TRY(c, c->s_outs.ensure((size_t)n * sizeof(mmp_place_out)));
+    HIP_TRY(c, c->s_extra.ensure((size_t)std::max(n_extra, 1) * 4));
+    HIP_TRY(c, hipMemcpyAsync(c->s_reqs.p, reqs, (size_t)n * sizeof(mmp_place_req_c), hipMemcpyHostToDevice, st));
+    if (n_extra) HIP_TRY(c, hipMemcpyAsync(c->s_extra.p, extra_pool, (size_t)n_extra * 4, hipMemcpyHostToDevice, st));
+    {
+        std::lock_guard<std::shared_mutex> g(c->mu);
+        if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+        if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard: use mmp_shard_place_phase_dev");
+        PlaceOpts o;
+        o.caller = caller;
+        KT_BEGIN(c, st);
+        const int rc = place_launch(c, c->s_reqs.p, n, c->s_extra.p, now, c->s_outs.p, st, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr,
+                                    nullptr, &o);
+        if (rc != MMP_OK) return rc;
+        KT_END(c, st);
+    }
+    HIP_TRY(c, hipMemcpyAsync(outs, c->s_outs.p, (size_t)n * sizeof(mmp_place_out), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    kt_collect(c);
+    return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_place_batch_c");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_place_batch_c", e.what());
+}
+
 int mmp_place_batch(mmp_ctx *c, const mmp_place_req *reqs, int32_t n, const int32_t *extra_pool, int32_t n_extra,
                     int64_t now, mmp_place_out *outs)
 try {
@@ -3533,7 +3678,7 @@ try {
             if (rc != MMP_OK) return rc;
         }
         const auto t2 = std::chrono::steady_clock::now();
-        HIP_TRY(c, slot_wait(f));
+        HIP_TRY(c, slot_wait(f, f->seq.load(std::memory_order_relaxed)));
         memcpy(outs, f->outs, (size_t)n * sizeof(mmp_place_out));
         if (trace) {
             static thread_local double acc[3] = {0, 0, 0};
@@ -3636,7 +3781,7 @@ try {
             hipLaunchKernelGGL(serve_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, f->stream, A);
             HIP_TRY(c, hipGetLastError());
         }
-        HIP_TRY(c, slot_wait(f));
+        HIP_TRY(c, slot_wait(f, f->seq.load(std::memory_order_relaxed)));
         memcpy(outs, f->outs, (size_t)n * sizeof(mmp_serve_out));
         return MMP_OK;
     }
@@ -3747,7 +3892,7 @@ try {
             hipLaunchKernelGGL(gate_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, f->stream, A);
             HIP_TRY(c, hipGetLastError());
         }
-        HIP_TRY(c, slot_wait(f));
+        HIP_TRY(c, slot_wait(f, f->seq.load(std::memory_order_relaxed)));
         memcpy(outs, f->outs, (size_t)n * sizeof(mmp_gate_out));
         return MMP_OK;
     }
@@ -3856,7 +4001,7 @@ try {
             if (rc != MMP_OK) return rc;
         }
     }
-    HIP_TRY(c, slot_wait(f));
+    HIP_TRY(c, slot_wait(f, f->seq.load(std::memory_order_relaxed)));
     memcpy(pouts, obase, (size_t)n * sizeof(mmp_place_out));
     memcpy(gouts, obase + kMissGoutOff, (size_t)n * sizeof(mmp_gate_out));
     return MMP_OK;
@@ -3910,6 +4055,7 @@ try {
         {
             std::shared_lock<std::shared_mutex> g(c->mu);  // capture the published snapshot + enqueue
             if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+            if (c->n_shards > 0) return fail(c, MMP_ESTATE, "context is a pod-axis shard");
             GateArgs G = gate_args(c, n, now, in_use_expiry);
             G.reqs = reinterpret_cast<const mmp_gate_req *>(base);
             G.excl_pod = pool;
@@ -3942,7 +4088,7 @@ try {
                 hipLaunchKernelGGL(route_batch_kernel, dim3(div_up(n, 256)), dim3(256), 0, f->stream, G, S);
             HIP_TRY(c, hipGetLastError());
         }
-        HIP_TRY(c, slot_wait(f));
+        HIP_TRY(c, slot_wait(f, f->seq.load(std::memory_order_relaxed)));
         memcpy(gouts, obase, (size_t)n * sizeof(mmp_gate_out));
         memcpy(souts, obase + kRouteSoutOff, (size_t)n * sizeof(mmp_serve_out));
         return MMP_OK;
@@ -4665,7 +4811,7 @@ try {
             evict_launch(c, A, n, f->stream);
             HIP_TRY(c, hipGetLastError());
         }
-        HIP_TRY(c, slot_wait(f));
+        HIP_TRY(c, slot_wait(f, f->seq.load(std::memory_order_relaxed)));
         memcpy(outs, f->outs, (size_t)n * sizeof(mmp_evict_out));
         return MMP_OK;
     }

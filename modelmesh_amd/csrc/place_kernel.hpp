@@ -158,7 +158,38 @@ struct PlaceArgs {
     // more than one workgroup is an argument of place_batch_flag_kernel, not part of this block.
     uint32_t *done_flag;
     uint32_t done_seq;
+    int32_t extra_bound;  // bounded calls: 1 + the entries of `extra` the caller declared; 0: not declared, requests are followed as they are
 };
+
+// The request of decision d.  FORM kReq64: an mmp_place_req row.  kReqC: the single-caller form — an mmp_place_req_c row (24 B) and
+// the caller's side from the kernel's arguments (wave-uniform: the caller's position, remaining space and every test on them are
+// scalar work then).
+enum { kReq64 = 0, kReqC = 1 };
+template <int FORM>
+__device__ __forceinline__ mmp_place_req fetch_req(const PlaceArgs &A, const mmp_place_caller &C, int d)
+{
+    if (FORM == kReq64) return A.reqs[d];
+    const mmp_place_req_c q = reinterpret_cast<const mmp_place_req_c *>(A.reqs)[d];
+    mmp_place_req r;
+    r.model = q.model;
+    r.self_pod = C.self_pod;
+    r.flags = C.flags;
+    r.pick = q.pick;
+    r.last_used = q.last_used;
+    r.extra_off = q.extra_off;
+    r.n_extra = q.n_extra;
+    r.fresh_lru = C.fresh_lru;
+    r.fresh_capacity = C.fresh_capacity;
+    r.fresh_used = C.fresh_used;
+    r.fresh_count = C.fresh_count;
+    r.fresh_rpm = C.fresh_rpm;
+    return r;
+}
+// a request whose exclusion range leaves the pool the caller declared (PlaceArgs::extra_bound != 0)
+__device__ __forceinline__ bool bad_extra_range(const PlaceArgs &A, const mmp_place_req &rq)
+{
+    return rq.n_extra < 0 || (rq.n_extra > 0 && (rq.extra_off < 0 || (int64_t)rq.extra_off + rq.n_extra > (int64_t)A.extra_bound - 1));
+}
 
 // (int)(double) with Java narrowing semantics
 __device__ __forceinline__ int32_t jd2i(double d)
@@ -744,10 +775,10 @@ __device__ __forceinline__ int32_t pod_view_pos(const Snap &S, int32_t pod, int3
 template <bool VIEW, bool LATE = false>
 __device__ __forceinline__ ResolvedReq resolve_req(const Snap &S, const PlaceArgs &A, const mmp_place_req &rq);
 
-template <bool VIEW, bool LATE = false>
-__device__ __forceinline__ ResolvedReq resolve_one(const Snap &S, const PlaceArgs &A, int d)
+template <bool VIEW, bool LATE = false, int FORM = kReq64>
+__device__ __forceinline__ ResolvedReq resolve_one(const Snap &S, const PlaceArgs &A, int d, const mmp_place_caller &C = mmp_place_caller{})
 {
-    const mmp_place_req rq = A.reqs[d];
+    const mmp_place_req rq = fetch_req<FORM>(A, C, d);
     return resolve_req<VIEW, LATE>(S, A, rq);
 }
 
@@ -1252,10 +1283,11 @@ __device__ __forceinline__ int lane_case_b(const Snap &S, const ResolvedReq &r, 
 template <bool VIEW, bool LONG = false>
 __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, mmp_place_out &o, const BLds Bt = BLds{});
 
-template <bool VIEW, bool LONG = false>
-__device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, int d, mmp_place_out &o, const BLds Bt = BLds{})
+template <bool VIEW, bool LONG = false, int FORM = kReq64>
+__device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, int d, mmp_place_out &o, const BLds Bt = BLds{},
+                                           const mmp_place_caller &C = mmp_place_caller{})
 {
-    const ResolvedReq r = resolve_one<VIEW>(S, A, d);
+    const ResolvedReq r = resolve_one<VIEW, false, FORM>(S, A, d, C);
     return lane_decide_r<VIEW, LONG>(S, A, r, o, Bt);
 }
 
@@ -1836,12 +1868,14 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
     return kLaneDone;
 }
 
-__device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int d, uint64_t *ew, uint64_t *fw)
+template <int FORM = kReq64>
+__device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int d, uint64_t *ew, uint64_t *fw,
+                                          const mmp_place_caller &C = mmp_place_caller{})
 {
     const int lane = lane_id();
     const int P = S.P, W = S.W;
     mmp_place_out *out = &A.outs[d];
-    const mmp_place_req rq = A.reqs[d];
+    const mmp_place_req rq = fetch_req<FORM>(A, C, d);
     if (rq.model < 0 || rq.model >= A.n_models) {
         write_out(out, MMP_NONE, -1, 0, 0);
         return;
@@ -2131,9 +2165,9 @@ constexpr int kPlaceLaneLds = kWinLdsBytes + kLaneScratchBytes;  // the most the
 constexpr int kPlaceStaticLds = 2 * kPlaceBlock * 4 + 64 + 256;                // the lists (+ place_single_kernel's request)
 // bytes of the long path's per-type tables when they are staged in LDS: elig + pref ([T][W] words each), pc + nz ([2][T][W + 1] ints each)
 __host__ __device__ constexpr size_t long_tables_bytes(int T, int W) { return (size_t)T * W * 16 + (size_t)4 * T * (W + 1) * 4; }
-template <bool WITH_LONG>
+template <bool WITH_LONG, int FORM = kReq64>
 __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, int32_t wpad, unsigned char *smem,
-                                            uint32_t *done_blocks = nullptr)
+                                            uint32_t *done_blocks = nullptr, const mmp_place_caller &C = mmp_place_caller{})
 {
     __shared__ int32_t fb_list[kPlaceBlock], lr_list[kPlaceBlock];
     __shared__ int32_t fb_n, lr_n;
@@ -2166,7 +2200,20 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
     // return in order, so the LDS-bound copies issued before it have landed when it has; and nothing issued AFTER the
     // barrier (the model row, the caller's position, the late-bound exclusions) has to be drained for it.
     mmp_place_req rq{};
-    if (d < A.n) rq = A.reqs[d];
+    if (d < A.n) rq = fetch_req<FORM>(A, C, d);
+    // bounded calls: a request whose exclusions lie outside the declared pool is answered here and takes no further part
+    bool live = d < A.n;
+    if (A.extra_bound != 0) {  // (wave-uniform)
+        if (live && bad_extra_range(A, rq)) {
+            live = false;
+            mmp_place_out bo;
+            bo.chosen = MMP_NONE;
+            bo.best = MMP_BAD_REQUEST;
+            bo.n_candidates = 0;
+            bo.hash = 0;
+            A.outs[d] = bo;
+        }
+    }
     // The long path on a full cluster reads, per decision, ~57 words of tables every decision shares — the type's eligibility /
     // preference rows (the scans), the prefix counts (8 binary-search steps), the next-non-empty-word rows: 20 KB on C3.  Staged
     // here (beside the request fetch, before the barrier) for launches that fill the chip, where they relieve L2 (-5 % at 800k;
@@ -2203,9 +2250,9 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     ResolvedReq r;
-    if (d < A.n) r = resolve_req<false, true>(S, A, rq);
+    if (live) r = resolve_req<false, true>(S, A, rq);
     PHASE(0);  // request + model row resolved
-    if (d < A.n) {
+    if (live) {
         mmp_place_out o;
         int code = kLaneHeadMiss;
         if (WITH_LONG && A.long_first) {  // (wave-uniform) a full cluster: nearly every decision would end in the long phase anyway
@@ -2235,7 +2282,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
         if ((int)threadIdx.x < nlr) {
             const int ld = lr_list[threadIdx.x];
             mmp_place_out o;
-            if (lane_decide<false, true>(Sl, A, ld, o, Bt) != kLaneDone)
+            if (lane_decide<false, true, FORM>(Sl, A, ld, o, Bt, C) != kLaneDone)
                 fb_list[atomicAdd(&fb_n, 1)] = ld;
             else
                 A.outs[ld] = o;
@@ -2249,7 +2296,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
         uint64_t *fw = ew + wpad;
         for (int i = wave; i < nfb; i += kPlaceWaves) {
             const int fd = __builtin_amdgcn_readfirstlane(fb_list[i]);
-            place_one(S, A, fd, ew, fw);
+            place_one<FORM>(S, A, fd, ew, fw, C);
             wave_sync();
             PHASE_COUNT(12, 1);  // decisions the wave path took
         }
@@ -2284,6 +2331,25 @@ __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(4, 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     place_block<true>(S, A, wpad, smem);
+}
+
+// The single-caller form (mmp_place_batch_c): the same three kernels on 24-byte request rows, the caller's side in the arguments
+__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void place_batch_c_kernel(Snap S, PlaceArgs A, int32_t wpad,
+                                                                                                            mmp_place_caller C)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    place_block<false, kReqC>(S, A, wpad, smem, nullptr, C);
+}
+__global__ __launch_bounds__(kPlaceBlock) void place_batch_long_c_kernel(Snap S, PlaceArgs A, int32_t wpad, mmp_place_caller C)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    place_block<true, kReqC>(S, A, wpad, smem, nullptr, C);
+}
+__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void place_batch_long4_c_kernel(Snap S, PlaceArgs A, int32_t wpad,
+                                                                                                                  mmp_place_caller C)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    place_block<true, kReqC>(S, A, wpad, smem, nullptr, C);
 }
 
 // The latency path's launches of more than one workgroup: done_blocks = device counter of finished

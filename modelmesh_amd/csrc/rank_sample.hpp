@@ -29,7 +29,11 @@ __global__ __launch_bounds__(256) void sample_gather_kernel(const mmp_pod_row *_
     if (i <= S) hist[i * kCtrStride] = cur[i * kCtrStride] = 0;
 }
 
-// one workgroup per sample, one LANE per pair: its rank among the samples = how many sort before it; written in place
+// one workgroup per sample, one LANE per pair: its rank among the samples = how many sort before it; written in place.
+// Two samples that compare equal (rows with one id_order and every other field the same: the table is not strictly ordered) are
+// told apart by their sample index, so that every slot of `split` is written exactly once — the splitters stay sorted, the equal
+// rows land in one range, and the scatter's occupancy check reports them (MMP_EORDER) instead of a stale splitter from an earlier
+// commit deciding where rows go.
 __global__ __launch_bounds__(256) void sample_sort_kernel(const RankRow *__restrict__ srows, int32_t S, int64_t churn2, RankRow *__restrict__ split)
 {
     __shared__ int32_t s_cnt;
@@ -37,7 +41,10 @@ __global__ __launch_bounds__(256) void sample_sort_kernel(const RankRow *__restr
     __syncthreads();
     const RankRow me = srows[blockIdx.x];
     int32_t c = 0;
-    for (int j = threadIdx.x; j < S; j += 256) c += placement_less(srows[j], me, churn2) ? 1 : 0;
+    for (int j = threadIdx.x; j < S; j += 256) {
+        const RankRow o = srows[j];
+        c += (placement_less(o, me, churn2) || (j < (int)blockIdx.x && !placement_less(me, o, churn2))) ? 1 : 0;
+    }
     c = wave_sum_i32(c);
     if (lane_id() == 0 && c) atomicAdd(&s_cnt, c);
     __syncthreads();

@@ -334,6 +334,29 @@ class Solver:
         self._ck(self.lib.mmp_place_batch_dev(self.h, C.c_void_p(d_reqs), int(n), C.c_void_p(d_extra or None),
                                               int(now), C.c_void_p(d_outs), C.c_void_p(stream or None)))
 
+    def place_dev2(self, d_reqs: int, n: int, d_extra: int, n_extra_pool: int, now: int, d_outs: int, stream: int = 0):
+        """place_dev with the pool's length: requests whose exclusion range leaves it are answered MMP_BAD_REQUEST, not followed."""
+        self._ck(self.lib.mmp_place_batch_dev2(self.h, C.c_void_p(d_reqs), int(n), C.c_void_p(d_extra or None), int(n_extra_pool),
+                                               int(now), C.c_void_p(d_outs), C.c_void_p(stream or None)))
+
+    def place_c(self, caller, reqs_c, extra_pool: Optional[np.ndarray], now: int) -> np.ndarray:
+        """The single-caller form (mmp_place_batch_c): caller = 1 PLACE_CALLER row, reqs_c = PLACE_REQ_C rows."""
+        from ._lib import PLACE_CALLER, PLACE_REQ_C
+        caller = np.ascontiguousarray(caller, dtype=PLACE_CALLER).reshape(1)
+        reqs_c = np.ascontiguousarray(reqs_c, dtype=PLACE_REQ_C)
+        extra = np.zeros(0, np.int32) if extra_pool is None else np.ascontiguousarray(extra_pool, dtype=np.int32)
+        outs = np.zeros(len(reqs_c), dtype=PLACE_OUT)
+        self._ck(self.lib.mmp_place_batch_c(self.h, ptr(caller), ptr(reqs_c) if len(reqs_c) else None, len(reqs_c),
+                                            ptr(extra) if len(extra) else None, len(extra), int(now), ptr(outs) if len(reqs_c) else None))
+        return outs
+
+    def place_c_dev(self, caller, d_reqs: int, n: int, d_extra: int, n_extra_pool: int, now: int, d_outs: int, stream: int = 0):
+        """The single-caller form on raw device pointers (24-byte rows), no sync; `caller` is a host PLACE_CALLER row."""
+        from ._lib import PLACE_CALLER
+        caller = np.ascontiguousarray(caller, dtype=PLACE_CALLER).reshape(1)
+        self._ck(self.lib.mmp_place_batch_c_dev(self.h, ptr(caller), C.c_void_p(d_reqs), int(n), C.c_void_p(d_extra or None),
+                                                int(n_extra_pool), int(now), C.c_void_p(d_outs), C.c_void_p(stream or None)))
+
     def place_multi_dev(self, d_reqs, ns, d_extras, now: int, d_outs, stream: int = 0):
         """Several request arrays (raw device pointers), ONE launch, no sync: the same as place_dev per array."""
         k = len(d_reqs)

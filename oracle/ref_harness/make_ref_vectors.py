@@ -141,6 +141,15 @@ def main():
         print(f"{name}: {len(order)} instances in clusterState, {len(reqs)} decisions: "
               f"{int((place[:, 0] >= 0).sum())} remote, {int((place[:, 0] == -2).sum())} self, {int((place[:, 0] == -1).sum())} none; "
               f"mean shortlist {place[:, 1].mean():.1f}")
+    for name, fleet, ids, reqs, extra in rf.caller_place_cases():
+        blob = rf.input_blob(fleet, ids, reqs, extra)
+        order, place, _, _ = run(blob, len(reqs), 0)
+        out[f"{name}/order"], out[f"{name}/place"] = order, place
+        out[f"{name}/digest"] = np.frombuffer(rf.digest(blob).encode(), np.uint8)
+        names.append(name)
+        print(f"{name}: one caller (instance {int(reqs['self_pod'][0])}), {len(reqs)} decisions: "
+              f"{int((place[:, 0] >= 0).sum())} remote, {int((place[:, 0] == -2).sum())} self, {int((place[:, 0] == -1).sum())} none; "
+              f"mean shortlist {place[:, 1].mean():.1f}")
     for name, fleet, ids, reqs, in_use, last_used, xp, xt in rf.serve_cases():
         blob = rf.input_blob(fleet, ids, serve=(reqs, in_use, last_used, xp, xt))
         _, _, serve, _ = run(blob, 0, len(reqs))

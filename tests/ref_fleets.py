@@ -74,6 +74,37 @@ def place_cases():
     yield from big_place_cases()
 
 
+def caller_place_cases():
+    """(name, fleet, ids, reqs, extra): batches issued by ONE instance — every request of a batch carries the same self /
+    favourSelf / getFreshInstanceRecord() (MM.java:5369-5386), as the batches of the rate task, the janitor, the reaper and
+    preShutdown do.  The harness decides them as ordinary getNext calls; the device in the single-caller form
+    (mmp_place_batch_c: 24-byte rows, tests/test_ref_vectors_gpu.py)."""
+    for k, (seed, profile, pods) in enumerate(((3, None, 200), (5, "full", 700), (8, "prefer", 300), (12, "full", 5000), (14, None, 65))):
+        fleet = wl.fuzz_fleet(seed, pods=pods, profile=profile)
+        ids = string_ids(fleet, 200 + k)
+        rng = np.random.default_rng(900 + k)
+        for j in range(3):
+            reqs, extra = wl.fuzz_requests(fleet, 70 * k + j, 3000)
+            sp = -1 if (k + j) % 5 == 4 else int(rng.integers(0, pods))
+            row = fleet.pods[max(sp, 0)]
+            reqs["self_pod"], reqs["flags"] = sp, (j == 1)
+            reqs["fresh_lru"] = row["lru_time"] if j != 2 else fleet.now - 130_000
+            reqs["fresh_capacity"] = row["capacity"]
+            reqs["fresh_used"] = row["used"] if j == 0 else int(row["capacity"] * [0.2, 0.8, 0.99][(k + j) % 3])
+            reqs["fresh_count"] = int(row["count"]) + j
+            reqs["fresh_rpm"] = 0 if j < 2 else 120
+            yield f"caller_{k}_{j}", fleet, ids, reqs, extra
+    fleet = wl.make_full_cluster(wl.make_fleet("C3"))
+    ids = string_ids(fleet, 14)
+    reqs, extra = wl.make_requests(fleet, seed=0xBE7C1)
+    reqs = wl.sample_requests(reqs, 4000, 5)
+    row = fleet.pods[4321]
+    reqs["self_pod"], reqs["flags"] = 4321, 0
+    reqs["fresh_lru"], reqs["fresh_capacity"], reqs["fresh_used"] = row["lru_time"], row["capacity"], row["used"]
+    reqs["fresh_count"], reqs["fresh_rpm"] = row["count"], 0
+    yield "caller_C3_full_cluster", fleet, ids, reqs, extra
+
+
 def big_place_cases():
     """The configurations the bench quotes (BASELINE.json configs[2], [3]) and the two regimes with paths of their own on the
     device: the whole 10k / 50k-instance order and a seeded sample of the one-decision-per-model batch.  C3 as it is (window
@@ -373,6 +404,9 @@ def scaledown_edge_cases():
     for k, (self_flags, last_check_ago) in enumerate(((2, 500), (1, 7_000), (4, 7_000))):
         fleet, rng = _rebalance_fleet(4, 300, 600, 0.99)
         fleet.pods["flags"][0] = self_flags
+        if k:  # without type constraints instanceSetStats() stays the cluster's when this instance is not in clusterState (:1446-1448)
+            fleet.n_types, fleet.allowed, fleet.prefer, fleet.has_allowed, fleet.has_prefer = 0, None, None, None, None
+            fleet.models["type"] = 0
         fleet.ent_time[:] = fleet.now - 90_000_000
         entries = _local_entries(fleet, rng, 800)
         entries["last_heavy_time"] = 0

@@ -28,7 +28,7 @@ def test_header_symbols_are_all_exported_and_typed():
     lib = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/mmplace.h but not exported"
-    assert _lib.load().mmp_abi_version() == 2  # 2: mmp_serve_req carries its own counters (round 3)
+    assert _lib.load().mmp_abi_version() == 3  # 3: latency-based rebalancers, single-caller requests, bounded device calls (round 5)
 
 
 def test_struct_layouts_match_the_header():

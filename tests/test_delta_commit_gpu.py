@@ -84,3 +84,54 @@ def test_insertion_rerank_equals_ranking_from_scratch(monkeypatch, seed, pods, m
     finally:
         full.close()
         ins.close()
+
+
+@pytest.mark.parametrize("pods", [64, 9000])
+def test_a_changed_row_that_ties_is_refused_by_both_paths(monkeypatch, pods):
+    """A republished row that now compares EQUAL to another row (the same id_order, every other field the same: a duplicate or
+    unset id) is not a strict order.  Ranking from scratch reports it (MMP_EORDER, two rows of one rank); the insertion path
+    must not publish it either — it sends the commit down the full path — and the commits after the row is repaired agree again."""
+    fleet = wl.fuzz_fleet(7, pods=pods, models=100)
+    fleet.pods["version"] = 7
+    monkeypatch.setenv("MMP_NO_DELTA", "1")
+    full = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    monkeypatch.delenv("MMP_NO_DELTA")
+    ins = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        full.load_fleet(fleet)
+        ins.load_fleet(fleet)
+        present = np.nonzero((fleet.pods["flags"] & (_lib.POD_SHUTTING_DOWN | _lib.POD_TOMBSTONE)) == 0)[0]
+        a, b, c3 = (int(x) for x in present[[3, len(present) // 2, len(present) - 2]])
+        for s in (full, ins):  # a first small change: the insertion path is warm (its host mirror of the order exists)
+            row = fleet.pods[[a]].copy()
+            row["rpm"] += 1
+            s.upsert_pods(np.array([a], np.int32), row)
+            s.commit()
+        assert ins.delta_commits() == 1 and np.array_equal(full.order(), ins.order())
+        # (1) a changed row ties with an UNCHANGED one; (2) two changed rows tie with each other
+        for idx, src in ((np.array([a], np.int32), fleet.pods[[b]].copy()),
+                         (np.array([a, c3], np.int32), fleet.pods[[b, b]].copy())):
+            if len(idx) == 2:
+                src["rpm"] += 7  # equal to each other, different from row b
+            codes = []
+            for s in (full, ins):
+                s.upsert_pods(idx, src)
+                with pytest.raises(Exception) as ei:
+                    s.commit()
+                codes.append(getattr(ei.value, "code", None))
+            assert codes[0] == codes[1] == _lib.MMP_EORDER, codes
+        # repaired: both publish the same order again, and the insertion path is in use again afterwards
+        for s in (full, ins):
+            s.upsert_pods(np.array([a, c3], np.int32), fleet.pods[[a, c3]].copy())
+            s.commit()
+        assert np.array_equal(full.order(), ins.order())
+        n0 = ins.delta_commits()
+        for s in (full, ins):
+            row = fleet.pods[[b]].copy()
+            row["count"] += 1
+            s.upsert_pods(np.array([b], np.int32), row)
+            s.commit()
+        assert np.array_equal(full.order(), ins.order()) and ins.delta_commits() == n0 + 1
+    finally:
+        full.close()
+        ins.close()

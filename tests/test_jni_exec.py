@@ -21,7 +21,7 @@ def veneer(tmp_path_factory):
 
 
 def test_abi_version_and_min_space_units_through_the_veneer(veneer):
-    assert veneer.call("abiVersion") == 2
+    assert veneer.call("abiVersion") == 3
     # MM.java:765-771: max(defaultModelSizeUnits * loadingThreads * 2, capacity / 20) unless there is no unload manager
     assert veneer.call("minSpaceUnits", 128, 8, 1_000_000, 1) == _lib.load().mmp_min_space_units(128, 8, 1_000_000, 1)
 

@@ -69,6 +69,18 @@ def test_placement_order_and_load_targets_equal_the_reference_text(ref):
     assert ref["C3_full_cluster/place"][:, 1].max() == 10_000  # whole-table shortlists under the reference's own text
 
 
+def test_single_caller_batches_equal_the_reference_text(ref):
+    """Batches of ONE calling instance (tests/ref_fleets.py:caller_place_cases) under the reference's getNext text; the device
+    decides the same vectors in the single-caller form (tests/test_ref_vectors_gpu.py)."""
+    n = 0
+    for name, fleet, ids, reqs, extra in rf.caller_place_cases():
+        assert rf.digest(rf.input_blob(fleet, ids, reqs, extra)) == bytes(ref[f"{name}/digest"]).decode(), name
+        got = OracleFleet(fleet).place(reqs, extra, fleet.now, threads=4)
+        check_place(name, fleet, reqs, got, ref[f"{name}/place"])
+        n += len(reqs)
+    assert n >= 45_000
+
+
 def test_serve_targets_equal_the_reference_text(ref):
     for name, fleet, ids, reqs, in_use, last_used, xp, xt in rf.serve_cases():
         assert rf.digest(rf.input_blob(fleet, ids, serve=(reqs, in_use, last_used, xp, xt))) == bytes(ref[f"{name}/digest"]).decode()

@@ -35,6 +35,28 @@ def test_hip_order_and_load_targets_equal_the_reference_text(ref):
     assert n_dec >= 100_000
 
 
+@pytest.mark.parametrize("env", [{}, {"MMP_LONG_MODE": "1"}, {"MMP_FORCE_WAVE": "1"}], ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()) or "default")
+def test_hip_single_caller_form_equals_the_reference_text(ref, env, monkeypatch):
+    """mmp_place_batch_c (the caller's side once per call, 24-byte requests) on the batches of ONE calling instance the
+    reference's own getNext text decided — through the kernels the library picks, the prefix-table kernels forced on, and the
+    wave path alone."""
+    from modelmesh_amd._lib import split_caller
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name, fleet, ids, reqs, extra in rf.caller_place_cases():
+        want = ref[f"{name}/place"]
+        if "MMP_FORCE_WAVE" in env and name == "caller_C3_full_cluster":
+            reqs, want = reqs[:1100], want[:1100]
+        caller, rc = split_caller(reqs)
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        try:
+            s.load_fleet(fleet)
+            got = s.place_c(caller, rc, extra, fleet.now)
+        finally:
+            s.close()
+        check_place(name, fleet, reqs, got, want)
+
+
 @pytest.mark.parametrize("env", [{"MMP_LONG_MODE": "1"}, {"MMP_LONG_MODE": "0"}, {"MMP_NO_CASEB": "1"}, {"MMP_NO_LONG_LDS": "1"},
                                  {"MMP_FORCE_WAVE": "1"}], ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_every_device_path_equals_the_reference_text_on_the_bench_configurations(ref, env, monkeypatch):
