@@ -79,12 +79,13 @@ struct DevBuf {
 // device storage of one committed snapshot
 struct SnapBufs {
     DevBuf pods, lru, rem, cnt, rpm, orig, pos_of, elig, elig_nors, pref, has_pref, fullw, ge, pc, ph, nz, heads, bslots, bpm, bwin, bsurv, bpcs;
+    DevBuf sel, rk;  // Snap::sel / ::rk
     DevBuf ctpos;  // Snap::ctpos
     uint64_t types_gen = 0;  // has_pref holds the type table of this generation
     int32_t n_bslots = 0;  // case (b) slots this snapshot has (place_kernel.hpp: BSlot), read back at commit
     void release()
     {
-        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge, &pc, &ph, &nz, &heads, &bslots, &bpm, &bwin, &bsurv, &bpcs, &ctpos})
+        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge, &pc, &ph, &nz, &heads, &bslots, &bpm, &bwin, &bsurv, &bpcs, &ctpos, &sel, &rk})
             b->release();
     }
 };
@@ -1444,6 +1445,8 @@ try {
     HIP_TRY(c, B.pc.ensure((size_t)2 * T * (W + 1) * 4));
     HIP_TRY(c, B.nz.ensure((size_t)2 * T * (W + 1) * 4));
     HIP_TRY(c, B.ph.ensure((size_t)2 * T * (W + 1) * 8));
+    HIP_TRY(c, B.sel.ensure((size_t)2 * T * W * 64 * 4));
+    HIP_TRY(c, B.rk.ensure((size_t)2 * T * W * 64 * 4));
     // rounded up to the 1 KB chunks place_block stages (rows beyond T are never read as windows)
     const size_t wins_bytes = (((size_t)std::max(T, kWinLds) * sizeof(TypeWin) + 1023) / 1024) * 1024;
     HIP_TRY(c, B.heads.ensure(wins_bytes));
@@ -1614,6 +1617,8 @@ try {
     S.nz = B.nz.as<int32_t>();
     S.ph = B.ph.as<uint64_t>();
     S.ctpos = P > 0 ? B.ctpos.as<int32_t>() : nullptr;
+    S.sel = P > 0 ? B.sel.as<int32_t>() : nullptr;
+    S.rk = P > 0 ? B.rk.as<int32_t>() : nullptr;
 
     bool next_long = c->long_mode == 1, next_full = false;
     {  // the partitions of the type constraints (host) and their uploads: inputs, like the table itself
@@ -1709,6 +1714,7 @@ try {
         L2.tstats = N.tstats.as<StatsAcc>();
         L2.nb_finish = div_up(std::max(N.n_pts, T), 64);
         hipLaunchKernelGGL(commit_level2_kernel, dim3(4 * T + L2.nb_finish), dim3(64), 0, st, L2);
+        hipLaunchKernelGGL(build_sel_kernel, dim3(2 * T * W), dim3(64), 0, st, S, B.sel.as<int32_t>(), B.rk.as<int32_t>());
         // the running minimum of the case (b) candidates' rpm, then the survivor bitmaps of the rpm rule's four limits
         hipLaunchKernelGGL(prefix_min_rpm_kernel, dim3(kBSlots), dim3(64), 0, st, S, B.bslots.as<BSlot>(), n_bslots_dev, B.bpm.as<int32_t>(),
                            (int32_t)(W * 64));

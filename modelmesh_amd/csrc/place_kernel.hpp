@@ -595,6 +595,23 @@ __global__ __launch_bounds__(64) void commit_level2_kernel(CommitL2 A)
 
 // pm[slot][p] = min rpm over the preferred eligible positions in (best0, p]; INT32_MAX before the first one.
 // One wavefront per slot, 64 positions per step.
+// sel / rk (Snap): one wavefront per 64-position word of a candidate bitmap row (variant 0: elig, 1: elig & pref), a lane per position
+__global__ __launch_bounds__(64) void build_sel_kernel(Snap S, int32_t *__restrict__ sel, int32_t *__restrict__ rk)
+{
+    const int W = S.W, T = S.T;
+    const int row = blockIdx.x / W, w = blockIdx.x - row * W;  // row = variant * T + type
+    const int type = row >= T ? row - T : row;
+    uint64_t v = S.elig[(size_t)type * W + w];
+    if (row >= T) v &= S.pref[(size_t)type * W + w];
+    const int base = S.pc[(size_t)row * (W + 1) + w];
+    const int l = lane_id();
+    const bool bit = (v >> l) & 1ull;
+    const int k = base + __popcll((unsigned long long)(v & ((1ull << l) - 1ull)));
+    const size_t r0 = (size_t)row * (size_t)W * 64;
+    rk[r0 + (size_t)w * 64 + l] = bit ? k : -1;
+    if (bit) sel[r0 + k] = w * 64 + l;
+}
+
 __global__ __launch_bounds__(64) void prefix_min_rpm_kernel(Snap S, const BSlot *__restrict__ slots, const int32_t *__restrict__ n_slots,
                                                             int32_t *__restrict__ pm, int32_t stride)
 {
@@ -1470,16 +1487,20 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
         // takes one off the count and its own term off the hash (linear, wave.hpp) — no word is rebuilt with exclusions cleared.
         const int32_t *PC = nullptr;
         const uint64_t *PH = nullptr;
+        const int32_t *SEL = nullptr, *RK = nullptr;  // the row's inverse tables (Snap::sel / ::rk)
         uint32_t xmask = 0;             // slots of sx[] that are distinct candidates inside [start, end)
         int32_t sx[kInlineExcl];        // the exclusions in ascending position order (LONG only)
-        uint64_t rv[kInlineExcl];       // per slot: the raw candidate word it falls into (0 if outside [start, end))
-        int32_t pcw[kInlineExcl];       // per slot: the prefix count in front of that word
+        int32_t rkx[kInlineExcl];       // per slot: the candidate's number in the row's numbering (pc's), -1 if it is none / outside [start, end)
         uint64_t r_lo = 0, r_hi = 0;    // the raw end words clipped to [start, end)
         int n_rlo = 0, pbase = 0;
+        int g0 = 0;                     // the number (pc's numbering) of the first candidate bit at or behind `start`
         if (LONG && is_long) {
-            const size_t tb = ((size_t)(has_pm ? 1 : 0) * S.T + type) * (size_t)(W + 1);
+            const size_t row = (size_t)(has_pm ? 1 : 0) * S.T + type;
+            const size_t tb = row * (size_t)(W + 1);
             PC = S.pc + tb;
             PH = S.ph + tb;
+            SEL = S.sel + row * (size_t)W * 64;
+            RK = S.rk + row * (size_t)W * 64;
             auto raw = [&](int w) {
                 uint64_t v = L.E[w];
                 if (has_pm) v &= Pm[w];
@@ -1487,19 +1508,20 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
             };
             sort_excl(L.ex, sx);
             // everything the corrections read is fetched here, together (the slots are independent of one another): one load
-            // latency instead of one per exclusion
+            // latency instead of one per exclusion — and ONE load per exclusion (rk) instead of its word, its preference word and
+            // its prefix count
 #pragma unroll
             for (int i = 0; i < kInlineExcl; i++) {
                 const int e = sx[i];
                 const bool in = e >= start && e < end;  // (the padding, INT32_MAX, is not)
-                rv[i] = in ? raw(e >> 6) : 0ull;
-                pcw[i] = in ? PC[e >> 6] : 0;
+                rkx[i] = in ? RK[e] : -1;
             }
             r_lo = raw(wlo) & ((~0ull) << (start & 63));                 // start lies in wlo or is the first bit of wlo + 1
             if ((start >> 6) != wlo) r_lo = 0;
             r_hi = raw(whi) & ((end & 63) ? bits_below(end) : ~0ull);    // end - 1 lies in whi
             n_rlo = __popcll((unsigned long long)r_lo);
             pbase = PC[wlo + 1];
+            g0 = pbase - n_rlo;
             ccount = 1 + n_rlo + __popcll((unsigned long long)r_hi) + (PC[whi] - pbase);
             const uint64_t m_lo = audit_mul((uint64_t)wlo);
             hsum = (m_lo << (bestpos & 63)) + r_lo * m_lo + audit_term(r_hi, (uint64_t)whi) + (PH[whi] - PH[wlo + 1]);
@@ -1507,7 +1529,7 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
             for (int i = 0; i < kInlineExcl; i++) {
                 const int e = sx[i];
                 const bool dup = i > 0 && sx[i - 1] == e;  // the same pod twice among the exclusions (tried and loaded, say)
-                const uint64_t bit = dup ? 0ull : (rv[i] >> (e & 63)) & 1ull;  // rv is 0 outside [start, end)
+                const bool bit = !dup && rkx[i] >= 0;      // rkx is -1 outside [start, end) and for a position that is no candidate
                 xmask |= (uint32_t)bit << i;
                 if (bit) hsum -= audit_mul((uint64_t)(e >> 6)) << (e & 63);
             }
@@ -1562,15 +1584,9 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
                     // from it: the best if the rpm rule nulls it, the caller's own entry if the rule nulls it, the effective
                     // exclusions.  t = the raw rank of the index-th survivor: every removed entry at or before it pushes it one
                     // further (one ascending pass).  The search over the prefix counts is then the plain one.
-                    auto rank_at = [&](uint64_t word, int pc_before, int pos) {  // raw rank of the candidate at `pos` (>= start)
-                        return 1 + n_rlo + (pc_before - pbase) + __popcll((unsigned long long)(word & bits_below(pos)));
-                    };
+                    // raw rank of a candidate at or behind `start` = its number in the row's numbering - g0 + 1 (the best is rank 0)
                     int rho_s = 0;
-                    if (null_s) {  // (self_in_c: the caller's entry is a candidate inside [start, end))
-                        uint64_t v = L.E[sw];
-                        if (has_pm) v &= Pm[sw];
-                        rho_s = rank_at(v, PC[sw], selfpos);
-                    }
+                    if (null_s) rho_s = 1 + RK[selfpos] - g0;  // (self_in_c: the caller's entry is a candidate inside [start, end))
                     bool self_pending = null_s;
                     int t = index + (null0 ? 1 : 0);
 #pragma unroll
@@ -1580,24 +1596,13 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
                             self_pending = false;
                         }
                         if ((xmask >> i) & 1u) {
-                            if (rank_at(rv[i], pcw[i], sx[i]) <= t) t++;
+                            if (1 + rkx[i] - g0 <= t) t++;
                         }
                     }
                     if (self_pending && rho_s <= t) t++;
-                    if (t == 0) {
-                        cpos = bestpos;
-                    } else if (t - 1 < n_rlo) {
-                        cpos = wlo * 64 + select_kth_bit(r_lo, t - 1);
-                    } else {
-                        const int T = t - 1 - n_rlo + pbase;  // the word: the first w in (wlo, whi) with PC[w + 1] > T, else whi
-                        const int lo = first_word_over(PC, wlo + 1, whi, T);
-                        uint64_t v = r_hi;
-                        if (lo < whi) {
-                            v = L.E[lo];
-                            if (has_pm) v &= Pm[lo];
-                        }
-                        cpos = lo * 64 + select_kth_bit(v, T - PC[lo]);
-                    }
+                    // the t-th entry of the shortlist: the best itself, or candidate number g0 + t - 1 of the row — one lookup (round 4:
+                    // a binary search over the prefix counts, eight dependent loads, and a select inside the word it found)
+                    cpos = t == 0 ? bestpos : SEL[g0 + t - 1];
                 }
             } else {
                 int running = 0;

@@ -53,6 +53,12 @@ struct Snap {
     // (non-full instances of one version stand in count order, PLACEMENT_ORDER :4676) — ctpos[kGeRows] = the end of that
     // non-decreasing head, ctpos[r] = its first position with count >= kGeBase + r (the end if none).  Null on shard views.
     const int32_t *ctpos;
+    // The inverse of pc, [2][T][W * 64] each (round 5; null on shard views): sel[k] = position of the k-th candidate bit of the
+    // row (k counted over the whole table: pc's numbering), rk[pos] = that k for a position whose bit is set, -1 otherwise.  The
+    // long path's index-th survivor is then ONE lookup instead of a binary search over pc plus a select inside the word, and an
+    // excluded candidate's place in the shortlist one lookup instead of its word, its preference word and its prefix count.
+    const int32_t *sel;
+    const int32_t *rk;
 };
 
 // count >= 10 is a fixed clause of the shortlist's count break (MM.java:4925-4926); the other clause,
