@@ -48,6 +48,11 @@ final class MmPlace {
     static native int modelsUpsert(long h, ByteBuffer idx, ByteBuffer rows, int n, ByteBuffer entPod, ByteBuffer entTime, int nEntries);
     static native int commit(long h);
     static native int placeBatch(long h, ByteBuffer reqs, int n, ByteBuffer extraPool, int nExtra, long nowMs, ByteBuffer outs);
+    /** the single-caller form: caller = one mmp_place_caller (this instance's index, favourSelf, getFreshInstanceRecord()),
+     *  reqs = n mmp_place_req_c rows of 24 bytes {model, pick, lastUsedTime, extraOff, nExtra} — what the rate task, the janitor,
+     *  the reaper and preShutdown issue: every decision of such a batch has the same self */
+    static native int placeBatchCaller(long h, ByteBuffer caller, ByteBuffer reqs, int n, ByteBuffer extraPool, int nExtra,
+                                       long nowMs, ByteBuffer outs);
     static native int serveBatch(long h, ByteBuffer reqs, int n, ByteBuffer counters, int nCounters,
                                  ByteBuffer exclPod, ByteBuffer exclTime, int nExcl, long nowMs, ByteBuffer outs);
     /** keep one wavefront resident that serves placeBatch(n = 1) from 64 pinned request slots: no launch per request */

@@ -120,6 +120,21 @@ JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_placeBatch(JNIEnv *
                  mmp_place_batch(ctx_of(h), buf<mmp_place_req>(env, reqs), n, buf<int32_t>(env, extraPool), nExtra,
                                  nowMs, buf<mmp_place_out>(env, outs)));
 }
+// the single-caller form: the caller's side (mmp_place_caller, 40 bytes) once per call, 24-byte requests — the batches of the rate
+// task, the janitor, the reaper and preShutdown, which all run on ONE instance
+JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_placeBatchCaller(JNIEnv *env, jclass, jlong h, jobject caller,
+                                                                              jobject reqs, jint n, jobject extraPool,
+                                                                              jint nExtra, jlong nowMs, jobject outs)
+{
+    if (!holds<mmp_place_caller>(env, caller, 1, "placeBatchCaller: caller shorter than one mmp_place_caller") ||
+        !holds<mmp_place_req_c>(env, reqs, n, "placeBatchCaller: reqs shorter than n requests") ||
+        !holds<int32_t>(env, extraPool, nExtra, "placeBatchCaller: extraPool shorter than nExtra entries") ||
+        !holds<mmp_place_out>(env, outs, n, "placeBatchCaller: outs shorter than n results"))
+        return MMP_EINVAL;
+    return check(env, ctx_of(h),
+                 mmp_place_batch_c(ctx_of(h), buf<mmp_place_caller>(env, caller), buf<mmp_place_req_c>(env, reqs), n,
+                                   buf<int32_t>(env, extraPool), nExtra, nowMs, buf<mmp_place_out>(env, outs)));
+}
 
 // The resident decision kernel: placeBatch(n = 1) without a kernel launch (include/mmplace.h: mmp_resident).
 JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_resident(JNIEnv *env, jclass, jlong h, jboolean enable)

@@ -241,3 +241,85 @@ def test_async_batches_on_two_virtual_shards():
     for (reqs, extra), a, b in zip(batches, results[0][0], results[1][0]):
         assert np.array_equal(a, b)
         assert_same_decisions(fleet, reqs, a, orc.place(reqs, extra, fleet.now, threads=8))
+
+
+# ---- two real PROCESSES, the in-library group, the exchange words moved by gloo (both on cuda:0) ---------------------------
+def _group_worker(rank, world, port, q):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s = None
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+
+        def fn(_user, dev_buf, count, elem64, op_min, stream):  # mmp_exchange_fn over the process group (bench.py's _gloo_exchange_callback)
+            try:
+                t = torch.empty(int(count), dtype=torch.int64 if elem64 else torch.int32)
+                nb = t.numel() * t.element_size()
+                if hip.hipStreamSynchronize(stream) != 0 or hip.hipMemcpy(t.data_ptr(), dev_buf, nb, 2) != 0:
+                    return 1
+                dist.all_reduce(t, op=dist.ReduceOp.MIN if op_min else dist.ReduceOp.SUM)
+                return 0 if hip.hipMemcpy(dev_buf, t.data_ptr(), nb, 1) == 0 else 1
+            except Exception:  # noqa: BLE001
+                return 1
+        cb = XFN(fn)
+        fleet = wl.make_fleet("C2")
+        batches = [wl.make_requests(fleet, 21), wl.make_requests(fleet, 22, n=3000)]
+        s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+        assert s.lib.mmp_shard_group_set_exchange(s.h, C.cast(cb, C.c_void_p), None) == 0
+        s.shard_group_init(None, rank, world)
+        s.load_fleet(fleet, commit=False)
+        s.shard_commit()
+        orc = OracleFleet(fleet)
+        ok = True
+        for reqs, extra in batches:
+            outs, _ = s.shard_place(reqs, extra, fleet.now)
+            want = orc.place(reqs, extra, fleet.now, threads=4)
+            ok = ok and all(np.array_equal(outs[f], want[f]) for f in ("chosen", "best", "n_candidates", "hash"))
+        # asynchronous batches too (a batch is completed by the next call / the final wait): the same control flow on both ranks
+        d_r = torch.from_numpy(np.ascontiguousarray(batches[0][0]).view(np.uint8).reshape(-1).copy()).to("cuda:0")
+        d_x = torch.from_numpy(np.ascontiguousarray(batches[0][1])).to("cuda:0")
+        d_o = torch.zeros(len(batches[0][0]) * 16, dtype=torch.uint8, device="cuda:0")
+        for _ in range(3):
+            s.shard_place_async_dev(d_r.data_ptr(), len(batches[0][0]), d_x.data_ptr(), fleet.now, d_o.data_ptr())
+        s.shard_wait()
+        from modelmesh_amd._lib import PLACE_OUT
+        got = np.frombuffer(d_o.cpu().numpy().tobytes(), dtype=PLACE_OUT)
+        want = orc.place(batches[0][0], batches[0][1], fleet.now, threads=4)
+        ok = ok and all(np.array_equal(got[f], want[f]) for f in ("chosen", "best", "n_candidates", "hash"))
+        s.shard_group_destroy()
+        q.put((rank, bool(ok)))
+    finally:
+        if s is not None:
+            s.close()
+        dist.destroy_process_group()
+
+
+def test_two_processes_in_library_group_over_gloo_on_one_gpu():
+    """The control flow of the driver's N-rank run (bench.py pod_axis_lib_leg) at world 2 on this one device: two processes,
+    each with its own context and its shard of C2's instance table, the group protocol inside the library (sharded commit,
+    speculative exchange, six-phase rest, asynchronous batches) with the exchange words moved by gloo through
+    mmp_shard_group_set_exchange — RCCL refuses two ranks on one device, so this is every line of the 2-rank path but
+    ncclAllReduce itself.  Both ranks' result rows equal the oracle."""
+    import socket
+
+    import torch.multiprocessing as mp
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_group_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, True), (1, True)]
