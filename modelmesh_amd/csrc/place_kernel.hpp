@@ -2313,7 +2313,10 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
 
 // 6 wavefronts per SIMD (80 VGPRs, 100 bytes of spill per lane) instead of the 5 the unconstrained allocation (95) gives:
 // measured -3.4 % per 800k-decision launch, -5 % per step on two streams; 7 the same, 8 (64 VGPRs) +7 %.
-__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void place_batch_kernel(Snap S, PlaceArgs A, int32_t wpad)
+#ifndef MMP_PLACE_EU
+#define MMP_PLACE_EU 6
+#endif
+__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(MMP_PLACE_EU, MMP_PLACE_EU))) void place_batch_kernel(Snap S, PlaceArgs A, int32_t wpad)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     place_block<false>(S, A, wpad, smem);
@@ -2339,7 +2342,12 @@ __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(4, 
 }
 
 // The single-caller form (mmp_place_batch_c): the same three kernels on 24-byte request rows, the caller's side in the arguments
-__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void place_batch_c_kernel(Snap S, PlaceArgs A, int32_t wpad,
+// (measured, round 5, 800k decisions of one caller per launch: 4 / 5 / 6 / 7 / 8 wavefronts per SIMD 23.7 / 21.1 / 20.5 / 19.3 / 19.7 us —
+// with a third of the request bytes a wavefront waits less for memory and one more per SIMD fills the issue slots)
+#ifndef MMP_C_WAVES
+#define MMP_C_WAVES 7
+#endif
+__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(MMP_C_WAVES, MMP_C_WAVES))) void place_batch_c_kernel(Snap S, PlaceArgs A, int32_t wpad,
                                                                                                             mmp_place_caller C)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -170,3 +170,63 @@ def test_route_miss_and_delta_commits_through_the_veneer_equal_the_c_abi(veneer)
         assert veneer.call("deltaCommits", h, nb) == 0 and int(nb.arr[0]) in (0, 1)
     finally:
         veneer.call("destroy", h)
+
+
+def test_round5_natives_through_the_veneer_equal_the_c_abi(veneer):
+    """placeBatchCaller (the single-caller form) and the latency-based rebalancers (scaleupPlanConc / scaledownPlanConc) under the
+    mock JVM give the rows the ctypes path gives — on the reference-text cases of tests/ref_fleets.py."""
+    name, fleet, ids, reqs, extra = next(iter(rf.caller_place_cases()))
+    caller, rc = _lib.split_caller(reqs)
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        want = s.place_c(caller, rc, extra, fleet.now)
+    finally:
+        s.close()
+    h = _stage(veneer, fleet)
+    try:
+        ex = np.ascontiguousarray(extra, dtype=np.int32)
+        outs = jm.ByteBuffer(np.zeros(len(rc), dtype=_lib.PLACE_OUT))
+        assert veneer.call("placeBatchCaller", h, _bb(caller), _bb(rc), len(rc), _bb(ex), len(ex), int(fleet.now), outs) == 0
+        assert veneer.env.pending() is None and np.array_equal(outs.arr, want)
+        short = jm.ByteBuffer(np.zeros(3, dtype=_lib.PLACE_OUT))  # a direct buffer shorter than n results: refused, not overrun
+        assert veneer.call("placeBatchCaller", h, _bb(caller), _bb(rc), len(rc), _bb(ex), len(ex), int(fleet.now), short) != 0
+        veneer.env.clear()
+    finally:
+        veneer.call("destroy", h)
+
+    name, fleet, ids, entries, conc, sp, cp = next(c for c in rf.scaleup_conc_cases() if c[0].endswith("_1_1"))
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        w_out, w_co, w_ov, w_sk, w_res = s.scaleup_plan_conc(entries, conc, sp, cp)
+    finally:
+        s.close()
+    h = _stage(veneer, fleet)
+    try:
+        o = jm.ByteBuffer(np.zeros(len(entries), dtype=_lib.SCALEUP_OUT))
+        co = jm.ByteBuffer(np.zeros(len(entries), dtype=_lib.CONC_OUT))
+        ov = jm.ByteBuffer(np.zeros(fleet.n_pods, np.uint8))
+        sk = jm.ByteBuffer(np.zeros(1, np.int32))
+        res = jm.ByteBuffer(np.zeros(1, dtype=_lib.CONC_RESULT))
+        assert veneer.call("scaleupPlanConc", h, _bb(entries), _bb(conc), len(entries), _bb(sp), _bb(cp), o, co, ov, sk, res) == 0
+        assert veneer.env.pending() is None
+        assert np.array_equal(o.arr, w_out) and np.array_equal(co.arr, w_co) and np.array_equal(ov.arr, w_ov)
+        assert int(sk.arr[0]) == w_sk and res.arr[0] == w_res
+    finally:
+        veneer.call("destroy", h)
+
+    name, fleet, ids, entries, conc, dp, dyn = next(iter(rf.scaledown_conc_cases()))
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        want = s.scaledown_plan_conc(entries, conc, dp, dyn)
+    finally:
+        s.close()
+    h = _stage(veneer, fleet)
+    try:
+        rem = jm.ByteBuffer(np.zeros(len(entries), np.uint8))
+        assert veneer.call("scaledownPlanConc", h, _bb(entries), _bb(conc), len(entries), _bb(dp), int(dyn), rem) == 0
+        assert veneer.env.pending() is None and np.array_equal(rem.arr, want)
+    finally:
+        veneer.call("destroy", h)
