@@ -274,7 +274,9 @@ typedef struct {
     int32_t reserved;
     int64_t loaded_time;              /* registry load time of the evicted copy, <0 if absent    */
     int64_t load_timeout_ms;
-    int64_t fresh_lru, fresh_capacity, fresh_used; /* getFreshInstanceRecord(), MM.java:5369     */
+    int64_t fresh_lru, fresh_capacity, fresh_used; /* getFreshInstanceRecord(), MM.java:5369; fresh_lru may be
+                                                      runtimeCache.oldestTime() as it is: -1 (empty cache) is read as
+                                                      Long.MAX_VALUE by the publish rule (:5423-5425)         */
     int32_t fresh_count, fresh_loading_threads, fresh_in_progress, fresh_rpm;
     int64_t last_published;           /* lastPublished, MM.java:5387                             */
 } mmp_gate_req;

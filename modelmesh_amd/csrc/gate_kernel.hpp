@@ -234,7 +234,8 @@ __device__ __forceinline__ mmp_gate_out gate_eval(const GateArgs &A, const mmp_g
             const bool have_cur = self_in && !(cur.flags & MMP_POD_TOMBSTONE);
             if (have_cur) {
                 const bool cur_sd = cur.flags & MMP_POD_SHUTTING_DOWN, sd = r.flags & MMP_GATE_FRESH_SHUTTING_DOWN;
-                const int64_t cap = r.fresh_capacity, used = r.fresh_used, oldest = r.fresh_lru;
+                // (a host may pass runtimeCache.oldestTime() as it is: -1 = the cache is empty, read as Long.MAX_VALUE, :5423-5425)
+                const int64_t cap = r.fresh_capacity, used = r.fresh_used, oldest = r.fresh_lru == -1 ? INT64_MAX : r.fresh_lru;
                 const int32_t count = r.fresh_count;
                 if (!old) {
                     const int64_t d_lru = jabs64(jsub64(cur.lru_time, oldest));

@@ -156,6 +156,7 @@ int orc_should_publish(const orc_pod *cur, const orc_pod *fresh, int64_t now, in
     int old = last_done > FREQ * 4;
     if (!cur) return fresh->shutting_down ? 0 : 1; /* :5432-5436: no record and shutting down -> return, else create it */
     int64_t cap = fresh->capacity, used = fresh->used, oldest = fresh->lru_time;
+    if (oldest == -1) oldest = INT64_MAX; /* :5423-5425: runtimeCache.oldestTime() of an empty cache */
     int32_t count = fresh->count;
     if (!old) {
         int64_t diff;

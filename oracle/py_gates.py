@@ -157,6 +157,8 @@ def should_publish(cur, fresh, now, last_published, force, pre_shutdown, min_spa
     if cur is None:
         return not shutting
     oldest, cap, used, count = fresh["lru_time"], fresh["capacity"], fresh["used"], fresh["count"]
+    if oldest == -1:                                      # :5423-5425: runtimeCache.oldestTime() of an empty cache
+        oldest = LONG_MAX
     threads, in_prog, rpms = fresh["loading_threads"], fresh["loading_in_progress"], fresh["rpm"]
 
     def is_full(avail):

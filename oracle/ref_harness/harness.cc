@@ -120,7 +120,9 @@ static const struct { Object ABORT_REQUEST = Object::abort_request(); } LoadBala
 // ---- fields of the enclosing ModelMesh instance, set per fleet / per request by main() --------------------------------
 static long minSpaceUnits, minChurnAgeMs;           // MM.java:765-771, :697
 static String instanceId;                           // MM.java:338
-static boolean sendDestinationId = false;
+// MMP_REF_SEND_DEST=1 (make_ref_vectors.py's second pass over two cases): the mesh tells the chosen instance its own id through the
+// request context (:4997-4999, :4386-4388) — a side effect behind the decision; the pass must give the same decisions
+static boolean sendDestinationId = getenv("MMP_REF_SEND_DEST") != nullptr;
 static long g_now;
 static long currentTimeMillis() { return g_now; }
 static InstanceRecord g_fresh;
@@ -686,16 +688,26 @@ enum class Status { LOADING, LOADING_FAILED, LOADED };
 struct StatusInfo { Status s; Status getStatus() const { return s; } String getErrorMessages() const { return null; } };
 struct ShutdownCacheEntry : ::CacheEntry {  // + what the loop reads (the entry's removal and abort state: the cache's business)
     long loadTimestamp = 0, loadCompleteTimestamp = 0;
-    boolean isAborted() const { return false; }
+    // MMP_REF_MIGRATION_FAULTS=1 (make_ref_vectors.py's second pass over the preShutdown cases): every third entry's load was
+    // aborted (the loop deregisters it, :7027-7030), every fourth triggered copy comes back LOADING_FAILED (:7033-7036: logged, not
+    // waited for) — outcomes of the cache and of the remote call, not inputs of the plan
+    int ordinal = 0;
+    boolean isAborted() const { return g_faults && ordinal % 3 == 0; }
+    static bool g_faults;
     using ::CacheEntry::CacheEntry;
 };
+bool ShutdownCacheEntry::g_faults = getenv("MMP_REF_MIGRATION_FAULTS") != nullptr;
 static std::map<std::string, ShutdownCacheEntry> g_cache;  // runtimeCache.getQuietly
 static const struct {
     ShutdownCacheEntry getQuietly(const String &id) const { auto it = g_cache.find(id.str()); return it == g_cache.end() ? ShutdownCacheEntry(null) : it->second; }
     long getLastUsedTime(const String &) const { return -1L; }  // (only asked when the descending map carried 0: an entry gone meanwhile)
 } runtimeCache;
 static std::vector<std::string> g_triggered;
-static StatusInfo triggerNewModelCopyElsewhere(const String &modelId, const ModelRecord &, long, int) { g_triggered.push_back(modelId.str()); return StatusInfo{Status::LOADING}; }
+static StatusInfo triggerNewModelCopyElsewhere(const String &modelId, const ModelRecord &, long, int)
+{
+    g_triggered.push_back(modelId.str());
+    return StatusInfo{ShutdownCacheEntry::g_faults && g_triggered.size() % 4 == 0 ? Status::LOADING_FAILED : Status::LOADING};
+}
 static void deregisterModelAsync(const String &, long, long, long) {}
 static Set<String> ConcurrentHashMap_newKeySet() { return Set<String>::make(); }
 static const struct {
@@ -1451,14 +1463,21 @@ int main(int argc, char **argv)
         }
         Collection<String> explicitExcludes = Collection<String>::make();
         for (int32_t k = 0; k < q.n_explicit; k++) explicitExcludes.add(ids[gexplicit[q.explicit_off + k]]);
-        try { checkLoadFailureCount(mr, null); } catch (const TException &) { bits |= MMP_GATE_FAILURES_BREACHED; }
-        try { checkLoadLocationCount(mr, explicitExcludes, null); } catch (const TException &) { bits |= MMP_GATE_LOCATIONS_BREACHED; }
+        // MMP_REF_EXC_CONTEXT=1 (make_ref_vectors.py's second pass over the guard cases): the request has ALREADY seen a load
+        // failure / an internal failure elsewhere, or is not an external request — the Java then rethrows THAT exception instead
+        // of a new one (:4019-4031, :4598-4601, :4618-4621).  Which exception flies is not part of the decision (it throws either
+        // way): the pass must give the same bits, and executes those lines.
+        static const bool exc_ctx = getenv("MMP_REF_EXC_CONTEXT") != nullptr;
+        const ModelLoadException lfs = (exc_ctx && (d % 3) != 2) ? ModelLoadException(String("seen before"), null, 0L, null) : ModelLoadException(null);
+        const TException ifs = (exc_ctx && (d % 3) != 1) ? newInternalException(String("internal failure seen before"), null) : TException(null);
+        try { checkLoadFailureCount(mr, lfs); } catch (const TException &) { bits |= MMP_GATE_FAILURES_BREACHED; }
+        try { checkLoadLocationCount(mr, explicitExcludes, ifs); } catch (const TException &) { bits |= MMP_GATE_LOCATIONS_BREACHED; }
         {   // the load-target filter of the request: loaded / failed of the record + the explicit excludes (:4706-4715)
             CacheMissExcludeSet ltf;
             for (auto &e : mr.instanceIds.keySet()) ltf.loaded.add(e);
             for (auto &e : mr.failed.keySet()) ltf.failed.add(e);
             ltf.explicit_ = explicitExcludes;
-            try { throwIfLocalLoadNotAllowed(modelId, true, mr, &ltf, null, null); } catch (const TException &) { bits |= MMP_GATE_LOCAL_NOT_ALLOWED; }
+            try { throwIfLocalLoadNotAllowed(modelId, !(exc_ctx && (d % 5) == 0), mr, &ltf, lfs, ifs); } catch (const TException &) { bits |= MMP_GATE_LOCAL_NOT_ALLOWED; }
         }
         runtimeCache.g_cap = q.cache_capacity;
         runtimeCache.g_wsize = q.cache_weighted_size;
@@ -1895,6 +1914,7 @@ int main(int argc, char **argv)
             ce.isnull = false;
             ce.failed = (x.flags & MMP_CE_FAILED) != 0;  // ce == null || ce.isFailed()
             ce.weight = x.weight;
+            ce.ordinal = (int)e;
             a21::g_cache[key] = ce;
             cache.push_back(Entry<String, Long>(String(key), Long(x.last_used)));
         }

@@ -37,11 +37,13 @@ def proactive_inputs(fleet, units, partitioned):
 
 
 def run(blob: bytes, n_place: int, n_serve: int, n_gate: int = 0, n_scale: int = -1, n_pods: int = 0, n_sd: int = -1, proactive: bool = False,
-        events: bool = False, upgrade: int = -1, types=None, migration: int = -1, conc: bool = False):
+        events: bool = False, upgrade: int = -1, types=None, migration: int = -1, conc: bool = False, env=None):
+    """env: one of the harness' CONTEXT switches (harness.cc: MMP_REF_EXC_CONTEXT, MMP_REF_SEND_DEST, MMP_REF_MIGRATION_FAULTS) for
+    a second pass over a case: state around the decision that the reference's text consults for side effects only."""
     with tempfile.TemporaryDirectory() as td:
         fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
         open(fin, "wb").write(blob)
-        subprocess.run([HARNESS, fin, fout], check=True)
+        subprocess.run([HARNESS, fin, fout], check=True, env=dict(os.environ, **env) if env else None)
         raw = open(fout, "rb").read()
     n_present = int(np.frombuffer(raw, "<i8", 1)[0])
     off = 8
@@ -135,6 +137,9 @@ def main():
     for name, fleet, ids, reqs, extra in rf.place_cases():
         blob = rf.input_blob(fleet, ids, reqs, extra)
         order, place, _, _ = run(blob, len(reqs), 0)
+        if name in ("fuzz_None_3", "fuzz_prefer_5"):  # the same decisions with the destination id sent along (:4997-4999)
+            o2, p2, _, _ = run(blob, len(reqs), 0, env={"MMP_REF_SEND_DEST": "1"})
+            assert np.array_equal(o2, order) and np.array_equal(p2, place), name
         out[f"{name}/order"], out[f"{name}/place"] = order, place
         out[f"{name}/digest"] = np.frombuffer(rf.digest(blob).encode(), np.uint8)
         names.append(name)
@@ -153,6 +158,8 @@ def main():
     for name, fleet, ids, reqs, in_use, last_used, xp, xt in rf.serve_cases():
         blob = rf.input_blob(fleet, ids, serve=(reqs, in_use, last_used, xp, xt))
         _, _, serve, _ = run(blob, 0, len(reqs))
+        if name.endswith("_0"):  # ... and the serve target's (:4386-4388)
+            assert np.array_equal(run(blob, 0, len(reqs), env={"MMP_REF_SEND_DEST": "1"})[2], serve), name
         out[f"{name}/serve"] = serve
         out[f"{name}/digest"] = np.frombuffer(rf.digest(blob).encode(), np.uint8)
         names.append(name)
@@ -162,6 +169,9 @@ def main():
         tstats = np.ascontiguousarray(ob.type_set_stats(fleet))  # an INPUT of the guards (rows a5 / a18 are pinned separately)
         blob = rf.input_blob(fleet, ids, gates=(reqs, xp, xt, expl, expiry, tstats))
         _, _, _, gate = run(blob, 0, 0, len(reqs))
+        # which exception flies when a guard refuses (one seen earlier in the request, or a new one: :4019-4031, :4598-4601,
+        # :4618-4621) is not part of the decision: the same bits with failures "seen before" and for internal requests
+        assert np.array_equal(run(blob, 0, 0, len(reqs), env={"MMP_REF_EXC_CONTEXT": "1"})[3], gate), name
         out[f"{name}/gate"] = gate
         out[f"{name}/digest"] = np.frombuffer(rf.digest(blob).encode(), np.uint8)
         names.append(name)
@@ -262,6 +272,10 @@ def main():
     for name, fleet, ids, entries, self_pod, now in rf.migration_cases():
         blob = rf.input_blob(fleet, ids, migration=(entries, self_pod, now))
         bits = run(blob, 0, 0, migration=len(entries))
+        # aborted loads (deregistered at once, :7027-7030) and copies that fail to load elsewhere (:7033-7036): the same copies
+        # are triggered; the shutdown does not wait for a copy that failed
+        b2 = run(blob, 0, 0, migration=len(entries), env={"MMP_REF_MIGRATION_FAULTS": "1"})
+        assert np.array_equal(b2 & 1, bits & 1) and np.all((b2 >> 1) <= (bits >> 1)) and (b2 >> 1).sum() < (bits >> 1).sum(), name
         out[f"{name}/migration"] = bits
         out[f"{name}/digest"] = np.frombuffer(rf.digest(blob).encode(), np.uint8)
         names.append(name)

@@ -225,6 +225,7 @@ def gate_cases():
         cur = fleet.pods[r["self_pod"]]
         near = rng.random(n) < 0.6
         r["fresh_lru"] = np.where(near, cur["lru_time"], cur["lru_time"] - rng.choice([0, 10_000, 30_000], n))
+        r["fresh_lru"] = np.where(rng.random(n) < 0.04, -1, r["fresh_lru"])  # an empty cache: oldestTime() == -1, read as Long.MAX_VALUE (:5423-5425)
         r["fresh_capacity"] = np.where(near, cur["capacity"], cur["capacity"] - rng.choice([0, 100, 50_000], n))
         r["fresh_used"] = np.where(near, cur["used"], (cur["used"] * rng.choice([1.0, 1.1, 1.3], n)).astype(np.int64))
         r["fresh_count"] = cur["count"] + rng.choice([0, 0, 1, 2, 10], n)
