@@ -56,4 +56,5 @@ PY
   echo
   echo "# never executed (body:line-in-body: text)"
   grep -E '^\s+#####:' *.inc.gcov | sed -E 's/\.inc\.gcov:\s+#####:\s*([0-9]+):\s*/:\1: /' | cut -c1-160
+  cat "$root/tools/ref_coverage_residual.txt"
 } > "$out"
