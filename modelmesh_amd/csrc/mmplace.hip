@@ -186,6 +186,8 @@ struct mmp_ctx {
     std::atomic<size_t> lds_granted{48 * 1024};  // dynamic LDS the place kernels may be launched with so far
     int32_t no_caseb = 0;    // MMP_NO_CASEB=1: case (b) decisions never use the whole-window tables (tests: the wave path decides them)
     int32_t cfg_plan_sorted = 0;  // MMP_PLAN_SORTED=1: mmp_proactive_plan takes its sorted (fallback) path on every input; 2: never (tests)
+    int32_t cfg_plan_fused = 1;   // MMP_PLAN_FUSED=0: the plan as its eight dependent launches (comparison; the one-launch form is the default)
+    int32_t plan_grid_max = 0;    // workgroups the one-launch plan may have: all of them resident at once
     int32_t no_long_lds = 0; // MMP_NO_LONG_LDS=1: the long path reads its per-type tables from global memory (tests, comparison)
     int32_t no_heads = 0;    // MMP_NO_HEADS=1: decisions do not use the per-type head windows (tests: lane_decide_r alone)
 
@@ -635,6 +637,19 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     if (const char *nd = getenv("MMP_NO_DELTA")) c->no_delta = nd[0] == '1';
     if (const char *sb = getenv("MMP_SINGLE_BLOCK")) c->single_block = sb[0] == '1';
     if (const char *sp = getenv("MMP_PLAN_SORTED")) c->cfg_plan_sorted = atoi(sp);
+    if (const char *pf = getenv("MMP_PLAN_FUSED")) c->cfg_plan_fused = atoi(pf);
+    {
+        // the one-launch plan waits at grid-wide barriers: every workgroup has to be on the chip (one per compute unit at most);
+        // it keeps the bucket offsets in 64 KB of dynamic LDS beside its 23 KB of static
+        int cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0 &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(proactive_plan_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kPlanFusedLds) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, proactive_plan_fused_kernel, kPlanFusedBlock, kPlanFusedLds) == hipSuccess &&
+            per_cu > 0)
+            c->plan_grid_max = std::min(cus, kPlanFusedGrid);
+        (void)hipGetLastError();
+    }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete c;
         return fail(nullptr, MMP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
@@ -4213,26 +4228,36 @@ try {
         U.skip = c->s_d.as<uint8_t>();
     }
     // The bucketed plan: six dependent launches, every size read on the device, ONE read of the result at the end.
-    const int32_t n_cnt_words = 3 * (kPlanBuckets + 1) + 3 * kPlanBuckets;
-    HIP_TRY(c, c->r_counts.ensure((size_t)std::max(n_cnt_words, nb + 1) * 4));
-    HIP_TRY(c, c->r_part.ensure((size_t)nb * sizeof(PlanPartial)));
+    const int32_t n_cnt_words = 3 * (kPlanBuckets + 1) + 3 * kPlanBuckets + 1;  // (even: the one-launch plan's chunk totals follow, 8 bytes each)
+    static_assert((3 * (kPlanBuckets + 1) + 3 * kPlanBuckets + 1) % 2 == 0, "chunk totals are 8-byte aligned");
+    HIP_TRY(c, c->r_counts.ensure((size_t)std::max(n_cnt_words + 2 * div_up(std::max(M, 1), kPlanFusedBlock), nb + 1) * 4));
+    HIP_TRY(c, c->r_part.ensure((size_t)nb * std::max(sizeof(PlanPartial), (size_t)kPlanPartWords * 8)));
     counts = c->r_counts.as<int32_t>();
     int32_t *hist = counts, *dcnt = hist + kPlanBuckets, *dge = dcnt + kPlanBuckets, *off = dge + kPlanBuckets,
             *cur = off + kPlanBuckets + 1, *doff = cur + kPlanBuckets + 1;
     PlanPartial *part = c->r_part.as<PlanPartial>();
     KT_BEGIN(c, st);  // device span of the whole plan
-    hipLaunchKernelGGL(proactive_space_scalars_kernel, dim3(std::min(std::max(div_up(P, 256), 1), 512)), dim3(256), 0, st, pods, P,
-                       U, default_units, now, ps);
-    hipLaunchKernelGGL(proactive_qualify_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps, part, hist);
-    hipLaunchKernelGGL(proactive_hist_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps, part, nb, hist);
-    hipLaunchKernelGGL(proactive_scan_kernel, dim3(1), dim3(kPlanScanBlock), 0, st, ps, hist, off, cur);
-    hipLaunchKernelGGL(proactive_bin_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps, cur, c->r_keys.as<int64_t>(),
-                       c->r_vals.as<int32_t>());
-    hipLaunchKernelGGL(proactive_bucket_rank_kernel, dim3(kPlanBuckets / 4), dim3(256), 0, st, c->r_keys.as<int64_t>(),
-                       c->r_vals.as<int32_t>(), off, ps, c->r_vals2.as<int32_t>(), dcnt, dge);
-    hipLaunchKernelGGL(proactive_scan2_kernel, dim3(1), dim3(kPlanScanBlock), 0, st, ps, dcnt, dge, doff);
-    hipLaunchKernelGGL(proactive_emit_kernel, dim3(nb), dim3(kCompactBlock), 0, st, c->r_keys.as<int64_t>(), c->r_vals.as<int32_t>(),
-                       c->r_vals2.as<int32_t>(), doff, ps, max_out, c->r_out_model.as<int32_t>(), c->r_out_lu.as<int64_t>());
+    if (c->cfg_plan_fused && c->plan_grid_max > 0) {
+        // ONE launch, the steps separated by grid-wide barriers (rebalance_kernels.hpp: proactive_plan_fused_kernel)
+        const int G = std::max(std::min(div_up(std::max(M, 1), kPlanFusedBlock), (int)c->plan_grid_max), 1);
+        hipLaunchKernelGGL(proactive_plan_fused_kernel, dim3(G), dim3(kPlanFusedBlock), kPlanFusedLds, st, pods, P, models, M, U, default_units, now,
+                           ps, c->r_part.as<uint64_t>(), hist, c->r_keys2.as<int32_t>(), c->r_keys.as<int64_t>(), c->r_vals.as<int32_t>(),
+                           c->r_vals2.as<int32_t>(), reinterpret_cast<uint64_t *>(counts + n_cnt_words), max_out,
+                           c->r_out_model.as<int32_t>(), c->r_out_lu.as<int64_t>());
+    } else {
+        hipLaunchKernelGGL(proactive_space_scalars_kernel, dim3(std::min(std::max(div_up(P, 256), 1), 512)), dim3(256), 0, st, pods, P,
+                           U, default_units, now, ps);
+        hipLaunchKernelGGL(proactive_qualify_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps, part, hist);
+        hipLaunchKernelGGL(proactive_hist_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps, part, nb, hist);
+        hipLaunchKernelGGL(proactive_scan_kernel, dim3(1), dim3(kPlanScanBlock), 0, st, ps, hist, off, cur);
+        hipLaunchKernelGGL(proactive_bin_kernel, dim3(nb), dim3(kCompactBlock), 0, st, models, M, U, ps, cur, c->r_keys.as<int64_t>(),
+                           c->r_vals.as<int32_t>());
+        hipLaunchKernelGGL(proactive_bucket_rank_kernel, dim3(kPlanBuckets / 4), dim3(256), 0, st, c->r_keys.as<int64_t>(),
+                           c->r_vals.as<int32_t>(), off, ps, c->r_vals2.as<int32_t>(), dcnt, dge);
+        hipLaunchKernelGGL(proactive_scan2_kernel, dim3(1), dim3(kPlanScanBlock), 0, st, ps, dcnt, dge, doff);
+        hipLaunchKernelGGL(proactive_emit_kernel, dim3(nb), dim3(kCompactBlock), 0, st, c->r_keys.as<int64_t>(), c->r_vals.as<int32_t>(),
+                           c->r_vals2.as<int32_t>(), doff, ps, max_out, c->r_out_model.as<int32_t>(), c->r_out_lu.as<int64_t>());
+    }
     KT_END(c, st);
     HIP_TRY(c, hipGetLastError());
     PlanScalars h{};

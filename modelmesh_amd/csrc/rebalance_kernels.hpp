@@ -24,7 +24,11 @@ struct PlanScalars {  // mirrors mmp_proactive_info + work counters
     long long kmin, kmax;
     unsigned int ticket[4];
     int32_t overflow;              // a bucket holds more than kPlanBucketMax candidates: the host takes the sorted path
-    int32_t bucket_map;            // 0: linear in age, 1: floating (exponent + mantissa of age)
+    int32_t bucket_map;            // 0: linear in age; m >= 8: floating (exponent + m mantissa bits of age)
+    long long t_phase[16];         // -DMMP_PLAN_CLOCK builds: the 100 MHz clock at the one-launch plan's phase boundaries (workgroup 0)
+    // the one-launch plan's barrier (plan_grid_barrier): the arrivals and the flag that lets the workgroups go, a cache line each
+    alignas(128) unsigned int bar_count[32];
+    alignas(128) unsigned int bar_flag[32];
 };
 
 // The instance subset a plan is made for (triggerProactiveLoadsForInstanceSubset, MM.java:6616: one call per
@@ -275,6 +279,16 @@ __global__ __launch_bounds__(kCompactBlock) void distinct_scatter_kernel(const i
 // A bucket above kPlanBucketMax under both maps (thousands of models on one millisecond) raises `overflow`: the sorted path runs.
 constexpr int kPlanBuckets = 16384, kPlanLinBits = 14, kPlanMantBits = 8, kPlanBucketMax = 1024, kPlanLdsBucket = 256;
 
+// the floating map's mantissa bits: as many as keep the bucket of the oldest key (age = range) inside the table — 8 always do
+// ((64 - 8 + 1) << 8 = 14592); a key range of 2^34 ms takes 9 (buckets half as wide, half as full)
+__device__ __forceinline__ int plan_mantissa_bits(uint64_t range)
+{
+    const int e_max = range ? 63 - __builtin_clzll(range) : 0;
+    int m = kPlanMantBits;
+    while (m < 13 && ((e_max - (m + 1) + 2) << (m + 1)) <= kPlanBuckets && e_max >= m + 1) m++;
+    return m;
+}
+
 // true in exactly one workgroup of the launch: the one that arrives last (its view includes every other workgroup's writes)
 __device__ __forceinline__ bool last_workgroup(unsigned int *ticket)
 {
@@ -417,7 +431,7 @@ __device__ __forceinline__ PlanRange plan_fold(const PlanPartial *__restrict__ p
         if (t.n_qual > 0) {
             const double range = (double)((uint64_t)t.kmax - (uint64_t)t.kmin);
             const double mean_age = (double)t.kmax - t.key_sum / (double)t.n_qual;
-            map = mean_age * 8.0 < range ? 1 : 0;
+            map = mean_age * 8.0 < range ? plan_mantissa_bits((uint64_t)t.kmax - (uint64_t)t.kmin) : 0;
         }
         s_r = PlanRange{t.kmin, t.kmax, t.n_qual, map};
         if (store) {
@@ -439,17 +453,16 @@ __device__ __forceinline__ int plan_bucket_linear(uint64_t age, uint64_t range)
     const int bits = range ? 64 - __builtin_clzll(range) : 0;
     return (int)(age >> (bits > kPlanLinBits ? bits - kPlanLinBits : 0));
 }
-__device__ __forceinline__ int plan_bucket_floating(uint64_t age)
+__device__ __forceinline__ int plan_bucket_floating(uint64_t age, int m)
 {
-    constexpr int m = kPlanMantBits;
     if (age < (1ull << m)) return (int)age;
     const int e = 63 - __builtin_clzll(age);  // >= m
-    return ((e - m + 1) << m) + (int)((age >> (e - m)) & ((1u << m) - 1));  // < (64 - m + 1) << m = 14592
+    return ((e - m + 1) << m) + (int)((age >> (e - m)) & ((1u << m) - 1));  // < (e_max - m + 2) << m
 }
 __device__ __forceinline__ int plan_bucket_of(int64_t key, int64_t kmin, int64_t kmax, int map)
 {
     const uint64_t age = (uint64_t)kmax - (uint64_t)key;
-    return map ? plan_bucket_floating(age) : plan_bucket_linear(age, (uint64_t)kmax - (uint64_t)kmin);
+    return map ? plan_bucket_floating(age, map) : plan_bucket_linear(age, (uint64_t)kmax - (uint64_t)kmin);
 }
 __device__ __forceinline__ int plan_bucket(int64_t key, const PlanScalars *ps) { return plan_bucket_of(key, ps->kmin, ps->kmax, ps->bucket_map); }
 
@@ -487,11 +500,11 @@ __global__ __launch_bounds__(kCompactBlock) void proactive_hist_kernel(const mmp
 // exclusive scan of kPlanBuckets counts by ONE workgroup of 1024; off[kPlanBuckets] = total, returned in every thread;
 // *max_out = the fullest bucket
 constexpr int kPlanScanBlock = 1024;
-__device__ __forceinline__ int32_t bucket_scan(const int32_t *__restrict__ cnt, int32_t *__restrict__ off, int32_t *__restrict__ off2,
-                                               int32_t *max_out)
+template <int BLOCK = kPlanScanBlock>
+__device__ __forceinline__ int32_t bucket_scan(const int32_t *cnt, int32_t *off, int32_t *off2, int32_t *max_out)
 {
-    __shared__ int32_t wtot[kPlanScanBlock / 64], wmax[kPlanScanBlock / 64];
-    constexpr int per = kPlanBuckets / kPlanScanBlock;
+    __shared__ int32_t wtot[BLOCK / 64], wmax[BLOCK / 64];
+    constexpr int per = kPlanBuckets / BLOCK;
     static_assert(per % 4 == 0, "a thread's counts are read as int4");
     int32_t v[per], mine = 0, mx = 0;
 #pragma unroll
@@ -513,7 +526,7 @@ __device__ __forceinline__ int32_t bucket_scan(const int32_t *__restrict__ cnt, 
     if (lane_id() == 0) wmax[threadIdx.x >> 6] = mx;
     __syncthreads();
     int32_t before = incl - mine, total = 0, m2 = 0;
-    for (int w = 0; w < kPlanScanBlock / 64; w++) {
+    for (int w = 0; w < BLOCK / 64; w++) {
         if (w < (int)(threadIdx.x >> 6)) before += wtot[w];
         total += wtot[w];
         m2 = wmax[w] > m2 ? wmax[w] : m2;
@@ -529,7 +542,7 @@ __device__ __forceinline__ int32_t bucket_scan(const int32_t *__restrict__ cnt, 
         reinterpret_cast<int4 *>(off)[(threadIdx.x * per + k) >> 2] = o;
         if (off2) reinterpret_cast<int4 *>(off2)[(threadIdx.x * per + k) >> 2] = o;
     }
-    if (threadIdx.x == kPlanScanBlock - 1) off[kPlanBuckets] = total;
+    if (threadIdx.x == BLOCK - 1) off[kPlanBuckets] = total;
     if (max_out) *max_out = m2;
     return total;
 }
@@ -593,23 +606,15 @@ __device__ __forceinline__ void rank_heavy_bucket(const int64_t *__restrict__ ke
 // one WAVEFRONT per bucket (four buckets per workgroup): an entry is a run start if no equal key has a lower model index (the
 // TreeSet's first one seen); its local rank = run starts of the bucket with a larger key.  rank[pos] = local rank, -1 = duplicate.
 // dcnt[b] = run starts of the bucket, dge[b] = those of them at or above the cutoff.
-__global__ __launch_bounds__(256) void proactive_bucket_rank_kernel(const int64_t *__restrict__ keys, const int32_t *__restrict__ vals,
-                                                                    const int32_t *__restrict__ off, const PlanScalars *ps,
-                                                                    int32_t *__restrict__ rank, int32_t *__restrict__ dcnt,
-                                                                    int32_t *__restrict__ dge)
+__device__ __forceinline__ void plan_rank_bucket(int b, int64_t *s_key, int32_t *s_val, const int64_t *keys, const int32_t *vals,
+                                                 const int32_t *off, int64_t cutoff, int32_t *rank, int32_t *dcnt, int32_t *dge)
 {
-    __shared__ int64_t s_key_all[4][kPlanLdsBucket];
-    __shared__ int32_t s_val_all[4][kPlanLdsBucket];
-    if (ps->overflow) return;
-    const int wv = threadIdx.x >> 6, lane = lane_id();
-    int64_t *s_key = s_key_all[wv];
-    int32_t *s_val = s_val_all[wv];
-    const int b = blockIdx.x * 4 + wv, lo = off[b], cnt = off[b + 1] - lo;
+    const int lane = lane_id();
+    const int lo = off[b], cnt = off[b + 1] - lo;
     if (cnt > kPlanLdsBucket && cnt <= kPlanBucketMax) {  // a heavy bucket (rare): the same counting, the bucket read from L2
-        rank_heavy_bucket(keys + lo, vals + lo, cnt, ps->cutoff, rank + lo, dcnt + b, dge + b);
+        rank_heavy_bucket(keys + lo, vals + lo, cnt, cutoff, rank + lo, dcnt + b, dge + b);
         return;
     }
-    const int64_t cutoff = ps->cutoff;
     int32_t starts = 0, ge = 0;
     if (cnt == 1) {
         if (lane == 0) {
@@ -654,6 +659,7 @@ __global__ __launch_bounds__(256) void proactive_bucket_rank_kernel(const int64_
             }
             rank[lo + e] = r;
         }
+        wave_sync();  // (the tile is the wavefront's again for its next bucket)
     }
     starts = wave_sum_i32(starts);
     ge = wave_sum_i32(ge);
@@ -661,6 +667,17 @@ __global__ __launch_bounds__(256) void proactive_bucket_rank_kernel(const int64_
         dcnt[b] = starts;
         dge[b] = ge;
     }
+}
+__global__ __launch_bounds__(256) void proactive_bucket_rank_kernel(const int64_t *__restrict__ keys, const int32_t *__restrict__ vals,
+                                                                    const int32_t *__restrict__ off, const PlanScalars *ps,
+                                                                    int32_t *__restrict__ rank, int32_t *__restrict__ dcnt,
+                                                                    int32_t *__restrict__ dge)
+{
+    __shared__ int64_t s_key_all[4][kPlanLdsBucket];
+    __shared__ int32_t s_val_all[4][kPlanLdsBucket];
+    if (ps->overflow) return;
+    const int wv = threadIdx.x >> 6;
+    plan_rank_bucket(blockIdx.x * 4 + wv, s_key_all[wv], s_val_all[wv], keys, vals, off, ps->cutoff, rank, dcnt, dge);
 }
 
 // distinct counts -> global rank offsets, and :6709-6734: free space first, then only entries at or above the cutoff (the list is
@@ -720,6 +737,669 @@ __global__ void proactive_final_kernel(PlanScalars *ps)
     const int32_t by_free = ps->free_count < n_sel ? (ps->free_count > 0 ? ps->free_count : 0) : n_sel;
     const int32_t by_cut = ps->n_ge_cutoff < n_sel ? ps->n_ge_cutoff : n_sel;
     ps->n_selected = by_free > by_cut ? by_free : by_cut;
+}
+
+// ---- the plan as ONE launch (round 5) ----------------------------------------------------------------
+// The eight launches above each wait for the one before: 58 us on C3, of which the kernels' own work is a third.  Here the same
+// steps are phases of ONE launch whose workgroups are all on the chip (at most two per compute unit: a grid-wide barrier cannot
+// wait for a workgroup that has not started), separated by four barriers.
+//
+// What a barrier costs decides the design.  With ordinary loads and stores every workgroup needs a device-scope release and
+// acquire fence at every barrier — on gfx950 a write-back and an invalidation of its XCD's whole L2 each, 400 workgroups x 2 of
+// them per barrier: 16-36 us per barrier, measured (tools/plan_clock.py).  So everything one workgroup writes and another reads
+// inside this launch (histograms, offsets, the binned pairs, ranks, the partials) goes through DEVICE-SCOPE relaxed atomics —
+// `sc1` loads and stores, coherent at the memory side without any cache maintenance — and a barrier is: every lane waits for its
+// own stores (s_waitcnt vmcnt(0)), the workgroup barrier, one counter increment, one flag.  The registry and the instance table
+// (inputs: never written here) are read the ordinary, cached way.
+//   A  space budget over the pods; candidate / qualified counts and key ranges over the registry for BOTH forms the qualify rule
+//      can take (freeCount > 0: every candidate; else only lastUsed > cutoff, :6683-6685) — freeCount is known after the barrier
+//                                                                                               | barrier 1
+//   B  scalars (:6621-6664) and the fold of the partials in every workgroup; histogram of the chosen map, each qualified model
+//      keeping the slot its increment returned                                                  | barrier 2; the last workgroup to
+//                                                                                                 arrive scans the buckets first
+//   C  (lastUsed, model) pairs to offset + slot                                                  | barrier 3
+//   D  per ENTRY (work follows the qualified count, not the bucket count): a bucket that lies inside one wavefront's 64 entries is
+//      ranked through lane shuffles; the one bucket a wavefront's range can cut is ranked by the wavefront where it starts, from
+//      memory (plan_rank_bucket)                                                                 | barrier 4; the last workgroup
+//                                                                                                 scans the rank offsets, :6709-6734
+//   E  emit
+// 64 workgroups of 1024 lanes rather than 400 of 256: what a barrier costs grows with the workgroups that arrive at it (their
+// increments of one counter are applied one after the other, ~25 ns each)
+constexpr int kPlanFusedBlock = 1024, kPlanFusedGrid = 64, kPlanPartWords = 8;
+
+template <typename T>
+__device__ __forceinline__ T dld(const T *p)
+{
+    return __hip_atomic_load(const_cast<T *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ void dst(T *p, T v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Barrier number `gen` (1-based) of the launch: one counter, one flag (in cache lines of their own: polls in the line the arrivals
+// are counted in would queue in front of them).  1.6-2.4 us with 64 workgroups.  Measured and dropped: a flag per workgroup, the first
+// wavefront of each reading all of them (no counter to queue at) — 2.9-3.2 us.
+__device__ __forceinline__ void plan_grid_barrier(PlanScalars *ps, unsigned int gen)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's sc1 stores and atomics are done at the memory side
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (__hip_atomic_fetch_add(&ps->bar_count[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen * gridDim.x - 1)
+            __hip_atomic_store(&ps->bar_flag[0], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+            while (__hip_atomic_load(&ps->bar_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+}
+#ifdef MMP_PLAN_CLOCK
+#define PLAN_CLOCK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) dst(&ps->t_phase[k], (long long)wall_clock64()); } while (0)
+#define PLAN_CLOCK_ANY(k) do { if (threadIdx.x == 0) dst(&ps->t_phase[k], (long long)wall_clock64()); } while (0)  // (the last workgroup)
+#else
+#define PLAN_CLOCK(k) do { } while (0)
+#define PLAN_CLOCK_ANY(k) do { } while (0)
+#endif
+
+// Wavefront totals through DPP moves (row-local permutes, then the two row broadcasts of gfx9): seven VALU steps per value and
+// no trip through the LDS crossbar.  The eight totals of a PlanPartial2 by ds_bpermute shuffles were 4 us of phase A, and again of B.
+// Every lane of the wavefront must be active.  The result is the same in every lane.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_mov32(uint32_t old, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint64_t dpp_mov64(uint64_t old, uint64_t v)
+{
+    return (uint64_t)dpp_mov32<CTRL, ROW_MASK>((uint32_t)old, (uint32_t)v) |
+           ((uint64_t)dpp_mov32<CTRL, ROW_MASK>((uint32_t)(old >> 32), (uint32_t)(v >> 32)) << 32);
+}
+template <typename Op>
+__device__ __forceinline__ uint64_t wave_reduce_dpp64(uint64_t v, uint64_t ident, Op op)
+{
+    v = op(v, dpp_mov64<0xB1>(v, v));           // quad_perm [1,0,3,2]
+    v = op(v, dpp_mov64<0x4E>(v, v));           // quad_perm [2,3,0,1]
+    v = op(v, dpp_mov64<0x141>(v, v));          // row_half_mirror
+    v = op(v, dpp_mov64<0x140>(v, v));          // row_mirror: every lane of a row of 16 has the row's total
+    v = op(v, dpp_mov64<0x142, 0xA>(ident, v));  // row_bcast:15 into rows 1 and 3
+    v = op(v, dpp_mov64<0x143, 0xC>(ident, v));  // row_bcast:31 into rows 2 and 3: lane 63 has the total
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63) << 32);
+}
+__device__ __forceinline__ int32_t wave_sum_dpp_i32(int32_t x)
+{
+    uint32_t v = (uint32_t)x;
+    v += dpp_mov32<0xB1>(v, v);
+    v += dpp_mov32<0x4E>(v, v);
+    v += dpp_mov32<0x141>(v, v);
+    v += dpp_mov32<0x140>(v, v);
+    v += dpp_mov32<0x142, 0xA>(0u, v);
+    v += dpp_mov32<0x143, 0xC>(0u, v);
+    return __builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ int64_t wave_min_dpp_i64(int64_t x)
+{
+    return (int64_t)wave_reduce_dpp64((uint64_t)x, (uint64_t)INT64_MAX, [](uint64_t a, uint64_t b) { return (int64_t)a < (int64_t)b ? a : b; });
+}
+__device__ __forceinline__ int64_t wave_max_dpp_i64(int64_t x)
+{
+    return (int64_t)wave_reduce_dpp64((uint64_t)x, (uint64_t)INT64_MIN, [](uint64_t a, uint64_t b) { return (int64_t)a > (int64_t)b ? a : b; });
+}
+__device__ __forceinline__ double wave_sum_f64(double x)
+{
+    return __longlong_as_double((long long)wave_reduce_dpp64((uint64_t)__double_as_longlong(x), 0ull, [](uint64_t a, uint64_t b) {
+        return (uint64_t)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
+    }));
+}
+
+struct PlanPartial2 {
+    int32_t n_cand, nq_a, nq_b;
+    int64_t kmin_a, kmin_b, kmax;
+    double sum_a, sum_b;
+};
+__device__ __forceinline__ void plan_partial_add(PlanPartial2 &t, const PlanPartial2 &v)
+{
+    t.n_cand += v.n_cand;
+    t.nq_a += v.nq_a;
+    t.nq_b += v.nq_b;
+    t.kmin_a = v.kmin_a < t.kmin_a ? v.kmin_a : t.kmin_a;
+    t.kmin_b = v.kmin_b < t.kmin_b ? v.kmin_b : t.kmin_b;
+    t.kmax = v.kmax > t.kmax ? v.kmax : t.kmax;
+    t.sum_a += v.sum_a;
+    t.sum_b += v.sum_b;
+}
+// the workgroup's total in thread 0: wavefront totals by shuffles, then one LDS atomic per field and wavefront (a loop of thread 0
+// over sixteen rows of eight fields was 3 us of phase A).  The order of the double adds is not fixed — the sums only choose the bucket
+// map, and every workgroup folds the same published partials in the same order.
+struct PlanPartialLds {
+    int32_t n_cand, nq_a, nq_b, pad;
+    long long kmin_a, kmin_b, kmax;
+    double sum_a, sum_b;
+};
+__device__ __forceinline__ void plan_partial_reduce(PlanPartial2 &t, PlanPartialLds *s_acc)
+{
+    if (threadIdx.x == 0) *s_acc = PlanPartialLds{0, 0, 0, 0, INT64_MAX, INT64_MAX, INT64_MIN, 0.0, 0.0};
+    t.n_cand = wave_sum_dpp_i32(t.n_cand);
+    t.nq_a = wave_sum_dpp_i32(t.nq_a);
+    t.nq_b = wave_sum_dpp_i32(t.nq_b);
+    t.kmin_a = wave_min_dpp_i64(t.kmin_a);
+    t.kmin_b = wave_min_dpp_i64(t.kmin_b);
+    t.kmax = wave_max_dpp_i64(t.kmax);
+    t.sum_a = wave_sum_f64(t.sum_a);
+    t.sum_b = wave_sum_f64(t.sum_b);
+    __syncthreads();
+    if (lane_id() == 0) {
+        atomicAdd(&s_acc->n_cand, t.n_cand);
+        atomicAdd(&s_acc->nq_a, t.nq_a);
+        atomicAdd(&s_acc->nq_b, t.nq_b);
+        atomicMin(&s_acc->kmin_a, (long long)t.kmin_a);
+        atomicMin(&s_acc->kmin_b, (long long)t.kmin_b);
+        atomicMax(&s_acc->kmax, (long long)t.kmax);
+        atomicAdd(&s_acc->sum_a, t.sum_a);
+        atomicAdd(&s_acc->sum_b, t.sum_b);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        t.n_cand = s_acc->n_cand;
+        t.nq_a = s_acc->nq_a;
+        t.nq_b = s_acc->nq_b;
+        t.kmin_a = s_acc->kmin_a;
+        t.kmin_b = s_acc->kmin_b;
+        t.kmax = s_acc->kmax;
+        t.sum_a = s_acc->sum_a;
+        t.sum_b = s_acc->sum_b;
+    }
+}
+
+// A bucket too long for the workgroup's LDS window (rare: hundreds of models on one bucket width, and the window cut through it):
+// ranked by ONE wavefront with every pair fetched from memory on every pass; rank[] carries the run-start flags between the passes.
+// Returns (in every lane) the run starts of the bucket; *ge_out those at or above the cutoff.  rank[e] = base + local rank, -1 = duplicate.
+__device__ __forceinline__ int32_t plan_rank_bucket_mem(int lo, int cnt, const int64_t *keys, const int32_t *vals, int64_t cutoff, int32_t base,
+                                                        int32_t *rank, int32_t *ge_out)
+{
+    const int lane = lane_id();
+    int32_t starts = 0, ge = 0;
+    for (int e = lane; e < cnt; e += 64) {
+        const int64_t key = dld(&keys[lo + e]);
+        const int32_t val = dld(&vals[lo + e]);
+        bool first = true;
+        for (int j = 0; j < cnt; j++) first &= !(dld(&keys[lo + j]) == key && dld(&vals[lo + j]) < val);
+        dst(&rank[lo + e], first ? 0 : -1);
+        starts += first ? 1 : 0;
+        ge += (first && key >= cutoff) ? 1 : 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_sync();
+    // second pass into registers first: a rank written while other lanes still read the flags could be taken for a duplicate's -1
+    // only if it were negative — base + r is not
+    for (int e = lane; e < cnt; e += 64) {
+        if (dld(&rank[lo + e]) < 0) continue;
+        const int64_t key = dld(&keys[lo + e]);
+        int32_t r = 0;
+        for (int j = 0; j < cnt; j++) r += (dld(&keys[lo + j]) > key && dld(&rank[lo + j]) >= 0) ? 1 : 0;
+        dst(&rank[lo + e], base + r);
+    }
+    *ge_out = wave_sum_i32(ge);
+    return wave_sum_i32(starts);
+}
+
+constexpr int kPlanChunk = kPlanFusedBlock, kPlanAhead = kPlanLdsBucket, kPlanWindow = kPlanChunk + kPlanAhead;
+constexpr size_t kPlanFusedLds = (size_t)(kPlanBuckets + 1) * sizeof(int32_t);  // dynamic: the offset table
+constexpr uint64_t kPlanChunkValid = 1ull << 63;
+
+// Exclusive scan of the finished histogram into the workgroup's LDS table (s_off[kPlanBuckets] = the total); returns the fullest
+// bucket.  Lane t takes the int4 at k * 1024 + t of each quarter k of the table: neighbouring lanes read and write neighbouring
+// 16 bytes (a lane scanning 16 buckets of its own reads and writes at a stride of 64 bytes: 3.9 us against this form's).
+__device__ __forceinline__ int32_t plan_scan_to_lds(const int32_t *hist, int32_t *s_off)
+{
+    static_assert(kPlanBuckets == 4 * 4 * kPlanFusedBlock, "four int4 per lane");
+    __shared__ int32_t s_wtot[4][kPlanFusedBlock / 64], s_wmax[kPlanFusedBlock / 64];
+    const int tid = threadIdx.x, wv = tid >> 6;
+    int4 x[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = reinterpret_cast<const int4 *>(hist)[k * kPlanFusedBlock + tid];
+    int32_t sum[4], incl[4], mx = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        sum[k] = x[k].x + x[k].y + x[k].z + x[k].w;
+        const int32_t a = x[k].x > x[k].y ? x[k].x : x[k].y, b = x[k].z > x[k].w ? x[k].z : x[k].w;
+        mx = a > mx ? a : mx;
+        mx = b > mx ? b : mx;
+        incl[k] = wave_incl_scan_i32(sum[k]);
+    }
+    mx = (int32_t)wave_max_dpp_i64(mx);
+    if (lane_id() == 63) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) s_wtot[k][wv] = incl[k];
+        s_wmax[wv] = mx;
+    }
+    __syncthreads();
+    int32_t base = 0, fullest = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int32_t before = 0, tot = 0;
+        for (int w = 0; w < kPlanFusedBlock / 64; w++) {
+            const int32_t v = s_wtot[k][w];
+            before += w < wv ? v : 0;
+            tot += v;
+        }
+        int4 o;
+        o.x = base + before + incl[k] - sum[k];
+        o.y = o.x + x[k].x;
+        o.z = o.y + x[k].y;
+        o.w = o.z + x[k].z;
+        reinterpret_cast<int4 *>(s_off)[k * kPlanFusedBlock + tid] = o;
+        base += tot;
+    }
+    for (int w = 0; w < kPlanFusedBlock / 64; w++) fullest = s_wmax[w] > fullest ? s_wmax[w] : fullest;
+    if (tid == 0) s_off[kPlanBuckets] = base;
+    return fullest;
+}
+
+__global__ __launch_bounds__(kPlanFusedBlock) void proactive_plan_fused_kernel(
+    const mmp_pod_row *__restrict__ pods, int32_t P, const mmp_model_row *__restrict__ models, int32_t M, PlanSubset U,
+    int32_t default_units, int64_t now, PlanScalars *ps, uint64_t *part, int32_t *hist, int32_t *slot, int64_t *keys,
+    int32_t *vals, int32_t *rank, uint64_t *chunk_tot, int32_t max_out, int32_t *__restrict__ out_model, int64_t *__restrict__ out_lu)
+{
+    extern __shared__ int32_t s_off[];  // kPlanBuckets + 1 bucket offsets: every workgroup scans the histogram itself (dynamic LDS)
+    __shared__ PlanScalars s_ps;  // this workgroup's copy of the scalars (every workgroup computes the same ones)
+    __shared__ PlanPartialLds s_acc;
+    __shared__ int64_t s_key[kPlanWindow];
+    __shared__ int32_t s_val[kPlanWindow], s_pre[kPlanWindow + 1];
+    __shared__ uint8_t s_first[kPlanWindow];
+    __shared__ int32_t s_wcnt[kPlanWindow / 64], s_misc[8];
+    const int tid = threadIdx.x, G = gridDim.x, nthreads = G * kPlanFusedBlock, gtid = blockIdx.x * kPlanFusedBlock + tid;
+    const int nb = (M + kPlanFusedBlock - 1) / kPlanFusedBlock;
+    const StatsAcc *st = U.stats;
+
+    // ---- A ----
+    PLAN_CLOCK(0);
+    // the lane's first two registry rows: in flight while the rest of the phase's inputs arrive
+    const int ia = blockIdx.x * kPlanFusedBlock + tid, ib = (blockIdx.x + G) * kPlanFusedBlock + tid;
+    const mmp_model_row ra = models[ia < M ? ia : 0], rb = models[ib < M ? ib : 0];
+    // ... and its first instance row (the workgroups share the instance table evenly)
+    const int per_wg = (P + G - 1) / G, p_end = (blockIdx.x + 1) * per_wg < P ? (blockIdx.x + 1) * per_wg : P;
+    const int pa = blockIdx.x * per_wg + tid;
+    const mmp_pod_row rp = pods[pa < P ? pa : 0];
+    const int32_t pts_a = U.pts >= 0 ? U.pod_pts[pa < P ? pa : 0] : 0;
+    for (int k = gtid; k < kPlanBuckets; k += nthreads) dst(&hist[k], 0);
+    for (int k = gtid; k < nb; k += nthreads) dst(&chunk_tot[k], (uint64_t)0);  // (chunks of qualified entries: at most nb of them)
+    // what of the scalars does not need the space budget: the candidate rule's inputs and the cutoff (one lane, while the others
+    // add up the instances)
+    if (tid == kPlanFusedBlock - 1) {
+        s_ps.cand_enabled = (int64_t)U.global->total_capacity > 0 ? 1 : 0;
+        s_ps.cand_glru = (int64_t)U.global->total_free > 0 ? 0 : U.global->global_lru;
+        const int64_t glru = st->global_lru;
+        int64_t cutoff = 0;
+        if (glru != INT64_MAX) {
+            const int64_t third = age_of(glru, now) / 3;
+            cutoff = (int64_t)((uint64_t)glru + (uint64_t)(third > 1200000 ? third : 1200000));
+        }
+        s_ps.cutoff = cutoff;
+    }
+    {
+        int64_t sum = 0;
+        if ((int64_t)st->total_capacity > 0 && (int64_t)st->total_free > 0) {
+            const int32_t se = size_estimate_of(st, default_units);
+            if (se != 0) {
+                auto add = [&](const mmp_pod_row &r, int32_t pts) {  // :6633-6649
+                    if (r.flags & (MMP_POD_SHUTTING_DOWN | MMP_POD_TOMBSTONE)) return;
+                    if (U.pts >= 0 && pts != U.pts) return;
+                    const int32_t max_loads = (int32_t)((uint32_t)r.loading_threads * 50u - (uint32_t)r.loading_in_progress);
+                    if (max_loads <= 0) return;
+                    const int64_t avail = jsub64(remaining_of(r.capacity, r.used), r.capacity / 8);
+                    if (avail > 0) {
+                        const int64_t by_loads = (int64_t)(int32_t)((uint32_t)max_loads * (uint32_t)se);
+                        sum = (int64_t)((uint64_t)sum + (uint64_t)(avail < by_loads ? avail : by_loads));
+                    }
+                };
+                if (pa < p_end) add(rp, pts_a);
+                for (int p = pa + kPlanFusedBlock; p < p_end; p += kPlanFusedBlock) add(pods[p], U.pts >= 0 ? U.pod_pts[p] : 0);
+            }
+        }
+        sum = wave_sum_i64(sum);
+        if (lane_id() == 0 && sum != 0) atomicAdd(&ps->space_acc, (unsigned long long)sum);
+    }
+    PLAN_CLOCK(13);
+    __syncthreads();
+    {
+        PlanPartial2 t{0, 0, 0, INT64_MAX, INT64_MAX, INT64_MIN, 0.0, 0.0};
+        const int64_t cutoff = s_ps.cutoff;
+        auto take = [&](const mmp_model_row &m, int i) {
+            if (!proactive_candidate(m, &s_ps)) return;
+            t.n_cand++;
+            if (plan_excluded(U, i, m.type)) return;
+            const int64_t lu = m.last_used;
+            t.nq_a++;
+            t.kmin_a = lu < t.kmin_a ? lu : t.kmin_a;
+            t.kmax = lu > t.kmax ? lu : t.kmax;
+            t.sum_a += (double)lu;
+            if (lu > cutoff) {
+                t.nq_b++;
+                t.kmin_b = lu < t.kmin_b ? lu : t.kmin_b;
+                t.sum_b += (double)lu;
+            }
+        };
+        if (ia < M) take(ra, ia);
+        if (ib < M) take(rb, ib);
+        for (int vb = blockIdx.x + 2 * G; vb < nb; vb += 2 * G) {  // two rows per lane and turn, both loads in flight
+            const int i0 = vb * kPlanFusedBlock + tid, i1 = (vb + G) * kPlanFusedBlock + tid;
+            const bool h0 = i0 < M, h1 = i1 < M;
+            const mmp_model_row m0 = models[h0 ? i0 : 0], m1 = models[h1 ? i1 : 0];
+            if (h0) take(m0, i0);
+            if (h1) take(m1, i1);
+        }
+        PLAN_CLOCK(14);
+        plan_partial_reduce(t, &s_acc);
+        PLAN_CLOCK(15);
+        if (tid == 0) {
+            uint64_t *o = part + (size_t)blockIdx.x * kPlanPartWords;
+            dst(&o[0], (uint64_t)(uint32_t)t.n_cand | ((uint64_t)(uint32_t)t.nq_a << 32));
+            dst(&o[1], (uint64_t)(uint32_t)t.nq_b);
+            dst(&o[2], (uint64_t)t.kmin_a);
+            dst(&o[3], (uint64_t)t.kmin_b);
+            dst(&o[4], (uint64_t)t.kmax);
+            dst(&o[5], (uint64_t)__double_as_longlong(t.sum_a));
+            dst(&o[6], (uint64_t)__double_as_longlong(t.sum_b));
+        }
+    }
+    PLAN_CLOCK(1);
+    plan_grid_barrier(ps, 1);
+    PLAN_CLOCK(2);
+
+    // ---- B ----
+    if (tid < 64) {  // the fold of the partials (one per workgroup, at most 64: one wavefront) and the scalars, :6621-6664
+        static_assert(kPlanFusedGrid <= 64, "one lane per workgroup's partial");
+        PlanPartial2 t{0, 0, 0, INT64_MAX, INT64_MAX, INT64_MIN, 0.0, 0.0};
+        const unsigned long long acc = __hip_atomic_load(&ps->space_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < G) {
+            const uint64_t *o = part + (size_t)tid * kPlanPartWords;
+            const uint64_t w0 = dld(&o[0]);
+            t.n_cand = (int32_t)(uint32_t)w0;
+            t.nq_a = (int32_t)(uint32_t)(w0 >> 32);
+            t.nq_b = (int32_t)(uint32_t)dld(&o[1]);
+            t.kmin_a = (int64_t)dld(&o[2]);
+            t.kmin_b = (int64_t)dld(&o[3]);
+            t.kmax = (int64_t)dld(&o[4]);
+            t.sum_a = __longlong_as_double((long long)dld(&o[5]));
+            t.sum_b = __longlong_as_double((long long)dld(&o[6]));
+        }
+        t.n_cand = wave_sum_dpp_i32(t.n_cand);
+        t.nq_a = wave_sum_dpp_i32(t.nq_a);
+        t.nq_b = wave_sum_dpp_i32(t.nq_b);
+        t.kmin_a = wave_min_dpp_i64(t.kmin_a);
+        t.kmin_b = wave_min_dpp_i64(t.kmin_b);
+        t.kmax = wave_max_dpp_i64(t.kmax);
+        t.sum_a = wave_sum_f64(t.sum_a);
+        t.sum_b = wave_sum_f64(t.sum_b);
+        if (tid == 0) {
+            proactive_scalars(U, default_units, now, &s_ps, acc);
+            const bool all = s_ps.free_count > 0;  // :6683-6685: with free space every candidate qualifies
+            const int32_t nq = s_ps.total_count > 0 ? (all ? t.nq_a : t.nq_b) : 0;
+            const int64_t kmin = all ? t.kmin_a : t.kmin_b;
+            const double ksum = all ? t.sum_a : t.sum_b;
+            int map = 0;
+            if (nq > 0) {
+                const double range = (double)((uint64_t)t.kmax - (uint64_t)kmin);
+                const double mean_age = (double)t.kmax - ksum / (double)nq;
+                map = mean_age * 8.0 < range ? plan_mantissa_bits((uint64_t)t.kmax - (uint64_t)kmin) : 0;
+            }
+            s_ps.n_candidates = t.n_cand;
+            s_ps.n_qualified = nq;
+            s_ps.kmin = kmin;
+            s_ps.kmax = t.kmax;
+            s_ps.bucket_map = map;
+            if (blockIdx.x == 0) {  // (device-scope stores: the row also holds the barrier's counters)
+                dst(&ps->size_estimate, s_ps.size_estimate);
+                dst(&ps->free_count, s_ps.free_count);
+                dst(&ps->total_count, s_ps.total_count);
+                dst(&ps->error, s_ps.error);
+                dst(&ps->space_to_fill, s_ps.space_to_fill);
+                dst(&ps->cutoff, s_ps.cutoff);
+                dst(&ps->cand_enabled, s_ps.cand_enabled);
+                dst(&ps->cand_glru, s_ps.cand_glru);
+                dst(&ps->n_candidates, t.n_cand);
+                dst(&ps->n_qualified, nq);
+                dst(&ps->kmin, (long long)kmin);
+                dst(&ps->kmax, (long long)t.kmax);
+                dst(&ps->bucket_map, map);
+            }
+        }
+    }
+    __syncthreads();
+    const int32_t nq = s_ps.n_qualified;
+    if (nq <= 0) return;  // (every workgroup: the same scalars)
+    for (int vb = blockIdx.x; vb < nb; vb += 2 * G) {
+        const int i0 = vb * kPlanFusedBlock + tid, i1 = (vb + G) * kPlanFusedBlock + tid;
+        const bool h0 = i0 < M, h1 = i1 < M, again = vb != (int)blockIdx.x;  // (the first two rows are still in registers)
+        const mmp_model_row m0 = again ? models[h0 ? i0 : 0] : ra, m1 = again ? models[h1 ? i1 : 0] : rb;
+        const bool q0 = h0 && proactive_qualifies(m0, i0, U, &s_ps), q1 = h1 && proactive_qualifies(m1, i1, U, &s_ps);
+        // hist[b] += 1; the lane's slot in its bucket = what the add returned (one add per lane, all in flight together: an add per
+        // DISTINCT bucket of the wavefront, each waiting for the one before, cost 24 us here)
+        const int32_t my0 = q0 ? atomicAdd(&hist[plan_bucket(m0.last_used, &s_ps)], 1) : -1;
+        const int32_t my1 = q1 ? atomicAdd(&hist[plan_bucket(m1.last_used, &s_ps)], 1) : -1;
+        if (h0) slot[i0] = my0;  // read back by this lane in phase C
+        if (h1) slot[i1] = my1;
+    }
+    PLAN_CLOCK(3);
+    plan_grid_barrier(ps, 2);
+    // The bucket offsets: EVERY workgroup scans the finished histogram into its own LDS (64 KB read from memory per workgroup,
+    // 2 us) — one workgroup scanning for all, a write-back, a flag and 64 x 3 device-scope offset loads per lane later cost more.
+    // The adds went to the memory side; one invalidation so that the ordinary int4 loads here do not find an older line in this L2.
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    {
+        PLAN_CLOCK(10);
+        const int32_t fullest = plan_scan_to_lds(hist, s_off);
+        __syncthreads();
+        PLAN_CLOCK(11);
+        if (fullest > kPlanBucketMax) {  // (every workgroup finds the same) the host takes the sorted path
+            if (blockIdx.x == 0 && tid == 0) dst(&ps->overflow, 1);
+            return;
+        }
+    }
+
+    // ---- C ----
+    PLAN_CLOCK(4);
+    for (int vb = blockIdx.x; vb < nb; vb += 2 * G) {
+        const int i0 = vb * kPlanFusedBlock + tid, i1 = (vb + G) * kPlanFusedBlock + tid;
+        const bool h0 = i0 < M, h1 = i1 < M;
+        const int32_t my0 = h0 ? slot[i0] : -1, my1 = h1 ? slot[i1] : -1;
+        const int64_t lu0 = models[h0 ? i0 : 0].last_used, lu1 = models[h1 ? i1 : 0].last_used;
+        const int32_t o0 = my0 >= 0 ? s_off[plan_bucket(lu0, &s_ps)] : 0, o1 = my1 >= 0 ? s_off[plan_bucket(lu1, &s_ps)] : 0;
+        if (my0 >= 0) {
+            dst(&keys[o0 + my0], lu0);
+            dst(&vals[o0 + my0], (int32_t)i0);
+        }
+        if (my1 >= 0) {
+            dst(&keys[o1 + my1], lu1);
+            dst(&vals[o1 + my1], (int32_t)i1);
+        }
+    }
+    PLAN_CLOCK(5);
+    plan_grid_barrier(ps, 3);
+    PLAN_CLOCK(6);
+
+    // ---- D ----
+    // A workgroup takes kPlanChunk entries at a time plus the kPlanAhead behind them into LDS and ranks every bucket that STARTS in
+    // the chunk (a bucket is whole in the window unless it is longer than the lookahead and cut by the window's end: that one
+    // goes through memory).  Per entry: a run start = no equal key with a lower model index (the TreeSet's first one seen); its
+    // rank inside the chunk = run starts of the chunk's earlier buckets + run starts of its bucket with a larger key.  The chunk
+    // publishes its run starts; an entry's final place is then the run starts of all earlier chunks + that rank (phase E).
+    const int64_t cutoff = s_ps.cutoff;
+    const int n_chunks = (nq + kPlanChunk - 1) / kPlanChunk;
+    for (int c = blockIdx.x; c < n_chunks; c += G) {
+        const int E0 = c * kPlanChunk, n_here = nq - E0 < kPlanWindow ? nq - E0 : kPlanWindow;
+        __syncthreads();  // (the window of this workgroup's last chunk is done with)
+        for (int j = tid; j < n_here; j += kPlanFusedBlock) {
+            s_key[j] = dld(&keys[E0 + j]);
+            s_val[j] = dld(&vals[E0 + j]);
+        }
+        // the lane's entries: j0 = tid (the chunk), j1 = kPlanChunk + tid (the lookahead; lanes below kPlanAhead)
+        int lo[2], cn[2];
+        bool mine[2];  // the entry's bucket starts in this chunk and is whole in the window
+        int cut_lo = -1, cut_cnt = 0;  // the bucket the window's end cuts (the lane that holds its first entry knows)
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int j = h * kPlanChunk + tid;
+            lo[h] = cn[h] = 0;
+            mine[h] = false;
+            if (j < n_here && (h == 0 || tid < kPlanAhead)) {
+                const int b = plan_bucket(s_key[j], &s_ps);
+                const int l = s_off[b] - E0, hi = s_off[b + 1] - E0;
+                lo[h] = l;
+                cn[h] = hi - l;
+                const bool starts_here = l >= 0 && l < kPlanChunk;
+                mine[h] = starts_here && hi <= kPlanWindow;
+                if (starts_here && hi > kPlanWindow && j == l) {
+                    cut_lo = l;
+                    cut_cnt = hi - l;
+                }
+            }
+        }
+        bool first[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int j = h * kPlanChunk + tid;
+            first[h] = mine[h];
+            if (mine[h]) {
+                const int64_t key = s_key[j];
+                const int32_t val = s_val[j];
+                for (int t = 0; t < cn[h]; t++) first[h] &= !(s_key[lo[h] + t] == key && s_val[lo[h] + t] < val);
+            }
+            if (j < kPlanWindow) s_first[j] = first[h] ? 1 : 0;
+        }
+        __syncthreads();
+        // run starts in front of every window position (exclusive), s_pre[kPlanWindow] = all of them
+        {
+            const int wv = tid >> 6, lane = lane_id();
+            const uint64_t m0 = __ballot(first[0]), m1 = __ballot(first[1]);
+            if (lane == 0) {
+                s_wcnt[wv] = (int32_t)__popcll(m0);
+                if (wv < kPlanAhead / 64) s_wcnt[kPlanChunk / 64 + wv] = (int32_t)__popcll(m1);
+            }
+            __syncthreads();
+            int32_t before0 = 0, before1 = 0;
+            for (int w = 0; w < kPlanWindow / 64; w++) {
+                const int32_t n = s_wcnt[w];
+                before0 += w < wv ? n : 0;
+                before1 += w < kPlanChunk / 64 + wv ? n : 0;
+            }
+            s_pre[tid] = before0 + (int32_t)__popcll(m0 & ((1ull << lane) - 1));
+            if (tid < kPlanAhead) s_pre[kPlanChunk + tid] = before1 + (int32_t)__popcll(m1 & ((1ull << lane) - 1));
+            if (tid == 0) {
+                int32_t all = 0;
+                for (int w = 0; w < kPlanWindow / 64; w++) all += s_wcnt[w];
+                s_pre[kPlanWindow] = all;
+            }
+        }
+        __syncthreads();
+        int32_t ge = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int j = h * kPlanChunk + tid;
+            if (!mine[h]) continue;
+            int32_t r = -1;
+            if (first[h]) {
+                const int64_t key = s_key[j];
+                r = s_pre[lo[h]];
+                for (int t = 0; t < cn[h]; t++) r += (s_first[lo[h] + t] && s_key[lo[h] + t] > key) ? 1 : 0;
+                ge += key >= cutoff;
+            }
+            dst(&rank[E0 + j], r);
+        }
+        // the cut bucket: one wavefront, from memory; its entries rank behind every run start of the window
+        {
+            const uint64_t has = __ballot(cut_lo >= 0);
+            if (tid < 64) s_misc[0] = -1;
+            __syncthreads();
+            if (cut_lo >= 0) {
+                s_misc[0] = cut_lo;
+                s_misc[1] = cut_cnt;
+            }
+            (void)has;
+            __syncthreads();
+        }
+        int32_t cut_starts = 0, cut_ge = 0;
+        if (s_misc[0] >= 0 && tid < 64)
+            cut_starts = plan_rank_bucket_mem(E0 + s_misc[0], s_misc[1], keys, vals, cutoff, s_pre[kPlanWindow], rank, &cut_ge);
+        // the chunk's totals: run starts, and those of them at or above the cutoff — published when every lane's ranks are written
+        ge = wave_sum_i32(ge);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // (s_wcnt is read above)
+        if (lane_id() == 0) s_wcnt[tid >> 6] = ge;
+        __syncthreads();
+        if (tid == 0) {
+            int32_t g = cut_ge;
+            for (int w = 0; w < kPlanFusedBlock / 64; w++) g += s_wcnt[w];
+            dst(&chunk_tot[c], kPlanChunkValid | ((uint64_t)(uint32_t)g << 31) | (uint64_t)(uint32_t)(s_pre[kPlanWindow] + cut_starts));
+        }
+    }
+    PLAN_CLOCK(7);
+
+    // ---- E ----  (no barrier: a chunk waits for the totals of the chunks in front of it, each in a word of its own)
+    PLAN_CLOCK(8);
+    for (int c = blockIdx.x; c < n_chunks; c += G) {
+        const int E0 = c * kPlanChunk, e = E0 + tid;
+        // this lane's entry first (the loads are in flight while the totals arrive); its rank — which the chunk in front of this one
+        // may have written — after they have
+        int32_t r = -1, val = 0, lo = 0;
+        int64_t key = 0;
+        if (e < nq) {
+            key = dld(&keys[e]);
+            val = dld(&vals[e]);
+            lo = s_off[plan_bucket(key, &s_ps)];
+        }
+        // run starts (and those at or above the cutoff) of the chunks 0 .. c-1, and of chunk c-1 alone
+        int32_t sum = 0, sum_ge = 0, prev = 0;
+        for (int k = tid; k < c; k += kPlanFusedBlock) {
+            uint64_t w;
+            while (!((w = dld(&chunk_tot[k])) & kPlanChunkValid)) __builtin_amdgcn_s_sleep(1);
+            sum += (int32_t)(w & 0x7fffffffu);
+            sum_ge += (int32_t)((w >> 31) & 0x7fffffffu);
+            if (k == c - 1) prev = (int32_t)(w & 0x7fffffffu);
+        }
+        sum = wave_sum_i32(sum);
+        sum_ge = wave_sum_i32(sum_ge);
+        prev = wave_sum_i32(prev);
+        __syncthreads();
+        if (lane_id() == 0) {
+            s_wcnt[tid >> 6] = sum;
+            s_pre[tid >> 6] = sum_ge;
+            s_pre[64 + (tid >> 6)] = prev;
+        }
+        __syncthreads();
+        if (e < nq) r = dld(&rank[e]);
+        int32_t base = 0, base_ge = 0, last_one = 0;
+        for (int w = 0; w < kPlanFusedBlock / 64; w++) {
+            base += s_wcnt[w];
+            base_ge += s_pre[w];
+            last_one += s_pre[64 + w];
+        }
+        if (r >= 0) {
+            // the entry's bucket starts in this chunk or in the one before (a bucket is no longer than a chunk)
+            const int32_t d = (lo >= E0 ? base : base - last_one) + r;
+            if (d < s_ps.total_count && d < max_out) {
+                out_model[d] = val;
+                out_lu[d] = key;
+            }
+        }
+        if (c == n_chunks - 1 && tid == 0) {  // the last chunk knows every total: :6709-6734
+            uint64_t w;
+            while (!((w = dld(&chunk_tot[c])) & kPlanChunkValid)) __builtin_amdgcn_s_sleep(1);
+            const int32_t total = base + (int32_t)(w & 0x7fffffffu), n_ge = base_ge + (int32_t)((w >> 31) & 0x7fffffffu);
+            dst(&ps->n_distinct, total);
+            const int32_t n_sel = total < s_ps.total_count ? total : s_ps.total_count;
+            const int32_t by_free = s_ps.free_count < n_sel ? (s_ps.free_count > 0 ? s_ps.free_count : 0) : n_sel;
+            const int32_t by_cut = n_ge < n_sel ? n_ge : n_sel;
+            dst(&ps->n_ge_cutoff, by_cut);
+            dst(&ps->n_selected, by_free > by_cut ? by_free : by_cut);
+            PLAN_CLOCK_ANY(12);
+        }
+    }
+    PLAN_CLOCK(9);
 }
 
 }  // namespace mmp

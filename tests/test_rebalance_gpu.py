@@ -247,14 +247,16 @@ def test_proactive_plan_per_partition_matches_oracle(seed):
         s.close()
 
 
-@pytest.mark.parametrize("mode", ["2", "1"])  # 2: the bucketed plan only (an overflow would raise); 1: the sorted path only
+@pytest.mark.parametrize("mode", ["2", "2-launches", "1"])  # 2: the bucketed plan only (an overflow would raise) — as ONE launch
+# (the default) and as its eight dependent launches (MMP_PLAN_FUSED=0); 1: the sorted path only
 @pytest.mark.parametrize("seed,pods,models,used,dup,keys", [
     (11, 300, 20000, 0.2, 0.02, "ms"), (12, 300, 20000, 0.95, 0.0, "ms"), (13, 1000, 100_000, 0.6, 0.02, "ms"),
     (14, 64, 3000, 0.3, 0.5, "few"), (15, 300, 20000, 0.3, 0.0, "wide"), (16, 64, 600, 0.3, 1.0, "one")])
 def test_proactive_plan_bucketed_and_sorted_paths(monkeypatch, mode, seed, pods, models, used, dup, keys):
     """The plan without the sort (key-range buckets, ranks by counting) and the sorted path it falls back to, each forced on the
     same registries: ties (the TreeSet keeps the first model seen), one single lastUsed value, keys across the whole int64 range."""
-    monkeypatch.setenv("MMP_PLAN_SORTED", mode)
+    monkeypatch.setenv("MMP_PLAN_SORTED", mode[0])
+    monkeypatch.setenv("MMP_PLAN_FUSED", "0" if mode.endswith("launches") else "1")
     fleet = _plan_fleet(seed, pods, models, used, dup_frac=dup)
     rng = np.random.default_rng(seed)
     m = fleet.models
@@ -285,5 +287,29 @@ def test_proactive_plan_falls_back_when_a_bucket_overflows():
         gm, gl, gi = s.proactive_plan(6400, fleet.now, 20000)
         wm, wl_, wi = ob.proactive_plan(fleet, 6400, fleet.now, 20000)
         assert int(gi["n_selected"]) == int(wi["n_selected"]) and np.array_equal(gm, wm) and np.array_equal(gl, wl_)
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("seed,pods,models,dup,keys", [(21, 1000, 100_000, 0.02, "ms"), (22, 64, 3000, 0.5, "few"), (23, 300, 50_000, 0.004, "ms"), (24, 64, 3000, 0.0, "few40")])
+def test_one_launch_plan_is_the_same_every_time(monkeypatch, seed, pods, models, dup, keys):
+    """The one-launch plan hands data between its workgroups through device-scope loads and stores and grid-wide barriers of its own:
+    300 plans of the same registry (every one reusing the scratch the one before left behind) equal the oracle's."""
+    monkeypatch.setenv("MMP_PLAN_SORTED", "2")
+    monkeypatch.setenv("MMP_PLAN_FUSED", "1")
+    fleet = _plan_fleet(seed, pods, models, 0.4, dup_frac=dup)
+    if keys == "few":    # buckets of ~300 entries: ranked from memory
+        fleet.models["last_used"] = fleet.now - np.random.default_rng(seed).choice(np.arange(1, 9) * 700_000, models)
+    elif keys == "few40":  # buckets of ~60: most of them cut by a wavefront's range
+        fleet.models["last_used"] = fleet.now - np.random.default_rng(seed).choice(np.arange(1, 41) * 140_000, models)
+    s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
+    try:
+        s.load_fleet(fleet)
+        wm, wl_, wi = ob.proactive_plan(fleet, 6400, fleet.now, models)
+        assert len(wm) > 0
+        for k in range(300):
+            gm, gl, gi = s.proactive_plan(6400, fleet.now, models)
+            assert int(gi["n_selected"]) == int(wi["n_selected"]) and int(gi["n_candidates"]) == int(wi["n_candidates"]), k
+            assert np.array_equal(gm, wm) and np.array_equal(gl, wl_), k
     finally:
         s.close()
