@@ -470,6 +470,20 @@ int mmp_snapshot_commit(mmp_ctx *ctx);
  * placed by binary search with the literal comparator — instead of sorting; the result is the same snapshot.
  * *n_commits_out = commits that took that path on this context (diagnostics; MMP_NO_DELTA=1 in the environment disables it). */
 int mmp_delta_commits(mmp_ctx *ctx, int64_t *n_commits_out);
+/* The per-type SHORTLISTS of the published snapshot (diagnostics).  What getNext's walk (MM.java:4806-4947: first eligible instance,
+ * preference step, the three breaks, count) yields depends on the request only through positions of its own — its exclusions, the
+ * calling instance — that lie INSIDE the shortlist, and through one bit, the fresh-row test of :4913-4922.  commit records, per type row
+ * (the first 12) and per value of that bit, the shortlist of a request that has no position of its own in reach; large single-caller
+ * batches (mmp_place_batch_c / _c_dev) decide a request from it after checking exactly that, and every other request by the ordinary
+ * path in the same launch (results identical either way; MMP_NO_MEMO=1 in the environment keeps every request on the ordinary path).
+ * rows[2 * t + bit] = {valid, lo, hi, n_candidates}: the list holds for requests without a position in [lo, hi).
+ * *n_rows_out = 2 * min(type rows, 12); rows beyond cap_rows are not written. */
+typedef struct {
+    int32_t valid;
+    int32_t lo, hi;
+    int32_t n_candidates;
+} mmp_shortlist_row;
+int mmp_shortlists(mmp_ctx *ctx, mmp_shortlist_row *rows, int32_t cap_rows, int32_t *n_rows_out);
 /* clusterState iteration order (the `getCacheState` dump, MM.java:5552-5608).
  * order_out has room for n_pods ints; *n_out = rows actually in the set. */
 int mmp_get_order(mmp_ctx *ctx, int32_t *order_out, int32_t *n_out);

@@ -80,12 +80,13 @@ struct DevBuf {
 struct SnapBufs {
     DevBuf pods, lru, rem, cnt, rpm, orig, pos_of, elig, elig_nors, pref, has_pref, fullw, ge, pc, ph, nz, heads, bslots, bpm, bwin, bsurv, bpcs;
     DevBuf sel, rk;  // Snap::sel / ::rk
+    DevBuf memo, memo_cand;  // Snap::memo / ::memo_cand (place_kernel.hpp: TypeMemo)
     DevBuf ctpos;  // Snap::ctpos
     uint64_t types_gen = 0;  // has_pref holds the type table of this generation
     int32_t n_bslots = 0;  // case (b) slots this snapshot has (place_kernel.hpp: BSlot), read back at commit
     void release()
     {
-        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge, &pc, &ph, &nz, &heads, &bslots, &bpm, &bwin, &bsurv, &bpcs, &ctpos, &sel, &rk})
+        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge, &pc, &ph, &nz, &heads, &bslots, &bpm, &bwin, &bsurv, &bpcs, &ctpos, &sel, &rk, &memo, &memo_cand})
             b->release();
     }
 };
@@ -96,6 +97,7 @@ struct SnapBufs {
 // registry view resolved against THIS snapshot's rank positions.
 struct SnapSide {
     DevBuf d_allowed, d_has_allowed, stats_acc, d_pts, d_prohib, pstats, tstats, rmodels;
+    DevBuf mtw;  // PlaceArgs::mtw: rmodels[i].type, an int per model (valid whenever rmodels is)
     uint64_t types_gen = 0;  // d_allowed / d_has_allowed hold the type table of this generation
     bool rmodels_ok = false;
     std::vector<int32_t> pts_of;        // pod -> partition (-1: not in the table)
@@ -104,7 +106,7 @@ struct SnapSide {
     std::vector<StatsAcc> pstats_h, tstats_h;  // host mirrors (pstats_h has n_pts + 1 entries: the last is EMPTY_STATS)
     void release()
     {
-        for (DevBuf *b : {&d_allowed, &d_has_allowed, &stats_acc, &d_pts, &d_prohib, &pstats, &tstats, &rmodels}) b->release();
+        for (DevBuf *b : {&d_allowed, &d_has_allowed, &stats_acc, &d_pts, &d_prohib, &pstats, &tstats, &rmodels, &mtw}) b->release();
     }
 };
 
@@ -189,6 +191,8 @@ struct mmp_ctx {
     int32_t cfg_plan_fused = 1;   // MMP_PLAN_FUSED=0: the plan as its eight dependent launches (comparison; the one-launch form is the default)
     int32_t plan_grid_max = 0;    // workgroups the one-launch plan may have: all of them resident at once
     int32_t no_long_lds = 0; // MMP_NO_LONG_LDS=1: the long path reads its per-type tables from global memory (tests, comparison)
+    int32_t no_memo = 0;     // MMP_NO_MEMO=1: single-caller batches do not use the per-type shortlists (place_kernel.hpp: TypeMemo)
+    int32_t memo_from = -1;  // MMP_MEMO_FROM=n: decisions from which a single-caller batch takes the kernel with the shortlists in front (default kMemoFrom)
     int32_t no_heads = 0;    // MMP_NO_HEADS=1: decisions do not use the per-type head windows (tests: lane_decide_r alone)
 
     // host staging (inputs of the next commit)
@@ -432,9 +436,10 @@ int rebuild_resolved(mmp_ctx *c, SnapSide &sd, const Snap &snap, bool committed,
     sd.rmodels_ok = false;
     if (!committed || c->n_models <= 0) return MMP_OK;  // (shard contexts: `snap` carries the whole table's pos_of — resolved positions are GLOBAL)
     HIP_TRY(c, sd.rmodels.ensure((size_t)c->n_models * sizeof(ResolvedModel)));
+    HIP_TRY(c, sd.mtw.ensure((size_t)c->n_models * 4));
     hipLaunchKernelGGL(resolve_models_kernel, dim3(div_up(c->n_models, 256)), dim3(256), 0, c->stream, snap,
                        c->models.as<mmp_model_row>(), c->ent_pod.as<int32_t>(), c->n_models,
-                       sd.rmodels.as<ResolvedModel>());
+                       sd.rmodels.as<ResolvedModel>(), sd.mtw.as<int32_t>());
     HIP_TRY(c, hipGetLastError());
     if (sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
     sd.rmodels_ok = true;
@@ -492,6 +497,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     A.reqs = static_cast<const mmp_place_req *>(d_reqs);
     A.models = c->models.as<mmp_model_row>();
     A.rmodels = cur_side(c).rmodels_ok ? cur_side(c).rmodels.as<ResolvedModel>() : nullptr;
+    A.mtw = cur_side(c).rmodels_ok ? cur_side(c).mtw.as<int32_t>() : nullptr;
     A.wins = (c->no_heads || c->n_shards > 0) ? nullptr : c->sb[c->cur].heads.as<TypeWin>();
     A.ent_pod = c->ent_pod.as<int32_t>();
     A.extra = static_cast<const int32_t *>(d_extra);
@@ -554,10 +560,15 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_multi_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_multi_long4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_c_m_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_long_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_long4_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         c->lds_granted.store((size_t)want, std::memory_order_release);
     }
+    // single-caller batches with the per-type shortlists in front (place_batch_c_m_kernel): head windows and the resolved registry view
+    // in place, not the full-cluster regime (its shortlists span the table), none of the diagnostic routes, a launch that fills the chip
+    const bool use_memo = caller && !c->snap_long && !c->no_memo && !c->force_wave && A.wins && A.rmodels && c->snap.memo &&
+                          n >= (c->memo_from >= 0 ? c->memo_from : kMemoFrom);
     HIP_TRY(c, order_after_registry(c, st));
     if (segs) {  // several request arrays, one launch (multi_kernel.hpp); n = the decisions of all of them
         if (c->snap_long && n >= kLongDenseFrom)
@@ -579,6 +590,8 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
         hipLaunchKernelGGL(place_batch_long4_c_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *caller);
     else if (caller && c->snap_long)
         hipLaunchKernelGGL(place_batch_long_c_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *caller);
+    else if (use_memo)
+        hipLaunchKernelGGL(place_batch_c_m_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *caller);
     else if (caller)
         hipLaunchKernelGGL(place_batch_c_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *caller);
     else if (c->snap_long && n >= kLongDenseFrom)
@@ -629,6 +642,8 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     }
     if (const char *fw = getenv("MMP_FORCE_WAVE")) c->force_wave = fw[0] == '1';
     if (const char *nh = getenv("MMP_NO_HEADS")) c->no_heads = nh[0] == '1';
+    if (const char *nm = getenv("MMP_NO_MEMO")) c->no_memo = nm[0] == '1';
+    if (const char *mf = getenv("MMP_MEMO_FROM")) c->memo_from = atoi(mf);
     if (const char *nl = getenv("MMP_NO_LONG_LDS")) c->no_long_lds = nl[0] == '1';
     if (const char *nb = getenv("MMP_NO_CASEB")) c->no_caseb = nb[0] == '1';
     const bool want_resident = getenv("MMP_RESIDENT") && getenv("MMP_RESIDENT")[0] == '1';
@@ -1216,28 +1231,30 @@ try {
     // A table that has to grow moves (the old allocation is freed): only then is the state lock needed this early.
     const bool grows = (size_t)count * sizeof(mmp_model_row) > c->models.cap || (size_t)(base + n_entries) * 4 > c->ent_pod.cap ||
                        (size_t)(base + n_entries) * 8 > c->ent_time.cap ||
-                       (cur_side(c).rmodels_ok && (size_t)count * sizeof(ResolvedModel) > cur_side(c).rmodels.cap);
+                       (cur_side(c).rmodels_ok && ((size_t)count * sizeof(ResolvedModel) > cur_side(c).rmodels.cap || (size_t)count * 4 > cur_side(c).mtw.cap));
     if (grows) {  // copy-on-write (grow_cow): decisions are held off for the pointer swap only
-        DevBuf fm, fp, ft, fr;
-        auto drop = [&] { fm.release(); fp.release(); ft.release(); fr.release(); };
+        DevBuf fm, fp, ft, fr, fw;
+        auto drop = [&] { fm.release(); fp.release(); ft.release(); fr.release(); fw.release(); };
         int rc = grow_cow(c, c->models, (size_t)c->n_models * sizeof(mmp_model_row), (size_t)count * sizeof(mmp_model_row), fm);
         if (rc == MMP_OK) rc = grow_cow(c, c->ent_pod, (size_t)base * 4, (size_t)(base + n_entries) * 4, fp);
         if (rc == MMP_OK) rc = grow_cow(c, c->ent_time, (size_t)base * 8, (size_t)(base + n_entries) * 8, ft);
         // (the unpublished side's view is rebuilt from the model table by the next commit)
         if (rc == MMP_OK && cur_side(c).rmodels_ok)
             rc = grow_cow(c, cur_side(c).rmodels, (size_t)c->n_models * sizeof(ResolvedModel), (size_t)count * sizeof(ResolvedModel), fr);
+        if (rc == MMP_OK && cur_side(c).rmodels_ok) rc = grow_cow(c, cur_side(c).mtw, (size_t)c->n_models * 4, (size_t)count * 4, fw);
         if (rc == MMP_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(c, MMP_EHIP, "mmp_models_upsert: growing the registry tables failed");
         if (rc != MMP_OK) {
             drop();
             return rc;
         }
-        DevBuf olds[4];
+        DevBuf olds[5];
         {
             std::lock_guard<std::shared_mutex> g(c->mu);
             if (fm.p) { olds[0] = c->models; c->models = fm; }
             if (fp.p) { olds[1] = c->ent_pod; c->ent_pod = fp; }
             if (ft.p) { olds[2] = c->ent_time; c->ent_time = ft; }
             if (fr.p) { olds[3] = cur_side(c).rmodels; cur_side(c).rmodels = fr; }
+            if (fw.p) { olds[4] = cur_side(c).mtw; cur_side(c).mtw = fw; }
         }
         const hipError_t q = quiesce_decisions(c);  // kernels that captured the old allocations
         for (DevBuf &o : olds) o.release();
@@ -1262,7 +1279,7 @@ try {
         KT_BEGIN(c, st);
         hipLaunchKernelGGL(upsert_models_kernel, dim3(div_up(k, 256)), dim3(256), 0, st, c->snap, c->u_idx.as<int32_t>(),
                            c->u_rows.as<mmp_model_row>(), k, c->ent_pod.as<int32_t>(), c->models.as<mmp_model_row>(),
-                           resolved ? cur_side(c).rmodels.as<ResolvedModel>() : nullptr);
+                           resolved ? cur_side(c).rmodels.as<ResolvedModel>() : nullptr, resolved ? cur_side(c).mtw.as<int32_t>() : nullptr);
         KT_END(c, st);
         // From here on the rewrite may be running.  Nothing may leave this block with the lock released, the rewrite enqueued
         // and no way for later decisions to order themselves behind it: a launch or event error drains the stream first, and
@@ -1462,6 +1479,8 @@ try {
     HIP_TRY(c, B.ph.ensure((size_t)2 * T * (W + 1) * 8));
     HIP_TRY(c, B.sel.ensure((size_t)2 * T * W * 64 * 4));
     HIP_TRY(c, B.rk.ensure((size_t)2 * T * W * 64 * 4));
+    HIP_TRY(c, B.memo.ensure((size_t)kWinLds * sizeof(TypeMemo)));
+    HIP_TRY(c, B.memo_cand.ensure((size_t)kWinLds * 2 * kMemoCand * 4));
     // rounded up to the 1 KB chunks place_block stages (rows beyond T are never read as windows)
     const size_t wins_bytes = (((size_t)std::max(T, kWinLds) * sizeof(TypeWin) + 1023) / 1024) * 1024;
     HIP_TRY(c, B.heads.ensure(wins_bytes));
@@ -1634,6 +1653,8 @@ try {
     S.ctpos = P > 0 ? B.ctpos.as<int32_t>() : nullptr;
     S.sel = P > 0 ? B.sel.as<int32_t>() : nullptr;
     S.rk = P > 0 ? B.rk.as<int32_t>() : nullptr;
+    S.memo = B.memo.as<TypeMemo>();
+    S.memo_cand = B.memo_cand.as<int32_t>();
 
     bool next_long = c->long_mode == 1, next_full = false;
     {  // the partitions of the type constraints (host) and their uploads: inputs, like the table itself
@@ -1730,6 +1751,10 @@ try {
         L2.nb_finish = div_up(std::max(N.n_pts, T), 64);
         hipLaunchKernelGGL(commit_level2_kernel, dim3(4 * T + L2.nb_finish), dim3(64), 0, st, L2);
         hipLaunchKernelGGL(build_sel_kernel, dim3(2 * T * W), dim3(64), 0, st, S, B.sel.as<int32_t>(), B.rk.as<int32_t>());
+        // the per-type shortlists (TypeMemo) from the finished head windows; the registry view below is resolved against them
+        HIP_TRY(c, hipMemsetAsync(B.memo.p, 0, (size_t)kWinLds * sizeof(TypeMemo), st));
+        hipLaunchKernelGGL(build_memo_kernel, dim3(std::min(T, kWinLds)), dim3(64), 0, st, S, B.heads.as<TypeWin>(), B.memo.as<TypeMemo>(),
+                           B.memo_cand.as<int32_t>());
         // the running minimum of the case (b) candidates' rpm, then the survivor bitmaps of the rpm rule's four limits
         hipLaunchKernelGGL(prefix_min_rpm_kernel, dim3(kBSlots), dim3(64), 0, st, S, B.bslots.as<BSlot>(), n_bslots_dev, B.bpm.as<int32_t>(),
                            (int32_t)(W * 64));
@@ -1738,6 +1763,7 @@ try {
         HIP_TRY(c, hipGetLastError());
     } else {
         HIP_TRY(c, hipMemsetAsync(B.heads.p, 0, wins_bytes, st));
+        HIP_TRY(c, hipMemsetAsync(B.memo.p, 0, (size_t)kWinLds * sizeof(TypeMemo), st));
         HIP_TRY(c, hipMemsetAsync(B.pc.p, 0, (size_t)2 * T * (W + 1) * 4, st));
         HIP_TRY(c, hipMemsetAsync(B.nz.p, 0, (size_t)2 * T * (W + 1) * 4, st));
         HIP_TRY(c, hipMemsetAsync(B.ph.p, 0, (size_t)2 * T * (W + 1) * 8, st));
@@ -1828,6 +1854,28 @@ try {
     return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_get_order");
 } catch (const std::exception &e) {
     return fail(c, MMP_EHIP, "%s: %s", "mmp_get_order", e.what());
+}
+
+int mmp_shortlists(mmp_ctx *c, mmp_shortlist_row *rows, int32_t cap_rows, int32_t *n_rows_out)
+try {
+    if (!c || !n_rows_out || (!rows && cap_rows > 0) || cap_rows < 0) return fail(c, MMP_EINVAL, "mmp_shortlists: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int32_t nt = c->snap.memo ? std::min(c->snap.T, kWinLds) : 0;
+    std::vector<TypeMemo> h((size_t)std::max(nt, 1));
+    if (nt) HIP_TRY(c, copy_sync(c, h.data(), c->snap.memo, (size_t)nt * sizeof(TypeMemo), hipMemcpyDeviceToHost));
+    for (int32_t i = 0; i < 2 * nt && i < cap_rows; i++) {
+        const MemoVar &v = h[i >> 1].v[i & 1];
+        rows[i] = mmp_shortlist_row{v.valid, v.lo, v.hi, v.ccount};
+    }
+    *n_rows_out = 2 * nt;
+    return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shortlists");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_shortlists", e.what());
 }
 
 int mmp_cluster_stats(mmp_ctx *c, mmp_stats *out)

@@ -131,10 +131,42 @@ struct __attribute__((aligned(16))) TypeWin {
 static_assert(sizeof(TypeWin) % 16 == 0, "TypeWin is staged in 16-byte pieces");
 static_assert(kGeRows % 2 == 0, "ct + pad_ keep the rows 16-byte aligned");
 
+// ---- per-type shortlists (round 5) ----------------------------------------------------------------
+// What lane_decide_win computes from a head window depends on the REQUEST in four ways only: its exclusions, the caller's own
+// entry (position + fresh record), the rpm rule's inputs (lastUsedTime, the fresh rpm) and the random pick.  The first two reach
+// the shortlist only when one of those positions lies inside it — and a shortlist is a few dozen positions at the head of an
+// order of thousands.  For every other request of the type the walk — first eligible instance, preference step, break scans,
+// count, audit hash — yields one of TWO shortlists, selected by the fresh-row test of MM.java:4913-4922 (which compares the
+// CALLER's fresh record with the best instance: one bit per request).  commit() runs lane_decide_win once per (type, bit) with no
+// exclusions (build_memo_kernel) and keeps: the positions the result depends on [lo, hi), the candidates' count and audit-hash
+// sum, the best row's fields the rpm rule reads, and the candidates' pod indices in shortlist order (Snap::memo_cand).  memo_try
+// decides a request by CHECKING that none of its positions falls into [lo, hi) — the model's exclusions were checked when its
+// registry row was resolved (ResolvedModel::type, bits kMemoBlk) — and applying the rpm rule and the pick to the recorded list; a
+// request that fails the check goes through the ordinary lane phase, in the same launch.  Used by the single-caller batch kernel
+// (place_batch_c_m_kernel, where it pays: see there); what else was tried with these records — a second phase per workgroup, a
+// wavefront per 256 requests, launch-wide lists, consumer workgroups, two launches — is in profiles/r5/shortlist_experiments.
+constexpr int kMemoCand = kWinWords * 64;
+constexpr int kMemoBlkShift = 24;  // ResolvedModel::type bit 24 + v: one of the model's exclusions lies inside shortlist v of its type (or no such shortlist)
+constexpr int32_t kMemoTypeMask = (1 << kMemoBlkShift) - 1;
+struct __attribute__((aligned(16))) MemoVar {
+    int32_t valid;       // 0: lane_decide_win gave no answer from the window for this (type, bit)
+    int32_t lo, hi;      // the answer holds for requests with no exclusion and no caller's entry at a position in [lo, hi)
+    int32_t ccount;      // candidates (:4940)
+    uint32_t hash;       // audit hash of the candidate words, folded
+    int32_t pad_[3];
+};
+struct __attribute__((aligned(16))) TypeMemo {
+    int64_t b_rem, b_lru;  // the best instance's remaining space and lruTime (the fresh-row test compares against them)
+    int32_t best_is_full, b_rpm, best_idx, pad_;
+    MemoVar v[2];          // [fresh-row break does not fire, fires]
+};
+static_assert(sizeof(TypeMemo) == 96, "TypeMemo is 96 bytes");
+
 struct PlaceArgs {
     const mmp_place_req *reqs;
     const mmp_model_row *models;
     const ResolvedModel *rmodels;  // null: not built (pod-axis shard contexts)
+    const int32_t *mtw;            // rmodels[i].type as an array of its own (the shortlist kernel's gather: 4 bytes per model instead of a 32-byte row)
     const TypeWin *wins;           // null: not built (pod-axis shard contexts, MMP_NO_HEADS=1)
     const struct BSlot *bslots;    // case (b) slots of the snapshot (long kernel only; see BSlot), n_bslots of them,
     const struct BLaunch *bwin;    // ... their whole-window tables (build_bsurv_kernel)
@@ -836,7 +868,7 @@ __device__ __forceinline__ ResolvedReq resolve_req(const Snap &S, const PlaceArg
         r.n_excl = 0;
     } else if (A.rmodels && A.rmodels[rq.model].n_ents <= kResolvedInline) {
         const ResolvedModel m = A.rmodels[rq.model];
-        r.type = m.type;
+        r.type = m.type & kMemoTypeMask;
         r.n_excl = m.n_ents + rq.n_extra;
         if (r.n_excl <= kInlineExcl) {
 #pragma unroll
@@ -899,17 +931,33 @@ __device__ __forceinline__ ResolvedModel resolve_model_row(const Snap &S, const 
         }
         r.pos[k] = pos;
     }
+    // which of the type's two recorded shortlists (TypeMemo) this model's exclusions leave untouched
+    uint32_t blk = 3u;
+    if (S.memo && r.type < kWinLds && r.n_ents <= kResolvedInline) {
+        blk = 0;
+#pragma unroll
+        for (int v = 0; v < 2; v++) {
+            const MemoVar mv = S.memo[r.type].v[v];
+            bool hit = !mv.valid;
+#pragma unroll
+            for (int k = 0; k < kResolvedInline; k++) hit |= r.pos[k] >= mv.lo && r.pos[k] < mv.hi;  // (-1 < lo: never)
+            if (hit) blk |= 1u << v;
+        }
+    }
+    r.type |= (int32_t)(blk << kMemoBlkShift);
     return r;
 }
 
 // One lane per model.
 __global__ void resolve_models_kernel(Snap S, const mmp_model_row *__restrict__ models,
                                       const int32_t *__restrict__ ent_pod, int32_t n_models,
-                                      ResolvedModel *__restrict__ out)
+                                      ResolvedModel *__restrict__ out, int32_t *__restrict__ mtw)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_models) return;
-    out[i] = resolve_model_row(S, models[i], ent_pod);
+    const ResolvedModel r = resolve_model_row(S, models[i], ent_pod);
+    out[i] = r;
+    mtw[i] = r.type;
 }
 
 // Registry events (mmp_models_upsert): rows[i] replaces models[idx[i]]; its entries were appended to the
@@ -917,13 +965,17 @@ __global__ void resolve_models_kernel(Snap S, const mmp_model_row *__restrict__ 
 // shard context).  idx holds no duplicates (the host keeps the last row per model).
 __global__ void upsert_models_kernel(Snap S, const int32_t *__restrict__ idx, const mmp_model_row *__restrict__ rows, int32_t n,
                                      const int32_t *__restrict__ ent_pod, mmp_model_row *__restrict__ models,
-                                     ResolvedModel *__restrict__ resolved)
+                                     ResolvedModel *__restrict__ resolved, int32_t *__restrict__ mtw)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const mmp_model_row m = rows[i];
     models[idx[i]] = m;
-    if (resolved) resolved[idx[i]] = resolve_model_row(S, m, ent_pod);
+    if (resolved) {
+        const ResolvedModel r = resolve_model_row(S, m, ent_pod);
+        resolved[idx[i]] = r;
+        mtw[idx[i]] = r.type;
+    }
 }
 
 // Arena compaction: offs = exclusive scan of the per-model entry counts; entries move to the fresh arrays.
@@ -1645,9 +1697,19 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
 // VIEW: S is a pod-axis shard's view of its slice (windows built over the view by the sharded commit): positions are local, the
 // audit hash takes the GLOBAL word index, and a shortlist that reaches the end of a slice with more slices behind it is not the
 // window's to answer (kLaneHeadMiss; lane_decide_r<true> then reports kLaneIncomplete).
-template <bool VIEW = false>
+// What build_memo_kernel takes out of lane_decide_win<…, MEMO> (see TypeMemo): the walk's result for a request WITHOUT
+// exclusions or a caller's entry in reach, with the fresh-row break (MM.java:4913-4922) forced to `nsb`.
+struct MemoCap {
+    int nsb;
+    int best0, bestpos, end, wlo, whi, ccount;
+    uint64_t hsum;
+    int64_t b_rem, b_lru;
+    int32_t b_rpm, best_idx;
+    bool best_is_full;
+};
+template <bool VIEW = false, bool MEMO = false, int SCR = kPlaceBlock>  // SCR: lanes per scratch column
 __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, const TypeWin *Ws,
-                                               uint64_t *scr, mmp_place_out &o)
+                                               uint64_t *scr, mmp_place_out &o, MemoCap *mc = nullptr)
 {
     PHASE_T0();
     if (r.type < 0 || r.type >= kWinLds || r.n_excl > kInlineExcl || A.force_wave) return kLaneHeadMiss;
@@ -1660,7 +1722,7 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
 #pragma unroll
         for (int j = 0; j < kWinWords; j++) e6[j] = Wn.E[j];  // words beyond nw are zero in the record
 #pragma unroll
-        for (int j = 0; j < kWinWords; j++) scrE[j * kPlaceBlock] = e6[j];
+        for (int j = 0; j < kWinWords; j++) scrE[j * SCR] = e6[j];
     }
     WinRow r0 = Wn.rowsE[0];
     if (!hdr.x) return kLaneHeadMiss;
@@ -1674,15 +1736,15 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
         const int j = (e >> 6) - w0;
         if (e >= 0 && j >= 0 && j < nw) {
             const unsigned long long m = ~(1ull << (e & 63));
-            atomicAnd((unsigned long long *)&scrE[j * kPlaceBlock], m);
+            atomicAnd((unsigned long long *)&scrE[j * SCR], m);
         }
     };
 #pragma unroll
     for (int i = 0; i < kInlineExcl; i++) clear_at(r.excl_pos[i]);
 #pragma unroll
     for (int i = 0; i < kLateExtra; i++) clear_at(r.late_pos[i]);  // -1 unless late-bound
-    auto ew = [&](int w) { return scrE[(w - w0) * kPlaceBlock]; };  // w0 <= w < w0 + nw
-    auto dw = [&](int w) { return scrE[(w - w0) * kPlaceBlock] & Wn.Pm[w - w0]; };  // ... that may be chosen (preference mask)
+    auto ew = [&](int w) { return scrE[(w - w0) * SCR]; };  // w0 <= w < w0 + nw
+    auto dw = [&](int w) { return scrE[(w - w0) * SCR] & Wn.Pm[w - w0]; };  // ... that may be chosen (preference mask)
     // first set bit of f(w) at a position in [from, to) of the window (to <= win_end); kNoPos if none
     auto first_in = [&](auto f, int from, int to) {
         if (from >= to) return (int)kNoPos;
@@ -1779,6 +1841,10 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
         if (T >= kGeBase + kGeRows) return kLaneHeadMiss;
         from_t = win_lo + (int)Wn.ct[T - kGeBase];  // counts do not decrease along the window
     }
+    if (MEMO) {  // the type's shortlist for either outcome of the fresh-row test; no caller's entry in reach
+        ns_break = mc->nsb != 0;
+        self_break = false;
+    }
     // ONE walk over the candidate words from the best position on: the first position that ends the list — the first
     // candidate that is not the caller's own entry when the fresh-row rule fires, the caller's own entry when its rule
     // fires, the first candidate whose count is past the threshold — and, up to it, the candidates' count and audit
@@ -1813,7 +1879,7 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
         }
         if (self_here && (end == kNoPos || selfpos < end)) self_in_c = true;
         if (w == wlo) v |= 1ull << (bestpos & 63);
-        scrE[(w - w0) * kPlaceBlock] = v;
+        scrE[(w - w0) * SCR] = v;
         whi = w;
         ccount += __popcll((unsigned long long)v);
         hsum += audit_term(v, (uint64_t)((VIEW ? S.w_base : 0) + w));
@@ -1821,6 +1887,21 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
     }
     if (end == kNoPos && (win_end < P || (VIEW && S.more_after))) return kLaneHeadMiss;  // the list runs past the window (or the slice)
     PHASE(3);  // break scans + count + audit hash
+    if (MEMO) {
+        mc->best0 = best0;
+        mc->bestpos = bestpos;
+        mc->end = end;
+        mc->wlo = wlo;
+        mc->whi = whi;
+        mc->ccount = ccount;
+        mc->hsum = hsum;
+        mc->b_rem = b_rem;
+        mc->b_lru = b_lru;
+        mc->b_rpm = b_rpm;
+        mc->best_idx = best_idx;
+        mc->best_is_full = best_is_full;
+        return kLaneDone;
+    }
     if (self_in_c && favour) {  // :4931-4933
         o.chosen = MMP_SELF;
         return kLaneDone;
@@ -1848,7 +1929,7 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
         const int sw = self_in_c ? (selfpos >> 6) : -1;
         int running = 0;
         for (int w = wlo; w <= whi; w++) {
-            uint64_t v = scrE[(w - w0) * kPlaceBlock];  // the word's candidates; those the rpm filter left in:
+            uint64_t v = scrE[(w - w0) * SCR];  // the word's candidates; those the rpm filter left in:
             uint64_t special = 0;
             if (w == wlo) special |= 1ull << (bestpos & 63);
             if (w == sw) special |= 1ull << (selfpos & 63);
@@ -2170,7 +2251,69 @@ constexpr int kPlaceLaneLds = kWinLdsBytes + kLaneScratchBytes;  // the most the
 constexpr int kPlaceStaticLds = 2 * kPlaceBlock * 4 + 64 + 256;                // the lists (+ place_single_kernel's request)
 // bytes of the long path's per-type tables when they are staged in LDS: elig + pref ([T][W] words each), pc + nz ([2][T][W + 1] ints each)
 __host__ __device__ constexpr size_t long_tables_bytes(int T, int W) { return (size_t)T * W * 16 + (size_t)4 * T * (W + 1) * 4; }
-template <bool WITH_LONG, int FORM = kReq64>
+// A request against its type's recorded shortlists (see TypeMemo), a lane per request, the tables read from (L1-resident) global
+// memory: true = decided, the result row written.  false: a position of the request's own inside the shortlist, more exclusions than
+// the checks see, no shortlist for the type — the ordinary path decides.
+template <int FORM>
+__device__ __forceinline__ bool memo_try(const Snap &S, const PlaceArgs &A, const mmp_place_req &rq, int d)
+{
+    const bool m_ok = (uint32_t)rq.model < (uint32_t)A.n_models;
+    int32_t tf = A.mtw[m_ok ? rq.model : 0];
+    if (!m_ok) tf = -1;  // (type mask all ones: no shortlist)
+    const bool s_ok = (uint32_t)rq.self_pod < (uint32_t)S.P;
+    int32_t sp = S.pos_of[s_ok ? rq.self_pod : 0];
+    if (!s_ok) sp = -1;
+    int32_t xp[kLateExtra];
+#pragma unroll
+    for (int j = 0; j < kLateExtra; j++) xp[j] = -1;
+    const bool x_ok = (uint32_t)rq.n_extra <= (uint32_t)kLateExtra && !(A.extra_bound != 0 && bad_extra_range(A, rq));
+    if (__ballot(x_ok && rq.n_extra > 0)) {  // (wave-uniform) the request's own exclusions: their positions
+#pragma unroll
+        for (int j = 0; j < kLateExtra; j++)
+            if (x_ok && j < rq.n_extra) xp[j] = pod_view_pos<false>(S, A.extra[rq.extra_off + j], S.P);
+    }
+    const int type = tf & kMemoTypeMask;
+    const bool t_ok = type < kWinLds && x_ok;
+    const TypeMemo *Mp = &S.memo[t_ok ? type : 0];
+    const int64_t b_rem = Mp->b_rem, b_lru = Mp->b_lru;
+    const int32_t full = Mp->best_is_full, b_rpm = Mp->b_rpm, best_idx = Mp->best_idx;
+    // the fresh-row test, MM.java:4913-4922 (as lane_decide_win has it); the full-mode form only in wavefronts that hold such a type
+    const int64_t f_rem = remaining_of(rq.fresh_capacity, rq.fresh_used);
+    bool nsb = f_rem < S.min_space || f_rem < (b_rem >> 2);
+    if (__ballot(full != 0)) {  // (wave-uniform)
+        const int64_t rel = age_of(b_lru, A.now) / 10;
+        const int64_t d1 = jsub64(rq.fresh_lru, b_lru);
+        if (full) nsb = d1 > 45000LL && d1 > rel;
+    }
+    const MemoVar V = Mp->v[nsb ? 1 : 0];
+    const int lo = V.lo;
+    const uint32_t len = (uint32_t)(V.hi - lo);
+    bool miss = !t_ok || !V.valid || ((tf >> (kMemoBlkShift + (nsb ? 1 : 0))) & 1) || (uint32_t)(sp - lo) < len;  // (-1 - lo wraps far beyond len)
+#pragma unroll
+    for (int j = 0; j < kLateExtra; j++) miss |= (uint32_t)(xp[j] - lo) < len;
+    if (miss) return false;
+    const int ccount = V.ccount;
+    const int32_t f_rpm = rq.fresh_rpm;
+    // rpm filter, :4951-4980: the best instance and "the others" (fresh rpm, quirks B#2/B#3); no caller's entry in the list
+    RpmRule rule;
+    rule.init(age_of(rq.last_used, A.now), f_rpm < b_rpm ? f_rpm : b_rpm);
+    const int32_t lim = rule.limit();
+    const bool null0 = ccount >= 2 && b_rpm >= 100 && b_rpm > lim;
+    const bool null_o = ccount >= 2 && f_rpm >= 100 && f_rpm > lim;
+    const int remaining = ccount - (null0 ? 1 : 0) - (null_o ? ccount - 1 : 0);
+    const int index = remaining <= 1 ? 0 : (int)(((uint64_t)rq.pick * (uint64_t)(uint32_t)remaining) >> 32);
+    const int k = null_o ? 0 : index + (null0 ? 1 : 0);
+    mmp_place_out o;
+    o.chosen = MMP_NONE;
+    if (remaining >= 1) o.chosen = S.memo_cand[(type * 2 + (nsb ? 1 : 0)) * kMemoCand + k];
+    o.best = best_idx;
+    o.n_candidates = ccount;
+    o.hash = V.hash ^ ((uint32_t)remaining * 0x9E3779B1u);
+    A.outs[d] = o;
+    return true;
+}
+
+template <bool WITH_LONG, int FORM = kReq64, bool MEMO = false>
 __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, int32_t wpad, unsigned char *smem,
                                             uint32_t *done_blocks = nullptr, const mmp_place_caller &C = mmp_place_caller{})
 {
@@ -2254,6 +2397,8 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // the type's recorded shortlist first (TypeMemo): a wavefront whose requests are all covered is done here
+    if (MEMO && live && memo_try<FORM>(S, A, rq, d)) live = false;
     ResolvedReq r;
     if (live) r = resolve_req<false, true>(S, A, rq);
     PHASE(0);  // request + model row resolved
@@ -2353,6 +2498,80 @@ __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(MMP
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     place_block<false, kReqC>(S, A, wpad, smem, nullptr, C);
 }
+// ---- per-type shortlists: build (commit) and use (see TypeMemo) ------------------------------------------------------------------
+// One wavefront per type row: lanes 0 / 1 run lane_decide_win on the type's window for a request without exclusions and without a
+// caller's entry, the fresh-row break off / on; then the wavefront writes the candidates' pod indices in shortlist order.
+__global__ __launch_bounds__(64) void build_memo_kernel(Snap S, const TypeWin *__restrict__ wins, TypeMemo *__restrict__ memo,
+                                                        int32_t *__restrict__ cand)
+{
+    __shared__ uint64_t scr[kWinWords * kPlaceBlock];
+    __shared__ MemoCap caps[2];
+    __shared__ int ok[2];
+    const int t = blockIdx.x, lane = lane_id();
+    if (lane < 2) {
+        PlaceArgs A{};
+        ResolvedReq r{};
+        r.type = t;
+        r.selfpos = -1;
+        r.n_late = -1;
+#pragma unroll
+        for (int i = 0; i < kInlineExcl; i++) r.excl_pos[i] = -1;
+#pragma unroll
+        for (int i = 0; i < kLateExtra; i++) r.late_pos[i] = -1;
+        MemoCap mc{};
+        mc.nsb = lane;
+        mmp_place_out o;
+        const int code = lane_decide_win<false, true>(S, A, r, wins, scr + lane, o, &mc);
+        caps[lane] = mc;
+        ok[lane] = code == kLaneDone && mc.ccount <= kMemoCand;
+    }
+    __syncthreads();
+    const int w0 = wins[t].w0;
+    if (lane == 0) {
+        TypeMemo M{};
+        const MemoCap &c0 = caps[ok[0] ? 0 : 1];  // the best row does not depend on the bit
+        M.b_rem = c0.b_rem;
+        M.b_lru = c0.b_lru;
+        M.best_is_full = c0.best_is_full;
+        M.b_rpm = c0.b_rpm;
+        M.best_idx = c0.best_idx;
+        for (int v = 0; v < 2; v++) {
+            const MemoCap &c = caps[v];
+            M.v[v].valid = ok[v];
+            M.v[v].lo = c.best0;
+            M.v[v].hi = c.end == kNoPos ? S.P : c.end + 1;  // the instance that ends the list is part of what the answer depends on
+            M.v[v].ccount = c.ccount;
+            M.v[v].hash = (uint32_t)(c.hsum ^ (c.hsum >> 32));
+        }
+        memo[t] = M;
+    }
+    for (int v = 0; v < 2; v++) {
+        if (!ok[v]) continue;
+        int32_t *out = cand + ((size_t)t * 2 + v) * kMemoCand;
+        int running = 0;
+        for (int w = caps[v].wlo; w <= caps[v].whi; w++) {
+            const uint64_t word = scr[v + (w - w0) * kPlaceBlock];  // the walk parked the clipped candidate words here (best bit set)
+            if ((word >> lane) & 1ull) out[running + __popcll((unsigned long long)(word & ((1ull << lane) - 1ull)))] = S.orig[w * 64 + lane];
+            running += __popcll((unsigned long long)word);
+        }
+    }
+}
+
+// The single-caller window kernel with the recorded shortlists in front (place_block<..., MEMO>; see TypeMemo).  One caller means one
+// position of "self" for the whole batch, so a request leaves the shortlist only through its model's instances or its own exclusions
+// (C3: 0.6 % + the few whose exclusions fall into the list): two wavefronts in three decide all 64 requests from the record and skip the
+// lane phase.  Measured, C3, 800 000 decisions of one caller per launch (tools/r5/memo_sweep.py, profiles/r5/shortlist_experiments):
+// 19.0 -> 17.0 us on one stream, 12.3 -> 10.3 us per launch on four; 1.6 M: 34.7 -> 30.2 us; at 400 000 the two meet (12.2 / 11.4 us),
+// below that the prefix is the longer chain — hence kMemoFrom.  Batches of request ROWS (a caller per request: one request in 80 has its
+// own caller inside the list, so every second wavefront runs the lane phase anyway) gain nothing from it and keep place_batch_kernel.
+__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(MMP_C_WAVES, MMP_C_WAVES))) void place_batch_c_m_kernel(Snap S, PlaceArgs A, int32_t wpad,
+                                                                                                              mmp_place_caller C)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    place_block<false, kReqC, true>(S, A, wpad, smem, nullptr, C);
+}
+constexpr int kMemoFrom = 6 * 1024 * 64;  // decisions from which a single-caller batch takes the kernel with the shortlists in front (one round of the chip at 6 wavefronts per SIMD)
+
 __global__ __launch_bounds__(kPlaceBlock) void place_batch_long_c_kernel(Snap S, PlaceArgs A, int32_t wpad, mmp_place_caller C)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

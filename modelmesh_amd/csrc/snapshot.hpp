@@ -59,6 +59,10 @@ struct Snap {
     // excluded candidate's place in the shortlist one lookup instead of its word, its preference word and its prefix count.
     const int32_t *sel;
     const int32_t *rk;
+    // The per-type shortlists of place_kernel.hpp: TypeMemo (round 5; null on shard views and when the head windows are off):
+    // memo[min(T, kWinLds)], memo_cand[kWinLds][2][kMemoCand] = the shortlists' pod indices in candidate order.
+    const struct TypeMemo *memo;
+    const int32_t *memo_cand;
 };
 
 // count >= 10 is a fixed clause of the shortlist's count break (MM.java:4925-4926); the other clause,

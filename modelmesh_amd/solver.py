@@ -293,6 +293,13 @@ class Solver:
         self._ck(self.lib.mmp_delta_commits(self.h, C.byref(n)))
         return n.value
 
+    def shortlists(self) -> np.ndarray:
+        """The published snapshot's per-type shortlists (mmp_shortlists): rows [2 * type + bit] of (valid, lo, hi, n_candidates)."""
+        out = np.zeros(24, dtype=np.dtype([("valid", "<i4"), ("lo", "<i4"), ("hi", "<i4"), ("n_candidates", "<i4")]))
+        n = C.c_int32(0)
+        self._ck(self.lib.mmp_shortlists(self.h, ptr(out), len(out), C.byref(n)))
+        return out[: n.value].copy()
+
     def stats(self) -> np.ndarray:
         out = np.zeros(1, dtype=STATS)
         self._ck(self.lib.mmp_cluster_stats(self.h, ptr(out)))
