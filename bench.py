@@ -664,6 +664,17 @@ def single_caller_leg(fleet, solver, dev, sets: int = 8):
         e1.record(st)
         torch.cuda.synchronize(dev)
         ms[form] = e0.elapsed_time(e1) / K
+    # the single-caller launches round-robin on four streams, as the timed region issues its steps: wall time per launch
+    sts4 = [st] + [torch.cuda.Stream(dev) for _ in range(3)]
+    args4 = [tuple(list(a[:-1]) + [C.c_void_p(sts4[i % 4].cuda_stream)]) for i, a in enumerate(args)]
+    for i in range(20):
+        fn(*args4[i % 4])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(4 * K):
+        fn(*args4[i % 4])
+    torch.cuda.synchronize(dev)
+    ms4 = (time.perf_counter() - t0) * 1e3 / (4 * K)
     rq0, rc0, ex0 = hosts[0]
     want = OracleFleet(fleet).place(rq0, ex0, fleet.now, threads=usable_cpus())
     got_r = np.frombuffer(bufs[0][4].cpu().numpy().tobytes(), dtype=PLACE_OUT)
@@ -684,14 +695,19 @@ def single_caller_leg(fleet, solver, dev, sets: int = 8):
     return {"decisions_per_launch": n, "request_sets": sets, "caller": int(sp),
             "kernel_ms_rows_64B": ms["rows"], "kernel_ms_single_caller_24B": ms["caller"],
             "decisions_per_s_single_caller": n / (ms["caller"] * 1e-3),
+            "ms_per_launch_single_caller_4_streams": ms4, "decisions_per_s_single_caller_4_streams": n / (ms4 * 1e-3),
+            "shortlists": {"kernel": "place_batch_c_m_kernel: a request is checked against its type's recorded shortlist before the lane "
+                                     "phase (place_kernel.hpp: TypeMemo, memo_try); batches from 393216 decisions on",
+                           "rows": [[int(v) for v in r] for r in solver.shortlists()]},
             "hbm_bytes_per_decision": {"rows": 80, "single_caller": 40},
             "hbm_only_frac": {"rows": hbm_stream_bytes(n) / (ms["rows"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "single_caller": hbm_stream_bytes(n, 24) / (ms["caller"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "host_boundary_decisions_per_s": {"rows": n / t_host["rows"], "single_caller": n / t_host["caller"]},
             "parity_vs_oracle": parity,
             "note": "mmp_place_batch_c_dev / mmp_place_batch_c: self and getFreshInstanceRecord() belong to the calling instance "
-                    "(MM.java:5369-5386) and travel once per call; the launch is bound by instruction issue, not by the request "
-                    "stream (profiles/r5/place_experiments/README.md), so halving the bytes buys 14 %, not 2 x"}
+                    "(MM.java:5369-5386) and travel once per call; the launch is bound by the instructions of a decision, not by "
+                    "the request stream (profiles/r5/place_experiments/README.md, profiles/r5/shortlist_experiments/README.md): "
+                    "halving the bytes bought 14 %, the shortlists in front of the lane phase another 10-12 %"}
 
 
 def multi_entry_leg(fleet, solver, dev, k: int = 8):
