@@ -191,8 +191,8 @@ struct mmp_ctx {
     int32_t cfg_plan_fused = 1;   // MMP_PLAN_FUSED=0: the plan as its eight dependent launches (comparison; the one-launch form is the default)
     int32_t plan_grid_max = 0;    // workgroups the one-launch plan may have: all of them resident at once
     int32_t no_long_lds = 0; // MMP_NO_LONG_LDS=1: the long path reads its per-type tables from global memory (tests, comparison)
-    int32_t no_memo = 0;     // MMP_NO_MEMO=1: single-caller batches do not use the per-type shortlists (place_kernel.hpp: TypeMemo)
-    int32_t memo_from = -1;  // MMP_MEMO_FROM=n: decisions from which a single-caller batch takes the kernel with the shortlists in front (default kMemoFrom)
+    int32_t no_memo = 0;     // MMP_NO_MEMO=1: batches do not use the per-type shortlists (place_kernel.hpp: TypeMemo)
+    int32_t memo_from = -1;  // MMP_MEMO_FROM=n: decisions from which a batch takes the kernel with the shortlists in front (default kMemoFrom)
     int32_t no_heads = 0;    // MMP_NO_HEADS=1: decisions do not use the per-type head windows (tests: lane_decide_r alone)
 
     // host staging (inputs of the next commit)
@@ -561,14 +561,15 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_multi_long4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_c_m_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_m_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_long_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_long4_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         c->lds_granted.store((size_t)want, std::memory_order_release);
     }
-    // single-caller batches with the per-type shortlists in front (place_batch_c_m_kernel): head windows and the resolved registry view
-    // in place, not the full-cluster regime (its shortlists span the table), none of the diagnostic routes, a launch that fills the chip
-    const bool use_memo = caller && !c->snap_long && !c->no_memo && !c->force_wave && A.wins && A.rmodels && c->snap.memo &&
-                          n >= (c->memo_from >= 0 ? c->memo_from : kMemoFrom);
+    // batches with the per-type shortlists in front (place_batch_m_kernel / place_batch_c_m_kernel): head windows and the resolved registry
+    // view in place, not the full-cluster regime (its shortlists span the table), none of the diagnostic routes, a launch that fills the chip
+    const bool use_memo = !segs && !inline_req && !done_flag && !c->snap_long && !c->no_memo && !c->force_wave && A.wins && A.rmodels && c->snap.memo &&
+                          n >= (c->memo_from >= 0 ? c->memo_from : (caller ? kMemoFromC : kMemoFrom));
     HIP_TRY(c, order_after_registry(c, st));
     if (segs) {  // several request arrays, one launch (multi_kernel.hpp); n = the decisions of all of them
         if (c->snap_long && n >= kLongDenseFrom)
@@ -590,6 +591,8 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
         hipLaunchKernelGGL(place_batch_long4_c_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *caller);
     else if (caller && c->snap_long)
         hipLaunchKernelGGL(place_batch_long_c_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *caller);
+    else if (use_memo && !caller)
+        hipLaunchKernelGGL(place_batch_m_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad);
     else if (use_memo)
         hipLaunchKernelGGL(place_batch_c_m_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *caller);
     else if (caller)

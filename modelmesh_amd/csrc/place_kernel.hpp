@@ -2313,7 +2313,13 @@ __device__ __forceinline__ bool memo_try(const Snap &S, const PlaceArgs &A, cons
     return true;
 }
 
-template <bool WITH_LONG, int FORM = kReq64, bool MEMO = false>
+// NOBAR (the kernels with the shortlist check in front: place_batch_m_kernel, place_batch_c_m_kernel): no workgroup barrier at all —
+// the head windows are read from global memory (a few L1-resident rows) instead of being staged in LDS by the workgroup, and a
+// wavefront keeps the general path's list for itself.  A wavefront whose requests the shortlists all cover then neither waits for
+// the staging nor, at the end, for the lane phase of the workgroup's other wavefronts (with the barriers the check bought nothing
+// for request rows: 27.4 against 25.9 us; without them 24.7).  The kernels WITHOUT the check keep staging + barrier: for them the
+// windows in LDS are the faster read (800k rows: 26.0 against 26.5 us, four streams 17.75 against 18.4).
+template <bool WITH_LONG, int FORM = kReq64, bool MEMO = false, bool NOBAR = false>
 __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, int32_t wpad, unsigned char *smem,
                                             uint32_t *done_blocks = nullptr, const mmp_place_caller &C = mmp_place_caller{})
 {
@@ -2331,11 +2337,12 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
     // The windows are fetched beside the request (they depend on nothing) and parked in LDS while the
     // request -> model row chain is in flight; the barrier below is the one the lists needed anyway.
     const bool use_wins = A.wins != nullptr;  // wave-uniform
+    const TypeWin *Ws = NOBAR ? A.wins : s_wins;
     // global -> LDS directly (global_load_lds_dwordx4: no staging registers), one 1 KB chunk per wavefront and
     // trip: lane l of the wavefront that takes chunk c moves bytes [1024 c + 16 l, +16).  The window table is
     // allocated for kWinLds rows, so whole chunks are always in bounds.
     constexpr int kWinBytes = (int)sizeof(TypeWin);
-    if (use_wins) {
+    if (use_wins && !NOBAR) {
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         const int chunks = ((S.T < kWinLds ? S.T : kWinLds) * kWinBytes + 1023) >> 10;
         const char *src = reinterpret_cast<const char *>(A.wins);
@@ -2395,11 +2402,14 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
         Bt.pcs = A.bpcs;
         Bt.launch = A.bwin;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (!NOBAR) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     // the type's recorded shortlist first (TypeMemo): a wavefront whose requests are all covered is done here
     if (MEMO && live && memo_try<FORM>(S, A, rq, d)) live = false;
     ResolvedReq r;
+    int wcode = 0;  // (NOBAR) this lane's decision is left to the general path
     if (live) r = resolve_req<false, true>(S, A, rq);
     PHASE(0);  // request + model row resolved
     if (live) {
@@ -2409,7 +2419,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
             merge_late_extras(r);
             code = lane_decide_r<false, true>(Sl, A, r, o, Bt);
         } else {
-            if (use_wins) code = lane_decide_win(S, A, r, s_wins, s_scr + threadIdx.x, o);
+            if (use_wins) code = lane_decide_win(S, A, r, Ws, s_scr + threadIdx.x, o);
             if (code == kLaneHeadMiss) {
                 merge_late_extras(r);
                 code = lane_decide_r<false>(S, A, r, o, Bt);
@@ -2417,12 +2427,33 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
         }
         if (WITH_LONG && (code == kLaneLong || code == kLaneCaseB))
             lr_list[atomicAdd(&lr_n, 1)] = d;
-        else if (code != kLaneDone)
-            fb_list[atomicAdd(&fb_n, 1)] = d;
-        else
+        else if (code != kLaneDone) {
+            if (NOBAR)
+                wcode = 1;
+            else
+                fb_list[atomicAdd(&fb_n, 1)] = d;
+        } else
             A.outs[d] = o;
     }
     PHASE(8);  // the whole lane phase of this wavefront (incl. the result store)
+    if (NOBAR) {  // the general path for this wavefront's own leftovers, a decision at a time
+        const uint64_t fb = __ballot(wcode != 0);
+        if (fb) {
+            const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            int32_t *mine = fb_list + wave * 64;
+            if (wcode) mine[__popcll((unsigned long long)(fb & ((1ull << lane_id()) - 1ull)))] = d;
+            wave_sync();
+            uint64_t *ew = reinterpret_cast<uint64_t *>(smem) + (size_t)wave * 2 * wpad;
+            uint64_t *fw = ew + wpad;
+            const int nf = __popcll((unsigned long long)fb);
+            for (int i = 0; i < nf; i++) {
+                const int fd = __builtin_amdgcn_readfirstlane(mine[i]);
+                place_one<FORM>(S, A, fd, ew, fw, C);
+                wave_sync();
+            }
+        }
+        return;
+    }
     __syncthreads();
     PHASE(9);  // waiting for the workgroup's other wavefronts
     // the decisions whose shortlist spans many words: again one lane each, this time through the prefix tables
@@ -2557,20 +2588,30 @@ __global__ __launch_bounds__(64) void build_memo_kernel(Snap S, const TypeWin *_
     }
 }
 
-// The single-caller window kernel with the recorded shortlists in front (place_block<..., MEMO>; see TypeMemo).  One caller means one
-// position of "self" for the whole batch, so a request leaves the shortlist only through its model's instances or its own exclusions
-// (C3: 0.6 % + the few whose exclusions fall into the list): two wavefronts in three decide all 64 requests from the record and skip the
-// lane phase.  Measured, C3, 800 000 decisions of one caller per launch (tools/r5/memo_sweep.py, profiles/r5/shortlist_experiments):
-// 19.0 -> 17.0 us on one stream, 12.3 -> 10.3 us per launch on four; 1.6 M: 34.7 -> 30.2 us; at 400 000 the two meet (12.2 / 11.4 us),
-// below that the prefix is the longer chain — hence kMemoFrom.  Batches of request ROWS (a caller per request: one request in 80 has its
-// own caller inside the list, so every second wavefront runs the lane phase anyway) gain nothing from it and keep place_batch_kernel.
+// The window kernels with the recorded shortlists in front (place_block<..., MEMO, NOBAR>; see TypeMemo): a wavefront whose 64 requests
+// are all covered is done after ~150 instructions and no barrier.  One caller per batch (place_batch_c_m_kernel) means one position of
+// "self" for the whole batch, so a request leaves the shortlist only through its model's instances or its own exclusions (C3: 0.65 %):
+// two wavefronts in three skip the lane phase.  Request rows (place_batch_m_kernel) bring a caller per request — 1.3 % leave, every
+// second wavefront runs the lane phase behind the check.  Measured, C3, per launch on one stream / on four (tools/r5/memo_sweep.py,
+// profiles/r5/shortlist_experiments): 800k of one caller 19.0 -> 15.2 us / 12.3 -> 9.2 us (87 G decisions/s); 800k rows 26.0 -> 24.7 us /
+// 17.75 -> 16.45 us; 1.6 M rows 43.5 -> 41.0 / 35.1 -> 32.4; 400k rows 15.7 -> 13.7 / 8.7 -> 8.4; at 200k the two meet and below the check is
+// the longer chain — hence kMemoFrom.  7 wavefronts per SIMD for both (rows at 6: 25.0 / 17.7 us).
 __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(MMP_C_WAVES, MMP_C_WAVES))) void place_batch_c_m_kernel(Snap S, PlaceArgs A, int32_t wpad,
                                                                                                               mmp_place_caller C)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    place_block<false, kReqC, true>(S, A, wpad, smem, nullptr, C);
+    place_block<false, kReqC, true, true>(S, A, wpad, smem, nullptr, C);
 }
-constexpr int kMemoFrom = 6 * 1024 * 64;  // decisions from which a single-caller batch takes the kernel with the shortlists in front (one round of the chip at 6 wavefronts per SIMD)
+__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void place_batch_m_kernel(Snap S, PlaceArgs A, int32_t wpad)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    place_block<false, kReq64, true, true>(S, A, wpad, smem);
+}
+// decisions from which a batch takes the kernel with the shortlists in front (measured, C3, one stream / four streams, per launch:
+// rows 200k 10.2 -> 10.1 / 5.8 -> 5.95 us, 400k 15.8 -> 13.55 / 8.8 -> 8.4; one caller 100k 7.2 -> 7.1 / 4.2 -> 4.1, 200k 9.15 -> 8.4 / 4.96 -> 5.04,
+// 400k 12.3 -> 10.4 / 6.6 -> 6.1; below, the check is the longer chain — a 100k launch of rows: 7.75 -> 8.6 us)
+constexpr int kMemoFrom = 4 * 1024 * 64;      // request rows
+constexpr int kMemoFromC = 3 * 512 * 64;      // the single-caller form
 
 __global__ __launch_bounds__(kPlaceBlock) void place_batch_long_c_kernel(Snap S, PlaceArgs A, int32_t wpad, mmp_place_caller C)
 {

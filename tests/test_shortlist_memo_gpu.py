@@ -1,7 +1,8 @@
-"""GPU: single-caller batches decided with the per-type shortlists a commit records (place_kernel.hpp: TypeMemo, memo_try,
-place_batch_c_m_kernel; include/mmplace.h: mmp_shortlists) equal the oracle AND the same context with the shortlists switched off
-(MMP_NO_MEMO=1: every request on the ordinary lane path) — on the bench configuration, on fuzzed fleets of every profile
-(MMP_MEMO_FROM=0 sends single-caller batches of every size through that kernel; by default it takes launches that fill the chip);
+"""GPU: batches — of one caller and of request rows — decided with the per-type shortlists a commit records (place_kernel.hpp:
+TypeMemo, memo_try, place_batch_c_m_kernel / place_batch_m_kernel; include/mmplace.h: mmp_shortlists) equal the oracle AND the same
+context with the shortlists switched off (MMP_NO_MEMO=1: every request on the ordinary lane path) — on the bench configuration, on
+fuzzed fleets of every profile (MMP_MEMO_FROM=0 sends batches of every size through those kernels; by default they take launches that
+fill the chip);
 on batches built so that EVERY request has a position of its own inside its shortlist (the calling instance, a model's loaded
 instance, a request's own exclusion: the check must send them all down the ordinary path); and across commits and registry events
 that move the shortlists (the block bits of the resolved registry view are rebuilt)."""
@@ -100,6 +101,10 @@ def test_bench_configuration_is_covered_and_exact():
         place_as_caller(s, orc, fleet, one_caller(fleet, reqs, 9000, drift=10**9), extra, "a caller that is full by its fresh record")
         for n in (70_001, 1500):
             place_as_caller(s, orc, fleet, one[:n], extra, f"n={n}")
+        # request rows, a caller per request (place_batch_m_kernel)
+        assert covered_share(s, fleet, orc, reqs, extra) > 0.97
+        _same(s.place(reqs, extra, fleet.now), orc.place(reqs, extra, fleet.now, threads=8), "request rows")
+        _same(s.place(reqs[:70_001], extra, fleet.now), orc.place(reqs[:70_001], extra, fleet.now, threads=8), "request rows, n=70001")
     finally:
         s.close()
 
@@ -114,15 +119,17 @@ def test_fuzzed_fleets_with_and_without_the_shortlists(seed, profile, monkeypatc
     callers = [int(orc.order[0]), int(orc.order[min(5, len(orc.order) - 1)]), int(rng.integers(0, fleet.n_pods)), -1]
     batches = [one_caller(fleet, reqs, p, favour=j & 1, drift=(0, 90_000)[j >> 1 & 1], rpm=(0, 180)[j % 3 == 0],
                           lru=None if j % 2 else fleet.now - 50_000) for j, p in enumerate(callers)]
+    batches.append(reqs)  # and the rows as they came: a caller per request
     want = [orc.place(b, extra, fleet.now, threads=8) for b in batches]
     for env in ({}, {"MMP_NO_MEMO": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         s = _solver(fleet)
         try:
-            for b, w in zip(batches, want):
+            for b, w in zip(batches[:-1], want[:-1]):
                 caller, rc = _lib.split_caller(b)
                 _same(s.place_c(caller, rc, extra, fleet.now), w, env or "shortlists")
+            _same(s.place(batches[-1], extra, fleet.now), want[-1], ("rows", env or "shortlists"))
         finally:
             s.close()
 
@@ -162,6 +169,13 @@ def test_requests_with_a_position_inside_their_shortlist_take_the_ordinary_path(
     try:
         for j, p in enumerate(callers):
             place_as_caller(s, orc, fleet, one_caller(fleet, reqs, p, favour=j & 1), extra, (how, p))
+        if how in ("self", "mixed"):  # rows: every request (self) / every second one (mixed) called by an instance at the head
+            sel = np.ones(n, bool) if how == "self" else rng.random(n) < 0.5
+            reqs["self_pod"] = np.where(sel, rng.choice(head, n), reqs["self_pod"])
+            row = fleet.pods[reqs["self_pod"]]
+            for f, g in (("fresh_lru", "lru_time"), ("fresh_capacity", "capacity"), ("fresh_used", "used"), ("fresh_count", "count")):
+                reqs[f] = row[g]
+        _same(s.place(reqs, extra, fleet.now), orc.place(reqs, extra, fleet.now, threads=8), (how, "rows"))
     finally:
         s.close()
 

@@ -47,7 +47,7 @@ sts = [st] + [torch.cuda.Stream(dev) for _ in range(3)]
 K = 200
 ref = {}
 for env in VARIANTS:
-    for k in ("MMP_NO_MEMO", "MMP_MEMO_FROM", "MMP_MEMO_TRAIL"):
+    for k in ("MMP_NO_MEMO", "MMP_MEMO_FROM", "MMP_MEMO_TRAIL", "MMP_MEMO_ROWS"):
         os.environ.pop(k, None)
     os.environ.update(env)
     s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
@@ -91,6 +91,6 @@ for env in VARIANTS:
             same = "identical" if torch.equal(outs, ref[n]) else f"DIFFERENT ({int((outs != ref[n]).view(-1, 16).any(1).sum())} rows)"
         else:
             ref[n] = outs.clone()
-        print(f"{tag:36s} n {n:9d}  {us:7.2f} us per launch  {n / us / 1e3:6.2f} G/s  hbm_only {n * (40 if FORM_C else 80) / us / 1e3 / 8000:5.3f}  "
+        print(f"{tag:40s} n {n:9d}  {us:7.2f} us per launch  {n / us / 1e3:6.2f} G/s  hbm_only {n * (40 if FORM_C else 80) / us / 1e3 / 8000:5.3f}  "
               f"4 streams {us4:6.2f} us per launch {n / us4 / 1e3:6.2f} G/s  results {same}", flush=True)
     s.close()
