@@ -1452,7 +1452,9 @@ def main():
         value = total / elapsed
         alg = int(np.mean([algorithmic_bytes(fleet, bq[0]) for bq in batches[:4]]))
         kb = int(np.mean([kernel_bytes(fleet, bq[0]) for bq in batches[:4]]))
-        traffic, traffic_prov = measured_traffic(args.workload, n)
+        # launches from 262 144 decisions on take the kernel with the per-type shortlists in front (place_kernel.hpp: kMemoFrom)
+        kname = "place_batch_m_kernel" if n >= 262_144 and os.environ.get("MMP_NO_MEMO") != "1" else "place_batch_kernel"
+        traffic, traffic_prov = measured_traffic(args.workload, n, kernel=kname)
         # roofline of the dominant kernel: bytes it has to move per launch (measured by the PMC passes when a
         # summary is committed, else the compulsory streams) / its average launch duration / the HBM peak
         moved = traffic if traffic else kb
@@ -1474,7 +1476,7 @@ def main():
                        "host_issue_us_per_step": None if issue_s is None else issue_s / args.steps * 1e6},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_provenance": traffic_prov,
-                         "kernel": "place_batch_kernel", "kernel_ms": gpu_ms_per_step,
+                         "kernel": kname, "kernel_ms": gpu_ms_per_step,
                          "kernel_ms_per_launch_event_pairs": kern_ms,
                          "bytes_per_launch": moved,
                          "bytes_per_launch_source": "rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE (profiles/)" if traffic else

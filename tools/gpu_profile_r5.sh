@@ -28,11 +28,11 @@ if [ -n "${PROFILE_ONLY:-}" ]; then  # one configuration again (after a script f
   profile_one $PROFILE_ONLY
   exit 0
 fi
-profile_one C3_800k place_batch_kernel --workload C3
+profile_one C3_800k place_batch_m_kernel --workload C3   # (launches from 262 144 decisions on: the kernel with the shortlists in front)
 profile_one C3_100k place_batch_kernel --workload C3 --decisions-per-step 100000
 profile_one C3_full_cluster_100k place_batch_long_kernel --workload C3 --decisions-per-step 100000 --full-cluster
 profile_one C3_full_cluster_800k place_batch_long4_kernel --workload C3 --full-cluster   # (launches of >= 196 608 decisions take the 4-wavefront instantiation)
-[[ "${PROFILE_WORKLOADS:-C3 C4}" == *C4* ]] && profile_one C4 place_batch_kernel --workload C4
+[[ "${PROFILE_WORKLOADS:-C3 C4}" == *C4* ]] && profile_one C4 place_batch_m_kernel --workload C4
 
 # two overlapping streams (the timed region's shape): kernel stats only
 rm -rf /tmp/p_2s
@@ -64,7 +64,7 @@ digest gate_batch_kernel gate_batch_kernel_800k 500000 2000000
 digest evict_batch_kernel evict_batch_kernel_800k 3000000 1000000000
 digest route_batch_kernel route_batch_kernel 50000 400000
 digest route_batch_kernel route_batch_kernel_800k 500000 2000000
-digest place_batch_c_kernel place_batch_c_kernel_800k 500000 2000000   # the single-caller kernel (bench.py: single_caller leg)
+digest place_batch_c_m_kernel place_batch_c_kernel_800k 500000 2000000   # the single-caller kernel (bench.py: single_caller leg)
 
 # the bench lines: the driver's flags, then the defaults; C4
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_C3_n1_steps20.json.log 2> $OUT/bench_C3_steps20.err; echo "bench(20) exit $?"
