@@ -557,6 +557,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_single_lean_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(miss_single_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_multi_m_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_multi_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_multi_long4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
@@ -568,7 +569,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     }
     // batches with the per-type shortlists in front (place_batch_m_kernel / place_batch_c_m_kernel): head windows and the resolved registry
     // view in place, not the full-cluster regime (its shortlists span the table), none of the diagnostic routes, a launch that fills the chip
-    const bool use_memo = !segs && !inline_req && !done_flag && !c->snap_long && !c->no_memo && !c->force_wave && A.wins && A.rmodels && c->snap.memo &&
+    const bool use_memo = !inline_req && !done_flag && !c->snap_long && !c->no_memo && !c->force_wave && A.wins && A.rmodels && c->snap.memo &&
                           n >= (c->memo_from >= 0 ? c->memo_from : (caller ? kMemoFromC : kMemoFrom));
     HIP_TRY(c, order_after_registry(c, st));
     if (segs) {  // several request arrays, one launch (multi_kernel.hpp); n = the decisions of all of them
@@ -576,6 +577,8 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
             hipLaunchKernelGGL(place_multi_long4_kernel, dim3(seg_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *segs);
         else if (c->snap_long)
             hipLaunchKernelGGL(place_multi_long_kernel, dim3(seg_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *segs);
+        else if (use_memo)
+            hipLaunchKernelGGL(place_multi_m_kernel, dim3(seg_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *segs);
         else
             hipLaunchKernelGGL(place_multi_kernel, dim3(seg_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *segs);
     } else if (inline_req && fused_gate)  // one cache-miss route: the guards beside the load target (multi_kernel.hpp)
@@ -1754,8 +1757,8 @@ try {
         L2.nb_finish = div_up(std::max(N.n_pts, T), 64);
         hipLaunchKernelGGL(commit_level2_kernel, dim3(4 * T + L2.nb_finish), dim3(64), 0, st, L2);
         hipLaunchKernelGGL(build_sel_kernel, dim3(2 * T * W), dim3(64), 0, st, S, B.sel.as<int32_t>(), B.rk.as<int32_t>());
-        // the per-type shortlists (TypeMemo) from the finished head windows; the registry view below is resolved against them
-        HIP_TRY(c, hipMemsetAsync(B.memo.p, 0, (size_t)kWinLds * sizeof(TypeMemo), st));
+        // the per-type shortlists (TypeMemo) from the finished head windows (every row a decision can name is written, valid or
+        // not); the registry view below is resolved against them
         hipLaunchKernelGGL(build_memo_kernel, dim3(std::min(T, kWinLds)), dim3(64), 0, st, S, B.heads.as<TypeWin>(), B.memo.as<TypeMemo>(),
                            B.memo_cand.as<int32_t>());
         // the running minimum of the case (b) candidates' rpm, then the survivor bitmaps of the rpm rule's four limits

@@ -45,6 +45,13 @@ __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(6, 
     const PlaceArgs As = segment_args(A, G);
     place_block<false>(S, As, wpad, smem);
 }
+// ... with the per-type shortlists checked first and no workgroup barrier (place_batch_m_kernel's workgroup; launches of >= kMemoFrom decisions)
+__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(7, 7))) void place_multi_m_kernel(Snap S, PlaceArgs A, int32_t wpad, PlaceSegs G)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const PlaceArgs As = segment_args(A, G);
+    place_block<false, kReq64, true, true>(S, As, wpad, smem);
+}
 __global__ __launch_bounds__(kPlaceBlock) void place_multi_long_kernel(Snap S, PlaceArgs A, int32_t wpad, PlaceSegs G)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

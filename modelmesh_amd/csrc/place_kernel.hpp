@@ -2590,12 +2590,14 @@ __global__ __launch_bounds__(64) void build_memo_kernel(Snap S, const TypeWin *_
 
 // The window kernels with the recorded shortlists in front (place_block<..., MEMO, NOBAR>; see TypeMemo): a wavefront whose 64 requests
 // are all covered is done after ~150 instructions and no barrier.  One caller per batch (place_batch_c_m_kernel) means one position of
-// "self" for the whole batch, so a request leaves the shortlist only through its model's instances or its own exclusions (C3: 0.65 %):
-// two wavefronts in three skip the lane phase.  Request rows (place_batch_m_kernel) bring a caller per request — 1.3 % leave, every
-// second wavefront runs the lane phase behind the check.  Measured, C3, per launch on one stream / on four (tools/r5/memo_sweep.py,
-// profiles/r5/shortlist_experiments): 800k of one caller 19.0 -> 15.2 us / 12.3 -> 9.2 us (87 G decisions/s); 800k rows 26.0 -> 24.7 us /
-// 17.75 -> 16.45 us; 1.6 M rows 43.5 -> 41.0 / 35.1 -> 32.4; 400k rows 15.7 -> 13.7 / 8.7 -> 8.4; at 200k the two meet and below the check is
-// the longer chain — hence kMemoFrom.  7 wavefronts per SIMD for both (rows at 6: 25.0 / 17.7 us).
+// "self" for the whole batch, so a request leaves the shortlist only through its model's instances or its own exclusions (C3: 0.65 % for a
+// caller with room, two wavefronts in three skip the lane phase; a FULL caller's fresh-row test fires, its shortlists are the best
+// instance alone and nearly every wavefront is covered).  Request rows (place_batch_m_kernel) bring a caller per request — 1.3 % leave,
+// every second wavefront runs the lane phase behind the check.  Measured, C3, per launch on one stream / on four (tools/r5/memo_sweep.py,
+// profiles/r5/shortlist_experiments): 800k of one caller with room 19.9 -> 17.7 us / 12.6 -> 11.1 us (72 G decisions/s), of a full caller
+// 20.0 -> 15.3 us / 12.7 -> 9.3 us (86 G decisions/s); 800k rows 25.9 -> 24.7 us / 17.7 -> 16.7 us; 1.6 M rows 43.4 -> 41.2 / 35.2 -> 32.6; 400k
+// rows 15.8 -> 13.55 / 8.8 -> 8.4; at 200k the two meet and below the check is the longer chain — hence kMemoFrom.  7 wavefronts per SIMD
+// for both (rows at 6: 25.0 / 17.7 us).
 __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(MMP_C_WAVES, MMP_C_WAVES))) void place_batch_c_m_kernel(Snap S, PlaceArgs A, int32_t wpad,
                                                                                                               mmp_place_caller C)
 {
@@ -2608,10 +2610,10 @@ __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(7, 
     place_block<false, kReq64, true, true>(S, A, wpad, smem);
 }
 // decisions from which a batch takes the kernel with the shortlists in front (measured, C3, one stream / four streams, per launch:
-// rows 200k 10.2 -> 10.1 / 5.8 -> 5.95 us, 400k 15.8 -> 13.55 / 8.8 -> 8.4; one caller 100k 7.2 -> 7.1 / 4.2 -> 4.1, 200k 9.15 -> 8.4 / 4.96 -> 5.04,
-// 400k 12.3 -> 10.4 / 6.6 -> 6.1; below, the check is the longer chain — a 100k launch of rows: 7.75 -> 8.6 us)
+// rows 200k 10.2 -> 10.1 / 5.8 -> 5.95 us, 400k 15.8 -> 13.55 / 8.8 -> 8.4; one caller 200k 9.15 -> 8.4 / 4.96 -> 5.04 (a full caller), 400k
+// 12.7 -> 11.35 / 6.9 -> 6.7 (a caller with room); below, the check is the longer chain — a 100k launch of rows: 7.75 -> 8.6 us)
 constexpr int kMemoFrom = 4 * 1024 * 64;      // request rows
-constexpr int kMemoFromC = 3 * 512 * 64;      // the single-caller form
+constexpr int kMemoFromC = 3 * 1024 * 64;     // the single-caller form
 
 __global__ __launch_bounds__(kPlaceBlock) void place_batch_long_c_kernel(Snap S, PlaceArgs A, int32_t wpad, mmp_place_caller C)
 {

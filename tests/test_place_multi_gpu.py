@@ -20,10 +20,14 @@ def _dev(arr):
     return torch.from_numpy(a.view(np.uint8).reshape(-1)).to(torch.device("cuda", 0))
 
 
+@pytest.mark.parametrize("memo_from", [None, "0"], ids=["default", "MMP_MEMO_FROM=0"])
 @pytest.mark.parametrize("full", [False, True])
 @pytest.mark.parametrize("sizes", [[1, 255, 256, 257, 0, 3000], [5000] * 19, [100_000, 17, 100_000]])
-def test_multi_equals_the_separate_calls_and_the_oracle(full, sizes):
+def test_multi_equals_the_separate_calls_and_the_oracle(full, sizes, memo_from, monkeypatch):
+    """(MMP_MEMO_FROM=0: launches of every size through place_multi_m_kernel, the per-type shortlists checked first)"""
     import torch
+    if memo_from is not None:
+        monkeypatch.setenv("MMP_MEMO_FROM", memo_from)
     fleet = wl.make_fleet("C2")
     if full:
         wl.make_full_cluster(fleet)

@@ -36,8 +36,10 @@ for b in range(6):
     rq = np.concatenate(parts)
     ex = np.concatenate(ex_parts)
     if FORM_C:
-        for f in ("self_pod", "flags", "fresh_lru", "fresh_capacity", "fresh_used", "fresh_count", "fresh_rpm"):
-            rq[f] = rq[f][17]
+        CALLER = int(os.environ.get("MEMO_SWEEP_CALLER", "17"))  # pod 17 is FULL on C3 (its shortlists are the best instance alone); 4321 has room
+        row = fleet.pods[CALLER]
+        rq["self_pod"], rq["flags"], rq["fresh_rpm"] = CALLER, 0, 0
+        rq["fresh_lru"], rq["fresh_capacity"], rq["fresh_used"], rq["fresh_count"] = row["lru_time"], row["capacity"], row["used"], row["count"]
         caller, rq = _lib.split_caller(rq)
     bufs.append((torch.from_numpy(rq.view(np.uint8).reshape(-1)).to(dev), torch.from_numpy(np.ascontiguousarray(ex)).to(dev),
                  torch.zeros(nmax * 16, dtype=torch.uint8, device=dev), len(ex)))
