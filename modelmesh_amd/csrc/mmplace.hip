@@ -1756,11 +1756,10 @@ try {
         L2.tstats = N.tstats.as<StatsAcc>();
         L2.nb_finish = div_up(std::max(N.n_pts, T), 64);
         hipLaunchKernelGGL(commit_level2_kernel, dim3(4 * T + L2.nb_finish), dim3(64), 0, st, L2);
-        hipLaunchKernelGGL(build_sel_kernel, dim3(2 * T * W), dim3(64), 0, st, S, B.sel.as<int32_t>(), B.rk.as<int32_t>());
-        // the per-type shortlists (TypeMemo) from the finished head windows (every row a decision can name is written, valid or
-        // not); the registry view below is resolved against them
-        hipLaunchKernelGGL(build_memo_kernel, dim3(std::min(T, kWinLds)), dim3(64), 0, st, S, B.heads.as<TypeWin>(), B.memo.as<TypeMemo>(),
-                           B.memo_cand.as<int32_t>());
+        // sel / rk from the prefix tables, and the per-type shortlists (TypeMemo) from the finished head windows (every row a decision
+        // can name is written, valid or not): one launch; the registry view below is resolved against the shortlists' ranges
+        hipLaunchKernelGGL(build_sel_memo_kernel, dim3(2 * T * W + std::min(T, kWinLds)), dim3(64), 0, st, S, B.sel.as<int32_t>(), B.rk.as<int32_t>(),
+                           B.heads.as<TypeWin>(), B.memo.as<TypeMemo>(), B.memo_cand.as<int32_t>());
         // the running minimum of the case (b) candidates' rpm, then the survivor bitmaps of the rpm rule's four limits
         hipLaunchKernelGGL(prefix_min_rpm_kernel, dim3(kBSlots), dim3(64), 0, st, S, B.bslots.as<BSlot>(), n_bslots_dev, B.bpm.as<int32_t>(),
                            (int32_t)(W * 64));

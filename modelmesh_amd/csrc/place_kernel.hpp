@@ -138,7 +138,7 @@ static_assert(kGeRows % 2 == 0, "ct + pad_ keep the rows 16-byte aligned");
 // order of thousands.  For every other request of the type the walk — first eligible instance, preference step, break scans,
 // count, audit hash — yields one of TWO shortlists, selected by the fresh-row test of MM.java:4913-4922 (which compares the
 // CALLER's fresh record with the best instance: one bit per request).  commit() runs lane_decide_win once per (type, bit) with no
-// exclusions (build_memo_kernel) and keeps: the positions the result depends on [lo, hi), the candidates' count and audit-hash
+// exclusions (build_sel_memo_kernel: build_memo_body) and keeps: the positions the result depends on [lo, hi), the candidates' count and audit-hash
 // sum, the best row's fields the rpm rule reads, and the candidates' pod indices in shortlist order (Snap::memo_cand).  memo_try
 // decides a request by CHECKING that none of its positions falls into [lo, hi) — the model's exclusions were checked when its
 // registry row was resolved (ResolvedModel::type, bits kMemoBlk) — and applying the rpm rule and the pick to the recorded list; a
@@ -628,10 +628,10 @@ __global__ __launch_bounds__(64) void commit_level2_kernel(CommitL2 A)
 // pm[slot][p] = min rpm over the preferred eligible positions in (best0, p]; INT32_MAX before the first one.
 // One wavefront per slot, 64 positions per step.
 // sel / rk (Snap): one wavefront per 64-position word of a candidate bitmap row (variant 0: elig, 1: elig & pref), a lane per position
-__global__ __launch_bounds__(64) void build_sel_kernel(Snap S, int32_t *__restrict__ sel, int32_t *__restrict__ rk)
+__device__ __forceinline__ void build_sel_body(int bid, const Snap &S, int32_t *__restrict__ sel, int32_t *__restrict__ rk)
 {
     const int W = S.W, T = S.T;
-    const int row = blockIdx.x / W, w = blockIdx.x - row * W;  // row = variant * T + type
+    const int row = bid / W, w = bid - row * W;  // row = variant * T + type
     const int type = row >= T ? row - T : row;
     uint64_t v = S.elig[(size_t)type * W + w];
     if (row >= T) v &= S.pref[(size_t)type * W + w];
@@ -1697,7 +1697,7 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
 // VIEW: S is a pod-axis shard's view of its slice (windows built over the view by the sharded commit): positions are local, the
 // audit hash takes the GLOBAL word index, and a shortlist that reaches the end of a slice with more slices behind it is not the
 // window's to answer (kLaneHeadMiss; lane_decide_r<true> then reports kLaneIncomplete).
-// What build_memo_kernel takes out of lane_decide_win<…, MEMO> (see TypeMemo): the walk's result for a request WITHOUT
+// What build_memo_body takes out of lane_decide_win<…, MEMO> (see TypeMemo): the walk's result for a request WITHOUT
 // exclusions or a caller's entry in reach, with the fresh-row break (MM.java:4913-4922) forced to `nsb`.
 struct MemoCap {
     int nsb;
@@ -2532,13 +2532,15 @@ __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(MMP
 // ---- per-type shortlists: build (commit) and use (see TypeMemo) ------------------------------------------------------------------
 // One wavefront per type row: lanes 0 / 1 run lane_decide_win on the type's window for a request without exclusions and without a
 // caller's entry, the fresh-row break off / on; then the wavefront writes the candidates' pod indices in shortlist order.
-__global__ __launch_bounds__(64) void build_memo_kernel(Snap S, const TypeWin *__restrict__ wins, TypeMemo *__restrict__ memo,
-                                                        int32_t *__restrict__ cand)
+// (the last blocks of build_sel_memo_kernel: one launch builds sel / rk and the shortlists — both need only what level 2 left)
+__device__ __forceinline__ void build_memo_body(int t, const Snap &S, const TypeWin *__restrict__ wins, TypeMemo *__restrict__ memo,
+                                                int32_t *__restrict__ cand)
 {
-    __shared__ uint64_t scr[kWinWords * kPlaceBlock];
+    constexpr int kScr = 2;  // scratch columns: the two lanes that decide
+    __shared__ uint64_t scr[kWinWords * kScr];
     __shared__ MemoCap caps[2];
     __shared__ int ok[2];
-    const int t = blockIdx.x, lane = lane_id();
+    const int lane = lane_id();
     if (lane < 2) {
         PlaceArgs A{};
         ResolvedReq r{};
@@ -2552,7 +2554,7 @@ __global__ __launch_bounds__(64) void build_memo_kernel(Snap S, const TypeWin *_
         MemoCap mc{};
         mc.nsb = lane;
         mmp_place_out o;
-        const int code = lane_decide_win<false, true>(S, A, r, wins, scr + lane, o, &mc);
+        const int code = lane_decide_win<false, true, kScr>(S, A, r, wins, scr + lane, o, &mc);
         caps[lane] = mc;
         ok[lane] = code == kLaneDone && mc.ccount <= kMemoCand;
     }
@@ -2581,11 +2583,20 @@ __global__ __launch_bounds__(64) void build_memo_kernel(Snap S, const TypeWin *_
         int32_t *out = cand + ((size_t)t * 2 + v) * kMemoCand;
         int running = 0;
         for (int w = caps[v].wlo; w <= caps[v].whi; w++) {
-            const uint64_t word = scr[v + (w - w0) * kPlaceBlock];  // the walk parked the clipped candidate words here (best bit set)
+            const uint64_t word = scr[v + (w - w0) * kScr];  // the walk parked the clipped candidate words here (best bit set)
             if ((word >> lane) & 1ull) out[running + __popcll((unsigned long long)(word & ((1ull << lane) - 1ull)))] = S.orig[w * 64 + lane];
             running += __popcll((unsigned long long)word);
         }
     }
+}
+__global__ __launch_bounds__(64) void build_sel_memo_kernel(Snap S, int32_t *__restrict__ sel, int32_t *__restrict__ rk, const TypeWin *__restrict__ wins,
+                                                            TypeMemo *__restrict__ memo, int32_t *__restrict__ cand)
+{
+    const int n_sel = 2 * S.T * S.W;
+    if ((int)blockIdx.x < n_sel)
+        build_sel_body((int)blockIdx.x, S, sel, rk);
+    else
+        build_memo_body((int)blockIdx.x - n_sel, S, wins, memo, cand);
 }
 
 // The window kernels with the recorded shortlists in front (place_block<..., MEMO, NOBAR>; see TypeMemo): a wavefront whose 64 requests
