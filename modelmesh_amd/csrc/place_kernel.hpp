@@ -2374,7 +2374,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
     // here (beside the request fetch, before the barrier) for launches that fill the chip, where they relieve L2 (-5 % at 800k;
     // a 100k launch is not faster with them: the host decides, PlaceArgs::long_first).
     Snap Sl = S;
-    if (WITH_LONG && A.long_first > 1) {  // wave-uniform
+    if (WITH_LONG && !NOBAR && A.long_first > 1) {  // wave-uniform (the barrier-free instantiation is launched without staged tables)
         unsigned char *tb = smem + (A.long_first - 1);
         const int nE = S.T * S.W, nPC = 2 * S.T * (S.W + 1);
         uint64_t *lE = reinterpret_cast<uint64_t *>(tb), *lP = lE + nE;
@@ -2425,7 +2425,13 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
                 code = lane_decide_r<false>(S, A, r, o, Bt);
             }
         }
-        if (WITH_LONG && (code == kLaneLong || code == kLaneCaseB))
+        if (WITH_LONG && NOBAR && (code == kLaneLong || code == kLaneCaseB)) {  // the prefix-table phase at once, in this lane
+            code = lane_decide<false, true, FORM>(Sl, A, d, o, Bt, C);
+            if (code == kLaneDone)
+                A.outs[d] = o;
+            else
+                wcode = 1;
+        } else if (WITH_LONG && (code == kLaneLong || code == kLaneCaseB))
             lr_list[atomicAdd(&lr_n, 1)] = d;
         else if (code != kLaneDone) {
             if (NOBAR)
@@ -2499,10 +2505,12 @@ __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(MMP
 }
 
 // the same with the long-shortlist phase (see place_block): 144 VGPRs, 3 wavefronts per SIMD
+// (launches below kLongDenseFrom decisions: the per-type tables are never staged in LDS for them, so the workgroup needs no barrier —
+// place_block<..., NOBAR>: no window staging either, which the full-cluster path does not read)
 __global__ __launch_bounds__(kPlaceBlock) void place_batch_long_kernel(Snap S, PlaceArgs A, int32_t wpad)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    place_block<true>(S, A, wpad, smem);
+    place_block<true, kReq64, false, true>(S, A, wpad, smem);
 }
 
 // ... for launches that put more than three wavefronts on a SIMD: 128 VGPRs (88 instead of 48 bytes of spill per lane), 4
@@ -2629,7 +2637,7 @@ constexpr int kMemoFromC = 3 * 1024 * 64;     // the single-caller form
 __global__ __launch_bounds__(kPlaceBlock) void place_batch_long_c_kernel(Snap S, PlaceArgs A, int32_t wpad, mmp_place_caller C)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    place_block<true, kReqC>(S, A, wpad, smem, nullptr, C);
+    place_block<true, kReqC, false, true>(S, A, wpad, smem, nullptr, C);
 }
 __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void place_batch_long4_c_kernel(Snap S, PlaceArgs A, int32_t wpad,
                                                                                                                   mmp_place_caller C)
