@@ -80,7 +80,7 @@ __device__ __forceinline__ void single_place_wave(const Snap &S, PlaceArgs A, in
     TypeWin *s_wins = reinterpret_cast<TypeWin *>(smem);
     uint64_t *s_scr = reinterpret_cast<uint64_t *>(smem + win_lds_bytes(S.T));
     const int lane = lane_id();
-    const bool use_wins = A.wins != nullptr;
+    const bool use_wins = A.wins != nullptr && !A.long_first;  // (a full cluster decides through the prefix tables: the windows are not read)
     if (use_wins) {
         const int chunks = ((S.T < kWinLds ? S.T : kWinLds) * (int)sizeof(TypeWin) + 1023) >> 10;
         const char *src = reinterpret_cast<const char *>(A.wins);
