@@ -157,10 +157,16 @@ struct __attribute__((aligned(16))) MemoVar {
 };
 struct __attribute__((aligned(16))) TypeMemo {
     int64_t b_rem, b_lru;  // the best instance's remaining space and lruTime (the fresh-row test compares against them)
-    int32_t best_is_full, b_rpm, best_idx, pad_;
+    int32_t best_is_full, b_rpm, best_idx;
+    int32_t plain;         // 1: no preference step was taken (the best instance is the type's first eligible one, bestpos == best0)
     MemoVar v[2];          // [fresh-row break does not fire, fires]
+    // Shortlist 0 again as a bitmap — the walk's clipped candidate words (best bit set) of window words [w0, w0 + kWinWords) — and where
+    // it ends (kNoPos: at the end of the table): with them the check also answers a request whose CALLER stands inside the list
+    // (memo_try: "the caller's own entry").
+    uint64_t cw[kWinWords];
+    int32_t w0, end0, pad_[2];
 };
-static_assert(sizeof(TypeMemo) == 96, "TypeMemo is 96 bytes");
+static_assert(sizeof(TypeMemo) == 160, "TypeMemo is 160 bytes");
 
 struct PlaceArgs {
     const mmp_place_req *reqs;
@@ -2288,25 +2294,76 @@ __device__ __forceinline__ bool memo_try(const Snap &S, const PlaceArgs &A, cons
     const MemoVar V = Mp->v[nsb ? 1 : 0];
     const int lo = V.lo;
     const uint32_t len = (uint32_t)(V.hi - lo);
-    bool miss = !t_ok || !V.valid || ((tf >> (kMemoBlkShift + (nsb ? 1 : 0))) & 1) || (uint32_t)(sp - lo) < len;  // (-1 - lo wraps far beyond len)
+    bool miss = !t_ok || !V.valid || ((tf >> (kMemoBlkShift + (nsb ? 1 : 0))) & 1);
 #pragma unroll
-    for (int j = 0; j < kLateExtra; j++) miss |= (uint32_t)(xp[j] - lo) < len;
+    for (int j = 0; j < kLateExtra; j++) miss |= (uint32_t)(xp[j] - lo) < len;  // (-1 - lo wraps far beyond len)
+    // The caller's own entry inside the list.  In the plain case — no preference step, the fresh-row break off — the caller is just
+    // one more candidate of the SAME list (the break rules compare the best instance's row with itself: they cannot fire, MM.java:4909-
+    // 4926 as lane_decide_win has them; the count break reads the snapshot's counts): what changes is favourSelf (:4931), the rpm
+    // rule's classes (:4951-4980: the caller's entry carries the snapshot rpm, "the others" the fresh one) and that choosing it means
+    // ABORT_REQUEST (:4989).  The caller AS the best instance, behind a preference step, or with the fresh-row break on: the lane phase.
+    bool self_in = false;
+    int ks = 0;
+    const bool sp_in = (uint32_t)(sp - lo) < len;
+    if (FORM != kReq64) {
+        miss |= sp_in;  // (one caller per batch: it stands inside the list for all requests or for none — not worth the instructions)
+    } else if (__ballot(sp_in && !miss)) {  // (wave-uniform)
+        if (sp_in && !miss) {
+            const int end0 = Mp->end0;
+            if (nsb || !Mp->plain || sp == lo)
+                miss = true;
+            else if (sp != end0) {  // (the instance that ends the list is not part of it)
+                const int jw = (sp >> 6) - Mp->w0;
+                uint64_t wj = 0;
+                int below = 0;
+#pragma unroll
+                for (int j = 0; j < kWinWords; j++) {
+                    const uint64_t cwj = Mp->cw[j];
+                    if (j < jw) below += __popcll((unsigned long long)cwj);
+                    if (j == jw) wj = cwj;
+                }
+                if ((wj >> (sp & 63)) & 1ull) {
+                    self_in = true;
+                    ks = below + __popcll((unsigned long long)(wj & ((1ull << (sp & 63)) - 1ull)));
+                }
+            }
+        }
+    }
     if (miss) return false;
     const int ccount = V.ccount;
     const int32_t f_rpm = rq.fresh_rpm;
-    // rpm filter, :4951-4980: the best instance and "the others" (fresh rpm, quirks B#2/B#3); no caller's entry in the list
+    mmp_place_out o;
+    o.best = best_idx;
+    if (self_in && (rq.flags & MMP_REQ_FAVOUR_SELF)) {  // :4931-4933
+        o.chosen = MMP_SELF;
+        o.n_candidates = 0;
+        o.hash = 0;
+        A.outs[d] = o;
+        return true;
+    }
+    // rpm filter, :4951-4980: the best instance, the caller's entry (the same snapshot rpm class as the best one here), "the others"
+    // (the fresh rpm, quirks B#2/B#3)
+    const int n_others = ccount - 1 - (self_in ? 1 : 0);
     RpmRule rule;
-    rule.init(age_of(rq.last_used, A.now), f_rpm < b_rpm ? f_rpm : b_rpm);
+    rule.init(age_of(rq.last_used, A.now), (n_others > 0 && f_rpm < b_rpm) ? f_rpm : b_rpm);
     const int32_t lim = rule.limit();
     const bool null0 = ccount >= 2 && b_rpm >= 100 && b_rpm > lim;
-    const bool null_o = ccount >= 2 && f_rpm >= 100 && f_rpm > lim;
-    const int remaining = ccount - (null0 ? 1 : 0) - (null_o ? ccount - 1 : 0);
+    const bool null_s = self_in && null0;
+    const bool null_o = ccount >= 2 && n_others > 0 && f_rpm >= 100 && f_rpm > lim;
+    const int remaining = ccount - (null0 ? 1 : 0) - (null_s ? 1 : 0) - (null_o ? n_others : 0);
     const int index = remaining <= 1 ? 0 : (int)(((uint64_t)rq.pick * (uint64_t)(uint32_t)remaining) >> 32);
-    const int k = null_o ? 0 : index + (null0 ? 1 : 0);
-    mmp_place_out o;
+    int k;
+    if (null_o)
+        k = index == 0 ? 0 : ks;  // survivors: the best instance, then the caller's entry (both or neither: one rpm)
+    else {
+        k = index + (null0 ? 1 : 0);
+        if (null_s && k >= ks) k += 1;
+    }
     o.chosen = MMP_NONE;
-    if (remaining >= 1) o.chosen = S.memo_cand[(type * 2 + (nsb ? 1 : 0)) * kMemoCand + k];
-    o.best = best_idx;
+    if (remaining >= 1) {
+        o.chosen = S.memo_cand[(type * 2 + (nsb ? 1 : 0)) * kMemoCand + k];
+        if (self_in && k == ks) o.chosen = MMP_SELF;  // :4989-4991
+    }
     o.n_candidates = ccount;
     o.hash = V.hash ^ ((uint32_t)remaining * 0x9E3779B1u);
     A.outs[d] = o;
@@ -2576,6 +2633,10 @@ __device__ __forceinline__ void build_memo_body(int t, const Snap &S, const Type
         M.best_is_full = c0.best_is_full;
         M.b_rpm = c0.b_rpm;
         M.best_idx = c0.best_idx;
+        M.plain = c0.bestpos == c0.best0;
+        M.w0 = w0;
+        M.end0 = caps[0].end;
+        for (int j = 0; j < kWinWords; j++) M.cw[j] = (ok[0] && w0 + j >= caps[0].wlo && w0 + j <= caps[0].whi) ? scr[j * kScr] : 0ull;
         for (int v = 0; v < 2; v++) {
             const MemoCap &c = caps[v];
             M.v[v].valid = ok[v];

@@ -175,6 +175,10 @@ def test_requests_with_a_position_inside_their_shortlist_take_the_ordinary_path(
             row = fleet.pods[reqs["self_pod"]]
             for f, g in (("fresh_lru", "lru_time"), ("fresh_capacity", "capacity"), ("fresh_used", "used"), ("fresh_count", "count")):
                 reqs[f] = row[g]
+            # the caller's own entry inside the list is answered by the check itself (memo_try): every class of the rpm rule, favourSelf
+            reqs["fresh_rpm"] = rng.choice(np.array([0, 0, 150, 900, 5000, 2_000_000], np.int32), n)
+            reqs["flags"] = (rng.random(n) < 0.3).astype(np.uint32)
+            reqs["fresh_used"] += np.where(rng.random(n) < 0.3, rng.integers(0, 4_000_000, n), 0)  # (some callers full by their fresh record)
         _same(s.place(reqs, extra, fleet.now), orc.place(reqs, extra, fleet.now, threads=8), (how, "rows"))
     finally:
         s.close()

@@ -16,4 +16,4 @@ one() {
 one C3_800k place_batch_m_kernel --workload C3
 one C3_100k place_batch_kernel --workload C3 --decisions-per-step 100000
 one C3_full_cluster_100k place_batch_long_kernel --workload C3 --decisions-per-step 100000 --full-cluster
-one C3_full_cluster_800k place_batch_long4_kernel --workload C3 --full-cluster
+# one C3_full_cluster_800k place_batch_long4_kernel --workload C3 --full-cluster   (not read by bench.py)
