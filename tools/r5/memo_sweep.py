@@ -16,7 +16,7 @@ from modelmesh_amd import _lib  # noqa: E402
 from modelmesh_amd import workload as wl  # noqa: E402
 from modelmesh_amd.solver import Solver  # noqa: E402
 
-VARIANTS = [{"MMP_NO_MEMO": "1"}, {"MMP_MEMO_FROM": "0"}] + [{"MMP_MEMO_FROM": "0", "MMP_MEMO_TRAIL": t} for t in os.environ.get("MEMO_SWEEP_TRAILS", "").split(",") if t]
+VARIANTS = [{"MMP_NO_MEMO": "1"}, {"MMP_MEMO_FROM": "0"}]
 FORM_C = os.environ.get("MEMO_SWEEP_FORM") == "c"
 ns = [int(x) for x in sys.argv[1:]] or [100_000, 200_000, 400_000, 800_000, 1_600_000]
 fleet = wl.make_fleet("C3")
@@ -49,7 +49,7 @@ sts = [st] + [torch.cuda.Stream(dev) for _ in range(3)]
 K = 200
 ref = {}
 for env in VARIANTS:
-    for k in ("MMP_NO_MEMO", "MMP_MEMO_FROM", "MMP_MEMO_TRAIL", "MMP_MEMO_ROWS"):
+    for k in ("MMP_NO_MEMO", "MMP_MEMO_FROM"):
         os.environ.pop(k, None)
     os.environ.update(env)
     s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
