@@ -80,13 +80,13 @@ struct DevBuf {
 struct SnapBufs {
     DevBuf pods, lru, rem, cnt, rpm, orig, pos_of, elig, elig_nors, pref, has_pref, fullw, ge, pc, ph, nz, heads, bslots, bpm, bwin, bsurv, bpcs;
     DevBuf sel, rk;  // Snap::sel / ::rk
-    DevBuf memo, memo_cand;  // Snap::memo / ::memo_cand (place_kernel.hpp: TypeMemo)
+    DevBuf memo, memo_cand, memo_rk;  // Snap::memo / ::memo_cand / ::memo_rk (place_kernel.hpp: TypeMemo)
     DevBuf ctpos;  // Snap::ctpos
     uint64_t types_gen = 0;  // has_pref holds the type table of this generation
     int32_t n_bslots = 0;  // case (b) slots this snapshot has (place_kernel.hpp: BSlot), read back at commit
     void release()
     {
-        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge, &pc, &ph, &nz, &heads, &bslots, &bpm, &bwin, &bsurv, &bpcs, &ctpos, &sel, &rk, &memo, &memo_cand})
+        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge, &pc, &ph, &nz, &heads, &bslots, &bpm, &bwin, &bsurv, &bpcs, &ctpos, &sel, &rk, &memo, &memo_cand, &memo_rk})
             b->release();
     }
 };
@@ -119,6 +119,8 @@ struct SnapSide {
 // the latency slots, the resident kernel's request slots) is allocated fine-grained and device-mapped explicitly:
 // hipHostMallocDefault would leave the choice to the process environment (HIP_HOST_COHERENT).
 constexpr unsigned int kPinnedFlags = hipHostMallocCoherent | hipHostMallocMapped;
+constexpr int kTailBlocks = 16;    // workgroups of a split batch's tail launch (measured: see place_kernel.hpp)
+constexpr int kMaxMissBufs = 64;   // streams with split batches in flight that get a buffer of their own (more: those batches go unsplit)
 constexpr int kFastSlots = 4;
 constexpr int kFastN = 4096;       // decisions per fast call
 constexpr int kFastExtra = 16384;  // extra-exclusion pool entries per fast call
@@ -194,6 +196,25 @@ struct mmp_ctx {
     int32_t no_memo = 0;     // MMP_NO_MEMO=1: batches do not use the per-type shortlists (place_kernel.hpp: TypeMemo)
     int32_t memo_from = -1;  // MMP_MEMO_FROM=n: decisions from which a batch takes the kernel with the shortlists in front (default kMemoFrom)
     int32_t no_heads = 0;    // MMP_NO_HEADS=1: decisions do not use the per-type head windows (tests: lane_decide_r alone)
+    // the split form of a large batch (place_kernel.hpp: place_memo_kernel + place_tail_kernel)
+    int32_t no_split = 0;    // MMP_NO_SPLIT=1: never (the one-launch kernels with the check in front instead)
+    int32_t split_from = -1; // MMP_SPLIT_FROM=n: decisions from which a batch is split (default kSplitFrom / kSplitFromC)
+    int32_t tail_blocks = kTailBlocks;  // MMP_TAIL_BLOCKS: workgroups of the tail launch
+    int32_t split_notail = 0;  // MMP_SPLIT_NOTAIL=1: the tail launch is left out — the batch's results are INCOMPLETE (timing the first launch alone)
+    // per stream that has issued a split batch: the words its first launches leave for its tails (launches of one stream are ordered,
+    // so one buffer per stream will do) and a pinned pair the tail reports to: {undecided, of how many}
+    struct MissBuf {
+        hipStream_t st = nullptr;
+        uint64_t *words = nullptr;
+        size_t cap = 0;
+        int32_t *report = nullptr;
+    };
+    std::vector<MissBuf> miss_bufs;   // guarded by miss_mu (a leaf lock)
+    std::vector<void *> miss_retired; // outgrown word buffers: a launch in flight may still read them; freed with the context
+    int32_t *miss_reports = nullptr;  // pinned, kMaxMissBufs pairs
+    std::mutex miss_mu;
+    std::atomic<bool> split_off{false};  // a tail reported more than 1/32 of its batch: batches go unsplit until the next commit / registry event
+    std::atomic<int64_t> n_split{0};     // split batches issued (mmp_split_batches)
 
     // host staging (inputs of the next commit)
     std::vector<mmp_pod_row> pods;
@@ -481,6 +502,52 @@ hipError_t slot_wait(FastSlot *f, uint32_t seq)
 }
 
 hipError_t order_after_registry(mmp_ctx *c, hipStream_t st);
+// The word buffer of a split batch on `st` (n_words wavefronts) and the stream's report pair; false: none to be had (too many
+// streams, no memory) — the batch goes unsplit.  Also reads what the stream's last tail reported.
+bool miss_buffer(mmp_ctx *c, hipStream_t st, size_t n_words, uint64_t **words, int32_t **report)
+{
+    std::lock_guard<std::mutex> g(c->miss_mu);
+    mmp_ctx::MissBuf *mb = nullptr;
+    for (auto &b : c->miss_bufs)
+        if (b.st == st) mb = &b;
+    if (!mb) {
+        if ((int)c->miss_bufs.size() >= kMaxMissBufs) return false;
+        if (!c->miss_reports) {
+            if (hipHostMalloc(reinterpret_cast<void **>(&c->miss_reports), (size_t)kMaxMissBufs * 2 * sizeof(int32_t), kPinnedFlags) != hipSuccess) {
+                c->miss_reports = nullptr;
+                return false;
+            }
+            memset(c->miss_reports, 0, (size_t)kMaxMissBufs * 2 * sizeof(int32_t));
+        }
+        mmp_ctx::MissBuf nb;
+        nb.st = st;
+        nb.report = c->miss_reports + 2 * c->miss_bufs.size();
+        c->miss_bufs.push_back(nb);
+        mb = &c->miss_bufs.back();
+    }
+    if (mb->cap < n_words) {
+        size_t want = std::max<size_t>(n_words, 4096);
+        want = std::max(want, mb->cap * 2);
+        void *p = nullptr;
+        if (hipMalloc(&p, want * sizeof(uint64_t)) != hipSuccess) return false;
+        if (mb->words) c->miss_retired.push_back(mb->words);  // (a launch in flight may still read it)
+        mb->words = static_cast<uint64_t *>(p);
+        mb->cap = want;
+    }
+    // the last tail of this stream that has finished: more than 1/32 of its batch undecided -> the records do not fit these batches
+    const int32_t undecided = __atomic_load_n(&mb->report[0], __ATOMIC_RELAXED), of = __atomic_load_n(&mb->report[1], __ATOMIC_RELAXED);
+    if (of > 0 && (int64_t)undecided * 32 > (int64_t)of) c->split_off.store(true, std::memory_order_relaxed);
+    *words = mb->words;
+    *report = mb->report;
+    return true;
+}
+// a new snapshot / registry: split batches get another chance (the reports of the old one's tails are void)
+void split_reset(mmp_ctx *c)
+{
+    std::lock_guard<std::mutex> g(c->miss_mu);
+    if (c->miss_reports) memset(c->miss_reports, 0, (size_t)kMaxMissBufs * 2 * sizeof(int32_t));
+    c->split_off.store(false, std::memory_order_relaxed);
+}
 // what only some callers of place_launch bring: the caller's side of the single-caller form (d_reqs are mmp_place_req_c rows then),
 // the declared length of the exclusion pool (bounded calls; extra_bound = 1 + entries, 0 = not declared)
 struct PlaceOpts {
@@ -565,20 +632,45 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_m_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_long_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_long4_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_tail_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         c->lds_granted.store((size_t)want, std::memory_order_release);
     }
     // batches with the per-type shortlists in front (place_batch_m_kernel / place_batch_c_m_kernel): head windows and the resolved registry
     // view in place, not the full-cluster regime (its shortlists span the table), none of the diagnostic routes, a launch that fills the chip
     const bool use_memo = !inline_req && !done_flag && !c->snap_long && !c->no_memo && !c->force_wave && A.wins && A.rmodels && c->snap.memo &&
                           n >= (c->memo_from >= 0 ? c->memo_from : (caller ? kMemoFromC : kMemoFrom));
+    // NOBAR kernels: a region per wavefront (place_wave_lds) instead of the shared one
+    const size_t lds_nobar = (size_t)kPlaceWaves * place_wave_lds(wpad);
     HIP_TRY(c, order_after_registry(c, st));
+    // the split form: the check alone in a launch of its own, the rest in a dense tail behind it (place_kernel.hpp: place_memo_kernel)
+    if (use_memo && !segs && !c->no_split && !c->split_off.load(std::memory_order_relaxed) &&
+        n >= (c->split_from >= 0 ? c->split_from : (caller ? kSplitFromC : kSplitFrom))) {
+        const int grid = div_up(n, kPlaceBlock);
+        uint64_t *words = nullptr;
+        int32_t *report = nullptr;
+        if (miss_buffer(c, st, (size_t)grid * kPlaceWaves, &words, &report) && !c->split_off.load(std::memory_order_relaxed)) {
+            const int n_words = div_up(n, 64);
+            const size_t lds_memo = (size_t)kPlaceWaves * memo_stage_bytes(c->snap.T);  // a copy of the types' records per wavefront
+            if (caller) {
+                hipLaunchKernelGGL(place_memo_c_kernel, dim3(grid), dim3(kPlaceBlock), lds_memo, st, c->snap, A, words, *caller);
+                if (!c->split_notail) hipLaunchKernelGGL(place_tail_c_kernel, dim3(c->tail_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, words, n_words, report, *caller);
+            } else {
+                hipLaunchKernelGGL(place_memo_kernel, dim3(grid), dim3(kPlaceBlock), lds_memo, st, c->snap, A, words);
+                if (!c->split_notail) hipLaunchKernelGGL(place_tail_kernel, dim3(c->tail_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, words, n_words, report);
+            }
+            HIP_TRY(c, hipGetLastError());
+            c->n_split.fetch_add(1, std::memory_order_relaxed);
+            return MMP_OK;
+        }
+    }
     if (segs) {  // several request arrays, one launch (multi_kernel.hpp); n = the decisions of all of them
         if (c->snap_long && n >= kLongDenseFrom)
             hipLaunchKernelGGL(place_multi_long4_kernel, dim3(seg_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *segs);
         else if (c->snap_long)
             hipLaunchKernelGGL(place_multi_long_kernel, dim3(seg_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *segs);
         else if (use_memo)
-            hipLaunchKernelGGL(place_multi_m_kernel, dim3(seg_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *segs);
+            hipLaunchKernelGGL(place_multi_m_kernel, dim3(seg_blocks), dim3(kPlaceBlock), lds_nobar, st, c->snap, A, wpad, *segs);
         else
             hipLaunchKernelGGL(place_multi_kernel, dim3(seg_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *segs);
     } else if (inline_req && fused_gate)  // one cache-miss route: the guards beside the load target (multi_kernel.hpp)
@@ -593,17 +685,17 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     else if (caller && c->snap_long && n >= kLongDenseFrom)
         hipLaunchKernelGGL(place_batch_long4_c_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *caller);
     else if (caller && c->snap_long)
-        hipLaunchKernelGGL(place_batch_long_c_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *caller);
+        hipLaunchKernelGGL(place_batch_long_c_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds_nobar, st, c->snap, A, wpad, *caller);
     else if (use_memo && !caller)
-        hipLaunchKernelGGL(place_batch_m_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad);
+        hipLaunchKernelGGL(place_batch_m_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds_nobar, st, c->snap, A, wpad);
     else if (use_memo)
-        hipLaunchKernelGGL(place_batch_c_m_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *caller);
+        hipLaunchKernelGGL(place_batch_c_m_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds_nobar, st, c->snap, A, wpad, *caller);
     else if (caller)
         hipLaunchKernelGGL(place_batch_c_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *caller);
     else if (c->snap_long && n >= kLongDenseFrom)
         hipLaunchKernelGGL(place_batch_long4_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad);
     else if (c->snap_long)
-        hipLaunchKernelGGL(place_batch_long_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad);
+        hipLaunchKernelGGL(place_batch_long_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds_nobar, st, c->snap, A, wpad);
     else
         hipLaunchKernelGGL(place_batch_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad);
     HIP_TRY(c, hipGetLastError());
@@ -650,6 +742,10 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     if (const char *nh = getenv("MMP_NO_HEADS")) c->no_heads = nh[0] == '1';
     if (const char *nm = getenv("MMP_NO_MEMO")) c->no_memo = nm[0] == '1';
     if (const char *mf = getenv("MMP_MEMO_FROM")) c->memo_from = atoi(mf);
+    if (const char *ns = getenv("MMP_NO_SPLIT")) c->no_split = ns[0] == '1';
+    if (const char *sf = getenv("MMP_SPLIT_FROM")) c->split_from = atoi(sf);
+    if (const char *tb = getenv("MMP_TAIL_BLOCKS")) c->tail_blocks = std::max(1, std::min(atoi(tb), 1024));
+    if (const char *nt = getenv("MMP_SPLIT_NOTAIL")) c->split_notail = nt[0] == '1';
     if (const char *nl = getenv("MMP_NO_LONG_LDS")) c->no_long_lds = nl[0] == '1';
     if (const char *nb = getenv("MMP_NO_CASEB")) c->no_caseb = nb[0] == '1';
     const bool want_resident = getenv("MMP_RESIDENT") && getenv("MMP_RESIDENT")[0] == '1';
@@ -753,6 +849,11 @@ void mmp_destroy(mmp_ctx *c)
     c->sb[1].release();
     c->side[0].release();
     c->side[1].release();
+    // (caller-owned streams a split batch ran on are the caller's to drain before it destroys the context, as for every *_dev call)
+    for (auto &mb : c->miss_bufs)
+        if (mb.words) (void)hipFree(mb.words);
+    for (void *p : c->miss_retired) (void)hipFree(p);
+    if (c->miss_reports) (void)hipHostFree(c->miss_reports);
     for (DevBuf *b : {&c->rank, &c->occupancy, &c->flag, &c->rs_list, &c->rs_bad, &c->d_prefer,
                       &c->models, &c->ent_pod, &c->ent_time, &c->c_seg,
                       &c->c_lu, &c->c_wt, &c->c_cap, &c->s_reqs, &c->s_outs, &c->s_extra, &c->s_a, &c->s_b,
@@ -1088,6 +1189,7 @@ try {
         c->m_cnt[i] = rows[i].n_loaded + rows[i].n_failed;
         c->ent_live += c->m_cnt[i];
     }
+    split_reset(c);
     return rebuild_resolved(c);
 } catch (const std::bad_alloc &) {
     return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_models_load");
@@ -1486,7 +1588,8 @@ try {
     HIP_TRY(c, B.sel.ensure((size_t)2 * T * W * 64 * 4));
     HIP_TRY(c, B.rk.ensure((size_t)2 * T * W * 64 * 4));
     HIP_TRY(c, B.memo.ensure((size_t)kWinLds * sizeof(TypeMemo)));
-    HIP_TRY(c, B.memo_cand.ensure((size_t)kWinLds * 2 * kMemoCand * 4));
+    HIP_TRY(c, B.memo_cand.ensure((size_t)kWinLds * kMemoCand * 4));
+    HIP_TRY(c, B.memo_rk.ensure((size_t)kWinLds * kMemoCand * 2));
     // rounded up to the 1 KB chunks place_block stages (rows beyond T are never read as windows)
     const size_t wins_bytes = (((size_t)std::max(T, kWinLds) * sizeof(TypeWin) + 1023) / 1024) * 1024;
     HIP_TRY(c, B.heads.ensure(wins_bytes));
@@ -1661,6 +1764,7 @@ try {
     S.rk = P > 0 ? B.rk.as<int32_t>() : nullptr;
     S.memo = B.memo.as<TypeMemo>();
     S.memo_cand = B.memo_cand.as<int32_t>();
+    S.memo_rk = B.memo_rk.as<int16_t>();
 
     bool next_long = c->long_mode == 1, next_full = false;
     {  // the partitions of the type constraints (host) and their uploads: inputs, like the table itself
@@ -1759,7 +1863,7 @@ try {
         // sel / rk from the prefix tables, and the per-type shortlists (TypeMemo) from the finished head windows (every row a decision
         // can name is written, valid or not): one launch; the registry view below is resolved against the shortlists' ranges
         hipLaunchKernelGGL(build_sel_memo_kernel, dim3(2 * T * W + std::min(T, kWinLds)), dim3(64), 0, st, S, B.sel.as<int32_t>(), B.rk.as<int32_t>(),
-                           B.heads.as<TypeWin>(), B.memo.as<TypeMemo>(), B.memo_cand.as<int32_t>());
+                           B.heads.as<TypeWin>(), B.memo.as<TypeMemo>(), B.memo_cand.as<int32_t>(), B.memo_rk.as<int16_t>());
         // the running minimum of the case (b) candidates' rpm, then the survivor bitmaps of the rpm rule's four limits
         hipLaunchKernelGGL(prefix_min_rpm_kernel, dim3(kBSlots), dim3(64), 0, st, S, B.bslots.as<BSlot>(), n_bslots_dev, B.bpm.as<int32_t>(),
                            (int32_t)(W * 64));
@@ -1823,6 +1927,7 @@ try {
     c->snap = S;
     c->cur = 1 - c->cur;
     c->committed = true;
+    split_reset(c);
     c->stats.total_capacity = (int64_t)acc.total_capacity;
     c->stats.total_free = (int64_t)acc.total_free;
     c->stats.global_lru = (int64_t)acc.global_lru;
@@ -1869,7 +1974,7 @@ try {
     if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
     HIP_TRY(c, hipSetDevice(c->cfg.device));
     const int32_t nt = c->snap.memo ? std::min(c->snap.T, kWinLds) : 0;
-    std::vector<TypeMemo> h((size_t)std::max(nt, 1));
+    std::vector<TypeMemo> h((size_t)std::max(nt, 1));  // (whole rows: the records' heads are read below)
     if (nt) HIP_TRY(c, copy_sync(c, h.data(), c->snap.memo, (size_t)nt * sizeof(TypeMemo), hipMemcpyDeviceToHost));
     for (int32_t i = 0; i < 2 * nt && i < cap_rows; i++) {
         const MemoVar &v = h[i >> 1].v[i & 1];
@@ -1881,6 +1986,14 @@ try {
     return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shortlists");
 } catch (const std::exception &e) {
     return fail(c, MMP_EHIP, "%s: %s", "mmp_shortlists", e.what());
+}
+
+int mmp_split_batches(mmp_ctx *c, int64_t *n_split_out, int32_t *off_out)
+{
+    if (!c) return fail(c, MMP_EINVAL, "mmp_split_batches: null context");
+    if (n_split_out) *n_split_out = c->n_split.load(std::memory_order_relaxed);
+    if (off_out) *off_out = c->split_off.load(std::memory_order_relaxed) ? 1 : 0;
+    return MMP_OK;
 }
 
 int mmp_cluster_stats(mmp_ctx *c, mmp_stats *out)

@@ -131,42 +131,82 @@ struct __attribute__((aligned(16))) TypeWin {
 static_assert(sizeof(TypeWin) % 16 == 0, "TypeWin is staged in 16-byte pieces");
 static_assert(kGeRows % 2 == 0, "ct + pad_ keep the rows 16-byte aligned");
 
-// ---- per-type shortlists (round 5) ----------------------------------------------------------------
+// ---- per-type shortlists (rounds 5-6) ---------------------------------------------------------------
 // What lane_decide_win computes from a head window depends on the REQUEST in four ways only: its exclusions, the caller's own
 // entry (position + fresh record), the rpm rule's inputs (lastUsedTime, the fresh rpm) and the random pick.  The first two reach
 // the shortlist only when one of those positions lies inside it — and a shortlist is a few dozen positions at the head of an
 // order of thousands.  For every other request of the type the walk — first eligible instance, preference step, break scans,
 // count, audit hash — yields one of TWO shortlists, selected by the fresh-row test of MM.java:4913-4922 (which compares the
 // CALLER's fresh record with the best instance: one bit per request).  commit() runs lane_decide_win once per (type, bit) with no
-// exclusions (build_sel_memo_kernel: build_memo_body) and keeps: the positions the result depends on [lo, hi), the candidates' count and audit-hash
-// sum, the best row's fields the rpm rule reads, and the candidates' pod indices in shortlist order (Snap::memo_cand).  memo_try
-// decides a request by CHECKING that none of its positions falls into [lo, hi) — the model's exclusions were checked when its
-// registry row was resolved (ResolvedModel::type, bits kMemoBlk) — and applying the rpm rule and the pick to the recorded list; a
-// request that fails the check goes through the ordinary lane phase, in the same launch.  Used by the single-caller batch kernel
-// (place_batch_c_m_kernel, where it pays: see there); what else was tried with these records — a second phase per workgroup, a
-// wavefront per 256 requests, launch-wide lists, consumer workgroups, two launches — is in profiles/r5/shortlist_experiments.
-constexpr int kMemoCand = kWinWords * 64;
-constexpr int kMemoBlkShift = 24;  // ResolvedModel::type bit 24 + v: one of the model's exclusions lies inside shortlist v of its type (or no such shortlist)
-constexpr int32_t kMemoTypeMask = (1 << kMemoBlkShift) - 1;
+// exclusions (build_sel_memo_kernel: build_memo_body) and keeps: the positions the result depends on [lo, hi), the candidates' count and
+// audit-hash sum, the best row's fields the rpm rule reads, the candidates' pod indices in shortlist order (Snap::memo_cand) and — round 6
+// — for every position of the type's window what it IS to the list (Snap::memo_rk: the best instance, the type's first eligible
+// instance, candidate number k, nothing).  memo_try decides a request from those records:
+//   * no position of its own inside [lo, hi): the recorded list as it stands (round 5);
+//   * round 6: own positions inside the list that leave its SHAPE alone — an exclusion that is candidate k of the list takes that
+//     candidate out (count - 1, its own term off the linear audit hash, the pick skips rank k: at most two per request); the caller
+//     as candidate k is one more candidate with the rpm class / favourSelf / ABORT_REQUEST rules of MM.java:4931, :4951-4991; the
+//     caller as the best instance with favourSelf is ABORT_REQUEST at once (:4891-4895); a position that is no candidate (another
+//     type's instance, the instance that ends the list) changes nothing;
+//   * anything that would change the walk itself — the best / first eligible instance excluded, the caller as the best instance
+//     without favourSelf, a third excluded candidate, the fresh-row break with the caller next in line — is left to the ordinary
+//     lane phase (in the same wavefront: place_batch_m_kernel & co; or in the tail launch of the split form: place_memo_kernel +
+//     place_tail_kernel below).
+// The model's own exclusions are classified when its registry row is resolved (resolve_model_row -> PlaceArgs::mtw, one word per
+// model: type row, "needs the ordinary path", the window offsets of up to two excluded candidates), so a covered request never reads
+// the 32-byte registry row.  What else was tried with these records — a second phase per workgroup, a wavefront per 256 requests,
+// launch-wide lists, consumer workgroups — is in profiles/r5/shortlist_experiments.
+constexpr int kMemoCand = kWinWords * 64;  // positions of a window == the most candidates a recorded list can have
+// PlaceArgs::mtw, one word per model
+constexpr uint32_t kMtwTypeMask = 15u;     // bits 0-3: the model's type row if it has recorded shortlists (< kWinLds), else 15
+constexpr uint32_t kMtwTail = 1u << 4;     // the model's exclusions change the walk for either list: the ordinary path decides
+constexpr uint32_t kMtwTail1 = 1u << 5;    // ... for the list of a FULL caller (fresh-row break on): the instance that ends it is excluded
+constexpr int kMtwOffShift = 8;            // bits 8-16, 17-25: window offset + 1 of the model's first / second exclusion that is a candidate
+constexpr uint32_t kMtwOffMask = 511u;     //   of list 0 (0: none)
+constexpr uint32_t kMtwNone = kMtwTypeMask | kMtwTail | kMtwTail1;
+static_assert(kWinLds <= 15 && kMemoCand < 511, "mtw packs a type row in 4 bits and a window offset + 1 in 9");
+constexpr int kMtwMaxEnts = 32;            // entries of a model the classification walks (more: the ordinary path)
+// Snap::memo_rk values (int16 per window position): k >= 1: candidate k of list 0 (k = 0 is the best instance)
+constexpr int kRkNone = -1;                // nothing to the list
+constexpr int kRkFirst = -2;               // the type's first eligible instance where that is not the best one (a preference step was taken)
 struct __attribute__((aligned(16))) MemoVar {
     int32_t valid;       // 0: lane_decide_win gave no answer from the window for this (type, bit)
-    int32_t lo, hi;      // the answer holds for requests with no exclusion and no caller's entry at a position in [lo, hi)
+    int32_t lo, hi;      // own positions of a request matter only inside [lo, hi)
     int32_t ccount;      // candidates (:4940)
-    uint32_t hash;       // audit hash of the candidate words, folded
-    int32_t pad_[3];
+    uint64_t hsum;       // audit-hash sum of the candidate words (linear in the candidate bits: wave.hpp)
+    uint32_t hash;       // ... folded
+    int32_t pad_;
 };
-struct __attribute__((aligned(16))) TypeMemo {
+static_assert(sizeof(MemoVar) == 32, "MemoVar is 32 bytes");
+struct __attribute__((aligned(16))) TypeMemoHead {
     int64_t b_rem, b_lru;  // the best instance's remaining space and lruTime (the fresh-row test compares against them)
     int32_t best_is_full, b_rpm, best_idx;
     int32_t plain;         // 1: no preference step was taken (the best instance is the type's first eligible one, bestpos == best0)
     MemoVar v[2];          // [fresh-row break does not fire, fires]
-    // Shortlist 0 again as a bitmap — the walk's clipped candidate words (best bit set) of window words [w0, w0 + kWinWords) — and where
-    // it ends (kNoPos: at the end of the table): with them the check also answers a request whose CALLER stands inside the list
-    // (memo_try: "the caller's own entry").
-    uint64_t cw[kWinWords];
-    int32_t w0, end0, pad_[2];
+    int32_t w0;            // first word of the type's window: memo_rk / mtw offsets count from position w0 * 64
+    int32_t bestpos, best0;
+    int32_t e_rpm;         // rpm of the first eligible instance's snapshot row: the class of the caller's own entry (quirk B#2)
+    int32_t sbk;           // the caller's own entry would END the list (its break rule, :4909-4922 with curInst = bestEntry's row):
+                           // only where a preference step was taken; such requests take the ordinary path
+    int32_t end0;          // where list 0 ends (kNoPos: at the end of the table)
+    int32_t pad_[2];
 };
-static_assert(sizeof(TypeMemo) == 160, "TypeMemo is 160 bytes");
+static_assert(sizeof(TypeMemoHead) == 128, "TypeMemoHead is 128 bytes");
+// ... and, in the same 512-byte row, the head of list 0 — the pod indices of its first kMemoNear candidates and what the first
+// kMemoNear positions from the type's first eligible instance on are to it (the first entries of memo_cand / memo_rk again, the latter
+// counted from `best0` instead of the window's start): everything a request of the type normally touches in one contiguous piece that
+// the lean launch copies into LDS, a copy per wavefront and no barrier (place_memo_body).
+constexpr int kMemoNear = 64;
+struct __attribute__((aligned(16))) TypeMemo : TypeMemoHead {
+    int32_t cand64[kMemoNear];
+    int16_t rk64[kMemoNear];
+};
+static_assert(sizeof(TypeMemo) == 512, "TypeMemo is 512 bytes");
+// bytes of the table the lean launch stages per wavefront: whole 1 KB pieces (the table is allocated for kWinLds rows)
+__host__ __device__ constexpr int memo_stage_bytes(int type_rows)
+{
+    return (((type_rows < kWinLds ? type_rows : kWinLds) * (int)sizeof(TypeMemo) + 1023) / 1024) * 1024;
+}
 
 struct PlaceArgs {
     const mmp_place_req *reqs;
@@ -874,7 +914,7 @@ __device__ __forceinline__ ResolvedReq resolve_req(const Snap &S, const PlaceArg
         r.n_excl = 0;
     } else if (A.rmodels && A.rmodels[rq.model].n_ents <= kResolvedInline) {
         const ResolvedModel m = A.rmodels[rq.model];
-        r.type = m.type & kMemoTypeMask;
+        r.type = m.type;
         r.n_excl = m.n_ents + rq.n_extra;
         if (r.n_excl <= kInlineExcl) {
 #pragma unroll
@@ -922,8 +962,9 @@ __device__ __forceinline__ ResolvedReq resolve_req(const Snap &S, const PlaceArg
     return r;
 }
 
-// Follow one model's entry list through pos_of once (see ResolvedModel).
-__device__ __forceinline__ ResolvedModel resolve_model_row(const Snap &S, const mmp_model_row &m, const int32_t *__restrict__ ent_pod)
+// Follow one model's entry list through pos_of once (see ResolvedModel), and classify its exclusions against the type's recorded
+// shortlists (`mtw`: see kMtw*).
+__device__ __forceinline__ ResolvedModel resolve_model_row(const Snap &S, const mmp_model_row &m, const int32_t *__restrict__ ent_pod, uint32_t &mtw)
 {
     ResolvedModel r;
     r.type = (m.type < 0 || m.type >= S.T) ? 0 : m.type;
@@ -937,20 +978,38 @@ __device__ __forceinline__ ResolvedModel resolve_model_row(const Snap &S, const 
         }
         r.pos[k] = pos;
     }
-    // which of the type's two recorded shortlists (TypeMemo) this model's exclusions leave untouched
-    uint32_t blk = 3u;
-    if (S.memo && r.type < kWinLds && r.n_ents <= kResolvedInline) {
-        blk = 0;
-#pragma unroll
-        for (int v = 0; v < 2; v++) {
-            const MemoVar mv = S.memo[r.type].v[v];
-            bool hit = !mv.valid;
-#pragma unroll
-            for (int k = 0; k < kResolvedInline; k++) hit |= r.pos[k] >= mv.lo && r.pos[k] < mv.hi;  // (-1 < lo: never)
-            if (hit) blk |= 1u << v;
+    mtw = kMtwNone;
+    if (S.memo && r.type < kWinLds && r.n_ents <= kMtwMaxEnts) {
+        const TypeMemo &M = S.memo[r.type];
+        const MemoVar v0 = M.v[0], v1 = M.v[1];
+        const int wl = M.w0 * 64;
+        const int16_t *RK = S.memo_rk + (size_t)r.type * kMemoCand;
+        uint32_t w = (uint32_t)r.type, o1 = 0, o2 = 0;
+        for (int k = 0; k < r.n_ents; k++) {
+            const int32_t pod = ent_pod[m.ent_off + k];
+            if (pod < 0 || pod >= S.P) continue;
+            const int32_t pos = S.pos_of[pod];
+            if (v0.valid && pos >= v0.lo && pos < v0.hi) {
+                const int rk = RK[pos - wl];
+                if (rk == 0 || rk == kRkFirst)
+                    w |= kMtwTail;  // the best / first eligible instance is excluded: another walk
+                else if (rk > 0) {
+                    const uint32_t off = (uint32_t)(pos - wl) + 1u;
+                    if (off == o1 || off == o2) continue;
+                    if (!o1)
+                        o1 = off;
+                    else if (!o2)
+                        o2 = off;
+                    else
+                        w |= kMtwTail;  // a third excluded candidate
+                }
+            }
+            // list 1 (the caller is full: the list ends at the first candidate behind the best instance, MM.java:4909-4922) depends on
+            // the best / first eligible instance and on the instance that ends it
+            if (v1.valid && pos >= v1.lo && pos < v1.hi && (pos == M.best0 || pos == M.bestpos || pos == v1.hi - 1)) w |= kMtwTail1;
         }
+        mtw = w | (o1 << kMtwOffShift) | (o2 << (kMtwOffShift + 9));
     }
-    r.type |= (int32_t)(blk << kMemoBlkShift);
     return r;
 }
 
@@ -961,9 +1020,10 @@ __global__ void resolve_models_kernel(Snap S, const mmp_model_row *__restrict__ 
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_models) return;
-    const ResolvedModel r = resolve_model_row(S, models[i], ent_pod);
+    uint32_t w;
+    const ResolvedModel r = resolve_model_row(S, models[i], ent_pod, w);
     out[i] = r;
-    mtw[i] = r.type;
+    mtw[i] = (int32_t)w;
 }
 
 // Registry events (mmp_models_upsert): rows[i] replaces models[idx[i]]; its entries were appended to the
@@ -978,9 +1038,10 @@ __global__ void upsert_models_kernel(Snap S, const int32_t *__restrict__ idx, co
     const mmp_model_row m = rows[i];
     models[idx[i]] = m;
     if (resolved) {
-        const ResolvedModel r = resolve_model_row(S, m, ent_pod);
+        uint32_t w;
+        const ResolvedModel r = resolve_model_row(S, m, ent_pod, w);
         resolved[idx[i]] = r;
-        mtw[idx[i]] = r.type;
+        mtw[idx[i]] = (int32_t)w;
     }
 }
 
@@ -1710,8 +1771,9 @@ struct MemoCap {
     int best0, bestpos, end, wlo, whi, ccount;
     uint64_t hsum;
     int64_t b_rem, b_lru;
-    int32_t b_rpm, best_idx;
+    int32_t b_rpm, best_idx, e_rpm;
     bool best_is_full;
+    bool sbk;  // the break rule of the caller's own entry (curInst = bestEntry's row) as the walk computed it for a caller that is not the best instance
 };
 template <bool VIEW = false, bool MEMO = false, int SCR = kPlaceBlock>  // SCR: lanes per scratch column
 __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, const TypeWin *Ws,
@@ -1848,6 +1910,8 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
         from_t = win_lo + (int)Wn.ct[T - kGeBase];  // counts do not decrease along the window
     }
     if (MEMO) {  // the type's shortlist for either outcome of the fresh-row test; no caller's entry in reach
+        mc->sbk = self_break;
+        mc->e_rpm = e_rpm;
         ns_break = mc->nsb != 0;
         self_break = false;
     }
@@ -2254,18 +2318,25 @@ constexpr int kWinLdsBytes = win_lds_bytes(kWinLds);
 constexpr int kLaneScratchBytes = kWinWords * kPlaceBlock * 8;  // one column of kWinWords words per lane
 __host__ __device__ constexpr int place_lane_lds(int type_rows) { return win_lds_bytes(type_rows) + kLaneScratchBytes; }
 constexpr int kPlaceLaneLds = kWinLdsBytes + kLaneScratchBytes;  // the most the lane phase needs: windows + scratch
+// the barrier-free kernels (place_block<..., NOBAR>): per wavefront max(its 64 lanes' scratch columns, its general path's two tiles), 16-byte aligned
+__host__ __device__ constexpr int place_wave_lds(int wpad)
+{
+    return (((kWinWords * 64 * 8 > 2 * wpad * 8 ? kWinWords * 64 * 8 : 2 * wpad * 8) + 15) / 16) * 16;
+}
 constexpr int kPlaceStaticLds = 2 * kPlaceBlock * 4 + 64 + 256;                // the lists (+ place_single_kernel's request)
 // bytes of the long path's per-type tables when they are staged in LDS: elig + pref ([T][W] words each), pc + nz ([2][T][W + 1] ints each)
 __host__ __device__ constexpr size_t long_tables_bytes(int T, int W) { return (size_t)T * W * 16 + (size_t)4 * T * (W + 1) * 4; }
 // A request against its type's recorded shortlists (see TypeMemo), a lane per request, the tables read from (L1-resident) global
-// memory: true = decided, the result row written.  false: a position of the request's own inside the shortlist, more exclusions than
-// the checks see, no shortlist for the type — the ordinary path decides.
+// memory: true = decided, the result row written.  false: the request's own positions would change the walk itself (or: more
+// exclusions than the check sees, no recorded list for the type) — the ordinary path decides.
+// `rows`: the snapshot's records — S.memo, or the wavefront's copy of it in LDS.
 template <int FORM>
-__device__ __forceinline__ bool memo_try(const Snap &S, const PlaceArgs &A, const mmp_place_req &rq, int d)
+__device__ __forceinline__ bool memo_try(const Snap &S, const PlaceArgs &A, const mmp_place_req &rq, int d, const TypeMemo *rows)
 {
+    // first level: the model's word, the caller's position, the positions of the request's own exclusions — side by side
     const bool m_ok = (uint32_t)rq.model < (uint32_t)A.n_models;
-    int32_t tf = A.mtw[m_ok ? rq.model : 0];
-    if (!m_ok) tf = -1;  // (type mask all ones: no shortlist)
+    uint32_t mw = (uint32_t)A.mtw[m_ok ? rq.model : 0];
+    if (!m_ok) mw = kMtwNone;
     const bool s_ok = (uint32_t)rq.self_pod < (uint32_t)S.P;
     int32_t sp = S.pos_of[s_ok ? rq.self_pod : 0];
     if (!s_ok) sp = -1;
@@ -2278,11 +2349,16 @@ __device__ __forceinline__ bool memo_try(const Snap &S, const PlaceArgs &A, cons
         for (int j = 0; j < kLateExtra; j++)
             if (x_ok && j < rq.n_extra) xp[j] = pod_view_pos<false>(S, A.extra[rq.extra_off + j], S.P);
     }
-    const int type = tf & kMemoTypeMask;
+    // second level: the type's record — the best row AND both lists' headers at once (one level of the chain instead of two; the lean
+    // kernel has the registers)
+    const int type = (int)(mw & kMtwTypeMask);
     const bool t_ok = type < kWinLds && x_ok;
-    const TypeMemo *Mp = &S.memo[t_ok ? type : 0];
+    const TypeMemo *Mp = &rows[type < kWinLds ? type : 0];
     const int64_t b_rem = Mp->b_rem, b_lru = Mp->b_lru;
-    const int32_t full = Mp->best_is_full, b_rpm = Mp->b_rpm, best_idx = Mp->best_idx;
+    const int4 bh = *reinterpret_cast<const int4 *>(&Mp->best_is_full);  // best_is_full, b_rpm, best_idx, plain
+    const int4 v0h = *reinterpret_cast<const int4 *>(&Mp->v[0]), v1h = *reinterpret_cast<const int4 *>(&Mp->v[1]);  // valid, lo, hi, ccount
+    const uint64_t hs0 = Mp->v[0].hsum, hs1 = Mp->v[1].hsum;
+    const int32_t full = bh.x, b_rpm = bh.y, best_idx = bh.z;
     // the fresh-row test, MM.java:4913-4922 (as lane_decide_win has it); the full-mode form only in wavefronts that hold such a type
     const int64_t f_rem = remaining_of(rq.fresh_capacity, rq.fresh_used);
     bool nsb = f_rem < S.min_space || f_rem < (b_rem >> 2);
@@ -2291,81 +2367,157 @@ __device__ __forceinline__ bool memo_try(const Snap &S, const PlaceArgs &A, cons
         const int64_t d1 = jsub64(rq.fresh_lru, b_lru);
         if (full) nsb = d1 > 45000LL && d1 > rel;
     }
-    const MemoVar V = Mp->v[nsb ? 1 : 0];
-    const int lo = V.lo;
-    const uint32_t len = (uint32_t)(V.hi - lo);
-    bool miss = !t_ok || !V.valid || ((tf >> (kMemoBlkShift + (nsb ? 1 : 0))) & 1);
+    const int4 vh = nsb ? v1h : v0h;
+    uint64_t hsum = nsb ? hs1 : hs0;
+    const int lo = vh.y;
+    const uint32_t len = (uint32_t)(vh.z - lo);
+    bool miss = !t_ok || !vh.x || (mw & (nsb ? kMtwTail1 : kMtwTail)) != 0;
+    // own positions inside [lo, hi): the caller, the request's exclusions; the model's come classified in its word
+    bool x_in = false;
 #pragma unroll
-    for (int j = 0; j < kLateExtra; j++) miss |= (uint32_t)(xp[j] - lo) < len;  // (-1 - lo wraps far beyond len)
-    // The caller's own entry inside the list.  In the plain case — no preference step, the fresh-row break off — the caller is just
-    // one more candidate of the SAME list (the break rules compare the best instance's row with itself: they cannot fire, MM.java:4909-
-    // 4926 as lane_decide_win has them; the count break reads the snapshot's counts): what changes is favourSelf (:4931), the rpm
-    // rule's classes (:4951-4980: the caller's entry carries the snapshot rpm, "the others" the fresh one) and that choosing it means
-    // ABORT_REQUEST (:4989).  The caller AS the best instance, behind a preference step, or with the fresh-row break on: the lane phase.
-    bool self_in = false;
-    int ks = 0;
+    for (int j = 0; j < kLateExtra; j++) x_in |= (uint32_t)(xp[j] - lo) < len;  // (-1 - lo wraps far beyond len)
     const bool sp_in = (uint32_t)(sp - lo) < len;
-    if (FORM != kReq64) {
-        miss |= sp_in;  // (one caller per batch: it stands inside the list for all requests or for none — not worth the instructions)
-    } else if (__ballot(sp_in && !miss)) {  // (wave-uniform)
-        if (sp_in && !miss) {
-            const int end0 = Mp->end0;
-            if (nsb || !Mp->plain || sp == lo)
-                miss = true;
-            else if (sp != end0) {  // (the instance that ends the list is not part of it)
-                const int jw = (sp >> 6) - Mp->w0;
-                uint64_t wj = 0;
-                int below = 0;
-#pragma unroll
-                for (int j = 0; j < kWinWords; j++) {
-                    const uint64_t cwj = Mp->cw[j];
-                    if (j < jw) below += __popcll((unsigned long long)cwj);
-                    if (j == jw) wj = cwj;
+    const uint32_t moff = nsb ? 0u : (mw >> kMtwOffShift);  // (list 1 is the best instance alone: nothing to take out of it)
+    const bool favour = (rq.flags & MMP_REQ_FAVOUR_SELF) != 0;
+    int ccount = vh.w;
+    int r1 = 0, r2 = 0;      // candidate numbers of the (at most two) excluded candidates, 0: none
+    int ks = 0;              // the caller's candidate number when its own entry is a candidate (self_in)
+    bool self_in = false, self_best = false;
+    int32_t e_rpm = 0;
+#ifdef MMP_XP_NOOWN  // (experiment builds only, tools/r6: what the own-positions block costs)
+    miss |= x_in || sp_in || moff != 0;
+#endif
+    const bool own = !miss && (x_in || sp_in || moff != 0);
+    if (__ballot(own)) {  // (wave-uniform: a third of the wavefronts of a batch of request rows, C3)
+        if (own) {
+            const int4 mt = *reinterpret_cast<const int4 *>(&Mp->w0);  // w0, bestpos, best0, e_rpm
+            const int32_t sbk = Mp->sbk;
+            const int wl = mt.x * 64;
+            // what each own position is to the list: one lookup apiece, all in flight together — in the row itself for the first
+            // kMemoNear positions from the first eligible instance on (nearly always), else in the window-wide table
+            const int16_t *RK = S.memo_rk + type * kMemoCand;
+            auto rk_of = [&](int pos) {
+                const int rel = pos - lo;  // (lo = the type's first eligible instance for either list; callers pass positions >= lo)
+                int v = (int)Mp->rk64[rel < kMemoNear ? rel : 0];
+                if (rel >= kMemoNear) {  // (the row may live in LDS, the table does not: kept apart from the load above, or the
+                    int g = (int)RK[pos - wl];           // compiler merges the two into one FLAT load through a selected pointer)
+                    asm volatile("" : "+v"(g));
+                    v = g;
                 }
-                if ((wj >> (sp & 63)) & 1ull) {
-                    self_in = true;
-                    ks = below + __popcll((unsigned long long)(wj & ((1ull << (sp & 63)) - 1ull)));
+                return v;
+            };
+            const int o1 = (int)(moff & kMtwOffMask) - 1, o2 = (int)((moff >> 9) & kMtwOffMask) - 1;
+            const int srk = sp_in ? rk_of(sp) : kRkNone;
+            int xr[kLateExtra];
+#pragma unroll
+            for (int j = 0; j < kLateExtra; j++) xr[j] = (uint32_t)(xp[j] - lo) < len ? rk_of(xp[j]) : kRkNone;
+            const int m1 = o1 >= 0 ? rk_of(wl + o1) : kRkNone, m2 = o2 >= 0 ? rk_of(wl + o2) : kRkNone;
+            const int end_v = vh.z - 1;  // the instance that ends the list (list 1 depends on it)
+            // an exclusion at a list position: the best / first eligible instance -> another walk; candidate k -> taken out
+            auto take = [&](int rk, int pos) {
+                if (rk == 0 || rk == kRkFirst || (nsb && pos == end_v))
+                    miss = true;
+                else if (!nsb && rk > 0 && rk != r1 && rk != r2) {
+                    if (r1 == 0)
+                        r1 = rk;
+                    else if (r2 == 0)
+                        r2 = rk;
+                    else
+                        miss = true;
+                    hsum -= audit_mul((uint64_t)(pos >> 6)) << (pos & 63);
+                }
+            };
+            take(m1, wl + o1);
+            take(m2, wl + o2);
+#pragma unroll
+            for (int j = 0; j < kLateExtra; j++) take(xr[j], xp[j]);
+            // The caller's own entry.  As the best instance: ABORT_REQUEST with favourSelf (:4891-4895), else its fresh row replaces
+            // the best row in every rule: the ordinary path.  As candidate k with the fresh-row break off: one more candidate of the
+            // SAME list (the break rules compare the best row with itself where no preference step was taken; where one was, `sbk`
+            // says whether the caller's own break fires); what changes is favourSelf (:4931), the rpm rule's classes (:4951-4980: the
+            // caller's entry carries the snapshot rpm of the FIRST eligible instance, "the others" the fresh one) and that choosing it
+            // means ABORT_REQUEST (:4989).  With the fresh-row break on, the caller next in line behind the best instance stays in the
+            // list (the break skips it): the ordinary path; further back it is not reached.
+            if (sp_in) {
+                if (srk == 0) {
+                    if (favour)
+                        self_best = true;
+                    else
+                        miss = true;
+                } else if (srk == kRkFirst)
+                    miss = true;
+                else if (nsb) {
+                    if (sp == end_v) miss = true;
+                } else if (srk > 0 && srk != r1 && srk != r2) {  // (an excluded caller is no candidate)
+                    if (sbk)
+                        miss = true;
+                    else {
+                        self_in = true;
+                        ks = srk;
+                        e_rpm = mt.w;
+                    }
                 }
             }
+            ccount -= (r1 != 0) + (r2 != 0);
         }
     }
     if (miss) return false;
-    const int ccount = V.ccount;
-    const int32_t f_rpm = rq.fresh_rpm;
     mmp_place_out o;
     o.best = best_idx;
-    if (self_in && (rq.flags & MMP_REQ_FAVOUR_SELF)) {  // :4931-4933
+    if (self_best || (self_in && favour)) {  // :4891-4895, :4931-4933
         o.chosen = MMP_SELF;
         o.n_candidates = 0;
         o.hash = 0;
         A.outs[d] = o;
         return true;
     }
-    // rpm filter, :4951-4980: the best instance, the caller's entry (the same snapshot rpm class as the best one here), "the others"
-    // (the fresh rpm, quirks B#2/B#3)
+    // rpm filter, :4951-4980: the best instance, the caller's entry, "the others" (the fresh rpm, quirks B#2/B#3)
+    const int32_t f_rpm = rq.fresh_rpm;
     const int n_others = ccount - 1 - (self_in ? 1 : 0);
+    int32_t mn = b_rpm;
+    if (self_in && e_rpm < mn) mn = e_rpm;
+    if (n_others > 0 && f_rpm < mn) mn = f_rpm;
     RpmRule rule;
-    rule.init(age_of(rq.last_used, A.now), (n_others > 0 && f_rpm < b_rpm) ? f_rpm : b_rpm);
+    rule.init(age_of(rq.last_used, A.now), mn);
     const int32_t lim = rule.limit();
     const bool null0 = ccount >= 2 && b_rpm >= 100 && b_rpm > lim;
-    const bool null_s = self_in && null0;
+    const bool null_s = ccount >= 2 && self_in && e_rpm >= 100 && e_rpm > lim;
     const bool null_o = ccount >= 2 && n_others > 0 && f_rpm >= 100 && f_rpm > lim;
     const int remaining = ccount - (null0 ? 1 : 0) - (null_s ? 1 : 0) - (null_o ? n_others : 0);
     const int index = remaining <= 1 ? 0 : (int)(((uint64_t)rq.pick * (uint64_t)(uint32_t)remaining) >> 32);
+    // candidate number of the index-th survivor
     int k;
     if (null_o)
-        k = index == 0 ? 0 : ks;  // survivors: the best instance, then the caller's entry (both or neither: one rpm)
+        k = (!null0 && index == 0) ? 0 : ks;  // survivors: the best instance, then the caller's entry (whichever the rule left in)
     else {
         k = index + (null0 ? 1 : 0);
-        if (null_s && k >= ks) k += 1;
+        if (__ballot(null_s || r1 != 0)) {  // (wave-uniform) numbers taken out of the list, ascending: each one at or before k pushes it on
+            int a = null_s ? ks : INT32_MAX, b = r1 ? r1 : INT32_MAX, c = r2 ? r2 : INT32_MAX, t;
+            if (a > b) { t = a; a = b; b = t; }
+            if (b > c) { t = b; b = c; c = t; }
+            if (a > b) { t = a; a = b; b = t; }
+            if (a <= k) k++;
+            if (b <= k) k++;
+            if (c <= k) k++;
+        }
     }
     o.chosen = MMP_NONE;
     if (remaining >= 1) {
-        o.chosen = S.memo_cand[(type * 2 + (nsb ? 1 : 0)) * kMemoCand + k];
+#ifdef MMP_XP_NOCAND  // (experiment builds only: the last gather of the chain left out — wrong results)
+        o.chosen = best_idx + k;
+#else
+        o.chosen = Mp->cand64[k < kMemoNear ? k : 0];
+        if (k >= kMemoNear) {  // (see rk_of)
+            int32_t g = S.memo_cand[type * kMemoCand + k];
+            asm volatile("" : "+v"(g));
+            o.chosen = g;
+        }
+        if (k == 0) o.chosen = best_idx;
+#endif
         if (self_in && k == ks) o.chosen = MMP_SELF;  // :4989-4991
     }
     o.n_candidates = ccount;
-    o.hash = V.hash ^ ((uint32_t)remaining * 0x9E3779B1u);
+    o.hash = (uint32_t)(hsum ^ (hsum >> 32)) ^ ((uint32_t)remaining * 0x9E3779B1u);
     A.outs[d] = o;
     return true;
 }
@@ -2376,20 +2528,28 @@ __device__ __forceinline__ bool memo_try(const Snap &S, const PlaceArgs &A, cons
 // the staging nor, at the end, for the lane phase of the workgroup's other wavefronts (with the barriers the check bought nothing
 // for request rows: 27.4 against 25.9 us; without them 24.7).  The kernels WITHOUT the check keep staging + barrier: for them the
 // windows in LDS are the faster read (800k rows: 26.0 against 26.5 us, four streams 17.75 against 18.4).
-template <bool WITH_LONG, int FORM = kReq64, bool MEMO = false, bool NOBAR = false>
+// LIST (the tail launch of the split form, place_tail_body): the workgroup's decisions come as a list — this lane's is `d_list`
+// (-1: none) — and the function may be called again by the same workgroup (it ends behind a barrier then).
+template <bool WITH_LONG, int FORM = kReq64, bool MEMO = false, bool NOBAR = false, bool LIST = false>
 __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, int32_t wpad, unsigned char *smem,
-                                            uint32_t *done_blocks = nullptr, const mmp_place_caller &C = mmp_place_caller{})
+                                            uint32_t *done_blocks = nullptr, const mmp_place_caller &C = mmp_place_caller{}, int d_list = -1)
 {
+    static_assert(!(LIST && NOBAR), "the list form keeps the workgroup's barriers");
     __shared__ int32_t fb_list[kPlaceBlock], lr_list[kPlaceBlock];
     __shared__ int32_t fb_n, lr_n;
     // The staged windows and the per-lane scratch of the lane phase, and the wave path's bitmap tiles (kPlaceWaves x 2
     // bitmaps x wpad words) of the phase behind it, share ONE dynamic LDS region (smem; the host sizes it for the
     // larger of the two, place_lane_lds(T) / the tiles): a 50k-instance table's tiles are 50 KB, and next to 41 KB of
     // windows + scratch they left room for one workgroup per CU (C4, round 2: 86 us per 1M decisions).
+    // NOBAR: nothing orders one wavefront's lane phase before another's general path, so every wavefront has a region of its OWN
+    // (place_wave_lds(wpad) bytes: its lanes' scratch columns, and — the lane phase being over by then — its general path's two tiles).
     TypeWin *s_wins = reinterpret_cast<TypeWin *>(smem);
-    uint64_t *s_scr = reinterpret_cast<uint64_t *>(smem + win_lds_bytes(S.T));  // per lane: the window's eligibility words with the request's exclusions cleared
+    const int wave_nb = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned char *smem_w = smem + (size_t)wave_nb * place_wave_lds(wpad);
+    uint64_t *s_scr = NOBAR ? reinterpret_cast<uint64_t *>(smem_w)
+                            : reinterpret_cast<uint64_t *>(smem + win_lds_bytes(S.T));  // per lane: the window's eligibility words with the request's exclusions cleared
     if (threadIdx.x == 0) fb_n = lr_n = 0;
-    const int d = blockIdx.x * kPlaceBlock + threadIdx.x;
+    const int d = LIST ? d_list : (int)(blockIdx.x * kPlaceBlock + threadIdx.x);
     PHASE_T0();
     // The windows are fetched beside the request (they depend on nothing) and parked in LDS while the
     // request -> model row chain is in flight; the barrier below is the one the lists needed anyway.
@@ -2411,10 +2571,10 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
     // The workgroup barrier sits right behind the request fetch — the one load every decision needs first.  Loads
     // return in order, so the LDS-bound copies issued before it have landed when it has; and nothing issued AFTER the
     // barrier (the model row, the caller's position, the late-bound exclusions) has to be drained for it.
-    mmp_place_req rq{};
-    if (d < A.n) rq = fetch_req<FORM>(A, C, d);
     // bounded calls: a request whose exclusions lie outside the declared pool is answered here and takes no further part
-    bool live = d < A.n;
+    bool live = LIST ? d >= 0 : d < A.n;
+    mmp_place_req rq{};
+    if (live) rq = fetch_req<FORM>(A, C, d);
     if (A.extra_bound != 0) {  // (wave-uniform)
         if (live && bad_extra_range(A, rq)) {
             live = false;
@@ -2464,7 +2624,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
         __syncthreads();
     }
     // the type's recorded shortlist first (TypeMemo): a wavefront whose requests are all covered is done here
-    if (MEMO && live && memo_try<FORM>(S, A, rq, d)) live = false;
+    if (MEMO && live && memo_try<FORM>(S, A, rq, d, S.memo)) live = false;
     ResolvedReq r;
     int wcode = 0;  // (NOBAR) this lane's decision is left to the general path
     if (live) r = resolve_req<false, true>(S, A, rq);
@@ -2476,7 +2636,9 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
             merge_late_extras(r);
             code = lane_decide_r<false, true>(Sl, A, r, o, Bt);
         } else {
-            if (use_wins) code = lane_decide_win(S, A, r, Ws, s_scr + threadIdx.x, o);
+            if (use_wins)
+                code = NOBAR ? lane_decide_win<false, false, 64>(S, A, r, Ws, s_scr + lane_id(), o)
+                             : lane_decide_win(S, A, r, Ws, s_scr + threadIdx.x, o);
             if (code == kLaneHeadMiss) {
                 merge_late_extras(r);
                 code = lane_decide_r<false>(S, A, r, o, Bt);
@@ -2506,7 +2668,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
             int32_t *mine = fb_list + wave * 64;
             if (wcode) mine[__popcll((unsigned long long)(fb & ((1ull << lane_id()) - 1ull)))] = d;
             wave_sync();
-            uint64_t *ew = reinterpret_cast<uint64_t *>(smem) + (size_t)wave * 2 * wpad;
+            uint64_t *ew = reinterpret_cast<uint64_t *>(smem_w);  // (this wavefront's own region: its lane phase is over)
             uint64_t *fw = ew + wpad;
             const int nf = __popcll((unsigned long long)fb);
             for (int i = 0; i < nf; i++) {
@@ -2515,6 +2677,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
                 wave_sync();
             }
         }
+        announce_done(DoneFlag{A.done_flag, done_blocks, A.done_seq});  // (latency-slot launches of the barrier-free long kernel; a no-op otherwise)
         return;
     }
     __syncthreads();
@@ -2548,6 +2711,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
     PHASE(10);  // long phase + wave path
     PHASE_COUNT(11, 1);  // wavefronts
     announce_done(DoneFlag{A.done_flag, done_blocks, A.done_seq});
+    if (LIST) __syncthreads();  // the next call resets the lists
 }
 
 // 6 wavefronts per SIMD (80 VGPRs, 100 bytes of spill per lane) instead of the 5 the unconstrained allocation (95) gives:
@@ -2599,7 +2763,7 @@ __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(MMP
 // caller's entry, the fresh-row break off / on; then the wavefront writes the candidates' pod indices in shortlist order.
 // (the last blocks of build_sel_memo_kernel: one launch builds sel / rk and the shortlists — both need only what level 2 left)
 __device__ __forceinline__ void build_memo_body(int t, const Snap &S, const TypeWin *__restrict__ wins, TypeMemo *__restrict__ memo,
-                                                int32_t *__restrict__ cand)
+                                                int32_t *__restrict__ cand, int16_t *__restrict__ rkt)
 {
     constexpr int kScr = 2;  // scratch columns: the two lanes that decide
     __shared__ uint64_t scr[kWinWords * kScr];
@@ -2625,9 +2789,10 @@ __device__ __forceinline__ void build_memo_body(int t, const Snap &S, const Type
     }
     __syncthreads();
     const int w0 = wins[t].w0;
+    const bool any = ok[0] || ok[1];
+    const MemoCap &c0 = caps[ok[0] ? 0 : 1];  // the best row does not depend on the bit
     if (lane == 0) {
-        TypeMemo M{};
-        const MemoCap &c0 = caps[ok[0] ? 0 : 1];  // the best row does not depend on the bit
+        TypeMemoHead M{};
         M.b_rem = c0.b_rem;
         M.b_lru = c0.b_lru;
         M.best_is_full = c0.best_is_full;
@@ -2635,37 +2800,62 @@ __device__ __forceinline__ void build_memo_body(int t, const Snap &S, const Type
         M.best_idx = c0.best_idx;
         M.plain = c0.bestpos == c0.best0;
         M.w0 = w0;
+        M.bestpos = c0.bestpos;
+        M.best0 = c0.best0;
+        M.e_rpm = c0.e_rpm;
+        M.sbk = c0.sbk ? 1 : 0;
         M.end0 = caps[0].end;
-        for (int j = 0; j < kWinWords; j++) M.cw[j] = (ok[0] && w0 + j >= caps[0].wlo && w0 + j <= caps[0].whi) ? scr[j * kScr] : 0ull;
         for (int v = 0; v < 2; v++) {
             const MemoCap &c = caps[v];
             M.v[v].valid = ok[v];
             M.v[v].lo = c.best0;
             M.v[v].hi = c.end == kNoPos ? S.P : c.end + 1;  // the instance that ends the list is part of what the answer depends on
             M.v[v].ccount = c.ccount;
+            M.v[v].hsum = c.hsum;
             M.v[v].hash = (uint32_t)(c.hsum ^ (c.hsum >> 32));
         }
-        memo[t] = M;
+        static_cast<TypeMemoHead &>(memo[t]) = M;
     }
-    for (int v = 0; v < 2; v++) {
-        if (!ok[v]) continue;
-        int32_t *out = cand + ((size_t)t * 2 + v) * kMemoCand;
-        int running = 0;
-        for (int w = caps[v].wlo; w <= caps[v].whi; w++) {
-            const uint64_t word = scr[v + (w - w0) * kScr];  // the walk parked the clipped candidate words here (best bit set)
-            if ((word >> lane) & 1ull) out[running + __popcll((unsigned long long)(word & ((1ull << lane) - 1ull)))] = S.orig[w * 64 + lane];
-            running += __popcll((unsigned long long)word);
+    __shared__ int32_t near_c[kMemoNear];  // the row's own copy of the list's head (TypeMemo::cand64 / ::rk64), gathered here first
+    __shared__ int32_t near_r[kMemoNear];
+    near_c[lane] = 0;
+    near_r[lane] = kRkNone;
+    wave_sync();
+    // list 0: the candidates' pod indices in shortlist order, and what every position of the window is to the list
+    int32_t *out = cand + (size_t)t * kMemoCand;
+    int16_t *rk = rkt + (size_t)t * kMemoCand;
+    int running = 0;
+    for (int j = 0; j < kWinWords; j++) {
+        const int w = w0 + j, pos = w * 64 + lane;
+        // the walk parked the clipped candidate words here (best bit set)
+        const uint64_t word = (ok[0] && w >= caps[0].wlo && w <= caps[0].whi) ? scr[j * kScr] : 0ull;
+        const bool bit = (word >> lane) & 1ull;
+        const int k = running + __popcll((unsigned long long)(word & ((1ull << lane) - 1ull)));
+        int v = kRkNone;
+        if (bit) {
+            v = k;  // (the best instance is the list's first bit: k == 0)
+            const int32_t pod = S.orig[pos];
+            out[k] = pod;
+            if (k < kMemoNear) near_c[k] = pod;
         }
+        if (any && pos == c0.bestpos) v = 0;
+        if (any && pos == c0.best0 && c0.best0 != c0.bestpos) v = kRkFirst;
+        rk[j * 64 + lane] = (int16_t)v;
+        if (any && pos >= c0.best0 && pos - c0.best0 < kMemoNear) near_r[pos - c0.best0] = v;
+        running += __popcll((unsigned long long)word);
     }
+    wave_sync();
+    memo[t].cand64[lane] = near_c[lane];
+    memo[t].rk64[lane] = (int16_t)near_r[lane];
 }
 __global__ __launch_bounds__(64) void build_sel_memo_kernel(Snap S, int32_t *__restrict__ sel, int32_t *__restrict__ rk, const TypeWin *__restrict__ wins,
-                                                            TypeMemo *__restrict__ memo, int32_t *__restrict__ cand)
+                                                            TypeMemo *__restrict__ memo, int32_t *__restrict__ cand, int16_t *__restrict__ memo_rk)
 {
     const int n_sel = 2 * S.T * S.W;
     if ((int)blockIdx.x < n_sel)
         build_sel_body((int)blockIdx.x, S, sel, rk);
     else
-        build_memo_body((int)blockIdx.x - n_sel, S, wins, memo, cand);
+        build_memo_body((int)blockIdx.x - n_sel, S, wins, memo, cand, memo_rk);
 }
 
 // The window kernels with the recorded shortlists in front (place_block<..., MEMO, NOBAR>; see TypeMemo): a wavefront whose 64 requests
@@ -2694,6 +2884,177 @@ __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(7, 
 // 12.7 -> 11.35 / 6.9 -> 6.7 (a caller with room); below, the check is the longer chain — a 100k launch of rows: 7.75 -> 8.6 us)
 constexpr int kMemoFrom = 4 * 1024 * 64;      // request rows
 constexpr int kMemoFromC = 3 * 1024 * 64;     // the single-caller form
+// decisions from which a batch is split into place_memo_kernel + place_tail_kernel
+constexpr int kSplitFrom = 4 * 1024 * 64;
+constexpr int kSplitFromC = 3 * 1024 * 64;
+
+// ---- the split form (round 6): a launch that does nothing but the shortlist check, and a dense tail --------------------------------
+// place_batch_m_kernel carries the check AND the ordinary path — ~150 instructions in front of ~1000, one register allocation (72 VGPRs
+// + scratch), 25 KB of LDS per workgroup — so the requests the records cover pay for the ones they do not.  Here the two are two
+// launches.  place_memo_kernel: a lane per request, memo_try and nothing else — no LDS, no barrier, no scratch, 8 wavefronts per
+// SIMD; a wavefront leaves ONE word behind, the ballot of its requests the check did not decide (miss[wavefront]).
+// place_tail_kernel, queued right behind it on the same stream (so it runs while the next batch's first launch does, given a second
+// stream): a handful of workgroups, each sums all the words (a popcount per word, a scan over the workgroup), deals the undecided
+// requests out in runs of 64 — run r to workgroup r mod G — and decides its share with the ordinary place_block, windows, lists,
+// general path and all (place_block<..., LIST>).  With the check answering 99.9 % of a batch of request rows (C3) the tail is a few
+// hundred requests; a batch the records do not fit (every request with a position inside its list) still comes out right — the tail
+// then loops — and the host stops splitting when a tail reports more than 1/32 of its batch (mmp_ctx::split_off).
+template <int FORM>
+__device__ __forceinline__ void place_memo_body(const Snap &S, const PlaceArgs &A, uint64_t *__restrict__ miss, const mmp_place_caller &C,
+                                                unsigned char *smem)
+{
+    // The types' records (TypeMemo rows: 512 bytes a type) into LDS, a copy per WAVEFRONT — global -> LDS directly, issued before the
+    // request fetch and landed when that has (loads return in order), no barrier: the check then reads its type's record, the head of
+    // its candidate list and what its own positions are to the list from LDS instead of as three more dependent levels of (L1-resident)
+    // global gathers — a record is 80 bytes per lane, more than the request itself.
+    const int stage = memo_stage_bytes(S.T);
+    unsigned char *mine = smem + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * stage;
+    {
+        const char *src = reinterpret_cast<const char *>(S.memo);
+        for (int c = 0; c < stage; c += 1024)
+            __builtin_amdgcn_global_load_lds(src + c + lane_id() * 16, (__attribute__((address_space(3))) void *)(mine + c), 16, 0, 0);
+    }
+    const int d = blockIdx.x * kPlaceBlock + threadIdx.x;
+    bool live = d < A.n;
+    mmp_place_req rq{};
+    if (live) rq = fetch_req<FORM>(A, C, d);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_sync();
+    if (A.extra_bound != 0) {  // (wave-uniform) bounded calls: as place_block answers them
+        if (live && bad_extra_range(A, rq)) {
+            live = false;
+            mmp_place_out bo;
+            bo.chosen = MMP_NONE;
+            bo.best = MMP_BAD_REQUEST;
+            bo.n_candidates = 0;
+            bo.hash = 0;
+            A.outs[d] = bo;
+        }
+    }
+    bool todo = false;
+#ifdef MMP_XP_STREAM  // (experiment builds only: the batch streamed in and out, nothing decided — the floor of a kernel of this form)
+    if (live) {
+        mmp_place_out o;
+        o.chosen = rq.model ^ rq.self_pod;
+        o.best = (int32_t)(rq.pick ^ rq.flags) + rq.n_extra + rq.extra_off;
+        o.n_candidates = (int32_t)(rq.last_used ^ rq.fresh_lru);
+        o.hash = (uint32_t)(rq.fresh_capacity ^ rq.fresh_used) + (uint32_t)rq.fresh_count + (uint32_t)rq.fresh_rpm;
+        A.outs[d] = o;
+    }
+#else
+    if (live) todo = !memo_try<FORM>(S, A, rq, d, reinterpret_cast<const TypeMemo *>(mine));
+#endif
+    const uint64_t mk = __ballot(todo);
+    if (lane_id() == 0) miss[d >> 6] = mk;
+}
+__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void place_memo_kernel(Snap S, PlaceArgs A, uint64_t *__restrict__ miss)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    place_memo_body<kReq64>(S, A, miss, mmp_place_caller{}, smem);
+}
+__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void place_memo_c_kernel(Snap S, PlaceArgs A, uint64_t *__restrict__ miss,
+                                                                                                           mmp_place_caller C)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    place_memo_body<kReqC>(S, A, miss, C, smem);
+}
+
+// n_words = the first launch's wavefronts (ceil(n / 64)); `total_out` (may be null): workgroup 0 leaves {undecided requests, n}
+// there (pinned host memory: the host reads the pair some launches later, never waits for it)
+template <int FORM>
+__device__ __forceinline__ void place_tail_body(const Snap &S, const PlaceArgs &A, int32_t wpad, unsigned char *smem, const uint64_t *__restrict__ miss,
+                                                int32_t n_words, int32_t *total_out, const mmp_place_caller &C)
+{
+    __shared__ int32_t t_wsum[kPlaceWaves];
+    __shared__ int32_t t_list[kPlaceBlock];
+    // A tail wavefront is ONE long dependent chain on a SIMD it shares with up to eight wavefronts of the next batch's first launch:
+    // it goes first whenever it can issue (the few of them cost the others nothing; without it a tail lasted as long as the launch
+    // it ran beside)
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const int G = gridDim.x, g = blockIdx.x;
+    // Thread t owns the word PAIRS t, t + 256, ... (16-byte loads, coalesced, sixteen in flight per trip: a loop of single dependent
+    // loads was 35 us for the 12 500 words of an 800k batch); ANY numbering of the undecided requests will do — a result row goes to
+    // its request's index whoever decides it.  nzmap: which of the thread's first 64 pairs hold a bit at all (the second walk below
+    // visits only those).
+    typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+    const u64x2_t *pairs = reinterpret_cast<const u64x2_t *>(miss);
+    const int n_pairs = (n_words + 1) >> 1;
+    auto pair_at = [&](int p) {  // (the word behind the last one is not the first launch's to write)
+        u64x2_t v = pairs[p];
+        if (2 * p + 1 >= n_words) v.y = 0ull;
+        return v;
+    };
+    int cnt = 0;
+    uint64_t nzmap = 0;
+    for (int i0 = 0; i0 * kPlaceBlock + tid < n_pairs; i0 += 16) {
+        u64x2_t m[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int p = (i0 + j) * kPlaceBlock + tid;
+            m[j] = p < n_pairs ? pair_at(p) : u64x2_t{0ull, 0ull};
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            cnt += __popcll(m[j].x) + __popcll(m[j].y);
+            if ((m[j].x | m[j].y) && i0 + j < 64) nzmap |= 1ull << (i0 + j);
+        }
+    }
+    const int incl = wave_incl_scan_i32(cnt);
+    if (lane == 63) t_wsum[wave] = incl;
+    __syncthreads();
+    int off = incl - cnt, total = 0;
+#pragma unroll
+    for (int k = 0; k < kPlaceWaves; k++) {
+        if (k < wave) off += t_wsum[k];
+        total += t_wsum[k];
+    }
+    if (total_out && g == 0 && tid == 0) {
+        __hip_atomic_store(total_out, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(total_out + 1, A.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // run r = ranks [64 r, 64 r + 64) belongs to workgroup r mod G, as its (r / G)-th run: four runs a pass
+    const int runs = (total + 63) >> 6;
+    for (int pass = 0; (pass * kPlaceWaves) * G + g < runs; pass++) {  // (workgroup-uniform)
+        t_list[tid] = -1;
+        __syncthreads();
+        if (cnt) {
+            int r = off;
+            auto visit = [&](int p, const u64x2_t v) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    uint64_t m = h ? v.y : v.x;
+                    while (m) {
+                        const int b = __ffsll((unsigned long long)m) - 1;
+                        m &= m - 1;
+                        const int run = r >> 6, q = run / G;
+                        if (run - q * G == g && q / kPlaceWaves == pass) t_list[(q % kPlaceWaves) * 64 + (r & 63)] = (2 * p + h) * 64 + b;
+                        r++;
+                    }
+                }
+            };
+            for (uint64_t mp = nzmap; mp; mp &= mp - 1) {
+                const int p = (__ffsll((unsigned long long)mp) - 1) * kPlaceBlock + tid;
+                visit(p, pair_at(p));
+            }
+            for (int p = 64 * kPlaceBlock + tid; p < n_pairs; p += kPlaceBlock) visit(p, pair_at(p));  // (batches beyond 2M decisions)
+        }
+        __syncthreads();
+        place_block<false, FORM, false, false, true>(S, A, wpad, smem, nullptr, C, t_list[tid]);
+    }
+}
+__global__ __launch_bounds__(kPlaceBlock) void place_tail_kernel(Snap S, PlaceArgs A, int32_t wpad, const uint64_t *__restrict__ miss, int32_t n_words,
+                                                                 int32_t *total_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    place_tail_body<kReq64>(S, A, wpad, smem, miss, n_words, total_out, mmp_place_caller{});
+}
+__global__ __launch_bounds__(kPlaceBlock) void place_tail_c_kernel(Snap S, PlaceArgs A, int32_t wpad, const uint64_t *__restrict__ miss, int32_t n_words,
+                                                                   int32_t *total_out, mmp_place_caller C)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    place_tail_body<kReqC>(S, A, wpad, smem, miss, n_words, total_out, C);
+}
 
 __global__ __launch_bounds__(kPlaceBlock) void place_batch_long_c_kernel(Snap S, PlaceArgs A, int32_t wpad, mmp_place_caller C)
 {

@@ -60,9 +60,11 @@ struct Snap {
     const int32_t *sel;
     const int32_t *rk;
     // The per-type shortlists of place_kernel.hpp: TypeMemo (round 5; null on shard views and when the head windows are off):
-    // memo[min(T, kWinLds)], memo_cand[kWinLds][2][kMemoCand] = the shortlists' pod indices in candidate order.
+    // memo[kWinLds], memo_cand[kWinLds][kMemoCand] = list 0's pod indices in candidate order, memo_rk[kWinLds][kMemoCand] = what
+    // each position of the type's window is to list 0 (candidate number, the best instance, nothing: kRk*).
     const struct TypeMemo *memo;
     const int32_t *memo_cand;
+    const int16_t *memo_rk;
 };
 
 // count >= 10 is a fixed clause of the shortlist's count break (MM.java:4925-4926); the other clause,

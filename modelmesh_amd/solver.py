@@ -300,6 +300,12 @@ class Solver:
         self._ck(self.lib.mmp_shortlists(self.h, ptr(out), len(out), C.byref(n)))
         return out[: n.value].copy()
 
+    def split_batches(self):
+        """(batches this context decided as two launches — shortlist check + tail —, whether that is switched off): mmp_split_batches."""
+        n, off = C.c_int64(0), C.c_int32(0)
+        self._ck(self.lib.mmp_split_batches(self.h, C.byref(n), C.byref(off)))
+        return int(n.value), bool(off.value)
+
     def stats(self) -> np.ndarray:
         out = np.zeros(1, dtype=STATS)
         self._ck(self.lib.mmp_cluster_stats(self.h, ptr(out)))

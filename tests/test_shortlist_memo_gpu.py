@@ -1,11 +1,13 @@
 """GPU: batches — of one caller and of request rows — decided with the per-type shortlists a commit records (place_kernel.hpp:
-TypeMemo, memo_try, place_batch_c_m_kernel / place_batch_m_kernel; include/mmplace.h: mmp_shortlists) equal the oracle AND the same
-context with the shortlists switched off (MMP_NO_MEMO=1: every request on the ordinary lane path) — on the bench configuration, on
-fuzzed fleets of every profile (MMP_MEMO_FROM=0 sends batches of every size through those kernels; by default they take launches that
-fill the chip);
+TypeMemo, memo_try; include/mmplace.h: mmp_shortlists, mmp_split_batches) equal the oracle AND the same context with the shortlists
+switched off (MMP_NO_MEMO=1: every request on the ordinary lane path) — on the bench configuration, on fuzzed fleets of every profile;
 on batches built so that EVERY request has a position of its own inside its shortlist (the calling instance, a model's loaded
-instance, a request's own exclusion: the check must send them all down the ordinary path); and across commits and registry events
-that move the shortlists (the block bits of the resolved registry view are rebuilt)."""
+instance, a request's own exclusion: the check takes excluded candidates out of the recorded list and treats the caller as one more
+candidate, and leaves what changes the walk itself to the ordinary path); and across commits and registry events that move the
+shortlists (the registry's per-model words are rebuilt).  Every test runs in BOTH forms the library has for such batches, at every
+batch size (by default they take launches that fill the chip): "one launch" = the check in front of the lane phase of the same kernel
+(place_batch_m_kernel / place_batch_c_m_kernel: MMP_MEMO_FROM=0, MMP_NO_SPLIT=1) and "split" = the check alone in a first launch, the
+rest in a dense tail launch (place_memo_kernel + place_tail_kernel: MMP_SPLIT_FROM=0)."""
 import numpy as np
 import pytest
 
@@ -18,9 +20,14 @@ pytestmark = pytest.mark.gpu
 FIELDS = ("chosen", "best", "n_candidates", "hash")
 
 
-@pytest.fixture(autouse=True)
-def _every_batch_through_the_shortlists(monkeypatch):
+@pytest.fixture(autouse=True, params=["one launch", "split"])
+def _every_batch_through_the_shortlists(request, monkeypatch):
     monkeypatch.setenv("MMP_MEMO_FROM", "0")
+    if request.param == "split":
+        monkeypatch.setenv("MMP_SPLIT_FROM", "0")
+    else:
+        monkeypatch.setenv("MMP_NO_SPLIT", "1")
+    return request.param
 
 
 def _solver(fleet):
@@ -81,7 +88,7 @@ def covered_share(s, fleet, orc, reqs, extra):
     return float(ok.mean())
 
 
-def test_bench_configuration_is_covered_and_exact():
+def test_bench_configuration_is_covered_and_exact(_every_batch_through_the_shortlists):
     """C3, one decision per model from one caller: all four type rows have both shortlists, they answer > 97 % of the requests
     (the rest carry a position of their own inside the list), and every decision equals the oracle's; so do batches that are not
     a whole number of workgroups, callers that favour themselves, are absent from the table, or bring a drifted fresh record."""
@@ -105,6 +112,11 @@ def test_bench_configuration_is_covered_and_exact():
         assert covered_share(s, fleet, orc, reqs, extra) > 0.97
         _same(s.place(reqs, extra, fleet.now), orc.place(reqs, extra, fleet.now, threads=8), "request rows")
         _same(s.place(reqs[:70_001], extra, fleet.now), orc.place(reqs[:70_001], extra, fleet.now, threads=8), "request rows, n=70001")
+        n_split, off = s.split_batches()
+        if _every_batch_through_the_shortlists == "split":
+            assert n_split >= 7 and not off, (n_split, off)  # every batch above (but the one of 1500: a latency slot) took the two launches; no tail was large
+        else:
+            assert n_split == 0
     finally:
         s.close()
 
@@ -219,5 +231,103 @@ def test_shortlists_follow_commits_and_registry_events():
                 fleet.ent_time = np.concatenate([fleet.ent_time, new_time])
                 fleet.models[mi] = rows
         assert len(seen) > 1, "the write stream never moved a shortlist"
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("blocks", [1, 3, 16, 64])
+def test_the_tail_deals_its_requests_out_whatever_its_size(blocks, monkeypatch, _every_batch_through_the_shortlists):
+    """The split form's second launch (place_tail_kernel) with 1 / 3 / 16 / 64 workgroups, on a batch that is not a whole number of
+    wavefronts and in which every third request has a position of its own at the head of the order: a few thousand undecided
+    requests, several passes per workgroup when there are few of them — every row equals the oracle's."""
+    if _every_batch_through_the_shortlists != "split":
+        pytest.skip("the split form only")
+    monkeypatch.setenv("MMP_TAIL_BLOCKS", str(blocks))
+    fleet = wl.make_fleet("C2")
+    orc = OracleFleet(fleet)
+    rng = np.random.default_rng(blocks)
+    reqs, extra = wl.make_requests(fleet, 21, n=30_011)
+    n = len(reqs)
+    head = orc.order[:8].astype(np.int32)
+    sel = rng.random(n) < 0.33
+    reqs["self_pod"] = np.where(sel, rng.choice(head, n), reqs["self_pod"])
+    row = fleet.pods[reqs["self_pod"]]
+    for f, g in (("fresh_lru", "lru_time"), ("fresh_capacity", "capacity"), ("fresh_used", "used"), ("fresh_count", "count")):
+        reqs[f] = row[g]
+    s = _solver(fleet)
+    try:
+        _same(s.place(reqs, extra, fleet.now), orc.place(reqs, extra, fleet.now, threads=8), f"{blocks} workgroups")
+        assert s.split_batches()[0] == 1
+    finally:
+        s.close()
+
+
+def test_a_batch_the_records_do_not_fit_switches_the_split_off_until_the_next_commit(_every_batch_through_the_shortlists):
+    """Every request called by the type's best instance without favourSelf: the check decides none of them, the tail all — right, but
+    slowly — and reports it; the batches after it go through one launch until a commit gives the split another chance."""
+    if _every_batch_through_the_shortlists != "split":
+        pytest.skip("the split form only")
+    fleet = wl.make_fleet("C2")
+    orc = OracleFleet(fleet)
+    reqs, extra = wl.make_requests(fleet, 33, n=20_000, extra_frac=0.0)
+    hostile = reqs.copy()
+    hostile["self_pod"] = orc.order[0]
+    hostile["flags"] = 0
+    row = fleet.pods[hostile["self_pod"]]
+    for f, g in (("fresh_lru", "lru_time"), ("fresh_capacity", "capacity"), ("fresh_used", "used"), ("fresh_count", "count")):
+        hostile[f] = row[g]
+    s = _solver(fleet)
+    try:
+        _same(s.place(hostile, extra, fleet.now), orc.place(hostile, extra, fleet.now, threads=8), "hostile")
+        assert s.split_batches() == (1, False)  # (the report is read by the NEXT split batch of the stream)
+        _same(s.place(reqs, extra, fleet.now), orc.place(reqs, extra, fleet.now, threads=8), "after")
+        n_split, off = s.split_batches()
+        assert off and n_split == 1, (n_split, off)
+        _same(s.place(reqs, extra, fleet.now), orc.place(reqs, extra, fleet.now, threads=8), "unsplit")
+        assert s.split_batches() == (1, True)
+        s.commit()
+        assert s.split_batches() == (1, False)
+        _same(s.place(reqs, extra, fleet.now), orc.place(reqs, extra, fleet.now, threads=8), "after the commit")
+        assert s.split_batches() == (2, False)
+    finally:
+        s.close()
+
+
+def test_more_exclusions_than_the_lane_phase_takes_next_to_requests_the_check_leaves(_every_batch_through_the_shortlists):
+    """in the kernels without a workgroup barrier a wavefront's general path (a model with more than 8 excluded
+    instances: place_one, two tiles of the whole table in LDS) ran while other wavefronts of the workgroup were still in their lane
+    phase on per-lane LDS scratch that overlapped those tiles.  Every wavefront now owns its region (place_wave_lds).  A batch that
+    mixes both kinds in every workgroup, 5 000 instances (tiles of 1.3 KB over the scratch columns), decided three times."""
+    fleet = wl.make_fleet("C3", models=40_000, pods=5_000)
+    rng = np.random.default_rng(77)
+    # a sixth of the models get 9-12 loaded instances spread over the table
+    m = fleet.models
+    big = rng.random(fleet.n_models) < 0.16
+    k = np.where(big, rng.integers(9, 13, fleet.n_models), m["n_loaded"] + m["n_failed"]).astype(np.int64)
+    off = np.zeros(fleet.n_models + 1, np.int64)
+    np.cumsum(k, out=off[1:])
+    ent = np.zeros(int(off[-1]), np.int32)
+    for i in range(fleet.n_models):
+        if big[i]:
+            ent[off[i]:off[i + 1]] = np.sort(rng.choice(fleet.n_pods, int(k[i]), replace=False))
+        else:
+            ent[off[i]:off[i + 1]] = fleet.ent_pod[m["ent_off"][i]: m["ent_off"][i] + k[i]]
+    fleet.ent_pod, fleet.ent_time = ent, np.full(len(ent), fleet.now - 10_000, np.int64)
+    fleet.models["ent_off"] = off[:-1]
+    fleet.models["n_loaded"] = np.where(big, k, m["n_loaded"])
+    fleet.models["n_failed"] = np.where(big, 0, m["n_failed"])
+    orc = OracleFleet(fleet)
+    reqs, extra = wl.make_requests(fleet, 5)
+    head = orc.order[:40].astype(np.int32)
+    sel = rng.random(len(reqs)) < 0.2  # ... and a fifth of the callers stand at the head of the order (the lane phase runs in every workgroup)
+    reqs["self_pod"] = np.where(sel, rng.choice(head, len(reqs)), reqs["self_pod"])
+    row = fleet.pods[reqs["self_pod"]]
+    for f, g in (("fresh_lru", "lru_time"), ("fresh_capacity", "capacity"), ("fresh_used", "used"), ("fresh_count", "count")):
+        reqs[f] = row[g]
+    want = orc.place(reqs, extra, fleet.now, threads=8)
+    s = _solver(fleet)
+    try:
+        for rep in range(3):
+            _same(s.place(reqs, extra, fleet.now), want, f"rep {rep}")
     finally:
         s.close()
