@@ -119,6 +119,7 @@ struct SnapSide {
 // the latency slots, the resident kernel's request slots) is allocated fine-grained and device-mapped explicitly:
 // hipHostMallocDefault would leave the choice to the process environment (HIP_HOST_COHERENT).
 constexpr unsigned int kPinnedFlags = hipHostMallocCoherent | hipHostMallocMapped;
+constexpr int kTailStaticLds = 512;  // what place_tail_body keeps in static LDS beside place_block's own
 constexpr int kTailBlocks = 16;    // workgroups of a split batch's tail launch (measured: see place_kernel.hpp)
 constexpr int kMaxMissBufs = 64;   // streams with split batches in flight that get a buffer of their own (more: those batches go unsplit)
 constexpr int kFastSlots = 4;
@@ -205,8 +206,8 @@ struct mmp_ctx {
     // so one buffer per stream will do) and a pinned pair the tail reports to: {undecided, of how many}
     struct MissBuf {
         hipStream_t st = nullptr;
-        uint64_t *words = nullptr;
-        size_t cap = 0;
+        int32_t *words = nullptr;  // place_kernel.hpp: rest_buffer_ints — counters + kRestLists lists
+        size_t cap = 0;            // ints
         int32_t *report = nullptr;
     };
     std::vector<MissBuf> miss_bufs;   // guarded by miss_mu (a leaf lock)
@@ -502,9 +503,9 @@ hipError_t slot_wait(FastSlot *f, uint32_t seq)
 }
 
 hipError_t order_after_registry(mmp_ctx *c, hipStream_t st);
-// The word buffer of a split batch on `st` (n_words wavefronts) and the stream's report pair; false: none to be had (too many
-// streams, no memory) — the batch goes unsplit.  Also reads what the stream's last tail reported.
-bool miss_buffer(mmp_ctx *c, hipStream_t st, size_t n_words, uint64_t **words, int32_t **report)
+// The buffer of a split batch on `st` (`ints`: rest_buffer_ints of its first launch) and the stream's report pair; false: none to be
+// had (too many streams, no memory) — the batch goes unsplit.  Also reads what the stream's last tail reported.
+bool miss_buffer(mmp_ctx *c, hipStream_t st, size_t ints, int32_t **words, int32_t **report)
 {
     std::lock_guard<std::mutex> g(c->miss_mu);
     mmp_ctx::MissBuf *mb = nullptr;
@@ -525,13 +526,18 @@ bool miss_buffer(mmp_ctx *c, hipStream_t st, size_t n_words, uint64_t **words, i
         c->miss_bufs.push_back(nb);
         mb = &c->miss_bufs.back();
     }
-    if (mb->cap < n_words) {
-        size_t want = std::max<size_t>(n_words, 4096);
-        want = std::max(want, mb->cap * 2);
+    if (mb->cap < ints) {
+        size_t want = std::max<size_t>(ints, 65536);
+        want = std::max(want, mb->cap + mb->cap / 2);
         void *p = nullptr;
-        if (hipMalloc(&p, want * sizeof(uint64_t)) != hipSuccess) return false;
+        if (hipMalloc(&p, want * sizeof(int32_t)) != hipSuccess) return false;
+        // the counters start at zero (every tail leaves them so); ordered before the stream's first launch on this buffer
+        if (hipMemsetAsync(p, 0, (size_t)kRestLists * kRestCntStride * sizeof(int32_t), st) != hipSuccess) {
+            (void)hipFree(p);
+            return false;
+        }
         if (mb->words) c->miss_retired.push_back(mb->words);  // (a launch in flight may still read it)
-        mb->words = static_cast<uint64_t *>(p);
+        mb->words = static_cast<int32_t *>(p);
         mb->cap = want;
     }
     // the last tail of this stream that has finished: more than 1/32 of its batch undecided -> the records do not fit these batches
@@ -632,8 +638,8 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_m_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_long_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_long4_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_tail_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want - kTailStaticLds));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_tail_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want - kTailStaticLds));
         c->lds_granted.store((size_t)want, std::memory_order_release);
     }
     // batches with the per-type shortlists in front (place_batch_m_kernel / place_batch_c_m_kernel): head windows and the resolved registry
@@ -647,17 +653,22 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     if (use_memo && !segs && !c->no_split && !c->split_off.load(std::memory_order_relaxed) &&
         n >= (c->split_from >= 0 ? c->split_from : (caller ? kSplitFromC : kSplitFrom))) {
         const int grid = div_up(n, kPlaceBlock);
-        uint64_t *words = nullptr;
+        const int n_words = grid * kPlaceWaves;  // wavefronts of the first launch
+        const int cap = rest_list_cap(n_words);
+        int32_t *words = nullptr;
         int32_t *report = nullptr;
-        if (miss_buffer(c, st, (size_t)grid * kPlaceWaves, &words, &report) && !c->split_off.load(std::memory_order_relaxed)) {
-            const int n_words = div_up(n, 64);
+        if (lds + kPlaceStaticLds + kTailStaticLds <= c->lds_limit && miss_buffer(c, st, rest_buffer_ints(n_words), &words, &report) &&
+            !c->split_off.load(std::memory_order_relaxed)) {
             const size_t lds_memo = (size_t)kPlaceWaves * memo_stage_bytes(c->snap.T);  // a copy of the types' records per wavefront
+            if (c->split_notail) words = nullptr;  // (diagnostics: the undecided requests are not even recorded)
             if (caller) {
-                hipLaunchKernelGGL(place_memo_c_kernel, dim3(grid), dim3(kPlaceBlock), lds_memo, st, c->snap, A, words, *caller);
-                if (!c->split_notail) hipLaunchKernelGGL(place_tail_c_kernel, dim3(c->tail_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, words, n_words, report, *caller);
+                hipLaunchKernelGGL(place_memo_c_kernel, dim3(grid), dim3(kPlaceBlock), lds_memo, st, c->snap, A, words, cap, *caller);
+                if (!c->split_notail)
+                    hipLaunchKernelGGL(place_tail_c_kernel, dim3(c->tail_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, words, cap, report, *caller);
             } else {
-                hipLaunchKernelGGL(place_memo_kernel, dim3(grid), dim3(kPlaceBlock), lds_memo, st, c->snap, A, words);
-                if (!c->split_notail) hipLaunchKernelGGL(place_tail_kernel, dim3(c->tail_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, words, n_words, report);
+                hipLaunchKernelGGL(place_memo_kernel, dim3(grid), dim3(kPlaceBlock), lds_memo, st, c->snap, A, words, cap);
+                if (!c->split_notail)
+                    hipLaunchKernelGGL(place_tail_kernel, dim3(c->tail_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, words, cap, report);
             }
             HIP_TRY(c, hipGetLastError());
             c->n_split.fetch_add(1, std::memory_order_relaxed);
@@ -744,7 +755,7 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     if (const char *mf = getenv("MMP_MEMO_FROM")) c->memo_from = atoi(mf);
     if (const char *ns = getenv("MMP_NO_SPLIT")) c->no_split = ns[0] == '1';
     if (const char *sf = getenv("MMP_SPLIT_FROM")) c->split_from = atoi(sf);
-    if (const char *tb = getenv("MMP_TAIL_BLOCKS")) c->tail_blocks = std::max(1, std::min(atoi(tb), 1024));
+    if (const char *tb = getenv("MMP_TAIL_BLOCKS")) c->tail_blocks = std::max(1, std::min(atoi(tb), kRestLists));
     if (const char *nt = getenv("MMP_SPLIT_NOTAIL")) c->split_notail = nt[0] == '1';
     if (const char *nl = getenv("MMP_NO_LONG_LDS")) c->no_long_lds = nl[0] == '1';
     if (const char *nb = getenv("MMP_NO_CASEB")) c->no_caseb = nb[0] == '1';

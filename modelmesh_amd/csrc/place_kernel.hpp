@@ -2345,9 +2345,21 @@ __device__ __forceinline__ bool memo_try(const Snap &S, const PlaceArgs &A, cons
     for (int j = 0; j < kLateExtra; j++) xp[j] = -1;
     const bool x_ok = (uint32_t)rq.n_extra <= (uint32_t)kLateExtra && !(A.extra_bound != 0 && bad_extra_range(A, rq));
     if (__ballot(x_ok && rq.n_extra > 0)) {  // (wave-uniform) the request's own exclusions: their positions
+        // Branch-free: all four pool reads in flight together, then all four position gathers (a lane without a j-th exclusion reads a
+        // harmless word instead) — a load under a branch of its own is waited for before the next one is issued, and with one request
+        // in twenty carrying 1-3 exclusions nearly every wavefront walked them as six dependent levels.
+        int32_t ep[kLateExtra];
 #pragma unroll
-        for (int j = 0; j < kLateExtra; j++)
-            if (x_ok && j < rq.n_extra) xp[j] = pod_view_pos<false>(S, A.extra[rq.extra_off + j], S.P);
+        for (int j = 0; j < kLateExtra; j++) {
+            const int32_t *pa = (x_ok && j < rq.n_extra) ? A.extra + rq.extra_off + j : S.pos_of;
+            ep[j] = *pa;
+        }
+#pragma unroll
+        for (int j = 0; j < kLateExtra; j++) {
+            const bool on = x_ok && j < rq.n_extra && (uint32_t)ep[j] < (uint32_t)S.P;
+            const int32_t v = S.pos_of[on ? ep[j] : 0];
+            xp[j] = on ? v : -1;
+        }
     }
     // second level: the type's record — the best row AND both lists' headers at once (one level of the chain instead of two; the lean
     // kernel has the registers)
@@ -2396,22 +2408,38 @@ __device__ __forceinline__ bool memo_try(const Snap &S, const PlaceArgs &A, cons
             // what each own position is to the list: one lookup apiece, all in flight together — in the row itself for the first
             // kMemoNear positions from the first eligible instance on (nearly always), else in the window-wide table
             const int16_t *RK = S.memo_rk + type * kMemoCand;
-            auto rk_of = [&](int pos) {
-                const int rel = pos - lo;  // (lo = the type's first eligible instance for either list; callers pass positions >= lo)
-                int v = (int)Mp->rk64[rel < kMemoNear ? rel : 0];
-                if (rel >= kMemoNear) {  // (the row may live in LDS, the table does not: kept apart from the load above, or the
-                    int g = (int)RK[pos - wl];           // compiler merges the two into one FLAT load through a selected pointer)
-                    asm volatile("" : "+v"(g));
-                    v = g;
-                }
-                return v;
-            };
+            // (all seven row reads first, then — hardly ever — the window-wide table for the positions the row does not reach: kept
+            // apart, or the compiler merges a row read and a table read into one FLAT load through a selected pointer)
             const int o1 = (int)(moff & kMtwOffMask) - 1, o2 = (int)((moff >> 9) & kMtwOffMask) - 1;
-            const int srk = sp_in ? rk_of(sp) : kRkNone;
+            int qp[kLateExtra + 3];  // the own positions that lie inside [lo, hi), -1: none
+            qp[0] = sp_in ? sp : -1;
+            qp[1] = o1 >= 0 ? wl + o1 : -1;
+            qp[2] = o2 >= 0 ? wl + o2 : -1;
+#pragma unroll
+            for (int j = 0; j < kLateExtra; j++) qp[3 + j] = (uint32_t)(xp[j] - lo) < len ? xp[j] : -1;
+            int qr[kLateExtra + 3];
+            bool far = false;
+#pragma unroll
+            for (int j = 0; j < kLateExtra + 3; j++) {
+                const int rel = qp[j] - lo;  // (lo = the type's first eligible instance for either list)
+                const bool near = qp[j] >= 0 && rel < kMemoNear;
+                qr[j] = (int)Mp->rk64[near ? rel : 0];
+                if (!near) qr[j] = kRkNone;
+                far |= qp[j] >= 0 && rel >= kMemoNear;
+            }
+            if (__ballot(far)) {
+#pragma unroll
+                for (int j = 0; j < kLateExtra + 3; j++) {
+                    const bool f = qp[j] >= 0 && qp[j] - lo >= kMemoNear;
+                    int g = (int)RK[f ? qp[j] - wl : 0];
+                    asm volatile("" : "+v"(g));
+                    if (f) qr[j] = g;
+                }
+            }
+            const int srk = qr[0], m1 = qr[1], m2 = qr[2];
             int xr[kLateExtra];
 #pragma unroll
-            for (int j = 0; j < kLateExtra; j++) xr[j] = (uint32_t)(xp[j] - lo) < len ? rk_of(xp[j]) : kRkNone;
-            const int m1 = o1 >= 0 ? rk_of(wl + o1) : kRkNone, m2 = o2 >= 0 ? rk_of(wl + o2) : kRkNone;
+            for (int j = 0; j < kLateExtra; j++) xr[j] = qr[3 + j];
             const int end_v = vh.z - 1;  // the instance that ends the list (list 1 depends on it)
             // an exclusion at a list position: the best / first eligible instance -> another walk; candidate k -> taken out
             auto take = [&](int rk, int pos) {
@@ -2891,16 +2919,25 @@ constexpr int kSplitFromC = 3 * 1024 * 64;
 // ---- the split form (round 6): a launch that does nothing but the shortlist check, and a dense tail --------------------------------
 // place_batch_m_kernel carries the check AND the ordinary path — ~150 instructions in front of ~1000, one register allocation (72 VGPRs
 // + scratch), 25 KB of LDS per workgroup — so the requests the records cover pay for the ones they do not.  Here the two are two
-// launches.  place_memo_kernel: a lane per request, memo_try and nothing else — no LDS, no barrier, no scratch, 8 wavefronts per
-// SIMD; a wavefront leaves ONE word behind, the ballot of its requests the check did not decide (miss[wavefront]).
-// place_tail_kernel, queued right behind it on the same stream (so it runs while the next batch's first launch does, given a second
-// stream): a handful of workgroups, each sums all the words (a popcount per word, a scan over the workgroup), deals the undecided
-// requests out in runs of 64 — run r to workgroup r mod G — and decides its share with the ordinary place_block, windows, lists,
-// general path and all (place_block<..., LIST>).  With the check answering 99.9 % of a batch of request rows (C3) the tail is a few
-// hundred requests; a batch the records do not fit (every request with a position inside its list) still comes out right — the tail
-// then loops — and the host stops splitting when a tail reports more than 1/32 of its batch (mmp_ctx::split_off).
+// launches.  place_memo_kernel: a lane per request, memo_try and nothing else — the records in LDS (a copy per wavefront), no barrier,
+// no scratch, 8 wavefronts per SIMD.  A wavefront with requests the check did not decide (one in sixteen, C3) reserves room for them
+// in one of kRestLists lists — wavefront w in list w mod 64: ONE returning atomic on a counter that ~1/64 of those wavefronts share
+// (a launch-wide list behind ONE counter was 16 ns per atomic in sequence, profiles/r5/shortlist_experiments v3) — and leaves their
+// indices there.  place_tail_kernel, queued right behind it on the same stream (so it runs beside the next batch's first launch, given a
+// second stream): workgroup g takes lists g, g + G, ..., reads their counts and entries — two dependent loads, no scan (summing a word
+// per first-launch wavefront took a tail workgroup 8 us) — decides them with the ordinary place_block, windows, lists, general path
+// and all (place_block<..., LIST>), and zeroes its counters for the stream's next batch.  With the check answering 99.8 % of a batch
+// of request rows (C3) the tail is a thousand requests; a batch the records do not fit (every request with a position inside its list)
+// still comes out right — the tail then loops — and the host stops splitting when a tail reports more than 1/32 of its batch
+// (mmp_ctx::split_off).
+constexpr int kRestLists = 64;
+constexpr int kRestCntStride = 32;  // ints between two counters: a 128-byte line each
+// ints of the stream's buffer for a first launch of n_words wavefronts: the counters, then kRestLists lists of rest_list_cap entries
+__host__ __device__ constexpr int rest_list_cap(int n_words) { return ((n_words + kRestLists - 1) / kRestLists) * 64; }
+__host__ __device__ constexpr size_t rest_buffer_ints(int n_words) { return (size_t)kRestLists * kRestCntStride + (size_t)kRestLists * rest_list_cap(n_words); }
+
 template <int FORM>
-__device__ __forceinline__ void place_memo_body(const Snap &S, const PlaceArgs &A, uint64_t *__restrict__ miss, const mmp_place_caller &C,
+__device__ __forceinline__ void place_memo_body(const Snap &S, const PlaceArgs &A, int32_t *__restrict__ rest, int32_t cap, const mmp_place_caller &C,
                                                 unsigned char *smem)
 {
     // The types' records (TypeMemo rows: 512 bytes a type) into LDS, a copy per WAVEFRONT — global -> LDS directly, issued before the
@@ -2945,115 +2982,87 @@ __device__ __forceinline__ void place_memo_body(const Snap &S, const PlaceArgs &
     if (live) todo = !memo_try<FORM>(S, A, rq, d, reinterpret_cast<const TypeMemo *>(mine));
 #endif
     const uint64_t mk = __ballot(todo);
-    if (lane_id() == 0) miss[d >> 6] = mk;
+    if (mk && rest) {  // (wave-uniform; rest == null: diagnostics, nobody will decide them) the undecided requests of this wavefront: room in its list, then their indices
+        const int l = __builtin_amdgcn_readfirstlane(d >> 6) & (kRestLists - 1);
+        const int first = __ffsll((unsigned long long)mk) - 1;
+        int base = 0;
+        if (lane_id() == first)
+            base = __hip_atomic_fetch_add(rest + l * kRestCntStride, __popcll((unsigned long long)mk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        base = readlane_i32(base, first);
+        if (todo) rest[kRestLists * kRestCntStride + (size_t)l * cap + base + __popcll((unsigned long long)(mk & ((1ull << lane_id()) - 1ull)))] = d;
+    }
 }
-__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void place_memo_kernel(Snap S, PlaceArgs A, uint64_t *__restrict__ miss)
+__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void place_memo_kernel(Snap S, PlaceArgs A, int32_t *__restrict__ rest, int32_t cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    place_memo_body<kReq64>(S, A, miss, mmp_place_caller{}, smem);
+    place_memo_body<kReq64>(S, A, rest, cap, mmp_place_caller{}, smem);
 }
-__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void place_memo_c_kernel(Snap S, PlaceArgs A, uint64_t *__restrict__ miss,
+__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void place_memo_c_kernel(Snap S, PlaceArgs A, int32_t *__restrict__ rest, int32_t cap,
                                                                                                            mmp_place_caller C)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    place_memo_body<kReqC>(S, A, miss, C, smem);
+    place_memo_body<kReqC>(S, A, rest, cap, C, smem);
 }
 
-// n_words = the first launch's wavefronts (ceil(n / 64)); `total_out` (may be null): workgroup 0 leaves {undecided requests, n}
-// there (pinned host memory: the host reads the pair some launches later, never waits for it)
+// `report` (may be null): workgroup 0 leaves {undecided requests, n} there (pinned host memory: the host reads the pair some launches
+// later, never waits for it)
 template <int FORM>
-__device__ __forceinline__ void place_tail_body(const Snap &S, const PlaceArgs &A, int32_t wpad, unsigned char *smem, const uint64_t *__restrict__ miss,
-                                                int32_t n_words, int32_t *total_out, const mmp_place_caller &C)
+__device__ __forceinline__ void place_tail_body(const Snap &S, const PlaceArgs &A, int32_t wpad, unsigned char *smem, int32_t *__restrict__ rest, int32_t cap,
+                                                int32_t *report, const mmp_place_caller &C)
 {
-    __shared__ int32_t t_wsum[kPlaceWaves];
-    __shared__ int32_t t_list[kPlaceBlock];
+    __shared__ int32_t t_cnt[kRestLists + 1];  // this workgroup's lists: running totals
     // A tail wavefront is ONE long dependent chain on a SIMD it shares with up to eight wavefronts of the next batch's first launch:
-    // it goes first whenever it can issue (the few of them cost the others nothing; without it a tail lasted as long as the launch
-    // it ran beside)
+    // it goes first whenever it can issue
     __builtin_amdgcn_s_setprio(3);
-    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    PHASE_T0();
+    const int tid = threadIdx.x;
     const int G = gridDim.x, g = blockIdx.x;
-    // Thread t owns the word PAIRS t, t + 256, ... (16-byte loads, coalesced, sixteen in flight per trip: a loop of single dependent
-    // loads was 35 us for the 12 500 words of an 800k batch); ANY numbering of the undecided requests will do — a result row goes to
-    // its request's index whoever decides it.  nzmap: which of the thread's first 64 pairs hold a bit at all (the second walk below
-    // visits only those).
-    typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
-    const u64x2_t *pairs = reinterpret_cast<const u64x2_t *>(miss);
-    const int n_pairs = (n_words + 1) >> 1;
-    auto pair_at = [&](int p) {  // (the word behind the last one is not the first launch's to write)
-        u64x2_t v = pairs[p];
-        if (2 * p + 1 >= n_words) v.y = 0ull;
-        return v;
-    };
-    int cnt = 0;
-    uint64_t nzmap = 0;
-    for (int i0 = 0; i0 * kPlaceBlock + tid < n_pairs; i0 += 16) {
-        u64x2_t m[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int p = (i0 + j) * kPlaceBlock + tid;
-            m[j] = p < n_pairs ? pair_at(p) : u64x2_t{0ull, 0ull};
-        }
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            cnt += __popcll(m[j].x) + __popcll(m[j].y);
-            if ((m[j].x | m[j].y) && i0 + j < 64) nzmap |= 1ull << (i0 + j);
-        }
-    }
-    const int incl = wave_incl_scan_i32(cnt);
-    if (lane == 63) t_wsum[wave] = incl;
-    __syncthreads();
-    int off = incl - cnt, total = 0;
-#pragma unroll
-    for (int k = 0; k < kPlaceWaves; k++) {
-        if (k < wave) off += t_wsum[k];
-        total += t_wsum[k];
-    }
-    if (total_out && g == 0 && tid == 0) {
-        __hip_atomic_store(total_out, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(total_out + 1, A.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    // run r = ranks [64 r, 64 r + 64) belongs to workgroup r mod G, as its (r / G)-th run: four runs a pass
-    const int runs = (total + 63) >> 6;
-    for (int pass = 0; (pass * kPlaceWaves) * G + g < runs; pass++) {  // (workgroup-uniform)
-        t_list[tid] = -1;
-        __syncthreads();
-        if (cnt) {
-            int r = off;
-            auto visit = [&](int p, const u64x2_t v) {
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    uint64_t m = h ? v.y : v.x;
-                    while (m) {
-                        const int b = __ffsll((unsigned long long)m) - 1;
-                        m &= m - 1;
-                        const int run = r >> 6, q = run / G;
-                        if (run - q * G == g && q / kPlaceWaves == pass) t_list[(q % kPlaceWaves) * 64 + (r & 63)] = (2 * p + h) * 64 + b;
-                        r++;
-                    }
-                }
-            };
-            for (uint64_t mp = nzmap; mp; mp &= mp - 1) {
-                const int p = (__ffsll((unsigned long long)mp) - 1) * kPlaceBlock + tid;
-                visit(p, pair_at(p));
+    if (g >= kRestLists) return;
+    const int mine = (kRestLists - g + G - 1) / G;  // lists g, g + G, ...
+    if (tid < 64) {
+        const int c = tid < mine ? rest[(g + tid * G) * kRestCntStride] : 0;
+        const int incl = wave_incl_scan_i32(c);
+        t_cnt[tid + 1] = incl;
+        if (tid == 0) t_cnt[0] = 0;
+        if (report && g == 0) {  // (every list's count: read here, at the very start — the other workgroups zero theirs at their end)
+            const int all = wave_sum_i32(rest[tid * kRestCntStride]);
+            if (tid == 0) {
+                __hip_atomic_store(report, all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(report + 1, A.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            for (int p = 64 * kPlaceBlock + tid; p < n_pairs; p += kPlaceBlock) visit(p, pair_at(p));  // (batches beyond 2M decisions)
         }
-        __syncthreads();
-        place_block<false, FORM, false, false, true>(S, A, wpad, smem, nullptr, C, t_list[tid]);
     }
+    __syncthreads();
+    const int total = t_cnt[mine];
+    PHASE(13);  // (tail) the counts read
+    for (int base = 0; base < total; base += kPlaceBlock) {  // (workgroup-uniform)
+        int d = -1;
+        const int i = base + tid;
+        if (i < total) {
+            int k = 0;
+            while (t_cnt[k + 1] <= i) k++;  // (a handful of lists per workgroup)
+            d = rest[kRestLists * kRestCntStride + (size_t)(g + k * G) * cap + (i - t_cnt[k])];
+        }
+        PHASE(14);  // (tail) this pass's entries read
+        place_block<false, FORM, false, false, true>(S, A, wpad, smem, nullptr, C, d);
+    }
+    if (tid < mine) rest[(g + tid * G) * kRestCntStride] = 0;  // for the stream's next batch (ordered behind this launch)
 }
-__global__ __launch_bounds__(kPlaceBlock) void place_tail_kernel(Snap S, PlaceArgs A, int32_t wpad, const uint64_t *__restrict__ miss, int32_t n_words,
-                                                                 int32_t *total_out)
+// (5 wavefronts per SIMD = 96 VGPRs: a tail wavefront then fits on a SIMD that holds eight wavefronts of another stream's first launch —
+// 8 x 48 + 96 <= 512 registers; with the 154 the compiler takes unasked, the tail's workgroups waited for a compute unit to drain)
+#ifndef MMP_TAIL_EU
+#define MMP_TAIL_EU 5
+#endif
+__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(MMP_TAIL_EU, MMP_TAIL_EU))) void place_tail_kernel(Snap S, PlaceArgs A, int32_t wpad, int32_t *__restrict__ rest, int32_t cap, int32_t *report)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    place_tail_body<kReq64>(S, A, wpad, smem, miss, n_words, total_out, mmp_place_caller{});
+    place_tail_body<kReq64>(S, A, wpad, smem, rest, cap, report, mmp_place_caller{});
 }
-__global__ __launch_bounds__(kPlaceBlock) void place_tail_c_kernel(Snap S, PlaceArgs A, int32_t wpad, const uint64_t *__restrict__ miss, int32_t n_words,
-                                                                   int32_t *total_out, mmp_place_caller C)
+__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(MMP_TAIL_EU, MMP_TAIL_EU))) void place_tail_c_kernel(Snap S, PlaceArgs A, int32_t wpad, int32_t *__restrict__ rest, int32_t cap, int32_t *report,
+                                                                   mmp_place_caller C)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    place_tail_body<kReqC>(S, A, wpad, smem, miss, n_words, total_out, C);
+    place_tail_body<kReqC>(S, A, wpad, smem, rest, cap, report, C);
 }
 
 __global__ __launch_bounds__(kPlaceBlock) void place_batch_long_c_kernel(Snap S, PlaceArgs A, int32_t wpad, mmp_place_caller C)

@@ -53,7 +53,8 @@ for b in range(6):
                  torch.zeros(nmax * 16, dtype=torch.uint8, device=dev), len(ex)))
 import time
 st = torch.cuda.Stream(dev)
-sts = [st] + [torch.cuda.Stream(dev) for _ in range(3)]
+NST = int(os.environ.get("SWEEP_STREAMS", "4"))
+sts = [st] + [torch.cuda.Stream(dev) for _ in range(NST - 1)]
 K = int(os.environ.get("SWEEP_K", "200"))
 ref = {}
 for env in VARIANTS:
@@ -86,13 +87,13 @@ for env in VARIANTS:
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / K
         # the same launches round-robin on four streams (the bench's timed region): wall time per launch
-        margs = [tuple(list(a[:-1]) + [C.c_void_p(sts[i % 4].cuda_stream)]) for i, a in enumerate(args + args)]
+        margs = [tuple(list(a[:-1]) + [C.c_void_p(sts[i % NST].cuda_stream)]) for i, a in enumerate(args * (NST * 6 // 6 if NST % 6 == 0 else NST))]
         for i in range(24):
-            fn(*margs[i % 12])
+            fn(*margs[i % len(margs)])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(4 * K):
-            fn(*margs[i % 12])
+            fn(*margs[i % len(margs)])
         torch.cuda.synchronize()
         us4 = (time.perf_counter() - t0) * 1e6 / (4 * K)
         outs = torch.cat([o[2][: n * 16] for o in bufs])
@@ -103,5 +104,5 @@ for env in VARIANTS:
             ref[n] = outs.clone()
         extra_note = f"  split batches {s.split_batches()}"
         print(f"{tag:58s} n {n:9d}  {us:7.2f} us per launch  {n / us / 1e3:6.2f} G/s  hbm_only {n * (40 if FORM_C else 80) / us / 1e3 / 8000:5.3f}  "
-              f"4 streams {us4:6.2f} us per launch {n / us4 / 1e3:6.2f} G/s  results {same}{extra_note}", flush=True)
+              f"{NST} streams {us4:6.2f} us per launch {n / us4 / 1e3:6.2f} G/s  results {same}{extra_note}", flush=True)
     s.close()
