@@ -1241,7 +1241,8 @@ def main():
     # what is measured.  The timed steps go to streams of their own; torch's current stream is the legacy null
     # stream, whose launches order against every blocking stream of the process.
     _fn = solver.lib.mmp_place_batch_dev
-    streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
+    _prio = os.environ.get("MMP_BENCH_STREAM_PRIO")  # (experiments: "alt" = every second stream at high priority)
+    streams = [torch.cuda.Stream(dev, priority=(-1 if _prio == "alt" and i % 2 == 0 else 0)) for i in range(n_streams)]
 
     def call_args(b, st):
         r_, e_, o_ = d_bufs[b]
@@ -1256,6 +1257,7 @@ def main():
     _done = [torch.cuda.Event() for _ in streams]
     _last_stream = [n_streams - 1]  # index of the stream that got the most recent launch
     _fence_t = [0.0]  # when the last fence knew the device was done (before its closing synchronize)
+    _fence_default = ["last"]
 
     def fence():
         # Closing a region (tools/region_anatomy.py, 20 steps on 4 streams, device-side span 73 us): torch.cuda.synchronize()
@@ -1263,14 +1265,25 @@ def main():
         # ISSUE order costs more (+83 us: every query of an unfinished event makes the runtime do work on that queue);
         # polling them in REVERSE order — the stream that got the last launch first, by then the others are done — gets the
         # host there in +26 us, and the synchronize that closes the region finds nothing left to wait for (+7 us).
-        _mode = os.environ.get("MMP_BENCH_FENCE", "last")  # (experiments: "sync" = synchronize only, "spin" = issue order)
-        if _mode != "sync":
+        # (round 6) "streams": every stream synchronised in turn, then the device — each call retires its stream's finished commands
+        # while the other streams still run; with two launches per step (a split batch) the synchronize that closes a region of 40
+        # kernels otherwise spends 60 us retiring them (tools/r6/host_issue.py: 20 kernels 6 us, 40 kernels 45-60 us, whatever the kernels)
+        _mode = os.environ.get("MMP_BENCH_FENCE", _fence_default[0])  # (experiments: "sync" = synchronize only, "spin" = issue order)
+        if _mode == "streams":
+            for st_ in streams:
+                st_.synchronize()
+        elif _mode != "sync":
             for e_, st_ in zip(_done, streams):
                 e_.record(st_)
             for k_ in range(len(_done)):
                 e_ = _done[k_] if _mode == "spin" else _done[(_last_stream[0] - k_) % len(_done)]
                 while not e_.query():
-                    pass
+                    # (round 6) hipStreamQuery on the other streams while waiting: the runtime retires their finished commands NOW,
+                    # beside the device's work, instead of all of them inside the closing synchronize (a split batch is two launches
+                    # per step: 40 commands + 4 markers to retire cost that synchronize 50-60 us of a 350 us region)
+                    if _mode == "last":
+                        for st_ in streams:
+                            st_.query()
         _fence_t[0] = time.perf_counter()
         torch.cuda.synchronize(dev)
         if world > 1:
@@ -1289,6 +1302,8 @@ def main():
     for i in range(max(n_batches, n_streams)):
         check(_fn(*_args[i % period]))
     fence()
+    if solver.split_batches()[0] > 0:
+        _fence_default[0] = "streams"
     # ... and the device brought out of its idle power state: the host spent seconds generating the batches above, and
     # a 20-step region (~90 us) right after that was measured anywhere between 89 and 184 us.  ~10 ms of the same
     # launches first; none of it is timed and none of it replaces a warm-up step.
@@ -1347,6 +1362,7 @@ def main():
                 for a in sched_:
                     _fn(*a)
                 t1_ = time.perf_counter()
+                _flush(solver.h)
                 fence()
                 t2_ = time.perf_counter()
                 print(f"region {rep_ + 1}: issue {(t1_ - t0_) * 1e6:.1f} us, known done {(_fence_t[0] - t0_) * 1e6:.1f} us, "

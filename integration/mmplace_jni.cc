@@ -360,6 +360,16 @@ JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_scaleupPlanConc(JNI
                                                                              jobject concParams, jobject outs, jobject concOuts,
                                                                              jobject overloadedOut, jobject skipped, jobject result)
 {
+    if (!holds<mmp_cache_entry>(env, entries, n, "scaleupPlanConc: entries shorter than n rows") ||
+        !holds<mmp_conc_entry>(env, conc, n, "scaleupPlanConc: conc shorter than n rows") ||
+        !holds<mmp_scaleup_params>(env, params, 1, "scaleupPlanConc: params shorter than one mmp_scaleup_params") ||
+        !holds<mmp_conc_params>(env, concParams, 1, "scaleupPlanConc: concParams shorter than one mmp_conc_params") ||
+        !holds<mmp_scaleup_out>(env, outs, n, "scaleupPlanConc: outs shorter than n rows") ||
+        !holds<mmp_conc_out>(env, concOuts, n, "scaleupPlanConc: concOuts shorter than n rows") ||
+        !holds<uint8_t>(env, overloadedOut, 1, "scaleupPlanConc: overloadedOut shorter than one byte") ||
+        !holds<int32_t>(env, skipped, 1, "scaleupPlanConc: skipped shorter than one int") ||
+        !holds<mmp_conc_result>(env, result, 1, "scaleupPlanConc: result shorter than one mmp_conc_result"))
+        return MMP_EINVAL;
     return check(env, ctx_of(h),
                  mmp_scaleup_plan_conc(ctx_of(h), buf<mmp_cache_entry>(env, entries), buf<mmp_conc_entry>(env, conc), n,
                                        buf<mmp_scaleup_params>(env, params), buf<mmp_conc_params>(env, concParams),
@@ -371,6 +381,11 @@ JNIEXPORT jint JNICALL Java_com_ibm_watson_modelmesh_MmPlace_scaledownPlanConc(J
                                                                                jobject conc, jint n, jobject params,
                                                                                jlong dynamicRpmScaleConstant, jobject removedOut)
 {
+    if (!holds<mmp_cache_entry>(env, entries, n, "scaledownPlanConc: entries shorter than n rows") ||
+        !holds<mmp_conc_entry>(env, conc, n, "scaledownPlanConc: conc shorter than n rows") ||
+        !holds<mmp_scaledown_params>(env, params, 1, "scaledownPlanConc: params shorter than one mmp_scaledown_params") ||
+        !holds<uint8_t>(env, removedOut, n, "scaledownPlanConc: removedOut shorter than n bytes"))
+        return MMP_EINVAL;
     return check(env, ctx_of(h),
                  mmp_scaledown_plan_conc(ctx_of(h), buf<mmp_cache_entry>(env, entries), buf<mmp_conc_entry>(env, conc), n,
                                          buf<mmp_scaledown_params>(env, params), dynamicRpmScaleConstant,

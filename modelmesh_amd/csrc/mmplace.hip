@@ -119,6 +119,7 @@ struct SnapSide {
 // the latency slots, the resident kernel's request slots) is allocated fine-grained and device-mapped explicitly:
 // hipHostMallocDefault would leave the choice to the process environment (HIP_HOST_COHERENT).
 constexpr unsigned int kPinnedFlags = hipHostMallocCoherent | hipHostMallocMapped;
+constexpr size_t kSelMaxBytes = (size_t)32 << 20;  // Snap::sel / ::rk are built up to this size each (per snapshot side)
 constexpr int kTailStaticLds = 512;  // what place_tail_body keeps in static LDS beside place_block's own
 constexpr int kTailBlocks = 16;    // workgroups of a split batch's tail launch (measured: see place_kernel.hpp)
 constexpr int kMaxMissBufs = 64;   // streams with split batches in flight that get a buffer of their own (more: those batches go unsplit)
@@ -156,8 +157,11 @@ struct mmp_ctx {
     std::mutex pool_mu;
     // the resident decision kernel for single requests (place_kernel.hpp: place_resident_kernel; mmp_resident)
     struct Resident {
-        bool enabled = false, running = false;
-        uint32_t generation = 0;  // of the kernel launched last (1, 2, ...)
+        // written under launch_mu (running, generation) / the state lock (enabled) and READ without either by every single request on its
+        // way in (the optimistic checks of mmp_place_batch / resident_place; resident_ensure looks again under the locks): atomics
+        // (tools/asan_lib.sh, ThreadSanitizer: plain bools here were its first two reports)
+        std::atomic<bool> enabled{false}, running{false};
+        std::atomic<uint32_t> generation{0};  // of the kernel launched last (1, 2, ...)
         hipStream_t stream = nullptr;
         ResidentSlot *slots = nullptr;  // pinned, device-mapped: host -> device
         ResidentAnswer *answers = nullptr;  // pinned, device-mapped: device -> host
@@ -406,7 +410,7 @@ void resident_stop(mmp_ctx *c)
     if (!R.slots) return;
     std::lock_guard<std::mutex> g(R.launch_mu);
     if (!R.running) return;
-    __atomic_store_n(&R.ctl->stop, R.generation, __ATOMIC_RELEASE);
+    __atomic_store_n(&R.ctl->stop, R.generation.load(std::memory_order_relaxed), __ATOMIC_RELEASE);
     (void)hipStreamSynchronize(R.stream);
     R.running = false;
 }
@@ -503,6 +507,9 @@ hipError_t slot_wait(FastSlot *f, uint32_t seq)
 }
 
 hipError_t order_after_registry(mmp_ctx *c, hipStream_t st);
+#ifdef MMP_XP_EMPTYTAIL  // (experiment builds only, tools/r6: what the runtime charges for a second launch per call, whatever it does)
+__global__ void xp_noop_kernel(int32_t *p) { if (p == nullptr) __builtin_trap(); }
+#endif
 // The buffer of a split batch on `st` (`ints`: rest_buffer_ints of its first launch) and the stream's report pair; false: none to be
 // had (too many streams, no memory) — the batch goes unsplit.  Also reads what the stream's last tail reported.
 bool miss_buffer(mmp_ctx *c, hipStream_t st, size_t ints, int32_t **words, int32_t **report)
@@ -661,12 +668,19 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
             !c->split_off.load(std::memory_order_relaxed)) {
             const size_t lds_memo = (size_t)kPlaceWaves * memo_stage_bytes(c->snap.T);  // a copy of the types' records per wavefront
             if (c->split_notail) words = nullptr;  // (diagnostics: the undecided requests are not even recorded)
+            if (getenv("MMP_SPLIT_NOREPORT")) report = nullptr;  // (experiment)
             if (caller) {
                 hipLaunchKernelGGL(place_memo_c_kernel, dim3(grid), dim3(kPlaceBlock), lds_memo, st, c->snap, A, words, cap, *caller);
                 if (!c->split_notail)
                     hipLaunchKernelGGL(place_tail_c_kernel, dim3(c->tail_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, words, cap, report, *caller);
             } else {
                 hipLaunchKernelGGL(place_memo_kernel, dim3(grid), dim3(kPlaceBlock), lds_memo, st, c->snap, A, words, cap);
+#ifdef MMP_XP_EMPTYTAIL
+                if (getenv("MMP_XP_EMPTYTAIL")) {
+                    hipLaunchKernelGGL(xp_noop_kernel, dim3(atoi(getenv("MMP_XP_EMPTYTAIL"))), dim3(kPlaceBlock), 0, st, words);
+                    return MMP_OK;
+                }
+#endif
                 if (!c->split_notail)
                     hipLaunchKernelGGL(place_tail_kernel, dim3(c->tail_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, words, cap, report);
             }
@@ -949,9 +963,15 @@ try {
     if (!c || n < 0 || (n > 0 && (!rows || !idx))) return fail(c, MMP_EINVAL, "mmp_pods_upsert: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::shared_mutex> g(c->mu);
+    {  // all of the call or none of it: a bad index must not leave the rows before it applied
+        int32_t count = (int32_t)c->pods.size();
+        for (int32_t i = 0; i < n; i++) {
+            if (idx[i] < 0 || idx[i] > count) return fail(c, MMP_EINVAL, "mmp_pods_upsert: index %d out of range", idx[i]);
+            if (idx[i] == count) count++;
+        }
+    }
     for (int32_t i = 0; i < n; i++) {
         const int32_t k = idx[i];
-        if (k < 0 || k > (int32_t)c->pods.size()) return fail(c, MMP_EINVAL, "mmp_pods_upsert: index %d out of range", k);
         if (k == (int32_t)c->pods.size()) {
             c->pods.push_back(rows[i]);
             c->dirty_all = true;
@@ -972,9 +992,10 @@ try {
     if (!c || n < 0 || (n > 0 && !idx)) return fail(c, MMP_EINVAL, "mmp_pods_remove: bad argument");
     std::lock_guard<std::mutex> gb(c->batch_mu);
     std::lock_guard<std::shared_mutex> g(c->mu);
+    for (int32_t i = 0; i < n; i++)  // (all of the call or none of it)
+        if (idx[i] < 0 || idx[i] >= (int32_t)c->pods.size()) return fail(c, MMP_EINVAL, "mmp_pods_remove: index %d out of range", idx[i]);
     for (int32_t i = 0; i < n; i++) {
         const int32_t k = idx[i];
-        if (k < 0 || k >= (int32_t)c->pods.size()) return fail(c, MMP_EINVAL, "mmp_pods_remove: index %d out of range", k);
         c->pods[k].flags |= MMP_POD_TOMBSTONE;
         c->pods[k].flags &= ~MMP_POD_LIVE;
         note_dirty(c, k);
@@ -1596,8 +1617,15 @@ try {
     HIP_TRY(c, B.pc.ensure((size_t)2 * T * (W + 1) * 4));
     HIP_TRY(c, B.nz.ensure((size_t)2 * T * (W + 1) * 4));
     HIP_TRY(c, B.ph.ensure((size_t)2 * T * (W + 1) * 8));
-    HIP_TRY(c, B.sel.ensure((size_t)2 * T * W * 64 * 4));
-    HIP_TRY(c, B.rk.ensure((size_t)2 * T * W * 64 * 4));
+    // the long path's inverse tables (Snap::sel / ::rk): 512 bytes per type row and 64-position word, each, rebuilt at every commit —
+    // 320 KB on C3, but a table of 100 type rows x 100 000 instances would be 80 MB a piece: beyond kSelMaxBytes they are not built
+    // and a shortlist that spans the table takes the wave path
+    const size_t sel_bytes = (size_t)2 * T * W * 64 * 4;
+    const bool have_sel = sel_bytes <= kSelMaxBytes;
+    if (have_sel) {
+        HIP_TRY(c, B.sel.ensure(sel_bytes));
+        HIP_TRY(c, B.rk.ensure(sel_bytes));
+    }
     HIP_TRY(c, B.memo.ensure((size_t)kWinLds * sizeof(TypeMemo)));
     HIP_TRY(c, B.memo_cand.ensure((size_t)kWinLds * kMemoCand * 4));
     HIP_TRY(c, B.memo_rk.ensure((size_t)kWinLds * kMemoCand * 2));
@@ -1771,8 +1799,8 @@ try {
     S.nz = B.nz.as<int32_t>();
     S.ph = B.ph.as<uint64_t>();
     S.ctpos = P > 0 ? B.ctpos.as<int32_t>() : nullptr;
-    S.sel = P > 0 ? B.sel.as<int32_t>() : nullptr;
-    S.rk = P > 0 ? B.rk.as<int32_t>() : nullptr;
+    S.sel = P > 0 && have_sel ? B.sel.as<int32_t>() : nullptr;
+    S.rk = P > 0 && have_sel ? B.rk.as<int32_t>() : nullptr;
     S.memo = B.memo.as<TypeMemo>();
     S.memo_cand = B.memo_cand.as<int32_t>();
     S.memo_rk = B.memo_rk.as<int16_t>();
@@ -1873,7 +1901,8 @@ try {
         hipLaunchKernelGGL(commit_level2_kernel, dim3(4 * T + L2.nb_finish), dim3(64), 0, st, L2);
         // sel / rk from the prefix tables, and the per-type shortlists (TypeMemo) from the finished head windows (every row a decision
         // can name is written, valid or not): one launch; the registry view below is resolved against the shortlists' ranges
-        hipLaunchKernelGGL(build_sel_memo_kernel, dim3(2 * T * W + std::min(T, kWinLds)), dim3(64), 0, st, S, B.sel.as<int32_t>(), B.rk.as<int32_t>(),
+        hipLaunchKernelGGL(build_sel_memo_kernel, dim3((have_sel ? 2 * T * W : 0) + std::min(T, kWinLds)), dim3(64), 0, st, S,
+                           have_sel ? B.sel.as<int32_t>() : nullptr, have_sel ? B.rk.as<int32_t>() : nullptr,
                            B.heads.as<TypeWin>(), B.memo.as<TypeMemo>(), B.memo_cand.as<int32_t>(), B.memo_rk.as<int16_t>());
         // the running minimum of the case (b) candidates' rpm, then the survivor bitmaps of the rpm rule's four limits
         hipLaunchKernelGGL(prefix_min_rpm_kernel, dim3(kBSlots), dim3(64), 0, st, S, B.bslots.as<BSlot>(), n_bslots_dev, B.bpm.as<int32_t>(),
@@ -3469,15 +3498,18 @@ int resident_ensure(mmp_ctx *c)
     std::lock_guard<std::mutex> g(R.launch_mu);
     if (R.running && __atomic_load_n(&R.ctl->exited, __ATOMIC_ACQUIRE) != R.generation) return MMP_OK;
     static const bool dbg = getenv("MMP_RESIDENT_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "[resident] ensure: running %d exited %u -> (re)launch #%llu\n", (int)R.running, R.ctl->exited,
+    if (dbg) fprintf(stderr, "[resident] ensure: running %d exited %u -> (re)launch #%llu\n", (int)R.running.load(), R.ctl->exited,
                      (unsigned long long)R.launches.load() + 1);
     if (R.running) {
         HIP_TRY(c, hipStreamSynchronize(R.stream));  // it left by itself (idle): returns at once
         R.running = false;
         if (dbg) fprintf(stderr, "[resident] previous kernel retired\n");
     }
-    R.generation++;
-    if (R.generation == 0) R.generation = 1;
+    {
+        uint32_t g2 = R.generation.load(std::memory_order_relaxed) + 1;
+        if (g2 == 0) g2 = 1;
+        R.generation.store(g2, std::memory_order_release);
+    }
     PlaceArgs A{};
     A.models = c->models.as<mmp_model_row>();
     A.rmodels = cur_side(c).rmodels_ok ? cur_side(c).rmodels.as<ResolvedModel>() : nullptr;
@@ -3488,7 +3520,7 @@ int resident_ensure(mmp_ctx *c)
     A.n_pods_all = c->snap.P;
     HIP_TRY(c, order_after_registry(c, R.stream));
     hipLaunchKernelGGL(place_resident_kernel, dim3(1), dim3(64), (size_t)kPlaceLaneLds, R.stream, c->snap, A, R.slots, R.answers, R.ctl,
-                       R.idle_ticks, R.generation);
+                       R.idle_ticks, R.generation.load(std::memory_order_relaxed));
     HIP_TRY(c, hipGetLastError());
     R.running = true;
     R.launches.fetch_add(1, std::memory_order_relaxed);
@@ -4414,7 +4446,11 @@ try {
             *cur = off + kPlanBuckets + 1, *doff = cur + kPlanBuckets + 1;
     PlanPartial *part = c->r_part.as<PlanPartial>();
     KT_BEGIN(c, st);  // device span of the whole plan
-    if (c->cfg_plan_fused && c->plan_grid_max > 0) {
+    // The one-launch form prefetches registry / instance rows unconditionally and waits at grid-wide barriers: it needs a registry
+    // and a table to read (an empty or never-loaded one takes the eight launches, which guard every access: ADVICE r5), and every
+    // workgroup on the chip at once — plan_grid_max is what the occupancy query granted at mmp_create; a launch never asks for more
+    const bool fused_ok = c->cfg_plan_fused && c->plan_grid_max > 0 && M > 0 && P > 0 && models != nullptr && pods != nullptr;
+    if (fused_ok) {
         // ONE launch, the steps separated by grid-wide barriers (rebalance_kernels.hpp: proactive_plan_fused_kernel)
         const int G = std::max(std::min(div_up(std::max(M, 1), kPlanFusedBlock), (int)c->plan_grid_max), 1);
         hipLaunchKernelGGL(proactive_plan_fused_kernel, dim3(G), dim3(kPlanFusedBlock), kPlanFusedLds, st, pods, P, models, M, U, default_units, now,
@@ -4441,6 +4477,7 @@ try {
     HIP_TRY(c, hipMemcpyAsync(&h, ps, sizeof h, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     kt_collect(c);
+    // (overflow == 2: the one-launch plan gave up at a grid barrier — its workgroups were not all on the chip; the general path below)
     if (h.overflow && c->cfg_plan_sorted == 2) return fail(c, MMP_ESTATE, "mmp_proactive_plan: a key bucket overflowed and MMP_PLAN_SORTED=2 forbids the sorted path");
     if (!h.overflow && c->cfg_plan_sorted != 1) {
         const int32_t n_copy = std::min(h.n_selected, max_out);
@@ -4621,9 +4658,9 @@ try {
     if (!cp) return fail(c, MMP_EINVAL, "mmp_scaleup_plan_conc: conc_params is null");
     return scaleup_plan_impl(c, "mmp_scaleup_plan_conc", entries, conc, n, p, cp, outs, conc_outs, overloaded_out, skipped, result);
 } catch (const std::bad_alloc &) {
-    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_scaleup_plan");
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_scaleup_plan_conc");
 } catch (const std::exception &e) {
-    return fail(c, MMP_EHIP, "%s: %s", "mmp_scaleup_plan", e.what());
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_scaleup_plan_conc", e.what());
 }
 
 // the janitor's scale-down: the one body of mmp_scaledown_plan (conc == null) and mmp_scaledown_plan_conc
@@ -4697,9 +4734,9 @@ try {
     if (n > 0 && !conc) return fail(c, MMP_EINVAL, "mmp_scaledown_plan_conc: conc is null");
     return scaledown_plan_impl(c, "mmp_scaledown_plan_conc", entries, conc, n, p, dynamic_rpm_scale_constant, removed_out);
 } catch (const std::bad_alloc &) {
-    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_scaledown_plan");
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_scaledown_plan_conc");
 } catch (const std::exception &e) {
-    return fail(c, MMP_EHIP, "%s: %s", "mmp_scaledown_plan", e.what());
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_scaledown_plan_conc", e.what());
 }
 
 int mmp_migration_plan(mmp_ctx *c, const mmp_cache_entry *entries, int32_t n, int32_t self_pod, int64_t now,

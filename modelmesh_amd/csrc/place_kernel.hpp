@@ -1577,8 +1577,8 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
         }
         if (VIEW && S.more_after && end >= P) return kLaneIncomplete;  // the shortlist runs into the next shard
         const bool is_long = ((end > start ? end - 1 : bestpos) >> 6) - (bestpos >> 6) >= kLaneSpan;
-        if (is_long && (!LONG || !S.pc)) {
-            if (VIEW || !S.pc) {
+        if (is_long && (!LONG || !S.pc || !S.sel)) {
+            if (VIEW || !S.pc || !S.sel) {  // (no prefix / inverse tables: shard views; snapshots whose tables would be too large, kSelMaxBytes)
                 fb = true;
                 break;
             }
@@ -2879,7 +2879,7 @@ __device__ __forceinline__ void build_memo_body(int t, const Snap &S, const Type
 __global__ __launch_bounds__(64) void build_sel_memo_kernel(Snap S, int32_t *__restrict__ sel, int32_t *__restrict__ rk, const TypeWin *__restrict__ wins,
                                                             TypeMemo *__restrict__ memo, int32_t *__restrict__ cand, int16_t *__restrict__ memo_rk)
 {
-    const int n_sel = 2 * S.T * S.W;
+    const int n_sel = sel ? 2 * S.T * S.W : 0;  // (sel == null: the inverse tables are not built for this snapshot, kSelMaxBytes)
     if ((int)blockIdx.x < n_sel)
         build_sel_body((int)blockIdx.x, S, sel, rk);
     else

@@ -781,17 +781,38 @@ __device__ __forceinline__ void dst(T *p, T v)
 // Barrier number `gen` (1-based) of the launch: one counter, one flag (in cache lines of their own: polls in the line the arrivals
 // are counted in would queue in front of them).  1.6-2.4 us with 64 workgroups.  Measured and dropped: a flag per workgroup, the first
 // wavefront of each reading all of them (no counter to queue at) — 2.9-3.2 us.
-__device__ __forceinline__ void plan_grid_barrier(PlanScalars *ps, unsigned int gen)
+// The launch ASSUMES its workgroups are all on the chip (the host sizes the grid by the occupancy query and never asks for more than
+// one per compute unit) — which another tenant's resident kernels could still deny it.  A workgroup that has waited kPlanBarrierTicks
+// (20 ms; an ordinary wait is microseconds) gives up instead of hanging the queue: it raises PlanScalars::overflow to 2, every
+// workgroup that sees that leaves, and the host runs the plan as separate launches (the path it takes for an overflowing bucket).
+// false: leave the kernel.
+constexpr long long kPlanBarrierTicks = 2'000'000;  // of the 100 MHz wall clock
+__device__ __forceinline__ bool plan_grid_barrier(PlanScalars *ps, unsigned int gen)
 {
+    __shared__ int s_abort;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's sc1 stores and atomics are done at the memory side
     __syncthreads();
     if (threadIdx.x == 0) {
+        int ab = 0;
         if (__hip_atomic_fetch_add(&ps->bar_count[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen * gridDim.x - 1)
             __hip_atomic_store(&ps->bar_flag[0], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else
-            while (__hip_atomic_load(&ps->bar_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) __builtin_amdgcn_s_sleep(1);
+        else {
+            const long long t0 = wall_clock64();
+            unsigned int spins = 0;
+            while (__hip_atomic_load(&ps->bar_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 255u) == 0 && wall_clock64() - t0 > kPlanBarrierTicks) {
+                    ab = 1;
+                    break;
+                }
+            }
+        }
+        if (ab) __hip_atomic_store(&ps->overflow, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_load(&ps->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2) ab = 1;  // somebody gave up before
+        s_abort = ab;
     }
     __syncthreads();
+    return s_abort == 0;
 }
 #ifdef MMP_PLAN_CLOCK
 #define PLAN_CLOCK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) dst(&ps->t_phase[k], (long long)wall_clock64()); } while (0)
@@ -1105,7 +1126,7 @@ __global__ __launch_bounds__(kPlanFusedBlock) void proactive_plan_fused_kernel(
         }
     }
     PLAN_CLOCK(1);
-    plan_grid_barrier(ps, 1);
+    if (!plan_grid_barrier(ps, 1)) return;
     PLAN_CLOCK(2);
 
     // ---- B ----
@@ -1183,7 +1204,7 @@ __global__ __launch_bounds__(kPlanFusedBlock) void proactive_plan_fused_kernel(
         if (h1) slot[i1] = my1;
     }
     PLAN_CLOCK(3);
-    plan_grid_barrier(ps, 2);
+    if (!plan_grid_barrier(ps, 2)) return;
     // The bucket offsets: EVERY workgroup scans the finished histogram into its own LDS (64 KB read from memory per workgroup,
     // 2 us) — one workgroup scanning for all, a write-back, a flag and 64 x 3 device-scope offset loads per lane later cost more.
     // The adds went to the memory side; one invalidation so that the ordinary int4 loads here do not find an older line in this L2.
@@ -1218,7 +1239,7 @@ __global__ __launch_bounds__(kPlanFusedBlock) void proactive_plan_fused_kernel(
         }
     }
     PLAN_CLOCK(5);
-    plan_grid_barrier(ps, 3);
+    if (!plan_grid_barrier(ps, 3)) return;
     PLAN_CLOCK(6);
 
     // ---- D ----
@@ -1356,7 +1377,10 @@ __global__ __launch_bounds__(kPlanFusedBlock) void proactive_plan_fused_kernel(
         int32_t sum = 0, sum_ge = 0, prev = 0;
         for (int k = tid; k < c; k += kPlanFusedBlock) {
             uint64_t w;
-            while (!((w = dld(&chunk_tot[k])) & kPlanChunkValid)) __builtin_amdgcn_s_sleep(1);
+            for (unsigned int spins = 0; !((w = dld(&chunk_tot[k])) & kPlanChunkValid); spins++) {  // (its owner passed barrier 3 with this workgroup)
+                __builtin_amdgcn_s_sleep(1);
+                if ((spins & 1023u) == 1023u && dld(&ps->overflow) == 2) break;  // ... unless it gave up there (plan_grid_barrier): nothing of this launch is used
+            }
             sum += (int32_t)(w & 0x7fffffffu);
             sum_ge += (int32_t)((w >> 31) & 0x7fffffffu);
             if (k == c - 1) prev = (int32_t)(w & 0x7fffffffu);
@@ -1388,7 +1412,10 @@ __global__ __launch_bounds__(kPlanFusedBlock) void proactive_plan_fused_kernel(
         }
         if (c == n_chunks - 1 && tid == 0) {  // the last chunk knows every total: :6709-6734
             uint64_t w;
-            while (!((w = dld(&chunk_tot[c])) & kPlanChunkValid)) __builtin_amdgcn_s_sleep(1);
+            for (unsigned int spins = 0; !((w = dld(&chunk_tot[c])) & kPlanChunkValid); spins++) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((spins & 1023u) == 1023u && dld(&ps->overflow) == 2) break;
+            }
             const int32_t total = base + (int32_t)(w & 0x7fffffffu), n_ge = base_ge + (int32_t)((w >> 31) & 0x7fffffffu);
             dst(&ps->n_distinct, total);
             const int32_t n_sel = total < s_ps.total_count ? total : s_ps.total_count;
