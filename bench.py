@@ -819,27 +819,44 @@ def seam_tail_cpp(reps: int = 8000):
     libdir = os.path.join(ROOT, "modelmesh_amd", "lib")
     subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "micro", "seam_tail.cc"),
                     "-L" + libdir, "-lmmplace", "-Wl,-rpath," + libdir, "-lpthread", "-o", exe], check=True, capture_output=True)
+    def parse(stdout, what):
+        out = {}
+        for m in re.finditer(r"^(\w+)\s+n=1\s+p50\s+([\d.]+)\s+p90\s+([\d.]+)\s+p99\s+([\d.]+)\s+p99\.9\s+([\d.]+)\s+max\s+([\d.]+)", stdout, re.M):
+            out[m.group(1)] = {"p50_us": float(m.group(2)), "p90_us": float(m.group(3)), "p99_us": float(m.group(4)), "p99_9_us": float(m.group(5)),
+                               "max_us": float(m.group(6))}
+        m = re.search(r"slow calls .*?: (\d+) of (\d+) = ([\d.]+) %; by kind: place (\d+) serve (\d+) gates (\d+) route (\d+)", stdout)
+        if m:
+            out["slow_calls"] = {"share_pct": float(m.group(3)), "by_kind": {"place": int(m.group(4)), "serve": int(m.group(5)), "gates": int(m.group(6)),
+                                                                           "route": int(m.group(7))}}
+        m = re.search(r"(\d+) of (\d+) directly behind another slow call", stdout)
+        if m and "slow_calls" in out:
+            out["slow_calls"]["directly_behind_another"] = int(m.group(1))
+        m = re.search(r"calling thread: (.*?); while measuring: (\d+) voluntary and (\d+) involuntary context switches", stdout)
+        if m:
+            out["calling_thread"] = {"state": m.group(1), "voluntary_context_switches": int(m.group(2)), "involuntary_context_switches": int(m.group(3))}
+        out["note"] = f"{reps} calls of each kind, round-robin, one C++ thread, {what}; slow = more than 1.6 x the kind's p50"
+        return out
+
+    # round 6: the same run with the calling thread left to the scheduler and PINNED to one CPU of the process's mask.
+    # On the 256-thread host behind a 16-CPU quota the unpinned thread is moved around (hundreds of context switches per run) and 0.5 %
+    # of its calls are slow, in bursts, on every kind alike; pinned, it is switched a handful of times and the tail goes with it
+    # (profiles/r6/seam_tail_pinning.txt).  A mesh's request threads are the host's to pin; the line carries both.
     try:
-        r = subprocess.run([exe, str(reps)], capture_output=True, text=True, timeout=300)
+        cpus = sorted(os.sched_getaffinity(0))
+        pin = cpus[len(cpus) // 2]
+        runs = {}
+        for label, extra_args, what in (("pinned_to_one_cpu", ["pin", str(pin)], f"pinned to CPU {pin}"), ("unpinned", [], "not pinned")):
+            r = subprocess.run([exe, str(reps)] + extra_args, capture_output=True, text=True, timeout=300)
+            if r.returncode != 0:
+                raise RuntimeError(f"seam_tail exit {r.returncode}: {r.stderr[-300:]}")
+            runs[label] = parse(r.stdout, what)
     finally:
         try:
             os.unlink(exe)
         except OSError:
             pass
-    if r.returncode != 0:
-        raise RuntimeError(f"seam_tail exit {r.returncode}: {r.stderr[-300:]}")
-    out = {}
-    for m in re.finditer(r"^(\w+)\s+n=1\s+p50\s+([\d.]+)\s+p90\s+([\d.]+)\s+p99\s+([\d.]+)\s+p99\.9\s+([\d.]+)\s+max\s+([\d.]+)", r.stdout, re.M):
-        out[m.group(1)] = {"p50_us": float(m.group(2)), "p90_us": float(m.group(3)), "p99_us": float(m.group(4)), "p99_9_us": float(m.group(5)),
-                           "max_us": float(m.group(6))}
-    m = re.search(r"slow calls .*?: (\d+) of (\d+) = ([\d.]+) %; by kind: place (\d+) serve (\d+) gates (\d+) route (\d+)", r.stdout)
-    if m:
-        out["slow_calls"] = {"share_pct": float(m.group(3)), "by_kind": {"place": int(m.group(4)), "serve": int(m.group(5)), "gates": int(m.group(6)),
-                                                                       "route": int(m.group(7))}}
-    m = re.search(r"(\d+) of (\d+) directly behind another slow call", r.stdout)
-    if m:
-        out["slow_calls"]["directly_behind_another"] = int(m.group(1))
-    out["note"] = f"{reps} calls of each kind, round-robin, one C++ thread; slow = more than 1.6 x the kind's p50"
+    out = dict(runs["pinned_to_one_cpu"])  # (the percentiles at the top level of the object are the pinned run's)
+    out["unpinned"] = runs["unpinned"]
     return out
 
 
@@ -1504,13 +1521,13 @@ def main():
         value = total / elapsed
         alg = int(np.mean([algorithmic_bytes(fleet, bq[0]) for bq in batches[:4]]))
         kb = int(np.mean([kernel_bytes(fleet, bq[0]) for bq in batches[:4]]))
-        # launches from 262 144 decisions on are SPLIT: the per-type shortlists checked in a launch of its own (place_memo_kernel, the
+        # launches from 393 216 decisions on are SPLIT: the per-type shortlists checked in a launch of its own (place_memo_kernel, the
         # dominant kernel: every request and result row passes through it), the rest decided by a tail launch (place_kernel.hpp:
         # kSplitFrom); MMP_NO_SPLIT=1: one launch with the check in front (place_batch_m_kernel); MMP_NO_MEMO=1: place_batch_kernel
         n_split, split_off = solver.split_batches()
         split_on = n_split > 0
         kname = ("place_memo_kernel" if split_on else
-                 "place_batch_m_kernel" if n >= 262_144 and os.environ.get("MMP_NO_MEMO") != "1" else "place_batch_kernel")
+                 "place_batch_m_kernel" if n >= 262_144 and os.environ.get("MMP_NO_MEMO") != "1" else "place_batch_kernel")  # (kMemoFrom)
         traffic, traffic_prov = measured_traffic(args.workload, n, kernel=kname)
         # roofline of the dominant kernel: bytes it has to move per launch (measured by the PMC passes when a
         # summary is committed, else the compulsory streams) / its average launch duration / the HBM peak
@@ -1650,6 +1667,17 @@ def main():
         from modelmesh_amd._lib import ptr as _ptr
         _one_args = (solver.h, _ptr(one), C.c_int32(1), None, C.c_int32(0), C.c_int64(fleet.now), _ptr(one_out))
         _place = solver.lib.mmp_place_batch
+        # (round 6) the calling thread pinned to one CPU for the single-request loops, as a mesh's request threads can be: on this host
+        # (256 hardware threads behind a 16-CPU quota) an unpinned thread is migrated a few hundred times per 80 000 calls and 0.5 % of
+        # its calls are slow — the whole of the p99 (profiles/r6/seam_tail_pinning.txt)
+        _aff = None
+        try:
+            _aff = os.sched_getaffinity(0)
+            _pin = sorted(_aff)[len(_aff) // 2]
+            os.sched_setaffinity(0, {_pin})
+            line["single_decision_thread"] = f"pinned to CPU {_pin} (sched_setaffinity) for the n = 1 latency loops"
+        except (AttributeError, OSError):
+            _aff = None
         for i in range(0 if args.kernel_only else 2000):
             one[0] = reqs[i % n]
             one["extra_off"] = 0
@@ -1667,6 +1695,11 @@ def main():
             t1 = time.perf_counter()
             solver.place(one, None, fleet.now)
             lat_py.append(time.perf_counter() - t1)
+        if _aff is not None:
+            try:
+                os.sched_setaffinity(0, _aff)
+            except OSError:
+                pass
         if lat:
             lat = np.array(lat[200:]) * 1e6
             line["p50_decision_latency_us"] = float(np.percentile(lat, 50))

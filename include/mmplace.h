@@ -484,11 +484,13 @@ typedef struct {
     int32_t n_candidates;
 } mmp_shortlist_row;
 int mmp_shortlists(mmp_ctx *ctx, mmp_shortlist_row *rows, int32_t cap_rows, int32_t *n_rows_out);
-/* Large device-pointer batches (mmp_place_batch_dev / _dev2 / _c_dev; request rows from 262 144 decisions, the single-caller form from
- * 196 608) are decided by TWO launches on the caller's stream: the first checks every request against the shortlists above and decides
- * what they cover — on the bench configuration 99.9 % — the second, a few workgroups, decides the rest by the ordinary path (results
- * identical either way; MMP_NO_SPLIT=1 in the environment keeps such batches in one launch).  A second launch that finds more than 1/32
- * of its batch left switches the split off until the next commit.  Diagnostics: *n_split_out = batches issued that way on this
+/* Large batches (request rows from 393 216 decisions, the single-caller form from 524 288; host-pointer and device-pointer calls alike)
+ * are decided by TWO launches on the call's stream: the first checks every request against the shortlists above and decides what they
+ * cover — on the bench configuration 99.97 % — the second, a few workgroups, decides the rest by the ordinary path (results identical
+ * either way; MMP_NO_SPLIT=1 in the environment keeps such batches in one launch).  The second launch is hidden behind the first launch of
+ * the next batch only if that one runs on ANOTHER hardware queue: a host that issues batches from several streams should give each a queue
+ * of its own (GPU_MAX_HW_QUEUES >= its streams + the library's: 8 for four).  A second launch that finds more than 1/32 of its batch left
+ * switches the split off until the next commit.  Diagnostics: *n_split_out = batches issued that way on this
  * context, *off_out = 1 while the split is switched off (either may be null). */
 int mmp_split_batches(mmp_ctx *ctx, int64_t *n_split_out, int32_t *off_out);
 /* clusterState iteration order (the `getCacheState` dump, MM.java:5552-5608).

@@ -80,13 +80,15 @@ struct DevBuf {
 struct SnapBufs {
     DevBuf pods, lru, rem, cnt, rpm, orig, pos_of, elig, elig_nors, pref, has_pref, fullw, ge, pc, ph, nz, heads, bslots, bpm, bwin, bsurv, bpcs;
     DevBuf sel, rk;  // Snap::sel / ::rk
+    DevBuf amul;     // Snap::amul
+    int32_t amul_w = 0;  // words it holds
     DevBuf memo, memo_cand, memo_rk;  // Snap::memo / ::memo_cand / ::memo_rk (place_kernel.hpp: TypeMemo)
     DevBuf ctpos;  // Snap::ctpos
     uint64_t types_gen = 0;  // has_pref holds the type table of this generation
     int32_t n_bslots = 0;  // case (b) slots this snapshot has (place_kernel.hpp: BSlot), read back at commit
     void release()
     {
-        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge, &pc, &ph, &nz, &heads, &bslots, &bpm, &bwin, &bsurv, &bpcs, &ctpos, &sel, &rk, &memo, &memo_cand, &memo_rk})
+        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge, &pc, &ph, &nz, &heads, &bslots, &bpm, &bwin, &bsurv, &bpcs, &ctpos, &sel, &rk, &amul, &memo, &memo_cand, &memo_rk})
             b->release();
     }
 };
@@ -200,6 +202,7 @@ struct mmp_ctx {
     int32_t no_long_lds = 0; // MMP_NO_LONG_LDS=1: the long path reads its per-type tables from global memory (tests, comparison)
     int32_t no_memo = 0;     // MMP_NO_MEMO=1: batches do not use the per-type shortlists (place_kernel.hpp: TypeMemo)
     int32_t memo_from = -1;  // MMP_MEMO_FROM=n: decisions from which a batch takes the kernel with the shortlists in front (default kMemoFrom)
+    int32_t long_dense_from = kLongDenseFrom;  // MMP_LONG_DENSE_FROM=n: decisions from which a full-cluster batch takes the 4-wavefront instantiation with its tables staged in LDS
     int32_t no_heads = 0;    // MMP_NO_HEADS=1: decisions do not use the per-type head windows (tests: lane_decide_r alone)
     // the split form of a large batch (place_kernel.hpp: place_memo_kernel + place_tail_kernel)
     int32_t no_split = 0;    // MMP_NO_SPLIT=1: never (the one-launch kernels with the check in front instead)
@@ -600,7 +603,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     A.long_first = (c->snap_long && c->snap_full && A.rmodels) ? 1 : 0;
     // the long path's per-type tables in LDS when they are small (C3: 20 KB) and the launch fills the chip: measured on the full
     // cluster, 800k decisions per launch 70.8 -> 67.1 us; at 100k (1.5 wavefronts per SIMD) 20.4 -> 21.0 us, hence the size condition
-    if (A.long_first && !inline_req && !done_flag && !c->no_long_lds && n >= kLongDenseFrom) {
+    if (A.long_first && !inline_req && !done_flag && !c->no_long_lds && n >= c->long_dense_from) {
         const size_t tb = long_tables_bytes(c->snap.T, c->snap.W);
         // (only where they fit beside the wave tile and the static part: a device with 64 KB of LDS per workgroup keeps reading
         // them from global memory instead of failing the launch)
@@ -690,7 +693,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
         }
     }
     if (segs) {  // several request arrays, one launch (multi_kernel.hpp); n = the decisions of all of them
-        if (c->snap_long && n >= kLongDenseFrom)
+        if (c->snap_long && n >= c->long_dense_from)
             hipLaunchKernelGGL(place_multi_long4_kernel, dim3(seg_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *segs);
         else if (c->snap_long)
             hipLaunchKernelGGL(place_multi_long_kernel, dim3(seg_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *segs);
@@ -707,7 +710,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     else if (done_flag && n > kPlaceBlock)
         hipLaunchKernelGGL(place_batch_flag_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad,
                            done_blocks);
-    else if (caller && c->snap_long && n >= kLongDenseFrom)
+    else if (caller && c->snap_long && n >= c->long_dense_from)
         hipLaunchKernelGGL(place_batch_long4_c_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *caller);
     else if (caller && c->snap_long)
         hipLaunchKernelGGL(place_batch_long_c_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds_nobar, st, c->snap, A, wpad, *caller);
@@ -717,7 +720,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
         hipLaunchKernelGGL(place_batch_c_m_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds_nobar, st, c->snap, A, wpad, *caller);
     else if (caller)
         hipLaunchKernelGGL(place_batch_c_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *caller);
-    else if (c->snap_long && n >= kLongDenseFrom)
+    else if (c->snap_long && n >= c->long_dense_from)
         hipLaunchKernelGGL(place_batch_long4_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad);
     else if (c->snap_long)
         hipLaunchKernelGGL(place_batch_long_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds_nobar, st, c->snap, A, wpad);
@@ -776,6 +779,7 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     const bool want_resident = getenv("MMP_RESIDENT") && getenv("MMP_RESIDENT")[0] == '1';
     if (const char *rm = getenv("MMP_RANK_MODE")) c->rank_mode = atoi(rm);
     if (const char *lm = getenv("MMP_LONG_MODE")) c->long_mode = atoi(lm);
+    if (const char *ld = getenv("MMP_LONG_DENSE_FROM")) c->long_dense_from = atoi(ld);
     if (const char *nd = getenv("MMP_NO_DELTA")) c->no_delta = nd[0] == '1';
     if (const char *sb = getenv("MMP_SINGLE_BLOCK")) c->single_block = sb[0] == '1';
     if (const char *sp = getenv("MMP_PLAN_SORTED")) c->cfg_plan_sorted = atoi(sp);
@@ -1799,6 +1803,15 @@ try {
     S.nz = B.nz.as<int32_t>();
     S.ph = B.ph.as<uint64_t>();
     S.ctpos = P > 0 ? B.ctpos.as<int32_t>() : nullptr;
+    if (B.amul_w != W) {  // the audit hash's word multipliers: a function of the word index alone
+        HIP_TRY(c, B.amul.ensure((size_t)W * 8));
+        std::vector<uint64_t> am((size_t)W);
+        for (int32_t w = 0; w < W; w++) am[(size_t)w] = audit_mul((uint64_t)w);
+        HIP_TRY(c, hipMemcpyAsync(B.amul.p, am.data(), (size_t)W * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipStreamSynchronize(st));  // (`am` leaves scope; once per table size)
+        B.amul_w = W;
+    }
+    S.amul = B.amul.as<uint64_t>();
     S.sel = P > 0 && have_sel ? B.sel.as<int32_t>() : nullptr;
     S.rk = P > 0 && have_sel ? B.rk.as<int32_t>() : nullptr;
     S.memo = B.memo.as<TypeMemo>();

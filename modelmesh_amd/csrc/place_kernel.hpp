@@ -1391,7 +1391,7 @@ __device__ __forceinline__ int lane_case_b(const Snap &S, const ResolvedReq &r, 
     for (int i = 0; i < kInlineExcl; i++) {
         const int e = sx[i];
         const uint64_t bit = (uint64_t)((xmask >> i) & 1u);
-        if (bit) hsum -= audit_mul((uint64_t)(e >> 6)) << (e & 63);
+        if (bit) hsum -= S.amul[e >> 6] << (e & 63);
         removed_surv += (int)(bit & (sw_[i] >> (e & 63)));
     }
     const int remaining = pcc[whi + 1] - p0c - removed_surv;
@@ -1629,11 +1629,13 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
             // everything the corrections read is fetched here, together (the slots are independent of one another): one load
             // latency instead of one per exclusion — and ONE load per exclusion (rk) instead of its word, its preference word and
             // its prefix count
+            uint64_t amx[kInlineExcl];  // the slots' word multipliers (the hash correction below), fetched beside their ranks
 #pragma unroll
             for (int i = 0; i < kInlineExcl; i++) {
                 const int e = sx[i];
                 const bool in = e >= start && e < end;  // (the padding, INT32_MAX, is not)
                 rkx[i] = in ? RK[e] : -1;
+                amx[i] = in ? S.amul[e >> 6] : 0ull;
             }
             r_lo = raw(wlo) & ((~0ull) << (start & 63));                 // start lies in wlo or is the first bit of wlo + 1
             if ((start >> 6) != wlo) r_lo = 0;
@@ -1650,7 +1652,7 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
                 const bool dup = i > 0 && sx[i - 1] == e;  // the same pod twice among the exclusions (tried and loaded, say)
                 const bool bit = !dup && rkx[i] >= 0;      // rkx is -1 outside [start, end) and for a position that is no candidate
                 xmask |= (uint32_t)bit << i;
-                if (bit) hsum -= audit_mul((uint64_t)(e >> 6)) << (e & 63);
+                if (bit) hsum -= amx[i] << (e & 63);
             }
             ccount -= __popc(xmask);
         } else {
@@ -2024,8 +2026,14 @@ __device__ __forceinline__ int lane_decide_win(const Snap &S, const PlaceArgs &A
     return kLaneDone;
 }
 
+// (MMP_PLACE_ONE_NOINLINE: experiment builds, tools/r6 — the general path as a function of its own)
+#ifdef MMP_PLACE_ONE_NOINLINE
+#define MMP_PLACE_ONE_ATTR __attribute__((noinline))
+#else
+#define MMP_PLACE_ONE_ATTR __forceinline__
+#endif
 template <int FORM = kReq64>
-__device__ __forceinline__ void place_one(const Snap &S, const PlaceArgs &A, int d, uint64_t *ew, uint64_t *fw,
+__device__ MMP_PLACE_ONE_ATTR void place_one(const Snap &S, const PlaceArgs &A, int d, uint64_t *ew, uint64_t *fw,
                                           const mmp_place_caller &C = mmp_place_caller{})
 {
     const int lane = lane_id();
@@ -2912,9 +2920,12 @@ __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(7, 
 // 12.7 -> 11.35 / 6.9 -> 6.7 (a caller with room); below, the check is the longer chain — a 100k launch of rows: 7.75 -> 8.6 us)
 constexpr int kMemoFrom = 4 * 1024 * 64;      // request rows
 constexpr int kMemoFromC = 3 * 1024 * 64;     // the single-caller form
-// decisions from which a batch is split into place_memo_kernel + place_tail_kernel
-constexpr int kSplitFrom = 4 * 1024 * 64;
-constexpr int kSplitFromC = 3 * 1024 * 64;
+// decisions from which a batch is split into place_memo_kernel + place_tail_kernel.  Measured, C3, round-robin on four streams with a
+// hardware queue each, per call (tools/r6/split_sweep.py, profiles/r6/split_sweeps.txt): request rows 300k 5.7 -> 7.3 us, 400k 7.3 -> 7.2,
+// 800k 15.8 -> 12.7 (63 G decisions/s); one caller 400k 5.9 -> 7.1, 800k 11.1 -> 8.1 (98 G decisions/s); C4, 1M rows 27.5 -> 15.7 (the one-launch
+// kernels are bound by their LDS there).  A pair of launches has a floor of ~7 us; on ONE stream the tail is not hidden (800k rows: 26.2 -> 27.9 us).
+constexpr int kSplitFrom = 6 * 1024 * 64;
+constexpr int kSplitFromC = 8 * 1024 * 64;
 
 // ---- the split form (round 6): a launch that does nothing but the shortlist check, and a dense tail --------------------------------
 // place_batch_m_kernel carries the check AND the ordinary path — ~150 instructions in front of ~1000, one register allocation (72 VGPRs

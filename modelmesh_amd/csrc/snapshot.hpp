@@ -59,6 +59,9 @@ struct Snap {
     // excluded candidate's place in the shortlist one lookup instead of its word, its preference word and its prefix count.
     const int32_t *sel;
     const int32_t *rk;
+    // audit_mul(w) for every 64-position word w of the table (round 6; null on shard views): the long path takes an excluded candidate's
+    // term off the audit hash with one lookup (a 64-bit multiply-mix per exclusion slot was a tenth of its instructions)
+    const uint64_t *amul;
     // The per-type shortlists of place_kernel.hpp: TypeMemo (round 5; null on shard views and when the head windows are off):
     // memo[kWinLds], memo_cand[kWinLds][kMemoCand] = list 0's pod indices in candidate order, memo_rk[kWinLds][kMemoCand] = what
     // each position of the type's window is to list 0 (candidate number, the best instance, nothing: kRk*).

@@ -6,6 +6,9 @@
 // predecessor (another kind) was slow too — a disturbance that does not care which call it hits (the host, the driver, the
 // device's scheduler) shows as equal shares and as bursts; a slow call path shows as one kind's own tail.
 //   g++ -O2 -std=c++17 -Iinclude tools/micro/seam_tail.cc -Lmodelmesh_amd/lib -lmmplace -Wl,-rpath,$PWD/modelmesh_amd/lib -lpthread -o /tmp/seam_tail
+#include <sched.h>
+#include <sys/resource.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -21,6 +24,23 @@ static const int64_t NOW = 1760000000000LL;
 int main(int argc, char **argv)
 {
     const int reps = argc > 1 ? atoi(argv[1]) : 20000;
+    // round 6: is the tail the host's?  `pin <cpu>` binds the calling thread to one CPU (sched_setaffinity) and asks for
+    // SCHED_FIFO (granted or not, reported); either way the run reports what the kernel charged the thread while it measured: voluntary
+    // and INVOLUNTARY context switches (getrusage RUSAGE_THREAD) — a slow call that coincides with neither is not the scheduler's.
+    int pin_cpu = -1;
+    for (int a = 2; a + 1 < argc; a++)
+        if (!strcmp(argv[a], "pin")) pin_cpu = atoi(argv[a + 1]);
+    bool pinned = false, fifo = false;
+    if (pin_cpu >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(pin_cpu, &set);
+        pinned = sched_setaffinity(0, sizeof set, &set) == 0;
+        sched_param sp;
+        memset(&sp, 0, sizeof sp);
+        sp.sched_priority = 10;
+        fifo = sched_setscheduler(0, SCHED_FIFO, &sp) == 0;
+    }
     const int P = 10000, M = 100000;
     std::vector<mmp_pod_row> pods(P);
     memset(pods.data(), 0, sizeof(mmp_pod_row) * P);
@@ -57,6 +77,8 @@ int main(int argc, char **argv)
         return 1;
     }
     const char *names[4] = {"place", "serve", "gates", "route"};
+    rusage ru0;
+    getrusage(RUSAGE_THREAD, &ru0);
     std::vector<double> us[4];
     std::vector<int> kind_of;     // call sequence
     std::vector<double> us_seq;
@@ -89,6 +111,11 @@ int main(int argc, char **argv)
         if (rc) { fprintf(stderr, "%s: %s\n", names[k], mmp_last_error(c)); return 1; }
         if (j >= 500) { us[k].push_back(d); kind_of.push_back(k); us_seq.push_back(d); }
     }
+    rusage ru1;
+    getrusage(RUSAGE_THREAD, &ru1);
+    printf("calling thread: %s%s; while measuring: %ld voluntary and %ld involuntary context switches over %d calls (cpu now %d)\n",
+           pin_cpu >= 0 ? (pinned ? "pinned to one CPU" : "pinning REFUSED") : "not pinned", pin_cpu >= 0 ? (fifo ? ", SCHED_FIFO" : ", SCHED_FIFO refused") : "",
+           ru1.ru_nvcsw - ru0.ru_nvcsw, ru1.ru_nivcsw - ru0.ru_nivcsw, 4 * (reps + 500), sched_getcpu());
     double p50[4];
     for (int k = 0; k < 4; k++) {
         std::vector<double> s = us[k];

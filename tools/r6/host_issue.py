@@ -30,13 +30,14 @@ s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
 s.load_fleet(fleet)
 d_reqs = torch.from_numpy(reqs.view(np.uint8).reshape(-1)).to(dev)
 d_extra = torch.from_numpy(np.ascontiguousarray(extra)).to(dev)
-outs = [torch.zeros(n * 16, dtype=torch.uint8, device=dev) for _ in range(4)]
-sts = [torch.cuda.Stream(dev) for _ in range(4)]
+NS = int(os.environ.get("NSTREAMS", "4"))
+outs = [torch.zeros(n * 16, dtype=torch.uint8, device=dev) for _ in range(NS)]
+sts = [torch.cuda.Stream(dev) for _ in range(NS)]
 fn = s.lib.mmp_place_batch_dev
 args = [(s.h, C.c_void_p(d_reqs.data_ptr()), C.c_int32(n), C.c_void_p(d_extra.data_ptr()), C.c_int64(fleet.now), C.c_void_p(outs[i].data_ptr()),
-         C.c_void_p(sts[i].cuda_stream)) for i in range(4)]
+         C.c_void_p(sts[i].cuda_stream)) for i in range(NS)]
 for i in range(400):
-    fn(*args[i % 4])
+    fn(*args[i % NS])
 torch.cuda.synchronize()
 pc = time.perf_counter
 for label, sync in (("back to back, 4 streams", False), ("a synchronisation behind every call", True)):
@@ -44,7 +45,7 @@ for label, sync in (("back to back, 4 streams", False), ("a synchronisation behi
     for rep in range(10):
         for i in range(20):
             t0 = pc()
-            fn(*args[i % 4])
+            fn(*args[i % NS])
             ts.append(pc() - t0)
             if sync:
                 torch.cuda.synchronize()
@@ -58,7 +59,7 @@ close_us, span_us = [], []
 for rep in range(30):
     t0 = pc()
     for i in range(20 * int(os.environ.get("CALLS_X", "1"))):
-        fn(*args[i % 4])
+        fn(*args[i % NS])
     for e, st in zip(evs, sts):
         e.record(st)
     for e in reversed(evs):
@@ -78,7 +79,7 @@ for label, style in (("events polled (last stream first), then synchronize", "po
     for rep in range(30):
         t0 = pc()
         for i in range(20):
-            fn(*args[i % 4])
+            fn(*args[i % NS])
         if style == "poll":
             for e, st in zip(evs, sts):
                 e.record(st)
@@ -99,7 +100,7 @@ ts = np.zeros((30, 20))
 for rep in range(30):
     for i in range(20):
         t0 = pc()
-        fn(*args[i % 4])
+        fn(*args[i % NS])
         ts[rep, i] = pc() - t0
     torch.cuda.synchronize()
 print("per position in a 20-call region (us, median over 30 regions):", " ".join(f"{v:.1f}" for v in np.median(ts, axis=0) * 1e6))
