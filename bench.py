@@ -1111,7 +1111,9 @@ def secondary_kernels_leg(fleet, solver, device: int, workload: str = "C3", reps
         timed("cache_replay_kernel", replay, int((32 * e_cache + 16).sum() + 64 * len(ops)), len(ops),
               "cache operations", "16 B per deque entry read + 16 B written, 32 B per operation in + 32 B out; caches of up to 48 / 160 "
               "deque slots are replayed by 8- / 16-lane teams (8 / 4 caches per wavefront), larger ones by a wavefront each: a chain of "
-              "dependent steps per cache (table row -> entries + operation -> LDS deque -> result), not a stream")
+              "dependent steps per cache (table row -> entries + operation -> LDS deque -> result), not a stream.  Every repetition "
+              "reloads the caches first (the replay mutates them), so the kernel reads the deques COLD, from HBM: 16-17 us here against "
+              "13 us for a replay of resident caches (profiles/r5/README.md) — the same kernel")
 
         # f-1 KV wire format: Jackson JSON of the instance table and of the registry, parsed on device
         ids = wire.make_ids(rng, P)
