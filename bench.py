@@ -696,8 +696,11 @@ def single_caller_leg(fleet, solver, dev, sets: int = 8):
             "kernel_ms_rows_64B": ms["rows"], "kernel_ms_single_caller_24B": ms["caller"],
             "decisions_per_s_single_caller": n / (ms["caller"] * 1e-3),
             "ms_per_launch_single_caller_4_streams": ms4, "decisions_per_s_single_caller_4_streams": n / (ms4 * 1e-3),
-            "shortlists": {"kernel": "place_batch_c_m_kernel: a request is checked against its type's recorded shortlist before the lane "
-                                     "phase (place_kernel.hpp: TypeMemo, memo_try); batches from 393216 decisions on",
+            "shortlists": {"kernel": "place_memo_c_kernel + place_tail_c_kernel from 524288 rows on (two launches on the call's stream: "
+                                     "the type's recorded shortlist checked by a lane per request, the undecided ones in a dense "
+                                     "tail; place_kernel.hpp: TypeMemo, memo_try, place_tail_body); place_batch_c_m_kernel (one "
+                                     "launch, the check in front of the lane phase) from 262144 rows on; `kernel_ms_*` = the whole "
+                                     "call on ONE stream",
                            "rows": [[int(v) for v in r] for r in solver.shortlists()]},
             "hbm_bytes_per_decision": {"rows": 80, "single_caller": 40},
             "hbm_only_frac": {"rows": hbm_stream_bytes(n) / (ms["rows"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -707,7 +710,8 @@ def single_caller_leg(fleet, solver, dev, sets: int = 8):
             "note": "mmp_place_batch_c_dev / mmp_place_batch_c: self and getFreshInstanceRecord() belong to the calling instance "
                     "(MM.java:5369-5386) and travel once per call; the launch is bound by the instructions of a decision, not by "
                     "the request stream (profiles/r5/place_experiments/README.md, profiles/r5/shortlist_experiments/README.md): "
-                    "halving the bytes bought 14 %, the shortlists in front of the lane phase another 10-12 %"}
+                    "halving the bytes bought 14 %, the shortlists in front of the lane phase another 10-12 %; round 6: split into "
+                    "two launches, four streams with a hardware queue each 8.1-8.4 us per 800k rows (profiles/r6/README.md)"}
 
 
 def multi_entry_leg(fleet, solver, dev, k: int = 8):
@@ -1533,6 +1537,10 @@ def main():
         traffic, traffic_prov = measured_traffic(args.workload, n, kernel=kname)
         # roofline of the dominant kernel: bytes it has to move per launch (measured by the PMC passes when a
         # summary is committed, else the compulsory streams) / its average launch duration / the HBM peak
+        if split_on:
+            # what place_memo_kernel asks the memory system for: the request and result streams, the model's word (4 B of an array of its
+            # own, not the 32-byte registry row), the caller's position (4 B), the request's own exclusions and their positions
+            kb = int(np.mean([80 * len(bq[0]) + 8 * len(bq[0]) + 8 * int(bq[0]["n_extra"].sum()) for bq in batches[:4]]))
         moved = traffic if traffic else kb
         pair_ms = gpu_ms_per_step  # one call on one stream: the kernel alone, or first launch + tail of a split batch
         if first_ms is not None:
@@ -1568,7 +1576,8 @@ def main():
                                      "the first launches of the other streams (`ms_per_step`)"},
                          "bytes_per_launch": moved,
                          "bytes_per_launch_source": "rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE (profiles/)" if traffic else
-                                                    "compulsory streams (request 64 B + resolved model row + exclusions + result 16 B)",
+                                                    ("compulsory streams (request 64 B + the model's word 4 B + the caller's position 4 B + own exclusions + result 16 B)" if split_on else
+                                                     "compulsory streams (request 64 B + resolved model row + exclusions + result 16 B)"),
                          "kernel_bytes_per_launch": kb,
                          # HBM ONLY: request stream + result rows over the kernel's own duration.  `frac` above is the counter
                          # figure, which counts the launch's L2 misses on the 3.2 MB registry view — Infinity Cache hits — as

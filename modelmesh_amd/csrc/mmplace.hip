@@ -208,6 +208,7 @@ struct mmp_ctx {
     int32_t no_split = 0;    // MMP_NO_SPLIT=1: never (the one-launch kernels with the check in front instead)
     int32_t split_from = -1; // MMP_SPLIT_FROM=n: decisions from which a batch is split (default kSplitFrom / kSplitFromC)
     int32_t tail_blocks = kTailBlocks;  // MMP_TAIL_BLOCKS: workgroups of the tail launch
+    int32_t memo_lds_min = 0;  // MMP_MEMO_LDS_MIN=bytes: dynamic LDS the first launch of a split batch asks for at least (an occupancy cap: see kMemoLdsMin)
     int32_t split_notail = 0;  // MMP_SPLIT_NOTAIL=1: the tail launch is left out — the batch's results are INCOMPLETE (timing the first launch alone)
     // per stream that has issued a split batch: the words its first launches leave for its tails (launches of one stream are ordered,
     // so one buffer per stream will do) and a pinned pair the tail reports to: {undecided, of how many}
@@ -669,7 +670,8 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
         int32_t *report = nullptr;
         if (lds + kPlaceStaticLds + kTailStaticLds <= c->lds_limit && miss_buffer(c, st, rest_buffer_ints(n_words), &words, &report) &&
             !c->split_off.load(std::memory_order_relaxed)) {
-            const size_t lds_memo = (size_t)kPlaceWaves * memo_stage_bytes(c->snap.T);  // a copy of the types' records per wavefront
+            size_t lds_memo = (size_t)kPlaceWaves * memo_stage_bytes(c->snap.T);  // a copy of the types' records per wavefront
+            lds_memo = std::max(lds_memo, (size_t)c->memo_lds_min);
             if (c->split_notail) words = nullptr;  // (diagnostics: the undecided requests are not even recorded)
             if (getenv("MMP_SPLIT_NOREPORT")) report = nullptr;  // (experiment)
             if (caller) {
@@ -774,6 +776,7 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     if (const char *sf = getenv("MMP_SPLIT_FROM")) c->split_from = atoi(sf);
     if (const char *tb = getenv("MMP_TAIL_BLOCKS")) c->tail_blocks = std::max(1, std::min(atoi(tb), kRestLists));
     if (const char *nt = getenv("MMP_SPLIT_NOTAIL")) c->split_notail = nt[0] == '1';
+    if (const char *ml = getenv("MMP_MEMO_LDS_MIN")) c->memo_lds_min = std::max(0, std::min(atoi(ml), 60 * 1024));
     if (const char *nl = getenv("MMP_NO_LONG_LDS")) c->no_long_lds = nl[0] == '1';
     if (const char *nb = getenv("MMP_NO_CASEB")) c->no_caseb = nb[0] == '1';
     const bool want_resident = getenv("MMP_RESIDENT") && getenv("MMP_RESIDENT")[0] == '1';

@@ -2713,6 +2713,8 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
                 wave_sync();
             }
         }
+        PHASE(10);  // the general path
+        PHASE_COUNT(11, 1);  // wavefronts
         announce_done(DoneFlag{A.done_flag, done_blocks, A.done_seq});  // (latency-slot launches of the barrier-free long kernel; a no-op otherwise)
         return;
     }

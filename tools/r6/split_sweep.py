@@ -21,6 +21,8 @@ from modelmesh_amd.solver import Solver  # noqa: E402
 VARIANTS = [{"MMP_NO_MEMO": "1"}, {"MMP_MEMO_FROM": "0", "MMP_NO_SPLIT": "1"}, {"MMP_MEMO_FROM": "0", "MMP_SPLIT_FROM": "0"}]
 if os.environ.get("SWEEP_TAILS"):
     VARIANTS += [{"MMP_MEMO_FROM": "0", "MMP_SPLIT_FROM": "0", "MMP_TAIL_BLOCKS": t} for t in os.environ["SWEEP_TAILS"].split(",")]
+if os.environ.get("SWEEP_LDS"):
+    VARIANTS += [{"MMP_MEMO_FROM": "0", "MMP_SPLIT_FROM": "0", "MMP_MEMO_LDS_MIN": v} for v in os.environ["SWEEP_LDS"].split(",")]
 if os.environ.get("SWEEP_NOTAIL"):
     VARIANTS += [{"MMP_MEMO_FROM": "0", "MMP_SPLIT_FROM": "0", "MMP_SPLIT_NOTAIL": "1"}]
 if os.environ.get("SWEEP_ONLY"):
@@ -58,7 +60,7 @@ sts = [st] + [torch.cuda.Stream(dev) for _ in range(NST - 1)]
 K = int(os.environ.get("SWEEP_K", "200"))
 ref = {}
 for env in VARIANTS:
-    for k in ("MMP_NO_MEMO", "MMP_MEMO_FROM", "MMP_NO_SPLIT", "MMP_SPLIT_FROM", "MMP_TAIL_BLOCKS", "MMP_SPLIT_NOTAIL"):
+    for k in ("MMP_NO_MEMO", "MMP_MEMO_FROM", "MMP_NO_SPLIT", "MMP_SPLIT_FROM", "MMP_TAIL_BLOCKS", "MMP_SPLIT_NOTAIL", "MMP_MEMO_LDS_MIN"):
         os.environ.pop(k, None)
     os.environ.update(env)
     s = Solver(fleet.min_space_units, fleet.min_churn_age_ms)
