@@ -484,6 +484,15 @@ typedef struct {
     int32_t n_candidates;
 } mmp_shortlist_row;
 int mmp_shortlists(mmp_ctx *ctx, mmp_shortlist_row *rows, int32_t cap_rows, int32_t *n_rows_out);
+/* The same for the LONG shortlists of a cluster whose instances are (nearly) all full (diagnostics; ModelMesh.java:4880-4991 through the
+ * prefix tables): there a shortlist spans the table and a request always has positions of its own inside it, which the prefix-table
+ * path treats as corrections (count, audit hash, the pick's rank) of a list it never builds.  The walk itself — first eligible
+ * instance, preference step, break scans — depends on the request only when an exclusion or the calling instance sits on a position
+ * that steers it; commit records it per type row (every row) and per value of the fresh-row bit, and a request none of whose own
+ * positions is one of those is decided from the record (results identical; MMP_NO_LONG_MEMO=1 in the environment: no records).
+ * rows[2 * t + bit] = {valid, lo = the type's first eligible position, hi = where the list ends, n_candidates}; *n_rows_out = 2 * type
+ * rows (0: no records for this snapshot). */
+int mmp_long_shortlists(mmp_ctx *ctx, mmp_shortlist_row *rows, int32_t cap_rows, int32_t *n_rows_out);
 /* Large batches (request rows from 393 216 decisions, the single-caller form from 524 288; host-pointer and device-pointer calls alike)
  * are decided by TWO launches on the call's stream: the first checks every request against the shortlists above and decides what they
  * cover — on the bench configuration 99.97 % — the second, a few workgroups, decides the rest by the ordinary path (results identical

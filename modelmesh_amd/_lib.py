@@ -170,6 +170,7 @@ SYMBOLS = [
     ("mmp_get_order", C.c_int, [_P, _P, C.POINTER(C.c_int32)]),
     ("mmp_delta_commits", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("mmp_shortlists", C.c_int, [_P, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    ("mmp_long_shortlists", C.c_int, [_P, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     ("mmp_split_batches", C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     ("mmp_place_batch_dev2", C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int64, _P, _P]),
     ("mmp_place_batch_c", C.c_int, [_P, _P, _P, C.c_int32, _P, C.c_int32, C.c_int64, _P]),

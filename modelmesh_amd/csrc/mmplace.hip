@@ -83,12 +83,13 @@ struct SnapBufs {
     DevBuf amul;     // Snap::amul
     int32_t amul_w = 0;  // words it holds
     DevBuf memo, memo_cand, memo_rk;  // Snap::memo / ::memo_cand / ::memo_rk (place_kernel.hpp: TypeMemo)
+    DevBuf lmemo;                     // Snap::lmemo (place_kernel.hpp: LongMemo)
     DevBuf ctpos;  // Snap::ctpos
     uint64_t types_gen = 0;  // has_pref holds the type table of this generation
     int32_t n_bslots = 0;  // case (b) slots this snapshot has (place_kernel.hpp: BSlot), read back at commit
     void release()
     {
-        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge, &pc, &ph, &nz, &heads, &bslots, &bpm, &bwin, &bsurv, &bpcs, &ctpos, &sel, &rk, &amul, &memo, &memo_cand, &memo_rk})
+        for (DevBuf *b : {&pods, &lru, &rem, &cnt, &rpm, &orig, &pos_of, &elig, &elig_nors, &pref, &has_pref, &fullw, &ge, &pc, &ph, &nz, &heads, &bslots, &bpm, &bwin, &bsurv, &bpcs, &ctpos, &sel, &rk, &amul, &memo, &memo_cand, &memo_rk, &lmemo})
             b->release();
     }
 };
@@ -200,8 +201,11 @@ struct mmp_ctx {
     int32_t cfg_plan_fused = 1;   // MMP_PLAN_FUSED=0: the plan as its eight dependent launches (comparison; the one-launch form is the default)
     int32_t plan_grid_max = 0;    // workgroups the one-launch plan may have: all of them resident at once
     int32_t no_long_lds = 0; // MMP_NO_LONG_LDS=1: the long path reads its per-type tables from global memory (tests, comparison)
+    int32_t long_split_from = -1;  // MMP_LONG_SPLIT_FROM=n: requests from which a full-cluster batch is split (default kLongSplitFrom)
+    int32_t no_long_memo = 0;  // MMP_NO_LONG_MEMO=1: commit records no walks of the long shortlists (place_kernel.hpp: LongMemo)
     int32_t no_memo = 0;     // MMP_NO_MEMO=1: batches do not use the per-type shortlists (place_kernel.hpp: TypeMemo)
     int32_t memo_from = -1;  // MMP_MEMO_FROM=n: decisions from which a batch takes the kernel with the shortlists in front (default kMemoFrom)
+    bool long_dense_env = false;  // MMP_LONG_DENSE_FROM was given
     int32_t long_dense_from = kLongDenseFrom;  // MMP_LONG_DENSE_FROM=n: decisions from which a full-cluster batch takes the 4-wavefront instantiation with its tables staged in LDS
     int32_t no_heads = 0;    // MMP_NO_HEADS=1: decisions do not use the per-type head windows (tests: lane_decide_r alone)
     // the split form of a large batch (place_kernel.hpp: place_memo_kernel + place_tail_kernel)
@@ -604,7 +608,11 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     A.long_first = (c->snap_long && c->snap_full && A.rmodels) ? 1 : 0;
     // the long path's per-type tables in LDS when they are small (C3: 20 KB) and the launch fills the chip: measured on the full
     // cluster, 800k decisions per launch 70.8 -> 67.1 us; at 100k (1.5 wavefronts per SIMD) 20.4 -> 21.0 us, hence the size condition
-    if (A.long_first && !inline_req && !done_flag && !c->no_long_lds && n >= c->long_dense_from) {
+    // With the recorded long walks (place_kernel.hpp: LongMemo) hardly a request searches those tables, and the barrier-free
+    // instantiation is the faster one at every size (C3 full cluster, 200k / 400k / 800k requests per launch: 16.0 / 25.6 / 40.3 us against
+    // 18.5 / 28.9 / 43.5 us; profiles/r6/long_records.txt)
+    const int32_t dense_from = (A.long_first && c->snap.lmemo && !c->long_dense_env) ? INT32_MAX : c->long_dense_from;
+    if (A.long_first && !inline_req && !done_flag && !c->no_long_lds && n >= dense_from) {
         const size_t tb = long_tables_bytes(c->snap.T, c->snap.W);
         // (only where they fit beside the wave tile and the static part: a device with 64 KB of LDS per workgroup keeps reading
         // them from global memory instead of failing the launch)
@@ -651,6 +659,8 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_batch_long4_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want - kTailStaticLds));
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_tail_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want - kTailStaticLds));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_long_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want - kTailStaticLds));
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(place_long_tail_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want - kTailStaticLds));
         c->lds_granted.store((size_t)want, std::memory_order_release);
     }
     // batches with the per-type shortlists in front (place_batch_m_kernel / place_batch_c_m_kernel): head windows and the resolved registry
@@ -694,6 +704,35 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
             return MMP_OK;
         }
     }
+    // ... and on a full cluster: the recorded long walks alone in the first launch (place_kernel.hpp: place_long_memo_kernel)
+    if (A.long_first && c->snap.lmemo && !segs && !inline_req && !done_flag && !c->force_wave && !c->no_split &&
+        !c->split_off.load(std::memory_order_relaxed) && n >= (c->long_split_from >= 0 ? c->long_split_from : kLongSplitFrom)) {
+        const int grid = div_up(n, kPlaceBlock);
+        const int n_words = grid * kPlaceWaves;
+        const int cap = rest_list_cap(n_words);
+        int32_t *words = nullptr;
+        int32_t *report = nullptr;
+        // (the tail reads the tables from global memory: its requests are a handful)
+        const size_t lds_tail = std::max<size_t>((size_t)kPlaceWaves * 2 * wpad * sizeof(uint64_t), (size_t)place_lane_lds(c->snap.T));
+        if (lds_tail + kPlaceStaticLds + kTailStaticLds <= c->lds_limit && miss_buffer(c, st, rest_buffer_ints(n_words), &words, &report) &&
+            !c->split_off.load(std::memory_order_relaxed)) {
+            PlaceArgs At = A;
+            At.long_first = 1;
+            if (c->split_notail) words = nullptr;
+            if (caller) {
+                hipLaunchKernelGGL(place_long_memo_c_kernel, dim3(grid), dim3(kPlaceBlock), 0, st, c->snap, A, words, cap, *caller);
+                if (!c->split_notail)
+                    hipLaunchKernelGGL(place_long_tail_c_kernel, dim3(c->tail_blocks), dim3(kPlaceBlock), lds_tail, st, c->snap, At, wpad, words, cap, report, *caller);
+            } else {
+                hipLaunchKernelGGL(place_long_memo_kernel, dim3(grid), dim3(kPlaceBlock), 0, st, c->snap, A, words, cap);
+                if (!c->split_notail)
+                    hipLaunchKernelGGL(place_long_tail_kernel, dim3(c->tail_blocks), dim3(kPlaceBlock), lds_tail, st, c->snap, At, wpad, words, cap, report);
+            }
+            HIP_TRY(c, hipGetLastError());
+            c->n_split.fetch_add(1, std::memory_order_relaxed);
+            return MMP_OK;
+        }
+    }
     if (segs) {  // several request arrays, one launch (multi_kernel.hpp); n = the decisions of all of them
         if (c->snap_long && n >= c->long_dense_from)
             hipLaunchKernelGGL(place_multi_long4_kernel, dim3(seg_blocks), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *segs);
@@ -712,7 +751,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
     else if (done_flag && n > kPlaceBlock)
         hipLaunchKernelGGL(place_batch_flag_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad,
                            done_blocks);
-    else if (caller && c->snap_long && n >= c->long_dense_from)
+    else if (caller && c->snap_long && n >= dense_from)
         hipLaunchKernelGGL(place_batch_long4_c_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *caller);
     else if (caller && c->snap_long)
         hipLaunchKernelGGL(place_batch_long_c_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds_nobar, st, c->snap, A, wpad, *caller);
@@ -722,7 +761,7 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
         hipLaunchKernelGGL(place_batch_c_m_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds_nobar, st, c->snap, A, wpad, *caller);
     else if (caller)
         hipLaunchKernelGGL(place_batch_c_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad, *caller);
-    else if (c->snap_long && n >= c->long_dense_from)
+    else if (c->snap_long && n >= dense_from)
         hipLaunchKernelGGL(place_batch_long4_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds, st, c->snap, A, wpad);
     else if (c->snap_long)
         hipLaunchKernelGGL(place_batch_long_kernel, dim3(div_up(n, kPlaceBlock)), dim3(kPlaceBlock), lds_nobar, st, c->snap, A, wpad);
@@ -771,6 +810,8 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     if (const char *fw = getenv("MMP_FORCE_WAVE")) c->force_wave = fw[0] == '1';
     if (const char *nh = getenv("MMP_NO_HEADS")) c->no_heads = nh[0] == '1';
     if (const char *nm = getenv("MMP_NO_MEMO")) c->no_memo = nm[0] == '1';
+    if (const char *nm = getenv("MMP_NO_LONG_MEMO")) c->no_long_memo = nm[0] == '1';
+    if (const char *lf = getenv("MMP_LONG_SPLIT_FROM")) c->long_split_from = atoi(lf);
     if (const char *mf = getenv("MMP_MEMO_FROM")) c->memo_from = atoi(mf);
     if (const char *ns = getenv("MMP_NO_SPLIT")) c->no_split = ns[0] == '1';
     if (const char *sf = getenv("MMP_SPLIT_FROM")) c->split_from = atoi(sf);
@@ -782,7 +823,10 @@ int mmp_create(const mmp_config *cfg, mmp_ctx **out)
     const bool want_resident = getenv("MMP_RESIDENT") && getenv("MMP_RESIDENT")[0] == '1';
     if (const char *rm = getenv("MMP_RANK_MODE")) c->rank_mode = atoi(rm);
     if (const char *lm = getenv("MMP_LONG_MODE")) c->long_mode = atoi(lm);
-    if (const char *ld = getenv("MMP_LONG_DENSE_FROM")) c->long_dense_from = atoi(ld);
+    if (const char *ld = getenv("MMP_LONG_DENSE_FROM")) {
+        c->long_dense_from = atoi(ld);
+        c->long_dense_env = true;
+    }
     if (const char *nd = getenv("MMP_NO_DELTA")) c->no_delta = nd[0] == '1';
     if (const char *sb = getenv("MMP_SINGLE_BLOCK")) c->single_block = sb[0] == '1';
     if (const char *sp = getenv("MMP_PLAN_SORTED")) c->cfg_plan_sorted = atoi(sp);
@@ -1820,6 +1864,11 @@ try {
     S.memo = B.memo.as<TypeMemo>();
     S.memo_cand = B.memo_cand.as<int32_t>();
     S.memo_rk = B.memo_rk.as<int16_t>();
+    S.lmemo = nullptr;
+    if (P > 0 && have_sel && !c->no_long_memo) {  // the recorded walks of the long shortlists (place_kernel.hpp: LongMemo)
+        HIP_TRY(c, B.lmemo.ensure((size_t)T * kLongLevels * sizeof(LongMemo)));
+        S.lmemo = B.lmemo.as<LongMemo>();
+    }
 
     bool next_long = c->long_mode == 1, next_full = false;
     {  // the partitions of the type constraints (host) and their uploads: inputs, like the table itself
@@ -1917,9 +1966,10 @@ try {
         hipLaunchKernelGGL(commit_level2_kernel, dim3(4 * T + L2.nb_finish), dim3(64), 0, st, L2);
         // sel / rk from the prefix tables, and the per-type shortlists (TypeMemo) from the finished head windows (every row a decision
         // can name is written, valid or not): one launch; the registry view below is resolved against the shortlists' ranges
-        hipLaunchKernelGGL(build_sel_memo_kernel, dim3((have_sel ? 2 * T * W : 0) + std::min(T, kWinLds)), dim3(64), 0, st, S,
+        hipLaunchKernelGGL(build_sel_memo_kernel, dim3((have_sel ? 2 * T * W : 0) + std::min(T, kWinLds) + (S.lmemo ? T : 0)), dim3(64), 0, st, S,
                            have_sel ? B.sel.as<int32_t>() : nullptr, have_sel ? B.rk.as<int32_t>() : nullptr,
-                           B.heads.as<TypeWin>(), B.memo.as<TypeMemo>(), B.memo_cand.as<int32_t>(), B.memo_rk.as<int16_t>());
+                           B.heads.as<TypeWin>(), B.memo.as<TypeMemo>(), B.memo_cand.as<int32_t>(), B.memo_rk.as<int16_t>(),
+                           B.lmemo.as<LongMemo>());
         // the running minimum of the case (b) candidates' rpm, then the survivor bitmaps of the rpm rule's four limits
         hipLaunchKernelGGL(prefix_min_rpm_kernel, dim3(kBSlots), dim3(64), 0, st, S, B.bslots.as<BSlot>(), n_bslots_dev, B.bpm.as<int32_t>(),
                            (int32_t)(W * 64));
@@ -2042,6 +2092,29 @@ try {
     return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_shortlists");
 } catch (const std::exception &e) {
     return fail(c, MMP_EHIP, "%s: %s", "mmp_shortlists", e.what());
+}
+
+int mmp_long_shortlists(mmp_ctx *c, mmp_shortlist_row *rows, int32_t cap_rows, int32_t *n_rows_out)
+try {
+    if (!c || !n_rows_out || (!rows && cap_rows > 0) || cap_rows < 0) return fail(c, MMP_EINVAL, "mmp_long_shortlists: bad argument");
+    std::lock_guard<std::mutex> gb(c->batch_mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
+    if (!c->committed) return fail(c, MMP_ESTATE, "no committed snapshot");
+    HIP_TRY(c, hipSetDevice(c->cfg.device));
+    const int32_t nt = c->snap.lmemo ? c->snap.T : 0;
+    std::vector<LongMemo> h((size_t)std::max(nt, 1) * kLongLevels);
+    if (nt) HIP_TRY(c, copy_sync(c, h.data(), c->snap.lmemo, (size_t)nt * kLongLevels * sizeof(LongMemo), hipMemcpyDeviceToHost));
+    for (int32_t i = 0; i < 2 * nt && i < cap_rows; i++) {
+        const LongMemo &m = h[(size_t)(i >> 1) * kLongLevels];  // (the record of a request that excludes none of the first instances)
+        const LongVar &v = m.v[i & 1];
+        rows[i] = mmp_shortlist_row{v.valid, m.best0, v.end, v.ccount};
+    }
+    *n_rows_out = 2 * nt;
+    return MMP_OK;
+} catch (const std::bad_alloc &) {
+    return fail(c, MMP_ENOMEM, "%s: out of host memory", "mmp_long_shortlists");
+} catch (const std::exception &e) {
+    return fail(c, MMP_EHIP, "%s: %s", "mmp_long_shortlists", e.what());
 }
 
 int mmp_split_batches(mmp_ctx *c, int64_t *n_split_out, int32_t *off_out)

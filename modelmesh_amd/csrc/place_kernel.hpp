@@ -41,7 +41,20 @@ __device__ unsigned int g_phase[4096][16];  // one row per wavefront of the laun
     do {                                                                                           \
         if (lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) g_phase[PHASE_ROW()][k] += (unsigned int)(n); \
     } while (0)
+#define PHASE_WHY(bit)  /* (long_memo_try) why a request was left to the walk: slot 7 counts such lanes, slot 9 ors the reasons */ \
+    do {                                                                                           \
+        atomicAdd(&g_phase[PHASE_ROW()][7], 1u);                                                   \
+        atomicOr(&g_phase[PHASE_ROW()][9], (unsigned int)(bit));                                   \
+        g_phase[PHASE_ROW()][13] = (unsigned int)r.model;                                          \
+    } while (0)
+#define PHASE_ABS(k)  /* the constant-rate clock all XCDs share (10 ns ticks, low 32 bits): when a wavefront started / ended, tools/r6/wave_timeline.py */ \
+    do {                                                                                           \
+        const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                            \
+        if (lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1) g_phase[PHASE_ROW()][k] = (unsigned int)t_; \
+    } while (0)
 #else
+#define PHASE_WHY(bit) do { } while (0)
+#define PHASE_ABS(k) do { } while (0)
 #define PHASE_T0() do { } while (0)
 #define PHASE(k) do { } while (0)
 #define PHASE_COUNT(k, n) do { } while (0)
@@ -207,6 +220,40 @@ __host__ __device__ constexpr int memo_stage_bytes(int type_rows)
 {
     return (((type_rows < kWinLds ? type_rows : kWinLds) * (int)sizeof(TypeMemo) + 1023) / 1024) * 1024;
 }
+
+// ---- recorded walks of the long shortlists (round 6) --------------------------------------------------------------------------------
+// On a cluster whose instances are (nearly) all full a shortlist spans thousands of positions, so a request always has positions of
+// its own inside it — and the prefix-table phase (lane_decide_r<..., LONG>) already treats those as corrections of a list it never
+// builds: an excluded candidate takes one off the count, its term off the linear hash, one rank off the pick.  What it still walks
+// per request — the first eligible instance, the preference step, the break scans, the prefix-table differences: a third of a
+// wavefront's time — depends on the request only if an exclusion or the caller sits on one of the few positions that STEER the walk:
+// [best0, bestpos] and the instance that ends the list.  commit runs the walk once per (type, fresh-row bit) without exclusions
+// (build_long_memo_kernel) and long_memo_try answers from the record whenever none of those positions is the request's own.
+struct __attribute__((aligned(16))) LongVar {
+    int32_t valid;   // 0: no record for this (type, bit) — the walk left the common shape
+    int32_t end;     // the list is best ∪ candidates of [bestpos + 1, end); the instance at `end` ended it (S.P: nothing did)
+    int32_t ccount;  // 1 + the row's candidate bits in [bestpos + 1, end)
+    int32_t g0;      // the number (pc's numbering) of the first candidate bit at or behind bestpos + 1
+    uint64_t hsum;   // audit-hash sum of that list
+    uint64_t pad_;
+};
+struct __attribute__((aligned(16))) LongMemo {
+    int64_t b_rem, b_lru;  // the best instance's row: what the fresh-row test (:4913-4922) compares the caller's fresh record with
+    int32_t best_is_full, b_rpm, best_idx, has_pm;
+    int32_t best0, bestpos, e_rpm, sbk;  // e_rpm / sbk: the first eligible instance's rpm / the break rule of the caller's own entry (:4909-4922 on that row)
+    LongVar v[2];          // [fresh-row break does not fire, fires]
+    int32_t pad_[4];
+};
+static_assert(sizeof(LongVar) == 32 && sizeof(LongMemo) == 128, "LongMemo is one 128-byte line");
+// Snap::lmemo[type * kLongLevels + l]: the walk of a request that excludes exactly the type's first l eligible instances — a model with
+// a copy on the first instance of the order is one request in a few thousand, but a wavefront that holds one runs both the check and
+// the walk, and at 100k requests per launch the slowest wavefront IS the launch (tools/r6/wave_timeline.py)
+constexpr int kLongLevels = 3;
+struct LongCap {  // what lane_decide_r<..., LONG> leaves for build_long_memo_kernel
+    int32_t nsb;  // in: the fresh-row bit to assume
+    int32_t ok;
+    LongMemo m;   // head fields + v[nsb]
+};
 
 struct PlaceArgs {
     const mmp_place_req *reqs;
@@ -1417,7 +1464,8 @@ __device__ __forceinline__ int lane_case_b(const Snap &S, const ResolvedReq &r, 
 }
 
 template <bool VIEW, bool LONG = false>
-__device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, mmp_place_out &o, const BLds Bt = BLds{});
+__device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, mmp_place_out &o, const BLds Bt = BLds{},
+                                             LongCap *lc = nullptr);
 
 template <bool VIEW, bool LONG = false, int FORM = kReq64>
 __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, int d, mmp_place_out &o, const BLds Bt = BLds{},
@@ -1429,8 +1477,10 @@ __device__ __forceinline__ int lane_decide(const Snap &S, const PlaceArgs &A, in
 
 // Bt: the staged case (b) tables of the long kernel (null: case (b) is the wave path's).  The first lane phase (LONG = false)
 // answers kLaneLong for a case (b) decision when they exist, the LONG phase decides it from them.
+// lc (LONG only; commit's build_long_memo_kernel): the walk for a request without exclusions or a caller's entry, the fresh-row bit
+// forced to lc->nsb — returns once the list is known and leaves it there (see LongMemo).
 template <bool VIEW, bool LONG>
-__device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, mmp_place_out &o, const BLds Bt)
+__device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, mmp_place_out &o, const BLds Bt, LongCap *lc)
 {
     PHASE_T0();
     o.chosen = MMP_NONE;
@@ -1532,6 +1582,7 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
             ns_break = f_rem < S.min_space || f_rem < q;
             self_break = e_rem < S.min_space || e_rem < q;
         }
+        if (LONG && lc) ns_break = lc->nsb != 0;
         const int start = bestpos + 1;
         const bool self_in_d = selfpos >= start && selfpos < P && ((dw(selfpos >> 6) >> (selfpos & 63)) & 1ull);
         int end = P;
@@ -1613,7 +1664,7 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
         uint64_t r_lo = 0, r_hi = 0;    // the raw end words clipped to [start, end)
         int n_rlo = 0, pbase = 0;
         int g0 = 0;                     // the number (pc's numbering) of the first candidate bit at or behind `start`
-        if (LONG && is_long) {
+        if (LONG && (is_long || lc)) {  // (lc: the record of a short list is taken by the same formulas — prefix differences hold for any range)
             const size_t row = (size_t)(has_pm ? 1 : 0) * S.T + type;
             const size_t tb = row * (size_t)(W + 1);
             PC = S.pc + tb;
@@ -1655,6 +1706,27 @@ __device__ __forceinline__ int lane_decide_r(const Snap &S, const PlaceArgs &A, 
                 if (bit) hsum -= amx[i] << (e & 63);
             }
             ccount -= __popc(xmask);
+            if (lc) {
+                LongMemo &M = lc->m;
+                M.b_rem = b_rem;
+                M.b_lru = b_lru;
+                M.best_is_full = best_is_full;
+                M.b_rpm = b_rpm;
+                M.best_idx = best_idx;
+                M.has_pm = has_pm;
+                M.best0 = best0;
+                M.bestpos = bestpos;
+                M.e_rpm = e_rpm;
+                M.sbk = self_break;
+                LongVar &V = M.v[lc->nsb ? 1 : 0];
+                V.valid = 1;
+                V.end = end;
+                V.ccount = ccount;
+                V.g0 = g0;
+                V.hsum = hsum;
+                lc->ok = 1;
+                return kLaneDone;
+            }
         } else {
             for (int w = wlo; w <= whi; w++) {
                 const uint64_t v = cand(w);
@@ -2558,6 +2630,246 @@ __device__ __forceinline__ bool memo_try(const Snap &S, const PlaceArgs &A, cons
     return true;
 }
 
+// A resolved request (exclusions merged) against its type's recorded long walk (see LongMemo): true = decided, `o` filled (the caller
+// stores it).  false: one of the request's own positions steers the walk — an exclusion or the caller inside [best0, bestpos], the
+// instance that ends the list excluded (or, with the fresh-row break on, the caller: that scan skips it), the caller's own break rule
+// cutting the list short — or there is no record: lane_decide_r<..., LONG> walks.  Behind the record the steps are the prefix-table
+// phase's own: corrections for the excluded candidates, the rpm rule's three classes, the index-th survivor by one `sel` lookup.
+__device__ __forceinline__ bool long_memo_try(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, mmp_place_out &o)
+{
+    if (r.type < 0 || r.n_excl > kInlineExcl || A.force_wave) {
+        PHASE_WHY(1);
+        return false;
+    }
+    const LongMemo *Mp = S.lmemo + (size_t)r.type * kLongLevels;
+    int64_t b_rem = Mp->b_rem, b_lru = Mp->b_lru;
+    int4 h1 = *reinterpret_cast<const int4 *>(&Mp->best_is_full);  // best_is_full, b_rpm, best_idx, has_pm
+    int4 h2 = *reinterpret_cast<const int4 *>(&Mp->best0);         // best0, bestpos, e_rpm, sbk
+    int4 v0 = *reinterpret_cast<const int4 *>(&Mp->v[0]), v1 = *reinterpret_cast<const int4 *>(&Mp->v[1]);  // valid, end, ccount, g0
+    uint64_t hs0 = Mp->v[0].hsum, hs1 = Mp->v[1].hsum;
+    const int32_t nb1 = Mp[1].best0, nb2 = Mp[2].best0;  // the type's second / third eligible instance (fetched beside the record)
+    auto excluded = [&](int p) {
+        bool x = false;
+#pragma unroll
+        for (int i = 0; i < kInlineExcl; i++) x |= r.excl_pos[i] == p;
+        return x;
+    };
+    // the type's first eligible instance(s) excluded: the record of that many levels down (wave-uniform test: hardly ever)
+    int lvl = 0;
+    if (excluded(h2.x)) lvl = excluded(nb1) ? 2 : 1;
+    if (__ballot(lvl != 0)) {
+        if (lvl != 0) {
+            const LongMemo *Lp = Mp + lvl;
+            b_rem = Lp->b_rem;
+            b_lru = Lp->b_lru;
+            h1 = *reinterpret_cast<const int4 *>(&Lp->best_is_full);
+            h2 = *reinterpret_cast<const int4 *>(&Lp->best0);
+            v0 = *reinterpret_cast<const int4 *>(&Lp->v[0]);
+            v1 = *reinterpret_cast<const int4 *>(&Lp->v[1]);
+            hs0 = Lp->v[0].hsum;
+            hs1 = Lp->v[1].hsum;
+        }
+    }
+    (void)nb2;
+    const int P = S.P, W = S.W;
+    const int best0 = h2.x, bestpos = h2.y;
+    const int selfpos = r.selfpos;
+    const bool favour = (r.flags & MMP_REQ_FAVOUR_SELF) != 0;
+    // The caller IS the best instance (no preference step taken): ABORT_REQUEST with favourSelf (:4891-4895); else its fresh record
+    // replaces the best row in every rule (:4811-4830) — a full caller (fresh record below minSpace) puts the walk into the LRU-window
+    // mode with d1 = 0: no fresh-row break, no count break, its own entry in front of the range: the list of bit 0 where nothing ended
+    // that one either, with the caller's fresh rpm as the best instance's
+    const bool self_best = selfpos >= 0 && selfpos == best0 && best0 == bestpos && (v0.x | v1.x) != 0;
+    if (self_best && favour) {
+        o.chosen = MMP_SELF;
+        o.best = h1.z;
+        o.n_candidates = 0;
+        o.hash = 0;
+        return true;
+    }
+    bool nsb;  // :4913-4922, as lane_decide_r has it
+    if (h1.x) {
+        const int64_t rel = age_of(b_lru, A.now) / 10;
+        const int64_t d1 = jsub64(r.fresh_lru, b_lru);
+        nsb = d1 > 45000LL && d1 > rel;
+    } else
+        nsb = r.f_rem < S.min_space || r.f_rem < (b_rem >> 2);
+    if (self_best) nsb = false;
+    const int4 vh = nsb ? v1 : v0;
+    uint64_t hsum = nsb ? hs1 : hs0;
+    if (!vh.x) {
+        PHASE_WHY(2);
+        return false;
+    }
+    const int end = vh.y, start = bestpos + 1, g0 = vh.w;
+    if (self_best && !(r.f_rem < S.min_space && end == P)) {
+        PHASE_WHY(4);
+        return false;
+    }
+    const int32_t b_rpm = self_best ? r.fresh_rpm : h1.y, best_idx = h1.z, e_rpm = h2.z, f_rpm = r.fresh_rpm;
+    bool hit = self_best || (!(selfpos >= best0 && selfpos <= bestpos) && !(nsb && selfpos == end));
+    bool self_excl = false;
+#pragma unroll
+    for (int i = 0; i < kInlineExcl; i++) {
+        const int e = r.excl_pos[i];
+        hit &= !(e >= best0 && e <= bestpos) && e != end;
+        self_excl |= e == selfpos;
+    }
+    if (!hit) {
+        PHASE_WHY(8);
+        return false;
+    }
+    const size_t row = (size_t)(h1.w ? 1 : 0) * S.T + r.type;
+    const int32_t *SEL = S.sel + row * (size_t)W * 64, *RK = S.rk + row * (size_t)W * 64;
+    int32_t sx[kInlineExcl], rkx[kInlineExcl];
+    uint64_t amx[kInlineExcl];
+    sort_excl(r.excl_pos, sx);
+    // everything the corrections read, and what the caller's own position is to the row, fetched together
+#pragma unroll
+    for (int i = 0; i < kInlineExcl; i++) {
+        const int e = sx[i];
+        const bool in = e >= start && e < end;  // (the padding, INT32_MAX, is not)
+        rkx[i] = in ? RK[e] : -1;
+        amx[i] = in ? S.amul[e >> 6] : 0ull;
+    }
+    const bool s_rng = selfpos >= start && selfpos < P;
+    int32_t srk = RK[s_rng ? selfpos : 0];
+    if (!s_rng) srk = -1;
+    const bool self_in_d = srk >= 0 && !(self_excl && selfpos >= 0);
+    if (self_in_d && h2.w && selfpos < end) {  // the caller's own break ends the list at its position: another list
+        PHASE_WHY(16);
+        return false;
+    }
+    const bool self_in_c = self_in_d && selfpos < end;
+    o.chosen = MMP_NONE;
+    o.best = best_idx;
+    o.n_candidates = 0;
+    o.hash = 0;
+    if (self_in_c && favour) {  // :4931-4933
+        o.chosen = MMP_SELF;
+        return true;
+    }
+    uint32_t xmask = 0;  // slots of sx[] that are distinct candidates inside [start, end)
+#pragma unroll
+    for (int i = 0; i < kInlineExcl; i++) {
+        const int e = sx[i];
+        const bool dup = i > 0 && sx[i - 1] == e;
+        const bool bit = !dup && rkx[i] >= 0;
+        xmask |= (uint32_t)bit << i;
+        if (bit) hsum -= amx[i] << (e & 63);
+    }
+    const int ccount = vh.z - __popc(xmask);
+    int remaining = ccount;
+    bool null0 = false, null_s = false, null_o = false;
+    int n_others = 0;
+    if (ccount >= 2) {  // rpm filter, :4951-4980 (quirks B#2/B#3: three rpm classes)
+        n_others = ccount - 1 - (self_in_c ? 1 : 0);
+        int32_t mn = b_rpm;
+        if (self_in_c && e_rpm < mn) mn = e_rpm;
+        if (n_others > 0 && f_rpm < mn) mn = f_rpm;
+        RpmRule rule;
+        rule.init(age_of(r.last_used, A.now), mn);
+        null0 = rule.nulls(b_rpm);
+        null_s = self_in_c && rule.nulls(e_rpm);
+        null_o = n_others > 0 && rule.nulls(f_rpm);
+        remaining = ccount - (null0 ? 1 : 0) - (null_s ? 1 : 0) - (null_o ? n_others : 0);
+    }
+    const int index = remaining <= 1 ? 0 : (int)(((uint64_t)r.pick * (uint64_t)(uint32_t)remaining) >> 32);
+    int cpos = kNoPos;
+    if (remaining >= 1) {
+        if (null_o) {  // only the best and the self entry can be left, in that order
+            int k = index;
+            if (!null0) {
+                if (k == 0) cpos = bestpos;
+                k--;
+            }
+            if (cpos == kNoPos && self_in_c && !null_s && k == 0) cpos = selfpos;
+        } else {
+            // t = the raw rank of the index-th survivor: every removed entry at or before it pushes it one further (one ascending pass)
+            const int rho_s = null_s ? 1 + srk - g0 : 0;
+            bool self_pending = null_s;
+            int t = index + (null0 ? 1 : 0);
+#pragma unroll
+            for (int i = 0; i < kInlineExcl; i++) {
+                if (self_pending && selfpos < sx[i]) {
+                    if (rho_s <= t) t++;
+                    self_pending = false;
+                }
+                if ((xmask >> i) & 1u) {
+                    if (1 + rkx[i] - g0 <= t) t++;
+                }
+            }
+            if (self_pending && rho_s <= t) t++;
+            cpos = t == 0 ? bestpos : SEL[g0 + t - 1];
+        }
+    }
+    o.n_candidates = ccount;
+    o.hash = (uint32_t)(hsum ^ (hsum >> 32)) ^ ((uint32_t)remaining * 0x9E3779B1u);
+    if (cpos != kNoPos) {
+        o.chosen = S.orig[cpos];
+        if (!favour && cpos == selfpos) o.chosen = MMP_SELF;  // :4989-4991
+    }
+    return true;
+}
+
+// commit (the last blocks of build_sel_memo_kernel): one wavefront per type row, lanes 0 / 1 = the fresh-row bit (see LongMemo); reads
+// the prefix tables, not sel / rk (a request without exclusions looks nothing up in them), so it runs beside their construction
+__device__ __forceinline__ void build_long_memo_body(int t, const Snap &S, LongMemo *__restrict__ out)
+{
+    __shared__ LongCap caps[2 * kLongLevels];
+    const int lane = lane_id();
+    if (lane < 2 * kLongLevels) {
+        const int level = lane >> 1;
+        PlaceArgs A{};
+        ResolvedReq r{};
+        r.type = t;
+        r.selfpos = -1;
+        r.n_late = -1;
+#pragma unroll
+        for (int i = 0; i < kInlineExcl; i++) r.excl_pos[i] = -1;
+#pragma unroll
+        for (int i = 0; i < kLateExtra; i++) r.late_pos[i] = -1;
+        // level l: the type's first l eligible instances excluded
+        bool bad = false;
+        int p = -1;
+        const uint64_t *E = S.elig + (size_t)t * S.W;
+#pragma unroll
+        for (int j = 0; j < kLongLevels - 1; j++) {
+            if (j < level && !bad) {
+                bool far = false;
+                const int q = lane_first([&](int w) { return E[w]; }, p + 1, S.P, far, S.nz, (size_t)t * (size_t)(S.W + 1));
+                if (far || q == kNoPos)
+                    bad = true;
+                else {
+                    r.excl_pos[j] = q;
+                    p = q;
+                }
+            }
+        }
+        r.n_excl = level;
+        LongCap lc{};
+        lc.nsb = lane & 1;
+        if (!bad) {
+            mmp_place_out o;
+            const int code = lane_decide_r<false, true>(S, A, r, o, BLds{}, &lc);
+            if (code != kLaneDone) lc.ok = 0;
+        }
+        caps[lane] = lc;
+    }
+    __syncthreads();
+    if (lane < kLongLevels) {
+        const LongCap &c0 = caps[2 * lane], &c1 = caps[2 * lane + 1];
+        LongMemo M = (c0.ok ? c0 : c1).m;  // the head fields do not depend on the bit
+        M.v[0] = c0.ok ? c0.m.v[0] : LongVar{};
+        M.v[1] = c1.ok ? c1.m.v[1] : LongVar{};
+        if (!c0.ok && !c1.ok) {
+            M = LongMemo{};
+            M.best0 = M.bestpos = kNoPos;  // (never a request's own position)
+        }
+        out[(size_t)t * kLongLevels + lane] = M;
+    }
+}
+
 // NOBAR (the kernels with the shortlist check in front: place_batch_m_kernel, place_batch_c_m_kernel): no workgroup barrier at all —
 // the head windows are read from global memory (a few L1-resident rows) instead of being staged in LDS by the workgroup, and a
 // wavefront keeps the general path's list for itself.  A wavefront whose requests the shortlists all cover then neither waits for
@@ -2587,6 +2899,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
     if (threadIdx.x == 0) fb_n = lr_n = 0;
     const int d = LIST ? d_list : (int)(blockIdx.x * kPlaceBlock + threadIdx.x);
     PHASE_T0();
+    PHASE_ABS(14);
     // The windows are fetched beside the request (they depend on nothing) and parked in LDS while the
     // request -> model row chain is in flight; the barrier below is the one the lists needed anyway.
     const bool use_wins = A.wins != nullptr;  // wave-uniform
@@ -2670,7 +2983,10 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
         int code = kLaneHeadMiss;
         if (WITH_LONG && A.long_first) {  // (wave-uniform) a full cluster: nearly every decision would end in the long phase anyway
             merge_late_extras(r);
-            code = lane_decide_r<false, true>(Sl, A, r, o, Bt);
+            // the type's recorded walk first (LongMemo): a wavefront whose requests it all answers skips the scans
+            const bool rec = S.lmemo != nullptr && long_memo_try(S, A, r, o);  // (S.lmemo: wave-uniform)
+            code = kLaneDone;
+            if (!rec) code = lane_decide_r<false, true>(Sl, A, r, o, Bt);
         } else {
             if (use_wins)
                 code = NOBAR ? lane_decide_win<false, false, 64>(S, A, r, Ws, s_scr + lane_id(), o)
@@ -2715,6 +3031,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
         }
         PHASE(10);  // the general path
         PHASE_COUNT(11, 1);  // wavefronts
+        PHASE_ABS(15);
         announce_done(DoneFlag{A.done_flag, done_blocks, A.done_seq});  // (latency-slot launches of the barrier-free long kernel; a no-op otherwise)
         return;
     }
@@ -2748,6 +3065,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
     }
     PHASE(10);  // long phase + wave path
     PHASE_COUNT(11, 1);  // wavefronts
+    PHASE_ABS(15);
     announce_done(DoneFlag{A.done_flag, done_blocks, A.done_seq});
     if (LIST) __syncthreads();  // the next call resets the lists
 }
@@ -2887,13 +3205,17 @@ __device__ __forceinline__ void build_memo_body(int t, const Snap &S, const Type
     memo[t].rk64[lane] = (int16_t)near_r[lane];
 }
 __global__ __launch_bounds__(64) void build_sel_memo_kernel(Snap S, int32_t *__restrict__ sel, int32_t *__restrict__ rk, const TypeWin *__restrict__ wins,
-                                                            TypeMemo *__restrict__ memo, int32_t *__restrict__ cand, int16_t *__restrict__ memo_rk)
+                                                            TypeMemo *__restrict__ memo, int32_t *__restrict__ cand, int16_t *__restrict__ memo_rk,
+                                                            LongMemo *__restrict__ lmemo)
 {
     const int n_sel = sel ? 2 * S.T * S.W : 0;  // (sel == null: the inverse tables are not built for this snapshot, kSelMaxBytes)
+    const int n_memo = S.T < kWinLds ? S.T : kWinLds;
     if ((int)blockIdx.x < n_sel)
         build_sel_body((int)blockIdx.x, S, sel, rk);
-    else
+    else if ((int)blockIdx.x < n_sel + n_memo)
         build_memo_body((int)blockIdx.x - n_sel, S, wins, memo, cand, memo_rk);
+    else
+        build_long_memo_body((int)blockIdx.x - n_sel - n_memo, S, lmemo);  // (launched with T more blocks when lmemo != null)
 }
 
 // The window kernels with the recorded shortlists in front (place_block<..., MEMO, NOBAR>; see TypeMemo): a wavefront whose 64 requests
@@ -2949,6 +3271,21 @@ constexpr int kRestCntStride = 32;  // ints between two counters: a 128-byte lin
 __host__ __device__ constexpr int rest_list_cap(int n_words) { return ((n_words + kRestLists - 1) / kRestLists) * 64; }
 __host__ __device__ constexpr size_t rest_buffer_ints(int n_words) { return (size_t)kRestLists * kRestCntStride + (size_t)kRestLists * rest_list_cap(n_words); }
 
+// the undecided requests of this wavefront (`todo` lanes): room in its list — ONE returning atomic — then their indices
+__device__ __forceinline__ void rest_append(int32_t *__restrict__ rest, int32_t cap, int d, bool todo)
+{
+    const uint64_t mk = __ballot(todo);
+    if (mk && rest) {  // (wave-uniform; rest == null: diagnostics, nobody will decide them)
+        const int l = __builtin_amdgcn_readfirstlane(d >> 6) & (kRestLists - 1);
+        const int first = __ffsll((unsigned long long)mk) - 1;
+        int base = 0;
+        if (lane_id() == first)
+            base = __hip_atomic_fetch_add(rest + l * kRestCntStride, __popcll((unsigned long long)mk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        base = readlane_i32(base, first);
+        if (todo) rest[kRestLists * kRestCntStride + (size_t)l * cap + base + __popcll((unsigned long long)(mk & ((1ull << lane_id()) - 1ull)))] = d;
+    }
+}
+
 template <int FORM>
 __device__ __forceinline__ void place_memo_body(const Snap &S, const PlaceArgs &A, int32_t *__restrict__ rest, int32_t cap, const mmp_place_caller &C,
                                                 unsigned char *smem)
@@ -2994,16 +3331,7 @@ __device__ __forceinline__ void place_memo_body(const Snap &S, const PlaceArgs &
 #else
     if (live) todo = !memo_try<FORM>(S, A, rq, d, reinterpret_cast<const TypeMemo *>(mine));
 #endif
-    const uint64_t mk = __ballot(todo);
-    if (mk && rest) {  // (wave-uniform; rest == null: diagnostics, nobody will decide them) the undecided requests of this wavefront: room in its list, then their indices
-        const int l = __builtin_amdgcn_readfirstlane(d >> 6) & (kRestLists - 1);
-        const int first = __ffsll((unsigned long long)mk) - 1;
-        int base = 0;
-        if (lane_id() == first)
-            base = __hip_atomic_fetch_add(rest + l * kRestCntStride, __popcll((unsigned long long)mk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        base = readlane_i32(base, first);
-        if (todo) rest[kRestLists * kRestCntStride + (size_t)l * cap + base + __popcll((unsigned long long)(mk & ((1ull << lane_id()) - 1ull)))] = d;
-    }
+    rest_append(rest, cap, d, todo);
 }
 __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void place_memo_kernel(Snap S, PlaceArgs A, int32_t *__restrict__ rest, int32_t cap)
 {
@@ -3019,7 +3347,7 @@ __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(8, 
 
 // `report` (may be null): workgroup 0 leaves {undecided requests, n} there (pinned host memory: the host reads the pair some launches
 // later, never waits for it)
-template <int FORM>
+template <int FORM, bool WITH_LONG = false>
 __device__ __forceinline__ void place_tail_body(const Snap &S, const PlaceArgs &A, int32_t wpad, unsigned char *smem, int32_t *__restrict__ rest, int32_t cap,
                                                 int32_t *report, const mmp_place_caller &C)
 {
@@ -3057,7 +3385,7 @@ __device__ __forceinline__ void place_tail_body(const Snap &S, const PlaceArgs &
             d = rest[kRestLists * kRestCntStride + (size_t)(g + k * G) * cap + (i - t_cnt[k])];
         }
         PHASE(14);  // (tail) this pass's entries read
-        place_block<false, FORM, false, false, true>(S, A, wpad, smem, nullptr, C, d);
+        place_block<WITH_LONG, FORM, false, false, true>(S, A, wpad, smem, nullptr, C, d);
     }
     if (tid < mine) rest[(g + tid * G) * kRestCntStride] = 0;  // for the stream's next batch (ordered behind this launch)
 }
@@ -3077,6 +3405,69 @@ __global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(MMP
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     place_tail_body<kReqC>(S, A, wpad, smem, rest, cap, report, C);
 }
+
+// ---- the split form on a full cluster (round 6): the recorded long walks in a launch of their own ------------------------------------
+// place_batch_long_kernel carries the record check (long_memo_try) AND the walk it replaces: 139 VGPRs, three wavefronts per SIMD, for
+// requests of which one in a hundred thousand needs the walk.  From kLongSplitFrom requests on the check runs alone — request ->
+// {registry row with the model's positions, caller position, late exclusions} -> record -> rk / amul lookups -> sel -> orig — and leaves
+// what it cannot answer in the stream's lists for place_long_tail_kernel (place_block<WITH_LONG, ..., LIST>: the walk, case (b), the
+// general path), exactly as place_memo_kernel / place_tail_kernel do for the head windows.
+template <int FORM>
+__device__ __forceinline__ void place_long_memo_body(const Snap &S, const PlaceArgs &A, int32_t *__restrict__ rest, int32_t cap, const mmp_place_caller &C)
+{
+    const int d = blockIdx.x * kPlaceBlock + threadIdx.x;
+    bool live = d < A.n;
+    mmp_place_req rq{};
+    if (live) rq = fetch_req<FORM>(A, C, d);
+    if (A.extra_bound != 0) {  // (wave-uniform) bounded calls: as place_block answers them
+        if (live && bad_extra_range(A, rq)) {
+            live = false;
+            mmp_place_out bo;
+            bo.chosen = MMP_NONE;
+            bo.best = MMP_BAD_REQUEST;
+            bo.n_candidates = 0;
+            bo.hash = 0;
+            A.outs[d] = bo;
+        }
+    }
+    bool todo = false;
+    if (live) {
+        ResolvedReq r = resolve_req<false, true>(S, A, rq);
+        merge_late_extras(r);
+        mmp_place_out o;
+        if (long_memo_try(S, A, r, o))
+            A.outs[d] = o;
+        else
+            todo = true;
+    }
+    rest_append(rest, cap, d, todo);
+}
+#ifndef MMP_LONG_MEMO_EU
+#define MMP_LONG_MEMO_EU 6
+#endif
+__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(MMP_LONG_MEMO_EU, MMP_LONG_MEMO_EU))) void place_long_memo_kernel(Snap S, PlaceArgs A, int32_t *__restrict__ rest, int32_t cap)
+{
+    place_long_memo_body<kReq64>(S, A, rest, cap, mmp_place_caller{});
+}
+__global__ __launch_bounds__(kPlaceBlock) __attribute__((amdgpu_waves_per_eu(MMP_LONG_MEMO_EU, MMP_LONG_MEMO_EU))) void place_long_memo_c_kernel(Snap S, PlaceArgs A, int32_t *__restrict__ rest, int32_t cap,
+                                                                                                                          mmp_place_caller C)
+{
+    place_long_memo_body<kReqC>(S, A, rest, cap, C);
+}
+__global__ __launch_bounds__(kPlaceBlock) void place_long_tail_kernel(Snap S, PlaceArgs A, int32_t wpad, int32_t *__restrict__ rest, int32_t cap, int32_t *report)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    place_tail_body<kReq64, true>(S, A, wpad, smem, rest, cap, report, mmp_place_caller{});
+}
+__global__ __launch_bounds__(kPlaceBlock) void place_long_tail_c_kernel(Snap S, PlaceArgs A, int32_t wpad, int32_t *__restrict__ rest, int32_t cap, int32_t *report, mmp_place_caller C)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    place_tail_body<kReqC, true>(S, A, wpad, smem, rest, cap, report, C);
+}
+// Requests from which a full-cluster batch is split: NEVER by default.  Measured (tools/r6/long_split_sweep.sh, profiles/r6/long_records.txt,
+// C3 full cluster, 800k requests): the first launch alone 33.1 us against 40.3 us for the one-launch kernel, but its tail — the walk,
+// 194 VGPRs — is 14.8 us: 47.9 us per call on one stream, 30.2 us on four (one launch: 30.1).  MMP_LONG_SPLIT_FROM=n switches it on.
+constexpr int kLongSplitFrom = INT32_MAX;
 
 __global__ __launch_bounds__(kPlaceBlock) void place_batch_long_c_kernel(Snap S, PlaceArgs A, int32_t wpad, mmp_place_caller C)
 {

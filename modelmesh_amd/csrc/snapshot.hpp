@@ -68,6 +68,9 @@ struct Snap {
     const struct TypeMemo *memo;
     const int32_t *memo_cand;
     const int16_t *memo_rk;
+    // The recorded walks of the long shortlists (round 6; place_kernel.hpp: LongMemo), a row per type; null: not built (no inverse
+    // tables, shard views, MMP_NO_LONG_MEMO=1)
+    const struct LongMemo *lmemo;
 };
 
 // count >= 10 is a fixed clause of the shortlist's count break (MM.java:4925-4926); the other clause,

@@ -300,6 +300,13 @@ class Solver:
         self._ck(self.lib.mmp_shortlists(self.h, ptr(out), len(out), C.byref(n)))
         return out[: n.value].copy()
 
+    def long_shortlists(self, cap_types: int = 256) -> np.ndarray:
+        """The published snapshot's recorded walks of the long shortlists (mmp_long_shortlists): rows [2 * type + bit]."""
+        out = np.zeros(2 * cap_types, dtype=np.dtype([("valid", "<i4"), ("lo", "<i4"), ("hi", "<i4"), ("n_candidates", "<i4")]))
+        n = C.c_int32(0)
+        self._ck(self.lib.mmp_long_shortlists(self.h, ptr(out), len(out), C.byref(n)))
+        return out[: min(n.value, len(out))].copy()
+
     def split_batches(self):
         """(batches this context decided as two launches — shortlist check + tail —, whether that is switched off): mmp_split_batches."""
         n, off = C.c_int64(0), C.c_int32(0)

@@ -60,7 +60,7 @@ def test_veneer_covers_the_whole_c_abi():
                 "mmp_shard_group_set_exchange"}  # the host-driven exchange protocol / a C callback: not for a JVM
     not_for_jvm = {n for n in abi if n.endswith("_dev") or n.endswith("_dev2")} | stepwise | {
         "mmp_stream_retire", "mmp_issue_threads", "mmp_issue_flush", "mmp_resident_stats", "mmp_shard_wait",
-        "mmp_backend", "mmp_sync", "mmp_pods_get", "mmp_models_get", "mmp_shortlists", "mmp_split_batches"}
+        "mmp_backend", "mmp_sync", "mmp_pods_get", "mmp_models_get", "mmp_shortlists", "mmp_long_shortlists", "mmp_split_batches"}
     missing = abi - used - not_for_jvm
     assert not missing, sorted(missing)
 
