@@ -103,7 +103,9 @@ __device__ __forceinline__ void single_place_wave(const Snap &S, PlaceArgs A, in
         int code = kLaneHeadMiss;
         if (A.long_first) {
             merge_late_extras(r);
-            code = lane_decide_r<false, true>(S, A, r, o, BLds{});
+            // the type's recorded walk first (place_kernel.hpp: LongMemo): half the dependent levels of the walk itself
+            code = kLaneDone;
+            if (!(S.lmemo != nullptr && long_memo_try(S, A, r, o))) code = lane_decide_r<false, true>(S, A, r, o, BLds{});
         } else {
             if (use_wins) code = lane_decide_win(S, A, r, s_wins, s_scr, o);
             if (code == kLaneHeadMiss) {  // straight to the instantiation with the prefix-table phase: occupancy is nothing here, and a

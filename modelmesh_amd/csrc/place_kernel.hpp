@@ -2637,17 +2637,17 @@ __device__ __forceinline__ bool memo_try(const Snap &S, const PlaceArgs &A, cons
 // phase's own: corrections for the excluded candidates, the rpm rule's three classes, the index-th survivor by one `sel` lookup.
 __device__ __forceinline__ bool long_memo_try(const Snap &S, const PlaceArgs &A, const ResolvedReq &r, mmp_place_out &o)
 {
-    if (r.type < 0 || r.n_excl > kInlineExcl || A.force_wave) {
-        PHASE_WHY(1);
-        return false;
-    }
-    const LongMemo *Mp = S.lmemo + (size_t)r.type * kLongLevels;
+    bool miss = r.type < 0 || r.n_excl > kInlineExcl || A.force_wave;
+#ifdef MMP_PHASE_CLOCK
+    if (miss) PHASE_WHY(1);
+#endif
+    const LongMemo *Mp = S.lmemo + (size_t)(r.type < 0 ? 0 : r.type) * kLongLevels;
     int64_t b_rem = Mp->b_rem, b_lru = Mp->b_lru;
     int4 h1 = *reinterpret_cast<const int4 *>(&Mp->best_is_full);  // best_is_full, b_rpm, best_idx, has_pm
     int4 h2 = *reinterpret_cast<const int4 *>(&Mp->best0);         // best0, bestpos, e_rpm, sbk
     int4 v0 = *reinterpret_cast<const int4 *>(&Mp->v[0]), v1 = *reinterpret_cast<const int4 *>(&Mp->v[1]);  // valid, end, ccount, g0
     uint64_t hs0 = Mp->v[0].hsum, hs1 = Mp->v[1].hsum;
-    const int32_t nb1 = Mp[1].best0, nb2 = Mp[2].best0;  // the type's second / third eligible instance (fetched beside the record)
+    const int32_t nb1 = Mp[1].best0;  // the type's second eligible instance (fetched beside the record)
     auto excluded = [&](int p) {
         bool x = false;
 #pragma unroll
@@ -2670,7 +2670,6 @@ __device__ __forceinline__ bool long_memo_try(const Snap &S, const PlaceArgs &A,
             hs1 = Lp->v[1].hsum;
         }
     }
-    (void)nb2;
     const int P = S.P, W = S.W;
     const int best0 = h2.x, bestpos = h2.y;
     const int selfpos = r.selfpos;
@@ -2680,13 +2679,7 @@ __device__ __forceinline__ bool long_memo_try(const Snap &S, const PlaceArgs &A,
     // mode with d1 = 0: no fresh-row break, no count break, its own entry in front of the range: the list of bit 0 where nothing ended
     // that one either, with the caller's fresh rpm as the best instance's
     const bool self_best = selfpos >= 0 && selfpos == best0 && best0 == bestpos && (v0.x | v1.x) != 0;
-    if (self_best && favour) {
-        o.chosen = MMP_SELF;
-        o.best = h1.z;
-        o.n_candidates = 0;
-        o.hash = 0;
-        return true;
-    }
+    const bool abort_now = !miss && self_best && favour;
     bool nsb;  // :4913-4922, as lane_decide_r has it
     if (h1.x) {
         const int64_t rel = age_of(b_lru, A.now) / 10;
@@ -2697,27 +2690,46 @@ __device__ __forceinline__ bool long_memo_try(const Snap &S, const PlaceArgs &A,
     if (self_best) nsb = false;
     const int4 vh = nsb ? v1 : v0;
     uint64_t hsum = nsb ? hs1 : hs0;
-    if (!vh.x) {
-        PHASE_WHY(2);
-        return false;
-    }
     const int end = vh.y, start = bestpos + 1, g0 = vh.w;
-    if (self_best && !(r.f_rem < S.min_space && end == P)) {
-        PHASE_WHY(4);
-        return false;
-    }
     const int32_t b_rpm = self_best ? r.fresh_rpm : h1.y, best_idx = h1.z, e_rpm = h2.z, f_rpm = r.fresh_rpm;
-    bool hit = self_best || (!(selfpos >= best0 && selfpos <= bestpos) && !(nsb && selfpos == end));
     bool self_excl = false;
+    if (!abort_now) {
+        if (!vh.x) {
+            if (!miss) PHASE_WHY(2);
+            miss = true;
+        }
+        if (self_best && !(r.f_rem < S.min_space && end == P)) {
+            if (!miss) PHASE_WHY(4);
+            miss = true;
+        }
+        bool hit = self_best || (!(selfpos >= best0 && selfpos <= bestpos) && !(nsb && selfpos == end));
 #pragma unroll
-    for (int i = 0; i < kInlineExcl; i++) {
-        const int e = r.excl_pos[i];
-        hit &= !(e >= best0 && e <= bestpos) && e != end;
-        self_excl |= e == selfpos;
+        for (int i = 0; i < kInlineExcl; i++) {
+            const int e = r.excl_pos[i];
+            hit &= !(e >= best0 && e <= bestpos) && e != end;
+            self_excl |= e == selfpos;
+        }
+        if (!hit) {
+            if (!miss) PHASE_WHY(8);
+            miss = true;
+        }
+        // the caller's own break rule (a type-level fact, `sbk`) would end the list at the caller's position if that is a candidate:
+        // another list.  (Whether it is a candidate is one more lookup; such types are left to the walk for every caller in range.)
+        if (h2.w && selfpos >= start && selfpos < end && !self_excl) {
+            if (!miss) PHASE_WHY(16);
+            miss = true;
+        }
     }
-    if (!hit) {
-        PHASE_WHY(8);
-        return false;
+    // (Measured and not kept: the whole wavefront walking as soon as ONE of its requests must — a walk with 64 lanes active is slower
+    // than the check plus a walk with one: the slowest wavefront of a 100k launch 12.3 -> 13.8 us, and that wavefront IS the launch;
+    // 800k requests 40.3 -> 43.1 us.  tools/r6/wave_timeline.py, profiles/r6/long_records.txt)
+    if (miss) return false;
+    if (abort_now) {
+        o.chosen = MMP_SELF;
+        o.best = h1.z;
+        o.n_candidates = 0;
+        o.hash = 0;
+        return true;
     }
     const size_t row = (size_t)(h1.w ? 1 : 0) * S.T + r.type;
     const int32_t *SEL = S.sel + row * (size_t)W * 64, *RK = S.rk + row * (size_t)W * 64;
@@ -2736,10 +2748,6 @@ __device__ __forceinline__ bool long_memo_try(const Snap &S, const PlaceArgs &A,
     int32_t srk = RK[s_rng ? selfpos : 0];
     if (!s_rng) srk = -1;
     const bool self_in_d = srk >= 0 && !(self_excl && selfpos >= 0);
-    if (self_in_d && h2.w && selfpos < end) {  // the caller's own break ends the list at its position: another list
-        PHASE_WHY(16);
-        return false;
-    }
     const bool self_in_c = self_in_d && selfpos < end;
     o.chosen = MMP_NONE;
     o.best = best_idx;

@@ -77,6 +77,10 @@ def test_recorded_long_walks_next_to_requests_that_steer_the_walk(seed, monkeypa
         got = s.place(reqs, extra, fleet.now)
         assert_same_decisions(fleet, reqs, got, want)
         assert s.split_batches()[0] == 0
+        # one request per call (the single-decision kernel reads the same records), the rewritten requests among them
+        for i in list(range(40)) + [int(j) for j in np.nonzero(reqs["n_extra"] > 0)[0][:80]]:
+            one = s.place(reqs[i:i + 1], extra, fleet.now)
+            assert_same_decisions(fleet, reqs[i:i + 1], one, want[i:i + 1])
     finally:
         s.close()
     # the same batch as two launches: the records alone, then the walk for what they leave (place_long_memo_kernel + place_long_tail_kernel)
