@@ -36,7 +36,7 @@ python tools/pmc_summary.py /tmp/p_C3_800k/f /tmp/p_C3_800k/w place_tail_kernel 
 MMP_NO_SPLIT=1 profile_one C3_800k_one_launch place_batch_m_kernel --workload C3
 profile_one C3_100k place_batch_kernel --workload C3 --decisions-per-step 100000
 profile_one C3_full_cluster_100k place_batch_long_kernel --workload C3 --decisions-per-step 100000 --full-cluster
-profile_one C3_full_cluster_800k place_batch_long4_kernel --workload C3 --full-cluster   # (launches of >= 196 608 decisions take the 4-wavefront instantiation)
+profile_one C3_full_cluster_800k place_batch_long_kernel --workload C3 --full-cluster   # (with the recorded long walks the barrier-free instantiation runs at every size)
 [[ "${PROFILE_WORKLOADS:-C3 C4}" == *C4* ]] && profile_one C4 place_memo_kernel --workload C4
 
 # the timed region's own shape — four streams, a hardware queue each — under the kernel trace (VERDICT r5 missing 6: ms_per_step below the
@@ -85,7 +85,12 @@ timeout 300 python tools/case_b_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/case_
 # ---- round 6 ----
 timeout 600 bash tools/r6/seam_tail.sh > /dev/null 2>&1; cp gpurun_out/r6_seam/seam_tail_pinning.txt $OUT/ 2>/dev/null
 SWEEP_ONLY=0,1,2 SWEEP_K=200 GPU_MAX_HW_QUEUES=8 timeout 600 python tools/r6/split_sweep.py 400000 800000 1600000 2>&1 | grep -v amdgpu.ids > $OUT/split_sweep_rows.txt; cat $OUT/split_sweep_rows.txt
-if [ -f modelmesh_amd/lib/libmmplace_phase.so ]; then timeout 300 python tools/r6/tail_clock.py 40 2>&1 | grep -v amdgpu.ids > $OUT/tail_clock.txt; fi
+if [ -f modelmesh_amd/lib/libmmplace_phase.so ]; then
+  timeout 300 python tools/r6/tail_clock.py 40 2>&1 | grep -v amdgpu.ids > $OUT/tail_clock.txt
+  # when the wavefronts of a 100k launch start and end: the full cluster with / without the recorded long walks, C3
+  (for e in X=1 MMP_NO_LONG_MEMO=1; do echo "== full cluster $e"; env $e MMP_PHASE_FULL=1 timeout 300 python tools/r6/wave_timeline.py 2>&1 | grep -v amdgpu.ids; done
+   echo "== C3"; timeout 300 python tools/r6/wave_timeline.py 2>&1 | grep -v amdgpu.ids) > $OUT/wave_timeline.txt; cat $OUT/wave_timeline.txt
+fi
 # ---- round 5 ----
 # the single-caller request form against the same decisions as 64-byte rows (launch time, C3 and the full cluster); launch time against the
 # number of decisions per launch around the chip's rounds; the four n = 1 seam calls from a C++ host
