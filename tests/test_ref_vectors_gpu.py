@@ -36,13 +36,15 @@ def test_hip_order_and_load_targets_equal_the_reference_text(ref):
 
 
 @pytest.mark.parametrize("env", [{}, {"MMP_LONG_MODE": "1"}, {"MMP_FORCE_WAVE": "1"}, {"MMP_MEMO_FROM": "0", "MMP_NO_SPLIT": "1"},
-                                 {"MMP_MEMO_FROM": "0", "MMP_SPLIT_FROM": "0"}],
+                                 {"MMP_MEMO_FROM": "0", "MMP_SPLIT_FROM": "0"}, {"MMP_NO_LONG_MEMO": "1"}, {"MMP_LONG_SPLIT_FROM": "0"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()) or "default")
 def test_hip_single_caller_form_equals_the_reference_text(ref, env, monkeypatch):
     """mmp_place_batch_c (the caller's side once per call, 24-byte requests) on the batches of ONE calling instance the
     reference's own getNext text decided — through the kernels the library picks, the prefix-table kernels forced on, the
     wave path alone, and the per-type shortlists checked first for batches of every size, in both forms: in front of the lane phase
-    of the same kernel (MMP_MEMO_FROM=0, MMP_NO_SPLIT=1) and as a launch of its own with a tail launch behind it (MMP_SPLIT_FROM=0)."""
+    of the same kernel (MMP_MEMO_FROM=0, MMP_NO_SPLIT=1) and as a launch of its own with a tail launch behind it (MMP_SPLIT_FROM=0);
+    the full-cluster case without the recorded long walks (MMP_NO_LONG_MEMO=1) and with them in a launch of their own
+    (MMP_LONG_SPLIT_FROM=0: place_long_memo_c_kernel + place_long_tail_c_kernel)."""
     from modelmesh_amd._lib import split_caller
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -63,7 +65,9 @@ def test_hip_single_caller_form_equals_the_reference_text(ref, env, monkeypatch)
 @pytest.mark.parametrize("env", [{"MMP_LONG_MODE": "1"}, {"MMP_LONG_MODE": "0"}, {"MMP_NO_CASEB": "1"}, {"MMP_NO_LONG_LDS": "1"},
                                  {"MMP_FORCE_WAVE": "1"}, {"MMP_LONG_MODE": "0", "MMP_MEMO_FROM": "0", "MMP_NO_SPLIT": "1"},
                                  {"MMP_LONG_MODE": "0", "MMP_MEMO_FROM": "0", "MMP_SPLIT_FROM": "0"},
-                                 {"MMP_LONG_MODE": "0", "MMP_MEMO_FROM": "0", "MMP_SPLIT_FROM": "0", "MMP_TAIL_BLOCKS": "5"}],
+                                 {"MMP_LONG_MODE": "0", "MMP_MEMO_FROM": "0", "MMP_SPLIT_FROM": "0", "MMP_TAIL_BLOCKS": "5"},
+                                 {"MMP_NO_LONG_MEMO": "1"}, {"MMP_LONG_SPLIT_FROM": "0"}, {"MMP_LONG_SPLIT_FROM": "0", "MMP_TAIL_BLOCKS": "5"},
+                                 {"MMP_LONG_DENSE_FROM": "0"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_every_device_path_equals_the_reference_text_on_the_bench_configurations(ref, env, monkeypatch):
     """C3 / C3 with every instance full / C3 with sparse types / C4 (tests/ref_fleets.py:big_place_cases) through each path the
@@ -72,7 +76,9 @@ def test_every_device_path_equals_the_reference_text_on_the_bench_configurations
     wave-per-decision path alone (MMP_FORCE_WAVE=1; the full-cluster case there on a sample: whole-table shortlists take ~3 us
     each on it), and the per-type shortlists checked first — in front of the lane phase of the same kernel (MMP_MEMO_FROM=0,
     MMP_NO_SPLIT=1: place_batch_m_kernel) and split into the check's own launch + a tail launch (MMP_SPLIT_FROM=0: place_memo_kernel +
-    place_tail_kernel, 16 and 5 tail workgroups) — all equal to what the reference's own getNext text decided."""
+    place_tail_kernel, 16 and 5 tail workgroups); the full cluster without the recorded long walks (MMP_NO_LONG_MEMO=1), with them in
+    a launch of their own (MMP_LONG_SPLIT_FROM=0: place_long_memo_kernel + place_long_tail_kernel) and inside the 4-wavefront
+    instantiation (MMP_LONG_DENSE_FROM=0) — all equal to what the reference's own getNext text decided."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     for name, fleet, ids, reqs, extra in rf.big_place_cases():
