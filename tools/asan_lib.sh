@@ -46,7 +46,7 @@ run() {
   # binds /opt/rocm's itself (MMP_NO_TORCH_PRELOAD=1) and the suites that need torch tensors stay with stress.cc.
   export MMP_NO_TORCH_PRELOAD=1
   echo "== pytest, tsan"
-  MMP_LIB_PATH=$PWD/$V/libmmplace_tsan.so LD_PRELOAD=$RT/libclang_rt.tsan-x86_64.so timeout 2400 setarch -R python -m pytest -p no:cacheprovider tests/test_resident_gpu.py tests/test_delta_commit_gpu.py tests/test_churn_gpu.py tests/test_registry_upsert_gpu.py tests/test_miss_gpu.py tests/test_route_gpu.py tests/test_cache_replay_gpu.py tests/test_shortlist_memo_gpu.py -m gpu -q > $OUT/pytest_tsan.log 2>&1
+  MMP_LIB_PATH=$PWD/$V/libmmplace_tsan.so LD_PRELOAD=$RT/libclang_rt.tsan-x86_64.so timeout 2400 setarch -R python -m pytest -p no:cacheprovider tests/test_resident_gpu.py tests/test_delta_commit_gpu.py tests/test_churn_gpu.py tests/test_registry_upsert_gpu.py tests/test_miss_gpu.py tests/test_route_gpu.py tests/test_cache_replay_gpu.py tests/test_shortlist_memo_gpu.py tests/test_long_memo_gpu.py -m gpu -q > $OUT/pytest_tsan.log 2>&1
   echo "exit $?" >> $OUT/pytest_tsan.log; tail -3 $OUT/pytest_tsan.log; grep -c "WARNING: ThreadSanitizer" $OUT/pytest_tsan.log
 }
 case ${1:-build} in
