@@ -152,6 +152,10 @@ def test_null_pointers_and_negative_counts_are_refused(ctx):
     assert L.mmp_get_order(s.h, null, C.byref(n_out)) == EINVAL
     assert L.mmp_shortlists(s.h, null, 4, C.byref(n_out)) == EINVAL
     assert L.mmp_shortlists(s.h, null, -4, C.byref(n_out)) == EINVAL
+    assert L.mmp_long_shortlists(s.h, null, 4, C.byref(n_out)) == EINVAL
+    assert L.mmp_long_shortlists(s.h, null, -4, C.byref(n_out)) == EINVAL
+    assert L.mmp_long_shortlists(s.h, null, 0, None) == EINVAL
+    assert L.mmp_long_shortlists(None, null, 0, C.byref(n_out)) == EINVAL
     assert L.mmp_split_batches(None, None, None) == EINVAL
     assert L.mmp_cluster_stats(s.h, null) == EINVAL
     assert L.mmp_snapshot_commit(None) == EINVAL
