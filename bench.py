@@ -1133,13 +1133,15 @@ def secondary_kernels_leg(fleet, solver, device: int, workload: str = "C3", reps
             live = np.ones(P, np.uint8)
             pb = sum(len(v) for v in pv)
             timed("ingest_pods_kernel", lambda: js.ingest_pods_json(pv, np.arange(P, dtype=np.int32), live),
-                  pb + 64 * P, pb, "JSON bytes", "InstanceRecord JSON read once + 64 B row written", s=js)
+                  pb + 64 * P, pb, "JSON bytes", "InstanceRecord JSON read once + 64 B row written; call_wall_ms is mostly the Python "
+                  "packer in front of the C call (solver.py:_pack joins the values into one blob), not the library", s=js)
             js.load_type_names(["NLCLASSIFIER"] + ["type-%d" % t for t in range(1, max(wf.n_types, 1))], 0)
             mb = sum(len(v) for v in mv)
             timed("ingest_models_kernel + rocprim scan + compact_entries_kernel", lambda: js.ingest_models_json(mv),
                   mb + 24 * wf.n_models + 36 * len(wf.ent_pod), mb, "JSON bytes",
                   "ModelRecord JSON read once + rows written + entries parked, read back and written to the CSR "
-                  f"arrays (12 B x 3 per entry); {wf.n_models} of the {M} registry values", s=js)
+                  f"arrays (12 B x 3 per entry); {wf.n_models} of the {M} registry values; call_wall_ms is mostly the Python packer "
+                  "in front of the C call (solver.py:_pack)", s=js)
         finally:
             js.close()
     finally:
