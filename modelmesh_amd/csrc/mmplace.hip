@@ -683,7 +683,6 @@ int place_launch(mmp_ctx *c, const void *d_reqs, int32_t n, const void *d_extra,
             size_t lds_memo = (size_t)kPlaceWaves * memo_stage_bytes(c->snap.T);  // a copy of the types' records per wavefront
             lds_memo = std::max(lds_memo, (size_t)c->memo_lds_min);
             if (c->split_notail) words = nullptr;  // (diagnostics: the undecided requests are not even recorded)
-            if (getenv("MMP_SPLIT_NOREPORT")) report = nullptr;  // (experiment)
             if (caller) {
                 hipLaunchKernelGGL(place_memo_c_kernel, dim3(grid), dim3(kPlaceBlock), lds_memo, st, c->snap, A, words, cap, *caller);
                 if (!c->split_notail)
