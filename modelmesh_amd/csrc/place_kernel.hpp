@@ -2410,6 +2410,18 @@ __host__ __device__ constexpr size_t long_tables_bytes(int T, int W) { return (s
 // memory: true = decided, the result row written.  false: the request's own positions would change the walk itself (or: more
 // exclusions than the check sees, no recorded list for the type) — the ordinary path decides.
 // `rows`: the snapshot's records — S.memo, or the wavefront's copy of it in LDS.
+// The result row of a request the check decides, as a NON-TEMPORAL 16-byte store: nobody on the device reads the rows again, and 12.8 MB
+// of them per 800k batch otherwise take lines of L2 from the tables every request gathers from.  Measured (tools/r6/exp30.sh, one visit,
+// alternating builds): the first launch alone 19.06 -> 18.36 us per 800k rows, a split call on four streams 13.12 -> 12.2 us (61 -> 65.5 G
+// decisions/s).  The same for the request LOADS is a loss (21.8 / 17.4 us): they are read once, but in 64-byte pieces a lane.  The lane
+// phase of place_block stores its rows the same way (800k rows through place_batch_kernel 25.6 -> 24.6 us, the full cluster 41.8 -> 40.8 us,
+// 100k launches unchanged: tools/r6/exp31.sh).
+__device__ __forceinline__ void store_out_streaming(mmp_place_out *p, const mmp_place_out &o)
+{
+    typedef int v4i_ __attribute__((ext_vector_type(4)));
+    static_assert(sizeof(mmp_place_out) == 16, "one 16-byte store");
+    __builtin_nontemporal_store(*reinterpret_cast<const v4i_ *>(&o), reinterpret_cast<v4i_ *>(p));
+}
 template <int FORM>
 __device__ __forceinline__ bool memo_try(const Snap &S, const PlaceArgs &A, const mmp_place_req &rq, int d, const TypeMemo *rows)
 {
@@ -2576,7 +2588,7 @@ __device__ __forceinline__ bool memo_try(const Snap &S, const PlaceArgs &A, cons
         o.chosen = MMP_SELF;
         o.n_candidates = 0;
         o.hash = 0;
-        A.outs[d] = o;
+        store_out_streaming(A.outs + d, o);
         return true;
     }
     // rpm filter, :4951-4980: the best instance, the caller's entry, "the others" (the fresh rpm, quirks B#2/B#3)
@@ -2626,7 +2638,7 @@ __device__ __forceinline__ bool memo_try(const Snap &S, const PlaceArgs &A, cons
     }
     o.n_candidates = ccount;
     o.hash = (uint32_t)(hsum ^ (hsum >> 32)) ^ ((uint32_t)remaining * 0x9E3779B1u);
-    A.outs[d] = o;
+    store_out_streaming(A.outs + d, o);
     return true;
 }
 
@@ -3007,7 +3019,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
         if (WITH_LONG && NOBAR && (code == kLaneLong || code == kLaneCaseB)) {  // the prefix-table phase at once, in this lane
             code = lane_decide<false, true, FORM>(Sl, A, d, o, Bt, C);
             if (code == kLaneDone)
-                A.outs[d] = o;
+                store_out_streaming(A.outs + d, o);
             else
                 wcode = 1;
         } else if (WITH_LONG && (code == kLaneLong || code == kLaneCaseB))
@@ -3018,7 +3030,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
             else
                 fb_list[atomicAdd(&fb_n, 1)] = d;
         } else
-            A.outs[d] = o;
+            store_out_streaming(A.outs + d, o);
     }
     PHASE(8);  // the whole lane phase of this wavefront (incl. the result store)
     if (NOBAR) {  // the general path for this wavefront's own leftovers, a decision at a time
@@ -3055,7 +3067,7 @@ __device__ __forceinline__ void place_block(const Snap &S, const PlaceArgs &A, i
             if (lane_decide<false, true, FORM>(Sl, A, ld, o, Bt, C) != kLaneDone)
                 fb_list[atomicAdd(&fb_n, 1)] = ld;
             else
-                A.outs[ld] = o;
+                store_out_streaming(A.outs + ld, o);
         }
         __syncthreads();
     }
