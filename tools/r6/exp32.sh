@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the variant libraries were built from temporary edits of the kernel sources — which stores / loads are non-temporal — that are not in the tree:
+#  what was kept is store_out_streaming in place_kernel.hpp; profiles/r6/nontemporal_result_stores.txt has the numbers)
 # non-temporal result stores in serve / gate / route kernels against the product: the bench's per-kernel leg, alternating, one visit
 set -u
 export TMPDIR=/tmp
